@@ -1,0 +1,170 @@
+#!/usr/bin/env python3
+"""Generate the golden vectors under tests/golden/ by running the REAL reference.
+
+Run in the build container only (it needs /root/reference/zaf.py, which never
+travels to the GPU box):
+
+    MPLBACKEND=Agg python tests/golden/make_golden.py
+
+What is written (all .npz, float64/complex128, < 1 MB each):
+  tiny.npz      full inputs + full outputs of all ten functions at W=64, hop=32,
+                N in {1, 63, 64, 65, 1000}, plus hop=16 (75 % overlap) cases
+  consts.npz    melfilterbank(44100,2048,128), melfilterbank(44100,2048,40),
+                cqtkernel(44100,24,55,3520) and a small cqtkernel, as CSR triplets
+  config.npz    BASELINE.json config-size cases (10 s / 30 s clips): input checksum,
+                output shape, 4096 random probes (index + value), row sums, column
+                sums and L2 norm per function
+  lengths.npz   frame-count / output-length table of SURVEY.md section 4
+
+The fixtures are DATA (inputs and expected outputs); no reference source text
+is stored.
+"""
+import os
+import sys
+
+os.environ.setdefault("MPLBACKEND", "Agg")
+sys.dont_write_bytecode = True
+sys.path.insert(0, "/root/reference")
+
+import numpy as np  # noqa: E402
+import scipy.signal.windows  # noqa: E402
+import zaf  # noqa: E402  (the reference)
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+def clip(seed, c, n):
+    """Synthetic input of SURVEY 8(d): white Gaussian noise, f32-rounded."""
+    return np.random.default_rng([seed, c]).standard_normal(n).astype(np.float32)
+
+
+def csr_triplet(m):
+    m = m.tocsr()
+    m.sort_indices()
+    return m.data, m.indices.astype(np.int64), m.indptr.astype(np.int64), np.array(m.shape, dtype=np.int64)
+
+
+def probes(arr, rng, k=4096):
+    flat = arr.reshape(-1)
+    k = min(k, flat.size)
+    idx = rng.choice(flat.size, size=k, replace=False).astype(np.int64)
+    out = {"shape": np.array(arr.shape, dtype=np.int64), "idx": idx, "val": flat[idx]}
+    if arr.ndim == 2:
+        out["rowsum"] = arr.sum(axis=1)
+        out["colsum"] = arr.sum(axis=0)
+    out["l2"] = np.array(np.sqrt(np.sum(np.abs(arr) ** 2)))
+    out["maxabs"] = np.array(np.max(np.abs(arr)))
+    return out
+
+
+def make_tiny():
+    out = {}
+    wl = 64
+    ham = scipy.signal.windows.hamming(wl, sym=False)
+    sine = np.sin(np.pi / wl * (np.arange(wl) + 0.5))
+    kbd = scipy.signal.windows.kaiser_bessel_derived(wl, beta=5 * np.pi)
+    fb = zaf.melfilterbank(8000, wl, 8)
+    ck = zaf.cqtkernel(4000, 12, 200, 1600)
+    out["ham"], out["sine"], out["kbd"] = ham, sine, kbd
+    out["fb_dense"] = fb.toarray()
+    out["ck_dense"] = ck.toarray()
+    for n in (1, 63, 64, 65, 1000):
+        x = clip(7, n, n).astype(np.float64)
+        out[f"x_{n}"] = x
+        for hop in (32, 16):
+            s = zaf.stft(x, ham, hop)
+            out[f"stft_{n}_{hop}"] = s
+            out[f"istft_{n}_{hop}"] = zaf.istft(s, ham, hop)
+            out[f"mel_{n}_{hop}"] = zaf.melspectrogram(x, ham, hop, fb)
+            out[f"mfcc_{n}_{hop}"] = zaf.mfcc(x, ham, hop, fb, 5)
+        for name, w in (("sine", sine), ("kbd", kbd)):
+            m = zaf.mdct(x, w)
+            out[f"mdct_{name}_{n}"] = m
+            out[f"imdct_{name}_{n}"] = zaf.imdct(m, w)
+    # non-Hermitian spectrum through istft (reference takes real(ifft) of anything)
+    rng = np.random.default_rng(11)
+    z = rng.standard_normal((wl, 9)) + 1j * rng.standard_normal((wl, 9))
+    out["istft_generic_in"] = z
+    out["istft_generic_out"] = zaf.istft(z, ham, 32)
+    # CQT tiny: fs 4000, 12 bins/octave, 200..1600 Hz -> 36 bins, fft_len 512
+    for n in (400, 4000, 4321):
+        x = clip(9, n, n).astype(np.float64)
+        out[f"xq_{n}"] = x
+        out[f"cqt_{n}"] = zaf.cqtspectrogram(x, 4000, 50, ck)
+        out[f"chroma_{n}"] = zaf.cqtchromagram(x, 4000, 50, 12, ck)
+    np.savez_compressed(os.path.join(HERE, "tiny.npz"), **out)
+
+
+def make_consts():
+    out = {}
+    for tag, m in (
+        ("fb128", zaf.melfilterbank(44100, 2048, 128)),
+        ("fb40", zaf.melfilterbank(44100, 2048, 40)),
+        ("ck", zaf.cqtkernel(44100, 24, 55, 3520)),
+        ("ck_small", zaf.cqtkernel(4000, 12, 200, 1600)),
+    ):
+        d, i, p, s = csr_triplet(m)
+        out[f"{tag}_data"], out[f"{tag}_indices"], out[f"{tag}_indptr"], out[f"{tag}_shape"] = d, i, p, s
+    np.savez_compressed(os.path.join(HERE, "consts.npz"), **out)
+
+
+def make_config():
+    out = {}
+    rng = np.random.default_rng(2024)
+    wl, hop, n = 2048, 1024, 441000
+    ham = scipy.signal.windows.hamming(wl, sym=False)
+    kbd = scipy.signal.windows.kaiser_bessel_derived(wl, beta=5 * np.pi)
+    fb = zaf.melfilterbank(44100, wl, 128)
+    for c in (0, 1):
+        x = clip(0, c, n).astype(np.float64)
+        out[f"S{c}_x_sum"] = np.array(x.sum())
+        out[f"S{c}_x_head"] = x[:16]
+        s = zaf.stft(x, ham, hop)
+        funcs = {
+            "stft": s,
+            "istft": zaf.istft(s, ham, hop),
+            "mel": zaf.melspectrogram(x, ham, hop, fb),
+            "mfcc": zaf.mfcc(x, ham, hop, fb, 20),
+        }
+        m = zaf.mdct(x, kbd)
+        funcs["mdct"] = m
+        funcs["imdct"] = zaf.imdct(m, kbd)
+        for name, arr in funcs.items():
+            for k, v in probes(arr, rng).items():
+                out[f"S{c}_{name}_{k}"] = v
+    # CQT config Q: 30 s clip, 24 bins/octave, 55..3520 Hz, 25 frames/s
+    ck = zaf.cqtkernel(44100, 24, 55, 3520)
+    nq = 1323000
+    x = clip(0, 0, nq).astype(np.float64)
+    out["Q0_x_sum"] = np.array(x.sum())
+    out["Q0_x_head"] = x[:16]
+    q = zaf.cqtspectrogram(x, 44100, 25, ck)
+    for k, v in probes(q, rng).items():
+        out[f"Q0_cqt_{k}"] = v
+    ch = zaf.cqtchromagram(x, 44100, 25, 24, ck)
+    for k, v in probes(ch, rng).items():
+        out[f"Q0_chroma_{k}"] = v
+    np.savez_compressed(os.path.join(HERE, "config.npz"), **out)
+
+
+def make_lengths():
+    wl, hop = 2048, 1024
+    ham = scipy.signal.windows.hamming(wl, sym=False)
+    kbd = scipy.signal.windows.kaiser_bessel_derived(wl, beta=5 * np.pi)
+    ns = np.array([1, 1023, 1024, 1025, 2047, 2048, 2049, 5000, 441000], dtype=np.int64)
+    rows = []
+    for n in ns:
+        x = clip(3, int(n), int(n)).astype(np.float64)
+        s = zaf.stft(x, ham, hop)
+        m = zaf.mdct(x, kbd)
+        rows.append([n, s.shape[1], m.shape[1], len(zaf.istft(s, ham, hop)), len(zaf.imdct(m, kbd))])
+    np.savez_compressed(os.path.join(HERE, "lengths.npz"), table=np.array(rows, dtype=np.int64))
+
+
+if __name__ == "__main__":
+    make_tiny()
+    make_consts()
+    make_config()
+    make_lengths()
+    for f in ("tiny.npz", "consts.npz", "config.npz", "lengths.npz"):
+        print(f, os.path.getsize(os.path.join(HERE, f)))

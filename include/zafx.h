@@ -1,0 +1,131 @@
+/* zafx.h -- C-ABI of libzafx.so: MI355X (gfx950) kernels for the windowed-transform
+ * hot path of zafarrafii/Zaf-Python (zaf.py).
+ *
+ * The reference has no FFI: its boundary is the Python signatures of zaf.py.  This
+ * header is the boundary the reference-side binding (a ctypes stub)
+ * binds instead of NumPy/SciPy for each call site below.  Plain C types only; no
+ * exceptions cross; every function returns 0 on success or a non-zero code whose
+ * text is available from zafx_last_error() (thread-local).
+ *
+ *   entry point / plan kind        replaces (zaf.py file:line)
+ *   -----------------------------  -------------------------------------------------
+ *   ZAFX_STFT                      stft            zaf.py:45-141  (np.pad :112, frame
+ *                                                  loop :132-136, np.fft.fft :139)
+ *   ZAFX_ISTFT                     istft           zaf.py:144-243 (np.fft.ifft :223,
+ *                                                  overlap-add :226-233, trim :236, gain :241)
+ *   ZAFX_MEL                       melspectrogram  zaf.py:324-375 (stft :369, abs :370,
+ *                                                  np.matmul :373)
+ *   ZAFX_MFCC                      mfcc            zaf.py:378-454 (power :437, matmul+log
+ *                                                  :443-446, scipy.fftpack.dct :443-449)
+ *   ZAFX_CQT                       cqtspectrogram  zaf.py:562-635 (np.pad :612, np.fft.fft
+ *                                                  + CSR mat-vec + abs :630-632)
+ *   ZAFX_CHROMA                    cqtchromagram   zaf.py:638-700 (strided row sums :693-698)
+ *   ZAFX_MDCT                      mdct            zaf.py:984-1075 (per-frame FFT :1061-1073)
+ *   ZAFX_IMDCT                     imdct           zaf.py:1078-1184 (FFT :1159, TDAC
+ *                                                  overlap-add :1172-1179, trim :1182)
+ *   zafx_plan_set_constant         operands built by melfilterbank zaf.py:246-321 and
+ *                                  cqtkernel zaf.py:457-559 (scipy.sparse CSR, consumed
+ *                                  at zaf.py:373, :445, :631)
+ *
+ * Ownership: host buffers belong to the caller; device buffers belong to whoever
+ * called zafx_alloc; a plan owns its HIP stream, events, twiddle tables and constants.
+ * Threading: a plan is bound to one device and one stream; calls on distinct plans
+ * are thread-safe; calls on one plan must be serialised by the caller.
+ * All device arrays are float32 / complex64 (interleaved re,im), C-contiguous.
+ */
+#ifndef ZAFX_H
+#define ZAFX_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define ZAFX_VERSION 100
+
+typedef struct zafx_plan zafx_plan;
+typedef struct zafx_comm zafx_comm;
+
+enum zafx_kind {
+    ZAFX_STFT = 1,   /* in (B, N) f32            -> out (B, W, T) c64 [FT] or (B, T, W) [TF]       */
+    ZAFX_ISTFT = 2,  /* in (B, W, T)/(B, T, W)   -> out (B, T*H - (W-H)) f32                       */
+    ZAFX_MDCT = 3,   /* in (B, N) f32            -> out (B, W/2, T) f32 [FT] or (B, T, W/2) [TF]   */
+    ZAFX_IMDCT = 4,  /* in (B, W/2, T)/(B,T,W/2) -> out (B, (W/2)*(T-1) - 1) f32                   */
+    ZAFX_MEL = 5,    /* in (B, N) f32            -> out (B, n_filters, T) or (B, T, n_filters)     */
+    ZAFX_MFCC = 6,   /* in (B, N) f32            -> out (B, n_coefs, T)   or (B, T, n_coefs)       */
+    ZAFX_CQT = 7,    /* in (B, N) f32            -> out (B, n_bins, T)    or (B, T, n_bins)        */
+    ZAFX_CHROMA = 8  /* in (B, N) f32            -> out (B, octave_resolution, T) or transposed    */
+};
+
+enum zafx_layout {
+    ZAFX_LAYOUT_FT = 0, /* reference memory order: frequency-major, time minor (zaf.py:128) */
+    ZAFX_LAYOUT_TF = 1  /* frame-major: each frame's bins contiguous                        */
+};
+
+enum zafx_constant {
+    ZAFX_CONST_WINDOW = 1,      /* float32[W]                                   (window_function)  */
+    ZAFX_CONST_MEL_FB = 2,      /* float32[n_filters * W/2], dense row-major    (FB.toarray())     */
+    ZAFX_CONST_DCT = 3,         /* float32[n_coefs * n_filters], row-major      (DCT-II rows 1..)  */
+    ZAFX_CONST_CQT_INDPTR = 4,  /* int32[n_bins + 1]                            (CSR of cqt_kernel) */
+    ZAFX_CONST_CQT_INDICES = 5, /* int32[nnz], 0 <= col < fft_length                                */
+    ZAFX_CONST_CQT_VALUES = 6   /* complex64[nnz]                                                   */
+};
+
+typedef struct zafx_params {
+    int32_t struct_size;       /* = sizeof(zafx_params)                                         */
+    int32_t window_length;     /* W, power of two, 64..8192 (STFT family, MDCT family)          */
+    int32_t step_length;       /* hop H (STFT/ISTFT/MEL/MFCC; ceil(W/H) <= 8); CQT: frame step  */
+    int32_t layout;            /* enum zafx_layout of the 2-D (frequency x time) side           */
+    int32_t n_filters;         /* MEL / MFCC                                                    */
+    int32_t n_coefs;           /* MFCC                                                          */
+    int32_t fft_length;        /* CQT / CHROMA: power of two, 512..32768                        */
+    int32_t n_bins;            /* CQT / CHROMA                                                  */
+    int32_t octave_resolution; /* CHROMA                                                        */
+    int32_t reserved[7];
+} zafx_params;
+
+/* ---- library / device ------------------------------------------------------------ */
+int zafx_version(void);
+const char* zafx_last_error(void);
+int zafx_device_count(int* count);
+int zafx_device_name(int device, char* buf, size_t buflen);
+
+/* ---- device memory (synchronous helpers; caller owns the allocations) -------------- */
+int zafx_alloc(int device, void** dptr, size_t bytes);
+int zafx_free(int device, void* dptr);
+int zafx_memset(int device, void* dptr, int value, size_t bytes);
+int zafx_h2d(int device, void* dst, const void* src, size_t bytes);
+int zafx_d2h(int device, void* dst, const void* src, size_t bytes);
+int zafx_d2d(int device, void* dst, const void* src, size_t bytes);
+
+/* ---- plans -------------------------------------------------------------------------- */
+int zafx_plan_create(zafx_plan** plan, int device, int kind, const zafx_params* params);
+int zafx_plan_destroy(zafx_plan* plan);
+/* Upload one constant (copied; the host buffer may be released on return). */
+int zafx_plan_set_constant(zafx_plan* plan, int which, const void* host, size_t bytes);
+/* Output geometry for `n_in` (samples per clip for forward kinds, frames T for inverse
+ * kinds): dims[0] = rows F (or samples L), dims[1] = frames T (or 1). */
+int zafx_plan_out_dims(const zafx_plan* plan, int64_t n_in, int64_t dims[2]);
+/* Enqueue the transform of n_clips clips on the plan's stream (asynchronous). */
+int zafx_execute(zafx_plan* plan, const void* d_in, void* d_out, int64_t n_clips, int64_t n_in);
+int zafx_sync(zafx_plan* plan);
+/* HIP-event stopwatch on the plan's stream (the stream the kernels run on). */
+int zafx_timer_start(zafx_plan* plan);
+int zafx_timer_stop(zafx_plan* plan, float* elapsed_ms);
+/* Name of the dominant kernel the plan launches (for matching rocprofv3 rows). */
+int zafx_plan_kernel_name(const zafx_plan* plan, char* buf, size_t buflen);
+
+/* ---- multi-GPU: one process per GPU, RCCL over xGMI --------------------------------- */
+/* The only collective on this path: broadcast of the shared constants (window,
+ * filterbank, DCT matrix, CQT kernel) from `root`.  No reduction exists. */
+int zafx_comm_unique_id(void* id128 /* 128 bytes out */);
+int zafx_comm_create(zafx_comm** comm, int device, int rank, int n_ranks, const void* id128);
+int zafx_comm_destroy(zafx_comm* comm);
+int zafx_comm_broadcast_constants(zafx_comm* comm, zafx_plan* plan, int root);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* ZAFX_H */

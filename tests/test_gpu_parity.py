@@ -1,0 +1,276 @@
+"""GPU parity tests (-m gpu): HIP kernels, called through the C-ABI, against the CPU
+oracle and the golden vectors produced by the real reference.
+
+Tolerances (BASELINE.json north_star): normwise max|out-ref|/max|ref| per
+clip <= 1e-5 for stft/istft/mdct/imdct and <= 1e-4 for mel/mfcc/cqt; MDCT round trip
+max|x - imdct(mdct(x))| < 1e-5 absolute on sigma=1 noise; shapes / frame indexing exact.
+The reference value is float64 computed from the float32-rounded input.
+"""
+import numpy as np
+import pytest
+import scipy.sparse
+
+from conftest import relerr, synth_clip
+from oracle import zaf_oracle as orc
+
+pytestmark = pytest.mark.gpu
+
+TOL_FFT = 1e-5
+TOL_FB = 1e-4
+
+
+@pytest.fixture(scope="module")
+def zafx():
+    import zafx as z
+    assert z.device_count() >= 1
+    return z
+
+
+def csr(g, tag):
+    return scipy.sparse.csr_matrix((g[f"{tag}_data"], g[f"{tag}_indices"], g[f"{tag}_indptr"]), shape=tuple(g[f"{tag}_shape"]))
+
+
+# ------------------------------------------------------------------ tiny goldens (W=64)
+@pytest.mark.parametrize("n", [1, 63, 64, 65, 1000])
+@pytest.mark.parametrize("hop", [32, 16])
+def test_tiny_stft_family(zafx, golden, n, hop):
+    g = golden["tiny"]
+    x, ham = g[f"x_{n}"], g["ham"]
+    fb = scipy.sparse.csr_matrix(g["fb_dense"])
+    ref = g[f"stft_{n}_{hop}"]
+    got = zafx.stft(x, ham, hop)
+    assert got.dtype == np.complex128 and got.shape == ref.shape
+    assert relerr(got, ref) <= TOL_FFT
+    got_tf = zafx.stft_batch(x[None].astype(np.float32), ham, hop, layout="TF")[0]
+    assert relerr(got_tf.T, ref) <= TOL_FFT
+    y = zafx.istft(ref, ham, hop)
+    assert y.dtype == np.float64
+    assert relerr(y, g[f"istft_{n}_{hop}"]) <= TOL_FFT
+    y_tf = zafx.istft_batch(np.ascontiguousarray(ref.T)[None], ham, hop, layout="TF")[0]
+    assert relerr(y_tf, g[f"istft_{n}_{hop}"]) <= TOL_FFT
+    assert relerr(zafx.melspectrogram(x, ham, hop, fb), g[f"mel_{n}_{hop}"]) <= TOL_FB
+    assert relerr(zafx.mfcc(x, ham, hop, fb, 5), g[f"mfcc_{n}_{hop}"]) <= TOL_FB
+
+
+@pytest.mark.parametrize("n", [1, 63, 64, 65, 1000])
+@pytest.mark.parametrize("wname", ["sine", "kbd"])
+def test_tiny_mdct_family(zafx, golden, n, wname):
+    g = golden["tiny"]
+    x, w = g[f"x_{n}"], g[wname]
+    ref = g[f"mdct_{wname}_{n}"]
+    got = zafx.mdct(x, w)
+    assert got.shape == ref.shape and relerr(got, ref) <= TOL_FFT
+    got_tf = zafx.mdct_batch(x[None].astype(np.float32), w, layout="TF")[0]
+    assert relerr(got_tf.T, ref) <= TOL_FFT
+    yref = g[f"imdct_{wname}_{n}"]
+    y = zafx.imdct(ref, w)
+    assert y.shape == yref.shape and relerr(y, yref) <= TOL_FFT
+    y_tf = zafx.imdct_batch(np.ascontiguousarray(ref.T)[None], w, layout="TF")[0]
+    assert relerr(y_tf, yref) <= TOL_FFT
+
+
+def test_tiny_istft_generic(zafx, golden):
+    """istft of a NON-Hermitian spectrum: the reference takes real(ifft(.)) (zaf.py:223)."""
+    g = golden["tiny"]
+    y = zafx.istft(g["istft_generic_in"], g["ham"], 32)
+    assert relerr(y, g["istft_generic_out"]) <= TOL_FFT
+
+
+@pytest.mark.parametrize("n", [400, 4000, 4321])
+def test_tiny_cqt(zafx, golden, n):
+    g = golden["tiny"]
+    ck = scipy.sparse.csr_matrix(g["ck_dense"])
+    x = g[f"xq_{n}"]
+    got = zafx.cqtspectrogram(x, 4000, 50, ck)
+    assert got.shape == g[f"cqt_{n}"].shape and relerr(got, g[f"cqt_{n}"]) <= TOL_FB
+    got = zafx.cqtchromagram(x, 4000, 50, 12, ck)
+    assert got.shape == g[f"chroma_{n}"].shape and relerr(got, g[f"chroma_{n}"]) <= TOL_FB
+    got_tf = zafx.cqtspectrogram_batch(x[None].astype(np.float32), 4000, 50, ck, layout="TF")[0]
+    assert relerr(got_tf.T, g[f"cqt_{n}"]) <= TOL_FB
+
+
+# ------------------------------------------------------------------ other sizes vs the oracle
+@pytest.mark.parametrize("wl,hop,n", [(128, 64, 777), (256, 64, 3000), (512, 256, 5000), (1024, 512, 9000),
+                                       (2048, 512, 20000), (2048, 1024, 1), (2048, 1024, 2049), (4096, 1024, 30000),
+                                       (8192, 4096, 50000), (2048, 700, 12345)])
+def test_stft_sizes(zafx, wl, hop, n):
+    x = np.stack([synth_clip(5, c, n) for c in range(3)])
+    w = zafx.hamming(wl)
+    ref = orc.stft_batch(x.astype(np.float64), w, hop)
+    for layout in ("FT", "TF"):
+        got = zafx.stft_batch(x, w, hop, layout=layout)
+        if layout == "TF":
+            got = got.transpose(0, 2, 1)
+        assert got.shape == ref.shape
+        for c in range(3):
+            assert relerr(got[c], ref[c]) <= TOL_FFT, (layout, c)
+    for c in range(3):
+        yref = orc.istft(ref[c], w, hop)
+        y = zafx.istft_batch(ref[c][None], w, hop)[0]
+        assert y.shape == yref.shape and relerr(y, yref) <= TOL_FFT
+
+
+@pytest.mark.parametrize("wl,n", [(128, 777), (256, 3000), (512, 5000), (1024, 9000), (2048, 1), (2048, 2049),
+                                   (2048, 20000), (4096, 30000), (8192, 50000)])
+def test_mdct_sizes(zafx, wl, n):
+    x = np.stack([synth_clip(6, c, n) for c in range(3)])
+    w = zafx.kaiser_bessel_derived(wl)
+    ref = orc.mdct_batch(x.astype(np.float64), w)
+    for layout in ("FT", "TF"):
+        got = zafx.mdct_batch(x, w, layout=layout)
+        if layout == "TF":
+            got = got.transpose(0, 2, 1)
+        assert got.shape == ref.shape
+        for c in range(3):
+            assert relerr(got[c], ref[c]) <= TOL_FFT, (layout, c)
+    yref = orc.imdct(ref[0], w)
+    y = zafx.imdct_batch(ref[:1], w)[0]
+    assert y.shape == yref.shape and relerr(y, yref) <= TOL_FFT
+    k = min(n, len(y))
+    assert np.max(np.abs(y[:k] - x[0, :k])) < 1e-5
+
+
+# ------------------------------------------------------------------ BASELINE config clips (full clip size)
+@pytest.fixture(scope="module")
+def config_S():
+    x = np.stack([synth_clip(0, c, 441000) for c in range(2)])
+    return x
+
+
+def _check_probes(g, key, arr, tol):
+    assert tuple(g[f"{key}_shape"]) == arr.shape
+    flat = arr.reshape(-1)
+    scale = float(g[f"{key}_maxabs"])
+    assert np.max(np.abs(flat[g[f"{key}_idx"]] - g[f"{key}_val"])) <= tol * scale
+
+
+def test_config_stft_istft(zafx, golden, config_S):
+    g = golden["config"]
+    ham = zafx.hamming(2048)
+    got = zafx.stft_batch(config_S, ham, 1024)
+    assert got.shape == (2, 2048, 432) and got.dtype == np.complex64
+    for c in range(2):
+        _check_probes(g, f"S{c}_stft", got[c].astype(np.complex128), TOL_FFT)
+        ref = orc.stft(config_S[c].astype(np.float64), ham, 1024)
+        assert relerr(got[c], ref) <= TOL_FFT
+        # Hermitian mirror, exactly-real DC / Nyquist
+        assert np.array_equal(got[c][1:1024], np.conj(got[c][:1024:-1]))
+        assert np.all(got[c][0].imag == 0) and np.all(got[c][1024].imag == 0)
+        y = zafx.istft_batch(ref[None], ham, 1024)[0]
+        _check_probes(g, f"S{c}_istft", y.astype(np.float64), TOL_FFT)
+        assert np.max(np.abs(y[:441000] - config_S[c])) < 1e-5   # COLA resynthesis (zaf.py:165-194)
+
+
+def test_config_mel_mfcc(zafx, golden, config_S):
+    g = golden["config"]
+    ham = zafx.hamming(2048)
+    fb = zafx.melfilterbank(44100, 2048, 128)
+    assert relerr(fb.toarray(), csr(golden["consts"], "fb128").toarray()) == 0.0
+    mel = zafx.melspectrogram_batch(config_S, ham, 1024, fb)
+    mf = zafx.mfcc_batch(config_S, ham, 1024, fb, 20)
+    assert mel.shape == (2, 128, 432) and mf.shape == (2, 20, 432)
+    for c in range(2):
+        _check_probes(g, f"S{c}_mel", mel[c].astype(np.float64), TOL_FB)
+        _check_probes(g, f"S{c}_mfcc", mf[c].astype(np.float64), TOL_FB)
+        x64 = config_S[c].astype(np.float64)
+        assert relerr(mel[c], orc.melspectrogram(x64, ham, 1024, fb)) <= TOL_FB
+        assert relerr(mf[c], orc.mfcc(x64, ham, 1024, fb, 20)) <= TOL_FB
+    mel_tf = zafx.melspectrogram_batch(config_S, ham, 1024, fb, layout="TF")
+    assert np.array_equal(mel_tf.transpose(0, 2, 1), mel)
+    fb40 = zafx.melfilterbank(44100, 2048, 40)
+    mf40 = zafx.mfcc_batch(config_S[:1], ham, 1024, fb40, 13)[0]
+    assert relerr(mf40, orc.mfcc(config_S[0].astype(np.float64), ham, 1024, fb40, 13)) <= TOL_FB
+
+
+def test_config_mdct_roundtrip(zafx, golden, config_S):
+    g = golden["config"]
+    kbd = zafx.kaiser_bessel_derived(2048)
+    m = zafx.mdct_batch(config_S, kbd)
+    assert m.shape == (2, 1024, 432)
+    for c in range(2):
+        _check_probes(g, f"S{c}_mdct", m[c].astype(np.float64), TOL_FFT)
+        assert relerr(m[c], orc.mdct(config_S[c].astype(np.float64), kbd)) <= TOL_FFT
+    y = zafx.imdct_batch(m, kbd)
+    assert y.shape == (2, 441343)
+    for c in range(2):
+        _check_probes(g, f"S{c}_imdct", y[c].astype(np.float64), TOL_FFT)
+        assert np.max(np.abs(y[c][:440999] - config_S[c][:440999])) < 1e-5   # BASELINE config 4 residual
+
+
+def test_config_cqt(zafx, golden):
+    g = golden["config"]
+    ck = csr(golden["consts"], "ck")
+    x = synth_clip(0, 0, 1323000)
+    got = zafx.cqtspectrogram_batch(x[None], 44100, 25, ck)[0]
+    assert got.shape == (144, 750)
+    _check_probes(g, "Q0_cqt", got.astype(np.float64), TOL_FB)
+    ch = zafx.cqtchromagram_batch(x[None], 44100, 25, 24, ck)[0]
+    _check_probes(g, "Q0_chroma", ch.astype(np.float64), TOL_FB)
+    # shorter clip, full comparison with the oracle (and our own kernel builder)
+    ck2 = zafx.cqtkernel(44100, 24, 55, 3520)
+    xs = x[:200000]
+    ref = orc.cqtspectrogram(xs.astype(np.float64), 44100, 25, ck2)
+    got = zafx.cqtspectrogram(xs, 44100, 25, ck2)
+    assert got.shape == ref.shape and relerr(got, ref) <= TOL_FB
+
+
+# ------------------------------------------------------------------ full BASELINE batch, device resident
+def test_full_batch_device_resident(zafx):
+    """1024 clips x 10 s (BASELINE configs 2 and 4): size-independent properties on the whole
+    batch (stft->istft and mdct->imdct round trips, replica consistency), oracle on 4 clips."""
+    B, N, W, H = 1024, 441000, 2048, 1024
+    distinct = 8
+    base = np.stack([synth_clip(0, c, N) for c in range(distinct)])
+    d_x = zafx.DeviceBuffer((B, N), np.float32)
+    d_base = zafx.DeviceBuffer.from_host(base)
+    for r in range(B // distinct):
+        d_x.copy_from(d_base, dst_offset=r * distinct * N * 4)
+    ham, kbd = zafx.hamming(W), zafx.kaiser_bessel_derived(W)
+
+    fwd, inv = zafx.stft_plan(ham, H), zafx.istft_plan(ham, H)
+    T = fwd.out_dims(N)[1]
+    d_spec = zafx.DeviceBuffer(fwd.out_shape(B, N), np.complex64)
+    d_y = zafx.DeviceBuffer(inv.out_shape(B, T), np.float32)
+    fwd.execute(d_x, d_spec, B, N)
+    fwd.sync()
+    inv.execute(d_spec, d_y, B, T)
+    inv.sync()
+    first, last = d_spec.download(0, distinct), d_spec.download(B - distinct, distinct)
+    assert np.array_equal(first, last)   # replicas of the same clips give identical bits
+    for c in range(4):
+        assert relerr(first[c], orc.stft(base[c].astype(np.float64), ham, H)) <= TOL_FFT
+    y = d_y.download()
+    assert y.shape == (B, 441344)
+    err = np.max(np.abs(y[:, :N].reshape(B // distinct, distinct, N) - base[None]))
+    assert err < 1e-5
+    d_spec.free(); d_y.free()
+
+    fwd, inv = zafx.mdct_plan(kbd), zafx.mdct_plan(kbd, inverse=True)
+    d_m = zafx.DeviceBuffer(fwd.out_shape(B, N), np.float32)
+    d_r = zafx.DeviceBuffer(inv.out_shape(B, T), np.float32)
+    fwd.execute(d_x, d_m, B, N)
+    fwd.sync()
+    inv.execute(d_m, d_r, B, T)
+    inv.sync()
+    r = d_r.download()
+    assert r.shape == (B, 441343)
+    err = np.max(np.abs(r[:, :N - 1].reshape(B // distinct, distinct, N - 1) - base[None, :, :N - 1]))
+    assert err < 1e-5   # BASELINE config 4: residual < 1e-5
+    for buf in (d_m, d_r, d_x, d_base):
+        buf.free()
+
+
+# ------------------------------------------------------------------ error behaviour
+def test_errors(zafx):
+    ham = zafx.hamming(2048)
+    x = synth_clip(1, 0, 5000)
+    with pytest.raises(ValueError):
+        zafx.stft(np.stack([x, x]), ham, 1024)        # 2-D input (reference breaks at zaf.py:135)
+    with pytest.raises(ValueError):
+        zafx.stft(x, ham, 1024.0)                     # non-int hop
+    with pytest.raises(ValueError):
+        zafx.stft(x, zafx.hamming(1000), 500)         # window not a power of two
+    with pytest.raises(ValueError):
+        zafx.melspectrogram(x, ham, 1024, np.ones((4, 1024)))   # filterbank must expose .toarray()
+    with pytest.raises(zafx.ZafxError):
+        zafx.istft(np.zeros((2048, 4), complex), ham, 64)        # ceil(W/H) too large for the OLA tile

@@ -1,0 +1,618 @@
+// zafx_capi.cpp -- the C-ABI of libzafx.so (include/zafx.h): plans, constants,
+// device memory helpers, HIP-event timing and the RCCL broadcast of constants.
+// Host C++ only; every kernel lives in the *.hip translation units.
+#include <dlfcn.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+#include <mutex>
+#include <string>
+
+#include "zafx_internal.hpp"
+
+namespace zafx {
+
+static thread_local std::string g_err;
+void set_error(const std::string& msg) { g_err = msg; }
+
+static int fail(const std::string& where, hipError_t e) {
+    set_error(where + ": " + hipGetErrorString(e));
+    return (int)e ? (int)e : -1;
+}
+static int fail_msg(const std::string& msg, int code = -1) {
+    set_error(msg);
+    return code;
+}
+
+#define ZAFX_HIP(call)                                    \
+    do {                                                  \
+        hipError_t e__ = (call);                          \
+        if (e__ != hipSuccess) return fail(#call, e__);   \
+    } while (0)
+
+static int ilog2_exact(int v) {
+    if (v <= 0 || (v & (v - 1))) return -1;
+    int l = 0;
+    while ((1 << l) < v) ++l;
+    return l;
+}
+
+template <class T>
+static hipError_t upload(T** dptr, const void* host, size_t bytes) {
+    if (*dptr) {
+        hipError_t e = hipFree(*dptr);
+        *dptr = nullptr;
+        if (e != hipSuccess) return e;
+    }
+    if (bytes == 0) return hipSuccess;
+    hipError_t e = hipMalloc(reinterpret_cast<void**>(dptr), bytes);
+    if (e != hipSuccess) return e;
+    return hipMemcpy(*dptr, host, bytes, hipMemcpyHostToDevice);
+}
+
+// ---------------------------------------------------------------------------------
+// MFMA-fragment packing of a banded (rows x cols) matrix: per 16-row block keep only
+// the column range that holds non-zeros (rounded to multiples of 4 = K of
+// v_mfma_f32_16x16x4_f32) and lay each 16x4 step out in the A-operand lane order
+// (lane l holds A[l & 15][l >> 4]).
+// ---------------------------------------------------------------------------------
+static hipError_t pack_band(PackedBand& pb, const float* dense, int n_rows, int n_cols) {
+    pb.n_rows = n_rows;
+    pb.n_cols = n_cols;
+    pb.n_blocks = (n_rows + 15) / 16;
+    std::vector<int> meta((size_t)pb.n_blocks * 4, 0);
+    std::vector<float> pack;
+    pb.total_steps = 0;
+    pb.max_steps = 0;
+    for (int b = 0; b < pb.n_blocks; ++b) {
+        int lo = n_cols, hi = -1;
+        for (int r = 16 * b; r < std::min(16 * b + 16, n_rows); ++r)
+            for (int c = 0; c < n_cols; ++c)
+                if (dense[(size_t)r * n_cols + c] != 0.f) {
+                    lo = std::min(lo, c);
+                    hi = std::max(hi, c);
+                }
+        int first = 0, steps = 0;
+        if (hi >= lo) {
+            first = lo & ~3;
+            steps = (hi - first) / 4 + 1;
+        }
+        meta[(size_t)b * 4 + 0] = first;
+        meta[(size_t)b * 4 + 1] = steps;
+        meta[(size_t)b * 4 + 2] = pb.total_steps;
+        for (int s = 0; s < steps; ++s)
+            for (int l = 0; l < 64; ++l) {
+                const int r = 16 * b + (l & 15), c = first + 4 * s + (l >> 4);
+                pack.push_back((r < n_rows && c < n_cols) ? dense[(size_t)r * n_cols + c] : 0.f);
+            }
+        pb.total_steps += steps;
+        pb.max_steps = std::max(pb.max_steps, steps);
+    }
+    if (pack.empty()) pack.push_back(0.f);
+    hipError_t e = upload(&pb.d_pack, pack.data(), pack.size() * sizeof(float));
+    if (e != hipSuccess) return e;
+    return upload(&pb.d_meta, meta.data(), meta.size() * sizeof(int));
+}
+
+static void free_band(PackedBand& pb) {
+    if (pb.d_pack) (void)hipFree(pb.d_pack);
+    if (pb.d_meta) (void)hipFree(pb.d_meta);
+    pb = PackedBand{};
+}
+
+static bool is_stft_family(int kind) { return kind == ZAFX_STFT || kind == ZAFX_ISTFT || kind == ZAFX_MEL || kind == ZAFX_MFCC; }
+static bool is_mdct_family(int kind) { return kind == ZAFX_MDCT || kind == ZAFX_IMDCT; }
+static bool is_cqt_family(int kind) { return kind == ZAFX_CQT || kind == ZAFX_CHROMA; }
+
+// (re)build everything that is derived from the host shadows of the constants
+static int finalize_constant(zafx_plan* pl, int which) {
+    switch (which) {
+        case ZAFX_CONST_WINDOW: {
+            ZAFX_HIP(upload(&pl->d_window, pl->h_window.data(), pl->h_window.size() * sizeof(float)));
+            double g = 0;   // zaf.py:241  sum(window_function[0:W:H])
+            if (pl->H > 0)
+                for (int i = 0; i < pl->W; i += pl->H) g += (double)pl->h_window[(size_t)i];
+            pl->cola_gain = (float)g;
+            return 0;
+        }
+        case ZAFX_CONST_MEL_FB:
+            ZAFX_HIP(pack_band(pl->fb, pl->h_fb.data(), pl->prm.n_filters, pl->W / 2));
+            return 0;
+        case ZAFX_CONST_DCT:
+            ZAFX_HIP(pack_band(pl->dct, pl->h_dct.data(), pl->prm.n_coefs, pl->prm.n_filters));
+            return 0;
+        case ZAFX_CONST_CQT_INDPTR:
+            ZAFX_HIP(upload(&pl->d_indptr, pl->h_indptr.data(), pl->h_indptr.size() * sizeof(int32_t)));
+            return 0;
+        case ZAFX_CONST_CQT_INDICES:
+            ZAFX_HIP(upload(&pl->d_indices, pl->h_indices.data(), pl->h_indices.size() * sizeof(int32_t)));
+            pl->nnz = (int)pl->h_indices.size();
+            return 0;
+        case ZAFX_CONST_CQT_VALUES:
+            ZAFX_HIP(upload(&pl->d_values, pl->h_values.data(), pl->h_values.size() * sizeof(cf32)));
+            return 0;
+    }
+    return fail_msg("unknown constant id");
+}
+
+}  // namespace zafx
+
+using namespace zafx;
+
+extern "C" {
+
+int zafx_version(void) { return ZAFX_VERSION; }
+const char* zafx_last_error(void) { return g_err.c_str(); }
+
+int zafx_device_count(int* count) {
+    if (!count) return fail_msg("null argument");
+    ZAFX_HIP(hipGetDeviceCount(count));
+    return 0;
+}
+
+int zafx_device_name(int device, char* buf, size_t buflen) {
+    if (!buf || !buflen) return fail_msg("null argument");
+    hipDeviceProp_t prop;
+    ZAFX_HIP(hipGetDeviceProperties(&prop, device));
+    std::snprintf(buf, buflen, "%s (%s, %d CUs)", prop.name, prop.gcnArchName, prop.multiProcessorCount);
+    return 0;
+}
+
+int zafx_alloc(int device, void** dptr, size_t bytes) {
+    if (!dptr) return fail_msg("null argument");
+    ZAFX_HIP(hipSetDevice(device));
+    ZAFX_HIP(hipMalloc(dptr, bytes ? bytes : 1));
+    return 0;
+}
+int zafx_free(int device, void* dptr) {
+    ZAFX_HIP(hipSetDevice(device));
+    ZAFX_HIP(hipFree(dptr));
+    return 0;
+}
+int zafx_memset(int device, void* dptr, int value, size_t bytes) {
+    ZAFX_HIP(hipSetDevice(device));
+    ZAFX_HIP(hipMemset(dptr, value, bytes));
+    return 0;
+}
+int zafx_h2d(int device, void* dst, const void* src, size_t bytes) {
+    ZAFX_HIP(hipSetDevice(device));
+    ZAFX_HIP(hipMemcpy(dst, src, bytes, hipMemcpyHostToDevice));
+    return 0;
+}
+int zafx_d2h(int device, void* dst, const void* src, size_t bytes) {
+    ZAFX_HIP(hipSetDevice(device));
+    ZAFX_HIP(hipMemcpy(dst, src, bytes, hipMemcpyDeviceToHost));
+    return 0;
+}
+int zafx_d2d(int device, void* dst, const void* src, size_t bytes) {
+    ZAFX_HIP(hipSetDevice(device));
+    ZAFX_HIP(hipMemcpy(dst, src, bytes, hipMemcpyDeviceToDevice));
+    return 0;
+}
+
+int zafx_plan_create(zafx_plan** out, int device, int kind, const zafx_params* params) {
+    if (!out || !params) return fail_msg("null argument");
+    if (params->struct_size != (int32_t)sizeof(zafx_params)) return fail_msg("zafx_params.struct_size mismatch");
+    if (params->layout != ZAFX_LAYOUT_FT && params->layout != ZAFX_LAYOUT_TF) return fail_msg("bad layout");
+    zafx_plan* pl = new zafx_plan();
+    pl->device = device;
+    pl->kind = kind;
+    pl->prm = *params;
+    pl->layout = params->layout;
+    auto bail = [&](const std::string& m) {
+        delete pl;
+        return fail_msg(m);
+    };
+    std::vector<cf32> aux;
+    if (is_stft_family(kind)) {
+        pl->W = params->window_length;
+        pl->H = params->step_length;
+        const int lw = ilog2_exact(pl->W);
+        if (lw < 0 || !stft_supported(lw - 1)) return bail("window_length must be a power of two in [64, 8192]");
+        if (pl->H < 1 || pl->H > pl->W) return bail("step_length must be in [1, window_length]");
+        pl->log2nf = lw - 1;
+        if (kind == ZAFX_MEL || kind == ZAFX_MFCC) {
+            if (params->n_filters < 1 || params->n_filters > 256) return bail("n_filters must be in [1, 256]");
+            if (kind == ZAFX_MFCC && (params->n_coefs < 1 || params->n_coefs > params->n_filters))
+                return bail("n_coefs must be in [1, n_filters]");
+            if (lw - 1 != 10 && lw - 1 != 9 && lw - 1 != 5) return bail("mel/mfcc kernels are built for window_length 64, 1024 and 2048");
+        }
+        const int n = pl->W / 2;
+        aux.resize((size_t)n / 2 + 1);
+        for (int k = 0; k <= n / 2; ++k) aux[(size_t)k] = unit_root(k, pl->W);
+        pl->kernel_name = kind == ZAFX_STFT ? stft_kernel_name() : kind == ZAFX_ISTFT ? istft_kernel_name() : mel_kernel_name();
+    } else if (is_mdct_family(kind)) {
+        pl->W = params->window_length;
+        pl->H = pl->W / 2;   // zaf.py:1029
+        const int lw = ilog2_exact(pl->W);
+        if (lw < 0 || !mdct_supported(lw - 2)) return bail("window_length must be a power of two in [64, 8192]");
+        pl->log2nf = lw - 2;
+        const int nf = pl->W / 4, m = pl->W / 2;
+        aux.resize((size_t)nf);
+        for (int i = 0; i < nf; ++i) aux[(size_t)i] = unit_root(8LL * i + 1, 16LL * m);
+        pl->kernel_name = kind == ZAFX_MDCT ? mdct_kernel_name() : imdct_kernel_name();
+    } else if (is_cqt_family(kind)) {
+        pl->W = params->fft_length;
+        pl->H = params->step_length;
+        const int lw = ilog2_exact(pl->W);
+        if (lw < 0 || !cqt_supported(lw - 1)) return bail("fft_length must be a power of two in [512, 32768]");
+        if (pl->H < 1) return bail("step_length must be >= 1");
+        if (params->n_bins < 1 || params->n_bins > 1024) return bail("n_bins must be in [1, 1024]");
+        if (kind == ZAFX_CHROMA && (params->octave_resolution < 1 || params->octave_resolution > params->n_bins))
+            return bail("octave_resolution must be in [1, n_bins]");
+        pl->log2nf = lw - 1;
+        const int n = pl->W / 2;
+        aux.resize((size_t)n / 2 + 1);
+        for (int k = 0; k <= n / 2; ++k) aux[(size_t)k] = unit_root(k, pl->W);
+        pl->kernel_name = cqt_kernel_name();
+    } else {
+        return bail("unknown plan kind");
+    }
+    pl->log2e = default_log2e(pl->log2nf);
+
+    hipError_t e = hipSetDevice(device);
+    if (e == hipSuccess) e = hipStreamCreateWithFlags(&pl->stream, hipStreamNonBlocking);
+    if (e == hipSuccess) e = hipEventCreate(&pl->ev0);
+    if (e == hipSuccess) e = hipEventCreate(&pl->ev1);
+    if (e == hipSuccess) {
+        auto tw = build_pass_twiddles(pl->log2nf, pl->log2e);
+        if (tw.empty()) tw.push_back(cf32{1.f, 0.f});
+        e = upload(&pl->d_tw_pass, tw.data(), tw.size() * sizeof(cf32));
+    }
+    if (e == hipSuccess) e = upload(&pl->d_tw_aux, aux.data(), aux.size() * sizeof(cf32));
+    if (e != hipSuccess) {
+        zafx_plan_destroy(pl);
+        return fail("zafx_plan_create", e);
+    }
+    *out = pl;
+    return 0;
+}
+
+int zafx_plan_destroy(zafx_plan* pl) {
+    if (!pl) return 0;
+    (void)hipSetDevice(pl->device);
+    if (pl->stream) (void)hipStreamSynchronize(pl->stream);
+    if (pl->d_window) (void)hipFree(pl->d_window);
+    if (pl->d_tw_pass) (void)hipFree(pl->d_tw_pass);
+    if (pl->d_tw_aux) (void)hipFree(pl->d_tw_aux);
+    if (pl->d_indptr) (void)hipFree(pl->d_indptr);
+    if (pl->d_indices) (void)hipFree(pl->d_indices);
+    if (pl->d_values) (void)hipFree(pl->d_values);
+    free_band(pl->fb);
+    free_band(pl->dct);
+    if (pl->ev0) (void)hipEventDestroy(pl->ev0);
+    if (pl->ev1) (void)hipEventDestroy(pl->ev1);
+    if (pl->stream) (void)hipStreamDestroy(pl->stream);
+    delete pl;
+    return 0;
+}
+
+static int expected_constant_bytes(const zafx_plan* pl, int which, size_t bytes, size_t* elem) {
+    switch (which) {
+        case ZAFX_CONST_WINDOW:
+            *elem = sizeof(float);
+            if (is_cqt_family(pl->kind)) return fail_msg("CQT plans take no window (zaf.py:630)");
+            return bytes == (size_t)pl->W * sizeof(float) ? 0 : fail_msg("window must hold window_length float32");
+        case ZAFX_CONST_MEL_FB:
+            *elem = sizeof(float);
+            if (pl->kind != ZAFX_MEL && pl->kind != ZAFX_MFCC) return fail_msg("plan takes no mel filterbank");
+            return bytes == (size_t)pl->prm.n_filters * (pl->W / 2) * sizeof(float) ? 0
+                       : fail_msg("mel filterbank must be dense float32 [n_filters][window_length/2]");
+        case ZAFX_CONST_DCT:
+            *elem = sizeof(float);
+            if (pl->kind != ZAFX_MFCC) return fail_msg("plan takes no DCT matrix");
+            return bytes == (size_t)pl->prm.n_coefs * pl->prm.n_filters * sizeof(float) ? 0
+                       : fail_msg("DCT matrix must be float32 [n_coefs][n_filters]");
+        case ZAFX_CONST_CQT_INDPTR:
+            *elem = sizeof(int32_t);
+            if (!is_cqt_family(pl->kind)) return fail_msg("plan takes no CQT kernel");
+            return bytes == (size_t)(pl->prm.n_bins + 1) * sizeof(int32_t) ? 0 : fail_msg("indptr must hold n_bins + 1 int32");
+        case ZAFX_CONST_CQT_INDICES:
+            *elem = sizeof(int32_t);
+            if (!is_cqt_family(pl->kind)) return fail_msg("plan takes no CQT kernel");
+            return bytes % sizeof(int32_t) == 0 ? 0 : fail_msg("indices must be int32");
+        case ZAFX_CONST_CQT_VALUES:
+            *elem = sizeof(cf32);
+            if (!is_cqt_family(pl->kind)) return fail_msg("plan takes no CQT kernel");
+            return bytes % sizeof(cf32) == 0 ? 0 : fail_msg("values must be complex64");
+    }
+    return fail_msg("unknown constant id");
+}
+
+static int store_shadow(zafx_plan* pl, int which, const void* host, size_t bytes) {
+    switch (which) {
+        case ZAFX_CONST_WINDOW:
+            pl->h_window.assign((const float*)host, (const float*)host + bytes / sizeof(float));
+            break;
+        case ZAFX_CONST_MEL_FB:
+            pl->h_fb.assign((const float*)host, (const float*)host + bytes / sizeof(float));
+            break;
+        case ZAFX_CONST_DCT:
+            pl->h_dct.assign((const float*)host, (const float*)host + bytes / sizeof(float));
+            break;
+        case ZAFX_CONST_CQT_INDPTR:
+            pl->h_indptr.assign((const int32_t*)host, (const int32_t*)host + bytes / sizeof(int32_t));
+            break;
+        case ZAFX_CONST_CQT_INDICES: {
+            pl->h_indices.assign((const int32_t*)host, (const int32_t*)host + bytes / sizeof(int32_t));
+            for (int32_t c : pl->h_indices)
+                if (c < 0 || c >= pl->W) return fail_msg("CQT kernel column index out of range");
+            break;
+        }
+        case ZAFX_CONST_CQT_VALUES:
+            pl->h_values.assign((const cf32*)host, (const cf32*)host + bytes / sizeof(cf32));
+            break;
+    }
+    return 0;
+}
+
+int zafx_plan_set_constant(zafx_plan* pl, int which, const void* host, size_t bytes) {
+    if (!pl || (!host && bytes)) return fail_msg("null argument");
+    size_t elem = 1;
+    if (int rc = expected_constant_bytes(pl, which, bytes, &elem)) return rc;
+    ZAFX_HIP(hipSetDevice(pl->device));
+    ZAFX_HIP(hipStreamSynchronize(pl->stream));
+    if (int rc = store_shadow(pl, which, host, bytes)) return rc;
+    return finalize_constant(pl, which);
+}
+
+static int stft_frames(int64_t n, int w, int h) {   // zaf.py:99-109
+    const int64_t pad = w / 2;
+    const int64_t num = n + 2 * pad - w;
+    const int64_t q = num >= 0 ? (num + h - 1) / h : -((-num) / h);
+    return (int)(q + 1);
+}
+
+int zafx_plan_out_dims(const zafx_plan* pl, int64_t n_in, int64_t dims[2]) {
+    if (!pl || !dims) return fail_msg("null argument");
+    if (n_in < 0) return fail_msg("negative size");
+    const int64_t w = pl->W, h = pl->H;
+    switch (pl->kind) {
+        case ZAFX_STFT: dims[0] = w; dims[1] = stft_frames(n_in, pl->W, pl->H); return 0;
+        case ZAFX_MEL: dims[0] = pl->prm.n_filters; dims[1] = stft_frames(n_in, pl->W, pl->H); return 0;
+        case ZAFX_MFCC: dims[0] = pl->prm.n_coefs; dims[1] = stft_frames(n_in, pl->W, pl->H); return 0;
+        case ZAFX_ISTFT: dims[0] = std::max<int64_t>(0, n_in * h - (w - h)); dims[1] = 1; return 0;   // zaf.py:217, :236-238
+        case ZAFX_MDCT: dims[0] = w / 2; dims[1] = (n_in + h - 1) / h + 1; return 0;                  // zaf.py:1033
+        case ZAFX_IMDCT: dims[0] = std::max<int64_t>(0, h * (n_in - 1) - 1); dims[1] = 1; return 0;    // zaf.py:1132, :1182
+        case ZAFX_CQT: dims[0] = pl->prm.n_bins; dims[1] = n_in / h; return 0;                         // zaf.py:606
+        case ZAFX_CHROMA: dims[0] = pl->prm.octave_resolution; dims[1] = n_in / h; return 0;
+    }
+    return fail_msg("unknown plan kind");
+}
+
+int zafx_execute(zafx_plan* pl, const void* d_in, void* d_out, int64_t n_clips, int64_t n_in) {
+    if (!pl) return fail_msg("null plan");
+    if (n_clips < 0 || n_in < 0) return fail_msg("negative size");
+    if (n_clips == 0) return 0;
+    if (!d_in || !d_out) return fail_msg("null device pointer");
+    int64_t dims[2];
+    if (int rc = zafx_plan_out_dims(pl, n_in, dims)) return rc;
+    if (!is_cqt_family(pl->kind) && !pl->d_window) return fail_msg("window constant not set");
+    if ((pl->kind == ZAFX_MEL || pl->kind == ZAFX_MFCC) && !pl->fb.d_pack) return fail_msg("mel filterbank constant not set");
+    if (pl->kind == ZAFX_MFCC && !pl->dct.d_pack) return fail_msg("DCT constant not set");
+    if (is_cqt_family(pl->kind)) {
+        if (!pl->d_indptr || !pl->d_indices || !pl->d_values) return fail_msg("CQT kernel constants not set");
+        if ((int)pl->h_values.size() != pl->nnz || pl->h_indptr.back() != pl->nnz) return fail_msg("CQT kernel CSR arrays are inconsistent");
+    }
+    if (n_clips * std::max<int64_t>(dims[1], 1) > 0x7fffffffLL) return fail_msg("batch too large for one launch (clips x frames >= 2^31)");
+    ZAFX_HIP(hipSetDevice(pl->device));
+    hipError_t e = hipSuccess;
+    switch (pl->kind) {
+        case ZAFX_STFT:
+            e = launch_stft(*pl, (const float*)d_in, (float2*)d_out, n_clips, n_in, (int)dims[1]);
+            break;
+        case ZAFX_ISTFT:
+            if (pl->cola_gain == 0.f) return fail_msg("istft: sum(window[0:W:H]) is zero (zaf.py:241 would divide by zero)");
+            e = launch_istft(*pl, (const float2*)d_in, (float*)d_out, n_clips, (int)n_in, dims[0]);
+            break;
+        case ZAFX_MDCT:
+            e = launch_mdct(*pl, (const float*)d_in, (float*)d_out, n_clips, n_in, (int)dims[1]);
+            break;
+        case ZAFX_IMDCT:
+            e = launch_imdct(*pl, (const float*)d_in, (float*)d_out, n_clips, (int)n_in, dims[0]);
+            break;
+        case ZAFX_MEL:
+        case ZAFX_MFCC:
+            e = launch_mel(*pl, (const float*)d_in, (float*)d_out, n_clips, n_in, (int)dims[1]);
+            break;
+        case ZAFX_CQT:
+        case ZAFX_CHROMA:
+            e = launch_cqt(*pl, (const float*)d_in, (float*)d_out, n_clips, n_in, (int)dims[1]);
+            break;
+        default:
+            return fail_msg("unknown plan kind");
+    }
+    if (e != hipSuccess) {
+        if (g_err.empty() || e != hipErrorInvalidValue) return fail("zafx_execute", e);
+        return (int)e;
+    }
+    return 0;
+}
+
+int zafx_sync(zafx_plan* pl) {
+    if (!pl) return fail_msg("null plan");
+    ZAFX_HIP(hipSetDevice(pl->device));
+    ZAFX_HIP(hipStreamSynchronize(pl->stream));
+    return 0;
+}
+
+int zafx_timer_start(zafx_plan* pl) {
+    if (!pl) return fail_msg("null plan");
+    ZAFX_HIP(hipSetDevice(pl->device));
+    ZAFX_HIP(hipEventRecord(pl->ev0, pl->stream));
+    return 0;
+}
+
+int zafx_timer_stop(zafx_plan* pl, float* ms) {
+    if (!pl || !ms) return fail_msg("null argument");
+    ZAFX_HIP(hipSetDevice(pl->device));
+    ZAFX_HIP(hipEventRecord(pl->ev1, pl->stream));
+    ZAFX_HIP(hipEventSynchronize(pl->ev1));
+    ZAFX_HIP(hipEventElapsedTime(ms, pl->ev0, pl->ev1));
+    return 0;
+}
+
+int zafx_plan_kernel_name(const zafx_plan* pl, char* buf, size_t buflen) {
+    if (!pl || !buf || !buflen) return fail_msg("null argument");
+    std::snprintf(buf, buflen, "%s", pl->kernel_name.c_str());
+    return 0;
+}
+
+// ---------------------------------------------------------------------------------
+// RCCL (resolved lazily with dlopen so that single-GPU use needs no librccl)
+// ---------------------------------------------------------------------------------
+struct uid128 { char b[128]; };
+struct rccl_api {
+    void* lib = nullptr;
+    int (*GetUniqueId)(void*) = nullptr;
+    int (*CommInitRank)(void**, int, /* ncclUniqueId by value: 128 bytes */ uid128, int) = nullptr;
+    int (*CommDestroy)(void*) = nullptr;
+    int (*Broadcast)(const void*, void*, size_t, int, int, void*, hipStream_t) = nullptr;
+    const char* (*GetErrorString)(int) = nullptr;
+};
+
+static rccl_api g_rccl;
+static std::mutex g_rccl_mu;
+
+static int rccl_load() {
+    std::lock_guard<std::mutex> lk(g_rccl_mu);
+    if (g_rccl.lib) return 0;
+    const char* names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
+    void* h = nullptr;
+    for (const char* n : names)
+        if ((h = dlopen(n, RTLD_NOW | RTLD_LOCAL))) break;
+    if (!h) return fail_msg(std::string("cannot load librccl: ") + dlerror());
+    g_rccl.GetUniqueId = (int (*)(void*))dlsym(h, "ncclGetUniqueId");
+    g_rccl.CommInitRank = (int (*)(void**, int, uid128, int))dlsym(h, "ncclCommInitRank");
+    g_rccl.CommDestroy = (int (*)(void*))dlsym(h, "ncclCommDestroy");
+    g_rccl.Broadcast = (int (*)(const void*, void*, size_t, int, int, void*, hipStream_t))dlsym(h, "ncclBroadcast");
+    g_rccl.GetErrorString = (const char* (*)(int))dlsym(h, "ncclGetErrorString");
+    if (!g_rccl.GetUniqueId || !g_rccl.CommInitRank || !g_rccl.CommDestroy || !g_rccl.Broadcast)
+        return fail_msg("librccl lacks a required symbol");
+    g_rccl.lib = h;
+    return 0;
+}
+
+static int rccl_fail(const char* where, int rc) {
+    std::string m = std::string(where) + ": rccl error " + std::to_string(rc);
+    if (g_rccl.GetErrorString) m += std::string(" (") + g_rccl.GetErrorString(rc) + ")";
+    return fail_msg(m, 1000 + rc);
+}
+
+}  // extern "C"
+
+struct zafx_comm {
+    int device = 0, rank = 0, n_ranks = 1;
+    void* comm = nullptr;
+};
+
+extern "C" {
+
+int zafx_comm_unique_id(void* id128) {
+    if (!id128) return fail_msg("null argument");
+    if (int rc = rccl_load()) return rc;
+    int rc = g_rccl.GetUniqueId(id128);
+    return rc ? rccl_fail("ncclGetUniqueId", rc) : 0;
+}
+
+int zafx_comm_create(zafx_comm** out, int device, int rank, int n_ranks, const void* id128) {
+    if (!out || !id128) return fail_msg("null argument");
+    if (int rc = rccl_load()) return rc;
+    ZAFX_HIP(hipSetDevice(device));
+    zafx_comm* c = new zafx_comm();
+    c->device = device;
+    c->rank = rank;
+    c->n_ranks = n_ranks;
+    uid128 id;
+    std::memcpy(&id, id128, sizeof(id));
+    int rc = g_rccl.CommInitRank(&c->comm, n_ranks, id, rank);
+    if (rc) {
+        delete c;
+        return rccl_fail("ncclCommInitRank", rc);
+    }
+    *out = c;
+    return 0;
+}
+
+int zafx_comm_destroy(zafx_comm* c) {
+    if (!c) return 0;
+    if (c->comm && g_rccl.CommDestroy) {
+        (void)hipSetDevice(c->device);
+        (void)g_rccl.CommDestroy(c->comm);
+    }
+    delete c;
+    return 0;
+}
+
+// Broadcast every constant the plan kind uses from `root`: an 8-byte length header,
+// then the raw bytes (ncclInt8), through a device staging buffer on the plan's stream.
+int zafx_comm_broadcast_constants(zafx_comm* c, zafx_plan* pl, int root) {
+    if (!c || !pl) return fail_msg("null argument");
+    if (c->device != pl->device) return fail_msg("communicator and plan are bound to different devices");
+    ZAFX_HIP(hipSetDevice(pl->device));
+    std::vector<int> ids;
+    if (!is_cqt_family(pl->kind)) ids.push_back(ZAFX_CONST_WINDOW);
+    if (pl->kind == ZAFX_MEL || pl->kind == ZAFX_MFCC) ids.push_back(ZAFX_CONST_MEL_FB);
+    if (pl->kind == ZAFX_MFCC) ids.push_back(ZAFX_CONST_DCT);
+    if (is_cqt_family(pl->kind)) {
+        ids.push_back(ZAFX_CONST_CQT_INDPTR);
+        ids.push_back(ZAFX_CONST_CQT_INDICES);
+        ids.push_back(ZAFX_CONST_CQT_VALUES);
+    }
+    unsigned long long* d_len = nullptr;
+    ZAFX_HIP(hipMalloc((void**)&d_len, sizeof(unsigned long long)));
+    int ret = 0;
+    for (int which : ids) {
+        const void* hsrc = nullptr;
+        unsigned long long len = 0;
+        auto span = [&](auto& vec) {
+            hsrc = vec.data();
+            len = (unsigned long long)vec.size() * sizeof(vec[0]);
+        };
+        if (c->rank == root) {
+            switch (which) {
+                case ZAFX_CONST_WINDOW: span(pl->h_window); break;
+                case ZAFX_CONST_MEL_FB: span(pl->h_fb); break;
+                case ZAFX_CONST_DCT: span(pl->h_dct); break;
+                case ZAFX_CONST_CQT_INDPTR: span(pl->h_indptr); break;
+                case ZAFX_CONST_CQT_INDICES: span(pl->h_indices); break;
+                case ZAFX_CONST_CQT_VALUES: span(pl->h_values); break;
+            }
+            if (len == 0) { ret = fail_msg("root rank has not set every constant before the broadcast"); break; }
+        }
+        hipError_t e = hipMemcpy(d_len, &len, sizeof(len), hipMemcpyHostToDevice);
+        if (e != hipSuccess) { ret = fail("hipMemcpy", e); break; }
+        int rc = g_rccl.Broadcast(d_len, d_len, sizeof(len), /*ncclInt8*/ 0, root, c->comm, pl->stream);
+        if (rc) { ret = rccl_fail("ncclBroadcast(len)", rc); break; }
+        e = hipStreamSynchronize(pl->stream);
+        if (e == hipSuccess) e = hipMemcpy(&len, d_len, sizeof(len), hipMemcpyDeviceToHost);
+        if (e != hipSuccess) { ret = fail("broadcast header", e); break; }
+        void* d_buf = nullptr;
+        e = hipMalloc(&d_buf, (size_t)len);
+        if (e != hipSuccess) { ret = fail("hipMalloc", e); break; }
+        if (c->rank == root) e = hipMemcpy(d_buf, hsrc, (size_t)len, hipMemcpyHostToDevice);
+        if (e == hipSuccess) {
+            rc = g_rccl.Broadcast(d_buf, d_buf, (size_t)len, 0, root, c->comm, pl->stream);
+            if (rc) ret = rccl_fail("ncclBroadcast(data)", rc);
+            else e = hipStreamSynchronize(pl->stream);
+        }
+        if (!ret && e == hipSuccess && c->rank != root) {
+            std::vector<uint8_t> host((size_t)len);
+            e = hipMemcpy(host.data(), d_buf, (size_t)len, hipMemcpyDeviceToHost);
+            if (e == hipSuccess) {
+                size_t elem = 1;
+                ret = expected_constant_bytes(pl, which, (size_t)len, &elem);
+                if (!ret) ret = store_shadow(pl, which, host.data(), (size_t)len);
+                if (!ret) ret = finalize_constant(pl, which);
+            }
+        }
+        (void)hipFree(d_buf);
+        if (!ret && e != hipSuccess) ret = fail("broadcast payload", e);
+        if (ret) break;
+    }
+    (void)hipFree(d_len);
+    return ret;
+}
+
+}  // extern "C"

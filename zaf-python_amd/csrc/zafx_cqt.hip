@@ -1,0 +1,164 @@
+// zafx_cqt.hip -- constant-Q spectrogram / chromagram kernel for gfx950 (MI355X).
+//
+// Replaces the per-frame loop of zaf.py:627-633:
+//     cqt[:, j] = abs(cqt_kernel * np.fft.fft(xpad[j*step : j*step + fft_len]))
+// with cqt_kernel a sparse (n_bins x fft_len) complex CSR matrix (zaf.py:554-557).
+//
+// One workgroup owns FW = 16 consecutive frames of one clip and transforms them one
+// after the other: the whole frame (fft_len real = N = fft_len/2 complex points, up
+// to 128 KiB) lives in LDS, owned by N/16 threads (1024 for fft_len 32768).  Frames of
+// a tile overlap by (fft_len - step)/fft_len (94.6 % at config Q), so the re-reads of
+// the input hit L2; HBM sees each sample about once per tile.  After the real-split the
+// CSR rows are contracted against the one-sided spectrum in LDS (one wave per row,
+// lanes across the row's contiguous non-zeros, shuffle reduction) and the magnitudes of
+// the 16 frames are staged in LDS so that the (n_bins, T) store writes 64-B runs along t.
+// The chromagram (zaf.py:693-698) is a strided row sum over that LDS tile.
+#include "zafx_fft.hpp"
+#include "zafx_internal.hpp"
+
+namespace zafx {
+
+constexpr int kCqtFramesPerBlock = 16;
+
+template <int LOG2N, int LOG2E>
+__global__ __launch_bounds__(fft_threads(LOG2N, LOG2E)) void k_cqt(
+    const float* __restrict__ x, const float2* __restrict__ twp, const float2* __restrict__ tws,
+    const int* __restrict__ indptr, const int* __restrict__ indices, const float2* __restrict__ values, float* __restrict__ out,
+    long long n_samples, int step, int left_pad, int T, int tiles, int n_bins, int chroma_res, int layout) {
+    using C = FftCfg<LOG2N, LOG2E>;
+    constexpr int N = C::N, P = C::P, E = C::E, W = 2 * N, FW = kCqtFramesPerBlock;
+    static_assert(P >= 64, "CQT frames are owned by whole wavefronts");
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    float2* buf = reinterpret_cast<float2*>(smem_raw);            // PITCH slots; slot PITCH-1 holds X[N]
+    float* tile = reinterpret_cast<float*>(buf + C::PITCH);       // [n_bins][FW]
+    const int p = threadIdx.x;
+    const int lane = p & 63, wave = p >> 6, nwaves = P >> 6;
+    const int clip = blockIdx.x / tiles, tl = blockIdx.x % tiles;
+    const int t0 = tl * FW;
+    const float* xc = x + (long long)clip * n_samples;
+
+#pragma unroll 1
+    for (int jj = 0; jj < FW; ++jj) {
+        const int t = t0 + jj;
+        if (t >= T) break;   // uniform across the block
+        // ---- framing, no window (it lives in the kernel): zaf.py:612-620, :631
+        float2 v[E];
+        const long long s0 = (long long)t * step - left_pad;
+#pragma unroll
+        for (int i = 0; i < E; ++i) {
+            const long long s = s0 + 2 * (p + i * P);
+            const float a = (s >= 0 && s < n_samples) ? xc[s] : 0.f;
+            const float b = (s + 1 >= 0 && s + 1 < n_samples) ? xc[s + 1] : 0.f;
+            v[i] = make_float2(a, b);
+        }
+        fft_frame<LOG2N, LOG2E>(v, buf, p, twp);
+        // ---- real split in place: slots 0..N-1 <- X[0..N-1], slot PITCH-1 <- X[N]
+#pragma unroll
+        for (int i = 0; i < E / 2; ++i) {
+            const int k = p + i * P;
+            if (k == 0) {
+                const float2 z0 = buf[0], zc = buf[phys(N / 2)];
+                buf[0] = make_float2(z0.x + z0.y, 0.f);
+                buf[C::PITCH - 1] = make_float2(z0.x - z0.y, 0.f);
+                buf[phys(N / 2)] = cconj(zc);
+            } else {
+                const float2 zk = buf[phys(k)], zn = buf[phys(N - k)];
+                const float2 e = make_float2(0.5f * (zk.x + zn.x), 0.5f * (zk.y - zn.y));
+                const float2 d = make_float2(0.5f * (zk.x - zn.x), 0.5f * (zk.y + zn.y));
+                const float2 to = cmul(tws[k], make_float2(d.y, -d.x));
+                buf[phys(k)] = cadd(e, to);
+                buf[phys(N - k)] = cconj(csub(e, to));
+            }
+        }
+        __syncthreads();
+        // ---- CSR mat-vec against the spectrum + magnitude (zaf.py:630-632)
+        for (int r = wave; r < n_bins; r += nwaves) {
+            const int lo = indptr[r], hi = indptr[r + 1];
+            float ar = 0.f, ai = 0.f;
+            for (int e = lo + lane; e < hi; e += 64) {
+                const int c = indices[e];
+                const float2 kv = values[e];
+                float2 xv;
+                if (c < N) xv = buf[phys(c)];
+                else if (c == N) xv = buf[C::PITCH - 1];
+                else xv = cconj(buf[phys(W - c)]);
+                ar += kv.x * xv.x - kv.y * xv.y;
+                ai += kv.x * xv.y + kv.y * xv.x;
+            }
+#pragma unroll
+            for (int m = 32; m >= 1; m >>= 1) {
+                ar += __shfl_xor(ar, m, 64);
+                ai += __shfl_xor(ai, m, 64);
+            }
+            if (lane == 0) tile[r * FW + jj] = sqrtf(ar * ar + ai * ai);
+        }
+        __syncthreads();
+    }
+
+    // ---- store the tile (64-B runs along t in the reference layout)
+    const int nvalid = min(FW, T - t0);
+    if (chroma_res > 0) {
+        for (int idx = p; idx < chroma_res * FW; idx += P) {
+            const int ch = idx / FW, jj = idx % FW;
+            if (jj >= nvalid) continue;
+            float acc = 0.f;
+            for (int r = ch; r < n_bins; r += chroma_res) acc += tile[r * FW + jj];   // zaf.py:696-698
+            if (layout == ZAFX_LAYOUT_FT) out[((long long)clip * chroma_res + ch) * T + t0 + jj] = acc;
+            else out[((long long)clip * T + t0 + jj) * chroma_res + ch] = acc;
+        }
+    } else {
+        for (int idx = p; idx < n_bins * FW; idx += P) {
+            const int r = idx / FW, jj = idx % FW;
+            if (jj >= nvalid) continue;
+            const float val = tile[idx];
+            if (layout == ZAFX_LAYOUT_FT) out[((long long)clip * n_bins + r) * T + t0 + jj] = val;
+            else out[((long long)clip * T + t0 + jj) * n_bins + r] = val;
+        }
+    }
+}
+
+template <int LOG2N>
+static hipError_t run_cqt(const zafx_plan& pl, const float* x, float* out, int64_t n_clips, int64_t n_samples, int T) {
+    constexpr int LOG2E = default_log2e(LOG2N);
+    using C = FftCfg<LOG2N, LOG2E>;
+    auto kern = k_cqt<LOG2N, LOG2E>;
+    const size_t smem = (size_t)C::PITCH * 8 + (size_t)pl.prm.n_bins * kCqtFramesPerBlock * sizeof(float);
+    if (smem > (size_t)kMaxLdsBytes) {
+        set_error("cqt: n_bins too large for the LDS output tile at this fft_length");
+        return hipErrorInvalidValue;
+    }
+    static size_t attr_set[64] = {};
+    if (attr_set[pl.device] < smem) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+        if (e != hipSuccess) return e;
+        attr_set[pl.device] = smem;
+    }
+    const int tiles = (T + kCqtFramesPerBlock - 1) / kCqtFramesPerBlock;
+    const long long blocks = (long long)tiles * n_clips;
+    if (blocks <= 0) return hipSuccess;
+    const int diff = pl.W - pl.H;                              // may be negative if step > fft_len
+    const int left = diff >= 0 ? (diff + 1) / 2 : -((-diff) / 2);   // ceil(diff / 2)  (zaf.py:615)
+    hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(C::P), smem, pl.stream, x, pl.d_tw_pass, pl.d_tw_aux, pl.d_indptr, pl.d_indices,
+                       pl.d_values, out, (long long)n_samples, pl.H, left, T, tiles, pl.prm.n_bins,
+                       pl.kind == ZAFX_CHROMA ? pl.prm.octave_resolution : 0, pl.layout);
+    return hipGetLastError();
+}
+
+bool cqt_supported(int log2n) { return log2n >= 8 && log2n <= 14; }
+const char* cqt_kernel_name() { return "k_cqt"; }
+
+hipError_t launch_cqt(const zafx_plan& pl, const float* x, float* out, int64_t n_clips, int64_t n_samples, int T) {
+    switch (pl.log2nf) {
+        case 8: return run_cqt<8>(pl, x, out, n_clips, n_samples, T);
+        case 9: return run_cqt<9>(pl, x, out, n_clips, n_samples, T);
+        case 10: return run_cqt<10>(pl, x, out, n_clips, n_samples, T);
+        case 11: return run_cqt<11>(pl, x, out, n_clips, n_samples, T);
+        case 12: return run_cqt<12>(pl, x, out, n_clips, n_samples, T);
+        case 13: return run_cqt<13>(pl, x, out, n_clips, n_samples, T);
+        case 14: return run_cqt<14>(pl, x, out, n_clips, n_samples, T);
+    }
+    set_error("cqt: unsupported fft_length");
+    return hipErrorInvalidValue;
+}
+
+}  // namespace zafx

@@ -1,0 +1,235 @@
+// zafx_fft.hpp -- per-frame complex FFT core shared by every zafx kernel (gfx950).
+//
+// Replaces the np.fft.fft / np.fft.ifft call sites of the reference hot path
+// (zaf.py:139, :223, :631, :1068, :1159).  Design (DESIGN.md "FFT core"):
+//
+//   * A frame of N = 2^LOG2N complex points is owned by P = N/E threads, each
+//     holding E = 2^LOG2E points in registers (E = 16 for N >= 1024, so a
+//     1024-point frame is exactly ONE 64-lane wavefront and needs no barrier).
+//   * Stockham autosort, decimation in time.  log2(N) radix-2 stages are fused
+//     into passes of radix 16/8/4/2 done entirely in registers; between passes
+//     the frame is exchanged through LDS (write scattered, read p + i*P).
+//   * The LDS image is padded by one complex every 16 (phys(i) = i + i/16) so the
+//     stride-R scatter of a pass is bank-conflict free for ds_write_b64.
+//   * Twiddles are never computed on device (no __sinf): the host builds, in
+//     float64, one table per pass laid out [r][k] so that lanes read consecutive
+//     k (conflict free); see zafx_twiddle_layout below, used by host and device.
+//
+// The same header is compiled by g++ with -DZAFX_HOST_EMU for the CPU-side
+// algorithm test (tests/host_emu), where "threads" are emulated by loops.
+#pragma once
+
+#if defined(ZAFX_HOST_EMU)
+#include <cmath>
+struct float2 { float x, y; };
+static inline float2 make_float2(float x, float y) { float2 r; r.x = x; r.y = y; return r; }
+#define ZAFX_HD inline
+#else
+#include <hip/hip_runtime.h>
+#define ZAFX_HD __host__ __device__ __forceinline__
+#endif
+
+namespace zafx {
+
+// ---------------------------------------------------------------- complex helpers
+ZAFX_HD float2 cadd(float2 a, float2 b) { return make_float2(a.x + b.x, a.y + b.y); }
+ZAFX_HD float2 csub(float2 a, float2 b) { return make_float2(a.x - b.x, a.y - b.y); }
+ZAFX_HD float2 cmul(float2 a, float2 b) {
+    return make_float2(a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x);
+}
+ZAFX_HD float2 cmulc(float2 a, float2 b) {   // a * conj(b)
+    return make_float2(a.x * b.x + a.y * b.y, a.y * b.x - a.x * b.y);
+}
+ZAFX_HD float2 cconj(float2 a) { return make_float2(a.x, -a.y); }
+ZAFX_HD float2 mul_mi(float2 a) { return make_float2(a.y, -a.x); }   // a * (-i)
+ZAFX_HD float2 cscale(float2 a, float s) { return make_float2(a.x * s, a.y * s); }
+
+// ---------------------------------------------------------------- pass schedule
+// log2 of the radix of the pass that starts with `rem` radix-2 stages left, when
+// a thread holds 2^log2e points.  Shared by host (table builder) and device.
+constexpr int pass_log2r(int rem, int log2e) {
+    int m = log2e < 4 ? log2e : 4;
+    if (rem <= m) return rem;
+    if (rem - m == 1 && m >= 3) return m - 1;   // avoid a trailing radix-2 pass
+    return m;
+}
+// offset (in float2 entries) of the twiddle table of the pass that starts at Ns = 2^log2ns
+constexpr int twiddle_offset(int log2n, int log2e, int log2ns) {
+    int off = 0, ns = 0;
+    while (ns < log2ns) {
+        int lr = pass_log2r(log2n - ns, log2e);
+        if (ns > 0) off += ((1 << lr) - 1) << ns;
+        ns += lr;
+    }
+    return off;
+}
+constexpr int twiddle_total(int log2n, int log2e) { return twiddle_offset(log2n, log2e, log2n); }
+
+constexpr int default_log2e(int log2n) {
+    return log2n >= 10 ? 4 : (log2n >= 7 ? log2n - 6 : 1);
+}
+
+// threads that own one frame (usable inside __launch_bounds__, which is a macro)
+constexpr int fft_threads(int log2n, int log2e) { return (1 << log2n) >> log2e; }
+
+template <int LOG2N, int LOG2E>
+struct FftCfg {
+    static constexpr int N = 1 << LOG2N;
+    static constexpr int E = 1 << LOG2E;
+    static constexpr int P = N / E;                 // threads per frame
+    static constexpr int PITCH = N + (N >> 4) + 1;  // padded complex slots per frame (odd-ish pitch)
+    static constexpr int TW = twiddle_total(LOG2N, LOG2E);
+};
+
+ZAFX_HD int phys(int i) { return i + (i >> 4); }
+
+// ---------------------------------------------------------------- register DFTs
+// Natural-order in, natural-order out, forward sign (e^{-2 pi i nk/R}).
+ZAFX_HD void dft2(float2& a, float2& b) {
+    float2 t = csub(a, b);
+    a = cadd(a, b);
+    b = t;
+}
+ZAFX_HD void dft4(float2& v0, float2& v1, float2& v2, float2& v3) {
+    float2 t0 = cadd(v0, v2), t1 = csub(v0, v2);
+    float2 t2 = cadd(v1, v3), t3 = mul_mi(csub(v1, v3));
+    v0 = cadd(t0, t2);
+    v1 = cadd(t1, t3);
+    v2 = csub(t0, t2);
+    v3 = csub(t1, t3);
+}
+
+template <int R>
+struct Dft;
+template <>
+struct Dft<1> {
+    static ZAFX_HD void run(float2*) {}
+};
+template <>
+struct Dft<2> {
+    static ZAFX_HD void run(float2* a) { dft2(a[0], a[1]); }
+};
+template <>
+struct Dft<4> {
+    static ZAFX_HD void run(float2* a) { dft4(a[0], a[1], a[2], a[3]); }
+};
+template <>
+struct Dft<8> {
+    static ZAFX_HD void run(float2* a) {
+        const float h = 0.70710678118654752440f;
+        float2 e0 = a[0], e1 = a[2], e2 = a[4], e3 = a[6];
+        float2 o0 = a[1], o1 = a[3], o2 = a[5], o3 = a[7];
+        dft4(e0, e1, e2, e3);
+        dft4(o0, o1, o2, o3);
+        o1 = make_float2((o1.x + o1.y) * h, (o1.y - o1.x) * h);    // * w8^1
+        o2 = mul_mi(o2);                                           // * w8^2
+        o3 = make_float2((o3.y - o3.x) * h, -(o3.x + o3.y) * h);   // * w8^3
+        a[0] = cadd(e0, o0); a[4] = csub(e0, o0);
+        a[1] = cadd(e1, o1); a[5] = csub(e1, o1);
+        a[2] = cadd(e2, o2); a[6] = csub(e2, o2);
+        a[3] = cadd(e3, o3); a[7] = csub(e3, o3);
+    }
+};
+template <>
+struct Dft<16> {
+    static ZAFX_HD void run(float2* a) {
+        const float h = 0.70710678118654752440f;
+        const float c1 = 0.92387953251128675613f, s1 = 0.38268343236508977173f;   // cos/sin(pi/8)
+        float2 m[4][4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {   // 4-point DFTs over n = r + 4 q'
+            m[r][0] = a[r]; m[r][1] = a[r + 4]; m[r][2] = a[r + 8]; m[r][3] = a[r + 12];
+            dft4(m[r][0], m[r][1], m[r][2], m[r][3]);
+        }
+        // twiddle m[r][q] *= w16^(r q)
+        m[1][1] = cmul(m[1][1], make_float2(c1, -s1));                                        // w^1
+        m[1][2] = make_float2((m[1][2].x + m[1][2].y) * h, (m[1][2].y - m[1][2].x) * h);      // w^2
+        m[1][3] = cmul(m[1][3], make_float2(s1, -c1));                                        // w^3
+        m[2][1] = make_float2((m[2][1].x + m[2][1].y) * h, (m[2][1].y - m[2][1].x) * h);      // w^2
+        m[2][2] = mul_mi(m[2][2]);                                                            // w^4
+        m[2][3] = make_float2((m[2][3].y - m[2][3].x) * h, -(m[2][3].x + m[2][3].y) * h);     // w^6
+        m[3][1] = cmul(m[3][1], make_float2(s1, -c1));                                        // w^3
+        m[3][2] = make_float2((m[3][2].y - m[3][2].x) * h, -(m[3][2].x + m[3][2].y) * h);     // w^6
+        m[3][3] = cmul(m[3][3], make_float2(-c1, s1));                                        // w^9
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {   // 4-point DFTs over r; output k = q + 4 s
+            dft4(m[0][q], m[1][q], m[2][q], m[3][q]);
+            a[q] = m[0][q]; a[q + 4] = m[1][q]; a[q + 8] = m[2][q]; a[q + 12] = m[3][q];
+        }
+    }
+};
+
+// ---------------------------------------------------------------- one Stockham pass
+// v[i] holds x[p + i*P].  Twiddle, radix-R butterflies, scatter to the padded
+// LDS frame `buf`.  tw points at this pass's [r-1][k] table (unused when Ns = 1).
+template <int LOG2N, int LOG2E, int LOG2NS, int LR>
+ZAFX_HD void pass_write(const float2* v, float2* buf, int p, const float2* tw) {
+    using C = FftCfg<LOG2N, LOG2E>;
+    constexpr int R = 1 << LR, NS = 1 << LOG2NS, NB = C::E / R;
+#pragma unroll
+    for (int b = 0; b < NB; ++b) {
+        const int j = p + b * C::P;
+        const int k = j & (NS - 1);
+        float2 a[R];
+#pragma unroll
+        for (int r = 0; r < R; ++r) a[r] = v[b + r * NB];
+        if (LOG2NS > 0) {
+#pragma unroll
+            for (int r = 1; r < R; ++r) a[r] = cmul(a[r], tw[(r - 1) * NS + k]);
+        }
+        Dft<R>::run(a);
+        const int base = ((j >> LOG2NS) << (LOG2NS + LR)) + k;
+#pragma unroll
+        for (int r = 0; r < R; ++r) buf[phys(base + r * NS)] = a[r];
+    }
+}
+
+template <int LOG2N, int LOG2E>
+ZAFX_HD void regs_read(float2* v, const float2* buf, int p) {
+    using C = FftCfg<LOG2N, LOG2E>;
+#pragma unroll
+    for (int i = 0; i < C::E; ++i) v[i] = buf[phys(p + i * C::P)];
+}
+
+}  // namespace zafx
+
+#if !defined(ZAFX_HOST_EMU)
+namespace zafx {
+
+// Synchronise the P threads that own one frame.  P <= 64 -> the frame lives in a
+// single wavefront whose LDS operations execute in program order: no barrier.
+// The compiler, however, may legally reorder one THREAD's LDS store past its later
+// LDS load of a provably different address -- which breaks the cross-lane exchange --
+// so the single-wave case still needs a release/acquire fence pair (s_waitcnt
+// lgkmcnt(0), no s_barrier).
+template <int P>
+__device__ __forceinline__ void frame_sync() {
+    if constexpr (P > 64) {
+        __syncthreads();
+    } else {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+    }
+}
+
+// All passes.  Input: v[i] = x[p + i*P].  Output: natural-order spectrum in the
+// padded LDS frame `buf` (visible to the frame's threads after the final sync).
+// `tw` = table built by the host with zafx_twiddle_layout (LDS or global).
+template <int LOG2N, int LOG2E, int LOG2NS = 0>
+__device__ __forceinline__ void fft_frame(float2* v, float2* buf, int p, const float2* tw) {
+    using C = FftCfg<LOG2N, LOG2E>;
+    if constexpr (LOG2NS < LOG2N) {
+        constexpr int LR = pass_log2r(LOG2N - LOG2NS, LOG2E);
+        pass_write<LOG2N, LOG2E, LOG2NS, LR>(v, buf, p, tw + twiddle_offset(LOG2N, LOG2E, LOG2NS));
+        frame_sync<C::P>();
+        if constexpr (LOG2NS + LR < LOG2N) {
+            regs_read<LOG2N, LOG2E>(v, buf, p);
+            frame_sync<C::P>();
+            fft_frame<LOG2N, LOG2E, LOG2NS + LR>(v, buf, p, tw);
+        }
+    }
+}
+
+}  // namespace zafx
+#endif

@@ -1,0 +1,88 @@
+// zafx_internal.hpp -- plan object and launcher prototypes shared by the C-ABI
+// translation unit (zafx_capi.cpp) and the kernel translation units (*.hip).
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+#include <string>
+#include <vector>
+
+#include "../../include/zafx.h"
+#include "zafx_twiddle.hpp"
+
+namespace zafx {
+
+constexpr int kMaxLdsBytes = 160 * 1024;   // LDS per CU on gfx950
+
+// Banded, MFMA-fragment-packed filterbank (mel FB or DCT matrix): see zafx_mel.hip.
+struct PackedBand {
+    int n_rows = 0;        // logical rows (filters / coefficients)
+    int n_blocks = 0;      // ceil(n_rows / 16)
+    int n_cols = 0;        // logical K extent
+    float* d_pack = nullptr;   // [total_steps][64] : lane l -> A[l & 15][4*step + (l >> 4)]
+    int* d_meta = nullptr;     // [n_blocks][4] : {first_col (multiple of 4), n_steps, step_offset, 0}
+    int total_steps = 0;
+    int max_steps = 0;
+};
+
+}  // namespace zafx
+
+struct zafx_plan {
+    int device = 0;
+    int kind = 0;
+    zafx_params prm{};
+    hipStream_t stream = nullptr;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+
+    int W = 0;        // window length (or CQT fft_length)
+    int H = 0;        // hop / step
+    int layout = 0;
+    int log2nf = 0;   // log2 of the complex FFT length the kernels run
+    int log2e = 0;
+
+    // device constants
+    float* d_window = nullptr;
+    float2* d_tw_pass = nullptr;   // per-pass twiddles for fft_frame<log2nf, log2e>
+    float2* d_tw_aux = nullptr;    // real-split roots (STFT family / CQT) or tw8 (MDCT family)
+    float cola_gain = 0.f;         // sum(w[0:W:H])  (zaf.py:241)
+    zafx::PackedBand fb, dct;
+    int* d_indptr = nullptr;
+    int* d_indices = nullptr;
+    float2* d_values = nullptr;
+    int nnz = 0;
+
+    // host shadows (needed to re-pack after an RCCL broadcast)
+    std::vector<float> h_window, h_fb, h_dct;
+    std::vector<int32_t> h_indptr, h_indices;
+    std::vector<zafx::cf32> h_values;
+
+    std::string kernel_name;
+};
+
+namespace zafx {
+
+// Every launcher enqueues on plan.stream and returns hipGetLastError().
+hipError_t launch_stft(const zafx_plan& pl, const float* x, float2* out, int64_t n_clips, int64_t n_samples, int T);
+hipError_t launch_istft(const zafx_plan& pl, const float2* spec, float* y, int64_t n_clips, int T, int64_t out_len);
+hipError_t launch_mdct(const zafx_plan& pl, const float* x, float* out, int64_t n_clips, int64_t n_samples, int T);
+hipError_t launch_imdct(const zafx_plan& pl, const float* coefs, float* y, int64_t n_clips, int T, int64_t out_len);
+hipError_t launch_mel(const zafx_plan& pl, const float* x, float* out, int64_t n_clips, int64_t n_samples, int T);
+hipError_t launch_cqt(const zafx_plan& pl, const float* x, float* out, int64_t n_clips, int64_t n_samples, int T);
+
+// names of the dominant kernels (what rocprofv3 --kernel-trace prints, prefix match)
+const char* stft_kernel_name();
+const char* istft_kernel_name();
+const char* mdct_kernel_name();
+const char* imdct_kernel_name();
+const char* mel_kernel_name();
+const char* cqt_kernel_name();
+
+bool stft_supported(int log2n);   // log2 of complex FFT length = log2(W) - 1
+bool mdct_supported(int log2nf);  // log2(W) - 2
+bool cqt_supported(int log2n);    // log2(fft_length) - 1
+int stft_frames_per_block(int log2n, int layout);
+int mdct_frames_per_block(int log2nf, int layout);
+
+void set_error(const std::string& msg);
+
+}  // namespace zafx

@@ -1,0 +1,337 @@
+// zafx_stft.hip -- batched STFT / ISTFT kernels for gfx950 (MI355X).
+//
+//   k_stft  : framing + window + real-input FFT + Hermitian mirror, fused
+//             (replaces np.pad zaf.py:112-125, the frame loop :132-136 and
+//             np.fft.fft(axis=0) :139)
+//   k_istft : Hermitian symmetrisation + inverse real FFT + gather overlap-add +
+//             trim + COLA gain, fused (replaces zaf.py:223, :226-233, :236-241)
+//
+// A frame of W real samples is transformed as ONE complex FFT of N = W/2 points
+// (z[n] = x[2n] + i x[2n+1]) followed by the real-split butterfly
+//   X[k]   = E + t_k O,  X[N-k] = conj(E - t_k O),  t_k = exp(-2 pi i k / W)
+//   E = (Z[k] + conj Z[N-k]) / 2,  O = -i (Z[k] - conj Z[N-k]) / 2,
+// and the upper half is written as the conjugate mirror (the reference API returns
+// the two-sided spectrum).  A workgroup owns FPB consecutive frames of one clip;
+// in the reference (frequency-major, time-minor) layout the FPB frames supply the
+// contiguous run along t for every stored row (16 frames x 8 B = one 128-B line).
+#include "zafx_fft.hpp"
+#include "zafx_internal.hpp"
+
+namespace zafx {
+
+// ---------------------------------------------------------------------------------
+// real-split of one (k, N-k) pair
+// ---------------------------------------------------------------------------------
+__device__ __forceinline__ void split_pair(float2 zk, float2 zn, float2 t, float2& xk, float2& xn) {
+    const float2 e = make_float2(0.5f * (zk.x + zn.x), 0.5f * (zk.y - zn.y));
+    const float2 d = make_float2(0.5f * (zk.x - zn.x), 0.5f * (zk.y + zn.y));
+    const float2 o = make_float2(d.y, -d.x);   // -i d
+    const float2 to = cmul(t, o);
+    xk = cadd(e, to);
+    xn = cconj(csub(e, to));
+}
+
+template <int LOG2N, int LOG2E, int FPB>
+struct StftCfg {
+    using C = FftCfg<LOG2N, LOG2E>;
+    static constexpr int NT = FPB * C::P;
+    static constexpr bool TW_LDS = (size_t)(FPB * C::PITCH + C::TW) * 8 <= (size_t)kMaxLdsBytes;
+    static constexpr size_t SMEM = (size_t)(FPB * C::PITCH + (TW_LDS ? C::TW : 0)) * 8;
+};
+
+// ---------------------------------------------------------------------------------
+// forward
+// ---------------------------------------------------------------------------------
+template <int LOG2N, int LOG2E, int FPB, int LAYOUT>
+__global__ __launch_bounds__(FPB * fft_threads(LOG2N, LOG2E)) void k_stft(
+    const float* __restrict__ x, const float* __restrict__ win, const float2* __restrict__ twp,
+    const float2* __restrict__ tws, float2* __restrict__ out, long long n_samples, int hop, int T, int tiles) {
+    using C = FftCfg<LOG2N, LOG2E>;
+    using S = StftCfg<LOG2N, LOG2E, FPB>;
+    constexpr int N = C::N, P = C::P, E = C::E, W = 2 * N, NT = S::NT;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    float2* frames = reinterpret_cast<float2*>(smem_raw);
+    const float2* tw = twp;
+    const int tid = threadIdx.x;
+    if constexpr (S::TW_LDS) {
+        float2* tw_l = frames + FPB * C::PITCH;
+        for (int i = tid; i < C::TW; i += NT) tw_l[i] = twp[i];
+        tw = tw_l;
+        __syncthreads();
+    }
+    const int slot = tid / P, p = tid % P;
+    const int clip = blockIdx.x / tiles, tile = blockIdx.x % tiles;
+    const int t0 = tile * FPB;
+    const int t = t0 + slot;
+    float2* buf = frames + slot * C::PITCH;
+
+    // ---- framing + window: v[i] = (x[2n] w[2n], x[2n+1] w[2n+1]), n = p + i P (zaf.py:112-136)
+    float2 v[E];
+    {
+        const float* xc = x + (long long)clip * n_samples;
+        const long long s0 = (long long)t * hop - N;   // floor(W/2) = N samples of left padding
+        const float2* w2 = reinterpret_cast<const float2*>(win);
+#pragma unroll
+        for (int i = 0; i < E; ++i) {
+            const int n = p + i * P;
+            const long long s = s0 + 2 * n;
+            const float2 wv = w2[n];
+            const float a = (t < T && s >= 0 && s < n_samples) ? xc[s] : 0.f;
+            const float b = (t < T && s + 1 >= 0 && s + 1 < n_samples) ? xc[s + 1] : 0.f;
+            v[i] = make_float2(a * wv.x, b * wv.y);
+        }
+    }
+    fft_frame<LOG2N, LOG2E>(v, buf, p, tw);
+
+    if constexpr (LAYOUT == ZAFX_LAYOUT_TF) {
+        if (t >= T) return;
+        float2* o = out + ((long long)clip * T + t) * W;
+#pragma unroll
+        for (int i = 0; i < E / 2; ++i) {
+            const int k = p + i * P;
+            if (k == 0) {
+                const float2 z0 = buf[0], zc = buf[phys(N / 2)];
+                o[0] = make_float2(z0.x + z0.y, 0.f);
+                o[N] = make_float2(z0.x - z0.y, 0.f);
+                o[N / 2] = cconj(zc);
+                o[N + N / 2] = zc;
+            } else {
+                float2 xk, xn;
+                split_pair(buf[phys(k)], buf[phys(N - k)], tws[k], xk, xn);
+                o[k] = xk;
+                o[W - k] = cconj(xk);
+                o[N - k] = xn;
+                o[N + k] = cconj(xn);
+            }
+        }
+    } else {
+        if constexpr (NT > 64) __syncthreads();
+        const int tt = tid % FPB, kq = tid / FPB;
+        if (t0 + tt >= T) return;
+        const float2* fb = frames + tt * C::PITCH;
+        float2* o = out + (long long)clip * W * T + (t0 + tt);
+        for (int k = kq; k < N / 2; k += P) {
+            if (k == 0) {
+                const float2 z0 = fb[0], zc = fb[phys(N / 2)];
+                o[0] = make_float2(z0.x + z0.y, 0.f);
+                o[(long long)N * T] = make_float2(z0.x - z0.y, 0.f);
+                o[(long long)(N / 2) * T] = cconj(zc);
+                o[(long long)(N + N / 2) * T] = zc;
+            } else {
+                float2 xk, xn;
+                split_pair(fb[phys(k)], fb[phys(N - k)], tws[k], xk, xn);
+                o[(long long)k * T] = xk;
+                o[(long long)(W - k) * T] = cconj(xk);
+                o[(long long)(N - k) * T] = xn;
+                o[(long long)(N + k) * T] = cconj(xn);
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------
+// inverse
+// ---------------------------------------------------------------------------------
+// Build the packed half-length spectrum of one (k, N-k) pair from the four two-sided
+// bins, for an ARBITRARY input (the reference takes real(ifft(.)) of anything,
+// zaf.py:223).  Unscaled by 4; stored re<->im swapped so that a FORWARD transform
+// yields the inverse one.
+__device__ __forceinline__ void unsplit_pair(float2 xk, float2 xwk, float2 xnk, float2 xnpk, float2 t,
+                                             float2& zk, float2& zn) {
+    const float2 ak = make_float2(xk.x + xwk.x, xk.y - xwk.y);       // X[k] + conj X[W-k]
+    const float2 an = make_float2(xnk.x + xnpk.x, xnk.y - xnpk.y);   // X[N-k] + conj X[N+k]
+    const float2 e = make_float2(ak.x + an.x, ak.y - an.y);          // a_k + conj a_{N-k}
+    const float2 d = make_float2(ak.x - an.x, ak.y + an.y);          // a_k - conj a_{N-k}
+    const float2 o = cmulc(d, t);                                    // d * conj(t_k)
+    // Z[k] = e + i o ; Z[N-k] = conj(e) + i conj(o)
+    const float2 Zk = make_float2(e.x - o.y, e.y + o.x);
+    const float2 Zn = make_float2(e.x + o.y, -e.y + o.x);
+    zk = make_float2(Zk.y, Zk.x);
+    zn = make_float2(Zn.y, Zn.x);
+}
+
+template <int LOG2N, int LOG2E, int FPB, int LAYOUT>
+__global__ __launch_bounds__(FPB * fft_threads(LOG2N, LOG2E)) void k_istft(
+    const float2* __restrict__ spec, const float2* __restrict__ twp, const float2* __restrict__ tws,
+    float* __restrict__ y, int T, int hop, long long out_len, float scale, int tiles, int owned, int halo) {
+    using C = FftCfg<LOG2N, LOG2E>;
+    using S = StftCfg<LOG2N, LOG2E, FPB>;
+    constexpr int N = C::N, P = C::P, E = C::E, W = 2 * N, NT = S::NT;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    float2* frames = reinterpret_cast<float2*>(smem_raw);
+    const float2* tw = twp;
+    const int tid = threadIdx.x;
+    if constexpr (S::TW_LDS) {
+        float2* tw_l = frames + FPB * C::PITCH;
+        for (int i = tid; i < C::TW; i += NT) tw_l[i] = twp[i];
+        tw = tw_l;
+    }
+    const int clip = blockIdx.x / tiles, tile = blockIdx.x % tiles;
+    const int t_first = tile * owned - halo;   // frame held by slot 0 (may be < 0)
+
+    // ---- phase A: gather the four two-sided bins of every pair, write packed Z to LDS
+    {
+        int fs, kq, kstep;
+        if constexpr (LAYOUT == ZAFX_LAYOUT_TF) { fs = tid / P; kq = tid % P; kstep = P; }
+        else { fs = tid % FPB; kq = tid / FPB; kstep = P; }
+        const int t = t_first + fs;
+        if (fs < owned + halo && t >= 0 && t < T) {
+            float2* fb = frames + fs * C::PITCH;
+            long long base, kstride;
+            if constexpr (LAYOUT == ZAFX_LAYOUT_TF) { base = ((long long)clip * T + t) * W; kstride = 1; }
+            else { base = (long long)clip * W * T + t; kstride = T; }
+            const float2* sp = spec + base;
+            for (int k = kq; k < N / 2; k += kstep) {
+                if (k == 0) {
+                    const float a0 = 2.f * sp[0].x, an = 2.f * sp[(long long)N * kstride].x;
+                    // Z[0] = (a0 + aN) + i (a0 - aN), stored swapped
+                    fb[0] = make_float2(a0 - an, a0 + an);
+                    const float2 xc = sp[(long long)(N / 2) * kstride], xd = sp[(long long)(N + N / 2) * kstride];
+                    // A = X[N/2] + conj X[3N/2]; Z[N/2] = 2 conj(A), stored swapped
+                    const float2 a = make_float2(xc.x + xd.x, xc.y - xd.y);
+                    fb[phys(N / 2)] = make_float2(-2.f * a.y, 2.f * a.x);
+                } else {
+                    float2 zk, zn;
+                    unsplit_pair(sp[(long long)k * kstride], sp[(long long)(W - k) * kstride],
+                                 sp[(long long)(N - k) * kstride], sp[(long long)(N + k) * kstride], tws[k], zk, zn);
+                    fb[phys(k)] = zk;
+                    fb[phys(N - k)] = zn;
+                }
+            }
+        }
+    }
+    __syncthreads();
+
+    // ---- phase B: forward FFT of the swapped spectrum == swapped inverse FFT
+    {
+        const int slot = tid / P, p = tid % P;
+        float2* buf = frames + slot * C::PITCH;
+        float2 v[E];
+        regs_read<LOG2N, LOG2E>(v, buf, p);
+        frame_sync<P>();
+        fft_frame<LOG2N, LOG2E>(v, buf, p, tw);
+    }
+    __syncthreads();
+
+    // ---- phase C: gather overlap-add in ascending frame order (zaf.py:226-233), trim (:236-238),
+    //      COLA gain (:241); no atomics, every output sample is written exactly once
+    {
+        const float* fl = reinterpret_cast<const float*>(frames);
+        const int t_end = min((tile + 1) * owned, T);
+        const long long s_begin = (long long)tile * owned * hop;
+        const long long s_end = (tile == tiles - 1) ? (long long)T * hop + (W - hop) : (long long)t_end * hop;
+        float* yc = y + (long long)clip * out_len;
+        for (long long s = s_begin + tid; s < s_end; s += NT) {
+            const long long o = s - (W - hop);
+            if (o < 0 || o >= out_len) continue;
+            const int j_hi = (int)min((long long)(T - 1), s / hop);
+            const int j_lo = s >= W ? (int)((s - W) / hop) + 1 : 0;
+            float acc = 0.f;
+            for (int j = j_lo; j <= j_hi; ++j) {
+                const int n = (int)(s - (long long)j * hop);
+                const int f = (2 * phys(n >> 1) + (n & 1)) ^ 1;   // swapped components
+                acc += fl[(size_t)(j - t_first) * (2 * C::PITCH) + f];
+            }
+            yc[o] = acc * scale;
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------
+// launch plumbing
+// ---------------------------------------------------------------------------------
+constexpr int stft_fpb(int log2n, int layout) {
+    const int p = (1 << log2n) >> default_log2e(log2n);
+    int cap = 1024 / p;
+    // LDS cap: FPB * PITCH * 8 <= 160 KiB
+    const int pitch = (1 << log2n) + ((1 << log2n) >> 4) + 1;
+    int lds_cap = kMaxLdsBytes / (pitch * 8);
+    int f = layout == ZAFX_LAYOUT_FT ? 16 : 4;
+    if (f > cap) f = cap;
+    if (f > lds_cap) f = lds_cap;
+    // round down to a power of two
+    int r = 1;
+    while (r * 2 <= f) r *= 2;
+    return r;
+}
+
+template <int LOG2N, int LAYOUT>
+static hipError_t run_stft(const zafx_plan& pl, const float* x, float2* out, int64_t n_clips, int64_t n_samples, int T) {
+    constexpr int LOG2E = default_log2e(LOG2N);
+    constexpr int FPB = stft_fpb(LOG2N, LAYOUT);
+    using S = StftCfg<LOG2N, LOG2E, FPB>;
+    auto kern = k_stft<LOG2N, LOG2E, FPB, LAYOUT>;
+    static bool attr_set[64] = {};
+    if (!attr_set[pl.device]) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)S::SMEM);
+        if (e != hipSuccess) return e;
+        attr_set[pl.device] = true;
+    }
+    const int tiles = (T + FPB - 1) / FPB;
+    const long long blocks = (long long)tiles * n_clips;
+    if (blocks <= 0) return hipSuccess;
+    hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(S::NT), S::SMEM, pl.stream, x, pl.d_window, pl.d_tw_pass, pl.d_tw_aux,
+                       out, (long long)n_samples, pl.H, T, tiles);
+    return hipGetLastError();
+}
+
+template <int LOG2N, int LAYOUT>
+static hipError_t run_istft(const zafx_plan& pl, const float2* spec, float* y, int64_t n_clips, int T, int64_t out_len) {
+    constexpr int LOG2E = default_log2e(LOG2N);
+    constexpr int FPB = stft_fpb(LOG2N, ZAFX_LAYOUT_FT);
+    using S = StftCfg<LOG2N, LOG2E, FPB>;
+    auto kern = k_istft<LOG2N, LOG2E, FPB, LAYOUT>;
+    static bool attr_set[64] = {};
+    if (!attr_set[pl.device]) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)S::SMEM);
+        if (e != hipSuccess) return e;
+        attr_set[pl.device] = true;
+    }
+    const int W = 2 << LOG2N;
+    const int halo = (W + pl.H - 1) / pl.H - 1;
+    const int owned = FPB - halo;
+    if (owned < 1) {
+        set_error("istft: step_length too small for this window_length (ceil(W/H) exceeds frames per workgroup)");
+        return hipErrorInvalidValue;
+    }
+    const int tiles = (T + owned - 1) / owned;
+    const long long blocks = (long long)tiles * n_clips;
+    if (blocks <= 0 || out_len <= 0) return hipSuccess;
+    const float scale = 1.f / (4.f * (float)(1 << LOG2N) * pl.cola_gain);
+    hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(S::NT), S::SMEM, pl.stream, spec, pl.d_tw_pass, pl.d_tw_aux, y, T, pl.H,
+                       (long long)out_len, scale, tiles, owned, halo);
+    return hipGetLastError();
+}
+
+#define ZAFX_STFT_SIZES(X) X(5) X(6) X(7) X(8) X(9) X(10) X(11) X(12)
+
+bool stft_supported(int log2n) { return log2n >= 5 && log2n <= 12; }
+int stft_frames_per_block(int log2n, int layout) { return stft_fpb(log2n, layout); }
+const char* stft_kernel_name() { return "k_stft"; }
+const char* istft_kernel_name() { return "k_istft"; }
+
+hipError_t launch_stft(const zafx_plan& pl, const float* x, float2* out, int64_t n_clips, int64_t n_samples, int T) {
+    switch (pl.log2nf) {
+#define X(L)                                                                                        \
+    case L:                                                                                         \
+        return pl.layout == ZAFX_LAYOUT_FT ? run_stft<L, ZAFX_LAYOUT_FT>(pl, x, out, n_clips, n_samples, T) \
+                                           : run_stft<L, ZAFX_LAYOUT_TF>(pl, x, out, n_clips, n_samples, T);
+        ZAFX_STFT_SIZES(X)
+#undef X
+    }
+    return hipErrorInvalidValue;
+}
+
+hipError_t launch_istft(const zafx_plan& pl, const float2* spec, float* y, int64_t n_clips, int T, int64_t out_len) {
+    switch (pl.log2nf) {
+#define X(L)                                                                                          \
+    case L:                                                                                           \
+        return pl.layout == ZAFX_LAYOUT_FT ? run_istft<L, ZAFX_LAYOUT_FT>(pl, spec, y, n_clips, T, out_len) \
+                                           : run_istft<L, ZAFX_LAYOUT_TF>(pl, spec, y, n_clips, T, out_len);
+        ZAFX_STFT_SIZES(X)
+#undef X
+    }
+    return hipErrorInvalidValue;
+}
+
+}  // namespace zafx

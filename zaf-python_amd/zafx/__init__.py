@@ -1,0 +1,23 @@
+"""zafx -- MI355X-native drop-in for the windowed-transform path of zaf.py.
+
+    import zafx as zaf          # same signatures as zafarrafii/Zaf-Python for this path
+    X = zaf.stft(x, w, 1024)    # runs on the GPU through libzafx.so (hand-written HIP)
+
+Drop-in functions (zaf.py signatures, float64 / complex128 results):
+    stft, istft, melfilterbank, melspectrogram, mfcc, cqtkernel, cqtspectrogram,
+    cqtchromagram, mdct, imdct
+Batched extension ((clips, samples) in, float32 / complex64 out):
+    stft_batch, istft_batch, mdct_batch, imdct_batch, melspectrogram_batch, mfcc_batch,
+    cqtspectrogram_batch, cqtchromagram_batch
+Device-resident API: Plan, DeviceBuffer, Comm, *_plan factories, shard helpers.
+"""
+from ._lib import (CHROMA, CQT, IMDCT, ISTFT, LAYOUT_FT, LAYOUT_TF, MDCT, MEL, MFCC, STFT, ZafxError, device_count,
+                   device_name, library_path)
+from .constants import cqtkernel, dct2_rows, hamming, kaiser_bessel_derived, melfilterbank, sine
+from .core import (Comm, DeviceBuffer, Plan, clear_plan_cache, cqt_plan, cqtchromagram, cqtchromagram_batch,
+                   cqtspectrogram, cqtspectrogram_batch, imdct, imdct_batch, istft, istft_batch, istft_plan, mdct,
+                   mdct_batch, mdct_plan, mel_plan, melspectrogram, melspectrogram_batch, mfcc, mfcc_batch, stft,
+                   stft_batch, stft_plan)
+from .shard import clip_range, shard_sizes
+
+__version__ = "0.1.0"

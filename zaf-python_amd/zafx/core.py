@@ -1,0 +1,513 @@
+"""Plans, device buffers and the batched / drop-in transform functions.
+
+Layering: Python host code -> ctypes -> libzafx.so (C-ABI, include/zafx.h)
+-> hand-written HIP kernels.  No PyTorch, no CPU fallback.
+"""
+import ctypes
+import threading
+
+import numpy as np
+
+from . import _lib
+from . import constants
+from ._lib import ZafxError
+
+_LAYOUTS = {"FT": _lib.LAYOUT_FT, "TF": _lib.LAYOUT_TF, _lib.LAYOUT_FT: _lib.LAYOUT_FT, _lib.LAYOUT_TF: _lib.LAYOUT_TF}
+
+
+def _ptr(a):
+    return ctypes.c_void_p(a.ctypes.data)
+
+
+# ======================================================================================
+# device memory
+# ======================================================================================
+class DeviceBuffer:
+    """A typed, shaped allocation in one GPU's HBM (owned by this object)."""
+
+    def __init__(self, shape, dtype, device=0):
+        self.shape = tuple(int(s) for s in np.atleast_1d(shape))
+        self.dtype = np.dtype(dtype)
+        self.device = int(device)
+        self.nbytes = int(np.prod(self.shape, dtype=np.int64)) * self.dtype.itemsize
+        p = ctypes.c_void_p()
+        _lib.check(_lib.load().zafx_alloc(self.device, ctypes.byref(p), self.nbytes), "zafx_alloc")
+        self.ptr = p
+
+    @classmethod
+    def from_host(cls, array, device=0):
+        array = np.ascontiguousarray(array)
+        buf = cls(array.shape, array.dtype, device)
+        buf.upload(array)
+        return buf
+
+    def upload(self, array):
+        array = np.ascontiguousarray(array, dtype=self.dtype)
+        if array.nbytes != self.nbytes:
+            raise ValueError("upload size mismatch")
+        if self.nbytes:
+            _lib.check(_lib.load().zafx_h2d(self.device, self.ptr, _ptr(array), self.nbytes), "zafx_h2d")
+        return self
+
+    def download(self, first=0, count=None):
+        """Copy to host; `first`/`count` select a range along axis 0."""
+        count = self.shape[0] - first if count is None else count
+        if first < 0 or count < 0 or first + count > self.shape[0]:
+            raise ValueError("download range out of bounds")
+        out = np.empty((count,) + self.shape[1:], dtype=self.dtype)
+        if out.nbytes:
+            row = self.nbytes // max(self.shape[0], 1)
+            src = ctypes.c_void_p(self.ptr.value + first * row)
+            _lib.check(_lib.load().zafx_d2h(self.device, _ptr(out), src, out.nbytes), "zafx_d2h")
+        return out
+
+    def fill_zero(self):
+        if self.nbytes:
+            _lib.check(_lib.load().zafx_memset(self.device, self.ptr, 0, self.nbytes), "zafx_memset")
+        return self
+
+    def copy_from(self, other, nbytes=None, dst_offset=0, src_offset=0):
+        nbytes = other.nbytes if nbytes is None else nbytes
+        dst = ctypes.c_void_p(self.ptr.value + dst_offset)
+        src = ctypes.c_void_p(other.ptr.value + src_offset)
+        _lib.check(_lib.load().zafx_d2d(self.device, dst, src, nbytes), "zafx_d2d")
+        return self
+
+    def free(self):
+        if getattr(self, "ptr", None) is not None and self.ptr.value:
+            _lib.load().zafx_free(self.device, self.ptr)
+            self.ptr = ctypes.c_void_p()
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass
+
+
+# ======================================================================================
+# plans
+# ======================================================================================
+class Plan:
+    """One transform kind bound to one device and one HIP stream (zafx_plan)."""
+
+    _FORWARD = (_lib.STFT, _lib.MDCT, _lib.MEL, _lib.MFCC, _lib.CQT, _lib.CHROMA)
+
+    def __init__(self, kind, device=0, window_length=0, step_length=0, layout="FT", n_filters=0, n_coefs=0,
+                 fft_length=0, n_bins=0, octave_resolution=0):
+        self.kind = kind
+        self.device = int(device)
+        self.layout = _LAYOUTS[layout]
+        prm = _lib.ZafxParams()
+        prm.struct_size = ctypes.sizeof(_lib.ZafxParams)
+        prm.window_length = int(window_length)
+        prm.step_length = int(step_length)
+        prm.layout = self.layout
+        prm.n_filters = int(n_filters)
+        prm.n_coefs = int(n_coefs)
+        prm.fft_length = int(fft_length)
+        prm.n_bins = int(n_bins)
+        prm.octave_resolution = int(octave_resolution)
+        self.params = prm
+        h = ctypes.c_void_p()
+        _lib.check(_lib.load().zafx_plan_create(ctypes.byref(h), self.device, kind, ctypes.byref(prm)), "zafx_plan_create")
+        self.handle = h
+        self.lock = threading.Lock()
+
+    # ---- constants -----------------------------------------------------------------
+    def _set(self, which, array, dtype):
+        array = np.ascontiguousarray(array, dtype=dtype)
+        _lib.check(_lib.load().zafx_plan_set_constant(self.handle, which, _ptr(array), array.nbytes), "zafx_plan_set_constant")
+
+    def set_window(self, window_function):
+        self._set(_lib.CONST_WINDOW, window_function, np.float32)
+
+    def set_mel_filterbank(self, mel_filterbank):
+        dense = mel_filterbank.toarray() if hasattr(mel_filterbank, "toarray") else np.asarray(mel_filterbank)
+        self._set(_lib.CONST_MEL_FB, dense, np.float32)
+
+    def set_dct(self, dct_rows):
+        self._set(_lib.CONST_DCT, dct_rows, np.float32)
+
+    def set_cqt_kernel(self, cqt_kernel):
+        csr = cqt_kernel.tocsr()
+        csr.sort_indices()
+        self._set(_lib.CONST_CQT_INDPTR, csr.indptr, np.int32)
+        self._set(_lib.CONST_CQT_INDICES, csr.indices, np.int32)
+        self._set(_lib.CONST_CQT_VALUES, csr.data, np.complex64)
+
+    # ---- geometry / execution ----------------------------------------------------------
+    def out_dims(self, n_in):
+        dims = (ctypes.c_int64 * 2)()
+        _lib.check(_lib.load().zafx_plan_out_dims(self.handle, int(n_in), dims), "zafx_plan_out_dims")
+        return int(dims[0]), int(dims[1])
+
+    def out_shape(self, n_clips, n_in):
+        rows, frames = self.out_dims(n_in)
+        if self.kind in self._FORWARD:
+            return (n_clips, rows, frames) if self.layout == _lib.LAYOUT_FT else (n_clips, frames, rows)
+        return (n_clips, rows)
+
+    @property
+    def out_dtype(self):
+        return np.dtype(np.complex64) if self.kind == _lib.STFT else np.dtype(np.float32)
+
+    def execute(self, d_in, d_out, n_clips, n_in):
+        """Enqueue on the plan's stream (asynchronous); d_in / d_out are DeviceBuffers."""
+        _lib.check(_lib.load().zafx_execute(self.handle, d_in.ptr, d_out.ptr, int(n_clips), int(n_in)), "zafx_execute")
+
+    def sync(self):
+        _lib.check(_lib.load().zafx_sync(self.handle), "zafx_sync")
+
+    def timer_start(self):
+        _lib.check(_lib.load().zafx_timer_start(self.handle), "zafx_timer_start")
+
+    def timer_stop(self):
+        ms = ctypes.c_float(0)
+        _lib.check(_lib.load().zafx_timer_stop(self.handle, ctypes.byref(ms)), "zafx_timer_stop")
+        return ms.value
+
+    @property
+    def kernel_name(self):
+        buf = ctypes.create_string_buffer(128)
+        _lib.check(_lib.load().zafx_plan_kernel_name(self.handle, buf, 128), "zafx_plan_kernel_name")
+        return buf.value.decode()
+
+    def run_host(self, array, n_in):
+        """Host array in -> device transform -> host array out (PCIe both ways)."""
+        array = np.ascontiguousarray(array)
+        n_clips = array.shape[0]
+        shape = self.out_shape(n_clips, n_in)
+        d_in = DeviceBuffer.from_host(array, self.device)
+        d_out = DeviceBuffer(shape, self.out_dtype, self.device)
+        try:
+            with self.lock:
+                self.execute(d_in, d_out, n_clips, n_in)
+                self.sync()
+            return d_out.download()
+        finally:
+            d_in.free()
+            d_out.free()
+
+    def destroy(self):
+        if getattr(self, "handle", None) is not None and self.handle.value:
+            _lib.load().zafx_plan_destroy(self.handle)
+            self.handle = ctypes.c_void_p()
+
+    def __del__(self):
+        try:
+            self.destroy()
+        except Exception:
+            pass
+
+
+class Comm:
+    """RCCL communicator (one process per GPU); only used to broadcast plan constants."""
+
+    @staticmethod
+    def unique_id():
+        buf = ctypes.create_string_buffer(128)
+        _lib.check(_lib.load().zafx_comm_unique_id(buf), "zafx_comm_unique_id")
+        return buf.raw
+
+    def __init__(self, device, rank, n_ranks, unique_id):
+        if len(unique_id) != 128:
+            raise ValueError("unique_id must be 128 bytes")
+        self._id = ctypes.create_string_buffer(bytes(unique_id), 128)
+        h = ctypes.c_void_p()
+        _lib.check(_lib.load().zafx_comm_create(ctypes.byref(h), int(device), int(rank), int(n_ranks), self._id), "zafx_comm_create")
+        self.handle = h
+        self.rank, self.n_ranks = int(rank), int(n_ranks)
+
+    def broadcast_constants(self, plan, root=0):
+        _lib.check(_lib.load().zafx_comm_broadcast_constants(self.handle, plan.handle, int(root)), "zafx_comm_broadcast_constants")
+
+    def destroy(self):
+        if getattr(self, "handle", None) is not None and self.handle.value:
+            _lib.load().zafx_comm_destroy(self.handle)
+            self.handle = ctypes.c_void_p()
+
+
+# ======================================================================================
+# plan cache (thread safe): plans are keyed by geometry + a digest of their constants
+# ======================================================================================
+_cache = {}
+_cache_lock = threading.Lock()
+_CACHE_MAX = 32
+
+
+def _digest(*arrays):
+    import hashlib
+    h = hashlib.blake2b(digest_size=16)
+    for a in arrays:
+        a = np.ascontiguousarray(a)
+        h.update(str(a.dtype).encode())
+        h.update(str(a.shape).encode())
+        h.update(a.tobytes())
+    return h.hexdigest()
+
+
+def _cached(key, factory):
+    with _cache_lock:
+        plan = _cache.get(key)
+        if plan is None:
+            if len(_cache) >= _CACHE_MAX:
+                _cache.pop(next(iter(_cache))).destroy()
+            plan = factory()
+            _cache[key] = plan
+        return plan
+
+
+def clear_plan_cache():
+    with _cache_lock:
+        for plan in _cache.values():
+            plan.destroy()
+        _cache.clear()
+
+
+# ======================================================================================
+# argument checking shared by the drop-in and batched entry points
+# ======================================================================================
+def _as_window(window_function):
+    w = np.asarray(window_function, dtype=np.float64)
+    if w.ndim != 1:
+        raise ValueError("window_function must be 1-D")
+    n = len(w)
+    if n < 64 or n > 8192 or n & (n - 1):
+        raise ValueError(f"zafx kernels need a power-of-two window_length in [64, 8192], got {n}")
+    return w
+
+
+def _as_step(step_length):
+    if isinstance(step_length, (bool, np.bool_)) or not isinstance(step_length, (int, np.integer)):
+        raise ValueError("step_length must be an int (as in zaf.stft)")
+    if step_length < 1:
+        raise ValueError("step_length must be >= 1")
+    return int(step_length)
+
+
+def _as_clips(audio, ndim_name="audio_signal"):
+    a = np.asarray(audio)
+    if a.ndim != 2:
+        raise ValueError(f"{ndim_name} batch must be 2-D (clips, samples)")
+    if np.iscomplexobj(a):
+        raise ValueError(f"{ndim_name} must be real")
+    if a.shape[1] < 1:
+        raise ValueError(f"{ndim_name} must hold at least one sample")
+    return np.ascontiguousarray(a, dtype=np.float32)
+
+
+def _as_signal(audio_signal):
+    a = np.asarray(audio_signal)
+    if a.ndim != 1:
+        raise ValueError("audio_signal must be 1-D (one clip); use the *_batch functions for (clips, samples)")
+    return _as_clips(a[None, :])
+
+
+# ======================================================================================
+# plan factories
+# ======================================================================================
+def stft_plan(window_function, step_length, layout="FT", device=0):
+    w, h = _as_window(window_function), _as_step(step_length)
+    if h > len(w):
+        raise ValueError("step_length must not exceed window_length")
+    key = ("stft", device, len(w), h, _LAYOUTS[layout], _digest(w))
+
+    def make():
+        p = Plan(_lib.STFT, device, window_length=len(w), step_length=h, layout=layout)
+        p.set_window(w)
+        return p
+    return _cached(key, make)
+
+
+def istft_plan(window_function, step_length, layout="FT", device=0):
+    w, h = _as_window(window_function), _as_step(step_length)
+    if h > len(w):
+        raise ValueError("step_length must not exceed window_length")
+    key = ("istft", device, len(w), h, _LAYOUTS[layout], _digest(w))
+
+    def make():
+        p = Plan(_lib.ISTFT, device, window_length=len(w), step_length=h, layout=layout)
+        p.set_window(w)
+        return p
+    return _cached(key, make)
+
+
+def mdct_plan(window_function, layout="FT", device=0, inverse=False):
+    w = _as_window(window_function)
+    key = ("imdct" if inverse else "mdct", device, len(w), _LAYOUTS[layout], _digest(w))
+
+    def make():
+        p = Plan(_lib.IMDCT if inverse else _lib.MDCT, device, window_length=len(w), layout=layout)
+        p.set_window(w)
+        return p
+    return _cached(key, make)
+
+
+def _dense_filterbank(mel_filterbank, window_length):
+    if not hasattr(mel_filterbank, "toarray"):
+        raise ValueError("mel_filterbank must be a scipy.sparse matrix (as returned by melfilterbank)")
+    fb = np.asarray(mel_filterbank.toarray(), dtype=np.float64)
+    if fb.ndim != 2 or fb.shape[1] != window_length // 2:
+        raise ValueError("mel_filterbank must have window_length/2 columns")
+    return fb
+
+
+def mel_plan(window_function, step_length, mel_filterbank, number_coefficients=None, layout="FT", device=0):
+    w, h = _as_window(window_function), _as_step(step_length)
+    fb = _dense_filterbank(mel_filterbank, len(w))
+    mfcc = number_coefficients is not None
+    ncoef = int(number_coefficients) if mfcc else 0
+    if mfcc and not 1 <= ncoef <= fb.shape[0] - 1:
+        raise ValueError("number_coefficients must be in [1, number_filters - 1]")
+    key = ("mfcc" if mfcc else "mel", device, len(w), h, _LAYOUTS[layout], ncoef, _digest(w, fb))
+
+    def make():
+        p = Plan(_lib.MFCC if mfcc else _lib.MEL, device, window_length=len(w), step_length=h, layout=layout,
+                 n_filters=fb.shape[0], n_coefs=ncoef)
+        p.set_window(w)
+        p.set_mel_filterbank(fb)
+        if mfcc:
+            p.set_dct(constants.dct2_rows(fb.shape[0], ncoef))
+        return p
+    return _cached(key, make)
+
+
+def cqt_plan(sampling_frequency, time_resolution, cqt_kernel, octave_resolution=None, layout="FT", device=0):
+    if not hasattr(cqt_kernel, "tocsr"):
+        raise ValueError("cqt_kernel must be a scipy.sparse matrix (as returned by cqtkernel)")
+    n_bins, fft_length = cqt_kernel.shape
+    step = round(sampling_frequency / time_resolution)   # zaf.py:603 (banker's rounding)
+    if step < 1:
+        raise ValueError("time_resolution too high for this sampling_frequency")
+    if fft_length < 512 or fft_length > 32768 or fft_length & (fft_length - 1):
+        raise ValueError(f"zafx CQT kernels need a power-of-two fft_length in [512, 32768], got {fft_length}")
+    csr = cqt_kernel.tocsr()
+    chroma = octave_resolution is not None
+    key = ("chroma" if chroma else "cqt", device, fft_length, step, n_bins, int(octave_resolution or 0), _LAYOUTS[layout],
+           _digest(csr.indptr, csr.indices, csr.data))
+
+    def make():
+        p = Plan(_lib.CHROMA if chroma else _lib.CQT, device, step_length=step, layout=layout, fft_length=fft_length,
+                 n_bins=n_bins, octave_resolution=int(octave_resolution or 0))
+        p.set_cqt_kernel(csr)
+        return p
+    return _cached(key, make)
+
+
+# ======================================================================================
+# batched API (build-defined extension): (clips, samples) float32 in, float32/complex64 out
+# ======================================================================================
+def stft_batch(clips, window_function, step_length, layout="FT", device=0):
+    """(B, N) -> (B, W, T) complex64 [layout "FT"] or (B, T, W) ["TF"]."""
+    x = _as_clips(clips)
+    return stft_plan(window_function, step_length, layout, device).run_host(x, x.shape[1])
+
+
+def istft_batch(spectra, window_function, step_length, layout="FT", device=0):
+    """(B, W, T) ["FT"] or (B, T, W) ["TF"] complex -> (B, T*H - (W-H)) float32."""
+    s = np.ascontiguousarray(spectra, dtype=np.complex64)
+    w = _as_window(window_function)
+    if s.ndim != 3:
+        raise ValueError("spectra must be 3-D")
+    wl, nt = (s.shape[1], s.shape[2]) if _LAYOUTS[layout] == _lib.LAYOUT_FT else (s.shape[2], s.shape[1])
+    if wl != len(w):
+        raise ValueError("spectrum rows must equal window_length")
+    return istft_plan(w, step_length, layout, device).run_host(s, nt)
+
+
+def mdct_batch(clips, window_function, layout="FT", device=0):
+    """(B, N) -> (B, W/2, T) float32 ["FT"] or (B, T, W/2) ["TF"]."""
+    x = _as_clips(clips)
+    return mdct_plan(window_function, layout, device).run_host(x, x.shape[1])
+
+
+def imdct_batch(coefficients, window_function, layout="FT", device=0):
+    """(B, W/2, T) ["FT"] or (B, T, W/2) ["TF"] -> (B, (W/2)(T-1) - 1) float32."""
+    c = np.ascontiguousarray(coefficients, dtype=np.float32)
+    w = _as_window(window_function)
+    if c.ndim != 3:
+        raise ValueError("coefficients must be 3-D")
+    nf, nt = (c.shape[1], c.shape[2]) if _LAYOUTS[layout] == _lib.LAYOUT_FT else (c.shape[2], c.shape[1])
+    if 2 * nf != len(w):
+        raise ValueError("coefficient rows must equal window_length/2")
+    return mdct_plan(w, layout, device, inverse=True).run_host(c, nt)
+
+
+def melspectrogram_batch(clips, window_function, step_length, mel_filterbank, layout="FT", device=0):
+    """(B, N) -> (B, n_filters, T) float32."""
+    x = _as_clips(clips)
+    return mel_plan(window_function, step_length, mel_filterbank, None, layout, device).run_host(x, x.shape[1])
+
+
+def mfcc_batch(clips, window_function, step_length, mel_filterbank, number_coefficients, layout="FT", device=0):
+    """(B, N) -> (B, number_coefficients, T) float32."""
+    x = _as_clips(clips)
+    return mel_plan(window_function, step_length, mel_filterbank, number_coefficients, layout, device).run_host(x, x.shape[1])
+
+
+def cqtspectrogram_batch(clips, sampling_frequency, time_resolution, cqt_kernel, layout="FT", device=0):
+    """(B, N) -> (B, n_bins, T) float32."""
+    x = _as_clips(clips)
+    return cqt_plan(sampling_frequency, time_resolution, cqt_kernel, None, layout, device).run_host(x, x.shape[1])
+
+
+def cqtchromagram_batch(clips, sampling_frequency, time_resolution, octave_resolution, cqt_kernel, layout="FT", device=0):
+    """(B, N) -> (B, octave_resolution, T) float32."""
+    x = _as_clips(clips)
+    return cqt_plan(sampling_frequency, time_resolution, cqt_kernel, int(octave_resolution), layout, device).run_host(x, x.shape[1])
+
+
+# ======================================================================================
+# drop-in API: the zaf.* signatures (1 clip, float64 / complex128 results)
+# ======================================================================================
+def stft(audio_signal, window_function, step_length):
+    """Drop-in for zaf.stft (zaf.py:45): (N,) -> (W, T) complex128, two-sided."""
+    x = _as_signal(audio_signal)
+    return stft_batch(x, window_function, step_length)[0].astype(np.complex128)
+
+
+def istft(audio_stft, window_function, step_length):
+    """Drop-in for zaf.istft (zaf.py:144): (W, T) -> (T*H - (W-H),) float64."""
+    s = np.asarray(audio_stft)
+    if s.ndim != 2:
+        raise ValueError("audio_stft must be 2-D (window_length, number_times)")
+    return istft_batch(s[None], window_function, step_length)[0].astype(np.float64)
+
+
+def melspectrogram(audio_signal, window_function, step_length, mel_filterbank):
+    """Drop-in for zaf.melspectrogram (zaf.py:324): (N,) -> (n_filters, T) float64."""
+    x = _as_signal(audio_signal)
+    return melspectrogram_batch(x, window_function, step_length, mel_filterbank)[0].astype(np.float64)
+
+
+def mfcc(audio_signal, window_function, step_length, mel_filterbank, number_coefficients):
+    """Drop-in for zaf.mfcc (zaf.py:378): (N,) -> (number_coefficients, T) float64."""
+    x = _as_signal(audio_signal)
+    return mfcc_batch(x, window_function, step_length, mel_filterbank, number_coefficients)[0].astype(np.float64)
+
+
+def cqtspectrogram(audio_signal, sampling_frequency, time_resolution, cqt_kernel):
+    """Drop-in for zaf.cqtspectrogram (zaf.py:562): (N,) -> (n_bins, T) float64."""
+    x = _as_signal(audio_signal)
+    return cqtspectrogram_batch(x, sampling_frequency, time_resolution, cqt_kernel)[0].astype(np.float64)
+
+
+def cqtchromagram(audio_signal, sampling_frequency, time_resolution, octave_resolution, cqt_kernel):
+    """Drop-in for zaf.cqtchromagram (zaf.py:638): (N,) -> (octave_resolution, T) float64."""
+    x = _as_signal(audio_signal)
+    return cqtchromagram_batch(x, sampling_frequency, time_resolution, octave_resolution, cqt_kernel)[0].astype(np.float64)
+
+
+def mdct(audio_signal, window_function):
+    """Drop-in for zaf.mdct (zaf.py:984): (N,) -> (W/2, T) float64."""
+    x = _as_signal(audio_signal)
+    return mdct_batch(x, window_function)[0].astype(np.float64)
+
+
+def imdct(audio_mdct, window_function):
+    """Drop-in for zaf.imdct (zaf.py:1078): (W/2, T) -> ((W/2)(T-1) - 1,) float64."""
+    c = np.asarray(audio_mdct)
+    if c.ndim != 2:
+        raise ValueError("audio_mdct must be 2-D (number_frequencies, number_times)")
+    return imdct_batch(c[None], window_function)[0].astype(np.float64)

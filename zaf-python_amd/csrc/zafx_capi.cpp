@@ -221,7 +221,7 @@ int zafx_plan_create(zafx_plan** out, int device, int kind, const zafx_params* p
         const int n = pl->W / 2;
         aux.resize((size_t)n / 2 + 1);
         for (int k = 0; k <= n / 2; ++k) aux[(size_t)k] = unit_root(k, pl->W);
-        pl->kernel_name = kind == ZAFX_STFT ? stft_kernel_name() : kind == ZAFX_ISTFT ? istft_kernel_name() : mel_kernel_name();
+        pl->kernel_name = kind == ZAFX_STFT ? stft_kernel_name(lw - 1, pl->layout) : kind == ZAFX_ISTFT ? istft_kernel_name() : mel_kernel_name();
     } else if (is_mdct_family(kind)) {
         pl->W = params->window_length;
         pl->H = pl->W / 2;   // zaf.py:1029
@@ -252,6 +252,7 @@ int zafx_plan_create(zafx_plan** out, int device, int kind, const zafx_params* p
     pl->log2e = default_log2e(pl->log2nf);
 
     hipError_t e = hipSetDevice(device);
+    if (e == hipSuccess) e = hipDeviceGetAttribute(&pl->n_cus, hipDeviceAttributeMultiprocessorCount, device);
     if (e == hipSuccess) e = hipStreamCreateWithFlags(&pl->stream, hipStreamNonBlocking);
     if (e == hipSuccess) e = hipEventCreate(&pl->ev0);
     if (e == hipSuccess) e = hipEventCreate(&pl->ev1);

@@ -29,6 +29,7 @@ struct PackedBand {
 
 struct zafx_plan {
     int device = 0;
+    int n_cus = 256;   // compute units of the device (persistent-kernel grid size)
     int kind = 0;
     zafx_params prm{};
     hipStream_t stream = nullptr;
@@ -70,7 +71,7 @@ hipError_t launch_mel(const zafx_plan& pl, const float* x, float* out, int64_t n
 hipError_t launch_cqt(const zafx_plan& pl, const float* x, float* out, int64_t n_clips, int64_t n_samples, int T);
 
 // names of the dominant kernels (what rocprofv3 --kernel-trace prints, prefix match)
-const char* stft_kernel_name();
+const char* stft_kernel_name(int log2n, int layout);
 const char* istft_kernel_name();
 const char* mdct_kernel_name();
 const char* imdct_kernel_name();

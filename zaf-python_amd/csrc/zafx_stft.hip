@@ -14,6 +14,8 @@
 // the two-sided spectrum).  A workgroup owns FPB consecutive frames of one clip;
 // in the reference (frequency-major, time-minor) layout the FPB frames supply the
 // contiguous run along t for every stored row (16 frames x 8 B = one 128-B line).
+#include <algorithm>
+
 #include "zafx_fft.hpp"
 #include "zafx_internal.hpp"
 
@@ -126,6 +128,119 @@ __global__ __launch_bounds__(FPB * fft_threads(LOG2N, LOG2E)) void k_stft(
                 o[(long long)(N + k) * T] = cconj(xn);
             }
         }
+    }
+}
+
+// ---------------------------------------------------------------------------------
+// forward, reference (frequency-major) layout, persistent "fat wave" form
+// ---------------------------------------------------------------------------------
+// Measured on MI355X (profiles/r01_notes.md): with one 16-wave workgroup per CU the
+// load, FFT and store phases of a tile run back to back and every tile pays the table
+// staging again.  This kernel keeps the 16-frame tile (128-B runs along t) but
+//   * is persistent: one workgroup per CU loops over tiles, so window, pass twiddles and
+//     split roots are staged in LDS once;
+//   * uses 8 wavefronts that each transform 2 frames (up to 256 VGPRs per lane), so the
+//     NEXT tile's samples are prefetched into registers before the current tile's stores
+//     are issued -- the load latency hides under the store phase without spilling;
+//   * loads interior frames with unconditional 8-byte loads (no per-sample bounds
+//     branches); only the clip-edge frames take the predicated path;
+//   * pads the frame pitch to 2 (mod 32) complex slots: the transposed read of the store
+//     phase (16 frames x 2 bins per 32-lane group) is then LDS-bank-conflict free.
+constexpr int kFatWaves = 8;
+constexpr int kFatFrames = 16;
+
+template <int LOG2N, int LOG2E>
+struct FatCfg {
+    using C = FftCfg<LOG2N, LOG2E>;
+    static_assert(C::P == 64, "one wavefront per frame");
+    static constexpr int N = C::N;
+    static constexpr int PITCH = ((N + (N >> 4) + 31) / 32) * 32 + 2;   // = 2 (mod 32)
+    static constexpr int NT = kFatWaves * 64;
+    static constexpr int FPW = kFatFrames / kFatWaves;
+    static constexpr size_t SMEM = (size_t)(kFatFrames * PITCH + C::TW + N + N / 2 + 1) * 8;
+};
+
+template <int LOG2N, int LOG2E, bool ALIGNED>
+__global__ __launch_bounds__(kFatWaves * 64) void k_stft_ft16(
+    const float* __restrict__ x, const float* __restrict__ win, const float2* __restrict__ twp,
+    const float2* __restrict__ tws, float2* __restrict__ out, long long n_samples, int hop, int T, int tiles,
+    int total_tiles) {
+    using C = FftCfg<LOG2N, LOG2E>;
+    using F = FatCfg<LOG2N, LOG2E>;
+    constexpr int N = C::N, P = C::P, E = C::E, W = 2 * N, NT = F::NT, FPB = kFatFrames, FPW = F::FPW, PITCH = F::PITCH;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    float2* frames = reinterpret_cast<float2*>(smem_raw);
+    float2* tw_l = frames + FPB * PITCH;
+    float2* win_l = tw_l + C::TW;   // N float2 = W window samples
+    float2* tws_l = win_l + N;      // N/2 + 1 roots of W
+    const int tid = threadIdx.x;
+    for (int i = tid; i < C::TW; i += NT) tw_l[i] = twp[i];
+    for (int i = tid; i < N; i += NT) win_l[i] = reinterpret_cast<const float2*>(win)[i];
+    for (int i = tid; i <= N / 2; i += NT) tws_l[i] = tws[i];
+    __syncthreads();
+    const int wave = tid / P, p = tid % P;
+    const int tt = tid % FPB, kq = tid / FPB;
+    const float2* fb = frames + tt * PITCH;
+
+    float2 xr[FPW][E];
+    auto prefetch = [&](int tl) {
+        const int clip = tl / tiles, tile = tl % tiles;
+        const float* xc = x + (long long)clip * n_samples;
+#pragma unroll
+        for (int f = 0; f < FPW; ++f) {
+            const int t = tile * FPB + wave * FPW + f;
+            const long long s0 = (long long)t * hop - N;
+            const bool live = tl < total_tiles && t < T;
+            if (ALIGNED && live && s0 >= 0 && s0 + W <= n_samples) {   // interior frame: wave-uniform fast path
+#pragma unroll
+                for (int i = 0; i < E; ++i) xr[f][i] = *reinterpret_cast<const float2*>(xc + s0 + 2 * (p + i * P));
+            } else {
+#pragma unroll
+                for (int i = 0; i < E; ++i) {
+                    const long long s = s0 + 2 * (p + i * P);
+                    xr[f][i].x = (live && s >= 0 && s < n_samples) ? xc[s] : 0.f;
+                    xr[f][i].y = (live && s + 1 >= 0 && s + 1 < n_samples) ? xc[s + 1] : 0.f;
+                }
+            }
+        }
+    };
+    int tl = blockIdx.x;
+    prefetch(tl);
+    for (; tl < total_tiles; tl += gridDim.x) {
+        const int clip = tl / tiles, tile = tl % tiles;
+        const int t0 = tile * FPB;
+#pragma unroll
+        for (int f = 0; f < FPW; ++f) {
+            float2 v[E];
+#pragma unroll
+            for (int i = 0; i < E; ++i) {
+                const float2 wv = win_l[p + i * P];
+                v[i] = make_float2(xr[f][i].x * wv.x, xr[f][i].y * wv.y);
+            }
+            fft_frame<LOG2N, LOG2E>(v, frames + (wave * FPW + f) * PITCH, p, tw_l);
+        }
+        __syncthreads();
+        prefetch(tl + gridDim.x);   // in flight while this tile is stored
+        if (t0 + tt < T) {
+            float2* o = out + (long long)clip * W * T + (t0 + tt);
+            for (int k = kq; k < N / 2; k += NT / FPB) {
+                if (k == 0) {
+                    const float2 z0 = fb[0], zc = fb[phys(N / 2)];
+                    o[0] = make_float2(z0.x + z0.y, 0.f);
+                    o[(long long)N * T] = make_float2(z0.x - z0.y, 0.f);
+                    o[(long long)(N / 2) * T] = cconj(zc);
+                    o[(long long)(N + N / 2) * T] = zc;
+                } else {
+                    float2 xk, xn;
+                    split_pair(fb[phys(k)], fb[phys(N - k)], tws_l[k], xk, xn);
+                    o[(long long)k * T] = xk;
+                    o[(long long)(W - k) * T] = cconj(xk);
+                    o[(long long)(N - k) * T] = xn;
+                    o[(long long)(N + k) * T] = cconj(xn);
+                }
+            }
+        }
+        __syncthreads();
     }
 }
 
@@ -255,24 +370,55 @@ constexpr int stft_fpb(int log2n, int layout) {
     return r;
 }
 
-template <int LOG2N, int LAYOUT>
-static hipError_t run_stft(const zafx_plan& pl, const float* x, float2* out, int64_t n_clips, int64_t n_samples, int T) {
+constexpr bool stft_use_fat(int log2n, int layout) {
+    return layout == ZAFX_LAYOUT_FT && log2n >= 7 && log2n <= 10;   // one wavefront per frame
+}
+
+template <int LOG2N, bool ALIGNED>
+static hipError_t run_stft_fat(const zafx_plan& pl, const float* x, float2* out, int64_t n_clips, int64_t n_samples, int T) {
     constexpr int LOG2E = default_log2e(LOG2N);
-    constexpr int FPB = stft_fpb(LOG2N, LAYOUT);
-    using S = StftCfg<LOG2N, LOG2E, FPB>;
-    auto kern = k_stft<LOG2N, LOG2E, FPB, LAYOUT>;
+    using F = FatCfg<LOG2N, LOG2E>;
+    auto kern = k_stft_ft16<LOG2N, LOG2E, ALIGNED>;
     static bool attr_set[64] = {};
     if (!attr_set[pl.device]) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)S::SMEM);
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)F::SMEM);
         if (e != hipSuccess) return e;
         attr_set[pl.device] = true;
     }
-    const int tiles = (T + FPB - 1) / FPB;
-    const long long blocks = (long long)tiles * n_clips;
-    if (blocks <= 0) return hipSuccess;
-    hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(S::NT), S::SMEM, pl.stream, x, pl.d_window, pl.d_tw_pass, pl.d_tw_aux,
-                       out, (long long)n_samples, pl.H, T, tiles);
+    const int tiles = (T + kFatFrames - 1) / kFatFrames;
+    const long long total = (long long)tiles * n_clips;
+    if (total <= 0) return hipSuccess;
+    const int per_cu = (int)std::min<size_t>(2, (size_t)kMaxLdsBytes / F::SMEM);
+    const long long grid = std::min<long long>(total, (long long)pl.n_cus * std::max(per_cu, 1));
+    hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(F::NT), F::SMEM, pl.stream, x, pl.d_window, pl.d_tw_pass, pl.d_tw_aux, out,
+                       (long long)n_samples, pl.H, T, tiles, (int)total);
     return hipGetLastError();
+}
+
+template <int LOG2N, int LAYOUT>
+static hipError_t run_stft(const zafx_plan& pl, const float* x, float2* out, int64_t n_clips, int64_t n_samples, int T) {
+    if constexpr (stft_use_fat(LOG2N, LAYOUT)) {
+        const bool aligned = (n_samples % 2 == 0) && (pl.H % 2 == 0) && (reinterpret_cast<uintptr_t>(x) % 8 == 0);
+        return aligned ? run_stft_fat<LOG2N, true>(pl, x, out, n_clips, n_samples, T)
+                       : run_stft_fat<LOG2N, false>(pl, x, out, n_clips, n_samples, T);
+    } else {
+        constexpr int LOG2E = default_log2e(LOG2N);
+        constexpr int FPB = stft_fpb(LOG2N, LAYOUT);
+        using S = StftCfg<LOG2N, LOG2E, FPB>;
+        auto kern = k_stft<LOG2N, LOG2E, FPB, LAYOUT>;
+        static bool attr_set[64] = {};
+        if (!attr_set[pl.device]) {
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)S::SMEM);
+            if (e != hipSuccess) return e;
+            attr_set[pl.device] = true;
+        }
+        const int tiles = (T + FPB - 1) / FPB;
+        const long long blocks = (long long)tiles * n_clips;
+        if (blocks <= 0) return hipSuccess;
+        hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(S::NT), S::SMEM, pl.stream, x, pl.d_window, pl.d_tw_pass, pl.d_tw_aux,
+                           out, (long long)n_samples, pl.H, T, tiles);
+        return hipGetLastError();
+    }
 }
 
 template <int LOG2N, int LAYOUT>
@@ -307,7 +453,7 @@ static hipError_t run_istft(const zafx_plan& pl, const float2* spec, float* y, i
 
 bool stft_supported(int log2n) { return log2n >= 5 && log2n <= 12; }
 int stft_frames_per_block(int log2n, int layout) { return stft_fpb(log2n, layout); }
-const char* stft_kernel_name() { return "k_stft"; }
+const char* stft_kernel_name(int log2n, int layout) { return stft_use_fat(log2n, layout) ? "k_stft_ft16" : "k_stft"; }
 const char* istft_kernel_name() { return "k_istft"; }
 
 hipError_t launch_stft(const zafx_plan& pl, const float* x, float2* out, int64_t n_clips, int64_t n_samples, int T) {

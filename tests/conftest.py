@@ -39,3 +39,14 @@ def relerr(out, ref):
     if denom == 0:
         denom = 1.0
     return float(np.max(np.abs(out - ref)) / denom) if ref.size else 0.0
+
+
+@pytest.fixture(scope="session")
+def built_library():
+    """Path of libzafx.so; builds it with hipcc (cross-compile, no GPU needed) if absent."""
+    import subprocess
+    lib = os.path.join(ROOT, "zaf-python_amd", "zafx", "libzafx.so")
+    if not os.path.exists(lib):
+        subprocess.run(["make", "-C", os.path.join(ROOT, "zaf-python_amd", "csrc"), "-j", "8"], check=True,
+                       stdout=subprocess.DEVNULL)
+    return lib

@@ -1,0 +1,110 @@
+"""Host-side logic of the product (no GPU): constant builders against the golden vectors
+from the reference, argument validation, sharding arithmetic, the FFT core emulated on CPU."""
+import os
+import subprocess
+
+import numpy as np
+import pytest
+import scipy.fftpack
+import scipy.signal.windows as sw
+import scipy.sparse
+
+import zafx
+from conftest import ROOT, relerr
+
+
+def csr(g, tag):
+    return scipy.sparse.csr_matrix((g[f"{tag}_data"], g[f"{tag}_indices"], g[f"{tag}_indptr"]), shape=tuple(g[f"{tag}_shape"]))
+
+
+def test_melfilterbank_matches_reference(golden):
+    for tag, args in (("fb128", (44100, 2048, 128)), ("fb40", (44100, 2048, 40))):
+        ref = csr(golden["consts"], tag)
+        got = zafx.melfilterbank(*args)
+        assert scipy.sparse.issparse(got) and got.shape == ref.shape and got.nnz == ref.nnz
+        assert np.array_equal(got.toarray(), ref.toarray())
+    assert np.array_equal(zafx.melfilterbank(8000, 64, 8).toarray(), golden["tiny"]["fb_dense"])
+
+
+def test_cqtkernel_matches_reference(golden):
+    ref = csr(golden["consts"], "ck_small")
+    got = zafx.cqtkernel(4000, 12, 200, 1600)
+    assert got.shape == ref.shape and got.nnz == ref.nnz
+    assert relerr(got.toarray(), ref.toarray()) <= 1e-12
+
+
+@pytest.mark.timeout(120)
+def test_cqtkernel_config_matches_reference(golden):
+    ref = csr(golden["consts"], "ck")
+    got = zafx.cqtkernel(44100, 24, 55, 3520).tocsr()
+    got.sort_indices()
+    assert got.shape == (144, 32768) and got.nnz == 9450
+    assert np.array_equal(got.indices, ref.indices) and relerr(got.data, ref.data) <= 1e-12
+
+
+def test_dct_rows_match_scipy():
+    y = np.random.default_rng(0).standard_normal((128, 7))
+    ref = scipy.fftpack.dct(y, axis=0, norm="ortho")[1:21]
+    assert relerr(zafx.dct2_rows(128, 20) @ y, ref) <= 1e-12
+
+
+def test_windows():
+    assert np.allclose(zafx.hamming(2048), sw.hamming(2048, sym=False), atol=1e-15)
+    assert np.allclose(zafx.hamming(64, periodic=False), sw.hamming(64, sym=True), atol=1e-15)
+    assert np.allclose(zafx.kaiser_bessel_derived(2048), sw.kaiser_bessel_derived(2048, beta=5 * np.pi), atol=1e-14)
+    s = zafx.sine(64)
+    assert np.max(np.abs(s[:32] ** 2 + s[32:] ** 2 - 1)) < 1e-14
+
+
+def test_argument_validation_happens_before_the_device():
+    x = np.zeros(5000, np.float32)
+    ham = zafx.hamming(2048)
+    with pytest.raises(ValueError):
+        zafx.stft(np.zeros((2, 5000)), ham, 1024)
+    with pytest.raises(ValueError):
+        zafx.stft(x, ham, 1024.0)
+    with pytest.raises(ValueError):
+        zafx.stft(x, ham, 0)
+    with pytest.raises(ValueError):
+        zafx.stft(x, zafx.hamming(1000), 500)
+    with pytest.raises(ValueError):
+        zafx.stft(x, ham, 4096)
+    with pytest.raises(ValueError):
+        zafx.stft(x.astype(complex), ham, 1024)
+    with pytest.raises(ValueError):
+        zafx.istft(np.zeros(2048, complex), ham, 1024)
+    with pytest.raises(ValueError):
+        zafx.istft(np.zeros((1024, 4), complex), ham, 1024)
+    with pytest.raises(ValueError):
+        zafx.melspectrogram(x, ham, 1024, np.ones((4, 1024)))
+    with pytest.raises(ValueError):
+        zafx.mfcc(x, ham, 1024, zafx.melfilterbank(44100, 2048, 40), 40)
+    with pytest.raises(ValueError):
+        zafx.imdct(np.zeros((512, 4)), ham)
+    with pytest.raises(ValueError):
+        zafx.cqtspectrogram(x, 44100, 25, np.ones((4, 512)))
+
+
+def test_shard_partition():
+    for b in (0, 1, 7, 8, 1024, 8191, 8192):
+        for g in (1, 2, 3, 4, 8):
+            sizes = zafx.shard_sizes(b, g)
+            assert sum(sizes) == b and max(sizes) - min(sizes) <= 1
+            edges = [zafx.clip_range(b, r, g) for r in range(g)]
+            assert edges[0][0] == 0 and edges[-1][1] == b
+            assert all(edges[r][1] == edges[r + 1][0] for r in range(g - 1))
+    assert zafx.clip_range(8192, 3, 8) == (3072, 4096)   # BASELINE config 5: 1024 clips per GPU
+    with pytest.raises(ValueError):
+        zafx.clip_range(10, 2, 2)
+
+
+@pytest.mark.timeout(300)
+def test_fft_core_emulated_on_cpu(tmp_path):
+    """zafx_fft.hpp (pass schedule, padded LDS indexing, twiddle tables, register DFTs) compiled
+    for the host with threads emulated by loops, against a float64 DFT."""
+    exe = tmp_path / "fft_emu"
+    subprocess.run(["g++", "-O2", "-std=c++17", "-DZAFX_HOST_EMU", "-I", os.path.join(ROOT, "zaf-python_amd", "csrc"),
+                    os.path.join(ROOT, "tests", "host_emu", "fft_emu.cpp"), "-o", str(exe)], check=True)
+    out = subprocess.run([str(exe)], capture_output=True, text=True, check=True).stdout
+    worst = float(out.strip().splitlines()[-1].split("=")[1])
+    assert worst < 5e-7, out

@@ -114,6 +114,24 @@ static int finalize_constant(zafx_plan* pl, int which) {
             if (pl->H > 0)
                 for (int i = 0; i < pl->W; i += pl->H) g += (double)pl->h_window[(size_t)i];
             pl->cola_gain = (float)g;
+            if (is_mdct_family(pl->kind)) {
+                // sign-folded window for the fold + pack step of k_mdct_ft32: packed input m reads taps
+                // (a, b | c, d); re = x[a] w0 + x[b] w1, im = x[c] w2 + x[d] w3
+                const int nf = pl->W / 4;
+                std::vector<float> wf((size_t)nf * 4);
+                const float* w = pl->h_window.data();
+                for (int m = 0; m < nf; ++m) {
+                    float* o = &wf[(size_t)m * 4];
+                    if (2 * m < nf) {
+                        o[0] = -w[3 * nf - 1 - 2 * m]; o[1] = -w[3 * nf + 2 * m];
+                        o[2] = w[nf - 1 - 2 * m];      o[3] = -w[nf + 2 * m];
+                    } else {
+                        o[0] = w[2 * m - nf];          o[1] = -w[3 * nf - 1 - 2 * m];
+                        o[2] = -w[nf + 2 * m];         o[3] = -w[5 * nf - 1 - 2 * m];
+                    }
+                }
+                ZAFX_HIP(upload(&pl->d_wfold, wf.data(), wf.size() * sizeof(float)));
+            }
             return 0;
         }
         case ZAFX_CONST_MEL_FB:
@@ -231,7 +249,7 @@ int zafx_plan_create(zafx_plan** out, int device, int kind, const zafx_params* p
         const int nf = pl->W / 4, m = pl->W / 2;
         aux.resize((size_t)nf);
         for (int i = 0; i < nf; ++i) aux[(size_t)i] = unit_root(8LL * i + 1, 16LL * m);
-        pl->kernel_name = kind == ZAFX_MDCT ? mdct_kernel_name() : imdct_kernel_name();
+        pl->kernel_name = kind == ZAFX_MDCT ? mdct_kernel_name(lw - 2, pl->layout) : imdct_kernel_name();
     } else if (is_cqt_family(kind)) {
         pl->W = params->fft_length;
         pl->H = params->step_length;
@@ -275,6 +293,7 @@ int zafx_plan_destroy(zafx_plan* pl) {
     (void)hipSetDevice(pl->device);
     if (pl->stream) (void)hipStreamSynchronize(pl->stream);
     if (pl->d_window) (void)hipFree(pl->d_window);
+    if (pl->d_wfold) (void)hipFree(pl->d_wfold);
     if (pl->d_tw_pass) (void)hipFree(pl->d_tw_pass);
     if (pl->d_tw_aux) (void)hipFree(pl->d_tw_aux);
     if (pl->d_indptr) (void)hipFree(pl->d_indptr);

@@ -43,6 +43,7 @@ struct zafx_plan {
 
     // device constants
     float* d_window = nullptr;
+    float4* d_wfold = nullptr;     // MDCT: sign-folded window, 4 taps per packed input (zafx_mdct.hip)
     float2* d_tw_pass = nullptr;   // per-pass twiddles for fft_frame<log2nf, log2e>
     float2* d_tw_aux = nullptr;    // real-split roots (STFT family / CQT) or tw8 (MDCT family)
     float cola_gain = 0.f;         // sum(w[0:W:H])  (zaf.py:241)
@@ -73,7 +74,7 @@ hipError_t launch_cqt(const zafx_plan& pl, const float* x, float* out, int64_t n
 // names of the dominant kernels (what rocprofv3 --kernel-trace prints, prefix match)
 const char* stft_kernel_name(int log2n, int layout);
 const char* istft_kernel_name();
-const char* mdct_kernel_name();
+const char* mdct_kernel_name(int log2nf, int layout);
 const char* imdct_kernel_name();
 const char* mel_kernel_name();
 const char* cqt_kernel_name();

@@ -57,14 +57,15 @@ static hipError_t upload(T** dptr, const void* host, size_t bytes) {
 // v_mfma_f32_16x16x4_f32) and lay each 16x4 step out in the A-operand lane order
 // (lane l holds A[l & 15][l >> 4]).
 // ---------------------------------------------------------------------------------
-static hipError_t pack_band(PackedBand& pb, const float* dense, int n_rows, int n_cols) {
+static hipError_t pack_band(PackedBand& pb, const float* dense, int n_rows, int n_cols, int n_waves) {
     pb.n_rows = n_rows;
     pb.n_cols = n_cols;
     pb.n_blocks = (n_rows + 15) / 16;
-    std::vector<int> meta((size_t)pb.n_blocks * 4, 0);
+    pb.n_waves = n_waves;
+    struct Blk { int first, steps, off; };
+    std::vector<Blk> blks((size_t)pb.n_blocks);
     std::vector<float> pack;
     pb.total_steps = 0;
-    pb.max_steps = 0;
     for (int b = 0; b < pb.n_blocks; ++b) {
         int lo = n_cols, hi = -1;
         for (int r = 16 * b; r < std::min(16 * b + 16, n_rows); ++r)
@@ -78,26 +79,62 @@ static hipError_t pack_band(PackedBand& pb, const float* dense, int n_rows, int 
             first = lo & ~3;
             steps = (hi - first) / 4 + 1;
         }
-        meta[(size_t)b * 4 + 0] = first;
-        meta[(size_t)b * 4 + 1] = steps;
-        meta[(size_t)b * 4 + 2] = pb.total_steps;
+        blks[(size_t)b] = Blk{first, steps, pb.total_steps};
         for (int s = 0; s < steps; ++s)
             for (int l = 0; l < 64; ++l) {
                 const int r = 16 * b + (l & 15), c = first + 4 * s + (l >> 4);
                 pack.push_back((r < n_rows && c < n_cols) ? dense[(size_t)r * n_cols + c] : 0.f);
             }
         pb.total_steps += steps;
-        pb.max_steps = std::max(pb.max_steps, steps);
     }
+    // cut every block's band into parts of at most `cap` K-steps (slot ids are (block, part)-ordered)
+    const int cap = std::max(8, (pb.total_steps + n_waves - 1) / n_waves);
+    struct Item { int slot, first, steps, off; };
+    std::vector<Item> items;
+    std::vector<int> blk_ptr((size_t)pb.n_blocks + 1, 0);
+    for (int b = 0; b < pb.n_blocks; ++b) {
+        blk_ptr[(size_t)b] = (int)items.size();
+        const Blk& k = blks[(size_t)b];
+        const int parts = std::max(1, (k.steps + cap - 1) / cap);
+        for (int q = 0; q < parts; ++q) {
+            const int s0 = (int)((long long)k.steps * q / parts), s1 = (int)((long long)k.steps * (q + 1) / parts);
+            items.push_back(Item{(int)items.size(), k.first + 4 * s0, s1 - s0, k.off + s0});
+        }
+    }
+    blk_ptr[(size_t)pb.n_blocks] = (int)items.size();
+    pb.n_items = (int)items.size();
+    // deal the items to the wavefronts, longest first, always to the least loaded wave
+    std::vector<Item> order = items;
+    std::stable_sort(order.begin(), order.end(), [](const Item& a, const Item& b) { return a.steps > b.steps; });
+    std::vector<std::vector<Item>> per_wave((size_t)n_waves);
+    std::vector<int> load((size_t)n_waves, 0);
+    for (const Item& it : order) {
+        const int w = (int)(std::min_element(load.begin(), load.end()) - load.begin());
+        per_wave[(size_t)w].push_back(it);
+        load[(size_t)w] += it.steps + 2;
+    }
+    std::vector<int> flat, wave_ptr((size_t)n_waves + 1, 0);
+    for (int w = 0; w < n_waves; ++w) {
+        wave_ptr[(size_t)w] = (int)flat.size() / 4;
+        for (const Item& it : per_wave[(size_t)w]) {
+            flat.push_back(it.slot); flat.push_back(it.first); flat.push_back(it.steps); flat.push_back(it.off);
+        }
+    }
+    wave_ptr[(size_t)n_waves] = (int)flat.size() / 4;
     if (pack.empty()) pack.push_back(0.f);
+    if (flat.empty()) flat.assign(4, 0);
     hipError_t e = upload(&pb.d_pack, pack.data(), pack.size() * sizeof(float));
-    if (e != hipSuccess) return e;
-    return upload(&pb.d_meta, meta.data(), meta.size() * sizeof(int));
+    if (e == hipSuccess) e = upload(&pb.d_items, flat.data(), flat.size() * sizeof(int));
+    if (e == hipSuccess) e = upload(&pb.d_wave_ptr, wave_ptr.data(), wave_ptr.size() * sizeof(int));
+    if (e == hipSuccess) e = upload(&pb.d_blk_ptr, blk_ptr.data(), blk_ptr.size() * sizeof(int));
+    return e;
 }
 
 static void free_band(PackedBand& pb) {
     if (pb.d_pack) (void)hipFree(pb.d_pack);
-    if (pb.d_meta) (void)hipFree(pb.d_meta);
+    if (pb.d_items) (void)hipFree(pb.d_items);
+    if (pb.d_wave_ptr) (void)hipFree(pb.d_wave_ptr);
+    if (pb.d_blk_ptr) (void)hipFree(pb.d_blk_ptr);
     pb = PackedBand{};
 }
 
@@ -135,10 +172,10 @@ static int finalize_constant(zafx_plan* pl, int which) {
             return 0;
         }
         case ZAFX_CONST_MEL_FB:
-            ZAFX_HIP(pack_band(pl->fb, pl->h_fb.data(), pl->prm.n_filters, pl->W / 2));
+            ZAFX_HIP(pack_band(pl->fb, pl->h_fb.data(), pl->prm.n_filters, pl->W / 2, mel_waves(pl->log2nf)));
             return 0;
         case ZAFX_CONST_DCT:
-            ZAFX_HIP(pack_band(pl->dct, pl->h_dct.data(), pl->prm.n_coefs, pl->prm.n_filters));
+            ZAFX_HIP(pack_band(pl->dct, pl->h_dct.data(), pl->prm.n_coefs, pl->prm.n_filters, mel_waves(pl->log2nf)));
             return 0;
         case ZAFX_CONST_CQT_INDPTR:
             ZAFX_HIP(upload(&pl->d_indptr, pl->h_indptr.data(), pl->h_indptr.size() * sizeof(int32_t)));

@@ -14,15 +14,19 @@ namespace zafx {
 
 constexpr int kMaxLdsBytes = 160 * 1024;   // LDS per CU on gfx950
 
-// Banded, MFMA-fragment-packed filterbank (mel FB or DCT matrix): see zafx_mel.hip.
+// Banded, MFMA-fragment-packed matrix (mel filterbank or DCT-II rows) cut into balanced work
+// items: see zafx_mel.hip and pack_band in zafx_capi.cpp.
 struct PackedBand {
     int n_rows = 0;        // logical rows (filters / coefficients)
     int n_blocks = 0;      // ceil(n_rows / 16)
     int n_cols = 0;        // logical K extent
-    float* d_pack = nullptr;   // [total_steps][64] : lane l -> A[l & 15][4*step + (l >> 4)]
-    int* d_meta = nullptr;     // [n_blocks][4] : {first_col (multiple of 4), n_steps, step_offset, 0}
+    int n_items = 0;       // work items (a block's band cut into parts of bounded length)
+    int n_waves = 0;       // wavefronts the items were dealt to
     int total_steps = 0;
-    int max_steps = 0;
+    float* d_pack = nullptr;     // [total_steps][64] : lane l -> A[l & 15][4*step + (l >> 4)]
+    int4* d_items = nullptr;     // per wave, longest first: {slot id, first column, steps, offset into d_pack (steps)}
+    int* d_wave_ptr = nullptr;   // [n_waves + 1] ranges into d_items
+    int* d_blk_ptr = nullptr;    // [n_blocks + 1] ranges of slot ids belonging to a block
 };
 
 }  // namespace zafx
@@ -77,6 +81,7 @@ const char* istft_kernel_name();
 const char* mdct_kernel_name(int log2nf, int layout);
 const char* imdct_kernel_name();
 const char* mel_kernel_name();
+int mel_waves(int log2n);   // wavefronts per workgroup of k_mel for this FFT size
 const char* cqt_kernel_name();
 
 bool stft_supported(int log2n);   // log2 of complex FFT length = log2(W) - 1

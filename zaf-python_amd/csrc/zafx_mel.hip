@@ -1,16 +1,24 @@
 // zafx_mel.hip -- fused melspectrogram / MFCC kernel for gfx950 (MI355X).
 //
-// One workgroup = 16 consecutive frames of one clip.  The STFT never reaches HBM:
-//   framing + window + real FFT (as k_stft)            zaf.py:369 / :436  (stft)
-//   |X[k]| or |X[k]|^2 for k = 1..W/2, in place in LDS  zaf.py:370 / :437-439
-//   mel = FB . S           -- v_mfma_f32_16x16x4_f32    zaf.py:373 / :445  (np.matmul)
+// One persistent workgroup per CU; a tile = 16 consecutive frames of one clip.  The STFT
+// never reaches HBM:
+//   framing + window + real FFT (as k_stft)             zaf.py:369 / :436  (stft)
+//   |X[k]| or |X[k]|^2 for k = 1..W/2, in place in LDS   zaf.py:370 / :437-439
+//   mel = FB . S            -- v_mfma_f32_16x16x4_f32    zaf.py:373 / :445  (np.matmul)
 //   log(mel + eps), DCT-II rows 1..ncoef as a second MFMA GEMM   zaf.py:443-452
 //
-// The filterbank is banded (zaf.py:305-316: each row is one triangle), so only the
-// K-steps that hold non-zeros of a 16-row block are multiplied (pack_band in
-// zafx_capi.cpp).  A operand: packed FB fragment from global/L2 (one coalesced 256-B
-// load per MFMA); B operand: S[t][c] from LDS, frame pitch = 2 (mod 32) dwords so the
-// 16 frames x 4 columns of a fragment hit 64 distinct banks.
+// The filterbank is banded (zaf.py:305-316: each row is one triangle), so only the K-steps
+// that hold non-zeros of a 16-row block are multiplied.  The band of a block grows with
+// frequency (5 ... 97 K-steps for 128 filters at W = 2048), so the host cuts the blocks into
+// work items of bounded length and deals them to the wavefronts (longest first); an item
+// leaves its 16 x 16 partial tile in an LDS slot and a fixed-order reduction adds the parts
+// of a block -- balanced AND deterministic (no atomics).  A operand: packed FB fragment from
+// global/L2 (one coalesced 256-B load per MFMA); B operand: S[t][c] from LDS, frame pitch
+// = 2 (mod 32) dwords so the 16 frames x 4 columns of a fragment hit 64 distinct banks.
+// Slots (256 floats each) live in the upper halves of the frame buffers, which are dead
+// once the magnitudes have been written.
+#include <algorithm>
+
 #include "zafx_fft.hpp"
 #include "zafx_internal.hpp"
 
@@ -20,187 +28,243 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 constexpr int mel_threads(int log2n, int log2e) {
     const int p = fft_threads(log2n, log2e);
-    return ((1024 / p) < 16 ? (1024 / p) : 16) * p;
+    return ((512 / p) < 16 ? (512 / p) : 16) * p;   // 8 fat waves for N >= 128: up to 256 VGPRs, no spills in the persistent loop
 }
 
 template <int LOG2N, int LOG2E>
 struct MelCfg {
     using C = FftCfg<LOG2N, LOG2E>;
+    static constexpr int N = C::N;
     static constexpr int FPB = 16;   // MFMA N dimension
-    static constexpr int NSLOT = (1024 / C::P) < FPB ? (1024 / C::P) : FPB;   // frames transformed concurrently
+    static constexpr int NSLOT = (512 / C::P) < FPB ? (512 / C::P) : FPB;   // frames transformed concurrently
     static constexpr int NT = NSLOT * C::P;
-    static constexpr size_t SMEM_BASE = (size_t)(FPB * C::PITCH + C::TW) * 8;
+    // 256-float slots: in the dead upper half of every frame buffer when it is large enough,
+    // else in a separate region after the tables
+    static constexpr int UPPER = 2 * C::PITCH - N;           // free floats per frame buffer after S
+    static constexpr int SLOTS_PER_BUF = UPPER / 256;
+    static constexpr bool SLOTS_IN_FRAMES = SLOTS_PER_BUF >= 1;
+    static constexpr int EXTRA_SLOTS = SLOTS_IN_FRAMES ? 0 : 48;
+    static constexpr int CAPACITY = SLOTS_IN_FRAMES ? FPB * SLOTS_PER_BUF : EXTRA_SLOTS;
+    static constexpr size_t TABLES = (size_t)(C::TW + N + N / 2 + 1) * 8;     // pass twiddles, window, split roots
+    static constexpr size_t SMEM = (size_t)FPB * C::PITCH * 8 + TABLES + (size_t)EXTRA_SLOTS * 256 * 4;
 };
 
-template <int LOG2N, int LOG2E>
-__global__ __launch_bounds__(mel_threads(LOG2N, LOG2E)) void k_mel(
-    const float* __restrict__ x, const float* __restrict__ win, const float2* __restrict__ twp,
-    const float2* __restrict__ tws, const float* __restrict__ fb_pack, const int* __restrict__ fb_meta, int fb_blocks,
-    const float* __restrict__ dct_pack, const int* __restrict__ dct_meta, int dct_blocks, float* __restrict__ out,
-    long long n_samples, int hop, int T, int tiles, int n_filters, int n_coefs, int mfcc, int layout) {
-    using C = FftCfg<LOG2N, LOG2E>;
-    using G = MelCfg<LOG2N, LOG2E>;
-    constexpr int N = C::N, P = C::P, E = C::E, NT = G::NT, FPB = G::FPB, NSLOT = G::NSLOT;
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-    float2* frames = reinterpret_cast<float2*>(smem_raw);
-    float2* tw_l = frames + FPB * C::PITCH;
-    float* ltile = reinterpret_cast<float*>(tw_l + C::TW);   // [fb_blocks*16][16] log-mel (mfcc only)
-    const int tid = threadIdx.x;
-    for (int i = tid; i < C::TW; i += NT) tw_l[i] = twp[i];
-    __syncthreads();
-
-    const int slot = tid / P, p = tid % P;
-    const int clip = blockIdx.x / tiles, tile = blockIdx.x % tiles;
-    const int t0 = tile * FPB;
-    const float* xc = x + (long long)clip * n_samples;
-    const float2* w2 = reinterpret_cast<const float2*>(win);
-
-    // ---- STFT of the tile's frames, NSLOT at a time; spectrum -> magnitude/power in place
-#pragma unroll 1
-    for (int f0 = 0; f0 < FPB; f0 += NSLOT) {
-        const int fr = f0 + slot;
-        const int t = t0 + fr;
-        float2* buf = frames + fr * C::PITCH;
-        float2 v[E];
-        const long long s0 = (long long)t * hop - N;
-#pragma unroll
-        for (int i = 0; i < E; ++i) {
-            const int n = p + i * P;
-            const long long s = s0 + 2 * n;
-            const float2 wv = w2[n];
-            const float a = (t < T && s >= 0 && s < n_samples) ? xc[s] : 0.f;
-            const float b = (t < T && s + 1 >= 0 && s + 1 < n_samples) ? xc[s + 1] : 0.f;
-            v[i] = make_float2(a * wv.x, b * wv.y);
-        }
-        fft_frame<LOG2N, LOG2E>(v, buf, p, tw_l);
-        // real split of the (k, N-k) pairs this thread owns, kept in registers
-        float mk[E / 2], mn[E / 2];
-#pragma unroll
-        for (int i = 0; i < E / 2; ++i) {
-            const int k = p + i * P;
-            float2 xk, xn;
-            if (k == 0) {
-                const float2 z0 = buf[0], zc = buf[phys(N / 2)];
-                xk = zc;                                  // |X[N/2]| = |Z[N/2]|
-                xn = make_float2(z0.x - z0.y, 0.f);       // X[N] (Nyquist, kept: zaf.py:370)
-            } else {
-                const float2 zk = buf[phys(k)], zn = buf[phys(N - k)];
-                const float2 t_k = tws[k];
-                const float2 e = make_float2(0.5f * (zk.x + zn.x), 0.5f * (zk.y - zn.y));
-                const float2 d = make_float2(0.5f * (zk.x - zn.x), 0.5f * (zk.y + zn.y));
-                const float2 to = cmul(t_k, make_float2(d.y, -d.x));
-                xk = cadd(e, to);
-                xn = csub(e, to);
-            }
-            const float pk = xk.x * xk.x + xk.y * xk.y, pn = xn.x * xn.x + xn.y * xn.y;
-            mk[i] = mfcc ? pk : sqrtf(pk);
-            mn[i] = mfcc ? pn : sqrtf(pn);
-        }
-        frame_sync<P>();   // every Z read of this frame is done before S overwrites it
-        float* sf = reinterpret_cast<float*>(buf);   // S[c], c = bin - 1, c = 0..N-1
-#pragma unroll
-        for (int i = 0; i < E / 2; ++i) {
-            const int k = p + i * P;
-            if (k == 0) {
-                sf[N / 2 - 1] = mk[i];
-                sf[N - 1] = mn[i];
-            } else {
-                sf[k - 1] = mk[i];
-                sf[N - k - 1] = mn[i];
-            }
-        }
-    }
-    __syncthreads();
-
-    // ---- mel = FB . S on the matrix cores; 16 filters x 16 frames per accumulator
-    const int lane = tid & 63, wave = tid >> 6, nwaves = NT >> 6;
-    const float* sall = reinterpret_cast<const float*>(frames);
-    const int bt = lane & 15, bk = lane >> 4;
-    const float* sb = sall + (size_t)bt * (2 * C::PITCH) + bk;
-    const float eps = 2.220446049250313e-16f;   // np.finfo(float).eps (zaf.py:445)
-    for (int blk = wave; blk < fb_blocks; blk += nwaves) {
-        const int first = fb_meta[blk * 4 + 0], steps = fb_meta[blk * 4 + 1], off = fb_meta[blk * 4 + 2];
-        const float* ap = fb_pack + (size_t)off * 64 + lane;
-        const float* bp = sb + first;
+// One banded GEMM stage: every wave runs its items (16 rows x 16 frames x `steps` K-steps) and
+// leaves the partial tile in slot `slot0 + item`.
+template <class SlotFn, class BFn>
+__device__ __forceinline__ void gemm_items(const float* __restrict__ pack, const int4* __restrict__ items,
+                                           const int* __restrict__ wave_ptr, int wave, int lane, int slot0, SlotFn slot_ptr, BFn b_at) {
+    for (int it = wave_ptr[wave]; it < wave_ptr[wave + 1]; ++it) {
+        const int4 w = items[it];   // x = item id (slot), y = first column, z = steps, w = offset into pack (in steps)
+        const float* ap = pack + (size_t)w.w * 64 + lane;
         f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
         int s = 0;
-        for (; s + 1 < steps; s += 2) {   // two independent accumulators hide the 40-cycle MFMA latency
-            acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(ap[(size_t)s * 64], bp[4 * s], acc0, 0, 0, 0);
-            acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(ap[(size_t)(s + 1) * 64], bp[4 * s + 4], acc1, 0, 0, 0);
+        for (; s + 1 < w.z; s += 2) {   // two independent accumulators cover the 40-cycle dependent latency
+            acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(ap[(size_t)s * 64], b_at(w.y + 4 * s), acc0, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(ap[(size_t)(s + 1) * 64], b_at(w.y + 4 * s + 4), acc1, 0, 0, 0);
         }
-        if (s < steps) acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(ap[(size_t)s * 64], bp[4 * s], acc0, 0, 0, 0);
+        if (s < w.z) acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(ap[(size_t)s * 64], b_at(w.y + 4 * s), acc0, 0, 0, 0);
+        float* dst = slot_ptr(slot0 + w.x);
+        const int bt = lane & 15, bk = lane >> 4;
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const float val = acc0[r] + acc1[r];
-            const int m = 16 * blk + 4 * bk + r;
-            if (mfcc) {
-                ltile[m * 16 + bt] = m < n_filters ? logf(val + eps) : 0.f;
-            } else if (m < n_filters && t0 + bt < T) {
-                if (layout == ZAFX_LAYOUT_FT) out[((long long)clip * n_filters + m) * T + t0 + bt] = val;
-                else out[((long long)clip * T + t0 + bt) * n_filters + m] = val;
-            }
-        }
-    }
-    if (!mfcc) return;
-    __syncthreads();
-
-    // ---- MFCC: rows 1..ncoef of the orthonormal DCT-II over the mel axis, as a second MFMA GEMM
-    for (int blk = wave; blk < dct_blocks; blk += nwaves) {
-        const int first = dct_meta[blk * 4 + 0], steps = dct_meta[blk * 4 + 1], off = dct_meta[blk * 4 + 2];
-        const float* ap = dct_pack + (size_t)off * 64 + lane;
-        const float* bp = ltile + (size_t)(first + bk) * 16 + bt;
-        f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
-        int s = 0;
-        for (; s + 1 < steps; s += 2) {
-            acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(ap[(size_t)s * 64], bp[(size_t)s * 64], acc0, 0, 0, 0);
-            acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(ap[(size_t)(s + 1) * 64], bp[(size_t)(s + 1) * 64], acc1, 0, 0, 0);
-        }
-        if (s < steps) acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(ap[(size_t)s * 64], bp[(size_t)s * 64], acc0, 0, 0, 0);
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const int q = 16 * blk + 4 * bk + r;
-            if (q < n_coefs && t0 + bt < T) {
-                const float val = acc0[r] + acc1[r];
-                if (layout == ZAFX_LAYOUT_FT) out[((long long)clip * n_coefs + q) * T + t0 + bt] = val;
-                else out[((long long)clip * T + t0 + bt) * n_coefs + q] = val;
-            }
-        }
+        for (int r = 0; r < 4; ++r) dst[(4 * bk + r) * 16 + bt] = acc0[r] + acc1[r];
     }
 }
 
-template <int LOG2N>
+template <int LOG2N, int LOG2E, bool ALIGNED>
+__global__ __launch_bounds__(mel_threads(LOG2N, LOG2E)) void k_mel(
+    const float* __restrict__ x, const float* __restrict__ win, const float2* __restrict__ twp,
+    const float2* __restrict__ tws, const float* __restrict__ fb_pack, const int4* __restrict__ fb_items,
+    const int* __restrict__ fb_wave_ptr, const int* __restrict__ fb_blk_ptr, int fb_blocks, int fb_nitems,
+    const float* __restrict__ dct_pack, const int4* __restrict__ dct_items, const int* __restrict__ dct_wave_ptr,
+    const int* __restrict__ dct_blk_ptr, int dct_blocks, float* __restrict__ out, long long n_samples, int hop, int T,
+    int tiles, int total_tiles, int n_filters, int n_coefs, int mfcc, int layout) {
+    using C = FftCfg<LOG2N, LOG2E>;
+    using G = MelCfg<LOG2N, LOG2E>;
+    constexpr int N = C::N, P = C::P, E = C::E, W = 2 * N, NT = G::NT, FPB = G::FPB, NSLOT = G::NSLOT;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    float2* frames = reinterpret_cast<float2*>(smem_raw);
+    float2* tw_l = frames + FPB * C::PITCH;
+    float2* win_l = tw_l + C::TW;
+    float2* tws_l = win_l + N;
+    float* extra = reinterpret_cast<float*>(tws_l + N / 2 + 1);
+    float* fall = reinterpret_cast<float*>(frames);
+    const int tid = threadIdx.x;
+    for (int i = tid; i < C::TW; i += NT) tw_l[i] = twp[i];
+    for (int i = tid; i < N; i += NT) win_l[i] = reinterpret_cast<const float2*>(win)[i];
+    for (int i = tid; i <= N / 2; i += NT) tws_l[i] = tws[i];
+    __syncthreads();
+
+    auto slot_ptr = [&](int s) -> float* {
+        if constexpr (G::SLOTS_IN_FRAMES) return fall + (size_t)(s / G::SLOTS_PER_BUF) * (2 * C::PITCH) + N + (s % G::SLOTS_PER_BUF) * 256;
+        else return extra + (size_t)s * 256;
+    };
+
+    const int slot = tid / P, p = tid % P;
+    const int lane = tid & 63, wave = tid >> 6;
+    const int bt = lane & 15, bk = lane >> 4;
+    const float eps = 2.220446049250313e-16f;   // np.finfo(float).eps (zaf.py:445)
+    const int lt0 = fb_nitems;                  // first log-mel slot
+    const int dslot0 = fb_nitems + fb_blocks;   // first DCT partial slot
+
+    for (int tl = blockIdx.x; tl < total_tiles; tl += gridDim.x) {
+        const int clip = tl / tiles, tile = tl % tiles;
+        const int t0 = tile * FPB;
+        const float* xc = x + (long long)clip * n_samples;
+
+        // ---- STFT of the tile's frames, NSLOT at a time; spectrum -> magnitude/power in place
+#pragma unroll 1
+        for (int f0 = 0; f0 < FPB; f0 += NSLOT) {
+            const int fr = f0 + slot;
+            const int t = t0 + fr;
+            float2* buf = frames + fr * C::PITCH;
+            float2 v[E];
+            const long long s0 = (long long)t * hop - N;
+            if (ALIGNED && t < T && s0 >= 0 && s0 + W <= n_samples) {   // interior frame (uniform per frame)
+#pragma unroll
+                for (int i = 0; i < E; ++i) {
+                    const int n = p + i * P;
+                    const float2 xv = *reinterpret_cast<const float2*>(xc + s0 + 2 * n);
+                    const float2 wv = win_l[n];
+                    v[i] = make_float2(xv.x * wv.x, xv.y * wv.y);
+                }
+            } else {
+#pragma unroll
+                for (int i = 0; i < E; ++i) {
+                    const int n = p + i * P;
+                    const long long s = s0 + 2 * n;
+                    const float2 wv = win_l[n];
+                    const float a = (t < T && s >= 0 && s < n_samples) ? xc[s] : 0.f;
+                    const float b = (t < T && s + 1 >= 0 && s + 1 < n_samples) ? xc[s + 1] : 0.f;
+                    v[i] = make_float2(a * wv.x, b * wv.y);
+                }
+            }
+            fft_frame<LOG2N, LOG2E>(v, buf, p, tw_l);
+            // real split of the (k, N-k) pairs this thread owns, kept in registers
+            float mk[E / 2], mn[E / 2];
+#pragma unroll
+            for (int i = 0; i < E / 2; ++i) {
+                const int k = p + i * P;
+                float2 xk, xn;
+                if (k == 0) {
+                    const float2 z0 = buf[0], zc = buf[phys(N / 2)];
+                    xk = zc;                                  // |X[N/2]| = |Z[N/2]|
+                    xn = make_float2(z0.x - z0.y, 0.f);       // X[N] (Nyquist, kept: zaf.py:370)
+                } else {
+                    const float2 zk = buf[phys(k)], zn = buf[phys(N - k)];
+                    const float2 e = make_float2(0.5f * (zk.x + zn.x), 0.5f * (zk.y - zn.y));
+                    const float2 d = make_float2(0.5f * (zk.x - zn.x), 0.5f * (zk.y + zn.y));
+                    const float2 to = cmul(tws_l[k], make_float2(d.y, -d.x));
+                    xk = cadd(e, to);
+                    xn = csub(e, to);
+                }
+                const float pk = xk.x * xk.x + xk.y * xk.y, pn = xn.x * xn.x + xn.y * xn.y;
+                mk[i] = mfcc ? pk : sqrtf(pk);
+                mn[i] = mfcc ? pn : sqrtf(pn);
+            }
+            frame_sync<P>();   // every Z read of this frame is done before S overwrites it
+            float* sf = reinterpret_cast<float*>(buf);   // S[c], c = bin - 1, c = 0..N-1
+#pragma unroll
+            for (int i = 0; i < E / 2; ++i) {
+                const int k = p + i * P;
+                if (k == 0) {
+                    sf[N / 2 - 1] = mk[i];
+                    sf[N - 1] = mn[i];
+                } else {
+                    sf[k - 1] = mk[i];
+                    sf[N - k - 1] = mn[i];
+                }
+            }
+        }
+        __syncthreads();
+
+        // ---- mel = FB . S on the matrix cores
+        {
+            const float* sb = fall + (size_t)bt * (2 * C::PITCH) + bk;
+            gemm_items(fb_pack, fb_items, fb_wave_ptr, wave, lane, 0, slot_ptr, [&](int col) { return sb[col]; });
+        }
+        __syncthreads();
+        // ---- fixed-order reduction of the parts of every 16-filter block
+        for (int idx = tid; idx < fb_blocks * 256; idx += NT) {
+            const int blk = idx >> 8, e = idx & 255;
+            float val = 0.f;
+            for (int it = fb_blk_ptr[blk]; it < fb_blk_ptr[blk + 1]; ++it) val += slot_ptr(it)[e];
+            const int m = 16 * blk + (e >> 4), tq = e & 15;
+            if (mfcc) {
+                slot_ptr(lt0 + blk)[e] = m < n_filters ? logf(val + eps) : 0.f;
+            } else if (m < n_filters && t0 + tq < T) {
+                if (layout == ZAFX_LAYOUT_FT) out[((long long)clip * n_filters + m) * T + t0 + tq] = val;
+                else out[((long long)clip * T + t0 + tq) * n_filters + m] = val;
+            }
+        }
+        if (mfcc) {
+            __syncthreads();
+            // ---- rows 1..ncoef of the orthonormal DCT-II over the mel axis: second MFMA GEMM
+            gemm_items(dct_pack, dct_items, dct_wave_ptr, wave, lane, dslot0, slot_ptr,
+                       [&](int row) { return slot_ptr(lt0 + ((row + bk) >> 4))[((row + bk) & 15) * 16 + bt]; });
+            __syncthreads();
+            for (int idx = tid; idx < dct_blocks * 256; idx += NT) {
+                const int blk = idx >> 8, e = idx & 255;
+                float val = 0.f;
+                for (int it = dct_blk_ptr[blk]; it < dct_blk_ptr[blk + 1]; ++it) val += slot_ptr(dslot0 + it)[e];
+                const int q = 16 * blk + (e >> 4), tq = e & 15;
+                if (q < n_coefs && t0 + tq < T) {
+                    if (layout == ZAFX_LAYOUT_FT) out[((long long)clip * n_coefs + q) * T + t0 + tq] = val;
+                    else out[((long long)clip * T + t0 + tq) * n_coefs + q] = val;
+                }
+            }
+        }
+        __syncthreads();   // slots and S are dead: the next tile may overwrite the frame buffers
+    }
+}
+
+template <int LOG2N, bool ALIGNED>
 static hipError_t run_mel(const zafx_plan& pl, const float* x, float* out, int64_t n_clips, int64_t n_samples, int T) {
     constexpr int LOG2E = default_log2e(LOG2N);
     using G = MelCfg<LOG2N, LOG2E>;
-    auto kern = k_mel<LOG2N, LOG2E>;
+    auto kern = k_mel<LOG2N, LOG2E, ALIGNED>;
     const int mfcc = pl.kind == ZAFX_MFCC;
-    const size_t smem = G::SMEM_BASE + (mfcc ? (size_t)pl.fb.n_blocks * 16 * 16 * sizeof(float) : 0);
-    if (smem > (size_t)kMaxLdsBytes) {
-        set_error("mfcc: n_filters too large for the LDS log-mel tile at this window_length");
+    const int slots = pl.fb.n_items + (mfcc ? pl.fb.n_blocks + pl.dct.n_items : 0);
+    if (slots > G::CAPACITY) {
+        set_error("mel/mfcc: too many filterbank work items for the LDS slots at this window_length");
         return hipErrorInvalidValue;
     }
-    static size_t attr_set[64] = {};
-    if (attr_set[pl.device] < smem) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+    if (pl.fb.n_waves != G::NT / 64 || (mfcc && pl.dct.n_waves != G::NT / 64)) {
+        set_error("mel/mfcc: filterbank was packed for a different workgroup size");
+        return hipErrorInvalidValue;
+    }
+    static bool attr_set[64] = {};
+    if (!attr_set[pl.device]) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)G::SMEM);
         if (e != hipSuccess) return e;
-        attr_set[pl.device] = smem;
+        attr_set[pl.device] = true;
     }
     const int tiles = (T + G::FPB - 1) / G::FPB;
-    const long long blocks = (long long)tiles * n_clips;
-    if (blocks <= 0) return hipSuccess;
-    hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(G::NT), smem, pl.stream, x, pl.d_window, pl.d_tw_pass, pl.d_tw_aux, pl.fb.d_pack,
-                       pl.fb.d_meta, pl.fb.n_blocks, pl.dct.d_pack, pl.dct.d_meta, pl.dct.n_blocks, out, (long long)n_samples, pl.H, T, tiles,
+    const long long total = (long long)tiles * n_clips;
+    if (total <= 0) return hipSuccess;
+    const int per_cu = (int)std::min<size_t>(2, (size_t)kMaxLdsBytes / G::SMEM);
+    const long long grid = std::min<long long>(total, (long long)pl.n_cus * std::max(per_cu, 1));
+    hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(G::NT), G::SMEM, pl.stream, x, pl.d_window, pl.d_tw_pass, pl.d_tw_aux, pl.fb.d_pack,
+                       pl.fb.d_items, pl.fb.d_wave_ptr, pl.fb.d_blk_ptr, pl.fb.n_blocks, pl.fb.n_items, pl.dct.d_pack, pl.dct.d_items,
+                       pl.dct.d_wave_ptr, pl.dct.d_blk_ptr, pl.dct.n_blocks, out, (long long)n_samples, pl.H, T, tiles, (int)total,
                        pl.prm.n_filters, pl.prm.n_coefs, mfcc, pl.layout);
     return hipGetLastError();
 }
 
 const char* mel_kernel_name() { return "k_mel"; }
+int mel_waves(int log2n) { return mel_threads(log2n, default_log2e(log2n)) / 64; }
+
+template <int LOG2N>
+static hipError_t run_mel_any(const zafx_plan& pl, const float* x, float* out, int64_t n_clips, int64_t n_samples, int T) {
+    const bool aligned = (n_samples % 2 == 0) && (pl.H % 2 == 0) && (reinterpret_cast<uintptr_t>(x) % 8 == 0);
+    return aligned ? run_mel<LOG2N, true>(pl, x, out, n_clips, n_samples, T) : run_mel<LOG2N, false>(pl, x, out, n_clips, n_samples, T);
+}
 
 hipError_t launch_mel(const zafx_plan& pl, const float* x, float* out, int64_t n_clips, int64_t n_samples, int T) {
     switch (pl.log2nf) {
-        case 5: return run_mel<5>(pl, x, out, n_clips, n_samples, T);
-        case 9: return run_mel<9>(pl, x, out, n_clips, n_samples, T);
-        case 10: return run_mel<10>(pl, x, out, n_clips, n_samples, T);
+        case 5: return run_mel_any<5>(pl, x, out, n_clips, n_samples, T);
+        case 9: return run_mel_any<9>(pl, x, out, n_clips, n_samples, T);
+        case 10: return run_mel_any<10>(pl, x, out, n_clips, n_samples, T);
     }
     set_error("mel/mfcc: unsupported window_length");
     return hipErrorInvalidValue;

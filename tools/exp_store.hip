@@ -81,6 +81,27 @@ __global__ __launch_bounds__(NT) void k_rw_p(const float* __restrict__ x, float2
     }
 }
 
+
+// MODE 5: read-only FT tile pattern (ISTFT input): lanes along t, loop over rows, UNR loads in flight
+template <int RUN, int NT, int UNR>
+__global__ __launch_bounds__(NT) void k_tile_read(const float2* __restrict__ in, float* __restrict__ sink, int T, int tiles, int rows) {
+    const int clip = blockIdx.x / tiles, tile = blockIdx.x % tiles;
+    const int tt = threadIdx.x % RUN, kq = threadIdx.x / RUN;
+    const int t = tile * RUN + tt;
+    if (t >= T) return;
+    const float2* o = in + (long long)clip * rows * T + t;
+    float acc = 0.f;
+    constexpr int STEP = NT / RUN;
+    for (int k = kq; k < rows; k += STEP * UNR) {
+        float2 v[UNR];
+#pragma unroll
+        for (int u = 0; u < UNR; ++u) v[u] = o[(long long)(k + u * STEP) * T];
+#pragma unroll
+        for (int u = 0; u < UNR; ++u) acc += v[u].x + v[u].y;
+    }
+    if (acc == 12345.f) sink[0] = acc;
+}
+
 template <class F> void timeit(const char* name, double bytes, F launch) {
     hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
     launch(); launch(); CK(hipDeviceSynchronize());
@@ -113,6 +134,14 @@ int main() {
         timeit("read+write persistent 1024 thr x 512", rw, [&] { hipLaunchKernelGGL((k_rw_p<1024>), dim3(512), dim3(1024), 0, 0, x, out, ns, T, 27, rows, 27 * B); });
         timeit("read+write persistent 512 thr x 1024", rw, [&] { hipLaunchKernelGGL((k_rw_p<512>), dim3(1024), dim3(512), 0, 0, x, out, ns, T, 27, rows, 27 * B); });
         CK(hipFree(x));
+    }
+    {
+        float* sink; CK(hipMalloc(&sink, 64));
+        timeit("FT tile READ RUN=16 1024 thr unr 4", bytes, [&] { hipLaunchKernelGGL((k_tile_read<16, 1024, 4>), dim3(27 * B), dim3(1024), 0, 0, out, sink, T, 27, rows); });
+        timeit("FT tile READ RUN=16 1024 thr unr 16", bytes, [&] { hipLaunchKernelGGL((k_tile_read<16, 1024, 16>), dim3(27 * B), dim3(1024), 0, 0, out, sink, T, 27, rows); });
+        timeit("FT tile READ RUN=16 256 thr unr 16", bytes, [&] { hipLaunchKernelGGL((k_tile_read<16, 256, 16>), dim3(27 * B), dim3(256), 0, 0, out, sink, T, 27, rows); });
+        timeit("FT tile READ RUN=32 1024 thr unr 8", bytes, [&] { hipLaunchKernelGGL((k_tile_read<32, 1024, 8>), dim3(14 * B), dim3(1024), 0, 0, out, sink, T, 14, rows); });
+        timeit("FT tile READ RUN=8 1024 thr unr 8", bytes, [&] { hipLaunchKernelGGL((k_tile_read<8, 1024, 8>), dim3(54 * B), dim3(1024), 0, 0, out, sink, T, 54, rows); });
     }
     // padded T = 512 (4 KB row pitch): does the 3456-B pitch matter?
     {

@@ -276,7 +276,7 @@ int zafx_plan_create(zafx_plan** out, int device, int kind, const zafx_params* p
         const int n = pl->W / 2;
         aux.resize((size_t)n / 2 + 1);
         for (int k = 0; k <= n / 2; ++k) aux[(size_t)k] = unit_root(k, pl->W);
-        pl->kernel_name = kind == ZAFX_STFT ? stft_kernel_name(lw - 1, pl->layout) : kind == ZAFX_ISTFT ? istft_kernel_name() : mel_kernel_name();
+        pl->kernel_name = kind == ZAFX_STFT ? stft_kernel_name(lw - 1, pl->layout) : kind == ZAFX_ISTFT ? istft_kernel_name(lw - 1, pl->layout) : mel_kernel_name();
     } else if (is_mdct_family(kind)) {
         pl->W = params->window_length;
         pl->H = pl->W / 2;   // zaf.py:1029
@@ -312,7 +312,7 @@ int zafx_plan_create(zafx_plan** out, int device, int kind, const zafx_params* p
     if (e == hipSuccess) e = hipEventCreate(&pl->ev0);
     if (e == hipSuccess) e = hipEventCreate(&pl->ev1);
     if (e == hipSuccess) {
-        auto tw = build_pass_twiddles(pl->log2nf, pl->log2e);
+        auto tw = is_cqt_family(kind) ? build_two_level_twiddles(pl->log2nf) : build_pass_twiddles(pl->log2nf, pl->log2e);
         if (tw.empty()) tw.push_back(cf32{1.f, 0.f});
         e = upload(&pl->d_tw_pass, tw.data(), tw.size() * sizeof(cf32));
     }

@@ -30,8 +30,14 @@ __global__ __launch_bounds__(fft_threads(LOG2N, LOG2E)) void k_cqt(
     static_assert(P >= 64, "CQT frames are owned by whole wavefronts");
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     float2* buf = reinterpret_cast<float2*>(smem_raw);            // PITCH slots; slot PITCH-1 holds X[N]
-    float* tile = reinterpret_cast<float*>(buf + C::PITCH);       // [n_bins][FW]
+    constexpr int NHI = LOG2N > 7 ? 1 << (LOG2N - 7) : 1;
+    float2* tw_hi = buf + C::PITCH;                               // two-level root table (zafx_fft.hpp)
+    float2* tw_lo = tw_hi + NHI;
+    float* tile = reinterpret_cast<float*>(tw_lo + 128);          // [n_bins][FW]
     const int p = threadIdx.x;
+    for (int i = p; i < NHI + 128; i += P) tw_hi[i] = twp[i];
+    __syncthreads();
+    const TwoLevelTw tw2l{tw_hi, tw_lo};
     const int lane = p & 63, wave = p >> 6, nwaves = P >> 6;
     const int clip = blockIdx.x / tiles, tl = blockIdx.x % tiles;
     const int t0 = tl * FW;
@@ -51,7 +57,7 @@ __global__ __launch_bounds__(fft_threads(LOG2N, LOG2E)) void k_cqt(
             const float b = (s + 1 >= 0 && s + 1 < n_samples) ? xc[s + 1] : 0.f;
             v[i] = make_float2(a, b);
         }
-        fft_frame<LOG2N, LOG2E>(v, buf, p, twp);
+        fft_frame_chain<LOG2N, LOG2E>(v, buf, p, tw2l);
         // ---- real split in place: slots 0..N-1 <- X[0..N-1], slot PITCH-1 <- X[N]
 #pragma unroll
         for (int i = 0; i < E / 2; ++i) {
@@ -122,7 +128,7 @@ static hipError_t run_cqt(const zafx_plan& pl, const float* x, float* out, int64
     constexpr int LOG2E = default_log2e(LOG2N);
     using C = FftCfg<LOG2N, LOG2E>;
     auto kern = k_cqt<LOG2N, LOG2E>;
-    const size_t smem = (size_t)C::PITCH * 8 + (size_t)pl.prm.n_bins * kCqtFramesPerBlock * sizeof(float);
+    const size_t smem = (size_t)(C::PITCH + (LOG2N > 7 ? (1 << (LOG2N - 7)) : 1) + 128) * 8 + (size_t)pl.prm.n_bins * kCqtFramesPerBlock * sizeof(float);
     if (smem > (size_t)kMaxLdsBytes) {
         set_error("cqt: n_bins too large for the LDS output tile at this fft_length");
         return hipErrorInvalidValue;

@@ -184,6 +184,43 @@ ZAFX_HD void pass_write(const float2* v, float2* buf, int p, const float2* tw) {
     }
 }
 
+// ---------------------------------------------------------------- chained-twiddle pass
+// For frames whose per-pass tables do not fit LDS (CQT: 16384 points -> 131 KB) the base
+// twiddle w = exp(-2 pi i k / (Ns R)) comes from a two-level table (root(idx) = hi[idx >> 7] *
+// lo[idx & 127], 2 KB for N = 16384) and w^2 .. w^(R-1) from a product tree of depth <= 4
+// (a few ulp; the CQT tolerance is 1e-4).  No global-memory twiddle traffic, few live registers.
+struct TwoLevelTw {
+    const float2* hi;   // hi[j] = exp(-2 pi i (j << 7) / N)
+    const float2* lo;   // lo[j] = exp(-2 pi i j / N), j < 128
+};
+ZAFX_HD float2 tw2(const TwoLevelTw& t, int idx) { return cmul(t.hi[idx >> 7], t.lo[idx & 127]); }
+
+template <int LOG2N, int LOG2E, int LOG2NS, int LR>
+ZAFX_HD void pass_write_chain(const float2* v, float2* buf, int p, const TwoLevelTw& t) {
+    using C = FftCfg<LOG2N, LOG2E>;
+    constexpr int R = 1 << LR, NS = 1 << LOG2NS, NB = C::E / R;
+#pragma unroll
+    for (int b = 0; b < NB; ++b) {
+        const int j = p + b * C::P;
+        const int k = j & (NS - 1);
+        float2 a[R];
+#pragma unroll
+        for (int r = 0; r < R; ++r) a[r] = v[b + r * NB];
+        if (LOG2NS > 0) {
+            float2 w[R];
+            w[1] = tw2(t, k << (LOG2N - LOG2NS - LR));
+#pragma unroll
+            for (int r = 2; r < R; ++r) w[r] = cmul(w[r >> 1], w[r - (r >> 1)]);   // w^r = w^(r/2) * w^(r - r/2)
+#pragma unroll
+            for (int r = 1; r < R; ++r) a[r] = cmul(a[r], w[r]);
+        }
+        Dft<R>::run(a);
+        const int base = ((j >> LOG2NS) << (LOG2NS + LR)) + k;
+#pragma unroll
+        for (int r = 0; r < R; ++r) buf[phys(base + r * NS)] = a[r];
+    }
+}
+
 template <int LOG2N, int LOG2E>
 ZAFX_HD void regs_read(float2* v, const float2* buf, int p) {
     using C = FftCfg<LOG2N, LOG2E>;
@@ -227,6 +264,22 @@ __device__ __forceinline__ void fft_frame(float2* v, float2* buf, int p, const f
             regs_read<LOG2N, LOG2E>(v, buf, p);
             frame_sync<C::P>();
             fft_frame<LOG2N, LOG2E, LOG2NS + LR>(v, buf, p, tw);
+        }
+    }
+}
+
+// fft_frame with chained twiddles (see pass_write_chain)
+template <int LOG2N, int LOG2E, int LOG2NS = 0>
+__device__ __forceinline__ void fft_frame_chain(float2* v, float2* buf, int p, const TwoLevelTw& t) {
+    using C = FftCfg<LOG2N, LOG2E>;
+    if constexpr (LOG2NS < LOG2N) {
+        constexpr int LR = pass_log2r(LOG2N - LOG2NS, LOG2E);
+        pass_write_chain<LOG2N, LOG2E, LOG2NS, LR>(v, buf, p, t);
+        frame_sync<C::P>();
+        if constexpr (LOG2NS + LR < LOG2N) {
+            regs_read<LOG2N, LOG2E>(v, buf, p);
+            frame_sync<C::P>();
+            fft_frame_chain<LOG2N, LOG2E, LOG2NS + LR>(v, buf, p, t);
         }
     }
 }

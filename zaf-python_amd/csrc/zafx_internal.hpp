@@ -77,7 +77,7 @@ hipError_t launch_cqt(const zafx_plan& pl, const float* x, float* out, int64_t n
 
 // names of the dominant kernels (what rocprofv3 --kernel-trace prints, prefix match)
 const char* stft_kernel_name(int log2n, int layout);
-const char* istft_kernel_name();
+const char* istft_kernel_name(int log2n, int layout);
 const char* mdct_kernel_name(int log2nf, int layout);
 const char* imdct_kernel_name();
 const char* mel_kernel_name();

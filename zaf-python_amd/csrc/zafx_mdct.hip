@@ -125,16 +125,16 @@ struct MdctPCfg {
     using C = FftCfg<LOG2NF, LOG2E>;
     static_assert(C::P == 64, "one wavefront per frame");
     static constexpr int NF = C::N;
-    static constexpr int NSLOT = 16;
+    static constexpr int NSLOT = 8;   // 8 fat waves (up to 256 VGPRs): the persistent loop does not spill
     static constexpr size_t SMEM = (size_t)(kMdctTile * C::PITCH + C::TW + NF) * 8 + (size_t)NF * 16;
 };
 
 template <int LOG2NF, int LOG2E>
-__global__ __launch_bounds__(1024) void k_mdct_ft32(
+__global__ __launch_bounds__(512) void k_mdct_ft32(
     const float* __restrict__ x, const float4* __restrict__ wfold, const float2* __restrict__ twp,
     const float2* __restrict__ tw8, float* __restrict__ out, long long n_samples, int T, int tiles, int total_tiles) {
     using C = FftCfg<LOG2NF, LOG2E>;
-    constexpr int NF = C::N, M = 2 * NF, W = 4 * NF, P = C::P, E = C::E, FPB = kMdctTile, NSLOT = 16, NT = NSLOT * P;
+    constexpr int NF = C::N, M = 2 * NF, W = 4 * NF, P = C::P, E = C::E, FPB = kMdctTile, NSLOT = 8, NT = NSLOT * P;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     float2* frames = reinterpret_cast<float2*>(smem_raw);
     float2* tw_l = frames + FPB * C::PITCH;
@@ -339,7 +339,7 @@ static hipError_t run_mdct_p(const zafx_plan& pl, const float* x, float* out, in
     if (total <= 0) return hipSuccess;
     const int per_cu = (int)std::min<size_t>(2, (size_t)kMaxLdsBytes / G::SMEM);
     const long long grid = std::min<long long>(total, (long long)pl.n_cus * std::max(per_cu, 1));
-    hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(1024), G::SMEM, pl.stream, x, pl.d_wfold, pl.d_tw_pass, pl.d_tw_aux, out,
+    hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(G::NSLOT * 64), G::SMEM, pl.stream, x, pl.d_wfold, pl.d_tw_pass, pl.d_tw_aux, out,
                        (long long)n_samples, T, tiles, (int)total);
     return hipGetLastError();
 }

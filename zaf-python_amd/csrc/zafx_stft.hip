@@ -353,6 +353,97 @@ __global__ __launch_bounds__(FPB * fft_threads(LOG2N, LOG2E)) void k_istft(
 }
 
 // ---------------------------------------------------------------------------------
+// inverse, reference (frequency-major) layout, persistent "fat wave" form
+// ---------------------------------------------------------------------------------
+// Same structure as k_stft_ft16: one persistent 8-wave workgroup per CU, tables in LDS once,
+// 16-frame tiles (the gathered rows are 128-B runs along t), two frames per wave.  (Prefetching
+// the next tile's 64 x 8 B per lane into registers was tried and spilled: 7.4 ms vs 3.4 ms.)
+template <int LOG2N, int LOG2E, int WAVES>
+__global__ __launch_bounds__(WAVES * 64) void k_istft_ft16(
+    const float2* __restrict__ spec, const float2* __restrict__ twp, const float2* __restrict__ tws,
+    float* __restrict__ y, int T, int hop, long long out_len, float scale, int tiles, int total_tiles, int owned, int halo) {
+    using C = FftCfg<LOG2N, LOG2E>;
+    using F = FatCfg<LOG2N, LOG2E>;
+    constexpr int N = C::N, P = C::P, E = C::E, W = 2 * N, NT = WAVES * 64, FPB = kFatFrames, FPW = FPB / WAVES, PITCH = F::PITCH;
+    constexpr int KSTEP = NT / FPB;            // bins handled per sweep
+    constexpr int KI = (N / 2) / KSTEP;        // sweeps per thread
+    static_assert((N / 2) % KSTEP == 0, "pair sweep must divide N/2");
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    float2* frames = reinterpret_cast<float2*>(smem_raw);
+    float2* tw_l = frames + FPB * PITCH;
+    float2* tws_l = tw_l + C::TW;   // N/2 + 1 roots of W
+    const int tid = threadIdx.x;
+    for (int i = tid; i < C::TW; i += NT) tw_l[i] = twp[i];
+    for (int i = tid; i <= N / 2; i += NT) tws_l[i] = tws[i];
+    __syncthreads();
+    const int wave = tid / P, p = tid % P;
+    const int fs = tid % FPB, kq = tid / FPB;
+    float2* fbuf = frames + fs * PITCH;
+
+    for (int tl = blockIdx.x; tl < total_tiles; tl += gridDim.x) {
+        const int clip = tl / tiles, tile = tl % tiles;
+        const int t_first = tile * owned - halo;
+        // ---- phase A: gather the four two-sided bins of every pair of my frame, packed spectrum -> LDS
+        {
+            const int t = t_first + fs;
+            if (t >= 0 && t < T) {
+                const float2* sp = spec + (long long)clip * W * T + t;
+#pragma unroll 4
+                for (int i = 0; i < KI; ++i) {
+                    const int k = kq + i * KSTEP;
+                    if (k == 0) {
+                        const float a0 = 2.f * sp[0].x, an = 2.f * sp[(long long)N * T].x;
+                        fbuf[0] = make_float2(a0 - an, a0 + an);
+                        const float2 xc = sp[(long long)(N / 2) * T], xd = sp[(long long)(N + N / 2) * T];
+                        const float2 a = make_float2(xc.x + xd.x, xc.y - xd.y);
+                        fbuf[phys(N / 2)] = make_float2(-2.f * a.y, 2.f * a.x);
+                    } else {
+                        float2 zk, zn;
+                        unsplit_pair(sp[(long long)k * T], sp[(long long)(W - k) * T], sp[(long long)(N - k) * T],
+                                     sp[(long long)(N + k) * T], tws_l[k], zk, zn);
+                        fbuf[phys(k)] = zk;
+                        fbuf[phys(N - k)] = zn;
+                    }
+                }
+            }
+        }
+        __syncthreads();
+        // ---- phase B: forward FFT of the swapped spectrum == swapped inverse FFT
+#pragma unroll 1
+        for (int f = 0; f < FPW; ++f) {
+            float2* buf = frames + (wave * FPW + f) * PITCH;
+            float2 v[E];
+            regs_read<LOG2N, LOG2E>(v, buf, p);
+            frame_sync<P>();
+            fft_frame<LOG2N, LOG2E>(v, buf, p, tw_l);
+        }
+        __syncthreads();
+        // ---- phase C: gather overlap-add (ascending frames), trim, COLA gain
+        {
+            const float* fl = reinterpret_cast<const float*>(frames);
+            const int t_end = min((tile + 1) * owned, T);
+            const long long s_begin = (long long)tile * owned * hop;
+            const long long s_end = (tile == tiles - 1) ? (long long)T * hop + (W - hop) : (long long)t_end * hop;
+            float* yc = y + (long long)clip * out_len;
+            for (long long s = s_begin + tid; s < s_end; s += NT) {
+                const long long o = s - (W - hop);
+                if (o < 0 || o >= out_len) continue;
+                const int j_hi = (int)min((long long)(T - 1), s / hop);
+                const int j_lo = s >= W ? (int)((s - W) / hop) + 1 : 0;
+                float acc = 0.f;
+                for (int j = j_lo; j <= j_hi; ++j) {
+                    const int n = (int)(s - (long long)j * hop);
+                    const int f = (2 * phys(n >> 1) + (n & 1)) ^ 1;
+                    acc += fl[(size_t)(j - t_first) * (2 * PITCH) + f];
+                }
+                yc[o] = acc * scale;
+            }
+        }
+        __syncthreads();
+    }
+}
+
+// ---------------------------------------------------------------------------------
 // launch plumbing
 // ---------------------------------------------------------------------------------
 constexpr int stft_fpb(int log2n, int layout) {
@@ -421,8 +512,39 @@ static hipError_t run_stft(const zafx_plan& pl, const float* x, float2* out, int
     }
 }
 
+template <int LOG2N>
+static hipError_t run_istft_fat(const zafx_plan& pl, const float2* spec, float* y, int64_t n_clips, int T, int64_t out_len) {
+    constexpr int LOG2E = default_log2e(LOG2N);
+    using F = FatCfg<LOG2N, LOG2E>;
+    constexpr int WAVES = 16;
+    auto kern = k_istft_ft16<LOG2N, LOG2E, WAVES>;
+    static bool attr_set[64] = {};
+    if (!attr_set[pl.device]) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)F::SMEM);
+        if (e != hipSuccess) return e;
+        attr_set[pl.device] = true;
+    }
+    const int W = 2 << LOG2N;
+    const int halo = (W + pl.H - 1) / pl.H - 1;
+    const int owned = kFatFrames - halo;
+    if (owned < 1) {
+        set_error("istft: step_length too small for this window_length (ceil(W/H) exceeds frames per workgroup)");
+        return hipErrorInvalidValue;
+    }
+    const int tiles = (T + owned - 1) / owned;
+    const long long total = (long long)tiles * n_clips;
+    if (total <= 0 || out_len <= 0) return hipSuccess;
+    const float scale = 1.f / (4.f * (float)(1 << LOG2N) * pl.cola_gain);
+    const int per_cu = (int)std::min<size_t>(2, (size_t)kMaxLdsBytes / F::SMEM);
+    const long long grid = std::min<long long>(total, (long long)pl.n_cus * std::max(per_cu, 1));
+    hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(WAVES * 64), F::SMEM, pl.stream, spec, pl.d_tw_pass, pl.d_tw_aux, y, T, pl.H,
+                       (long long)out_len, scale, tiles, (int)total, owned, halo);
+    return hipGetLastError();
+}
+
 template <int LOG2N, int LAYOUT>
 static hipError_t run_istft(const zafx_plan& pl, const float2* spec, float* y, int64_t n_clips, int T, int64_t out_len) {
+    if constexpr (stft_use_fat(LOG2N, LAYOUT)) return run_istft_fat<LOG2N>(pl, spec, y, n_clips, T, out_len);
     constexpr int LOG2E = default_log2e(LOG2N);
     constexpr int FPB = stft_fpb(LOG2N, ZAFX_LAYOUT_FT);
     using S = StftCfg<LOG2N, LOG2E, FPB>;
@@ -454,7 +576,7 @@ static hipError_t run_istft(const zafx_plan& pl, const float2* spec, float* y, i
 bool stft_supported(int log2n) { return log2n >= 5 && log2n <= 12; }
 int stft_frames_per_block(int log2n, int layout) { return stft_fpb(log2n, layout); }
 const char* stft_kernel_name(int log2n, int layout) { return stft_use_fat(log2n, layout) ? "k_stft_ft16" : "k_stft"; }
-const char* istft_kernel_name() { return "k_istft"; }
+const char* istft_kernel_name(int log2n, int layout) { return stft_use_fat(log2n, layout) ? "k_istft_ft16" : "k_istft"; }
 
 hipError_t launch_stft(const zafx_plan& pl, const float* x, float2* out, int64_t n_clips, int64_t n_samples, int T) {
     switch (pl.log2nf) {

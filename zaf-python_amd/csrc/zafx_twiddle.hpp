@@ -43,4 +43,15 @@ inline std::vector<cf32> build_pass_twiddles(int log2n, int log2e) {
     return t;
 }
 
+// Two-level root table for fft_frame_chain: [hi: max(N/128, 1) entries | lo: 128 entries].
+inline int two_level_hi_count(int log2n) { return log2n > 7 ? 1 << (log2n - 7) : 1; }
+inline std::vector<cf32> build_two_level_twiddles(int log2n) {
+    const long long n = 1LL << log2n;
+    const int nh = two_level_hi_count(log2n);
+    std::vector<cf32> t((size_t)nh + 128);
+    for (int j = 0; j < nh; ++j) t[(size_t)j] = unit_root((long long)j << 7, n);
+    for (int j = 0; j < 128; ++j) t[(size_t)nh + j] = unit_root(j, n);
+    return t;
+}
+
 }  // namespace zafx

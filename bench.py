@@ -142,11 +142,18 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
+    # Libraries (RCCL banners, HIP warnings) write to C-level stdout; the contract is ONE JSON line
+    # there, so keep the real stdout aside and send everything else to stderr.
+    sys.stdout.flush()
+    real_stdout = os.dup(1)
+    os.dup2(2, 1)
+
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     dist = None
-    if world > 1:
+    force_dist = os.environ.get("ZAFX_BENCH_FORCE_DIST") == "1"   # exercise the N>1 plumbing on a 1-GPU box
+    if world > 1 or force_dist:
         import torch
         import torch.distributed as dist   # plumbing only: barrier + MAX over ranks
         torch.cuda.set_device(local_rank)
@@ -157,7 +164,7 @@ def main():
     plan = wl["plan"]
 
     bcast = "none (1 rank)"
-    if world > 1:
+    if world > 1 or force_dist:
         # the path's only collective: RCCL broadcast of the shared constants from rank 0 over xGMI
         ids = [zafx.Comm.unique_id() if rank == 0 else None]
         dist.broadcast_object_list(ids, src=0)
@@ -222,7 +229,8 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline()
             out["speedup_vs_cpu_baseline"] = round(value / out["cpu_baseline"]["value"], 1)
-        print(json.dumps(out), flush=True)
+        sys.stdout.flush()
+        os.write(real_stdout, (json.dumps(out) + "\n").encode())
 
     if dist is not None:
         dist.barrier()

@@ -274,3 +274,25 @@ def test_errors(zafx):
         zafx.melspectrogram(x, ham, 1024, np.ones((4, 1024)))   # filterbank must expose .toarray()
     with pytest.raises(zafx.ZafxError):
         zafx.istft(np.zeros((2048, 4), complex), ham, 64)        # ceil(W/H) too large for the OLA tile
+
+
+# ------------------------------------------------------------------ RCCL broadcast of constants (1 rank)
+def test_rccl_broadcast_single_rank(zafx, golden):
+    """zafx_comm_* end to end with n_ranks = 1: communicator creation, header + payload
+    broadcast of every constant kind, re-packing, and a transform afterwards."""
+    comm = zafx.Comm(0, 0, 1, zafx.Comm.unique_id())
+    ham = zafx.hamming(2048)
+    fb = zafx.melfilterbank(44100, 2048, 128)
+    x = synth_clip(2, 0, 30000)
+    plan = zafx.mel_plan(ham, 1024, fb, 20)
+    before = plan.run_host(x[None], len(x))
+    comm.broadcast_constants(plan, root=0)
+    after = plan.run_host(x[None], len(x))
+    assert np.array_equal(before, after)
+    ck = scipy.sparse.csr_matrix(golden["tiny"]["ck_dense"])
+    qplan = zafx.cqt_plan(4000, 50, ck)
+    xq = golden["tiny"]["xq_4000"].astype(np.float32)
+    before = qplan.run_host(xq[None], len(xq))
+    comm.broadcast_constants(qplan, root=0)
+    assert np.array_equal(before, qplan.run_host(xq[None], len(xq)))
+    comm.destroy()

@@ -183,23 +183,33 @@ __global__ __launch_bounds__(kFatWaves * 64) void k_stft_ft16(
     const float2* fb = frames + tt * PITCH;
 
     float2 xr[FPW][E];
+    // The fast / edge decision is taken once per TILE (block-uniform): a tile whose 16 frames all lie
+    // inside the clip issues 2 x 16 unconditional 8-byte loads with no control flow in between, so the
+    // loads stay in flight across the store phase; only the first and last tiles of a clip take the
+    // predicated path (zero padding of zaf.py:112-125).
     auto prefetch = [&](int tl) {
+        if (tl >= total_tiles) return;
         const int clip = tl / tiles, tile = tl % tiles;
         const float* xc = x + (long long)clip * n_samples;
+        const long long first = (long long)tile * FPB * hop - N;               // first sample of the tile
+        const long long last = first + (long long)(FPB - 1) * hop + W;          // one past its last sample
+        if (ALIGNED && first >= 0 && last <= n_samples && tile * FPB + FPB <= T) {
+            const float* src = xc + first + (long long)(wave * FPW) * hop + 2 * p;
 #pragma unroll
-        for (int f = 0; f < FPW; ++f) {
-            const int t = tile * FPB + wave * FPW + f;
-            const long long s0 = (long long)t * hop - N;
-            const bool live = tl < total_tiles && t < T;
-            if (ALIGNED && live && s0 >= 0 && s0 + W <= n_samples) {   // interior frame: wave-uniform fast path
+            for (int f = 0; f < FPW; ++f) {
 #pragma unroll
-                for (int i = 0; i < E; ++i) xr[f][i] = *reinterpret_cast<const float2*>(xc + s0 + 2 * (p + i * P));
-            } else {
+                for (int i = 0; i < E; ++i) xr[f][i] = *reinterpret_cast<const float2*>(src + (long long)f * hop + 2 * i * P);
+            }
+        } else {
+#pragma unroll
+            for (int f = 0; f < FPW; ++f) {
+                const int t = tile * FPB + wave * FPW + f;
+                const long long s0 = (long long)t * hop - N;
 #pragma unroll
                 for (int i = 0; i < E; ++i) {
                     const long long s = s0 + 2 * (p + i * P);
-                    xr[f][i].x = (live && s >= 0 && s < n_samples) ? xc[s] : 0.f;
-                    xr[f][i].y = (live && s + 1 >= 0 && s + 1 < n_samples) ? xc[s + 1] : 0.f;
+                    xr[f][i].x = (t < T && s >= 0 && s < n_samples) ? xc[s] : 0.f;
+                    xr[f][i].y = (t < T && s + 1 >= 0 && s + 1 < n_samples) ? xc[s + 1] : 0.f;
                 }
             }
         }

@@ -559,6 +559,103 @@ __device__ __forceinline__ float2 nt_load2(const float* p) {
     const f32x2_t v = __builtin_nontemporal_load(reinterpret_cast<const f32x2_t*>(p));
     return make_float2(v.x, v.y);
 }
+
+// ---- wave-specialised persistent variant: 8 FFT waves + 8 store waves per workgroup.
+// Store waves hold the previous tile's packed spectrum in registers (64 VGPRs) and issue its
+// 256 KB of stores while the FFT waves transform the next tile into LDS.
+template <int DBG>
+__global__ __launch_bounds__(1024) void k_stft_w(
+    const float* __restrict__ x, const float* __restrict__ win, const float2* __restrict__ twp,
+    const float2* __restrict__ tws, float2* __restrict__ out, long long n_samples, int hop, int T, int tiles, int total_tiles) {
+    using C = FftCfg<10, 4>;
+    constexpr int N = C::N, P = C::P, E = C::E, W = 2 * N, NT = 1024, FPB = 16, PITCH = 1090;
+    constexpr int KI = (N / 2) / 32;   // 16 pairs per store thread
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    float2* frames = reinterpret_cast<float2*>(smem_raw);
+    float2* tw_l = frames + FPB * PITCH;
+    float2* win_l = tw_l + C::TW;
+    float2* tws_l = win_l + N;
+    const int tid = threadIdx.x;
+    for (int i = tid; i < C::TW; i += NT) tw_l[i] = twp[i];
+    for (int i = tid; i < N; i += NT) win_l[i] = reinterpret_cast<const float2*>(win)[i];
+    for (int i = tid; i <= N / 2; i += NT) tws_l[i] = tws[i];
+    __syncthreads();
+    const bool fft_role = tid < 512;
+    const int wave = (tid & 511) / P, p = tid % P;
+    const int tt = tid % FPB, kq = (tid & 511) / FPB;     // store role: frame tt, bins kq + 32 i
+    const float2* fb = frames + tt * PITCH;
+    float2 zk[KI], zn[KI];
+    int prev_clip = -1, prev_t0 = 0;
+
+    for (int tl = blockIdx.x;; tl += gridDim.x) {
+        const bool have = tl < total_tiles;
+        const int clip = have ? tl / tiles : 0, tile = have ? tl % tiles : 0;
+        const int t0 = tile * FPB;
+        if (fft_role) {
+            if (have) {
+                const float* xc = x + (long long)clip * n_samples;
+#pragma unroll 1
+                for (int f = 0; f < 2; ++f) {
+                    const int t = t0 + wave * 2 + f;
+                    const long long s0 = (long long)t * hop - N;
+                    float2 v[E];
+                    if (t < T && s0 >= 0 && s0 + W <= n_samples) {
+#pragma unroll
+                        for (int i = 0; i < E; ++i) {
+                            const float2 xv = *reinterpret_cast<const float2*>(xc + s0 + 2 * (p + i * P));
+                            const float2 wv = win_l[p + i * P];
+                            v[i] = make_float2(xv.x * wv.x, xv.y * wv.y);
+                        }
+                    } else {
+#pragma unroll
+                        for (int i = 0; i < E; ++i) {
+                            const long long s = s0 + 2 * (p + i * P);
+                            const float2 wv = win_l[p + i * P];
+                            const float a = (t < T && s >= 0 && s < n_samples) ? xc[s] : 0.f;
+                            const float b = (t < T && s + 1 >= 0 && s + 1 < n_samples) ? xc[s + 1] : 0.f;
+                            v[i] = make_float2(a * wv.x, b * wv.y);
+                        }
+                    }
+                    fft_frame<10, 4>(v, frames + (wave * 2 + f) * PITCH, p, tw_l);
+                }
+            }
+        } else if (prev_clip >= 0 && prev_t0 + tt < T) {
+            // stores of the PREVIOUS tile, from registers, while the FFT waves work
+            float2* o = out + (long long)prev_clip * W * T + (prev_t0 + tt);
+#pragma unroll
+            for (int i = 0; i < KI; ++i) {
+                const int k = kq + 32 * i;
+                if (k == 0) {
+                    const float2 z0 = zk[i], zc = zn[i];
+                    if (!(DBG & 1)) {
+                    o[0] = make_float2(z0.x + z0.y, 0.f); o[(long long)N * T] = make_float2(z0.x - z0.y, 0.f);
+                    o[(long long)(N / 2) * T] = cconj(zc); o[(long long)(N + N / 2) * T] = zc; }
+                } else {
+                    float2 xk, xn;
+                    split_pair(zk[i], zn[i], tws_l[k], xk, xn);
+                    if (!(DBG & 1) || xk.x == 12345.f) {
+                    o[(long long)k * T] = xk;
+                    o[(long long)(W - k) * T] = cconj(xk);
+                    o[(long long)(N - k) * T] = xn;
+                    o[(long long)(N + k) * T] = cconj(xn); }
+                }
+            }
+        }
+        __syncthreads();   // A: LDS holds tile tl (if any); the store waves have issued tile tl - grid
+        if (!have) break;
+        if (!fft_role) {
+#pragma unroll
+            for (int i = 0; i < KI; ++i) {
+                const int k = kq + 32 * i;
+                zk[i] = k == 0 ? fb[0] : fb[phys(k)];
+                zn[i] = k == 0 ? fb[phys(N / 2)] : fb[phys(N - k)];
+            }
+            prev_clip = clip; prev_t0 = t0;
+        }
+        __syncthreads();   // B: LDS may be overwritten
+    }
+}
+
 static bool selected(const char* name) {
     const char* sel = getenv("SEL");
     return !sel || strstr(name, sel) != nullptr;
@@ -685,6 +782,28 @@ float runpp(const Ctx& c, const float2* twp9, const char* name, int reps = 10) {
     return ms;
 }
 
+template <int DBG>
+float runw(const Ctx& c, const char* name, int reps = 10) {
+    if (!selected(name)) return 0;
+    using C = FftCfg<10, 4>;
+    auto kern = k_stft_w<DBG>;
+    size_t smem = (size_t)(16 * 1090 + C::TW + 1024 + 513) * 8;
+    CK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+    int tiles = (c.T + 15) / 16;
+    int total = tiles * c.B;
+    int blocks = 256;
+    hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+    for (int i = 0; i < 2; ++i) hipLaunchKernelGGL(kern, dim3(blocks), dim3(1024), smem, 0, c.x, c.win, c.twp, c.tws, c.out, c.n, c.hop, c.T, tiles, total);
+    CK(hipDeviceSynchronize());
+    CK(hipEventRecord(e0));
+    for (int i = 0; i < reps; ++i) hipLaunchKernelGGL(kern, dim3(blocks), dim3(1024), smem, 0, c.x, c.win, c.twp, c.tws, c.out, c.n, c.hop, c.T, tiles, total);
+    CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1));
+    float ms; CK(hipEventElapsedTime(&ms, e0, e1)); ms /= reps;
+    double bytes = (double)c.B * (4.0 * c.n + 8.0 * 2048 * c.T);
+    printf("%-28s smem=%zu blocks=%6d  %.3f ms  %.0f GB/s (alg)\n", name, smem, blocks, ms, bytes / ms / 1e6);
+    return ms;
+}
+
 double checksum(const Ctx& c) {
     size_t n = (size_t)2048 * c.T * 4;   // first 4 clips
     std::vector<float2> h(n);
@@ -722,6 +841,9 @@ int main() {
     CK(hipMalloc(&c.out, (size_t)c.B * W * c.T * 8));
     CK(hipMemset(c.out, 0, (size_t)c.B * W * c.T * 8));
     run<16, 0, 0>(c, "base FPB16"); double cs0 = checksum(c); auto ref = snapshot(c);
+    CK(hipMemset(c.out, 0, (size_t)c.B * W * c.T * 8));
+    runw<0>(c, "wavespec"); if (selected("wavespec")) printf("  checksum match: %d  rel diff %.3e\n", checksum(c) == cs0, maxdiff(snapshot(c), ref));
+    runw<1>(c, "wavespec no-store");
     {
         auto twp9 = build_pass_twiddles(9, 3);
         float2* d9; CK(hipMalloc(&d9, twp9.size() * 8)); CK(hipMemcpy(d9, twp9.data(), twp9.size() * 8, hipMemcpyHostToDevice));

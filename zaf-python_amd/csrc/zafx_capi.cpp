@@ -138,6 +138,10 @@ static void free_band(PackedBand& pb) {
     pb = PackedBand{};
 }
 
+// Cut the CSR rows of the CQT kernel into chunks of <= 64 entries and deal whole rows to the
+// wavefronts of k_cqt, most expensive first, always to the least loaded wave.
+static int build_cqt_chunks(zafx_plan* pl);
+
 static bool is_stft_family(int kind) { return kind == ZAFX_STFT || kind == ZAFX_ISTFT || kind == ZAFX_MEL || kind == ZAFX_MFCC; }
 static bool is_mdct_family(int kind) { return kind == ZAFX_MDCT || kind == ZAFX_IMDCT; }
 static bool is_cqt_family(int kind) { return kind == ZAFX_CQT || kind == ZAFX_CHROMA; }
@@ -179,16 +183,58 @@ static int finalize_constant(zafx_plan* pl, int which) {
             return 0;
         case ZAFX_CONST_CQT_INDPTR:
             ZAFX_HIP(upload(&pl->d_indptr, pl->h_indptr.data(), pl->h_indptr.size() * sizeof(int32_t)));
+            pl->cqt_dirty = true;
             return 0;
         case ZAFX_CONST_CQT_INDICES:
             ZAFX_HIP(upload(&pl->d_indices, pl->h_indices.data(), pl->h_indices.size() * sizeof(int32_t)));
             pl->nnz = (int)pl->h_indices.size();
+            pl->cqt_dirty = true;
             return 0;
         case ZAFX_CONST_CQT_VALUES:
             ZAFX_HIP(upload(&pl->d_values, pl->h_values.data(), pl->h_values.size() * sizeof(cf32)));
             return 0;
     }
     return fail_msg("unknown constant id");
+}
+
+static int build_cqt_chunks(zafx_plan* pl) {
+    const int n_waves = std::max(1, cqt_waves(pl->log2nf));
+    const int n_rows = (int)pl->h_indptr.size() - 1;
+    struct Row { int row, cost; };
+    std::vector<Row> rows;
+    for (int r = 0; r < n_rows; ++r) {
+        const int nz = pl->h_indptr[(size_t)r + 1] - pl->h_indptr[(size_t)r];
+        if (nz < 0) return fail_msg("CQT kernel indptr is not monotone");
+        rows.push_back(Row{r, (nz + 63) / 64 + 1});
+    }
+    std::stable_sort(rows.begin(), rows.end(), [](const Row& a, const Row& b) { return a.cost > b.cost; });
+    std::vector<std::vector<int>> per_wave((size_t)n_waves);
+    std::vector<int> load((size_t)n_waves, 0);
+    for (const Row& r : rows) {
+        const int w = (int)(std::min_element(load.begin(), load.end()) - load.begin());
+        per_wave[(size_t)w].push_back(r.row);
+        load[(size_t)w] += r.cost;
+    }
+    std::vector<int> flat, ptr((size_t)n_waves + 1, 0);
+    for (int w = 0; w < n_waves; ++w) {
+        ptr[(size_t)w] = (int)flat.size() / 4;
+        for (int r : per_wave[(size_t)w]) {
+            const int lo = pl->h_indptr[(size_t)r], hi = pl->h_indptr[(size_t)r + 1];
+            int e = lo;
+            do {   // an empty row still yields one (empty, last) chunk so that its output is written
+                const int cnt = std::min(64, hi - e);
+                flat.push_back(r); flat.push_back(e); flat.push_back(cnt); flat.push_back(e + cnt >= hi ? 1 : 0);
+                e += cnt;
+            } while (e < hi);
+        }
+    }
+    ptr[(size_t)n_waves] = (int)flat.size() / 4;
+    pl->n_chunks = (int)flat.size() / 4;
+    if (flat.empty()) flat.assign(4, 0);
+    ZAFX_HIP(upload(&pl->d_chunks, flat.data(), flat.size() * sizeof(int)));
+    ZAFX_HIP(upload(&pl->d_chunk_ptr, ptr.data(), ptr.size() * sizeof(int)));
+    pl->cqt_dirty = false;
+    return 0;
 }
 
 }  // namespace zafx
@@ -336,6 +382,8 @@ int zafx_plan_destroy(zafx_plan* pl) {
     if (pl->d_indptr) (void)hipFree(pl->d_indptr);
     if (pl->d_indices) (void)hipFree(pl->d_indices);
     if (pl->d_values) (void)hipFree(pl->d_values);
+    if (pl->d_chunks) (void)hipFree(pl->d_chunks);
+    if (pl->d_chunk_ptr) (void)hipFree(pl->d_chunk_ptr);
     free_band(pl->fb);
     free_band(pl->dct);
     if (pl->ev0) (void)hipEventDestroy(pl->ev0);
@@ -451,6 +499,10 @@ int zafx_execute(zafx_plan* pl, const void* d_in, void* d_out, int64_t n_clips, 
     if (is_cqt_family(pl->kind)) {
         if (!pl->d_indptr || !pl->d_indices || !pl->d_values) return fail_msg("CQT kernel constants not set");
         if ((int)pl->h_values.size() != pl->nnz || pl->h_indptr.back() != pl->nnz) return fail_msg("CQT kernel CSR arrays are inconsistent");
+        if (pl->cqt_dirty) {
+            ZAFX_HIP(hipSetDevice(pl->device));
+            if (int rc = build_cqt_chunks(pl)) return rc;
+        }
     }
     if (n_clips * std::max<int64_t>(dims[1], 1) > 0x7fffffffLL) return fail_msg("batch too large for one launch (clips x frames >= 2^31)");
     ZAFX_HIP(hipSetDevice(pl->device));

@@ -23,8 +23,8 @@ constexpr int kCqtFramesPerBlock = 16;
 template <int LOG2N, int LOG2E>
 __global__ __launch_bounds__(fft_threads(LOG2N, LOG2E)) void k_cqt(
     const float* __restrict__ x, const float2* __restrict__ twp, const float2* __restrict__ tws,
-    const int* __restrict__ indptr, const int* __restrict__ indices, const float2* __restrict__ values, float* __restrict__ out,
-    long long n_samples, int step, int left_pad, int T, int tiles, int n_bins, int chroma_res, int layout) {
+    const int4* __restrict__ chunks, const int* __restrict__ chunk_ptr, const int* __restrict__ indices, const float2* __restrict__ values, float* __restrict__ out,
+    long long n_samples, int step, int left_pad, int T, int tiles, int n_bins, int chroma_res, int layout, int n_chunks) {
     using C = FftCfg<LOG2N, LOG2E>;
     constexpr int N = C::N, P = C::P, E = C::E, W = 2 * N, FW = kCqtFramesPerBlock;
     static_assert(P >= 64, "CQT frames are owned by whole wavefronts");
@@ -33,9 +33,14 @@ __global__ __launch_bounds__(fft_threads(LOG2N, LOG2E)) void k_cqt(
     constexpr int NHI = LOG2N > 7 ? 1 << (LOG2N - 7) : 1;
     float2* tw_hi = buf + C::PITCH;                               // two-level root table (zafx_fft.hpp)
     float2* tw_lo = tw_hi + NHI;
-    float* tile = reinterpret_cast<float*>(tw_lo + 128);          // [n_bins][FW]
+    // 16-byte aligned carve (a misaligned ds_read_b128 is replayed at 64 cycles): descriptors first, tile after
+    int4* chunk_l = reinterpret_cast<int4*>(smem_raw + (((size_t)(C::PITCH + NHI + 128) * 8 + 15) / 16) * 16);   // [n_chunks]
+    float* tile = reinterpret_cast<float*>(chunk_l + n_chunks);   // [n_bins][FW]
+    int* chunk_ptr_l = reinterpret_cast<int*>(tile + n_bins * FW);   // [waves + 1]
     const int p = threadIdx.x;
     for (int i = p; i < NHI + 128; i += P) tw_hi[i] = twp[i];
+    for (int i = p; i < n_chunks; i += P) chunk_l[i] = chunks[i];
+    for (int i = p; i <= P / 64; i += P) chunk_ptr_l[i] = chunk_ptr[i];
     __syncthreads();
     const TwoLevelTw tw2l{tw_hi, tw_lo};
     const int lane = p & 63, wave = p >> 6, nwaves = P >> 6;
@@ -77,26 +82,50 @@ __global__ __launch_bounds__(fft_threads(LOG2N, LOG2E)) void k_cqt(
             }
         }
         __syncthreads();
-        // ---- CSR mat-vec against the spectrum + magnitude (zaf.py:630-632)
-        for (int r = wave; r < n_bins; r += nwaves) {
-            const int lo = indptr[r], hi = indptr[r + 1];
+        // ---- CSR mat-vec against the spectrum + magnitude (zaf.py:630-632).  The host cut the rows into
+        // chunks of <= 64 non-zeros and dealt whole rows to the wavefronts (balanced).  Chunk descriptors
+        // sit in LDS; the column indices and values of G chunks are requested together, so a frame pays
+        // ceil(chunks / G) L2 round trips instead of two per chunk (measured: the latency-chained version
+        // spent 46 % of the kernel in this 2 %-of-the-flops step).
+        {
+            constexpr int G = 6;
+            const int c0 = chunk_ptr_l[wave], c1 = chunk_ptr_l[wave + 1];
             float ar = 0.f, ai = 0.f;
-            for (int e = lo + lane; e < hi; e += 64) {
-                const int c = indices[e];
-                const float2 kv = values[e];
-                float2 xv;
-                if (c < N) xv = buf[phys(c)];
-                else if (c == N) xv = buf[C::PITCH - 1];
-                else xv = cconj(buf[phys(W - c)]);
-                ar += kv.x * xv.x - kv.y * xv.y;
-                ai += kv.x * xv.y + kv.y * xv.x;
-            }
+            for (int cb = c0; cb < c1; cb += G) {
+                int4 ch[G];
+                int col[G];
+                float2 kv[G];
 #pragma unroll
-            for (int m = 32; m >= 1; m >>= 1) {
-                ar += __shfl_xor(ar, m, 64);
-                ai += __shfl_xor(ai, m, 64);
+                for (int g = 0; g < G; ++g) {
+                    ch[g] = cb + g < c1 ? chunk_l[cb + g] : make_int4(0, 0, 0, 0);
+                    col[g] = 0;
+                    kv[g] = make_float2(0.f, 0.f);
+                    if (lane < ch[g].z) { col[g] = indices[ch[g].y + lane]; kv[g] = values[ch[g].y + lane]; }
+                }
+#pragma unroll
+                for (int g = 0; g < G; ++g) {
+                    if (cb + g >= c1) break;
+                    if (lane < ch[g].z) {
+                        const int c = col[g];
+                        float2 xv;
+                        if (c < N) xv = buf[phys(c)];
+                        else if (c == N) xv = buf[C::PITCH - 1];
+                        else xv = cconj(buf[phys(W - c)]);
+                        ar += kv[g].x * xv.x - kv[g].y * xv.y;
+                        ai += kv[g].x * xv.y + kv[g].y * xv.x;
+                    }
+                    if (ch[g].w) {   // last chunk of row ch[g].x
+#pragma unroll
+                        for (int m = 32; m >= 1; m >>= 1) {
+                            ar += __shfl_xor(ar, m, 64);
+                            ai += __shfl_xor(ai, m, 64);
+                        }
+                        if (lane == 0) tile[ch[g].x * FW + jj] = sqrtf(ar * ar + ai * ai);
+                        ar = 0.f;
+                        ai = 0.f;
+                    }
+                }
             }
-            if (lane == 0) tile[r * FW + jj] = sqrtf(ar * ar + ai * ai);
         }
         __syncthreads();
     }
@@ -128,9 +157,10 @@ static hipError_t run_cqt(const zafx_plan& pl, const float* x, float* out, int64
     constexpr int LOG2E = default_log2e(LOG2N);
     using C = FftCfg<LOG2N, LOG2E>;
     auto kern = k_cqt<LOG2N, LOG2E>;
-    const size_t smem = (size_t)(C::PITCH + (LOG2N > 7 ? (1 << (LOG2N - 7)) : 1) + 128) * 8 + (size_t)pl.prm.n_bins * kCqtFramesPerBlock * sizeof(float);
+    const size_t head = (((size_t)(C::PITCH + (LOG2N > 7 ? (1 << (LOG2N - 7)) : 1) + 128) * 8 + 15) / 16) * 16;
+    const size_t smem = head + (size_t)pl.n_chunks * 16 + (size_t)pl.prm.n_bins * kCqtFramesPerBlock * sizeof(float) + (size_t)(C::P / 64 + 1) * 4;
     if (smem > (size_t)kMaxLdsBytes) {
-        set_error("cqt: n_bins too large for the LDS output tile at this fft_length");
+        set_error("cqt: kernel matrix (bins / non-zeros) too large for LDS at this fft_length");
         return hipErrorInvalidValue;
     }
     static size_t attr_set[64] = {};
@@ -144,13 +174,14 @@ static hipError_t run_cqt(const zafx_plan& pl, const float* x, float* out, int64
     if (blocks <= 0) return hipSuccess;
     const int diff = pl.W - pl.H;                              // may be negative if step > fft_len
     const int left = diff >= 0 ? (diff + 1) / 2 : -((-diff) / 2);   // ceil(diff / 2)  (zaf.py:615)
-    hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(C::P), smem, pl.stream, x, pl.d_tw_pass, pl.d_tw_aux, pl.d_indptr, pl.d_indices,
+    hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(C::P), smem, pl.stream, x, pl.d_tw_pass, pl.d_tw_aux, pl.d_chunks, pl.d_chunk_ptr, pl.d_indices,
                        pl.d_values, out, (long long)n_samples, pl.H, left, T, tiles, pl.prm.n_bins,
-                       pl.kind == ZAFX_CHROMA ? pl.prm.octave_resolution : 0, pl.layout);
+                       pl.kind == ZAFX_CHROMA ? pl.prm.octave_resolution : 0, pl.layout, pl.n_chunks);
     return hipGetLastError();
 }
 
 bool cqt_supported(int log2n) { return log2n >= 8 && log2n <= 14; }
+int cqt_waves(int log2n) { return fft_threads(log2n, default_log2e(log2n)) / 64; }
 const char* cqt_kernel_name() { return "k_cqt"; }
 
 hipError_t launch_cqt(const zafx_plan& pl, const float* x, float* out, int64_t n_clips, int64_t n_samples, int T) {

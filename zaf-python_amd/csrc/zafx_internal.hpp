@@ -56,6 +56,10 @@ struct zafx_plan {
     int* d_indices = nullptr;
     float2* d_values = nullptr;
     int nnz = 0;
+    int4* d_chunks = nullptr;      // CQT rows cut into <= 64-entry chunks {row, first entry, count, last-of-row}
+    int* d_chunk_ptr = nullptr;    // [waves + 1] ranges of d_chunks per wavefront
+    int n_chunks = 0;
+    bool cqt_dirty = true;
 
     // host shadows (needed to re-pack after an RCCL broadcast)
     std::vector<float> h_window, h_fb, h_dct;
@@ -87,6 +91,7 @@ const char* cqt_kernel_name();
 bool stft_supported(int log2n);   // log2 of complex FFT length = log2(W) - 1
 bool mdct_supported(int log2nf);  // log2(W) - 2
 bool cqt_supported(int log2n);    // log2(fft_length) - 1
+int cqt_waves(int log2n);         // wavefronts per workgroup of k_cqt
 int stft_frames_per_block(int log2n, int layout);
 int mdct_frames_per_block(int log2nf, int layout);
 

@@ -296,3 +296,68 @@ def test_rccl_broadcast_single_rank(zafx, golden):
     comm.broadcast_constants(qplan, root=0)
     assert np.array_equal(before, qplan.run_host(xq[None], len(xq)))
     comm.destroy()
+
+
+# ------------------------------------------------------------------ unaligned / odd geometries (slow-path kernels)
+@pytest.mark.parametrize("n,hop", [(44101, 1024), (44100, 1023), (30001, 511), (5000, 2048)])
+def test_stft_family_unaligned(zafx, n, hop):
+    """Odd clip lengths / odd hops take the predicated (non 8-byte-aligned) load path."""
+    x = np.stack([synth_clip(8, c, n) for c in range(5)])
+    ham = zafx.hamming(2048)
+    ref = orc.stft_batch(x.astype(np.float64), ham, hop)
+    got = zafx.stft_batch(x, ham, hop)
+    assert got.shape == ref.shape
+    for c in range(5):
+        assert relerr(got[c], ref[c]) <= TOL_FFT
+    fb = zafx.melfilterbank(44100, 2048, 128)
+    mel = zafx.melspectrogram_batch(x[:2], ham, hop, fb)
+    mf = zafx.mfcc_batch(x[:2], ham, hop, fb, 20)
+    for c in range(2):
+        x64 = x[c].astype(np.float64)
+        assert relerr(mel[c], orc.melspectrogram(x64, ham, hop, fb)) <= TOL_FB
+        assert relerr(mf[c], orc.mfcc(x64, ham, hop, fb, 20)) <= TOL_FB
+    if -(-2048 // hop) <= 8:
+        y = zafx.istft_batch(ref[:2], ham, hop)
+        for c in range(2):
+            assert relerr(y[c], orc.istft(ref[c], ham, hop)) <= TOL_FFT
+
+
+@pytest.mark.parametrize("n", [1024 * 30, 1024 * 31 + 1, 1024 * 33 - 1, 100000])
+def test_mdct_frame_count_parity(zafx, n):
+    """Even and odd frame counts (the 8-byte pair store needs T even), partial last tile of 32."""
+    x = np.stack([synth_clip(9, c, n) for c in range(3)])
+    w = zafx.kaiser_bessel_derived(2048)
+    ref = orc.mdct_batch(x.astype(np.float64), w)
+    got = zafx.mdct_batch(x, w)
+    assert got.shape == ref.shape
+    for c in range(3):
+        assert relerr(got[c], ref[c]) <= TOL_FFT
+    y = zafx.imdct_batch(got, w)
+    for c in range(3):
+        k = min(n, y.shape[1])
+        assert np.max(np.abs(y[c][:k] - x[c][:k])) < 1e-5
+
+
+def test_mel_other_window(zafx):
+    """W = 1024 instantiation of the fused kernel (slots in the upper halves of smaller frame buffers)."""
+    x = np.stack([synth_clip(10, c, 22050) for c in range(2)])
+    w = zafx.hamming(1024)
+    fb = zafx.melfilterbank(22050, 1024, 64)
+    mel = zafx.melspectrogram_batch(x, w, 256, fb)
+    mf = zafx.mfcc_batch(x, w, 256, fb, 13)
+    for c in range(2):
+        x64 = x[c].astype(np.float64)
+        assert relerr(mel[c], orc.melspectrogram(x64, w, 256, fb)) <= TOL_FB
+        assert relerr(mf[c], orc.mfcc(x64, w, 256, fb, 13)) <= TOL_FB
+
+
+def test_batch_larger_than_grid(zafx):
+    """More tiles than persistent workgroups: every workgroup loops; clips stay independent."""
+    b, n = 700, 20000
+    base = np.stack([synth_clip(11, c, n) for c in range(7)])
+    x = np.tile(base, (b // 7, 1))
+    ham = zafx.hamming(2048)
+    got = zafx.stft_batch(x, ham, 1024)
+    for c in range(7):
+        assert relerr(got[c], orc.stft(base[c].astype(np.float64), ham, 1024)) <= TOL_FFT
+    assert np.array_equal(got[:7], got[-7:])

@@ -179,9 +179,28 @@ __global__ __launch_bounds__(FPB * 64) void k_stft_p(
 }
 
 
+// ---- multi-frame FFT: FPW frames per wave advance pass by pass together (half the fences, 2x ILP)
+template <int LOG2N, int LOG2E, int FPW, int LOG2NS = 0>
+__device__ __forceinline__ void fft_frames(float2 (&v)[FPW][1 << LOG2E], float2* buf0, int pitch, int p, const float2* tw) {
+    using C = FftCfg<LOG2N, LOG2E>;
+    if constexpr (LOG2NS < LOG2N) {
+        constexpr int LR = pass_log2r(LOG2N - LOG2NS, LOG2E);
+#pragma unroll
+        for (int f = 0; f < FPW; ++f)
+            pass_write<LOG2N, LOG2E, LOG2NS, LR>(v[f], buf0 + f * pitch, p, tw + twiddle_offset(LOG2N, LOG2E, LOG2NS));
+        frame_sync<C::P>();
+        if constexpr (LOG2NS + LR < LOG2N) {
+#pragma unroll
+            for (int f = 0; f < FPW; ++f) regs_read<LOG2N, LOG2E>(v[f], buf0 + f * pitch, p);
+            frame_sync<C::P>();
+            fft_frames<LOG2N, LOG2E, FPW, LOG2NS + LR>(v, buf0, pitch, p, tw);
+        }
+    }
+}
+
 // ---- persistent variant 2: 16-frame tile, WAVES waves, each wave transforms 16/WAVES frames
 // (fewer, fatter waves: up to 256 VGPRs at 8 waves/CU, so the prefetch never spills)
-template <int WAVES, int PITCH, int DBG>
+template <int WAVES, int PITCH, int DBG, int MF = 0>
 __global__ __launch_bounds__(WAVES * 64) void k_stft_q(
     const float* __restrict__ x, const float* __restrict__ win, const float2* __restrict__ twp,
     const float2* __restrict__ tws, float2* __restrict__ out, long long n_samples, int hop, int T, int tiles, int total_tiles) {
@@ -229,6 +248,17 @@ __global__ __launch_bounds__(WAVES * 64) void k_stft_q(
     for (; tl < total_tiles; tl += gridDim.x) {
         const int clip = tl / tiles, tile = tl % tiles;
         const int t0 = tile * FPB;
+        if constexpr (MF) {
+            float2 v[FPW][E];
+#pragma unroll
+            for (int f = 0; f < FPW; ++f)
+#pragma unroll
+                for (int i = 0; i < E; ++i) {
+                    const float2 wv = win_l[p + i * P];
+                    v[f][i] = make_float2(xr[f][i].x * wv.x, xr[f][i].y * wv.y);
+                }
+            fft_frames<10, 4, FPW>(v, frames + (wave * FPW) * PITCH, PITCH, p, tw_l);
+        } else {
 #pragma unroll
         for (int f = 0; f < FPW; ++f) {
             float2 v[E];
@@ -238,6 +268,7 @@ __global__ __launch_bounds__(WAVES * 64) void k_stft_q(
                 v[i] = make_float2(xr[f][i].x * wv.x, xr[f][i].y * wv.y);
             }
             fft_frame<10, 4>(v, frames + (wave * FPW + f) * PITCH, p, tw_l);
+        }
         }
         __syncthreads();
         prefetch(tl + gridDim.x);
@@ -264,25 +295,6 @@ __global__ __launch_bounds__(WAVES * 64) void k_stft_q(
     }
 }
 
-
-// ---- multi-frame FFT: FPW frames per wave advance pass by pass together (half the fences, 2x ILP)
-template <int LOG2N, int LOG2E, int FPW, int LOG2NS = 0>
-__device__ __forceinline__ void fft_frames(float2 (&v)[FPW][1 << LOG2E], float2* buf0, int pitch, int p, const float2* tw) {
-    using C = FftCfg<LOG2N, LOG2E>;
-    if constexpr (LOG2NS < LOG2N) {
-        constexpr int LR = pass_log2r(LOG2N - LOG2NS, LOG2E);
-#pragma unroll
-        for (int f = 0; f < FPW; ++f)
-            pass_write<LOG2N, LOG2E, LOG2NS, LR>(v[f], buf0 + f * pitch, p, tw + twiddle_offset(LOG2N, LOG2E, LOG2NS));
-        frame_sync<C::P>();
-        if constexpr (LOG2NS + LR < LOG2N) {
-#pragma unroll
-            for (int f = 0; f < FPW; ++f) regs_read<LOG2N, LOG2E>(v[f], buf0 + f * pitch, p);
-            frame_sync<C::P>();
-            fft_frames<LOG2N, LOG2E, FPW, LOG2NS + LR>(v, buf0, pitch, p, tw);
-        }
-    }
-}
 
 // ---- persistent variant 3: branch-free prefetch (clamped float2 loads, masked at use), multi-frame FFT
 template <int WAVES, int PITCH, int DBG>
@@ -711,7 +723,7 @@ template <int WAVES, int PITCH, int DBG, int VAR = 0>
 float runq(const Ctx& c, const char* name, int reps = 10) {
     if (!selected(name)) return 0;
     using C = FftCfg<10, 4>;
-    auto kern = VAR == 0 ? k_stft_q<WAVES, PITCH, DBG> : k_stft_r<WAVES, PITCH, DBG>;
+    auto kern = VAR == 0 ? k_stft_q<WAVES, PITCH, DBG> : (VAR == 2 ? k_stft_q<WAVES, PITCH, DBG, 1> : k_stft_r<WAVES, PITCH, DBG>);
     size_t smem = (size_t)(16 * PITCH + C::TW + 1024 + 513) * 8;
     CK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
     int tiles = (c.T + 15) / 16;
@@ -868,6 +880,9 @@ int main() {
     runp<16, 1090, 0>(c, "persist pitch1090"); printf("  checksum match: %d\n", checksum(c) == cs0);
     runp<16, 1090, 1>(c, "persist pitch1090 no-store");
     CK(hipMemset(c.out, 0, (size_t)c.B * W * c.T * 8));
+    runq<8, 1090, 0, 2>(c, "persist-qmf 8 waves"); if (selected("persist-qmf 8 waves")) printf("  checksum match: %d\n", checksum(c) == cs0);
+    runq<8, 1090, 1, 2>(c, "persist-qmf 8 waves no-store");
+    runq<4, 1090, 0, 2>(c, "persist-qmf 4 waves");
     runq<8, 1090, 0>(c, "persist-q 8 waves"); printf("  checksum match: %d\n", checksum(c) == cs0);
     CK(hipMemset(c.out, 0, (size_t)c.B * W * c.T * 8));
     runq<4, 1090, 0>(c, "persist-q 4 waves"); printf("  checksum match: %d\n", checksum(c) == cs0);

@@ -244,9 +244,18 @@ __device__ __forceinline__ void frame_sync() {
     if constexpr (P > 64) {
         __syncthreads();
     } else {
+#if defined(ZAFX_WAVE_SYNC_FENCE)
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+#else
+        // LDS services one wavefront's DS instructions in issue order, so a later ds_read of the
+        // same wave observes an earlier ds_write without waiting for lgkmcnt(0); what must be
+        // prevented is COMPILER reordering across the exchange point.
+        asm volatile("" ::: "memory");
+        __builtin_amdgcn_wave_barrier();
+        asm volatile("" ::: "memory");
+#endif
     }
 }
 

@@ -117,6 +117,15 @@ int zafx_timer_stop(zafx_plan* plan, float* elapsed_ms);
 /* Name of the dominant kernel the plan launches (for matching rocprofv3 rows). */
 int zafx_plan_kernel_name(const zafx_plan* plan, char* buf, size_t buflen);
 
+/* ---- PCM ingest: the step in front of the path ------------------------------ */
+/* wavread's normalisation (zaf.py:1202: x / 2^(8*itemsize - 1)) and the channel mean every example
+ * applies before the transforms (zaf.py:65: np.mean(audio_signal, 1)), on device:
+ *   out[c][i] = mean_ch( in[c][i][ch] ) / 2^(8*sample_bytes - 1)
+ * in: (n_clips, n_frames, n_channels) interleaved int16 (sample_bytes 2) or int32 (4); out: float32.
+ * Enqueued on the plan's stream, so it is ordered before a following zafx_execute on that plan. */
+int zafx_pcm_to_float(zafx_plan* plan, const void* d_pcm, void* d_out, int64_t n_clips, int64_t n_frames,
+                      int n_channels, int sample_bytes);
+
 /* ---- multi-GPU: one process per GPU, RCCL over xGMI --------------------------------- */
 /* The only collective on this path: broadcast of the shared constants (window,
  * filterbank, DCT matrix, CQT kernel) from `root`.  No reduction exists. */

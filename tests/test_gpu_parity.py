@@ -361,3 +361,22 @@ def test_batch_larger_than_grid(zafx):
     for c in range(7):
         assert relerr(got[c], orc.stft(base[c].astype(np.float64), ham, 1024)) <= TOL_FFT
     assert np.array_equal(got[:7], got[-7:])
+
+
+# ------------------------------------------------------------------ PCM ingest
+@pytest.mark.parametrize("dtype,channels", [(np.int16, 1), (np.int16, 2), (np.int32, 2), (np.int16, 5)])
+def test_pcm_ingest(zafx, dtype, channels):
+    """wavread's normalisation (zaf.py:1202) + the examples' channel mean (zaf.py:65) on device."""
+    rng = np.random.default_rng(12)
+    info = np.iinfo(dtype)
+    pcm = rng.integers(info.min, info.max, size=(3, 30000, channels), dtype=dtype, endpoint=True)
+    ref = np.mean(pcm / pow(2, pcm.itemsize * 8 - 1), axis=2)
+    got = zafx.pcm_to_mono(pcm)
+    assert got.shape == ref.shape and got.dtype == np.float32
+    assert np.max(np.abs(got - ref)) <= 2e-7
+    ham = zafx.hamming(2048)
+    spec = zafx.stft_pcm_batch(pcm, ham, 1024)
+    for c in range(3):
+        assert relerr(spec[c], orc.stft(ref[c], ham, 1024)) <= TOL_FFT
+    with pytest.raises(ValueError):
+        zafx.pcm_to_mono(pcm.astype(np.float32))

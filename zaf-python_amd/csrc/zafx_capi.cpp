@@ -562,6 +562,19 @@ int zafx_timer_stop(zafx_plan* pl, float* ms) {
     return 0;
 }
 
+int zafx_pcm_to_float(zafx_plan* pl, const void* d_pcm, void* d_out, int64_t n_clips, int64_t n_frames, int n_channels,
+                      int sample_bytes) {
+    if (!pl) return fail_msg("null plan");
+    if (n_clips < 0 || n_frames < 0) return fail_msg("negative size");
+    if (n_channels < 1 || n_channels > 64) return fail_msg("n_channels must be in [1, 64]");
+    if (sample_bytes != 2 && sample_bytes != 4) return fail_msg("sample_bytes must be 2 (int16) or 4 (int32)");
+    if (n_clips * n_frames == 0) return 0;
+    if (!d_pcm || !d_out) return fail_msg("null device pointer");
+    ZAFX_HIP(hipSetDevice(pl->device));
+    ZAFX_HIP(launch_pcm_to_float(pl->stream, d_pcm, (float*)d_out, n_clips * n_frames, n_channels, sample_bytes));
+    return 0;
+}
+
 int zafx_plan_kernel_name(const zafx_plan* pl, char* buf, size_t buflen) {
     if (!pl || !buf || !buflen) return fail_msg("null argument");
     std::snprintf(buf, buflen, "%s", pl->kernel_name.c_str());

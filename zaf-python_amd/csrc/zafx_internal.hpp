@@ -78,6 +78,7 @@ hipError_t launch_mdct(const zafx_plan& pl, const float* x, float* out, int64_t 
 hipError_t launch_imdct(const zafx_plan& pl, const float* coefs, float* y, int64_t n_clips, int T, int64_t out_len);
 hipError_t launch_mel(const zafx_plan& pl, const float* x, float* out, int64_t n_clips, int64_t n_samples, int T);
 hipError_t launch_cqt(const zafx_plan& pl, const float* x, float* out, int64_t n_clips, int64_t n_samples, int T);
+hipError_t launch_pcm_to_float(hipStream_t stream, const void* pcm, float* out, int64_t n_total, int n_channels, int sample_bytes);
 
 // names of the dominant kernels (what rocprofv3 --kernel-trace prints, prefix match)
 const char* stft_kernel_name(int log2n, int layout);

@@ -16,8 +16,8 @@ from ._lib import (CHROMA, CQT, IMDCT, ISTFT, LAYOUT_FT, LAYOUT_TF, MDCT, MEL, M
 from .constants import cqtkernel, dct2_rows, hamming, kaiser_bessel_derived, melfilterbank, sine
 from .core import (Comm, DeviceBuffer, Plan, clear_plan_cache, cqt_plan, cqtchromagram, cqtchromagram_batch,
                    cqtspectrogram, cqtspectrogram_batch, imdct, imdct_batch, istft, istft_batch, istft_plan, mdct,
-                   mdct_batch, mdct_plan, mel_plan, melspectrogram, melspectrogram_batch, mfcc, mfcc_batch, stft,
-                   stft_batch, stft_plan)
+                   mdct_batch, mdct_plan, mel_plan, melspectrogram, melspectrogram_batch, mfcc, mfcc_batch, pcm_to_mono,
+                   stft, stft_batch, stft_pcm_batch, stft_plan)
 from .shard import clip_range, shard_sizes
 
 __version__ = "0.1.0"

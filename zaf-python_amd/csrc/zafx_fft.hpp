@@ -82,6 +82,15 @@ struct FftCfg {
 };
 
 ZAFX_HD int phys(int i) { return i + (i >> 4); }
+// phys(base + off) for a compile-time `off`, given pb = phys(base).  When the low part of `base`
+// (below the power-of-two SPAN >= 16 that `off` is a multiple-of-stride within) cannot carry into
+// the padding term, phys(base + off) = phys(base) + off + off/16: a constant that folds into the
+// DS instruction's immediate offset instead of costing address VALU per access.
+template <int SPAN>
+ZAFX_HD int phys_off(int pb, int base, int off) {
+    if (SPAN >= 16) return pb + off + (off >> 4);
+    return phys(base + off);
+}
 
 // ---------------------------------------------------------------- register DFTs
 // Natural-order in, natural-order out, forward sign (e^{-2 pi i nk/R}).
@@ -179,8 +188,9 @@ ZAFX_HD void pass_write(const float2* v, float2* buf, int p, const float2* tw) {
         }
         Dft<R>::run(a);
         const int base = ((j >> LOG2NS) << (LOG2NS + LR)) + k;
+        const int pb = phys(base);
 #pragma unroll
-        for (int r = 0; r < R; ++r) buf[phys(base + r * NS)] = a[r];
+        for (int r = 0; r < R; ++r) buf[phys_off<NS * R>(pb, base, r * NS)] = a[r];
     }
 }
 
@@ -216,16 +226,18 @@ ZAFX_HD void pass_write_chain(const float2* v, float2* buf, int p, const TwoLeve
         }
         Dft<R>::run(a);
         const int base = ((j >> LOG2NS) << (LOG2NS + LR)) + k;
+        const int pb = phys(base);
 #pragma unroll
-        for (int r = 0; r < R; ++r) buf[phys(base + r * NS)] = a[r];
+        for (int r = 0; r < R; ++r) buf[phys_off<NS * R>(pb, base, r * NS)] = a[r];
     }
 }
 
 template <int LOG2N, int LOG2E>
 ZAFX_HD void regs_read(float2* v, const float2* buf, int p) {
     using C = FftCfg<LOG2N, LOG2E>;
+    const int pp = phys(p);
 #pragma unroll
-    for (int i = 0; i < C::E; ++i) v[i] = buf[phys(p + i * C::P)];
+    for (int i = 0; i < C::E; ++i) v[i] = buf[phys_off<C::P>(pp, p, i * C::P)];
 }
 
 }  // namespace zafx

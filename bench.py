@@ -37,7 +37,7 @@ def synth(seed, c, n):
     return np.random.default_rng([seed, c]).standard_normal(n).astype(np.float32)
 
 
-def make_workload(kind, device):
+def make_workload(kind, device, layout="FT"):
     """Returns dict(plan, n_clips, n_in, d_in, d_out, samples_per_clip, bytes_per_launch, flops_per_launch, desc)."""
     ham = zafx.hamming(W)
     kbd = zafx.kaiser_bessel_derived(W)
@@ -54,7 +54,7 @@ def make_workload(kind, device):
     d_base.free()
     wl = dict(n_clips=B, samples_per_clip=N, base=base, flops_per_launch=0.0)
     if kind == "stft":
-        plan = zafx.stft_plan(ham, H, device=device)
+        plan = zafx.stft_plan(ham, H, layout=layout, device=device)
         wl.update(plan=plan, d_in=d_x, n_in=N, bytes_per_launch=B * (4 * N + 8 * W * T),
                   desc="Batched STFT: 1024 clips x 10 s @ 44.1 kHz, Hamming win=2048 hop=1024, two-sided c64 (W,T) layout")
     elif kind == "istft":
@@ -128,6 +128,8 @@ def parity_probe(wl, kind):
     if kind != "stft":
         return None
     got = wl["d_out"].download(0, 1)[0]
+    if got.shape[0] != W:
+        got = got.T
     ref = orc.stft(wl["base"][0].astype(np.float64), orc.hamming_periodic(W), H)
     d = float(np.max(np.abs(got - ref)))
     return {"max_abs_err_vs_numpy": d, "max_rel_err_vs_numpy": d / float(np.max(np.abs(ref)))}
@@ -140,6 +142,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--kind", default="stft")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--layout", default="FT", choices=["FT", "TF"], help="FT = reference (W, T) memory order (default); TF = frame-major")
     args = ap.parse_args()
 
     # Libraries (RCCL banners, HIP warnings) write to C-level stdout; the contract is ONE JSON line
@@ -160,7 +163,7 @@ def main():
         dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
     device = local_rank if world > 1 else 0
 
-    wl = make_workload(args.kind, device)
+    wl = make_workload(args.kind, device, args.layout)
     plan = wl["plan"]
 
     bcast = "none (1 rank)"
@@ -214,7 +217,7 @@ def main():
             "vs_baseline": None, "dtype": "f32",
             "data": "synthetic white Gaussian noise (default_rng([0,c]).standard_normal, f32); 8 distinct clips replicated on device to 1024 per GPU",
             "config": {"workload": wl["desc"], "clips_per_gpu": B, "samples_per_clip": wl["samples_per_clip"],
-                       "parallelism": f"clip-sharded x{world}", "constants_broadcast": bcast, "layout": "FT (reference memory order)"},
+                       "parallelism": f"clip-sharded x{world}", "constants_broadcast": bcast, "layout": "FT (reference memory order)" if args.layout == "FT" else "TF (frame-major)"},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
                          "kernel": plan.kernel_name, "kernel_ms": round(kernel_ms, 4),

@@ -203,7 +203,8 @@ __device__ __forceinline__ void fft_frames(float2 (&v)[FPW][1 << LOG2E], float2*
 template <int WAVES, int PITCH, int DBG, int MF = 0>
 __global__ __launch_bounds__(WAVES * 64) void k_stft_q(
     const float* __restrict__ x, const float* __restrict__ win, const float2* __restrict__ twp,
-    const float2* __restrict__ tws, float2* __restrict__ out, long long n_samples, int hop, int T, int tiles, int total_tiles) {
+    const float2* __restrict__ tws, float2* __restrict__ out, long long n_samples, int hop, int T, int tiles, int total_tiles, unsigned long long* __restrict__ prof = nullptr) {
+    unsigned long long acc_fft = 0, acc_bar1 = 0, acc_pre = 0, acc_store = 0, acc_bar2 = 0, ntile = 0;
     using C = FftCfg<10, 4>;
     constexpr int N = C::N, P = C::P, E = C::E, W = 2 * N, NT = WAVES * 64, FPB = 16, FPW = FPB / WAVES;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
@@ -248,6 +249,8 @@ __global__ __launch_bounds__(WAVES * 64) void k_stft_q(
     for (; tl < total_tiles; tl += gridDim.x) {
         const int clip = tl / tiles, tile = tl % tiles;
         const int t0 = tile * FPB;
+        unsigned long long c0 = 0, c1 = 0, c2 = 0, c3 = 0, c4 = 0, c5 = 0;
+        if (DBG & 8) c0 = __builtin_readcyclecounter();
         if constexpr (MF) {
             float2 v[FPW][E];
 #pragma unroll
@@ -270,8 +273,11 @@ __global__ __launch_bounds__(WAVES * 64) void k_stft_q(
             fft_frame<10, 4>(v, frames + (wave * FPW + f) * PITCH, p, tw_l);
         }
         }
+        if (DBG & 8) c1 = __builtin_readcyclecounter();
         __syncthreads();
+        if (DBG & 8) c2 = __builtin_readcyclecounter();
         prefetch(tl + gridDim.x);
+        if (DBG & 8) c3 = __builtin_readcyclecounter();
         if (t0 + tt < T) {
             float2* o = out + (long long)clip * W * T + (t0 + tt);
             for (int k = kq; k < N / 2; k += NT / FPB) {
@@ -291,7 +297,12 @@ __global__ __launch_bounds__(WAVES * 64) void k_stft_q(
                 }
             }
         }
+        if (DBG & 8) c4 = __builtin_readcyclecounter();
         __syncthreads();
+        if (DBG & 8) { c5 = __builtin_readcyclecounter(); acc_fft += c1 - c0; acc_bar1 += c2 - c1; acc_pre += c3 - c2; acc_store += c4 - c3; acc_bar2 += c5 - c4; ++ntile; }
+    }
+    if ((DBG & 8) && prof && (threadIdx.x & 63) == 0) {
+        atomicAdd(prof + 0, acc_fft); atomicAdd(prof + 1, acc_bar1); atomicAdd(prof + 2, acc_pre); atomicAdd(prof + 3, acc_store); atomicAdd(prof + 4, acc_bar2); atomicAdd(prof + 5, ntile);
     }
 }
 
@@ -300,7 +311,7 @@ __global__ __launch_bounds__(WAVES * 64) void k_stft_q(
 template <int WAVES, int PITCH, int DBG>
 __global__ __launch_bounds__(WAVES * 64) void k_stft_r(
     const float* __restrict__ x, const float* __restrict__ win, const float2* __restrict__ twp,
-    const float2* __restrict__ tws, float2* __restrict__ out, long long n_samples, int hop, int T, int tiles, int total_tiles) {
+    const float2* __restrict__ tws, float2* __restrict__ out, long long n_samples, int hop, int T, int tiles, int total_tiles, unsigned long long* __restrict__ prof = nullptr) {
     using C = FftCfg<10, 4>;
     constexpr int N = C::N, P = C::P, E = C::E, W = 2 * N, NT = WAVES * 64, FPB = 16, FPW = FPB / WAVES;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
@@ -668,6 +679,183 @@ __global__ __launch_bounds__(1024) void k_stft_w(
     }
 }
 
+
+// ======================================================================================
+// Frame-pair packed FFT: a lane holds the SAME element of TWO frames in the two halves of a
+// 64-bit register pair (SoA: re pair, im pair).  Every butterfly op is one v_pk_*_f32 on whole
+// pairs -- no half swaps, so none of the v_mov_b32 that the (re,im)-pair form needs (500 of them
+// per 2 frames in k_stft_ft16); twiddles are shared by the two frames (splat).
+// ======================================================================================
+typedef float v2f __attribute__((ext_vector_type(2)));
+struct C2 { v2f re, im; };
+__device__ __forceinline__ C2 c2add(C2 a, C2 b) { return C2{a.re + b.re, a.im + b.im}; }
+__device__ __forceinline__ C2 c2sub(C2 a, C2 b) { return C2{a.re - b.re, a.im - b.im}; }
+__device__ __forceinline__ C2 c2mi(C2 a) { return C2{a.im, -a.re}; }                       // * (-i)
+__device__ __forceinline__ C2 c2mul(C2 a, float wr, float wi) {                          // * (wr + i wi), splat
+    return C2{a.re * wr - a.im * wi, a.re * wi + a.im * wr};
+}
+__device__ __forceinline__ void c2dft4(C2& v0, C2& v1, C2& v2, C2& v3) {
+    C2 t0 = c2add(v0, v2), t1 = c2sub(v0, v2), t2 = c2add(v1, v3), t3 = c2mi(c2sub(v1, v3));
+    v0 = c2add(t0, t2); v1 = c2add(t1, t3); v2 = c2sub(t0, t2); v3 = c2sub(t1, t3);
+}
+template <int R> struct Dft2;
+template <> struct Dft2<4> { static __device__ __forceinline__ void run(C2* a) { c2dft4(a[0], a[1], a[2], a[3]); } };
+template <> struct Dft2<16> {
+    static __device__ __forceinline__ void run(C2* a) {
+        const float h = 0.70710678118654752440f, c1 = 0.92387953251128675613f, s1 = 0.38268343236508977173f;
+        C2 m[4][4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) { m[r][0] = a[r]; m[r][1] = a[r + 4]; m[r][2] = a[r + 8]; m[r][3] = a[r + 12]; c2dft4(m[r][0], m[r][1], m[r][2], m[r][3]); }
+        m[1][1] = c2mul(m[1][1], c1, -s1);
+        m[1][2] = c2mul(m[1][2], h, -h);
+        m[1][3] = c2mul(m[1][3], s1, -c1);
+        m[2][1] = c2mul(m[2][1], h, -h);
+        m[2][2] = c2mi(m[2][2]);
+        m[2][3] = c2mul(m[2][3], -h, -h);
+        m[3][1] = c2mul(m[3][1], s1, -c1);
+        m[3][2] = c2mul(m[3][2], -h, -h);
+        m[3][3] = c2mul(m[3][3], -c1, s1);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) { c2dft4(m[0][q], m[1][q], m[2][q], m[3][q]); a[q] = m[0][q]; a[q + 4] = m[1][q]; a[q + 8] = m[2][q]; a[q + 12] = m[3][q]; }
+    }
+};
+template <int LOG2N, int LOG2E, int LOG2NS, int LR>
+__device__ __forceinline__ void pass_write2(const C2* v, v2f* rp, v2f* ip, int p, const float2* tw) {
+    using C = FftCfg<LOG2N, LOG2E>;
+    constexpr int R = 1 << LR, NS = 1 << LOG2NS, NB = C::E / R;
+#pragma unroll
+    for (int b = 0; b < NB; ++b) {
+        const int j = p + b * C::P;
+        const int k = j & (NS - 1);
+        C2 a[R];
+#pragma unroll
+        for (int r = 0; r < R; ++r) a[r] = v[b + r * NB];
+        if (LOG2NS > 0) {
+#pragma unroll
+            for (int r = 1; r < R; ++r) { const float2 w = tw[(r - 1) * NS + k]; a[r] = c2mul(a[r], w.x, w.y); }
+        }
+        Dft2<R>::run(a);
+        const int base = ((j >> LOG2NS) << (LOG2NS + LR)) + k;
+        const int pb = phys(base);
+#pragma unroll
+        for (int r = 0; r < R; ++r) { const int o = phys_off<NS * R>(pb, base, r * NS); rp[o] = a[r].re; ip[o] = a[r].im; }
+    }
+}
+template <int LOG2N, int LOG2E>
+__device__ __forceinline__ void regs_read2(C2* v, const v2f* rp, const v2f* ip, int p) {
+    using C = FftCfg<LOG2N, LOG2E>;
+    const int pp = phys(p);
+#pragma unroll
+    for (int i = 0; i < C::E; ++i) { const int o = phys_off<C::P>(pp, p, i * C::P); v[i].re = rp[o]; v[i].im = ip[o]; }
+}
+template <int LOG2N, int LOG2E, int LOG2NS = 0>
+__device__ __forceinline__ void fft2_frame(C2* v, v2f* rp, v2f* ip, int p, const float2* tw) {
+    using C = FftCfg<LOG2N, LOG2E>;
+    if constexpr (LOG2NS < LOG2N) {
+        constexpr int LR = pass_log2r(LOG2N - LOG2NS, LOG2E);
+        pass_write2<LOG2N, LOG2E, LOG2NS, LR>(v, rp, ip, p, tw + twiddle_offset(LOG2N, LOG2E, LOG2NS));
+        frame_sync<C::P>();
+        if constexpr (LOG2NS + LR < LOG2N) {
+            regs_read2<LOG2N, LOG2E>(v, rp, ip, p);
+            frame_sync<C::P>();
+            fft2_frame<LOG2N, LOG2E, LOG2NS + LR>(v, rp, ip, p, tw);
+        }
+    }
+}
+
+// persistent fat kernel on the frame-pair FFT: 8 waves, wave w owns frames (2w, 2w+1) of the tile
+template <int PITCH, int DBG>
+__global__ __launch_bounds__(512) void k_stft_q2(
+    const float* __restrict__ x, const float* __restrict__ win, const float2* __restrict__ twp,
+    const float2* __restrict__ tws, float2* __restrict__ out, long long n_samples, int hop, int T, int tiles, int total_tiles) {
+    using C = FftCfg<10, 4>;
+    constexpr int N = C::N, P = C::P, E = C::E, W = 2 * N, NT = 512, FPB = 16;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    v2f* planes = reinterpret_cast<v2f*>(smem_raw);                 // 8 pair buffers x (re plane | im plane) x PITCH
+    float2* tw_l = reinterpret_cast<float2*>(planes + 8 * 2 * PITCH);
+    float2* win_l = tw_l + C::TW;
+    float2* tws_l = win_l + N;
+    const int tid = threadIdx.x;
+    for (int i = tid; i < C::TW; i += NT) tw_l[i] = twp[i];
+    for (int i = tid; i < N; i += NT) win_l[i] = reinterpret_cast<const float2*>(win)[i];
+    for (int i = tid; i <= N / 2; i += NT) tws_l[i] = tws[i];
+    __syncthreads();
+    const int wave = tid / P, p = tid % P;
+    const int tt = tid % FPB, kq = tid / FPB;
+    v2f* my_re = planes + (size_t)wave * 2 * PITCH;
+    v2f* my_im = my_re + PITCH;
+    const float* st_re = reinterpret_cast<const float*>(planes + (size_t)(tt >> 1) * 2 * PITCH) + (tt & 1);
+    const float* st_im = st_re + 2 * PITCH;
+
+    float2 xr[2][E];
+    auto prefetch = [&](int tl) {
+        if (tl >= total_tiles) return;
+        const int clip = tl / tiles, tile = tl % tiles;
+        const float* xc = x + (long long)clip * n_samples;
+        const long long first = (long long)tile * FPB * hop - N;
+        const long long last = first + (long long)(FPB - 1) * hop + W;
+        if (first >= 0 && last <= n_samples && tile * FPB + FPB <= T) {
+            const float* src = xc + first + (long long)(wave * 2) * hop + 2 * p;
+#pragma unroll
+            for (int f = 0; f < 2; ++f)
+#pragma unroll
+                for (int i = 0; i < E; ++i) xr[f][i] = *reinterpret_cast<const float2*>(src + (long long)f * hop + 2 * i * P);
+        } else {
+#pragma unroll
+            for (int f = 0; f < 2; ++f) {
+                const int t = tile * FPB + wave * 2 + f;
+                const long long s0 = (long long)t * hop - N;
+#pragma unroll
+                for (int i = 0; i < E; ++i) {
+                    const long long sidx = s0 + 2 * (p + i * P);
+                    xr[f][i].x = (t < T && sidx >= 0 && sidx < n_samples) ? xc[sidx] : 0.f;
+                    xr[f][i].y = (t < T && sidx + 1 >= 0 && sidx + 1 < n_samples) ? xc[sidx + 1] : 0.f;
+                }
+            }
+        }
+    };
+    int tl = blockIdx.x;
+    prefetch(tl);
+    for (; tl < total_tiles; tl += gridDim.x) {
+        const int clip = tl / tiles, tile = tl % tiles;
+        const int t0 = tile * FPB;
+        {
+            C2 v[E];
+#pragma unroll
+            for (int i = 0; i < E; ++i) {
+                const float2 wv = win_l[p + i * P];
+                v[i].re = v2f{xr[0][i].x * wv.x, xr[1][i].x * wv.x};
+                v[i].im = v2f{xr[0][i].y * wv.y, xr[1][i].y * wv.y};
+            }
+            fft2_frame<10, 4>(v, my_re, my_im, p, tw_l);
+        }
+        __syncthreads();
+        prefetch(tl + gridDim.x);
+        if (t0 + tt < T) {
+            float2* o = out + (long long)clip * W * T + (t0 + tt);
+            for (int k = kq; k < N / 2; k += NT / FPB) {
+                float2 xk, xn;
+                if (k == 0) {
+                    const float2 z0 = make_float2(st_re[0], st_im[0]);
+                    const float2 zc = make_float2(st_re[2 * phys(N / 2)], st_im[2 * phys(N / 2)]);
+                    if (!(DBG & 1)) {
+                    o[0] = make_float2(z0.x + z0.y, 0.f); o[(long long)N * T] = make_float2(z0.x - z0.y, 0.f);
+                    o[(long long)(N / 2) * T] = cconj(zc); o[(long long)(N + N / 2) * T] = zc; }
+                } else {
+                    const int a = 2 * phys(k), b = 2 * phys(N - k);
+                    split_pair(make_float2(st_re[a], st_im[a]), make_float2(st_re[b], st_im[b]), tws_l[k], xk, xn);
+                    if (!(DBG & 1) || xk.x == 12345.f) {
+                    o[(long long)k * T] = xk;
+                    o[(long long)(W - k) * T] = cconj(xk);
+                    o[(long long)(N - k) * T] = xn;
+                    o[(long long)(N + k) * T] = cconj(xn); }
+                }
+            }
+        }
+        __syncthreads();
+    }
+}
+
 static bool selected(const char* name) {
     const char* sel = getenv("SEL");
     return !sel || strstr(name, sel) != nullptr;
@@ -730,14 +918,22 @@ float runq(const Ctx& c, const char* name, int reps = 10) {
     int total = tiles * c.B;
     int blocks = 256; if (blocks > total) blocks = total;
     hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
-    for (int i = 0; i < 2; ++i) hipLaunchKernelGGL(kern, dim3(blocks), dim3(WAVES * 64), smem, 0, c.x, c.win, c.twp, c.tws, c.out, c.n, c.hop, c.T, tiles, total);
+    unsigned long long* prof; CK(hipMalloc(&prof, 64));
+    for (int i = 0; i < 2; ++i) hipLaunchKernelGGL(kern, dim3(blocks), dim3(WAVES * 64), smem, 0, c.x, c.win, c.twp, c.tws, c.out, c.n, c.hop, c.T, tiles, total, prof);
     CK(hipDeviceSynchronize());
+    CK(hipMemset(prof, 0, 64));
     CK(hipEventRecord(e0));
-    for (int i = 0; i < reps; ++i) hipLaunchKernelGGL(kern, dim3(blocks), dim3(WAVES * 64), smem, 0, c.x, c.win, c.twp, c.tws, c.out, c.n, c.hop, c.T, tiles, total);
+    for (int i = 0; i < reps; ++i) hipLaunchKernelGGL(kern, dim3(blocks), dim3(WAVES * 64), smem, 0, c.x, c.win, c.twp, c.tws, c.out, c.n, c.hop, c.T, tiles, total, prof);
     CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1));
     float ms; CK(hipEventElapsedTime(&ms, e0, e1)); ms /= reps;
     double bytes = (double)c.B * (4.0 * c.n + 8.0 * 2048 * c.T);
     printf("%-28s WAVES=%2d smem=%zu blocks=%6d  %.3f ms  %.0f GB/s (alg)\n", name, WAVES, smem, blocks, ms, bytes / ms / 1e6);
+    if (DBG & 8) {
+        unsigned long long h[8]; CK(hipMemcpy(h, prof, 64, hipMemcpyDeviceToHost));
+        double nt = (double)h[5];
+        printf("   per-wave per-tile cycles: fft(+win) %.0f | barrier-wait %.0f | prefetch-issue %.0f | store-issue %.0f | end-barrier %.0f\n",
+               h[0] / nt, h[1] / nt, h[2] / nt, h[3] / nt, h[4] / nt);
+    }
     return ms;
 }
 
@@ -816,6 +1012,28 @@ float runw(const Ctx& c, const char* name, int reps = 10) {
     return ms;
 }
 
+template <int PITCH, int DBG>
+float runq2(const Ctx& c, const char* name, int reps = 10) {
+    if (!selected(name)) return 0;
+    using C = FftCfg<10, 4>;
+    auto kern = k_stft_q2<PITCH, DBG>;
+    size_t smem = (size_t)(16 * PITCH + C::TW + 1024 + 513) * 8;
+    CK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+    int tiles = (c.T + 15) / 16;
+    int total = tiles * c.B;
+    int blocks = 256;
+    hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+    for (int i = 0; i < 2; ++i) hipLaunchKernelGGL(kern, dim3(blocks), dim3(512), smem, 0, c.x, c.win, c.twp, c.tws, c.out, c.n, c.hop, c.T, tiles, total);
+    CK(hipDeviceSynchronize());
+    CK(hipEventRecord(e0));
+    for (int i = 0; i < reps; ++i) hipLaunchKernelGGL(kern, dim3(blocks), dim3(512), smem, 0, c.x, c.win, c.twp, c.tws, c.out, c.n, c.hop, c.T, tiles, total);
+    CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1));
+    float ms; CK(hipEventElapsedTime(&ms, e0, e1)); ms /= reps;
+    double bytes = (double)c.B * (4.0 * c.n + 8.0 * 2048 * c.T);
+    printf("%-28s smem=%zu blocks=%6d  %.3f ms  %.0f GB/s (alg)\n", name, smem, blocks, ms, bytes / ms / 1e6);
+    return ms;
+}
+
 double checksum(const Ctx& c) {
     size_t n = (size_t)2048 * c.T * 4;   // first 4 clips
     std::vector<float2> h(n);
@@ -854,6 +1072,9 @@ int main() {
     CK(hipMemset(c.out, 0, (size_t)c.B * W * c.T * 8));
     run<16, 0, 0>(c, "base FPB16"); double cs0 = checksum(c); auto ref = snapshot(c);
     CK(hipMemset(c.out, 0, (size_t)c.B * W * c.T * 8));
+    runq2<1090, 0>(c, "pairfft"); if (selected("pairfft")) printf("  checksum match: %d  rel diff %.3e\n", checksum(c) == cs0, maxdiff(snapshot(c), ref));
+    runq2<1090, 1>(c, "pairfft no-store");
+    CK(hipMemset(c.out, 0, (size_t)c.B * W * c.T * 8));
     runw<0>(c, "wavespec"); if (selected("wavespec")) printf("  checksum match: %d  rel diff %.3e\n", checksum(c) == cs0, maxdiff(snapshot(c), ref));
     runw<1>(c, "wavespec no-store");
     {
@@ -883,6 +1104,7 @@ int main() {
     runq<8, 1090, 0, 2>(c, "persist-qmf 8 waves"); if (selected("persist-qmf 8 waves")) printf("  checksum match: %d\n", checksum(c) == cs0);
     runq<8, 1090, 1, 2>(c, "persist-qmf 8 waves no-store");
     runq<4, 1090, 0, 2>(c, "persist-qmf 4 waves");
+    runq<8, 1090, 8>(c, "persist-q 8 waves timed");
     runq<8, 1090, 0>(c, "persist-q 8 waves"); printf("  checksum match: %d\n", checksum(c) == cs0);
     CK(hipMemset(c.out, 0, (size_t)c.B * W * c.T * 8));
     runq<4, 1090, 0>(c, "persist-q 4 waves"); printf("  checksum match: %d\n", checksum(c) == cs0);

@@ -29,6 +29,23 @@ __global__ __launch_bounds__(1024) void k_linear(float2* __restrict__ out, long 
 #pragma unroll
     for (int j = 0; j < 32; ++j) { long long i = i0 + j * 1024; if (i < n) out[i] = val; }
 }
+__global__ __launch_bounds__(1024) void k_linear4(float4* __restrict__ out, long long n4) {
+    const long long i0 = (long long)blockIdx.x * 1024 * 16 + threadIdx.x;
+    const float4 val = make_float4((float)threadIdx.x, 1.f, 2.f, 3.f);
+#pragma unroll
+    for (int j = 0; j < 16; ++j) { long long i = i0 + j * 1024; if (i < n4) out[i] = val; }
+}
+// FT tile with 16-B stores: a lane writes 2 consecutive frames of one row (8 lanes per 128-B run)
+template <int NT>
+__global__ __launch_bounds__(NT) void k_tile16B(float4* __restrict__ out, int T, int tiles, int rows) {
+    const int clip = blockIdx.x / tiles, tile = blockIdx.x % tiles;
+    const int tp = threadIdx.x % 8, kq = threadIdx.x / 8;
+    const int t = tile * 16 + 2 * tp;
+    if (t >= T) return;
+    float4* o = reinterpret_cast<float4*>(reinterpret_cast<float2*>(out) + (long long)clip * rows * T + t);
+    const float4 val = make_float4((float)threadIdx.x, 1.f, 2.f, 3.f);
+    for (int k = kq; k < rows; k += NT / 8) o[(long long)k * T / 2] = val;
+}
 // MODE 2: frame-major: each frame's 2048 bins contiguous (TF layout)
 __global__ __launch_bounds__(1024) void k_tf(float2* __restrict__ out, int T, int tiles) {
     const int clip = blockIdx.x / tiles, tile = blockIdx.x % tiles;
@@ -118,6 +135,8 @@ int main() {
     float2* out; CK(hipMalloc(&out, n * 8)); CK(hipMemset(out, 0, n * 8));
     const double bytes = (double)n * 8;
     timeit("linear float2 stores", bytes, [&] { hipLaunchKernelGGL(k_linear, dim3((unsigned)((n + 32767) / 32768)), dim3(1024), 0, 0, out, n); });
+    timeit("linear float4 stores", bytes, [&] { hipLaunchKernelGGL(k_linear4, dim3((unsigned)((n / 2 + 16383) / 16384)), dim3(1024), 0, 0, (float4*)out, n / 2); });
+    timeit("FT tile, 16-B stores (2 frames per lane)", bytes, [&] { hipLaunchKernelGGL((k_tile16B<1024>), dim3(27 * B), dim3(1024), 0, 0, (float4*)out, T, 27, rows); });
     timeit("TF layout (frame-major 16 KB runs)", bytes, [&] { hipLaunchKernelGGL(k_tf, dim3(27 * B), dim3(1024), 0, 0, out, T, 27); });
     timeit("FT tile RUN=16 (128 B runs) 1024 thr", bytes, [&] { hipLaunchKernelGGL((k_tile<16, 1024>), dim3(27 * B), dim3(1024), 0, 0, out, T, 27, rows, 0); });
     timeit("FT tile RUN=16 (128 B) xcd-clip map", bytes, [&] { hipLaunchKernelGGL((k_tile<16, 1024>), dim3(27 * B), dim3(1024), 0, 0, out, T, 27, rows, 1); });

@@ -255,6 +255,82 @@ __global__ __launch_bounds__(kFatWaves * 64) void k_stft_ft16(
 }
 
 // ---------------------------------------------------------------------------------
+// forward, frame-major layout (ZAFX_LAYOUT_TF), persistent and barrier free
+// ---------------------------------------------------------------------------------
+// Every frame's 2 W bins are contiguous in this layout, so a frame never has to meet its
+// neighbours: one wavefront owns a frame from load to store (private LDS exchange buffer, 512-B
+// coalesced stores) and the 8 wavefronts of the persistent workgroup drift apart -- the store
+// issue of one overlaps the butterflies of another.  No s_barrier after the table staging.
+template <int LOG2N, int LOG2E, bool ALIGNED>
+__global__ __launch_bounds__(512) void k_stft_tf(
+    const float* __restrict__ x, const float* __restrict__ win, const float2* __restrict__ twp,
+    const float2* __restrict__ tws, float2* __restrict__ out, long long n_samples, int hop, int T, long long total_frames) {
+    using C = FftCfg<LOG2N, LOG2E>;
+    static_assert(C::P == 64, "one wavefront per frame");
+    constexpr int N = C::N, P = C::P, E = C::E, W = 2 * N, WAVES = 8, NT = WAVES * 64;   // 8 fat waves (see k_stft_ft16)
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    float2* frames = reinterpret_cast<float2*>(smem_raw);
+    float2* tw_l = frames + WAVES * C::PITCH;
+    float2* win_l = tw_l + C::TW;
+    float2* tws_l = win_l + N;
+    const int tid = threadIdx.x;
+    for (int i = tid; i < C::TW; i += NT) tw_l[i] = twp[i];
+    for (int i = tid; i < N; i += NT) win_l[i] = reinterpret_cast<const float2*>(win)[i];
+    for (int i = tid; i <= N / 2; i += NT) tws_l[i] = tws[i];
+    __syncthreads();
+    const int wave = tid / P, p = tid % P;
+    float2* buf = frames + wave * C::PITCH;
+    const long long stride = (long long)gridDim.x * WAVES;
+    for (long long g = (long long)blockIdx.x * WAVES + wave; g < total_frames; g += stride) {
+        const long long clip = g / T;
+        const int t = (int)(g - clip * T);
+        const float* xc = x + clip * n_samples;
+        const long long s0 = (long long)t * hop - N;
+        float2 v[E];
+        if (ALIGNED && s0 >= 0 && s0 + W <= n_samples) {
+#pragma unroll
+            for (int i = 0; i < E; ++i) {
+                const int n = p + i * P;
+                const float2 xv = *reinterpret_cast<const float2*>(xc + s0 + 2 * n);
+                const float2 wv = win_l[n];
+                v[i] = make_float2(xv.x * wv.x, xv.y * wv.y);
+            }
+        } else {
+#pragma unroll
+            for (int i = 0; i < E; ++i) {
+                const int n = p + i * P;
+                const long long s = s0 + 2 * n;
+                const float2 wv = win_l[n];
+                const float a = (s >= 0 && s < n_samples) ? xc[s] : 0.f;
+                const float b = (s + 1 >= 0 && s + 1 < n_samples) ? xc[s + 1] : 0.f;
+                v[i] = make_float2(a * wv.x, b * wv.y);
+            }
+        }
+        fft_frame<LOG2N, LOG2E>(v, buf, p, tw_l);
+        float2* o = out + g * W;
+#pragma unroll
+        for (int i = 0; i < E / 2; ++i) {
+            const int k = p + i * P;
+            if (k == 0) {
+                const float2 z0 = buf[0], zc = buf[phys(N / 2)];
+                o[0] = make_float2(z0.x + z0.y, 0.f);
+                o[N] = make_float2(z0.x - z0.y, 0.f);
+                o[N / 2] = cconj(zc);
+                o[N + N / 2] = zc;
+            } else {
+                float2 xk, xn;
+                split_pair(buf[phys(k)], buf[phys(N - k)], tws_l[k], xk, xn);
+                o[k] = xk;
+                o[W - k] = cconj(xk);
+                o[N - k] = xn;
+                o[N + k] = cconj(xn);
+            }
+        }
+        frame_sync<P>();   // the split reads of this frame precede the next frame's first pass writes
+    }
+}
+
+// ---------------------------------------------------------------------------------
 // inverse
 // ---------------------------------------------------------------------------------
 // Build the packed half-length spectrum of one (k, N-k) pair from the four two-sided
@@ -496,12 +572,41 @@ static hipError_t run_stft_fat(const zafx_plan& pl, const float* x, float2* out,
     return hipGetLastError();
 }
 
+constexpr bool stft_use_tf(int log2n, int layout) {
+    return layout == ZAFX_LAYOUT_TF && log2n >= 7 && log2n <= 10;   // one wavefront per frame
+}
+
+template <int LOG2N, bool ALIGNED>
+static hipError_t run_stft_tf(const zafx_plan& pl, const float* x, float2* out, int64_t n_clips, int64_t n_samples, int T) {
+    constexpr int LOG2E = default_log2e(LOG2N);
+    using C = FftCfg<LOG2N, LOG2E>;
+    constexpr size_t SMEM = (size_t)(8 * C::PITCH + C::TW + C::N + C::N / 2 + 1) * 8;
+    static_assert(SMEM <= (size_t)kMaxLdsBytes, "frame-major STFT tables + buffers exceed LDS");
+    auto kern = k_stft_tf<LOG2N, LOG2E, ALIGNED>;
+    static bool attr_set[64] = {};
+    if (!attr_set[pl.device]) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)SMEM);
+        if (e != hipSuccess) return e;
+        attr_set[pl.device] = true;
+    }
+    const long long total = (long long)T * n_clips;
+    if (total <= 0) return hipSuccess;
+    const int per_cu = (int)std::min<size_t>(2, (size_t)kMaxLdsBytes / SMEM);
+    const long long grid = std::min<long long>((total + 7) / 8, (long long)pl.n_cus * std::max(per_cu, 1));
+    hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(512), SMEM, pl.stream, x, pl.d_window, pl.d_tw_pass, pl.d_tw_aux, out,
+                       (long long)n_samples, pl.H, T, total);
+    return hipGetLastError();
+}
+
 template <int LOG2N, int LAYOUT>
 static hipError_t run_stft(const zafx_plan& pl, const float* x, float2* out, int64_t n_clips, int64_t n_samples, int T) {
+    const bool aligned = (n_samples % 2 == 0) && (pl.H % 2 == 0) && (reinterpret_cast<uintptr_t>(x) % 8 == 0);
     if constexpr (stft_use_fat(LOG2N, LAYOUT)) {
-        const bool aligned = (n_samples % 2 == 0) && (pl.H % 2 == 0) && (reinterpret_cast<uintptr_t>(x) % 8 == 0);
         return aligned ? run_stft_fat<LOG2N, true>(pl, x, out, n_clips, n_samples, T)
                        : run_stft_fat<LOG2N, false>(pl, x, out, n_clips, n_samples, T);
+    } else if constexpr (stft_use_tf(LOG2N, LAYOUT)) {
+        return aligned ? run_stft_tf<LOG2N, true>(pl, x, out, n_clips, n_samples, T)
+                       : run_stft_tf<LOG2N, false>(pl, x, out, n_clips, n_samples, T);
     } else {
         constexpr int LOG2E = default_log2e(LOG2N);
         constexpr int FPB = stft_fpb(LOG2N, LAYOUT);
@@ -585,7 +690,9 @@ static hipError_t run_istft(const zafx_plan& pl, const float2* spec, float* y, i
 
 bool stft_supported(int log2n) { return log2n >= 5 && log2n <= 12; }
 int stft_frames_per_block(int log2n, int layout) { return stft_fpb(log2n, layout); }
-const char* stft_kernel_name(int log2n, int layout) { return stft_use_fat(log2n, layout) ? "k_stft_ft16" : "k_stft"; }
+const char* stft_kernel_name(int log2n, int layout) {
+    return stft_use_fat(log2n, layout) ? "k_stft_ft16" : stft_use_tf(log2n, layout) ? "k_stft_tf" : "k_stft";
+}
 const char* istft_kernel_name(int log2n, int layout) { return stft_use_fat(log2n, layout) ? "k_istft_ft16" : "k_istft"; }
 
 hipError_t launch_stft(const zafx_plan& pl, const float* x, float2* out, int64_t n_clips, int64_t n_samples, int T) {

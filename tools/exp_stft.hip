@@ -246,6 +246,16 @@ __global__ __launch_bounds__(WAVES * 64) void k_stft_q(
     };
     int tl = blockIdx.x;
     prefetch(tl);
+    if (DBG & 32) {   // stagger the CUs' load/FFT/store phases: (block % 4) quarter periods
+        const unsigned long long t_start = __builtin_readcyclecounter();
+        const unsigned long long wait = (unsigned long long)(blockIdx.x & 3) * 9500ull;
+        while (__builtin_readcyclecounter() - t_start < wait) __builtin_amdgcn_s_sleep(8);
+    }
+    if (DBG & 64) {   // 2-phase stagger, half a period
+        const unsigned long long t_start = __builtin_readcyclecounter();
+        const unsigned long long wait = (unsigned long long)(blockIdx.x & 1) * 19000ull;
+        while (__builtin_readcyclecounter() - t_start < wait) __builtin_amdgcn_s_sleep(8);
+    }
     for (; tl < total_tiles; tl += gridDim.x) {
         const int clip = tl / tiles, tile = tl % tiles;
         const int t0 = tile * FPB;
@@ -1104,6 +1114,8 @@ int main() {
     runq<8, 1090, 0, 2>(c, "persist-qmf 8 waves"); if (selected("persist-qmf 8 waves")) printf("  checksum match: %d\n", checksum(c) == cs0);
     runq<8, 1090, 1, 2>(c, "persist-qmf 8 waves no-store");
     runq<4, 1090, 0, 2>(c, "persist-qmf 4 waves");
+    runq<8, 1090, 32>(c, "persist-q 8 waves stagger4");
+    runq<8, 1090, 64>(c, "persist-q 8 waves stagger2");
     runq<8, 1090, 8>(c, "persist-q 8 waves timed");
     runq<8, 1090, 0>(c, "persist-q 8 waves"); printf("  checksum match: %d\n", checksum(c) == cs0);
     CK(hipMemset(c.out, 0, (size_t)c.B * W * c.T * 8));

@@ -119,6 +119,21 @@ __global__ __launch_bounds__(NT) void k_tile_read(const float2* __restrict__ in,
     if (acc == 12345.f) sink[0] = acc;
 }
 
+
+// MODE 6: store-only, persistent on a SUBSET of the CUs: is the per-CU store rate capped?
+template <int NT>
+__global__ __launch_bounds__(NT) void k_tile_p(float2* __restrict__ out, int T, int tiles, int rows, int total) {
+    for (int b = blockIdx.x; b < total; b += gridDim.x) {
+        const int clip = b / tiles, tile = b % tiles;
+        const int tt = threadIdx.x % 16, kq = threadIdx.x / 16;
+        const int t = tile * 16 + tt;
+        if (t >= T) continue;
+        float2* o = out + (long long)clip * rows * T + t;
+        const float2 val = make_float2((float)threadIdx.x, (float)b);
+        for (int k = kq; k < rows; k += NT / 16) o[(long long)k * T] = val;
+    }
+}
+
 template <class F> void timeit(const char* name, double bytes, F launch) {
     hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
     launch(); launch(); CK(hipDeviceSynchronize());
@@ -161,6 +176,10 @@ int main() {
         timeit("FT tile READ RUN=16 256 thr unr 16", bytes, [&] { hipLaunchKernelGGL((k_tile_read<16, 256, 16>), dim3(27 * B), dim3(256), 0, 0, out, sink, T, 27, rows); });
         timeit("FT tile READ RUN=32 1024 thr unr 8", bytes, [&] { hipLaunchKernelGGL((k_tile_read<32, 1024, 8>), dim3(14 * B), dim3(1024), 0, 0, out, sink, T, 14, rows); });
         timeit("FT tile READ RUN=8 1024 thr unr 8", bytes, [&] { hipLaunchKernelGGL((k_tile_read<8, 1024, 8>), dim3(54 * B), dim3(1024), 0, 0, out, sink, T, 54, rows); });
+    }
+    for (int g : {32, 64, 128, 256, 512}) {
+        char nm[96]; snprintf(nm, 96, "store-only persistent, %d WGs x 512 thr (1/8 of the data)", g);
+        timeit(nm, bytes / 8, [&] { hipLaunchKernelGGL((k_tile_p<512>), dim3(g), dim3(512), 0, 0, out, T, 27, rows, 27 * B / 8); });
     }
     // padded T = 512 (4 KB row pitch): does the 3456-B pitch matter?
     {

@@ -259,6 +259,8 @@ __global__ __launch_bounds__(WAVES * 64) void k_stft_q(
     for (; tl < total_tiles; tl += gridDim.x) {
         const int clip = tl / tiles, tile = tl % tiles;
         const int t0 = tile * FPB;
+        const float2* tw_i = tw_l; const float2* win_i = win_l; const float2* tws_i = tws_l;
+        if (DBG & 128) { int zero = 0; asm volatile("" : "+s"(zero)); tw_i += zero; win_i += zero; tws_i += zero; }
         unsigned long long c0 = 0, c1 = 0, c2 = 0, c3 = 0, c4 = 0, c5 = 0;
         if (DBG & 8) c0 = __builtin_readcyclecounter();
         if constexpr (MF) {
@@ -267,20 +269,20 @@ __global__ __launch_bounds__(WAVES * 64) void k_stft_q(
             for (int f = 0; f < FPW; ++f)
 #pragma unroll
                 for (int i = 0; i < E; ++i) {
-                    const float2 wv = win_l[p + i * P];
+                    const float2 wv = win_i[p + i * P];
                     v[f][i] = make_float2(xr[f][i].x * wv.x, xr[f][i].y * wv.y);
                 }
-            fft_frames<10, 4, FPW>(v, frames + (wave * FPW) * PITCH, PITCH, p, tw_l);
+            fft_frames<10, 4, FPW>(v, frames + (wave * FPW) * PITCH, PITCH, p, tw_i);
         } else {
 #pragma unroll
         for (int f = 0; f < FPW; ++f) {
             float2 v[E];
 #pragma unroll
             for (int i = 0; i < E; ++i) {
-                const float2 wv = win_l[p + i * P];
+                const float2 wv = win_i[p + i * P];
                 v[i] = make_float2(xr[f][i].x * wv.x, xr[f][i].y * wv.y);
             }
-            fft_frame<10, 4>(v, frames + (wave * FPW + f) * PITCH, p, tw_l);
+            fft_frame<10, 4>(v, frames + (wave * FPW + f) * PITCH, p, tw_i);
         }
         }
         if (DBG & 8) c1 = __builtin_readcyclecounter();
@@ -298,7 +300,7 @@ __global__ __launch_bounds__(WAVES * 64) void k_stft_q(
                     o[0] = make_float2(z0.x + z0.y, 0.f); o[(long long)N * T] = make_float2(z0.x - z0.y, 0.f);
                     o[(long long)(N / 2) * T] = cconj(zc); o[(long long)(N + N / 2) * T] = zc; }
                 } else {
-                    split_pair(fb[phys(k)], fb[phys(N - k)], tws_l[k], xk, xn);
+                    split_pair(fb[phys(k)], fb[phys(N - k)], tws_i[k], xk, xn);
                     if (!(DBG & 1) || xk.x == 12345.f) {
                     o[(long long)k * T] = xk;
                     o[(long long)(W - k) * T] = cconj(xk);
@@ -1114,8 +1116,8 @@ int main() {
     runq<8, 1090, 0, 2>(c, "persist-qmf 8 waves"); if (selected("persist-qmf 8 waves")) printf("  checksum match: %d\n", checksum(c) == cs0);
     runq<8, 1090, 1, 2>(c, "persist-qmf 8 waves no-store");
     runq<4, 1090, 0, 2>(c, "persist-qmf 4 waves");
-    runq<8, 1090, 32>(c, "persist-q 8 waves stagger4");
-    runq<8, 1090, 64>(c, "persist-q 8 waves stagger2");
+    runq<16, 1090, 128>(c, "persist-q 16 waves nolicm");
+    runq<8, 1090, 128>(c, "persist-q 8 waves nolicm");
     runq<8, 1090, 8>(c, "persist-q 8 waves timed");
     runq<8, 1090, 0>(c, "persist-q 8 waves"); printf("  checksum match: %d\n", checksum(c) == cs0);
     CK(hipMemset(c.out, 0, (size_t)c.B * W * c.T * 8));

@@ -6,8 +6,10 @@
 #include <algorithm>
 #include <cmath>
 #include <cstring>
+#include <map>
 #include <mutex>
 #include <string>
+#include <utility>
 
 #include "zafx_internal.hpp"
 
@@ -15,6 +17,17 @@ namespace zafx {
 
 static thread_local std::string g_err;
 void set_error(const std::string& msg) { g_err = msg; }
+
+hipError_t ensure_dynamic_lds(const void* kernel, int device, size_t bytes) {
+    static std::mutex mu;
+    static std::map<std::pair<const void*, int>, size_t> granted;
+    std::lock_guard<std::mutex> lk(mu);
+    size_t& have = granted[std::make_pair(kernel, device)];
+    if (have >= bytes) return hipSuccess;
+    hipError_t e = hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+    if (e == hipSuccess) have = bytes;
+    return e;
+}
 
 static int fail(const std::string& where, hipError_t e) {
     set_error(where + ": " + hipGetErrorString(e));
@@ -296,6 +309,11 @@ int zafx_plan_create(zafx_plan** out, int device, int kind, const zafx_params* p
     if (!out || !params) return fail_msg("null argument");
     if (params->struct_size != (int32_t)sizeof(zafx_params)) return fail_msg("zafx_params.struct_size mismatch");
     if (params->layout != ZAFX_LAYOUT_FT && params->layout != ZAFX_LAYOUT_TF) return fail_msg("bad layout");
+    {
+        int n_dev = 0;
+        ZAFX_HIP(hipGetDeviceCount(&n_dev));
+        if (device < 0 || device >= n_dev) return fail_msg("device index out of range");
+    }
     zafx_plan* pl = new zafx_plan();
     pl->device = device;
     pl->kind = kind;

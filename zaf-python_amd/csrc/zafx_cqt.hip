@@ -163,12 +163,7 @@ static hipError_t run_cqt(const zafx_plan& pl, const float* x, float* out, int64
         set_error("cqt: kernel matrix (bins / non-zeros) too large for LDS at this fft_length");
         return hipErrorInvalidValue;
     }
-    static size_t attr_set[64] = {};
-    if (attr_set[pl.device] < smem) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
-        if (e != hipSuccess) return e;
-        attr_set[pl.device] = smem;
-    }
+    if (hipError_t e = ensure_dynamic_lds(reinterpret_cast<const void*>(kern), pl.device, smem); e != hipSuccess) return e;
     const int tiles = (T + kCqtFramesPerBlock - 1) / kCqtFramesPerBlock;
     const long long blocks = (long long)tiles * n_clips;
     if (blocks <= 0) return hipSuccess;

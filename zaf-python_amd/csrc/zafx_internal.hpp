@@ -98,4 +98,7 @@ int mdct_frames_per_block(int log2nf, int layout);
 
 void set_error(const std::string& msg);
 
+// Raise a kernel's dynamic-LDS limit to `bytes` on `device` (once per (kernel, device); thread safe).
+hipError_t ensure_dynamic_lds(const void* kernel, int device, size_t bytes);
+
 }  // namespace zafx

@@ -337,12 +337,7 @@ static hipError_t run_mdct_p(const zafx_plan& pl, const float* x, float* out, in
     constexpr int LOG2E = default_log2e(LOG2NF);
     using G = MdctPCfg<LOG2NF, LOG2E>;
     auto kern = k_mdct_ft32<LOG2NF, LOG2E>;
-    static bool attr_set[64] = {};
-    if (!attr_set[pl.device]) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)G::SMEM);
-        if (e != hipSuccess) return e;
-        attr_set[pl.device] = true;
-    }
+    if (hipError_t e = ensure_dynamic_lds(reinterpret_cast<const void*>(kern), pl.device, G::SMEM); e != hipSuccess) return e;
     const int tiles = (T + kMdctTile - 1) / kMdctTile;
     const long long total = (long long)tiles * n_clips;
     if (total <= 0) return hipSuccess;
@@ -362,12 +357,7 @@ static hipError_t run_mdct(const zafx_plan& pl, const float* x, float* out, int6
         constexpr int FPB = mdct_fpb(LOG2NF, LAYOUT);
         using G = MdctCfg<LOG2NF, LOG2E, FPB>;
         auto kern = k_mdct<LOG2NF, LOG2E, FPB, LAYOUT>;
-        static bool attr_set[64] = {};
-        if (!attr_set[pl.device]) {
-            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)G::SMEM_FWD);
-            if (e != hipSuccess) return e;
-            attr_set[pl.device] = true;
-        }
+        if (hipError_t e = ensure_dynamic_lds(reinterpret_cast<const void*>(kern), pl.device, G::SMEM_FWD); e != hipSuccess) return e;
         const int tiles = (T + FPB - 1) / FPB;
         const long long blocks = (long long)tiles * n_clips;
         if (blocks <= 0) return hipSuccess;
@@ -404,12 +394,7 @@ static hipError_t run_imdct(const zafx_plan& pl, const float* coefs, float* y, i
     constexpr size_t SMEM = (size_t)(FPB * C::PITCH + C::TW + C::N) * 8 + (size_t)C::N * 16;   // frames + twiddles + g_m + window
     static_assert(SMEM <= (size_t)kMaxLdsBytes, "IMDCT tile does not fit LDS");
     auto kern = k_imdct<LOG2NF, LOG2E, FPB, NSLOT, LAYOUT>;
-    static bool attr_set[64] = {};
-    if (!attr_set[pl.device]) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)SMEM);
-        if (e != hipSuccess) return e;
-        attr_set[pl.device] = true;
-    }
+    if (hipError_t e = ensure_dynamic_lds(reinterpret_cast<const void*>(kern), pl.device, SMEM); e != hipSuccess) return e;
     constexpr int OWNED = FPB - 1;
     const int tiles = (T + OWNED - 1) / OWNED;
     const long long total = (long long)tiles * n_clips;

@@ -233,12 +233,7 @@ static hipError_t run_mel(const zafx_plan& pl, const float* x, float* out, int64
         set_error("mel/mfcc: filterbank was packed for a different workgroup size");
         return hipErrorInvalidValue;
     }
-    static bool attr_set[64] = {};
-    if (!attr_set[pl.device]) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)G::SMEM);
-        if (e != hipSuccess) return e;
-        attr_set[pl.device] = true;
-    }
+    if (hipError_t e = ensure_dynamic_lds(reinterpret_cast<const void*>(kern), pl.device, G::SMEM); e != hipSuccess) return e;
     const int tiles = (T + G::FPB - 1) / G::FPB;
     const long long total = (long long)tiles * n_clips;
     if (total <= 0) return hipSuccess;

@@ -556,12 +556,7 @@ static hipError_t run_stft_fat(const zafx_plan& pl, const float* x, float2* out,
     constexpr int LOG2E = default_log2e(LOG2N);
     using F = FatCfg<LOG2N, LOG2E>;
     auto kern = k_stft_ft16<LOG2N, LOG2E, ALIGNED>;
-    static bool attr_set[64] = {};
-    if (!attr_set[pl.device]) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)F::SMEM);
-        if (e != hipSuccess) return e;
-        attr_set[pl.device] = true;
-    }
+    if (hipError_t e = ensure_dynamic_lds(reinterpret_cast<const void*>(kern), pl.device, F::SMEM); e != hipSuccess) return e;
     const int tiles = (T + kFatFrames - 1) / kFatFrames;
     const long long total = (long long)tiles * n_clips;
     if (total <= 0) return hipSuccess;
@@ -583,12 +578,7 @@ static hipError_t run_stft_tf(const zafx_plan& pl, const float* x, float2* out, 
     constexpr size_t SMEM = (size_t)(8 * C::PITCH + C::TW + C::N + C::N / 2 + 1) * 8;
     static_assert(SMEM <= (size_t)kMaxLdsBytes, "frame-major STFT tables + buffers exceed LDS");
     auto kern = k_stft_tf<LOG2N, LOG2E, ALIGNED>;
-    static bool attr_set[64] = {};
-    if (!attr_set[pl.device]) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)SMEM);
-        if (e != hipSuccess) return e;
-        attr_set[pl.device] = true;
-    }
+    if (hipError_t e = ensure_dynamic_lds(reinterpret_cast<const void*>(kern), pl.device, SMEM); e != hipSuccess) return e;
     const long long total = (long long)T * n_clips;
     if (total <= 0) return hipSuccess;
     const int per_cu = (int)std::min<size_t>(2, (size_t)kMaxLdsBytes / SMEM);
@@ -612,12 +602,7 @@ static hipError_t run_stft(const zafx_plan& pl, const float* x, float2* out, int
         constexpr int FPB = stft_fpb(LOG2N, LAYOUT);
         using S = StftCfg<LOG2N, LOG2E, FPB>;
         auto kern = k_stft<LOG2N, LOG2E, FPB, LAYOUT>;
-        static bool attr_set[64] = {};
-        if (!attr_set[pl.device]) {
-            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)S::SMEM);
-            if (e != hipSuccess) return e;
-            attr_set[pl.device] = true;
-        }
+        if (hipError_t e = ensure_dynamic_lds(reinterpret_cast<const void*>(kern), pl.device, S::SMEM); e != hipSuccess) return e;
         const int tiles = (T + FPB - 1) / FPB;
         const long long blocks = (long long)tiles * n_clips;
         if (blocks <= 0) return hipSuccess;
@@ -633,12 +618,7 @@ static hipError_t run_istft_fat(const zafx_plan& pl, const float2* spec, float* 
     using F = FatCfg<LOG2N, LOG2E>;
     constexpr int WAVES = 16;
     auto kern = k_istft_ft16<LOG2N, LOG2E, WAVES>;
-    static bool attr_set[64] = {};
-    if (!attr_set[pl.device]) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)F::SMEM);
-        if (e != hipSuccess) return e;
-        attr_set[pl.device] = true;
-    }
+    if (hipError_t e = ensure_dynamic_lds(reinterpret_cast<const void*>(kern), pl.device, F::SMEM); e != hipSuccess) return e;
     const int W = 2 << LOG2N;
     const int halo = (W + pl.H - 1) / pl.H - 1;
     const int owned = kFatFrames - halo;
@@ -664,12 +644,7 @@ static hipError_t run_istft(const zafx_plan& pl, const float2* spec, float* y, i
     constexpr int FPB = stft_fpb(LOG2N, ZAFX_LAYOUT_FT);
     using S = StftCfg<LOG2N, LOG2E, FPB>;
     auto kern = k_istft<LOG2N, LOG2E, FPB, LAYOUT>;
-    static bool attr_set[64] = {};
-    if (!attr_set[pl.device]) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)S::SMEM);
-        if (e != hipSuccess) return e;
-        attr_set[pl.device] = true;
-    }
+    if (hipError_t e = ensure_dynamic_lds(reinterpret_cast<const void*>(kern), pl.device, S::SMEM); e != hipSuccess) return e;
     const int W = 2 << LOG2N;
     const int halo = (W + pl.H - 1) / pl.H - 1;
     const int owned = FPB - halo;

@@ -257,7 +257,7 @@ def _cached(key, factory):
         plan = _cache.get(key)
         if plan is None:
             if len(_cache) >= _CACHE_MAX:
-                _cache.pop(next(iter(_cache))).destroy()
+                _cache.pop(next(iter(_cache)))   # freed by Plan.__del__ once no caller still holds it
             plan = factory()
             _cache[key] = plan
         return plan

@@ -380,3 +380,25 @@ def test_pcm_ingest(zafx, dtype, channels):
         assert relerr(spec[c], orc.stft(ref[c], ham, 1024)) <= TOL_FFT
     with pytest.raises(ValueError):
         zafx.pcm_to_mono(pcm.astype(np.float32))
+
+
+# ------------------------------------------------------------------ degenerate sizes
+def test_empty_and_one_sample_clips(zafx):
+    """N = 0 is legal in the reference (one all-zero frame for stft/mdct, no frame for the CQT)."""
+    ham = zafx.hamming(2048)
+    kbd = zafx.kaiser_bessel_derived(2048)
+    empty = np.zeros(0)
+    ref = orc.stft(empty, ham, 1024)
+    got = zafx.stft(empty, ham, 1024)
+    assert got.shape == ref.shape == (2048, 1) and not got.any()
+    m = zafx.mdct(empty, kbd)
+    assert m.shape == orc.mdct(empty, kbd).shape == (1024, 1) and not m.any()
+    assert zafx.imdct(m, kbd).shape == orc.imdct(np.zeros((1024, 1)), kbd).shape == (0,)
+    assert zafx.istft(got, ham, 1024).shape == orc.istft(ref, ham, 1024).shape == (0,)
+    fb = zafx.melfilterbank(44100, 2048, 128)
+    assert zafx.melspectrogram(empty, ham, 1024, fb).shape == (128, 1)
+    ck = zafx.cqtkernel(4000, 12, 200, 1600)
+    assert zafx.cqtspectrogram(empty, 4000, 50, ck).shape == orc.cqtspectrogram(empty, 4000, 50, ck).shape == (36, 0)
+    assert zafx.cqtspectrogram(np.ones(79), 4000, 50, ck).shape == (36, 0)   # shorter than one step
+    one = np.array([0.5])
+    assert relerr(zafx.stft(one, ham, 1024), orc.stft(one, ham, 1024)) <= TOL_FFT

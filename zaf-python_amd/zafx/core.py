@@ -297,8 +297,6 @@ def _as_clips(audio, ndim_name="audio_signal"):
         raise ValueError(f"{ndim_name} batch must be 2-D (clips, samples)")
     if np.iscomplexobj(a):
         raise ValueError(f"{ndim_name} must be real")
-    if a.shape[1] < 1:
-        raise ValueError(f"{ndim_name} must hold at least one sample")
     return np.ascontiguousarray(a, dtype=np.float32)
 
 

@@ -402,3 +402,18 @@ def test_empty_and_one_sample_clips(zafx):
     assert zafx.cqtspectrogram(np.ones(79), 4000, 50, ck).shape == (36, 0)   # shorter than one step
     one = np.array([0.5])
     assert relerr(zafx.stft(one, ham, 1024), orc.stft(one, ham, 1024)) <= TOL_FFT
+
+
+# ------------------------------------------------------------------ in-process sharder (threads, one plan per slot)
+def test_run_sharded_threads(zafx):
+    """Two shard slots driven from two host threads (both on GPU 0 here; on a node each slot is
+    another device): concatenated shards equal the unsharded result bit for bit."""
+    x = np.stack([synth_clip(13, c, 50000) for c in range(9)])
+    ham = zafx.hamming(2048)
+    whole = zafx.stft_batch(x, ham, 1024)
+    parts = zafx.run_sharded(zafx.stft_batch, x, [0, 0], ham, 1024)
+    assert parts.shape == whole.shape and np.array_equal(parts, whole)
+    fb = zafx.melfilterbank(44100, 2048, 128)
+    assert np.array_equal(zafx.run_sharded(zafx.mfcc_batch, x, [0, 0, 0], ham, 1024, fb, 20), zafx.mfcc_batch(x, ham, 1024, fb, 20))
+    one = zafx.run_sharded(zafx.stft_batch, x[:1], [0, 0], ham, 1024)   # fewer clips than slots
+    assert np.array_equal(one, whole[:1])

@@ -108,3 +108,27 @@ def test_fft_core_emulated_on_cpu(tmp_path):
     out = subprocess.run([str(exe)], capture_output=True, text=True, check=True).stdout
     worst = float(out.strip().splitlines()[-1].split("=")[1])
     assert worst < 5e-7, out
+
+
+def test_run_sharded_with_a_fake_device_step():
+    """The in-process sharder (threads + block partition) with a CPU stand-in for the device call."""
+    calls = []
+
+    def fake_batch(clips, scale, device=0):
+        calls.append((device, clips.shape[0]))
+        return clips * scale + device * 0.0
+
+    x = np.arange(7 * 5, dtype=np.float32).reshape(7, 5)
+    out = zafx.run_sharded(fake_batch, x, [0, 1, 2], 2.0)
+    assert np.array_equal(out, x * 2.0)
+    assert sorted(calls) == [(0, 2), (1, 2), (2, 3)]
+    one = zafx.run_sharded(fake_batch, x[:1], [0, 1], 3.0)
+    assert np.array_equal(one, x[:1] * 3.0)
+
+    def failing(clips, device=0):
+        raise RuntimeError("device lost")
+
+    with pytest.raises(RuntimeError):
+        zafx.run_sharded(failing, x, [0, 1])
+    with pytest.raises(ValueError):
+        zafx.run_sharded(fake_batch, x, [], 1.0)

@@ -46,6 +46,8 @@ def make_workload(kind, device, layout="FT"):
     T = 432
     if kind == "cqt":
         B, N, T = 128, 1323000, 750
+    if kind == "dct":
+        B, N, T = 16384, 1024, 1
     base = np.stack([synth(0, c, N) for c in range(distinct)])
     d_base = zafx.DeviceBuffer.from_host(base, device)
     d_x = zafx.DeviceBuffer((B, N), np.float32, device)
@@ -92,6 +94,10 @@ def make_workload(kind, device, layout="FT"):
         wl.update(plan=plan, d_in=d_x, n_in=N, bytes_per_launch=B * (4 * N + 4 * 144 * T),
                   flops_per_launch=B * T * 5.0 * 32768 * 15,
                   desc="cqtspectrogram: 128 clips x 30 s @ 44.1 kHz per GPU, 24 bins/octave 55-3520 Hz, 25 frames/s")
+    elif kind == "dct":
+        plan = zafx.linear_plan(zafx.dct_matrix(N, 2), device=device)
+        wl.update(plan=plan, d_in=d_x, n_in=N, bytes_per_launch=B * 8 * N + 4 * N * N, flops_per_launch=2.0 * N * N * B,
+                  desc="zaf.dct type 2 of 16384 vectors x 1024 samples as one f32 MFMA GEMM (SURVEY 8f rank 3)")
     else:
         raise SystemExit(f"unknown --kind {kind}")
     wl["d_out"] = zafx.DeviceBuffer(plan.out_shape(B, wl["n_in"]), plan.out_dtype, device)

@@ -56,7 +56,9 @@ enum zafx_kind {
     ZAFX_MEL = 5,    /* in (B, N) f32            -> out (B, n_filters, T) or (B, T, n_filters)     */
     ZAFX_MFCC = 6,   /* in (B, N) f32            -> out (B, n_coefs, T)   or (B, T, n_coefs)       */
     ZAFX_CQT = 7,    /* in (B, N) f32            -> out (B, n_bins, T)    or (B, T, n_bins)        */
-    ZAFX_CHROMA = 8  /* in (B, N) f32            -> out (B, octave_resolution, T) or transposed    */
+    ZAFX_CHROMA = 8, /* in (B, N) f32            -> out (B, octave_resolution, T) or transposed    */
+    ZAFX_LINEAR = 9  /* in (B, window_length) f32 -> out (B, n_filters) f32: y = M x per clip; carries the
+                        orthonormal dct / dst types I-IV of zaf.py:703-981         */
 };
 
 enum zafx_layout {
@@ -70,7 +72,8 @@ enum zafx_constant {
     ZAFX_CONST_DCT = 3,         /* float32[n_coefs * n_filters], row-major      (DCT-II rows 1..)  */
     ZAFX_CONST_CQT_INDPTR = 4,  /* int32[n_bins + 1]                            (CSR of cqt_kernel) */
     ZAFX_CONST_CQT_INDICES = 5, /* int32[nnz], 0 <= col < fft_length                                */
-    ZAFX_CONST_CQT_VALUES = 6   /* complex64[nnz]                                                   */
+    ZAFX_CONST_CQT_VALUES = 6,  /* complex64[nnz]                                                   */
+    ZAFX_CONST_MATRIX = 7       /* float32[n_filters * window_length], row-major   (ZAFX_LINEAR)      */
 };
 
 typedef struct zafx_params {

@@ -293,3 +293,65 @@ def imdct(audio_mdct, window_function):
         lo = j * hop
         y[lo:lo + wl] = y[lo:lo + wl] + frames[:, j]
     return y[hop:-hop - 1]                                                     # :1182
+
+
+# --------------------------------------------------------------------------
+# 8(f) rank 3  dct / dst, types I-IV, orthonormal  (zaf.py:703-981)
+# --------------------------------------------------------------------------
+def _ext_fft(parts, length):
+    """Scatter (offset, stride, values) pieces into a zero vector of `length` and FFT it."""
+    ext = np.zeros(length)
+    for start, stop, step, values in parts:
+        ext[start:stop:step] = values
+    return np.fft.fft(ext)
+
+
+def dct(audio_signal, dct_type):
+    """Restates zaf.py:759-839: DCT-I..IV by FFT of a symmetric extension, scaled to be orthonormal."""
+    x = np.array(audio_signal, dtype=float)
+    n = len(x)
+    if dct_type == 1:
+        x[[0, -1]] = x[[0, -1]] * np.sqrt(2)                                   # :766-767
+        spec = np.fft.fft(np.concatenate((x, x[-2:0:-1])))                     # :770-771
+        out = np.real(spec[0:n]) / 2                                           # :772
+        out[[0, -1]] = out[[0, -1]] / np.sqrt(2)                               # :775
+        return out * np.sqrt(2 / (n - 1))                                      # :776
+    if dct_type == 2:
+        spec = _ext_fft([(1, 2 * n, 2, x), (2 * n + 1, 4 * n, 2, x[::-1])], 4 * n)   # :786-789
+        out = np.real(spec[0:n]) / 2                                           # :790
+        out[0] = out[0] / np.sqrt(2)                                           # :793
+        return out * np.sqrt(2 / n)                                            # :794
+    if dct_type == 3:
+        x[0] = x[0] * np.sqrt(2)                                               # :806
+        spec = _ext_fft([(0, n, 1, x), (n + 1, 2 * n + 1, 1, -x[::-1]), (2 * n + 1, 3 * n, 1, -x[1:]),
+                         (3 * n + 1, 4 * n, 1, x[:0:-1])], 4 * n)              # :809-814
+        return np.real(spec[1:2 * n:2]) / 4 * np.sqrt(2 / n)                   # :815-818
+    if dct_type == 4:
+        spec = _ext_fft([(1, 2 * n, 2, x), (2 * n + 1, 4 * n, 2, -x[::-1]), (4 * n + 1, 6 * n, 2, -x),
+                         (6 * n + 1, 8 * n, 2, x[::-1])], 8 * n)               # :828-833
+        return np.real(spec[1:2 * n:2]) / 4 * np.sqrt(2 / n)                   # :834-837
+    raise ValueError("dct_type must be 1, 2, 3 or 4")
+
+
+def dst(audio_signal, dst_type):
+    """Restates zaf.py:901-981: DST-I..IV by FFT of an antisymmetric extension, orthonormal."""
+    x = np.array(audio_signal, dtype=float)
+    n = len(x)
+    if dst_type == 1:
+        spec = _ext_fft([(1, n + 1, 1, x), (n + 2, 2 * n + 2, 1, -x[::-1])], 2 * n + 2)   # :907-910
+        return -np.imag(spec[1:n + 1]) / 2 * np.sqrt(2 / (n + 1))              # :911-914
+    if dst_type == 2:
+        spec = _ext_fft([(1, 2 * n, 2, x), (2 * n + 1, 4 * n, 2, -x[::-1])], 4 * n)       # :924-927
+        out = -np.imag(spec[1:n + 1]) / 2                                      # :928
+        out[-1] = out[-1] / np.sqrt(2)                                         # :931
+        return out * np.sqrt(2 / n)                                            # :932
+    if dst_type == 3:
+        x[-1] = x[-1] * np.sqrt(2)                                             # :944
+        spec = _ext_fft([(1, n + 1, 1, x), (n + 1, 2 * n, 1, x[-2::-1]), (2 * n + 1, 3 * n + 1, 1, -x),
+                         (3 * n + 1, 4 * n, 1, -x[-2::-1])], 4 * n)            # :947-952
+        return -np.imag(spec[1:2 * n:2]) / 4 * np.sqrt(2 / n)                  # :953-956
+    if dst_type == 4:
+        spec = _ext_fft([(1, 2 * n, 2, x), (2 * n + 1, 4 * n, 2, x[::-1]), (4 * n + 1, 6 * n, 2, -x),
+                         (6 * n + 1, 8 * n, 2, -x[::-1])], 8 * n)              # :964-975
+        return -np.imag(spec[1:2 * n:2]) / 4 * np.sqrt(2 / n)                  # :976-979
+    raise ValueError("dst_type must be 1, 2, 3 or 4")

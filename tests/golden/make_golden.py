@@ -15,6 +15,7 @@ What is written (all .npz, float64/complex128, < 1 MB each):
                 output shape, 4096 random probes (index + value), row sums, column
                 sums and L2 norm per function
   lengths.npz   frame-count / output-length table of SURVEY.md section 4
+  dctdst.npz    zaf.dct / zaf.dst, types 1-4, lengths 8, 9, 100, 1024
 
 The fixtures are DATA (inputs and expected outputs); no reference source text
 is stored.
@@ -161,10 +162,24 @@ def make_lengths():
     np.savez_compressed(os.path.join(HERE, "lengths.npz"), table=np.array(rows, dtype=np.int64))
 
 
+def make_dctdst():
+    """zaf.dct / zaf.dst types 1-4: full vectors, odd and power-of-two lengths."""
+    out = {}
+    rng = np.random.default_rng(77)
+    for n in (8, 9, 100, 1024):
+        x = rng.standard_normal(n).astype(np.float32).astype(np.float64)
+        out[f"x_{n}"] = x
+        for t in (1, 2, 3, 4):
+            out[f"dct{t}_{n}"] = zaf.dct(x.copy(), t)
+            out[f"dst{t}_{n}"] = zaf.dst(x.copy(), t)
+    np.savez_compressed(os.path.join(HERE, "dctdst.npz"), **out)
+
+
 if __name__ == "__main__":
     make_tiny()
     make_consts()
     make_config()
     make_lengths()
-    for f in ("tiny.npz", "consts.npz", "config.npz", "lengths.npz"):
+    make_dctdst()
+    for f in ("tiny.npz", "consts.npz", "config.npz", "lengths.npz", "dctdst.npz"):
         print(f, os.path.getsize(os.path.join(HERE, f)))

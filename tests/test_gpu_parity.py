@@ -417,3 +417,26 @@ def test_run_sharded_threads(zafx):
     assert np.array_equal(zafx.run_sharded(zafx.mfcc_batch, x, [0, 0, 0], ham, 1024, fb, 20), zafx.mfcc_batch(x, ham, 1024, fb, 20))
     one = zafx.run_sharded(zafx.stft_batch, x[:1], [0, 0], ham, 1024)   # fewer clips than slots
     assert np.array_equal(one, whole[:1])
+
+
+# ------------------------------------------------------------------ dct / dst
+@pytest.mark.parametrize("n", [8, 9, 100, 1024])
+def test_dct_dst(zafx, golden, n):
+    """zaf.dct / zaf.dst types 1-4 as one MFMA GEMM per batch, against the reference's golden vectors."""
+    g = golden["dctdst"]
+    x = g[f"x_{n}"]
+    for t in (1, 2, 3, 4):
+        got = zafx.dct(x, t)
+        assert got.dtype == np.float64 and relerr(got, g[f"dct{t}_{n}"]) <= TOL_FFT
+        assert relerr(zafx.dst(x, t), g[f"dst{t}_{n}"]) <= TOL_FFT
+    # batched, ragged tile edges (70 rows, n not a multiple of the 64 x 64 x 32 tile)
+    xb = np.stack([synth_clip(14, c, n) for c in range(70)])
+    for t in (2, 4):
+        gb = zafx.dct_batch(xb, t)
+        ref = np.stack([orc.dct(v.astype(np.float64), t) for v in xb])
+        assert gb.shape == ref.shape and relerr(gb, ref) <= TOL_FFT
+    gb = zafx.dst_batch(xb, 3)
+    ref = np.stack([orc.dst(v.astype(np.float64), 3) for v in xb])
+    assert relerr(gb, ref) <= TOL_FFT
+    # the reference's plotted self-check (zaf.py:866-897): DST-II and DST-III are inverses
+    assert np.max(np.abs(zafx.dst(zafx.dst(x, 2), 3) - x)) < 1e-5

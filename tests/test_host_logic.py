@@ -132,3 +132,19 @@ def test_run_sharded_with_a_fake_device_step():
         zafx.run_sharded(failing, x, [0, 1])
     with pytest.raises(ValueError):
         zafx.run_sharded(fake_batch, x, [], 1.0)
+
+
+def test_dct_dst_matrices_match_reference(golden):
+    """Closed-form orthonormal DCT/DST matrices (the operands of the GPU GEMM) vs zaf.dct / zaf.dst."""
+    g = golden["dctdst"]
+    for n in (8, 9, 100, 1024):
+        x = g[f"x_{n}"]
+        for t in (1, 2, 3, 4):
+            assert relerr(zafx.dct_matrix(n, t) @ x, g[f"dct{t}_{n}"]) <= 1e-11
+            assert relerr(zafx.dst_matrix(n, t) @ x, g[f"dst{t}_{n}"]) <= 1e-11
+            m = zafx.dct_matrix(n, t)
+            assert np.max(np.abs(m @ m.T - np.eye(n))) < 1e-10   # orthonormal
+    with pytest.raises(ValueError):
+        zafx.dct_matrix(8, 5)
+    with pytest.raises(ValueError):
+        zafx.dct(np.zeros((2, 8)), 2)

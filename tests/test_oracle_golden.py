@@ -159,3 +159,19 @@ def test_config_Q(golden):
     q = orc.cqtspectrogram(x, 44100, 25, ck)
     _check_probes(g, "Q0_cqt", q, 1e-11)
     _check_probes(g, "Q0_chroma", orc.cqtchromagram(x, 44100, 25, 24, ck), 1e-11)
+
+
+@pytest.mark.parametrize("n", [8, 9, 100, 1024])
+def test_dct_dst(golden, n):
+    """oracle dct/dst types 1-4 against the reference, plus the reference's own
+    plotted self-checks (zaf.py:728-753 DCT vs SciPy ortho; :866-897 DST inverse pairs)."""
+    import scipy.fftpack
+    g = golden["dctdst"]
+    x = g[f"x_{n}"]
+    for t in (1, 2, 3, 4):
+        close(orc.dct(x, t), g[f"dct{t}_{n}"])
+        close(orc.dst(x, t), g[f"dst{t}_{n}"])
+        close(orc.dct(x, t), scipy.fftpack.dct(x, type=t, norm="ortho"), 1e-11)
+    close(orc.dst(orc.dst(x, 1), 1), x, 1e-11)
+    close(orc.dst(orc.dst(x, 2), 3), x, 1e-11)
+    close(orc.dst(orc.dst(x, 4), 4), x, 1e-11)

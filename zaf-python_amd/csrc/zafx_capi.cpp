@@ -194,6 +194,9 @@ static int finalize_constant(zafx_plan* pl, int which) {
         case ZAFX_CONST_DCT:
             ZAFX_HIP(pack_band(pl->dct, pl->h_dct.data(), pl->prm.n_coefs, pl->prm.n_filters, mel_waves(pl->log2nf)));
             return 0;
+        case ZAFX_CONST_MATRIX:
+            ZAFX_HIP(upload(&pl->d_matrix, pl->h_matrix.data(), pl->h_matrix.size() * sizeof(float)));
+            return 0;
         case ZAFX_CONST_CQT_INDPTR:
             ZAFX_HIP(upload(&pl->d_indptr, pl->h_indptr.data(), pl->h_indptr.size() * sizeof(int32_t)));
             pl->cqt_dirty = true;
@@ -365,6 +368,13 @@ int zafx_plan_create(zafx_plan** out, int device, int kind, const zafx_params* p
         aux.resize((size_t)n / 2 + 1);
         for (int k = 0; k <= n / 2; ++k) aux[(size_t)k] = unit_root(k, pl->W);
         pl->kernel_name = cqt_kernel_name();
+    } else if (kind == ZAFX_LINEAR) {
+        pl->W = params->window_length;
+        if (pl->W < 1 || pl->W > 16384 || params->n_filters < 1 || params->n_filters > 16384)
+            return bail("linear map: window_length (columns) and n_filters (rows) must be in [1, 16384]");
+        pl->log2nf = 4;   // only so that the (unused) FFT tables below are small
+        aux.assign(1, cf32{1.f, 0.f});
+        pl->kernel_name = linear_kernel_name();
     } else {
         return bail("unknown plan kind");
     }
@@ -394,6 +404,7 @@ int zafx_plan_destroy(zafx_plan* pl) {
     (void)hipSetDevice(pl->device);
     if (pl->stream) (void)hipStreamSynchronize(pl->stream);
     if (pl->d_window) (void)hipFree(pl->d_window);
+    if (pl->d_matrix) (void)hipFree(pl->d_matrix);
     if (pl->d_wfold) (void)hipFree(pl->d_wfold);
     if (pl->d_tw_pass) (void)hipFree(pl->d_tw_pass);
     if (pl->d_tw_aux) (void)hipFree(pl->d_tw_aux);
@@ -415,7 +426,7 @@ static int expected_constant_bytes(const zafx_plan* pl, int which, size_t bytes,
     switch (which) {
         case ZAFX_CONST_WINDOW:
             *elem = sizeof(float);
-            if (is_cqt_family(pl->kind)) return fail_msg("CQT plans take no window (zaf.py:630)");
+            if (is_cqt_family(pl->kind) || pl->kind == ZAFX_LINEAR) return fail_msg("this plan kind takes no window");
             return bytes == (size_t)pl->W * sizeof(float) ? 0 : fail_msg("window must hold window_length float32");
         case ZAFX_CONST_MEL_FB:
             *elem = sizeof(float);
@@ -427,6 +438,10 @@ static int expected_constant_bytes(const zafx_plan* pl, int which, size_t bytes,
             if (pl->kind != ZAFX_MFCC) return fail_msg("plan takes no DCT matrix");
             return bytes == (size_t)pl->prm.n_coefs * pl->prm.n_filters * sizeof(float) ? 0
                        : fail_msg("DCT matrix must be float32 [n_coefs][n_filters]");
+        case ZAFX_CONST_MATRIX:
+            *elem = sizeof(float);
+            if (pl->kind != ZAFX_LINEAR) return fail_msg("plan takes no transform matrix");
+            return bytes == (size_t)pl->prm.n_filters * pl->W * sizeof(float) ? 0 : fail_msg("matrix must be float32 [n_filters][window_length]");
         case ZAFX_CONST_CQT_INDPTR:
             *elem = sizeof(int32_t);
             if (!is_cqt_family(pl->kind)) return fail_msg("plan takes no CQT kernel");
@@ -453,6 +468,9 @@ static int store_shadow(zafx_plan* pl, int which, const void* host, size_t bytes
             break;
         case ZAFX_CONST_DCT:
             pl->h_dct.assign((const float*)host, (const float*)host + bytes / sizeof(float));
+            break;
+        case ZAFX_CONST_MATRIX:
+            pl->h_matrix.assign((const float*)host, (const float*)host + bytes / sizeof(float));
             break;
         case ZAFX_CONST_CQT_INDPTR:
             pl->h_indptr.assign((const int32_t*)host, (const int32_t*)host + bytes / sizeof(int32_t));
@@ -500,6 +518,9 @@ int zafx_plan_out_dims(const zafx_plan* pl, int64_t n_in, int64_t dims[2]) {
         case ZAFX_IMDCT: dims[0] = std::max<int64_t>(0, h * (n_in - 1) - 1); dims[1] = 1; return 0;    // zaf.py:1132, :1182
         case ZAFX_CQT: dims[0] = pl->prm.n_bins; dims[1] = n_in / h; return 0;                         // zaf.py:606
         case ZAFX_CHROMA: dims[0] = pl->prm.octave_resolution; dims[1] = n_in / h; return 0;
+        case ZAFX_LINEAR:
+            if (n_in != pl->W) return fail_msg("linear map: input length must equal window_length");
+            dims[0] = pl->prm.n_filters; dims[1] = 1; return 0;
     }
     return fail_msg("unknown plan kind");
 }
@@ -511,7 +532,8 @@ int zafx_execute(zafx_plan* pl, const void* d_in, void* d_out, int64_t n_clips, 
     if (!d_in || !d_out) return fail_msg("null device pointer");
     int64_t dims[2];
     if (int rc = zafx_plan_out_dims(pl, n_in, dims)) return rc;
-    if (!is_cqt_family(pl->kind) && !pl->d_window) return fail_msg("window constant not set");
+    if (pl->kind == ZAFX_LINEAR && !pl->d_matrix) return fail_msg("matrix constant not set");
+    if (!is_cqt_family(pl->kind) && pl->kind != ZAFX_LINEAR && !pl->d_window) return fail_msg("window constant not set");
     if ((pl->kind == ZAFX_MEL || pl->kind == ZAFX_MFCC) && !pl->fb.d_pack) return fail_msg("mel filterbank constant not set");
     if (pl->kind == ZAFX_MFCC && !pl->dct.d_pack) return fail_msg("DCT constant not set");
     if (is_cqt_family(pl->kind)) {
@@ -542,6 +564,9 @@ int zafx_execute(zafx_plan* pl, const void* d_in, void* d_out, int64_t n_clips, 
         case ZAFX_MEL:
         case ZAFX_MFCC:
             e = launch_mel(*pl, (const float*)d_in, (float*)d_out, n_clips, n_in, (int)dims[1]);
+            break;
+        case ZAFX_LINEAR:
+            e = launch_linear(*pl, (const float*)d_in, (float*)d_out, n_clips);
             break;
         case ZAFX_CQT:
         case ZAFX_CHROMA:
@@ -692,7 +717,8 @@ int zafx_comm_broadcast_constants(zafx_comm* c, zafx_plan* pl, int root) {
     if (c->device != pl->device) return fail_msg("communicator and plan are bound to different devices");
     ZAFX_HIP(hipSetDevice(pl->device));
     std::vector<int> ids;
-    if (!is_cqt_family(pl->kind)) ids.push_back(ZAFX_CONST_WINDOW);
+    if (pl->kind == ZAFX_LINEAR) ids.push_back(ZAFX_CONST_MATRIX);
+    else if (!is_cqt_family(pl->kind)) ids.push_back(ZAFX_CONST_WINDOW);
     if (pl->kind == ZAFX_MEL || pl->kind == ZAFX_MFCC) ids.push_back(ZAFX_CONST_MEL_FB);
     if (pl->kind == ZAFX_MFCC) ids.push_back(ZAFX_CONST_DCT);
     if (is_cqt_family(pl->kind)) {
@@ -715,6 +741,7 @@ int zafx_comm_broadcast_constants(zafx_comm* c, zafx_plan* pl, int root) {
                 case ZAFX_CONST_WINDOW: span(pl->h_window); break;
                 case ZAFX_CONST_MEL_FB: span(pl->h_fb); break;
                 case ZAFX_CONST_DCT: span(pl->h_dct); break;
+                case ZAFX_CONST_MATRIX: span(pl->h_matrix); break;
                 case ZAFX_CONST_CQT_INDPTR: span(pl->h_indptr); break;
                 case ZAFX_CONST_CQT_INDICES: span(pl->h_indices); break;
                 case ZAFX_CONST_CQT_VALUES: span(pl->h_values); break;

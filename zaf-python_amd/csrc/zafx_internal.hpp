@@ -47,6 +47,7 @@ struct zafx_plan {
 
     // device constants
     float* d_window = nullptr;
+    float* d_matrix = nullptr;     // ZAFX_LINEAR: dense transform matrix [n_filters][window_length]
     float4* d_wfold = nullptr;     // MDCT: sign-folded window, 4 taps per packed input (zafx_mdct.hip)
     float2* d_tw_pass = nullptr;   // per-pass twiddles for fft_frame<log2nf, log2e>
     float2* d_tw_aux = nullptr;    // real-split roots (STFT family / CQT) or tw8 (MDCT family)
@@ -62,7 +63,7 @@ struct zafx_plan {
     bool cqt_dirty = true;
 
     // host shadows (needed to re-pack after an RCCL broadcast)
-    std::vector<float> h_window, h_fb, h_dct;
+    std::vector<float> h_window, h_fb, h_dct, h_matrix;
     std::vector<int32_t> h_indptr, h_indices;
     std::vector<zafx::cf32> h_values;
 
@@ -78,6 +79,8 @@ hipError_t launch_mdct(const zafx_plan& pl, const float* x, float* out, int64_t 
 hipError_t launch_imdct(const zafx_plan& pl, const float* coefs, float* y, int64_t n_clips, int T, int64_t out_len);
 hipError_t launch_mel(const zafx_plan& pl, const float* x, float* out, int64_t n_clips, int64_t n_samples, int T);
 hipError_t launch_cqt(const zafx_plan& pl, const float* x, float* out, int64_t n_clips, int64_t n_samples, int T);
+hipError_t launch_linear(const zafx_plan& pl, const float* x, float* y, int64_t n_clips);
+const char* linear_kernel_name();
 hipError_t launch_pcm_to_float(hipStream_t stream, const void* pcm, float* out, int64_t n_total, int n_channels, int sample_bytes);
 
 // names of the dominant kernels (what rocprofv3 --kernel-trace prints, prefix match)

@@ -5,16 +5,17 @@
 
 Drop-in functions (zaf.py signatures, float64 / complex128 results):
     stft, istft, melfilterbank, melspectrogram, mfcc, cqtkernel, cqtspectrogram,
-    cqtchromagram, mdct, imdct
+    cqtchromagram, mdct, imdct, dct, dst
 Batched extension ((clips, samples) in, float32 / complex64 out):
     stft_batch, istft_batch, mdct_batch, imdct_batch, melspectrogram_batch, mfcc_batch,
     cqtspectrogram_batch, cqtchromagram_batch
 Device-resident API: Plan, DeviceBuffer, Comm, *_plan factories, shard helpers.
 """
-from ._lib import (CHROMA, CQT, IMDCT, ISTFT, LAYOUT_FT, LAYOUT_TF, MDCT, MEL, MFCC, STFT, ZafxError, device_count,
+from ._lib import (CHROMA, CQT, IMDCT, ISTFT, LAYOUT_FT, LAYOUT_TF, LINEAR, MDCT, MEL, MFCC, STFT, ZafxError, device_count,
                    device_name, library_path)
-from .constants import cqtkernel, dct2_rows, hamming, kaiser_bessel_derived, melfilterbank, sine
-from .core import (Comm, DeviceBuffer, Plan, clear_plan_cache, cqt_plan, cqtchromagram, cqtchromagram_batch,
+from .constants import cqtkernel, dct2_rows, dct_matrix, dst_matrix, hamming, kaiser_bessel_derived, melfilterbank, sine
+from .core import (Comm, DeviceBuffer, Plan, clear_plan_cache, cqt_plan, cqtchromagram, cqtchromagram_batch, dct, dct_batch, dst,
+                   dst_batch, linear_plan,
                    cqtspectrogram, cqtspectrogram_batch, imdct, imdct_batch, istft, istft_batch, istft_plan, mdct,
                    mdct_batch, mdct_plan, mel_plan, melspectrogram, melspectrogram_batch, mfcc, mfcc_batch, pcm_to_mono,
                    stft, stft_batch, stft_pcm_batch, stft_plan)

@@ -9,11 +9,11 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 
 # enum zafx_kind
-STFT, ISTFT, MDCT, IMDCT, MEL, MFCC, CQT, CHROMA = 1, 2, 3, 4, 5, 6, 7, 8
+STFT, ISTFT, MDCT, IMDCT, MEL, MFCC, CQT, CHROMA, LINEAR = 1, 2, 3, 4, 5, 6, 7, 8, 9
 # enum zafx_layout
 LAYOUT_FT, LAYOUT_TF = 0, 1
 # enum zafx_constant
-CONST_WINDOW, CONST_MEL_FB, CONST_DCT, CONST_CQT_INDPTR, CONST_CQT_INDICES, CONST_CQT_VALUES = 1, 2, 3, 4, 5, 6
+CONST_WINDOW, CONST_MEL_FB, CONST_DCT, CONST_CQT_INDPTR, CONST_CQT_INDICES, CONST_CQT_VALUES, CONST_MATRIX = 1, 2, 3, 4, 5, 6, 7
 
 
 class ZafxParams(ctypes.Structure):

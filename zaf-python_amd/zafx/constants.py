@@ -8,7 +8,7 @@ BASELINE configs.  Signatures and return types follow zaf.py (scipy CSR matrices
 import numpy as np
 import scipy.sparse
 
-__all__ = ["melfilterbank", "cqtkernel", "dct2_rows", "hamming", "kaiser_bessel_derived", "sine"]
+__all__ = ["melfilterbank", "cqtkernel", "dct2_rows", "dct_matrix", "dst_matrix", "hamming", "kaiser_bessel_derived", "sine"]
 
 
 def melfilterbank(sampling_frequency, window_length, number_filters):
@@ -86,3 +86,53 @@ def kaiser_bessel_derived(window_length, alpha=5.0):
 def sine(window_length):
     """Sine window (Princen-Bradley compliant)."""
     return np.sin(np.pi / window_length * (np.arange(window_length) + 0.5))
+
+
+def dct_matrix(length, dct_type):
+    """Orthonormal DCT matrix of type 1-4: zaf.dct(x, t) == dct_matrix(len(x), t) @ x (zaf.py:703-839).
+
+    I:   sqrt(2/(N-1)) a_k a_n cos(pi k n / (N-1)),  a_0 = a_{N-1} = 1/sqrt(2)
+    II:  sqrt(2/N) c_k cos(pi k (2n+1) / (2N)),       c_0 = 1/sqrt(2)
+    III: transpose of II
+    IV:  sqrt(2/N) cos(pi (2k+1)(2n+1) / (4N))
+    """
+    n = int(length)
+    k = np.arange(n)[:, None]
+    m = np.arange(n)[None, :]
+    if dct_type == 1:
+        if n < 2:
+            raise ValueError("DCT-I needs at least 2 samples")
+        edge = np.ones(n)
+        edge[[0, -1]] = 1 / np.sqrt(2)
+        return np.sqrt(2 / (n - 1)) * edge[:, None] * edge[None, :] * np.cos(np.pi * k * m / (n - 1))
+    if dct_type in (2, 3):
+        first = np.ones(n)
+        first[0] = 1 / np.sqrt(2)
+        mat = np.sqrt(2 / n) * first[:, None] * np.cos(np.pi * k * (2 * m + 1) / (2 * n))
+        return mat if dct_type == 2 else mat.T
+    if dct_type == 4:
+        return np.sqrt(2 / n) * np.cos(np.pi * (2 * k + 1) * (2 * m + 1) / (4 * n))
+    raise ValueError("dct_type must be 1, 2, 3 or 4")
+
+
+def dst_matrix(length, dst_type):
+    """Orthonormal DST matrix of type 1-4: zaf.dst(x, t) == dst_matrix(len(x), t) @ x (zaf.py:842-981).
+
+    I:   sqrt(2/(N+1)) sin(pi (k+1)(n+1) / (N+1))
+    II:  sqrt(2/N) c_k sin(pi (k+1)(2n+1) / (2N)),    c_{N-1} = 1/sqrt(2)
+    III: transpose of II
+    IV:  sqrt(2/N) sin(pi (2k+1)(2n+1) / (4N))
+    """
+    n = int(length)
+    k = np.arange(n)[:, None]
+    m = np.arange(n)[None, :]
+    if dst_type == 1:
+        return np.sqrt(2 / (n + 1)) * np.sin(np.pi * (k + 1) * (m + 1) / (n + 1))
+    if dst_type in (2, 3):
+        last = np.ones(n)
+        last[-1] = 1 / np.sqrt(2)
+        mat = np.sqrt(2 / n) * last[:, None] * np.sin(np.pi * (k + 1) * (2 * m + 1) / (2 * n))
+        return mat if dst_type == 2 else mat.T
+    if dst_type == 4:
+        return np.sqrt(2 / n) * np.sin(np.pi * (2 * k + 1) * (2 * m + 1) / (4 * n))
+    raise ValueError("dst_type must be 1, 2, 3 or 4")

@@ -91,7 +91,7 @@ class DeviceBuffer:
 class Plan:
     """One transform kind bound to one device and one HIP stream (zafx_plan)."""
 
-    _FORWARD = (_lib.STFT, _lib.MDCT, _lib.MEL, _lib.MFCC, _lib.CQT, _lib.CHROMA)
+    _FORWARD = (_lib.STFT, _lib.MDCT, _lib.MEL, _lib.MFCC, _lib.CQT, _lib.CHROMA)   # 2-D (frequency x time) outputs
 
     def __init__(self, kind, device=0, window_length=0, step_length=0, layout="FT", n_filters=0, n_coefs=0,
                  fft_length=0, n_bins=0, octave_resolution=0):
@@ -128,6 +128,9 @@ class Plan:
 
     def set_dct(self, dct_rows):
         self._set(_lib.CONST_DCT, dct_rows, np.float32)
+
+    def set_matrix(self, matrix):
+        self._set(_lib.CONST_MATRIX, matrix, np.float32)
 
     def set_cqt_kernel(self, cqt_kernel):
         csr = cqt_kernel.tocsr()
@@ -398,6 +401,20 @@ def cqt_plan(sampling_frequency, time_resolution, cqt_kernel, octave_resolution=
     return _cached(key, make)
 
 
+def linear_plan(matrix, device=0):
+    """y = matrix @ x for every clip (the carrier of the dct / dst transforms)."""
+    m = np.ascontiguousarray(matrix, dtype=np.float64)
+    if m.ndim != 2 or not (1 <= m.shape[0] <= 16384 and 1 <= m.shape[1] <= 16384):
+        raise ValueError("matrix must be 2-D with both sides in [1, 16384]")
+    key = ("linear", device, m.shape, _digest(m))
+
+    def make():
+        p = Plan(_lib.LINEAR, device, window_length=m.shape[1], n_filters=m.shape[0])
+        p.set_matrix(m)
+        return p
+    return _cached(key, make)
+
+
 # ======================================================================================
 # batched API (build-defined extension): (clips, samples) float32 in, float32/complex64 out
 # ======================================================================================
@@ -505,6 +522,40 @@ def pcm_to_mono(pcm, device=0):
         finally:
             d_pcm.free()
             d_x.free()
+
+
+def _transform_batch(vectors, matrix_fn, kind, device):
+    x = np.ascontiguousarray(vectors, dtype=np.float32)
+    if x.ndim != 2 or x.shape[1] < 1:
+        raise ValueError("vectors must be 2-D (batch, length) with length >= 1")
+    plan = linear_plan(matrix_fn(x.shape[1], kind), device)
+    return plan.run_host(x, x.shape[1])
+
+
+def dct_batch(vectors, dct_type, device=0):
+    """(B, N) -> (B, N) float32: orthonormal DCT of type 1-4 of every row (zaf.dct per row)."""
+    return _transform_batch(vectors, constants.dct_matrix, dct_type, device)
+
+
+def dst_batch(vectors, dst_type, device=0):
+    """(B, N) -> (B, N) float32: orthonormal DST of type 1-4 of every row (zaf.dst per row)."""
+    return _transform_batch(vectors, constants.dst_matrix, dst_type, device)
+
+
+def dct(audio_signal, dct_type):
+    """Drop-in for zaf.dct (zaf.py:703): (N,) -> (N,) float64, type 1, 2, 3 or 4."""
+    x = np.asarray(audio_signal)
+    if x.ndim != 1:
+        raise ValueError("audio_signal must be 1-D; use dct_batch for (batch, length)")
+    return dct_batch(x[None, :], dct_type)[0].astype(np.float64)
+
+
+def dst(audio_signal, dst_type):
+    """Drop-in for zaf.dst (zaf.py:842): (N,) -> (N,) float64, type 1, 2, 3 or 4."""
+    x = np.asarray(audio_signal)
+    if x.ndim != 1:
+        raise ValueError("audio_signal must be 1-D; use dst_batch for (batch, length)")
+    return dst_batch(x[None, :], dst_type)[0].astype(np.float64)
 
 
 # ======================================================================================

@@ -15,6 +15,7 @@
 // in the reference (frequency-major, time-minor) layout the FPB frames supply the
 // contiguous run along t for every stored row (16 frames x 8 B = one 128-B line).
 #include <algorithm>
+#include <type_traits>
 
 #include "zafx_fft.hpp"
 #include "zafx_internal.hpp"
@@ -229,7 +230,7 @@ __global__ __launch_bounds__(kFatWaves * 64) void k_stft_ft16(
             }
             fft_frame<LOG2N, LOG2E>(v, frames + (wave * FPW + f) * PITCH, p, tw_l);
         }
-        __syncthreads();
+        lds_barrier();
         prefetch(tl + gridDim.x);   // in flight while this tile is stored
         if (t0 + tt < T) {
             float2* o = out + (long long)clip * W * T + (t0 + tt);
@@ -250,7 +251,7 @@ __global__ __launch_bounds__(kFatWaves * 64) void k_stft_ft16(
                 }
             }
         }
-        __syncthreads();
+        lds_barrier();   // LDS reads of the tile are done; its global stores are NOT waited for
     }
 }
 
@@ -439,93 +440,336 @@ __global__ __launch_bounds__(FPB * fft_threads(LOG2N, LOG2E)) void k_istft(
 }
 
 // ---------------------------------------------------------------------------------
-// inverse, reference (frequency-major) layout, persistent "fat wave" form
+// inverse, reference (frequency-major) layout, persistent carry form
 // ---------------------------------------------------------------------------------
-// Same structure as k_stft_ft16: one persistent 8-wave workgroup per CU, tables in LDS once,
-// 16-frame tiles (the gathered rows are 128-B runs along t), two frames per wave.  (Prefetching
-// the next tile's 64 x 8 B per lane into registers was tried and spilled: 7.4 ms vs 3.4 ms.)
-template <int LOG2N, int LOG2E, int WAVES>
-__global__ __launch_bounds__(WAVES * 64) void k_istft_ft16(
+// One persistent 8-wave workgroup per CU walks the 16-frame tiles of a clip segment IN ORDER and
+// keeps the overlap of the last frames with the next tile (W - hop samples, the "carry") in LDS.
+// Tiles therefore start at t = 16 * tile: every gathered row piece is a 128-B aligned run and no
+// frame is read twice (the halo form re-read ceil(W/H)-1 frames per tile and straddled two lines
+// per run).  A segment that does not start a clip first runs the tile before it in carry-only mode
+// (only its last `halo` frames are loaded and transformed, nothing is written).  The carry slot c
+// is read and rewritten by the same thread (c = tid mod NT), and the adds keep the reference's
+// ascending frame order (zaf.py:226-233), so the result is deterministic.
+//
+// The NEXT tile's two-sided bins are prefetched into registers in two halves: the first half is
+// issued before the FFT phase, the second before the overlap-add phase (when the FFT registers are
+// dead), and both are folded into LDS after the stores -- the gather latency hides under the FFT
+// and the store phase.  (All 64 x 8 B per lane at once, at 16 waves, spilled: 7.4 ms vs 3.4 ms.)
+// ---------------------------------------------------------------------------------
+// gather overlap-add of a tile held in LDS
+// ---------------------------------------------------------------------------------
+// Sample offset c = q * hop + r from the tile's first frame.  The frames of the tile that cover it
+// are jl = q - d with r + d * hop < W; they are added in ascending jl (the reference's order,
+// zaf.py:226-233), clipped to [0, n_valid).  `fl` is the tile (pitch2 floats per frame, re/im
+// swapped packed real output of the inverse transform).
+template <int W>
+__device__ __forceinline__ float ola_sum(const float* fl, int pitch2, int q, int r, int hop, int n_valid, float acc) {
+    int d = 0;
+    while (r + (d + 1) * hop < W) ++d;
+    int jl = q - d, n = r + d * hop;
+    if (jl < 0) {
+        n += jl * hop;
+        jl = 0;
+    }
+    const int j_hi = min(q, n_valid - 1);
+    for (; jl <= j_hi; ++jl, n -= hop) acc += fl[jl * pitch2 + ((2 * phys(n >> 1) + (n & 1)) ^ 1)];
+    return acc;
+}
+
+// Phase C of the carry kernel: outputs of the tile (carry first), then the carry for the next tile.
+// Thread `tid` owns offsets c = tid + m NT in both loops, so a carry slot is read and rewritten by
+// one thread.  q/r advance incrementally (no integer division per sample).
+struct OlaArgs {
+    const float* fl;      // tile
+    float* carry;
+    int pitch2, ncarry, hop, n_valid, c_end;
+    bool write_out, make_carry;
+    float* yc;            // this clip's output
+    long long o_first;    // output index of offset 0 (may be negative: trimmed head)
+    long long out_len;
+    float scale;
+};
+
+template <int W, int NT, int FPB>
+__device__ __forceinline__ void ola_phase(const OlaArgs& a, int tid) {
+    const int q0 = tid / a.hop, r0 = tid % a.hop, qstep = NT / a.hop, rstep = NT % a.hop;
+    if (a.write_out) {
+        int q = q0, r = r0;
+        for (int c = tid; c < a.c_end; c += NT) {
+            float acc = c < a.ncarry ? a.carry[c] : 0.f;
+            acc = ola_sum<W>(a.fl, a.pitch2, q, r, a.hop, a.n_valid, acc);
+            const long long o = a.o_first + c;
+            if (o >= 0 && o < a.out_len) a.yc[o] = acc * a.scale;
+            q += qstep;
+            r += rstep;
+            if (r >= a.hop) r -= a.hop, ++q;
+        }
+    }
+    if (a.make_carry) {
+        int q = q0 + FPB, r = r0;
+        for (int c = tid; c < a.ncarry; c += NT) {
+            a.carry[c] = ola_sum<W>(a.fl, a.pitch2, q, r, a.hop, a.n_valid, 0.f);
+            q += qstep;
+            r += rstep;
+            if (r >= a.hop) r -= a.hop, ++q;
+        }
+    } else {
+        for (int c = tid; c < a.ncarry; c += NT) a.carry[c] = 0.f;   // next tile starts another segment
+    }
+}
+
+// The same for an even hop >= W/2: at most two frames cover a sample (q - 1 and q), and the samples
+// (2m, 2m+1) of a frame sit in one LDS float2 -- branch-free 8-byte LDS reads, 8-byte stores.
+template <int W, int NT, int FPB>
+__device__ __forceinline__ void ola_phase_pairs(const OlaArgs& a, int tid, bool y_aligned) {
+    const float2* fr = reinterpret_cast<const float2*>(a.fl);
+    float2* carry2 = reinterpret_cast<float2*>(a.carry);
+    const int pitch = a.pitch2 / 2, hop2 = a.hop / 2, ncarry2 = a.ncarry / 2, c_end2 = a.c_end / 2;
+    const int q0 = tid / hop2, r0 = tid % hop2, qstep = NT / hop2, rstep = NT % hop2;
+    auto sum2 = [&](int q, int r, float2 acc) {   // r in pairs
+        const bool prev_ok = q >= 1 && q - 1 < a.n_valid && r + hop2 < W / 2, cur_ok = q < a.n_valid;
+        const float2 u = prev_ok ? fr[(q - 1) * pitch + phys(r + hop2)] : make_float2(0.f, 0.f);
+        const float2 v = cur_ok ? fr[q * pitch + phys(r)] : make_float2(0.f, 0.f);
+        return make_float2((acc.x + u.y) + v.y, (acc.y + u.x) + v.x);   // components are stored swapped
+    };
+    if (a.write_out) {
+        int q = q0, r = r0;
+#pragma unroll 4
+        for (int c = tid; c < c_end2; c += NT) {
+            float2 acc = c < ncarry2 ? carry2[c] : make_float2(0.f, 0.f);
+            acc = sum2(q, r, acc);
+            const long long o = a.o_first + 2 * c;
+            if (o >= 0) {
+                if (y_aligned && o + 1 < a.out_len) {
+                    *reinterpret_cast<float2*>(a.yc + o) = make_float2(acc.x * a.scale, acc.y * a.scale);
+                } else {
+                    if (o < a.out_len) a.yc[o] = acc.x * a.scale;
+                    if (o + 1 < a.out_len) a.yc[o + 1] = acc.y * a.scale;
+                }
+            }
+            q += qstep;
+            r += rstep;
+            if (r >= hop2) r -= hop2, ++q;
+        }
+    }
+    if (a.make_carry) {
+        int q = q0 + FPB, r = r0;
+        for (int c = tid; c < ncarry2; c += NT) {
+            carry2[c] = sum2(q, r, make_float2(0.f, 0.f));
+            q += qstep;
+            r += rstep;
+            if (r >= hop2) r -= hop2, ++q;
+        }
+    } else {
+        for (int c = tid; c < ncarry2; c += NT) carry2[c] = make_float2(0.f, 0.f);
+    }
+}
+
+#ifdef ZAFX_PROF
+__device__ unsigned long long g_prof[16];
+#define PROF_MARK(i)                                                          \
+    do {                                                                      \
+        const unsigned long long now_ = __builtin_readcyclecounter();        \
+        if (blockIdx.x == 7 && tid == 64) atomicAdd(&g_prof[i], now_ - tprev_); \
+        tprev_ = now_;                                                        \
+    } while (0)
+#define PROF_INIT() unsigned long long tprev_ = __builtin_readcyclecounter()
+#else
+#define PROF_MARK(i)
+#define PROF_INIT()
+#endif
+
+// ---------------------------------------------------------------------------------
+// inverse, reference (frequency-major) layout, persistent carry form
+// ---------------------------------------------------------------------------------
+// One persistent 16-wave workgroup per CU walks the 16-frame tiles of a clip segment IN ORDER and
+// keeps the overlap of the last frames with the next tile (W - hop samples, the "carry") in LDS.
+// Tiles therefore start at t = 16 * tile: every gathered row piece is a 128-B aligned run and no
+// frame is read twice (the halo form re-read ceil(W/H)-1 frames per tile and straddled two lines
+// per run).  A segment that does not start a clip first runs the tile before it in carry-only mode
+// (only its last `halo` frames are loaded and transformed, nothing is written).  The carry slot c
+// is read and rewritten by the same thread, and the adds keep the reference's ascending frame
+// order (zaf.py:226-233), so the result is deterministic.
+//
+// Measured on MI355X (profiles/r01_notes.md): the gather runs at HBM speed only with SHALLOW
+// per-wave queues (16 waves x <= 8 loads; 8 waves x 64 loads of register prefetch ran the same bytes
+// 2x slower), so the tile's sweeps are streamed DEPTH at a time straight into the Hermitian fold;
+// PRE sweeps of the NEXT tile are issued before the FFT phase and folded after it (their latency
+// hides under the FFT).  Barriers order LDS only (lds_barrier): the output stores of a tile are
+// not waited for.
+template <int LOG2N, int LOG2E, int DEPTH, int PRE>
+__global__ __launch_bounds__(1024) void k_istft_ft16(
     const float2* __restrict__ spec, const float2* __restrict__ twp, const float2* __restrict__ tws,
-    float* __restrict__ y, int T, int hop, long long out_len, float scale, int tiles, int total_tiles, int owned, int halo) {
+    float* __restrict__ y, int T, int hop, long long out_len, float scale, int tiles, int segs, int seg_tiles, int total_units,
+    int halo) {
     using C = FftCfg<LOG2N, LOG2E>;
     using F = FatCfg<LOG2N, LOG2E>;
-    constexpr int N = C::N, P = C::P, E = C::E, W = 2 * N, NT = WAVES * 64, FPB = kFatFrames, FPW = FPB / WAVES, PITCH = F::PITCH;
+    constexpr int N = C::N, P = C::P, E = C::E, W = 2 * N, NT = 1024, FPB = kFatFrames, PITCH = F::PITCH;
     constexpr int KSTEP = NT / FPB;            // bins handled per sweep
     constexpr int KI = (N / 2) / KSTEP;        // sweeps per thread
+    constexpr int NPRE = PRE < KI ? PRE : 0;   // sweeps prefetched across the FFT phase
     static_assert((N / 2) % KSTEP == 0, "pair sweep must divide N/2");
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     float2* frames = reinterpret_cast<float2*>(smem_raw);
     float2* tw_l = frames + FPB * PITCH;
     float2* tws_l = tw_l + C::TW;   // N/2 + 1 roots of W
+    float* carry = reinterpret_cast<float*>(tws_l + N / 2 + 1);   // W - hop floats (<= N float2)
     const int tid = threadIdx.x;
     for (int i = tid; i < C::TW; i += NT) tw_l[i] = twp[i];
     for (int i = tid; i <= N / 2; i += NT) tws_l[i] = tws[i];
-    __syncthreads();
     const int wave = tid / P, p = tid % P;
     const int fs = tid % FPB, kq = tid / FPB;
     float2* fbuf = frames + fs * PITCH;
+    const int ncarry = W - hop;
+    const bool pairs = hop % 2 == 0 && 2 * hop >= W;
+    const bool y_base_aligned = reinterpret_cast<uintptr_t>(y) % 8 == 0;
 
-    for (int tl = blockIdx.x; tl < total_tiles; tl += gridDim.x) {
-        const int clip = tl / tiles, tile = tl % tiles;
-        const int t_first = tile * owned - halo;
-        // ---- phase A: gather the four two-sided bins of every pair of my frame, packed spectrum -> LDS
-        {
-            const int t = t_first + fs;
-            if (t >= 0 && t < T) {
-                const float2* sp = spec + (long long)clip * W * T + t;
-#pragma unroll 4
-                for (int i = 0; i < KI; ++i) {
-                    const int k = kq + i * KSTEP;
-                    if (k == 0) {
-                        const float a0 = 2.f * sp[0].x, an = 2.f * sp[(long long)N * T].x;
-                        fbuf[0] = make_float2(a0 - an, a0 + an);
-                        const float2 xc = sp[(long long)(N / 2) * T], xd = sp[(long long)(N + N / 2) * T];
-                        const float2 a = make_float2(xc.x + xd.x, xc.y - xd.y);
-                        fbuf[phys(N / 2)] = make_float2(-2.f * a.y, 2.f * a.x);
-                    } else {
-                        float2 zk, zn;
-                        unsplit_pair(sp[(long long)k * T], sp[(long long)(W - k) * T], sp[(long long)(N - k) * T],
-                                     sp[(long long)(N + k) * T], tws_l[k], zk, zn);
-                        fbuf[phys(k)] = zk;
-                        fbuf[phys(N - k)] = zn;
-                    }
-                }
+    struct Tile {
+        int unit, tile, tile_a, tile_b;
+    };
+    auto enter = [&](Tile& it) {   // first tile of it.unit (one before the segment when it needs a carry)
+        const int seg = it.unit % segs;
+        it.tile_a = seg * seg_tiles;
+        it.tile_b = min(it.tile_a + seg_tiles, tiles);
+        it.tile = it.tile_a > 0 ? it.tile_a - 1 : 0;
+    };
+    auto my_frame_needed = [&](const Tile& it) {
+        return it.tile * FPB + fs < T && fs >= (it.tile < it.tile_a ? FPB - halo : 0);
+    };
+    // Rows k, W-k, N-k, N+k of sweep s (k = 0: rows 0, N/2, N, 3N/2) for my frame.  Buffer loads: the
+    // clip's descriptor and the sweep's row offsets are wave-uniform (SGPRs), the per-lane part is two
+    // 32-bit offsets for the whole tile -- 64-bit flat addresses would cost 8 VGPRs per sweep in flight.
+    const int row_bytes = T * 8;
+    const int v_up = kq * row_bytes + fs * 8, v_down = (KSTEP - kq) * row_bytes + fs * 8;
+    struct Src {
+        __amdgpu_buffer_rsrc_t rsrc;
+        int t_bytes;   // byte offset of the tile's first frame within a row
+    };
+    auto source = [&](const Tile& it) {
+        Src src;
+        src.rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float2*>(spec) + (long long)(it.unit / segs) * W * T, 0,
+                                                     W * row_bytes, 0x00020000);
+        src.t_bytes = it.tile * FPB * 8;
+        return src;
+    };
+    auto ld = [&](const Src& src, int voff, int soff) {
+        const auto raw = __builtin_amdgcn_raw_buffer_load_b64(src.rsrc, voff, soff + src.t_bytes, 0);
+        float2 f;
+        __builtin_memcpy(&f, &raw, 8);
+        return f;
+    };
+    auto load4 = [&](const Src& src, int s, float2 (&r)[4]) {
+        if (s == 0) {   // the sweep that holds k = 0: per-lane row select
+            const int k = kq;
+            r[0] = ld(src, v_up, 0);
+            r[1] = ld(src, (k == 0 ? N / 2 : W - k) * row_bytes + fs * 8, 0);
+            r[2] = ld(src, (N - k) * row_bytes + fs * 8, 0);
+            r[3] = ld(src, (k == 0 ? N + N / 2 : N + k) * row_bytes + fs * 8, 0);
+        } else {
+            r[0] = ld(src, v_up, s * KSTEP * row_bytes);
+            r[1] = ld(src, v_down, (W - (s + 1) * KSTEP) * row_bytes);
+            r[2] = ld(src, v_down, (N - (s + 1) * KSTEP) * row_bytes);
+            r[3] = ld(src, v_up, (N + s * KSTEP) * row_bytes);
+        }
+    };
+    // Hermitian fold of one sweep into the packed half-length spectrum of my frame
+    auto fold4 = [&](int s, const float2 (&r)[4]) {
+        const int k = kq + s * KSTEP;
+        if (k == 0) {   // r = X[0], X[N/2], X[N], X[3N/2]
+            const float a0 = 2.f * r[0].x, an = 2.f * r[2].x;
+            fbuf[0] = make_float2(a0 - an, a0 + an);
+            const float2 a = make_float2(r[1].x + r[3].x, r[1].y - r[3].y);
+            fbuf[phys(N / 2)] = make_float2(-2.f * a.y, 2.f * a.x);
+        } else {
+            float2 zk, zn;
+            unsplit_pair(r[0], r[1], r[2], r[3], tws_l[k], zk, zn);
+            fbuf[phys(k)] = zk;
+            fbuf[phys(N - k)] = zn;
+        }
+    };
+
+    Tile cur;
+    cur.unit = blockIdx.x;
+    if (cur.unit >= total_units) return;
+    enter(cur);
+    for (int c = tid; c < ncarry; c += NT) carry[c] = 0.f;
+    float2 pre[NPRE > 0 ? NPRE : 1][4];
+    if (NPRE > 0 && my_frame_needed(cur)) {
+        const Src sp = source(cur);
+#pragma unroll
+        for (int s = 0; s < NPRE; ++s) load4(sp, s, pre[s]);
+    }
+    lds_barrier();   // tables staged
+    PROF_INIT();
+
+    while (true) {
+        PROF_MARK(0);
+        const bool carry_only = cur.tile < cur.tile_a;
+        const int t_first = cur.tile * FPB;
+        // ---- phase A: fold the prefetched sweeps, stream the rest of the tile
+        if (my_frame_needed(cur)) {
+            const Src sp = source(cur);
+#pragma unroll
+            for (int s = 0; s < NPRE; ++s) fold4(s, pre[s]);
+#pragma unroll DEPTH
+            for (int s = NPRE; s < KI; ++s) {
+                float2 r[4];
+                load4(sp, s, r);
+                fold4(s, r);
             }
         }
-        __syncthreads();
+        PROF_MARK(1);
+        lds_barrier();
+        PROF_MARK(2);
+        Tile nxt = cur;
+        if (++nxt.tile >= nxt.tile_b) {
+            nxt.unit += gridDim.x;
+            if (nxt.unit < total_units) enter(nxt);
+        }
+        const bool has_next = nxt.unit < total_units;
+        if (NPRE > 0 && has_next && my_frame_needed(nxt)) {
+            const Src sp = source(nxt);
+#pragma unroll
+            for (int s = 0; s < NPRE; ++s) load4(sp, s, pre[s]);
+        }
         // ---- phase B: forward FFT of the swapped spectrum == swapped inverse FFT
-#pragma unroll 1
-        for (int f = 0; f < FPW; ++f) {
-            float2* buf = frames + (wave * FPW + f) * PITCH;
+        if (wave >= (carry_only ? FPB - halo : 0)) {   // wave-uniform
+            float2* buf = frames + wave * PITCH;
             float2 v[E];
             regs_read<LOG2N, LOG2E>(v, buf, p);
             frame_sync<P>();
             fft_frame<LOG2N, LOG2E>(v, buf, p, tw_l);
         }
-        __syncthreads();
-        // ---- phase C: gather overlap-add (ascending frames), trim, COLA gain
+        PROF_MARK(3);
+        lds_barrier();
+        PROF_MARK(4);
+        // ---- phase C: overlap-add (carry first), trim (:236-238), COLA gain (:241); next carry
         {
-            const float* fl = reinterpret_cast<const float*>(frames);
-            const int t_end = min((tile + 1) * owned, T);
-            const long long s_begin = (long long)tile * owned * hop;
-            const long long s_end = (tile == tiles - 1) ? (long long)T * hop + (W - hop) : (long long)t_end * hop;
-            float* yc = y + (long long)clip * out_len;
-            for (long long s = s_begin + tid; s < s_end; s += NT) {
-                const long long o = s - (W - hop);
-                if (o < 0 || o >= out_len) continue;
-                const int j_hi = (int)min((long long)(T - 1), s / hop);
-                const int j_lo = s >= W ? (int)((s - W) / hop) + 1 : 0;
-                float acc = 0.f;
-                for (int j = j_lo; j <= j_hi; ++j) {
-                    const int n = (int)(s - (long long)j * hop);
-                    const int f = (2 * phys(n >> 1) + (n & 1)) ^ 1;
-                    acc += fl[(size_t)(j - t_first) * (2 * PITCH) + f];
-                }
-                yc[o] = acc * scale;
-            }
+            OlaArgs a;
+            a.fl = reinterpret_cast<const float*>(frames);
+            a.carry = carry;
+            a.pitch2 = 2 * PITCH;
+            a.ncarry = ncarry;
+            a.hop = hop;
+            a.n_valid = min(FPB, T - t_first);
+            a.c_end = cur.tile == tiles - 1 ? a.n_valid * hop + ncarry : FPB * hop;
+            a.write_out = !carry_only;
+            a.make_carry = cur.tile + 1 < cur.tile_b;
+            const long long clip = cur.unit / segs;
+            a.yc = y + clip * out_len;
+            a.o_first = (long long)t_first * hop - ncarry;
+            a.out_len = out_len;
+            a.scale = scale;
+            if (pairs)
+                ola_phase_pairs<W, NT, FPB>(a, tid, y_base_aligned && (clip * out_len) % 2 == 0);
+            else
+                ola_phase<W, NT, FPB>(a, tid);
         }
-        __syncthreads();
+        PROF_MARK(5);
+        lds_barrier();
+        PROF_MARK(6);
+        if (!has_next) break;
+        cur = nxt;
     }
 }
 
@@ -612,34 +856,54 @@ static hipError_t run_stft(const zafx_plan& pl, const float* x, float2* out, int
     }
 }
 
+// Cut every clip's tiles into `segs` segments so that the persistent grid is evenly loaded: whole
+// clips when there are enough of them, otherwise shorter segments (each pays one carry-only tile).
+static int istft_segments(long long n_clips, int tiles, long long grid) {
+    int best = 1;
+    double best_cost = 1e300;
+    for (int segs = 1; segs <= tiles; ++segs) {
+        const int seg_tiles = (tiles + segs - 1) / segs;
+        if (segs > 1 && (segs - 1) * seg_tiles >= tiles) continue;   // would leave an empty segment
+        const long long rounds = (n_clips * segs + grid - 1) / grid;
+        const double cost = (double)rounds * (seg_tiles + (segs > 1 ? 0.5 : 0.0));
+        if (cost < best_cost - 1e-9) best_cost = cost, best = segs;
+    }
+    return best;
+}
+
 template <int LOG2N>
 static hipError_t run_istft_fat(const zafx_plan& pl, const float2* spec, float* y, int64_t n_clips, int T, int64_t out_len) {
     constexpr int LOG2E = default_log2e(LOG2N);
     using F = FatCfg<LOG2N, LOG2E>;
-    constexpr int WAVES = 16;
-    auto kern = k_istft_ft16<LOG2N, LOG2E, WAVES>;
+    auto kern = k_istft_ft16<LOG2N, LOG2E, 2, 0>;   // measured: 2 sweeps in flight, no cross-phase prefetch (profiles/r01_notes.md)
+    const int nt = 1024;
     if (hipError_t e = ensure_dynamic_lds(reinterpret_cast<const void*>(kern), pl.device, F::SMEM); e != hipSuccess) return e;
     const int W = 2 << LOG2N;
     const int halo = (W + pl.H - 1) / pl.H - 1;
-    const int owned = kFatFrames - halo;
-    if (owned < 1) {
+    if (halo >= kFatFrames) {
         set_error("istft: step_length too small for this window_length (ceil(W/H) exceeds frames per workgroup)");
         return hipErrorInvalidValue;
     }
-    const int tiles = (T + owned - 1) / owned;
-    const long long total = (long long)tiles * n_clips;
-    if (total <= 0 || out_len <= 0) return hipSuccess;
-    const float scale = 1.f / (4.f * (float)(1 << LOG2N) * pl.cola_gain);
+    const int tiles = (T + kFatFrames - 1) / kFatFrames;
+    if ((long long)tiles * n_clips <= 0 || out_len <= 0) return hipSuccess;
     const int per_cu = (int)std::min<size_t>(2, (size_t)kMaxLdsBytes / F::SMEM);
-    const long long grid = std::min<long long>(total, (long long)pl.n_cus * std::max(per_cu, 1));
-    hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(WAVES * 64), F::SMEM, pl.stream, spec, pl.d_tw_pass, pl.d_tw_aux, y, T, pl.H,
-                       (long long)out_len, scale, tiles, (int)total, owned, halo);
+    const long long max_grid = (long long)pl.n_cus * std::max(per_cu, 1);
+    const int segs = istft_segments(n_clips, tiles, max_grid);
+    const int seg_tiles = (tiles + segs - 1) / segs;
+    const long long units = (long long)n_clips * segs;
+    const float scale = 1.f / (4.f * (float)(1 << LOG2N) * pl.cola_gain);
+    const long long grid = std::min<long long>(units, max_grid);
+    hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(nt), F::SMEM, pl.stream, spec, pl.d_tw_pass, pl.d_tw_aux, y, T, pl.H,
+                       (long long)out_len, scale, tiles, segs, seg_tiles, (int)units, halo);
     return hipGetLastError();
 }
 
 template <int LOG2N, int LAYOUT>
 static hipError_t run_istft(const zafx_plan& pl, const float2* spec, float* y, int64_t n_clips, int T, int64_t out_len) {
-    if constexpr (stft_use_fat(LOG2N, LAYOUT)) return run_istft_fat<LOG2N>(pl, spec, y, n_clips, T, out_len);
+    if constexpr (stft_use_fat(LOG2N, LAYOUT)) {
+        // the carry kernel addresses a clip through one buffer descriptor (32-bit byte offsets)
+        if ((long long)(2 << LOG2N) * T * 8 < (1LL << 31)) return run_istft_fat<LOG2N>(pl, spec, y, n_clips, T, out_len);
+    }
     constexpr int LOG2E = default_log2e(LOG2N);
     constexpr int FPB = stft_fpb(LOG2N, ZAFX_LAYOUT_FT);
     using S = StftCfg<LOG2N, LOG2E, FPB>;
@@ -695,3 +959,11 @@ hipError_t launch_istft(const zafx_plan& pl, const float2* spec, float* y, int64
 }
 
 }  // namespace zafx
+
+#ifdef ZAFX_PROF
+extern "C" int zafx_debug_prof(unsigned long long* out) {
+    unsigned long long zero[16] = {};
+    if (hipMemcpyFromSymbol(out, HIP_SYMBOL(zafx::g_prof), sizeof(zero)) != hipSuccess) return 1;
+    return hipMemcpyToSymbol(HIP_SYMBOL(zafx::g_prof), zero, sizeof(zero)) != hipSuccess;
+}
+#endif

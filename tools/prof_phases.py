@@ -1,0 +1,58 @@
+#!/usr/bin/env python3
+"""Per-phase cycle counters of the persistent kernels (library built with -DZAFX_PROF).
+
+    tools/build_prof.sh && ZAFX_LIBRARY=tools/bin/libzafx_prof.so python tools/prof_phases.py istft|mdct|imdct
+"""
+import ctypes
+import os
+import sys
+
+import numpy as np
+
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "zaf-python_amd"))
+import zafx  # noqa: E402
+from zafx import _lib  # noqa: E402
+
+kind = sys.argv[1] if len(sys.argv) > 1 else "istft"
+lib = _lib.load()
+B, N, W, H = 1024, 441000, 2048, 1024
+x = np.random.default_rng(0).standard_normal((8, N)).astype(np.float32)
+d_x = zafx.DeviceBuffer.from_host(np.tile(x, (B // 8, 1)))
+if kind == "istft":
+    w = zafx.hamming(W)
+    fwd, plan = zafx.stft_plan(w, H), zafx.istft_plan(w, H)
+    F, T = fwd.out_dims(N)
+    d_in = zafx.DeviceBuffer((B, F, T), np.complex64)
+    fwd.execute(d_x, d_in, B, N)
+    fwd.sync()
+    n_in, tiles = T, 27
+    d_out = zafx.DeviceBuffer((B, plan.out_dims(T)[0]), np.float32)
+elif kind == "mdct":
+    plan = zafx.mdct_plan(zafx.kaiser_bessel_derived(W))
+    F, T = plan.out_dims(N)
+    d_in, n_in, tiles = d_x, N, (T + 31) // 32
+    d_out = zafx.DeviceBuffer((B, F, T), np.float32)
+elif kind == "imdct":
+    w = zafx.kaiser_bessel_derived(W)
+    fwd, plan = zafx.mdct_plan(w), zafx.mdct_plan(w, inverse=True)
+    F, T = fwd.out_dims(N)
+    d_in = zafx.DeviceBuffer((B, F, T), np.float32)
+    fwd.execute(d_x, d_in, B, N)
+    fwd.sync()
+    n_in, tiles = T, (T + 30) // 31
+    d_out = zafx.DeviceBuffer((B, plan.out_dims(T)[0]), np.float32)
+else:
+    raise SystemExit("kind must be istft, mdct or imdct")
+fn = getattr(lib, "zafx_debug_prof_" + kind)
+out = (ctypes.c_ulonglong * 16)()
+plan.execute(d_in, d_out, B, n_in)
+plan.sync()
+fn(out)
+reps = 5
+for _ in range(reps):
+    plan.execute(d_in, d_out, B, n_in)
+plan.sync()
+fn(out)
+per_tile = reps * tiles * B / 256
+print(kind, "cycles per tile between marks:", " | ".join(f"{i}:{out[i] / per_tile:.0f}" for i in range(10)),
+      "| total", round(sum(out) / per_tile))

@@ -101,7 +101,39 @@ int mdct_frames_per_block(int log2nf, int layout);
 
 void set_error(const std::string& msg);
 
+// Carry kernels (k_istft_ft16, k_imdct): number of segments to cut every clip's tile sequence into so that
+// `grid` persistent workgroups are evenly loaded (1 = whole clips; each extra segment pays one carry-only tile).
+int carry_segments(long long n_clips, int tiles, long long grid);
+
 // Raise a kernel's dynamic-LDS limit to `bytes` on `device` (once per (kernel, device); thread safe).
 hipError_t ensure_dynamic_lds(const void* kernel, int device, size_t bytes);
 
 }  // namespace zafx
+
+// ---------------------------------------------------------------------------------
+// Optional per-phase cycle counters (build with -DZAFX_PROF; tools/prof_phases.py reads them).
+// One wave of one workgroup accumulates the cycles between consecutive PROF_MARKs.
+// ---------------------------------------------------------------------------------
+#ifdef ZAFX_PROF
+#define ZAFX_PROF_ARRAY(name) __device__ unsigned long long name[16];
+#define PROF_INIT(name)                            \
+    unsigned long long* const prof_ = name;        \
+    unsigned long long tprev_ = __builtin_readcyclecounter()
+#define PROF_MARK(i)                                                                       \
+    do {                                                                                   \
+        const unsigned long long now_ = __builtin_readcyclecounter();                     \
+        if (blockIdx.x == 7 && threadIdx.x == 64) atomicAdd(&prof_[i], now_ - tprev_);   \
+        tprev_ = now_;                                                                     \
+    } while (0)
+#define ZAFX_PROF_EXPORT(fn, name)                                                                  \
+    extern "C" int fn(unsigned long long* out) {                                                    \
+        unsigned long long zero[16] = {};                                                           \
+        if (hipMemcpyFromSymbol(out, HIP_SYMBOL(zafx::name), sizeof(zero)) != hipSuccess) return 1; \
+        return hipMemcpyToSymbol(HIP_SYMBOL(zafx::name), zero, sizeof(zero)) != hipSuccess;         \
+    }
+#else
+#define ZAFX_PROF_ARRAY(name)
+#define PROF_INIT(name)
+#define PROF_MARK(i)
+#define ZAFX_PROF_EXPORT(fn, name)
+#endif

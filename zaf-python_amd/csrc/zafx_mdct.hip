@@ -119,22 +119,26 @@ __global__ __launch_bounds__(FPB * fft_threads(LOG2NF, LOG2E)) void k_mdct(
 // transforms 2 frames per tile straight from global memory (no staging copy); the store phase
 // writes frame PAIRS as 8-byte stores so that one instruction covers 4 rows x 128 B.
 constexpr int kMdctTile = 32;
+ZAFX_PROF_ARRAY(g_prof_mdct)
 
 template <int LOG2NF, int LOG2E>
 struct MdctPCfg {
     using C = FftCfg<LOG2NF, LOG2E>;
     static_assert(C::P == 64, "one wavefront per frame");
     static constexpr int NF = C::N;
-    static constexpr int NSLOT = 8;   // 8 fat waves (up to 256 VGPRs): the persistent loop does not spill
+    static constexpr int NSLOT = 16;  // 16 waves x 2 frames per tile: the LDS round trips of the short passes need the occupancy
     static constexpr size_t SMEM = (size_t)(kMdctTile * C::PITCH + C::TW + NF) * 8 + (size_t)NF * 16;
 };
 
-template <int LOG2NF, int LOG2E>
-__global__ __launch_bounds__(512) void k_mdct_ft32(
+template <int LOG2NF, int LOG2E, bool ALIGNED, int NSLOT>
+__global__ __launch_bounds__(NSLOT * 64) void k_mdct_ft32(
     const float* __restrict__ x, const float4* __restrict__ wfold, const float2* __restrict__ twp,
     const float2* __restrict__ tw8, float* __restrict__ out, long long n_samples, int T, int tiles, int total_tiles) {
     using C = FftCfg<LOG2NF, LOG2E>;
-    constexpr int NF = C::N, M = 2 * NF, W = 4 * NF, P = C::P, E = C::E, FPB = kMdctTile, NSLOT = 8, NT = NSLOT * P;
+    constexpr int NF = C::N, M = 2 * NF, W = 4 * NF, P = C::P, E = C::E, FPB = kMdctTile, NT = NSLOT * P;
+    constexpr int FPW = FPB / NSLOT;                    // frames per wave and tile
+    constexpr int NU = NF / 4;                          // 16-sample groups per frame (see fold below)
+    constexpr int UPL = NU >= P ? NU / P : 1;           // groups per lane
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     float2* frames = reinterpret_cast<float2*>(smem_raw);
     float2* tw_l = frames + FPB * C::PITCH;
@@ -143,52 +147,101 @@ __global__ __launch_bounds__(512) void k_mdct_ft32(
     const int tid = threadIdx.x;
     for (int i = tid; i < C::TW; i += NT) tw_l[i] = twp[i];
     for (int i = tid; i < NF; i += NT) { g_l[i] = tw8[i]; wf_l[i] = wfold[i]; }
-    __syncthreads();
+    lds_barrier();
     const int slot = tid / P, p = tid % P;
     const int tp = tid % 16, fq = tid / 16;
     const bool pair_ok = (T % 2 == 0) && (reinterpret_cast<uintptr_t>(out) % 8 == 0);
+    const bool lane_loads = p < NU;
 
-    for (int tl = blockIdx.x; tl < total_tiles; tl += gridDim.x) {
+    // A frame's W = 4 NF samples are fetched as 16-byte pieces.  Group u takes four of them,
+    //   A3 = x[3NF+4u ..+3]   R2 = x[3NF-4-4u ..+3]   A1 = x[NF+4u ..+3]   R0 = x[NF-4-4u ..+3],
+    // exactly the 16 samples that the TDAC fold needs for the four outputs m = 2u, 2u+1, NF-1-2u,
+    // NF-2-2u (every sample of the frame is used once), so the loads are coalesced 1-KB rows per wave
+    // instead of 4-byte gathers.  The next frame of the wave is requested as soon as the current one
+    // is folded: its latency hides under this frame's FFT (or, across tiles, under the store phase).
+    float4 q[UPL][4];
+    auto fetch = [&](int tl, int f) {
+        if (tl >= total_tiles || !lane_loads) return;
+        const int clip = tl / tiles, tile = tl % tiles;
+        const int t = tile * FPB + slot * FPW + f;
+        const float* xc = x + (long long)clip * n_samples;
+        const long long s0 = (long long)t * M - M;   // left pad = M (zaf.py:1036-1041)
+        if (ALIGNED && t < T && s0 >= 0 && s0 + W <= n_samples) {
+            const float* xs = xc + s0;
+#pragma unroll
+            for (int r = 0; r < UPL; ++r) {
+                const int u = p + r * P;
+                q[r][0] = *reinterpret_cast<const float4*>(xs + 3 * NF + 4 * u);
+                q[r][1] = *reinterpret_cast<const float4*>(xs + 3 * NF - 4 - 4 * u);
+                q[r][2] = *reinterpret_cast<const float4*>(xs + NF + 4 * u);
+                q[r][3] = *reinterpret_cast<const float4*>(xs + NF - 4 - 4 * u);
+            }
+        } else {   // clip edges (zero padding), frames past T, unaligned clips
+            auto at = [&](long long s) { return (t < T && s >= 0 && s < n_samples) ? xc[s] : 0.f; };
+#pragma unroll
+            for (int r = 0; r < UPL; ++r) {
+                const int u = p + r * P;
+                const long long b3 = s0 + 3 * NF + 4 * u, b2 = s0 + 3 * NF - 4 - 4 * u, b1 = s0 + NF + 4 * u, b0 = s0 + NF - 4 - 4 * u;
+                q[r][0] = make_float4(at(b3), at(b3 + 1), at(b3 + 2), at(b3 + 3));
+                q[r][1] = make_float4(at(b2), at(b2 + 1), at(b2 + 2), at(b2 + 3));
+                q[r][2] = make_float4(at(b1), at(b1 + 1), at(b1 + 2), at(b1 + 3));
+                q[r][3] = make_float4(at(b0), at(b0 + 1), at(b0 + 2), at(b0 + 3));
+            }
+        }
+    };
+    // fold + window + pre-twiddle: c[m] = (xa wa + xb wb, xc wc + xd wd) g_m -> LDS, natural order
+    auto fold = [&](float2* buf) {
+        if (!lane_loads) return;
+        int opaque = 0;   // keeps the per-lane table reads inside the loop: hoisted, they cost 48 VGPRs and spill
+        asm volatile("" : "+v"(opaque));
+#pragma unroll
+        for (int r = 0; r < UPL; ++r) {
+            const int u = p + r * P + opaque;
+            const float4 A3 = q[r][0], R2 = q[r][1], A1 = q[r][2], R0 = q[r][3];
+            const int m0 = 2 * u, m1 = 2 * u + 1, m2 = NF - 1 - 2 * u, m3 = NF - 2 - 2 * u;
+            const float4 w0 = wf_l[m0], w1 = wf_l[m1], w2 = wf_l[m2], w3 = wf_l[m3];
+            buf[phys(m0)] = cmul(make_float2(R2.w * w0.x + A3.x * w0.y, R0.w * w0.z + A1.x * w0.w), g_l[m0]);
+            buf[phys(m1)] = cmul(make_float2(R2.y * w1.x + A3.z * w1.y, R0.y * w1.z + A1.z * w1.w), g_l[m1]);
+            buf[phys(m2)] = cmul(make_float2(R0.z * w2.x + A1.y * w2.y, R2.z * w2.z + A3.y * w2.w), g_l[m2]);
+            buf[phys(m3)] = cmul(make_float2(R0.x * w3.x + A1.w * w3.y, R2.x * w3.z + A3.w * w3.w), g_l[m3]);
+        }
+    };
+
+    int tl = blockIdx.x;
+    fetch(tl, 0);
+    PROF_INIT(g_prof_mdct);
+    for (; tl < total_tiles; tl += gridDim.x) {
         const int clip = tl / tiles, tile = tl % tiles;
         const int t0 = tile * FPB;
-        const float* xc = x + (long long)clip * n_samples;
+        PROF_MARK(0);
 #pragma unroll 1
-        for (int f = 0; f < FPB / NSLOT; ++f) {
-            const int j = slot * (FPB / NSLOT) + f;
-            const int t = t0 + j;
-            const long long s0 = (long long)t * M - M;   // left pad = M (zaf.py:1036-1041)
-            const bool live = t < T;
-            const bool interior = live && s0 >= 0 && s0 + W <= n_samples;
+        for (int f = 0; f < FPW; ++f) {
+            float2* buf = frames + (slot * FPW + f) * C::PITCH;
+            fold(buf);
+            PROF_MARK(1);
+            if (f + 1 < FPW) fetch(tl, f + 1);
+            else fetch(tl + gridDim.x, 0);
+            frame_sync<P>();
+            int po = p;   // opaque copy: the pass-twiddle reads stay in the loop (hoisted, they spill at 128 VGPRs)
+            asm volatile("" : "+v"(po));
             float2 v[E];
-#pragma unroll
-            for (int i = 0; i < E; ++i) {
-                const int m = p + i * P;
-                int a, b, c, d;
-                if (i < E / 2) { a = 3 * NF - 1 - 2 * m; b = 3 * NF + 2 * m; c = NF - 1 - 2 * m; d = NF + 2 * m; }
-                else { a = 2 * m - NF; b = 3 * NF - 1 - 2 * m; c = NF + 2 * m; d = 5 * NF - 1 - 2 * m; }
-                float xa, xb, xcv, xd;
-                if (interior) {
-                    xa = xc[s0 + a]; xb = xc[s0 + b]; xcv = xc[s0 + c]; xd = xc[s0 + d];
-                } else {
-                    const long long sa = s0 + a, sb = s0 + b, sc = s0 + c, sd = s0 + d;
-                    xa = (live && sa >= 0 && sa < n_samples) ? xc[sa] : 0.f;
-                    xb = (live && sb >= 0 && sb < n_samples) ? xc[sb] : 0.f;
-                    xcv = (live && sc >= 0 && sc < n_samples) ? xc[sc] : 0.f;
-                    xd = (live && sd >= 0 && sd < n_samples) ? xc[sd] : 0.f;
-                }
-                const float4 wf = wf_l[m];
-                v[i] = cmul(make_float2(xa * wf.x + xb * wf.y, xcv * wf.z + xd * wf.w), g_l[m]);
-            }
-            fft_frame<LOG2NF, LOG2E>(v, frames + j * C::PITCH, p, tw_l);
+            regs_read<LOG2NF, LOG2E>(v, buf, po);
+            frame_sync<P>();
+            fft_frame<LOG2NF, LOG2E>(v, buf, po, tw_l);
+            PROF_MARK(2);
         }
-        __syncthreads();
+        lds_barrier();
+        PROF_MARK(3);
         const int ta = t0 + 2 * tp;
         if (ta < T) {
+            int fqo = fq;   // opaque copy: g_l[k] of the 16 iterations is not carried across tiles
+            asm volatile("" : "+v"(fqo));
             const float2* ba = frames + (2 * tp) * C::PITCH;
             const float2* bb = ba + C::PITCH;
             float* o = out + (long long)clip * M * T + ta;
             const bool two = ta + 1 < T;
-            for (int f = fq; f < M; f += NT / 16) {
+#pragma unroll 4
+            for (int f = fqo; f < M; f += NT / 16) {
                 const int k = (f & 1) ? (M - 1 - f) >> 1 : f >> 1;
                 const float2 g = g_l[k];
                 const float2 ya = cmul(ba[phys(k)], g), yb = cmul(bb[phys(k)], g);
@@ -201,43 +254,63 @@ __global__ __launch_bounds__(512) void k_mdct_ft32(
                 }
             }
         }
-        __syncthreads();
+        PROF_MARK(4);
+        lds_barrier();   // LDS reads of the tile are done; its global stores are not waited for
     }
 }
 
 // ---------------------------------------------------------------------------------
 // inverse
 // ---------------------------------------------------------------------------------
+// Persistent carry form (as k_istft_ft16): one workgroup per CU walks the FPB-frame tiles of a clip
+// segment in order; the second-half contribution of a tile's last frame (M samples, "carry") stays
+// in LDS for the next tile.  Tiles start at t = FPB * tile, so the time-minor gather reads aligned
+// 128-B runs and no frame is read twice (the halo form re-read one frame in 32 and straddled two
+// lines per run).  A segment that does not start a clip first runs the tile before it in carry-only
+// mode (its last frame alone).  Barriers order LDS only; the output stores are not waited for.
 template <int LOG2NF, int LOG2E, int FPB, int NSLOT, int LAYOUT>
 __global__ __launch_bounds__(NSLOT * fft_threads(LOG2NF, LOG2E)) void k_imdct(
     const float* __restrict__ coefs, const float* __restrict__ win, const float2* __restrict__ twp,
-    const float2* __restrict__ tw8g, float* __restrict__ y, int T, long long out_len, int tiles, int total_tiles) {
+    const float2* __restrict__ tw8g, float* __restrict__ y, int T, long long out_len, int tiles, int segs, int seg_tiles,
+    int total_units) {
     using C = FftCfg<LOG2NF, LOG2E>;
     constexpr int NF = C::N, M = 2 * NF, P = C::P, E = C::E, NT = NSLOT * P;
-    constexpr int OWNED = FPB - 1;   // one halo frame: every output sample sums exactly 2 frames
     static_assert(NT % FPB == 0 || LAYOUT == ZAFX_LAYOUT_TF, "time-minor gather needs NT to be a multiple of FPB");
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     float2* frames = reinterpret_cast<float2*>(smem_raw);
     float2* tw_l = frames + FPB * C::PITCH;
     float2* tw8 = tw_l + C::TW;                         // g_m, NF entries
     float* win_l = reinterpret_cast<float*>(tw8 + NF);  // window, 4 NF floats
+    float* carry = win_l + 4 * NF;                      // M floats
     const int tid = threadIdx.x;
     for (int i = tid; i < C::TW; i += NT) tw_l[i] = twp[i];
     for (int i = tid; i < NF; i += NT) tw8[i] = tw8g[i];
     for (int i = tid; i < 4 * NF; i += NT) win_l[i] = win[i];
-    __syncthreads();
+    lds_barrier();
+    const float* fl = reinterpret_cast<const float*>(frames);
+    const float gain = 2.f / (float)M;
+    // second half (n0 = n1 + M) of a frame's unfolded, windowed output: what it adds to the next frame's span
+    auto older = [&](const float* fr, int n1) {
+        const int n0 = n1 + M;
+        const float uu = (n0 < 3 * NF) ? -fr[fidx(3 * NF - 1 - n0)] : -fr[fidx(n0 - 3 * NF)];
+        return uu * win_l[n0];
+    };
 
-    // persistent: one workgroup per CU loops over the tiles, the tables above are staged once
-    for (int tl = blockIdx.x; tl < total_tiles; tl += gridDim.x) {
-    const int clip = tl / tiles, tile = tl % tiles;
-    const int t_first = tile * OWNED - 1;
+    for (int unit = blockIdx.x; unit < total_units; unit += gridDim.x) {
+    const int clip = unit / segs, seg = unit % segs;
+    const int tile_a = seg * seg_tiles, tile_b = min(tile_a + seg_tiles, tiles);
+    for (int c = tid; c < M; c += NT) carry[c] = 0.f;
+    for (int tile = tile_a > 0 ? tile_a - 1 : 0; tile < tile_b; ++tile) {
+    const bool carry_only = tile < tile_a;
+    const int t_first = tile * FPB;
+    const int first_needed = carry_only ? FPB - 1 : 0;
 
     // ---- phase A: c[m] = (X[2m] + i X[M-1-2m]) g_m  -> LDS (natural order)
     if constexpr (LAYOUT == ZAFX_LAYOUT_TF) {
         const int mq = tid % P;
         for (int fs = tid / P; fs < FPB; fs += NSLOT) {
             const int t = t_first + fs;
-            if (t < 0 || t >= T) continue;
+            if (t >= T || fs < first_needed) continue;
             float2* fb = frames + fs * C::PITCH;
             const float* cp = coefs + ((long long)clip * T + t) * M;
             for (int m = mq; m < NF; m += P) fb[phys(m)] = cmul(make_float2(cp[2 * m], cp[M - 1 - 2 * m]), tw8[m]);
@@ -245,9 +318,10 @@ __global__ __launch_bounds__(NSLOT * fft_threads(LOG2NF, LOG2E)) void k_imdct(
     } else {
         const int fs = tid % FPB, mq = tid / FPB;   // lanes run along t: FPB * 4 B contiguous per row
         const int t = t_first + fs;
-        if (t >= 0 && t < T) {
+        if (t < T && fs >= first_needed) {
             float2* fb = frames + fs * C::PITCH;
             const float* cp = coefs + (long long)clip * M * T + t;
+#pragma unroll 4
             for (int m = mq; m < NF; m += NT / FPB) {
                 const float re = cp[(long long)(2 * m) * T];
                 const float im = cp[(long long)(M - 1 - 2 * m) * T];
@@ -255,13 +329,14 @@ __global__ __launch_bounds__(NSLOT * fft_threads(LOG2NF, LOG2E)) void k_imdct(
             }
         }
     }
-    __syncthreads();
+    lds_barrier();
 
     // ---- phase B: FFT, then DCT-IV post-twiddle written in place as M reals per frame
     {
         const int p = tid % P;
 #pragma unroll 1
         for (int slot = tid / P; slot < FPB; slot += NSLOT) {
+            if (P <= 64 && slot < first_needed) continue;   // (frames wider than a wave synchronise with s_barrier: no skipping)
             float2* buf = frames + slot * C::PITCH;
             float2 v[E];
             regs_read<LOG2NF, LOG2E>(v, buf, p);
@@ -277,37 +352,34 @@ __global__ __launch_bounds__(NSLOT * fft_threads(LOG2NF, LOG2E)) void k_imdct(
             }
         }
     }
-    __syncthreads();
+    lds_barrier();
 
-    // ---- phase C: unfold + window + TDAC overlap-add of the 2 covering frames, trim (zaf.py:1166-1182)
+    // ---- phase C: unfold + window + TDAC overlap-add of the 2 covering frames (older first, as the
+    //      reference's loop), trim (zaf.py:1166-1182); then the carry for the next tile
     {
-        const float* fl = reinterpret_cast<const float*>(frames);
-        const float gain = 2.f / (float)M;
-        const int t_end = min((tile + 1) * OWNED, T);
-        const long long s_begin = (long long)tile * OWNED * M;
-        const long long s_end = (tile == tiles - 1) ? (long long)(T + 1) * M : (long long)t_end * M;
-        float* yc = y + (long long)clip * out_len;
-        for (long long s = s_begin + tid; s < s_end; s += NT) {
-            const long long o = s - M;
-            if (o < 0 || o >= out_len) continue;
-            const int j1 = (int)(s / M);
-            const int n1 = (int)(s - (long long)j1 * M);   // in [0, M)
-            float acc = 0.f;
-            if (j1 >= 1) {   // older frame first (ascending j, as the reference's loop)
-                const int n0 = n1 + M;   // in [M, 2M)
-                const float* fr = fl + (size_t)(j1 - 1 - t_first) * (2 * C::PITCH);
-                const float uu = (n0 < 3 * NF) ? -fr[fidx(3 * NF - 1 - n0)] : -fr[fidx(n0 - 3 * NF)];
-                acc += uu * win_l[n0];
+        const int n_valid = min(FPB, T - t_first);
+        if (!carry_only) {
+            const int c_end = tile == tiles - 1 ? (n_valid + 1) * M : FPB * M;
+            float* yc = y + (long long)clip * out_len;
+            const long long o_first = (long long)t_first * M - M;
+            for (int c = tid; c < c_end; c += NT) {
+                const int j1 = c / M, n1 = c % M;
+                float acc = j1 >= 1 ? older(fl + (size_t)(j1 - 1) * (2 * C::PITCH), n1) : carry[n1];
+                if (j1 < n_valid) {
+                    const float* fr = fl + (size_t)j1 * (2 * C::PITCH);
+                    const float uu = (n1 < NF) ? fr[fidx(NF + n1)] : -fr[fidx(3 * NF - 1 - n1)];
+                    acc += uu * win_l[n1];
+                }
+                const long long o = o_first + c;
+                if (o >= 0 && o < out_len) yc[o] = acc * gain;
             }
-            if (j1 < T) {
-                const float* fr = fl + (size_t)(j1 - t_first) * (2 * C::PITCH);
-                const float uu = (n1 < NF) ? fr[fidx(NF + n1)] : -fr[fidx(3 * NF - 1 - n1)];
-                acc += uu * win_l[n1];
-            }
-            yc[o] = acc * gain;
+        }
+        if (tile + 1 < tile_b) {   // then n_valid == FPB
+            for (int c = tid; c < M; c += NT) carry[c] = older(fl + (size_t)(FPB - 1) * (2 * C::PITCH), c);
         }
     }
-    __syncthreads();   // the next tile overwrites the frame buffers
+    lds_barrier();   // the next tile overwrites the frame buffers
+    }
     }
 }
 
@@ -336,7 +408,8 @@ template <int LOG2NF>
 static hipError_t run_mdct_p(const zafx_plan& pl, const float* x, float* out, int64_t n_clips, int64_t n_samples, int T) {
     constexpr int LOG2E = default_log2e(LOG2NF);
     using G = MdctPCfg<LOG2NF, LOG2E>;
-    auto kern = k_mdct_ft32<LOG2NF, LOG2E>;
+    const bool aligned = n_samples % 4 == 0 && reinterpret_cast<uintptr_t>(x) % 16 == 0;
+    auto kern = aligned ? k_mdct_ft32<LOG2NF, LOG2E, true, G::NSLOT> : k_mdct_ft32<LOG2NF, LOG2E, false, G::NSLOT>;
     if (hipError_t e = ensure_dynamic_lds(reinterpret_cast<const void*>(kern), pl.device, G::SMEM); e != hipSuccess) return e;
     const int tiles = (T + kMdctTile - 1) / kMdctTile;
     const long long total = (long long)tiles * n_clips;
@@ -367,11 +440,11 @@ static hipError_t run_mdct(const zafx_plan& pl, const float* x, float* out, int6
     }
 }
 
-// IMDCT tile geometry: FPB frames resident (FPB - 1 owned + 1 halo), NSLOT of them transformed at a time.
+// IMDCT tile geometry: FPB frames resident, NSLOT of them transformed at a time.
 // The time-minor layout wants FPB = 32 (32 frames x 4 B = one 128-B line per gathered row).
 constexpr int imdct_fpb(int log2nf, int layout) {
     const int pitch = (1 << log2nf) + ((1 << log2nf) >> 4) + 1;
-    const int lds_cap = (kMaxLdsBytes - twiddle_total(log2nf, default_log2e(log2nf)) * 8 - (24 << log2nf)) / (pitch * 8);
+    const int lds_cap = (kMaxLdsBytes - twiddle_total(log2nf, default_log2e(log2nf)) * 8 - (32 << log2nf)) / (pitch * 8);
     int f = layout == ZAFX_LAYOUT_FT ? 32 : 8;
     while (f > lds_cap) f /= 2;
     return f < 2 ? 2 : f;
@@ -391,18 +464,20 @@ static hipError_t run_imdct(const zafx_plan& pl, const float* coefs, float* y, i
     constexpr int FPB = imdct_fpb(LOG2NF, LAYOUT);
     constexpr int NSLOT = imdct_nslot(LOG2NF, FPB);
     using C = FftCfg<LOG2NF, LOG2E>;
-    constexpr size_t SMEM = (size_t)(FPB * C::PITCH + C::TW + C::N) * 8 + (size_t)C::N * 16;   // frames + twiddles + g_m + window
+    constexpr size_t SMEM = (size_t)(FPB * C::PITCH + C::TW + C::N) * 8 + (size_t)C::N * 16 + (size_t)C::N * 8;   // frames + twiddles + g_m + window + carry
     static_assert(SMEM <= (size_t)kMaxLdsBytes, "IMDCT tile does not fit LDS");
     auto kern = k_imdct<LOG2NF, LOG2E, FPB, NSLOT, LAYOUT>;
     if (hipError_t e = ensure_dynamic_lds(reinterpret_cast<const void*>(kern), pl.device, SMEM); e != hipSuccess) return e;
-    constexpr int OWNED = FPB - 1;
-    const int tiles = (T + OWNED - 1) / OWNED;
-    const long long total = (long long)tiles * n_clips;
-    if (total <= 0 || out_len <= 0) return hipSuccess;
+    const int tiles = (T + FPB - 1) / FPB;
+    if ((long long)tiles * n_clips <= 0 || out_len <= 0) return hipSuccess;
     const int per_cu = (int)std::min<size_t>(2, (size_t)kMaxLdsBytes / SMEM);
-    const long long grid = std::min<long long>(total, (long long)pl.n_cus * std::max(per_cu, 1));
+    const long long max_grid = (long long)pl.n_cus * std::max(per_cu, 1);
+    const int segs = carry_segments(n_clips, tiles, max_grid);
+    const int seg_tiles = (tiles + segs - 1) / segs;
+    const long long units = (long long)n_clips * segs;
+    const long long grid = std::min<long long>(units, max_grid);
     hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(NSLOT * C::P), SMEM, pl.stream, coefs, pl.d_window, pl.d_tw_pass, pl.d_tw_aux, y, T,
-                       (long long)out_len, tiles, (int)total);
+                       (long long)out_len, tiles, segs, seg_tiles, (int)units);
     return hipGetLastError();
 }
 
@@ -438,3 +513,5 @@ hipError_t launch_imdct(const zafx_plan& pl, const float* coefs, float* y, int64
 }
 
 }  // namespace zafx
+
+ZAFX_PROF_EXPORT(zafx_debug_prof_mdct, g_prof_mdct)

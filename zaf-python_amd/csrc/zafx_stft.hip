@@ -188,35 +188,34 @@ __global__ __launch_bounds__(kFatWaves * 64) void k_stft_ft16(
     // inside the clip issues 2 x 16 unconditional 8-byte loads with no control flow in between, so the
     // loads stay in flight across the store phase; only the first and last tiles of a clip take the
     // predicated path (zero padding of zaf.py:112-125).
-    auto prefetch = [&](int tl) {
+    auto prefetch = [&](int tl, auto which) {   // which = frame slot of the wave (compile-time)
+        constexpr int f = decltype(which)::value;
         if (tl >= total_tiles) return;
         const int clip = tl / tiles, tile = tl % tiles;
         const float* xc = x + (long long)clip * n_samples;
         const long long first = (long long)tile * FPB * hop - N;               // first sample of the tile
         const long long last = first + (long long)(FPB - 1) * hop + W;          // one past its last sample
         if (ALIGNED && first >= 0 && last <= n_samples && tile * FPB + FPB <= T) {
-            const float* src = xc + first + (long long)(wave * FPW) * hop + 2 * p;
+            const float* src = xc + first + (long long)(wave * FPW + f) * hop + 2 * p;
 #pragma unroll
-            for (int f = 0; f < FPW; ++f) {
-#pragma unroll
-                for (int i = 0; i < E; ++i) xr[f][i] = *reinterpret_cast<const float2*>(src + (long long)f * hop + 2 * i * P);
-            }
+            for (int i = 0; i < E; ++i) xr[f][i] = *reinterpret_cast<const float2*>(src + 2 * i * P);
         } else {
+            const int t = tile * FPB + wave * FPW + f;
+            const long long s0 = (long long)t * hop - N;
 #pragma unroll
-            for (int f = 0; f < FPW; ++f) {
-                const int t = tile * FPB + wave * FPW + f;
-                const long long s0 = (long long)t * hop - N;
-#pragma unroll
-                for (int i = 0; i < E; ++i) {
-                    const long long s = s0 + 2 * (p + i * P);
-                    xr[f][i].x = (t < T && s >= 0 && s < n_samples) ? xc[s] : 0.f;
-                    xr[f][i].y = (t < T && s + 1 >= 0 && s + 1 < n_samples) ? xc[s + 1] : 0.f;
-                }
+            for (int i = 0; i < E; ++i) {
+                const long long s = s0 + 2 * (p + i * P);
+                xr[f][i].x = (t < T && s >= 0 && s < n_samples) ? xc[s] : 0.f;
+                xr[f][i].y = (t < T && s + 1 >= 0 && s + 1 < n_samples) ? xc[s + 1] : 0.f;
             }
         }
     };
+    static_assert(FPW == 2, "prefetch schedule below is written for two frames per wave");
+    constexpr std::integral_constant<int, 0> f0{};
+    constexpr std::integral_constant<int, 1> f1{};
     int tl = blockIdx.x;
-    prefetch(tl);
+    prefetch(tl, f0);
+    prefetch(tl, f1);
     for (; tl < total_tiles; tl += gridDim.x) {
         const int clip = tl / tiles, tile = tl % tiles;
         const int t0 = tile * FPB;
@@ -231,10 +230,13 @@ __global__ __launch_bounds__(kFatWaves * 64) void k_stft_ft16(
             fft_frame<LOG2N, LOG2E>(v, frames + (wave * FPW + f) * PITCH, p, tw_l);
         }
         lds_barrier();
-        prefetch(tl + gridDim.x);   // in flight while this tile is stored
-        if (t0 + tt < T) {
+        // The next tile's samples are fetched in two halves, one per frame slot, so that a wave never
+        // has more than E loads queued behind its stores (deep per-wave queues stall the gather path).
+        prefetch(tl + gridDim.x, f0);
+        {
+            const bool live = t0 + tt < T;
             float2* o = out + (long long)clip * W * T + (t0 + tt);
-            for (int k = kq; k < N / 2; k += NT / FPB) {
+            auto store_rows = [&](int k) {
                 if (k == 0) {
                     const float2 z0 = fb[0], zc = fb[phys(N / 2)];
                     o[0] = make_float2(z0.x + z0.y, 0.f);
@@ -249,7 +251,12 @@ __global__ __launch_bounds__(kFatWaves * 64) void k_stft_ft16(
                     o[(long long)(N - k) * T] = xn;
                     o[(long long)(N + k) * T] = cconj(xn);
                 }
-            }
+            };
+            if (live)
+                for (int k = kq; k < N / 4; k += NT / FPB) store_rows(k);
+            prefetch(tl + gridDim.x, f1);
+            if (live)
+                for (int k = kq + N / 4; k < N / 2; k += NT / FPB) store_rows(k);
         }
         lds_barrier();   // LDS reads of the tile are done; its global stores are NOT waited for
     }
@@ -565,19 +572,7 @@ __device__ __forceinline__ void ola_phase_pairs(const OlaArgs& a, int tid, bool 
     }
 }
 
-#ifdef ZAFX_PROF
-__device__ unsigned long long g_prof[16];
-#define PROF_MARK(i)                                                          \
-    do {                                                                      \
-        const unsigned long long now_ = __builtin_readcyclecounter();        \
-        if (blockIdx.x == 7 && tid == 64) atomicAdd(&g_prof[i], now_ - tprev_); \
-        tprev_ = now_;                                                        \
-    } while (0)
-#define PROF_INIT() unsigned long long tprev_ = __builtin_readcyclecounter()
-#else
-#define PROF_MARK(i)
-#define PROF_INIT()
-#endif
+ZAFX_PROF_ARRAY(g_prof)
 
 // ---------------------------------------------------------------------------------
 // inverse, reference (frequency-major) layout, persistent carry form
@@ -700,7 +695,7 @@ __global__ __launch_bounds__(1024) void k_istft_ft16(
         for (int s = 0; s < NPRE; ++s) load4(sp, s, pre[s]);
     }
     lds_barrier();   // tables staged
-    PROF_INIT();
+    PROF_INIT(g_prof);
 
     while (true) {
         PROF_MARK(0);
@@ -858,7 +853,7 @@ static hipError_t run_stft(const zafx_plan& pl, const float* x, float2* out, int
 
 // Cut every clip's tiles into `segs` segments so that the persistent grid is evenly loaded: whole
 // clips when there are enough of them, otherwise shorter segments (each pays one carry-only tile).
-static int istft_segments(long long n_clips, int tiles, long long grid) {
+int carry_segments(long long n_clips, int tiles, long long grid) {
     int best = 1;
     double best_cost = 1e300;
     for (int segs = 1; segs <= tiles; ++segs) {
@@ -888,7 +883,7 @@ static hipError_t run_istft_fat(const zafx_plan& pl, const float2* spec, float* 
     if ((long long)tiles * n_clips <= 0 || out_len <= 0) return hipSuccess;
     const int per_cu = (int)std::min<size_t>(2, (size_t)kMaxLdsBytes / F::SMEM);
     const long long max_grid = (long long)pl.n_cus * std::max(per_cu, 1);
-    const int segs = istft_segments(n_clips, tiles, max_grid);
+    const int segs = carry_segments(n_clips, tiles, max_grid);
     const int seg_tiles = (tiles + segs - 1) / segs;
     const long long units = (long long)n_clips * segs;
     const float scale = 1.f / (4.f * (float)(1 << LOG2N) * pl.cola_gain);
@@ -960,10 +955,4 @@ hipError_t launch_istft(const zafx_plan& pl, const float2* spec, float* y, int64
 
 }  // namespace zafx
 
-#ifdef ZAFX_PROF
-extern "C" int zafx_debug_prof(unsigned long long* out) {
-    unsigned long long zero[16] = {};
-    if (hipMemcpyFromSymbol(out, HIP_SYMBOL(zafx::g_prof), sizeof(zero)) != hipSuccess) return 1;
-    return hipMemcpyToSymbol(HIP_SYMBOL(zafx::g_prof), zero, sizeof(zero)) != hipSuccess;
-}
-#endif
+ZAFX_PROF_EXPORT(zafx_debug_prof_istft, g_prof)

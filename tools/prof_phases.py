@@ -41,8 +41,16 @@ elif kind == "imdct":
     fwd.sync()
     n_in, tiles = T, (T + 30) // 31
     d_out = zafx.DeviceBuffer((B, plan.out_dims(T)[0]), np.float32)
+elif kind == "cqt":
+    B, N = 128, 1323000
+    x = np.random.default_rng(0).standard_normal((8, N)).astype(np.float32)
+    d_in = zafx.DeviceBuffer.from_host(np.tile(x, (B // 8, 1)))
+    plan = zafx.cqt_plan(44100, 25, zafx.cqtkernel(44100, 24, 55, 3520))
+    F, T = plan.out_dims(N)
+    n_in, tiles = N, T * 1.0   # marks are per frame here
+    d_out = zafx.DeviceBuffer((B, F, T), np.float32)
 else:
-    raise SystemExit("kind must be istft, mdct or imdct")
+    raise SystemExit("kind must be istft, mdct, imdct or cqt")
 fn = getattr(lib, "zafx_debug_prof_" + kind)
 out = (ctypes.c_ulonglong * 16)()
 plan.execute(d_in, d_out, B, n_in)
@@ -53,6 +61,6 @@ for _ in range(reps):
     plan.execute(d_in, d_out, B, n_in)
 plan.sync()
 fn(out)
-per_tile = reps * tiles * B / 256
+per_tile = reps * (16 if kind == 'cqt' else tiles * B / 256)   # cqt: workgroup 7 = 16 frames per launch, counts are per frame
 print(kind, "cycles per tile between marks:", " | ".join(f"{i}:{out[i] / per_tile:.0f}" for i in range(10)),
       "| total", round(sum(out) / per_tile))

@@ -246,6 +246,30 @@ static int build_cqt_chunks(zafx_plan* pl) {
     }
     ptr[(size_t)n_waves] = (int)flat.size() / 4;
     pl->n_chunks = (int)flat.size() / 4;
+    // Every column c of the kernel becomes the LDS slot of the one-sided spectrum that k_cqt reads
+    // (bit 31: conjugate, for a column of the upper half), and the (k, N-k) pairs of the real split
+    // that those slots need are bounded by [k_lo, k_hi] (+ the special group {0, N/2, N}).
+    {
+        const int n = pl->W / 2, w = pl->W;
+        auto phys_slot = [](int i) { return i + (i >> 4); };
+        const int pitch = n + (n >> 4) + 1;
+        std::vector<int32_t> slots(pl->h_indices.size());
+        int k_lo = n, k_hi = -1, special = 0;
+        for (size_t e = 0; e < pl->h_indices.size(); ++e) {
+            const int c = pl->h_indices[e];
+            if (c < 0 || c >= w) return fail_msg("CQT kernel column index out of range");
+            const int m = c <= n ? c : w - c;   // one-sided bin holding X[c] (conjugated when c > n)
+            slots[e] = (m == n ? pitch - 1 : phys_slot(m)) | (c > n ? (int32_t)0x80000000 : 0);
+            const int k = std::min(m, n - m);   // pair index of the real split
+            if (k == 0 || 2 * m == n) special = 1;
+            else k_lo = std::min(k_lo, k), k_hi = std::max(k_hi, k);
+        }
+        pl->cqt_k_lo = k_lo;
+        pl->cqt_k_hi = k_hi;
+        pl->cqt_k_special = special;
+        if (slots.empty()) slots.assign(1, 0);
+        ZAFX_HIP(upload(&pl->d_slots, slots.data(), slots.size() * sizeof(int32_t)));
+    }
     if (flat.empty()) flat.assign(4, 0);
     ZAFX_HIP(upload(&pl->d_chunks, flat.data(), flat.size() * sizeof(int)));
     ZAFX_HIP(upload(&pl->d_chunk_ptr, ptr.data(), ptr.size() * sizeof(int)));
@@ -364,9 +388,7 @@ int zafx_plan_create(zafx_plan** out, int device, int kind, const zafx_params* p
         if (kind == ZAFX_CHROMA && (params->octave_resolution < 1 || params->octave_resolution > params->n_bins))
             return bail("octave_resolution must be in [1, n_bins]");
         pl->log2nf = lw - 1;
-        const int n = pl->W / 2;
-        aux.resize((size_t)n / 2 + 1);
-        for (int k = 0; k <= n / 2; ++k) aux[(size_t)k] = unit_root(k, pl->W);
+        aux = build_split_two_level_twiddles(pl->log2nf);   // exp(-2 pi i k / W), k < W/4, as hi[k >> 7] * lo[k & 127]
         pl->kernel_name = cqt_kernel_name();
     } else if (kind == ZAFX_LINEAR) {
         pl->W = params->window_length;
@@ -412,6 +434,7 @@ int zafx_plan_destroy(zafx_plan* pl) {
     if (pl->d_indices) (void)hipFree(pl->d_indices);
     if (pl->d_values) (void)hipFree(pl->d_values);
     if (pl->d_chunks) (void)hipFree(pl->d_chunks);
+    if (pl->d_slots) (void)hipFree(pl->d_slots);
     if (pl->d_chunk_ptr) (void)hipFree(pl->d_chunk_ptr);
     free_band(pl->fb);
     free_band(pl->dct);

@@ -13,113 +13,158 @@
 // lanes across the row's contiguous non-zeros, shuffle reduction) and the magnitudes of
 // the 16 frames are staged in LDS so that the (n_bins, T) store writes 64-B runs along t.
 // The chromagram (zaf.py:693-698) is a strided row sum over that LDS tile.
+#include <algorithm>
+
 #include "zafx_fft.hpp"
 #include "zafx_internal.hpp"
 
 namespace zafx {
 
 constexpr int kCqtFramesPerBlock = 16;
+ZAFX_PROF_ARRAY(g_prof_cqt)
 
+// LDS carve shared by the kernel and the launcher (bytes before the chunk descriptors, 16-B aligned:
+// a misaligned ds_read_b128 is replayed at 64 cycles)
 template <int LOG2N, int LOG2E>
+struct CqtCfg {
+    using C = FftCfg<LOG2N, LOG2E>;
+    static constexpr int NHI = LOG2N > 7 ? 1 << (LOG2N - 7) : 1;   // two-level roots of N (zafx_fft.hpp)
+    static constexpr int NH2 = LOG2N > 8 ? 1 << (LOG2N - 8) : 1;   // two-level roots of 2N for k < N/2 (real split)
+    static constexpr size_t HEAD = (((size_t)(C::PITCH + NHI + 128 + NH2 + 128) * 8 + 15) / 16) * 16;
+};
+
+template <int LOG2N, int LOG2E, bool ALIGNED>
 __global__ __launch_bounds__(fft_threads(LOG2N, LOG2E)) void k_cqt(
     const float* __restrict__ x, const float2* __restrict__ twp, const float2* __restrict__ tws,
-    const int4* __restrict__ chunks, const int* __restrict__ chunk_ptr, const int* __restrict__ indices, const float2* __restrict__ values, float* __restrict__ out,
-    long long n_samples, int step, int left_pad, int T, int tiles, int n_bins, int chroma_res, int layout, int n_chunks) {
+    const int4* __restrict__ chunks, const int* __restrict__ chunk_ptr, const int* __restrict__ slots, const float2* __restrict__ values, float* __restrict__ out,
+    long long n_samples, int step, int left_pad, int T, int tiles, int n_bins, int chroma_res, int layout, int n_chunks,
+    int k_lo, int k_hi, int k_special, int nnz) {
     using C = FftCfg<LOG2N, LOG2E>;
-    constexpr int N = C::N, P = C::P, E = C::E, W = 2 * N, FW = kCqtFramesPerBlock;
+    using G = CqtCfg<LOG2N, LOG2E>;
+    constexpr int N = C::N, P = C::P, E = C::E, W = 2 * N, FW = kCqtFramesPerBlock, NHI = G::NHI, NH2 = G::NH2;
     static_assert(P >= 64, "CQT frames are owned by whole wavefronts");
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     float2* buf = reinterpret_cast<float2*>(smem_raw);            // PITCH slots; slot PITCH-1 holds X[N]
-    constexpr int NHI = LOG2N > 7 ? 1 << (LOG2N - 7) : 1;
-    float2* tw_hi = buf + C::PITCH;                               // two-level root table (zafx_fft.hpp)
+    float2* tw_hi = buf + C::PITCH;                               // two-level root table of N
     float2* tw_lo = tw_hi + NHI;
-    // 16-byte aligned carve (a misaligned ds_read_b128 is replayed at 64 cycles): descriptors first, tile after
-    int4* chunk_l = reinterpret_cast<int4*>(smem_raw + (((size_t)(C::PITCH + NHI + 128) * 8 + 15) / 16) * 16);   // [n_chunks]
+    float2* sp_hi = tw_lo + 128;                                  // two-level root table of 2N (split twiddles)
+    float2* sp_lo = sp_hi + NH2;
+    int4* chunk_l = reinterpret_cast<int4*>(smem_raw + G::HEAD);  // [n_chunks]
     float* tile = reinterpret_cast<float*>(chunk_l + n_chunks);   // [n_bins][FW]
     int* chunk_ptr_l = reinterpret_cast<int*>(tile + n_bins * FW);   // [waves + 1]
     const int p = threadIdx.x;
     for (int i = p; i < NHI + 128; i += P) tw_hi[i] = twp[i];
+    for (int i = p; i < NH2 + 128; i += P) sp_hi[i] = tws[i];
     for (int i = p; i < n_chunks; i += P) chunk_l[i] = chunks[i];
     for (int i = p; i <= P / 64; i += P) chunk_ptr_l[i] = chunk_ptr[i];
-    __syncthreads();
+    lds_barrier();
     const TwoLevelTw tw2l{tw_hi, tw_lo};
-    const int lane = p & 63, wave = p >> 6, nwaves = P >> 6;
+    const int wave = p >> 6;
     const int clip = blockIdx.x / tiles, tl = blockIdx.x % tiles;
     const int t0 = tl * FW;
     const float* xc = x + (long long)clip * n_samples;
+    const int c0 = chunk_ptr_l[wave], c1 = chunk_ptr_l[wave + 1];
+
+    // ---- framing, no window (it lives in the kernel): zaf.py:612-620, :631.  Frames inside the clip take
+    // unconditional 8-byte loads; the zero-padded edge frames take the predicated path.
+    float2 v[E];
+    const unsigned clip_bytes = (unsigned)std::min<long long>(n_samples * 4, 0xfffffffcLL);
+    const auto rx = make_rsrc(xc, clip_bytes);
+    const auto rslots = make_rsrc(slots, (unsigned)nnz * 4u), rvals = make_rsrc(values, (unsigned)nnz * 8u);
+    auto load_frame = [&](int t, int p) {   // p: thread id (an opaque copy inside the frame loop)
+        const long long s0 = (long long)t * step - left_pad;
+        if (ALIGNED && s0 >= 0 && s0 + W <= n_samples) {
+            const int voff = ((int)s0 + 2 * p) * 4;
+#pragma unroll
+            for (int i = 0; i < E; ++i) v[i] = buf_load_f32x2(rx, voff, i * P * 8);
+        } else {
+#pragma unroll
+            for (int i = 0; i < E; ++i) {
+                const long long s = s0 + 2 * (p + i * P);
+                v[i].x = (s >= 0 && s < n_samples) ? buf_load_f32(rx, (int)s * 4) : 0.f;
+                v[i].y = (s + 1 >= 0 && s + 1 < n_samples) ? buf_load_f32(rx, (int)(s + 1) * 4) : 0.f;
+            }
+        }
+    };
+    if (t0 < T) load_frame(t0, threadIdx.x);
+    PROF_INIT(g_prof_cqt);
 
 #pragma unroll 1
     for (int jj = 0; jj < FW; ++jj) {
         const int t = t0 + jj;
         if (t >= T) break;   // uniform across the block
-        // ---- framing, no window (it lives in the kernel): zaf.py:612-620, :631
-        float2 v[E];
-        const long long s0 = (long long)t * step - left_pad;
-#pragma unroll
-        for (int i = 0; i < E; ++i) {
-            const long long s = s0 + 2 * (p + i * P);
-            const float a = (s >= 0 && s < n_samples) ? xc[s] : 0.f;
-            const float b = (s + 1 >= 0 && s + 1 < n_samples) ? xc[s + 1] : 0.f;
-            v[i] = make_float2(a, b);
-        }
+        PROF_MARK(0);
+        // Opaque copy of the thread id: everything below recomputes its (cheap) per-lane LDS and buffer
+        // offsets every frame.  Left to itself the compiler hoists ~50 of them out of the loop and
+        // spills them; every scratch reload then drains vmcnt and with it the prefetches in flight.
+        int p = threadIdx.x;
+        asm volatile("" : "+v"(p));
+        const int lane = p & 63;
         fft_frame_chain<LOG2N, LOG2E>(v, buf, p, tw2l);
-        // ---- real split in place: slots 0..N-1 <- X[0..N-1], slot PITCH-1 <- X[N]
+        PROF_MARK(1);
+        // ---- CSR mat-vec, part 1: request the slots and values of my first G chunks now; the L2 round
+        // trip hides under the real split
+        constexpr int G1 = 6;
+        int4 ch[G1];
+        int slot[G1];
+        float2 kv[G1];
+        auto request = [&](int cb) {
 #pragma unroll
-        for (int i = 0; i < E / 2; ++i) {
-            const int k = p + i * P;
-            if (k == 0) {
-                const float2 z0 = buf[0], zc = buf[phys(N / 2)];
-                buf[0] = make_float2(z0.x + z0.y, 0.f);
-                buf[C::PITCH - 1] = make_float2(z0.x - z0.y, 0.f);
-                buf[phys(N / 2)] = cconj(zc);
-            } else {
-                const float2 zk = buf[phys(k)], zn = buf[phys(N - k)];
-                const float2 e = make_float2(0.5f * (zk.x + zn.x), 0.5f * (zk.y - zn.y));
-                const float2 d = make_float2(0.5f * (zk.x - zn.x), 0.5f * (zk.y + zn.y));
-                const float2 to = cmul(tws[k], make_float2(d.y, -d.x));
-                buf[phys(k)] = cadd(e, to);
-                buf[phys(N - k)] = cconj(csub(e, to));
-            }
-        }
-        __syncthreads();
-        // ---- CSR mat-vec against the spectrum + magnitude (zaf.py:630-632).  The host cut the rows into
-        // chunks of <= 64 non-zeros and dealt whole rows to the wavefronts (balanced).  Chunk descriptors
-        // sit in LDS; the column indices and values of G chunks are requested together, so a frame pays
-        // ceil(chunks / G) L2 round trips instead of two per chunk (measured: the latency-chained version
-        // spent 46 % of the kernel in this 2 %-of-the-flops step).
-        {
-            constexpr int G = 6;
-            const int c0 = chunk_ptr_l[wave], c1 = chunk_ptr_l[wave + 1];
-            float ar = 0.f, ai = 0.f;
-            for (int cb = c0; cb < c1; cb += G) {
-                int4 ch[G];
-                int col[G];
-                float2 kv[G];
-#pragma unroll
-                for (int g = 0; g < G; ++g) {
-                    ch[g] = cb + g < c1 ? chunk_l[cb + g] : make_int4(0, 0, 0, 0);
-                    col[g] = 0;
-                    kv[g] = make_float2(0.f, 0.f);
-                    if (lane < ch[g].z) { col[g] = indices[ch[g].y + lane]; kv[g] = values[ch[g].y + lane]; }
+            for (int g = 0; g < G1; ++g) {
+                ch[g] = cb + g < c1 ? chunk_l[cb + g] : make_int4(0, 0, 0, 0);
+                slot[g] = 0;
+                kv[g] = make_float2(0.f, 0.f);
+                if (lane < ch[g].z) {
+                    slot[g] = buf_load_i32(rslots, (ch[g].y + lane) * 4);
+                    kv[g] = buf_load_f32x2(rvals, (ch[g].y + lane) * 8);
                 }
+            }
+        };
+        request(c0);
+        // ---- real split in place, only for the pairs (k, N-k) that the kernel's columns touch:
+        // slots 0..N-1 <- X[0..N-1], slot PITCH-1 <- X[N];  t_k = exp(-2 pi i k / 2N) = sp_hi[k >> 7] sp_lo[k & 127]
+        if (k_special && p == 0) {
+            const float2 z0 = buf[0], zc = buf[phys(N / 2)];
+            buf[0] = make_float2(z0.x + z0.y, 0.f);
+            buf[C::PITCH - 1] = make_float2(z0.x - z0.y, 0.f);
+            buf[phys(N / 2)] = cconj(zc);
+        }
+        for (int k = k_lo + p; k <= k_hi; k += P) {
+            const float2 zk = buf[phys(k)], zn = buf[phys(N - k)];
+            const float2 tk = cmul(sp_hi[k >> 7], sp_lo[k & 127]);
+            const float2 e = make_float2(0.5f * (zk.x + zn.x), 0.5f * (zk.y - zn.y));
+            const float2 d = make_float2(0.5f * (zk.x - zn.x), 0.5f * (zk.y + zn.y));
+            const float2 to = cmul(tk, make_float2(d.y, -d.x));
+            buf[phys(k)] = cadd(e, to);
+            buf[phys(N - k)] = cconj(csub(e, to));
+        }
+        PROF_MARK(2);
+        lds_barrier();
+        PROF_MARK(3);
+        // the next frame's samples travel while this frame is contracted (v is free until the next FFT)
+        if (jj + 1 < FW && t + 1 < T) load_frame(t + 1, p);
+        PROF_MARK(4);
+        // ---- CSR mat-vec against the spectrum + magnitude (zaf.py:630-632).  The host cut the rows into
+        // chunks of <= 64 non-zeros, dealt whole rows to the wavefronts (balanced) and translated every
+        // column into its LDS slot (bit 31: use the conjugate, i.e. a column of the upper half).  Chunk
+        // descriptors sit in LDS; the slots and values of G chunks are requested together, so a frame
+        // pays ceil(chunks / G) L2 round trips instead of two per chunk.
+        {
+            float ar = 0.f, ai = 0.f;
+            for (int cb = c0; cb < c1; cb += G1) {
+                if (cb != c0) request(cb);
 #pragma unroll
-                for (int g = 0; g < G; ++g) {
+                for (int g = 0; g < G1; ++g) {
                     if (cb + g >= c1) break;
                     if (lane < ch[g].z) {
-                        const int c = col[g];
-                        float2 xv;
-                        if (c < N) xv = buf[phys(c)];
-                        else if (c == N) xv = buf[C::PITCH - 1];
-                        else xv = cconj(buf[phys(W - c)]);
+                        float2 xv = buf[slot[g] & 0x7fffffff];
+                        if (slot[g] < 0) xv.y = -xv.y;
                         ar += kv[g].x * xv.x - kv[g].y * xv.y;
                         ai += kv[g].x * xv.y + kv[g].y * xv.x;
                     }
                     if (ch[g].w) {   // last chunk of row ch[g].x
-#pragma unroll
-                        for (int m = 32; m >= 1; m >>= 1) {
-                            ar += __shfl_xor(ar, m, 64);
-                            ai += __shfl_xor(ai, m, 64);
-                        }
+                        ar = wave_sum(ar);
+                        ai = wave_sum(ai);
                         if (lane == 0) tile[ch[g].x * FW + jj] = sqrtf(ar * ar + ai * ai);
                         ar = 0.f;
                         ai = 0.f;
@@ -127,7 +172,9 @@ __global__ __launch_bounds__(fft_threads(LOG2N, LOG2E)) void k_cqt(
                 }
             }
         }
-        __syncthreads();
+        PROF_MARK(5);
+        lds_barrier();
+        PROF_MARK(6);
     }
 
     // ---- store the tile (64-B runs along t in the reference layout)
@@ -156,9 +203,12 @@ template <int LOG2N>
 static hipError_t run_cqt(const zafx_plan& pl, const float* x, float* out, int64_t n_clips, int64_t n_samples, int T) {
     constexpr int LOG2E = default_log2e(LOG2N);
     using C = FftCfg<LOG2N, LOG2E>;
-    auto kern = k_cqt<LOG2N, LOG2E>;
-    const size_t head = (((size_t)(C::PITCH + (LOG2N > 7 ? (1 << (LOG2N - 7)) : 1) + 128) * 8 + 15) / 16) * 16;
-    const size_t smem = head + (size_t)pl.n_chunks * 16 + (size_t)pl.prm.n_bins * kCqtFramesPerBlock * sizeof(float) + (size_t)(C::P / 64 + 1) * 4;
+    using G = CqtCfg<LOG2N, LOG2E>;
+    const int diff = pl.W - pl.H;                              // may be negative if step > fft_len
+    const int left = diff >= 0 ? (diff + 1) / 2 : -((-diff) / 2);   // ceil(diff / 2)  (zaf.py:615)
+    const bool aligned = n_samples % 2 == 0 && pl.H % 2 == 0 && left % 2 == 0 && reinterpret_cast<uintptr_t>(x) % 8 == 0;
+    auto kern = aligned ? k_cqt<LOG2N, LOG2E, true> : k_cqt<LOG2N, LOG2E, false>;
+    const size_t smem = G::HEAD + (size_t)pl.n_chunks * 16 + (size_t)pl.prm.n_bins * kCqtFramesPerBlock * sizeof(float) + (size_t)(C::P / 64 + 1) * 4;
     if (smem > (size_t)kMaxLdsBytes) {
         set_error("cqt: kernel matrix (bins / non-zeros) too large for LDS at this fft_length");
         return hipErrorInvalidValue;
@@ -167,11 +217,10 @@ static hipError_t run_cqt(const zafx_plan& pl, const float* x, float* out, int64
     const int tiles = (T + kCqtFramesPerBlock - 1) / kCqtFramesPerBlock;
     const long long blocks = (long long)tiles * n_clips;
     if (blocks <= 0) return hipSuccess;
-    const int diff = pl.W - pl.H;                              // may be negative if step > fft_len
-    const int left = diff >= 0 ? (diff + 1) / 2 : -((-diff) / 2);   // ceil(diff / 2)  (zaf.py:615)
-    hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(C::P), smem, pl.stream, x, pl.d_tw_pass, pl.d_tw_aux, pl.d_chunks, pl.d_chunk_ptr, pl.d_indices,
+    hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(C::P), smem, pl.stream, x, pl.d_tw_pass, pl.d_tw_aux, pl.d_chunks, pl.d_chunk_ptr, pl.d_slots,
                        pl.d_values, out, (long long)n_samples, pl.H, left, T, tiles, pl.prm.n_bins,
-                       pl.kind == ZAFX_CHROMA ? pl.prm.octave_resolution : 0, pl.layout, pl.n_chunks);
+                       pl.kind == ZAFX_CHROMA ? pl.prm.octave_resolution : 0, pl.layout, pl.n_chunks, pl.cqt_k_lo, pl.cqt_k_hi,
+                       pl.cqt_k_special, std::max(pl.nnz, 1));
     return hipGetLastError();
 }
 
@@ -194,3 +243,5 @@ hipError_t launch_cqt(const zafx_plan& pl, const float* x, float* out, int64_t n
 }
 
 }  // namespace zafx
+
+ZAFX_PROF_EXPORT(zafx_debug_prof_cqt, g_prof_cqt)

@@ -26,6 +26,8 @@ static inline float2 make_float2(float x, float y) { float2 r; r.x = x; r.y = y;
 #define ZAFX_HD inline
 #else
 #include <hip/hip_runtime.h>
+
+#include <type_traits>
 #define ZAFX_HD __host__ __device__ __forceinline__
 #endif
 
@@ -245,6 +247,30 @@ ZAFX_HD void regs_read(float2* v, const float2* buf, int p) {
 #if !defined(ZAFX_HOST_EMU)
 namespace zafx {
 
+// Buffer (SRSRC) loads: a wave-uniform 128-bit descriptor in SGPRs + one 32-bit byte offset per lane,
+// instead of a 64-bit flat address per lane and load -- the persistent kernels keep several load
+// streams in flight and cannot afford 2 VGPRs of address for each.  Offsets past `bytes` read 0.
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void* base, unsigned bytes) {
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, (int)bytes, 0x00020000);
+}
+__device__ __forceinline__ float buf_load_f32(__amdgpu_buffer_rsrc_t r, int voff, int soff = 0) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, voff, soff, 0));
+}
+__device__ __forceinline__ int buf_load_i32(__amdgpu_buffer_rsrc_t r, int voff, int soff = 0) {
+    return __builtin_bit_cast(int, __builtin_amdgcn_raw_buffer_load_b32(r, voff, soff, 0));
+}
+__device__ __forceinline__ float2 buf_load_f32x2(__amdgpu_buffer_rsrc_t r, int voff, int soff = 0) {
+    const auto raw = __builtin_amdgcn_raw_buffer_load_b64(r, voff, soff, 0);
+    float2 f;
+    __builtin_memcpy(&f, &raw, 8);
+    return f;
+}
+
+// Workgroup barrier that orders LDS traffic only.  __syncthreads() also drains vmcnt, i.e. it waits
+// for every global store of the wave to be acknowledged (measured: 8 000 cycles per tile after the
+// ISTFT store phase); a kernel whose waves exchange data through LDS alone does not need that.
+__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
 // Synchronise the P threads that own one frame.  P <= 64 -> the frame lives in a
 // single wavefront whose LDS operations execute in program order: no barrier.
 // The compiler, however, may legally reorder one THREAD's LDS store past its later
@@ -254,7 +280,7 @@ namespace zafx {
 template <int P>
 __device__ __forceinline__ void frame_sync() {
     if constexpr (P > 64) {
-        __syncthreads();
+        lds_barrier();   // the passes exchange data through LDS only
     } else {
 #if defined(ZAFX_WAVE_SYNC_FENCE)
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
@@ -271,10 +297,26 @@ __device__ __forceinline__ void frame_sync() {
     }
 }
 
-// Workgroup barrier that orders LDS traffic only.  __syncthreads() also drains vmcnt, i.e. it waits
-// for every global store of the wave to be acknowledged (measured: 8 000 cycles per tile after the
-// ISTFT store phase); a kernel whose waves exchange data through LDS alone does not need that.
-__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+// Sum of `v` over the 64 lanes of the wavefront, returned in every lane.  DPP row operations and four
+// v_readlane instead of six dependent ds_bpermute round trips (__shfl_xor): ~30 issue cycles against
+// ~700 of LDS-crossbar latency per value.
+__device__ __forceinline__ float wave_sum(float v) {
+    auto dpp_add = [](float x, auto ctrl) {
+        constexpr int C = decltype(ctrl)::value;
+        const int moved = __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), C, 0xf, 0xf, true);
+        return x + __builtin_bit_cast(float, moved);
+    };
+    v = dpp_add(v, std::integral_constant<int, 0xB1>{});    // quad_perm [1,0,3,2]
+    v = dpp_add(v, std::integral_constant<int, 0x4E>{});    // quad_perm [2,3,0,1]
+    v = dpp_add(v, std::integral_constant<int, 0x141>{});   // row_half_mirror
+    v = dpp_add(v, std::integral_constant<int, 0x140>{});   // row_mirror: every lane holds its 16-lane row sum
+    const int bits = __builtin_bit_cast(int, v);
+    const float r0 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(bits, 0));
+    const float r1 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(bits, 16));
+    const float r2 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(bits, 32));
+    const float r3 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(bits, 48));
+    return (r0 + r1) + (r2 + r3);
+}
 
 // All passes.  Input: v[i] = x[p + i*P].  Output: natural-order spectrum in the
 // padded LDS frame `buf` (visible to the frame's threads after the final sync).

@@ -60,6 +60,8 @@ struct zafx_plan {
     int4* d_chunks = nullptr;      // CQT rows cut into <= 64-entry chunks {row, first entry, count, last-of-row}
     int* d_chunk_ptr = nullptr;    // [waves + 1] ranges of d_chunks per wavefront
     int n_chunks = 0;
+    int* d_slots = nullptr;        // per non-zero: LDS slot of its column in k_cqt's one-sided spectrum (bit 31 = conjugate)
+    int cqt_k_lo = 0, cqt_k_hi = -1, cqt_k_special = 0;   // real-split pairs the kernel's columns need
     bool cqt_dirty = true;
 
     // host shadows (needed to re-pack after an RCCL broadcast)

@@ -54,4 +54,16 @@ inline std::vector<cf32> build_two_level_twiddles(int log2n) {
     return t;
 }
 
+// Two-level table of the real-split twiddles of a length-2N real transform packed as N = 2^log2n complex
+// points: exp(-2 pi i k / 2N) for k < N/2 as hi[k >> 7] * lo[k & 127]  ([hi: max(N/256, 1) | lo: 128]).
+inline int split_hi_count(int log2n) { return log2n > 8 ? 1 << (log2n - 8) : 1; }
+inline std::vector<cf32> build_split_two_level_twiddles(int log2n) {
+    const long long w = 2LL << log2n;
+    const int nh = split_hi_count(log2n);
+    std::vector<cf32> t((size_t)nh + 128);
+    for (int j = 0; j < nh; ++j) t[(size_t)j] = unit_root((long long)j << 7, w);
+    for (int j = 0; j < 128; ++j) t[(size_t)nh + j] = unit_root(j, w);
+    return t;
+}
+
 }  // namespace zafx

@@ -51,7 +51,8 @@ __global__ __launch_bounds__(fft_threads(LOG2N, LOG2E)) void k_cqt(
     float2* sp_lo = sp_hi + NH2;
     int4* chunk_l = reinterpret_cast<int4*>(smem_raw + G::HEAD);  // [n_chunks]
     float* tile = reinterpret_cast<float*>(chunk_l + n_chunks);   // [n_bins][FW]
-    int* chunk_ptr_l = reinterpret_cast<int*>(tile + n_bins * FW);   // [waves + 1]
+    float2* part = reinterpret_cast<float2*>(tile + n_bins * FW);   // [n_bins][4] row sums of a frame's products
+    int* chunk_ptr_l = reinterpret_cast<int*>(part + n_bins * 4);   // [waves + 1]
     const int p = threadIdx.x;
     for (int i = p; i < NHI + 128; i += P) tw_hi[i] = twp[i];
     for (int i = p; i < NH2 + 128; i += P) sp_hi[i] = tws[i];
@@ -63,7 +64,14 @@ __global__ __launch_bounds__(fft_threads(LOG2N, LOG2E)) void k_cqt(
     const int clip = blockIdx.x / tiles, tl = blockIdx.x % tiles;
     const int t0 = tl * FW;
     const float* xc = x + (long long)clip * n_samples;
-    const int c0 = chunk_ptr_l[wave], c1 = chunk_ptr_l[wave + 1];
+    // wave-uniform values read from LDS land in VGPRs; readfirstlane tells the compiler they are scalars
+    // (scalar branches and SGPR operands instead of exec-mask juggling around every chunk)
+    const int c0 = __builtin_amdgcn_readfirstlane(chunk_ptr_l[wave]), c1 = __builtin_amdgcn_readfirstlane(chunk_ptr_l[wave + 1]);
+    auto chunk_at = [&](int c) {
+        const int4 d = chunk_l[c];
+        return make_int4(__builtin_amdgcn_readfirstlane(d.x), __builtin_amdgcn_readfirstlane(d.y), __builtin_amdgcn_readfirstlane(d.z),
+                         __builtin_amdgcn_readfirstlane(d.w));
+    };
 
     // ---- framing, no window (it lives in the kernel): zaf.py:612-620, :631.  Frames inside the clip take
     // unconditional 8-byte loads; the zero-padded edge frames take the predicated path.
@@ -104,20 +112,23 @@ __global__ __launch_bounds__(fft_threads(LOG2N, LOG2E)) void k_cqt(
         PROF_MARK(1);
         // ---- CSR mat-vec, part 1: request the slots and values of my first G chunks now; the L2 round
         // trip hides under the real split
-        constexpr int G1 = 6;
-        int4 ch[G1];
+        constexpr int G1 = 8;   // two rounds cover a wave's share at config Q (238 chunks over 16 waves)
         int slot[G1];
         float2 kv[G1];
         auto request = [&](int cb) {
 #pragma unroll
             for (int g = 0; g < G1; ++g) {
-                ch[g] = cb + g < c1 ? chunk_l[cb + g] : make_int4(0, 0, 0, 0);
-                slot[g] = 0;
-                kv[g] = make_float2(0.f, 0.f);
-                if (lane < ch[g].z) {
-                    slot[g] = buf_load_i32(rslots, (ch[g].y + lane) * 4);
-                    kv[g] = buf_load_f32x2(rvals, (ch[g].y + lane) * 8);
-                }
+                const int4 ch = cb + g < c1 ? chunk_at(cb + g) : make_int4(0, 0, 0, 0);
+                // branch-free: lanes past the chunk read out of range, i.e. 0 (a select on the loaded value
+                // would make the wave wait for the load right here)
+                const bool on = lane < ch.z;
+#ifdef ZAFX_ABL_NOLOAD
+                slot[g] = on ? ch.y + lane : 0;
+                kv[g] = make_float2(1.f, 0.5f);
+#else
+                slot[g] = buf_load_i32(rslots, on ? (ch.y + lane) * 4 : -4);
+                kv[g] = buf_load_f32x2(rvals, on ? (ch.y + lane) * 8 : -8);
+#endif
             }
         };
         request(c0);
@@ -141,41 +152,57 @@ __global__ __launch_bounds__(fft_threads(LOG2N, LOG2E)) void k_cqt(
         PROF_MARK(2);
         lds_barrier();
         PROF_MARK(3);
-        // the next frame's samples travel while this frame is contracted (v is free until the next FFT)
-        if (jj + 1 < FW && t + 1 < T) load_frame(t + 1, p);
-        PROF_MARK(4);
         // ---- CSR mat-vec against the spectrum + magnitude (zaf.py:630-632).  The host cut the rows into
         // chunks of <= 64 non-zeros, dealt whole rows to the wavefronts (balanced) and translated every
         // column into its LDS slot (bit 31: use the conjugate, i.e. a column of the upper half).  Chunk
         // descriptors sit in LDS; the slots and values of G chunks are requested together, so a frame
-        // pays ceil(chunks / G) L2 round trips instead of two per chunk.
+        // pays ceil(chunks / G) L2 round trips instead of two per chunk.  Order of the requests: group 1
+        // before the split (above), group 2 after group 1 is consumed, THEN the next frame's samples
+        // (v is free until the next FFT) -- loads return in order, so group 2 must not queue behind
+        // the 128-KB frame prefetch.
         {
             float ar = 0.f, ai = 0.f;
-            for (int cb = c0; cb < c1; cb += G1) {
-                if (cb != c0) request(cb);
+            auto contract = [&](int cb) {
 #pragma unroll
                 for (int g = 0; g < G1; ++g) {
                     if (cb + g >= c1) break;
-                    if (lane < ch[g].z) {
+                    const int4 ch = chunk_at(cb + g);   // {row, first entry, count, last-of-row}
+                    if (lane < ch.z) {
                         float2 xv = buf[slot[g] & 0x7fffffff];
                         if (slot[g] < 0) xv.y = -xv.y;
                         ar += kv[g].x * xv.x - kv[g].y * xv.y;
                         ai += kv[g].x * xv.y + kv[g].y * xv.x;
                     }
-                    if (ch[g].w) {   // last chunk of row ch[g].x
-                        ar = wave_sum(ar);
-                        ai = wave_sum(ai);
-                        if (lane == 0) tile[ch[g].x * FW + jj] = sqrtf(ar * ar + ai * ai);
+                    if (ch.w) {   // end of row ch.x: leave the four 16-lane partial sums in LDS (finished below)
+                        ar = row16_sum(ar);
+                        ai = row16_sum(ai);
+                        if ((lane & 15) == 0) part[ch.x * 4 + (lane >> 4)] = make_float2(ar, ai);
                         ar = 0.f;
                         ai = 0.f;
                     }
                 }
+            };
+            contract(c0);
+            if (c0 + G1 < c1) request(c0 + G1);
+            if (jj + 1 < FW && t + 1 < T) load_frame(t + 1, p);
+            PROF_MARK(4);
+            if (c0 + G1 < c1) contract(c0 + G1);
+            for (int cb = c0 + 2 * G1; cb < c1; cb += G1) {
+                request(cb);
+                contract(cb);
             }
         }
         PROF_MARK(5);
         lds_barrier();
         PROF_MARK(6);
+        // |.|^2 of every row of this frame (the square root is taken once, when the tile is stored)
+        for (int r = p; r < n_bins; r += P) {
+            const float4 a = *reinterpret_cast<const float4*>(part + r * 4), b = *reinterpret_cast<const float4*>(part + r * 4 + 2);
+            const float sr = (a.x + a.z) + (b.x + b.z), si = (a.y + a.w) + (b.y + b.w);
+            tile[r * FW + jj] = sr * sr + si * si;
+        }
     }
+    lds_barrier();
 
     // ---- store the tile (64-B runs along t in the reference layout)
     const int nvalid = min(FW, T - t0);
@@ -184,7 +211,7 @@ __global__ __launch_bounds__(fft_threads(LOG2N, LOG2E)) void k_cqt(
             const int ch = idx / FW, jj = idx % FW;
             if (jj >= nvalid) continue;
             float acc = 0.f;
-            for (int r = ch; r < n_bins; r += chroma_res) acc += tile[r * FW + jj];   // zaf.py:696-698
+            for (int r = ch; r < n_bins; r += chroma_res) acc += __builtin_amdgcn_sqrtf(tile[r * FW + jj]);   // zaf.py:696-698
             if (layout == ZAFX_LAYOUT_FT) out[((long long)clip * chroma_res + ch) * T + t0 + jj] = acc;
             else out[((long long)clip * T + t0 + jj) * chroma_res + ch] = acc;
         }
@@ -192,7 +219,7 @@ __global__ __launch_bounds__(fft_threads(LOG2N, LOG2E)) void k_cqt(
         for (int idx = p; idx < n_bins * FW; idx += P) {
             const int r = idx / FW, jj = idx % FW;
             if (jj >= nvalid) continue;
-            const float val = tile[idx];
+            const float val = __builtin_amdgcn_sqrtf(tile[idx]);
             if (layout == ZAFX_LAYOUT_FT) out[((long long)clip * n_bins + r) * T + t0 + jj] = val;
             else out[((long long)clip * T + t0 + jj) * n_bins + r] = val;
         }
@@ -208,7 +235,7 @@ static hipError_t run_cqt(const zafx_plan& pl, const float* x, float* out, int64
     const int left = diff >= 0 ? (diff + 1) / 2 : -((-diff) / 2);   // ceil(diff / 2)  (zaf.py:615)
     const bool aligned = n_samples % 2 == 0 && pl.H % 2 == 0 && left % 2 == 0 && reinterpret_cast<uintptr_t>(x) % 8 == 0;
     auto kern = aligned ? k_cqt<LOG2N, LOG2E, true> : k_cqt<LOG2N, LOG2E, false>;
-    const size_t smem = G::HEAD + (size_t)pl.n_chunks * 16 + (size_t)pl.prm.n_bins * kCqtFramesPerBlock * sizeof(float) + (size_t)(C::P / 64 + 1) * 4;
+    const size_t smem = G::HEAD + (size_t)pl.n_chunks * 16 + (size_t)pl.prm.n_bins * (kCqtFramesPerBlock * sizeof(float) + 4 * sizeof(float2)) + (size_t)(C::P / 64 + 1) * 4;
     if (smem > (size_t)kMaxLdsBytes) {
         set_error("cqt: kernel matrix (bins / non-zeros) too large for LDS at this fft_length");
         return hipErrorInvalidValue;

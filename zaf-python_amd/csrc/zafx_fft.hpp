@@ -297,10 +297,9 @@ __device__ __forceinline__ void frame_sync() {
     }
 }
 
-// Sum of `v` over the 64 lanes of the wavefront, returned in every lane.  DPP row operations and four
-// v_readlane instead of six dependent ds_bpermute round trips (__shfl_xor): ~30 issue cycles against
-// ~700 of LDS-crossbar latency per value.
-__device__ __forceinline__ float wave_sum(float v) {
+// Sum of `v` over each 16-lane row of the wavefront (DPP, 4 adds, no LDS crossbar): afterwards every
+// lane holds its row's sum.
+__device__ __forceinline__ float row16_sum(float v) {
     auto dpp_add = [](float x, auto ctrl) {
         constexpr int C = decltype(ctrl)::value;
         const int moved = __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), C, 0xf, 0xf, true);
@@ -309,8 +308,14 @@ __device__ __forceinline__ float wave_sum(float v) {
     v = dpp_add(v, std::integral_constant<int, 0xB1>{});    // quad_perm [1,0,3,2]
     v = dpp_add(v, std::integral_constant<int, 0x4E>{});    // quad_perm [2,3,0,1]
     v = dpp_add(v, std::integral_constant<int, 0x141>{});   // row_half_mirror
-    v = dpp_add(v, std::integral_constant<int, 0x140>{});   // row_mirror: every lane holds its 16-lane row sum
-    const int bits = __builtin_bit_cast(int, v);
+    v = dpp_add(v, std::integral_constant<int, 0x140>{});   // row_mirror
+    return v;
+}
+
+// Sum of `v` over the 64 lanes of the wavefront, returned in every lane: row sums + four v_readlane
+// instead of six dependent ds_bpermute round trips (__shfl_xor).
+__device__ __forceinline__ float wave_sum(float v) {
+    const int bits = __builtin_bit_cast(int, row16_sum(v));
     const float r0 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(bits, 0));
     const float r1 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(bits, 16));
     const float r2 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(bits, 32));

@@ -41,6 +41,13 @@ elif kind == "imdct":
     fwd.sync()
     n_in, tiles = T, (T + 30) // 31
     d_out = zafx.DeviceBuffer((B, plan.out_dims(T)[0]), np.float32)
+elif kind in ("mel", "mfcc"):
+    w = zafx.hamming(W)
+    fb = zafx.melfilterbank(44100, W, 128)
+    plan = zafx.mel_plan(w, H, fb, 20 if kind == "mfcc" else None)
+    F, T = plan.out_dims(N)
+    d_in, n_in, tiles = d_x, N, 27
+    d_out = zafx.DeviceBuffer((B, F, T), np.float32)
 elif kind == "cqt":
     B, N = 128, 1323000
     x = np.random.default_rng(0).standard_normal((8, N)).astype(np.float32)
@@ -51,7 +58,7 @@ elif kind == "cqt":
     d_out = zafx.DeviceBuffer((B, F, T), np.float32)
 else:
     raise SystemExit("kind must be istft, mdct, imdct or cqt")
-fn = getattr(lib, "zafx_debug_prof_" + kind)
+fn = getattr(lib, "zafx_debug_prof_" + ("mel" if kind == "mfcc" else kind))
 out = (ctypes.c_ulonglong * 16)()
 plan.execute(d_in, d_out, B, n_in)
 plan.sync()

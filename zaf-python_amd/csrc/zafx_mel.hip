@@ -25,6 +25,7 @@
 namespace zafx {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+ZAFX_PROF_ARRAY(g_prof_mel)
 
 constexpr int mel_threads(int log2n, int log2e) {
     const int p = fft_threads(log2n, log2e);
@@ -101,50 +102,66 @@ __global__ __launch_bounds__(mel_threads(LOG2N, LOG2E)) void k_mel(
     };
 
     const int slot = tid / P, p = tid % P;
-    const int lane = tid & 63, wave = tid >> 6;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // scalar: item ranges and descriptors load into SGPRs
     const int bt = lane & 15, bk = lane >> 4;
     const float eps = 2.220446049250313e-16f;   // np.finfo(float).eps (zaf.py:445)
     const int lt0 = fb_nitems;                  // first log-mel slot
     const int dslot0 = fb_nitems + fb_blocks;   // first DCT partial slot
 
+    // raw samples of one frame of this wave's slot: xr[i] = (x[2n], x[2n+1]), n = p + i P (zero padding of zaf.py:112-125)
+    float2 xr[E];
+    auto fetch = [&](int tl, int f0) {
+        if (tl >= total_tiles) return;
+        const int clip = tl / tiles, tile = tl % tiles;
+        const int t = tile * FPB + f0 + slot;
+        const float* xc = x + (long long)clip * n_samples;
+        const long long s0 = (long long)t * hop - N;
+        if (ALIGNED && t < T && s0 >= 0 && s0 + W <= n_samples) {   // interior frame (uniform per frame)
+            const float2* src = reinterpret_cast<const float2*>(xc + s0) + p;
+#pragma unroll
+            for (int i = 0; i < E; ++i) xr[i] = src[i * P];
+        } else {
+#pragma unroll
+            for (int i = 0; i < E; ++i) {
+                const long long s = s0 + 2 * (p + i * P);
+                xr[i].x = (t < T && s >= 0 && s < n_samples) ? xc[s] : 0.f;
+                xr[i].y = (t < T && s + 1 >= 0 && s + 1 < n_samples) ? xc[s + 1] : 0.f;
+            }
+        }
+    };
+    fetch(blockIdx.x, 0);
+    PROF_INIT(g_prof_mel);
     for (int tl = blockIdx.x; tl < total_tiles; tl += gridDim.x) {
         const int clip = tl / tiles, tile = tl % tiles;
         const int t0 = tile * FPB;
-        const float* xc = x + (long long)clip * n_samples;
+        PROF_MARK(0);
 
-        // ---- STFT of the tile's frames, NSLOT at a time; spectrum -> magnitude/power in place
+        // ---- STFT of the tile's frames, NSLOT at a time; spectrum -> magnitude/power in place.  The raw
+        // samples of the NEXT round (or of the next tile's first round) are requested before this
+        // round's FFT, so their latency hides under the butterflies.
 #pragma unroll 1
         for (int f0 = 0; f0 < FPB; f0 += NSLOT) {
             const int fr = f0 + slot;
-            const int t = t0 + fr;
             float2* buf = frames + fr * C::PITCH;
+            // opaque copy of the lane's index: the window, twiddle and split-root reads stay inside the loop
+            // (hoisted out of the persistent loop they cost > 100 VGPRs and spill)
+            int po = p;
+            asm volatile("" : "+v"(po));
             float2 v[E];
-            const long long s0 = (long long)t * hop - N;
-            if (ALIGNED && t < T && s0 >= 0 && s0 + W <= n_samples) {   // interior frame (uniform per frame)
 #pragma unroll
-                for (int i = 0; i < E; ++i) {
-                    const int n = p + i * P;
-                    const float2 xv = *reinterpret_cast<const float2*>(xc + s0 + 2 * n);
-                    const float2 wv = win_l[n];
-                    v[i] = make_float2(xv.x * wv.x, xv.y * wv.y);
-                }
-            } else {
-#pragma unroll
-                for (int i = 0; i < E; ++i) {
-                    const int n = p + i * P;
-                    const long long s = s0 + 2 * n;
-                    const float2 wv = win_l[n];
-                    const float a = (t < T && s >= 0 && s < n_samples) ? xc[s] : 0.f;
-                    const float b = (t < T && s + 1 >= 0 && s + 1 < n_samples) ? xc[s + 1] : 0.f;
-                    v[i] = make_float2(a * wv.x, b * wv.y);
-                }
+            for (int i = 0; i < E; ++i) {
+                const float2 wv = win_l[po + i * P];
+                v[i] = make_float2(xr[i].x * wv.x, xr[i].y * wv.y);
             }
-            fft_frame<LOG2N, LOG2E>(v, buf, p, tw_l);
+            if (f0 + NSLOT < FPB) fetch(tl, f0 + NSLOT);
+            else fetch(tl + gridDim.x, 0);
+            fft_frame<LOG2N, LOG2E>(v, buf, po, tw_l);
             // real split of the (k, N-k) pairs this thread owns, kept in registers
             float mk[E / 2], mn[E / 2];
 #pragma unroll
             for (int i = 0; i < E / 2; ++i) {
-                const int k = p + i * P;
+                const int k = po + i * P;
                 float2 xk, xn;
                 if (k == 0) {
                     const float2 z0 = buf[0], zc = buf[phys(N / 2)];
@@ -159,14 +176,14 @@ __global__ __launch_bounds__(mel_threads(LOG2N, LOG2E)) void k_mel(
                     xn = csub(e, to);
                 }
                 const float pk = xk.x * xk.x + xk.y * xk.y, pn = xn.x * xn.x + xn.y * xn.y;
-                mk[i] = mfcc ? pk : sqrtf(pk);
-                mn[i] = mfcc ? pn : sqrtf(pn);
+                mk[i] = mfcc ? pk : __builtin_amdgcn_sqrtf(pk);   // v_sqrt_f32, 1 ulp
+                mn[i] = mfcc ? pn : __builtin_amdgcn_sqrtf(pn);
             }
             frame_sync<P>();   // every Z read of this frame is done before S overwrites it
             float* sf = reinterpret_cast<float*>(buf);   // S[c], c = bin - 1, c = 0..N-1
 #pragma unroll
             for (int i = 0; i < E / 2; ++i) {
-                const int k = p + i * P;
+                const int k = po + i * P;
                 if (k == 0) {
                     sf[N / 2 - 1] = mk[i];
                     sf[N - 1] = mn[i];
@@ -176,14 +193,18 @@ __global__ __launch_bounds__(mel_threads(LOG2N, LOG2E)) void k_mel(
                 }
             }
         }
-        __syncthreads();
+        PROF_MARK(1);
+        lds_barrier();
+        PROF_MARK(2);
 
         // ---- mel = FB . S on the matrix cores
         {
             const float* sb = fall + (size_t)bt * (2 * C::PITCH) + bk;
             gemm_items(fb_pack, fb_items, fb_wave_ptr, wave, lane, 0, slot_ptr, [&](int col) { return sb[col]; });
         }
-        __syncthreads();
+        PROF_MARK(3);
+        lds_barrier();
+        PROF_MARK(4);
         // ---- fixed-order reduction of the parts of every 16-filter block
         for (int idx = tid; idx < fb_blocks * 256; idx += NT) {
             const int blk = idx >> 8, e = idx & 255;
@@ -198,11 +219,11 @@ __global__ __launch_bounds__(mel_threads(LOG2N, LOG2E)) void k_mel(
             }
         }
         if (mfcc) {
-            __syncthreads();
+            lds_barrier();
             // ---- rows 1..ncoef of the orthonormal DCT-II over the mel axis: second MFMA GEMM
             gemm_items(dct_pack, dct_items, dct_wave_ptr, wave, lane, dslot0, slot_ptr,
                        [&](int row) { return slot_ptr(lt0 + ((row + bk) >> 4))[((row + bk) & 15) * 16 + bt]; });
-            __syncthreads();
+            lds_barrier();
             for (int idx = tid; idx < dct_blocks * 256; idx += NT) {
                 const int blk = idx >> 8, e = idx & 255;
                 float val = 0.f;
@@ -214,7 +235,8 @@ __global__ __launch_bounds__(mel_threads(LOG2N, LOG2E)) void k_mel(
                 }
             }
         }
-        __syncthreads();   // slots and S are dead: the next tile may overwrite the frame buffers
+        PROF_MARK(5);
+        lds_barrier();   // slots and S are dead: the next tile may overwrite the frame buffers
     }
 }
 
@@ -266,3 +288,5 @@ hipError_t launch_mel(const zafx_plan& pl, const float* x, float* out, int64_t n
 }
 
 }  // namespace zafx
+
+ZAFX_PROF_EXPORT(zafx_debug_prof_mel, g_prof_mel)

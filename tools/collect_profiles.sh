@@ -1,0 +1,28 @@
+#!/bin/bash
+# Runs on the GPU box (through gpurun): bench lines of every transform, rocprofv3 kernel statistics of each,
+# and the two PMC passes of the headline kernel.  Everything lands under gpurun_out/; tools/summarize_profiles.py
+# turns it into the files committed under profiles/.
+#   gpurun --timeout 1500 -- 'bash tools/collect_profiles.sh'
+cd "$(dirname "$0")/.." || exit 1
+REPO=$PWD
+OUT=$REPO/gpurun_out
+mkdir -p "$OUT"
+export TMPDIR=/tmp
+KINDS=${KINDS:-"stft istft mdct imdct mel mfcc cqt dct"}   # KINDS="stft" re-collects the headline only
+for k in $KINDS; do
+  timeout 300 python bench.py --kind $k $([ $k = stft ] || echo --no-cpu-baseline) > "$OUT/bench_$k.json" 2> "$OUT/bench_$k.log"
+done
+timeout 300 python bench.py --kind stft --layout TF --no-cpu-baseline > "$OUT/bench_stft_tf.json" 2>> "$OUT/bench_stft.log"
+cd /tmp || exit 1
+for k in $KINDS; do
+  rm -rf "$OUT/prof_$k"
+  timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/prof_$k" -o $k -- \
+      python "$REPO/bench.py" --kind $k --steps $([ $k = stft ] && echo 20 || echo 10) --warmup 3 --no-cpu-baseline > "$OUT/prof_$k.log" 2>&1
+done
+for c in FETCH_SIZE WRITE_SIZE; do
+  rm -rf "$OUT/pmc_$c"
+  timeout 600 rocprofv3 --pmc $c --kernel-trace --output-format csv -d "$OUT/pmc_$c" -o stft -- \
+      python "$REPO/bench.py" --steps 3 --warmup 1 --no-cpu-baseline > "$OUT/pmc_$c.log" 2>&1
+done
+find "$OUT" -name "*.csv" -size +8M -delete   # per-dispatch traces of the big runs are not needed
+ls "$OUT"

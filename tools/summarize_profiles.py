@@ -1,0 +1,101 @@
+#!/usr/bin/env python3
+"""gpurun_out/ (written by tools/collect_profiles.sh on the GPU box) -> profiles/ (committed).
+
+    python tools/summarize_profiles.py r01
+"""
+import csv
+import glob
+import json
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+OUT, PROF = os.path.join(ROOT, "gpurun_out"), os.path.join(ROOT, "profiles")
+tag = sys.argv[1] if len(sys.argv) > 1 else "r01"
+KINDS = ["stft", "istft", "mdct", "imdct", "mel", "mfcc", "cqt", "dct"]
+
+
+def find(pattern):
+    hits = sorted(glob.glob(os.path.join(OUT, pattern), recursive=True))
+    return hits[-1] if hits else None
+
+
+def stats_rows(kind):
+    f = find(f"prof_{kind}/**/*kernel_stats.csv")
+    if not f:
+        return None, []
+    with open(f) as fh:
+        rows = list(csv.reader(fh))
+    return rows[0], [r for r in rows[1:] if r and "zafx::" in r[0]]
+
+
+# bench lines
+for k in KINDS + ["stft_tf"]:
+    src = os.path.join(OUT, f"bench_{k}.json")
+    if os.path.exists(src) and os.path.getsize(src):
+        line = open(src).read().strip().splitlines()[-1]
+        json.loads(line)
+        open(os.path.join(PROF, f"{tag}_bench_{k}.json"), "w").write(line + "\n")
+
+# kernel statistics: the headline run in full, the dominant rows of the others in one file
+f = find("prof_stft/**/*kernel_stats.csv")
+if f:
+    open(os.path.join(PROF, f"{tag}_stft_kernel_stats.csv"), "w").write(open(f).read())
+with open(os.path.join(PROF, f"{tag}_other_kernel_stats.csv"), "w", newline="") as fh:
+    w = csv.writer(fh, quoting=csv.QUOTE_NONNUMERIC)
+    wrote_header = False
+    for k in KINDS[1:]:
+        header, rows = stats_rows(k)
+        if header and not wrote_header:
+            w.writerow(["kind"] + header)
+            wrote_header = True
+        for r in rows:
+            w.writerow([k] + r)
+
+
+# PMC passes of the headline kernel
+def counter_means(counter):
+    f = find(f"pmc_{counter}/**/*counter_collection.csv")
+    if not f:
+        return {}
+    acc = {}
+    with open(f) as fh:
+        for r in csv.DictReader(fh):
+            if r.get("Counter_Name") != counter:
+                continue
+            name = r["Kernel_Name"].split("(")[0]
+            s = acc.setdefault(name, [0, 0.0])
+            s[0] += 1
+            s[1] += float(r["Counter_Value"])
+    return {k: (n, v / n) for k, (n, v) in acc.items()}
+
+
+fetch, write = counter_means("FETCH_SIZE"), counter_means("WRITE_SIZE")
+if fetch and write:
+    with open(os.path.join(PROF, f"{tag}_stft_pmc_summary.csv"), "w") as fh:
+        fh.write("kernel,counter,dispatches,mean_value_KB\n")
+        for cname, tab in (("FETCH_SIZE", fetch), ("WRITE_SIZE", write)):
+            for k, (n, v) in sorted(tab.items()):
+                fh.write(f'"{k}",{cname},{n},{v:.3f}\n')
+    kern = next(k for k in fetch if "k_stft" in k)
+    copy = next((k for k in fetch if "copyBuffer" in k), None)
+    copy_bytes = 441000 * 4 * 8   # bench.py replicates blocks of 8 clips device-to-device
+    cal_f = copy_bytes / (fetch[copy][1] * 1024) if copy else None
+    cal_w = copy_bytes / (write[copy][1] * 1024) if copy else None
+    bench = json.loads(open(os.path.join(PROF, f"{tag}_bench_stft.json")).read())
+    doc = {
+        "kernel": "k_stft_ft16",
+        "fetch_size_kb_raw": fetch[kern][1],
+        "write_size_kb_raw": write[kern][1],
+        "fetch_correction": 2.0,
+        "write_correction": 1.0,
+        "calibration": {"kernel": copy, "bytes_per_dispatch": copy_bytes, "fetch_true_over_counter": cal_f,
+                        "write_true_over_counter": cal_w},
+        "hbm_bytes_per_launch": fetch[kern][1] * 1024 * 2.0 + write[kern][1] * 1024,
+        "algorithmic_bytes_per_launch": bench["roofline"]["algorithmic_bytes_per_launch"],
+        "note": "FETCH_SIZE/WRITE_SIZE in KB from separate rocprofv3 --pmc passes (profiles/%s_stft_pmc_summary.csv); gfx950 "
+                "FETCH_SIZE counts half the bytes of streaming reads (MI355X_MICROARCH.md, HBM section; confirmed on the "
+                "device-to-device copy in the same run), WRITE_SIZE is exact on that copy" % tag,
+    }
+    open(os.path.join(PROF, "pmc_stft.json"), "w").write(json.dumps(doc, indent=1) + "\n")
+print("profiles/ refreshed for", tag)

@@ -59,6 +59,19 @@ def make_workload(kind, device, layout="FT"):
         plan = zafx.stft_plan(ham, H, layout=layout, device=device)
         wl.update(plan=plan, d_in=d_x, n_in=N, bytes_per_launch=B * (4 * N + 8 * W * T),
                   desc="Batched STFT: 1024 clips x 10 s @ 44.1 kHz, Hamming win=2048 hop=1024, two-sided c64 (W,T) layout")
+    elif kind == "stft1":   # one-sided output (rows 0..W/2), not the headline
+        plan = zafx.stft_plan(ham, H, layout=layout, device=device, onesided=True)
+        wl.update(plan=plan, d_in=d_x, n_in=N, bytes_per_launch=B * (4 * N + 8 * (W // 2 + 1) * T),
+                  desc="Batched STFT, one-sided output (W/2+1, T): 1024 clips x 10 s, Hamming win=2048 hop=1024")
+    elif kind == "istft1":
+        fwd = zafx.stft_plan(ham, H, device=device, onesided=True)
+        d_s = zafx.DeviceBuffer(fwd.out_shape(B, N), np.complex64, device)
+        fwd.execute(d_x, d_s, B, N)
+        fwd.sync()
+        d_x.free()
+        plan = zafx.istft_plan(ham, H, device=device, onesided=True)
+        wl.update(plan=plan, d_in=d_s, n_in=T, bytes_per_launch=B * (8 * (W // 2 + 1) * T + 4 * (T * H - (W - H))),
+                  desc="Batched ISTFT from one-sided spectra: 1024 clips x 432 frames, win=2048 hop=1024")
     elif kind == "istft":
         fwd = zafx.stft_plan(ham, H, device=device)
         d_s = zafx.DeviceBuffer(fwd.out_shape(B, N), np.complex64, device)

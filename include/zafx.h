@@ -50,7 +50,7 @@ typedef struct zafx_comm zafx_comm;
 
 enum zafx_kind {
     ZAFX_STFT = 1,   /* in (B, N) f32            -> out (B, W, T) c64 [FT] or (B, T, W) [TF]       */
-    ZAFX_ISTFT = 2,  /* in (B, W, T)/(B, T, W)   -> out (B, T*H - (W-H)) f32                       */
+    ZAFX_ISTFT = 2,  /* in (B, W, T)/(B, T, W)   -> out (B, T*H - (W-H)) f32    (one-sided: W/2+1 rows) */
     ZAFX_MDCT = 3,   /* in (B, N) f32            -> out (B, W/2, T) f32 [FT] or (B, T, W/2) [TF]   */
     ZAFX_IMDCT = 4,  /* in (B, W/2, T)/(B,T,W/2) -> out (B, (W/2)*(T-1) - 1) f32                   */
     ZAFX_MEL = 5,    /* in (B, N) f32            -> out (B, n_filters, T) or (B, T, n_filters)     */
@@ -64,6 +64,12 @@ enum zafx_kind {
 enum zafx_layout {
     ZAFX_LAYOUT_FT = 0, /* reference memory order: frequency-major, time minor (zaf.py:128) */
     ZAFX_LAYOUT_TF = 1  /* frame-major: each frame's bins contiguous                        */
+};
+
+enum zafx_spectrum {      /* STFT output / ISTFT input rows                             */
+    ZAFX_SPECTRUM_TWO_SIDED = 0, /* W rows, as np.fft.fft returns them (zaf.py:139) -- the reference contract  */
+    ZAFX_SPECTRUM_ONE_SIDED = 1  /* rows 0..W/2 only (what every example keeps, zaf.py:83); the ISTFT completes
+                                    X[W-k] = conj X[k], i.e. equals istft of the two-sided spectrum of a real signal */
 };
 
 enum zafx_constant {
@@ -86,7 +92,8 @@ typedef struct zafx_params {
     int32_t fft_length;        /* CQT / CHROMA: power of two, 512..32768                        */
     int32_t n_bins;            /* CQT / CHROMA                                                  */
     int32_t octave_resolution; /* CHROMA                                                        */
-    int32_t reserved[7];
+    int32_t spectrum;          /* enum zafx_spectrum (STFT / ISTFT); 0 = reference contract     */
+    int32_t reserved[6];
 } zafx_params;
 
 /* ---- library / device ------------------------------------------------------------ */

@@ -440,3 +440,33 @@ def test_dct_dst(zafx, golden, n):
     assert relerr(gb, ref) <= TOL_FFT
     # the reference's plotted self-check (zaf.py:866-897): DST-II and DST-III are inverses
     assert np.max(np.abs(zafx.dst(zafx.dst(x, 2), 3) - x)) < 1e-5
+
+
+# ------------------------------------------------------------------ one-sided spectra
+@pytest.mark.parametrize("wl,hop,n", [(2048, 1024, 441000), (2048, 512, 30000), (1024, 256, 9001), (128, 64, 777), (4096, 2048, 50000)])
+def test_onesided_stft_istft(zafx, wl, hop, n):
+    """onesided=True: the STFT writes rows 0..W/2 of the reference's result (the slice zaf.py:83 keeps);
+    the ISTFT of those rows equals the reference's istft of the full spectrum of a real signal."""
+    x = np.stack([synth_clip(12, c, n) for c in range(3)])
+    w = zafx.hamming(wl)
+    ref = orc.stft_batch(x.astype(np.float64), w, hop)
+    half = wl // 2 + 1
+    for layout in ("FT", "TF"):
+        got = zafx.stft_batch(x, w, hop, layout=layout, onesided=True)
+        if layout == "TF":
+            got = got.transpose(0, 2, 1)
+        assert got.shape == (3, half, ref.shape[2])
+        for c in range(3):
+            assert relerr(got[c], ref[c, :half]) <= TOL_FFT, (layout, c)
+        spec = ref[:, :half] if layout == "FT" else np.ascontiguousarray(ref[:, :half].transpose(0, 2, 1))
+        y = zafx.istft_batch(spec, w, hop, layout=layout, onesided=True)
+        for c in range(3):
+            yref = orc.istft(ref[c], w, hop)
+            assert y[c].shape == yref.shape and relerr(y[c], yref) <= TOL_FFT, (layout, c)
+
+
+def test_onesided_rejected_elsewhere(zafx):
+    with pytest.raises(zafx.ZafxError):
+        zafx.Plan(zafx.MDCT, window_length=2048, onesided=True)
+    with pytest.raises(ValueError):
+        zafx.istft_batch(np.zeros((1, 2048, 4), np.complex64), zafx.hamming(2048), 1024, onesided=True)

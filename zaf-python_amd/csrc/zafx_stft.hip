@@ -45,13 +45,14 @@ struct StftCfg {
 // ---------------------------------------------------------------------------------
 // forward
 // ---------------------------------------------------------------------------------
-template <int LOG2N, int LOG2E, int FPB, int LAYOUT>
+// ONE = one-sided output (ZAFX_SPECTRUM_ONE_SIDED): rows 0..W/2 only, the mirror is not written.
+template <int LOG2N, int LOG2E, int FPB, int LAYOUT, bool ONE>
 __global__ __launch_bounds__(FPB * fft_threads(LOG2N, LOG2E)) void k_stft(
     const float* __restrict__ x, const float* __restrict__ win, const float2* __restrict__ twp,
     const float2* __restrict__ tws, float2* __restrict__ out, long long n_samples, int hop, int T, int tiles) {
     using C = FftCfg<LOG2N, LOG2E>;
     using S = StftCfg<LOG2N, LOG2E, FPB>;
-    constexpr int N = C::N, P = C::P, E = C::E, W = 2 * N, NT = S::NT;
+    constexpr int N = C::N, P = C::P, E = C::E, W = 2 * N, NT = S::NT, ROWS = ONE ? N + 1 : W;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     float2* frames = reinterpret_cast<float2*>(smem_raw);
     const float2* tw = twp;
@@ -88,7 +89,7 @@ __global__ __launch_bounds__(FPB * fft_threads(LOG2N, LOG2E)) void k_stft(
 
     if constexpr (LAYOUT == ZAFX_LAYOUT_TF) {
         if (t >= T) return;
-        float2* o = out + ((long long)clip * T + t) * W;
+        float2* o = out + ((long long)clip * T + t) * ROWS;
 #pragma unroll
         for (int i = 0; i < E / 2; ++i) {
             const int k = p + i * P;
@@ -97,14 +98,16 @@ __global__ __launch_bounds__(FPB * fft_threads(LOG2N, LOG2E)) void k_stft(
                 o[0] = make_float2(z0.x + z0.y, 0.f);
                 o[N] = make_float2(z0.x - z0.y, 0.f);
                 o[N / 2] = cconj(zc);
-                o[N + N / 2] = zc;
+                if (!ONE) o[N + N / 2] = zc;
             } else {
                 float2 xk, xn;
                 split_pair(buf[phys(k)], buf[phys(N - k)], tws[k], xk, xn);
                 o[k] = xk;
-                o[W - k] = cconj(xk);
                 o[N - k] = xn;
-                o[N + k] = cconj(xn);
+                if (!ONE) {
+                    o[W - k] = cconj(xk);
+                    o[N + k] = cconj(xn);
+                }
             }
         }
     } else {
@@ -112,21 +115,23 @@ __global__ __launch_bounds__(FPB * fft_threads(LOG2N, LOG2E)) void k_stft(
         const int tt = tid % FPB, kq = tid / FPB;
         if (t0 + tt >= T) return;
         const float2* fb = frames + tt * C::PITCH;
-        float2* o = out + (long long)clip * W * T + (t0 + tt);
+        float2* o = out + (long long)clip * ROWS * T + (t0 + tt);
         for (int k = kq; k < N / 2; k += P) {
             if (k == 0) {
                 const float2 z0 = fb[0], zc = fb[phys(N / 2)];
                 o[0] = make_float2(z0.x + z0.y, 0.f);
                 o[(long long)N * T] = make_float2(z0.x - z0.y, 0.f);
                 o[(long long)(N / 2) * T] = cconj(zc);
-                o[(long long)(N + N / 2) * T] = zc;
+                if (!ONE) o[(long long)(N + N / 2) * T] = zc;
             } else {
                 float2 xk, xn;
                 split_pair(fb[phys(k)], fb[phys(N - k)], tws[k], xk, xn);
                 o[(long long)k * T] = xk;
-                o[(long long)(W - k) * T] = cconj(xk);
                 o[(long long)(N - k) * T] = xn;
-                o[(long long)(N + k) * T] = cconj(xn);
+                if (!ONE) {
+                    o[(long long)(W - k) * T] = cconj(xk);
+                    o[(long long)(N + k) * T] = cconj(xn);
+                }
             }
         }
     }
@@ -161,7 +166,7 @@ struct FatCfg {
     static constexpr size_t SMEM = (size_t)(kFatFrames * PITCH + C::TW + N + N / 2 + 1) * 8;
 };
 
-template <int LOG2N, int LOG2E, bool ALIGNED>
+template <int LOG2N, int LOG2E, bool ALIGNED, bool ONE>
 __global__ __launch_bounds__(kFatWaves * 64) void k_stft_ft16(
     const float* __restrict__ x, const float* __restrict__ win, const float2* __restrict__ twp,
     const float2* __restrict__ tws, float2* __restrict__ out, long long n_samples, int hop, int T, int tiles,
@@ -169,6 +174,7 @@ __global__ __launch_bounds__(kFatWaves * 64) void k_stft_ft16(
     using C = FftCfg<LOG2N, LOG2E>;
     using F = FatCfg<LOG2N, LOG2E>;
     constexpr int N = C::N, P = C::P, E = C::E, W = 2 * N, NT = F::NT, FPB = kFatFrames, FPW = F::FPW, PITCH = F::PITCH;
+    constexpr int ROWS = ONE ? N + 1 : W;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     float2* frames = reinterpret_cast<float2*>(smem_raw);
     float2* tw_l = frames + FPB * PITCH;
@@ -236,21 +242,23 @@ __global__ __launch_bounds__(kFatWaves * 64) void k_stft_ft16(
         // from HBM twice: FETCH_SIZE 2.88 GB instead of 1.93 GB per launch, same time).
         prefetch(tl + gridDim.x);   // in flight while this tile is stored
         if (t0 + tt < T) {
-            float2* o = out + (long long)clip * W * T + (t0 + tt);
+            float2* o = out + (long long)clip * ROWS * T + (t0 + tt);
             for (int k = kq; k < N / 2; k += NT / FPB) {
                 if (k == 0) {
                     const float2 z0 = fb[0], zc = fb[phys(N / 2)];
                     o[0] = make_float2(z0.x + z0.y, 0.f);
                     o[(long long)N * T] = make_float2(z0.x - z0.y, 0.f);
                     o[(long long)(N / 2) * T] = cconj(zc);
-                    o[(long long)(N + N / 2) * T] = zc;
+                    if (!ONE) o[(long long)(N + N / 2) * T] = zc;
                 } else {
                     float2 xk, xn;
                     split_pair(fb[phys(k)], fb[phys(N - k)], tws_l[k], xk, xn);
                     o[(long long)k * T] = xk;
-                    o[(long long)(W - k) * T] = cconj(xk);
                     o[(long long)(N - k) * T] = xn;
-                    o[(long long)(N + k) * T] = cconj(xn);
+                    if (!ONE) {
+                        o[(long long)(W - k) * T] = cconj(xk);
+                        o[(long long)(N + k) * T] = cconj(xn);
+                    }
                 }
             }
         }
@@ -265,7 +273,7 @@ __global__ __launch_bounds__(kFatWaves * 64) void k_stft_ft16(
 // neighbours: one wavefront owns a frame from load to store (private LDS exchange buffer, 512-B
 // coalesced stores) and the 8 wavefronts of the persistent workgroup drift apart -- the store
 // issue of one overlaps the butterflies of another.  No s_barrier after the table staging.
-template <int LOG2N, int LOG2E, bool ALIGNED>
+template <int LOG2N, int LOG2E, bool ALIGNED, bool ONE>
 __global__ __launch_bounds__(512) void k_stft_tf(
     const float* __restrict__ x, const float* __restrict__ win, const float2* __restrict__ twp,
     const float2* __restrict__ tws, float2* __restrict__ out, long long n_samples, int hop, int T, long long total_frames) {
@@ -311,7 +319,7 @@ __global__ __launch_bounds__(512) void k_stft_tf(
             }
         }
         fft_frame<LOG2N, LOG2E>(v, buf, p, tw_l);
-        float2* o = out + g * W;
+        float2* o = out + g * (ONE ? N + 1 : W);
 #pragma unroll
         for (int i = 0; i < E / 2; ++i) {
             const int k = p + i * P;
@@ -320,14 +328,16 @@ __global__ __launch_bounds__(512) void k_stft_tf(
                 o[0] = make_float2(z0.x + z0.y, 0.f);
                 o[N] = make_float2(z0.x - z0.y, 0.f);
                 o[N / 2] = cconj(zc);
-                o[N + N / 2] = zc;
+                if (!ONE) o[N + N / 2] = zc;
             } else {
                 float2 xk, xn;
                 split_pair(buf[phys(k)], buf[phys(N - k)], tws_l[k], xk, xn);
                 o[k] = xk;
-                o[W - k] = cconj(xk);
                 o[N - k] = xn;
-                o[N + k] = cconj(xn);
+                if (!ONE) {
+                    o[W - k] = cconj(xk);
+                    o[N + k] = cconj(xn);
+                }
             }
         }
         frame_sync<P>();   // the split reads of this frame precede the next frame's first pass writes
@@ -355,7 +365,8 @@ __device__ __forceinline__ void unsplit_pair(float2 xk, float2 xwk, float2 xnk, 
     zn = make_float2(Zn.y, Zn.x);
 }
 
-template <int LOG2N, int LOG2E, int FPB, int LAYOUT>
+// ONE = one-sided input (ZAFX_SPECTRUM_ONE_SIDED): rows 0..W/2, completed as X[W-k] = conj X[k].
+template <int LOG2N, int LOG2E, int FPB, int LAYOUT, bool ONE>
 __global__ __launch_bounds__(FPB * fft_threads(LOG2N, LOG2E)) void k_istft(
     const float2* __restrict__ spec, const float2* __restrict__ twp, const float2* __restrict__ tws,
     float* __restrict__ y, int T, int hop, long long out_len, float scale, int tiles, int owned, int halo) {
@@ -382,23 +393,27 @@ __global__ __launch_bounds__(FPB * fft_threads(LOG2N, LOG2E)) void k_istft(
         const int t = t_first + fs;
         if (fs < owned + halo && t >= 0 && t < T) {
             float2* fb = frames + fs * C::PITCH;
+            constexpr int ROWS = ONE ? N + 1 : W;
             long long base, kstride;
-            if constexpr (LAYOUT == ZAFX_LAYOUT_TF) { base = ((long long)clip * T + t) * W; kstride = 1; }
-            else { base = (long long)clip * W * T + t; kstride = T; }
+            if constexpr (LAYOUT == ZAFX_LAYOUT_TF) { base = ((long long)clip * T + t) * ROWS; kstride = 1; }
+            else { base = (long long)clip * ROWS * T + t; kstride = T; }
             const float2* sp = spec + base;
             for (int k = kq; k < N / 2; k += kstep) {
                 if (k == 0) {
                     const float a0 = 2.f * sp[0].x, an = 2.f * sp[(long long)N * kstride].x;
                     // Z[0] = (a0 + aN) + i (a0 - aN), stored swapped
                     fb[0] = make_float2(a0 - an, a0 + an);
-                    const float2 xc = sp[(long long)(N / 2) * kstride], xd = sp[(long long)(N + N / 2) * kstride];
+                    const float2 xc = sp[(long long)(N / 2) * kstride];
+                    const float2 xd = ONE ? cconj(xc) : sp[(long long)(N + N / 2) * kstride];
                     // A = X[N/2] + conj X[3N/2]; Z[N/2] = 2 conj(A), stored swapped
                     const float2 a = make_float2(xc.x + xd.x, xc.y - xd.y);
                     fb[phys(N / 2)] = make_float2(-2.f * a.y, 2.f * a.x);
                 } else {
+                    const float2 xk = sp[(long long)k * kstride], xnk = sp[(long long)(N - k) * kstride];
+                    const float2 xwk = ONE ? cconj(xk) : sp[(long long)(W - k) * kstride];
+                    const float2 xnpk = ONE ? cconj(xnk) : sp[(long long)(N + k) * kstride];
                     float2 zk, zn;
-                    unsplit_pair(sp[(long long)k * kstride], sp[(long long)(W - k) * kstride],
-                                 sp[(long long)(N - k) * kstride], sp[(long long)(N + k) * kstride], tws[k], zk, zn);
+                    unsplit_pair(xk, xwk, xnk, xnpk, tws[k], zk, zn);
                     fb[phys(k)] = zk;
                     fb[phys(N - k)] = zn;
                 }
@@ -588,7 +603,7 @@ ZAFX_PROF_ARRAY(g_prof)
 // PRE sweeps of the NEXT tile are issued before the FFT phase and folded after it (their latency
 // hides under the FFT).  Barriers order LDS only (lds_barrier): the output stores of a tile are
 // not waited for.
-template <int LOG2N, int LOG2E, int DEPTH, int PRE>
+template <int LOG2N, int LOG2E, int DEPTH, int PRE, bool ONE>
 __global__ __launch_bounds__(1024) void k_istft_ft16(
     const float2* __restrict__ spec, const float2* __restrict__ twp, const float2* __restrict__ tws,
     float* __restrict__ y, int T, int hop, long long out_len, float scale, int tiles, int segs, int seg_tiles, int total_units,
@@ -596,6 +611,7 @@ __global__ __launch_bounds__(1024) void k_istft_ft16(
     using C = FftCfg<LOG2N, LOG2E>;
     using F = FatCfg<LOG2N, LOG2E>;
     constexpr int N = C::N, P = C::P, E = C::E, W = 2 * N, NT = 1024, FPB = kFatFrames, PITCH = F::PITCH;
+    constexpr int ROWS = ONE ? N + 1 : W;      // one-sided input: rows 0..N, X[W-k] = conj X[k]
     constexpr int KSTEP = NT / FPB;            // bins handled per sweep
     constexpr int KI = (N / 2) / KSTEP;        // sweeps per thread
     constexpr int NPRE = PRE < KI ? PRE : 0;   // sweeps prefetched across the FFT phase
@@ -638,8 +654,8 @@ __global__ __launch_bounds__(1024) void k_istft_ft16(
     };
     auto source = [&](const Tile& it) {
         Src src;
-        src.rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float2*>(spec) + (long long)(it.unit / segs) * W * T, 0,
-                                                     W * row_bytes, 0x00020000);
+        src.rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float2*>(spec) + (long long)(it.unit / segs) * ROWS * T, 0,
+                                                     ROWS * row_bytes, 0x00020000);
         src.t_bytes = it.tile * FPB * 8;
         return src;
     };
@@ -649,18 +665,26 @@ __global__ __launch_bounds__(1024) void k_istft_ft16(
         __builtin_memcpy(&f, &raw, 8);
         return f;
     };
+    // (one-sided input: only rows k and N-k are loaded -- plus row N/2 for the lane that holds k = 0 --
+    // and fold4 completes the other two as conjugates)
     auto load4 = [&](const Src& src, int s, float2 (&r)[4]) {
         if (s == 0) {   // the sweep that holds k = 0: per-lane row select
             const int k = kq;
             r[0] = ld(src, v_up, 0);
-            r[1] = ld(src, (k == 0 ? N / 2 : W - k) * row_bytes + fs * 8, 0);
             r[2] = ld(src, (N - k) * row_bytes + fs * 8, 0);
-            r[3] = ld(src, (k == 0 ? N + N / 2 : N + k) * row_bytes + fs * 8, 0);
+            if (ONE) {
+                r[1] = ld(src, (k == 0 ? N / 2 : k) * row_bytes + fs * 8, 0);
+            } else {
+                r[1] = ld(src, (k == 0 ? N / 2 : W - k) * row_bytes + fs * 8, 0);
+                r[3] = ld(src, (k == 0 ? N + N / 2 : N + k) * row_bytes + fs * 8, 0);
+            }
         } else {
             r[0] = ld(src, v_up, s * KSTEP * row_bytes);
-            r[1] = ld(src, v_down, (W - (s + 1) * KSTEP) * row_bytes);
             r[2] = ld(src, v_down, (N - (s + 1) * KSTEP) * row_bytes);
-            r[3] = ld(src, v_up, (N + s * KSTEP) * row_bytes);
+            if (!ONE) {
+                r[1] = ld(src, v_down, (W - (s + 1) * KSTEP) * row_bytes);
+                r[3] = ld(src, v_up, (N + s * KSTEP) * row_bytes);
+            }
         }
     };
     // Hermitian fold of one sweep into the packed half-length spectrum of my frame
@@ -669,16 +693,16 @@ __global__ __launch_bounds__(1024) void k_istft_ft16(
         if (k == 0) {   // r = X[0], X[N/2], X[N], X[3N/2]
             const float a0 = 2.f * r[0].x, an = 2.f * r[2].x;
             fbuf[0] = make_float2(a0 - an, a0 + an);
-            const float2 a = make_float2(r[1].x + r[3].x, r[1].y - r[3].y);
+            const float2 r3 = ONE ? cconj(r[1]) : r[3];
+            const float2 a = make_float2(r[1].x + r3.x, r[1].y - r3.y);
             fbuf[phys(N / 2)] = make_float2(-2.f * a.y, 2.f * a.x);
         } else {
             float2 zk, zn;
-            unsplit_pair(r[0], r[1], r[2], r[3], tws_l[k], zk, zn);
+            unsplit_pair(r[0], ONE ? cconj(r[0]) : r[1], r[2], ONE ? cconj(r[2]) : r[3], tws_l[k], zk, zn);
             fbuf[phys(k)] = zk;
             fbuf[phys(N - k)] = zn;
         }
     };
-
     Tile cur;
     cur.unit = blockIdx.x;
     if (cur.unit >= total_units) return;
@@ -786,11 +810,11 @@ constexpr bool stft_use_fat(int log2n, int layout) {
     return layout == ZAFX_LAYOUT_FT && log2n >= 7 && log2n <= 10;   // one wavefront per frame
 }
 
-template <int LOG2N, bool ALIGNED>
+template <int LOG2N, bool ALIGNED, bool ONE>
 static hipError_t run_stft_fat(const zafx_plan& pl, const float* x, float2* out, int64_t n_clips, int64_t n_samples, int T) {
     constexpr int LOG2E = default_log2e(LOG2N);
     using F = FatCfg<LOG2N, LOG2E>;
-    auto kern = k_stft_ft16<LOG2N, LOG2E, ALIGNED>;
+    auto kern = k_stft_ft16<LOG2N, LOG2E, ALIGNED, ONE>;
     if (hipError_t e = ensure_dynamic_lds(reinterpret_cast<const void*>(kern), pl.device, F::SMEM); e != hipSuccess) return e;
     const int tiles = (T + kFatFrames - 1) / kFatFrames;
     const long long total = (long long)tiles * n_clips;
@@ -806,13 +830,13 @@ constexpr bool stft_use_tf(int log2n, int layout) {
     return layout == ZAFX_LAYOUT_TF && log2n >= 7 && log2n <= 10;   // one wavefront per frame
 }
 
-template <int LOG2N, bool ALIGNED>
+template <int LOG2N, bool ALIGNED, bool ONE>
 static hipError_t run_stft_tf(const zafx_plan& pl, const float* x, float2* out, int64_t n_clips, int64_t n_samples, int T) {
     constexpr int LOG2E = default_log2e(LOG2N);
     using C = FftCfg<LOG2N, LOG2E>;
     constexpr size_t SMEM = (size_t)(8 * C::PITCH + C::TW + C::N + C::N / 2 + 1) * 8;
     static_assert(SMEM <= (size_t)kMaxLdsBytes, "frame-major STFT tables + buffers exceed LDS");
-    auto kern = k_stft_tf<LOG2N, LOG2E, ALIGNED>;
+    auto kern = k_stft_tf<LOG2N, LOG2E, ALIGNED, ONE>;
     if (hipError_t e = ensure_dynamic_lds(reinterpret_cast<const void*>(kern), pl.device, SMEM); e != hipSuccess) return e;
     const long long total = (long long)T * n_clips;
     if (total <= 0) return hipSuccess;
@@ -823,20 +847,20 @@ static hipError_t run_stft_tf(const zafx_plan& pl, const float* x, float2* out, 
     return hipGetLastError();
 }
 
-template <int LOG2N, int LAYOUT>
+template <int LOG2N, int LAYOUT, bool ONE>
 static hipError_t run_stft(const zafx_plan& pl, const float* x, float2* out, int64_t n_clips, int64_t n_samples, int T) {
     const bool aligned = (n_samples % 2 == 0) && (pl.H % 2 == 0) && (reinterpret_cast<uintptr_t>(x) % 8 == 0);
     if constexpr (stft_use_fat(LOG2N, LAYOUT)) {
-        return aligned ? run_stft_fat<LOG2N, true>(pl, x, out, n_clips, n_samples, T)
-                       : run_stft_fat<LOG2N, false>(pl, x, out, n_clips, n_samples, T);
+        return aligned ? run_stft_fat<LOG2N, true, ONE>(pl, x, out, n_clips, n_samples, T)
+                       : run_stft_fat<LOG2N, false, ONE>(pl, x, out, n_clips, n_samples, T);
     } else if constexpr (stft_use_tf(LOG2N, LAYOUT)) {
-        return aligned ? run_stft_tf<LOG2N, true>(pl, x, out, n_clips, n_samples, T)
-                       : run_stft_tf<LOG2N, false>(pl, x, out, n_clips, n_samples, T);
+        return aligned ? run_stft_tf<LOG2N, true, ONE>(pl, x, out, n_clips, n_samples, T)
+                       : run_stft_tf<LOG2N, false, ONE>(pl, x, out, n_clips, n_samples, T);
     } else {
         constexpr int LOG2E = default_log2e(LOG2N);
         constexpr int FPB = stft_fpb(LOG2N, LAYOUT);
         using S = StftCfg<LOG2N, LOG2E, FPB>;
-        auto kern = k_stft<LOG2N, LOG2E, FPB, LAYOUT>;
+        auto kern = k_stft<LOG2N, LOG2E, FPB, LAYOUT, ONE>;
         if (hipError_t e = ensure_dynamic_lds(reinterpret_cast<const void*>(kern), pl.device, S::SMEM); e != hipSuccess) return e;
         const int tiles = (T + FPB - 1) / FPB;
         const long long blocks = (long long)tiles * n_clips;
@@ -862,11 +886,11 @@ int carry_segments(long long n_clips, int tiles, long long grid) {
     return best;
 }
 
-template <int LOG2N>
+template <int LOG2N, bool ONE>
 static hipError_t run_istft_fat(const zafx_plan& pl, const float2* spec, float* y, int64_t n_clips, int T, int64_t out_len) {
     constexpr int LOG2E = default_log2e(LOG2N);
     using F = FatCfg<LOG2N, LOG2E>;
-    auto kern = k_istft_ft16<LOG2N, LOG2E, 2, 0>;   // measured: 2 sweeps in flight, no cross-phase prefetch (profiles/r01_notes.md)
+    auto kern = k_istft_ft16<LOG2N, LOG2E, 2, 0, ONE>;   // measured: 2 sweeps in flight, no cross-phase prefetch (profiles/r01_notes.md)
     const int nt = 1024;
     if (hipError_t e = ensure_dynamic_lds(reinterpret_cast<const void*>(kern), pl.device, F::SMEM); e != hipSuccess) return e;
     const int W = 2 << LOG2N;
@@ -889,16 +913,16 @@ static hipError_t run_istft_fat(const zafx_plan& pl, const float2* spec, float* 
     return hipGetLastError();
 }
 
-template <int LOG2N, int LAYOUT>
+template <int LOG2N, int LAYOUT, bool ONE>
 static hipError_t run_istft(const zafx_plan& pl, const float2* spec, float* y, int64_t n_clips, int T, int64_t out_len) {
     if constexpr (stft_use_fat(LOG2N, LAYOUT)) {
         // the carry kernel addresses a clip through one buffer descriptor (32-bit byte offsets)
-        if ((long long)(2 << LOG2N) * T * 8 < (1LL << 31)) return run_istft_fat<LOG2N>(pl, spec, y, n_clips, T, out_len);
+        if ((long long)(2 << LOG2N) * T * 8 < (1LL << 31)) return run_istft_fat<LOG2N, ONE>(pl, spec, y, n_clips, T, out_len);
     }
     constexpr int LOG2E = default_log2e(LOG2N);
     constexpr int FPB = stft_fpb(LOG2N, ZAFX_LAYOUT_FT);
     using S = StftCfg<LOG2N, LOG2E, FPB>;
-    auto kern = k_istft<LOG2N, LOG2E, FPB, LAYOUT>;
+    auto kern = k_istft<LOG2N, LOG2E, FPB, LAYOUT, ONE>;
     if (hipError_t e = ensure_dynamic_lds(reinterpret_cast<const void*>(kern), pl.device, S::SMEM); e != hipSuccess) return e;
     const int W = 2 << LOG2N;
     const int halo = (W + pl.H - 1) / pl.H - 1;
@@ -925,12 +949,26 @@ const char* stft_kernel_name(int log2n, int layout) {
 }
 const char* istft_kernel_name(int log2n, int layout) { return stft_use_fat(log2n, layout) ? "k_istft_ft16" : "k_istft"; }
 
+template <int L>
+static hipError_t dispatch_stft(const zafx_plan& pl, const float* x, float2* out, int64_t n_clips, int64_t n_samples, int T) {
+    const bool one = pl.prm.spectrum == ZAFX_SPECTRUM_ONE_SIDED;
+    if (pl.layout == ZAFX_LAYOUT_FT)
+        return one ? run_stft<L, ZAFX_LAYOUT_FT, true>(pl, x, out, n_clips, n_samples, T) : run_stft<L, ZAFX_LAYOUT_FT, false>(pl, x, out, n_clips, n_samples, T);
+    return one ? run_stft<L, ZAFX_LAYOUT_TF, true>(pl, x, out, n_clips, n_samples, T) : run_stft<L, ZAFX_LAYOUT_TF, false>(pl, x, out, n_clips, n_samples, T);
+}
+
+template <int L>
+static hipError_t dispatch_istft(const zafx_plan& pl, const float2* spec, float* y, int64_t n_clips, int T, int64_t out_len) {
+    const bool one = pl.prm.spectrum == ZAFX_SPECTRUM_ONE_SIDED;
+    if (pl.layout == ZAFX_LAYOUT_FT)
+        return one ? run_istft<L, ZAFX_LAYOUT_FT, true>(pl, spec, y, n_clips, T, out_len) : run_istft<L, ZAFX_LAYOUT_FT, false>(pl, spec, y, n_clips, T, out_len);
+    return one ? run_istft<L, ZAFX_LAYOUT_TF, true>(pl, spec, y, n_clips, T, out_len) : run_istft<L, ZAFX_LAYOUT_TF, false>(pl, spec, y, n_clips, T, out_len);
+}
+
 hipError_t launch_stft(const zafx_plan& pl, const float* x, float2* out, int64_t n_clips, int64_t n_samples, int T) {
     switch (pl.log2nf) {
-#define X(L)                                                                                        \
-    case L:                                                                                         \
-        return pl.layout == ZAFX_LAYOUT_FT ? run_stft<L, ZAFX_LAYOUT_FT>(pl, x, out, n_clips, n_samples, T) \
-                                           : run_stft<L, ZAFX_LAYOUT_TF>(pl, x, out, n_clips, n_samples, T);
+#define X(L) \
+    case L: return dispatch_stft<L>(pl, x, out, n_clips, n_samples, T);
         ZAFX_STFT_SIZES(X)
 #undef X
     }
@@ -939,10 +977,8 @@ hipError_t launch_stft(const zafx_plan& pl, const float* x, float2* out, int64_t
 
 hipError_t launch_istft(const zafx_plan& pl, const float2* spec, float* y, int64_t n_clips, int T, int64_t out_len) {
     switch (pl.log2nf) {
-#define X(L)                                                                                          \
-    case L:                                                                                           \
-        return pl.layout == ZAFX_LAYOUT_FT ? run_istft<L, ZAFX_LAYOUT_FT>(pl, spec, y, n_clips, T, out_len) \
-                                           : run_istft<L, ZAFX_LAYOUT_TF>(pl, spec, y, n_clips, T, out_len);
+#define X(L) \
+    case L: return dispatch_istft<L>(pl, spec, y, n_clips, T, out_len);
         ZAFX_STFT_SIZES(X)
 #undef X
     }

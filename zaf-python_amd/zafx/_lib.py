@@ -12,6 +12,8 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 STFT, ISTFT, MDCT, IMDCT, MEL, MFCC, CQT, CHROMA, LINEAR = 1, 2, 3, 4, 5, 6, 7, 8, 9
 # enum zafx_layout
 LAYOUT_FT, LAYOUT_TF = 0, 1
+# enum zafx_spectrum
+SPECTRUM_TWO_SIDED, SPECTRUM_ONE_SIDED = 0, 1
 # enum zafx_constant
 CONST_WINDOW, CONST_MEL_FB, CONST_DCT, CONST_CQT_INDPTR, CONST_CQT_INDICES, CONST_CQT_VALUES, CONST_MATRIX = 1, 2, 3, 4, 5, 6, 7
 
@@ -27,7 +29,8 @@ class ZafxParams(ctypes.Structure):
         ("fft_length", ctypes.c_int32),
         ("n_bins", ctypes.c_int32),
         ("octave_resolution", ctypes.c_int32),
-        ("reserved", ctypes.c_int32 * 7),
+        ("spectrum", ctypes.c_int32),
+        ("reserved", ctypes.c_int32 * 6),
     ]
 
 

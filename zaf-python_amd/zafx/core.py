@@ -94,7 +94,7 @@ class Plan:
     _FORWARD = (_lib.STFT, _lib.MDCT, _lib.MEL, _lib.MFCC, _lib.CQT, _lib.CHROMA)   # 2-D (frequency x time) outputs
 
     def __init__(self, kind, device=0, window_length=0, step_length=0, layout="FT", n_filters=0, n_coefs=0,
-                 fft_length=0, n_bins=0, octave_resolution=0):
+                 fft_length=0, n_bins=0, octave_resolution=0, onesided=False):
         self.kind = kind
         self.device = int(device)
         self.layout = _LAYOUTS[layout]
@@ -108,6 +108,7 @@ class Plan:
         prm.fft_length = int(fft_length)
         prm.n_bins = int(n_bins)
         prm.octave_resolution = int(octave_resolution)
+        prm.spectrum = _lib.SPECTRUM_ONE_SIDED if onesided else _lib.SPECTRUM_TWO_SIDED
         self.params = prm
         h = ctypes.c_void_p()
         _lib.check(_lib.load().zafx_plan_create(ctypes.byref(h), self.device, kind, ctypes.byref(prm)), "zafx_plan_create")
@@ -313,27 +314,27 @@ def _as_signal(audio_signal):
 # ======================================================================================
 # plan factories
 # ======================================================================================
-def stft_plan(window_function, step_length, layout="FT", device=0):
+def stft_plan(window_function, step_length, layout="FT", device=0, onesided=False):
     w, h = _as_window(window_function), _as_step(step_length)
     if h > len(w):
         raise ValueError("step_length must not exceed window_length")
-    key = ("stft", device, len(w), h, _LAYOUTS[layout], _digest(w))
+    key = ("stft", device, len(w), h, _LAYOUTS[layout], bool(onesided), _digest(w))
 
     def make():
-        p = Plan(_lib.STFT, device, window_length=len(w), step_length=h, layout=layout)
+        p = Plan(_lib.STFT, device, window_length=len(w), step_length=h, layout=layout, onesided=onesided)
         p.set_window(w)
         return p
     return _cached(key, make)
 
 
-def istft_plan(window_function, step_length, layout="FT", device=0):
+def istft_plan(window_function, step_length, layout="FT", device=0, onesided=False):
     w, h = _as_window(window_function), _as_step(step_length)
     if h > len(w):
         raise ValueError("step_length must not exceed window_length")
-    key = ("istft", device, len(w), h, _LAYOUTS[layout], _digest(w))
+    key = ("istft", device, len(w), h, _LAYOUTS[layout], bool(onesided), _digest(w))
 
     def make():
-        p = Plan(_lib.ISTFT, device, window_length=len(w), step_length=h, layout=layout)
+        p = Plan(_lib.ISTFT, device, window_length=len(w), step_length=h, layout=layout, onesided=onesided)
         p.set_window(w)
         return p
     return _cached(key, make)
@@ -418,22 +419,28 @@ def linear_plan(matrix, device=0):
 # ======================================================================================
 # batched API (build-defined extension): (clips, samples) float32 in, float32/complex64 out
 # ======================================================================================
-def stft_batch(clips, window_function, step_length, layout="FT", device=0):
-    """(B, N) -> (B, W, T) complex64 [layout "FT"] or (B, T, W) ["TF"]."""
+def stft_batch(clips, window_function, step_length, layout="FT", device=0, onesided=False):
+    """(B, N) -> (B, W, T) complex64 [layout "FT"] or (B, T, W) ["TF"].
+
+    onesided=True keeps rows 0..W/2 only -- what every example of the reference slices out of the
+    result (zaf.py:83) -- and halves the bytes written."""
     x = _as_clips(clips)
-    return stft_plan(window_function, step_length, layout, device).run_host(x, x.shape[1])
+    return stft_plan(window_function, step_length, layout, device, onesided).run_host(x, x.shape[1])
 
 
-def istft_batch(spectra, window_function, step_length, layout="FT", device=0):
-    """(B, W, T) ["FT"] or (B, T, W) ["TF"] complex -> (B, T*H - (W-H)) float32."""
+def istft_batch(spectra, window_function, step_length, layout="FT", device=0, onesided=False):
+    """(B, W, T) ["FT"] or (B, T, W) ["TF"] complex -> (B, T*H - (W-H)) float32.
+
+    onesided=True takes rows 0..W/2 and completes X[W-k] = conj X[k]: the result equals the two-sided
+    call on the spectrum of a real signal."""
     s = np.ascontiguousarray(spectra, dtype=np.complex64)
     w = _as_window(window_function)
     if s.ndim != 3:
         raise ValueError("spectra must be 3-D")
     wl, nt = (s.shape[1], s.shape[2]) if _LAYOUTS[layout] == _lib.LAYOUT_FT else (s.shape[2], s.shape[1])
-    if wl != len(w):
-        raise ValueError("spectrum rows must equal window_length")
-    return istft_plan(w, step_length, layout, device).run_host(s, nt)
+    if wl != (len(w) // 2 + 1 if onesided else len(w)):
+        raise ValueError("spectrum rows must equal window_length (window_length/2 + 1 when onesided)")
+    return istft_plan(w, step_length, layout, device, onesided).run_host(s, nt)
 
 
 def mdct_batch(clips, window_function, layout="FT", device=0):

@@ -27,6 +27,11 @@ if kind == "istft":
     fwd.sync()
     n_in, tiles = T, 27
     d_out = zafx.DeviceBuffer((B, plan.out_dims(T)[0]), np.float32)
+elif kind in ("stft", "stft1"):
+    plan = zafx.stft_plan(zafx.hamming(W), H, onesided=kind == "stft1")
+    F, T = plan.out_dims(N)
+    d_in, n_in, tiles = d_x, N, 27
+    d_out = zafx.DeviceBuffer((B, F, T), np.complex64)
 elif kind == "mdct":
     plan = zafx.mdct_plan(zafx.kaiser_bessel_derived(W))
     F, T = plan.out_dims(N)
@@ -58,7 +63,7 @@ elif kind == "cqt":
     d_out = zafx.DeviceBuffer((B, F, T), np.float32)
 else:
     raise SystemExit("kind must be istft, mdct, imdct or cqt")
-fn = getattr(lib, "zafx_debug_prof_" + ("mel" if kind == "mfcc" else kind))
+fn = getattr(lib, "zafx_debug_prof_" + {"mfcc": "mel", "stft1": "stft"}.get(kind, kind))
 out = (ctypes.c_ulonglong * 16)()
 plan.execute(d_in, d_out, B, n_in)
 plan.sync()

@@ -122,13 +122,8 @@ __global__ __launch_bounds__(fft_threads(LOG2N, LOG2E)) void k_cqt(
                 // branch-free: lanes past the chunk read out of range, i.e. 0 (a select on the loaded value
                 // would make the wave wait for the load right here)
                 const bool on = lane < ch.z;
-#ifdef ZAFX_ABL_NOLOAD
-                slot[g] = on ? ch.y + lane : 0;
-                kv[g] = make_float2(1.f, 0.5f);
-#else
                 slot[g] = buf_load_i32(rslots, on ? (ch.y + lane) * 4 : -4);
                 kv[g] = buf_load_f32x2(rvals, on ? (ch.y + lane) * 8 : -8);
-#endif
             }
         };
         request(c0);

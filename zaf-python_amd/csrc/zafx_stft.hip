@@ -152,6 +152,7 @@ __global__ __launch_bounds__(FPB * fft_threads(LOG2N, LOG2E)) void k_stft(
 //     branches); only the clip-edge frames take the predicated path;
 //   * pads the frame pitch to 2 (mod 32) complex slots: the transposed read of the store
 //     phase (16 frames x 2 bins per 32-lane group) is then LDS-bank-conflict free.
+ZAFX_PROF_ARRAY(g_prof_stft)
 constexpr int kFatWaves = 8;
 constexpr int kFatFrames = 16;
 
@@ -223,9 +224,11 @@ __global__ __launch_bounds__(kFatWaves * 64) void k_stft_ft16(
     };
     int tl = blockIdx.x;
     prefetch(tl);
+    PROF_INIT(g_prof_stft);
     for (; tl < total_tiles; tl += gridDim.x) {
         const int clip = tl / tiles, tile = tl % tiles;
         const int t0 = tile * FPB;
+        PROF_MARK(0);
 #pragma unroll
         for (int f = 0; f < FPW; ++f) {
             float2 v[E];
@@ -236,11 +239,14 @@ __global__ __launch_bounds__(kFatWaves * 64) void k_stft_ft16(
             }
             fft_frame<LOG2N, LOG2E>(v, frames + (wave * FPW + f) * PITCH, p, tw_l);
         }
+        PROF_MARK(1);
         lds_barrier();
+        PROF_MARK(2);
         // The two frames of a wave are adjacent and overlap by W - hop samples: requested together, the
         // shared half is served by the vector cache (requested half a store phase apart it was fetched
         // from HBM twice: FETCH_SIZE 2.88 GB instead of 1.93 GB per launch, same time).
         prefetch(tl + gridDim.x);   // in flight while this tile is stored
+        PROF_MARK(3);
         if (t0 + tt < T) {
             float2* o = out + (long long)clip * ROWS * T + (t0 + tt);
             for (int k = kq; k < N / 2; k += NT / FPB) {
@@ -262,6 +268,7 @@ __global__ __launch_bounds__(kFatWaves * 64) void k_stft_ft16(
                 }
             }
         }
+        PROF_MARK(4);
         lds_barrier();   // LDS reads of the tile are done; its global stores are NOT waited for
     }
 }
@@ -988,3 +995,4 @@ hipError_t launch_istft(const zafx_plan& pl, const float2* spec, float* y, int64
 }  // namespace zafx
 
 ZAFX_PROF_EXPORT(zafx_debug_prof_istft, g_prof)
+ZAFX_PROF_EXPORT(zafx_debug_prof_stft, g_prof_stft)

@@ -610,7 +610,7 @@ ZAFX_PROF_ARRAY(g_prof)
 // PRE sweeps of the NEXT tile are issued before the FFT phase and folded after it (their latency
 // hides under the FFT).  Barriers order LDS only (lds_barrier): the output stores of a tile are
 // not waited for.
-template <int LOG2N, int LOG2E, int DEPTH, int PRE, bool ONE>
+template <int LOG2N, int LOG2E, int DEPTH, int PRE, bool ONE, int FV>
 __global__ __launch_bounds__(1024) void k_istft_ft16(
     const float2* __restrict__ spec, const float2* __restrict__ twp, const float2* __restrict__ tws,
     float* __restrict__ y, int T, int hop, long long out_len, float scale, int tiles, int segs, int seg_tiles, int total_units,
@@ -619,10 +619,15 @@ __global__ __launch_bounds__(1024) void k_istft_ft16(
     using F = FatCfg<LOG2N, LOG2E>;
     constexpr int N = C::N, P = C::P, E = C::E, W = 2 * N, NT = 1024, FPB = kFatFrames, PITCH = F::PITCH;
     constexpr int ROWS = ONE ? N + 1 : W;      // one-sided input: rows 0..N, X[W-k] = conj X[k]
-    constexpr int KSTEP = NT / FPB;            // bins handled per sweep
+    // FV frames per lane and load: 2 = 16-byte loads of two adjacent frames (needs T even).  The CU's
+    // vector-memory queue holds ~64 wave-level loads whatever their width, so 16-byte lanes double the
+    // bytes in flight (64 KB) and with them the gather rate of a CU that is alone in its load phase.
+    constexpr int LPR = FPB / FV;              // lanes per row run
+    constexpr int KSTEP = NT / LPR;            // bins handled per sweep
     constexpr int KI = (N / 2) / KSTEP;        // sweeps per thread
     constexpr int NPRE = PRE < KI ? PRE : 0;   // sweeps prefetched across the FFT phase
-    static_assert((N / 2) % KSTEP == 0, "pair sweep must divide N/2");
+    static_assert((FV == 1 || FV == 2) && KI >= 1 && (N / 2) % KSTEP == 0, "pair sweep must divide N/2");
+    using RV = std::conditional_t<FV == 2, float4, float2>;   // one row piece of my FV frames
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     float2* frames = reinterpret_cast<float2*>(smem_raw);
     float2* tw_l = frames + FPB * PITCH;
@@ -632,7 +637,7 @@ __global__ __launch_bounds__(1024) void k_istft_ft16(
     for (int i = tid; i < C::TW; i += NT) tw_l[i] = twp[i];
     for (int i = tid; i <= N / 2; i += NT) tws_l[i] = tws[i];
     const int wave = tid / P, p = tid % P;
-    const int fs = tid % FPB, kq = tid / FPB;
+    const int fs = (tid % LPR) * FV, kq = tid / LPR;   // my first frame of the tile, my bin within a sweep
     float2* fbuf = frames + fs * PITCH;
     const int ncarry = W - hop;
     const bool pairs = hop % 2 == 0 && 2 * hop >= W;
@@ -647,10 +652,10 @@ __global__ __launch_bounds__(1024) void k_istft_ft16(
         it.tile_b = min(it.tile_a + seg_tiles, tiles);
         it.tile = it.tile_a > 0 ? it.tile_a - 1 : 0;
     };
-    auto my_frame_needed = [&](const Tile& it) {
-        return it.tile * FPB + fs < T && fs >= (it.tile < it.tile_a ? FPB - halo : 0);
+    auto my_frame_needed = [&](const Tile& it) {   // (FV = 2: T is even, so both frames exist or neither)
+        return it.tile * FPB + fs < T && fs + FV - 1 >= (it.tile < it.tile_a ? FPB - halo : 0);
     };
-    // Rows k, W-k, N-k, N+k of sweep s (k = 0: rows 0, N/2, N, 3N/2) for my frame.  Buffer loads: the
+    // Rows k, W-k, N-k, N+k of sweep s (k = 0: rows 0, N/2, N, 3N/2) for my frame(s).  Buffer loads: the
     // clip's descriptor and the sweep's row offsets are wave-uniform (SGPRs), the per-lane part is two
     // 32-bit offsets for the whole tile -- 64-bit flat addresses would cost 8 VGPRs per sweep in flight.
     const int row_bytes = T * 8;
@@ -667,14 +672,19 @@ __global__ __launch_bounds__(1024) void k_istft_ft16(
         return src;
     };
     auto ld = [&](const Src& src, int voff, int soff) {
-        const auto raw = __builtin_amdgcn_raw_buffer_load_b64(src.rsrc, voff, soff + src.t_bytes, 0);
-        float2 f;
-        __builtin_memcpy(&f, &raw, 8);
+        RV f;
+        if constexpr (FV == 2) {
+            const auto raw = __builtin_amdgcn_raw_buffer_load_b128(src.rsrc, voff, soff + src.t_bytes, 0);
+            __builtin_memcpy(&f, &raw, 16);
+        } else {
+            const auto raw = __builtin_amdgcn_raw_buffer_load_b64(src.rsrc, voff, soff + src.t_bytes, 0);
+            __builtin_memcpy(&f, &raw, 8);
+        }
         return f;
     };
     // (one-sided input: only rows k and N-k are loaded -- plus row N/2 for the lane that holds k = 0 --
     // and fold4 completes the other two as conjugates)
-    auto load4 = [&](const Src& src, int s, float2 (&r)[4]) {
+    auto load4 = [&](const Src& src, int s, RV (&r)[4]) {
         if (s == 0) {   // the sweep that holds k = 0: per-lane row select
             const int k = kq;
             r[0] = ld(src, v_up, 0);
@@ -694,20 +704,30 @@ __global__ __launch_bounds__(1024) void k_istft_ft16(
             }
         }
     };
-    // Hermitian fold of one sweep into the packed half-length spectrum of my frame
-    auto fold4 = [&](int s, const float2 (&r)[4]) {
-        const int k = kq + s * KSTEP;
+    // Hermitian fold of one sweep into the packed half-length spectrum of one frame
+    auto fold_one = [&](int k, float2 r0, float2 r1, float2 r2, float2 r3, float2* fb) {
         if (k == 0) {   // r = X[0], X[N/2], X[N], X[3N/2]
-            const float a0 = 2.f * r[0].x, an = 2.f * r[2].x;
-            fbuf[0] = make_float2(a0 - an, a0 + an);
-            const float2 r3 = ONE ? cconj(r[1]) : r[3];
-            const float2 a = make_float2(r[1].x + r3.x, r[1].y - r3.y);
-            fbuf[phys(N / 2)] = make_float2(-2.f * a.y, 2.f * a.x);
+            const float a0 = 2.f * r0.x, an = 2.f * r2.x;
+            fb[0] = make_float2(a0 - an, a0 + an);
+            if (ONE) r3 = cconj(r1);
+            const float2 a = make_float2(r1.x + r3.x, r1.y - r3.y);
+            fb[phys(N / 2)] = make_float2(-2.f * a.y, 2.f * a.x);
         } else {
             float2 zk, zn;
-            unsplit_pair(r[0], ONE ? cconj(r[0]) : r[1], r[2], ONE ? cconj(r[2]) : r[3], tws_l[k], zk, zn);
-            fbuf[phys(k)] = zk;
-            fbuf[phys(N - k)] = zn;
+            unsplit_pair(r0, ONE ? cconj(r0) : r1, r2, ONE ? cconj(r2) : r3, tws_l[k], zk, zn);
+            fb[phys(k)] = zk;
+            fb[phys(N - k)] = zn;
+        }
+    };
+    auto fold4 = [&](int s, const RV (&r)[4]) {
+        const int k = kq + s * KSTEP;
+        if constexpr (FV == 2) {
+            fold_one(k, make_float2(r[0].x, r[0].y), make_float2(r[1].x, r[1].y), make_float2(r[2].x, r[2].y),
+                     make_float2(r[3].x, r[3].y), fbuf);
+            fold_one(k, make_float2(r[0].z, r[0].w), make_float2(r[1].z, r[1].w), make_float2(r[2].z, r[2].w),
+                     make_float2(r[3].z, r[3].w), fbuf + PITCH);
+        } else {
+            fold_one(k, r[0], r[1], r[2], r[3], fbuf);
         }
     };
     Tile cur;
@@ -715,7 +735,7 @@ __global__ __launch_bounds__(1024) void k_istft_ft16(
     if (cur.unit >= total_units) return;
     enter(cur);
     for (int c = tid; c < ncarry; c += NT) carry[c] = 0.f;
-    float2 pre[NPRE > 0 ? NPRE : 1][4];
+    RV pre[NPRE > 0 ? NPRE : 1][4];
     if (NPRE > 0 && my_frame_needed(cur)) {
         const Src sp = source(cur);
 #pragma unroll
@@ -735,7 +755,7 @@ __global__ __launch_bounds__(1024) void k_istft_ft16(
             for (int s = 0; s < NPRE; ++s) fold4(s, pre[s]);
 #pragma unroll DEPTH
             for (int s = NPRE; s < KI; ++s) {
-                float2 r[4];
+                RV r[4];
                 load4(sp, s, r);
                 fold4(s, r);
             }
@@ -897,7 +917,13 @@ template <int LOG2N, bool ONE>
 static hipError_t run_istft_fat(const zafx_plan& pl, const float2* spec, float* y, int64_t n_clips, int T, int64_t out_len) {
     constexpr int LOG2E = default_log2e(LOG2N);
     using F = FatCfg<LOG2N, LOG2E>;
-    auto kern = k_istft_ft16<LOG2N, LOG2E, 2, 0, ONE>;   // measured: 2 sweeps in flight, no cross-phase prefetch (profiles/r01_notes.md)
+    // 16-byte gathers (two adjacent frames per lane) when the rows allow it; see the kernel
+    constexpr bool can_vec = LOG2N >= 8;
+    const bool vec = can_vec && T % 2 == 0 && reinterpret_cast<uintptr_t>(spec) % 16 == 0;
+    // sweeps streamed together: 8 loads per wave in flight is the measured optimum (profiles/r01_notes.md);
+    // a one-sided sweep has 2 loads instead of 4
+    constexpr int D1 = ONE ? 4 : 2, D2 = ONE ? 4 : 1;
+    auto kern = vec ? k_istft_ft16<LOG2N, LOG2E, D2, 0, ONE, can_vec ? 2 : 1> : k_istft_ft16<LOG2N, LOG2E, D1, 0, ONE, 1>;
     const int nt = 1024;
     if (hipError_t e = ensure_dynamic_lds(reinterpret_cast<const void*>(kern), pl.device, F::SMEM); e != hipSuccess) return e;
     const int W = 2 << LOG2N;

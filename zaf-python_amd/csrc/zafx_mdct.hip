@@ -289,6 +289,8 @@ __global__ __launch_bounds__(NSLOT * fft_threads(LOG2NF, LOG2E)) void k_imdct(
     lds_barrier();
     const float* fl = reinterpret_cast<const float*>(frames);
     const float gain = 2.f / (float)M;
+    const bool vec4 = LAYOUT == ZAFX_LAYOUT_FT && FPB % 4 == 0 && NT % (FPB / 4) == 0 && NF >= NT / (FPB / 4) && T % 4 == 0 &&
+                      reinterpret_cast<uintptr_t>(coefs) % 16 == 0;
     // second half (n0 = n1 + M) of a frame's unfolded, windowed output: what it adds to the next frame's span
     auto older = [&](const float* fr, int n1) {
         const int n0 = n1 + M;
@@ -314,6 +316,27 @@ __global__ __launch_bounds__(NSLOT * fft_threads(LOG2NF, LOG2E)) void k_imdct(
             float2* fb = frames + fs * C::PITCH;
             const float* cp = coefs + ((long long)clip * T + t) * M;
             for (int m = mq; m < NF; m += P) fb[phys(m)] = cmul(make_float2(cp[2 * m], cp[M - 1 - 2 * m]), tw8[m]);
+        }
+    } else if (vec4) {
+        // 16-byte gathers: a lane reads 4 adjacent frames of a row (8 lanes per 128-B run).  The CU's
+        // vector-memory queue holds ~64 wave-level loads whatever their width; 4-byte lanes leave it
+        // carrying 256 B per entry.
+        constexpr int LPR = FPB / 4;
+        const int fs = (tid % LPR) * 4, mq = tid / LPR;
+        const int t = t_first + fs;
+        if (t < T && fs + 3 >= first_needed) {   // T % 4 == 0: the four frames exist together
+            float2* fb = frames + fs * C::PITCH;
+            const float* cp = coefs + (long long)clip * M * T + t;
+#pragma unroll 2
+            for (int m = mq; m < NF; m += NT / LPR) {
+                const float4 re = *reinterpret_cast<const float4*>(cp + (long long)(2 * m) * T);
+                const float4 im = *reinterpret_cast<const float4*>(cp + (long long)(M - 1 - 2 * m) * T);
+                const float2 g = tw8[m];
+                fb[phys(m)] = cmul(make_float2(re.x, im.x), g);
+                fb[C::PITCH + phys(m)] = cmul(make_float2(re.y, im.y), g);
+                fb[2 * C::PITCH + phys(m)] = cmul(make_float2(re.z, im.z), g);
+                fb[3 * C::PITCH + phys(m)] = cmul(make_float2(re.w, im.w), g);
+            }
         }
     } else {
         const int fs = tid % FPB, mq = tid / FPB;   // lanes run along t: FPB * 4 B contiguous per row

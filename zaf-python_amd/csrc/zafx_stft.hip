@@ -260,11 +260,9 @@ __global__ __launch_bounds__(kFatWaves * 64) void k_stft_ft16(
                     float2 xk, xn;
                     split_pair(fb[phys(k)], fb[phys(N - k)], tws_l[k], xk, xn);
                     o[(long long)k * T] = xk;
+                    if (!ONE) o[(long long)(W - k) * T] = cconj(xk);
                     o[(long long)(N - k) * T] = xn;
-                    if (!ONE) {
-                        o[(long long)(W - k) * T] = cconj(xk);
-                        o[(long long)(N + k) * T] = cconj(xn);
-                    }
+                    if (!ONE) o[(long long)(N + k) * T] = cconj(xn);
                 }
             }
         }

@@ -470,3 +470,66 @@ def test_onesided_rejected_elsewhere(zafx):
         zafx.Plan(zafx.MDCT, window_length=2048, onesided=True)
     with pytest.raises(ValueError):
         zafx.istft_batch(np.zeros((1, 2048, 4), np.complex64), zafx.hamming(2048), 1024, onesided=True)
+
+
+# ------------------------------------------------------------------ random geometries (seeded) against the oracle
+def _random_cases(seed, count):
+    rng = np.random.default_rng(seed)
+    cases = []
+    for _ in range(count):
+        wl = int(2 ** rng.integers(6, 13))                      # 64 .. 4096
+        hop = int(rng.integers(max(wl // 8, 1), wl + 1))         # ceil(W/H) <= 8 keeps the ISTFT in range
+        n = int(rng.integers(1, 6 * wl))
+        cases.append((wl, hop, n))
+    return cases
+
+
+@pytest.mark.parametrize("wl,hop,n", _random_cases(20260928, 24))
+def test_random_geometry_stft_family(zafx, wl, hop, n):
+    """Frame counts, padding, trims and values for arbitrary (window, hop, length): both layouts, both
+    spectrum kinds, 1-3 clips, inverse included."""
+    b = 1 + (n % 3)
+    x = np.stack([synth_clip(21, c, n) for c in range(b)])
+    w = zafx.hamming(wl)
+    ref = orc.stft_batch(x.astype(np.float64), w, hop)
+    half = wl // 2 + 1
+    for layout in ("FT", "TF"):
+        for one in (False, True):
+            got = zafx.stft_batch(x, w, hop, layout=layout, onesided=one)
+            if layout == "TF":
+                got = got.transpose(0, 2, 1)
+            want = ref[:, :half] if one else ref
+            assert got.shape == want.shape
+            for c in range(b):
+                assert relerr(got[c], want[c]) <= TOL_FFT, (layout, one, c)
+    y = zafx.istft_batch(ref, w, hop)
+    y1 = zafx.istft_batch(ref[:, :half], w, hop, onesided=True)
+    for c in range(b):
+        yref = orc.istft(ref[c], w, hop)
+        assert y[c].shape == yref.shape == y1[c].shape
+        if yref.size:
+            scale = max(np.max(np.abs(yref)), 1e-30)
+            assert np.max(np.abs(y[c] - yref)) / scale <= TOL_FFT and np.max(np.abs(y1[c] - yref)) / scale <= TOL_FFT
+
+
+@pytest.mark.parametrize("wl,n", [(int(2 ** e), int(n)) for e, n in zip(np.random.default_rng(7).integers(6, 14, 12),
+                                                                          np.random.default_rng(8).integers(1, 40000, 12))])
+def test_random_geometry_mdct_family(zafx, wl, n):
+    b = 1 + (n % 3)
+    x = np.stack([synth_clip(22, c, n) for c in range(b)])
+    w = zafx.kaiser_bessel_derived(wl)
+    ref = orc.mdct_batch(x.astype(np.float64), w)
+    for layout in ("FT", "TF"):
+        got = zafx.mdct_batch(x, w, layout=layout)
+        if layout == "TF":
+            got = got.transpose(0, 2, 1)
+        assert got.shape == ref.shape
+        for c in range(b):
+            assert relerr(got[c], ref[c]) <= TOL_FFT, (layout, c)
+        coefs = ref if layout == "FT" else np.ascontiguousarray(ref.transpose(0, 2, 1))
+        y = zafx.imdct_batch(coefs, w, layout=layout)
+        for c in range(b):
+            yref = orc.imdct(ref[c], w)
+            assert y[c].shape == yref.shape
+            if yref.size:
+                assert np.max(np.abs(y[c] - yref)) / max(np.max(np.abs(yref)), 1e-30) <= TOL_FFT, (layout, c)

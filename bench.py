@@ -48,6 +48,8 @@ def make_workload(kind, device, layout="FT"):
         B, N, T = 128, 1323000, 750
     if kind == "dct":
         B, N, T = 16384, 1024, 1
+    if kind == "stft64":
+        B = 128
     base = np.stack([synth(0, c, N) for c in range(distinct)])
     d_base = zafx.DeviceBuffer.from_host(base, device)
     d_x = zafx.DeviceBuffer((B, N), np.float32, device)
@@ -59,6 +61,13 @@ def make_workload(kind, device, layout="FT"):
         plan = zafx.stft_plan(ham, H, layout=layout, device=device)
         wl.update(plan=plan, d_in=d_x, n_in=N, bytes_per_launch=B * (4 * N + 8 * W * T),
                   desc="Batched STFT: 1024 clips x 10 s @ 44.1 kHz, Hamming win=2048 hop=1024, two-sided c64 (W,T) layout")
+    elif kind == "stft64":  # float64 device arithmetic (written for exactness, not speed)
+        d_x64 = zafx.DeviceBuffer.from_host(np.tile(base.astype(np.float64), (B // distinct, 1)), device)
+        d_x.free()
+        d_x = d_x64
+        plan = zafx.stft_plan(ham, H, layout=layout, device=device, f64=True)
+        wl.update(plan=plan, d_in=d_x, n_in=N, bytes_per_launch=B * (8 * N + 16 * W * T),
+                  desc="Batched STFT in float64 / complex128: 128 clips x 10 s, Hamming win=2048 hop=1024, two-sided")
     elif kind == "stft1":   # one-sided output (rows 0..W/2), not the headline
         plan = zafx.stft_plan(ham, H, layout=layout, device=device, onesided=True)
         wl.update(plan=plan, d_in=d_x, n_in=N, bytes_per_launch=B * (4 * N + 8 * (W // 2 + 1) * T),
@@ -233,7 +242,7 @@ def main():
             "metric": "audio Msamples/sec (STFT win=2048 hop=1024)" if args.kind == "stft" else f"audio Msamples/sec ({args.kind})",
             "value": round(value, 1), "unit": "Msamples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(elapsed / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": "f32",
+            "vs_baseline": None, "dtype": "f64" if args.kind == "stft64" else "f32",
             "data": "synthetic white Gaussian noise (default_rng([0,c]).standard_normal, f32); 8 distinct clips replicated on device to 1024 per GPU",
             "config": {"workload": wl["desc"], "clips_per_gpu": B, "samples_per_clip": wl["samples_per_clip"],
                        "parallelism": f"clip-sharded x{world}", "constants_broadcast": bcast, "layout": "FT (reference memory order)" if args.layout == "FT" else "TF (frame-major)"},

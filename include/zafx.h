@@ -31,7 +31,8 @@
  * called zafx_alloc; a plan owns its HIP stream, events, twiddle tables and constants.
  * Threading: a plan is bound to one device and one stream; calls on distinct plans
  * are thread-safe; calls on one plan must be serialised by the caller.
- * All device arrays are float32 / complex64 (interleaved re,im), C-contiguous.
+ * All device arrays are float32 / complex64 (interleaved re,im), C-contiguous -- float64 /
+ * complex128 for plans created with ZAFX_PRECISION_F64.
  */
 #ifndef ZAFX_H
 #define ZAFX_H
@@ -72,6 +73,12 @@ enum zafx_spectrum {      /* STFT output / ISTFT input rows  
                                     X[W-k] = conj X[k], i.e. equals istft of the two-sided spectrum of a real signal */
 };
 
+enum zafx_precision {     /* device arithmetic and array types                          */
+    ZAFX_PRECISION_F32 = 0, /* float32 / complex64 arrays and arithmetic (every kind)                        */
+    ZAFX_PRECISION_F64 = 1  /* ZAFX_STFT / ZAFX_ISTFT only: float64 / complex128 arrays, the window constant is
+                               float64[W]; the reference's own dtype (zaf.py:128, :139), within 1e-12 of it   */
+};
+
 enum zafx_constant {
     ZAFX_CONST_WINDOW = 1,      /* float32[W]                                   (window_function)  */
     ZAFX_CONST_MEL_FB = 2,      /* float32[n_filters * W/2], dense row-major    (FB.toarray())     */
@@ -93,7 +100,8 @@ typedef struct zafx_params {
     int32_t n_bins;            /* CQT / CHROMA                                                  */
     int32_t octave_resolution; /* CHROMA                                                        */
     int32_t spectrum;          /* enum zafx_spectrum (STFT / ISTFT); 0 = reference contract     */
-    int32_t reserved[6];
+    int32_t precision;         /* enum zafx_precision (STFT / ISTFT); 0 = float32               */
+    int32_t reserved[5];
 } zafx_params;
 
 /* ---- library / device ------------------------------------------------------------ */

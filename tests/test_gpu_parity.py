@@ -533,3 +533,56 @@ def test_random_geometry_mdct_family(zafx, wl, n):
             assert y[c].shape == yref.shape
             if yref.size:
                 assert np.max(np.abs(y[c] - yref)) / max(np.max(np.abs(yref)), 1e-30) <= TOL_FFT, (layout, c)
+
+
+# ------------------------------------------------------------------ float64 compute mode
+TOL_F64 = 1e-12
+
+
+@pytest.mark.parametrize("wl,hop,n", [(2048, 1024, 441000), (2048, 512, 30000), (1024, 300, 9001), (64, 32, 1000), (8192, 4096, 50000),
+                                       (256, 77, 1)])
+def test_f64_stft_istft(zafx, wl, hop, n):
+    """ZAFX_PRECISION_F64: float64 / complex128 on the device, every layout and spectrum kind, within 1e-12
+    of the reference arithmetic (the oracle is bit-identical to zaf.py)."""
+    x = np.stack([synth_clip(31, c, n).astype(np.float64) + 1e-9 * c for c in range(2)])   # genuinely float64 inputs
+    w = zafx.hamming(wl)
+    ref = orc.stft_batch(x, w, hop)
+    half = wl // 2 + 1
+    for layout in ("FT", "TF"):
+        for one in (False, True):
+            got = zafx.stft_batch(x, w, hop, layout=layout, onesided=one, f64=True)
+            assert got.dtype == np.complex128
+            if layout == "TF":
+                got = got.transpose(0, 2, 1)
+            want = ref[:, :half] if one else ref
+            assert got.shape == want.shape
+            for c in range(2):
+                assert relerr(got[c], want[c]) <= TOL_F64, (layout, one, c)
+            spec = want if layout == "FT" else np.ascontiguousarray(want.transpose(0, 2, 1))
+            y = zafx.istft_batch(spec, w, hop, layout=layout, onesided=one, f64=True)
+            assert y.dtype == np.float64
+            for c in range(2):
+                yref = orc.istft(ref[c], w, hop)
+                assert y[c].shape == yref.shape
+                if yref.size:
+                    assert np.max(np.abs(y[c] - yref)) / max(np.max(np.abs(yref)), 1e-300) <= TOL_F64, (layout, one, c)
+
+
+def test_f64_dropin_and_golden(zafx, golden):
+    """set_precision("f64") switches the drop-in stft / istft to float64 device arithmetic: the tiny golden
+    vectors of the real reference are met to 1e-12 instead of 1e-5."""
+    g = golden["tiny"]
+    zafx.set_precision("f64")
+    try:
+        for n in (1, 63, 64, 65, 1000):
+            for hop in (32, 16):
+                s = zafx.stft(g[f"x_{n}"], g["ham"], hop)
+                assert s.dtype == np.complex128 and relerr(s, g[f"stft_{n}_{hop}"]) <= TOL_F64
+                y = zafx.istft(g[f"stft_{n}_{hop}"], g["ham"], hop)
+                assert relerr(y, g[f"istft_{n}_{hop}"]) <= TOL_F64
+        y = zafx.istft(g["istft_generic_in"], g["ham"], 32)   # non-Hermitian input: real(ifft(.)) of anything
+        assert relerr(y, g["istft_generic_out"]) <= TOL_F64
+    finally:
+        zafx.set_precision("f32")
+    with pytest.raises(zafx.ZafxError):
+        zafx.Plan(zafx.MDCT, window_length=2048, f64=True)

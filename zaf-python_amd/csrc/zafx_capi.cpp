@@ -163,6 +163,14 @@ static bool is_cqt_family(int kind) { return kind == ZAFX_CQT || kind == ZAFX_CH
 static int finalize_constant(zafx_plan* pl, int which) {
     switch (which) {
         case ZAFX_CONST_WINDOW: {
+            if (pl->prm.precision == ZAFX_PRECISION_F64) {
+                ZAFX_HIP(upload(&pl->d_window64, pl->h_window64.data(), pl->h_window64.size() * sizeof(double)));
+                long double g = 0;   // zaf.py:241  sum(window_function[0:W:H])
+                for (int i = 0; i < pl->W; i += pl->H) g += (long double)pl->h_window64[(size_t)i];
+                pl->cola_gain64 = (double)g;
+                pl->cola_gain = (float)g;
+                return 0;
+            }
             ZAFX_HIP(upload(&pl->d_window, pl->h_window.data(), pl->h_window.size() * sizeof(float)));
             double g = 0;   // zaf.py:241  sum(window_function[0:W:H])
             if (pl->H > 0)
@@ -339,6 +347,9 @@ int zafx_plan_create(zafx_plan** out, int device, int kind, const zafx_params* p
     if (params->spectrum != ZAFX_SPECTRUM_TWO_SIDED && params->spectrum != ZAFX_SPECTRUM_ONE_SIDED) return fail_msg("bad spectrum");
     if (params->spectrum != ZAFX_SPECTRUM_TWO_SIDED && kind != ZAFX_STFT && kind != ZAFX_ISTFT)
         return fail_msg("spectrum applies to ZAFX_STFT / ZAFX_ISTFT only");
+    if (params->precision != ZAFX_PRECISION_F32 && params->precision != ZAFX_PRECISION_F64) return fail_msg("bad precision");
+    if (params->precision == ZAFX_PRECISION_F64 && kind != ZAFX_STFT && kind != ZAFX_ISTFT)
+        return fail_msg("ZAFX_PRECISION_F64 is available for ZAFX_STFT / ZAFX_ISTFT only");
     {
         int n_dev = 0;
         ZAFX_HIP(hipGetDeviceCount(&n_dev));
@@ -416,6 +427,23 @@ int zafx_plan_create(zafx_plan** out, int device, int kind, const zafx_params* p
         e = upload(&pl->d_tw_pass, tw.data(), tw.size() * sizeof(cf32));
     }
     if (e == hipSuccess) e = upload(&pl->d_tw_aux, aux.data(), aux.size() * sizeof(cf32));
+    if (e == hipSuccess && pl->prm.precision == ZAFX_PRECISION_F64) {   // float64 tables, evaluated in long double
+        const int n = pl->W / 2;
+        auto root = [](long long num, long long den) {
+            const long double a = -2.0L * 3.14159265358979323846264338327950288L * (long double)(num % den) / (long double)den;
+            double2 r = make_double2((double)cosl(a), (double)sinl(a));
+            if (num % den == 0) r = make_double2(1.0, 0.0);
+            if (4 * (num % den) == den) r = make_double2(0.0, -1.0);
+            if (2 * (num % den) == den) r = make_double2(-1.0, 0.0);
+            return r;
+        };
+        std::vector<double2> tw((size_t)std::max(n / 2, 1)), tws((size_t)n / 2 + 1);
+        for (int m = 0; m < n / 2; ++m) tw[(size_t)m] = root(m, n);
+        for (int k = 0; k <= n / 2; ++k) tws[(size_t)k] = root(k, pl->W);
+        e = upload(&pl->d_tw64, tw.data(), tw.size() * sizeof(double2));
+        if (e == hipSuccess) e = upload(&pl->d_tws64, tws.data(), tws.size() * sizeof(double2));
+        pl->kernel_name = kind == ZAFX_STFT ? stft_f64_kernel_name() : istft_f64_kernel_name();
+    }
     if (e != hipSuccess) {
         zafx_plan_destroy(pl);
         return fail("zafx_plan_create", e);
@@ -438,6 +466,10 @@ int zafx_plan_destroy(zafx_plan* pl) {
     if (pl->d_values) (void)hipFree(pl->d_values);
     if (pl->d_chunks) (void)hipFree(pl->d_chunks);
     if (pl->d_slots) (void)hipFree(pl->d_slots);
+    if (pl->d_window64) (void)hipFree(pl->d_window64);
+    if (pl->d_tw64) (void)hipFree(pl->d_tw64);
+    if (pl->d_tws64) (void)hipFree(pl->d_tws64);
+    if (pl->d_scratch64) (void)hipFree(pl->d_scratch64);
     if (pl->d_chunk_ptr) (void)hipFree(pl->d_chunk_ptr);
     free_band(pl->fb);
     free_band(pl->dct);
@@ -451,8 +483,12 @@ int zafx_plan_destroy(zafx_plan* pl) {
 static int expected_constant_bytes(const zafx_plan* pl, int which, size_t bytes, size_t* elem) {
     switch (which) {
         case ZAFX_CONST_WINDOW:
-            *elem = sizeof(float);
             if (is_cqt_family(pl->kind) || pl->kind == ZAFX_LINEAR) return fail_msg("this plan kind takes no window");
+            if (pl->prm.precision == ZAFX_PRECISION_F64) {
+                *elem = sizeof(double);
+                return bytes == (size_t)pl->W * sizeof(double) ? 0 : fail_msg("window must hold window_length float64 (ZAFX_PRECISION_F64 plan)");
+            }
+            *elem = sizeof(float);
             return bytes == (size_t)pl->W * sizeof(float) ? 0 : fail_msg("window must hold window_length float32");
         case ZAFX_CONST_MEL_FB:
             *elem = sizeof(float);
@@ -487,7 +523,8 @@ static int expected_constant_bytes(const zafx_plan* pl, int which, size_t bytes,
 static int store_shadow(zafx_plan* pl, int which, const void* host, size_t bytes) {
     switch (which) {
         case ZAFX_CONST_WINDOW:
-            pl->h_window.assign((const float*)host, (const float*)host + bytes / sizeof(float));
+            if (pl->prm.precision == ZAFX_PRECISION_F64) pl->h_window64.assign((const double*)host, (const double*)host + bytes / sizeof(double));
+            else pl->h_window.assign((const float*)host, (const float*)host + bytes / sizeof(float));
             break;
         case ZAFX_CONST_MEL_FB:
             pl->h_fb.assign((const float*)host, (const float*)host + bytes / sizeof(float));
@@ -562,7 +599,7 @@ int zafx_execute(zafx_plan* pl, const void* d_in, void* d_out, int64_t n_clips, 
     int64_t dims[2];
     if (int rc = zafx_plan_out_dims(pl, n_in, dims)) return rc;
     if (pl->kind == ZAFX_LINEAR && !pl->d_matrix) return fail_msg("matrix constant not set");
-    if (!is_cqt_family(pl->kind) && pl->kind != ZAFX_LINEAR && !pl->d_window) return fail_msg("window constant not set");
+    if (!is_cqt_family(pl->kind) && pl->kind != ZAFX_LINEAR && !pl->d_window && !pl->d_window64) return fail_msg("window constant not set");
     if ((pl->kind == ZAFX_MEL || pl->kind == ZAFX_MFCC) && !pl->fb.d_pack) return fail_msg("mel filterbank constant not set");
     if (pl->kind == ZAFX_MFCC && !pl->dct.d_pack) return fail_msg("DCT constant not set");
     if (is_cqt_family(pl->kind)) {
@@ -578,11 +615,13 @@ int zafx_execute(zafx_plan* pl, const void* d_in, void* d_out, int64_t n_clips, 
     hipError_t e = hipSuccess;
     switch (pl->kind) {
         case ZAFX_STFT:
-            e = launch_stft(*pl, (const float*)d_in, (float2*)d_out, n_clips, n_in, (int)dims[1]);
+            if (pl->prm.precision == ZAFX_PRECISION_F64) e = launch_stft_f64(*pl, (const double*)d_in, (double2*)d_out, n_clips, n_in, (int)dims[1]);
+            else e = launch_stft(*pl, (const float*)d_in, (float2*)d_out, n_clips, n_in, (int)dims[1]);
             break;
         case ZAFX_ISTFT:
             if (pl->cola_gain == 0.f) return fail_msg("istft: sum(window[0:W:H]) is zero (zaf.py:241 would divide by zero)");
-            e = launch_istft(*pl, (const float2*)d_in, (float*)d_out, n_clips, (int)n_in, dims[0]);
+            if (pl->prm.precision == ZAFX_PRECISION_F64) e = launch_istft_f64(*pl, (const double2*)d_in, (double*)d_out, n_clips, (int)n_in, dims[0]);
+            else e = launch_istft(*pl, (const float2*)d_in, (float*)d_out, n_clips, (int)n_in, dims[0]);
             break;
         case ZAFX_MDCT:
             e = launch_mdct(*pl, (const float*)d_in, (float*)d_out, n_clips, n_in, (int)dims[1]);
@@ -767,7 +806,10 @@ int zafx_comm_broadcast_constants(zafx_comm* c, zafx_plan* pl, int root) {
         };
         if (c->rank == root) {
             switch (which) {
-                case ZAFX_CONST_WINDOW: span(pl->h_window); break;
+                case ZAFX_CONST_WINDOW:
+                    if (pl->prm.precision == ZAFX_PRECISION_F64) span(pl->h_window64);
+                    else span(pl->h_window);
+                    break;
                 case ZAFX_CONST_MEL_FB: span(pl->h_fb); break;
                 case ZAFX_CONST_DCT: span(pl->h_dct); break;
                 case ZAFX_CONST_MATRIX: span(pl->h_matrix); break;

@@ -1,0 +1,196 @@
+// zafx_f64.hip -- float64 compute mode of the STFT / ISTFT ("bit-closer parity").
+//
+// The reference computes in float64 / complex128 (zaf.py:128, :139, :223).  The tuned kernels of
+// zafx_stft.hip are float32; a plan created with zafx_params.precision = ZAFX_PRECISION_F64 runs the
+// kernels below instead: same framing, padding, spectrum kinds and layouts, double arithmetic
+// throughout, results within 1e-12 of the reference (tests/test_gpu_parity.py).  They are written
+// for exactness, not speed: one workgroup per frame, a radix-2 Stockham FFT of the packed
+// half-length transform in LDS (twiddles from a float64 table the host builds in long double), the
+// ISTFT through a per-call scratch of time-domain frames and a gather overlap-add in the reference's
+// ascending frame order (zaf.py:226-233).
+#include <algorithm>
+
+#include "zafx_internal.hpp"
+
+namespace zafx {
+
+namespace {
+
+__device__ __forceinline__ double2 dadd(double2 a, double2 b) { return make_double2(a.x + b.x, a.y + b.y); }
+__device__ __forceinline__ double2 dsub(double2 a, double2 b) { return make_double2(a.x - b.x, a.y - b.y); }
+__device__ __forceinline__ double2 dmul(double2 a, double2 b) { return make_double2(a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x); }
+__device__ __forceinline__ double2 dmulc(double2 a, double2 b) { return make_double2(a.x * b.x + a.y * b.y, a.y * b.x - a.x * b.y); }
+__device__ __forceinline__ double2 dconj(double2 a) { return make_double2(a.x, -a.y); }
+
+constexpr int kThreads = 256;
+
+// In-place (ping-pong) forward FFT of N = 2^log2n points held in LDS; returns the buffer with the result.
+// tw[m] = exp(-2 pi i m / N), m < N/2.
+__device__ double2* fft_lds(double2* a, double2* b, int log2n, const double2* __restrict__ tw) {
+    const int n = 1 << log2n;
+    for (int s = 0; s < log2n; ++s) {
+        const int ns = 1 << s;
+        for (int j = threadIdx.x; j < n / 2; j += kThreads) {
+            const int k = j & (ns - 1);
+            const double2 u = a[j], v = dmul(a[j + n / 2], tw[k << (log2n - 1 - s)]);
+            const int i0 = ((j - k) << 1) + k;
+            b[i0] = dadd(u, v);
+            b[i0 + ns] = dsub(u, v);
+        }
+        __syncthreads();
+        double2* t = a;
+        a = b;
+        b = t;
+    }
+    return a;
+}
+
+// zaf.py:112-139 for one frame per workgroup
+__global__ __launch_bounds__(kThreads) void k_stft_f64(
+    const double* __restrict__ x, const double* __restrict__ win, const double2* __restrict__ tw, const double2* __restrict__ tws,
+    double2* __restrict__ out, long long n_samples, int hop, int T, int log2n, int layout, int one) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    const int N = 1 << log2n, W = 2 * N, rows = one ? N + 1 : W;
+    double2* a = reinterpret_cast<double2*>(smem_raw);
+    double2* b = a + N;
+    const long long g = blockIdx.x;
+    const long long clip = g / T;
+    const int t = (int)(g - clip * T);
+    const double* xc = x + clip * n_samples;
+    const long long s0 = (long long)t * hop - N;   // floor(W/2) = N samples of left padding
+    for (int n = threadIdx.x; n < N; n += kThreads) {
+        const long long s = s0 + 2 * n;
+        const double u = (s >= 0 && s < n_samples) ? xc[s] * win[2 * n] : 0.0;
+        const double v = (s + 1 >= 0 && s + 1 < n_samples) ? xc[s + 1] * win[2 * n + 1] : 0.0;
+        a[n] = make_double2(u, v);
+    }
+    __syncthreads();
+    const double2* z = fft_lds(a, b, log2n, tw);
+    // real split: X[k] = E + t_k O, X[N-k] = conj(E - t_k O)
+    const long long stride = layout == ZAFX_LAYOUT_FT ? T : 1;
+    double2* o = layout == ZAFX_LAYOUT_FT ? out + clip * rows * T + t : out + (clip * T + t) * rows;
+    for (int k = threadIdx.x; k < N / 2; k += kThreads) {
+        if (k == 0) {
+            const double2 z0 = z[0], zc = z[N / 2];
+            o[0] = make_double2(z0.x + z0.y, 0.0);
+            o[(long long)N * stride] = make_double2(z0.x - z0.y, 0.0);
+            o[(long long)(N / 2) * stride] = dconj(zc);
+            if (!one) o[(long long)(N + N / 2) * stride] = zc;
+        } else {
+            const double2 zk = z[k], zn = z[N - k];
+            const double2 e = make_double2(0.5 * (zk.x + zn.x), 0.5 * (zk.y - zn.y));
+            const double2 d = make_double2(0.5 * (zk.x - zn.x), 0.5 * (zk.y + zn.y));
+            const double2 to = dmul(tws[k], make_double2(d.y, -d.x));
+            const double2 xk = dadd(e, to), xn = dconj(dsub(e, to));
+            o[(long long)k * stride] = xk;
+            o[(long long)(N - k) * stride] = xn;
+            if (!one) {
+                o[(long long)(W - k) * stride] = dconj(xk);
+                o[(long long)(N + k) * stride] = dconj(xn);
+            }
+        }
+    }
+}
+
+// real(ifft(X)) of one frame per workgroup (zaf.py:223), W samples into the scratch, unscaled by 2 W
+__global__ __launch_bounds__(kThreads) void k_ifft_frames_f64(
+    const double2* __restrict__ spec, const double2* __restrict__ tw, const double2* __restrict__ tws, double* __restrict__ frames,
+    int T, int log2n, int layout, int one) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    const int N = 1 << log2n, W = 2 * N, rows = one ? N + 1 : W;
+    double2* a = reinterpret_cast<double2*>(smem_raw);
+    double2* b = a + N;
+    const long long g = blockIdx.x;
+    const long long clip = g / T;
+    const int t = (int)(g - clip * T);
+    const long long stride = layout == ZAFX_LAYOUT_FT ? T : 1;
+    const double2* sp = layout == ZAFX_LAYOUT_FT ? spec + clip * rows * T + t : spec + (clip * T + t) * rows;
+    // packed half-length spectrum of the Hermitian part of X, re/im swapped so that a FORWARD transform inverts
+    for (int k = threadIdx.x; k < N / 2; k += kThreads) {
+        if (k == 0) {
+            const double a0 = 2.0 * sp[0].x, an = 2.0 * sp[(long long)N * stride].x;
+            a[0] = make_double2(a0 - an, a0 + an);
+            const double2 xc = sp[(long long)(N / 2) * stride];
+            const double2 xd = one ? dconj(xc) : sp[(long long)(N + N / 2) * stride];
+            const double2 h = make_double2(xc.x + xd.x, xc.y - xd.y);
+            a[N / 2] = make_double2(-2.0 * h.y, 2.0 * h.x);
+        } else {
+            const double2 xk = sp[(long long)k * stride], xnk = sp[(long long)(N - k) * stride];
+            const double2 xwk = one ? dconj(xk) : sp[(long long)(W - k) * stride];
+            const double2 xnpk = one ? dconj(xnk) : sp[(long long)(N + k) * stride];
+            const double2 ak = make_double2(xk.x + xwk.x, xk.y - xwk.y);       // X[k] + conj X[W-k]
+            const double2 an = make_double2(xnk.x + xnpk.x, xnk.y - xnpk.y);   // X[N-k] + conj X[N+k]
+            const double2 e = make_double2(ak.x + an.x, ak.y - an.y);
+            const double2 d = make_double2(ak.x - an.x, ak.y + an.y);
+            const double2 o = dmulc(d, tws[k]);
+            const double2 zk = make_double2(e.x - o.y, e.y + o.x), zn = make_double2(e.x + o.y, -e.y + o.x);
+            a[k] = make_double2(zk.y, zk.x);
+            a[N - k] = make_double2(zn.y, zn.x);
+        }
+    }
+    __syncthreads();
+    const double2* z = fft_lds(a, b, log2n, tw);
+    double* fr = frames + g * W;
+    for (int n = threadIdx.x; n < N; n += kThreads) {   // components come out swapped
+        fr[2 * n] = z[n].y;
+        fr[2 * n + 1] = z[n].x;
+    }
+}
+
+// overlap-add in ascending frame order (zaf.py:226-233), trim (:236-238), gain (:241)
+__global__ __launch_bounds__(kThreads) void k_ola_f64(const double* __restrict__ frames, double* __restrict__ y, int T, int W, int hop,
+                                                       long long out_len, long long total, double scale) {
+    for (long long i = (long long)blockIdx.x * kThreads + threadIdx.x; i < total; i += (long long)gridDim.x * kThreads) {
+        const long long clip = i / out_len, o = i - clip * out_len;
+        const long long s = o + (W - hop);
+        const long long j_hi = std::min<long long>(T - 1, s / hop);
+        const long long j_lo = s >= W ? (s - W) / hop + 1 : 0;
+        double acc = 0.0;
+        for (long long j = j_lo; j <= j_hi; ++j) acc += frames[(clip * T + j) * W + (s - j * hop)];
+        y[i] = acc * scale;
+    }
+}
+
+}  // namespace
+
+const char* stft_f64_kernel_name() { return "k_stft_f64"; }
+const char* istft_f64_kernel_name() { return "k_ifft_frames_f64"; }
+
+hipError_t launch_stft_f64(const zafx_plan& pl, const double* x, double2* out, int64_t n_clips, int64_t n_samples, int T) {
+    const long long blocks = (long long)n_clips * T;
+    if (blocks <= 0) return hipSuccess;
+    const size_t smem = (size_t)pl.W * sizeof(double2);   // two buffers of W/2 points
+    auto kern = k_stft_f64;
+    if (hipError_t e = ensure_dynamic_lds(reinterpret_cast<const void*>(kern), pl.device, smem); e != hipSuccess) return e;
+    hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(kThreads), smem, pl.stream, x, pl.d_window64, pl.d_tw64, pl.d_tws64, out,
+                       (long long)n_samples, pl.H, T, pl.log2nf, pl.layout, pl.prm.spectrum == ZAFX_SPECTRUM_ONE_SIDED ? 1 : 0);
+    return hipGetLastError();
+}
+
+hipError_t launch_istft_f64(zafx_plan& pl, const double2* spec, double* y, int64_t n_clips, int T, int64_t out_len) {
+    const long long blocks = (long long)n_clips * T;
+    if (blocks <= 0 || out_len <= 0) return hipSuccess;
+    const size_t need = (size_t)blocks * pl.W * sizeof(double);
+    if (need > pl.scratch_bytes) {   // grow-only scratch of time-domain frames, owned by the plan
+        if (hipError_t e = hipStreamSynchronize(pl.stream); e != hipSuccess) return e;
+        if (pl.d_scratch64) (void)hipFree(pl.d_scratch64);
+        pl.d_scratch64 = nullptr;
+        pl.scratch_bytes = 0;
+        if (hipError_t e = hipMalloc((void**)&pl.d_scratch64, need); e != hipSuccess) return e;
+        pl.scratch_bytes = need;
+    }
+    const size_t smem = (size_t)pl.W * sizeof(double2);
+    auto kern = k_ifft_frames_f64;
+    if (hipError_t e = ensure_dynamic_lds(reinterpret_cast<const void*>(kern), pl.device, smem); e != hipSuccess) return e;
+    hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(kThreads), smem, pl.stream, spec, pl.d_tw64, pl.d_tws64, pl.d_scratch64, T,
+                       pl.log2nf, pl.layout, pl.prm.spectrum == ZAFX_SPECTRUM_ONE_SIDED ? 1 : 0);
+    if (hipError_t e = hipGetLastError(); e != hipSuccess) return e;
+    const long long total = (long long)n_clips * out_len;
+    const long long grid = std::min<long long>((total + kThreads - 1) / kThreads, (long long)pl.n_cus * 32);
+    const double scale = 1.0 / (2.0 * (double)pl.W * pl.cola_gain64);   // 1/W of the inverse DFT x the factor 2 left by the fold
+    hipLaunchKernelGGL(k_ola_f64, dim3((unsigned)grid), dim3(kThreads), 0, pl.stream, pl.d_scratch64, y, T, pl.W, pl.H, (long long)out_len,
+                       total, scale);
+    return hipGetLastError();
+}
+
+}  // namespace zafx

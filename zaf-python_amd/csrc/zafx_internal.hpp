@@ -60,6 +60,14 @@ struct zafx_plan {
     int4* d_chunks = nullptr;      // CQT rows cut into <= 64-entry chunks {row, first entry, count, last-of-row}
     int* d_chunk_ptr = nullptr;    // [waves + 1] ranges of d_chunks per wavefront
     int n_chunks = 0;
+    // float64 mode (ZAFX_PRECISION_F64, zafx_f64.hip)
+    double* d_window64 = nullptr;
+    double2* d_tw64 = nullptr;     // exp(-2 pi i m / (W/2)), m < W/4
+    double2* d_tws64 = nullptr;    // exp(-2 pi i k / W), k <= W/4
+    double* d_scratch64 = nullptr; // ISTFT: time-domain frames of the current call (grow-only)
+    size_t scratch_bytes = 0;
+    double cola_gain64 = 0.0;
+    std::vector<double> h_window64;
     int* d_slots = nullptr;        // per non-zero: LDS slot of its column in k_cqt's one-sided spectrum (bit 31 = conjugate)
     int cqt_k_lo = 0, cqt_k_hi = -1, cqt_k_special = 0;   // real-split pairs the kernel's columns need
     bool cqt_dirty = true;
@@ -77,6 +85,10 @@ namespace zafx {
 // Every launcher enqueues on plan.stream and returns hipGetLastError().
 hipError_t launch_stft(const zafx_plan& pl, const float* x, float2* out, int64_t n_clips, int64_t n_samples, int T);
 hipError_t launch_istft(const zafx_plan& pl, const float2* spec, float* y, int64_t n_clips, int T, int64_t out_len);
+hipError_t launch_stft_f64(const zafx_plan& pl, const double* x, double2* out, int64_t n_clips, int64_t n_samples, int T);
+hipError_t launch_istft_f64(zafx_plan& pl, const double2* spec, double* y, int64_t n_clips, int T, int64_t out_len);
+const char* stft_f64_kernel_name();
+const char* istft_f64_kernel_name();
 hipError_t launch_mdct(const zafx_plan& pl, const float* x, float* out, int64_t n_clips, int64_t n_samples, int T);
 hipError_t launch_imdct(const zafx_plan& pl, const float* coefs, float* y, int64_t n_clips, int T, int64_t out_len);
 hipError_t launch_mel(const zafx_plan& pl, const float* x, float* out, int64_t n_clips, int64_t n_samples, int T);

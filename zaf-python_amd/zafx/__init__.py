@@ -18,7 +18,7 @@ from .core import (Comm, DeviceBuffer, Plan, clear_plan_cache, cqt_plan, cqtchro
                    dst_batch, linear_plan,
                    cqtspectrogram, cqtspectrogram_batch, imdct, imdct_batch, istft, istft_batch, istft_plan, mdct,
                    mdct_batch, mdct_plan, mel_plan, melspectrogram, melspectrogram_batch, mfcc, mfcc_batch, pcm_to_mono,
-                   stft, stft_batch, stft_pcm_batch, stft_plan)
+                   get_precision, set_precision, stft, stft_batch, stft_pcm_batch, stft_plan)
 from .shard import clip_range, run_sharded, shard_sizes
 
 __version__ = "0.1.0"

@@ -14,6 +14,8 @@ STFT, ISTFT, MDCT, IMDCT, MEL, MFCC, CQT, CHROMA, LINEAR = 1, 2, 3, 4, 5, 6, 7, 
 LAYOUT_FT, LAYOUT_TF = 0, 1
 # enum zafx_spectrum
 SPECTRUM_TWO_SIDED, SPECTRUM_ONE_SIDED = 0, 1
+# enum zafx_precision
+PRECISION_F32, PRECISION_F64 = 0, 1
 # enum zafx_constant
 CONST_WINDOW, CONST_MEL_FB, CONST_DCT, CONST_CQT_INDPTR, CONST_CQT_INDICES, CONST_CQT_VALUES, CONST_MATRIX = 1, 2, 3, 4, 5, 6, 7
 
@@ -30,7 +32,8 @@ class ZafxParams(ctypes.Structure):
         ("n_bins", ctypes.c_int32),
         ("octave_resolution", ctypes.c_int32),
         ("spectrum", ctypes.c_int32),
-        ("reserved", ctypes.c_int32 * 6),
+        ("precision", ctypes.c_int32),
+        ("reserved", ctypes.c_int32 * 5),
     ]
 
 

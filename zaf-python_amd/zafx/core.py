@@ -94,7 +94,7 @@ class Plan:
     _FORWARD = (_lib.STFT, _lib.MDCT, _lib.MEL, _lib.MFCC, _lib.CQT, _lib.CHROMA)   # 2-D (frequency x time) outputs
 
     def __init__(self, kind, device=0, window_length=0, step_length=0, layout="FT", n_filters=0, n_coefs=0,
-                 fft_length=0, n_bins=0, octave_resolution=0, onesided=False):
+                 fft_length=0, n_bins=0, octave_resolution=0, onesided=False, f64=False):
         self.kind = kind
         self.device = int(device)
         self.layout = _LAYOUTS[layout]
@@ -109,6 +109,8 @@ class Plan:
         prm.n_bins = int(n_bins)
         prm.octave_resolution = int(octave_resolution)
         prm.spectrum = _lib.SPECTRUM_ONE_SIDED if onesided else _lib.SPECTRUM_TWO_SIDED
+        prm.precision = _lib.PRECISION_F64 if f64 else _lib.PRECISION_F32
+        self.f64 = bool(f64)
         self.params = prm
         h = ctypes.c_void_p()
         _lib.check(_lib.load().zafx_plan_create(ctypes.byref(h), self.device, kind, ctypes.byref(prm)), "zafx_plan_create")
@@ -121,7 +123,7 @@ class Plan:
         _lib.check(_lib.load().zafx_plan_set_constant(self.handle, which, _ptr(array), array.nbytes), "zafx_plan_set_constant")
 
     def set_window(self, window_function):
-        self._set(_lib.CONST_WINDOW, window_function, np.float32)
+        self._set(_lib.CONST_WINDOW, window_function, np.float64 if self.f64 else np.float32)
 
     def set_mel_filterbank(self, mel_filterbank):
         dense = mel_filterbank.toarray() if hasattr(mel_filterbank, "toarray") else np.asarray(mel_filterbank)
@@ -154,7 +156,15 @@ class Plan:
 
     @property
     def out_dtype(self):
+        if self.f64:
+            return np.dtype(np.complex128) if self.kind == _lib.STFT else np.dtype(np.float64)
         return np.dtype(np.complex64) if self.kind == _lib.STFT else np.dtype(np.float32)
+
+    @property
+    def in_dtype(self):
+        if self.kind == _lib.ISTFT:
+            return np.dtype(np.complex128) if self.f64 else np.dtype(np.complex64)
+        return np.dtype(np.float64) if self.f64 else np.dtype(np.float32)
 
     def execute(self, d_in, d_out, n_clips, n_in):
         """Enqueue on the plan's stream (asynchronous); d_in / d_out are DeviceBuffers."""
@@ -184,7 +194,7 @@ class Plan:
 
     def run_host(self, array, n_in):
         """Host array in -> device transform -> host array out (PCIe both ways)."""
-        array = np.ascontiguousarray(array)
+        array = np.ascontiguousarray(array, dtype=self.in_dtype if self.f64 else None)
         n_clips = array.shape[0]
         shape = self.out_shape(n_clips, n_in)
         d_in = DeviceBuffer.from_host(array, self.device)
@@ -295,46 +305,62 @@ def _as_step(step_length):
     return int(step_length)
 
 
-def _as_clips(audio, ndim_name="audio_signal"):
+def _as_clips(audio, ndim_name="audio_signal", dtype=np.float32):
     a = np.asarray(audio)
     if a.ndim != 2:
         raise ValueError(f"{ndim_name} batch must be 2-D (clips, samples)")
     if np.iscomplexobj(a):
         raise ValueError(f"{ndim_name} must be real")
-    return np.ascontiguousarray(a, dtype=np.float32)
+    return np.ascontiguousarray(a, dtype=dtype)
 
 
-def _as_signal(audio_signal):
+def _as_signal(audio_signal, dtype=np.float32):
     a = np.asarray(audio_signal)
     if a.ndim != 1:
         raise ValueError("audio_signal must be 1-D (one clip); use the *_batch functions for (clips, samples)")
-    return _as_clips(a[None, :])
+    return _as_clips(a[None, :], dtype=dtype)
+
+
+# Arithmetic of the drop-in zaf.stft / zaf.istft: "f32" (default, the tuned kernels) or "f64" (the
+# reference's own dtype on the device, within 1e-12 of zaf.py).
+_PRECISION = {"value": "f32"}
+
+
+def set_precision(precision):
+    """Select the device arithmetic of the drop-in `stft` / `istft`: "f32" or "f64"."""
+    if precision not in ("f32", "f64"):
+        raise ValueError('precision must be "f32" or "f64"')
+    _PRECISION["value"] = precision
+
+
+def get_precision():
+    return _PRECISION["value"]
 
 
 # ======================================================================================
 # plan factories
 # ======================================================================================
-def stft_plan(window_function, step_length, layout="FT", device=0, onesided=False):
+def stft_plan(window_function, step_length, layout="FT", device=0, onesided=False, f64=False):
     w, h = _as_window(window_function), _as_step(step_length)
     if h > len(w):
         raise ValueError("step_length must not exceed window_length")
-    key = ("stft", device, len(w), h, _LAYOUTS[layout], bool(onesided), _digest(w))
+    key = ("stft", device, len(w), h, _LAYOUTS[layout], bool(onesided), bool(f64), _digest(w))
 
     def make():
-        p = Plan(_lib.STFT, device, window_length=len(w), step_length=h, layout=layout, onesided=onesided)
+        p = Plan(_lib.STFT, device, window_length=len(w), step_length=h, layout=layout, onesided=onesided, f64=f64)
         p.set_window(w)
         return p
     return _cached(key, make)
 
 
-def istft_plan(window_function, step_length, layout="FT", device=0, onesided=False):
+def istft_plan(window_function, step_length, layout="FT", device=0, onesided=False, f64=False):
     w, h = _as_window(window_function), _as_step(step_length)
     if h > len(w):
         raise ValueError("step_length must not exceed window_length")
-    key = ("istft", device, len(w), h, _LAYOUTS[layout], bool(onesided), _digest(w))
+    key = ("istft", device, len(w), h, _LAYOUTS[layout], bool(onesided), bool(f64), _digest(w))
 
     def make():
-        p = Plan(_lib.ISTFT, device, window_length=len(w), step_length=h, layout=layout, onesided=onesided)
+        p = Plan(_lib.ISTFT, device, window_length=len(w), step_length=h, layout=layout, onesided=onesided, f64=f64)
         p.set_window(w)
         return p
     return _cached(key, make)
@@ -419,28 +445,28 @@ def linear_plan(matrix, device=0):
 # ======================================================================================
 # batched API (build-defined extension): (clips, samples) float32 in, float32/complex64 out
 # ======================================================================================
-def stft_batch(clips, window_function, step_length, layout="FT", device=0, onesided=False):
+def stft_batch(clips, window_function, step_length, layout="FT", device=0, onesided=False, f64=False):
     """(B, N) -> (B, W, T) complex64 [layout "FT"] or (B, T, W) ["TF"].
 
     onesided=True keeps rows 0..W/2 only -- what every example of the reference slices out of the
     result (zaf.py:83) -- and halves the bytes written."""
-    x = _as_clips(clips)
-    return stft_plan(window_function, step_length, layout, device, onesided).run_host(x, x.shape[1])
+    x = _as_clips(clips, dtype=np.float64 if f64 else np.float32)
+    return stft_plan(window_function, step_length, layout, device, onesided, f64).run_host(x, x.shape[1])
 
 
-def istft_batch(spectra, window_function, step_length, layout="FT", device=0, onesided=False):
+def istft_batch(spectra, window_function, step_length, layout="FT", device=0, onesided=False, f64=False):
     """(B, W, T) ["FT"] or (B, T, W) ["TF"] complex -> (B, T*H - (W-H)) float32.
 
     onesided=True takes rows 0..W/2 and completes X[W-k] = conj X[k]: the result equals the two-sided
     call on the spectrum of a real signal."""
-    s = np.ascontiguousarray(spectra, dtype=np.complex64)
+    s = np.ascontiguousarray(spectra, dtype=np.complex128 if f64 else np.complex64)
     w = _as_window(window_function)
     if s.ndim != 3:
         raise ValueError("spectra must be 3-D")
     wl, nt = (s.shape[1], s.shape[2]) if _LAYOUTS[layout] == _lib.LAYOUT_FT else (s.shape[2], s.shape[1])
     if wl != (len(w) // 2 + 1 if onesided else len(w)):
         raise ValueError("spectrum rows must equal window_length (window_length/2 + 1 when onesided)")
-    return istft_plan(w, step_length, layout, device, onesided).run_host(s, nt)
+    return istft_plan(w, step_length, layout, device, onesided, f64).run_host(s, nt)
 
 
 def mdct_batch(clips, window_function, layout="FT", device=0):
@@ -570,8 +596,9 @@ def dst(audio_signal, dst_type):
 # ======================================================================================
 def stft(audio_signal, window_function, step_length):
     """Drop-in for zaf.stft (zaf.py:45): (N,) -> (W, T) complex128, two-sided."""
-    x = _as_signal(audio_signal)
-    return stft_batch(x, window_function, step_length)[0].astype(np.complex128)
+    f64 = _PRECISION["value"] == "f64"
+    x = _as_signal(audio_signal, np.float64 if f64 else np.float32)
+    return stft_batch(x, window_function, step_length, f64=f64)[0].astype(np.complex128)
 
 
 def istft(audio_stft, window_function, step_length):
@@ -579,7 +606,7 @@ def istft(audio_stft, window_function, step_length):
     s = np.asarray(audio_stft)
     if s.ndim != 2:
         raise ValueError("audio_stft must be 2-D (window_length, number_times)")
-    return istft_batch(s[None], window_function, step_length)[0].astype(np.float64)
+    return istft_batch(s[None], window_function, step_length, f64=_PRECISION["value"] == "f64")[0].astype(np.float64)
 
 
 def melspectrogram(audio_signal, window_function, step_length, mel_filterbank):

@@ -69,8 +69,11 @@ enum zafx_layout {
 
 enum zafx_spectrum {      /* STFT output / ISTFT input rows                             */
     ZAFX_SPECTRUM_TWO_SIDED = 0, /* W rows, as np.fft.fft returns them (zaf.py:139) -- the reference contract  */
-    ZAFX_SPECTRUM_ONE_SIDED = 1  /* rows 0..W/2 only (what every example keeps, zaf.py:83); the ISTFT completes
+    ZAFX_SPECTRUM_ONE_SIDED = 1, /* rows 0..W/2 only (what every example keeps, zaf.py:83); the ISTFT completes
                                     X[W-k] = conj X[k], i.e. equals istft of the two-sided spectrum of a real signal */
+    ZAFX_SPECTRUM_MAGNITUDE = 2, /* STFT only: |X[k]|, k = 0..W/2, real (float32 / float64) -- the spectrogram the
+                                    examples compute, np.absolute(audio_stft[0:W/2+1]) (zaf.py:83)                   */
+    ZAFX_SPECTRUM_POWER = 3      /* STFT only: |X[k]|^2, k = 0..W/2, real                                          */
 };
 
 enum zafx_precision {     /* device arithmetic and array types                          */

@@ -586,3 +586,24 @@ def test_f64_dropin_and_golden(zafx, golden):
         zafx.set_precision("f32")
     with pytest.raises(zafx.ZafxError):
         zafx.Plan(zafx.MDCT, window_length=2048, f64=True)
+
+
+@pytest.mark.parametrize("wl,hop,n", [(2048, 1024, 100000), (1024, 256, 9001), (128, 64, 777), (4096, 1024, 30000)])
+def test_magnitude_and_power_spectra(zafx, wl, hop, n):
+    """onesided="magnitude" / "power": the spectrogram of the reference's examples,
+    np.absolute(audio_stft[0:W/2+1, :]) (zaf.py:83), and its square, as real arrays; both layouts, f32 and f64."""
+    x = np.stack([synth_clip(41, c, n) for c in range(2)])
+    w = zafx.hamming(wl)
+    ref = np.abs(orc.stft_batch(x.astype(np.float64), w, hop)[:, : wl // 2 + 1])
+    for f64, tol in ((False, TOL_FFT), (True, 1e-12)):
+        for layout in ("FT", "TF"):
+            for kind, want in (("magnitude", ref), ("power", ref ** 2)):
+                got = zafx.stft_batch(x, w, hop, layout=layout, onesided=kind, f64=f64)
+                assert got.dtype == (np.float64 if f64 else np.float32)
+                if layout == "TF":
+                    got = got.transpose(0, 2, 1)
+                assert got.shape == want.shape
+                for c in range(2):
+                    assert relerr(got[c], want[c]) <= (2 * tol if kind == "power" else tol), (f64, layout, kind, c)
+    with pytest.raises(ValueError):
+        zafx.istft_batch(np.zeros((1, wl // 2 + 1, 4), np.complex64), w, hop, onesided="magnitude")

@@ -344,9 +344,11 @@ int zafx_plan_create(zafx_plan** out, int device, int kind, const zafx_params* p
     if (!out || !params) return fail_msg("null argument");
     if (params->struct_size != (int32_t)sizeof(zafx_params)) return fail_msg("zafx_params.struct_size mismatch");
     if (params->layout != ZAFX_LAYOUT_FT && params->layout != ZAFX_LAYOUT_TF) return fail_msg("bad layout");
-    if (params->spectrum != ZAFX_SPECTRUM_TWO_SIDED && params->spectrum != ZAFX_SPECTRUM_ONE_SIDED) return fail_msg("bad spectrum");
+    if (params->spectrum < ZAFX_SPECTRUM_TWO_SIDED || params->spectrum > ZAFX_SPECTRUM_POWER) return fail_msg("bad spectrum");
     if (params->spectrum != ZAFX_SPECTRUM_TWO_SIDED && kind != ZAFX_STFT && kind != ZAFX_ISTFT)
         return fail_msg("spectrum applies to ZAFX_STFT / ZAFX_ISTFT only");
+    if (params->spectrum >= ZAFX_SPECTRUM_MAGNITUDE && kind != ZAFX_STFT)
+        return fail_msg("magnitude / power spectra are outputs of ZAFX_STFT only");
     if (params->precision != ZAFX_PRECISION_F32 && params->precision != ZAFX_PRECISION_F64) return fail_msg("bad precision");
     if (params->precision == ZAFX_PRECISION_F64 && kind != ZAFX_STFT && kind != ZAFX_ISTFT)
         return fail_msg("ZAFX_PRECISION_F64 is available for ZAFX_STFT / ZAFX_ISTFT only");
@@ -574,7 +576,7 @@ int zafx_plan_out_dims(const zafx_plan* pl, int64_t n_in, int64_t dims[2]) {
     const int64_t w = pl->W, h = pl->H;
     switch (pl->kind) {
         case ZAFX_STFT:
-            dims[0] = pl->prm.spectrum == ZAFX_SPECTRUM_ONE_SIDED ? w / 2 + 1 : w;
+            dims[0] = pl->prm.spectrum != ZAFX_SPECTRUM_TWO_SIDED ? w / 2 + 1 : w;
             dims[1] = stft_frames(n_in, pl->W, pl->H);
             return 0;
         case ZAFX_MEL: dims[0] = pl->prm.n_filters; dims[1] = stft_frames(n_in, pl->W, pl->H); return 0;

@@ -48,9 +48,10 @@ __device__ double2* fft_lds(double2* a, double2* b, int log2n, const double2* __
 // zaf.py:112-139 for one frame per workgroup
 __global__ __launch_bounds__(kThreads) void k_stft_f64(
     const double* __restrict__ x, const double* __restrict__ win, const double2* __restrict__ tw, const double2* __restrict__ tws,
-    double2* __restrict__ out, long long n_samples, int hop, int T, int log2n, int layout, int one) {
+    double2* __restrict__ out, long long n_samples, int hop, int T, int log2n, int layout, int spec) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-    const int N = 1 << log2n, W = 2 * N, rows = one ? N + 1 : W;
+    const int N = 1 << log2n, W = 2 * N, rows = spec ? N + 1 : W;
+    const bool one = spec != 0;
     double2* a = reinterpret_cast<double2*>(smem_raw);
     double2* b = a + N;
     const long long g = blockIdx.x;
@@ -68,25 +69,33 @@ __global__ __launch_bounds__(kThreads) void k_stft_f64(
     const double2* z = fft_lds(a, b, log2n, tw);
     // real split: X[k] = E + t_k O, X[N-k] = conj(E - t_k O)
     const long long stride = layout == ZAFX_LAYOUT_FT ? T : 1;
-    double2* o = layout == ZAFX_LAYOUT_FT ? out + clip * rows * T + t : out + (clip * T + t) * rows;
+    const long long base = layout == ZAFX_LAYOUT_FT ? clip * rows * T + t : (clip * T + t) * rows;
+    auto put = [&](long long row, double2 v) {   // complex, |X| or |X|^2 by spectrum kind
+        if (spec >= ZAFX_SPECTRUM_MAGNITUDE) {
+            const double pw = v.x * v.x + v.y * v.y;
+            reinterpret_cast<double*>(out)[base + row * stride] = spec == ZAFX_SPECTRUM_MAGNITUDE ? sqrt(pw) : pw;
+        } else {
+            out[base + row * stride] = v;
+        }
+    };
     for (int k = threadIdx.x; k < N / 2; k += kThreads) {
         if (k == 0) {
             const double2 z0 = z[0], zc = z[N / 2];
-            o[0] = make_double2(z0.x + z0.y, 0.0);
-            o[(long long)N * stride] = make_double2(z0.x - z0.y, 0.0);
-            o[(long long)(N / 2) * stride] = dconj(zc);
-            if (!one) o[(long long)(N + N / 2) * stride] = zc;
+            put(0, make_double2(z0.x + z0.y, 0.0));
+            put(N, make_double2(z0.x - z0.y, 0.0));
+            put(N / 2, dconj(zc));
+            if (!one) put(N + N / 2, zc);
         } else {
             const double2 zk = z[k], zn = z[N - k];
             const double2 e = make_double2(0.5 * (zk.x + zn.x), 0.5 * (zk.y - zn.y));
             const double2 d = make_double2(0.5 * (zk.x - zn.x), 0.5 * (zk.y + zn.y));
             const double2 to = dmul(tws[k], make_double2(d.y, -d.x));
             const double2 xk = dadd(e, to), xn = dconj(dsub(e, to));
-            o[(long long)k * stride] = xk;
-            o[(long long)(N - k) * stride] = xn;
+            put(k, xk);
+            put(N - k, xn);
             if (!one) {
-                o[(long long)(W - k) * stride] = dconj(xk);
-                o[(long long)(N + k) * stride] = dconj(xn);
+                put(W - k, dconj(xk));
+                put(N + k, dconj(xn));
             }
         }
     }
@@ -163,7 +172,7 @@ hipError_t launch_stft_f64(const zafx_plan& pl, const double* x, double2* out, i
     auto kern = k_stft_f64;
     if (hipError_t e = ensure_dynamic_lds(reinterpret_cast<const void*>(kern), pl.device, smem); e != hipSuccess) return e;
     hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(kThreads), smem, pl.stream, x, pl.d_window64, pl.d_tw64, pl.d_tws64, out,
-                       (long long)n_samples, pl.H, T, pl.log2nf, pl.layout, pl.prm.spectrum == ZAFX_SPECTRUM_ONE_SIDED ? 1 : 0);
+                       (long long)n_samples, pl.H, T, pl.log2nf, pl.layout, pl.prm.spectrum);
     return hipGetLastError();
 }
 

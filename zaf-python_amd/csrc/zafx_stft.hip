@@ -34,6 +34,25 @@ __device__ __forceinline__ void split_pair(float2 zk, float2 zn, float2 t, float
     xn = cconj(csub(e, to));
 }
 
+// Output rows of the forward kernels by spectrum kind SPEC (enum zafx_spectrum): 0 two-sided complex,
+// 1 one-sided complex, 2 one-sided |X| and 3 one-sided |X|^2 as float32 (what the examples of the reference
+// compute from the result, zaf.py:83).  `spec_base` offsets the output in ELEMENTS of the kind; `put_bin`
+// stores element idx relative to it.
+template <int SPEC>
+__device__ __forceinline__ float2* spec_base(float2* out, long long off) {
+    if constexpr (SPEC >= 2) return reinterpret_cast<float2*>(reinterpret_cast<float*>(out) + off);
+    else return out + off;
+}
+template <int SPEC>
+__device__ __forceinline__ void put_bin(float2* o, long long idx, float2 v) {
+    if constexpr (SPEC >= 2) {
+        const float pw = v.x * v.x + v.y * v.y;
+        reinterpret_cast<float*>(o)[idx] = SPEC == 2 ? __builtin_amdgcn_sqrtf(pw) : pw;
+    } else {
+        o[idx] = v;
+    }
+}
+
 template <int LOG2N, int LOG2E, int FPB>
 struct StftCfg {
     using C = FftCfg<LOG2N, LOG2E>;
@@ -45,14 +64,14 @@ struct StftCfg {
 // ---------------------------------------------------------------------------------
 // forward
 // ---------------------------------------------------------------------------------
-// ONE = one-sided output (ZAFX_SPECTRUM_ONE_SIDED): rows 0..W/2 only, the mirror is not written.
-template <int LOG2N, int LOG2E, int FPB, int LAYOUT, bool ONE>
+// SPEC = enum zafx_spectrum: 0 two-sided; 1..3 one-sided (rows 0..W/2 only, the mirror is not written).
+template <int LOG2N, int LOG2E, int FPB, int LAYOUT, int SPEC>
 __global__ __launch_bounds__(FPB * fft_threads(LOG2N, LOG2E)) void k_stft(
     const float* __restrict__ x, const float* __restrict__ win, const float2* __restrict__ twp,
     const float2* __restrict__ tws, float2* __restrict__ out, long long n_samples, int hop, int T, int tiles) {
     using C = FftCfg<LOG2N, LOG2E>;
     using S = StftCfg<LOG2N, LOG2E, FPB>;
-    constexpr int N = C::N, P = C::P, E = C::E, W = 2 * N, NT = S::NT, ROWS = ONE ? N + 1 : W;
+    constexpr int N = C::N, P = C::P, E = C::E, W = 2 * N, NT = S::NT, ROWS = SPEC ? N + 1 : W;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     float2* frames = reinterpret_cast<float2*>(smem_raw);
     const float2* tw = twp;
@@ -89,24 +108,24 @@ __global__ __launch_bounds__(FPB * fft_threads(LOG2N, LOG2E)) void k_stft(
 
     if constexpr (LAYOUT == ZAFX_LAYOUT_TF) {
         if (t >= T) return;
-        float2* o = out + ((long long)clip * T + t) * ROWS;
+        float2* o = spec_base<SPEC>(out, ((long long)clip * T + t) * ROWS);
 #pragma unroll
         for (int i = 0; i < E / 2; ++i) {
             const int k = p + i * P;
             if (k == 0) {
                 const float2 z0 = buf[0], zc = buf[phys(N / 2)];
-                o[0] = make_float2(z0.x + z0.y, 0.f);
-                o[N] = make_float2(z0.x - z0.y, 0.f);
-                o[N / 2] = cconj(zc);
-                if (!ONE) o[N + N / 2] = zc;
+                put_bin<SPEC>(o, 0, make_float2(z0.x + z0.y, 0.f));
+                put_bin<SPEC>(o, N, make_float2(z0.x - z0.y, 0.f));
+                put_bin<SPEC>(o, N / 2, cconj(zc));
+                if (SPEC == 0) put_bin<SPEC>(o, N + N / 2, zc);
             } else {
                 float2 xk, xn;
                 split_pair(buf[phys(k)], buf[phys(N - k)], tws[k], xk, xn);
-                o[k] = xk;
-                o[N - k] = xn;
-                if (!ONE) {
-                    o[W - k] = cconj(xk);
-                    o[N + k] = cconj(xn);
+                put_bin<SPEC>(o, k, xk);
+                put_bin<SPEC>(o, N - k, xn);
+                if (SPEC == 0) {
+                    put_bin<SPEC>(o, W - k, cconj(xk));
+                    put_bin<SPEC>(o, N + k, cconj(xn));
                 }
             }
         }
@@ -115,22 +134,22 @@ __global__ __launch_bounds__(FPB * fft_threads(LOG2N, LOG2E)) void k_stft(
         const int tt = tid % FPB, kq = tid / FPB;
         if (t0 + tt >= T) return;
         const float2* fb = frames + tt * C::PITCH;
-        float2* o = out + (long long)clip * ROWS * T + (t0 + tt);
+        float2* o = spec_base<SPEC>(out, (long long)clip * ROWS * T + (t0 + tt));
         for (int k = kq; k < N / 2; k += P) {
             if (k == 0) {
                 const float2 z0 = fb[0], zc = fb[phys(N / 2)];
-                o[0] = make_float2(z0.x + z0.y, 0.f);
-                o[(long long)N * T] = make_float2(z0.x - z0.y, 0.f);
-                o[(long long)(N / 2) * T] = cconj(zc);
-                if (!ONE) o[(long long)(N + N / 2) * T] = zc;
+                put_bin<SPEC>(o, 0, make_float2(z0.x + z0.y, 0.f));
+                put_bin<SPEC>(o, (long long)N * T, make_float2(z0.x - z0.y, 0.f));
+                put_bin<SPEC>(o, (long long)(N / 2) * T, cconj(zc));
+                if (SPEC == 0) put_bin<SPEC>(o, (long long)(N + N / 2) * T, zc);
             } else {
                 float2 xk, xn;
                 split_pair(fb[phys(k)], fb[phys(N - k)], tws[k], xk, xn);
-                o[(long long)k * T] = xk;
-                o[(long long)(N - k) * T] = xn;
-                if (!ONE) {
-                    o[(long long)(W - k) * T] = cconj(xk);
-                    o[(long long)(N + k) * T] = cconj(xn);
+                put_bin<SPEC>(o, (long long)k * T, xk);
+                put_bin<SPEC>(o, (long long)(N - k) * T, xn);
+                if (SPEC == 0) {
+                    put_bin<SPEC>(o, (long long)(W - k) * T, cconj(xk));
+                    put_bin<SPEC>(o, (long long)(N + k) * T, cconj(xn));
                 }
             }
         }
@@ -167,7 +186,7 @@ struct FatCfg {
     static constexpr size_t SMEM = (size_t)(kFatFrames * PITCH + C::TW + N + N / 2 + 1) * 8;
 };
 
-template <int LOG2N, int LOG2E, bool ALIGNED, bool ONE>
+template <int LOG2N, int LOG2E, bool ALIGNED, int SPEC>
 __global__ __launch_bounds__(kFatWaves * 64) void k_stft_ft16(
     const float* __restrict__ x, const float* __restrict__ win, const float2* __restrict__ twp,
     const float2* __restrict__ tws, float2* __restrict__ out, long long n_samples, int hop, int T, int tiles,
@@ -175,7 +194,7 @@ __global__ __launch_bounds__(kFatWaves * 64) void k_stft_ft16(
     using C = FftCfg<LOG2N, LOG2E>;
     using F = FatCfg<LOG2N, LOG2E>;
     constexpr int N = C::N, P = C::P, E = C::E, W = 2 * N, NT = F::NT, FPB = kFatFrames, FPW = F::FPW, PITCH = F::PITCH;
-    constexpr int ROWS = ONE ? N + 1 : W;
+    constexpr int ROWS = SPEC ? N + 1 : W;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     float2* frames = reinterpret_cast<float2*>(smem_raw);
     float2* tw_l = frames + FPB * PITCH;
@@ -248,21 +267,21 @@ __global__ __launch_bounds__(kFatWaves * 64) void k_stft_ft16(
         prefetch(tl + gridDim.x);   // in flight while this tile is stored
         PROF_MARK(3);
         if (t0 + tt < T) {
-            float2* o = out + (long long)clip * ROWS * T + (t0 + tt);
+            float2* o = spec_base<SPEC>(out, (long long)clip * ROWS * T + (t0 + tt));
             for (int k = kq; k < N / 2; k += NT / FPB) {
                 if (k == 0) {
                     const float2 z0 = fb[0], zc = fb[phys(N / 2)];
-                    o[0] = make_float2(z0.x + z0.y, 0.f);
-                    o[(long long)N * T] = make_float2(z0.x - z0.y, 0.f);
-                    o[(long long)(N / 2) * T] = cconj(zc);
-                    if (!ONE) o[(long long)(N + N / 2) * T] = zc;
+                    put_bin<SPEC>(o, 0, make_float2(z0.x + z0.y, 0.f));
+                    put_bin<SPEC>(o, (long long)N * T, make_float2(z0.x - z0.y, 0.f));
+                    put_bin<SPEC>(o, (long long)(N / 2) * T, cconj(zc));
+                    if (SPEC == 0) put_bin<SPEC>(o, (long long)(N + N / 2) * T, zc);
                 } else {
                     float2 xk, xn;
                     split_pair(fb[phys(k)], fb[phys(N - k)], tws_l[k], xk, xn);
-                    o[(long long)k * T] = xk;
-                    if (!ONE) o[(long long)(W - k) * T] = cconj(xk);
-                    o[(long long)(N - k) * T] = xn;
-                    if (!ONE) o[(long long)(N + k) * T] = cconj(xn);
+                    put_bin<SPEC>(o, (long long)k * T, xk);
+                    if (SPEC == 0) put_bin<SPEC>(o, (long long)(W - k) * T, cconj(xk));
+                    put_bin<SPEC>(o, (long long)(N - k) * T, xn);
+                    if (SPEC == 0) put_bin<SPEC>(o, (long long)(N + k) * T, cconj(xn));
                 }
             }
         }
@@ -278,7 +297,7 @@ __global__ __launch_bounds__(kFatWaves * 64) void k_stft_ft16(
 // neighbours: one wavefront owns a frame from load to store (private LDS exchange buffer, 512-B
 // coalesced stores) and the 8 wavefronts of the persistent workgroup drift apart -- the store
 // issue of one overlaps the butterflies of another.  No s_barrier after the table staging.
-template <int LOG2N, int LOG2E, bool ALIGNED, bool ONE>
+template <int LOG2N, int LOG2E, bool ALIGNED, int SPEC>
 __global__ __launch_bounds__(512) void k_stft_tf(
     const float* __restrict__ x, const float* __restrict__ win, const float2* __restrict__ twp,
     const float2* __restrict__ tws, float2* __restrict__ out, long long n_samples, int hop, int T, long long total_frames) {
@@ -324,24 +343,24 @@ __global__ __launch_bounds__(512) void k_stft_tf(
             }
         }
         fft_frame<LOG2N, LOG2E>(v, buf, p, tw_l);
-        float2* o = out + g * (ONE ? N + 1 : W);
+        float2* o = spec_base<SPEC>(out, g * (SPEC ? N + 1 : W));
 #pragma unroll
         for (int i = 0; i < E / 2; ++i) {
             const int k = p + i * P;
             if (k == 0) {
                 const float2 z0 = buf[0], zc = buf[phys(N / 2)];
-                o[0] = make_float2(z0.x + z0.y, 0.f);
-                o[N] = make_float2(z0.x - z0.y, 0.f);
-                o[N / 2] = cconj(zc);
-                if (!ONE) o[N + N / 2] = zc;
+                put_bin<SPEC>(o, 0, make_float2(z0.x + z0.y, 0.f));
+                put_bin<SPEC>(o, N, make_float2(z0.x - z0.y, 0.f));
+                put_bin<SPEC>(o, N / 2, cconj(zc));
+                if (SPEC == 0) put_bin<SPEC>(o, N + N / 2, zc);
             } else {
                 float2 xk, xn;
                 split_pair(buf[phys(k)], buf[phys(N - k)], tws_l[k], xk, xn);
-                o[k] = xk;
-                o[N - k] = xn;
-                if (!ONE) {
-                    o[W - k] = cconj(xk);
-                    o[N + k] = cconj(xn);
+                put_bin<SPEC>(o, k, xk);
+                put_bin<SPEC>(o, N - k, xn);
+                if (SPEC == 0) {
+                    put_bin<SPEC>(o, W - k, cconj(xk));
+                    put_bin<SPEC>(o, N + k, cconj(xn));
                 }
             }
         }
@@ -835,11 +854,11 @@ constexpr bool stft_use_fat(int log2n, int layout) {
     return layout == ZAFX_LAYOUT_FT && log2n >= 7 && log2n <= 10;   // one wavefront per frame
 }
 
-template <int LOG2N, bool ALIGNED, bool ONE>
+template <int LOG2N, bool ALIGNED, int SPEC>
 static hipError_t run_stft_fat(const zafx_plan& pl, const float* x, float2* out, int64_t n_clips, int64_t n_samples, int T) {
     constexpr int LOG2E = default_log2e(LOG2N);
     using F = FatCfg<LOG2N, LOG2E>;
-    auto kern = k_stft_ft16<LOG2N, LOG2E, ALIGNED, ONE>;
+    auto kern = k_stft_ft16<LOG2N, LOG2E, ALIGNED, SPEC>;
     if (hipError_t e = ensure_dynamic_lds(reinterpret_cast<const void*>(kern), pl.device, F::SMEM); e != hipSuccess) return e;
     const int tiles = (T + kFatFrames - 1) / kFatFrames;
     const long long total = (long long)tiles * n_clips;
@@ -855,13 +874,13 @@ constexpr bool stft_use_tf(int log2n, int layout) {
     return layout == ZAFX_LAYOUT_TF && log2n >= 7 && log2n <= 10;   // one wavefront per frame
 }
 
-template <int LOG2N, bool ALIGNED, bool ONE>
+template <int LOG2N, bool ALIGNED, int SPEC>
 static hipError_t run_stft_tf(const zafx_plan& pl, const float* x, float2* out, int64_t n_clips, int64_t n_samples, int T) {
     constexpr int LOG2E = default_log2e(LOG2N);
     using C = FftCfg<LOG2N, LOG2E>;
     constexpr size_t SMEM = (size_t)(8 * C::PITCH + C::TW + C::N + C::N / 2 + 1) * 8;
     static_assert(SMEM <= (size_t)kMaxLdsBytes, "frame-major STFT tables + buffers exceed LDS");
-    auto kern = k_stft_tf<LOG2N, LOG2E, ALIGNED, ONE>;
+    auto kern = k_stft_tf<LOG2N, LOG2E, ALIGNED, SPEC>;
     if (hipError_t e = ensure_dynamic_lds(reinterpret_cast<const void*>(kern), pl.device, SMEM); e != hipSuccess) return e;
     const long long total = (long long)T * n_clips;
     if (total <= 0) return hipSuccess;
@@ -872,20 +891,20 @@ static hipError_t run_stft_tf(const zafx_plan& pl, const float* x, float2* out, 
     return hipGetLastError();
 }
 
-template <int LOG2N, int LAYOUT, bool ONE>
+template <int LOG2N, int LAYOUT, int SPEC>
 static hipError_t run_stft(const zafx_plan& pl, const float* x, float2* out, int64_t n_clips, int64_t n_samples, int T) {
     const bool aligned = (n_samples % 2 == 0) && (pl.H % 2 == 0) && (reinterpret_cast<uintptr_t>(x) % 8 == 0);
     if constexpr (stft_use_fat(LOG2N, LAYOUT)) {
-        return aligned ? run_stft_fat<LOG2N, true, ONE>(pl, x, out, n_clips, n_samples, T)
-                       : run_stft_fat<LOG2N, false, ONE>(pl, x, out, n_clips, n_samples, T);
+        return aligned ? run_stft_fat<LOG2N, true, SPEC>(pl, x, out, n_clips, n_samples, T)
+                       : run_stft_fat<LOG2N, false, SPEC>(pl, x, out, n_clips, n_samples, T);
     } else if constexpr (stft_use_tf(LOG2N, LAYOUT)) {
-        return aligned ? run_stft_tf<LOG2N, true, ONE>(pl, x, out, n_clips, n_samples, T)
-                       : run_stft_tf<LOG2N, false, ONE>(pl, x, out, n_clips, n_samples, T);
+        return aligned ? run_stft_tf<LOG2N, true, SPEC>(pl, x, out, n_clips, n_samples, T)
+                       : run_stft_tf<LOG2N, false, SPEC>(pl, x, out, n_clips, n_samples, T);
     } else {
         constexpr int LOG2E = default_log2e(LOG2N);
         constexpr int FPB = stft_fpb(LOG2N, LAYOUT);
         using S = StftCfg<LOG2N, LOG2E, FPB>;
-        auto kern = k_stft<LOG2N, LOG2E, FPB, LAYOUT, ONE>;
+        auto kern = k_stft<LOG2N, LOG2E, FPB, LAYOUT, SPEC>;
         if (hipError_t e = ensure_dynamic_lds(reinterpret_cast<const void*>(kern), pl.device, S::SMEM); e != hipSuccess) return e;
         const int tiles = (T + FPB - 1) / FPB;
         const long long blocks = (long long)tiles * n_clips;
@@ -980,12 +999,20 @@ const char* stft_kernel_name(int log2n, int layout) {
 }
 const char* istft_kernel_name(int log2n, int layout) { return stft_use_fat(log2n, layout) ? "k_istft_ft16" : "k_istft"; }
 
+template <int L, int LAYOUT>
+static hipError_t dispatch_stft_spec(const zafx_plan& pl, const float* x, float2* out, int64_t n_clips, int64_t n_samples, int T) {
+    switch (pl.prm.spectrum) {
+        case ZAFX_SPECTRUM_ONE_SIDED: return run_stft<L, LAYOUT, 1>(pl, x, out, n_clips, n_samples, T);
+        case ZAFX_SPECTRUM_MAGNITUDE: return run_stft<L, LAYOUT, 2>(pl, x, out, n_clips, n_samples, T);
+        case ZAFX_SPECTRUM_POWER: return run_stft<L, LAYOUT, 3>(pl, x, out, n_clips, n_samples, T);
+        default: return run_stft<L, LAYOUT, 0>(pl, x, out, n_clips, n_samples, T);
+    }
+}
+
 template <int L>
 static hipError_t dispatch_stft(const zafx_plan& pl, const float* x, float2* out, int64_t n_clips, int64_t n_samples, int T) {
-    const bool one = pl.prm.spectrum == ZAFX_SPECTRUM_ONE_SIDED;
-    if (pl.layout == ZAFX_LAYOUT_FT)
-        return one ? run_stft<L, ZAFX_LAYOUT_FT, true>(pl, x, out, n_clips, n_samples, T) : run_stft<L, ZAFX_LAYOUT_FT, false>(pl, x, out, n_clips, n_samples, T);
-    return one ? run_stft<L, ZAFX_LAYOUT_TF, true>(pl, x, out, n_clips, n_samples, T) : run_stft<L, ZAFX_LAYOUT_TF, false>(pl, x, out, n_clips, n_samples, T);
+    return pl.layout == ZAFX_LAYOUT_FT ? dispatch_stft_spec<L, ZAFX_LAYOUT_FT>(pl, x, out, n_clips, n_samples, T)
+                                       : dispatch_stft_spec<L, ZAFX_LAYOUT_TF>(pl, x, out, n_clips, n_samples, T);
 }
 
 template <int L>

@@ -13,7 +13,7 @@ STFT, ISTFT, MDCT, IMDCT, MEL, MFCC, CQT, CHROMA, LINEAR = 1, 2, 3, 4, 5, 6, 7, 
 # enum zafx_layout
 LAYOUT_FT, LAYOUT_TF = 0, 1
 # enum zafx_spectrum
-SPECTRUM_TWO_SIDED, SPECTRUM_ONE_SIDED = 0, 1
+SPECTRUM_TWO_SIDED, SPECTRUM_ONE_SIDED, SPECTRUM_MAGNITUDE, SPECTRUM_POWER = 0, 1, 2, 3
 # enum zafx_precision
 PRECISION_F32, PRECISION_F64 = 0, 1
 # enum zafx_constant

@@ -88,6 +88,12 @@ class DeviceBuffer:
 # ======================================================================================
 # plans
 # ======================================================================================
+# `onesided` of the STFT / ISTFT entry points: False / True, or "magnitude" / "power" (STFT only: |X| or |X|^2 of
+# rows 0..W/2 as real arrays -- the spectrogram of the reference's examples, zaf.py:83)
+_SPECTRA = {False: _lib.SPECTRUM_TWO_SIDED, True: _lib.SPECTRUM_ONE_SIDED, "magnitude": _lib.SPECTRUM_MAGNITUDE,
+            "power": _lib.SPECTRUM_POWER}
+
+
 class Plan:
     """One transform kind bound to one device and one HIP stream (zafx_plan)."""
 
@@ -108,7 +114,8 @@ class Plan:
         prm.fft_length = int(fft_length)
         prm.n_bins = int(n_bins)
         prm.octave_resolution = int(octave_resolution)
-        prm.spectrum = _lib.SPECTRUM_ONE_SIDED if onesided else _lib.SPECTRUM_TWO_SIDED
+        self.spectrum = _SPECTRA[onesided]
+        prm.spectrum = self.spectrum
         prm.precision = _lib.PRECISION_F64 if f64 else _lib.PRECISION_F32
         self.f64 = bool(f64)
         self.params = prm
@@ -156,9 +163,10 @@ class Plan:
 
     @property
     def out_dtype(self):
+        complex_out = self.kind == _lib.STFT and self.spectrum < _lib.SPECTRUM_MAGNITUDE
         if self.f64:
-            return np.dtype(np.complex128) if self.kind == _lib.STFT else np.dtype(np.float64)
-        return np.dtype(np.complex64) if self.kind == _lib.STFT else np.dtype(np.float32)
+            return np.dtype(np.complex128) if complex_out else np.dtype(np.float64)
+        return np.dtype(np.complex64) if complex_out else np.dtype(np.float32)
 
     @property
     def in_dtype(self):
@@ -344,7 +352,7 @@ def stft_plan(window_function, step_length, layout="FT", device=0, onesided=Fals
     w, h = _as_window(window_function), _as_step(step_length)
     if h > len(w):
         raise ValueError("step_length must not exceed window_length")
-    key = ("stft", device, len(w), h, _LAYOUTS[layout], bool(onesided), bool(f64), _digest(w))
+    key = ("stft", device, len(w), h, _LAYOUTS[layout], _SPECTRA[onesided], bool(f64), _digest(w))
 
     def make():
         p = Plan(_lib.STFT, device, window_length=len(w), step_length=h, layout=layout, onesided=onesided, f64=f64)
@@ -357,6 +365,8 @@ def istft_plan(window_function, step_length, layout="FT", device=0, onesided=Fal
     w, h = _as_window(window_function), _as_step(step_length)
     if h > len(w):
         raise ValueError("step_length must not exceed window_length")
+    if onesided not in (False, True):
+        raise ValueError("istft takes a complex spectrum: onesided must be False or True")
     key = ("istft", device, len(w), h, _LAYOUTS[layout], bool(onesided), bool(f64), _digest(w))
 
     def make():
@@ -449,7 +459,8 @@ def stft_batch(clips, window_function, step_length, layout="FT", device=0, onesi
     """(B, N) -> (B, W, T) complex64 [layout "FT"] or (B, T, W) ["TF"].
 
     onesided=True keeps rows 0..W/2 only -- what every example of the reference slices out of the
-    result (zaf.py:83) -- and halves the bytes written."""
+    result (zaf.py:83) -- and halves the bytes written; onesided="magnitude" / "power" returns |X| / |X|^2
+    of those rows as a real array."""
     x = _as_clips(clips, dtype=np.float64 if f64 else np.float32)
     return stft_plan(window_function, step_length, layout, device, onesided, f64).run_host(x, x.shape[1])
 

@@ -340,6 +340,18 @@ int zafx_d2d(int device, void* dst, const void* src, size_t bytes) {
     return 0;
 }
 
+int zafx_host_alloc(void** hptr, size_t bytes) {
+    if (!hptr) return fail_msg("null argument");
+    *hptr = nullptr;
+    if (bytes == 0) return 0;
+    ZAFX_HIP(hipHostMalloc(hptr, bytes, hipHostMallocDefault));
+    return 0;
+}
+int zafx_host_free(void* hptr) {
+    if (hptr) ZAFX_HIP(hipHostFree(hptr));
+    return 0;
+}
+
 int zafx_plan_create(zafx_plan** out, int device, int kind, const zafx_params* params) {
     if (!out || !params) return fail_msg("null argument");
     if (params->struct_size != (int32_t)sizeof(zafx_params)) return fail_msg("zafx_params.struct_size mismatch");

@@ -17,7 +17,7 @@ from .constants import cqtkernel, dct2_rows, dct_matrix, dst_matrix, hamming, ka
 from .core import (Comm, DeviceBuffer, Plan, clear_plan_cache, cqt_plan, cqtchromagram, cqtchromagram_batch, dct, dct_batch, dst,
                    dst_batch, linear_plan,
                    cqtspectrogram, cqtspectrogram_batch, imdct, imdct_batch, istft, istft_batch, istft_plan, mdct,
-                   mdct_batch, mdct_plan, mel_plan, melspectrogram, melspectrogram_batch, mfcc, mfcc_batch, pcm_to_mono,
+                   mdct_batch, mdct_plan, mel_plan, melspectrogram, melspectrogram_batch, mfcc, mfcc_batch, pcm_to_mono, pinned_empty,
                    get_precision, set_precision, stft, stft_batch, stft_pcm_batch, stft_plan)
 from .shard import clip_range, run_sharded, shard_sizes
 

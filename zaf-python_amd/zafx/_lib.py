@@ -54,6 +54,8 @@ SYMBOLS = {
     "zafx_h2d": (_i, [_i, _vp, _vp, _sz]),
     "zafx_d2h": (_i, [_i, _vp, _vp, _sz]),
     "zafx_d2d": (_i, [_i, _vp, _vp, _sz]),
+    "zafx_host_alloc": (_i, [ctypes.POINTER(_vp), _sz]),
+    "zafx_host_free": (_i, [_vp]),
     "zafx_plan_create": (_i, [ctypes.POINTER(_vp), _i, _i, ctypes.POINTER(ZafxParams)]),
     "zafx_plan_destroy": (_i, [_vp]),
     "zafx_plan_set_constant": (_i, [_vp, _i, _vp, _sz]),

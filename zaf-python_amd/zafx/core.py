@@ -5,6 +5,7 @@ Layering: Python host code -> ctypes -> libzafx.so (C-ABI, include/z
 """
 import ctypes
 import threading
+import weakref
 
 import numpy as np
 
@@ -22,6 +23,41 @@ def _ptr(a):
 # ======================================================================================
 # device memory
 # ======================================================================================
+class _Pinned:
+    """Owner of one page-locked host allocation (zafx_host_alloc); freed when the last array view dies."""
+
+    def __init__(self, nbytes):
+        p = ctypes.c_void_p()
+        _lib.check(_lib.load().zafx_host_alloc(ctypes.byref(p), int(nbytes)), "zafx_host_alloc")
+        self.ptr, self.nbytes = p, int(nbytes)
+
+    def __del__(self):
+        try:
+            if self.ptr and self.ptr.value:
+                _lib.load().zafx_host_free(self.ptr)
+                self.ptr = ctypes.c_void_p()
+        except Exception:
+            pass
+
+
+def pinned_empty(shape, dtype):
+    """np.empty in page-locked host memory: transfers at the PCIe rate (~56 GB/s) instead of ~25 GB/s pageable."""
+    dtype = np.dtype(dtype)
+    shape = tuple(int(s) for s in np.atleast_1d(shape))
+    nbytes = int(np.prod(shape, dtype=np.int64)) * dtype.itemsize
+    if nbytes == 0:
+        return np.empty(shape, dtype)
+    owner = _Pinned(nbytes)
+    raw = (ctypes.c_uint8 * nbytes).from_address(owner.ptr.value)
+    arr = np.frombuffer(raw, dtype=dtype).reshape(shape)
+    _PINNED_OWNERS[id(raw)] = owner   # keep the allocation alive as long as `raw` (the array's base) lives
+    weakref.finalize(raw, _PINNED_OWNERS.pop, id(raw), None)
+    return arr
+
+
+_PINNED_OWNERS = {}
+
+
 class DeviceBuffer:
     """A typed, shaped allocation in one GPU's HBM (owned by this object)."""
 
@@ -49,12 +85,17 @@ class DeviceBuffer:
             _lib.check(_lib.load().zafx_h2d(self.device, self.ptr, _ptr(array), self.nbytes), "zafx_h2d")
         return self
 
-    def download(self, first=0, count=None):
-        """Copy to host; `first`/`count` select a range along axis 0."""
+    def download(self, first=0, count=None, out=None):
+        """Copy to host; `first`/`count` select a range along axis 0.  `out`: destination array (e.g. from
+        pinned_empty, reused across calls -- pinning costs ~0.2 ms/MB, so it only pays for a buffer that lives on)."""
         count = self.shape[0] - first if count is None else count
         if first < 0 or count < 0 or first + count > self.shape[0]:
             raise ValueError("download range out of bounds")
-        out = np.empty((count,) + self.shape[1:], dtype=self.dtype)
+        shape = (count,) + self.shape[1:]
+        if out is None:
+            out = np.empty(shape, dtype=self.dtype)
+        elif out.shape != shape or out.dtype != self.dtype or not out.flags.c_contiguous:
+            raise ValueError("out must be a C-contiguous array of the downloaded shape and dtype")
         if out.nbytes:
             row = self.nbytes // max(self.shape[0], 1)
             src = ctypes.c_void_p(self.ptr.value + first * row)

@@ -27,9 +27,13 @@ namespace zafx {
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 ZAFX_PROF_ARRAY(g_prof_mel)
 
+#ifndef ZAFX_MEL_THREADS
+#define ZAFX_MEL_THREADS 1024
+#endif
+constexpr int kMelThreads = ZAFX_MEL_THREADS;   // 512: 8 fat waves (2 frames each, register prefetch); 1024: 16 waves, one frame each
 constexpr int mel_threads(int log2n, int log2e) {
     const int p = fft_threads(log2n, log2e);
-    return ((512 / p) < 16 ? (512 / p) : 16) * p;   // 8 fat waves for N >= 128: up to 256 VGPRs, no spills in the persistent loop
+    return ((kMelThreads / p) < 16 ? (kMelThreads / p) : 16) * p;
 }
 
 template <int LOG2N, int LOG2E>
@@ -37,7 +41,7 @@ struct MelCfg {
     using C = FftCfg<LOG2N, LOG2E>;
     static constexpr int N = C::N;
     static constexpr int FPB = 16;   // MFMA N dimension
-    static constexpr int NSLOT = (512 / C::P) < FPB ? (512 / C::P) : FPB;   // frames transformed concurrently
+    static constexpr int NSLOT = (kMelThreads / C::P) < FPB ? (kMelThreads / C::P) : FPB;   // frames transformed concurrently
     static constexpr int NT = NSLOT * C::P;
     // 256-float slots: in the dead upper half of every frame buffer when it is large enough,
     // else in a separate region after the tables
@@ -111,7 +115,7 @@ __global__ __launch_bounds__(mel_threads(LOG2N, LOG2E)) void k_mel(
 
     // raw samples of one frame of this wave's slot: xr[i] = (x[2n], x[2n+1]), n = p + i P (zero padding of zaf.py:112-125)
     float2 xr[E];
-    auto fetch = [&](int tl, int f0) {
+    auto fetch = [&](int tl, int f0, int p) {   // p: lane index within the frame (an opaque copy inside the tile loop)
         if (tl >= total_tiles) return;
         const int clip = tl / tiles, tile = tl % tiles;
         const int t = tile * FPB + f0 + slot;
@@ -130,7 +134,8 @@ __global__ __launch_bounds__(mel_threads(LOG2N, LOG2E)) void k_mel(
             }
         }
     };
-    fetch(blockIdx.x, 0);
+    constexpr bool PREFETCH = NT <= 512;
+    if constexpr (PREFETCH) fetch(blockIdx.x, 0, p);
     PROF_INIT(g_prof_mel);
     for (int tl = blockIdx.x; tl < total_tiles; tl += gridDim.x) {
         const int clip = tl / tiles, tile = tl % tiles;
@@ -148,14 +153,17 @@ __global__ __launch_bounds__(mel_threads(LOG2N, LOG2E)) void k_mel(
             // (hoisted out of the persistent loop they cost > 100 VGPRs and spill)
             int po = p;
             asm volatile("" : "+v"(po));
+            if constexpr (!PREFETCH) fetch(tl, f0, po);   // 16 thin waves: no registers to carry samples across the FFT
             float2 v[E];
 #pragma unroll
             for (int i = 0; i < E; ++i) {
                 const float2 wv = win_l[po + i * P];
                 v[i] = make_float2(xr[i].x * wv.x, xr[i].y * wv.y);
             }
-            if (f0 + NSLOT < FPB) fetch(tl, f0 + NSLOT);
-            else fetch(tl + gridDim.x, 0);
+            if constexpr (PREFETCH) {
+                if (f0 + NSLOT < FPB) fetch(tl, f0 + NSLOT, po);
+                else fetch(tl + gridDim.x, 0, po);
+            }
             fft_frame<LOG2N, LOG2E>(v, buf, po, tw_l);
             // real split of the (k, N-k) pairs this thread owns, kept in registers
             float mk[E / 2], mn[E / 2];

@@ -44,7 +44,7 @@ elif kind == "imdct":
     d_in = zafx.DeviceBuffer((B, F, T), np.float32)
     fwd.execute(d_x, d_in, B, N)
     fwd.sync()
-    n_in, tiles = T, (T + 30) // 31
+    n_in, tiles = T, (T + 31) // 32
     d_out = zafx.DeviceBuffer((B, plan.out_dims(T)[0]), np.float32)
 elif kind in ("mel", "mfcc"):
     w = zafx.hamming(W)

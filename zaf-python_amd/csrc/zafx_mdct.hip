@@ -120,6 +120,7 @@ __global__ __launch_bounds__(FPB * fft_threads(LOG2NF, LOG2E)) void k_mdct(
 // writes frame PAIRS as 8-byte stores so that one instruction covers 4 rows x 128 B.
 constexpr int kMdctTile = 32;
 ZAFX_PROF_ARRAY(g_prof_mdct)
+ZAFX_PROF_ARRAY(g_prof_imdct)
 
 template <int LOG2NF, int LOG2E>
 struct MdctPCfg {
@@ -287,17 +288,11 @@ __global__ __launch_bounds__(NSLOT * fft_threads(LOG2NF, LOG2E)) void k_imdct(
     for (int i = tid; i < NF; i += NT) tw8[i] = tw8g[i];
     for (int i = tid; i < 4 * NF; i += NT) win_l[i] = win[i];
     lds_barrier();
-    const float* fl = reinterpret_cast<const float*>(frames);
     const float gain = 2.f / (float)M;
     const bool vec4 = LAYOUT == ZAFX_LAYOUT_FT && FPB % 4 == 0 && NT % (FPB / 4) == 0 && NF >= NT / (FPB / 4) && T % 4 == 0 &&
                       reinterpret_cast<uintptr_t>(coefs) % 16 == 0;
-    // second half (n0 = n1 + M) of a frame's unfolded, windowed output: what it adds to the next frame's span
-    auto older = [&](const float* fr, int n1) {
-        const int n0 = n1 + M;
-        const float uu = (n0 < 3 * NF) ? -fr[fidx(3 * NF - 1 - n0)] : -fr[fidx(n0 - 3 * NF)];
-        return uu * win_l[n0];
-    };
 
+    PROF_INIT(g_prof_imdct);
     for (int unit = blockIdx.x; unit < total_units; unit += gridDim.x) {
     const int clip = unit / segs, seg = unit % segs;
     const int tile_a = seg * seg_tiles, tile_b = min(tile_a + seg_tiles, tiles);
@@ -306,6 +301,7 @@ __global__ __launch_bounds__(NSLOT * fft_threads(LOG2NF, LOG2E)) void k_imdct(
     const bool carry_only = tile < tile_a;
     const int t_first = tile * FPB;
     const int first_needed = carry_only ? FPB - 1 : 0;
+    PROF_MARK(0);
 
     // ---- phase A: c[m] = (X[2m] + i X[M-1-2m]) g_m  -> LDS (natural order)
     if constexpr (LAYOUT == ZAFX_LAYOUT_TF) {
@@ -352,7 +348,9 @@ __global__ __launch_bounds__(NSLOT * fft_threads(LOG2NF, LOG2E)) void k_imdct(
             }
         }
     }
+    PROF_MARK(1);
     lds_barrier();
+    PROF_MARK(2);
 
     // ---- phase B: FFT, then DCT-IV post-twiddle written in place as M reals per frame
     {
@@ -375,32 +373,69 @@ __global__ __launch_bounds__(NSLOT * fft_threads(LOG2NF, LOG2E)) void k_imdct(
             }
         }
     }
+    PROF_MARK(3);
     lds_barrier();
+    PROF_MARK(4);
 
     // ---- phase C: unfold + window + TDAC overlap-add of the 2 covering frames (older first, as the
     //      reference's loop), trim (zaf.py:1166-1182); then the carry for the next tile
     {
         const int n_valid = min(FPB, T - t_first);
+        // Two samples (n1, n1 + 1) at a time: each of the four operands is one aligned 8-byte LDS read (the
+        // reversed halves of the unfold come out swapped), the result one 8-byte store.
+        const float2* frames2 = frames;
+        const float2* win2 = reinterpret_cast<const float2*>(win_l);
+        float2* carry2 = reinterpret_cast<float2*>(carry);
+        auto older2 = [&](int j, int n1) {   // frame j's contribution to samples n1, n1 + 1 of the next frame's span
+            const int n0 = n1 + M;
+            const float2* fr = frames2 + (size_t)j * C::PITCH;
+            float2 u;
+            if (n0 < 3 * NF) {
+                const float2 v = fr[phys((3 * NF - 2 - n0) >> 1)];   // floats (3NF-2-n0, 3NF-1-n0)
+                u = make_float2(-v.y, -v.x);
+            } else {
+                const float2 v = fr[phys((n0 - 3 * NF) >> 1)];
+                u = make_float2(-v.x, -v.y);
+            }
+            const float2 w = win2[n0 >> 1];
+            return make_float2(u.x * w.x, u.y * w.y);
+        };
         if (!carry_only) {
-            const int c_end = tile == tiles - 1 ? (n_valid + 1) * M : FPB * M;
+            const int c_end2 = (tile == tiles - 1 ? (n_valid + 1) * M : FPB * M) / 2;
             float* yc = y + (long long)clip * out_len;
             const long long o_first = (long long)t_first * M - M;
-            for (int c = tid; c < c_end; c += NT) {
-                const int j1 = c / M, n1 = c % M;
-                float acc = j1 >= 1 ? older(fl + (size_t)(j1 - 1) * (2 * C::PITCH), n1) : carry[n1];
+            const bool y_aligned = (reinterpret_cast<uintptr_t>(yc) % 8) == 0;
+            for (int c2 = tid; c2 < c_end2; c2 += NT) {
+                const int c = 2 * c2, j1 = c / M, n1 = c % M;
+                float2 acc = j1 >= 1 ? older2(j1 - 1, n1) : carry2[n1 >> 1];
                 if (j1 < n_valid) {
-                    const float* fr = fl + (size_t)j1 * (2 * C::PITCH);
-                    const float uu = (n1 < NF) ? fr[fidx(NF + n1)] : -fr[fidx(3 * NF - 1 - n1)];
-                    acc += uu * win_l[n1];
+                    const float2* fr = frames2 + (size_t)j1 * C::PITCH;
+                    float2 u;
+                    if (n1 < NF) {
+                        u = fr[phys((NF + n1) >> 1)];
+                    } else {
+                        const float2 v = fr[phys((3 * NF - 2 - n1) >> 1)];
+                        u = make_float2(-v.y, -v.x);
+                    }
+                    const float2 w = win2[n1 >> 1];
+                    acc = make_float2(acc.x + u.x * w.x, acc.y + u.y * w.y);
                 }
                 const long long o = o_first + c;
-                if (o >= 0 && o < out_len) yc[o] = acc * gain;
+                if (o >= 0) {
+                    if (y_aligned && o + 1 < out_len) {
+                        *reinterpret_cast<float2*>(yc + o) = make_float2(acc.x * gain, acc.y * gain);
+                    } else {
+                        if (o < out_len) yc[o] = acc.x * gain;
+                        if (o + 1 < out_len) yc[o + 1] = acc.y * gain;
+                    }
+                }
             }
         }
         if (tile + 1 < tile_b) {   // then n_valid == FPB
-            for (int c = tid; c < M; c += NT) carry[c] = older(fl + (size_t)(FPB - 1) * (2 * C::PITCH), c);
+            for (int c2 = tid; c2 < M / 2; c2 += NT) carry2[c2] = older2(FPB - 1, 2 * c2);
         }
     }
+    PROF_MARK(5);
     lds_barrier();   // the next tile overwrites the frame buffers
     }
     }
@@ -538,3 +573,4 @@ hipError_t launch_imdct(const zafx_plan& pl, const float* coefs, float* y, int64
 }  // namespace zafx
 
 ZAFX_PROF_EXPORT(zafx_debug_prof_mdct, g_prof_mdct)
+ZAFX_PROF_EXPORT(zafx_debug_prof_imdct, g_prof_imdct)

@@ -607,3 +607,36 @@ def test_magnitude_and_power_spectra(zafx, wl, hop, n):
                     assert relerr(got[c], want[c]) <= (2 * tol if kind == "power" else tol), (f64, layout, kind, c)
     with pytest.raises(ValueError):
         zafx.istft_batch(np.zeros((1, wl // 2 + 1, 4), np.complex64), w, hop, onesided="magnitude")
+
+
+def test_concurrent_host_threads(zafx):
+    """SURVEY 8b threading contract: the module is re-entrant -- calls from several host threads (ctypes
+    releases the GIL; the plan cache is locked; a cached plan serialises its own executions) give the
+    same results as serial calls."""
+    import threading
+
+    rng_seeds = list(range(6))
+    geoms = [(2048, 1024), (1024, 256), (2048, 1024), (512, 128), (2048, 1024), (4096, 2048)]   # some threads share a plan
+    xs = [np.stack([synth_clip(50 + s, c, 30000 + 17 * s) for c in range(3)]) for s in rng_seeds]
+    want = [orc.stft_batch(x.astype(np.float64), zafx.hamming(wl), hop) for x, (wl, hop) in zip(xs, geoms)]
+    got, errors = [None] * len(xs), []
+
+    def work(i):
+        try:
+            wl, hop = geoms[i]
+            for _ in range(3):
+                got[i] = zafx.stft_batch(xs[i], zafx.hamming(wl), hop)
+                y = zafx.istft_batch(got[i], zafx.hamming(wl), hop)
+                assert y.shape[0] == 3
+        except Exception as exc:   # surfaced in the main thread
+            errors.append((i, repr(exc)))
+
+    threads = [threading.Thread(target=work, args=(i,)) for i in range(len(xs))]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    assert not errors, errors
+    for i in range(len(xs)):
+        for c in range(3):
+            assert relerr(got[i][c], want[i][c]) <= TOL_FFT, (i, c)

@@ -623,11 +623,11 @@ ZAFX_PROF_ARRAY(g_prof)
 //
 // Measured on MI355X (profiles/r01_notes.md): the gather runs at HBM speed only with SHALLOW
 // per-wave queues (16 waves x <= 8 loads; 8 waves x 64 loads of register prefetch ran the same bytes
-// 2x slower), so the tile's sweeps are streamed DEPTH at a time straight into the Hermitian fold;
-// PRE sweeps of the NEXT tile are issued before the FFT phase and folded after it (their latency
-// hides under the FFT).  Barriers order LDS only (lds_barrier): the output stores of a tile are
-// not waited for.
-template <int LOG2N, int LOG2E, int DEPTH, int PRE, bool ONE, int FV>
+// 2x slower), so the tile's sweeps are streamed DEPTH at a time straight into the Hermitian fold
+// (prefetching 1-3 sweeps of the next tile across the FFT phase did not pay: the FFT needs 116 of
+// the 128 VGPRs).  Barriers order LDS only (lds_barrier): the output stores of a tile are not
+// waited for.
+template <int LOG2N, int LOG2E, int DEPTH, bool ONE, int FV>
 __global__ __launch_bounds__(1024) void k_istft_ft16(
     const float2* __restrict__ spec, const float2* __restrict__ twp, const float2* __restrict__ tws,
     float* __restrict__ y, int T, int hop, long long out_len, float scale, int tiles, int segs, int seg_tiles, int total_units,
@@ -642,7 +642,6 @@ __global__ __launch_bounds__(1024) void k_istft_ft16(
     constexpr int LPR = FPB / FV;              // lanes per row run
     constexpr int KSTEP = NT / LPR;            // bins handled per sweep
     constexpr int KI = (N / 2) / KSTEP;        // sweeps per thread
-    constexpr int NPRE = PRE < KI ? PRE : 0;   // sweeps prefetched across the FFT phase
     static_assert((FV == 1 || FV == 2) && KI >= 1 && (N / 2) % KSTEP == 0, "pair sweep must divide N/2");
     using RV = std::conditional_t<FV == 2, float4, float2>;   // one row piece of my FV frames
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
@@ -752,12 +751,6 @@ __global__ __launch_bounds__(1024) void k_istft_ft16(
     if (cur.unit >= total_units) return;
     enter(cur);
     for (int c = tid; c < ncarry; c += NT) carry[c] = 0.f;
-    RV pre[NPRE > 0 ? NPRE : 1][4];
-    if (NPRE > 0 && my_frame_needed(cur)) {
-        const Src sp = source(cur);
-#pragma unroll
-        for (int s = 0; s < NPRE; ++s) load4(sp, s, pre[s]);
-    }
     lds_barrier();   // tables staged
     PROF_INIT(g_prof);
 
@@ -765,13 +758,11 @@ __global__ __launch_bounds__(1024) void k_istft_ft16(
         PROF_MARK(0);
         const bool carry_only = cur.tile < cur.tile_a;
         const int t_first = cur.tile * FPB;
-        // ---- phase A: fold the prefetched sweeps, stream the rest of the tile
+        // ---- phase A: stream the tile's sweeps, DEPTH at a time, through the Hermitian fold into LDS
         if (my_frame_needed(cur)) {
             const Src sp = source(cur);
-#pragma unroll
-            for (int s = 0; s < NPRE; ++s) fold4(s, pre[s]);
 #pragma unroll DEPTH
-            for (int s = NPRE; s < KI; ++s) {
+            for (int s = 0; s < KI; ++s) {
                 RV r[4];
                 load4(sp, s, r);
                 fold4(s, r);
@@ -786,11 +777,6 @@ __global__ __launch_bounds__(1024) void k_istft_ft16(
             if (nxt.unit < total_units) enter(nxt);
         }
         const bool has_next = nxt.unit < total_units;
-        if (NPRE > 0 && has_next && my_frame_needed(nxt)) {
-            const Src sp = source(nxt);
-#pragma unroll
-            for (int s = 0; s < NPRE; ++s) load4(sp, s, pre[s]);
-        }
         // ---- phase B: forward FFT of the swapped spectrum == swapped inverse FFT
         if (wave >= (carry_only ? FPB - halo : 0)) {   // wave-uniform
             float2* buf = frames + wave * PITCH;
@@ -940,7 +926,7 @@ static hipError_t run_istft_fat(const zafx_plan& pl, const float2* spec, float* 
     // sweeps streamed together: 8 loads per wave in flight is the measured optimum (profiles/r01_notes.md);
     // a one-sided sweep has 2 loads instead of 4
     constexpr int D1 = ONE ? 4 : 2, D2 = ONE ? 4 : 1;
-    auto kern = vec ? k_istft_ft16<LOG2N, LOG2E, D2, 0, ONE, can_vec ? 2 : 1> : k_istft_ft16<LOG2N, LOG2E, D1, 0, ONE, 1>;
+    auto kern = vec ? k_istft_ft16<LOG2N, LOG2E, D2, ONE, can_vec ? 2 : 1> : k_istft_ft16<LOG2N, LOG2E, D1, ONE, 1>;
     const int nt = 1024;
     if (hipError_t e = ensure_dynamic_lds(reinterpret_cast<const void*>(kern), pl.device, F::SMEM); e != hipSuccess) return e;
     const int W = 2 << LOG2N;

@@ -197,12 +197,17 @@ def main():
     bcast = "none (1 rank)"
     if world > 1 or force_dist:
         # the path's only collective: RCCL broadcast of the shared constants from rank 0 over xGMI
-        ids = [zafx.Comm.unique_id() if rank == 0 else None]
-        dist.broadcast_object_list(ids, src=0)
-        comm = zafx.Comm(device, rank, world, ids[0])
-        comm.broadcast_constants(plan, root=0)
-        comm.destroy()
-        bcast = "rccl ncclBroadcast of plan constants from rank 0"
+        # (every rank has already built identical constants from the same deterministic host code, so an error
+        # here costs the demonstration of the collective, not the measurement)
+        try:
+            ids = [zafx.Comm.unique_id() if rank == 0 else None]
+            dist.broadcast_object_list(ids, src=0)
+            comm = zafx.Comm(device, rank, world, ids[0])
+            comm.broadcast_constants(plan, root=0)
+            comm.destroy()
+            bcast = "rccl ncclBroadcast of plan constants from rank 0"
+        except zafx.ZafxError as exc:
+            bcast = f"skipped ({exc}); every rank built its own constants"
 
     def sync_all():
         plan.sync()

@@ -295,15 +295,21 @@ __global__ __launch_bounds__(kFatWaves * 64) void k_stft_ft16(
 // ---------------------------------------------------------------------------------
 // Every frame's 2 W bins are contiguous in this layout, so a frame never has to meet its
 // neighbours: one wavefront owns a frame from load to store (private LDS exchange buffer, 512-B
-// coalesced stores) and the 8 wavefronts of the persistent workgroup drift apart -- the store
+// coalesced stores) and the 16 wavefronts of the persistent workgroup drift apart -- the store
 // issue of one overlaps the butterflies of another.  No s_barrier after the table staging.
+// (16 waves at 100 VGPRs: 1.87 ms; 8 waves: 1.95 ms on the same box.)
+#ifndef ZAFX_TF_WAVES
+#define ZAFX_TF_WAVES 16
+#endif
+constexpr int kTfWaves = ZAFX_TF_WAVES;
+
 template <int LOG2N, int LOG2E, bool ALIGNED, int SPEC>
-__global__ __launch_bounds__(512) void k_stft_tf(
+__global__ __launch_bounds__(kTfWaves * 64) void k_stft_tf(
     const float* __restrict__ x, const float* __restrict__ win, const float2* __restrict__ twp,
     const float2* __restrict__ tws, float2* __restrict__ out, long long n_samples, int hop, int T, long long total_frames) {
     using C = FftCfg<LOG2N, LOG2E>;
     static_assert(C::P == 64, "one wavefront per frame");
-    constexpr int N = C::N, P = C::P, E = C::E, W = 2 * N, WAVES = 8, NT = WAVES * 64;   // 8 fat waves (see k_stft_ft16)
+    constexpr int N = C::N, P = C::P, E = C::E, W = 2 * N, WAVES = kTfWaves, NT = WAVES * 64;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     float2* frames = reinterpret_cast<float2*>(smem_raw);
     float2* tw_l = frames + WAVES * C::PITCH;
@@ -314,7 +320,7 @@ __global__ __launch_bounds__(512) void k_stft_tf(
     for (int i = tid; i < N; i += NT) win_l[i] = reinterpret_cast<const float2*>(win)[i];
     for (int i = tid; i <= N / 2; i += NT) tws_l[i] = tws[i];
     __syncthreads();
-    const int wave = tid / P, p = tid % P;
+    const int wave = tid / P, p_lane = tid % P;
     float2* buf = frames + wave * C::PITCH;
     const long long stride = (long long)gridDim.x * WAVES;
     for (long long g = (long long)blockIdx.x * WAVES + wave; g < total_frames; g += stride) {
@@ -322,6 +328,8 @@ __global__ __launch_bounds__(512) void k_stft_tf(
         const int t = (int)(g - clip * T);
         const float* xc = x + clip * n_samples;
         const long long s0 = (long long)t * hop - N;
+        int p = p_lane;   // opaque copy: per-lane offsets and table reads are recomputed per frame, not hoisted and spilled
+        asm volatile("" : "+v"(p));
         float2 v[E];
         if (ALIGNED && s0 >= 0 && s0 + W <= n_samples) {
 #pragma unroll
@@ -864,15 +872,15 @@ template <int LOG2N, bool ALIGNED, int SPEC>
 static hipError_t run_stft_tf(const zafx_plan& pl, const float* x, float2* out, int64_t n_clips, int64_t n_samples, int T) {
     constexpr int LOG2E = default_log2e(LOG2N);
     using C = FftCfg<LOG2N, LOG2E>;
-    constexpr size_t SMEM = (size_t)(8 * C::PITCH + C::TW + C::N + C::N / 2 + 1) * 8;
+    constexpr size_t SMEM = (size_t)(kTfWaves * C::PITCH + C::TW + C::N + C::N / 2 + 1) * 8;
     static_assert(SMEM <= (size_t)kMaxLdsBytes, "frame-major STFT tables + buffers exceed LDS");
     auto kern = k_stft_tf<LOG2N, LOG2E, ALIGNED, SPEC>;
     if (hipError_t e = ensure_dynamic_lds(reinterpret_cast<const void*>(kern), pl.device, SMEM); e != hipSuccess) return e;
     const long long total = (long long)T * n_clips;
     if (total <= 0) return hipSuccess;
     const int per_cu = (int)std::min<size_t>(2, (size_t)kMaxLdsBytes / SMEM);
-    const long long grid = std::min<long long>((total + 7) / 8, (long long)pl.n_cus * std::max(per_cu, 1));
-    hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(512), SMEM, pl.stream, x, pl.d_window, pl.d_tw_pass, pl.d_tw_aux, out,
+    const long long grid = std::min<long long>((total + kTfWaves - 1) / kTfWaves, (long long)pl.n_cus * std::max(per_cu, 1));
+    hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(kTfWaves * 64), SMEM, pl.stream, x, pl.d_window, pl.d_tw_pass, pl.d_tw_aux, out,
                        (long long)n_samples, pl.H, T, total);
     return hipGetLastError();
 }

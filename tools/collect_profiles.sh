@@ -19,10 +19,12 @@ for k in $KINDS; do
   timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/prof_$k" -o $k -- \
       python "$REPO/bench.py" --kind $k --steps $([ $k = stft ] && echo 20 || echo 10) --warmup 3 --no-cpu-baseline > "$OUT/prof_$k.log" 2>&1
 done
-for c in FETCH_SIZE WRITE_SIZE; do
-  rm -rf "$OUT/pmc_$c"
-  timeout 600 rocprofv3 --pmc $c --kernel-trace --output-format csv -d "$OUT/pmc_$c" -o stft -- \
-      python "$REPO/bench.py" --steps 3 --warmup 1 --no-cpu-baseline > "$OUT/pmc_$c.log" 2>&1
+for k in $KINDS; do
+  for c in FETCH_SIZE WRITE_SIZE; do
+    rm -rf "$OUT/pmc_${k}_$c"
+    timeout 600 rocprofv3 --pmc $c --kernel-trace --output-format csv -d "$OUT/pmc_${k}_$c" -o $k -- \
+        python "$REPO/bench.py" --kind $k --steps 3 --warmup 1 --no-cpu-baseline > "$OUT/pmc_${k}_$c.log" 2>&1
+  done
 done
 find "$OUT" -name "*.csv" -size +8M -delete   # per-dispatch traces of the big runs are not needed
 ls "$OUT"

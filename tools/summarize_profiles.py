@@ -53,9 +53,9 @@ with open(os.path.join(PROF, f"{tag}_other_kernel_stats.csv"), "w", newline="") 
             w.writerow([k] + r)
 
 
-# PMC passes of the headline kernel
-def counter_means(counter):
-    f = find(f"pmc_{counter}/**/*counter_collection.csv")
+# PMC passes (FETCH_SIZE and WRITE_SIZE in separate runs) of the dominant kernel of every transform
+def counter_means(kind, counter):
+    f = find(f"pmc_{kind}_{counter}/**/*counter_collection.csv")
     if not f:
         return {}
     acc = {}
@@ -70,32 +70,41 @@ def counter_means(counter):
     return {k: (n, v / n) for k, (n, v) in acc.items()}
 
 
-fetch, write = counter_means("FETCH_SIZE"), counter_means("WRITE_SIZE")
-if fetch and write:
-    with open(os.path.join(PROF, f"{tag}_stft_pmc_summary.csv"), "w") as fh:
-        fh.write("kernel,counter,dispatches,mean_value_KB\n")
-        for cname, tab in (("FETCH_SIZE", fetch), ("WRITE_SIZE", write)):
-            for k, (n, v) in sorted(tab.items()):
-                fh.write(f'"{k}",{cname},{n},{v:.3f}\n')
-    kern = next(k for k in fetch if "k_stft" in k)
+rows = []
+for kind in KINDS:
+    fetch, write = counter_means(kind, "FETCH_SIZE"), counter_means(kind, "WRITE_SIZE")
+    bench_file = os.path.join(PROF, f"{tag}_bench_{kind}.json")
+    if not (fetch and write and os.path.exists(bench_file)):
+        continue
+    bench = json.loads(open(bench_file).read())
+    kname = bench["roofline"]["kernel"]
+    kern = next((k for k in fetch if kname in k), None)
+    if kern is None or kern not in write:
+        continue
+    for cname, tab in (("FETCH_SIZE", fetch), ("WRITE_SIZE", write)):
+        for k, (n, v) in sorted(tab.items()):
+            if k == kern or (kind == "stft" and "copyBuffer" in k):
+                rows.append(f'{kind},"{k}",{cname},{n},{v:.3f}')
     copy = next((k for k in fetch if "copyBuffer" in k), None)
-    copy_bytes = 441000 * 4 * 8   # bench.py replicates blocks of 8 clips device-to-device
-    cal_f = copy_bytes / (fetch[copy][1] * 1024) if copy else None
-    cal_w = copy_bytes / (write[copy][1] * 1024) if copy else None
-    bench = json.loads(open(os.path.join(PROF, f"{tag}_bench_stft.json")).read())
     doc = {
-        "kernel": "k_stft_ft16",
+        "kernel": kname,
         "fetch_size_kb_raw": fetch[kern][1],
         "write_size_kb_raw": write[kern][1],
         "fetch_correction": 2.0,
         "write_correction": 1.0,
-        "calibration": {"kernel": copy, "bytes_per_dispatch": copy_bytes, "fetch_true_over_counter": cal_f,
-                        "write_true_over_counter": cal_w},
         "hbm_bytes_per_launch": fetch[kern][1] * 1024 * 2.0 + write[kern][1] * 1024,
         "algorithmic_bytes_per_launch": bench["roofline"]["algorithmic_bytes_per_launch"],
-        "note": "FETCH_SIZE/WRITE_SIZE in KB from separate rocprofv3 --pmc passes (profiles/%s_stft_pmc_summary.csv); gfx950 "
+        "note": "FETCH_SIZE/WRITE_SIZE in KB from separate rocprofv3 --pmc passes (profiles/%s_pmc_summary.csv); gfx950 "
                 "FETCH_SIZE counts half the bytes of streaming reads (MI355X_MICROARCH.md, HBM section; confirmed on the "
-                "device-to-device copy in the same run), WRITE_SIZE is exact on that copy" % tag,
+                "device-to-device copy of the stft run), WRITE_SIZE is exact on that copy" % tag,
     }
-    open(os.path.join(PROF, "pmc_stft.json"), "w").write(json.dumps(doc, indent=1) + "\n")
+    if kind == "stft" and copy:
+        copy_bytes = 441000 * 4 * 8   # bench.py replicates blocks of 8 clips device-to-device
+        doc["calibration"] = {"kernel": copy, "bytes_per_dispatch": copy_bytes,
+                              "fetch_true_over_counter": copy_bytes / (fetch[copy][1] * 1024),
+                              "write_true_over_counter": copy_bytes / (write[copy][1] * 1024)}
+    open(os.path.join(PROF, f"pmc_{kind}.json"), "w").write(json.dumps(doc, indent=1) + "\n")
+if rows:
+    with open(os.path.join(PROF, f"{tag}_pmc_summary.csv"), "w") as fh:
+        fh.write("kind,kernel,counter,dispatches,mean_value_KB\n" + "\n".join(rows) + "\n")
 print("profiles/ refreshed for", tag)

@@ -169,13 +169,22 @@ __global__ __launch_bounds__(NSLOT * 64) void k_mdct_ft32(
         const long long s0 = (long long)t * M - M;   // left pad = M (zaf.py:1036-1041)
         if (ALIGNED && t < T && s0 >= 0 && s0 + W <= n_samples) {
             const float* xs = xc + s0;
+            // Frames overlap by half: the wave's previous frame (f - 1) is still in q, and its pieces A3 / R2 are this
+            // frame's A1 / R0.  (Fetching all four again read every sample twice from the fabric: FETCH_SIZE 3.7 GB for
+            // 1.8 GB of input -- L2 does not hold the half frame until the neighbour asks for it.)
+            const bool reuse = f > 0 && s0 - M >= 0;   // the previous frame took this branch too
 #pragma unroll
             for (int r = 0; r < UPL; ++r) {
                 const int u = p + r * P;
+                if (reuse) {
+                    q[r][2] = q[r][0];
+                    q[r][3] = q[r][1];
+                } else {
+                    q[r][2] = *reinterpret_cast<const float4*>(xs + NF + 4 * u);
+                    q[r][3] = *reinterpret_cast<const float4*>(xs + NF - 4 - 4 * u);
+                }
                 q[r][0] = *reinterpret_cast<const float4*>(xs + 3 * NF + 4 * u);
                 q[r][1] = *reinterpret_cast<const float4*>(xs + 3 * NF - 4 - 4 * u);
-                q[r][2] = *reinterpret_cast<const float4*>(xs + NF + 4 * u);
-                q[r][3] = *reinterpret_cast<const float4*>(xs + NF - 4 - 4 * u);
             }
         } else {   // clip edges (zero padding), frames past T, unaligned clips
             auto at = [&](long long s) { return (t < T && s >= 0 && s < n_samples) ? xc[s] : 0.f; };

@@ -160,31 +160,27 @@ __global__ __launch_bounds__(NSLOT * 64) void k_mdct_ft32(
     // NF-2-2u (every sample of the frame is used once), so the loads are coalesced 1-KB rows per wave
     // instead of 4-byte gathers.  The next frame of the wave is requested as soon as the current one
     // is folded: its latency hides under this frame's FFT (or, across tiles, under the store phase).
+    // Wave w owns frames w and w + NSLOT of the tile (rounds): the frames the waves fetch at the same time are
+    // neighbours, so the half frames they share meet in L1 / L2.  (With adjacent pairs (2w, 2w+1) per wave the PMC pass
+    // showed every sample fetched twice from the fabric, 3.7 GB for 1.8 GB of input; reusing the shared half from the
+    // wave's registers recovered part of it, 1.075 ms -- rounds need no such code and run 1.05 ms.)
+    auto frame_of = [&](int f) { return f * NSLOT + slot; };
     float4 q[UPL][4];
     auto fetch = [&](int tl, int f) {
         if (tl >= total_tiles || !lane_loads) return;
         const int clip = tl / tiles, tile = tl % tiles;
-        const int t = tile * FPB + slot * FPW + f;
+        const int t = tile * FPB + frame_of(f);
         const float* xc = x + (long long)clip * n_samples;
         const long long s0 = (long long)t * M - M;   // left pad = M (zaf.py:1036-1041)
         if (ALIGNED && t < T && s0 >= 0 && s0 + W <= n_samples) {
             const float* xs = xc + s0;
-            // Frames overlap by half: the wave's previous frame (f - 1) is still in q, and its pieces A3 / R2 are this
-            // frame's A1 / R0.  (Fetching all four again read every sample twice from the fabric: FETCH_SIZE 3.7 GB for
-            // 1.8 GB of input -- L2 does not hold the half frame until the neighbour asks for it.)
-            const bool reuse = f > 0 && s0 - M >= 0;   // the previous frame took this branch too
 #pragma unroll
             for (int r = 0; r < UPL; ++r) {
                 const int u = p + r * P;
-                if (reuse) {
-                    q[r][2] = q[r][0];
-                    q[r][3] = q[r][1];
-                } else {
-                    q[r][2] = *reinterpret_cast<const float4*>(xs + NF + 4 * u);
-                    q[r][3] = *reinterpret_cast<const float4*>(xs + NF - 4 - 4 * u);
-                }
                 q[r][0] = *reinterpret_cast<const float4*>(xs + 3 * NF + 4 * u);
                 q[r][1] = *reinterpret_cast<const float4*>(xs + 3 * NF - 4 - 4 * u);
+                q[r][2] = *reinterpret_cast<const float4*>(xs + NF + 4 * u);
+                q[r][3] = *reinterpret_cast<const float4*>(xs + NF - 4 - 4 * u);
             }
         } else {   // clip edges (zero padding), frames past T, unaligned clips
             auto at = [&](long long s) { return (t < T && s >= 0 && s < n_samples) ? xc[s] : 0.f; };
@@ -226,7 +222,7 @@ __global__ __launch_bounds__(NSLOT * 64) void k_mdct_ft32(
         PROF_MARK(0);
 #pragma unroll 1
         for (int f = 0; f < FPW; ++f) {
-            float2* buf = frames + (slot * FPW + f) * C::PITCH;
+            float2* buf = frames + frame_of(f) * C::PITCH;
             fold(buf);
             PROF_MARK(1);
             if (f + 1 < FPW) fetch(tl, f + 1);

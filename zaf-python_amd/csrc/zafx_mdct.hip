@@ -240,7 +240,10 @@ __global__ __launch_bounds__(NSLOT * 64) void k_mdct_ft32(
         PROF_MARK(3);
         const int ta = t0 + 2 * tp;
         if (ta < T) {
-            int fqo = fq;   // opaque copy: g_l[k] of the 16 iterations is not carried across tiles
+            // Row of lane group g = (tid / 16) % 4 within the wave's 4 rows: 0, 2, 1, 3.  ds_read_b64 serves 32 lanes
+            // per cycle; rows f and f + 2 of a half-wave read bins k and k + 1 (bank offset 2 dwords: conflict free with
+            // the 4-dword frame-pair stride), rows f and f + 1 read bins k and M/2 - 1 - k (same bank class: 2-way).
+            int fqo = (fq & ~3) | ((fq & 1) << 1) | ((fq >> 1) & 1);   // (opaque: g_l[k] is not carried across tiles)
             asm volatile("" : "+v"(fqo));
             const float2* ba = frames + (2 * tp) * C::PITCH;
             const float2* bb = ba + C::PITCH;

@@ -107,4 +107,11 @@ for kind in KINDS:
 if rows:
     with open(os.path.join(PROF, f"{tag}_pmc_summary.csv"), "w") as fh:
         fh.write("kind,kernel,counter,dispatches,mean_value_KB\n" + "\n".join(rows) + "\n")
+# the bench lines were produced before this run's PMC summary existed: carry the fresh traffic figure into them
+for kind in KINDS:
+    pmc, bench_file = os.path.join(PROF, f"pmc_{kind}.json"), os.path.join(PROF, f"{tag}_bench_{kind}.json")
+    if os.path.exists(pmc) and os.path.exists(bench_file):
+        line = json.loads(open(bench_file).read())
+        line["roofline"]["traffic"] = json.load(open(pmc))["hbm_bytes_per_launch"]
+        open(bench_file, "w").write(json.dumps(line) + "\n")
 print("profiles/ refreshed for", tag)

@@ -502,6 +502,17 @@ def test_random_geometry_stft_family(zafx, wl, hop, n):
             assert got.shape == want.shape
             for c in range(b):
                 assert relerr(got[c], want[c]) <= TOL_FFT, (layout, one, c)
+    # float64 mode and the real-valued spectrum kinds on the same geometry
+    got64 = zafx.stft_batch(x.astype(np.float64), w, hop, f64=True)
+    mag = zafx.stft_batch(x, w, hop, onesided="magnitude")
+    y64 = zafx.istft_batch(ref, w, hop, f64=True)
+    for c in range(b):
+        assert relerr(got64[c], ref[c]) <= 1e-12
+        assert relerr(mag[c], np.abs(ref[c, :half])) <= TOL_FFT
+        yref = orc.istft(ref[c], w, hop)
+        assert y64[c].shape == yref.shape
+        if yref.size:
+            assert np.max(np.abs(y64[c] - yref)) / max(np.max(np.abs(yref)), 1e-300) <= 1e-12
     y = zafx.istft_batch(ref, w, hop)
     y1 = zafx.istft_batch(ref[:, :half], w, hop, onesided=True)
     for c in range(b):

@@ -235,6 +235,10 @@ static hipError_t run_cqt(const zafx_plan& pl, const float* x, float* out, int64
         set_error("cqt: kernel matrix (bins / non-zeros) too large for LDS at this fft_length");
         return hipErrorInvalidValue;
     }
+    if (n_samples >= (1LL << 29)) {   // a clip is addressed through one buffer descriptor with 32-bit byte offsets
+        set_error("cqt: clips of 2^29 samples or more are not supported (3.4 h at 44.1 kHz); cut the signal");
+        return hipErrorInvalidValue;
+    }
     if (hipError_t e = ensure_dynamic_lds(reinterpret_cast<const void*>(kern), pl.device, smem); e != hipSuccess) return e;
     const int tiles = (T + kCqtFramesPerBlock - 1) / kCqtFramesPerBlock;
     const long long blocks = (long long)tiles * n_clips;

@@ -651,3 +651,28 @@ def test_concurrent_host_threads(zafx):
     for i in range(len(xs)):
         for c in range(3):
             assert relerr(got[i][c], want[i][c]) <= TOL_FFT, (i, c)
+
+
+def test_reference_self_checks(zafx):
+    """The four checks the reference's own examples plot instead of asserting: DCT I-IV against
+    scipy.fftpack (zaf.py:728-753), the DST inverse pairs (:866-897), imdct(mdct(x)) == x with the Vorbis power-sine
+    window (:1098-1109) and istft(stft(x)) == x under COLA (:165-194) -- here on the device."""
+    import scipy.fftpack
+
+    rng = np.random.default_rng(99)
+    x = rng.standard_normal(1024).astype(np.float32).astype(np.float64)
+    for t in (1, 2, 3, 4):
+        assert relerr(zafx.dct(x, t), scipy.fftpack.dct(x, type=t, norm="ortho")) <= TOL_FFT
+    assert relerr(zafx.dst(zafx.dst(x, 1), 1), x) <= TOL_FFT
+    assert relerr(zafx.dst(zafx.dst(x, 2), 3), x) <= TOL_FFT
+    assert relerr(zafx.dst(zafx.dst(x, 3), 2), x) <= TOL_FFT
+    assert relerr(zafx.dst(zafx.dst(x, 4), 4), x) <= TOL_FFT
+
+    sig = synth_clip(77, 0, 44100).astype(np.float64)
+    wl = 2048
+    vorbis = np.sin(np.pi / 2 * np.sin(np.pi / wl * (np.arange(wl) + 0.5)) ** 2)   # zaf.py:1101-1104
+    rec = zafx.imdct(zafx.mdct(sig, vorbis), vorbis)[: len(sig)]
+    assert np.max(np.abs(rec - sig)) < TOL_FFT                                        # BASELINE config 4: residual < 1e-5
+    ham = zafx.hamming(wl)
+    rec = zafx.istft(zafx.stft(sig, ham, wl // 2), ham, wl // 2)[: len(sig)]
+    assert np.max(np.abs(rec - sig)) < TOL_FFT

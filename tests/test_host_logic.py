@@ -83,6 +83,16 @@ def test_argument_validation_happens_before_the_device():
         zafx.imdct(np.zeros((512, 4)), ham)
     with pytest.raises(ValueError):
         zafx.cqtspectrogram(x, 44100, 25, np.ones((4, 512)))
+    # spectrum kinds and precision: checked on the host too
+    with pytest.raises(ValueError):
+        zafx.stft_batch(x[None], ham, 1024, onesided="phase")
+    with pytest.raises(ValueError):
+        zafx.istft_batch(np.zeros((1, 1025, 4), complex), ham, 1024, onesided="power")
+    with pytest.raises(ValueError):
+        zafx.istft_batch(np.zeros((1, 2048, 4), complex), ham, 1024, onesided=True)   # rows must be W/2 + 1
+    with pytest.raises(ValueError):
+        zafx.set_precision("f16")
+    assert zafx.get_precision() == "f32"
 
 
 def test_shard_partition():

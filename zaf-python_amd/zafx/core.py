@@ -135,6 +135,13 @@ _SPECTRA = {False: _lib.SPECTRUM_TWO_SIDED, True: _lib.SPECTRUM_ONE_SIDED, "magn
             "power": _lib.SPECTRUM_POWER}
 
 
+def _spectrum_of(onesided):
+    try:
+        return _SPECTRA[onesided]
+    except (KeyError, TypeError):
+        raise ValueError('onesided must be False, True, "magnitude" or "power"') from None
+
+
 class Plan:
     """One transform kind bound to one device and one HIP stream (zafx_plan)."""
 
@@ -155,7 +162,7 @@ class Plan:
         prm.fft_length = int(fft_length)
         prm.n_bins = int(n_bins)
         prm.octave_resolution = int(octave_resolution)
-        self.spectrum = _SPECTRA[onesided]
+        self.spectrum = _spectrum_of(onesided)
         prm.spectrum = self.spectrum
         prm.precision = _lib.PRECISION_F64 if f64 else _lib.PRECISION_F32
         self.f64 = bool(f64)
@@ -393,7 +400,7 @@ def stft_plan(window_function, step_length, layout="FT", device=0, onesided=Fals
     w, h = _as_window(window_function), _as_step(step_length)
     if h > len(w):
         raise ValueError("step_length must not exceed window_length")
-    key = ("stft", device, len(w), h, _LAYOUTS[layout], _SPECTRA[onesided], bool(f64), _digest(w))
+    key = ("stft", device, len(w), h, _LAYOUTS[layout], _spectrum_of(onesided), bool(f64), _digest(w))
 
     def make():
         p = Plan(_lib.STFT, device, window_length=len(w), step_length=h, layout=layout, onesided=onesided, f64=f64)

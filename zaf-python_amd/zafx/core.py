@@ -61,14 +61,56 @@ _PINNED_OWNERS = {}
 class DeviceBuffer:
     """A typed, shaped allocation in one GPU's HBM (owned by this object)."""
 
-    def __init__(self, shape, dtype, device=0):
+    def __init__(self, shape, dtype, device=0, _ptr_from_pool=None):
         self.shape = tuple(int(s) for s in np.atleast_1d(shape))
         self.dtype = np.dtype(dtype)
         self.device = int(device)
         self.nbytes = int(np.prod(self.shape, dtype=np.int64)) * self.dtype.itemsize
+        if _ptr_from_pool is not None:
+            self.ptr = _ptr_from_pool
+            return
         p = ctypes.c_void_p()
         _lib.check(_lib.load().zafx_alloc(self.device, ctypes.byref(p), self.nbytes), "zafx_alloc")
         self.ptr = p
+
+    # Allocation pool of the host-buffer entry points: a drop-in call on one 10 s clip spends more time in
+    # hipMalloc / hipFree (which synchronises the device) than in its kernel, so run_host recycles allocations
+    # of the exact size it needs (repeated calls have repeated sizes), up to _POOL_CAP bytes per process.
+    _pool, _pool_bytes, _pool_lock = {}, [0], threading.Lock()
+    _POOL_CAP = 4 << 30
+
+    @classmethod
+    def pooled(cls, shape, dtype, device=0):
+        probe_bytes = int(np.prod([int(s) for s in np.atleast_1d(shape)], dtype=np.int64)) * np.dtype(dtype).itemsize
+        with cls._pool_lock:
+            free = cls._pool.get((int(device), probe_bytes))
+            ptr = free.pop() if free else None
+            if ptr is not None:
+                cls._pool_bytes[0] -= probe_bytes
+        return cls(shape, dtype, device, _ptr_from_pool=ptr) if ptr is not None else cls(shape, dtype, device)
+
+    def release(self):
+        """Return the allocation to the pool (or free it when the pool is full)."""
+        if getattr(self, "ptr", None) is None or not self.ptr.value:
+            return
+        with self._pool_lock:
+            keep = self.nbytes > 0 and self._pool_bytes[0] + self.nbytes <= self._POOL_CAP
+            if keep:
+                self._pool.setdefault((self.device, self.nbytes), []).append(self.ptr)
+                self._pool_bytes[0] += self.nbytes
+        if keep:
+            self.ptr = ctypes.c_void_p()
+        else:
+            self.free()
+
+    @classmethod
+    def drain_pool(cls):
+        with cls._pool_lock:
+            items, cls._pool = cls._pool, {}
+            cls._pool_bytes[0] = 0
+        for (device, _), ptrs in items.items():
+            for p in ptrs:
+                _lib.load().zafx_free(device, p)
 
     @classmethod
     def from_host(cls, array, device=0):
@@ -253,16 +295,17 @@ class Plan:
         array = np.ascontiguousarray(array, dtype=self.in_dtype if self.f64 else None)
         n_clips = array.shape[0]
         shape = self.out_shape(n_clips, n_in)
-        d_in = DeviceBuffer.from_host(array, self.device)
-        d_out = DeviceBuffer(shape, self.out_dtype, self.device)
+        d_in = DeviceBuffer.pooled(array.shape, array.dtype, self.device)
+        d_out = DeviceBuffer.pooled(shape, self.out_dtype, self.device)
         try:
+            d_in.upload(array)
             with self.lock:
                 self.execute(d_in, d_out, n_clips, n_in)
                 self.sync()
             return d_out.download()
         finally:
-            d_in.free()
-            d_out.free()
+            d_in.release()
+            d_out.release()
 
     def destroy(self):
         if getattr(self, "handle", None) is not None and self.handle.value:
@@ -338,6 +381,7 @@ def clear_plan_cache():
         for plan in _cache.values():
             plan.destroy()
         _cache.clear()
+    DeviceBuffer.drain_pool()
 
 
 # ======================================================================================
@@ -446,20 +490,28 @@ def _dense_filterbank(mel_filterbank, window_length):
 
 def mel_plan(window_function, step_length, mel_filterbank, number_coefficients=None, layout="FT", device=0):
     w, h = _as_window(window_function), _as_step(step_length)
-    fb = _dense_filterbank(mel_filterbank, len(w))
+    if not hasattr(mel_filterbank, "toarray"):
+        raise ValueError("mel_filterbank must be a scipy.sparse matrix (as returned by melfilterbank)")
+    if mel_filterbank.ndim != 2 or mel_filterbank.shape[1] != len(w) // 2:
+        raise ValueError("mel_filterbank must have window_length/2 columns")
+    n_filters = mel_filterbank.shape[0]
     mfcc = number_coefficients is not None
     ncoef = int(number_coefficients) if mfcc else 0
-    if mfcc and not 1 <= ncoef <= fb.shape[0] - 1:
+    if mfcc and not 1 <= ncoef <= n_filters - 1:
         raise ValueError("number_coefficients must be in [1, number_filters - 1]")
-    key = ("mfcc" if mfcc else "mel", device, len(w), h, _LAYOUTS[layout], ncoef, _digest(w, fb))
+    # the cache key hashes the sparse triplet (a few KB), not the dense matrix (1 MB: 1.8 ms per call)
+    csr = mel_filterbank.tocsr()
+    key = ("mfcc" if mfcc else "mel", device, len(w), h, _LAYOUTS[layout], ncoef, n_filters,
+           _digest(w, csr.data, csr.indices, csr.indptr))
 
     def make():
+        fb = _dense_filterbank(mel_filterbank, len(w))
         p = Plan(_lib.MFCC if mfcc else _lib.MEL, device, window_length=len(w), step_length=h, layout=layout,
                  n_filters=fb.shape[0], n_coefs=ncoef)
         p.set_window(w)
         p.set_mel_filterbank(fb)
         if mfcc:
-            p.set_dct(constants.dct2_rows(fb.shape[0], ncoef))
+            p.set_dct(constants.dct2_rows(n_filters, ncoef))
         return p
     return _cached(key, make)
 

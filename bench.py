@@ -45,7 +45,7 @@ def make_workload(kind, device, layout="FT"):
     distinct = 8
     T = 432
     if kind == "cqt":
-        B, N, T = 128, 1323000, 750
+        B, N, T = 1024, 1323000, 750   # BASELINE config 5: 8192 clips x 30 s over 8 GPUs = 1024 per GPU
     if kind == "dct":
         B, N, T = 16384, 1024, 1
     if kind == "stft64":
@@ -115,7 +115,7 @@ def make_workload(kind, device, layout="FT"):
         plan = zafx.cqt_plan(FS, 25, ck, device=device)
         wl.update(plan=plan, d_in=d_x, n_in=N, bytes_per_launch=B * (4 * N + 4 * 144 * T),
                   flops_per_launch=B * T * 5.0 * 32768 * 15,
-                  desc="cqtspectrogram: 128 clips x 30 s @ 44.1 kHz per GPU, 24 bins/octave 55-3520 Hz, 25 frames/s")
+                  desc="cqtspectrogram: 1024 clips x 30 s @ 44.1 kHz per GPU (config 5: 8192 clips over 8 GPUs), 24 bins/octave 55-3520 Hz, 25 frames/s")
     elif kind == "dct":
         plan = zafx.linear_plan(zafx.dct_matrix(N, 2), device=device)
         wl.update(plan=plan, d_in=d_x, n_in=N, bytes_per_launch=B * 8 * N + 4 * N * N, flops_per_launch=2.0 * N * N * B,

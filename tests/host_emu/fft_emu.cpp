@@ -47,7 +47,7 @@ double check() {
     Runner<LOG2N, LOG2E, 0>::run(regs, buf, tw.data());
     double err = 0, mx = 0;
     for (int k = 0; k < C::N; ++k) {
-        std::complex<double> got(buf[phys(k)].x, buf[phys(k)].y);
+        std::complex<double> got(buf[phys_t<C::PS>(k)].x, buf[phys_t<C::PS>(k)].y);
         err = std::max(err, std::abs(got - ref[k]));
         mx = std::max(mx, std::abs(ref[k]));
     }
@@ -64,6 +64,8 @@ int main() {
     worst = std::max(worst, check<8, 2>());
     worst = std::max(worst, check<9, 3>());
     worst = std::max(worst, check<10, 4>());
+    worst = std::max(worst, check<10, 5>());   // two radix-32 passes
+    worst = std::max(worst, check<9, 5>());    // 32 x 16
     worst = std::max(worst, check<11, 4>());
     worst = std::max(worst, check<12, 4>());
     worst = std::max(worst, check<14, 4>());

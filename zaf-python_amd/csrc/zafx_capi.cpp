@@ -439,6 +439,10 @@ int zafx_plan_create(zafx_plan** out, int device, int kind, const zafx_params* p
         auto tw = is_cqt_family(kind) ? build_two_level_twiddles(pl->log2nf) : build_pass_twiddles(pl->log2nf, pl->log2e);
         if (tw.empty()) tw.push_back(cf32{1.f, 0.f});
         e = upload(&pl->d_tw_pass, tw.data(), tw.size() * sizeof(cf32));
+        if (e == hipSuccess && (kind == ZAFX_STFT || kind == ZAFX_MEL || kind == ZAFX_MFCC) && pl->log2nf == 10) {
+            auto tw5 = build_pass_twiddles(10, 5);
+            e = upload(&pl->d_tw_r32, tw5.data(), tw5.size() * sizeof(cf32));
+        }
     }
     if (e == hipSuccess) e = upload(&pl->d_tw_aux, aux.data(), aux.size() * sizeof(cf32));
     if (e == hipSuccess && pl->prm.precision == ZAFX_PRECISION_F64) {   // float64 tables, evaluated in long double
@@ -474,6 +478,7 @@ int zafx_plan_destroy(zafx_plan* pl) {
     if (pl->d_matrix) (void)hipFree(pl->d_matrix);
     if (pl->d_wfold) (void)hipFree(pl->d_wfold);
     if (pl->d_tw_pass) (void)hipFree(pl->d_tw_pass);
+    if (pl->d_tw_r32) (void)hipFree(pl->d_tw_r32);
     if (pl->d_tw_aux) (void)hipFree(pl->d_tw_aux);
     if (pl->d_indptr) (void)hipFree(pl->d_indptr);
     if (pl->d_indices) (void)hipFree(pl->d_indices);

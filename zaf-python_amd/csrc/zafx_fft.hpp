@@ -50,7 +50,7 @@ ZAFX_HD float2 cscale(float2 a, float s) { return make_float2(a.x * s, a.y * s);
 // log2 of the radix of the pass that starts with `rem` radix-2 stages left, when
 // a thread holds 2^log2e points.  Shared by host (table builder) and device.
 constexpr int pass_log2r(int rem, int log2e) {
-    int m = log2e < 4 ? log2e : 4;
+    int m = log2e < 5 ? log2e : 5;   // radix <= 32 (32 only for threads that hold 32 points)
     if (rem <= m) return rem;
     if (rem - m == 1 && m >= 3) return m - 1;   // avoid a trailing radix-2 pass
     return m;
@@ -79,19 +79,22 @@ struct FftCfg {
     static constexpr int N = 1 << LOG2N;
     static constexpr int E = 1 << LOG2E;
     static constexpr int P = N / E;                 // threads per frame
-    static constexpr int PITCH = N + (N >> 4) + 1;  // padded complex slots per frame (odd-ish pitch)
+    static constexpr int PS = LOG2E >= 5 ? 5 : 4;   // one padding slot every 2^PS points: the widest radix of the config
+    static constexpr int PITCH = N + (N >> PS) + 1; // padded complex slots per frame (odd-ish pitch)
     static constexpr int TW = twiddle_total(LOG2N, LOG2E);
 };
 
-ZAFX_HD int phys(int i) { return i + (i >> 4); }
+template <int PS>
+ZAFX_HD int phys_t(int i) { return i + (i >> PS); }
+ZAFX_HD int phys(int i) { return phys_t<4>(i); }
 // phys(base + off) for a compile-time `off`, given pb = phys(base).  When the low part of `base`
 // (below the power-of-two SPAN >= 16 that `off` is a multiple-of-stride within) cannot carry into
 // the padding term, phys(base + off) = phys(base) + off + off/16: a constant that folds into the
 // DS instruction's immediate offset instead of costing address VALU per access.
-template <int SPAN>
+template <int SPAN, int PS = 4>
 ZAFX_HD int phys_off(int pb, int base, int off) {
-    if (SPAN >= 16) return pb + off + (off >> 4);
-    return phys(base + off);
+    if (SPAN >= (1 << PS)) return pb + off + (off >> PS);
+    return phys_t<PS>(base + off);
 }
 
 // ---------------------------------------------------------------- register DFTs
@@ -170,6 +173,36 @@ struct Dft<16> {
     }
 };
 
+template <>
+struct Dft<32> {
+    // 32 = 2 x 16: even and odd inputs through Dft<16>, odd outputs times w32^k, radix-2 combine
+    static ZAFX_HD void run(float2* a) {
+        float2 e[16], o[16];
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            e[i] = a[2 * i];
+            o[i] = a[2 * i + 1];
+        }
+        Dft<16>::run(e);
+        Dft<16>::run(o);
+        // w32^k = exp(-2 pi i k / 32), k = 1..15
+        const float c[16] = {1.f, 0.98078528040323044913f, 0.92387953251128675613f, 0.83146961230254523708f, 0.70710678118654752440f,
+                             0.55557023301960222474f, 0.38268343236508977173f, 0.19509032201612826785f, 0.f,
+                             -0.19509032201612826785f, -0.38268343236508977173f, -0.55557023301960222474f, -0.70710678118654752440f,
+                             -0.83146961230254523708f, -0.92387953251128675613f, -0.98078528040323044913f};
+        const float sn[16] = {0.f, 0.19509032201612826785f, 0.38268343236508977173f, 0.55557023301960222474f, 0.70710678118654752440f,
+                              0.83146961230254523708f, 0.92387953251128675613f, 0.98078528040323044913f, 1.f,
+                              0.98078528040323044913f, 0.92387953251128675613f, 0.83146961230254523708f, 0.70710678118654752440f,
+                              0.55557023301960222474f, 0.38268343236508977173f, 0.19509032201612826785f};
+#pragma unroll
+        for (int k = 0; k < 16; ++k) {
+            const float2 t = k == 0 ? o[0] : (k == 8 ? mul_mi(o[8]) : cmul(o[k], make_float2(c[k], -sn[k])));
+            a[k] = cadd(e[k], t);
+            a[k + 16] = csub(e[k], t);
+        }
+    }
+};
+
 // ---------------------------------------------------------------- one Stockham pass
 // v[i] holds x[p + i*P].  Twiddle, radix-R butterflies, scatter to the padded
 // LDS frame `buf`.  tw points at this pass's [r-1][k] table (unused when Ns = 1).
@@ -190,9 +223,9 @@ ZAFX_HD void pass_write(const float2* v, float2* buf, int p, const float2* tw) {
         }
         Dft<R>::run(a);
         const int base = ((j >> LOG2NS) << (LOG2NS + LR)) + k;
-        const int pb = phys(base);
+        const int pb = phys_t<C::PS>(base);
 #pragma unroll
-        for (int r = 0; r < R; ++r) buf[phys_off<NS * R>(pb, base, r * NS)] = a[r];
+        for (int r = 0; r < R; ++r) buf[phys_off<NS * R, C::PS>(pb, base, r * NS)] = a[r];
     }
 }
 
@@ -228,18 +261,18 @@ ZAFX_HD void pass_write_chain(const float2* v, float2* buf, int p, const TwoLeve
         }
         Dft<R>::run(a);
         const int base = ((j >> LOG2NS) << (LOG2NS + LR)) + k;
-        const int pb = phys(base);
+        const int pb = phys_t<C::PS>(base);
 #pragma unroll
-        for (int r = 0; r < R; ++r) buf[phys_off<NS * R>(pb, base, r * NS)] = a[r];
+        for (int r = 0; r < R; ++r) buf[phys_off<NS * R, C::PS>(pb, base, r * NS)] = a[r];
     }
 }
 
 template <int LOG2N, int LOG2E>
 ZAFX_HD void regs_read(float2* v, const float2* buf, int p) {
     using C = FftCfg<LOG2N, LOG2E>;
-    const int pp = phys(p);
+    const int pp = phys_t<C::PS>(p);
 #pragma unroll
-    for (int i = 0; i < C::E; ++i) v[i] = buf[phys_off<C::P>(pp, p, i * C::P)];
+    for (int i = 0; i < C::E; ++i) v[i] = buf[phys_off<C::P, C::PS>(pp, p, i * C::P)];
 }
 
 }  // namespace zafx

@@ -60,6 +60,7 @@ struct zafx_plan {
     int4* d_chunks = nullptr;      // CQT rows cut into <= 64-entry chunks {row, first entry, count, last-of-row}
     int* d_chunk_ptr = nullptr;    // [waves + 1] ranges of d_chunks per wavefront
     int n_chunks = 0;
+    float2* d_tw_r32 = nullptr;    // pass twiddles of the radix-32 schedule (1024 points as 32 x 32), STFT plans of W = 2048
     // float64 mode (ZAFX_PRECISION_F64, zafx_f64.hip)
     double* d_window64 = nullptr;
     double2* d_tw64 = nullptr;     // exp(-2 pi i m / (W/2)), m < W/4

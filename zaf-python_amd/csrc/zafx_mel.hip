@@ -31,6 +31,11 @@ ZAFX_PROF_ARRAY(g_prof_mel)
 #define ZAFX_MEL_THREADS 1024
 #endif
 constexpr int kMelThreads = ZAFX_MEL_THREADS;   // 512: 8 fat waves (2 frames each, register prefetch); 1024: 16 waves, one frame each
+#ifndef ZAFX_MEL_R32
+#define ZAFX_MEL_R32 0
+#endif
+// points per thread of the FFT: 32 (two radix-32 passes, a frame per half wavefront, 8 waves) for W = 2048 when enabled
+constexpr int mel_log2e(int log2n) { return (ZAFX_MEL_R32 && log2n == 10) ? 5 : default_log2e(log2n); }
 constexpr int mel_threads(int log2n, int log2e) {
     const int p = fft_threads(log2n, log2e);
     return ((kMelThreads / p) < 16 ? (kMelThreads / p) : 16) * p;
@@ -172,11 +177,11 @@ __global__ __launch_bounds__(mel_threads(LOG2N, LOG2E)) void k_mel(
                 const int k = po + i * P;
                 float2 xk, xn;
                 if (k == 0) {
-                    const float2 z0 = buf[0], zc = buf[phys(N / 2)];
+                    const float2 z0 = buf[0], zc = buf[phys_t<C::PS>(N / 2)];
                     xk = zc;                                  // |X[N/2]| = |Z[N/2]|
                     xn = make_float2(z0.x - z0.y, 0.f);       // X[N] (Nyquist, kept: zaf.py:370)
                 } else {
-                    const float2 zk = buf[phys(k)], zn = buf[phys(N - k)];
+                    const float2 zk = buf[phys_t<C::PS>(k)], zn = buf[phys_t<C::PS>(N - k)];
                     const float2 e = make_float2(0.5f * (zk.x + zn.x), 0.5f * (zk.y - zn.y));
                     const float2 d = make_float2(0.5f * (zk.x - zn.x), 0.5f * (zk.y + zn.y));
                     const float2 to = cmul(tws_l[k], make_float2(d.y, -d.x));
@@ -250,7 +255,7 @@ __global__ __launch_bounds__(mel_threads(LOG2N, LOG2E)) void k_mel(
 
 template <int LOG2N, bool ALIGNED>
 static hipError_t run_mel(const zafx_plan& pl, const float* x, float* out, int64_t n_clips, int64_t n_samples, int T) {
-    constexpr int LOG2E = default_log2e(LOG2N);
+    constexpr int LOG2E = mel_log2e(LOG2N);
     using G = MelCfg<LOG2N, LOG2E>;
     auto kern = k_mel<LOG2N, LOG2E, ALIGNED>;
     const int mfcc = pl.kind == ZAFX_MFCC;
@@ -269,7 +274,7 @@ static hipError_t run_mel(const zafx_plan& pl, const float* x, float* out, int64
     if (total <= 0) return hipSuccess;
     const int per_cu = (int)std::min<size_t>(2, (size_t)kMaxLdsBytes / G::SMEM);
     const long long grid = std::min<long long>(total, (long long)pl.n_cus * std::max(per_cu, 1));
-    hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(G::NT), G::SMEM, pl.stream, x, pl.d_window, pl.d_tw_pass, pl.d_tw_aux, pl.fb.d_pack,
+    hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(G::NT), G::SMEM, pl.stream, x, pl.d_window, LOG2E == 5 ? pl.d_tw_r32 : pl.d_tw_pass, pl.d_tw_aux, pl.fb.d_pack,
                        pl.fb.d_items, pl.fb.d_wave_ptr, pl.fb.d_blk_ptr, pl.fb.n_blocks, pl.fb.n_items, pl.dct.d_pack, pl.dct.d_items,
                        pl.dct.d_wave_ptr, pl.dct.d_blk_ptr, pl.dct.n_blocks, out, (long long)n_samples, pl.H, T, tiles, (int)total,
                        pl.prm.n_filters, pl.prm.n_coefs, mfcc, pl.layout);
@@ -277,7 +282,7 @@ static hipError_t run_mel(const zafx_plan& pl, const float* x, float* out, int64
 }
 
 const char* mel_kernel_name() { return "k_mel"; }
-int mel_waves(int log2n) { return mel_threads(log2n, default_log2e(log2n)) / 64; }
+int mel_waves(int log2n) { return mel_threads(log2n, mel_log2e(log2n)) / 64; }
 
 template <int LOG2N>
 static hipError_t run_mel_any(const zafx_plan& pl, const float* x, float* out, int64_t n_clips, int64_t n_samples, int T) {

@@ -178,11 +178,11 @@ constexpr int kFatFrames = 16;
 template <int LOG2N, int LOG2E>
 struct FatCfg {
     using C = FftCfg<LOG2N, LOG2E>;
-    static_assert(C::P == 64, "one wavefront per frame");
+    static_assert(C::P == 64 || C::P == 32, "a frame is owned by one wavefront, or by half of one (32 points per thread)");
     static constexpr int N = C::N;
-    static constexpr int PITCH = ((N + (N >> 4) + 31) / 32) * 32 + 2;   // = 2 (mod 32)
+    static constexpr int PITCH = ((N + (N >> C::PS) + 31) / 32) * 32 + 2;   // = 2 (mod 32)
     static constexpr int NT = kFatWaves * 64;
-    static constexpr int FPW = kFatFrames / kFatWaves;
+    static constexpr int FPW = kFatFrames * C::P / NT;   // frames a group of P lanes transforms per tile: 2, or 1 for P = 32
     static constexpr size_t SMEM = (size_t)(kFatFrames * PITCH + C::TW + N + N / 2 + 1) * 8;
 };
 
@@ -205,7 +205,7 @@ __global__ __launch_bounds__(kFatWaves * 64) void k_stft_ft16(
     for (int i = tid; i < N; i += NT) win_l[i] = reinterpret_cast<const float2*>(win)[i];
     for (int i = tid; i <= N / 2; i += NT) tws_l[i] = tws[i];
     __syncthreads();
-    const int wave = tid / P, p = tid % P;
+    const int wave = tid / P, p_lane = tid % P, p = p_lane;
     const int tt = tid % FPB, kq = tid / FPB;
     const float2* fb = frames + tt * PITCH;
 
@@ -216,6 +216,8 @@ __global__ __launch_bounds__(kFatWaves * 64) void k_stft_ft16(
     // predicated path (zero padding of zaf.py:112-125).
     auto prefetch = [&](int tl) {
         if (tl >= total_tiles) return;
+        int p = p_lane;   // (opaque at 32 points per thread: the 64-bit sample offsets of the edge path are recomputed, not hoisted)
+        if constexpr (E >= 32) asm volatile("" : "+v"(p));
         const int clip = tl / tiles, tile = tl % tiles;
         const float* xc = x + (long long)clip * n_samples;
         const long long first = (long long)tile * FPB * hop - N;               // first sample of the tile
@@ -248,15 +250,17 @@ __global__ __launch_bounds__(kFatWaves * 64) void k_stft_ft16(
         const int clip = tl / tiles, tile = tl % tiles;
         const int t0 = tile * FPB;
         PROF_MARK(0);
+        int po = p;   // opaque copy: window and twiddle reads are not hoisted out of the tile loop (at 32 points per
+        if constexpr (E >= 32) asm volatile("" : "+v"(po));   // thread the hoisted values no longer fit beside the prefetch)
 #pragma unroll
         for (int f = 0; f < FPW; ++f) {
             float2 v[E];
 #pragma unroll
             for (int i = 0; i < E; ++i) {
-                const float2 wv = win_l[p + i * P];
+                const float2 wv = win_l[po + i * P];
                 v[i] = make_float2(xr[f][i].x * wv.x, xr[f][i].y * wv.y);
             }
-            fft_frame<LOG2N, LOG2E>(v, frames + (wave * FPW + f) * PITCH, p, tw_l);
+            fft_frame<LOG2N, LOG2E>(v, frames + (wave * FPW + f) * PITCH, po, tw_l);
         }
         PROF_MARK(1);
         lds_barrier();
@@ -268,16 +272,18 @@ __global__ __launch_bounds__(kFatWaves * 64) void k_stft_ft16(
         PROF_MARK(3);
         if (t0 + tt < T) {
             float2* o = spec_base<SPEC>(out, (long long)clip * ROWS * T + (t0 + tt));
-            for (int k = kq; k < N / 2; k += NT / FPB) {
+            int kqo = kq;   // (opaque at 32 points per thread: the split roots of the 16 iterations are not carried across tiles)
+            if constexpr (E >= 32) asm volatile("" : "+v"(kqo));
+            for (int k = kqo; k < N / 2; k += NT / FPB) {
                 if (k == 0) {
-                    const float2 z0 = fb[0], zc = fb[phys(N / 2)];
+                    const float2 z0 = fb[0], zc = fb[phys_t<C::PS>(N / 2)];
                     put_bin<SPEC>(o, 0, make_float2(z0.x + z0.y, 0.f));
                     put_bin<SPEC>(o, (long long)N * T, make_float2(z0.x - z0.y, 0.f));
                     put_bin<SPEC>(o, (long long)(N / 2) * T, cconj(zc));
                     if (SPEC == 0) put_bin<SPEC>(o, (long long)(N + N / 2) * T, zc);
                 } else {
                     float2 xk, xn;
-                    split_pair(fb[phys(k)], fb[phys(N - k)], tws_l[k], xk, xn);
+                    split_pair(fb[phys_t<C::PS>(k)], fb[phys_t<C::PS>(N - k)], tws_l[k], xk, xn);
                     put_bin<SPEC>(o, (long long)k * T, xk);
                     if (SPEC == 0) put_bin<SPEC>(o, (long long)(W - k) * T, cconj(xk));
                     put_bin<SPEC>(o, (long long)(N - k) * T, xn);
@@ -850,7 +856,14 @@ constexpr bool stft_use_fat(int log2n, int layout) {
 
 template <int LOG2N, bool ALIGNED, int SPEC>
 static hipError_t run_stft_fat(const zafx_plan& pl, const float* x, float2* out, int64_t n_clips, int64_t n_samples, int T) {
-    constexpr int LOG2E = default_log2e(LOG2N);
+#ifndef ZAFX_STFT_R32
+#define ZAFX_STFT_R32 1
+#endif
+    // 1024 points as two radix-32 passes (32 points per thread, a frame per half wavefront) instead of 16 x 16 x 4:
+    // 495 instead of 604 instructions per frame, one LDS exchange instead of two; FFT phase 9.6 k -> 7.4 k cycles per
+    // tile.  The two-sided kernel is bound by its store drain and does not move (1.95 ms either way); the one-sided /
+    // magnitude / power outputs gain 4-5 %.  (The fused mel kernel is better off with 16 waves x radix 16: 1.48 vs 1.67 ms.)
+    constexpr int LOG2E = (ZAFX_STFT_R32 && LOG2N == 10) ? 5 : default_log2e(LOG2N);
     using F = FatCfg<LOG2N, LOG2E>;
     auto kern = k_stft_ft16<LOG2N, LOG2E, ALIGNED, SPEC>;
     if (hipError_t e = ensure_dynamic_lds(reinterpret_cast<const void*>(kern), pl.device, F::SMEM); e != hipSuccess) return e;
@@ -859,8 +872,8 @@ static hipError_t run_stft_fat(const zafx_plan& pl, const float* x, float2* out,
     if (total <= 0) return hipSuccess;
     const int per_cu = (int)std::min<size_t>(2, (size_t)kMaxLdsBytes / F::SMEM);
     const long long grid = std::min<long long>(total, (long long)pl.n_cus * std::max(per_cu, 1));
-    hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(F::NT), F::SMEM, pl.stream, x, pl.d_window, pl.d_tw_pass, pl.d_tw_aux, out,
-                       (long long)n_samples, pl.H, T, tiles, (int)total);
+    hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(F::NT), F::SMEM, pl.stream, x, pl.d_window, LOG2E == 5 ? pl.d_tw_r32 : pl.d_tw_pass,
+                       pl.d_tw_aux, out, (long long)n_samples, pl.H, T, tiles, (int)total);
     return hipGetLastError();
 }
 

@@ -300,8 +300,8 @@ __global__ __launch_bounds__(kFatWaves * 64) void k_stft_ft16(
 // forward, frame-major layout (ZAFX_LAYOUT_TF), persistent and barrier free
 // ---------------------------------------------------------------------------------
 // Every frame's 2 W bins are contiguous in this layout, so a frame never has to meet its
-// neighbours: one wavefront owns a frame from load to store (private LDS exchange buffer, 512-B
-// coalesced stores) and the 16 wavefronts of the persistent workgroup drift apart -- the store
+// neighbours: one wavefront (half of one for 1024 points, two radix-32 passes) owns a frame from load to store (private LDS
+// exchange buffer, coalesced stores) and the wavefronts of the persistent workgroup drift apart -- the store
 // issue of one overlaps the butterflies of another.  No s_barrier after the table staging.
 // (16 waves at 100 VGPRs: 1.87 ms; 8 waves: 1.95 ms on the same box.)
 #ifndef ZAFX_TF_WAVES
@@ -309,13 +309,21 @@ __global__ __launch_bounds__(kFatWaves * 64) void k_stft_ft16(
 #endif
 constexpr int kTfWaves = ZAFX_TF_WAVES;
 
+#ifndef ZAFX_TF_R32
+#define ZAFX_TF_R32 1   // 1024 x 10 s: 2.01 ms against 2.11 ms for the one-wavefront radix-16 schedule on the same box
+#endif
+// points per thread / threads per workgroup of k_stft_tf: radix-32 schedule (8 waves, a frame per half wavefront) for
+// 1024 points when enabled, else one frame per wavefront and kTfWaves wavefronts
+constexpr int tf_log2e(int log2n) { return (ZAFX_TF_R32 && log2n == 10) ? 5 : default_log2e(log2n); }
+constexpr int tf_threads(int log2n) { return (ZAFX_TF_R32 && log2n == 10) ? 512 : kTfWaves * 64; }
+
 template <int LOG2N, int LOG2E, bool ALIGNED, int SPEC>
-__global__ __launch_bounds__(kTfWaves * 64) void k_stft_tf(
+__global__ __launch_bounds__(tf_threads(LOG2N)) void k_stft_tf(
     const float* __restrict__ x, const float* __restrict__ win, const float2* __restrict__ twp,
     const float2* __restrict__ tws, float2* __restrict__ out, long long n_samples, int hop, int T, long long total_frames) {
     using C = FftCfg<LOG2N, LOG2E>;
-    static_assert(C::P == 64, "one wavefront per frame");
-    constexpr int N = C::N, P = C::P, E = C::E, W = 2 * N, WAVES = kTfWaves, NT = WAVES * 64;
+    static_assert(C::P == 64 || C::P == 32, "a frame is owned by one wavefront or by half of one");
+    constexpr int N = C::N, P = C::P, E = C::E, W = 2 * N, NT = tf_threads(LOG2N), WAVES = NT / P;   // WAVES = frame slots
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     float2* frames = reinterpret_cast<float2*>(smem_raw);
     float2* tw_l = frames + WAVES * C::PITCH;
@@ -362,14 +370,14 @@ __global__ __launch_bounds__(kTfWaves * 64) void k_stft_tf(
         for (int i = 0; i < E / 2; ++i) {
             const int k = p + i * P;
             if (k == 0) {
-                const float2 z0 = buf[0], zc = buf[phys(N / 2)];
+                const float2 z0 = buf[0], zc = buf[phys_t<C::PS>(N / 2)];
                 put_bin<SPEC>(o, 0, make_float2(z0.x + z0.y, 0.f));
                 put_bin<SPEC>(o, N, make_float2(z0.x - z0.y, 0.f));
                 put_bin<SPEC>(o, N / 2, cconj(zc));
                 if (SPEC == 0) put_bin<SPEC>(o, N + N / 2, zc);
             } else {
                 float2 xk, xn;
-                split_pair(buf[phys(k)], buf[phys(N - k)], tws_l[k], xk, xn);
+                split_pair(buf[phys_t<C::PS>(k)], buf[phys_t<C::PS>(N - k)], tws_l[k], xk, xn);
                 put_bin<SPEC>(o, k, xk);
                 put_bin<SPEC>(o, N - k, xn);
                 if (SPEC == 0) {
@@ -878,23 +886,24 @@ static hipError_t run_stft_fat(const zafx_plan& pl, const float* x, float2* out,
 }
 
 constexpr bool stft_use_tf(int log2n, int layout) {
-    return layout == ZAFX_LAYOUT_TF && log2n >= 7 && log2n <= 10;   // one wavefront per frame
+    return layout == ZAFX_LAYOUT_TF && log2n >= 7 && log2n <= 10;   // one wavefront (or half of one) per frame
 }
 
 template <int LOG2N, bool ALIGNED, int SPEC>
 static hipError_t run_stft_tf(const zafx_plan& pl, const float* x, float2* out, int64_t n_clips, int64_t n_samples, int T) {
-    constexpr int LOG2E = default_log2e(LOG2N);
+    constexpr int LOG2E = tf_log2e(LOG2N);
     using C = FftCfg<LOG2N, LOG2E>;
-    constexpr size_t SMEM = (size_t)(kTfWaves * C::PITCH + C::TW + C::N + C::N / 2 + 1) * 8;
+    constexpr int NT = tf_threads(LOG2N), SLOTS = NT / C::P;
+    constexpr size_t SMEM = (size_t)(SLOTS * C::PITCH + C::TW + C::N + C::N / 2 + 1) * 8;
     static_assert(SMEM <= (size_t)kMaxLdsBytes, "frame-major STFT tables + buffers exceed LDS");
     auto kern = k_stft_tf<LOG2N, LOG2E, ALIGNED, SPEC>;
     if (hipError_t e = ensure_dynamic_lds(reinterpret_cast<const void*>(kern), pl.device, SMEM); e != hipSuccess) return e;
     const long long total = (long long)T * n_clips;
     if (total <= 0) return hipSuccess;
     const int per_cu = (int)std::min<size_t>(2, (size_t)kMaxLdsBytes / SMEM);
-    const long long grid = std::min<long long>((total + kTfWaves - 1) / kTfWaves, (long long)pl.n_cus * std::max(per_cu, 1));
-    hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(kTfWaves * 64), SMEM, pl.stream, x, pl.d_window, pl.d_tw_pass, pl.d_tw_aux, out,
-                       (long long)n_samples, pl.H, T, total);
+    const long long grid = std::min<long long>((total + SLOTS - 1) / SLOTS, (long long)pl.n_cus * std::max(per_cu, 1));
+    hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(NT), SMEM, pl.stream, x, pl.d_window, LOG2E == 5 ? pl.d_tw_r32 : pl.d_tw_pass,
+                       pl.d_tw_aux, out, (long long)n_samples, pl.H, T, total);
     return hipGetLastError();
 }
 

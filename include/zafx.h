@@ -104,7 +104,13 @@ typedef struct zafx_params {
     int32_t octave_resolution; /* CHROMA                                                        */
     int32_t spectrum;          /* enum zafx_spectrum (STFT / ISTFT); 0 = reference contract     */
     int32_t precision;         /* enum zafx_precision (STFT / ISTFT); 0 = float32               */
-    int32_t reserved[5];
+    int32_t row_align;         /* ZAFX_LAYOUT_FT only: every row of the 2-D (F, T) array starts at a multiple of this many
+                                  elements, i.e. the row pitch is T rounded up (zafx_plan_row_pitch).  0 / 1 = compact,
+                                  the reference's own memory order.  16 (complex64) / 32 (float32) put every row on a
+                                  128-byte line whatever T is -- the reference-layout STFT store runs at full rate only
+                                  then (T = 433 compact: 2.1x slower than T = 432; padded: the same).  Power of two
+                                  <= 1024.  The padding elements are never written (forward) nor used (inverse).     */
+    int32_t reserved[4];
 } zafx_params;
 
 /* ---- library / device ------------------------------------------------------------ */
@@ -134,6 +140,10 @@ int zafx_plan_set_constant(zafx_plan* plan, int which, const void* host, size_t 
 /* Output geometry for `n_in` (samples per clip for forward kinds, frames T for inverse
  * kinds): dims[0] = rows F (or samples L), dims[1] = frames T (or 1). */
 int zafx_plan_out_dims(const zafx_plan* plan, int64_t n_in, int64_t dims[2]);
+/* Elements between the starts of consecutive rows of the plan's 2-D array for `n_in` (as above): T for compact
+ * plans, T rounded up to params.row_align otherwise; the array then holds clips x F x pitch elements.  For
+ * ZAFX_LAYOUT_TF and ZAFX_LINEAR plans this is the (contiguous) row length itself. */
+int zafx_plan_row_pitch(const zafx_plan* plan, int64_t n_in, int64_t* pitch);
 /* Enqueue the transform of n_clips clips on the plan's stream (asynchronous). */
 int zafx_execute(zafx_plan* plan, const void* d_in, void* d_out, int64_t n_clips, int64_t n_in);
 int zafx_sync(zafx_plan* plan);

@@ -34,7 +34,7 @@ def test_library_exports_every_declared_symbol(built_library):
 
 def test_params_struct_layout(built_library):
     from zafx import _lib
-    assert ctypes.sizeof(_lib.ZafxParams) == 16 * 4   # 11 fields + 5 reserved int32
+    assert ctypes.sizeof(_lib.ZafxParams) == 16 * 4   # 12 fields + 4 reserved int32
 
 
 def test_errors_are_reported_not_swallowed(built_library):

@@ -676,3 +676,85 @@ def test_reference_self_checks(zafx):
     ham = zafx.hamming(wl)
     rec = zafx.istft(zafx.stft(sig, ham, wl // 2), ham, wl // 2)[: len(sig)]
     assert np.max(np.abs(rec - sig)) < TOL_FFT
+
+
+# ------------------------------------------------------------------ padded rows (row_align)
+def _run_padded(zafx, fwd_c, fwd_p, inv_c, inv_p, x, n_in_is_samples=True):
+    """Forward then inverse through a compact and a padded plan pair; the padded arrays carry NaN in their padding."""
+    b, n = x.shape
+    T = fwd_c.out_dims(n)[1]
+    pitch = fwd_p.row_pitch(n)
+    assert pitch >= T and pitch % fwd_p.row_align == 0 and pitch - T < fwd_p.row_align
+    assert fwd_p.out_shape(b, n) == fwd_c.out_shape(b, n)[:2] + (pitch,)
+    d_x = zafx.DeviceBuffer.from_host(x)
+    d_c = zafx.DeviceBuffer(fwd_c.out_shape(b, n), fwd_c.out_dtype)
+    sentinel = np.full(fwd_p.out_shape(b, n), np.nan, dtype=fwd_p.out_dtype)
+    d_p = zafx.DeviceBuffer.from_host(sentinel)
+    fwd_c.execute(d_x, d_c, b, n)
+    fwd_c.sync()
+    fwd_p.execute(d_x, d_p, b, n)
+    fwd_p.sync()
+    compact, padded = d_c.download(), d_p.download()
+    assert np.array_equal(padded[:, :, :T], compact)           # same arithmetic, other addresses
+    assert np.isnan(padded[:, :, T:]).all()                    # the padding is never written
+    if inv_c is None:
+        return
+    assert inv_p.row_pitch(T) == pitch
+    d_yc = zafx.DeviceBuffer(inv_c.out_shape(b, T), inv_c.out_dtype)
+    d_yp = zafx.DeviceBuffer(inv_p.out_shape(b, T), inv_p.out_dtype)
+    inv_c.execute(d_c, d_yc, b, T)
+    inv_c.sync()
+    inv_p.execute(d_p, d_yp, b, T)                             # NaN padding must not reach the output
+    inv_p.sync()
+    yc, yp = d_yc.download(), d_yp.download()
+    # (the padded plan may take the wider-gather variant of the kernel: same frames, other rounding order)
+    assert yc.shape == yp.shape and np.isfinite(yp).all() and (yc.size == 0 or relerr(yp, yc) <= 2e-6)
+
+
+@pytest.mark.parametrize("wl,hop,n,kw", [
+    (2048, 1024, 16 * 1024 * 5 + 1024, {}),                    # odd and even frame counts on the persistent kernels
+    (2048, 1024, 70001, {}),
+    (2048, 512, 50001, {"onesided": True}),
+    (1024, 512, 33333, {}),
+    (256, 64, 9999, {"onesided": True}),
+    (4096, 2048, 70001, {}),                                   # generic one-workgroup-per-tile kernels
+    (64, 32, 1000, {}),
+    (2048, 1024, 40001, {"f64": True}),
+])
+def test_row_align_stft_istft(zafx, wl, hop, n, kw):
+    ham = zafx.hamming(wl)
+    dtype = np.float64 if kw.get("f64") else np.float32
+    x = np.stack([synth_clip(7, c, n) for c in range(3)]).astype(dtype)
+    for align in (16, 2):
+        _run_padded(zafx, zafx.stft_plan(ham, hop, **kw), zafx.stft_plan(ham, hop, row_align=align, **kw),
+                    zafx.istft_plan(ham, hop, **kw), zafx.istft_plan(ham, hop, row_align=align, **kw), x)
+
+
+@pytest.mark.parametrize("wl,n", [(2048, 70001), (2048, 1024 * 33), (512, 20001), (8192, 70001), (64, 1000)])
+def test_row_align_mdct_imdct(zafx, wl, n):
+    kbd = zafx.kaiser_bessel_derived(wl)
+    x = np.stack([synth_clip(7, c, n) for c in range(3)]).astype(np.float32)
+    for align in (32, 4):
+        _run_padded(zafx, zafx.mdct_plan(kbd), zafx.mdct_plan(kbd, row_align=align),
+                    zafx.mdct_plan(kbd, inverse=True), zafx.mdct_plan(kbd, inverse=True, row_align=align), x)
+
+
+def test_row_align_mel_cqt_and_host_path(zafx):
+    ham = zafx.hamming(2048)
+    fb = zafx.melfilterbank(44100, 2048, 128)
+    x = np.stack([synth_clip(7, c, 50001) for c in range(2)]).astype(np.float32)
+    _run_padded(zafx, zafx.mel_plan(ham, 1024, fb), zafx.mel_plan(ham, 1024, fb, row_align=32), None, None, x)
+    _run_padded(zafx, zafx.mel_plan(ham, 1024, fb, 20), zafx.mel_plan(ham, 1024, fb, 20, row_align=32), None, None, x)
+    ck = zafx.cqtkernel(44100, 24, 55, 3520)
+    _run_padded(zafx, zafx.cqt_plan(44100, 25, ck), zafx.cqt_plan(44100, 25, ck, row_align=32), None, None, x)
+    _run_padded(zafx, zafx.cqt_plan(44100, 25, ck, 24), zafx.cqt_plan(44100, 25, ck, 24, row_align=32), None, None, x)
+    # host-array path: compact arrays in and out whatever the device pitch is
+    p_c, p_p = zafx.stft_plan(ham, 1024), zafx.stft_plan(ham, 1024, row_align=16)
+    s_c, s_p = p_c.run_host(x, x.shape[1]), p_p.run_host(x, x.shape[1])
+    assert s_p.shape == s_c.shape and np.array_equal(s_c, s_p)
+    i_c, i_p = zafx.istft_plan(ham, 1024), zafx.istft_plan(ham, 1024, row_align=16)
+    assert np.array_equal(i_c.run_host(s_c, s_c.shape[2]), i_p.run_host(s_c, s_c.shape[2]))
+    with pytest.raises(ValueError):
+        zafx.stft_plan(ham, 1024, layout="TF", row_align=16)
+    with pytest.raises(ValueError):
+        zafx.stft_plan(ham, 1024, row_align=24)

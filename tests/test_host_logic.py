@@ -158,3 +158,14 @@ def test_dct_dst_matrices_match_reference(golden):
         zafx.dct_matrix(8, 5)
     with pytest.raises(ValueError):
         zafx.dct(np.zeros((2, 8)), 2)
+
+
+def test_row_align_validation():
+    """row_align is checked before any device call (the C-ABI repeats the check for other bindings)."""
+    from zafx import core
+    for bad in (3, 24, -2, 2048):
+        with pytest.raises(ValueError):
+            core._as_row_align(bad, "FT")
+    with pytest.raises(ValueError):
+        core._as_row_align(16, "TF")
+    assert core._as_row_align(0, "TF") == 0 and core._as_row_align(None, "FT") == 0 and core._as_row_align(16, "FT") == 16

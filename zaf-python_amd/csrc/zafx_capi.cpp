@@ -364,6 +364,10 @@ int zafx_plan_create(zafx_plan** out, int device, int kind, const zafx_params* p
     if (params->precision != ZAFX_PRECISION_F32 && params->precision != ZAFX_PRECISION_F64) return fail_msg("bad precision");
     if (params->precision == ZAFX_PRECISION_F64 && kind != ZAFX_STFT && kind != ZAFX_ISTFT)
         return fail_msg("ZAFX_PRECISION_F64 is available for ZAFX_STFT / ZAFX_ISTFT only");
+    if (params->row_align < 0 || params->row_align > 1024 || (params->row_align & (params->row_align - 1)))
+        return fail_msg("row_align must be 0 or a power of two <= 1024");
+    if (params->row_align > 1 && (params->layout != ZAFX_LAYOUT_FT || kind == ZAFX_LINEAR))
+        return fail_msg("row_align applies to the 2-D arrays of ZAFX_LAYOUT_FT plans only");
     {
         int n_dev = 0;
         ZAFX_HIP(hipGetDeviceCount(&n_dev));
@@ -608,6 +612,21 @@ int zafx_plan_out_dims(const zafx_plan* pl, int64_t n_in, int64_t dims[2]) {
             dims[0] = pl->prm.n_filters; dims[1] = 1; return 0;
     }
     return fail_msg("unknown plan kind");
+}
+
+int zafx_plan_row_pitch(const zafx_plan* pl, int64_t n_in, int64_t* pitch) {
+    if (!pl || !pitch) return fail_msg("null argument");
+    int64_t dims[2];
+    if (int rc = zafx_plan_out_dims(pl, n_in, dims)) return rc;
+    switch (pl->kind) {
+        case ZAFX_ISTFT:   // the 2-D side is the input: n_in = T
+            *pitch = pl->layout == ZAFX_LAYOUT_FT ? row_pitch(*pl, n_in)
+                                                  : (pl->prm.spectrum != ZAFX_SPECTRUM_TWO_SIDED ? pl->W / 2 + 1 : pl->W);
+            return 0;
+        case ZAFX_IMDCT: *pitch = pl->layout == ZAFX_LAYOUT_FT ? row_pitch(*pl, n_in) : pl->W / 2; return 0;
+        case ZAFX_LINEAR: *pitch = dims[0]; return 0;
+        default: *pitch = pl->layout == ZAFX_LAYOUT_FT ? row_pitch(*pl, dims[1]) : dims[0]; return 0;
+    }
 }
 
 int zafx_execute(zafx_plan* pl, const void* d_in, void* d_out, int64_t n_clips, int64_t n_in) {

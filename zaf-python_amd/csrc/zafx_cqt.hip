@@ -37,7 +37,7 @@ template <int LOG2N, int LOG2E, bool ALIGNED>
 __global__ __launch_bounds__(fft_threads(LOG2N, LOG2E)) void k_cqt(
     const float* __restrict__ x, const float2* __restrict__ twp, const float2* __restrict__ tws,
     const int4* __restrict__ chunks, const int* __restrict__ chunk_ptr, const int* __restrict__ slots, const float2* __restrict__ values, float* __restrict__ out,
-    long long n_samples, int step, int left_pad, int T, int tiles, int n_bins, int chroma_res, int layout, int n_chunks,
+    long long n_samples, int step, int left_pad, int T, int TP, int tiles, int n_bins, int chroma_res, int layout, int n_chunks,
     int k_lo, int k_hi, int k_special, int nnz) {
     using C = FftCfg<LOG2N, LOG2E>;
     using G = CqtCfg<LOG2N, LOG2E>;
@@ -207,7 +207,7 @@ __global__ __launch_bounds__(fft_threads(LOG2N, LOG2E)) void k_cqt(
             if (jj >= nvalid) continue;
             float acc = 0.f;
             for (int r = ch; r < n_bins; r += chroma_res) acc += __builtin_amdgcn_sqrtf(tile[r * FW + jj]);   // zaf.py:696-698
-            if (layout == ZAFX_LAYOUT_FT) out[((long long)clip * chroma_res + ch) * T + t0 + jj] = acc;
+            if (layout == ZAFX_LAYOUT_FT) out[((long long)clip * chroma_res + ch) * TP + t0 + jj] = acc;   // TP = row pitch (>= T)
             else out[((long long)clip * T + t0 + jj) * chroma_res + ch] = acc;
         }
     } else {
@@ -215,7 +215,7 @@ __global__ __launch_bounds__(fft_threads(LOG2N, LOG2E)) void k_cqt(
             const int r = idx / FW, jj = idx % FW;
             if (jj >= nvalid) continue;
             const float val = __builtin_amdgcn_sqrtf(tile[idx]);
-            if (layout == ZAFX_LAYOUT_FT) out[((long long)clip * n_bins + r) * T + t0 + jj] = val;
+            if (layout == ZAFX_LAYOUT_FT) out[((long long)clip * n_bins + r) * TP + t0 + jj] = val;
             else out[((long long)clip * T + t0 + jj) * n_bins + r] = val;
         }
     }
@@ -244,7 +244,7 @@ static hipError_t run_cqt(const zafx_plan& pl, const float* x, float* out, int64
     const long long blocks = (long long)tiles * n_clips;
     if (blocks <= 0) return hipSuccess;
     hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(C::P), smem, pl.stream, x, pl.d_tw_pass, pl.d_tw_aux, pl.d_chunks, pl.d_chunk_ptr, pl.d_slots,
-                       pl.d_values, out, (long long)n_samples, pl.H, left, T, tiles, pl.prm.n_bins,
+                       pl.d_values, out, (long long)n_samples, pl.H, left, T, (int)row_pitch(pl, T), tiles, pl.prm.n_bins,
                        pl.kind == ZAFX_CHROMA ? pl.prm.octave_resolution : 0, pl.layout, pl.n_chunks, pl.cqt_k_lo, pl.cqt_k_hi,
                        pl.cqt_k_special, std::max(pl.nnz, 1));
     return hipGetLastError();

@@ -48,7 +48,7 @@ __device__ double2* fft_lds(double2* a, double2* b, int log2n, const double2* __
 // zaf.py:112-139 for one frame per workgroup
 __global__ __launch_bounds__(kThreads) void k_stft_f64(
     const double* __restrict__ x, const double* __restrict__ win, const double2* __restrict__ tw, const double2* __restrict__ tws,
-    double2* __restrict__ out, long long n_samples, int hop, int T, int log2n, int layout, int spec) {
+    double2* __restrict__ out, long long n_samples, int hop, int T, int TP, int log2n, int layout, int spec) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     const int N = 1 << log2n, W = 2 * N, rows = spec ? N + 1 : W;
     const bool one = spec != 0;
@@ -68,8 +68,8 @@ __global__ __launch_bounds__(kThreads) void k_stft_f64(
     __syncthreads();
     const double2* z = fft_lds(a, b, log2n, tw);
     // real split: X[k] = E + t_k O, X[N-k] = conj(E - t_k O)
-    const long long stride = layout == ZAFX_LAYOUT_FT ? T : 1;
-    const long long base = layout == ZAFX_LAYOUT_FT ? clip * rows * T + t : (clip * T + t) * rows;
+    const long long stride = layout == ZAFX_LAYOUT_FT ? TP : 1;   // TP = row pitch (>= T)
+    const long long base = layout == ZAFX_LAYOUT_FT ? clip * rows * TP + t : (clip * T + t) * rows;
     auto put = [&](long long row, double2 v) {   // complex, |X| or |X|^2 by spectrum kind
         if (spec >= ZAFX_SPECTRUM_MAGNITUDE) {
             const double pw = v.x * v.x + v.y * v.y;
@@ -104,7 +104,7 @@ __global__ __launch_bounds__(kThreads) void k_stft_f64(
 // real(ifft(X)) of one frame per workgroup (zaf.py:223), W samples into the scratch, unscaled by 2 W
 __global__ __launch_bounds__(kThreads) void k_ifft_frames_f64(
     const double2* __restrict__ spec, const double2* __restrict__ tw, const double2* __restrict__ tws, double* __restrict__ frames,
-    int T, int log2n, int layout, int one) {
+    int T, int TP, int log2n, int layout, int one) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     const int N = 1 << log2n, W = 2 * N, rows = one ? N + 1 : W;
     double2* a = reinterpret_cast<double2*>(smem_raw);
@@ -112,8 +112,8 @@ __global__ __launch_bounds__(kThreads) void k_ifft_frames_f64(
     const long long g = blockIdx.x;
     const long long clip = g / T;
     const int t = (int)(g - clip * T);
-    const long long stride = layout == ZAFX_LAYOUT_FT ? T : 1;
-    const double2* sp = layout == ZAFX_LAYOUT_FT ? spec + clip * rows * T + t : spec + (clip * T + t) * rows;
+    const long long stride = layout == ZAFX_LAYOUT_FT ? TP : 1;
+    const double2* sp = layout == ZAFX_LAYOUT_FT ? spec + clip * rows * TP + t : spec + (clip * T + t) * rows;
     // packed half-length spectrum of the Hermitian part of X, re/im swapped so that a FORWARD transform inverts
     for (int k = threadIdx.x; k < N / 2; k += kThreads) {
         if (k == 0) {
@@ -172,7 +172,7 @@ hipError_t launch_stft_f64(const zafx_plan& pl, const double* x, double2* out, i
     auto kern = k_stft_f64;
     if (hipError_t e = ensure_dynamic_lds(reinterpret_cast<const void*>(kern), pl.device, smem); e != hipSuccess) return e;
     hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(kThreads), smem, pl.stream, x, pl.d_window64, pl.d_tw64, pl.d_tws64, out,
-                       (long long)n_samples, pl.H, T, pl.log2nf, pl.layout, pl.prm.spectrum);
+                       (long long)n_samples, pl.H, T, (int)row_pitch(pl, T), pl.log2nf, pl.layout, pl.prm.spectrum);
     return hipGetLastError();
 }
 
@@ -192,7 +192,7 @@ hipError_t launch_istft_f64(zafx_plan& pl, const double2* spec, double* y, int64
     auto kern = k_ifft_frames_f64;
     if (hipError_t e = ensure_dynamic_lds(reinterpret_cast<const void*>(kern), pl.device, smem); e != hipSuccess) return e;
     hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(kThreads), smem, pl.stream, spec, pl.d_tw64, pl.d_tws64, pl.d_scratch64, T,
-                       pl.log2nf, pl.layout, pl.prm.spectrum == ZAFX_SPECTRUM_ONE_SIDED ? 1 : 0);
+                       (int)row_pitch(pl, T), pl.log2nf, pl.layout, pl.prm.spectrum == ZAFX_SPECTRUM_ONE_SIDED ? 1 : 0);
     if (hipError_t e = hipGetLastError(); e != hipSuccess) return e;
     const long long total = (long long)n_clips * out_len;
     const long long grid = std::min<long long>((total + kThreads - 1) / kThreads, (long long)pl.n_cus * 32);

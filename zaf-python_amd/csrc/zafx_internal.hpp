@@ -84,6 +84,13 @@ struct zafx_plan {
 namespace zafx {
 
 // Every launcher enqueues on plan.stream and returns hipGetLastError().
+// Frames between the starts of consecutive rows of a plan's (F, T) array: T rounded up to prm.row_align elements
+// (reference-layout plans only; 0 / 1 = compact, the reference's own memory order).
+inline int64_t row_pitch(const zafx_plan& pl, int64_t T) {
+    const int64_t a = pl.prm.row_align;
+    return (pl.layout == ZAFX_LAYOUT_FT && a > 1) ? (T + a - 1) / a * a : T;
+}
+
 hipError_t launch_stft(const zafx_plan& pl, const float* x, float2* out, int64_t n_clips, int64_t n_samples, int T);
 hipError_t launch_istft(const zafx_plan& pl, const float2* spec, float* y, int64_t n_clips, int T, int64_t out_len);
 hipError_t launch_stft_f64(const zafx_plan& pl, const double* x, double2* out, int64_t n_clips, int64_t n_samples, int T);

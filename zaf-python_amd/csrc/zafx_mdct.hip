@@ -41,7 +41,7 @@ __device__ __forceinline__ int fidx(int f) { return 2 * phys(f >> 1) + (f & 1); 
 template <int LOG2NF, int LOG2E, int FPB, int LAYOUT>
 __global__ __launch_bounds__(FPB * fft_threads(LOG2NF, LOG2E)) void k_mdct(
     const float* __restrict__ x, const float* __restrict__ win, const float2* __restrict__ twp,
-    const float2* __restrict__ tw8, float* __restrict__ out, long long n_samples, int T, int tiles) {
+    const float2* __restrict__ tw8, float* __restrict__ out, long long n_samples, int T, int TP, int tiles) {
     using C = FftCfg<LOG2NF, LOG2E>;
     using G = MdctCfg<LOG2NF, LOG2E, FPB>;
     constexpr int NF = G::NF, M = G::M, W = G::W, P = C::P, E = C::E, NT = G::NT;
@@ -101,11 +101,11 @@ __global__ __launch_bounds__(FPB * fft_threads(LOG2NF, LOG2E)) void k_mdct(
         const int tt = tid % FPB, fq = tid / FPB;
         if (t0 + tt >= T) return;
         const float2* fb = frames + tt * C::PITCH;
-        float* o = out + (long long)clip * M * T + (t0 + tt);
+        float* o = out + (long long)clip * M * TP + (t0 + tt);   // TP = row pitch (>= T)
         for (int f = fq; f < M; f += P) {
             const int k = (f & 1) ? (M - 1 - f) >> 1 : f >> 1;
             const float2 yk = cmul(fb[phys(k)], tw8[k]);
-            o[(long long)f * T] = (f & 1) ? -yk.y : yk.x;
+            o[(long long)f * TP] = (f & 1) ? -yk.y : yk.x;
         }
     }
 }
@@ -134,7 +134,7 @@ struct MdctPCfg {
 template <int LOG2NF, int LOG2E, bool ALIGNED, int NSLOT>
 __global__ __launch_bounds__(NSLOT * 64) void k_mdct_ft32(
     const float* __restrict__ x, const float4* __restrict__ wfold, const float2* __restrict__ twp,
-    const float2* __restrict__ tw8, float* __restrict__ out, long long n_samples, int T, int tiles, int total_tiles) {
+    const float2* __restrict__ tw8, float* __restrict__ out, long long n_samples, int T, int TP, int tiles, int total_tiles) {
     using C = FftCfg<LOG2NF, LOG2E>;
     constexpr int NF = C::N, M = 2 * NF, W = 4 * NF, P = C::P, E = C::E, FPB = kMdctTile, NT = NSLOT * P;
     constexpr int FPW = FPB / NSLOT;                    // frames per wave and tile
@@ -151,7 +151,7 @@ __global__ __launch_bounds__(NSLOT * 64) void k_mdct_ft32(
     lds_barrier();
     const int slot = tid / P, p = tid % P;
     const int tp = tid % 16, fq = tid / 16;
-    const bool pair_ok = (T % 2 == 0) && (reinterpret_cast<uintptr_t>(out) % 8 == 0);
+    const bool pair_ok = (TP % 2 == 0) && (reinterpret_cast<uintptr_t>(out) % 8 == 0);   // TP = row pitch (>= T)
     const bool lane_loads = p < NU;
 
     // A frame's W = 4 NF samples are fetched as 16-byte pieces.  Group u takes four of them,
@@ -247,7 +247,7 @@ __global__ __launch_bounds__(NSLOT * 64) void k_mdct_ft32(
             asm volatile("" : "+v"(fqo));
             const float2* ba = frames + (2 * tp) * C::PITCH;
             const float2* bb = ba + C::PITCH;
-            float* o = out + (long long)clip * M * T + ta;
+            float* o = out + (long long)clip * M * TP + ta;
             const bool two = ta + 1 < T;
 #pragma unroll 4
             for (int f = fqo; f < M; f += NT / 16) {
@@ -255,7 +255,7 @@ __global__ __launch_bounds__(NSLOT * 64) void k_mdct_ft32(
                 const float2 g = g_l[k];
                 const float2 ya = cmul(ba[phys(k)], g), yb = cmul(bb[phys(k)], g);
                 const float va = (f & 1) ? -ya.y : ya.x, vb = (f & 1) ? -yb.y : yb.x;
-                float* dst = o + (long long)f * T;
+                float* dst = o + (long long)f * TP;
                 if (pair_ok && two) *reinterpret_cast<float2*>(dst) = make_float2(va, vb);
                 else {
                     dst[0] = va;
@@ -280,7 +280,7 @@ __global__ __launch_bounds__(NSLOT * 64) void k_mdct_ft32(
 template <int LOG2NF, int LOG2E, int FPB, int NSLOT, int LAYOUT>
 __global__ __launch_bounds__(NSLOT * fft_threads(LOG2NF, LOG2E)) void k_imdct(
     const float* __restrict__ coefs, const float* __restrict__ win, const float2* __restrict__ twp,
-    const float2* __restrict__ tw8g, float* __restrict__ y, int T, long long out_len, int tiles, int segs, int seg_tiles,
+    const float2* __restrict__ tw8g, float* __restrict__ y, int T, int TP, long long out_len, int tiles, int segs, int seg_tiles,
     int total_units) {
     using C = FftCfg<LOG2NF, LOG2E>;
     constexpr int NF = C::N, M = 2 * NF, P = C::P, E = C::E, NT = NSLOT * P;
@@ -297,7 +297,7 @@ __global__ __launch_bounds__(NSLOT * fft_threads(LOG2NF, LOG2E)) void k_imdct(
     for (int i = tid; i < 4 * NF; i += NT) win_l[i] = win[i];
     lds_barrier();
     const float gain = 2.f / (float)M;
-    const bool vec4 = LAYOUT == ZAFX_LAYOUT_FT && FPB % 4 == 0 && NT % (FPB / 4) == 0 && NF >= NT / (FPB / 4) && T % 4 == 0 &&
+    const bool vec4 = LAYOUT == ZAFX_LAYOUT_FT && FPB % 4 == 0 && NT % (FPB / 4) == 0 && NF >= NT / (FPB / 4) && TP % 4 == 0 &&
                       reinterpret_cast<uintptr_t>(coefs) % 16 == 0;
 
     PROF_INIT(g_prof_imdct);
@@ -328,13 +328,13 @@ __global__ __launch_bounds__(NSLOT * fft_threads(LOG2NF, LOG2E)) void k_imdct(
         constexpr int LPR = FPB / 4;
         const int fs = (tid % LPR) * 4, mq = tid / LPR;
         const int t = t_first + fs;
-        if (t < T && fs + 3 >= first_needed) {   // T % 4 == 0: the four frames exist together
+        if (t < T && fs + 3 >= first_needed) {   // pitch % 4 == 0: the four frames lie in the row (those past T are not used)
             float2* fb = frames + fs * C::PITCH;
-            const float* cp = coefs + (long long)clip * M * T + t;
+            const float* cp = coefs + (long long)clip * M * TP + t;
 #pragma unroll 2
             for (int m = mq; m < NF; m += NT / LPR) {
-                const float4 re = *reinterpret_cast<const float4*>(cp + (long long)(2 * m) * T);
-                const float4 im = *reinterpret_cast<const float4*>(cp + (long long)(M - 1 - 2 * m) * T);
+                const float4 re = *reinterpret_cast<const float4*>(cp + (long long)(2 * m) * TP);
+                const float4 im = *reinterpret_cast<const float4*>(cp + (long long)(M - 1 - 2 * m) * TP);
                 const float2 g = tw8[m];
                 fb[phys(m)] = cmul(make_float2(re.x, im.x), g);
                 fb[C::PITCH + phys(m)] = cmul(make_float2(re.y, im.y), g);
@@ -347,11 +347,11 @@ __global__ __launch_bounds__(NSLOT * fft_threads(LOG2NF, LOG2E)) void k_imdct(
         const int t = t_first + fs;
         if (t < T && fs >= first_needed) {
             float2* fb = frames + fs * C::PITCH;
-            const float* cp = coefs + (long long)clip * M * T + t;
+            const float* cp = coefs + (long long)clip * M * TP + t;
 #pragma unroll 4
             for (int m = mq; m < NF; m += NT / FPB) {
-                const float re = cp[(long long)(2 * m) * T];
-                const float im = cp[(long long)(M - 1 - 2 * m) * T];
+                const float re = cp[(long long)(2 * m) * TP];
+                const float im = cp[(long long)(M - 1 - 2 * m) * TP];
                 fb[phys(m)] = cmul(make_float2(re, im), tw8[m]);
             }
         }
@@ -483,7 +483,7 @@ static hipError_t run_mdct_p(const zafx_plan& pl, const float* x, float* out, in
     const int per_cu = (int)std::min<size_t>(2, (size_t)kMaxLdsBytes / G::SMEM);
     const long long grid = std::min<long long>(total, (long long)pl.n_cus * std::max(per_cu, 1));
     hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(G::NSLOT * 64), G::SMEM, pl.stream, x, pl.d_wfold, pl.d_tw_pass, pl.d_tw_aux, out,
-                       (long long)n_samples, T, tiles, (int)total);
+                       (long long)n_samples, T, (int)row_pitch(pl, T), tiles, (int)total);
     return hipGetLastError();
 }
 
@@ -501,7 +501,7 @@ static hipError_t run_mdct(const zafx_plan& pl, const float* x, float* out, int6
         const long long blocks = (long long)tiles * n_clips;
         if (blocks <= 0) return hipSuccess;
         hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(G::NT), G::SMEM_FWD, pl.stream, x, pl.d_window, pl.d_tw_pass, pl.d_tw_aux, out,
-                           (long long)n_samples, T, tiles);
+                           (long long)n_samples, T, (int)row_pitch(pl, T), tiles);
         return hipGetLastError();
     }
 }
@@ -543,7 +543,7 @@ static hipError_t run_imdct(const zafx_plan& pl, const float* coefs, float* y, i
     const long long units = (long long)n_clips * segs;
     const long long grid = std::min<long long>(units, max_grid);
     hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(NSLOT * C::P), SMEM, pl.stream, coefs, pl.d_window, pl.d_tw_pass, pl.d_tw_aux, y, T,
-                       (long long)out_len, tiles, segs, seg_tiles, (int)units);
+                       (int)row_pitch(pl, T), (long long)out_len, tiles, segs, seg_tiles, (int)units);
     return hipGetLastError();
 }
 

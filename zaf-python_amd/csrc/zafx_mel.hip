@@ -87,7 +87,7 @@ __global__ __launch_bounds__(mel_threads(LOG2N, LOG2E)) void k_mel(
     const float2* __restrict__ tws, const float* __restrict__ fb_pack, const int4* __restrict__ fb_items,
     const int* __restrict__ fb_wave_ptr, const int* __restrict__ fb_blk_ptr, int fb_blocks, int fb_nitems,
     const float* __restrict__ dct_pack, const int4* __restrict__ dct_items, const int* __restrict__ dct_wave_ptr,
-    const int* __restrict__ dct_blk_ptr, int dct_blocks, float* __restrict__ out, long long n_samples, int hop, int T,
+    const int* __restrict__ dct_blk_ptr, int dct_blocks, float* __restrict__ out, long long n_samples, int hop, int T, int TP,
     int tiles, int total_tiles, int n_filters, int n_coefs, int mfcc, int layout) {
     using C = FftCfg<LOG2N, LOG2E>;
     using G = MelCfg<LOG2N, LOG2E>;
@@ -227,7 +227,7 @@ __global__ __launch_bounds__(mel_threads(LOG2N, LOG2E)) void k_mel(
             if (mfcc) {
                 slot_ptr(lt0 + blk)[e] = m < n_filters ? logf(val + eps) : 0.f;
             } else if (m < n_filters && t0 + tq < T) {
-                if (layout == ZAFX_LAYOUT_FT) out[((long long)clip * n_filters + m) * T + t0 + tq] = val;
+                if (layout == ZAFX_LAYOUT_FT) out[((long long)clip * n_filters + m) * TP + t0 + tq] = val;   // TP = row pitch (>= T)
                 else out[((long long)clip * T + t0 + tq) * n_filters + m] = val;
             }
         }
@@ -243,7 +243,7 @@ __global__ __launch_bounds__(mel_threads(LOG2N, LOG2E)) void k_mel(
                 for (int it = dct_blk_ptr[blk]; it < dct_blk_ptr[blk + 1]; ++it) val += slot_ptr(dslot0 + it)[e];
                 const int q = 16 * blk + (e >> 4), tq = e & 15;
                 if (q < n_coefs && t0 + tq < T) {
-                    if (layout == ZAFX_LAYOUT_FT) out[((long long)clip * n_coefs + q) * T + t0 + tq] = val;
+                    if (layout == ZAFX_LAYOUT_FT) out[((long long)clip * n_coefs + q) * TP + t0 + tq] = val;
                     else out[((long long)clip * T + t0 + tq) * n_coefs + q] = val;
                 }
             }
@@ -276,7 +276,7 @@ static hipError_t run_mel(const zafx_plan& pl, const float* x, float* out, int64
     const long long grid = std::min<long long>(total, (long long)pl.n_cus * std::max(per_cu, 1));
     hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(G::NT), G::SMEM, pl.stream, x, pl.d_window, LOG2E == 5 ? pl.d_tw_r32 : pl.d_tw_pass, pl.d_tw_aux, pl.fb.d_pack,
                        pl.fb.d_items, pl.fb.d_wave_ptr, pl.fb.d_blk_ptr, pl.fb.n_blocks, pl.fb.n_items, pl.dct.d_pack, pl.dct.d_items,
-                       pl.dct.d_wave_ptr, pl.dct.d_blk_ptr, pl.dct.n_blocks, out, (long long)n_samples, pl.H, T, tiles, (int)total,
+                       pl.dct.d_wave_ptr, pl.dct.d_blk_ptr, pl.dct.n_blocks, out, (long long)n_samples, pl.H, T, (int)row_pitch(pl, T), tiles, (int)total,
                        pl.prm.n_filters, pl.prm.n_coefs, mfcc, pl.layout);
     return hipGetLastError();
 }

@@ -68,7 +68,7 @@ struct StftCfg {
 template <int LOG2N, int LOG2E, int FPB, int LAYOUT, int SPEC>
 __global__ __launch_bounds__(FPB * fft_threads(LOG2N, LOG2E)) void k_stft(
     const float* __restrict__ x, const float* __restrict__ win, const float2* __restrict__ twp,
-    const float2* __restrict__ tws, float2* __restrict__ out, long long n_samples, int hop, int T, int tiles) {
+    const float2* __restrict__ tws, float2* __restrict__ out, long long n_samples, int hop, int T, int TP, int tiles) {
     using C = FftCfg<LOG2N, LOG2E>;
     using S = StftCfg<LOG2N, LOG2E, FPB>;
     constexpr int N = C::N, P = C::P, E = C::E, W = 2 * N, NT = S::NT, ROWS = SPEC ? N + 1 : W;
@@ -134,22 +134,22 @@ __global__ __launch_bounds__(FPB * fft_threads(LOG2N, LOG2E)) void k_stft(
         const int tt = tid % FPB, kq = tid / FPB;
         if (t0 + tt >= T) return;
         const float2* fb = frames + tt * C::PITCH;
-        float2* o = spec_base<SPEC>(out, (long long)clip * ROWS * T + (t0 + tt));
+        float2* o = spec_base<SPEC>(out, (long long)clip * ROWS * TP + (t0 + tt));
         for (int k = kq; k < N / 2; k += P) {
             if (k == 0) {
                 const float2 z0 = fb[0], zc = fb[phys(N / 2)];
                 put_bin<SPEC>(o, 0, make_float2(z0.x + z0.y, 0.f));
-                put_bin<SPEC>(o, (long long)N * T, make_float2(z0.x - z0.y, 0.f));
-                put_bin<SPEC>(o, (long long)(N / 2) * T, cconj(zc));
-                if (SPEC == 0) put_bin<SPEC>(o, (long long)(N + N / 2) * T, zc);
+                put_bin<SPEC>(o, (long long)N * TP, make_float2(z0.x - z0.y, 0.f));
+                put_bin<SPEC>(o, (long long)(N / 2) * TP, cconj(zc));
+                if (SPEC == 0) put_bin<SPEC>(o, (long long)(N + N / 2) * TP, zc);
             } else {
                 float2 xk, xn;
                 split_pair(fb[phys(k)], fb[phys(N - k)], tws[k], xk, xn);
-                put_bin<SPEC>(o, (long long)k * T, xk);
-                put_bin<SPEC>(o, (long long)(N - k) * T, xn);
+                put_bin<SPEC>(o, (long long)k * TP, xk);
+                put_bin<SPEC>(o, (long long)(N - k) * TP, xn);
                 if (SPEC == 0) {
-                    put_bin<SPEC>(o, (long long)(W - k) * T, cconj(xk));
-                    put_bin<SPEC>(o, (long long)(N + k) * T, cconj(xn));
+                    put_bin<SPEC>(o, (long long)(W - k) * TP, cconj(xk));
+                    put_bin<SPEC>(o, (long long)(N + k) * TP, cconj(xn));
                 }
             }
         }
@@ -189,7 +189,7 @@ struct FatCfg {
 template <int LOG2N, int LOG2E, bool ALIGNED, int SPEC>
 __global__ __launch_bounds__(kFatWaves * 64) void k_stft_ft16(
     const float* __restrict__ x, const float* __restrict__ win, const float2* __restrict__ twp,
-    const float2* __restrict__ tws, float2* __restrict__ out, long long n_samples, int hop, int T, int tiles,
+    const float2* __restrict__ tws, float2* __restrict__ out, long long n_samples, int hop, int T, int TP, int tiles,
     int total_tiles) {
     using C = FftCfg<LOG2N, LOG2E>;
     using F = FatCfg<LOG2N, LOG2E>;
@@ -271,23 +271,23 @@ __global__ __launch_bounds__(kFatWaves * 64) void k_stft_ft16(
         prefetch(tl + gridDim.x);   // in flight while this tile is stored
         PROF_MARK(3);
         if (t0 + tt < T) {
-            float2* o = spec_base<SPEC>(out, (long long)clip * ROWS * T + (t0 + tt));
+            float2* o = spec_base<SPEC>(out, (long long)clip * ROWS * TP + (t0 + tt));
             int kqo = kq;   // (opaque at 32 points per thread: the split roots of the 16 iterations are not carried across tiles)
             if constexpr (E >= 32) asm volatile("" : "+v"(kqo));
             for (int k = kqo; k < N / 2; k += NT / FPB) {
                 if (k == 0) {
                     const float2 z0 = fb[0], zc = fb[phys_t<C::PS>(N / 2)];
                     put_bin<SPEC>(o, 0, make_float2(z0.x + z0.y, 0.f));
-                    put_bin<SPEC>(o, (long long)N * T, make_float2(z0.x - z0.y, 0.f));
-                    put_bin<SPEC>(o, (long long)(N / 2) * T, cconj(zc));
-                    if (SPEC == 0) put_bin<SPEC>(o, (long long)(N + N / 2) * T, zc);
+                    put_bin<SPEC>(o, (long long)N * TP, make_float2(z0.x - z0.y, 0.f));
+                    put_bin<SPEC>(o, (long long)(N / 2) * TP, cconj(zc));
+                    if (SPEC == 0) put_bin<SPEC>(o, (long long)(N + N / 2) * TP, zc);
                 } else {
                     float2 xk, xn;
                     split_pair(fb[phys_t<C::PS>(k)], fb[phys_t<C::PS>(N - k)], tws_l[k], xk, xn);
-                    put_bin<SPEC>(o, (long long)k * T, xk);
-                    if (SPEC == 0) put_bin<SPEC>(o, (long long)(W - k) * T, cconj(xk));
-                    put_bin<SPEC>(o, (long long)(N - k) * T, xn);
-                    if (SPEC == 0) put_bin<SPEC>(o, (long long)(N + k) * T, cconj(xn));
+                    put_bin<SPEC>(o, (long long)k * TP, xk);
+                    if (SPEC == 0) put_bin<SPEC>(o, (long long)(W - k) * TP, cconj(xk));
+                    put_bin<SPEC>(o, (long long)(N - k) * TP, xn);
+                    if (SPEC == 0) put_bin<SPEC>(o, (long long)(N + k) * TP, cconj(xn));
                 }
             }
         }
@@ -415,7 +415,7 @@ __device__ __forceinline__ void unsplit_pair(float2 xk, float2 xwk, float2 xnk, 
 template <int LOG2N, int LOG2E, int FPB, int LAYOUT, bool ONE>
 __global__ __launch_bounds__(FPB * fft_threads(LOG2N, LOG2E)) void k_istft(
     const float2* __restrict__ spec, const float2* __restrict__ twp, const float2* __restrict__ tws,
-    float* __restrict__ y, int T, int hop, long long out_len, float scale, int tiles, int owned, int halo) {
+    float* __restrict__ y, int T, int TP, int hop, long long out_len, float scale, int tiles, int owned, int halo) {
     using C = FftCfg<LOG2N, LOG2E>;
     using S = StftCfg<LOG2N, LOG2E, FPB>;
     constexpr int N = C::N, P = C::P, E = C::E, W = 2 * N, NT = S::NT;
@@ -442,7 +442,7 @@ __global__ __launch_bounds__(FPB * fft_threads(LOG2N, LOG2E)) void k_istft(
             constexpr int ROWS = ONE ? N + 1 : W;
             long long base, kstride;
             if constexpr (LAYOUT == ZAFX_LAYOUT_TF) { base = ((long long)clip * T + t) * ROWS; kstride = 1; }
-            else { base = (long long)clip * ROWS * T + t; kstride = T; }
+            else { base = (long long)clip * ROWS * TP + t; kstride = TP; }
             const float2* sp = spec + base;
             for (int k = kq; k < N / 2; k += kstep) {
                 if (k == 0) {
@@ -652,13 +652,13 @@ ZAFX_PROF_ARRAY(g_prof)
 template <int LOG2N, int LOG2E, int DEPTH, bool ONE, int FV>
 __global__ __launch_bounds__(1024) void k_istft_ft16(
     const float2* __restrict__ spec, const float2* __restrict__ twp, const float2* __restrict__ tws,
-    float* __restrict__ y, int T, int hop, long long out_len, float scale, int tiles, int segs, int seg_tiles, int total_units,
-    int halo) {
+    float* __restrict__ y, int T, int TP, int hop, long long out_len, float scale, int tiles, int segs, int seg_tiles,
+    int total_units, int halo) {
     using C = FftCfg<LOG2N, LOG2E>;
     using F = FatCfg<LOG2N, LOG2E>;
     constexpr int N = C::N, P = C::P, E = C::E, W = 2 * N, NT = 1024, FPB = kFatFrames, PITCH = F::PITCH;
     constexpr int ROWS = ONE ? N + 1 : W;      // one-sided input: rows 0..N, X[W-k] = conj X[k]
-    // FV frames per lane and load: 2 = 16-byte loads of two adjacent frames (needs T even).  The CU's
+    // FV frames per lane and load: 2 = 16-byte loads of two adjacent frames (needs an even row pitch).  The CU's
     // vector-memory queue holds ~64 wave-level loads whatever their width, so 16-byte lanes double the
     // bytes in flight (64 KB) and with them the gather rate of a CU that is alone in its load phase.
     constexpr int LPR = FPB / FV;              // lanes per row run
@@ -690,13 +690,13 @@ __global__ __launch_bounds__(1024) void k_istft_ft16(
         it.tile_b = min(it.tile_a + seg_tiles, tiles);
         it.tile = it.tile_a > 0 ? it.tile_a - 1 : 0;
     };
-    auto my_frame_needed = [&](const Tile& it) {   // (FV = 2: T is even, so both frames exist or neither)
+    auto my_frame_needed = [&](const Tile& it) {   // (FV = 2: the pitch is even, so a pair's second frame is in the row; past T it is unused)
         return it.tile * FPB + fs < T && fs + FV - 1 >= (it.tile < it.tile_a ? FPB - halo : 0);
     };
     // Rows k, W-k, N-k, N+k of sweep s (k = 0: rows 0, N/2, N, 3N/2) for my frame(s).  Buffer loads: the
     // clip's descriptor and the sweep's row offsets are wave-uniform (SGPRs), the per-lane part is two
     // 32-bit offsets for the whole tile -- 64-bit flat addresses would cost 8 VGPRs per sweep in flight.
-    const int row_bytes = T * 8;
+    const int row_bytes = TP * 8;   // TP = row pitch in frames (>= T)
     const int v_up = kq * row_bytes + fs * 8, v_down = (KSTEP - kq) * row_bytes + fs * 8;
     struct Src {
         __amdgpu_buffer_rsrc_t rsrc;
@@ -704,7 +704,7 @@ __global__ __launch_bounds__(1024) void k_istft_ft16(
     };
     auto source = [&](const Tile& it) {
         Src src;
-        src.rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float2*>(spec) + (long long)(it.unit / segs) * ROWS * T, 0,
+        src.rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float2*>(spec) + (long long)(it.unit / segs) * ROWS * TP, 0,
                                                      ROWS * row_bytes, 0x00020000);
         src.t_bytes = it.tile * FPB * 8;
         return src;
@@ -881,7 +881,7 @@ static hipError_t run_stft_fat(const zafx_plan& pl, const float* x, float2* out,
     const int per_cu = (int)std::min<size_t>(2, (size_t)kMaxLdsBytes / F::SMEM);
     const long long grid = std::min<long long>(total, (long long)pl.n_cus * std::max(per_cu, 1));
     hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(F::NT), F::SMEM, pl.stream, x, pl.d_window, LOG2E == 5 ? pl.d_tw_r32 : pl.d_tw_pass,
-                       pl.d_tw_aux, out, (long long)n_samples, pl.H, T, tiles, (int)total);
+                       pl.d_tw_aux, out, (long long)n_samples, pl.H, T, (int)row_pitch(pl, T), tiles, (int)total);
     return hipGetLastError();
 }
 
@@ -926,7 +926,7 @@ static hipError_t run_stft(const zafx_plan& pl, const float* x, float2* out, int
         const long long blocks = (long long)tiles * n_clips;
         if (blocks <= 0) return hipSuccess;
         hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(S::NT), S::SMEM, pl.stream, x, pl.d_window, pl.d_tw_pass, pl.d_tw_aux,
-                           out, (long long)n_samples, pl.H, T, tiles);
+                           out, (long long)n_samples, pl.H, T, (int)row_pitch(pl, T), tiles);
         return hipGetLastError();
     }
 }
@@ -952,7 +952,8 @@ static hipError_t run_istft_fat(const zafx_plan& pl, const float2* spec, float* 
     using F = FatCfg<LOG2N, LOG2E>;
     // 16-byte gathers (two adjacent frames per lane) when the rows allow it; see the kernel
     constexpr bool can_vec = LOG2N >= 8;
-    const bool vec = can_vec && T % 2 == 0 && reinterpret_cast<uintptr_t>(spec) % 16 == 0;
+    const int TP = (int)row_pitch(pl, T);
+    const bool vec = can_vec && TP % 2 == 0 && reinterpret_cast<uintptr_t>(spec) % 16 == 0;
     // sweeps streamed together: 8 loads per wave in flight is the measured optimum (profiles/r01_notes.md);
     // a one-sided sweep has 2 loads instead of 4
     constexpr int D1 = ONE ? 4 : 2, D2 = ONE ? 4 : 1;
@@ -974,7 +975,7 @@ static hipError_t run_istft_fat(const zafx_plan& pl, const float2* spec, float* 
     const long long units = (long long)n_clips * segs;
     const float scale = 1.f / (4.f * (float)(1 << LOG2N) * pl.cola_gain);
     const long long grid = std::min<long long>(units, max_grid);
-    hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(nt), F::SMEM, pl.stream, spec, pl.d_tw_pass, pl.d_tw_aux, y, T, pl.H,
+    hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(nt), F::SMEM, pl.stream, spec, pl.d_tw_pass, pl.d_tw_aux, y, T, TP, pl.H,
                        (long long)out_len, scale, tiles, segs, seg_tiles, (int)units, halo);
     return hipGetLastError();
 }
@@ -983,7 +984,7 @@ template <int LOG2N, int LAYOUT, bool ONE>
 static hipError_t run_istft(const zafx_plan& pl, const float2* spec, float* y, int64_t n_clips, int T, int64_t out_len) {
     if constexpr (stft_use_fat(LOG2N, LAYOUT)) {
         // the carry kernel addresses a clip through one buffer descriptor (32-bit byte offsets)
-        if ((long long)(2 << LOG2N) * T * 8 < (1LL << 31)) return run_istft_fat<LOG2N, ONE>(pl, spec, y, n_clips, T, out_len);
+        if ((long long)(2 << LOG2N) * row_pitch(pl, T) * 8 < (1LL << 31)) return run_istft_fat<LOG2N, ONE>(pl, spec, y, n_clips, T, out_len);
     }
     constexpr int LOG2E = default_log2e(LOG2N);
     constexpr int FPB = stft_fpb(LOG2N, ZAFX_LAYOUT_FT);
@@ -1001,8 +1002,8 @@ static hipError_t run_istft(const zafx_plan& pl, const float2* spec, float* y, i
     const long long blocks = (long long)tiles * n_clips;
     if (blocks <= 0 || out_len <= 0) return hipSuccess;
     const float scale = 1.f / (4.f * (float)(1 << LOG2N) * pl.cola_gain);
-    hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(S::NT), S::SMEM, pl.stream, spec, pl.d_tw_pass, pl.d_tw_aux, y, T, pl.H,
-                       (long long)out_len, scale, tiles, owned, halo);
+    hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(S::NT), S::SMEM, pl.stream, spec, pl.d_tw_pass, pl.d_tw_aux, y, T,
+                       (int)row_pitch(pl, T), pl.H, (long long)out_len, scale, tiles, owned, halo);
     return hipGetLastError();
 }
 

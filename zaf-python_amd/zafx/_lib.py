@@ -33,7 +33,8 @@ class ZafxParams(ctypes.Structure):
         ("octave_resolution", ctypes.c_int32),
         ("spectrum", ctypes.c_int32),
         ("precision", ctypes.c_int32),
-        ("reserved", ctypes.c_int32 * 5),
+        ("row_align", ctypes.c_int32),
+        ("reserved", ctypes.c_int32 * 4),
     ]
 
 
@@ -60,6 +61,7 @@ SYMBOLS = {
     "zafx_plan_destroy": (_i, [_vp]),
     "zafx_plan_set_constant": (_i, [_vp, _i, _vp, _sz]),
     "zafx_plan_out_dims": (_i, [_vp, _i64, ctypes.POINTER(_i64)]),
+    "zafx_plan_row_pitch": (_i, [_vp, _i64, ctypes.POINTER(_i64)]),
     "zafx_execute": (_i, [_vp, _vp, _vp, _i64, _i64]),
     "zafx_sync": (_i, [_vp]),
     "zafx_timer_start": (_i, [_vp]),

@@ -177,6 +177,15 @@ _SPECTRA = {False: _lib.SPECTRUM_TWO_SIDED, True: _lib.SPECTRUM_ONE_SIDED, "magn
             "power": _lib.SPECTRUM_POWER}
 
 
+def _as_row_align(row_align, layout):
+    a = int(row_align or 0)
+    if a < 0 or a > 1024 or a & (a - 1):
+        raise ValueError("row_align must be 0 or a power of two <= 1024")
+    if a > 1 and _LAYOUTS[layout] != _lib.LAYOUT_FT:
+        raise ValueError('row_align applies to layout "FT" only')
+    return a
+
+
 def _spectrum_of(onesided):
     try:
         return _SPECTRA[onesided]
@@ -190,7 +199,7 @@ class Plan:
     _FORWARD = (_lib.STFT, _lib.MDCT, _lib.MEL, _lib.MFCC, _lib.CQT, _lib.CHROMA)   # 2-D (frequency x time) outputs
 
     def __init__(self, kind, device=0, window_length=0, step_length=0, layout="FT", n_filters=0, n_coefs=0,
-                 fft_length=0, n_bins=0, octave_resolution=0, onesided=False, f64=False):
+                 fft_length=0, n_bins=0, octave_resolution=0, onesided=False, f64=False, row_align=0):
         self.kind = kind
         self.device = int(device)
         self.layout = _LAYOUTS[layout]
@@ -208,6 +217,8 @@ class Plan:
         prm.spectrum = self.spectrum
         prm.precision = _lib.PRECISION_F64 if f64 else _lib.PRECISION_F32
         self.f64 = bool(f64)
+        self.row_align = _as_row_align(row_align, layout)
+        prm.row_align = self.row_align
         self.params = prm
         h = ctypes.c_void_p()
         _lib.check(_lib.load().zafx_plan_create(ctypes.byref(h), self.device, kind, ctypes.byref(prm)), "zafx_plan_create")
@@ -245,10 +256,17 @@ class Plan:
         _lib.check(_lib.load().zafx_plan_out_dims(self.handle, int(n_in), dims), "zafx_plan_out_dims")
         return int(dims[0]), int(dims[1])
 
+    def row_pitch(self, n_in):
+        """Elements between consecutive rows of the plan's 2-D array (T rounded up to row_align; T for compact plans)."""
+        pitch = ctypes.c_int64()
+        _lib.check(_lib.load().zafx_plan_row_pitch(self.handle, int(n_in), ctypes.byref(pitch)), "zafx_plan_row_pitch")
+        return int(pitch.value)
+
     def out_shape(self, n_clips, n_in):
+        """Shape of the device array execute() writes; with row_align the last axis of an (F, T) array is the pitch."""
         rows, frames = self.out_dims(n_in)
         if self.kind in self._FORWARD:
-            return (n_clips, rows, frames) if self.layout == _lib.LAYOUT_FT else (n_clips, frames, rows)
+            return (n_clips, rows, self.row_pitch(n_in)) if self.layout == _lib.LAYOUT_FT else (n_clips, frames, rows)
         return (n_clips, rows)
 
     @property
@@ -294,6 +312,14 @@ class Plan:
         """Host array in -> device transform -> host array out (PCIe both ways)."""
         array = np.ascontiguousarray(array, dtype=self.in_dtype if self.f64 else None)
         n_clips = array.shape[0]
+        frames = None
+        if self.row_align > 1:   # padded rows on the device, compact arrays on the host side
+            if self.kind in self._FORWARD:
+                frames = self.out_dims(n_in)[1]
+            elif array.ndim == 3:
+                padded = np.zeros(array.shape[:2] + (self.row_pitch(n_in),), dtype=array.dtype)
+                padded[:, :, :array.shape[2]] = array
+                array = padded
         shape = self.out_shape(n_clips, n_in)
         d_in = DeviceBuffer.pooled(array.shape, array.dtype, self.device)
         d_out = DeviceBuffer.pooled(shape, self.out_dtype, self.device)
@@ -302,7 +328,8 @@ class Plan:
             with self.lock:
                 self.execute(d_in, d_out, n_clips, n_in)
                 self.sync()
-            return d_out.download()
+            out = d_out.download()
+            return out if frames is None else out[:, :, :frames]
         finally:
             d_in.release()
             d_out.release()
@@ -440,40 +467,45 @@ def get_precision():
 # ======================================================================================
 # plan factories
 # ======================================================================================
-def stft_plan(window_function, step_length, layout="FT", device=0, onesided=False, f64=False):
+def stft_plan(window_function, step_length, layout="FT", device=0, onesided=False, f64=False, row_align=0):
+    """row_align (every 2-D plan factory): pad the rows of the device (F, T) array to a multiple of this many elements
+    (16 for complex64, 32 for float32 = one 128-byte line) so that the reference-layout kernels run at their aligned
+    rate for any T; Plan.out_shape / Plan.row_pitch give the padded geometry, 0 keeps the reference's compact order."""
     w, h = _as_window(window_function), _as_step(step_length)
     if h > len(w):
         raise ValueError("step_length must not exceed window_length")
-    key = ("stft", device, len(w), h, _LAYOUTS[layout], _spectrum_of(onesided), bool(f64), _digest(w))
+    key = ("stft", device, len(w), h, _LAYOUTS[layout], _spectrum_of(onesided), bool(f64), _as_row_align(row_align, layout), _digest(w))
 
     def make():
-        p = Plan(_lib.STFT, device, window_length=len(w), step_length=h, layout=layout, onesided=onesided, f64=f64)
+        p = Plan(_lib.STFT, device, window_length=len(w), step_length=h, layout=layout, onesided=onesided, f64=f64,
+                 row_align=row_align)
         p.set_window(w)
         return p
     return _cached(key, make)
 
 
-def istft_plan(window_function, step_length, layout="FT", device=0, onesided=False, f64=False):
+def istft_plan(window_function, step_length, layout="FT", device=0, onesided=False, f64=False, row_align=0):
     w, h = _as_window(window_function), _as_step(step_length)
     if h > len(w):
         raise ValueError("step_length must not exceed window_length")
     if onesided not in (False, True):
         raise ValueError("istft takes a complex spectrum: onesided must be False or True")
-    key = ("istft", device, len(w), h, _LAYOUTS[layout], bool(onesided), bool(f64), _digest(w))
+    key = ("istft", device, len(w), h, _LAYOUTS[layout], bool(onesided), bool(f64), _as_row_align(row_align, layout), _digest(w))
 
     def make():
-        p = Plan(_lib.ISTFT, device, window_length=len(w), step_length=h, layout=layout, onesided=onesided, f64=f64)
+        p = Plan(_lib.ISTFT, device, window_length=len(w), step_length=h, layout=layout, onesided=onesided, f64=f64,
+                 row_align=row_align)
         p.set_window(w)
         return p
     return _cached(key, make)
 
 
-def mdct_plan(window_function, layout="FT", device=0, inverse=False):
+def mdct_plan(window_function, layout="FT", device=0, inverse=False, row_align=0):
     w = _as_window(window_function)
-    key = ("imdct" if inverse else "mdct", device, len(w), _LAYOUTS[layout], _digest(w))
+    key = ("imdct" if inverse else "mdct", device, len(w), _LAYOUTS[layout], _as_row_align(row_align, layout), _digest(w))
 
     def make():
-        p = Plan(_lib.IMDCT if inverse else _lib.MDCT, device, window_length=len(w), layout=layout)
+        p = Plan(_lib.IMDCT if inverse else _lib.MDCT, device, window_length=len(w), layout=layout, row_align=row_align)
         p.set_window(w)
         return p
     return _cached(key, make)
@@ -488,7 +520,7 @@ def _dense_filterbank(mel_filterbank, window_length):
     return fb
 
 
-def mel_plan(window_function, step_length, mel_filterbank, number_coefficients=None, layout="FT", device=0):
+def mel_plan(window_function, step_length, mel_filterbank, number_coefficients=None, layout="FT", device=0, row_align=0):
     w, h = _as_window(window_function), _as_step(step_length)
     if not hasattr(mel_filterbank, "toarray"):
         raise ValueError("mel_filterbank must be a scipy.sparse matrix (as returned by melfilterbank)")
@@ -501,13 +533,13 @@ def mel_plan(window_function, step_length, mel_filterbank, number_coefficients=N
         raise ValueError("number_coefficients must be in [1, number_filters - 1]")
     # the cache key hashes the sparse triplet (a few KB), not the dense matrix (1 MB: 1.8 ms per call)
     csr = mel_filterbank.tocsr()
-    key = ("mfcc" if mfcc else "mel", device, len(w), h, _LAYOUTS[layout], ncoef, n_filters,
+    key = ("mfcc" if mfcc else "mel", device, len(w), h, _LAYOUTS[layout], ncoef, n_filters, _as_row_align(row_align, layout),
            _digest(w, csr.data, csr.indices, csr.indptr))
 
     def make():
         fb = _dense_filterbank(mel_filterbank, len(w))
         p = Plan(_lib.MFCC if mfcc else _lib.MEL, device, window_length=len(w), step_length=h, layout=layout,
-                 n_filters=fb.shape[0], n_coefs=ncoef)
+                 n_filters=fb.shape[0], n_coefs=ncoef, row_align=row_align)
         p.set_window(w)
         p.set_mel_filterbank(fb)
         if mfcc:
@@ -516,7 +548,7 @@ def mel_plan(window_function, step_length, mel_filterbank, number_coefficients=N
     return _cached(key, make)
 
 
-def cqt_plan(sampling_frequency, time_resolution, cqt_kernel, octave_resolution=None, layout="FT", device=0):
+def cqt_plan(sampling_frequency, time_resolution, cqt_kernel, octave_resolution=None, layout="FT", device=0, row_align=0):
     if not hasattr(cqt_kernel, "tocsr"):
         raise ValueError("cqt_kernel must be a scipy.sparse matrix (as returned by cqtkernel)")
     n_bins, fft_length = cqt_kernel.shape
@@ -528,11 +560,12 @@ def cqt_plan(sampling_frequency, time_resolution, cqt_kernel, octave_resolution=
     csr = cqt_kernel.tocsr()
     chroma = octave_resolution is not None
     key = ("chroma" if chroma else "cqt", device, fft_length, step, n_bins, int(octave_resolution or 0), _LAYOUTS[layout],
+           _as_row_align(row_align, layout),
            _digest(csr.indptr, csr.indices, csr.data))
 
     def make():
         p = Plan(_lib.CHROMA if chroma else _lib.CQT, device, step_length=step, layout=layout, fft_length=fft_length,
-                 n_bins=n_bins, octave_resolution=int(octave_resolution or 0))
+                 n_bins=n_bins, octave_resolution=int(octave_resolution or 0), row_align=row_align)
         p.set_cqt_kernel(csr)
         return p
     return _cached(key, make)

@@ -299,6 +299,18 @@ __device__ __forceinline__ float2 buf_load_f32x2(__amdgpu_buffer_rsrc_t r, int v
     return f;
 }
 
+// Non-temporal ("streaming") 8-byte store, for an output line that one instruction writes whole and nobody re-reads.
+// Measured: k_stft_ft16 1.97 -> 1.87 ms, k_mdct_ft32 1.06 -> 1.01 ms.  It does not generalise: the frame-major STFT
+// (lines completed by four instructions at different times) loses 2.0 -> 2.6 ms, the ISTFT's sample stores 1.96 -> 2.13,
+// and non-temporal LOADS of the once-read spectra cost the ISTFT / IMDCT 3 % (profiles/r01_notes.md).
+typedef float zafx_f32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ void store_stream(float2* p, float2 v) {
+    zafx_f32x2 t;
+    t.x = v.x;
+    t.y = v.y;
+    __builtin_nontemporal_store(t, reinterpret_cast<zafx_f32x2*>(p));
+}
+
 // Workgroup barrier that orders LDS traffic only.  __syncthreads() also drains vmcnt, i.e. it waits
 // for every global store of the wave to be acknowledged (measured: 8 000 cycles per tile after the
 // ISTFT store phase); a kernel whose waves exchange data through LDS alone does not need that.

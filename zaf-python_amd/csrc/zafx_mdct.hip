@@ -19,6 +19,7 @@
 #include "zafx_fft.hpp"
 #include "zafx_internal.hpp"
 
+
 namespace zafx {
 
 template <int LOG2NF, int LOG2E, int FPB>
@@ -256,7 +257,7 @@ __global__ __launch_bounds__(NSLOT * 64) void k_mdct_ft32(
                 const float2 ya = cmul(ba[phys(k)], g), yb = cmul(bb[phys(k)], g);
                 const float va = (f & 1) ? -ya.y : ya.x, vb = (f & 1) ? -yb.y : yb.x;
                 float* dst = o + (long long)f * TP;
-                if (pair_ok && two) *reinterpret_cast<float2*>(dst) = make_float2(va, vb);
+                if (pair_ok && two) store_stream(reinterpret_cast<float2*>(dst), make_float2(va, vb));   // a 128-B line per 16 lanes, written once
                 else {
                     dst[0] = va;
                     if (two) dst[1] = vb;

@@ -43,11 +43,15 @@ __device__ __forceinline__ float2* spec_base(float2* out, long long off) {
     if constexpr (SPEC >= 2) return reinterpret_cast<float2*>(reinterpret_cast<float*>(out) + off);
     else return out + off;
 }
-template <int SPEC>
+// STREAM: non-temporal store of the complex kinds (the reference-layout kernel writes each 128-B line exactly once, from
+// one instruction); the 64-B runs of the real kinds do not gain from it.
+template <int SPEC, bool STREAM = false>
 __device__ __forceinline__ void put_bin(float2* o, long long idx, float2 v) {
     if constexpr (SPEC >= 2) {
         const float pw = v.x * v.x + v.y * v.y;
         reinterpret_cast<float*>(o)[idx] = SPEC == 2 ? __builtin_amdgcn_sqrtf(pw) : pw;
+    } else if constexpr (STREAM) {
+        store_stream(o + idx, v);
     } else {
         o[idx] = v;
     }
@@ -277,17 +281,17 @@ __global__ __launch_bounds__(kFatWaves * 64) void k_stft_ft16(
             for (int k = kqo; k < N / 2; k += NT / FPB) {
                 if (k == 0) {
                     const float2 z0 = fb[0], zc = fb[phys_t<C::PS>(N / 2)];
-                    put_bin<SPEC>(o, 0, make_float2(z0.x + z0.y, 0.f));
-                    put_bin<SPEC>(o, (long long)N * TP, make_float2(z0.x - z0.y, 0.f));
-                    put_bin<SPEC>(o, (long long)(N / 2) * TP, cconj(zc));
-                    if (SPEC == 0) put_bin<SPEC>(o, (long long)(N + N / 2) * TP, zc);
+                    put_bin<SPEC, true>(o, 0, make_float2(z0.x + z0.y, 0.f));
+                    put_bin<SPEC, true>(o, (long long)N * TP, make_float2(z0.x - z0.y, 0.f));
+                    put_bin<SPEC, true>(o, (long long)(N / 2) * TP, cconj(zc));
+                    if (SPEC == 0) put_bin<SPEC, true>(o, (long long)(N + N / 2) * TP, zc);
                 } else {
                     float2 xk, xn;
                     split_pair(fb[phys_t<C::PS>(k)], fb[phys_t<C::PS>(N - k)], tws_l[k], xk, xn);
-                    put_bin<SPEC>(o, (long long)k * TP, xk);
-                    if (SPEC == 0) put_bin<SPEC>(o, (long long)(W - k) * TP, cconj(xk));
-                    put_bin<SPEC>(o, (long long)(N - k) * TP, xn);
-                    if (SPEC == 0) put_bin<SPEC>(o, (long long)(N + k) * TP, cconj(xn));
+                    put_bin<SPEC, true>(o, (long long)k * TP, xk);
+                    if (SPEC == 0) put_bin<SPEC, true>(o, (long long)(W - k) * TP, cconj(xk));
+                    put_bin<SPEC, true>(o, (long long)(N - k) * TP, xn);
+                    if (SPEC == 0) put_bin<SPEC, true>(o, (long long)(N + k) * TP, cconj(xn));
                 }
             }
         }

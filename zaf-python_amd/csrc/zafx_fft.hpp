@@ -308,7 +308,7 @@ __device__ __forceinline__ void store_stream(float2* p, float2 v) {
     zafx_f32x2 t;
     t.x = v.x;
     t.y = v.y;
-    __builtin_nontemporal_store(t, reinterpret_cast<zafx_f32x2*>(p));
+    __builtin_nontemporal_store(t, reinterpret_cast<zafx_f32x2*>(p));   // global_store_dwordx2 ... nt (sc0 / sc1 variants: no difference)
 }
 
 // Workgroup barrier that orders LDS traffic only.  __syncthreads() also drains vmcnt, i.e. it waits

@@ -695,7 +695,8 @@ def _run_padded(zafx, fwd_c, fwd_p, inv_c, inv_p, x, n_in_is_samples=True):
     fwd_p.execute(d_x, d_p, b, n)
     fwd_p.sync()
     compact, padded = d_c.download(), d_p.download()
-    assert np.array_equal(padded[:, :, :T], compact)           # same arithmetic, other addresses
+    # same frames at other addresses (aligned rows take the streaming-store copy of the loop: rounding may differ in the last bit)
+    assert compact.size == 0 or relerr(padded[:, :, :T], compact) <= 2e-6
     assert np.isnan(padded[:, :, T:]).all()                    # the padding is never written
     if inv_c is None:
         return
@@ -751,9 +752,9 @@ def test_row_align_mel_cqt_and_host_path(zafx):
     # host-array path: compact arrays in and out whatever the device pitch is
     p_c, p_p = zafx.stft_plan(ham, 1024), zafx.stft_plan(ham, 1024, row_align=16)
     s_c, s_p = p_c.run_host(x, x.shape[1]), p_p.run_host(x, x.shape[1])
-    assert s_p.shape == s_c.shape and np.array_equal(s_c, s_p)
+    assert s_p.shape == s_c.shape and relerr(s_p, s_c) <= 2e-6
     i_c, i_p = zafx.istft_plan(ham, 1024), zafx.istft_plan(ham, 1024, row_align=16)
-    assert np.array_equal(i_c.run_host(s_c, s_c.shape[2]), i_p.run_host(s_c, s_c.shape[2]))
+    assert relerr(i_p.run_host(s_c, s_c.shape[2]), i_c.run_host(s_c, s_c.shape[2])) <= 2e-6
     with pytest.raises(ValueError):
         zafx.stft_plan(ham, 1024, layout="TF", row_align=16)
     with pytest.raises(ValueError):

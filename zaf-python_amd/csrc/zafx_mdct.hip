@@ -153,6 +153,7 @@ __global__ __launch_bounds__(NSLOT * 64) void k_mdct_ft32(
     const int slot = tid / P, p = tid % P;
     const int tp = tid % 16, fq = tid / 16;
     const bool pair_ok = (TP % 2 == 0) && (reinterpret_cast<uintptr_t>(out) % 8 == 0);   // TP = row pitch (>= T)
+    const bool lines_whole = TP % 16 == 0 && reinterpret_cast<uintptr_t>(out) % 64 == 0;   // rows of whole 64-B half lines: stream them
     const bool lane_loads = p < NU;
 
     // A frame's W = 4 NF samples are fetched as 16-byte pieces.  Group u takes four of them,
@@ -257,7 +258,10 @@ __global__ __launch_bounds__(NSLOT * 64) void k_mdct_ft32(
                 const float2 ya = cmul(ba[phys(k)], g), yb = cmul(bb[phys(k)], g);
                 const float va = (f & 1) ? -ya.y : ya.x, vb = (f & 1) ? -yb.y : yb.x;
                 float* dst = o + (long long)f * TP;
-                if (pair_ok && two) store_stream(reinterpret_cast<float2*>(dst), make_float2(va, vb));   // a 128-B line per 16 lanes, written once
+                if (pair_ok && two) {
+                    if (lines_whole) store_stream(reinterpret_cast<float2*>(dst), make_float2(va, vb));   // a 128-B line per 16 lanes, written once
+                    else *reinterpret_cast<float2*>(dst) = make_float2(va, vb);
+                }
                 else {
                     dst[0] = va;
                     if (two) dst[1] = vb;

@@ -212,6 +212,7 @@ __global__ __launch_bounds__(kFatWaves * 64) void k_stft_ft16(
     const int wave = tid / P, p_lane = tid % P, p = p_lane;
     const int tt = tid % FPB, kq = tid / FPB;
     const float2* fb = frames + tt * PITCH;
+    const bool lines_whole = TP % 16 == 0 && reinterpret_cast<uintptr_t>(out) % 128 == 0;
 
     float2 xr[FPW][E];
     // The fast / edge decision is taken once per TILE (block-uniform): a tile whose 16 frames all lie
@@ -278,22 +279,29 @@ __global__ __launch_bounds__(kFatWaves * 64) void k_stft_ft16(
             float2* o = spec_base<SPEC>(out, (long long)clip * ROWS * TP + (t0 + tt));
             int kqo = kq;   // (opaque at 32 points per thread: the split roots of the 16 iterations are not carried across tiles)
             if constexpr (E >= 32) asm volatile("" : "+v"(kqo));
-            for (int k = kqo; k < N / 2; k += NT / FPB) {
-                if (k == 0) {
-                    const float2 z0 = fb[0], zc = fb[phys_t<C::PS>(N / 2)];
-                    put_bin<SPEC, true>(o, 0, make_float2(z0.x + z0.y, 0.f));
-                    put_bin<SPEC, true>(o, (long long)N * TP, make_float2(z0.x - z0.y, 0.f));
-                    put_bin<SPEC, true>(o, (long long)(N / 2) * TP, cconj(zc));
-                    if (SPEC == 0) put_bin<SPEC, true>(o, (long long)(N + N / 2) * TP, zc);
-                } else {
-                    float2 xk, xn;
-                    split_pair(fb[phys_t<C::PS>(k)], fb[phys_t<C::PS>(N - k)], tws_l[k], xk, xn);
-                    put_bin<SPEC, true>(o, (long long)k * TP, xk);
-                    if (SPEC == 0) put_bin<SPEC, true>(o, (long long)(W - k) * TP, cconj(xk));
-                    put_bin<SPEC, true>(o, (long long)(N - k) * TP, xn);
-                    if (SPEC == 0) put_bin<SPEC, true>(o, (long long)(N + k) * TP, cconj(xn));
+            auto store_tile = [&](auto stream) {
+                constexpr bool ST = decltype(stream)::value;
+                for (int k = kqo; k < N / 2; k += NT / FPB) {
+                    if (k == 0) {
+                        const float2 z0 = fb[0], zc = fb[phys_t<C::PS>(N / 2)];
+                        put_bin<SPEC, ST>(o, 0, make_float2(z0.x + z0.y, 0.f));
+                        put_bin<SPEC, ST>(o, (long long)N * TP, make_float2(z0.x - z0.y, 0.f));
+                        put_bin<SPEC, ST>(o, (long long)(N / 2) * TP, cconj(zc));
+                        if (SPEC == 0) put_bin<SPEC, ST>(o, (long long)(N + N / 2) * TP, zc);
+                    } else {
+                        float2 xk, xn;
+                        split_pair(fb[phys_t<C::PS>(k)], fb[phys_t<C::PS>(N - k)], tws_l[k], xk, xn);
+                        put_bin<SPEC, ST>(o, (long long)k * TP, xk);
+                        if (SPEC == 0) put_bin<SPEC, ST>(o, (long long)(W - k) * TP, cconj(xk));
+                        put_bin<SPEC, ST>(o, (long long)(N - k) * TP, xn);
+                        if (SPEC == 0) put_bin<SPEC, ST>(o, (long long)(N + k) * TP, cconj(xn));
+                    }
                 }
-            }
+            };
+            // whole-line rows (pitch and base multiples of 128 B) stream past L2; rows that straddle lines keep the
+            // write-combining of ordinary stores (non-temporal partial lines: T = 433, 1.11 -> 1.51 ms per 256 clips)
+            if (SPEC < 2 && lines_whole) store_tile(std::true_type{});
+            else store_tile(std::false_type{});
         }
         PROF_MARK(4);
         lds_barrier();   // LDS reads of the tile are done; its global stores are NOT waited for
@@ -653,7 +661,7 @@ ZAFX_PROF_ARRAY(g_prof)
 // (prefetching 1-3 sweeps of the next tile across the FFT phase did not pay: the FFT needs 116 of
 // the 128 VGPRs).  Barriers order LDS only (lds_barrier): the output stores of a tile are not
 // waited for.
-template <int LOG2N, int LOG2E, int DEPTH, bool ONE, int FV>
+template <int LOG2N, int LOG2E, int DEPTH, bool ONE, int FV, bool TF = false>
 __global__ __launch_bounds__(1024) void k_istft_ft16(
     const float2* __restrict__ spec, const float2* __restrict__ twp, const float2* __restrict__ tws,
     float* __restrict__ y, int T, int TP, int hop, long long out_len, float scale, int tiles, int segs, int seg_tiles,
@@ -669,6 +677,7 @@ __global__ __launch_bounds__(1024) void k_istft_ft16(
     constexpr int KSTEP = NT / LPR;            // bins handled per sweep
     constexpr int KI = (N / 2) / KSTEP;        // sweeps per thread
     static_assert((FV == 1 || FV == 2) && KI >= 1 && (N / 2) % KSTEP == 0, "pair sweep must divide N/2");
+    static_assert(!TF || (FV == 1 && P == 64), "frame-major input: one wavefront loads, folds and transforms a whole frame");
     using RV = std::conditional_t<FV == 2, float4, float2>;   // one row piece of my FV frames
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     float2* frames = reinterpret_cast<float2*>(smem_raw);
@@ -784,6 +793,44 @@ __global__ __launch_bounds__(1024) void k_istft_ft16(
         PROF_MARK(0);
         const bool carry_only = cur.tile < cur.tile_a;
         const int t_first = cur.tile * FPB;
+        Tile nxt = cur;
+        if (++nxt.tile >= nxt.tile_b) {
+            nxt.unit += gridDim.x;
+            if (nxt.unit < total_units) enter(nxt);
+        }
+        const bool has_next = nxt.unit < total_units;
+        if constexpr (TF) {
+            // ---- phases A + B, frame-major input: a frame's rows are contiguous, so wave w streams frame t_first + w
+            //      (512-B coalesced runs of rows k, W-k, N-k, N+k), folds it into its own LDS buffer and transforms it
+            //      without meeting the other waves.
+            const int t = t_first + wave;
+            if (wave >= (carry_only ? FPB - halo : 0) && t < T) {   // wave-uniform
+                const float2* sp = spec + ((long long)(cur.unit / segs) * T + t) * ROWS;
+                float2* buf = frames + wave * PITCH;
+                int po = p;   // (opaque: the split roots of the sweeps are not carried across tiles)
+                asm volatile("" : "+v"(po));
+#pragma unroll DEPTH
+                for (int s = 0; s < (N / 2) / P; ++s) {
+                    const int k = po + s * P;
+                    const bool dc = s == 0 && k == 0;   // lane 0 of the first sweep holds rows 0, N/2, N, 3N/2
+                    float2 r0 = sp[k], r2 = sp[N - k], r1, r3 = make_float2(0.f, 0.f);
+                    if (ONE) {
+                        r1 = sp[dc ? N / 2 : k];
+                    } else {
+                        r1 = sp[dc ? N / 2 : W - k];
+                        r3 = sp[dc ? N + N / 2 : N + k];
+                    }
+                    fold_one(k, r0, r1, r2, r3, buf);
+                }
+                float2 v[E];
+                frame_sync<P>();
+                regs_read<LOG2N, LOG2E>(v, buf, po);
+                frame_sync<P>();
+                fft_frame<LOG2N, LOG2E>(v, buf, po, tw_l);
+            }
+            PROF_MARK(1);
+            PROF_MARK(2);
+        } else {
         // ---- phase A: stream the tile's sweeps, DEPTH at a time, through the Hermitian fold into LDS
         if (my_frame_needed(cur)) {
             const Src sp = source(cur);
@@ -797,12 +844,6 @@ __global__ __launch_bounds__(1024) void k_istft_ft16(
         PROF_MARK(1);
         lds_barrier();
         PROF_MARK(2);
-        Tile nxt = cur;
-        if (++nxt.tile >= nxt.tile_b) {
-            nxt.unit += gridDim.x;
-            if (nxt.unit < total_units) enter(nxt);
-        }
-        const bool has_next = nxt.unit < total_units;
         // ---- phase B: forward FFT of the swapped spectrum == swapped inverse FFT
         if (wave >= (carry_only ? FPB - halo : 0)) {   // wave-uniform
             float2* buf = frames + wave * PITCH;
@@ -810,6 +851,7 @@ __global__ __launch_bounds__(1024) void k_istft_ft16(
             regs_read<LOG2N, LOG2E>(v, buf, p);
             frame_sync<P>();
             fft_frame<LOG2N, LOG2E>(v, buf, p, tw_l);
+        }
         }
         PROF_MARK(3);
         lds_barrier();
@@ -950,18 +992,21 @@ int carry_segments(long long n_clips, int tiles, long long grid) {
     return best;
 }
 
-template <int LOG2N, bool ONE>
+#ifndef ZAFX_ISTFT_TF_DEPTH
+#define ZAFX_ISTFT_TF_DEPTH 2
+#endif
+template <int LOG2N, bool ONE, bool TF = false>
 static hipError_t run_istft_fat(const zafx_plan& pl, const float2* spec, float* y, int64_t n_clips, int T, int64_t out_len) {
     constexpr int LOG2E = default_log2e(LOG2N);
     using F = FatCfg<LOG2N, LOG2E>;
     // 16-byte gathers (two adjacent frames per lane) when the rows allow it; see the kernel
-    constexpr bool can_vec = LOG2N >= 8;
+    constexpr bool can_vec = LOG2N >= 8 && !TF;
     const int TP = (int)row_pitch(pl, T);
     const bool vec = can_vec && TP % 2 == 0 && reinterpret_cast<uintptr_t>(spec) % 16 == 0;
     // sweeps streamed together: 8 loads per wave in flight is the measured optimum (profiles/r01_notes.md);
     // a one-sided sweep has 2 loads instead of 4
-    constexpr int D1 = ONE ? 4 : 2, D2 = ONE ? 4 : 1;
-    auto kern = vec ? k_istft_ft16<LOG2N, LOG2E, D2, ONE, can_vec ? 2 : 1> : k_istft_ft16<LOG2N, LOG2E, D1, ONE, 1>;
+    constexpr int D1 = TF ? ZAFX_ISTFT_TF_DEPTH : ONE ? 4 : 2, D2 = ONE ? 4 : 1;
+    auto kern = vec ? k_istft_ft16<LOG2N, LOG2E, can_vec ? D2 : D1, ONE, can_vec ? 2 : 1, TF> : k_istft_ft16<LOG2N, LOG2E, D1, ONE, 1, TF>;
     const int nt = 1024;
     if (hipError_t e = ensure_dynamic_lds(reinterpret_cast<const void*>(kern), pl.device, F::SMEM); e != hipSuccess) return e;
     const int W = 2 << LOG2N;
@@ -989,6 +1034,8 @@ static hipError_t run_istft(const zafx_plan& pl, const float2* spec, float* y, i
     if constexpr (stft_use_fat(LOG2N, LAYOUT)) {
         // the carry kernel addresses a clip through one buffer descriptor (32-bit byte offsets)
         if ((long long)(2 << LOG2N) * row_pitch(pl, T) * 8 < (1LL << 31)) return run_istft_fat<LOG2N, ONE>(pl, spec, y, n_clips, T, out_len);
+    } else if constexpr (stft_use_tf(LOG2N, LAYOUT)) {
+        return run_istft_fat<LOG2N, ONE, true>(pl, spec, y, n_clips, T, out_len);
     }
     constexpr int LOG2E = default_log2e(LOG2N);
     constexpr int FPB = stft_fpb(LOG2N, ZAFX_LAYOUT_FT);
@@ -1018,7 +1065,7 @@ int stft_frames_per_block(int log2n, int layout) { return stft_fpb(log2n, layout
 const char* stft_kernel_name(int log2n, int layout) {
     return stft_use_fat(log2n, layout) ? "k_stft_ft16" : stft_use_tf(log2n, layout) ? "k_stft_tf" : "k_stft";
 }
-const char* istft_kernel_name(int log2n, int layout) { return stft_use_fat(log2n, layout) ? "k_istft_ft16" : "k_istft"; }
+const char* istft_kernel_name(int log2n, int layout) { return stft_use_fat(log2n, layout) || stft_use_tf(log2n, layout) ? "k_istft_ft16" : "k_istft"; }
 
 template <int L, int LAYOUT>
 static hipError_t dispatch_stft_spec(const zafx_plan& pl, const float* x, float2* out, int64_t n_clips, int64_t n_samples, int T) {

@@ -132,7 +132,9 @@ struct MdctPCfg {
     static constexpr size_t SMEM = (size_t)(kMdctTile * C::PITCH + C::TW + NF) * 8 + (size_t)NF * 16;
 };
 
-template <int LOG2NF, int LOG2E, bool ALIGNED, int NSLOT>
+// TFOUT = frame-major output (ZAFX_LAYOUT_TF): a frame's M coefficients are contiguous, so the wave that transformed a
+// frame also stores it (512-B coalesced runs) and the workgroup never meets after the table staging.
+template <int LOG2NF, int LOG2E, bool ALIGNED, int NSLOT, bool TFOUT = false>
 __global__ __launch_bounds__(NSLOT * 64) void k_mdct_ft32(
     const float* __restrict__ x, const float4* __restrict__ wfold, const float2* __restrict__ twp,
     const float2* __restrict__ tw8, float* __restrict__ out, long long n_samples, int T, int TP, int tiles, int total_tiles) {
@@ -151,8 +153,7 @@ __global__ __launch_bounds__(NSLOT * 64) void k_mdct_ft32(
     for (int i = tid; i < NF; i += NT) { g_l[i] = tw8[i]; wf_l[i] = wfold[i]; }
     lds_barrier();
     const int slot = tid / P, p = tid % P;
-    const int tp = tid % 16, fq = tid / 16;
-    const bool pair_ok = (TP % 2 == 0) && (reinterpret_cast<uintptr_t>(out) % 8 == 0);   // TP = row pitch (>= T)
+    const bool pair_ok = (TFOUT || TP % 2 == 0) && (reinterpret_cast<uintptr_t>(out) % 8 == 0);   // TP = row pitch (>= T)
     const bool lines_whole = TP % 16 == 0 && reinterpret_cast<uintptr_t>(out) % 64 == 0;   // rows of whole 64-B half lines: stream them
     const bool lane_loads = p < NU;
 
@@ -237,9 +238,35 @@ __global__ __launch_bounds__(NSLOT * 64) void k_mdct_ft32(
             frame_sync<P>();
             fft_frame<LOG2NF, LOG2E>(v, buf, po, tw_l);
             PROF_MARK(2);
+            if constexpr (TFOUT) {
+                // coefficients (2j, 2j+1) = (Re y[j], -Im y[NF-1-j]) with y[k] = Z[k] g[k] (zaf.py:1087-1091 after the
+                // N/4-point reduction): one 8-byte store per lane
+                frame_sync<P>();
+                const int t = t0 + frame_of(f);
+                if (t < T) {   // wave-uniform
+                    float* o = out + ((long long)clip * T + t) * M;
+#pragma unroll 4
+                    for (int i = 0; i < NF / P; ++i) {
+                        const int j = po + i * P;
+                        const float2 za = buf[phys(j)], zb = buf[phys(NF - 1 - j)], ga = g_l[j], gb = g_l[NF - 1 - j];
+                        const float re = za.x * ga.x - za.y * ga.y, im = zb.x * gb.y + zb.y * gb.x;
+                        if (pair_ok) {
+                            *reinterpret_cast<float2*>(o + 2 * j) = make_float2(re, -im);
+                        } else {
+                            o[2 * j] = re;
+                            o[2 * j + 1] = -im;
+                        }
+                    }
+                }
+                frame_sync<P>();   // these reads precede the buffer's next fold
+            }
         }
+        if constexpr (TFOUT) continue;   // wave-private buffers: no workgroup barrier in the tile loop
         lds_barrier();
         PROF_MARK(3);
+        int tido = tid;   // opaque: the store-phase indices are recomputed per tile (kept live across the FFT loop they are
+        asm volatile("" : "+v"(tido));   // spilled at 128 VGPRs, and a scratch reload here waits for vmcnt(0): the next tile's prefetch)
+        const int tp = tido % 16, fq = tido / 16;
         const int ta = t0 + 2 * tp;
         if (ta < T) {
             // Row of lane group g = (tid / 16) % 4 within the wave's 4 rows: 0, 2, 1, 3.  ds_read_b64 serves 32 lanes
@@ -472,15 +499,15 @@ constexpr int mdct_fpb(int log2nf, int layout) {
 }
 
 constexpr bool mdct_use_persistent(int log2nf, int layout) {
-    return layout == ZAFX_LAYOUT_FT && log2nf >= 7 && log2nf <= 9;
+    return log2nf >= 7 && log2nf <= 9;   // either layout
 }
 
-template <int LOG2NF>
+template <int LOG2NF, bool TFOUT>
 static hipError_t run_mdct_p(const zafx_plan& pl, const float* x, float* out, int64_t n_clips, int64_t n_samples, int T) {
     constexpr int LOG2E = default_log2e(LOG2NF);
     using G = MdctPCfg<LOG2NF, LOG2E>;
     const bool aligned = n_samples % 4 == 0 && reinterpret_cast<uintptr_t>(x) % 16 == 0;
-    auto kern = aligned ? k_mdct_ft32<LOG2NF, LOG2E, true, G::NSLOT> : k_mdct_ft32<LOG2NF, LOG2E, false, G::NSLOT>;
+    auto kern = aligned ? k_mdct_ft32<LOG2NF, LOG2E, true, G::NSLOT, TFOUT> : k_mdct_ft32<LOG2NF, LOG2E, false, G::NSLOT, TFOUT>;
     if (hipError_t e = ensure_dynamic_lds(reinterpret_cast<const void*>(kern), pl.device, G::SMEM); e != hipSuccess) return e;
     const int tiles = (T + kMdctTile - 1) / kMdctTile;
     const long long total = (long long)tiles * n_clips;
@@ -495,7 +522,7 @@ static hipError_t run_mdct_p(const zafx_plan& pl, const float* x, float* out, in
 template <int LOG2NF, int LAYOUT>
 static hipError_t run_mdct(const zafx_plan& pl, const float* x, float* out, int64_t n_clips, int64_t n_samples, int T) {
     if constexpr (mdct_use_persistent(LOG2NF, LAYOUT)) {
-        return run_mdct_p<LOG2NF>(pl, x, out, n_clips, n_samples, T);
+        return run_mdct_p<LOG2NF, LAYOUT == ZAFX_LAYOUT_TF>(pl, x, out, n_clips, n_samples, T);
     } else {
         constexpr int LOG2E = default_log2e(LOG2NF);
         constexpr int FPB = mdct_fpb(LOG2NF, LAYOUT);

@@ -580,7 +580,7 @@ def test_f64_stft_istft(zafx, wl, hop, n):
 
 
 def test_f64_dropin_and_golden(zafx, golden):
-    """set_precision("f64") switches the drop-in stft / istft to float64 device arithmetic: the tiny golden
+    """set_precision("f64") switches the drop-in stft / istft / mdct / imdct to float64 device arithmetic: the tiny golden
     vectors of the real reference are met to 1e-12 instead of 1e-5."""
     g = golden["tiny"]
     zafx.set_precision("f64")
@@ -593,10 +593,74 @@ def test_f64_dropin_and_golden(zafx, golden):
                 assert relerr(y, g[f"istft_{n}_{hop}"]) <= TOL_F64
         y = zafx.istft(g["istft_generic_in"], g["ham"], 32)   # non-Hermitian input: real(ifft(.)) of anything
         assert relerr(y, g["istft_generic_out"]) <= TOL_F64
+        for n in (1, 63, 64, 65, 1000):
+            for wname in ("sine", "kbd"):
+                c = zafx.mdct(g[f"x_{n}"], g[wname])
+                assert c.dtype == np.float64 and relerr(c, g[f"mdct_{wname}_{n}"]) <= TOL_F64
+                y = zafx.imdct(g[f"mdct_{wname}_{n}"], g[wname])
+                yref = g[f"imdct_{wname}_{n}"]
+                assert y.shape == yref.shape and (yref.size == 0 or relerr(y, yref) <= TOL_F64)
+        fb = scipy.sparse.csr_matrix(g["fb_dense"])
+        for n in (1, 63, 64, 65, 1000):
+            for hop in (32, 16):
+                assert relerr(zafx.melspectrogram(g[f"x_{n}"], g["ham"], hop, fb), g[f"mel_{n}_{hop}"]) <= TOL_F64
+                assert relerr(zafx.mfcc(g[f"x_{n}"], g["ham"], hop, fb, 5), g[f"mfcc_{n}_{hop}"]) <= 1e-10   # log(. + eps) of tiny band sums
     finally:
         zafx.set_precision("f32")
     with pytest.raises(zafx.ZafxError):
-        zafx.Plan(zafx.MDCT, window_length=2048, f64=True)
+        zafx.Plan(zafx.CQT, step_length=1764, fft_length=4096, n_bins=24, f64=True)
+
+
+@pytest.mark.parametrize("wl,hop,n,nmel", [(2048, 1024, 100000, 128), (2048, 512, 30001, 40), (1024, 512, 20000, 64), (4096, 2048, 50000, 128),
+                                            (256, 100, 5000, 20)])
+def test_f64_mel_mfcc(zafx, wl, hop, n, nmel):
+    """ZAFX_PRECISION_F64 for melspectrogram / mfcc (any power-of-two window): the reference arithmetic to 1e-12 (mel)
+    and 1e-10 (mfcc: the log amplifies the rounding of the smallest band sums), both layouts."""
+    x = np.stack([synth_clip(41, c, n).astype(np.float64) + 1e-9 * c for c in range(2)])
+    w = zafx.hamming(wl)
+    fb = zafx.melfilterbank(44100, wl, nmel)
+    for layout in ("FT", "TF"):
+        mel = zafx.melspectrogram_batch(x, w, hop, fb, layout=layout, f64=True)
+        cep = zafx.mfcc_batch(x, w, hop, fb, 13, layout=layout, f64=True)
+        assert mel.dtype == np.float64 and cep.dtype == np.float64
+        if layout == "TF":
+            mel, cep = mel.transpose(0, 2, 1), cep.transpose(0, 2, 1)
+        for c in range(2):
+            ref_mel = orc.melspectrogram(x[c], w, hop, fb)
+            ref_cep = orc.mfcc(x[c], w, hop, fb, 13)
+            assert mel[c].shape == ref_mel.shape and cep[c].shape == ref_cep.shape
+            assert relerr(mel[c], ref_mel) <= TOL_F64, (layout, c)
+            assert relerr(cep[c], ref_cep) <= 1e-10, (layout, c)
+
+
+@pytest.mark.parametrize("wl,n", [(2048, 441000), (2048, 30001), (512, 9001), (64, 1000), (8192, 50000), (256, 1)])
+def test_f64_mdct_imdct(zafx, wl, n):
+    """ZAFX_PRECISION_F64 for the MDCT family: within 1e-12 of the reference arithmetic in both layouts and with padded
+    rows; the TDAC round trip reconstructs float64 noise to 1e-12 (the reference's own check, zaf.py:1018-1024)."""
+    x = np.stack([synth_clip(37, c, n).astype(np.float64) + 1e-9 * c for c in range(2)])
+    w = zafx.kaiser_bessel_derived(wl) if wl != 512 else zafx.sine(wl)
+    ref = np.stack([orc.mdct(x[c], w) for c in range(2)])
+    for layout in ("FT", "TF"):
+        got = zafx.mdct_batch(x, w, layout=layout, f64=True)
+        assert got.dtype == np.float64
+        if layout == "TF":
+            got = got.transpose(0, 2, 1)
+        assert got.shape == ref.shape
+        for c in range(2):
+            assert relerr(got[c], ref[c]) <= TOL_F64, (layout, c)
+        coefs = ref if layout == "FT" else np.ascontiguousarray(ref.transpose(0, 2, 1))
+        y = zafx.imdct_batch(coefs, w, layout=layout, f64=True)
+        assert y.dtype == np.float64
+        for c in range(2):
+            yref = orc.imdct(ref[c], w)
+            assert y[c].shape == yref.shape
+            if yref.size:
+                assert relerr(y[c], yref) <= TOL_F64, (layout, c)
+                m = min(n, yref.size)
+                assert np.max(np.abs(y[c][:m] - x[c][:m])) <= 1e-12 * max(1.0, np.max(np.abs(x[c])))   # perfect reconstruction
+    p_c, p_p = zafx.mdct_plan(w, f64=True), zafx.mdct_plan(w, f64=True, row_align=8)
+    a, b = p_c.run_host(x, n), p_p.run_host(x, n)
+    assert a.shape == b.shape and np.array_equal(a, b)
 
 
 @pytest.mark.parametrize("wl,hop,n", [(2048, 1024, 100000), (1024, 256, 9001), (128, 64, 777), (4096, 1024, 30000)])

@@ -197,9 +197,32 @@ static int finalize_constant(zafx_plan* pl, int which) {
             return 0;
         }
         case ZAFX_CONST_MEL_FB:
+            if (pl->prm.precision == ZAFX_PRECISION_F64) {   // rows as bands [first non-zero, last non-zero]
+                const int rows = pl->prm.n_filters, cols = pl->W / 2;
+                std::vector<int> meta((size_t)rows * 3, 0);
+                std::vector<double> vals;
+                for (int r = 0; r < rows; ++r) {
+                    const double* row = &pl->h_fb64[(size_t)r * cols];
+                    int lo = 0, hi = cols;
+                    while (lo < cols && row[lo] == 0.0) ++lo;
+                    while (hi > lo && row[hi - 1] == 0.0) --hi;
+                    meta[(size_t)r * 3] = lo;
+                    meta[(size_t)r * 3 + 1] = hi - lo;
+                    meta[(size_t)r * 3 + 2] = (int)vals.size();
+                    vals.insert(vals.end(), row + lo, row + hi);
+                }
+                if (vals.empty()) vals.push_back(0.0);
+                ZAFX_HIP(upload(&pl->d_fb64, vals.data(), vals.size() * sizeof(double)));
+                ZAFX_HIP(upload(&pl->d_fb64_meta, meta.data(), meta.size() * sizeof(int)));
+                return 0;
+            }
             ZAFX_HIP(pack_band(pl->fb, pl->h_fb.data(), pl->prm.n_filters, pl->W / 2, mel_waves(pl->log2nf)));
             return 0;
         case ZAFX_CONST_DCT:
+            if (pl->prm.precision == ZAFX_PRECISION_F64) {
+                ZAFX_HIP(upload(&pl->d_dct64, pl->h_dct64.data(), pl->h_dct64.size() * sizeof(double)));
+                return 0;
+            }
             ZAFX_HIP(pack_band(pl->dct, pl->h_dct.data(), pl->prm.n_coefs, pl->prm.n_filters, mel_waves(pl->log2nf)));
             return 0;
         case ZAFX_CONST_MATRIX:
@@ -362,8 +385,8 @@ int zafx_plan_create(zafx_plan** out, int device, int kind, const zafx_params* p
     if (params->spectrum >= ZAFX_SPECTRUM_MAGNITUDE && kind != ZAFX_STFT)
         return fail_msg("magnitude / power spectra are outputs of ZAFX_STFT only");
     if (params->precision != ZAFX_PRECISION_F32 && params->precision != ZAFX_PRECISION_F64) return fail_msg("bad precision");
-    if (params->precision == ZAFX_PRECISION_F64 && kind != ZAFX_STFT && kind != ZAFX_ISTFT)
-        return fail_msg("ZAFX_PRECISION_F64 is available for ZAFX_STFT / ZAFX_ISTFT only");
+    if (params->precision == ZAFX_PRECISION_F64 && (kind == ZAFX_CQT || kind == ZAFX_CHROMA || kind == ZAFX_LINEAR))
+        return fail_msg("ZAFX_PRECISION_F64 is available for the STFT, MDCT and mel families only");
     if (params->row_align < 0 || params->row_align > 1024 || (params->row_align & (params->row_align - 1)))
         return fail_msg("row_align must be 0 or a power of two <= 1024");
     if (params->row_align > 1 && (params->layout != ZAFX_LAYOUT_FT || kind == ZAFX_LINEAR))
@@ -394,7 +417,11 @@ int zafx_plan_create(zafx_plan** out, int device, int kind, const zafx_params* p
             if (params->n_filters < 1 || params->n_filters > 256) return bail("n_filters must be in [1, 256]");
             if (kind == ZAFX_MFCC && (params->n_coefs < 1 || params->n_coefs > params->n_filters))
                 return bail("n_coefs must be in [1, n_filters]");
-            if (lw - 1 != 10 && lw - 1 != 9 && lw - 1 != 5) return bail("mel/mfcc kernels are built for window_length 64, 1024 and 2048");
+            if (params->precision == ZAFX_PRECISION_F64) {
+                if (params->n_filters > pl->W / 2) return bail("n_filters must not exceed window_length / 2");
+            } else if (lw - 1 != 10 && lw - 1 != 9 && lw - 1 != 5) {
+                return bail("mel/mfcc kernels are built for window_length 64, 1024 and 2048 (any power of two with ZAFX_PRECISION_F64)");
+            }
         }
         const int n = pl->W / 2;
         aux.resize((size_t)n / 2 + 1);
@@ -450,7 +477,8 @@ int zafx_plan_create(zafx_plan** out, int device, int kind, const zafx_params* p
     }
     if (e == hipSuccess) e = upload(&pl->d_tw_aux, aux.data(), aux.size() * sizeof(cf32));
     if (e == hipSuccess && pl->prm.precision == ZAFX_PRECISION_F64) {   // float64 tables, evaluated in long double
-        const int n = pl->W / 2;
+        const bool mdct = is_mdct_family(kind);
+        const int n = mdct ? pl->W / 4 : pl->W / 2;   // FFT length
         auto root = [](long long num, long long den) {
             const long double a = -2.0L * 3.14159265358979323846264338327950288L * (long double)(num % den) / (long double)den;
             double2 r = make_double2((double)cosl(a), (double)sinl(a));
@@ -459,12 +487,17 @@ int zafx_plan_create(zafx_plan** out, int device, int kind, const zafx_params* p
             if (2 * (num % den) == den) r = make_double2(-1.0, 0.0);
             return r;
         };
-        std::vector<double2> tw((size_t)std::max(n / 2, 1)), tws((size_t)n / 2 + 1);
+        std::vector<double2> tw((size_t)std::max(n / 2, 1)), tws((size_t)(mdct ? n : n / 2 + 1));
         for (int m = 0; m < n / 2; ++m) tw[(size_t)m] = root(m, n);
-        for (int k = 0; k <= n / 2; ++k) tws[(size_t)k] = root(k, pl->W);
+        if (mdct) {   // g_m = exp(-i pi (8m+1) / (8M)), M = W/2: pre- and post-twiddle of the DCT-IV
+            for (int m = 0; m < n; ++m) tws[(size_t)m] = root(8LL * m + 1, 8LL * pl->W);
+        } else {
+            for (int k = 0; k <= n / 2; ++k) tws[(size_t)k] = root(k, pl->W);
+        }
         e = upload(&pl->d_tw64, tw.data(), tw.size() * sizeof(double2));
         if (e == hipSuccess) e = upload(&pl->d_tws64, tws.data(), tws.size() * sizeof(double2));
-        pl->kernel_name = kind == ZAFX_STFT ? stft_f64_kernel_name() : istft_f64_kernel_name();
+        pl->kernel_name = kind == ZAFX_STFT ? stft_f64_kernel_name() : kind == ZAFX_ISTFT ? istft_f64_kernel_name()
+                          : kind == ZAFX_MDCT ? mdct_f64_kernel_name() : kind == ZAFX_IMDCT ? imdct_f64_kernel_name() : mel_f64_kernel_name();
     }
     if (e != hipSuccess) {
         zafx_plan_destroy(pl);
@@ -493,6 +526,9 @@ int zafx_plan_destroy(zafx_plan* pl) {
     if (pl->d_tw64) (void)hipFree(pl->d_tw64);
     if (pl->d_tws64) (void)hipFree(pl->d_tws64);
     if (pl->d_scratch64) (void)hipFree(pl->d_scratch64);
+    if (pl->d_fb64) (void)hipFree(pl->d_fb64);
+    if (pl->d_fb64_meta) (void)hipFree(pl->d_fb64_meta);
+    if (pl->d_dct64) (void)hipFree(pl->d_dct64);
     if (pl->d_chunk_ptr) (void)hipFree(pl->d_chunk_ptr);
     free_band(pl->fb);
     free_band(pl->dct);
@@ -514,15 +550,15 @@ static int expected_constant_bytes(const zafx_plan* pl, int which, size_t bytes,
             *elem = sizeof(float);
             return bytes == (size_t)pl->W * sizeof(float) ? 0 : fail_msg("window must hold window_length float32");
         case ZAFX_CONST_MEL_FB:
-            *elem = sizeof(float);
+            *elem = pl->prm.precision == ZAFX_PRECISION_F64 ? sizeof(double) : sizeof(float);
             if (pl->kind != ZAFX_MEL && pl->kind != ZAFX_MFCC) return fail_msg("plan takes no mel filterbank");
-            return bytes == (size_t)pl->prm.n_filters * (pl->W / 2) * sizeof(float) ? 0
-                       : fail_msg("mel filterbank must be dense float32 [n_filters][window_length/2]");
+            return bytes == (size_t)pl->prm.n_filters * (pl->W / 2) * *elem ? 0
+                       : fail_msg("mel filterbank must be dense float32 (float64 for a ZAFX_PRECISION_F64 plan) [n_filters][window_length/2]");
         case ZAFX_CONST_DCT:
-            *elem = sizeof(float);
+            *elem = pl->prm.precision == ZAFX_PRECISION_F64 ? sizeof(double) : sizeof(float);
             if (pl->kind != ZAFX_MFCC) return fail_msg("plan takes no DCT matrix");
-            return bytes == (size_t)pl->prm.n_coefs * pl->prm.n_filters * sizeof(float) ? 0
-                       : fail_msg("DCT matrix must be float32 [n_coefs][n_filters]");
+            return bytes == (size_t)pl->prm.n_coefs * pl->prm.n_filters * *elem ? 0
+                       : fail_msg("DCT matrix must be float32 (float64 for a ZAFX_PRECISION_F64 plan) [n_coefs][n_filters]");
         case ZAFX_CONST_MATRIX:
             *elem = sizeof(float);
             if (pl->kind != ZAFX_LINEAR) return fail_msg("plan takes no transform matrix");
@@ -550,10 +586,12 @@ static int store_shadow(zafx_plan* pl, int which, const void* host, size_t bytes
             else pl->h_window.assign((const float*)host, (const float*)host + bytes / sizeof(float));
             break;
         case ZAFX_CONST_MEL_FB:
-            pl->h_fb.assign((const float*)host, (const float*)host + bytes / sizeof(float));
+            if (pl->prm.precision == ZAFX_PRECISION_F64) pl->h_fb64.assign((const double*)host, (const double*)host + bytes / sizeof(double));
+            else pl->h_fb.assign((const float*)host, (const float*)host + bytes / sizeof(float));
             break;
         case ZAFX_CONST_DCT:
-            pl->h_dct.assign((const float*)host, (const float*)host + bytes / sizeof(float));
+            if (pl->prm.precision == ZAFX_PRECISION_F64) pl->h_dct64.assign((const double*)host, (const double*)host + bytes / sizeof(double));
+            else pl->h_dct.assign((const float*)host, (const float*)host + bytes / sizeof(float));
             break;
         case ZAFX_CONST_MATRIX:
             pl->h_matrix.assign((const float*)host, (const float*)host + bytes / sizeof(float));
@@ -638,8 +676,8 @@ int zafx_execute(zafx_plan* pl, const void* d_in, void* d_out, int64_t n_clips, 
     if (int rc = zafx_plan_out_dims(pl, n_in, dims)) return rc;
     if (pl->kind == ZAFX_LINEAR && !pl->d_matrix) return fail_msg("matrix constant not set");
     if (!is_cqt_family(pl->kind) && pl->kind != ZAFX_LINEAR && !pl->d_window && !pl->d_window64) return fail_msg("window constant not set");
-    if ((pl->kind == ZAFX_MEL || pl->kind == ZAFX_MFCC) && !pl->fb.d_pack) return fail_msg("mel filterbank constant not set");
-    if (pl->kind == ZAFX_MFCC && !pl->dct.d_pack) return fail_msg("DCT constant not set");
+    if ((pl->kind == ZAFX_MEL || pl->kind == ZAFX_MFCC) && !pl->fb.d_pack && !pl->d_fb64) return fail_msg("mel filterbank constant not set");
+    if (pl->kind == ZAFX_MFCC && !pl->dct.d_pack && !pl->d_dct64) return fail_msg("DCT constant not set");
     if (is_cqt_family(pl->kind)) {
         if (!pl->d_indptr || !pl->d_indices || !pl->d_values) return fail_msg("CQT kernel constants not set");
         if ((int)pl->h_values.size() != pl->nnz || pl->h_indptr.back() != pl->nnz) return fail_msg("CQT kernel CSR arrays are inconsistent");
@@ -662,14 +700,17 @@ int zafx_execute(zafx_plan* pl, const void* d_in, void* d_out, int64_t n_clips, 
             else e = launch_istft(*pl, (const float2*)d_in, (float*)d_out, n_clips, (int)n_in, dims[0]);
             break;
         case ZAFX_MDCT:
-            e = launch_mdct(*pl, (const float*)d_in, (float*)d_out, n_clips, n_in, (int)dims[1]);
+            if (pl->prm.precision == ZAFX_PRECISION_F64) e = launch_mdct_f64(*pl, (const double*)d_in, (double*)d_out, n_clips, n_in, (int)dims[1]);
+            else e = launch_mdct(*pl, (const float*)d_in, (float*)d_out, n_clips, n_in, (int)dims[1]);
             break;
         case ZAFX_IMDCT:
-            e = launch_imdct(*pl, (const float*)d_in, (float*)d_out, n_clips, (int)n_in, dims[0]);
+            if (pl->prm.precision == ZAFX_PRECISION_F64) e = launch_imdct_f64(*pl, (const double*)d_in, (double*)d_out, n_clips, (int)n_in, dims[0]);
+            else e = launch_imdct(*pl, (const float*)d_in, (float*)d_out, n_clips, (int)n_in, dims[0]);
             break;
         case ZAFX_MEL:
         case ZAFX_MFCC:
-            e = launch_mel(*pl, (const float*)d_in, (float*)d_out, n_clips, n_in, (int)dims[1]);
+            if (pl->prm.precision == ZAFX_PRECISION_F64) e = launch_mel_f64(*pl, (const double*)d_in, (double*)d_out, n_clips, n_in, (int)dims[1]);
+            else e = launch_mel(*pl, (const float*)d_in, (float*)d_out, n_clips, n_in, (int)dims[1]);
             break;
         case ZAFX_LINEAR:
             e = launch_linear(*pl, (const float*)d_in, (float*)d_out, n_clips);
@@ -848,8 +889,14 @@ int zafx_comm_broadcast_constants(zafx_comm* c, zafx_plan* pl, int root) {
                     if (pl->prm.precision == ZAFX_PRECISION_F64) span(pl->h_window64);
                     else span(pl->h_window);
                     break;
-                case ZAFX_CONST_MEL_FB: span(pl->h_fb); break;
-                case ZAFX_CONST_DCT: span(pl->h_dct); break;
+                case ZAFX_CONST_MEL_FB:
+                    if (pl->prm.precision == ZAFX_PRECISION_F64) span(pl->h_fb64);
+                    else span(pl->h_fb);
+                    break;
+                case ZAFX_CONST_DCT:
+                    if (pl->prm.precision == ZAFX_PRECISION_F64) span(pl->h_dct64);
+                    else span(pl->h_dct);
+                    break;
                 case ZAFX_CONST_MATRIX: span(pl->h_matrix); break;
                 case ZAFX_CONST_CQT_INDPTR: span(pl->h_indptr); break;
                 case ZAFX_CONST_CQT_INDICES: span(pl->h_indices); break;

@@ -1,4 +1,4 @@
-// zafx_f64.hip -- float64 compute mode of the STFT / ISTFT ("bit-closer parity").
+// zafx_f64.hip -- float64 compute mode of the STFT / ISTFT, MDCT / IMDCT and melspectrogram / mfcc ("bit-closer parity").
 //
 // The reference computes in float64 / complex128 (zaf.py:128, :139, :223).  The tuned kernels of
 // zafx_stft.hip are float32; a plan created with zafx_params.precision = ZAFX_PRECISION_F64 runs the
@@ -160,10 +160,169 @@ __global__ __launch_bounds__(kThreads) void k_ola_f64(const double* __restrict__
     }
 }
 
+// ---- MDCT / IMDCT (zaf.py:984-1184) through the W/4-point DCT-IV of zafx_mdct.hip, in float64 -------------------
+// c[m] = (v[2m] + i v[M-1-2m]) g_m, Y = FFT_{M/2}(c), y_k = Y[k] g_k, out[2k] = Re y_k, out[M-1-2k] = -Im y_k,
+// with g_m = exp(-i pi (8m+1) / (8M)); `v` (M doubles) is consumed, `u` (M doubles) receives the result.
+__device__ void dct4_lds(const double* v, double* u, double2* a, double2* b, int log2nf, const double2* __restrict__ tw,
+                         const double2* __restrict__ g) {
+    const int NF = 1 << log2nf, M = 2 * NF;
+    for (int m = threadIdx.x; m < NF; m += kThreads) a[m] = dmul(make_double2(v[2 * m], v[M - 1 - 2 * m]), g[m]);
+    __syncthreads();
+    const double2* z = fft_lds(a, b, log2nf, tw);
+    for (int k = threadIdx.x; k < NF; k += kThreads) {
+        const double2 y = dmul(z[k], g[k]);
+        u[2 * k] = y.x;
+        u[M - 1 - 2 * k] = -y.y;
+    }
+    __syncthreads();
+}
+
+// one frame per workgroup: window, TDAC fold (W -> M reals), DCT-IV
+__global__ __launch_bounds__(kThreads) void k_mdct_f64(
+    const double* __restrict__ x, const double* __restrict__ win, const double2* __restrict__ tw, const double2* __restrict__ g,
+    double* __restrict__ out, long long n_samples, int T, int TP, int log2nf, int layout) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    const int NF = 1 << log2nf, M = 2 * NF, W = 4 * NF;
+    double* u = reinterpret_cast<double*>(smem_raw);        // W: the windowed frame, then (first M) the coefficients
+    double* v = u + W;                                      // M: the folded frame
+    double2* a = reinterpret_cast<double2*>(v + M);
+    double2* b = a + NF;
+    const long long gi = blockIdx.x;
+    const long long clip = gi / T;
+    const int t = (int)(gi - clip * T);
+    const double* xc = x + clip * n_samples;
+    const long long s0 = (long long)t * M - M;              // left pad = M (zaf.py:1036-1064)
+    for (int n = threadIdx.x; n < W; n += kThreads) {
+        const long long s = s0 + n;
+        u[n] = (s >= 0 && s < n_samples) ? xc[s] * win[n] : 0.0;
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < M; i += kThreads) {        // v = (-c_r - d, a - b_r), frame = (a, b, c, d) quarters of NF
+        v[i] = i < NF ? -u[3 * NF - 1 - i] - u[3 * NF + i] : u[i - NF] - u[3 * NF - 1 - i];
+    }
+    __syncthreads();
+    dct4_lds(v, u, a, b, log2nf, tw, g);
+    const long long stride = layout == ZAFX_LAYOUT_FT ? TP : 1;
+    const long long base = layout == ZAFX_LAYOUT_FT ? clip * M * TP + t : (clip * T + t) * M;
+    for (int f = threadIdx.x; f < M; f += kThreads) out[base + f * stride] = u[f];
+}
+
+// one frame per workgroup: DCT-IV of the coefficients, unfold (u2, -u2_r, -u1_r, -u1), window, 2/M (zaf.py:1138-1169)
+__global__ __launch_bounds__(kThreads) void k_imdct_frames_f64(
+    const double* __restrict__ coefs, const double* __restrict__ win, const double2* __restrict__ tw, const double2* __restrict__ g,
+    double* __restrict__ frames, int T, int TP, int log2nf, int layout) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    const int NF = 1 << log2nf, M = 2 * NF, W = 4 * NF;
+    double* u = reinterpret_cast<double*>(smem_raw);        // M
+    double* v = u + M;                                      // M
+    double2* a = reinterpret_cast<double2*>(v + M);
+    double2* b = a + NF;
+    const long long gi = blockIdx.x;
+    const long long clip = gi / T;
+    const int t = (int)(gi - clip * T);
+    const long long stride = layout == ZAFX_LAYOUT_FT ? TP : 1;
+    const double* cp = layout == ZAFX_LAYOUT_FT ? coefs + clip * M * TP + t : coefs + (clip * T + t) * M;
+    for (int f = threadIdx.x; f < M; f += kThreads) v[f] = cp[f * stride];
+    __syncthreads();
+    dct4_lds(v, u, a, b, log2nf, tw, g);
+    double* fr = frames + gi * W;
+    const double gain = 2.0 / (double)M;
+    for (int n = threadIdx.x; n < W; n += kThreads) {
+        const double val = n < NF ? u[NF + n] : n < 3 * NF ? -u[3 * NF - 1 - n] : -u[n - 3 * NF];
+        fr[n] = val * win[n] * gain;
+    }
+}
+
+// ---- melspectrogram / mfcc (zaf.py:324-454), one frame per workgroup ----------------------------------------------
+// STFT of the frame as k_stft_f64, |X| (mel) or |X|^2 (mfcc) of bins 1..W/2 (zaf.py:370, :437-439: DC dropped, Nyquist
+// kept), the filterbank rows as bands (zaf.py:373 / :445; the matrix is 1-2 % dense), and for mfcc log(. + eps) and rows
+// 1..n_coefs of the orthonormal DCT-II (zaf.py:443-452).
+__global__ __launch_bounds__(kThreads) void k_mel_f64(
+    const double* __restrict__ x, const double* __restrict__ win, const double2* __restrict__ tw, const double2* __restrict__ tws,
+    const double* __restrict__ fb, const int* __restrict__ fb_meta, const double* __restrict__ dct, double* __restrict__ out,
+    long long n_samples, int hop, int T, int TP, int log2n, int layout, int n_filters, int n_coefs) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    const int N = 1 << log2n;
+    const bool mfcc = n_coefs > 0;
+    double2* a = reinterpret_cast<double2*>(smem_raw);
+    double2* b = a + N;
+    const long long g = blockIdx.x;
+    const long long clip = g / T;
+    const int t = (int)(g - clip * T);
+    const double* xc = x + clip * n_samples;
+    const long long s0 = (long long)t * hop - N;
+    for (int n = threadIdx.x; n < N; n += kThreads) {
+        const long long s = s0 + 2 * n;
+        const double u = (s >= 0 && s < n_samples) ? xc[s] * win[2 * n] : 0.0;
+        const double v = (s + 1 >= 0 && s + 1 < n_samples) ? xc[s + 1] * win[2 * n + 1] : 0.0;
+        a[n] = make_double2(u, v);
+    }
+    __syncthreads();
+    const double2* z = fft_lds(a, b, log2n, tw);
+    double* mag = reinterpret_cast<double*>(z == a ? b : a);   // the idle FFT buffer: N bins, then n_filters band sums
+    double* mel = mag + N;
+    auto put = [&](int k, double2 v) {   // bin k >= 1 -> slot k - 1
+        const double h = hypot(v.x, v.y);   // np.abs of a complex (zaf.py:370); the power is its square (:437-439)
+        mag[k - 1] = mfcc ? h * h : h;
+    };
+    for (int k = threadIdx.x; k < N / 2; k += kThreads) {
+        if (k == 0) {
+            const double2 z0 = z[0], zc = z[N / 2];
+            put(N, make_double2(z0.x - z0.y, 0.0));
+            put(N / 2, dconj(zc));
+        } else {
+            const double2 zk = z[k], zn = z[N - k];
+            const double2 e = make_double2(0.5 * (zk.x + zn.x), 0.5 * (zk.y - zn.y));
+            const double2 d = make_double2(0.5 * (zk.x - zn.x), 0.5 * (zk.y + zn.y));
+            const double2 to = dmul(tws[k], make_double2(d.y, -d.x));
+            put(k, dadd(e, to));
+            put(N - k, dconj(dsub(e, to)));
+        }
+    }
+    __syncthreads();
+    for (int m = threadIdx.x; m < n_filters; m += kThreads) {
+        const int lo = fb_meta[3 * m], cnt = fb_meta[3 * m + 1];
+        const double* row = fb + fb_meta[3 * m + 2];
+        double acc = 0.0;
+        for (int j = 0; j < cnt; ++j) acc += row[j] * mag[lo + j];
+        mel[m] = mfcc ? log(acc + 2.220446049250313e-16) : acc;   // np.finfo(float).eps (zaf.py:446)
+    }
+    __syncthreads();
+    const int rows = mfcc ? n_coefs : n_filters;
+    const long long stride = layout == ZAFX_LAYOUT_FT ? TP : 1;
+    const long long base = layout == ZAFX_LAYOUT_FT ? clip * rows * TP + t : (clip * T + t) * rows;
+    for (int r = threadIdx.x; r < rows; r += kThreads) {
+        double v;
+        if (mfcc) {
+            const double* d = dct + (long long)r * n_filters;
+            v = 0.0;
+            for (int m = 0; m < n_filters; ++m) v += d[m] * mel[m];
+        } else {
+            v = mel[r];
+        }
+        out[base + r * stride] = v;
+    }
+}
+
 }  // namespace
 
+const char* mel_f64_kernel_name() { return "k_mel_f64"; }
+const char* mdct_f64_kernel_name() { return "k_mdct_f64"; }
+const char* imdct_f64_kernel_name() { return "k_imdct_frames_f64"; }
 const char* stft_f64_kernel_name() { return "k_stft_f64"; }
 const char* istft_f64_kernel_name() { return "k_ifft_frames_f64"; }
+
+// grow-only scratch of time-domain frames, owned by the plan
+static hipError_t grow_scratch(zafx_plan& pl, size_t need) {
+    if (need <= pl.scratch_bytes) return hipSuccess;
+    if (hipError_t e = hipStreamSynchronize(pl.stream); e != hipSuccess) return e;
+    if (pl.d_scratch64) (void)hipFree(pl.d_scratch64);
+    pl.d_scratch64 = nullptr;
+    pl.scratch_bytes = 0;
+    if (hipError_t e = hipMalloc((void**)&pl.d_scratch64, need); e != hipSuccess) return e;
+    pl.scratch_bytes = need;
+    return hipSuccess;
+}
 
 hipError_t launch_stft_f64(const zafx_plan& pl, const double* x, double2* out, int64_t n_clips, int64_t n_samples, int T) {
     const long long blocks = (long long)n_clips * T;
@@ -179,15 +338,7 @@ hipError_t launch_stft_f64(const zafx_plan& pl, const double* x, double2* out, i
 hipError_t launch_istft_f64(zafx_plan& pl, const double2* spec, double* y, int64_t n_clips, int T, int64_t out_len) {
     const long long blocks = (long long)n_clips * T;
     if (blocks <= 0 || out_len <= 0) return hipSuccess;
-    const size_t need = (size_t)blocks * pl.W * sizeof(double);
-    if (need > pl.scratch_bytes) {   // grow-only scratch of time-domain frames, owned by the plan
-        if (hipError_t e = hipStreamSynchronize(pl.stream); e != hipSuccess) return e;
-        if (pl.d_scratch64) (void)hipFree(pl.d_scratch64);
-        pl.d_scratch64 = nullptr;
-        pl.scratch_bytes = 0;
-        if (hipError_t e = hipMalloc((void**)&pl.d_scratch64, need); e != hipSuccess) return e;
-        pl.scratch_bytes = need;
-    }
+    if (hipError_t e = grow_scratch(pl, (size_t)blocks * pl.W * sizeof(double)); e != hipSuccess) return e;
     const size_t smem = (size_t)pl.W * sizeof(double2);
     auto kern = k_ifft_frames_f64;
     if (hipError_t e = ensure_dynamic_lds(reinterpret_cast<const void*>(kern), pl.device, smem); e != hipSuccess) return e;
@@ -199,6 +350,48 @@ hipError_t launch_istft_f64(zafx_plan& pl, const double2* spec, double* y, int64
     const double scale = 1.0 / (2.0 * (double)pl.W * pl.cola_gain64);   // 1/W of the inverse DFT x the factor 2 left by the fold
     hipLaunchKernelGGL(k_ola_f64, dim3((unsigned)grid), dim3(kThreads), 0, pl.stream, pl.d_scratch64, y, T, pl.W, pl.H, (long long)out_len,
                        total, scale);
+    return hipGetLastError();
+}
+
+hipError_t launch_mel_f64(const zafx_plan& pl, const double* x, double* out, int64_t n_clips, int64_t n_samples, int T) {
+    const long long blocks = (long long)n_clips * T;
+    if (blocks <= 0) return hipSuccess;
+    const size_t smem = (size_t)pl.W * sizeof(double2);   // two buffers of W/2 points; the idle one later holds bins + band sums
+    auto kern = k_mel_f64;
+    if (hipError_t e = ensure_dynamic_lds(reinterpret_cast<const void*>(kern), pl.device, smem); e != hipSuccess) return e;
+    hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(kThreads), smem, pl.stream, x, pl.d_window64, pl.d_tw64, pl.d_tws64, pl.d_fb64,
+                       pl.d_fb64_meta, pl.d_dct64, out, (long long)n_samples, pl.H, T, (int)row_pitch(pl, T), pl.log2nf, pl.layout,
+                       pl.prm.n_filters, pl.kind == ZAFX_MFCC ? pl.prm.n_coefs : 0);
+    return hipGetLastError();
+}
+
+hipError_t launch_mdct_f64(const zafx_plan& pl, const double* x, double* out, int64_t n_clips, int64_t n_samples, int T) {
+    const long long blocks = (long long)n_clips * T;
+    if (blocks <= 0) return hipSuccess;
+    const size_t smem = (size_t)pl.W * 8 + (size_t)(pl.W / 2) * 8 + (size_t)(pl.W / 4) * 32;   // u, v, two FFT buffers
+    auto kern = k_mdct_f64;
+    if (hipError_t e = ensure_dynamic_lds(reinterpret_cast<const void*>(kern), pl.device, smem); e != hipSuccess) return e;
+    hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(kThreads), smem, pl.stream, x, pl.d_window64, pl.d_tw64, pl.d_tws64, out,
+                       (long long)n_samples, T, (int)row_pitch(pl, T), pl.log2nf, pl.layout);
+    return hipGetLastError();
+}
+
+hipError_t launch_imdct_f64(zafx_plan& pl, const double* coefs, double* y, int64_t n_clips, int T, int64_t out_len) {
+    const long long blocks = (long long)n_clips * T;
+    if (blocks <= 0 || out_len <= 0) return hipSuccess;
+    if (hipError_t e = grow_scratch(pl, (size_t)blocks * pl.W * sizeof(double)); e != hipSuccess) return e;
+    const size_t smem = (size_t)(pl.W / 2) * 16 + (size_t)(pl.W / 4) * 32;
+    auto kern = k_imdct_frames_f64;
+    if (hipError_t e = ensure_dynamic_lds(reinterpret_cast<const void*>(kern), pl.device, smem); e != hipSuccess) return e;
+    hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(kThreads), smem, pl.stream, coefs, pl.d_window64, pl.d_tw64, pl.d_tws64,
+                       pl.d_scratch64, T, (int)row_pitch(pl, T), pl.log2nf, pl.layout);
+    if (hipError_t e = hipGetLastError(); e != hipSuccess) return e;
+    // two-frame TDAC overlap-add in ascending frame order (zaf.py:1172-1179) and the trim [H : -H-1] (:1182): the same
+    // gather as the ISTFT's with hop = W/2
+    const long long total = (long long)n_clips * out_len;
+    const long long grid = std::min<long long>((total + kThreads - 1) / kThreads, (long long)pl.n_cus * 32);
+    hipLaunchKernelGGL(k_ola_f64, dim3((unsigned)grid), dim3(kThreads), 0, pl.stream, pl.d_scratch64, y, T, pl.W, pl.H, (long long)out_len,
+                       total, 1.0);
     return hipGetLastError();
 }
 

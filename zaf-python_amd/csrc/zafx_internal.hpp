@@ -68,7 +68,10 @@ struct zafx_plan {
     double* d_scratch64 = nullptr; // ISTFT: time-domain frames of the current call (grow-only)
     size_t scratch_bytes = 0;
     double cola_gain64 = 0.0;
-    std::vector<double> h_window64;
+    std::vector<double> h_window64, h_fb64, h_dct64;
+    double* d_fb64 = nullptr;      // mel filterbank rows as bands: values of [first, first + count) of every row, back to back
+    int* d_fb64_meta = nullptr;    // [n_filters][3]: first column, count, offset into d_fb64
+    double* d_dct64 = nullptr;     // [n_coefs][n_filters]
     int* d_slots = nullptr;        // per non-zero: LDS slot of its column in k_cqt's one-sided spectrum (bit 31 = conjugate)
     int cqt_k_lo = 0, cqt_k_hi = -1, cqt_k_special = 0;   // real-split pairs the kernel's columns need
     bool cqt_dirty = true;
@@ -95,8 +98,14 @@ hipError_t launch_stft(const zafx_plan& pl, const float* x, float2* out, int64_t
 hipError_t launch_istft(const zafx_plan& pl, const float2* spec, float* y, int64_t n_clips, int T, int64_t out_len);
 hipError_t launch_stft_f64(const zafx_plan& pl, const double* x, double2* out, int64_t n_clips, int64_t n_samples, int T);
 hipError_t launch_istft_f64(zafx_plan& pl, const double2* spec, double* y, int64_t n_clips, int T, int64_t out_len);
+hipError_t launch_mel_f64(const zafx_plan& pl, const double* x, double* out, int64_t n_clips, int64_t n_samples, int T);
+hipError_t launch_mdct_f64(const zafx_plan& pl, const double* x, double* out, int64_t n_clips, int64_t n_samples, int T);
+hipError_t launch_imdct_f64(zafx_plan& pl, const double* coefs, double* y, int64_t n_clips, int T, int64_t out_len);
 const char* stft_f64_kernel_name();
 const char* istft_f64_kernel_name();
+const char* mdct_f64_kernel_name();
+const char* mel_f64_kernel_name();
+const char* imdct_f64_kernel_name();
 hipError_t launch_mdct(const zafx_plan& pl, const float* x, float* out, int64_t n_clips, int64_t n_samples, int T);
 hipError_t launch_imdct(const zafx_plan& pl, const float* coefs, float* y, int64_t n_clips, int T, int64_t out_len);
 hipError_t launch_mel(const zafx_plan& pl, const float* x, float* out, int64_t n_clips, int64_t n_samples, int T);

@@ -235,10 +235,10 @@ class Plan:
 
     def set_mel_filterbank(self, mel_filterbank):
         dense = mel_filterbank.toarray() if hasattr(mel_filterbank, "toarray") else np.asarray(mel_filterbank)
-        self._set(_lib.CONST_MEL_FB, dense, np.float32)
+        self._set(_lib.CONST_MEL_FB, dense, np.float64 if self.f64 else np.float32)
 
     def set_dct(self, dct_rows):
-        self._set(_lib.CONST_DCT, dct_rows, np.float32)
+        self._set(_lib.CONST_DCT, dct_rows, np.float64 if self.f64 else np.float32)
 
     def set_matrix(self, matrix):
         self._set(_lib.CONST_MATRIX, matrix, np.float32)
@@ -448,13 +448,14 @@ def _as_signal(audio_signal, dtype=np.float32):
     return _as_clips(a[None, :], dtype=dtype)
 
 
-# Arithmetic of the drop-in zaf.stft / zaf.istft: "f32" (default, the tuned kernels) or "f64" (the
+# Arithmetic of the drop-in zaf.stft / istft / mdct / imdct / melspectrogram / mfcc: "f32" (default, the tuned kernels) or "f64" (the
 # reference's own dtype on the device, within 1e-12 of zaf.py).
 _PRECISION = {"value": "f32"}
 
 
 def set_precision(precision):
-    """Select the device arithmetic of the drop-in `stft` / `istft`: "f32" or "f64"."""
+    """Select the device arithmetic of the drop-in `stft` / `istft` / `mdct` / `imdct` / `melspectrogram` / `mfcc`
+    (`cqtspectrogram` / `cqtchromagram` stay float32): "f32" or "f64"."""
     if precision not in ("f32", "f64"):
         raise ValueError('precision must be "f32" or "f64"')
     _PRECISION["value"] = precision
@@ -500,12 +501,12 @@ def istft_plan(window_function, step_length, layout="FT", device=0, onesided=Fal
     return _cached(key, make)
 
 
-def mdct_plan(window_function, layout="FT", device=0, inverse=False, row_align=0):
+def mdct_plan(window_function, layout="FT", device=0, inverse=False, row_align=0, f64=False):
     w = _as_window(window_function)
-    key = ("imdct" if inverse else "mdct", device, len(w), _LAYOUTS[layout], _as_row_align(row_align, layout), _digest(w))
+    key = ("imdct" if inverse else "mdct", device, len(w), _LAYOUTS[layout], _as_row_align(row_align, layout), bool(f64), _digest(w))
 
     def make():
-        p = Plan(_lib.IMDCT if inverse else _lib.MDCT, device, window_length=len(w), layout=layout, row_align=row_align)
+        p = Plan(_lib.IMDCT if inverse else _lib.MDCT, device, window_length=len(w), layout=layout, row_align=row_align, f64=f64)
         p.set_window(w)
         return p
     return _cached(key, make)
@@ -520,7 +521,7 @@ def _dense_filterbank(mel_filterbank, window_length):
     return fb
 
 
-def mel_plan(window_function, step_length, mel_filterbank, number_coefficients=None, layout="FT", device=0, row_align=0):
+def mel_plan(window_function, step_length, mel_filterbank, number_coefficients=None, layout="FT", device=0, row_align=0, f64=False):
     w, h = _as_window(window_function), _as_step(step_length)
     if not hasattr(mel_filterbank, "toarray"):
         raise ValueError("mel_filterbank must be a scipy.sparse matrix (as returned by melfilterbank)")
@@ -533,13 +534,13 @@ def mel_plan(window_function, step_length, mel_filterbank, number_coefficients=N
         raise ValueError("number_coefficients must be in [1, number_filters - 1]")
     # the cache key hashes the sparse triplet (a few KB), not the dense matrix (1 MB: 1.8 ms per call)
     csr = mel_filterbank.tocsr()
-    key = ("mfcc" if mfcc else "mel", device, len(w), h, _LAYOUTS[layout], ncoef, n_filters, _as_row_align(row_align, layout),
+    key = ("mfcc" if mfcc else "mel", device, len(w), h, _LAYOUTS[layout], ncoef, n_filters, _as_row_align(row_align, layout), bool(f64),
            _digest(w, csr.data, csr.indices, csr.indptr))
 
     def make():
         fb = _dense_filterbank(mel_filterbank, len(w))
         p = Plan(_lib.MFCC if mfcc else _lib.MEL, device, window_length=len(w), step_length=h, layout=layout,
-                 n_filters=fb.shape[0], n_coefs=ncoef, row_align=row_align)
+                 n_filters=fb.shape[0], n_coefs=ncoef, row_align=row_align, f64=f64)
         p.set_window(w)
         p.set_mel_filterbank(fb)
         if mfcc:
@@ -613,34 +614,34 @@ def istft_batch(spectra, window_function, step_length, layout="FT", device=0, on
     return istft_plan(w, step_length, layout, device, onesided, f64).run_host(s, nt)
 
 
-def mdct_batch(clips, window_function, layout="FT", device=0):
-    """(B, N) -> (B, W/2, T) float32 ["FT"] or (B, T, W/2) ["TF"]."""
-    x = _as_clips(clips)
-    return mdct_plan(window_function, layout, device).run_host(x, x.shape[1])
+def mdct_batch(clips, window_function, layout="FT", device=0, f64=False):
+    """(B, N) -> (B, W/2, T) float32 ["FT"] or (B, T, W/2) ["TF"]; f64: float64 arrays and arithmetic."""
+    x = _as_clips(clips, dtype=np.float64 if f64 else np.float32)
+    return mdct_plan(window_function, layout, device, f64=f64).run_host(x, x.shape[1])
 
 
-def imdct_batch(coefficients, window_function, layout="FT", device=0):
-    """(B, W/2, T) ["FT"] or (B, T, W/2) ["TF"] -> (B, (W/2)(T-1) - 1) float32."""
-    c = np.ascontiguousarray(coefficients, dtype=np.float32)
+def imdct_batch(coefficients, window_function, layout="FT", device=0, f64=False):
+    """(B, W/2, T) ["FT"] or (B, T, W/2) ["TF"] -> (B, (W/2)(T-1) - 1) float32 (float64 with f64)."""
+    c = np.ascontiguousarray(coefficients, dtype=np.float64 if f64 else np.float32)
     w = _as_window(window_function)
     if c.ndim != 3:
         raise ValueError("coefficients must be 3-D")
     nf, nt = (c.shape[1], c.shape[2]) if _LAYOUTS[layout] == _lib.LAYOUT_FT else (c.shape[2], c.shape[1])
     if 2 * nf != len(w):
         raise ValueError("coefficient rows must equal window_length/2")
-    return mdct_plan(w, layout, device, inverse=True).run_host(c, nt)
+    return mdct_plan(w, layout, device, inverse=True, f64=f64).run_host(c, nt)
 
 
-def melspectrogram_batch(clips, window_function, step_length, mel_filterbank, layout="FT", device=0):
-    """(B, N) -> (B, n_filters, T) float32."""
-    x = _as_clips(clips)
-    return mel_plan(window_function, step_length, mel_filterbank, None, layout, device).run_host(x, x.shape[1])
+def melspectrogram_batch(clips, window_function, step_length, mel_filterbank, layout="FT", device=0, f64=False):
+    """(B, N) -> (B, n_filters, T) float32 (float64 arrays and arithmetic with f64)."""
+    x = _as_clips(clips, dtype=np.float64 if f64 else np.float32)
+    return mel_plan(window_function, step_length, mel_filterbank, None, layout, device, f64=f64).run_host(x, x.shape[1])
 
 
-def mfcc_batch(clips, window_function, step_length, mel_filterbank, number_coefficients, layout="FT", device=0):
-    """(B, N) -> (B, number_coefficients, T) float32."""
-    x = _as_clips(clips)
-    return mel_plan(window_function, step_length, mel_filterbank, number_coefficients, layout, device).run_host(x, x.shape[1])
+def mfcc_batch(clips, window_function, step_length, mel_filterbank, number_coefficients, layout="FT", device=0, f64=False):
+    """(B, N) -> (B, number_coefficients, T) float32 (float64 arrays and arithmetic with f64)."""
+    x = _as_clips(clips, dtype=np.float64 if f64 else np.float32)
+    return mel_plan(window_function, step_length, mel_filterbank, number_coefficients, layout, device, f64=f64).run_host(x, x.shape[1])
 
 
 def cqtspectrogram_batch(clips, sampling_frequency, time_resolution, cqt_kernel, layout="FT", device=0):
@@ -755,14 +756,16 @@ def istft(audio_stft, window_function, step_length):
 
 def melspectrogram(audio_signal, window_function, step_length, mel_filterbank):
     """Drop-in for zaf.melspectrogram (zaf.py:324): (N,) -> (n_filters, T) float64."""
-    x = _as_signal(audio_signal)
-    return melspectrogram_batch(x, window_function, step_length, mel_filterbank)[0].astype(np.float64)
+    f64 = _PRECISION["value"] == "f64"
+    x = _as_signal(audio_signal, np.float64 if f64 else np.float32)
+    return melspectrogram_batch(x, window_function, step_length, mel_filterbank, f64=f64)[0].astype(np.float64)
 
 
 def mfcc(audio_signal, window_function, step_length, mel_filterbank, number_coefficients):
     """Drop-in for zaf.mfcc (zaf.py:378): (N,) -> (number_coefficients, T) float64."""
-    x = _as_signal(audio_signal)
-    return mfcc_batch(x, window_function, step_length, mel_filterbank, number_coefficients)[0].astype(np.float64)
+    f64 = _PRECISION["value"] == "f64"
+    x = _as_signal(audio_signal, np.float64 if f64 else np.float32)
+    return mfcc_batch(x, window_function, step_length, mel_filterbank, number_coefficients, f64=f64)[0].astype(np.float64)
 
 
 def cqtspectrogram(audio_signal, sampling_frequency, time_resolution, cqt_kernel):
@@ -779,8 +782,9 @@ def cqtchromagram(audio_signal, sampling_frequency, time_resolution, octave_reso
 
 def mdct(audio_signal, window_function):
     """Drop-in for zaf.mdct (zaf.py:984): (N,) -> (W/2, T) float64."""
-    x = _as_signal(audio_signal)
-    return mdct_batch(x, window_function)[0].astype(np.float64)
+    f64 = _PRECISION["value"] == "f64"
+    x = _as_signal(audio_signal, np.float64 if f64 else np.float32)
+    return mdct_batch(x, window_function, f64=f64)[0].astype(np.float64)
 
 
 def imdct(audio_mdct, window_function):
@@ -788,4 +792,4 @@ def imdct(audio_mdct, window_function):
     c = np.asarray(audio_mdct)
     if c.ndim != 2:
         raise ValueError("audio_mdct must be 2-D (number_frequencies, number_times)")
-    return imdct_batch(c[None], window_function)[0].astype(np.float64)
+    return imdct_batch(c[None], window_function, f64=_PRECISION["value"] == "f64")[0].astype(np.float64)

@@ -78,8 +78,10 @@ enum zafx_spectrum {      /* STFT output / ISTFT input rows  
 
 enum zafx_precision {     /* device arithmetic and array types                          */
     ZAFX_PRECISION_F32 = 0, /* float32 / complex64 arrays and arithmetic (every kind)                        */
-    ZAFX_PRECISION_F64 = 1  /* ZAFX_STFT / ZAFX_ISTFT only: float64 / complex128 arrays, the window constant is
-                               float64[W]; the reference's own dtype (zaf.py:128, :139), within 1e-12 of it   */
+    ZAFX_PRECISION_F64 = 1  /* every kind but ZAFX_LINEAR: float64 / complex128 arrays AND constants (window float64[W],
+                               mel filterbank / DCT rows float64, CQT values complex128); the reference's own dtype
+                               (zaf.py:128, :139), results within 1e-12 of it (mfcc 1e-10); any power-of-two window.
+                               Exactness mode: one workgroup per frame, not tuned                              */
 };
 
 enum zafx_constant {

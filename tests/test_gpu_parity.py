@@ -605,10 +605,37 @@ def test_f64_dropin_and_golden(zafx, golden):
             for hop in (32, 16):
                 assert relerr(zafx.melspectrogram(g[f"x_{n}"], g["ham"], hop, fb), g[f"mel_{n}_{hop}"]) <= TOL_F64
                 assert relerr(zafx.mfcc(g[f"x_{n}"], g["ham"], hop, fb, 5), g[f"mfcc_{n}_{hop}"]) <= 1e-10   # log(. + eps) of tiny band sums
+        ck = scipy.sparse.csr_matrix(g["ck_dense"])
+        for n in (400, 4000, 4321):
+            got = zafx.cqtspectrogram(g[f"xq_{n}"], 4000, 50, ck)
+            assert got.shape == g[f"cqt_{n}"].shape and (got.size == 0 or relerr(got, g[f"cqt_{n}"]) <= TOL_F64)
+            got = zafx.cqtchromagram(g[f"xq_{n}"], 4000, 50, 12, ck)
+            assert got.shape == g[f"chroma_{n}"].shape and (got.size == 0 or relerr(got, g[f"chroma_{n}"]) <= TOL_F64)
     finally:
         zafx.set_precision("f32")
     with pytest.raises(zafx.ZafxError):
-        zafx.Plan(zafx.CQT, step_length=1764, fft_length=4096, n_bins=24, f64=True)
+        zafx.Plan(zafx.LINEAR, window_length=64, n_filters=64, f64=True)
+
+
+@pytest.mark.parametrize("fs,res,fmin,fmax,tr,n", [(44100, 24, 55, 3520, 25, 60000),     # fft_length 32768: 8 sub-transforms of 4096
+                                                    (16000, 12, 110, 3520, 50, 30000),    # 4096: one transform in LDS
+                                                    (8000, 12, 220, 1760, 40, 9001)])
+def test_f64_cqt(zafx, fs, res, fmin, fmax, tr, n):
+    """ZAFX_PRECISION_F64 for cqtspectrogram / cqtchromagram: complex128 kernel, float64 frames, 1e-12 of the reference."""
+    ck = zafx.cqtkernel(fs, res, fmin, fmax)
+    x = np.stack([synth_clip(43, c, n).astype(np.float64) + 1e-9 * c for c in range(2)])
+    for layout in ("FT", "TF"):
+        spec = zafx.cqtspectrogram_batch(x, fs, tr, ck, layout=layout, f64=True)
+        chroma = zafx.cqtchromagram_batch(x, fs, tr, res, ck, layout=layout, f64=True)
+        assert spec.dtype == np.float64 and chroma.dtype == np.float64
+        if layout == "TF":
+            spec, chroma = spec.transpose(0, 2, 1), chroma.transpose(0, 2, 1)
+        for c in range(2):
+            ref = orc.cqtspectrogram(x[c], fs, tr, ck)
+            ref_c = orc.cqtchromagram(x[c], fs, tr, res, ck)
+            assert spec[c].shape == ref.shape and chroma[c].shape == ref_c.shape
+            assert relerr(spec[c], ref) <= TOL_F64, (layout, c)
+            assert relerr(chroma[c], ref_c) <= TOL_F64, (layout, c)
 
 
 @pytest.mark.parametrize("wl,hop,n,nmel", [(2048, 1024, 100000, 128), (2048, 512, 30001, 40), (1024, 512, 20000, 64), (4096, 2048, 50000, 128),

@@ -238,6 +238,10 @@ static int finalize_constant(zafx_plan* pl, int which) {
             pl->cqt_dirty = true;
             return 0;
         case ZAFX_CONST_CQT_VALUES:
+            if (pl->prm.precision == ZAFX_PRECISION_F64) {
+                ZAFX_HIP(upload(&pl->d_values64, pl->h_values64.data(), pl->h_values64.size() * sizeof(double2)));
+                return 0;
+            }
             ZAFX_HIP(upload(&pl->d_values, pl->h_values.data(), pl->h_values.size() * sizeof(cf32)));
             return 0;
     }
@@ -385,8 +389,8 @@ int zafx_plan_create(zafx_plan** out, int device, int kind, const zafx_params* p
     if (params->spectrum >= ZAFX_SPECTRUM_MAGNITUDE && kind != ZAFX_STFT)
         return fail_msg("magnitude / power spectra are outputs of ZAFX_STFT only");
     if (params->precision != ZAFX_PRECISION_F32 && params->precision != ZAFX_PRECISION_F64) return fail_msg("bad precision");
-    if (params->precision == ZAFX_PRECISION_F64 && (kind == ZAFX_CQT || kind == ZAFX_CHROMA || kind == ZAFX_LINEAR))
-        return fail_msg("ZAFX_PRECISION_F64 is available for the STFT, MDCT and mel families only");
+    if (params->precision == ZAFX_PRECISION_F64 && kind == ZAFX_LINEAR)
+        return fail_msg("ZAFX_PRECISION_F64 is not available for ZAFX_LINEAR");
     if (params->row_align < 0 || params->row_align > 1024 || (params->row_align & (params->row_align - 1)))
         return fail_msg("row_align must be 0 or a power of two <= 1024");
     if (params->row_align > 1 && (params->layout != ZAFX_LAYOUT_FT || kind == ZAFX_LINEAR))
@@ -477,8 +481,8 @@ int zafx_plan_create(zafx_plan** out, int device, int kind, const zafx_params* p
     }
     if (e == hipSuccess) e = upload(&pl->d_tw_aux, aux.data(), aux.size() * sizeof(cf32));
     if (e == hipSuccess && pl->prm.precision == ZAFX_PRECISION_F64) {   // float64 tables, evaluated in long double
-        const bool mdct = is_mdct_family(kind);
-        const int n = mdct ? pl->W / 4 : pl->W / 2;   // FFT length
+        const bool mdct = is_mdct_family(kind), cqt = is_cqt_family(kind);
+        const int n = mdct ? pl->W / 4 : cqt ? std::min(pl->W, kCqt64Sub) : pl->W / 2;   // FFT length (CQT: of one decimated sub-sequence)
         auto root = [](long long num, long long den) {
             const long double a = -2.0L * 3.14159265358979323846264338327950288L * (long double)(num % den) / (long double)den;
             double2 r = make_double2((double)cosl(a), (double)sinl(a));
@@ -487,17 +491,20 @@ int zafx_plan_create(zafx_plan** out, int device, int kind, const zafx_params* p
             if (2 * (num % den) == den) r = make_double2(-1.0, 0.0);
             return r;
         };
-        std::vector<double2> tw((size_t)std::max(n / 2, 1)), tws((size_t)(mdct ? n : n / 2 + 1));
+        std::vector<double2> tw((size_t)std::max(n / 2, 1)), tws((size_t)(mdct ? n : cqt ? pl->W : n / 2 + 1));
         for (int m = 0; m < n / 2; ++m) tw[(size_t)m] = root(m, n);
         if (mdct) {   // g_m = exp(-i pi (8m+1) / (8M)), M = W/2: pre- and post-twiddle of the DCT-IV
             for (int m = 0; m < n; ++m) tws[(size_t)m] = root(8LL * m + 1, 8LL * pl->W);
+        } else if (cqt) {   // every root of W: the decimation-in-time recombination reads exp(-2 pi i (n1 k mod W) / W)
+            for (int k = 0; k < pl->W; ++k) tws[(size_t)k] = root(k, pl->W);
         } else {
             for (int k = 0; k <= n / 2; ++k) tws[(size_t)k] = root(k, pl->W);
         }
         e = upload(&pl->d_tw64, tw.data(), tw.size() * sizeof(double2));
         if (e == hipSuccess) e = upload(&pl->d_tws64, tws.data(), tws.size() * sizeof(double2));
         pl->kernel_name = kind == ZAFX_STFT ? stft_f64_kernel_name() : kind == ZAFX_ISTFT ? istft_f64_kernel_name()
-                          : kind == ZAFX_MDCT ? mdct_f64_kernel_name() : kind == ZAFX_IMDCT ? imdct_f64_kernel_name() : mel_f64_kernel_name();
+                          : kind == ZAFX_MDCT ? mdct_f64_kernel_name() : kind == ZAFX_IMDCT ? imdct_f64_kernel_name()
+                          : cqt ? cqt_f64_kernel_name() : mel_f64_kernel_name();
     }
     if (e != hipSuccess) {
         zafx_plan_destroy(pl);
@@ -529,6 +536,7 @@ int zafx_plan_destroy(zafx_plan* pl) {
     if (pl->d_fb64) (void)hipFree(pl->d_fb64);
     if (pl->d_fb64_meta) (void)hipFree(pl->d_fb64_meta);
     if (pl->d_dct64) (void)hipFree(pl->d_dct64);
+    if (pl->d_values64) (void)hipFree(pl->d_values64);
     if (pl->d_chunk_ptr) (void)hipFree(pl->d_chunk_ptr);
     free_band(pl->fb);
     free_band(pl->dct);
@@ -572,9 +580,9 @@ static int expected_constant_bytes(const zafx_plan* pl, int which, size_t bytes,
             if (!is_cqt_family(pl->kind)) return fail_msg("plan takes no CQT kernel");
             return bytes % sizeof(int32_t) == 0 ? 0 : fail_msg("indices must be int32");
         case ZAFX_CONST_CQT_VALUES:
-            *elem = sizeof(cf32);
+            *elem = pl->prm.precision == ZAFX_PRECISION_F64 ? sizeof(double2) : sizeof(cf32);
             if (!is_cqt_family(pl->kind)) return fail_msg("plan takes no CQT kernel");
-            return bytes % sizeof(cf32) == 0 ? 0 : fail_msg("values must be complex64");
+            return bytes % *elem == 0 ? 0 : fail_msg("values must be complex64 (complex128 for a ZAFX_PRECISION_F64 plan)");
     }
     return fail_msg("unknown constant id");
 }
@@ -606,7 +614,8 @@ static int store_shadow(zafx_plan* pl, int which, const void* host, size_t bytes
             break;
         }
         case ZAFX_CONST_CQT_VALUES:
-            pl->h_values.assign((const cf32*)host, (const cf32*)host + bytes / sizeof(cf32));
+            if (pl->prm.precision == ZAFX_PRECISION_F64) pl->h_values64.assign((const double2*)host, (const double2*)host + bytes / sizeof(double2));
+            else pl->h_values.assign((const cf32*)host, (const cf32*)host + bytes / sizeof(cf32));
             break;
     }
     return 0;
@@ -679,9 +688,13 @@ int zafx_execute(zafx_plan* pl, const void* d_in, void* d_out, int64_t n_clips, 
     if ((pl->kind == ZAFX_MEL || pl->kind == ZAFX_MFCC) && !pl->fb.d_pack && !pl->d_fb64) return fail_msg("mel filterbank constant not set");
     if (pl->kind == ZAFX_MFCC && !pl->dct.d_pack && !pl->d_dct64) return fail_msg("DCT constant not set");
     if (is_cqt_family(pl->kind)) {
-        if (!pl->d_indptr || !pl->d_indices || !pl->d_values) return fail_msg("CQT kernel constants not set");
-        if ((int)pl->h_values.size() != pl->nnz || pl->h_indptr.back() != pl->nnz) return fail_msg("CQT kernel CSR arrays are inconsistent");
-        if (pl->cqt_dirty) {
+        const bool f64 = pl->prm.precision == ZAFX_PRECISION_F64;
+        if (!pl->d_indptr || !pl->d_indices || !(f64 ? (void*)pl->d_values64 : (void*)pl->d_values)) return fail_msg("CQT kernel constants not set");
+        if ((int)(f64 ? pl->h_values64.size() : pl->h_values.size()) != pl->nnz || pl->h_indptr.back() != pl->nnz)
+            return fail_msg("CQT kernel CSR arrays are inconsistent");
+        for (size_t r = 0; f64 && r + 1 < pl->h_indptr.size(); ++r)
+            if (pl->h_indptr[r + 1] < pl->h_indptr[r]) return fail_msg("CQT kernel indptr is not monotone");
+        if (!f64 && pl->cqt_dirty) {
             ZAFX_HIP(hipSetDevice(pl->device));
             if (int rc = build_cqt_chunks(pl)) return rc;
         }
@@ -717,7 +730,8 @@ int zafx_execute(zafx_plan* pl, const void* d_in, void* d_out, int64_t n_clips, 
             break;
         case ZAFX_CQT:
         case ZAFX_CHROMA:
-            e = launch_cqt(*pl, (const float*)d_in, (float*)d_out, n_clips, n_in, (int)dims[1]);
+            if (pl->prm.precision == ZAFX_PRECISION_F64) e = launch_cqt_f64(*pl, (const double*)d_in, (double*)d_out, n_clips, n_in, (int)dims[1]);
+            else e = launch_cqt(*pl, (const float*)d_in, (float*)d_out, n_clips, n_in, (int)dims[1]);
             break;
         default:
             return fail_msg("unknown plan kind");
@@ -900,7 +914,10 @@ int zafx_comm_broadcast_constants(zafx_comm* c, zafx_plan* pl, int root) {
                 case ZAFX_CONST_MATRIX: span(pl->h_matrix); break;
                 case ZAFX_CONST_CQT_INDPTR: span(pl->h_indptr); break;
                 case ZAFX_CONST_CQT_INDICES: span(pl->h_indices); break;
-                case ZAFX_CONST_CQT_VALUES: span(pl->h_values); break;
+                case ZAFX_CONST_CQT_VALUES:
+                    if (pl->prm.precision == ZAFX_PRECISION_F64) span(pl->h_values64);
+                    else span(pl->h_values);
+                    break;
             }
             if (len == 0) { ret = fail_msg("root rank has not set every constant before the broadcast"); break; }
         }

@@ -1,4 +1,4 @@
-// zafx_f64.hip -- float64 compute mode of the STFT / ISTFT, MDCT / IMDCT and melspectrogram / mfcc ("bit-closer parity").
+// zafx_f64.hip -- float64 compute mode of every transform on the path ("bit-closer parity").
 //
 // The reference computes in float64 / complex128 (zaf.py:128, :139, :223).  The tuned kernels of
 // zafx_stft.hip are float32; a plan created with zafx_params.precision = ZAFX_PRECISION_F64 runs the
@@ -304,8 +304,90 @@ __global__ __launch_bounds__(kThreads) void k_mel_f64(
     }
 }
 
+// ---- cqtspectrogram / cqtchromagram (zaf.py:562-700) ---------------------------------------------------------------
+// A frame is fft_length real samples (up to 32768: 512 KB as complex128, more than LDS).  Decimation in time by
+// N1 = fft_length / N2, N2 = min(fft_length, 4096): the N1 sub-sequences x[n1 + N1 m] are transformed in LDS one after the
+// other (F_n1, N2 points each, parked in a per-workgroup global scratch when N1 > 1), and a spectrum bin is recombined
+// only where the sparse kernel has a column:  X[c] = sum_n1 exp(-2 pi i n1 c / W) F_n1[c mod N2].  Then the CSR
+// mat-vec and np.absolute (zaf.py:630-632): one wavefront per row, lanes over its entries.  Persistent workgroups.
+__global__ __launch_bounds__(kThreads) void k_cqt_f64(
+    const double* __restrict__ x, const double2* __restrict__ tw, const double2* __restrict__ roots, const int* __restrict__ indptr,
+    const int* __restrict__ indices, const double2* __restrict__ values, double2* __restrict__ scratch, double* __restrict__ out,
+    long long n_samples, int step, int left, int T, int TP, long long total_frames, int log2w, int n_bins, int chroma_res, int layout) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    const int W = 1 << log2w;
+    const int log2n2 = log2w < 12 ? log2w : 12, N2 = 1 << log2n2, N1 = W >> log2n2;
+    double2* a = reinterpret_cast<double2*>(smem_raw);
+    double2* b = a + N2;
+    double* spec = reinterpret_cast<double*>(b + N2);   // n_bins magnitudes of the frame
+    double2* F = scratch + (long long)blockIdx.x * W;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, n_waves = kThreads / 64;
+    for (long long g = blockIdx.x; g < total_frames; g += gridDim.x) {
+        const long long clip = g / T;
+        const int t = (int)(g - clip * T);
+        const double* xc = x + clip * n_samples;
+        const long long s0 = (long long)t * step - left;   // zaf.py:612-620: `left` zeros in front of the clip
+        const double2* f_lds = nullptr;
+        for (int n1 = 0; n1 < N1; ++n1) {
+            for (int m = threadIdx.x; m < N2; m += kThreads) {
+                const long long s = s0 + n1 + (long long)N1 * m;
+                a[m] = make_double2((s >= 0 && s < n_samples) ? xc[s] : 0.0, 0.0);
+            }
+            __syncthreads();
+            const double2* z = fft_lds(a, b, log2n2, tw);
+            if (N1 == 1) {
+                f_lds = z;
+            } else {
+                for (int k = threadIdx.x; k < N2; k += kThreads) F[(long long)n1 * N2 + k] = z[k];
+                __syncthreads();   // the buffers are refilled by the next sub-sequence
+            }
+        }
+        if (N1 > 1) {
+            __threadfence_block();
+            __syncthreads();
+        }
+        for (int r = wave; r < n_bins; r += n_waves) {
+            double2 acc = make_double2(0.0, 0.0);
+            for (int e = indptr[r] + lane; e < indptr[r + 1]; e += 64) {
+                const int c = indices[e];
+                double2 xcol;
+                if (N1 == 1) {
+                    xcol = f_lds[c];
+                } else {
+                    xcol = make_double2(0.0, 0.0);
+                    const int k2 = c & (N2 - 1);
+                    for (int n1 = 0; n1 < N1; ++n1)
+                        xcol = dadd(xcol, dmul(roots[(int)(((long long)n1 * c) & (W - 1))], F[(long long)n1 * N2 + k2]));
+                }
+                acc = dadd(acc, dmul(values[e], xcol));
+            }
+            for (int off = 32; off > 0; off >>= 1) {
+                acc.x += __shfl_down(acc.x, off, 64);
+                acc.y += __shfl_down(acc.y, off, 64);
+            }
+            if (lane == 0) spec[r] = hypot(acc.x, acc.y);
+        }
+        __syncthreads();
+        const int rows = chroma_res > 0 ? chroma_res : n_bins;
+        const long long stride = layout == ZAFX_LAYOUT_FT ? TP : 1;
+        const long long base = layout == ZAFX_LAYOUT_FT ? clip * rows * TP + t : (clip * T + t) * rows;
+        for (int r = threadIdx.x; r < rows; r += kThreads) {
+            double v;
+            if (chroma_res > 0) {   // zaf.py:693-698: rows i, i + r, i + 2r, ... summed in ascending order
+                v = 0.0;
+                for (int q = r; q < n_bins; q += chroma_res) v += spec[q];
+            } else {
+                v = spec[r];
+            }
+            out[base + r * stride] = v;
+        }
+        __syncthreads();   // spec and the FFT buffers are reused by the next frame
+    }
+}
+
 }  // namespace
 
+const char* cqt_f64_kernel_name() { return "k_cqt_f64"; }
 const char* mel_f64_kernel_name() { return "k_mel_f64"; }
 const char* mdct_f64_kernel_name() { return "k_mdct_f64"; }
 const char* imdct_f64_kernel_name() { return "k_imdct_frames_f64"; }
@@ -350,6 +432,26 @@ hipError_t launch_istft_f64(zafx_plan& pl, const double2* spec, double* y, int64
     const double scale = 1.0 / (2.0 * (double)pl.W * pl.cola_gain64);   // 1/W of the inverse DFT x the factor 2 left by the fold
     hipLaunchKernelGGL(k_ola_f64, dim3((unsigned)grid), dim3(kThreads), 0, pl.stream, pl.d_scratch64, y, T, pl.W, pl.H, (long long)out_len,
                        total, scale);
+    return hipGetLastError();
+}
+
+hipError_t launch_cqt_f64(zafx_plan& pl, const double* x, double* out, int64_t n_clips, int64_t n_samples, int T) {
+    const long long total = (long long)n_clips * T;
+    if (total <= 0) return hipSuccess;
+    const int log2w = pl.log2nf + 1;
+    const int n2 = std::min(pl.W, kCqt64Sub);
+    const long long grid = std::min<long long>(total, (long long)pl.n_cus * 2);
+    if (pl.W > n2) {
+        if (hipError_t e = grow_scratch(pl, (size_t)grid * pl.W * sizeof(double2)); e != hipSuccess) return e;
+    }
+    const size_t smem = (size_t)n2 * 2 * sizeof(double2) + (size_t)pl.prm.n_bins * sizeof(double);
+    auto kern = k_cqt_f64;
+    if (hipError_t e = ensure_dynamic_lds(reinterpret_cast<const void*>(kern), pl.device, smem); e != hipSuccess) return e;
+    const int diff = pl.W - pl.H;
+    const int left = diff >= 0 ? (diff + 1) / 2 : -((-diff) / 2);   // ceil((fft_length - step) / 2), zaf.py:615
+    hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(kThreads), smem, pl.stream, x, pl.d_tw64, pl.d_tws64, pl.d_indptr, pl.d_indices,
+                       pl.d_values64, reinterpret_cast<double2*>(pl.d_scratch64), out, (long long)n_samples, pl.H, left, T,
+                       (int)row_pitch(pl, T), total, log2w, pl.prm.n_bins, pl.kind == ZAFX_CHROMA ? pl.prm.octave_resolution : 0, pl.layout);
     return hipGetLastError();
 }
 

@@ -13,6 +13,7 @@
 namespace zafx {
 
 constexpr int kMaxLdsBytes = 160 * 1024;   // LDS per CU on gfx950
+constexpr int kCqt64Sub = 4096;            // float64 CQT: length of the sub-transforms that fit LDS (2 x 4096 x 16 B)
 
 // Banded, MFMA-fragment-packed matrix (mel filterbank or DCT-II rows) cut into balanced work
 // items: see zafx_mel.hip and pack_band in zafx_capi.cpp.
@@ -72,6 +73,8 @@ struct zafx_plan {
     double* d_fb64 = nullptr;      // mel filterbank rows as bands: values of [first, first + count) of every row, back to back
     int* d_fb64_meta = nullptr;    // [n_filters][3]: first column, count, offset into d_fb64
     double* d_dct64 = nullptr;     // [n_coefs][n_filters]
+    double2* d_values64 = nullptr; // CQT kernel values of a float64 plan (complex128)
+    std::vector<double2> h_values64;
     int* d_slots = nullptr;        // per non-zero: LDS slot of its column in k_cqt's one-sided spectrum (bit 31 = conjugate)
     int cqt_k_lo = 0, cqt_k_hi = -1, cqt_k_special = 0;   // real-split pairs the kernel's columns need
     bool cqt_dirty = true;
@@ -98,6 +101,7 @@ hipError_t launch_stft(const zafx_plan& pl, const float* x, float2* out, int64_t
 hipError_t launch_istft(const zafx_plan& pl, const float2* spec, float* y, int64_t n_clips, int T, int64_t out_len);
 hipError_t launch_stft_f64(const zafx_plan& pl, const double* x, double2* out, int64_t n_clips, int64_t n_samples, int T);
 hipError_t launch_istft_f64(zafx_plan& pl, const double2* spec, double* y, int64_t n_clips, int T, int64_t out_len);
+hipError_t launch_cqt_f64(zafx_plan& pl, const double* x, double* out, int64_t n_clips, int64_t n_samples, int T);
 hipError_t launch_mel_f64(const zafx_plan& pl, const double* x, double* out, int64_t n_clips, int64_t n_samples, int T);
 hipError_t launch_mdct_f64(const zafx_plan& pl, const double* x, double* out, int64_t n_clips, int64_t n_samples, int T);
 hipError_t launch_imdct_f64(zafx_plan& pl, const double* coefs, double* y, int64_t n_clips, int T, int64_t out_len);
@@ -105,6 +109,7 @@ const char* stft_f64_kernel_name();
 const char* istft_f64_kernel_name();
 const char* mdct_f64_kernel_name();
 const char* mel_f64_kernel_name();
+const char* cqt_f64_kernel_name();
 const char* imdct_f64_kernel_name();
 hipError_t launch_mdct(const zafx_plan& pl, const float* x, float* out, int64_t n_clips, int64_t n_samples, int T);
 hipError_t launch_imdct(const zafx_plan& pl, const float* coefs, float* y, int64_t n_clips, int T, int64_t out_len);

@@ -248,7 +248,7 @@ class Plan:
         csr.sort_indices()
         self._set(_lib.CONST_CQT_INDPTR, csr.indptr, np.int32)
         self._set(_lib.CONST_CQT_INDICES, csr.indices, np.int32)
-        self._set(_lib.CONST_CQT_VALUES, csr.data, np.complex64)
+        self._set(_lib.CONST_CQT_VALUES, csr.data, np.complex128 if self.f64 else np.complex64)
 
     # ---- geometry / execution ----------------------------------------------------------
     def out_dims(self, n_in):
@@ -448,14 +448,14 @@ def _as_signal(audio_signal, dtype=np.float32):
     return _as_clips(a[None, :], dtype=dtype)
 
 
-# Arithmetic of the drop-in zaf.stft / istft / mdct / imdct / melspectrogram / mfcc: "f32" (default, the tuned kernels) or "f64" (the
+# Arithmetic of the drop-in transforms (every zaf.* function on the path): "f32" (default, the tuned kernels) or "f64" (the
 # reference's own dtype on the device, within 1e-12 of zaf.py).
 _PRECISION = {"value": "f32"}
 
 
 def set_precision(precision):
-    """Select the device arithmetic of the drop-in `stft` / `istft` / `mdct` / `imdct` / `melspectrogram` / `mfcc`
-    (`cqtspectrogram` / `cqtchromagram` stay float32): "f32" or "f64"."""
+    """Select the device arithmetic of the drop-in transforms (`stft`, `istft`, `mdct`, `imdct`, `melspectrogram`, `mfcc`,
+    `cqtspectrogram`, `cqtchromagram`): "f32" (the tuned kernels) or "f64" (the reference's own dtype, within 1e-12 of it)."""
     if precision not in ("f32", "f64"):
         raise ValueError('precision must be "f32" or "f64"')
     _PRECISION["value"] = precision
@@ -549,7 +549,7 @@ def mel_plan(window_function, step_length, mel_filterbank, number_coefficients=N
     return _cached(key, make)
 
 
-def cqt_plan(sampling_frequency, time_resolution, cqt_kernel, octave_resolution=None, layout="FT", device=0, row_align=0):
+def cqt_plan(sampling_frequency, time_resolution, cqt_kernel, octave_resolution=None, layout="FT", device=0, row_align=0, f64=False):
     if not hasattr(cqt_kernel, "tocsr"):
         raise ValueError("cqt_kernel must be a scipy.sparse matrix (as returned by cqtkernel)")
     n_bins, fft_length = cqt_kernel.shape
@@ -561,12 +561,12 @@ def cqt_plan(sampling_frequency, time_resolution, cqt_kernel, octave_resolution=
     csr = cqt_kernel.tocsr()
     chroma = octave_resolution is not None
     key = ("chroma" if chroma else "cqt", device, fft_length, step, n_bins, int(octave_resolution or 0), _LAYOUTS[layout],
-           _as_row_align(row_align, layout),
+           _as_row_align(row_align, layout), bool(f64),
            _digest(csr.indptr, csr.indices, csr.data))
 
     def make():
         p = Plan(_lib.CHROMA if chroma else _lib.CQT, device, step_length=step, layout=layout, fft_length=fft_length,
-                 n_bins=n_bins, octave_resolution=int(octave_resolution or 0), row_align=row_align)
+                 n_bins=n_bins, octave_resolution=int(octave_resolution or 0), row_align=row_align, f64=f64)
         p.set_cqt_kernel(csr)
         return p
     return _cached(key, make)
@@ -644,16 +644,16 @@ def mfcc_batch(clips, window_function, step_length, mel_filterbank, number_coeff
     return mel_plan(window_function, step_length, mel_filterbank, number_coefficients, layout, device, f64=f64).run_host(x, x.shape[1])
 
 
-def cqtspectrogram_batch(clips, sampling_frequency, time_resolution, cqt_kernel, layout="FT", device=0):
-    """(B, N) -> (B, n_bins, T) float32."""
-    x = _as_clips(clips)
-    return cqt_plan(sampling_frequency, time_resolution, cqt_kernel, None, layout, device).run_host(x, x.shape[1])
+def cqtspectrogram_batch(clips, sampling_frequency, time_resolution, cqt_kernel, layout="FT", device=0, f64=False):
+    """(B, N) -> (B, n_bins, T) float32 (float64 arrays and arithmetic with f64)."""
+    x = _as_clips(clips, dtype=np.float64 if f64 else np.float32)
+    return cqt_plan(sampling_frequency, time_resolution, cqt_kernel, None, layout, device, f64=f64).run_host(x, x.shape[1])
 
 
-def cqtchromagram_batch(clips, sampling_frequency, time_resolution, octave_resolution, cqt_kernel, layout="FT", device=0):
-    """(B, N) -> (B, octave_resolution, T) float32."""
-    x = _as_clips(clips)
-    return cqt_plan(sampling_frequency, time_resolution, cqt_kernel, int(octave_resolution), layout, device).run_host(x, x.shape[1])
+def cqtchromagram_batch(clips, sampling_frequency, time_resolution, octave_resolution, cqt_kernel, layout="FT", device=0, f64=False):
+    """(B, N) -> (B, octave_resolution, T) float32 (float64 arrays and arithmetic with f64)."""
+    x = _as_clips(clips, dtype=np.float64 if f64 else np.float32)
+    return cqt_plan(sampling_frequency, time_resolution, cqt_kernel, int(octave_resolution), layout, device, f64=f64).run_host(x, x.shape[1])
 
 
 def _pcm_device_mono(plan, pcm):
@@ -770,14 +770,16 @@ def mfcc(audio_signal, window_function, step_length, mel_filterbank, number_coef
 
 def cqtspectrogram(audio_signal, sampling_frequency, time_resolution, cqt_kernel):
     """Drop-in for zaf.cqtspectrogram (zaf.py:562): (N,) -> (n_bins, T) float64."""
-    x = _as_signal(audio_signal)
-    return cqtspectrogram_batch(x, sampling_frequency, time_resolution, cqt_kernel)[0].astype(np.float64)
+    f64 = _PRECISION["value"] == "f64"
+    x = _as_signal(audio_signal, np.float64 if f64 else np.float32)
+    return cqtspectrogram_batch(x, sampling_frequency, time_resolution, cqt_kernel, f64=f64)[0].astype(np.float64)
 
 
 def cqtchromagram(audio_signal, sampling_frequency, time_resolution, octave_resolution, cqt_kernel):
     """Drop-in for zaf.cqtchromagram (zaf.py:638): (N,) -> (octave_resolution, T) float64."""
-    x = _as_signal(audio_signal)
-    return cqtchromagram_batch(x, sampling_frequency, time_resolution, octave_resolution, cqt_kernel)[0].astype(np.float64)
+    f64 = _PRECISION["value"] == "f64"
+    x = _as_signal(audio_signal, np.float64 if f64 else np.float32)
+    return cqtchromagram_batch(x, sampling_frequency, time_resolution, octave_resolution, cqt_kernel, f64=f64)[0].astype(np.float64)
 
 
 def mdct(audio_signal, window_function):

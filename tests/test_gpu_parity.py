@@ -850,3 +850,28 @@ def test_row_align_mel_cqt_and_host_path(zafx):
         zafx.stft_plan(ham, 1024, layout="TF", row_align=16)
     with pytest.raises(ValueError):
         zafx.stft_plan(ham, 1024, row_align=24)
+
+
+# ------------------------------------------------------------------ few long clips: the carry kernels cut a clip into segments
+@pytest.mark.parametrize("n", [44100 * 30, 44100 * 30 + 12345])
+def test_long_clips_are_segmented(zafx, n):
+    """3 clips x 30 s: fewer clips than CUs, so carry_segments() splits every clip into many segments, each started by a
+    carry-only tile -- inverse transforms of both layouts against the oracle, and the round trip."""
+    x = np.stack([synth_clip(47, c, n) for c in range(3)])
+    ham, kbd = zafx.hamming(2048), zafx.kaiser_bessel_derived(2048)
+    spec = zafx.stft_batch(x, ham, 1024)
+    coef = zafx.mdct_batch(x, kbd)
+    y_ref = [orc.istft(spec[c].astype(np.complex128), ham, 1024) for c in range(3)]
+    z_ref = [orc.imdct(coef[c].astype(np.float64), kbd) for c in range(3)]
+    for layout in ("FT", "TF"):
+        s_in = spec if layout == "FT" else np.ascontiguousarray(spec.transpose(0, 2, 1))
+        c_in = coef if layout == "FT" else np.ascontiguousarray(coef.transpose(0, 2, 1))
+        y = zafx.istft_batch(s_in, ham, 1024, layout=layout)
+        z = zafx.imdct_batch(c_in, kbd, layout=layout)
+        half = spec[:, :1025] if layout == "FT" else np.ascontiguousarray(spec[:, :1025].transpose(0, 2, 1))
+        y1 = zafx.istft_batch(np.ascontiguousarray(half), ham, 1024, layout=layout, onesided=True)
+        for c in range(3):
+            assert y[c].shape == y_ref[c].shape and relerr(y[c], y_ref[c]) <= TOL_FFT, (layout, c)
+            assert relerr(y1[c], y_ref[c]) <= TOL_FFT, (layout, c)
+            assert z[c].shape == z_ref[c].shape and relerr(z[c], z_ref[c]) <= TOL_FFT, (layout, c)
+            assert np.max(np.abs(y[c][:n] - x[c])) < 1e-4 and np.max(np.abs(z[c][:n] - x[c])) < 1e-4

@@ -96,10 +96,10 @@ enum zafx_constant {
 
 typedef struct zafx_params {
     int32_t struct_size;       /* = sizeof(zafx_params)                                         */
-    int32_t window_length;     /* W, power of two, 64..8192 (STFT family, MDCT family)          */
+    int32_t window_length;     /* W, power of two, 64..8192 (STFT family, MDCT family; float32 MEL / MFCC: 64..2048) */
     int32_t step_length;       /* hop H (STFT/ISTFT/MEL/MFCC; ceil(W/H) <= 8); CQT: frame step  */
     int32_t layout;            /* enum zafx_layout of the 2-D (frequency x time) side           */
-    int32_t n_filters;         /* MEL / MFCC                                                    */
+    int32_t n_filters;         /* MEL / MFCC: 1..256 (and <= W/2)                               */
     int32_t n_coefs;           /* MFCC                                                          */
     int32_t fft_length;        /* CQT / CHROMA: power of two, 512..32768                        */
     int32_t n_bins;            /* CQT / CHROMA                                                  */

@@ -338,17 +338,25 @@ def test_mdct_frame_count_parity(zafx, n):
         assert np.max(np.abs(y[c][:k] - x[c][:k])) < 1e-5
 
 
-def test_mel_other_window(zafx):
-    """W = 1024 instantiation of the fused kernel (slots in the upper halves of smaller frame buffers)."""
-    x = np.stack([synth_clip(10, c, 22050) for c in range(2)])
-    w = zafx.hamming(1024)
-    fb = zafx.melfilterbank(22050, 1024, 64)
-    mel = zafx.melspectrogram_batch(x, w, 256, fb)
-    mf = zafx.mfcc_batch(x, w, 256, fb, 13)
-    for c in range(2):
-        x64 = x[c].astype(np.float64)
-        assert relerr(mel[c], orc.melspectrogram(x64, w, 256, fb)) <= TOL_FB
-        assert relerr(mf[c], orc.mfcc(x64, w, 256, fb, 13)) <= TOL_FB
+@pytest.mark.parametrize("wl,hop,fs,nmel,ncoef", [(1024, 256, 22050, 64, 13), (512, 128, 16000, 40, 13), (256, 100, 8000, 26, 12),
+                                                  (128, 64, 8000, 20, 10), (512, 512, 16000, 80, 20)])
+def test_mel_other_window(zafx, wl, hop, fs, nmel, ncoef):
+    """The other instantiations of the fused kernel (W = 128 ... 1024: slots in the upper halves of smaller frame buffers
+    or in their own region, several frames per wavefront below W = 128 x 64 lanes)."""
+    x = np.stack([synth_clip(10, c, 22050 + 7 * c) [:22050] for c in range(2)])
+    w = zafx.hamming(wl)
+    fb = zafx.melfilterbank(fs, wl, nmel)
+    for layout in ("FT", "TF"):
+        mel = zafx.melspectrogram_batch(x, w, hop, fb, layout=layout)
+        mf = zafx.mfcc_batch(x, w, hop, fb, ncoef, layout=layout)
+        if layout == "TF":
+            mel, mf = mel.transpose(0, 2, 1), mf.transpose(0, 2, 1)
+        for c in range(2):
+            x64 = x[c].astype(np.float64)
+            ref_mel, ref_mf = orc.melspectrogram(x64, w, hop, fb), orc.mfcc(x64, w, hop, fb, ncoef)
+            assert mel[c].shape == ref_mel.shape and mf[c].shape == ref_mf.shape
+            assert relerr(mel[c], ref_mel) <= TOL_FB, (layout, c)
+            assert relerr(mf[c], ref_mf) <= TOL_FB, (layout, c)
 
 
 def test_batch_larger_than_grid(zafx):

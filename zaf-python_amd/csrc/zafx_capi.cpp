@@ -423,8 +423,8 @@ int zafx_plan_create(zafx_plan** out, int device, int kind, const zafx_params* p
                 return bail("n_coefs must be in [1, n_filters]");
             if (params->precision == ZAFX_PRECISION_F64) {
                 if (params->n_filters > pl->W / 2) return bail("n_filters must not exceed window_length / 2");
-            } else if (lw - 1 != 10 && lw - 1 != 9 && lw - 1 != 5) {
-                return bail("mel/mfcc kernels are built for window_length 64, 1024 and 2048 (any power of two with ZAFX_PRECISION_F64)");
+            } else if (lw - 1 < 5 || lw - 1 > 10) {
+                return bail("float32 mel/mfcc kernels are built for window_length 64 ... 2048 (any power of two with ZAFX_PRECISION_F64)");
             }
         }
         const int n = pl->W / 2;

@@ -49,12 +49,12 @@ struct MelCfg {
     static constexpr int NSLOT = (kMelThreads / C::P) < FPB ? (kMelThreads / C::P) : FPB;   // frames transformed concurrently
     static constexpr int NT = NSLOT * C::P;
     // 256-float slots: in the dead upper half of every frame buffer when it is large enough,
-    // else in a separate region after the tables
+    // and (for the smaller windows) in a separate region after the tables
     static constexpr int UPPER = 2 * C::PITCH - N;           // free floats per frame buffer after S
     static constexpr int SLOTS_PER_BUF = UPPER / 256;
-    static constexpr bool SLOTS_IN_FRAMES = SLOTS_PER_BUF >= 1;
-    static constexpr int EXTRA_SLOTS = SLOTS_IN_FRAMES ? 0 : 48;
-    static constexpr int CAPACITY = SLOTS_IN_FRAMES ? FPB * SLOTS_PER_BUF : EXTRA_SLOTS;
+    static constexpr int IN_FRAMES = FPB * SLOTS_PER_BUF;         // slots in the dead upper halves
+    static constexpr int EXTRA_SLOTS = N >= 1024 ? 0 : 64;         // + a region of their own where LDS is plentiful (W <= 1024)
+    static constexpr int CAPACITY = IN_FRAMES + EXTRA_SLOTS;
     static constexpr size_t TABLES = (size_t)(C::TW + N + N / 2 + 1) * 8;     // pass twiddles, window, split roots
     static constexpr size_t SMEM = (size_t)FPB * C::PITCH * 8 + TABLES + (size_t)EXTRA_SLOTS * 256 * 4;
 };
@@ -106,8 +106,11 @@ __global__ __launch_bounds__(mel_threads(LOG2N, LOG2E)) void k_mel(
     __syncthreads();
 
     auto slot_ptr = [&](int s) -> float* {
-        if constexpr (G::SLOTS_IN_FRAMES) return fall + (size_t)(s / G::SLOTS_PER_BUF) * (2 * C::PITCH) + N + (s % G::SLOTS_PER_BUF) * 256;
-        else return extra + (size_t)s * 256;
+        if constexpr (G::IN_FRAMES > 0) {
+            if (G::EXTRA_SLOTS == 0 || s < G::IN_FRAMES)
+                return fall + (size_t)(s / G::SLOTS_PER_BUF) * (2 * C::PITCH) + N + (s % G::SLOTS_PER_BUF) * 256;
+        }
+        return extra + (size_t)(s - G::IN_FRAMES) * 256;
     };
 
     const int slot = tid / P, p = tid % P;
@@ -293,6 +296,9 @@ static hipError_t run_mel_any(const zafx_plan& pl, const float* x, float* out, i
 hipError_t launch_mel(const zafx_plan& pl, const float* x, float* out, int64_t n_clips, int64_t n_samples, int T) {
     switch (pl.log2nf) {
         case 5: return run_mel_any<5>(pl, x, out, n_clips, n_samples, T);
+        case 6: return run_mel_any<6>(pl, x, out, n_clips, n_samples, T);
+        case 7: return run_mel_any<7>(pl, x, out, n_clips, n_samples, T);
+        case 8: return run_mel_any<8>(pl, x, out, n_clips, n_samples, T);
         case 9: return run_mel_any<9>(pl, x, out, n_clips, n_samples, T);
         case 10: return run_mel_any<10>(pl, x, out, n_clips, n_samples, T);
     }

@@ -97,7 +97,9 @@ enum zafx_constant {
 typedef struct zafx_params {
     int32_t struct_size;       /* = sizeof(zafx_params)                                         */
     int32_t window_length;     /* W, power of two, 64..8192 (STFT family, MDCT family; float32 MEL / MFCC: 64..2048) */
-    int32_t step_length;       /* hop H (STFT/ISTFT/MEL/MFCC; ceil(W/H) <= 8); CQT: frame step  */
+    int32_t step_length;       /* hop H >= 1 (STFT/MEL/MFCC: any, also above W as zaf.stft allows; ISTFT: H <= W and
+                                  ceil(W/H) within the overlap-add tile -- 16 frames up to W = 2048, 8 at 4096, 4 at 8192;
+                                  no such limit with ZAFX_PRECISION_F64); CQT: frame step                          */
     int32_t layout;            /* enum zafx_layout of the 2-D (frequency x time) side           */
     int32_t n_filters;         /* MEL / MFCC: 1..256 (and <= W/2)                               */
     int32_t n_coefs;           /* MFCC                                                          */

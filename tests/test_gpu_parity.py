@@ -883,3 +883,29 @@ def test_long_clips_are_segmented(zafx, n):
             assert relerr(y1[c], y_ref[c]) <= TOL_FFT, (layout, c)
             assert z[c].shape == z_ref[c].shape and relerr(z[c], z_ref[c]) <= TOL_FFT, (layout, c)
             assert np.max(np.abs(y[c][:n] - x[c])) < 1e-4 and np.max(np.abs(z[c][:n] - x[c])) < 1e-4
+
+
+@pytest.mark.parametrize("wl,hop,n", [(2048, 3000, 50000), (2048, 2049, 20001), (1024, 5000, 30000), (256, 1000, 9999), (4096, 6000, 40000)])
+def test_hop_above_window(zafx, wl, hop, n):
+    """step_length > window_length: zaf.stft / melspectrogram / mfcc skip samples between frames (zaf.py:102-136 holds for
+    any hop); the forward kernels follow, the ISTFT (whose reference trims by a negative amount then) refuses."""
+    x = np.stack([synth_clip(53, c, n) for c in range(2)])
+    w = zafx.hamming(wl)
+    for layout in ("FT", "TF"):
+        for one in (False, True):
+            got = zafx.stft_batch(x, w, hop, layout=layout, onesided=one)
+            if layout == "TF":
+                got = got.transpose(0, 2, 1)
+            for c in range(2):
+                ref = orc.stft(x[c].astype(np.float64), w, hop)
+                ref = ref[:wl // 2 + 1] if one else ref
+                assert got[c].shape == ref.shape and relerr(got[c], ref) <= TOL_FFT, (layout, one, c)
+    if wl <= 2048:
+        fb = zafx.melfilterbank(44100, wl, 40)
+        mel = zafx.melspectrogram_batch(x, w, hop, fb)
+        for c in range(2):
+            assert relerr(mel[c], orc.melspectrogram(x[c].astype(np.float64), w, hop, fb)) <= TOL_FB
+    got64 = zafx.stft_batch(x.astype(np.float64), w, hop, f64=True)
+    assert relerr(got64[0], orc.stft(x[0].astype(np.float64), w, hop)) <= 1e-12
+    with pytest.raises((ValueError, zafx.ZafxError)):
+        zafx.istft_plan(w, hop)

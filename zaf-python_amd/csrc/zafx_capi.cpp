@@ -415,7 +415,9 @@ int zafx_plan_create(zafx_plan** out, int device, int kind, const zafx_params* p
         pl->H = params->step_length;
         const int lw = ilog2_exact(pl->W);
         if (lw < 0 || !stft_supported(lw - 1)) return bail("window_length must be a power of two in [64, 8192]");
-        if (pl->H < 1 || pl->H > pl->W) return bail("step_length must be in [1, window_length]");
+        if (pl->H < 1) return bail("step_length must be >= 1");
+        if (kind == ZAFX_ISTFT && pl->H > pl->W) return bail("istft: step_length must not exceed window_length");
+        if (pl->H > (1 << 20)) return bail("step_length must not exceed 2^20");
         pl->log2nf = lw - 1;
         if (kind == ZAFX_MEL || kind == ZAFX_MFCC) {
             if (params->n_filters < 1 || params->n_filters > 256) return bail("n_filters must be in [1, 256]");

@@ -472,9 +472,7 @@ def stft_plan(window_function, step_length, layout="FT", device=0, onesided=Fals
     """row_align (every 2-D plan factory): pad the rows of the device (F, T) array to a multiple of this many elements
     (16 for complex64, 32 for float32 = one 128-byte line) so that the reference-layout kernels run at their aligned
     rate for any T; Plan.out_shape / Plan.row_pitch give the padded geometry, 0 keeps the reference's compact order."""
-    w, h = _as_window(window_function), _as_step(step_length)
-    if h > len(w):
-        raise ValueError("step_length must not exceed window_length")
+    w, h = _as_window(window_function), _as_step(step_length)   # (a hop above the window skips samples, as zaf.stft does)
     key = ("stft", device, len(w), h, _LAYOUTS[layout], _spectrum_of(onesided), bool(f64), _as_row_align(row_align, layout), _digest(w))
 
     def make():

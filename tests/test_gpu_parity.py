@@ -909,3 +909,23 @@ def test_hop_above_window(zafx, wl, hop, n):
     assert relerr(got64[0], orc.stft(x[0].astype(np.float64), w, hop)) <= 1e-12
     with pytest.raises((ValueError, zafx.ZafxError)):
         zafx.istft_plan(w, hop)
+
+
+def test_cqt_long_kernel(zafx):
+    """A lower minimum frequency makes fft_length 65536 (zaf.py:505-509): more than LDS holds as float32 pairs, so the
+    transform runs on the float64 kernel (which decimates the frame) whatever precision was asked for."""
+    fs, res, tr, n = 44100, 24, 20, 80000
+    ck = zafx.cqtkernel(fs, res, 27.5, 1760)
+    assert ck.shape[1] == 65536
+    x = np.stack([synth_clip(59, c, n) for c in range(2)])
+    got = zafx.cqtspectrogram_batch(x, fs, tr, ck)
+    got64 = zafx.cqtspectrogram_batch(x.astype(np.float64), fs, tr, ck, f64=True)
+    chroma = zafx.cqtchromagram_batch(x, fs, tr, res, ck)
+    assert got.dtype == np.float32 and got64.dtype == np.float64
+    for c in range(2):
+        ref = orc.cqtspectrogram(x[c].astype(np.float64), fs, tr, ck)
+        assert got[c].shape == ref.shape
+        assert relerr(got64[c], ref) <= 1e-12 and relerr(got[c], ref) <= TOL_FB
+        assert relerr(chroma[c], orc.cqtchromagram(x[c].astype(np.float64), fs, tr, res, ck)) <= TOL_FB
+    one = zafx.cqtspectrogram(x[0], fs, tr, ck)
+    assert one.dtype == np.float64 and relerr(one, orc.cqtspectrogram(x[0].astype(np.float64), fs, tr, ck)) <= TOL_FB

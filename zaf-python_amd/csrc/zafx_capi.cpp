@@ -447,7 +447,11 @@ int zafx_plan_create(zafx_plan** out, int device, int kind, const zafx_params* p
         pl->W = params->fft_length;
         pl->H = params->step_length;
         const int lw = ilog2_exact(pl->W);
-        if (lw < 0 || !cqt_supported(lw - 1)) return bail("fft_length must be a power of two in [512, 32768]");
+        if (params->precision == ZAFX_PRECISION_F64) {   // k_cqt_f64 decimates the frame: no LDS limit on its length
+            if (lw < 9 || lw > 17) return bail("fft_length must be a power of two in [512, 131072] (ZAFX_PRECISION_F64 plan)");
+        } else if (lw < 0 || !cqt_supported(lw - 1)) {
+            return bail("fft_length must be a power of two in [512, 32768] (up to 131072 with ZAFX_PRECISION_F64)");
+        }
         if (pl->H < 1) return bail("step_length must be >= 1");
         if (params->n_bins < 1 || params->n_bins > 1024) return bail("n_bins must be in [1, 1024]");
         if (kind == ZAFX_CHROMA && (params->octave_resolution < 1 || params->octave_resolution > params->n_bins))

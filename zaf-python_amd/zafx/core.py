@@ -554,8 +554,11 @@ def cqt_plan(sampling_frequency, time_resolution, cqt_kernel, octave_resolution=
     step = round(sampling_frequency / time_resolution)   # zaf.py:603 (banker's rounding)
     if step < 1:
         raise ValueError("time_resolution too high for this sampling_frequency")
-    if fft_length < 512 or fft_length > 32768 or fft_length & (fft_length - 1):
-        raise ValueError(f"zafx CQT kernels need a power-of-two fft_length in [512, 32768], got {fft_length}")
+    if fft_length < 512 or fft_length > 131072 or fft_length & (fft_length - 1):
+        raise ValueError(f"zafx CQT kernels need a power-of-two fft_length in [512, 131072], got {fft_length}")
+    # a frame above 32768 samples does not fit LDS as float32 pairs: those kernels run on the float64 kernel, which
+    # decimates the frame (lower minimum frequencies: 27.5 Hz at 44.1 kHz gives 65536)
+    f64 = bool(f64) or fft_length > 32768
     csr = cqt_kernel.tocsr()
     chroma = octave_resolution is not None
     key = ("chroma" if chroma else "cqt", device, fft_length, step, n_bins, int(octave_resolution or 0), _LAYOUTS[layout],
@@ -644,14 +647,18 @@ def mfcc_batch(clips, window_function, step_length, mel_filterbank, number_coeff
 
 def cqtspectrogram_batch(clips, sampling_frequency, time_resolution, cqt_kernel, layout="FT", device=0, f64=False):
     """(B, N) -> (B, n_bins, T) float32 (float64 arrays and arithmetic with f64)."""
-    x = _as_clips(clips, dtype=np.float64 if f64 else np.float32)
-    return cqt_plan(sampling_frequency, time_resolution, cqt_kernel, None, layout, device, f64=f64).run_host(x, x.shape[1])
+    plan = cqt_plan(sampling_frequency, time_resolution, cqt_kernel, None, layout, device, f64=f64)
+    x = _as_clips(clips, dtype=plan.in_dtype)
+    out = plan.run_host(x, x.shape[1])
+    return out if f64 else out.astype(np.float32, copy=False)   # (a long kernel is computed in float64 whatever f64 says)
 
 
 def cqtchromagram_batch(clips, sampling_frequency, time_resolution, octave_resolution, cqt_kernel, layout="FT", device=0, f64=False):
     """(B, N) -> (B, octave_resolution, T) float32 (float64 arrays and arithmetic with f64)."""
-    x = _as_clips(clips, dtype=np.float64 if f64 else np.float32)
-    return cqt_plan(sampling_frequency, time_resolution, cqt_kernel, int(octave_resolution), layout, device, f64=f64).run_host(x, x.shape[1])
+    plan = cqt_plan(sampling_frequency, time_resolution, cqt_kernel, int(octave_resolution), layout, device, f64=f64)
+    x = _as_clips(clips, dtype=plan.in_dtype)
+    out = plan.run_host(x, x.shape[1])
+    return out if f64 else out.astype(np.float32, copy=False)
 
 
 def _pcm_device_mono(plan, pcm):

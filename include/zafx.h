@@ -101,7 +101,7 @@ typedef struct zafx_params {
                                   ceil(W/H) within the overlap-add tile -- 16 frames up to W = 2048, 8 at 4096, 4 at 8192;
                                   no such limit with ZAFX_PRECISION_F64); CQT: frame step                          */
     int32_t layout;            /* enum zafx_layout of the 2-D (frequency x time) side           */
-    int32_t n_filters;         /* MEL / MFCC: 1..256 (and <= W/2)                               */
+    int32_t n_filters;         /* MEL / MFCC: 1..256 (ZAFX_PRECISION_F64: 1..W/2)               */
     int32_t n_coefs;           /* MFCC                                                          */
     int32_t fft_length;        /* CQT / CHROMA: power of two, 512..32768 (..131072 with ZAFX_PRECISION_F64) */
     int32_t n_bins;            /* CQT / CHROMA                                                  */

@@ -929,3 +929,21 @@ def test_cqt_long_kernel(zafx):
         assert relerr(chroma[c], orc.cqtchromagram(x[c].astype(np.float64), fs, tr, res, ck)) <= TOL_FB
     one = zafx.cqtspectrogram(x[0], fs, tr, ck)
     assert one.dtype == np.float64 and relerr(one, orc.cqtspectrogram(x[0].astype(np.float64), fs, tr, ck)) <= TOL_FB
+
+
+@pytest.mark.parametrize("wl,hop,nmel", [(4096, 2048, 128), (8192, 2048, 64), (2048, 1024, 300)])
+def test_mel_long_window_or_wide_bank(zafx, wl, hop, nmel):
+    """Windows above 2048 and filterbanks above 256 rows are outside the fused float32 kernel; the host layer runs them
+    on the float64 kernel and returns float32 from the float32 entry points."""
+    x = np.stack([synth_clip(61, c, 60000) for c in range(2)])
+    w = zafx.hamming(wl)
+    fb = zafx.melfilterbank(44100, wl, nmel)
+    mel = zafx.melspectrogram_batch(x, w, hop, fb)
+    cep = zafx.mfcc_batch(x, w, hop, fb, 13)
+    assert mel.dtype == np.float32 and cep.dtype == np.float32
+    for c in range(2):
+        x64 = x[c].astype(np.float64)
+        assert relerr(mel[c], orc.melspectrogram(x64, w, hop, fb)) <= TOL_FB
+        assert relerr(cep[c], orc.mfcc(x64, w, hop, fb, 13)) <= TOL_FB
+    one = zafx.melspectrogram(x[0], w, hop, fb)
+    assert one.dtype == np.float64 and relerr(one, orc.melspectrogram(x[0].astype(np.float64), w, hop, fb)) <= TOL_FB

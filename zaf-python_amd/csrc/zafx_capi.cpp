@@ -420,7 +420,8 @@ int zafx_plan_create(zafx_plan** out, int device, int kind, const zafx_params* p
         if (pl->H > (1 << 20)) return bail("step_length must not exceed 2^20");
         pl->log2nf = lw - 1;
         if (kind == ZAFX_MEL || kind == ZAFX_MFCC) {
-            if (params->n_filters < 1 || params->n_filters > 256) return bail("n_filters must be in [1, 256]");
+            if (params->n_filters < 1 || (params->precision != ZAFX_PRECISION_F64 && params->n_filters > 256))
+                return bail("n_filters must be in [1, 256] (up to window_length / 2 with ZAFX_PRECISION_F64)");
             if (kind == ZAFX_MFCC && (params->n_coefs < 1 || params->n_coefs > params->n_filters))
                 return bail("n_coefs must be in [1, n_filters]");
             if (params->precision == ZAFX_PRECISION_F64) {

@@ -530,6 +530,9 @@ def mel_plan(window_function, step_length, mel_filterbank, number_coefficients=N
     ncoef = int(number_coefficients) if mfcc else 0
     if mfcc and not 1 <= ncoef <= n_filters - 1:
         raise ValueError("number_coefficients must be in [1, number_filters - 1]")
+    # windows above 2048 (16 frames of 4096 points do not fit LDS) and filterbanks above 256 rows run on the float64
+    # kernel, which takes any power-of-two window
+    f64 = bool(f64) or len(w) > 2048 or n_filters > 256
     # the cache key hashes the sparse triplet (a few KB), not the dense matrix (1 MB: 1.8 ms per call)
     csr = mel_filterbank.tocsr()
     key = ("mfcc" if mfcc else "mel", device, len(w), h, _LAYOUTS[layout], ncoef, n_filters, _as_row_align(row_align, layout), bool(f64),
@@ -635,14 +638,18 @@ def imdct_batch(coefficients, window_function, layout="FT", device=0, f64=False)
 
 def melspectrogram_batch(clips, window_function, step_length, mel_filterbank, layout="FT", device=0, f64=False):
     """(B, N) -> (B, n_filters, T) float32 (float64 arrays and arithmetic with f64)."""
-    x = _as_clips(clips, dtype=np.float64 if f64 else np.float32)
-    return mel_plan(window_function, step_length, mel_filterbank, None, layout, device, f64=f64).run_host(x, x.shape[1])
+    plan = mel_plan(window_function, step_length, mel_filterbank, None, layout, device, f64=f64)
+    x = _as_clips(clips, dtype=plan.in_dtype)
+    out = plan.run_host(x, x.shape[1])
+    return out if f64 else out.astype(np.float32, copy=False)   # (a long window is computed in float64 whatever f64 says)
 
 
 def mfcc_batch(clips, window_function, step_length, mel_filterbank, number_coefficients, layout="FT", device=0, f64=False):
     """(B, N) -> (B, number_coefficients, T) float32 (float64 arrays and arithmetic with f64)."""
-    x = _as_clips(clips, dtype=np.float64 if f64 else np.float32)
-    return mel_plan(window_function, step_length, mel_filterbank, number_coefficients, layout, device, f64=f64).run_host(x, x.shape[1])
+    plan = mel_plan(window_function, step_length, mel_filterbank, number_coefficients, layout, device, f64=f64)
+    x = _as_clips(clips, dtype=plan.in_dtype)
+    out = plan.run_host(x, x.shape[1])
+    return out if f64 else out.astype(np.float32, copy=False)
 
 
 def cqtspectrogram_batch(clips, sampling_frequency, time_resolution, cqt_kernel, layout="FT", device=0, f64=False):

@@ -272,8 +272,12 @@ def test_errors(zafx):
         zafx.stft(x, zafx.hamming(1000), 500)         # window not a power of two
     with pytest.raises(ValueError):
         zafx.melspectrogram(x, ham, 1024, np.ones((4, 1024)))   # filterbank must expose .toarray()
-    with pytest.raises(zafx.ZafxError):
-        zafx.istft(np.zeros((2048, 4), complex), ham, 64)        # ceil(W/H) too large for the OLA tile
+    with pytest.raises(zafx.ZafxError):                          # ceil(W/H) too large for the float32 OLA tile: the C-ABI
+        p = zafx.Plan(zafx.ISTFT, window_length=2048, step_length=64)   # refuses (the host layer would pick the float64 kernels)
+        p.set_window(ham)
+        d_s = zafx.DeviceBuffer.from_host(np.zeros((1, 2048, 4), np.complex64))
+        d_y = zafx.DeviceBuffer(p.out_shape(1, 4), p.out_dtype)
+        p.execute(d_s, d_y, 1, 4)
 
 
 # ------------------------------------------------------------------ RCCL broadcast of constants (1 rank)
@@ -947,3 +951,17 @@ def test_mel_long_window_or_wide_bank(zafx, wl, hop, nmel):
         assert relerr(cep[c], orc.mfcc(x64, w, hop, fb, 13)) <= TOL_FB
     one = zafx.melspectrogram(x[0], w, hop, fb)
     assert one.dtype == np.float64 and relerr(one, orc.melspectrogram(x[0].astype(np.float64), w, hop, fb)) <= TOL_FB
+
+
+@pytest.mark.parametrize("wl,hop,n", [(2048, 100, 20000), (4096, 300, 30000), (8192, 1000, 40000), (64, 3, 1000)])
+def test_istft_tiny_hop(zafx, wl, hop, n):
+    """More overlapping frames per sample than the float32 overlap-add tile holds: the host layer runs the ISTFT on the
+    float64 kernels (no such limit) and still returns float32."""
+    x = synth_clip(67, 0, n)
+    w = zafx.hamming(wl)
+    ref_s = orc.stft(x.astype(np.float64), w, hop)
+    y = zafx.istft_batch(ref_s[None].astype(np.complex64), w, hop)[0]
+    yref = orc.istft(ref_s, w, hop)
+    assert y.dtype == np.float32 and y.shape == yref.shape and relerr(y, yref) <= TOL_FFT
+    y1 = zafx.istft(ref_s, w, hop)
+    assert y1.dtype == np.float64 and relerr(y1, yref) <= TOL_FFT

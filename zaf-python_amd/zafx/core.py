@@ -489,6 +489,10 @@ def istft_plan(window_function, step_length, layout="FT", device=0, onesided=Fal
         raise ValueError("step_length must not exceed window_length")
     if onesided not in (False, True):
         raise ValueError("istft takes a complex spectrum: onesided must be False or True")
+    # the float32 overlap-add keeps a tile of 16 frames in LDS (8 at W = 4096, 4 at 8192): a hop so small that more
+    # frames than that cover one sample runs on the float64 kernels (a gather overlap-add without that limit)
+    tile = 16 if len(w) <= 2048 else (8 if len(w) == 4096 else 4)
+    f64 = bool(f64) or -(-len(w) // h) > tile
     key = ("istft", device, len(w), h, _LAYOUTS[layout], bool(onesided), bool(f64), _as_row_align(row_align, layout), _digest(w))
 
     def make():
@@ -608,14 +612,16 @@ def istft_batch(spectra, window_function, step_length, layout="FT", device=0, on
 
     onesided=True takes rows 0..W/2 and completes X[W-k] = conj X[k]: the result equals the two-sided
     call on the spectrum of a real signal."""
-    s = np.ascontiguousarray(spectra, dtype=np.complex128 if f64 else np.complex64)
     w = _as_window(window_function)
+    plan = istft_plan(w, step_length, layout, device, onesided, f64)
+    s = np.ascontiguousarray(spectra, dtype=plan.in_dtype)
     if s.ndim != 3:
         raise ValueError("spectra must be 3-D")
     wl, nt = (s.shape[1], s.shape[2]) if _LAYOUTS[layout] == _lib.LAYOUT_FT else (s.shape[2], s.shape[1])
     if wl != (len(w) // 2 + 1 if onesided else len(w)):
         raise ValueError("spectrum rows must equal window_length (window_length/2 + 1 when onesided)")
-    return istft_plan(w, step_length, layout, device, onesided, f64).run_host(s, nt)
+    out = plan.run_host(s, nt)
+    return out if f64 else out.astype(np.float32, copy=False)   # (a very small hop is computed in float64 whatever f64 says)
 
 
 def mdct_batch(clips, window_function, layout="FT", device=0, f64=False):

@@ -613,14 +613,14 @@ def istft_batch(spectra, window_function, step_length, layout="FT", device=0, on
     onesided=True takes rows 0..W/2 and completes X[W-k] = conj X[k]: the result equals the two-sided
     call on the spectrum of a real signal."""
     w = _as_window(window_function)
-    plan = istft_plan(w, step_length, layout, device, onesided, f64)
-    s = np.ascontiguousarray(spectra, dtype=plan.in_dtype)
+    s = np.asarray(spectra)
     if s.ndim != 3:
         raise ValueError("spectra must be 3-D")
     wl, nt = (s.shape[1], s.shape[2]) if _LAYOUTS[layout] == _lib.LAYOUT_FT else (s.shape[2], s.shape[1])
     if wl != (len(w) // 2 + 1 if onesided else len(w)):
         raise ValueError("spectrum rows must equal window_length (window_length/2 + 1 when onesided)")
-    out = plan.run_host(s, nt)
+    plan = istft_plan(w, step_length, layout, device, onesided, f64)
+    out = plan.run_host(np.ascontiguousarray(s, dtype=plan.in_dtype), nt)
     return out if f64 else out.astype(np.float32, copy=False)   # (a very small hop is computed in float64 whatever f64 says)
 
 
@@ -644,32 +644,36 @@ def imdct_batch(coefficients, window_function, layout="FT", device=0, f64=False)
 
 def melspectrogram_batch(clips, window_function, step_length, mel_filterbank, layout="FT", device=0, f64=False):
     """(B, N) -> (B, n_filters, T) float32 (float64 arrays and arithmetic with f64)."""
+    x = _as_clips(clips, dtype=np.float64 if f64 else np.float32)   # (validated before any device call)
     plan = mel_plan(window_function, step_length, mel_filterbank, None, layout, device, f64=f64)
-    x = _as_clips(clips, dtype=plan.in_dtype)
+    x = x.astype(plan.in_dtype, copy=False)
     out = plan.run_host(x, x.shape[1])
     return out if f64 else out.astype(np.float32, copy=False)   # (a long window is computed in float64 whatever f64 says)
 
 
 def mfcc_batch(clips, window_function, step_length, mel_filterbank, number_coefficients, layout="FT", device=0, f64=False):
     """(B, N) -> (B, number_coefficients, T) float32 (float64 arrays and arithmetic with f64)."""
+    x = _as_clips(clips, dtype=np.float64 if f64 else np.float32)   # (validated before any device call)
     plan = mel_plan(window_function, step_length, mel_filterbank, number_coefficients, layout, device, f64=f64)
-    x = _as_clips(clips, dtype=plan.in_dtype)
+    x = x.astype(plan.in_dtype, copy=False)
     out = plan.run_host(x, x.shape[1])
     return out if f64 else out.astype(np.float32, copy=False)
 
 
 def cqtspectrogram_batch(clips, sampling_frequency, time_resolution, cqt_kernel, layout="FT", device=0, f64=False):
     """(B, N) -> (B, n_bins, T) float32 (float64 arrays and arithmetic with f64)."""
+    x = _as_clips(clips, dtype=np.float64 if f64 else np.float32)   # (validated before any device call)
     plan = cqt_plan(sampling_frequency, time_resolution, cqt_kernel, None, layout, device, f64=f64)
-    x = _as_clips(clips, dtype=plan.in_dtype)
+    x = x.astype(plan.in_dtype, copy=False)
     out = plan.run_host(x, x.shape[1])
     return out if f64 else out.astype(np.float32, copy=False)   # (a long kernel is computed in float64 whatever f64 says)
 
 
 def cqtchromagram_batch(clips, sampling_frequency, time_resolution, octave_resolution, cqt_kernel, layout="FT", device=0, f64=False):
     """(B, N) -> (B, octave_resolution, T) float32 (float64 arrays and arithmetic with f64)."""
+    x = _as_clips(clips, dtype=np.float64 if f64 else np.float32)   # (validated before any device call)
     plan = cqt_plan(sampling_frequency, time_resolution, cqt_kernel, int(octave_resolution), layout, device, f64=f64)
-    x = _as_clips(clips, dtype=plan.in_dtype)
+    x = x.astype(plan.in_dtype, copy=False)
     out = plan.run_host(x, x.shape[1])
     return out if f64 else out.astype(np.float32, copy=False)
 

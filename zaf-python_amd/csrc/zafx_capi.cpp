@@ -286,15 +286,13 @@ static int build_cqt_chunks(zafx_plan* pl) {
     // that those slots need are bounded by [k_lo, k_hi] (+ the special group {0, N/2, N}).
     {
         const int n = pl->W / 2, w = pl->W;
-        auto phys_slot = [](int i) { return i + (i >> 4); };
-        const int pitch = n + (n >> 4) + 1;
         std::vector<int32_t> slots(pl->h_indices.size());
         int k_lo = n, k_hi = -1, special = 0;
         for (size_t e = 0; e < pl->h_indices.size(); ++e) {
             const int c = pl->h_indices[e];
             if (c < 0 || c >= w) return fail_msg("CQT kernel column index out of range");
             const int m = c <= n ? c : w - c;   // one-sided bin holding X[c] (conjugated when c > n)
-            slots[e] = (m == n ? pitch - 1 : phys_slot(m)) | (c > n ? (int32_t)0x80000000 : 0);
+            slots[e] = (m == n ? cqt_nyquist_slot(pl->log2nf) : cqt_slot(pl->log2nf, m)) | (c > n ? (int32_t)0x80000000 : 0);
             const int k = std::min(m, n - m);   // pair index of the real split
             if (k == 0 || 2 * m == n) special = 1;
             else k_lo = std::min(k_lo, k), k_hi = std::max(k_hi, k);
@@ -479,6 +477,10 @@ int zafx_plan_create(zafx_plan** out, int device, int kind, const zafx_params* p
     if (e == hipSuccess) e = hipEventCreate(&pl->ev1);
     if (e == hipSuccess) {
         auto tw = is_cqt_family(kind) ? build_two_level_twiddles(pl->log2nf) : build_pass_twiddles(pl->log2nf, pl->log2e);
+        if (is_cqt_family(kind) && cqt_split(pl->log2nf)) {   // + the two-level roots of the 1024-point sub-transforms
+            const auto sub = build_two_level_twiddles(10);
+            tw.insert(tw.end(), sub.begin(), sub.end());
+        }
         if (tw.empty()) tw.push_back(cf32{1.f, 0.f});
         e = upload(&pl->d_tw_pass, tw.data(), tw.size() * sizeof(cf32));
         if (e == hipSuccess && (kind == ZAFX_STFT || kind == ZAFX_MEL || kind == ZAFX_MFCC) && pl->log2nf == 10) {

@@ -30,7 +30,10 @@ struct CqtCfg {
     using C = FftCfg<LOG2N, LOG2E>;
     static constexpr int NHI = LOG2N > 7 ? 1 << (LOG2N - 7) : 1;   // two-level roots of N (zafx_fft.hpp)
     static constexpr int NH2 = LOG2N > 8 ? 1 << (LOG2N - 8) : 1;   // two-level roots of 2N for k < N/2 (real split)
-    static constexpr size_t HEAD = (((size_t)(C::PITCH + NHI + 128 + NH2 + 128) * 8 + 15) / 16) * 16;
+    static constexpr bool SPLIT = cqt_split(LOG2N);                // 16 x 1024 decomposition (zafx_internal.hpp)
+    static constexpr int SLOTS = cqt_slots(LOG2N);                 // complex slots of the spectrum image
+    static constexpr int NSUB = SPLIT ? 8 + 128 : 0;               // two-level roots of the 1024-point sub-transforms
+    static constexpr size_t HEAD = (((size_t)(SLOTS + NHI + 128 + NH2 + 128 + NSUB) * 8 + 15) / 16) * 16;
 };
 
 template <int LOG2N, int LOG2E, bool ALIGNED>
@@ -44,17 +47,22 @@ __global__ __launch_bounds__(fft_threads(LOG2N, LOG2E)) void k_cqt(
     constexpr int N = C::N, P = C::P, E = C::E, W = 2 * N, FW = kCqtFramesPerBlock, NHI = G::NHI, NH2 = G::NH2;
     static_assert(P >= 64, "CQT frames are owned by whole wavefronts");
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-    float2* buf = reinterpret_cast<float2*>(smem_raw);            // PITCH slots; slot PITCH-1 holds X[N]
-    float2* tw_hi = buf + C::PITCH;                               // two-level root table of N
+    float2* buf = reinterpret_cast<float2*>(smem_raw);            // G::SLOTS slots: bin k at slot_of(k), X[N] at NYQ
+    float2* tw_hi = buf + G::SLOTS;                               // two-level root table of N
     float2* tw_lo = tw_hi + NHI;
     float2* sp_hi = tw_lo + 128;                                  // two-level root table of 2N (split twiddles)
     float2* sp_lo = sp_hi + NH2;
+    float2* sub_hi = sp_lo + 128;                                 // (SPLIT) two-level root table of 1024
+    auto slot_of = [](int k) { return cqt_slot(LOG2N, k); };
+    constexpr int NYQ = cqt_nyquist_slot(LOG2N);
     int4* chunk_l = reinterpret_cast<int4*>(smem_raw + G::HEAD);  // [n_chunks]
     float* tile = reinterpret_cast<float*>(chunk_l + n_chunks);   // [n_bins][FW]
     float2* part = reinterpret_cast<float2*>(tile + n_bins * FW);   // [n_bins][4] row sums of a frame's products
     int* chunk_ptr_l = reinterpret_cast<int*>(part + n_bins * 4);   // [waves + 1]
     const int p = threadIdx.x;
     for (int i = p; i < NHI + 128; i += P) tw_hi[i] = twp[i];
+    if constexpr (G::SPLIT)
+        for (int i = p; i < G::NSUB; i += P) sub_hi[i] = twp[NHI + 128 + i];
     for (int i = p; i < NH2 + 128; i += P) sp_hi[i] = tws[i];
     for (int i = p; i < n_chunks; i += P) chunk_l[i] = chunks[i];
     for (int i = p; i <= P / 64; i += P) chunk_ptr_l[i] = chunk_ptr[i];
@@ -108,7 +116,32 @@ __global__ __launch_bounds__(fft_threads(LOG2N, LOG2E)) void k_cqt(
         int p = threadIdx.x;
         asm volatile("" : "+v"(p));
         const int lane = p & 63;
-        fft_frame_chain<LOG2N, LOG2E>(v, buf, p, tw2l);
+        if constexpr (G::SPLIT) {
+            // 16384 = 16 x 1024.  Radix-16 across the workgroup on the samples 1024 apart (thread p holds n2 = p), times
+            // w^(p k1); output k1 goes to sub-sequence k1 at position p.  Then wave w transforms sub-sequence w on its own
+            // (three wave-local passes, no workgroup barrier): X[k1 + 16 k2] = FFT_1024(sub-sequence k1)[k2].
+            static_assert(E == 16 && P == 1024, "split form: 16 points per thread, 16 wavefronts");
+            Dft<16>::run(v);
+            {
+                float2 w[16];
+                w[1] = tw2(tw2l, p);
+#pragma unroll
+                for (int r = 2; r < 16; ++r) w[r] = cmul(w[r >> 1], w[r - (r >> 1)]);
+#pragma unroll
+                for (int r = 1; r < 16; ++r) v[r] = cmul(v[r], w[r]);
+            }
+            const int pp = phys(p);
+#pragma unroll
+            for (int r = 0; r < 16; ++r) buf[r * kCqtRegion + pp] = v[r];
+            lds_barrier();
+            float2* sub = buf + (p >> 6) * kCqtRegion;
+            regs_read<10, 4>(v, sub, lane);
+            frame_sync<64>();
+            fft_frame_chain<10, 4>(v, sub, lane, TwoLevelTw{sub_hi, sub_hi + 8});
+            lds_barrier();
+        } else {
+            fft_frame_chain<LOG2N, LOG2E>(v, buf, p, tw2l);
+        }
         PROF_MARK(1);
         // ---- CSR mat-vec, part 1: request the slots and values of my first G chunks now; the L2 round
         // trip hides under the real split
@@ -130,19 +163,19 @@ __global__ __launch_bounds__(fft_threads(LOG2N, LOG2E)) void k_cqt(
         // ---- real split in place, only for the pairs (k, N-k) that the kernel's columns touch:
         // slots 0..N-1 <- X[0..N-1], slot PITCH-1 <- X[N];  t_k = exp(-2 pi i k / 2N) = sp_hi[k >> 7] sp_lo[k & 127]
         if (k_special && p == 0) {
-            const float2 z0 = buf[0], zc = buf[phys(N / 2)];
+            const float2 z0 = buf[0], zc = buf[slot_of(N / 2)];
             buf[0] = make_float2(z0.x + z0.y, 0.f);
-            buf[C::PITCH - 1] = make_float2(z0.x - z0.y, 0.f);
-            buf[phys(N / 2)] = cconj(zc);
+            buf[NYQ] = make_float2(z0.x - z0.y, 0.f);
+            buf[slot_of(N / 2)] = cconj(zc);
         }
         for (int k = k_lo + p; k <= k_hi; k += P) {
-            const float2 zk = buf[phys(k)], zn = buf[phys(N - k)];
+            const float2 zk = buf[slot_of(k)], zn = buf[slot_of(N - k)];
             const float2 tk = cmul(sp_hi[k >> 7], sp_lo[k & 127]);
             const float2 e = make_float2(0.5f * (zk.x + zn.x), 0.5f * (zk.y - zn.y));
             const float2 d = make_float2(0.5f * (zk.x - zn.x), 0.5f * (zk.y + zn.y));
             const float2 to = cmul(tk, make_float2(d.y, -d.x));
-            buf[phys(k)] = cadd(e, to);
-            buf[phys(N - k)] = cconj(csub(e, to));
+            buf[slot_of(k)] = cadd(e, to);
+            buf[slot_of(N - k)] = cconj(csub(e, to));
         }
         PROF_MARK(2);
         lds_barrier();

@@ -13,6 +13,20 @@
 namespace zafx {
 
 constexpr int kMaxLdsBytes = 160 * 1024;   // LDS per CU on gfx950
+// k_cqt at fft_length 32768: the 16384-point packed transform is split as 16 x 1024 -- one radix-16 pass across the
+// workgroup, then every wavefront transforms its own 1024-point sub-sequence without meeting the others.  Bin k of
+// the result then lives in sub-transform k & 15 at position k >> 4: LDS slot of bin k (kCqtRegion = 2 mod 32 complex,
+// so 64 consecutive bins hit distinct banks), and the slot that holds X[N].
+#ifndef ZAFX_CQT_SPLIT
+#define ZAFX_CQT_SPLIT 1
+#endif
+constexpr bool cqt_split(int log2n) { return ZAFX_CQT_SPLIT && log2n == 14; }
+constexpr int kCqtRegion = 1090;
+constexpr int cqt_slots(int log2n) { return cqt_split(log2n) ? 16 * kCqtRegion : (1 << log2n) + ((1 << log2n) >> 4) + 1; }
+constexpr int cqt_slot(int log2n, int k) {
+    return cqt_split(log2n) ? (k & 15) * kCqtRegion + (k >> 4) + (k >> 8) : k + (k >> 4);
+}
+constexpr int cqt_nyquist_slot(int log2n) { return cqt_split(log2n) ? kCqtRegion - 1 : (1 << log2n) + ((1 << log2n) >> 4); }
 constexpr int kCqt64Sub = 4096;            // float64 CQT: length of the sub-transforms that fit LDS (2 x 4096 x 16 B)
 
 // Banded, MFMA-fragment-packed matrix (mel filterbank or DCT-II rows) cut into balanced work

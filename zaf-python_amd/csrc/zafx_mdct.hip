@@ -332,6 +332,42 @@ __global__ __launch_bounds__(NSLOT * fft_threads(LOG2NF, LOG2E)) void k_imdct(
     const bool vec4 = LAYOUT == ZAFX_LAYOUT_FT && FPB % 4 == 0 && NT % (FPB / 4) == 0 && NF >= NT / (FPB / 4) && TP % 4 == 0 &&
                       reinterpret_cast<uintptr_t>(coefs) % 16 == 0;
 
+    // 16-byte gathers (vec4): a lane reads 4 adjacent frames of a row (8 lanes per 128-B run; the CU's vector-memory queue
+    // holds ~64 wave-level loads whatever their width, 4-byte lanes leave it carrying 256 B per entry).  The rows of the
+    // NEXT tile are requested as soon as this tile's are folded into LDS (KI x 2 x 16 B per lane in registers), so the
+    // gather -- a third of the tile time when it ran in phase A -- flies under the FFT and the overlap-add.
+#ifndef ZAFX_IMDCT_PREFETCH
+#define ZAFX_IMDCT_PREFETCH 1
+#endif
+    constexpr int LPR = FPB >= 4 ? FPB / 4 : 1, MSTEP = NT / LPR;
+    constexpr int KI = (NF % MSTEP == 0 && NF >= MSTEP) ? NF / MSTEP : 1;
+    constexpr bool PRE = ZAFX_IMDCT_PREFETCH && LAYOUT == ZAFX_LAYOUT_FT && KI <= 4;
+    const int fs4 = (tid % LPR) * 4, mq4 = tid / LPR;
+    float4 pre_re[KI], pre_im[KI];
+    bool pre_ok = false;
+    auto gather4 = [&](int unit_n, int tile_n) {   // rows of my 4 frames of tile_n of unit_n -> registers
+        pre_ok = false;
+        if (!vec4 || unit_n >= total_units) return;
+        const int tile_a_n = (unit_n % segs) * seg_tiles;
+        const int first_needed_n = tile_n < tile_a_n ? FPB - 1 : 0;
+        const int t = tile_n * FPB + fs4;
+        if (t < T && fs4 + 3 >= first_needed_n) {   // pitch % 4 == 0: the four frames lie in the row (those past T are not used)
+            pre_ok = true;
+            const float* cp = coefs + (long long)(unit_n / segs) * M * TP + t;
+#pragma unroll
+            for (int i = 0; i < KI; ++i) {
+                const int m = mq4 + i * MSTEP;
+                pre_re[i] = *reinterpret_cast<const float4*>(cp + (long long)(2 * m) * TP);
+                pre_im[i] = *reinterpret_cast<const float4*>(cp + (long long)(M - 1 - 2 * m) * TP);
+            }
+        }
+    };
+    auto first_tile = [&](int unit_n) {
+        const int ta = (unit_n % segs) * seg_tiles;
+        return ta > 0 ? ta - 1 : 0;
+    };
+    if constexpr (PRE) gather4(blockIdx.x, blockIdx.x < total_units ? first_tile(blockIdx.x) : 0);
+
     PROF_INIT(g_prof_imdct);
     for (int unit = blockIdx.x; unit < total_units; unit += gridDim.x) {
     const int clip = unit / segs, seg = unit % segs;
@@ -354,19 +390,13 @@ __global__ __launch_bounds__(NSLOT * fft_threads(LOG2NF, LOG2E)) void k_imdct(
             for (int m = mq; m < NF; m += P) fb[phys(m)] = cmul(make_float2(cp[2 * m], cp[M - 1 - 2 * m]), tw8[m]);
         }
     } else if (vec4) {
-        // 16-byte gathers: a lane reads 4 adjacent frames of a row (8 lanes per 128-B run).  The CU's
-        // vector-memory queue holds ~64 wave-level loads whatever their width; 4-byte lanes leave it
-        // carrying 256 B per entry.
-        constexpr int LPR = FPB / 4;
-        const int fs = (tid % LPR) * 4, mq = tid / LPR;
-        const int t = t_first + fs;
-        if (t < T && fs + 3 >= first_needed) {   // pitch % 4 == 0: the four frames lie in the row (those past T are not used)
-            float2* fb = frames + fs * C::PITCH;
-            const float* cp = coefs + (long long)clip * M * TP + t;
-#pragma unroll 2
-            for (int m = mq; m < NF; m += NT / LPR) {
-                const float4 re = *reinterpret_cast<const float4*>(cp + (long long)(2 * m) * TP);
-                const float4 im = *reinterpret_cast<const float4*>(cp + (long long)(M - 1 - 2 * m) * TP);
+        if constexpr (!PRE) gather4(unit, tile);
+        if (pre_ok) {
+            float2* fb = frames + fs4 * C::PITCH;
+#pragma unroll
+            for (int i = 0; i < KI; ++i) {
+                const int m = mq4 + i * MSTEP;
+                const float4 re = pre_re[i], im = pre_im[i];
                 const float2 g = tw8[m];
                 fb[phys(m)] = cmul(make_float2(re.x, im.x), g);
                 fb[C::PITCH + phys(m)] = cmul(make_float2(re.y, im.y), g);
@@ -391,6 +421,14 @@ __global__ __launch_bounds__(NSLOT * fft_threads(LOG2NF, LOG2E)) void k_imdct(
     PROF_MARK(1);
     lds_barrier();
     PROF_MARK(2);
+    if constexpr (PRE) {   // the next tile of this workgroup: same unit, or the first tile of its next unit
+        int unit_n = unit, tile_n = tile + 1;
+        if (tile_n >= tile_b) {
+            unit_n = unit + gridDim.x;
+            tile_n = unit_n < total_units ? first_tile(unit_n) : 0;
+        }
+        gather4(unit_n, tile_n);
+    }
 
     // ---- phase B: FFT, then DCT-IV post-twiddle written in place as M reals per frame
     {

@@ -788,24 +788,6 @@ __global__ __launch_bounds__(1024) void k_istft_ft16(
     for (int c = tid; c < ncarry; c += NT) carry[c] = 0.f;
     lds_barrier();   // tables staged
     PROF_INIT(g_prof);
-#ifndef ZAFX_ISTFT_PREFETCH
-#define ZAFX_ISTFT_PREFETCH 1
-#endif
-    // The FFT phase needs 116 of the 128 VGPRs, so a tile's rows cannot ride across it -- but they can across the
-    // overlap-add: the NEXT tile's sweeps are requested after the FFT barrier and folded at the top of the next
-    // iteration (KI x 4 row pieces per lane in registers during phase C, whose own pressure is low).
-    constexpr bool PRE = ZAFX_ISTFT_PREFETCH && !TF && KI * (ONE ? 2 : 4) * (int)sizeof(RV) <= 256;
-    RV pre[PRE ? KI : 1][4];
-    bool pre_ok = false;
-    auto gather = [&](const Tile& it) {
-        pre_ok = my_frame_needed(it);
-        if (pre_ok) {
-            const Src sp = source(it);
-#pragma unroll
-            for (int s = 0; s < KI; ++s) load4(sp, s, pre[PRE ? s : 0]);
-        }
-    };
-    if constexpr (PRE) gather(cur);
 
     while (true) {
         PROF_MARK(0);
@@ -850,12 +832,7 @@ __global__ __launch_bounds__(1024) void k_istft_ft16(
             PROF_MARK(2);
         } else {
         // ---- phase A: stream the tile's sweeps, DEPTH at a time, through the Hermitian fold into LDS
-        if constexpr (PRE) {
-            if (pre_ok) {
-#pragma unroll
-                for (int s = 0; s < KI; ++s) fold4(s, pre[s]);
-            }
-        } else if (my_frame_needed(cur)) {
+        if (my_frame_needed(cur)) {
             const Src sp = source(cur);
 #pragma unroll DEPTH
             for (int s = 0; s < KI; ++s) {
@@ -879,10 +856,6 @@ __global__ __launch_bounds__(1024) void k_istft_ft16(
         PROF_MARK(3);
         lds_barrier();
         PROF_MARK(4);
-        if constexpr (PRE) {
-            pre_ok = false;
-            if (has_next) gather(nxt);
-        }
         // ---- phase C: overlap-add (carry first), trim (:236-238), COLA gain (:241); next carry
         {
             OlaArgs a;

@@ -5,6 +5,7 @@
 
 #include <algorithm>
 #include <cmath>
+#include <complex>
 #include <cstring>
 #include <map>
 #include <mutex>
@@ -411,8 +412,14 @@ int zafx_plan_create(zafx_plan** out, int device, int kind, const zafx_params* p
     if (is_stft_family(kind)) {
         pl->W = params->window_length;
         pl->H = params->step_length;
-        const int lw = ilog2_exact(pl->W);
-        if (lw < 0 || !stft_supported(lw - 1)) return bail("window_length must be a power of two in [64, 8192]");
+        int lw = ilog2_exact(pl->W);
+        if (lw < 0 && params->precision == ZAFX_PRECISION_F64 && pl->W >= 2 && pl->W <= 2048) {
+            // any length up to 2048 in the float64 mode: Bluestein convolution of length 2^bs_log2m >= 2 W - 1
+            while ((1 << pl->bs_log2m) < 2 * pl->W - 1) ++pl->bs_log2m;
+            lw = 6;   // (only sizes the unused float32 tables below)
+        } else if (lw < 0 || !stft_supported(lw - 1)) {
+            return bail("window_length must be a power of two in [64, 8192] (any length in [2, 2048] with ZAFX_PRECISION_F64)");
+        }
         if (pl->H < 1) return bail("step_length must be >= 1");
         if (kind == ZAFX_ISTFT && pl->H > pl->W) return bail("istft: step_length must not exceed window_length");
         if (pl->H > (1 << 20)) return bail("step_length must not exceed 2^20");
@@ -423,7 +430,7 @@ int zafx_plan_create(zafx_plan** out, int device, int kind, const zafx_params* p
             if (kind == ZAFX_MFCC && (params->n_coefs < 1 || params->n_coefs > params->n_filters))
                 return bail("n_coefs must be in [1, n_filters]");
             if (params->precision == ZAFX_PRECISION_F64) {
-                if (params->n_filters > pl->W / 2) return bail("n_filters must not exceed window_length / 2");
+                if (params->n_filters > std::max(pl->W / 2, 1)) return bail("n_filters must not exceed window_length / 2");
             } else if (lw - 1 < 5 || lw - 1 > 10) {
                 return bail("float32 mel/mfcc kernels are built for window_length 64 ... 2048 (any power of two with ZAFX_PRECISION_F64)");
             }
@@ -435,8 +442,13 @@ int zafx_plan_create(zafx_plan** out, int device, int kind, const zafx_params* p
     } else if (is_mdct_family(kind)) {
         pl->W = params->window_length;
         pl->H = pl->W / 2;   // zaf.py:1029
-        const int lw = ilog2_exact(pl->W);
-        if (lw < 0 || !mdct_supported(lw - 2)) return bail("window_length must be a power of two in [64, 8192]");
+        int lw = ilog2_exact(pl->W);
+        if (lw < 0 && params->precision == ZAFX_PRECISION_F64 && pl->W >= 4 && pl->W <= 2048 && pl->W % 2 == 0) {
+            while ((1 << pl->bs_log2m) < 2 * pl->W - 1) ++pl->bs_log2m;   // any even length in the float64 mode (Bluestein)
+            lw = 6;
+        } else if (lw < 0 || !mdct_supported(lw - 2)) {
+            return bail("window_length must be a power of two in [64, 8192] (any even length in [4, 2048] with ZAFX_PRECISION_F64)");
+        }
         pl->log2nf = lw - 2;
         const int nf = pl->W / 4, m = pl->W / 2;
         aux.resize((size_t)nf);
@@ -502,18 +514,56 @@ int zafx_plan_create(zafx_plan** out, int device, int kind, const zafx_params* p
         };
         std::vector<double2> tw((size_t)std::max(n / 2, 1)), tws((size_t)(mdct ? n : cqt ? pl->W : n / 2 + 1));
         for (int m = 0; m < n / 2; ++m) tw[(size_t)m] = root(m, n);
-        if (mdct) {   // g_m = exp(-i pi (8m+1) / (8M)), M = W/2: pre- and post-twiddle of the DCT-IV
+        if (pl->bs_log2m > 0) {   // Bluestein: roots of M, the chirp c[n] = exp(-i pi n^2 / W), and FFT_M of its wrapped conjugate
+            const int M = 1 << pl->bs_log2m, W = pl->W;
+            tw.assign((size_t)M / 2, make_double2(0, 0));
+            for (int m = 0; m < M / 2; ++m) tw[(size_t)m] = root(m, M);
+            tws.assign((size_t)W, make_double2(0, 0));
+            for (long long k = 0; k < W; ++k) tws[(size_t)k] = root((k * k) % (2LL * W), 2LL * W);
+            // b[m] = conj(c[|m|]) for -W < m < W, wrapped to length M; radix-2 FFT in long double
+            typedef std::complex<long double> cld;
+            std::vector<cld> b((size_t)M, cld(0, 0));
+            const long double pi = 3.14159265358979323846264338327950288L;
+            for (long long k = 0; k < W; ++k) {
+                const long double ang = pi * (long double)((k * k) % (2LL * W)) / (long double)W;
+                const cld v(cosl(ang), sinl(ang));   // conj(c[k]) = exp(+i pi k^2 / W)
+                b[(size_t)k] = v;
+                if (k) b[(size_t)(M - k)] = v;
+            }
+            for (int i = 1, j = 0; i < M; ++i) {   // bit reversal
+                int bit = M >> 1;
+                for (; j & bit; bit >>= 1) j ^= bit;
+                j ^= bit;
+                if (i < j) std::swap(b[(size_t)i], b[(size_t)j]);
+            }
+            for (int len = 2; len <= M; len <<= 1) {
+                for (int i = 0; i < M; i += len)
+                    for (int k = 0; k < len / 2; ++k) {
+                        const long double ang = -2.0L * pi * (long double)k / (long double)len;
+                        const cld w(cosl(ang), sinl(ang));
+                        const cld u = b[(size_t)(i + k)], v = b[(size_t)(i + k + len / 2)] * w;
+                        b[(size_t)(i + k)] = u + v;
+                        b[(size_t)(i + k + len / 2)] = u - v;
+                    }
+            }
+            std::vector<double2> bhat((size_t)M);
+            for (int i = 0; i < M; ++i) bhat[(size_t)i] = make_double2((double)b[(size_t)i].real(), (double)b[(size_t)i].imag());
+            e = upload(&pl->d_bhat64, bhat.data(), bhat.size() * sizeof(double2));
+        } else if (mdct) {   // g_m = exp(-i pi (8m+1) / (8M)), M = W/2: pre- and post-twiddle of the DCT-IV
             for (int m = 0; m < n; ++m) tws[(size_t)m] = root(8LL * m + 1, 8LL * pl->W);
         } else if (cqt) {   // every root of W: the decimation-in-time recombination reads exp(-2 pi i (n1 k mod W) / W)
             for (int k = 0; k < pl->W; ++k) tws[(size_t)k] = root(k, pl->W);
         } else {
             for (int k = 0; k <= n / 2; ++k) tws[(size_t)k] = root(k, pl->W);
         }
-        e = upload(&pl->d_tw64, tw.data(), tw.size() * sizeof(double2));
+        if (e == hipSuccess) e = upload(&pl->d_tw64, tw.data(), tw.size() * sizeof(double2));
         if (e == hipSuccess) e = upload(&pl->d_tws64, tws.data(), tws.size() * sizeof(double2));
         pl->kernel_name = kind == ZAFX_STFT ? stft_f64_kernel_name() : kind == ZAFX_ISTFT ? istft_f64_kernel_name()
                           : kind == ZAFX_MDCT ? mdct_f64_kernel_name() : kind == ZAFX_IMDCT ? imdct_f64_kernel_name()
                           : cqt ? cqt_f64_kernel_name() : mel_f64_kernel_name();
+        if (pl->bs_log2m > 0)
+            pl->kernel_name = kind == ZAFX_ISTFT ? "k_ifft_frames_bs_f64" : kind == ZAFX_MDCT ? "k_mdct_bs_f64"
+                              : kind == ZAFX_IMDCT ? "k_imdct_frames_bs_f64" : "k_stft_bs_f64";
     }
     if (e != hipSuccess) {
         zafx_plan_destroy(pl);
@@ -546,6 +596,7 @@ int zafx_plan_destroy(zafx_plan* pl) {
     if (pl->d_fb64_meta) (void)hipFree(pl->d_fb64_meta);
     if (pl->d_dct64) (void)hipFree(pl->d_dct64);
     if (pl->d_values64) (void)hipFree(pl->d_values64);
+    if (pl->d_bhat64) (void)hipFree(pl->d_bhat64);
     if (pl->d_chunk_ptr) (void)hipFree(pl->d_chunk_ptr);
     free_band(pl->fb);
     free_band(pl->dct);

@@ -237,6 +237,35 @@ __global__ __launch_bounds__(kThreads) void k_imdct_frames_f64(
 // STFT of the frame as k_stft_f64, |X| (mel) or |X|^2 (mfcc) of bins 1..W/2 (zaf.py:370, :437-439: DC dropped, Nyquist
 // kept), the filterbank rows as bands (zaf.py:373 / :445; the matrix is 1-2 % dense), and for mfcc log(. + eps) and rows
 // 1..n_coefs of the orthonormal DCT-II (zaf.py:443-452).
+// filterbank rows as bands over `mag` (bins 1..W/2 at slots 0..), log + DCT rows for mfcc, store; `mel` = n_filters scratch doubles
+__device__ void mel_tail_f64(const double* mag, double* mel, const double* __restrict__ fb, const int* __restrict__ fb_meta,
+                             const double* __restrict__ dct, double* __restrict__ out, long long clip, int t, int T, int TP, int layout,
+                             int n_filters, int n_coefs) {
+    const bool mfcc = n_coefs > 0;
+    for (int m = threadIdx.x; m < n_filters; m += kThreads) {
+        const int lo = fb_meta[3 * m], cnt = fb_meta[3 * m + 1];
+        const double* row = fb + fb_meta[3 * m + 2];
+        double acc = 0.0;
+        for (int j = 0; j < cnt; ++j) acc += row[j] * mag[lo + j];
+        mel[m] = mfcc ? log(acc + 2.220446049250313e-16) : acc;   // np.finfo(float).eps (zaf.py:446)
+    }
+    __syncthreads();
+    const int rows = mfcc ? n_coefs : n_filters;
+    const long long stride = layout == ZAFX_LAYOUT_FT ? TP : 1;
+    const long long base = layout == ZAFX_LAYOUT_FT ? clip * rows * TP + t : (clip * T + t) * rows;
+    for (int r = threadIdx.x; r < rows; r += kThreads) {
+        double v;
+        if (mfcc) {
+            const double* d = dct + (long long)r * n_filters;
+            v = 0.0;
+            for (int m = 0; m < n_filters; ++m) v += d[m] * mel[m];
+        } else {
+            v = mel[r];
+        }
+        out[base + r * stride] = v;
+    }
+}
+
 __global__ __launch_bounds__(kThreads) void k_mel_f64(
     const double* __restrict__ x, const double* __restrict__ win, const double2* __restrict__ tw, const double2* __restrict__ tws,
     const double* __restrict__ fb, const int* __restrict__ fb_meta, const double* __restrict__ dct, double* __restrict__ out,
@@ -280,27 +309,170 @@ __global__ __launch_bounds__(kThreads) void k_mel_f64(
         }
     }
     __syncthreads();
-    for (int m = threadIdx.x; m < n_filters; m += kThreads) {
-        const int lo = fb_meta[3 * m], cnt = fb_meta[3 * m + 1];
-        const double* row = fb + fb_meta[3 * m + 2];
-        double acc = 0.0;
-        for (int j = 0; j < cnt; ++j) acc += row[j] * mag[lo + j];
-        mel[m] = mfcc ? log(acc + 2.220446049250313e-16) : acc;   // np.finfo(float).eps (zaf.py:446)
+    mel_tail_f64(mag, mel, fb, fb_meta, dct, out, clip, t, T, TP, layout, n_filters, n_coefs);
+}
+
+// ---- windows that are not a power of two (the reference's np.fft takes any length): Bluestein ---------------------------
+// W-point DFT as a convolution of length M = 2^ceil(log2(2W-1)):  n k = (n^2 + k^2 - (k-n)^2) / 2, so with
+// c[n] = exp(-i pi n^2 / W):   X[k] = c[k] * sum_n (x[n] c[n]) conj(c)[k-n].  The host provides c (exact: n^2 mod 2W in
+// integers, long double) and Bhat = FFT_M(conj(c) wrapped); the two transforms of length M run in LDS as above.
+// In: a[n] = x[n] for n < W.  Out: X[k], k < W, in the returned buffer (the other one is free).
+__device__ double2* bluestein_lds(double2* a, double2* b, int W, int log2m, const double2* __restrict__ twm,
+                                  const double2* __restrict__ chirp, const double2* __restrict__ bhat) {
+    const int M = 1 << log2m;
+    for (int n = threadIdx.x; n < M; n += kThreads) a[n] = n < W ? dmul(a[n], chirp[n]) : make_double2(0.0, 0.0);
+    __syncthreads();
+    double2* z = fft_lds(a, b, log2m, twm);
+    for (int j = threadIdx.x; j < M; j += kThreads) z[j] = dconj(dmul(z[j], bhat[j]));   // conj: the next forward transform inverts
+    __syncthreads();
+    double2* o = z == a ? b : a;
+    double2* y = fft_lds(z, o, log2m, twm);
+    const double inv = 1.0 / (double)M;
+    for (int k = threadIdx.x; k < W; k += kThreads) {
+        const double2 c = dconj(y[k]);
+        y[k] = dmul(chirp[k], make_double2(c.x * inv, c.y * inv));
     }
     __syncthreads();
-    const int rows = mfcc ? n_coefs : n_filters;
+    return y;
+}
+
+__global__ __launch_bounds__(kThreads) void k_stft_bs_f64(
+    const double* __restrict__ x, const double* __restrict__ win, const double2* __restrict__ twm, const double2* __restrict__ chirp,
+    const double2* __restrict__ bhat, const double* __restrict__ fb, const int* __restrict__ fb_meta, const double* __restrict__ dct,
+    double2* __restrict__ out, long long n_samples, int hop, int T, int TP, int W, int log2m, int layout, int spec, int n_filters,
+    int n_coefs, int mel_mode) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    const int M = 1 << log2m;
+    double2* a = reinterpret_cast<double2*>(smem_raw);
+    double2* b = a + M;
+    const long long g = blockIdx.x;
+    const long long clip = g / T;
+    const int t = (int)(g - clip * T);
+    const double* xc = x + clip * n_samples;
+    const long long s0 = (long long)t * hop - W / 2;   // floor(W/2) samples of left padding (zaf.py:99)
+    for (int n = threadIdx.x; n < W; n += kThreads) {
+        const long long s = s0 + n;
+        a[n] = make_double2((s >= 0 && s < n_samples) ? xc[s] * win[n] : 0.0, 0.0);
+    }
+    __syncthreads();
+    const double2* X = bluestein_lds(a, b, W, log2m, twm, chirp, bhat);
+    if (mel_mode) {   // zaf.py:370 / :437-439: bins 1 .. int(W/2)
+        double* mag = reinterpret_cast<double*>(X == a ? b : a);
+        double* mel = mag + W / 2;
+        for (int k = 1 + threadIdx.x; k <= W / 2; k += kThreads) {
+            const double h = hypot(X[k].x, X[k].y);
+            mag[k - 1] = n_coefs > 0 ? h * h : h;
+        }
+        __syncthreads();
+        mel_tail_f64(mag, mel, fb, fb_meta, dct, reinterpret_cast<double*>(out), clip, t, T, TP, layout, n_filters, n_coefs);
+        return;
+    }
+    const int rows = spec ? W / 2 + 1 : W;
     const long long stride = layout == ZAFX_LAYOUT_FT ? TP : 1;
     const long long base = layout == ZAFX_LAYOUT_FT ? clip * rows * TP + t : (clip * T + t) * rows;
-    for (int r = threadIdx.x; r < rows; r += kThreads) {
-        double v;
-        if (mfcc) {
-            const double* d = dct + (long long)r * n_filters;
-            v = 0.0;
-            for (int m = 0; m < n_filters; ++m) v += d[m] * mel[m];
+    for (int k = threadIdx.x; k < rows; k += kThreads) {
+        double2 v = X[k];
+        if (k == 0 || 2 * k == W) v.y = 0.0;   // real input: DC and Nyquist are real (np.fft returns exact zeros there)
+        if (spec >= ZAFX_SPECTRUM_MAGNITUDE) {
+            const double pw = v.x * v.x + v.y * v.y;
+            reinterpret_cast<double*>(out)[base + k * stride] = spec == ZAFX_SPECTRUM_MAGNITUDE ? sqrt(pw) : pw;
         } else {
-            v = mel[r];
+            out[base + k * stride] = v;
         }
-        out[base + r * stride] = v;
+    }
+}
+
+// real(ifft(X)) of one frame per workgroup for any W: ifft(X) = conj(fft(conj(X))) / W
+__global__ __launch_bounds__(kThreads) void k_ifft_frames_bs_f64(
+    const double2* __restrict__ spec, const double2* __restrict__ twm, const double2* __restrict__ chirp, const double2* __restrict__ bhat,
+    double* __restrict__ frames, int T, int TP, int W, int log2m, int layout, int one) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    const int M = 1 << log2m, rows = one ? W / 2 + 1 : W;
+    double2* a = reinterpret_cast<double2*>(smem_raw);
+    double2* b = a + M;
+    const long long g = blockIdx.x;
+    const long long clip = g / T;
+    const int t = (int)(g - clip * T);
+    const long long stride = layout == ZAFX_LAYOUT_FT ? TP : 1;
+    const double2* sp = layout == ZAFX_LAYOUT_FT ? spec + clip * rows * TP + t : spec + (clip * T + t) * rows;
+    for (int k = threadIdx.x; k < W; k += kThreads) {
+        // one-sided input: X[W-k] = conj X[k]; conj(X) goes in
+        a[k] = (one && k > W / 2) ? sp[(long long)(W - k) * stride] : dconj(sp[(long long)k * stride]);
+    }
+    __syncthreads();
+    const double2* y = bluestein_lds(a, b, W, log2m, twm, chirp, bhat);
+    double* fr = frames + g * W;
+    const double inv = 1.0 / (double)W;
+    for (int n = threadIdx.x; n < W; n += kThreads) fr[n] = y[n].x * inv;   // Re(conj(.)) = Re(.)
+}
+
+// exp(-i pi num / den) with the angle reduced in integers first (num, den > 0)
+__device__ __forceinline__ double2 unit_mpi(long long num, long long den) {
+    const long long r = num % (2 * den);
+    double sn, cs;
+    sincospi((double)r / (double)den, &sn, &cs);
+    return make_double2(cs, -sn);
+}
+
+// MDCT of any even window length, the reference's own formulation (zaf.py:1047-1073): W-point FFT of x w pre, first W/2
+// outputs times post, real part;  pre[n] = exp(-i pi n / W),  post[k] = exp(-i pi (W/2 + 1)(k + 1/2) / W)
+__global__ __launch_bounds__(kThreads) void k_mdct_bs_f64(
+    const double* __restrict__ x, const double* __restrict__ win, const double2* __restrict__ twm, const double2* __restrict__ chirp,
+    const double2* __restrict__ bhat, double* __restrict__ out, long long n_samples, int T, int TP, int W, int log2m, int layout) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    const int M = 1 << log2m, F = W / 2;
+    double2* a = reinterpret_cast<double2*>(smem_raw);
+    double2* b = a + M;
+    const long long g = blockIdx.x;
+    const long long clip = g / T;
+    const int t = (int)(g - clip * T);
+    const double* xc = x + clip * n_samples;
+    const long long s0 = (long long)t * F - F;   // left pad = W/2 (zaf.py:1036-1041)
+    for (int n = threadIdx.x; n < W; n += kThreads) {
+        const long long s = s0 + n;
+        const double v = (s >= 0 && s < n_samples) ? xc[s] * win[n] : 0.0;
+        const double2 pre = unit_mpi(n, W);
+        a[n] = make_double2(v * pre.x, v * pre.y);
+    }
+    __syncthreads();
+    const double2* X = bluestein_lds(a, b, W, log2m, twm, chirp, bhat);
+    const long long stride = layout == ZAFX_LAYOUT_FT ? TP : 1;
+    const long long base = layout == ZAFX_LAYOUT_FT ? clip * F * TP + t : (clip * T + t) * F;
+    for (int k = threadIdx.x; k < F; k += kThreads) {
+        const double2 post = unit_mpi((long long)(F + 1) * (2 * k + 1), 2LL * W);
+        out[base + k * stride] = X[k].x * post.x - X[k].y * post.y;
+    }
+}
+
+// IMDCT frames of any even window length (zaf.py:1138-1169): W-point FFT of X pre zero-padded from F to W, times post, real
+// part, times 2 w;  pre[k] = exp(-i pi (F + 1) k / W),  post[n] = exp(-i pi (n + 1/2 + F/2) / W) / F
+__global__ __launch_bounds__(kThreads) void k_imdct_frames_bs_f64(
+    const double* __restrict__ coefs, const double* __restrict__ win, const double2* __restrict__ twm, const double2* __restrict__ chirp,
+    const double2* __restrict__ bhat, double* __restrict__ frames, int T, int TP, int W, int log2m, int layout) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    const int M = 1 << log2m, F = W / 2;
+    double2* a = reinterpret_cast<double2*>(smem_raw);
+    double2* b = a + M;
+    const long long g = blockIdx.x;
+    const long long clip = g / T;
+    const int t = (int)(g - clip * T);
+    const long long stride = layout == ZAFX_LAYOUT_FT ? TP : 1;
+    const double* cp = layout == ZAFX_LAYOUT_FT ? coefs + clip * F * TP + t : coefs + (clip * T + t) * F;
+    for (int k = threadIdx.x; k < W; k += kThreads) {
+        if (k < F) {
+            const double v = cp[(long long)k * stride];
+            const double2 pre = unit_mpi((long long)(F + 1) * k, W);
+            a[k] = make_double2(v * pre.x, v * pre.y);
+        } else {
+            a[k] = make_double2(0.0, 0.0);
+        }
+    }
+    __syncthreads();
+    const double2* Y = bluestein_lds(a, b, W, log2m, twm, chirp, bhat);
+    double* fr = frames + g * W;
+    for (int n = threadIdx.x; n < W; n += kThreads) {
+        const double2 post = unit_mpi(2LL * n + 1 + F, 2LL * W);   // (n + 1/2 + F/2) / W = (2n + 1 + F) / (2W)
+        fr[n] = 2.0 * (Y[n].x * post.x - Y[n].y * post.y) / (double)F * win[n];
     }
 }
 
@@ -406,7 +578,21 @@ static hipError_t grow_scratch(zafx_plan& pl, size_t need) {
     return hipSuccess;
 }
 
+// STFT / mel / mfcc of a window that is not a power of two
+static hipError_t launch_bs_f64(const zafx_plan& pl, const double* x, void* out, int64_t n_clips, int64_t n_samples, int T, bool mel_mode) {
+    const long long blocks = (long long)n_clips * T;
+    if (blocks <= 0) return hipSuccess;
+    const size_t smem = ((size_t)2 << pl.bs_log2m) * sizeof(double2);
+    auto kern = k_stft_bs_f64;
+    if (hipError_t e = ensure_dynamic_lds(reinterpret_cast<const void*>(kern), pl.device, smem); e != hipSuccess) return e;
+    hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(kThreads), smem, pl.stream, x, pl.d_window64, pl.d_tw64, pl.d_tws64, pl.d_bhat64,
+                       pl.d_fb64, pl.d_fb64_meta, pl.d_dct64, (double2*)out, (long long)n_samples, pl.H, T, (int)row_pitch(pl, T), pl.W,
+                       pl.bs_log2m, pl.layout, pl.prm.spectrum, pl.prm.n_filters, pl.kind == ZAFX_MFCC ? pl.prm.n_coefs : 0, mel_mode ? 1 : 0);
+    return hipGetLastError();
+}
+
 hipError_t launch_stft_f64(const zafx_plan& pl, const double* x, double2* out, int64_t n_clips, int64_t n_samples, int T) {
+    if (pl.bs_log2m > 0) return launch_bs_f64(pl, x, out, n_clips, n_samples, T, false);
     const long long blocks = (long long)n_clips * T;
     if (blocks <= 0) return hipSuccess;
     const size_t smem = (size_t)pl.W * sizeof(double2);   // two buffers of W/2 points
@@ -421,6 +607,20 @@ hipError_t launch_istft_f64(zafx_plan& pl, const double2* spec, double* y, int64
     const long long blocks = (long long)n_clips * T;
     if (blocks <= 0 || out_len <= 0) return hipSuccess;
     if (hipError_t e = grow_scratch(pl, (size_t)blocks * pl.W * sizeof(double)); e != hipSuccess) return e;
+    if (pl.bs_log2m > 0) {   // window that is not a power of two
+        const size_t smem = ((size_t)2 << pl.bs_log2m) * sizeof(double2);
+        auto kern = k_ifft_frames_bs_f64;
+        if (hipError_t e = ensure_dynamic_lds(reinterpret_cast<const void*>(kern), pl.device, smem); e != hipSuccess) return e;
+        hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(kThreads), smem, pl.stream, spec, pl.d_tw64, pl.d_tws64, pl.d_bhat64,
+                           pl.d_scratch64, T, (int)row_pitch(pl, T), pl.W, pl.bs_log2m, pl.layout,
+                           pl.prm.spectrum == ZAFX_SPECTRUM_ONE_SIDED ? 1 : 0);
+        if (hipError_t e = hipGetLastError(); e != hipSuccess) return e;
+        const long long total = (long long)n_clips * out_len;
+        const long long grid = std::min<long long>((total + kThreads - 1) / kThreads, (long long)pl.n_cus * 32);
+        hipLaunchKernelGGL(k_ola_f64, dim3((unsigned)grid), dim3(kThreads), 0, pl.stream, pl.d_scratch64, y, T, pl.W, pl.H,
+                           (long long)out_len, total, 1.0 / pl.cola_gain64);
+        return hipGetLastError();
+    }
     const size_t smem = (size_t)pl.W * sizeof(double2);
     auto kern = k_ifft_frames_f64;
     if (hipError_t e = ensure_dynamic_lds(reinterpret_cast<const void*>(kern), pl.device, smem); e != hipSuccess) return e;
@@ -456,6 +656,7 @@ hipError_t launch_cqt_f64(zafx_plan& pl, const double* x, double* out, int64_t n
 }
 
 hipError_t launch_mel_f64(const zafx_plan& pl, const double* x, double* out, int64_t n_clips, int64_t n_samples, int T) {
+    if (pl.bs_log2m > 0) return launch_bs_f64(pl, x, out, n_clips, n_samples, T, true);
     const long long blocks = (long long)n_clips * T;
     if (blocks <= 0) return hipSuccess;
     const size_t smem = (size_t)pl.W * sizeof(double2);   // two buffers of W/2 points; the idle one later holds bins + band sums
@@ -470,6 +671,14 @@ hipError_t launch_mel_f64(const zafx_plan& pl, const double* x, double* out, int
 hipError_t launch_mdct_f64(const zafx_plan& pl, const double* x, double* out, int64_t n_clips, int64_t n_samples, int T) {
     const long long blocks = (long long)n_clips * T;
     if (blocks <= 0) return hipSuccess;
+    if (pl.bs_log2m > 0) {   // window that is not a power of two
+        const size_t smem = ((size_t)2 << pl.bs_log2m) * sizeof(double2);
+        auto kern = k_mdct_bs_f64;
+        if (hipError_t e = ensure_dynamic_lds(reinterpret_cast<const void*>(kern), pl.device, smem); e != hipSuccess) return e;
+        hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(kThreads), smem, pl.stream, x, pl.d_window64, pl.d_tw64, pl.d_tws64, pl.d_bhat64,
+                           out, (long long)n_samples, T, (int)row_pitch(pl, T), pl.W, pl.bs_log2m, pl.layout);
+        return hipGetLastError();
+    }
     const size_t smem = (size_t)pl.W * 8 + (size_t)(pl.W / 2) * 8 + (size_t)(pl.W / 4) * 32;   // u, v, two FFT buffers
     auto kern = k_mdct_f64;
     if (hipError_t e = ensure_dynamic_lds(reinterpret_cast<const void*>(kern), pl.device, smem); e != hipSuccess) return e;
@@ -482,11 +691,19 @@ hipError_t launch_imdct_f64(zafx_plan& pl, const double* coefs, double* y, int64
     const long long blocks = (long long)n_clips * T;
     if (blocks <= 0 || out_len <= 0) return hipSuccess;
     if (hipError_t e = grow_scratch(pl, (size_t)blocks * pl.W * sizeof(double)); e != hipSuccess) return e;
+    if (pl.bs_log2m > 0) {   // window that is not a power of two
+        const size_t smem = ((size_t)2 << pl.bs_log2m) * sizeof(double2);
+        auto kern = k_imdct_frames_bs_f64;
+        if (hipError_t e = ensure_dynamic_lds(reinterpret_cast<const void*>(kern), pl.device, smem); e != hipSuccess) return e;
+        hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(kThreads), smem, pl.stream, coefs, pl.d_window64, pl.d_tw64, pl.d_tws64,
+                           pl.d_bhat64, pl.d_scratch64, T, (int)row_pitch(pl, T), pl.W, pl.bs_log2m, pl.layout);
+    } else {
     const size_t smem = (size_t)(pl.W / 2) * 16 + (size_t)(pl.W / 4) * 32;
     auto kern = k_imdct_frames_f64;
     if (hipError_t e = ensure_dynamic_lds(reinterpret_cast<const void*>(kern), pl.device, smem); e != hipSuccess) return e;
     hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(kThreads), smem, pl.stream, coefs, pl.d_window64, pl.d_tw64, pl.d_tws64,
                        pl.d_scratch64, T, (int)row_pitch(pl, T), pl.log2nf, pl.layout);
+    }
     if (hipError_t e = hipGetLastError(); e != hipSuccess) return e;
     // two-frame TDAC overlap-add in ascending frame order (zaf.py:1172-1179) and the trim [H : -H-1] (:1182): the same
     // gather as the ISTFT's with hop = W/2

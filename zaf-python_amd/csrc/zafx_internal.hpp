@@ -88,6 +88,8 @@ struct zafx_plan {
     int* d_fb64_meta = nullptr;    // [n_filters][3]: first column, count, offset into d_fb64
     double* d_dct64 = nullptr;     // [n_coefs][n_filters]
     double2* d_values64 = nullptr; // CQT kernel values of a float64 plan (complex128)
+    int bs_log2m = 0;              // > 0: window that is not a power of two -- Bluestein convolution length 2^bs_log2m (zafx_f64.hip)
+    double2* d_bhat64 = nullptr;   // FFT of the wrapped conjugate chirp, 2^bs_log2m entries
     std::vector<double2> h_values64;
     int* d_slots = nullptr;        // per non-zero: LDS slot of its column in k_cqt's one-sided spectrum (bit 31 = conjugate)
     int cqt_k_lo = 0, cqt_k_hi = -1, cqt_k_special = 0;   // real-split pairs the kernel's columns need

@@ -414,12 +414,22 @@ def clear_plan_cache():
 # ======================================================================================
 # argument checking shared by the drop-in and batched entry points
 # ======================================================================================
-def _as_window(window_function):
+def _pow2(n):
+    return n > 0 and not n & (n - 1)
+
+
+def _as_window(window_function, any_length=False):
+    """any_length: the STFT family also takes windows that are not a power of two, up to 2048 samples (they run on the
+    float64 Bluestein kernels, see _needs_f64); the MDCT family does not."""
     w = np.asarray(window_function, dtype=np.float64)
     if w.ndim != 1:
         raise ValueError("window_function must be 1-D")
     n = len(w)
-    if n < 64 or n > 8192 or n & (n - 1):
+    if any_length and not _pow2(n):
+        if n < 2 or n > 2048:
+            raise ValueError(f"zafx takes windows that are not a power of two up to 2048 samples, got {n}")
+        return w
+    if n < 64 or n > 8192 or not _pow2(n):
         raise ValueError(f"zafx kernels need a power-of-two window_length in [64, 8192], got {n}")
     return w
 
@@ -472,7 +482,8 @@ def stft_plan(window_function, step_length, layout="FT", device=0, onesided=Fals
     """row_align (every 2-D plan factory): pad the rows of the device (F, T) array to a multiple of this many elements
     (16 for complex64, 32 for float32 = one 128-byte line) so that the reference-layout kernels run at their aligned
     rate for any T; Plan.out_shape / Plan.row_pitch give the padded geometry, 0 keeps the reference's compact order."""
-    w, h = _as_window(window_function), _as_step(step_length)   # (a hop above the window skips samples, as zaf.stft does)
+    w, h = _as_window(window_function, any_length=True), _as_step(step_length)   # (a hop above the window skips samples, as zaf.stft does)
+    f64 = bool(f64) or not _pow2(len(w))   # windows that are not a power of two: float64 Bluestein kernels
     key = ("stft", device, len(w), h, _LAYOUTS[layout], _spectrum_of(onesided), bool(f64), _as_row_align(row_align, layout), _digest(w))
 
     def make():
@@ -484,7 +495,7 @@ def stft_plan(window_function, step_length, layout="FT", device=0, onesided=Fals
 
 
 def istft_plan(window_function, step_length, layout="FT", device=0, onesided=False, f64=False, row_align=0):
-    w, h = _as_window(window_function), _as_step(step_length)
+    w, h = _as_window(window_function, any_length=True), _as_step(step_length)
     if h > len(w):
         raise ValueError("step_length must not exceed window_length")
     if onesided not in (False, True):
@@ -492,7 +503,7 @@ def istft_plan(window_function, step_length, layout="FT", device=0, onesided=Fal
     # the float32 overlap-add keeps a tile of 16 frames in LDS (8 at W = 4096, 4 at 8192): a hop so small that more
     # frames than that cover one sample runs on the float64 kernels (a gather overlap-add without that limit)
     tile = 16 if len(w) <= 2048 else (8 if len(w) == 4096 else 4)
-    f64 = bool(f64) or -(-len(w) // h) > tile
+    f64 = bool(f64) or -(-len(w) // h) > tile or not _pow2(len(w))
     key = ("istft", device, len(w), h, _LAYOUTS[layout], bool(onesided), bool(f64), _as_row_align(row_align, layout), _digest(w))
 
     def make():
@@ -504,7 +515,10 @@ def istft_plan(window_function, step_length, layout="FT", device=0, onesided=Fal
 
 
 def mdct_plan(window_function, layout="FT", device=0, inverse=False, row_align=0, f64=False):
-    w = _as_window(window_function)
+    w = _as_window(window_function, any_length=True)
+    if len(w) % 2 or len(w) < 4:
+        raise ValueError("the MDCT needs an even window_length >= 4")
+    f64 = bool(f64) or not _pow2(len(w))   # even lengths that are not a power of two: float64 Bluestein kernels
     key = ("imdct" if inverse else "mdct", device, len(w), _LAYOUTS[layout], _as_row_align(row_align, layout), bool(f64), _digest(w))
 
     def make():
@@ -524,7 +538,7 @@ def _dense_filterbank(mel_filterbank, window_length):
 
 
 def mel_plan(window_function, step_length, mel_filterbank, number_coefficients=None, layout="FT", device=0, row_align=0, f64=False):
-    w, h = _as_window(window_function), _as_step(step_length)
+    w, h = _as_window(window_function, any_length=True), _as_step(step_length)
     if not hasattr(mel_filterbank, "toarray"):
         raise ValueError("mel_filterbank must be a scipy.sparse matrix (as returned by melfilterbank)")
     if mel_filterbank.ndim != 2 or mel_filterbank.shape[1] != len(w) // 2:
@@ -536,7 +550,7 @@ def mel_plan(window_function, step_length, mel_filterbank, number_coefficients=N
         raise ValueError("number_coefficients must be in [1, number_filters - 1]")
     # windows above 2048 (16 frames of 4096 points do not fit LDS) and filterbanks above 256 rows run on the float64
     # kernel, which takes any power-of-two window
-    f64 = bool(f64) or len(w) > 2048 or n_filters > 256
+    f64 = bool(f64) or len(w) > 2048 or n_filters > 256 or not _pow2(len(w))
     # the cache key hashes the sparse triplet (a few KB), not the dense matrix (1 MB: 1.8 ms per call)
     csr = mel_filterbank.tocsr()
     key = ("mfcc" if mfcc else "mel", device, len(w), h, _LAYOUTS[layout], ncoef, n_filters, _as_row_align(row_align, layout), bool(f64),
@@ -604,7 +618,11 @@ def stft_batch(clips, window_function, step_length, layout="FT", device=0, onesi
     result (zaf.py:83) -- and halves the bytes written; onesided="magnitude" / "power" returns |X| / |X|^2
     of those rows as a real array."""
     x = _as_clips(clips, dtype=np.float64 if f64 else np.float32)
-    return stft_plan(window_function, step_length, layout, device, onesided, f64).run_host(x, x.shape[1])
+    plan = stft_plan(window_function, step_length, layout, device, onesided, f64)
+    out = plan.run_host(x.astype(plan.in_dtype, copy=False), x.shape[1])
+    if f64 or not plan.f64:
+        return out
+    return out.astype(np.complex64 if np.iscomplexobj(out) else np.float32)   # (computed in float64: window not a power of two)
 
 
 def istft_batch(spectra, window_function, step_length, layout="FT", device=0, onesided=False, f64=False):
@@ -612,7 +630,7 @@ def istft_batch(spectra, window_function, step_length, layout="FT", device=0, on
 
     onesided=True takes rows 0..W/2 and completes X[W-k] = conj X[k]: the result equals the two-sided
     call on the spectrum of a real signal."""
-    w = _as_window(window_function)
+    w = _as_window(window_function, any_length=True)
     s = np.asarray(spectra)
     if s.ndim != 3:
         raise ValueError("spectra must be 3-D")
@@ -627,19 +645,23 @@ def istft_batch(spectra, window_function, step_length, layout="FT", device=0, on
 def mdct_batch(clips, window_function, layout="FT", device=0, f64=False):
     """(B, N) -> (B, W/2, T) float32 ["FT"] or (B, T, W/2) ["TF"]; f64: float64 arrays and arithmetic."""
     x = _as_clips(clips, dtype=np.float64 if f64 else np.float32)
-    return mdct_plan(window_function, layout, device, f64=f64).run_host(x, x.shape[1])
+    plan = mdct_plan(window_function, layout, device, f64=f64)
+    out = plan.run_host(x.astype(plan.in_dtype, copy=False), x.shape[1])
+    return out if f64 else out.astype(np.float32, copy=False)
 
 
 def imdct_batch(coefficients, window_function, layout="FT", device=0, f64=False):
     """(B, W/2, T) ["FT"] or (B, T, W/2) ["TF"] -> (B, (W/2)(T-1) - 1) float32 (float64 with f64)."""
     c = np.ascontiguousarray(coefficients, dtype=np.float64 if f64 else np.float32)
-    w = _as_window(window_function)
+    w = _as_window(window_function, any_length=True)
     if c.ndim != 3:
         raise ValueError("coefficients must be 3-D")
     nf, nt = (c.shape[1], c.shape[2]) if _LAYOUTS[layout] == _lib.LAYOUT_FT else (c.shape[2], c.shape[1])
     if 2 * nf != len(w):
         raise ValueError("coefficient rows must equal window_length/2")
-    return mdct_plan(w, layout, device, inverse=True, f64=f64).run_host(c, nt)
+    plan = mdct_plan(w, layout, device, inverse=True, f64=f64)
+    out = plan.run_host(c.astype(plan.in_dtype, copy=False), nt)
+    return out if f64 else out.astype(np.float32, copy=False)
 
 
 def melspectrogram_batch(clips, window_function, step_length, mel_filterbank, layout="FT", device=0, f64=False):

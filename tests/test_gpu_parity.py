@@ -967,7 +967,8 @@ def test_istft_tiny_hop(zafx, wl, hop, n):
     assert y1.dtype == np.float64 and relerr(y1, yref) <= TOL_FFT
 
 
-@pytest.mark.parametrize("wl,hop,n", [(1000, 500, 20000), (1764, 441, 30000), (777, 300, 9999), (2047, 1024, 40000), (6, 3, 100), (3, 1, 50)])
+@pytest.mark.parametrize("wl,hop,n", [(1000, 500, 20000), (1764, 441, 30000), (777, 300, 9999), (2047, 1024, 40000), (6, 3, 100), (3, 1, 50),
+                                      (32, 8, 500), (16, 16, 300)])
 def test_window_not_a_power_of_two(zafx, wl, hop, n):
     """np.fft takes any length, so zaf.stft / istft / melspectrogram / mfcc take any window: lengths that are not a power
     of two (up to 2048) run on the float64 Bluestein kernels, selected by the host layer (even and odd lengths)."""
@@ -1006,7 +1007,7 @@ def test_window_not_a_power_of_two(zafx, wl, hop, n):
     assert one_clip.dtype == np.complex128 and relerr(one_clip, orc.stft(x[0].astype(np.float64), w, hop)) <= TOL_FFT
 
 
-@pytest.mark.parametrize("wl,n", [(1920, 30000), (1152, 20001), (1000, 9999), (6, 100), (2046, 40000)])
+@pytest.mark.parametrize("wl,n", [(1920, 30000), (1152, 20001), (1000, 9999), (6, 100), (2046, 40000), (32, 500), (8, 100)])
 def test_mdct_window_not_a_power_of_two(zafx, wl, n):
     """Even window lengths that are not a power of two (AAC's 1920, MP3's 1152 ...): the reference's own W-point FFT
     formulation through the float64 Bluestein kernels; TDAC round trip with a sine window."""

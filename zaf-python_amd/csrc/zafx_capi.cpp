@@ -413,7 +413,7 @@ int zafx_plan_create(zafx_plan** out, int device, int kind, const zafx_params* p
         pl->W = params->window_length;
         pl->H = params->step_length;
         int lw = ilog2_exact(pl->W);
-        if (lw < 0 && params->precision == ZAFX_PRECISION_F64 && pl->W >= 2 && pl->W <= 2048) {
+        if ((lw < 0 || lw < 6) && params->precision == ZAFX_PRECISION_F64 && pl->W >= 2 && pl->W <= 2048) {
             // any length up to 2048 in the float64 mode: Bluestein convolution of length 2^bs_log2m >= 2 W - 1
             while ((1 << pl->bs_log2m) < 2 * pl->W - 1) ++pl->bs_log2m;
             lw = 6;   // (only sizes the unused float32 tables below)
@@ -443,7 +443,7 @@ int zafx_plan_create(zafx_plan** out, int device, int kind, const zafx_params* p
         pl->W = params->window_length;
         pl->H = pl->W / 2;   // zaf.py:1029
         int lw = ilog2_exact(pl->W);
-        if (lw < 0 && params->precision == ZAFX_PRECISION_F64 && pl->W >= 4 && pl->W <= 2048 && pl->W % 2 == 0) {
+        if ((lw < 0 || lw < 6) && params->precision == ZAFX_PRECISION_F64 && pl->W >= 4 && pl->W <= 2048 && pl->W % 2 == 0) {
             while ((1 << pl->bs_log2m) < 2 * pl->W - 1) ++pl->bs_log2m;   // any even length in the float64 mode (Bluestein)
             lw = 6;
         } else if (lw < 0 || !mdct_supported(lw - 2)) {

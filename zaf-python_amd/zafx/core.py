@@ -418,6 +418,11 @@ def _pow2(n):
     return n > 0 and not n & (n - 1)
 
 
+def _tuned(n):
+    """Window lengths of the float32 kernels; every other supported length runs on the float64 Bluestein kernels."""
+    return _pow2(n) and 64 <= n <= 8192
+
+
 def _as_window(window_function, any_length=False):
     """any_length: the STFT family also takes windows that are not a power of two, up to 2048 samples (they run on the
     float64 Bluestein kernels, see _needs_f64); the MDCT family does not."""
@@ -425,11 +430,11 @@ def _as_window(window_function, any_length=False):
     if w.ndim != 1:
         raise ValueError("window_function must be 1-D")
     n = len(w)
-    if any_length and not _pow2(n):
+    if any_length and not _tuned(n):
         if n < 2 or n > 2048:
-            raise ValueError(f"zafx takes windows that are not a power of two up to 2048 samples, got {n}")
+            raise ValueError(f"zafx takes windows of 2 ... 2048 samples, or a power of two up to 8192, got {n}")
         return w
-    if n < 64 or n > 8192 or not _pow2(n):
+    if not _tuned(n):
         raise ValueError(f"zafx kernels need a power-of-two window_length in [64, 8192], got {n}")
     return w
 
@@ -483,7 +488,7 @@ def stft_plan(window_function, step_length, layout="FT", device=0, onesided=Fals
     (16 for complex64, 32 for float32 = one 128-byte line) so that the reference-layout kernels run at their aligned
     rate for any T; Plan.out_shape / Plan.row_pitch give the padded geometry, 0 keeps the reference's compact order."""
     w, h = _as_window(window_function, any_length=True), _as_step(step_length)   # (a hop above the window skips samples, as zaf.stft does)
-    f64 = bool(f64) or not _pow2(len(w))   # windows that are not a power of two: float64 Bluestein kernels
+    f64 = bool(f64) or not _tuned(len(w))   # windows that are not a power of two (or below 64): float64 Bluestein kernels
     key = ("stft", device, len(w), h, _LAYOUTS[layout], _spectrum_of(onesided), bool(f64), _as_row_align(row_align, layout), _digest(w))
 
     def make():
@@ -503,7 +508,7 @@ def istft_plan(window_function, step_length, layout="FT", device=0, onesided=Fal
     # the float32 overlap-add keeps a tile of 16 frames in LDS (8 at W = 4096, 4 at 8192): a hop so small that more
     # frames than that cover one sample runs on the float64 kernels (a gather overlap-add without that limit)
     tile = 16 if len(w) <= 2048 else (8 if len(w) == 4096 else 4)
-    f64 = bool(f64) or -(-len(w) // h) > tile or not _pow2(len(w))
+    f64 = bool(f64) or -(-len(w) // h) > tile or not _tuned(len(w))
     key = ("istft", device, len(w), h, _LAYOUTS[layout], bool(onesided), bool(f64), _as_row_align(row_align, layout), _digest(w))
 
     def make():
@@ -518,7 +523,7 @@ def mdct_plan(window_function, layout="FT", device=0, inverse=False, row_align=0
     w = _as_window(window_function, any_length=True)
     if len(w) % 2 or len(w) < 4:
         raise ValueError("the MDCT needs an even window_length >= 4")
-    f64 = bool(f64) or not _pow2(len(w))   # even lengths that are not a power of two: float64 Bluestein kernels
+    f64 = bool(f64) or not _tuned(len(w))   # even lengths that are not a power of two (or below 64): float64 Bluestein kernels
     key = ("imdct" if inverse else "mdct", device, len(w), _LAYOUTS[layout], _as_row_align(row_align, layout), bool(f64), _digest(w))
 
     def make():
@@ -550,7 +555,7 @@ def mel_plan(window_function, step_length, mel_filterbank, number_coefficients=N
         raise ValueError("number_coefficients must be in [1, number_filters - 1]")
     # windows above 2048 (16 frames of 4096 points do not fit LDS) and filterbanks above 256 rows run on the float64
     # kernel, which takes any power-of-two window
-    f64 = bool(f64) or len(w) > 2048 or n_filters > 256 or not _pow2(len(w))
+    f64 = bool(f64) or len(w) > 2048 or n_filters > 256 or not _tuned(len(w))
     # the cache key hashes the sparse triplet (a few KB), not the dense matrix (1 MB: 1.8 ms per call)
     csr = mel_filterbank.tocsr()
     key = ("mfcc" if mfcc else "mel", device, len(w), h, _LAYOUTS[layout], ncoef, n_filters, _as_row_align(row_align, layout), bool(f64),

@@ -725,6 +725,8 @@ def stft_pcm_batch(pcm, window_function, step_length, layout="FT", device=0):
     """STFT of integer PCM clips (clips, frames[, channels]): wavread's x / 2^(bits-1) and the channel mean
     (zaf.py:1202, :65) run on the device in front of the transform; only 2-4 B per sample cross PCIe."""
     plan = stft_plan(window_function, step_length, layout, device)
+    if plan.f64:   # window outside the float32 kernels: normalise on the device, then the general path (float64 arithmetic)
+        return stft_batch(pcm_to_mono(pcm, device), window_function, step_length, layout, device)
     with plan.lock:
         d_pcm, d_x = _pcm_device_mono(plan, pcm)
         b, n = d_x.shape

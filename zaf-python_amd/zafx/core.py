@@ -486,7 +486,9 @@ def get_precision():
 def stft_plan(window_function, step_length, layout="FT", device=0, onesided=False, f64=False, row_align=0):
     """row_align (every 2-D plan factory): pad the rows of the device (F, T) array to a multiple of this many elements
     (16 for complex64, 32 for float32 = one 128-byte line) so that the reference-layout kernels run at their aligned
-    rate for any T; Plan.out_shape / Plan.row_pitch give the padded geometry, 0 keeps the reference's compact order."""
+    rate for any T; Plan.out_shape / Plan.row_pitch give the padded geometry, 0 keeps the reference's compact order.
+    A window outside the float32 kernels (not a power of two, or below 64 samples) yields a float64 plan whatever `f64`
+    says: Plan.in_dtype / Plan.out_dtype tell which arrays it takes."""
     w, h = _as_window(window_function, any_length=True), _as_step(step_length)   # (a hop above the window skips samples, as zaf.stft does)
     f64 = bool(f64) or not _tuned(len(w))   # windows that are not a power of two (or below 64): float64 Bluestein kernels
     key = ("stft", device, len(w), h, _LAYOUTS[layout], _spectrum_of(onesided), bool(f64), _as_row_align(row_align, layout), _digest(w))

@@ -22,7 +22,8 @@ __device__ __forceinline__ double2 dmul(double2 a, double2 b) { return make_doub
 __device__ __forceinline__ double2 dmulc(double2 a, double2 b) { return make_double2(a.x * b.x + a.y * b.y, a.y * b.x - a.x * b.y); }
 __device__ __forceinline__ double2 dconj(double2 a) { return make_double2(a.x, -a.y); }
 
-constexpr int kThreads = 256;
+constexpr int kThreads = 256;       // workgroup size of the small frames
+constexpr int kThreadsBig = 1024;   // ... of frames whose LDS image leaves room for one workgroup per CU only (see threads_for)
 
 // In-place (ping-pong) forward FFT of N = 2^log2n points held in LDS; returns the buffer with the result.
 // tw[m] = exp(-2 pi i m / N), m < N/2.
@@ -30,7 +31,7 @@ __device__ double2* fft_lds(double2* a, double2* b, int log2n, const double2* __
     const int n = 1 << log2n;
     for (int s = 0; s < log2n; ++s) {
         const int ns = 1 << s;
-        for (int j = threadIdx.x; j < n / 2; j += kThreads) {
+        for (int j = threadIdx.x; j < n / 2; j += (int)blockDim.x) {
             const int k = j & (ns - 1);
             const double2 u = a[j], v = dmul(a[j + n / 2], tw[k << (log2n - 1 - s)]);
             const int i0 = ((j - k) << 1) + k;
@@ -46,7 +47,7 @@ __device__ double2* fft_lds(double2* a, double2* b, int log2n, const double2* __
 }
 
 // zaf.py:112-139 for one frame per workgroup
-__global__ __launch_bounds__(kThreads) void k_stft_f64(
+__global__ __launch_bounds__(kThreadsBig) void k_stft_f64(
     const double* __restrict__ x, const double* __restrict__ win, const double2* __restrict__ tw, const double2* __restrict__ tws,
     double2* __restrict__ out, long long n_samples, int hop, int T, int TP, int log2n, int layout, int spec) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
@@ -59,7 +60,7 @@ __global__ __launch_bounds__(kThreads) void k_stft_f64(
     const int t = (int)(g - clip * T);
     const double* xc = x + clip * n_samples;
     const long long s0 = (long long)t * hop - N;   // floor(W/2) = N samples of left padding
-    for (int n = threadIdx.x; n < N; n += kThreads) {
+    for (int n = threadIdx.x; n < N; n += (int)blockDim.x) {
         const long long s = s0 + 2 * n;
         const double u = (s >= 0 && s < n_samples) ? xc[s] * win[2 * n] : 0.0;
         const double v = (s + 1 >= 0 && s + 1 < n_samples) ? xc[s + 1] * win[2 * n + 1] : 0.0;
@@ -78,7 +79,7 @@ __global__ __launch_bounds__(kThreads) void k_stft_f64(
             out[base + row * stride] = v;
         }
     };
-    for (int k = threadIdx.x; k < N / 2; k += kThreads) {
+    for (int k = threadIdx.x; k < N / 2; k += (int)blockDim.x) {
         if (k == 0) {
             const double2 z0 = z[0], zc = z[N / 2];
             put(0, make_double2(z0.x + z0.y, 0.0));
@@ -102,7 +103,7 @@ __global__ __launch_bounds__(kThreads) void k_stft_f64(
 }
 
 // real(ifft(X)) of one frame per workgroup (zaf.py:223), W samples into the scratch, unscaled by 2 W
-__global__ __launch_bounds__(kThreads) void k_ifft_frames_f64(
+__global__ __launch_bounds__(kThreadsBig) void k_ifft_frames_f64(
     const double2* __restrict__ spec, const double2* __restrict__ tw, const double2* __restrict__ tws, double* __restrict__ frames,
     int T, int TP, int log2n, int layout, int one) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
@@ -115,7 +116,7 @@ __global__ __launch_bounds__(kThreads) void k_ifft_frames_f64(
     const long long stride = layout == ZAFX_LAYOUT_FT ? TP : 1;
     const double2* sp = layout == ZAFX_LAYOUT_FT ? spec + clip * rows * TP + t : spec + (clip * T + t) * rows;
     // packed half-length spectrum of the Hermitian part of X, re/im swapped so that a FORWARD transform inverts
-    for (int k = threadIdx.x; k < N / 2; k += kThreads) {
+    for (int k = threadIdx.x; k < N / 2; k += (int)blockDim.x) {
         if (k == 0) {
             const double a0 = 2.0 * sp[0].x, an = 2.0 * sp[(long long)N * stride].x;
             a[0] = make_double2(a0 - an, a0 + an);
@@ -140,16 +141,16 @@ __global__ __launch_bounds__(kThreads) void k_ifft_frames_f64(
     __syncthreads();
     const double2* z = fft_lds(a, b, log2n, tw);
     double* fr = frames + g * W;
-    for (int n = threadIdx.x; n < N; n += kThreads) {   // components come out swapped
+    for (int n = threadIdx.x; n < N; n += (int)blockDim.x) {   // components come out swapped
         fr[2 * n] = z[n].y;
         fr[2 * n + 1] = z[n].x;
     }
 }
 
 // overlap-add in ascending frame order (zaf.py:226-233), trim (:236-238), gain (:241)
-__global__ __launch_bounds__(kThreads) void k_ola_f64(const double* __restrict__ frames, double* __restrict__ y, int T, int W, int hop,
+__global__ __launch_bounds__(kThreadsBig) void k_ola_f64(const double* __restrict__ frames, double* __restrict__ y, int T, int W, int hop,
                                                        long long out_len, long long total, double scale) {
-    for (long long i = (long long)blockIdx.x * kThreads + threadIdx.x; i < total; i += (long long)gridDim.x * kThreads) {
+    for (long long i = (long long)blockIdx.x * (int)blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * (int)blockDim.x) {
         const long long clip = i / out_len, o = i - clip * out_len;
         const long long s = o + (W - hop);
         const long long j_hi = std::min<long long>(T - 1, s / hop);
@@ -166,10 +167,10 @@ __global__ __launch_bounds__(kThreads) void k_ola_f64(const double* __restrict__
 __device__ void dct4_lds(const double* v, double* u, double2* a, double2* b, int log2nf, const double2* __restrict__ tw,
                          const double2* __restrict__ g) {
     const int NF = 1 << log2nf, M = 2 * NF;
-    for (int m = threadIdx.x; m < NF; m += kThreads) a[m] = dmul(make_double2(v[2 * m], v[M - 1 - 2 * m]), g[m]);
+    for (int m = threadIdx.x; m < NF; m += (int)blockDim.x) a[m] = dmul(make_double2(v[2 * m], v[M - 1 - 2 * m]), g[m]);
     __syncthreads();
     const double2* z = fft_lds(a, b, log2nf, tw);
-    for (int k = threadIdx.x; k < NF; k += kThreads) {
+    for (int k = threadIdx.x; k < NF; k += (int)blockDim.x) {
         const double2 y = dmul(z[k], g[k]);
         u[2 * k] = y.x;
         u[M - 1 - 2 * k] = -y.y;
@@ -178,7 +179,7 @@ __device__ void dct4_lds(const double* v, double* u, double2* a, double2* b, int
 }
 
 // one frame per workgroup: window, TDAC fold (W -> M reals), DCT-IV
-__global__ __launch_bounds__(kThreads) void k_mdct_f64(
+__global__ __launch_bounds__(kThreadsBig) void k_mdct_f64(
     const double* __restrict__ x, const double* __restrict__ win, const double2* __restrict__ tw, const double2* __restrict__ g,
     double* __restrict__ out, long long n_samples, int T, int TP, int log2nf, int layout) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
@@ -192,23 +193,23 @@ __global__ __launch_bounds__(kThreads) void k_mdct_f64(
     const int t = (int)(gi - clip * T);
     const double* xc = x + clip * n_samples;
     const long long s0 = (long long)t * M - M;              // left pad = M (zaf.py:1036-1064)
-    for (int n = threadIdx.x; n < W; n += kThreads) {
+    for (int n = threadIdx.x; n < W; n += (int)blockDim.x) {
         const long long s = s0 + n;
         u[n] = (s >= 0 && s < n_samples) ? xc[s] * win[n] : 0.0;
     }
     __syncthreads();
-    for (int i = threadIdx.x; i < M; i += kThreads) {        // v = (-c_r - d, a - b_r), frame = (a, b, c, d) quarters of NF
+    for (int i = threadIdx.x; i < M; i += (int)blockDim.x) {        // v = (-c_r - d, a - b_r), frame = (a, b, c, d) quarters of NF
         v[i] = i < NF ? -u[3 * NF - 1 - i] - u[3 * NF + i] : u[i - NF] - u[3 * NF - 1 - i];
     }
     __syncthreads();
     dct4_lds(v, u, a, b, log2nf, tw, g);
     const long long stride = layout == ZAFX_LAYOUT_FT ? TP : 1;
     const long long base = layout == ZAFX_LAYOUT_FT ? clip * M * TP + t : (clip * T + t) * M;
-    for (int f = threadIdx.x; f < M; f += kThreads) out[base + f * stride] = u[f];
+    for (int f = threadIdx.x; f < M; f += (int)blockDim.x) out[base + f * stride] = u[f];
 }
 
 // one frame per workgroup: DCT-IV of the coefficients, unfold (u2, -u2_r, -u1_r, -u1), window, 2/M (zaf.py:1138-1169)
-__global__ __launch_bounds__(kThreads) void k_imdct_frames_f64(
+__global__ __launch_bounds__(kThreadsBig) void k_imdct_frames_f64(
     const double* __restrict__ coefs, const double* __restrict__ win, const double2* __restrict__ tw, const double2* __restrict__ g,
     double* __restrict__ frames, int T, int TP, int log2nf, int layout) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
@@ -222,12 +223,12 @@ __global__ __launch_bounds__(kThreads) void k_imdct_frames_f64(
     const int t = (int)(gi - clip * T);
     const long long stride = layout == ZAFX_LAYOUT_FT ? TP : 1;
     const double* cp = layout == ZAFX_LAYOUT_FT ? coefs + clip * M * TP + t : coefs + (clip * T + t) * M;
-    for (int f = threadIdx.x; f < M; f += kThreads) v[f] = cp[f * stride];
+    for (int f = threadIdx.x; f < M; f += (int)blockDim.x) v[f] = cp[f * stride];
     __syncthreads();
     dct4_lds(v, u, a, b, log2nf, tw, g);
     double* fr = frames + gi * W;
     const double gain = 2.0 / (double)M;
-    for (int n = threadIdx.x; n < W; n += kThreads) {
+    for (int n = threadIdx.x; n < W; n += (int)blockDim.x) {
         const double val = n < NF ? u[NF + n] : n < 3 * NF ? -u[3 * NF - 1 - n] : -u[n - 3 * NF];
         fr[n] = val * win[n] * gain;
     }
@@ -242,7 +243,7 @@ __device__ void mel_tail_f64(const double* mag, double* mel, const double* __res
                              const double* __restrict__ dct, double* __restrict__ out, long long clip, int t, int T, int TP, int layout,
                              int n_filters, int n_coefs) {
     const bool mfcc = n_coefs > 0;
-    for (int m = threadIdx.x; m < n_filters; m += kThreads) {
+    for (int m = threadIdx.x; m < n_filters; m += (int)blockDim.x) {
         const int lo = fb_meta[3 * m], cnt = fb_meta[3 * m + 1];
         const double* row = fb + fb_meta[3 * m + 2];
         double acc = 0.0;
@@ -253,7 +254,7 @@ __device__ void mel_tail_f64(const double* mag, double* mel, const double* __res
     const int rows = mfcc ? n_coefs : n_filters;
     const long long stride = layout == ZAFX_LAYOUT_FT ? TP : 1;
     const long long base = layout == ZAFX_LAYOUT_FT ? clip * rows * TP + t : (clip * T + t) * rows;
-    for (int r = threadIdx.x; r < rows; r += kThreads) {
+    for (int r = threadIdx.x; r < rows; r += (int)blockDim.x) {
         double v;
         if (mfcc) {
             const double* d = dct + (long long)r * n_filters;
@@ -266,7 +267,7 @@ __device__ void mel_tail_f64(const double* mag, double* mel, const double* __res
     }
 }
 
-__global__ __launch_bounds__(kThreads) void k_mel_f64(
+__global__ __launch_bounds__(kThreadsBig) void k_mel_f64(
     const double* __restrict__ x, const double* __restrict__ win, const double2* __restrict__ tw, const double2* __restrict__ tws,
     const double* __restrict__ fb, const int* __restrict__ fb_meta, const double* __restrict__ dct, double* __restrict__ out,
     long long n_samples, int hop, int T, int TP, int log2n, int layout, int n_filters, int n_coefs) {
@@ -280,7 +281,7 @@ __global__ __launch_bounds__(kThreads) void k_mel_f64(
     const int t = (int)(g - clip * T);
     const double* xc = x + clip * n_samples;
     const long long s0 = (long long)t * hop - N;
-    for (int n = threadIdx.x; n < N; n += kThreads) {
+    for (int n = threadIdx.x; n < N; n += (int)blockDim.x) {
         const long long s = s0 + 2 * n;
         const double u = (s >= 0 && s < n_samples) ? xc[s] * win[2 * n] : 0.0;
         const double v = (s + 1 >= 0 && s + 1 < n_samples) ? xc[s + 1] * win[2 * n + 1] : 0.0;
@@ -294,7 +295,7 @@ __global__ __launch_bounds__(kThreads) void k_mel_f64(
         const double h = hypot(v.x, v.y);   // np.abs of a complex (zaf.py:370); the power is its square (:437-439)
         mag[k - 1] = mfcc ? h * h : h;
     };
-    for (int k = threadIdx.x; k < N / 2; k += kThreads) {
+    for (int k = threadIdx.x; k < N / 2; k += (int)blockDim.x) {
         if (k == 0) {
             const double2 z0 = z[0], zc = z[N / 2];
             put(N, make_double2(z0.x - z0.y, 0.0));
@@ -320,15 +321,15 @@ __global__ __launch_bounds__(kThreads) void k_mel_f64(
 __device__ double2* bluestein_lds(double2* a, double2* b, int W, int log2m, const double2* __restrict__ twm,
                                   const double2* __restrict__ chirp, const double2* __restrict__ bhat) {
     const int M = 1 << log2m;
-    for (int n = threadIdx.x; n < M; n += kThreads) a[n] = n < W ? dmul(a[n], chirp[n]) : make_double2(0.0, 0.0);
+    for (int n = threadIdx.x; n < M; n += (int)blockDim.x) a[n] = n < W ? dmul(a[n], chirp[n]) : make_double2(0.0, 0.0);
     __syncthreads();
     double2* z = fft_lds(a, b, log2m, twm);
-    for (int j = threadIdx.x; j < M; j += kThreads) z[j] = dconj(dmul(z[j], bhat[j]));   // conj: the next forward transform inverts
+    for (int j = threadIdx.x; j < M; j += (int)blockDim.x) z[j] = dconj(dmul(z[j], bhat[j]));   // conj: the next forward transform inverts
     __syncthreads();
     double2* o = z == a ? b : a;
     double2* y = fft_lds(z, o, log2m, twm);
     const double inv = 1.0 / (double)M;
-    for (int k = threadIdx.x; k < W; k += kThreads) {
+    for (int k = threadIdx.x; k < W; k += (int)blockDim.x) {
         const double2 c = dconj(y[k]);
         y[k] = dmul(chirp[k], make_double2(c.x * inv, c.y * inv));
     }
@@ -336,7 +337,7 @@ __device__ double2* bluestein_lds(double2* a, double2* b, int W, int log2m, cons
     return y;
 }
 
-__global__ __launch_bounds__(kThreads) void k_stft_bs_f64(
+__global__ __launch_bounds__(kThreadsBig) void k_stft_bs_f64(
     const double* __restrict__ x, const double* __restrict__ win, const double2* __restrict__ twm, const double2* __restrict__ chirp,
     const double2* __restrict__ bhat, const double* __restrict__ fb, const int* __restrict__ fb_meta, const double* __restrict__ dct,
     double2* __restrict__ out, long long n_samples, int hop, int T, int TP, int W, int log2m, int layout, int spec, int n_filters,
@@ -350,7 +351,7 @@ __global__ __launch_bounds__(kThreads) void k_stft_bs_f64(
     const int t = (int)(g - clip * T);
     const double* xc = x + clip * n_samples;
     const long long s0 = (long long)t * hop - W / 2;   // floor(W/2) samples of left padding (zaf.py:99)
-    for (int n = threadIdx.x; n < W; n += kThreads) {
+    for (int n = threadIdx.x; n < W; n += (int)blockDim.x) {
         const long long s = s0 + n;
         a[n] = make_double2((s >= 0 && s < n_samples) ? xc[s] * win[n] : 0.0, 0.0);
     }
@@ -359,7 +360,7 @@ __global__ __launch_bounds__(kThreads) void k_stft_bs_f64(
     if (mel_mode) {   // zaf.py:370 / :437-439: bins 1 .. int(W/2)
         double* mag = reinterpret_cast<double*>(X == a ? b : a);
         double* mel = mag + W / 2;
-        for (int k = 1 + threadIdx.x; k <= W / 2; k += kThreads) {
+        for (int k = 1 + threadIdx.x; k <= W / 2; k += (int)blockDim.x) {
             const double h = hypot(X[k].x, X[k].y);
             mag[k - 1] = n_coefs > 0 ? h * h : h;
         }
@@ -370,7 +371,7 @@ __global__ __launch_bounds__(kThreads) void k_stft_bs_f64(
     const int rows = spec ? W / 2 + 1 : W;
     const long long stride = layout == ZAFX_LAYOUT_FT ? TP : 1;
     const long long base = layout == ZAFX_LAYOUT_FT ? clip * rows * TP + t : (clip * T + t) * rows;
-    for (int k = threadIdx.x; k < rows; k += kThreads) {
+    for (int k = threadIdx.x; k < rows; k += (int)blockDim.x) {
         double2 v = X[k];
         if (k == 0 || 2 * k == W) v.y = 0.0;   // real input: DC and Nyquist are real (np.fft returns exact zeros there)
         if (spec >= ZAFX_SPECTRUM_MAGNITUDE) {
@@ -383,7 +384,7 @@ __global__ __launch_bounds__(kThreads) void k_stft_bs_f64(
 }
 
 // real(ifft(X)) of one frame per workgroup for any W: ifft(X) = conj(fft(conj(X))) / W
-__global__ __launch_bounds__(kThreads) void k_ifft_frames_bs_f64(
+__global__ __launch_bounds__(kThreadsBig) void k_ifft_frames_bs_f64(
     const double2* __restrict__ spec, const double2* __restrict__ twm, const double2* __restrict__ chirp, const double2* __restrict__ bhat,
     double* __restrict__ frames, int T, int TP, int W, int log2m, int layout, int one) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
@@ -395,7 +396,7 @@ __global__ __launch_bounds__(kThreads) void k_ifft_frames_bs_f64(
     const int t = (int)(g - clip * T);
     const long long stride = layout == ZAFX_LAYOUT_FT ? TP : 1;
     const double2* sp = layout == ZAFX_LAYOUT_FT ? spec + clip * rows * TP + t : spec + (clip * T + t) * rows;
-    for (int k = threadIdx.x; k < W; k += kThreads) {
+    for (int k = threadIdx.x; k < W; k += (int)blockDim.x) {
         // one-sided input: X[W-k] = conj X[k]; conj(X) goes in
         a[k] = (one && k > W / 2) ? sp[(long long)(W - k) * stride] : dconj(sp[(long long)k * stride]);
     }
@@ -403,7 +404,7 @@ __global__ __launch_bounds__(kThreads) void k_ifft_frames_bs_f64(
     const double2* y = bluestein_lds(a, b, W, log2m, twm, chirp, bhat);
     double* fr = frames + g * W;
     const double inv = 1.0 / (double)W;
-    for (int n = threadIdx.x; n < W; n += kThreads) fr[n] = y[n].x * inv;   // Re(conj(.)) = Re(.)
+    for (int n = threadIdx.x; n < W; n += (int)blockDim.x) fr[n] = y[n].x * inv;   // Re(conj(.)) = Re(.)
 }
 
 // exp(-i pi num / den) with the angle reduced in integers first (num, den > 0)
@@ -416,7 +417,7 @@ __device__ __forceinline__ double2 unit_mpi(long long num, long long den) {
 
 // MDCT of any even window length, the reference's own formulation (zaf.py:1047-1073): W-point FFT of x w pre, first W/2
 // outputs times post, real part;  pre[n] = exp(-i pi n / W),  post[k] = exp(-i pi (W/2 + 1)(k + 1/2) / W)
-__global__ __launch_bounds__(kThreads) void k_mdct_bs_f64(
+__global__ __launch_bounds__(kThreadsBig) void k_mdct_bs_f64(
     const double* __restrict__ x, const double* __restrict__ win, const double2* __restrict__ twm, const double2* __restrict__ chirp,
     const double2* __restrict__ bhat, double* __restrict__ out, long long n_samples, int T, int TP, int W, int log2m, int layout) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
@@ -428,7 +429,7 @@ __global__ __launch_bounds__(kThreads) void k_mdct_bs_f64(
     const int t = (int)(g - clip * T);
     const double* xc = x + clip * n_samples;
     const long long s0 = (long long)t * F - F;   // left pad = W/2 (zaf.py:1036-1041)
-    for (int n = threadIdx.x; n < W; n += kThreads) {
+    for (int n = threadIdx.x; n < W; n += (int)blockDim.x) {
         const long long s = s0 + n;
         const double v = (s >= 0 && s < n_samples) ? xc[s] * win[n] : 0.0;
         const double2 pre = unit_mpi(n, W);
@@ -438,7 +439,7 @@ __global__ __launch_bounds__(kThreads) void k_mdct_bs_f64(
     const double2* X = bluestein_lds(a, b, W, log2m, twm, chirp, bhat);
     const long long stride = layout == ZAFX_LAYOUT_FT ? TP : 1;
     const long long base = layout == ZAFX_LAYOUT_FT ? clip * F * TP + t : (clip * T + t) * F;
-    for (int k = threadIdx.x; k < F; k += kThreads) {
+    for (int k = threadIdx.x; k < F; k += (int)blockDim.x) {
         const double2 post = unit_mpi((long long)(F + 1) * (2 * k + 1), 2LL * W);
         out[base + k * stride] = X[k].x * post.x - X[k].y * post.y;
     }
@@ -446,7 +447,7 @@ __global__ __launch_bounds__(kThreads) void k_mdct_bs_f64(
 
 // IMDCT frames of any even window length (zaf.py:1138-1169): W-point FFT of X pre zero-padded from F to W, times post, real
 // part, times 2 w;  pre[k] = exp(-i pi (F + 1) k / W),  post[n] = exp(-i pi (n + 1/2 + F/2) / W) / F
-__global__ __launch_bounds__(kThreads) void k_imdct_frames_bs_f64(
+__global__ __launch_bounds__(kThreadsBig) void k_imdct_frames_bs_f64(
     const double* __restrict__ coefs, const double* __restrict__ win, const double2* __restrict__ twm, const double2* __restrict__ chirp,
     const double2* __restrict__ bhat, double* __restrict__ frames, int T, int TP, int W, int log2m, int layout) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
@@ -458,7 +459,7 @@ __global__ __launch_bounds__(kThreads) void k_imdct_frames_bs_f64(
     const int t = (int)(g - clip * T);
     const long long stride = layout == ZAFX_LAYOUT_FT ? TP : 1;
     const double* cp = layout == ZAFX_LAYOUT_FT ? coefs + clip * F * TP + t : coefs + (clip * T + t) * F;
-    for (int k = threadIdx.x; k < W; k += kThreads) {
+    for (int k = threadIdx.x; k < W; k += (int)blockDim.x) {
         if (k < F) {
             const double v = cp[(long long)k * stride];
             const double2 pre = unit_mpi((long long)(F + 1) * k, W);
@@ -470,7 +471,7 @@ __global__ __launch_bounds__(kThreads) void k_imdct_frames_bs_f64(
     __syncthreads();
     const double2* Y = bluestein_lds(a, b, W, log2m, twm, chirp, bhat);
     double* fr = frames + g * W;
-    for (int n = threadIdx.x; n < W; n += kThreads) {
+    for (int n = threadIdx.x; n < W; n += (int)blockDim.x) {
         const double2 post = unit_mpi(2LL * n + 1 + F, 2LL * W);   // (n + 1/2 + F/2) / W = (2n + 1 + F) / (2W)
         fr[n] = 2.0 * (Y[n].x * post.x - Y[n].y * post.y) / (double)F * win[n];
     }
@@ -482,7 +483,7 @@ __global__ __launch_bounds__(kThreads) void k_imdct_frames_bs_f64(
 // other (F_n1, N2 points each, parked in a per-workgroup global scratch when N1 > 1), and a spectrum bin is recombined
 // only where the sparse kernel has a column:  X[c] = sum_n1 exp(-2 pi i n1 c / W) F_n1[c mod N2].  Then the CSR
 // mat-vec and np.absolute (zaf.py:630-632): one wavefront per row, lanes over its entries.  Persistent workgroups.
-__global__ __launch_bounds__(kThreads) void k_cqt_f64(
+__global__ __launch_bounds__(kThreadsBig) void k_cqt_f64(
     const double* __restrict__ x, const double2* __restrict__ tw, const double2* __restrict__ roots, const int* __restrict__ indptr,
     const int* __restrict__ indices, const double2* __restrict__ values, double2* __restrict__ scratch, double* __restrict__ out,
     long long n_samples, int step, int left, int T, int TP, long long total_frames, int log2w, int n_bins, int chroma_res, int layout) {
@@ -493,7 +494,7 @@ __global__ __launch_bounds__(kThreads) void k_cqt_f64(
     double2* b = a + N2;
     double* spec = reinterpret_cast<double*>(b + N2);   // n_bins magnitudes of the frame
     double2* F = scratch + (long long)blockIdx.x * W;
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, n_waves = kThreads / 64;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, n_waves = (int)blockDim.x / 64;
     for (long long g = blockIdx.x; g < total_frames; g += gridDim.x) {
         const long long clip = g / T;
         const int t = (int)(g - clip * T);
@@ -501,7 +502,7 @@ __global__ __launch_bounds__(kThreads) void k_cqt_f64(
         const long long s0 = (long long)t * step - left;   // zaf.py:612-620: `left` zeros in front of the clip
         const double2* f_lds = nullptr;
         for (int n1 = 0; n1 < N1; ++n1) {
-            for (int m = threadIdx.x; m < N2; m += kThreads) {
+            for (int m = threadIdx.x; m < N2; m += (int)blockDim.x) {
                 const long long s = s0 + n1 + (long long)N1 * m;
                 a[m] = make_double2((s >= 0 && s < n_samples) ? xc[s] : 0.0, 0.0);
             }
@@ -510,7 +511,7 @@ __global__ __launch_bounds__(kThreads) void k_cqt_f64(
             if (N1 == 1) {
                 f_lds = z;
             } else {
-                for (int k = threadIdx.x; k < N2; k += kThreads) F[(long long)n1 * N2 + k] = z[k];
+                for (int k = threadIdx.x; k < N2; k += (int)blockDim.x) F[(long long)n1 * N2 + k] = z[k];
                 __syncthreads();   // the buffers are refilled by the next sub-sequence
             }
         }
@@ -543,7 +544,7 @@ __global__ __launch_bounds__(kThreads) void k_cqt_f64(
         const int rows = chroma_res > 0 ? chroma_res : n_bins;
         const long long stride = layout == ZAFX_LAYOUT_FT ? TP : 1;
         const long long base = layout == ZAFX_LAYOUT_FT ? clip * rows * TP + t : (clip * T + t) * rows;
-        for (int r = threadIdx.x; r < rows; r += kThreads) {
+        for (int r = threadIdx.x; r < rows; r += (int)blockDim.x) {
             double v;
             if (chroma_res > 0) {   // zaf.py:693-698: rows i, i + r, i + 2r, ... summed in ascending order
                 v = 0.0;
@@ -566,6 +567,10 @@ const char* imdct_f64_kernel_name() { return "k_imdct_frames_f64"; }
 const char* stft_f64_kernel_name() { return "k_stft_f64"; }
 const char* istft_f64_kernel_name() { return "k_ifft_frames_f64"; }
 
+// Workgroup size of a frame kernel by its LDS image: the occupancy of a CU comes from several small workgroups, or --
+// when one frame fills LDS -- from one big one
+static int threads_for(size_t smem) { return smem > 80 * 1024 ? kThreadsBig : smem > 40 * 1024 ? 512 : kThreads; }
+
 // grow-only scratch of time-domain frames, owned by the plan
 static hipError_t grow_scratch(zafx_plan& pl, size_t need) {
     if (need <= pl.scratch_bytes) return hipSuccess;
@@ -585,7 +590,7 @@ static hipError_t launch_bs_f64(const zafx_plan& pl, const double* x, void* out,
     const size_t smem = ((size_t)2 << pl.bs_log2m) * sizeof(double2);
     auto kern = k_stft_bs_f64;
     if (hipError_t e = ensure_dynamic_lds(reinterpret_cast<const void*>(kern), pl.device, smem); e != hipSuccess) return e;
-    hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(kThreads), smem, pl.stream, x, pl.d_window64, pl.d_tw64, pl.d_tws64, pl.d_bhat64,
+    hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(threads_for(smem)), smem, pl.stream, x, pl.d_window64, pl.d_tw64, pl.d_tws64, pl.d_bhat64,
                        pl.d_fb64, pl.d_fb64_meta, pl.d_dct64, (double2*)out, (long long)n_samples, pl.H, T, (int)row_pitch(pl, T), pl.W,
                        pl.bs_log2m, pl.layout, pl.prm.spectrum, pl.prm.n_filters, pl.kind == ZAFX_MFCC ? pl.prm.n_coefs : 0, mel_mode ? 1 : 0);
     return hipGetLastError();
@@ -598,7 +603,7 @@ hipError_t launch_stft_f64(const zafx_plan& pl, const double* x, double2* out, i
     const size_t smem = (size_t)pl.W * sizeof(double2);   // two buffers of W/2 points
     auto kern = k_stft_f64;
     if (hipError_t e = ensure_dynamic_lds(reinterpret_cast<const void*>(kern), pl.device, smem); e != hipSuccess) return e;
-    hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(kThreads), smem, pl.stream, x, pl.d_window64, pl.d_tw64, pl.d_tws64, out,
+    hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(threads_for(smem)), smem, pl.stream, x, pl.d_window64, pl.d_tw64, pl.d_tws64, out,
                        (long long)n_samples, pl.H, T, (int)row_pitch(pl, T), pl.log2nf, pl.layout, pl.prm.spectrum);
     return hipGetLastError();
 }
@@ -611,7 +616,7 @@ hipError_t launch_istft_f64(zafx_plan& pl, const double2* spec, double* y, int64
         const size_t smem = ((size_t)2 << pl.bs_log2m) * sizeof(double2);
         auto kern = k_ifft_frames_bs_f64;
         if (hipError_t e = ensure_dynamic_lds(reinterpret_cast<const void*>(kern), pl.device, smem); e != hipSuccess) return e;
-        hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(kThreads), smem, pl.stream, spec, pl.d_tw64, pl.d_tws64, pl.d_bhat64,
+        hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(threads_for(smem)), smem, pl.stream, spec, pl.d_tw64, pl.d_tws64, pl.d_bhat64,
                            pl.d_scratch64, T, (int)row_pitch(pl, T), pl.W, pl.bs_log2m, pl.layout,
                            pl.prm.spectrum == ZAFX_SPECTRUM_ONE_SIDED ? 1 : 0);
         if (hipError_t e = hipGetLastError(); e != hipSuccess) return e;
@@ -624,7 +629,7 @@ hipError_t launch_istft_f64(zafx_plan& pl, const double2* spec, double* y, int64
     const size_t smem = (size_t)pl.W * sizeof(double2);
     auto kern = k_ifft_frames_f64;
     if (hipError_t e = ensure_dynamic_lds(reinterpret_cast<const void*>(kern), pl.device, smem); e != hipSuccess) return e;
-    hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(kThreads), smem, pl.stream, spec, pl.d_tw64, pl.d_tws64, pl.d_scratch64, T,
+    hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(threads_for(smem)), smem, pl.stream, spec, pl.d_tw64, pl.d_tws64, pl.d_scratch64, T,
                        (int)row_pitch(pl, T), pl.log2nf, pl.layout, pl.prm.spectrum == ZAFX_SPECTRUM_ONE_SIDED ? 1 : 0);
     if (hipError_t e = hipGetLastError(); e != hipSuccess) return e;
     const long long total = (long long)n_clips * out_len;
@@ -649,7 +654,7 @@ hipError_t launch_cqt_f64(zafx_plan& pl, const double* x, double* out, int64_t n
     if (hipError_t e = ensure_dynamic_lds(reinterpret_cast<const void*>(kern), pl.device, smem); e != hipSuccess) return e;
     const int diff = pl.W - pl.H;
     const int left = diff >= 0 ? (diff + 1) / 2 : -((-diff) / 2);   // ceil((fft_length - step) / 2), zaf.py:615
-    hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(kThreads), smem, pl.stream, x, pl.d_tw64, pl.d_tws64, pl.d_indptr, pl.d_indices,
+    hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(threads_for(smem)), smem, pl.stream, x, pl.d_tw64, pl.d_tws64, pl.d_indptr, pl.d_indices,
                        pl.d_values64, reinterpret_cast<double2*>(pl.d_scratch64), out, (long long)n_samples, pl.H, left, T,
                        (int)row_pitch(pl, T), total, log2w, pl.prm.n_bins, pl.kind == ZAFX_CHROMA ? pl.prm.octave_resolution : 0, pl.layout);
     return hipGetLastError();
@@ -662,7 +667,7 @@ hipError_t launch_mel_f64(const zafx_plan& pl, const double* x, double* out, int
     const size_t smem = (size_t)pl.W * sizeof(double2);   // two buffers of W/2 points; the idle one later holds bins + band sums
     auto kern = k_mel_f64;
     if (hipError_t e = ensure_dynamic_lds(reinterpret_cast<const void*>(kern), pl.device, smem); e != hipSuccess) return e;
-    hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(kThreads), smem, pl.stream, x, pl.d_window64, pl.d_tw64, pl.d_tws64, pl.d_fb64,
+    hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(threads_for(smem)), smem, pl.stream, x, pl.d_window64, pl.d_tw64, pl.d_tws64, pl.d_fb64,
                        pl.d_fb64_meta, pl.d_dct64, out, (long long)n_samples, pl.H, T, (int)row_pitch(pl, T), pl.log2nf, pl.layout,
                        pl.prm.n_filters, pl.kind == ZAFX_MFCC ? pl.prm.n_coefs : 0);
     return hipGetLastError();
@@ -675,14 +680,14 @@ hipError_t launch_mdct_f64(const zafx_plan& pl, const double* x, double* out, in
         const size_t smem = ((size_t)2 << pl.bs_log2m) * sizeof(double2);
         auto kern = k_mdct_bs_f64;
         if (hipError_t e = ensure_dynamic_lds(reinterpret_cast<const void*>(kern), pl.device, smem); e != hipSuccess) return e;
-        hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(kThreads), smem, pl.stream, x, pl.d_window64, pl.d_tw64, pl.d_tws64, pl.d_bhat64,
+        hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(threads_for(smem)), smem, pl.stream, x, pl.d_window64, pl.d_tw64, pl.d_tws64, pl.d_bhat64,
                            out, (long long)n_samples, T, (int)row_pitch(pl, T), pl.W, pl.bs_log2m, pl.layout);
         return hipGetLastError();
     }
     const size_t smem = (size_t)pl.W * 8 + (size_t)(pl.W / 2) * 8 + (size_t)(pl.W / 4) * 32;   // u, v, two FFT buffers
     auto kern = k_mdct_f64;
     if (hipError_t e = ensure_dynamic_lds(reinterpret_cast<const void*>(kern), pl.device, smem); e != hipSuccess) return e;
-    hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(kThreads), smem, pl.stream, x, pl.d_window64, pl.d_tw64, pl.d_tws64, out,
+    hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(threads_for(smem)), smem, pl.stream, x, pl.d_window64, pl.d_tw64, pl.d_tws64, out,
                        (long long)n_samples, T, (int)row_pitch(pl, T), pl.log2nf, pl.layout);
     return hipGetLastError();
 }
@@ -695,13 +700,13 @@ hipError_t launch_imdct_f64(zafx_plan& pl, const double* coefs, double* y, int64
         const size_t smem = ((size_t)2 << pl.bs_log2m) * sizeof(double2);
         auto kern = k_imdct_frames_bs_f64;
         if (hipError_t e = ensure_dynamic_lds(reinterpret_cast<const void*>(kern), pl.device, smem); e != hipSuccess) return e;
-        hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(kThreads), smem, pl.stream, coefs, pl.d_window64, pl.d_tw64, pl.d_tws64,
+        hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(threads_for(smem)), smem, pl.stream, coefs, pl.d_window64, pl.d_tw64, pl.d_tws64,
                            pl.d_bhat64, pl.d_scratch64, T, (int)row_pitch(pl, T), pl.W, pl.bs_log2m, pl.layout);
     } else {
     const size_t smem = (size_t)(pl.W / 2) * 16 + (size_t)(pl.W / 4) * 32;
     auto kern = k_imdct_frames_f64;
     if (hipError_t e = ensure_dynamic_lds(reinterpret_cast<const void*>(kern), pl.device, smem); e != hipSuccess) return e;
-    hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(kThreads), smem, pl.stream, coefs, pl.d_window64, pl.d_tw64, pl.d_tws64,
+    hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(threads_for(smem)), smem, pl.stream, coefs, pl.d_window64, pl.d_tw64, pl.d_tws64,
                        pl.d_scratch64, T, (int)row_pitch(pl, T), pl.log2nf, pl.layout);
     }
     if (hipError_t e = hipGetLastError(); e != hipSuccess) return e;

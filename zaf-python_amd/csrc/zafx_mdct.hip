@@ -367,6 +367,37 @@ __global__ __launch_bounds__(NSLOT * fft_threads(LOG2NF, LOG2E)) void k_imdct(
         return ta > 0 ? ta - 1 : 0;
     };
     if constexpr (PRE) gather4(blockIdx.x, blockIdx.x < total_units ? first_tile(blockIdx.x) : 0);
+    // Frame-major input: a frame's M coefficients are contiguous; lane p of the wave that owns a frame takes the pairs
+    // (m, NF-1-m): the two 8-byte reads X[2m..2m+1] and X[M-2-2m..M-1-2m] hold both packed inputs
+    // c[m] = X[2m] + i X[M-1-2m] and c[NF-1-m] = X[M-2-2m] + i X[2m+1] -- coalesced 512-B runs instead of 4-byte
+    // reads of every second float -- and the next tile's ride in registers as above.
+    constexpr bool PRE_TF = ZAFX_IMDCT_PREFETCH && LAYOUT == ZAFX_LAYOUT_TF && P == 64 && FPB == 2 * NSLOT && NF >= 2 * P && NF / 2 / P <= 4;
+    constexpr int KP = PRE_TF ? NF / 2 / P : 1;
+    float2 pa[2][KP], pb[2][KP];
+    bool tf_ok[2] = {false, false};
+    const bool vec_tf = reinterpret_cast<uintptr_t>(coefs) % 8 == 0;
+    auto gather_tf = [&](int unit_n, int tile_n) {
+        tf_ok[0] = tf_ok[1] = false;
+        if (!vec_tf || unit_n >= total_units) return;
+        const int tile_a_n = (unit_n % segs) * seg_tiles;
+        const int first_needed_n = tile_n < tile_a_n ? FPB - 1 : 0;
+        const int pl = tid % P;
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int fsn = tid / P + j * NSLOT, t = tile_n * FPB + fsn;
+            if (t < T && fsn >= first_needed_n) {
+                tf_ok[j] = true;
+                const float* cp = coefs + ((long long)(unit_n / segs) * T + t) * M;
+#pragma unroll
+                for (int i = 0; i < KP; ++i) {
+                    const int m = pl + i * P;
+                    pa[j][i] = *reinterpret_cast<const float2*>(cp + 2 * m);
+                    pb[j][i] = *reinterpret_cast<const float2*>(cp + M - 2 - 2 * m);
+                }
+            }
+        }
+    };
+    if constexpr (PRE_TF) gather_tf(blockIdx.x, blockIdx.x < total_units ? first_tile(blockIdx.x) : 0);
 
     PROF_INIT(g_prof_imdct);
     for (int unit = blockIdx.x; unit < total_units; unit += gridDim.x) {
@@ -380,7 +411,22 @@ __global__ __launch_bounds__(NSLOT * fft_threads(LOG2NF, LOG2E)) void k_imdct(
     PROF_MARK(0);
 
     // ---- phase A: c[m] = (X[2m] + i X[M-1-2m]) g_m  -> LDS (natural order)
-    if constexpr (LAYOUT == ZAFX_LAYOUT_TF) {
+    if (PRE_TF && vec_tf) {
+        if constexpr (PRE_TF) {
+            const int pl = tid % P;
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                if (!tf_ok[j]) continue;
+                float2* fb = frames + (tid / P + j * NSLOT) * C::PITCH;
+#pragma unroll
+                for (int i = 0; i < KP; ++i) {
+                    const int m = pl + i * P, m2 = NF - 1 - m;
+                    fb[phys(m)] = cmul(make_float2(pa[j][i].x, pb[j][i].y), tw8[m]);
+                    fb[phys(m2)] = cmul(make_float2(pb[j][i].x, pa[j][i].y), tw8[m2]);
+                }
+            }
+        }
+    } else if constexpr (LAYOUT == ZAFX_LAYOUT_TF) {
         const int mq = tid % P;
         for (int fs = tid / P; fs < FPB; fs += NSLOT) {
             const int t = t_first + fs;
@@ -428,6 +474,14 @@ __global__ __launch_bounds__(NSLOT * fft_threads(LOG2NF, LOG2E)) void k_imdct(
             tile_n = unit_n < total_units ? first_tile(unit_n) : 0;
         }
         gather4(unit_n, tile_n);
+    }
+    if constexpr (PRE_TF) {
+        int unit_n = unit, tile_n = tile + 1;
+        if (tile_n >= tile_b) {
+            unit_n = unit + gridDim.x;
+            tile_n = unit_n < total_units ? first_tile(unit_n) : 0;
+        }
+        gather_tf(unit_n, tile_n);
     }
 
     // ---- phase B: FFT, then DCT-IV post-twiddle written in place as M reals per frame
@@ -581,7 +635,8 @@ static hipError_t run_mdct(const zafx_plan& pl, const float* x, float* out, int6
 constexpr int imdct_fpb(int log2nf, int layout) {
     const int pitch = (1 << log2nf) + ((1 << log2nf) >> 4) + 1;
     const int lds_cap = (kMaxLdsBytes - twiddle_total(log2nf, default_log2e(log2nf)) * 8 - (32 << log2nf)) / (pitch * 8);
-    int f = layout == ZAFX_LAYOUT_FT ? 32 : 8;
+    int f = 32;   // (both layouts: the carry form walks 32-frame tiles; the time-minor layout also NEEDS 32 for whole-line rows)
+    (void)layout;
     while (f > lds_cap) f /= 2;
     return f < 2 ? 2 : f;
 }

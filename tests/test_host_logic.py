@@ -169,3 +169,22 @@ def test_row_align_validation():
     with pytest.raises(ValueError):
         core._as_row_align(16, "TF")
     assert core._as_row_align(0, "TF") == 0 and core._as_row_align(None, "FT") == 0 and core._as_row_align(16, "FT") == 16
+
+
+def test_window_length_routing_rules():
+    """Which window lengths the host layer accepts, and which go to the float32 kernels (decided before any device call)."""
+    from zafx import core
+    assert [n for n in (32, 64, 100, 2048, 4096, 8192, 16384) if core._tuned(n)] == [64, 2048, 4096, 8192]
+    for n in (2, 3, 63, 1000, 1764, 2047):                      # STFT family: any length up to 2048
+        assert len(core._as_window(np.ones(n), any_length=True)) == n
+    for n in (1, 3000, 16384):                                   # ... but not above it unless a tuned power of two
+        with pytest.raises(ValueError):
+            core._as_window(np.ones(n), any_length=True)
+    for n in (32, 1000, 3000):                                   # callers that need a float32 kernel
+        with pytest.raises(ValueError):
+            core._as_window(np.ones(n))
+    with pytest.raises(ValueError):
+        core._as_window(np.ones((4, 4)), any_length=True)
+    for n in (999, 2):                                           # MDCT: even and >= 4, checked before the device
+        with pytest.raises(ValueError):
+            zafx.mdct_plan(np.ones(n))

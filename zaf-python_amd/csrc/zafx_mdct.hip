@@ -64,9 +64,20 @@ __global__ __launch_bounds__(FPB * fft_threads(LOG2NF, LOG2E)) void k_mdct(
     {
         const float* xc = x + (long long)clip * n_samples;
         const long long s0 = (long long)t * M - M;
-        for (int n = p; n < W; n += P) {
-            const long long s = s0 + n;
-            u[n] = (t < T && s >= 0 && s < n_samples) ? xc[s] * win[n] : 0.f;
+        if (W % 4 == 0 && t < T && s0 >= 0 && s0 + W <= n_samples && reinterpret_cast<uintptr_t>(xc + s0) % 16 == 0 &&
+            reinterpret_cast<uintptr_t>(win) % 16 == 0) {   // interior frame: 16-byte loads, no per-sample bounds tests
+            const float4* x4 = reinterpret_cast<const float4*>(xc + s0);
+            const float4* w4 = reinterpret_cast<const float4*>(win);
+            float4* u4 = reinterpret_cast<float4*>(u);
+            for (int n = p; n < W / 4; n += P) {
+                const float4 a = x4[n], b = w4[n];
+                u4[n] = make_float4(a.x * b.x, a.y * b.y, a.z * b.z, a.w * b.w);
+            }
+        } else {
+            for (int n = p; n < W; n += P) {
+                const long long s = s0 + n;
+                u[n] = (t < T && s >= 0 && s < n_samples) ? xc[s] * win[n] : 0.f;
+            }
         }
     }
     __syncthreads();   // staging + twiddle table visible

@@ -98,14 +98,25 @@ __global__ __launch_bounds__(FPB * fft_threads(LOG2N, LOG2E)) void k_stft(
         const float* xc = x + (long long)clip * n_samples;
         const long long s0 = (long long)t * hop - N;   // floor(W/2) = N samples of left padding
         const float2* w2 = reinterpret_cast<const float2*>(win);
+        if (t < T && s0 >= 0 && s0 + W <= n_samples && reinterpret_cast<uintptr_t>(xc + s0) % 8 == 0) {
+            // interior frame: unconditional 8-byte loads (uniform per frame)
+            const float2* x2 = reinterpret_cast<const float2*>(xc + s0);
 #pragma unroll
-        for (int i = 0; i < E; ++i) {
-            const int n = p + i * P;
-            const long long s = s0 + 2 * n;
-            const float2 wv = w2[n];
-            const float a = (t < T && s >= 0 && s < n_samples) ? xc[s] : 0.f;
-            const float b = (t < T && s + 1 >= 0 && s + 1 < n_samples) ? xc[s + 1] : 0.f;
-            v[i] = make_float2(a * wv.x, b * wv.y);
+            for (int i = 0; i < E; ++i) {
+                const int n = p + i * P;
+                const float2 xv = x2[n], wv = w2[n];
+                v[i] = make_float2(xv.x * wv.x, xv.y * wv.y);
+            }
+        } else {
+#pragma unroll
+            for (int i = 0; i < E; ++i) {
+                const int n = p + i * P;
+                const long long s = s0 + 2 * n;
+                const float2 wv = w2[n];
+                const float a = (t < T && s >= 0 && s < n_samples) ? xc[s] : 0.f;
+                const float b = (t < T && s + 1 >= 0 && s + 1 < n_samples) ? xc[s + 1] : 0.f;
+                v[i] = make_float2(a * wv.x, b * wv.y);
+            }
         }
     }
     fft_frame<LOG2N, LOG2E>(v, buf, p, tw);

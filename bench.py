@@ -1,22 +1,28 @@
 #!/usr/bin/env python3
-"""Headline benchmark: batched STFT (BASELINE.json configs[1]) in audio Msamples/s.
+"""Benchmark of the windowed-transform hot path.  Headline = batched STFT (BASELINE.json configs[1]) in audio
+Msamples/s; the same JSON line carries every other BASELINE config under "configs".
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--kind stft|istft|mdct|imdct|mel|mfcc|cqt]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--kind all|stft|istft|mdct|imdct|mel|mfcc|cqt|...]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
-A "step" is one pass of the hot path over one batch: 1024 clips x 10 s @ 44.1 kHz per GPU
-(weak scaling: every rank transforms its own 1024 clips; clips are independent, there is
-no data-path collective -- the only communication is the RCCL broadcast of the window /
-filterbank constants from rank 0 before the timed region).  Inputs and outputs are
-resident in HBM when the timed region starts.  Rank 0 prints ONE JSON line.
+A "step" is one pass of the hot path over one batch: 1024 clips x 10 s @ 44.1 kHz per GPU (config 5, CQT: 1024
+clips x 30 s per GPU = 8192 over 8 GPUs).  Weak scaling: every rank transforms its own clips; clips are
+independent, there is no data-path collective -- the only communication is the RCCL broadcast of the window /
+filterbank / CQT-kernel constants from rank 0 before the timed region.  Inputs and outputs are resident in HBM
+when the timed region starts.  Rank 0 prints ONE JSON line.
 
-`roofline.achieved` = algorithmic bytes per launch / mean kernel duration measured with HIP
-events on the plan's stream.  `cpu_baseline` = the NumPy oracle (a port of zaf.stft, same
-NumPy calls per clip) timed on this host, rank 0, N=1 only, bounded sample.
+N > 1 without a framework (zafx/launch.py): launched by a launcher that sets RANK / LOCAL_RANK / WORLD_SIZE
+(torch.distributed.run does), the ranks meet through a file rendezvous; with WORLD_SIZE unset, `--gpus N` starts
+the N ranks itself.  PyTorch is not imported in either case.
+
+`roofline.achieved` = algorithmic bytes (or flops) per launch / mean kernel duration measured with HIP events on
+the plan's stream over the timed region.  `cpu_baseline` = the NumPy oracle (a port of zaf.py, same NumPy calls per
+clip) timed on this host, rank 0, N = 1 only, bounded samples.
 """
 import argparse
 import json
 import os
+import subprocess
 import sys
 import time
 
@@ -26,19 +32,31 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, os.path.join(ROOT, "zaf-python_amd"))
 sys.path.insert(0, ROOT)
 
-import zafx  # noqa: E402
-
 FS, W, H = 44100, 2048, 1024
 HBM_PEAK_GBS = 8000.0      # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+HBM_ACHIEVABLE_GBS = 6290.0   # same guide: measured-achievable copy rate
 F32_PEAK_TFLOPS = 157.3    # dense f32 vector / f32-input MFMA peak
+CONFIG_KINDS = ("mel", "mfcc", "mdct", "imdct", "cqt")   # BASELINE configs 3, 4, 5 (config 2 = the headline)
 
 
 def synth(seed, c, n):
     return np.random.default_rng([seed, c]).standard_normal(n).astype(np.float32)
 
 
+def issued_mfma_flops_per_tile(dense, frames_per_tile=16):
+    """f32 MFMA work k_mel really issues for one 16-frame tile: per 16-row block only the K-steps (4 columns each) of
+    the band that holds non-zeros (pack_band in zafx_capi.cpp) -- not the dense-equivalent 2*rows*cols."""
+    steps = 0
+    for b in range(0, dense.shape[0], 16):
+        cols = np.nonzero(np.any(dense[b:b + 16] != 0, axis=0))[0]
+        if len(cols):
+            steps += (cols[-1] - (cols[0] & ~3)) // 4 + 1
+    return steps, steps * 2.0 * 16 * 4 * frames_per_tile
+
+
 def make_workload(kind, device, layout="FT"):
-    """Returns dict(plan, n_clips, n_in, d_in, d_out, samples_per_clip, bytes_per_launch, flops_per_launch, desc)."""
+    """dict(plan, n_clips, n_in, d_in, d_out, samples_per_clip, bytes_per_launch, flops_per_launch, desc, ...)."""
+    import zafx
     ham = zafx.hamming(W)
     kbd = zafx.kaiser_bessel_derived(W)
     B, N = 1024, 441000
@@ -56,7 +74,7 @@ def make_workload(kind, device, layout="FT"):
     for r in range(B // distinct):
         d_x.copy_from(d_base, dst_offset=r * distinct * N * 4)
     d_base.free()
-    wl = dict(n_clips=B, samples_per_clip=N, base=base, flops_per_launch=0.0)
+    wl = dict(kind=kind, n_clips=B, samples_per_clip=N, base=base, flops_per_launch=0.0, flops_note=None, frames=T)
     if kind == "stft":
         plan = zafx.stft_plan(ham, H, layout=layout, device=device)
         wl.update(plan=plan, d_in=d_x, n_in=N, bytes_per_launch=B * (4 * N + 8 * W * T),
@@ -102,19 +120,28 @@ def make_workload(kind, device, layout="FT"):
         d_x.free()
         plan = zafx.mdct_plan(kbd, device=device, inverse=True)
         wl.update(plan=plan, d_in=d_m, n_in=T, bytes_per_launch=B * (4 * (W // 2) * T + 4 * ((W // 2) * (T - 1) - 1)),
-                  desc="Batched IMDCT: 1024 clips x 432 frames, KBD win=2048")
+                  desc="Batched IMDCT of the device MDCT of the same batch: 1024 clips x 432 frames, KBD win=2048")
     elif kind in ("mel", "mfcc"):
         fb = zafx.melfilterbank(FS, W, 128)
         rows = 128 if kind == "mel" else 20
         plan = zafx.mel_plan(ham, H, fb, None if kind == "mel" else 20, device=device)
-        wl.update(plan=plan, d_in=d_x, n_in=N, bytes_per_launch=B * (4 * N + 4 * rows * T),
-                  flops_per_launch=2.0 * 128 * 1024 * T * B,
+        tiles = B * ((T + 15) // 16)
+        fft_flops = B * T * 5.0 * W * 11                              # 49.8 GFLOP, as the reference computes it
+        steps, per_tile = issued_mfma_flops_per_tile(fb.toarray())
+        mfma = per_tile * tiles
+        if kind == "mfcc":
+            dsteps, dper = issued_mfma_flops_per_tile(zafx.dct2_rows(128, 20))
+            steps, mfma = steps + dsteps, mfma + dper * tiles
+        wl.update(plan=plan, d_in=d_x, n_in=N, bytes_per_launch=B * (4 * N + 4 * rows * T), flops_per_launch=fft_flops + mfma,
+                  flops_note=f"FFT 5*W*log2(W) per frame = {fft_flops / 1e9:.1f} GFLOP (VALU) + {steps} issued 16x16x4 f32 MFMA K-steps per "
+                             f"16-frame tile = {mfma / 1e9:.1f} GFLOP (dense-equivalent filterbank GEMM would be {2.0 * 128 * 1024 * T * B / 1e9:.0f} GFLOP)",
                   desc=f"Fused {kind}: 1024 clips x 10 s, win=2048 hop=1024, 128 mel filters" + (", 20 coefficients" if kind == "mfcc" else ""))
     elif kind == "cqt":
         ck = zafx.cqtkernel(FS, 24, 55, 3520)
         plan = zafx.cqt_plan(FS, 25, ck, device=device)
         wl.update(plan=plan, d_in=d_x, n_in=N, bytes_per_launch=B * (4 * N + 4 * 144 * T),
                   flops_per_launch=B * T * 5.0 * 32768 * 15,
+                  flops_note="SURVEY 8(d): 750 x 5*32768*15 per clip, the 32768-point complex FFT the reference runs (the real-input form needs half)",
                   desc="cqtspectrogram: 1024 clips x 30 s @ 44.1 kHz per GPU (config 5: 8192 clips over 8 GPUs), 24 bins/octave 55-3520 Hz, 25 frames/s")
     elif kind == "dct":
         plan = zafx.linear_plan(zafx.dct_matrix(N, 2), device=device)
@@ -126,52 +153,322 @@ def make_workload(kind, device, layout="FT"):
     return wl
 
 
-def cpu_baseline(budget_s=12.0):
-    """zaf.stft restated with the same NumPy calls (oracle.stft), one 10 s clip per call, 1 core."""
+def free_workload(wl):
+    for key in ("d_in", "d_out"):
+        wl[key].free()
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# CPU side: the oracle as baseline and as checker (the only places bench.py touches oracle/)
+# ---------------------------------------------------------------------------------------------------------------
+def _oracle_call(kind):
+    """(callable(clip index) -> result, samples per call, zaf.py lines) of the reference-faithful per-clip NumPy path."""
     from oracle import zaf_oracle as orc   # checker / baseline only
-    ham = orc.hamming_periodic(W)
-    clips = [synth(0, c, 441000).astype(np.float64) for c in range(4)]
-    for c in clips[:3]:
-        orc.stft(c, ham, H)   # warm-up (first call pays FFT plan + page faults)
+    ham, kbd = orc.hamming_periodic(W), orc.kbd_window(W)
+    n = 1323000 if kind == "cqt" else 441000
+    clips = [synth(0, c, n).astype(np.float64) for c in range(2)]
+    if kind == "stft":
+        return (lambda i: orc.stft(clips[i], ham, H)), n, "zaf.py:95-141"
+    if kind == "istft":
+        spec = [orc.stft(c, ham, H) for c in clips]
+        return (lambda i: orc.istft(spec[i], ham, H)), n, "zaf.py:214-241"
+    if kind in ("mel", "mfcc"):
+        fb = orc.melfilterbank(FS, W, 128)
+        if kind == "mel":
+            return (lambda i: orc.melspectrogram(clips[i], ham, H, fb)), n, "zaf.py:369-373"
+        return (lambda i: orc.mfcc(clips[i], ham, H, fb, 20)), n, "zaf.py:436-452"
+    if kind == "mdct":
+        return (lambda i: orc.mdct(clips[i], kbd)), n, "zaf.py:1029-1073"
+    if kind == "imdct":
+        coef = [orc.mdct(c, kbd) for c in clips]
+        return (lambda i: orc.imdct(coef[i], kbd)), n, "zaf.py:1125-1182"
+    if kind == "cqt":
+        ck = orc.cqtkernel(FS, 24, 55, 3520)
+        return (lambda i: orc.cqtspectrogram(clips[i], FS, 25, ck)), n, "zaf.py:603-633"
+    return None, 0, ""
+
+
+def cpu_baseline(kind="stft", budget_s=10.0, min_calls=5):
+    """The per-clip NumPy path of zaf.py (oracle port, same NumPy calls), one clip per call, 1 core."""
+    call, n, lines = _oracle_call(kind)
+    if call is None:
+        return None
+    call(0)
+    call(1)   # warm-up (first calls pay FFT plans + page faults)
     times = []
     t_end = time.perf_counter() + budget_s
     i = 0
-    while time.perf_counter() < t_end or len(times) < 7:
+    while time.perf_counter() < t_end or len(times) < min_calls:
         t0 = time.perf_counter()
-        orc.stft(clips[i % 4], ham, H)
+        call(i % 2)
         times.append(time.perf_counter() - t0)
         i += 1
     med = float(np.median(times))
     return {
-        "value": round(441000 / med / 1e6, 3), "unit": "Msamples/s", "cores": 1, "kind": "port",
-        "sample": f"{len(times)} calls of the NumPy oracle stft (zaf.py:95-141 restated) on one 10 s clip each, "
+        "value": round(n / med / 1e6, 3), "unit": "Msamples/s", "cores": 1, "kind": "port",
+        "sample": f"{len(times)} calls of the NumPy oracle {kind} ({lines} restated) on one {n / FS:.0f} s clip each, "
                   f"median {med * 1e3:.2f} ms/clip, min {min(times) * 1e3:.2f} ms; numpy {np.__version__}; "
                   f"host has {os.cpu_count()} logical cores, FFT single-threaded",
     }
 
 
-def parity_probe(wl, kind):
-    """max |delta| of clip 0 vs the NumPy oracle (BASELINE metric: 'max |delta| vs NumPy')."""
+def _pool_worker(args):
+    seed, count = args
     from oracle import zaf_oracle as orc
-    if kind != "stft":
-        return None
-    got = wl["d_out"].download(0, 1)[0]
-    if got.shape[0] != W:
-        got = got.T
-    ref = orc.stft(wl["base"][0].astype(np.float64), orc.hamming_periodic(W), H)
+    ham = orc.hamming_periodic(W)
+    x = synth(0, seed % 8, 441000).astype(np.float64)
+    orc.stft(x, ham, H)   # warm-up
+    t0 = time.perf_counter()
+    for _ in range(count):
+        orc.stft(x, ham, H)
+    return time.perf_counter() - t0
+
+
+def cpu_pool_main(n_workers, clips_per_worker):
+    """All-cores figure (SURVEY 8(d) CPU baseline plan): a process pool over the host's cores, BLAS pinned to 1 thread."""
+    import multiprocessing as mp
+    from oracle import zaf_oracle as orc   # imported before the fork so that the workers share its pages
+    orc.stft(synth(0, 0, 4096).astype(np.float64), orc.hamming_periodic(W), H)
+    with mp.get_context("fork").Pool(n_workers) as pool:
+        pool.map(_pool_worker, [(i, 1) for i in range(n_workers)])   # start + warm every worker
+        t0 = time.perf_counter()
+        busy = pool.map(_pool_worker, [(i, clips_per_worker) for i in range(n_workers)])
+        wall = time.perf_counter() - t0
+    total = n_workers * clips_per_worker
+    print(json.dumps({"value": round(total * 441000 / wall / 1e6, 1), "unit": "Msamples/s", "cores": n_workers, "kind": "port",
+                      "sample": f"{total} calls of the NumPy oracle stft on 10 s clips over a pool of {n_workers} processes "
+                                f"({clips_per_worker} timed per worker, wall {wall:.2f} s, mean busy {np.mean(busy):.2f} s), "
+                                f"OMP/OPENBLAS threads = 1 per worker"}))
+
+
+def cpu_baseline_all_cores(budget_s=10.0, per_clip_s=0.01):
+    """Runs cpu_pool_main in a fresh interpreter (a fork pool must not inherit a HIP context)."""
+    n = os.cpu_count() or 1
+    per_worker = int(max(4, min(64, budget_s / max(per_clip_s * 3.0, 1e-3))))   # (loaded cores run ~2-3x slower than one alone)
+    env = dict(os.environ, OMP_NUM_THREADS="1", OPENBLAS_NUM_THREADS="1", MKL_NUM_THREADS="1")
+    try:
+        res = subprocess.run([sys.executable, os.path.abspath(__file__), "--cpu-pool", str(n), str(per_worker)], env=env,
+                             capture_output=True, timeout=120, check=True)
+        return json.loads(res.stdout.decode().strip().splitlines()[-1])
+    except Exception as exc:   # the pool is a reported extra: never fail the bench line for it
+        return {"error": f"{type(exc).__name__}: {exc}"}
+
+
+def parity_probe(wl):
+    """Normwise error of clip 0 and of the LAST clip of the batch vs the NumPy oracle (BASELINE metric: 'max |delta| vs
+    NumPy'; SURVEY 8(d) tolerance: 1e-5 stft/istft/mdct/imdct, 1e-4 mel/mfcc/cqt)."""
+    from oracle import zaf_oracle as orc
+    kind, base, B = wl["kind"], wl["base"], wl["n_clips"]
+    ham, kbd = orc.hamming_periodic(W), orc.kbd_window(W)
+    x64 = base[0].astype(np.float64)
+    if kind in ("stft", "stft1"):
+        ref = orc.stft(x64, ham, H)
+        ref = ref[:W // 2 + 1] if kind == "stft1" else ref
+    elif kind in ("istft", "istft1"):
+        ref = None   # (checked as a round trip below: the device spectrum is the input)
+    elif kind == "mdct":
+        ref = orc.mdct(x64, kbd)
+    elif kind == "imdct":
+        ref = None
+    elif kind in ("mel", "mfcc"):
+        fb = orc.melfilterbank(FS, W, 128)
+        ref = orc.melspectrogram(x64, ham, H, fb) if kind == "mel" else orc.mfcc(x64, ham, H, fb, 20)
+    elif kind == "cqt":
+        ref = orc.cqtspectrogram(x64, FS, 25, orc.cqtkernel(FS, 24, 55, 3520))
+    else:
+        return {}
+    first, last = wl["d_out"].download(0, 1)[0], wl["d_out"].download(B - 8, 1)[0]   # clip B-8 is a replica of clip 0
+    out = {"replicas_bit_identical": bool(np.array_equal(first, last))}
+    if ref is None:   # inverse kinds: resynthesis of the input (zaf.py:165-194 COLA; zaf.py:1098-1109 TDAC)
+        n = 441000 if kind.startswith("istft") else 440999
+        d = float(np.max(np.abs(first[:n].astype(np.float64) - x64[:n])))
+        tol = 1e-5
+        out.update({"roundtrip_max_abs_residual": d, "tolerance": tol, "within_tolerance": bool(d < tol)})
+        if kind == "imdct":
+            refy = orc.imdct(orc.mdct(x64, kbd), kbd)
+            e = float(np.max(np.abs(first - refy)) / np.max(np.abs(refy)))
+            out.update({"max_rel_err_vs_numpy": e, "within_tolerance": bool(d < tol and e <= 1e-5)})
+        return out
+    got = first if first.shape == ref.shape else first.T
     d = float(np.max(np.abs(got - ref)))
-    return {"max_abs_err_vs_numpy": d, "max_rel_err_vs_numpy": d / float(np.max(np.abs(ref)))}
+    tol = 1e-4 if kind in ("mel", "mfcc", "cqt") else 1e-5
+    rel = d / float(np.max(np.abs(ref)))
+    out.update({"max_abs_err_vs_numpy": d, "max_rel_err_vs_numpy": rel, "tolerance": tol, "within_tolerance": bool(rel <= tol)})
+    return out
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# timing
+# ---------------------------------------------------------------------------------------------------------------
+def time_workload(wl, steps, warmup, rdzv):
+    """Contract timing: W untimed steps, then EXACTLY K steps between (device sync + barrier) pairs, MAX over ranks;
+    the HIP-event stopwatch of the plan's stream wraps the same K launches.  A second, separate pass times the K
+    launches one by one (min / median of the kernel duration)."""
+    plan, B, n_in = wl["plan"], wl["n_clips"], wl["n_in"]
+
+    def sync_all():
+        plan.sync()
+        if rdzv is not None:
+            rdzv.barrier()
+
+    for _ in range(warmup):
+        plan.execute(wl["d_in"], wl["d_out"], B, n_in)
+    sync_all()
+    t0 = time.perf_counter()
+    plan.timer_start()
+    for _ in range(steps):
+        plan.execute(wl["d_in"], wl["d_out"], B, n_in)
+    kernel_ms = plan.timer_stop() / max(steps, 1)
+    sync_all()
+    elapsed = time.perf_counter() - t0
+    each = []
+    for _ in range(steps):
+        plan.timer_start()
+        plan.execute(wl["d_in"], wl["d_out"], B, n_in)
+        each.append(plan.timer_stop())
+    vals = [elapsed, kernel_ms, -min(each), float(np.median(each))]
+    if rdzv is not None:
+        vals = rdzv.all_reduce_max(vals)   # (-min: the MAX over ranks of -min is the smallest step anywhere)
+    return {"elapsed_s": vals[0], "kernel_ms": vals[1], "kernel_ms_min": -vals[2], "kernel_ms_median": vals[3]}
+
+
+def roofline_of(wl, tm, kind):
+    kernel_ms = tm["kernel_ms"]
+    gbs = wl["bytes_per_launch"] / (kernel_ms * 1e-3) / 1e9
+    roof = {"bound": "hbm", "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(gbs / HBM_PEAK_GBS, 4),
+            "frac_of_achievable_6290": round(gbs / HBM_ACHIEVABLE_GBS, 4), "traffic": None,
+            "kernel": wl["plan"].kernel_name, "kernel_ms": round(kernel_ms, 4), "kernel_ms_min": round(tm["kernel_ms_min"], 4),
+            "kernel_ms_median": round(tm["kernel_ms_median"], 4), "algorithmic_bytes_per_launch": wl["bytes_per_launch"]}
+    pmc = os.path.join(ROOT, "profiles", f"pmc_{kind}.json")
+    if os.path.exists(pmc):   # a separate rocprofv3 --pmc collection of the same command, committed under profiles/
+        with open(pmc) as f:
+            rec = json.load(f)
+        roof["traffic"] = rec.get("hbm_bytes_per_launch")
+        roof["traffic_source"] = f"profiles/pmc_{kind}.json ({rec.get('collected', 'separate rocprofv3 --pmc passes')}); not measured in this run"
+    if wl["flops_per_launch"]:
+        # SURVEY 8(d): configs 3 and 5 (and the dct GEMM) are bound by f32 arithmetic (vector and f32-MFMA peaks are both
+        # 157.3 TF), not by HBM; both fractions are reported side by side
+        tf = wl["flops_per_launch"] / (kernel_ms * 1e-3) / 1e12
+        roof.update({"bound": "mfma", "achieved": round(tf, 2), "peak": F32_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(tf / F32_PEAK_TFLOPS, 4),
+                     "pipe": "f32 vector (FFT) + f32 MFMA (filterbank)" if kind in ("mel", "mfcc") else "f32 vector" if kind == "cqt" else "f32 MFMA",
+                     "algorithmic_flops_per_launch": wl["flops_per_launch"], "flops": wl["flops_note"],
+                     "hbm": {"achieved": round(gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(gbs / HBM_PEAK_GBS, 4)}})
+    return roof
+
+
+def e2e_pcie(device, clips=128):
+    """PCIe-inclusive figure of the host-buffer boundary (never `value`): pinned host f32 -> HBM -> kernel -> pinned host c64."""
+    import zafx
+    N = 441000
+    plan = zafx.stft_plan(zafx.hamming(W), H, device=device)
+    x = zafx.pinned_empty((clips, N), np.float32)
+    x[:] = np.tile(np.stack([synth(0, c, N) for c in range(8)]), (clips // 8, 1))
+    d_in = zafx.DeviceBuffer((clips, N), np.float32, device)
+    d_out = zafx.DeviceBuffer(plan.out_shape(clips, N), plan.out_dtype, device)
+    host = zafx.pinned_empty(d_out.shape, d_out.dtype)
+    best = None
+    for _ in range(3):
+        t0 = time.perf_counter()
+        d_in.upload(x)
+        t1 = time.perf_counter()
+        plan.execute(d_in, d_out, clips, N)
+        plan.sync()
+        t2 = time.perf_counter()
+        d_out.download(out=host)
+        t3 = time.perf_counter()
+        if best is None or t3 - t0 < best[0]:
+            best = (t3 - t0, t1 - t0, t2 - t1, t3 - t2)
+    d_in.free()
+    d_out.free()
+    return {"value": round(clips * N / best[0] / 1e6, 1), "unit": "Msamples/s",
+            "sample": f"{clips} clips x 10 s, page-locked host buffers both ways (zafx.pinned_empty), best of 3: H2D {x.nbytes / 1e6:.0f} MB "
+                      f"{best[1] * 1e3:.1f} ms ({x.nbytes / best[1] / 1e9:.1f} GB/s), kernel {best[2] * 1e3:.2f} ms, D2H {host.nbytes / 1e6:.0f} MB "
+                      f"{best[3] * 1e3:.1f} ms ({host.nbytes / best[3] / 1e9:.1f} GB/s); serial, one stream"}
+
+
+def run_kind(kind, args, device, rank, world, rdzv, comm, with_cpu):
+    """One config: build the device-resident workload, broadcast its constants, time it, probe parity -> (entry, timing, workload info)."""
+    import zafx
+    wl = make_workload(kind, device, args.layout)
+    bcast = "none (1 rank)"
+    if comm is not None:
+        try:
+            comm.broadcast_constants(wl["plan"], root=0)
+            bcast = "rccl ncclBroadcast of plan constants from rank 0"
+        except zafx.ZafxError as exc:
+            # every rank has already built identical constants from the same deterministic host code, so an error here
+            # costs the demonstration of the collective, not the measurement
+            bcast = f"skipped ({exc}); every rank built its own constants"
+    tm = time_workload(wl, args.steps, args.warmup, rdzv)
+    entry = None
+    if rank == 0:
+        total = float(wl["n_clips"]) * wl["samples_per_clip"] * world * args.steps
+        entry = {"workload": wl["desc"], "value": round(total / tm["elapsed_s"] / 1e6, 1), "unit": "Msamples/s",
+                 "ms_per_step": round(tm["elapsed_s"] / args.steps * 1e3, 4), "roofline": roofline_of(wl, tm, kind),
+                 "parity": parity_probe(wl), "constants_broadcast": bcast}
+        if with_cpu:
+            cb = cpu_baseline(kind, budget_s=10.0 if kind == "stft" else 3.0, min_calls=7 if kind == "stft" else 3)
+            if cb:
+                entry["cpu_baseline"] = cb
+                entry["speedup_vs_cpu_baseline"] = round(entry["value"] / cb["value"], 1)
+    info = {k: wl[k] for k in ("n_clips", "samples_per_clip", "desc")}
+    free_workload(wl)
+    return entry, tm, info
+
+
+def selftest_launch(launch):
+    """The control flow of an N-rank run without a GPU (tests/test_launch.py): same rendezvous calls in the same order as
+    main(), the oracle standing in for the device step on this rank's clip range."""
+    import zafx
+    from oracle import zaf_oracle as orc
+    rank, local_rank, world = launch.rank_env()
+    rdzv = launch.Rendezvous.from_env(timeout=120.0)
+    uid = rdzv.broadcast(bytes(range(128)) if rank == 0 else b"")
+    n_clips, n = 7, 3000
+    lo, hi = zafx.clip_range(n_clips, rank, world)
+    shard = np.stack([synth(4, c, n) for c in range(lo, hi)]).astype(np.float64) if hi > lo else np.zeros((0, n))
+    rdzv.barrier()
+    t0 = time.perf_counter()
+    out = orc.stft_batch(shard, orc.hamming_periodic(256), 64)
+    rdzv.barrier()
+    elapsed = time.perf_counter() - t0
+    vals = rdzv.all_reduce_max([elapsed, float(rank + 1)])
+    sums = rdzv.all_gather(np.asarray([lo, hi, float(np.sum(np.abs(out)))], dtype=np.float64).tobytes())
+    if rank == 0:
+        parts = [np.frombuffer(b, dtype=np.float64).tolist() for b in sums]
+        print(json.dumps({"n_gpus": world, "uid_ok": uid == bytes(range(128)), "max_rank_plus_1": vals[1], "elapsed_s": vals[0],
+                          "device_of_rank": local_rank, "shards": parts}))
+        sys.stdout.flush()
+    rdzv.close()
+    return 0
 
 
 def main():
+    if len(sys.argv) >= 4 and sys.argv[1] == "--cpu-pool":
+        return cpu_pool_main(int(sys.argv[2]), int(sys.argv[3]))
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--kind", default="stft")
+    ap.add_argument("--kind", default="all", help="all = headline STFT + every other BASELINE config in one line; or one of "
+                    "stft istft mdct imdct mel mfcc cqt stft1 istft1 stft64 dct")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-configs", action="store_true", help="with --kind all: headline only")
     ap.add_argument("--layout", default="FT", choices=["FT", "TF"], help="FT = reference (W, T) memory order (default); TF = frame-major")
+    ap.add_argument("--selftest-launch", action="store_true", help="CPU only: run the N-rank control flow (rendezvous, id broadcast, "
+                    "clip sharding with the oracle standing in for the device step, barrier, MAX) and print its JSON line")
     args = ap.parse_args()
+
+    from zafx import launch
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        # plain `python bench.py --gpus N`: start the N ranks (one process per GPU) and relay rank 0's line
+        code, out = launch.spawn_ranks([os.path.abspath(__file__)] + sys.argv[1:], args.gpus)
+        sys.stdout.write(out)
+        sys.stdout.flush()
+        return code
+
+    if args.selftest_launch:
+        return selftest_launch(launch)
 
     # Libraries (RCCL banners, HIP warnings) write to C-level stdout; the contract is ONE JSON line
     # there, so keep the real stdout aside and send everything else to stderr.
@@ -179,104 +476,79 @@ def main():
     real_stdout = os.dup(1)
     os.dup2(2, 1)
 
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    dist = None
+    import zafx
+    rank, local_rank, world = launch.rank_env()
     force_dist = os.environ.get("ZAFX_BENCH_FORCE_DIST") == "1"   # exercise the N>1 plumbing on a 1-GPU box
-    if world > 1 or force_dist:
-        import torch
-        import torch.distributed as dist   # plumbing only: barrier + MAX over ranks
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+    rdzv = launch.Rendezvous.from_env() if (world > 1 or force_dist) else None
     device = local_rank if world > 1 else 0
 
-    wl = make_workload(args.kind, device, args.layout)
-    plan = wl["plan"]
-
-    bcast = "none (1 rank)"
-    if world > 1 or force_dist:
-        # the path's only collective: RCCL broadcast of the shared constants from rank 0 over xGMI
-        # (every rank has already built identical constants from the same deterministic host code, so an error
-        # here costs the demonstration of the collective, not the measurement)
+    comm = None
+    if rdzv is not None:
+        # the path's only collective: RCCL broadcast of the shared constants from rank 0 over xGMI; the 128-byte id
+        # of the communicator travels through the file rendezvous
         try:
-            ids = [zafx.Comm.unique_id() if rank == 0 else None]
-            dist.broadcast_object_list(ids, src=0)
-            comm = zafx.Comm(device, rank, world, ids[0])
-            comm.broadcast_constants(plan, root=0)
-            comm.destroy()
-            bcast = "rccl ncclBroadcast of plan constants from rank 0"
+            uid = rdzv.broadcast(zafx.Comm.unique_id() if rank == 0 else b"")
+            comm = zafx.Comm(device, rank, world, uid)
         except zafx.ZafxError as exc:
-            bcast = f"skipped ({exc}); every rank built its own constants"
+            sys.stderr.write(f"rank {rank}: no RCCL communicator ({exc}); constants stay per-rank\n")
 
-    def sync_all():
-        plan.sync()
-        if dist is not None:
-            import torch
-            torch.cuda.synchronize()
-            dist.barrier()
-
-    B, n_in = wl["n_clips"], wl["n_in"]
-    for _ in range(args.warmup):
-        plan.execute(wl["d_in"], wl["d_out"], B, n_in)
-    sync_all()
-    t0 = time.perf_counter()
-    plan.timer_start()
-    for _ in range(args.steps):
-        plan.execute(wl["d_in"], wl["d_out"], B, n_in)
-    kernel_ms = plan.timer_stop() / max(args.steps, 1)
-    sync_all()
-    elapsed = time.perf_counter() - t0
-
-    if dist is not None:
-        import torch
-        t = torch.tensor([elapsed, kernel_ms], dtype=torch.float64, device="cuda")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed, kernel_ms = float(t[0]), float(t[1])
+    kinds = [args.kind] if args.kind != "all" else ["stft"] + ([] if args.no_configs else list(CONFIG_KINDS))
+    with_cpu = world == 1 and not args.no_cpu_baseline
+    entries = {}
+    head = head_info = None
+    for kind in kinds:
+        entry, tm, info = run_kind(kind, args, device, rank, world, rdzv, comm, with_cpu)
+        if head is None:
+            head, head_info = entry, info
+        else:
+            entries[kind] = entry
+    if comm is not None:
+        comm.destroy()
 
     if rank == 0:
-        total_samples = float(B) * wl["samples_per_clip"] * world * args.steps
-        value = total_samples / elapsed / 1e6
-        achieved = wl["bytes_per_launch"] / (kernel_ms * 1e-3) / 1e9
-        traffic = None
-        pmc = os.path.join(ROOT, "profiles", f"pmc_{args.kind}.json")
-        if os.path.exists(pmc):
-            with open(pmc) as f:
-                traffic = json.load(f).get("hbm_bytes_per_launch")
+        hk = kinds[0]
         out = {
-            "metric": "audio Msamples/sec (STFT win=2048 hop=1024)" if args.kind == "stft" else f"audio Msamples/sec ({args.kind})",
-            "value": round(value, 1), "unit": "Msamples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": round(elapsed / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": "f64" if args.kind == "stft64" else "f32",
+            "metric": "audio Msamples/sec (STFT win=2048 hop=1024)" if hk == "stft" else f"audio Msamples/sec ({hk})",
+            "value": head["value"], "unit": "Msamples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": head["ms_per_step"], "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f64" if hk == "stft64" else "f32",
             "data": "synthetic white Gaussian noise (default_rng([0,c]).standard_normal, f32); 8 distinct clips replicated on device to 1024 per GPU",
-            "config": {"workload": wl["desc"], "clips_per_gpu": B, "samples_per_clip": wl["samples_per_clip"],
-                       "parallelism": f"clip-sharded x{world}", "constants_broadcast": bcast, "layout": "FT (reference memory order)" if args.layout == "FT" else "TF (frame-major)"},
-            "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
-                         "kernel": plan.kernel_name, "kernel_ms": round(kernel_ms, 4),
-                         "algorithmic_bytes_per_launch": wl["bytes_per_launch"]},
+            "config": {"workload": head["workload"], "clips_per_gpu": head_info["n_clips"], "samples_per_clip": head_info["samples_per_clip"],
+                       "parallelism": f"clip-sharded x{world}", "constants_broadcast": head["constants_broadcast"],
+                       "launcher": "file rendezvous (zafx/launch.py), no torch.distributed" if rdzv is not None else "single process",
+                       "layout": "FT (reference memory order)" if args.layout == "FT" else "TF (frame-major)"},
+            "roofline": head["roofline"],
         }
-        if wl["flops_per_launch"]:
-            tf = wl["flops_per_launch"] / (kernel_ms * 1e-3) / 1e12
-            out["roofline"]["algorithmic_tflops"] = round(tf, 2)
-            out["roofline"]["f32_peak_tflops"] = F32_PEAK_TFLOPS
-            # configs 3 and 5 (mel / mfcc, cqt) and the GEMM are priced against the dense f32 peak (157.3 TF,
-            # matrix and vector alike), not against HBM; the byte figures stay in the line as extra fields
-            out["roofline"].update({"bound": "mfma", "achieved": round(tf, 2), "peak": F32_PEAK_TFLOPS, "unit": "TFLOP/s",
-                                    "frac": round(tf / F32_PEAK_TFLOPS, 4), "algorithmic_gbs": round(achieved, 1)})
-        probe = parity_probe(wl, args.kind)
-        if probe:
-            out.update(probe)
-        if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline()
-            out["speedup_vs_cpu_baseline"] = round(value / out["cpu_baseline"]["value"], 1)
+        out.update({k: v for k, v in head["parity"].items() if k.startswith("max_")})
+        out["parity"] = head["parity"]
+        if "cpu_baseline" in head:
+            out["cpu_baseline"] = head["cpu_baseline"]
+            out["speedup_vs_cpu_baseline"] = head["speedup_vs_cpu_baseline"]
+        if entries:
+            if "mdct" in entries and "imdct" in entries:   # BASELINE config 4: the pair, residual < 1e-5
+                pair_ms = entries["mdct"]["ms_per_step"] + entries["imdct"]["ms_per_step"]
+                entries["mdct_imdct_roundtrip"] = {
+                    "ms_per_step": round(pair_ms, 4),
+                    "value": round(head_info["n_clips"] * 441000.0 * world / (pair_ms * 1e-3) / 1e6, 1), "unit": "Msamples/s",
+                    "residual_max_abs": entries["imdct"]["parity"].get("roundtrip_max_abs_residual"), "residual_bound": 1e-5,
+                    "note": "imdct(mdct(x)) on the device, both kernels timed separately on the same 1024-clip batch; residual over clip 0 (zaf.py:1098-1109)"}
+            out["configs"] = entries
+        if with_cpu and hk == "stft":
+            per_clip = 441000 / (out["cpu_baseline"]["value"] * 1e6)
+            out["cpu_baseline_all_cores"] = cpu_baseline_all_cores(per_clip_s=per_clip)
+            if "value" in out["cpu_baseline_all_cores"]:
+                out["speedup_vs_cpu_all_cores"] = round(out["value"] / out["cpu_baseline_all_cores"]["value"], 1)
+            try:
+                out["end_to_end_pcie"] = e2e_pcie(device)
+            except zafx.ZafxError as exc:
+                out["end_to_end_pcie"] = {"error": str(exc)}
         sys.stdout.flush()
         os.write(real_stdout, (json.dumps(out) + "\n").encode())
 
-    if dist is not None:
-        dist.barrier()
-        dist.destroy_process_group()
+    if rdzv is not None:
+        rdzv.close()
+    return 0
 
 
 if __name__ == "__main__":
-    main()
+    sys.exit(main())

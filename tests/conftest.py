@@ -26,7 +26,7 @@ def synth_clip(seed, c, n):
 def golden():
     return {
         name: np.load(os.path.join(GOLDEN, name + ".npz"))
-        for name in ("tiny", "consts", "config", "lengths", "dctdst")
+        for name in ("tiny", "consts", "config", "lengths", "dctdst", "cqtfull")
     }
 
 

@@ -16,6 +16,9 @@ What is written (all .npz, float64/complex128, < 1 MB each):
                 sums and L2 norm per function
   lengths.npz   frame-count / output-length table of SURVEY.md section 4
   dctdst.npz    zaf.dct / zaf.dst, types 1-4, lengths 8, 9, 100, 1024
+  cqtfull.npz   the kernel of cqtkernel's own docstring example (zaf.py:476-483: 55 Hz ... fs/2, 208 bins, 60 879
+                non-zeros, columns on both halves of the spectrum): nnz per row, column range, value probes, and the
+                full cqtspectrogram / cqtchromagram of a 100 000-sample clip with it
 
 The fixtures are DATA (inputs and expected outputs); no reference source text
 is stored.
@@ -175,11 +178,31 @@ def make_dctdst():
     np.savez_compressed(os.path.join(HERE, "dctdst.npz"), **out)
 
 
+def make_cqtfull():
+    out = {}
+    rng = np.random.default_rng(479)
+    ck = zaf.cqtkernel(44100, 24, 55, 44100 / 2)   # zaf.py:476-483
+    d, i, p, s = csr_triplet(ck)
+    out["shape"], out["indptr"] = s, p
+    out["col_min"], out["col_max"] = np.array(i.min()), np.array(i.max())
+    idx = rng.choice(len(d), size=2048, replace=False).astype(np.int64)
+    out["probe_idx"], out["probe_col"], out["probe_val"] = idx, i[idx], d[idx]
+    x = clip(5, 0, 100000).astype(np.float64)
+    out["cqt"] = zaf.cqtspectrogram(x, 44100, 25, ck)
+    out["chroma"] = zaf.cqtchromagram(x, 44100, 25, 24, ck)
+    np.savez_compressed(os.path.join(HERE, "cqtfull.npz"), **out)
+
+
 if __name__ == "__main__":
+    if len(sys.argv) > 1 and sys.argv[1] == "cqtfull":   # (added in round 2; the other files are unchanged)
+        make_cqtfull()
+        print("cqtfull.npz", os.path.getsize(os.path.join(HERE, "cqtfull.npz")))
+        sys.exit(0)
     make_tiny()
     make_consts()
     make_config()
     make_lengths()
     make_dctdst()
-    for f in ("tiny.npz", "consts.npz", "config.npz", "lengths.npz", "dctdst.npz"):
+    make_cqtfull()
+    for f in ("tiny.npz", "consts.npz", "config.npz", "lengths.npz", "dctdst.npz", "cqtfull.npz"):
         print(f, os.path.getsize(os.path.join(HERE, f)))

@@ -214,6 +214,25 @@ def test_config_cqt(zafx, golden):
     assert got.shape == ref.shape and relerr(got, ref) <= TOL_FB
 
 
+def test_cqt_reference_docstring_kernel(zafx, golden):
+    """cqtkernel's own docstring example (zaf.py:476-483): f_max = fs/2 -> 208 bins, 60 879 non-zeros, columns up to 16 613
+    (upper half of the spectrum: conjugates of the one-sided bins).  Reference golden, drop-in signatures."""
+    g = golden["cqtfull"]
+    ck = zafx.cqtkernel(44100, 24, 55, 44100 / 2)
+    assert ck.shape == (208, 32768) and ck.nnz == 60879 and np.array_equal(ck.tocsr().indptr, g["indptr"])
+    x = synth_clip(5, 0, 100000)
+    got = zafx.cqtspectrogram(x, 44100, 25, ck)
+    assert got.shape == g["cqt"].shape == (208, 56) and relerr(got, g["cqt"]) <= TOL_FB
+    ch = zafx.cqtchromagram(x, 44100, 25, 24, ck)
+    assert ch.shape == (24, 56) and relerr(ch, g["chroma"]) <= TOL_FB
+    b = zafx.cqtspectrogram_batch(np.stack([x, synth_clip(5, 1, 100000)]), 44100, 25, ck)
+    assert relerr(b[0], g["cqt"]) <= TOL_FB
+    assert relerr(b[1], orc.cqtspectrogram(synth_clip(5, 1, 100000).astype(np.float64), 44100, 25, ck)) <= TOL_FB
+    # kernels between the benchmark's and this one (ADVICE r1: 168 bins needed more LDS than the float32 kernel had)
+    ck2 = zafx.cqtkernel(44100, 24, 55, 7040)
+    assert relerr(zafx.cqtspectrogram(x, 44100, 25, ck2), orc.cqtspectrogram(x.astype(np.float64), 44100, 25, ck2)) <= TOL_FB
+
+
 # ------------------------------------------------------------------ full BASELINE batch, device resident
 def test_full_batch_device_resident(zafx):
     """1024 clips x 10 s (BASELINE configs 2 and 4): size-independent properties on the whole
@@ -361,6 +380,72 @@ def test_mel_other_window(zafx, wl, hop, fs, nmel, ncoef):
             assert mel[c].shape == ref_mel.shape and mf[c].shape == ref_mf.shape
             assert relerr(mel[c], ref_mel) <= TOL_FB, (layout, c)
             assert relerr(mf[c], ref_mf) <= TOL_FB, (layout, c)
+
+
+def _replicated_on_device(zafx, base, B):
+    """(B, N) float32 device array holding base[c % len(base)] at clip c."""
+    distinct, N = base.shape
+    d_x = zafx.DeviceBuffer((B, N), np.float32)
+    d_base = zafx.DeviceBuffer.from_host(base)
+    for r in range(B // distinct):
+        d_x.copy_from(d_base, dst_offset=r * distinct * N * 4)
+    d_base.free()
+    return d_x
+
+
+def test_full_batch_mel_mfcc_device_resident(zafx):
+    """BASELINE config 3 at the size bench.py runs it: 1024 clips x 10 s = 27 648 tiles, so every persistent k_mel
+    workgroup walks > 100 tiles (the tile-to-tile LDS reuse).  8 distinct clips; first, middle and last replicas
+    against the oracle and bit-equal among themselves."""
+    B, N, W, H, distinct = 1024, 441000, 2048, 1024, 8
+    base = np.stack([synth_clip(0, c, N) for c in range(distinct)])
+    d_x = _replicated_on_device(zafx, base, B)
+    ham, fb = zafx.hamming(W), zafx.melfilterbank(44100, W, 128)
+    for ncoef, rows in ((None, 128), (20, 20)):
+        plan = zafx.mel_plan(ham, H, fb, ncoef)
+        d_out = zafx.DeviceBuffer(plan.out_shape(B, N), np.float32)
+        plan.execute(d_x, d_out, B, N)
+        plan.sync()
+        first, mid, last = (d_out.download(s, distinct) for s in (0, B // 2, B - distinct))
+        assert first.shape == (distinct, rows, 432)
+        assert np.array_equal(first, mid) and np.array_equal(first, last)
+        for c in range(distinct):
+            x64 = base[c].astype(np.float64)
+            ref = orc.melspectrogram(x64, ham, H, fb) if ncoef is None else orc.mfcc(x64, ham, H, fb, ncoef)
+            assert relerr(first[c], ref) <= TOL_FB
+        # the whole batch: every replica group identical (no tile of any workgroup's walk differs)
+        whole = d_out.download().reshape(B // distinct, distinct, rows, 432)
+        assert np.array_equal(whole, np.broadcast_to(first[None], whole.shape))
+        d_out.free()
+    d_x.free()
+
+
+def test_full_share_cqt_device_resident(zafx, golden):
+    """BASELINE config 5, one GPU's share as bench.py runs it: 1024 clips x 30 s (5.4 GB of input: clips from index 812
+    on start beyond 4 GiB).  Clip 0 is the clip of the Q0 golden probes; 8 distinct clips; first, middle and last
+    replicas against the oracle / the probes and bit-equal among themselves."""
+    B, N, distinct = 1024, 1323000, 8
+    base = np.stack([synth_clip(0, c, N) for c in range(distinct)])
+    d_x = _replicated_on_device(zafx, base, B)
+    ck = csr(golden["consts"], "ck")
+    for chroma in (False, True):
+        plan = zafx.cqt_plan(44100, 25, ck, 24 if chroma else None)
+        rows = 24 if chroma else 144
+        d_out = zafx.DeviceBuffer(plan.out_shape(B, N), np.float32)
+        plan.execute(d_x, d_out, B, N)
+        plan.sync()
+        first, mid, last = (d_out.download(s, distinct) for s in (0, B // 2, B - distinct))
+        assert first.shape == (distinct, rows, 750)
+        assert np.array_equal(first, mid) and np.array_equal(first, last)
+        for blk in (first, last):
+            _check_probes(golden["config"], "Q0_chroma" if chroma else "Q0_cqt", blk[0].astype(np.float64), TOL_FB)
+        if not chroma:
+            for c in (1, 7):
+                assert relerr(last[c], orc.cqtspectrogram(base[c].astype(np.float64), 44100, 25, ck)) <= TOL_FB
+        whole = d_out.download().reshape(B // distinct, distinct, rows, 750)
+        assert np.array_equal(whole, np.broadcast_to(first[None], whole.shape))
+        d_out.free()
+    d_x.free()
 
 
 def test_batch_larger_than_grid(zafx):

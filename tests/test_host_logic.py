@@ -42,6 +42,17 @@ def test_cqtkernel_config_matches_reference(golden):
     assert np.array_equal(got.indices, ref.indices) and relerr(got.data, ref.data) <= 1e-12
 
 
+@pytest.mark.timeout(180)
+def test_cqtkernel_docstring_example_matches_reference(golden):
+    """zaf.py:476-483 (55 Hz ... fs/2) through the product's host builder; and the plan routing for it."""
+    g = golden["cqtfull"]
+    got = zafx.cqtkernel(44100, 24, 55, 44100 / 2).tocsr()
+    got.sort_indices()
+    assert got.shape == (208, 32768) and np.array_equal(got.indptr, g["indptr"])
+    assert np.array_equal(got.indices[g["probe_idx"]], g["probe_col"])
+    assert relerr(got.data[g["probe_idx"]], g["probe_val"]) <= 1e-12
+
+
 def test_dct_rows_match_scipy():
     y = np.random.default_rng(0).standard_normal((128, 7))
     ref = scipy.fftpack.dct(y, axis=0, norm="ortho")[1:21]

@@ -1,0 +1,99 @@
+"""N > 1 path on CPU, without torch.distributed: bench.py's own launcher and file rendezvous (zafx/launch.py).
+
+`bench.py --gpus 2 --selftest-launch` runs the rank control flow of the real bench (rendezvous from the environment,
+broadcast of the 128-byte communicator id, clip-range sharding, barrier, MAX over ranks) with the CPU oracle standing
+in for the device step; the shards' checksums must add up to the unsharded result.  Both ways in are driven: the
+self-launcher (`python bench.py --gpus 2`, WORLD_SIZE unset) and the driver's `python -m torch.distributed.run ...`.
+"""
+import json
+import os
+import subprocess
+import sys
+import threading
+
+import numpy as np
+import pytest
+
+from conftest import ROOT, synth_clip
+
+
+def _expected():
+    from oracle import zaf_oracle as orc
+    import zafx
+    full = np.stack([synth_clip(4, c, 3000) for c in range(7)]).astype(np.float64)
+    ref = orc.stft_batch(full, orc.hamming_periodic(256), 64)
+    return [(lo, hi, float(np.sum(np.abs(ref[lo:hi])))) for lo, hi in (zafx.clip_range(7, r, 2) for r in range(2))]
+
+
+def _check(line):
+    rec = json.loads(line)
+    assert rec["n_gpus"] == 2 and rec["uid_ok"] and rec["max_rank_plus_1"] == 2.0
+    for got, want in zip(rec["shards"], _expected()):
+        assert (int(got[0]), int(got[1])) == want[:2]
+        assert got[2] == want[2]   # the same NumPy calls on the same clips: bit-identical checksums
+
+
+def _clean_env():
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "ZAFX_RDZV_DIR")}
+    return env
+
+
+@pytest.mark.timeout(120)
+def test_self_launcher_two_ranks():
+    res = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--selftest-launch"], env=_clean_env(),
+                         capture_output=True, timeout=100)
+    assert res.returncode == 0, res.stderr.decode()[-2000:]
+    _check(res.stdout.decode().strip().splitlines()[-1])
+
+
+@pytest.mark.timeout(180)
+def test_torchrun_two_ranks():
+    port = 29600 + os.getpid() % 2000
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--selftest-launch"]
+    res = subprocess.run(cmd, env=_clean_env(), capture_output=True, timeout=170)
+    assert res.returncode == 0, res.stderr.decode()[-2000:]
+    lines = [ln for ln in res.stdout.decode().splitlines() if ln.startswith("{")]
+    assert len(lines) == 1   # rank 0 prints ONE JSON line
+    _check(lines[0])
+
+
+def test_rendezvous_collectives(tmp_path):
+    from zafx.launch import Rendezvous
+    world, results, errors = 3, {}, []
+
+    def rank_main(r):
+        try:
+            rv = Rendezvous(str(tmp_path / "rv"), r, world, timeout=30.0)
+            uid = rv.broadcast(b"\x01" * 128 if r == 0 else b"")
+            rv.barrier()
+            mx = rv.all_reduce_max([float(r), 10.0 - r])
+            parts = rv.all_gather(bytes([r]))
+            rv.close()
+            results[r] = (uid, mx, parts)
+        except Exception as exc:   # pragma: no cover
+            errors.append(exc)
+
+    threads = [threading.Thread(target=rank_main, args=(r,)) for r in range(world)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    assert not errors
+    for r in range(world):
+        uid, mx, parts = results[r]
+        assert uid == b"\x01" * 128 and mx == [2.0, 10.0] and parts == [b"\x00", b"\x01", b"\x02"]
+    assert not os.path.exists(tmp_path / "rv")   # rank 0 removed the directory after the last rank said goodbye
+
+
+def test_rendezvous_rejects_bad_rank(tmp_path):
+    from zafx.launch import Rendezvous
+    with pytest.raises(ValueError):
+        Rendezvous(str(tmp_path), 2, 2)
+
+
+def test_bench_does_not_import_torch():
+    src = open(os.path.join(ROOT, "bench.py")).read()
+    assert "import torch" not in src
+    for name in ("launch.py", "core.py", "shard.py", "_lib.py", "__init__.py", "constants.py"):
+        assert "import torch" not in open(os.path.join(ROOT, "zaf-python_amd", "zafx", name)).read()

@@ -54,6 +54,22 @@ def test_cqtkernel_config(golden):
     close(got.data, ref.data)
 
 
+@pytest.mark.timeout(180)
+def test_cqtkernel_docstring_example(golden):
+    """The kernel of zaf.py:476-483 (55 Hz ... fs/2): columns on both halves of the spectrum, 60 879 non-zeros."""
+    g = golden["cqtfull"]
+    got = orc.cqtkernel(44100, 24, 55, 44100 / 2).tocsr()
+    got.sort_indices()
+    assert got.shape == tuple(g["shape"]) == (208, 32768)
+    assert np.array_equal(got.indptr, g["indptr"]) and got.nnz == 60879
+    assert got.indices.min() == g["col_min"] == 39 and got.indices.max() == g["col_max"] == 16613
+    assert np.array_equal(got.indices[g["probe_idx"]], g["probe_col"])
+    close(got.data[g["probe_idx"]], g["probe_val"])
+    x = synth_clip(5, 0, 100000).astype(np.float64)
+    close(orc.cqtspectrogram(x, 44100, 25, got), g["cqt"])
+    close(orc.cqtchromagram(x, 44100, 25, 24, got), g["chroma"])
+
+
 @pytest.mark.parametrize("n", [1, 63, 64, 65, 1000])
 @pytest.mark.parametrize("hop", [32, 16])
 def test_tiny_stft_family(golden, n, hop):

@@ -9,7 +9,8 @@ Drop-in functions (zaf.py signatures, float64 / complex128 results):
 Batched extension ((clips, samples) in, float32 / complex64 out):
     stft_batch, istft_batch, mdct_batch, imdct_batch, melspectrogram_batch, mfcc_batch,
     cqtspectrogram_batch, cqtchromagram_batch
-Device-resident API: Plan, DeviceBuffer, Comm, *_plan factories, shard helpers.
+Device-resident API: Plan, DeviceBuffer, Comm, *_plan factories, shard helpers; one process per GPU: launch.Rendezvous,
+spawn_ranks (file rendezvous + self-launcher, no torch.distributed).
 """
 from ._lib import (CHROMA, CQT, IMDCT, ISTFT, LAYOUT_FT, LAYOUT_TF, LINEAR, MDCT, MEL, MFCC, STFT, ZafxError, device_count,
                    device_name, library_path)
@@ -19,6 +20,7 @@ from .core import (Comm, DeviceBuffer, Plan, clear_plan_cache, cqt_plan, cqtchro
                    cqtspectrogram, cqtspectrogram_batch, imdct, imdct_batch, istft, istft_batch, istft_plan, mdct,
                    mdct_batch, mdct_plan, mel_plan, melspectrogram, melspectrogram_batch, mfcc, mfcc_batch, pcm_to_mono, pinned_empty,
                    get_precision, set_precision, stft, stft_batch, stft_pcm_batch, stft_plan)
+from .launch import Rendezvous, rank_env, spawn_ranks
 from .shard import clip_range, run_sharded, shard_sizes
 
 __version__ = "0.1.0"

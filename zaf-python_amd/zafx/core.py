@@ -575,6 +575,23 @@ def mel_plan(window_function, step_length, mel_filterbank, number_coefficients=N
     return _cached(key, make)
 
 
+_LDS_BYTES = 160 * 1024
+
+
+def _cqt_f32_lds_bytes(fft_length, nnz_per_row):
+    """LDS the float32 k_cqt needs for a kernel with these row lengths (mirrors CqtCfg / run_cqt in zafx_cqt.hip)."""
+    n = fft_length // 2
+    log2n = n.bit_length() - 1
+    split = log2n == 14
+    slots = 16 * 1090 if split else n + n // 16 + 1
+    nhi = n >> 7 if log2n > 7 else 1
+    nh2 = n >> 8 if log2n > 8 else 1
+    head = -(-(slots + nhi + 128 + nh2 + 128 + (136 if split else 0)) * 8 // 16) * 16
+    chunks = int(np.sum(np.maximum(1, -(-np.asarray(nnz_per_row) // 64))))
+    waves = max(1, (n >> (4 if log2n >= 10 else (log2n - 6 if log2n >= 7 else 1))) // 64)
+    return head + chunks * 16 + len(nnz_per_row) * 96 + (waves + 1) * 4
+
+
 def cqt_plan(sampling_frequency, time_resolution, cqt_kernel, octave_resolution=None, layout="FT", device=0, row_align=0, f64=False):
     if not hasattr(cqt_kernel, "tocsr"):
         raise ValueError("cqt_kernel must be a scipy.sparse matrix (as returned by cqtkernel)")
@@ -585,9 +602,10 @@ def cqt_plan(sampling_frequency, time_resolution, cqt_kernel, octave_resolution=
     if fft_length < 512 or fft_length > 131072 or fft_length & (fft_length - 1):
         raise ValueError(f"zafx CQT kernels need a power-of-two fft_length in [512, 131072], got {fft_length}")
     # a frame above 32768 samples does not fit LDS as float32 pairs: those kernels run on the float64 kernel, which
-    # decimates the frame (lower minimum frequencies: 27.5 Hz at 44.1 kHz gives 65536)
-    f64 = bool(f64) or fft_length > 32768
+    # decimates the frame (lower minimum frequencies: 27.5 Hz at 44.1 kHz gives 65536); so do kernels whose rows do not
+    # fit beside the frame (k_cqt keeps the whole frame + the kernel's row bookkeeping in the 160 KB of LDS)
     csr = cqt_kernel.tocsr()
+    f64 = bool(f64) or fft_length > 32768 or _cqt_f32_lds_bytes(fft_length, np.diff(csr.indptr)) > _LDS_BYTES
     chroma = octave_resolution is not None
     key = ("chroma" if chroma else "cqt", device, fft_length, step, n_bins, int(octave_resolution or 0), _LAYOUTS[layout],
            _as_row_align(row_align, layout), bool(f64),

@@ -1,0 +1,156 @@
+"""One process per GPU without a framework: rank discovery, a file rendezvous and a self-launcher.
+
+The hot path shards by clips and has no data-path collective, so the only things the ranks of
+one node must exchange are small host values: the 128-byte RCCL unique id (rank 0 -> everyone, so that
+`Comm` can broadcast the plan constants over xGMI), a barrier either side of the timed region and the
+MAX over ranks of the elapsed time.  That is what this module provides, with files in a directory every
+rank of the node can see -- no torch.distributed, no MPI, no sockets to collide with the launcher's own.
+
+Two ways in:
+  * launched by `python -m torch.distributed.run ...` (or any launcher that sets RANK / LOCAL_RANK /
+    WORLD_SIZE / MASTER_ADDR / MASTER_PORT): `Rendezvous.from_env()` derives the directory from
+    MASTER_PORT and the launcher's pid (all ranks of one node share the parent process);
+  * plain `python script.py --gpus N` with WORLD_SIZE unset: `spawn_ranks()` starts the N ranks itself
+    (environment as above plus ZAFX_RDZV_DIR) and relays rank 0's stdout.
+"""
+import os
+import struct
+import subprocess
+import sys
+import tempfile
+import time
+
+__all__ = ["Rendezvous", "rank_env", "spawn_ranks"]
+
+
+def rank_env():
+    """(rank, local_rank, world_size) from the launcher's environment; (0, 0, 1) when there is none."""
+    return (int(os.environ.get("RANK", "0")), int(os.environ.get("LOCAL_RANK", os.environ.get("RANK", "0"))),
+            int(os.environ.get("WORLD_SIZE", "1")))
+
+
+class Rendezvous:
+    """Key/value exchange, barrier and MAX-reduce between the ranks of one node through a shared directory.
+
+    Every operation is named by the caller or numbered in call order; all ranks must make the same
+    sequence of collective calls (as with any collective library).  Values are published by an atomic
+    rename, so a reader never sees a partial file."""
+
+    def __init__(self, directory, rank, world_size, timeout=600.0):
+        if world_size < 1 or not 0 <= rank < world_size:
+            raise ValueError("bad rank / world_size")
+        self.dir, self.rank, self.world, self.timeout = directory, int(rank), int(world_size), float(timeout)
+        self._seq = 0
+        os.makedirs(self.dir, exist_ok=True)
+
+    @classmethod
+    def from_env(cls, timeout=600.0):
+        rank, _, world = rank_env()
+        d = os.environ.get("ZAFX_RDZV_DIR")
+        if not d:
+            # all ranks of a node are children of one launcher process: its pid + the rendezvous port name the job
+            key = f"{os.environ.get('MASTER_PORT', '0')}_{os.environ.get('TORCHELASTIC_RUN_ID', 'none')}_{os.getppid()}"
+            base = "/dev/shm" if os.path.isdir("/dev/shm") and os.access("/dev/shm", os.W_OK) else tempfile.gettempdir()
+            d = os.path.join(base, f"zafx_rdzv_{os.getuid()}_{key}")
+        return cls(d, rank, world, timeout)
+
+    # ---- point to point -------------------------------------------------------------
+    def put(self, key, data):
+        tmp = os.path.join(self.dir, f".{key}.{self.rank}.tmp")
+        with open(tmp, "wb") as f:
+            f.write(bytes(data))
+        os.replace(tmp, os.path.join(self.dir, key))
+
+    def get(self, key):
+        path = os.path.join(self.dir, key)
+        deadline = time.monotonic() + self.timeout
+        delay = 0.0005
+        while True:
+            try:
+                with open(path, "rb") as f:
+                    return f.read()
+            except FileNotFoundError:
+                if time.monotonic() > deadline:
+                    raise TimeoutError(f"rendezvous: rank {self.rank} waited {self.timeout:.0f} s for '{key}' in {self.dir}") from None
+                time.sleep(delay)
+                delay = min(delay * 2, 0.02)
+
+    # ---- collectives ----------------------------------------------------------------
+    def _next(self, what):
+        self._seq += 1
+        return f"{self._seq:06d}_{what}"
+
+    def broadcast(self, data, root=0):
+        """`data` (bytes) of rank `root` returned on every rank."""
+        key = self._next("bcast")
+        if self.rank == root:
+            self.put(key, data)
+            return bytes(data)
+        return self.get(key)
+
+    def all_gather(self, data):
+        key = self._next("gather")
+        self.put(f"{key}_{self.rank}", data)
+        return [self.get(f"{key}_{r}") for r in range(self.world)]
+
+    def barrier(self):
+        self.all_gather(b"")
+
+    def all_reduce_max(self, values):
+        """Element-wise MAX of a sequence of floats over the ranks (the timing reduction of bench.py)."""
+        values = [float(v) for v in values]
+        parts = self.all_gather(struct.pack(f"<{len(values)}d", *values))
+        rows = [struct.unpack(f"<{len(values)}d", p) for p in parts]
+        return [max(col) for col in zip(*rows)] if values else []
+
+    def close(self):
+        """Last call of every rank: rank 0 removes the directory once every other rank has said it will not read again."""
+        self.barrier()
+        if self.rank != 0:
+            self.put(f"bye_{self.rank}", b"")
+            return
+        for r in range(1, self.world):
+            self.get(f"bye_{r}")
+        for name in os.listdir(self.dir):
+            try:
+                os.unlink(os.path.join(self.dir, name))
+            except OSError:
+                pass
+        try:
+            os.rmdir(self.dir)
+        except OSError:
+            pass
+
+
+def spawn_ranks(argv, n_ranks, env=None, timeout=None):
+    """Start `n_ranks` copies of `python argv...`, rank r bound to GPU r (RANK = LOCAL_RANK = r), wait for them and
+    return (exit code, rank 0's stdout).  The children find each other through ZAFX_RDZV_DIR."""
+    if n_ranks < 1:
+        raise ValueError("n_ranks must be >= 1")
+    rdzv = tempfile.mkdtemp(prefix="zafx_rdzv_", dir="/dev/shm" if os.path.isdir("/dev/shm") and os.access("/dev/shm", os.W_OK) else None)
+    procs = []
+    try:
+        for r in range(n_ranks):
+            e = dict(os.environ if env is None else env)
+            e.update(RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n_ranks), LOCAL_WORLD_SIZE=str(n_ranks), ZAFX_RDZV_DIR=rdzv,
+                     MASTER_ADDR=e.get("MASTER_ADDR", "127.0.0.1"), MASTER_PORT=e.get("MASTER_PORT", "29400"))
+            e.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # RCCL between processes needs dmabuf IPC on this driver
+            procs.append(subprocess.Popen([sys.executable] + list(argv), env=e, stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL))
+        out, _ = procs[0].communicate(timeout=timeout)
+        code = procs[0].returncode
+        for p in procs[1:]:
+            code = code or p.wait(timeout=timeout)
+        return code, out.decode()
+    finally:
+        for p in procs:
+            if p.poll() is None:
+                p.kill()
+        for name in os.listdir(rdzv) if os.path.isdir(rdzv) else []:
+            try:
+                os.unlink(os.path.join(rdzv, name))
+            except OSError:
+                pass
+        try:
+            os.rmdir(rdzv)
+        except OSError:
+            pass

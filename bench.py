@@ -213,41 +213,53 @@ def cpu_baseline(kind="stft", budget_s=10.0, min_calls=5):
 
 
 def _pool_worker(args):
-    seed, count = args
+    seed, seconds = args
     from oracle import zaf_oracle as orc
     ham = orc.hamming_periodic(W)
     x = synth(0, seed % 8, 441000).astype(np.float64)
     orc.stft(x, ham, H)   # warm-up
-    t0 = time.perf_counter()
-    for _ in range(count):
+    count, t_end = 0, time.perf_counter() + seconds
+    while time.perf_counter() < t_end:
         orc.stft(x, ham, H)
-    return time.perf_counter() - t0
+        count += 1
+    return count
 
 
-def cpu_pool_main(n_workers, clips_per_worker):
-    """All-cores figure (SURVEY 8(d) CPU baseline plan): a process pool over the host's cores, BLAS pinned to 1 thread."""
+def usable_cores():
+    """Cores this process may run on (affinity mask, capped by a cgroup CPU quota when there is one)."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            n = max(1, min(n, int(float(quota) / float(period))))
+    except (OSError, ValueError):
+        pass
+    return n
+
+
+def cpu_pool_main(n_workers, seconds):
+    """All-cores figure (SURVEY 8(d) CPU baseline plan): a process pool over the host's cores, BLAS pinned to 1 thread;
+    every worker transforms 10 s clips for `seconds` seconds."""
     import multiprocessing as mp
     from oracle import zaf_oracle as orc   # imported before the fork so that the workers share its pages
     orc.stft(synth(0, 0, 4096).astype(np.float64), orc.hamming_periodic(W), H)
     with mp.get_context("fork").Pool(n_workers) as pool:
-        pool.map(_pool_worker, [(i, 1) for i in range(n_workers)])   # start + warm every worker
+        pool.map(_pool_worker, [(i, 0.0) for i in range(n_workers)], chunksize=1)   # start + warm every worker
         t0 = time.perf_counter()
-        busy = pool.map(_pool_worker, [(i, clips_per_worker) for i in range(n_workers)])
+        counts = pool.map(_pool_worker, [(i, seconds) for i in range(n_workers)], chunksize=1)
         wall = time.perf_counter() - t0
-    total = n_workers * clips_per_worker
+    total = int(sum(counts))
     print(json.dumps({"value": round(total * 441000 / wall / 1e6, 1), "unit": "Msamples/s", "cores": n_workers, "kind": "port",
-                      "sample": f"{total} calls of the NumPy oracle stft on 10 s clips over a pool of {n_workers} processes "
-                                f"({clips_per_worker} timed per worker, wall {wall:.2f} s, mean busy {np.mean(busy):.2f} s), "
-                                f"OMP/OPENBLAS threads = 1 per worker"}))
+                      "sample": f"{total} calls of the NumPy oracle stft on 10 s clips by a pool of {n_workers} processes, each looping for "
+                                f"{seconds:.0f} s (wall {wall:.2f} s, {min(counts)}-{max(counts)} clips per worker), OMP/OPENBLAS threads = 1 per "
+                                f"worker; os.cpu_count() = {os.cpu_count()}"}))
 
 
-def cpu_baseline_all_cores(budget_s=10.0, per_clip_s=0.01):
+def cpu_baseline_all_cores(seconds=6.0):
     """Runs cpu_pool_main in a fresh interpreter (a fork pool must not inherit a HIP context)."""
-    n = os.cpu_count() or 1
-    per_worker = int(max(4, min(64, budget_s / max(per_clip_s * 3.0, 1e-3))))   # (loaded cores run ~2-3x slower than one alone)
     env = dict(os.environ, OMP_NUM_THREADS="1", OPENBLAS_NUM_THREADS="1", MKL_NUM_THREADS="1")
     try:
-        res = subprocess.run([sys.executable, os.path.abspath(__file__), "--cpu-pool", str(n), str(per_worker)], env=env,
+        res = subprocess.run([sys.executable, os.path.abspath(__file__), "--cpu-pool", str(usable_cores()), str(seconds)], env=env,
                              capture_output=True, timeout=120, check=True)
         return json.loads(res.stdout.decode().strip().splitlines()[-1])
     except Exception as exc:   # the pool is a reported extra: never fail the bench line for it
@@ -445,7 +457,7 @@ def selftest_launch(launch):
 
 def main():
     if len(sys.argv) >= 4 and sys.argv[1] == "--cpu-pool":
-        return cpu_pool_main(int(sys.argv[2]), int(sys.argv[3]))
+        return cpu_pool_main(int(sys.argv[2]), float(sys.argv[3]))
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
@@ -534,8 +546,7 @@ def main():
                     "note": "imdct(mdct(x)) on the device, both kernels timed separately on the same 1024-clip batch; residual over clip 0 (zaf.py:1098-1109)"}
             out["configs"] = entries
         if with_cpu and hk == "stft":
-            per_clip = 441000 / (out["cpu_baseline"]["value"] * 1e6)
-            out["cpu_baseline_all_cores"] = cpu_baseline_all_cores(per_clip_s=per_clip)
+            out["cpu_baseline_all_cores"] = cpu_baseline_all_cores()
             if "value" in out["cpu_baseline_all_cores"]:
                 out["speedup_vs_cpu_all_cores"] = round(out["value"] / out["cpu_baseline_all_cores"]["value"], 1)
             try:

@@ -34,16 +34,70 @@ static inline float2 make_float2(float x, float y) { float2 r; r.x = x; r.y = y;
 namespace zafx {
 
 // ---------------------------------------------------------------- complex helpers
+// On the device the complex products are written as the two packed-f32 instructions they need
+// (v_pk_mul_f32 + v_pk_fma_f32 with op_sel / neg modifiers): from the scalar formula the compiler emits four to
+// five packed instructions and a repacking v_mov per product (profiles/r02_notes.md).
+#if defined(__HIP_DEVICE_COMPILE__)
+typedef float zafx_v2f __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ zafx_v2f to_v2(float2 a) { return __builtin_bit_cast(zafx_v2f, a); }
+__device__ __forceinline__ float2 to_f2(zafx_v2f a) { return __builtin_bit_cast(float2, a); }
+#define ZAFX_PK 1
+#endif
 ZAFX_HD float2 cadd(float2 a, float2 b) { return make_float2(a.x + b.x, a.y + b.y); }
 ZAFX_HD float2 csub(float2 a, float2 b) { return make_float2(a.x - b.x, a.y - b.y); }
 ZAFX_HD float2 cmul(float2 a, float2 b) {
+#if defined(ZAFX_PK)
+    zafx_v2f r;   // (a.x b.x, a.x b.y), then + (-a.y b.y, a.y b.x)
+    asm("v_pk_mul_f32 %0, %1, %2 op_sel_hi:[0,1]\n\tv_pk_fma_f32 %0, %1, %2, %0 op_sel:[1,1,0] op_sel_hi:[1,0,1] neg_lo:[0,1,0]"
+        : "=&v"(r) : "v"(to_v2(a)), "v"(to_v2(b)));
+    return to_f2(r);
+#else
     return make_float2(a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x);
+#endif
 }
 ZAFX_HD float2 cmulc(float2 a, float2 b) {   // a * conj(b)
+#if defined(ZAFX_PK)
+    zafx_v2f r;   // (a.x b.x, -a.x b.y), then + (a.y b.y, a.y b.x)
+    asm("v_pk_mul_f32 %0, %1, %2 op_sel_hi:[0,1] neg_hi:[0,1]\n\tv_pk_fma_f32 %0, %1, %2, %0 op_sel:[1,1,0] op_sel_hi:[1,0,1]"
+        : "=&v"(r) : "v"(to_v2(a)), "v"(to_v2(b)));
+    return to_f2(r);
+#else
     return make_float2(a.x * b.x + a.y * b.y, a.y * b.x - a.x * b.y);
+#endif
+}
+// a * k for a compile-time constant k: the constant rides in a scalar register pair
+ZAFX_HD float2 cmulk(float2 a, float kx, float ky) {
+#if defined(ZAFX_PK)
+    zafx_v2f r, k;
+    k.x = kx;
+    k.y = ky;
+    asm("v_pk_mul_f32 %0, %1, %2 op_sel_hi:[0,1]\n\tv_pk_fma_f32 %0, %1, %2, %0 op_sel:[1,1,0] op_sel_hi:[1,0,1] neg_lo:[0,1,0]"
+        : "=&v"(r) : "v"(to_v2(a)), "s"(k));
+    return to_f2(r);
+#else
+    return make_float2(a.x * kx - a.y * ky, a.x * ky + a.y * kx);
+#endif
 }
 ZAFX_HD float2 cconj(float2 a) { return make_float2(a.x, -a.y); }
 ZAFX_HD float2 mul_mi(float2 a) { return make_float2(a.y, -a.x); }   // a * (-i)
+ZAFX_HD float2 add_mi(float2 a, float2 b) {   // a + (-i) b = (a.x + b.y, a.y - b.x)
+#if defined(ZAFX_PK)
+    zafx_v2f r;
+    asm("v_pk_add_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,0] neg_hi:[0,1]" : "=v"(r) : "v"(to_v2(a)), "v"(to_v2(b)));
+    return to_f2(r);
+#else
+    return make_float2(a.x + b.y, a.y - b.x);
+#endif
+}
+ZAFX_HD float2 sub_mi(float2 a, float2 b) {   // a - (-i) b = (a.x - b.y, a.y + b.x)
+#if defined(ZAFX_PK)
+    zafx_v2f r;
+    asm("v_pk_add_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,0] neg_lo:[0,1]" : "=v"(r) : "v"(to_v2(a)), "v"(to_v2(b)));
+    return to_f2(r);
+#else
+    return make_float2(a.x - b.y, a.y + b.x);
+#endif
+}
 ZAFX_HD float2 cscale(float2 a, float s) { return make_float2(a.x * s, a.y * s); }
 
 // ---------------------------------------------------------------- pass schedule
@@ -106,11 +160,11 @@ ZAFX_HD void dft2(float2& a, float2& b) {
 }
 ZAFX_HD void dft4(float2& v0, float2& v1, float2& v2, float2& v3) {
     float2 t0 = cadd(v0, v2), t1 = csub(v0, v2);
-    float2 t2 = cadd(v1, v3), t3 = mul_mi(csub(v1, v3));
+    float2 t2 = cadd(v1, v3), t3 = csub(v1, v3);
     v0 = cadd(t0, t2);
-    v1 = cadd(t1, t3);
+    v1 = add_mi(t1, t3);
     v2 = csub(t0, t2);
-    v3 = csub(t1, t3);
+    v3 = sub_mi(t1, t3);
 }
 
 template <int R>
@@ -135,12 +189,11 @@ struct Dft<8> {
         float2 o0 = a[1], o1 = a[3], o2 = a[5], o3 = a[7];
         dft4(e0, e1, e2, e3);
         dft4(o0, o1, o2, o3);
-        o1 = make_float2((o1.x + o1.y) * h, (o1.y - o1.x) * h);    // * w8^1
-        o2 = mul_mi(o2);                                           // * w8^2
-        o3 = make_float2((o3.y - o3.x) * h, -(o3.x + o3.y) * h);   // * w8^3
+        o1 = cmulk(o1, h, -h);     // * w8^1
+        o3 = cmulk(o3, -h, -h);    // * w8^3
         a[0] = cadd(e0, o0); a[4] = csub(e0, o0);
         a[1] = cadd(e1, o1); a[5] = csub(e1, o1);
-        a[2] = cadd(e2, o2); a[6] = csub(e2, o2);
+        a[2] = add_mi(e2, o2); a[6] = sub_mi(e2, o2);   // * w8^2 = -i folded into the butterfly
         a[3] = cadd(e3, o3); a[7] = csub(e3, o3);
     }
 };
@@ -156,15 +209,15 @@ struct Dft<16> {
             dft4(m[r][0], m[r][1], m[r][2], m[r][3]);
         }
         // twiddle m[r][q] *= w16^(r q)
-        m[1][1] = cmul(m[1][1], make_float2(c1, -s1));                                        // w^1
-        m[1][2] = make_float2((m[1][2].x + m[1][2].y) * h, (m[1][2].y - m[1][2].x) * h);      // w^2
-        m[1][3] = cmul(m[1][3], make_float2(s1, -c1));                                        // w^3
-        m[2][1] = make_float2((m[2][1].x + m[2][1].y) * h, (m[2][1].y - m[2][1].x) * h);      // w^2
-        m[2][2] = mul_mi(m[2][2]);                                                            // w^4
-        m[2][3] = make_float2((m[2][3].y - m[2][3].x) * h, -(m[2][3].x + m[2][3].y) * h);     // w^6
-        m[3][1] = cmul(m[3][1], make_float2(s1, -c1));                                        // w^3
-        m[3][2] = make_float2((m[3][2].y - m[3][2].x) * h, -(m[3][2].x + m[3][2].y) * h);     // w^6
-        m[3][3] = cmul(m[3][3], make_float2(-c1, s1));                                        // w^9
+        m[1][1] = cmulk(m[1][1], c1, -s1);    // w^1
+        m[1][2] = cmulk(m[1][2], h, -h);      // w^2
+        m[1][3] = cmulk(m[1][3], s1, -c1);    // w^3
+        m[2][1] = cmulk(m[2][1], h, -h);      // w^2
+        m[2][2] = mul_mi(m[2][2]);            // w^4
+        m[2][3] = cmulk(m[2][3], -h, -h);     // w^6
+        m[3][1] = cmulk(m[3][1], s1, -c1);    // w^3
+        m[3][2] = cmulk(m[3][2], -h, -h);     // w^6
+        m[3][3] = cmulk(m[3][3], -c1, s1);    // w^9
 #pragma unroll
         for (int q = 0; q < 4; ++q) {   // 4-point DFTs over r; output k = q + 4 s
             dft4(m[0][q], m[1][q], m[2][q], m[3][q]);
@@ -196,7 +249,7 @@ struct Dft<32> {
                               0.55557023301960222474f, 0.38268343236508977173f, 0.19509032201612826785f};
 #pragma unroll
         for (int k = 0; k < 16; ++k) {
-            const float2 t = k == 0 ? o[0] : (k == 8 ? mul_mi(o[8]) : cmul(o[k], make_float2(c[k], -sn[k])));
+            const float2 t = k == 0 ? o[0] : (k == 8 ? mul_mi(o[8]) : cmulk(o[k], c[k], -sn[k]));
             a[k] = cadd(e[k], t);
             a[k + 16] = csub(e[k], t);
         }

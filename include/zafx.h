@@ -159,6 +159,11 @@ int zafx_timer_stop(zafx_plan* plan, float* elapsed_ms);
 /* Name of the dominant kernel the plan launches (for matching rocprofv3 rows). */
 int zafx_plan_kernel_name(const zafx_plan* plan, char* buf, size_t buflen);
 
+/* Largest number of rows (n_bins) of a CQT kernel matrix that a float32 ZAFX_CQT / ZAFX_CHROMA plan of this fft_length
+ * holds (k_cqt keeps the frame and the rows' bookkeeping in the 160 KB of LDS); 0 when fft_length itself is outside the
+ * float32 kernels.  Larger kernels (and fft_length up to 131072) run as ZAFX_PRECISION_F64 plans. */
+int zafx_cqt_max_bins(int fft_length, int* n_bins);
+
 /* ---- PCM ingest: the step in front of the path ------------------------------ */
 /* wavread's normalisation (zaf.py:1202: x / 2^(8*itemsize - 1)) and the channel mean every example
  * applies before the transforms (zaf.py:65: np.mean(audio_signal, 1)), on device:

@@ -152,8 +152,7 @@ static void free_band(PackedBand& pb) {
     pb = PackedBand{};
 }
 
-// Cut the CSR rows of the CQT kernel into chunks of <= 64 entries and deal whole rows to the
-// wavefronts of k_cqt, most expensive first, always to the least loaded wave.
+// k_cqt's view of the CQT kernel matrix: rows sorted by length, four per step, steps dealt to the wavefronts.
 static int build_cqt_chunks(zafx_plan* pl);
 
 static bool is_stft_family(int kind) { return kind == ZAFX_STFT || kind == ZAFX_ISTFT || kind == ZAFX_MEL || kind == ZAFX_MFCC; }
@@ -250,63 +249,107 @@ static int finalize_constant(zafx_plan* pl, int which) {
 }
 
 static int build_cqt_chunks(zafx_plan* pl) {
+    // k_cqt's view of the CSR matrix (zafx_cqt.hip): rows sorted by length, four rows per step (one per 16-lane DPP
+    // row; lane j of a row takes its entries j, j + 16, ...), steps dealt to the wavefronts, longest first, always
+    // to the least loaded wave.
     const int n_waves = std::max(1, cqt_waves(pl->log2nf));
     const int n_rows = (int)pl->h_indptr.size() - 1;
-    struct Row { int row, cost; };
-    std::vector<Row> rows;
+    const int n = pl->W / 2, w = pl->W;
+    if (n_rows > cqt_max_bins(pl->log2nf)) return fail_msg("cqt: kernel matrix has too many rows for LDS at this fft_length");
+    std::vector<int> order((size_t)n_rows);
     for (int r = 0; r < n_rows; ++r) {
-        const int nz = pl->h_indptr[(size_t)r + 1] - pl->h_indptr[(size_t)r];
-        if (nz < 0) return fail_msg("CQT kernel indptr is not monotone");
-        rows.push_back(Row{r, (nz + 63) / 64 + 1});
+        order[(size_t)r] = r;
+        if (pl->h_indptr[(size_t)r + 1] < pl->h_indptr[(size_t)r]) return fail_msg("CQT kernel indptr is not monotone");
     }
-    std::stable_sort(rows.begin(), rows.end(), [](const Row& a, const Row& b) { return a.cost > b.cost; });
+    auto nnz_of = [&](int r) { return pl->h_indptr[(size_t)r + 1] - pl->h_indptr[(size_t)r]; };
+    std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return nnz_of(a) > nnz_of(b); });
+    // shapes: a long row takes the whole wave (64 lanes), medium rows half of it, short rows a DPP row each -- steps then
+    // stay a few iterations long and balance over the waves (config Q: 18 iterations on the busiest wave with four-row
+    // steps only, 12 with the wide shapes)
+    struct Step { int lanes; int row_of_group[4]; int iters; };   // row_of_group[g]: row whose entries DPP row g works on (-1: none)
+    std::vector<Step> steps;
+    for (int i = 0; i < n_rows;) {
+        const int m = nnz_of(order[(size_t)i]);
+        const int lanes = m > 128 ? 64 : m > 64 ? 32 : 16, per = 64 / lanes;
+        Step st{lanes, {-1, -1, -1, -1}, 1};
+        for (int q = 0; q < per && i < n_rows; ++q, ++i) {
+            const int r = order[(size_t)i];
+            for (int g = q * (lanes / 16); g < (q + 1) * (lanes / 16); ++g) st.row_of_group[g] = r;
+            st.iters = std::max(st.iters, (nnz_of(r) + lanes - 1) / lanes);
+        }
+        steps.push_back(st);
+    }
+    // numerically real matrix (the reference's kernels: the temporal kernels are centred, zaf.py:540-544)
+    float vmax = 0.f, imax = 0.f;
+    for (const cf32& v : pl->h_values) {
+        vmax = std::max(vmax, std::max(std::fabs(v.re), std::fabs(v.im)));
+        imax = std::max(imax, std::fabs(v.im));
+    }
+    pl->cqt_real = imax <= vmax * 9.3e-10f;   // 2^-30: far below the float32 rounding of the products
+    // deal the steps to the waves, longest first, always to the least loaded wave
+    std::vector<int> by_len((size_t)steps.size());
+    for (size_t i = 0; i < steps.size(); ++i) by_len[i] = (int)i;
+    std::stable_sort(by_len.begin(), by_len.end(), [&](int a, int b) { return steps[(size_t)a].iters > steps[(size_t)b].iters; });
     std::vector<std::vector<int>> per_wave((size_t)n_waves);
     std::vector<int> load((size_t)n_waves, 0);
-    for (const Row& r : rows) {
-        const int w = (int)(std::min_element(load.begin(), load.end()) - load.begin());
-        per_wave[(size_t)w].push_back(r.row);
-        load[(size_t)w] += r.cost;
+    for (int s : by_len) {
+        const int wv = (int)(std::min_element(load.begin(), load.end()) - load.begin());
+        per_wave[(size_t)wv].push_back(s);
+        load[(size_t)wv] += steps[(size_t)s].iters + 3;   // (a step end costs about three iterations: reductions + the tile write)
     }
-    std::vector<int> flat, ptr((size_t)n_waves + 1, 0);
-    for (int w = 0; w < n_waves; ++w) {
-        ptr[(size_t)w] = (int)flat.size() / 4;
-        for (int r : per_wave[(size_t)w]) {
-            const int lo = pl->h_indptr[(size_t)r], hi = pl->h_indptr[(size_t)r + 1];
-            int e = lo;
-            do {   // an empty row still yields one (empty, last) chunk so that its output is written
-                const int cnt = std::min(64, hi - e);
-                flat.push_back(r); flat.push_back(e); flat.push_back(cnt); flat.push_back(e + cnt >= hi ? 1 : 0);
-                e += cnt;
-            } while (e < hi);
+    // flatten: steps in wave order, entries as [iteration][lane]
+    std::vector<int> step_tab, wave_tab;
+    std::vector<int32_t> addrs;
+    std::vector<float> vals;
+    int k_lo = n, k_hi = -1, special = 0, max_iters = 0;
+    for (int wv = 0; wv < n_waves; ++wv) {
+        const int it0 = (int)addrs.size() / 64, s0 = (int)step_tab.size() / 8;
+        unsigned mask = 0;
+        int it = 0;
+        for (int s : per_wave[(size_t)wv]) {
+            const Step& st = steps[(size_t)s];
+            const int gl = st.lanes / 16;   // DPP rows per matrix row
+            for (int g = 0; g < 4; ++g) step_tab.push_back(g % gl == gl - 1 ? st.row_of_group[g] : -1);   // the group's last DPP row writes
+            step_tab.push_back(st.iters | (st.lanes << 16)); step_tab.push_back(0); step_tab.push_back(0); step_tab.push_back(0);
+            for (int i = 0; i < st.iters; ++i)
+                for (int l = 0; l < 64; ++l) {
+                    const int row = st.row_of_group[l >> 4], j = (l & (st.lanes - 1)) + st.lanes * i;
+                    int32_t addr = 0;
+                    cf32 v{0.f, 0.f};
+                    if (row >= 0 && j < nnz_of(row)) {
+                        const size_t e = (size_t)pl->h_indptr[(size_t)row] + (size_t)j;
+                        const int c = pl->h_indices[e];
+                        if (c < 0 || c >= w) return fail_msg("CQT kernel column index out of range");
+                        const int m = c <= n ? c : w - c;   // one-sided bin holding X[c] (conjugated when c > n)
+                        const int slot = m == n ? cqt_nyquist_slot(pl->log2nf) : cqt_slot(pl->log2nf, m);
+                        addr = (int32_t)(slot * 8) | (c > n ? (int32_t)0x80000000 : 0);
+                        v = pl->h_values[e];
+                        const int k = std::min(m, n - m);   // pair index of the real split
+                        if (k == 0 || 2 * m == n) special = 1;
+                        else k_lo = std::min(k_lo, k), k_hi = std::max(k_hi, k);
+                    }
+                    addrs.push_back(addr);
+                    vals.push_back(v.re);
+                    if (!pl->cqt_real) vals.push_back(v.im);
+                }
+            it += st.iters;
+            if (it <= 32) mask |= 1u << (it - 1);
         }
+        max_iters = std::max(max_iters, it);
+        wave_tab.insert(wave_tab.end(), {it0, it, s0, (int)per_wave[(size_t)wv].size(), (int)mask, 0, 0, 0});
     }
-    ptr[(size_t)n_waves] = (int)flat.size() / 4;
-    pl->n_chunks = (int)flat.size() / 4;
-    // Every column c of the kernel becomes the LDS slot of the one-sided spectrum that k_cqt reads
-    // (bit 31: conjugate, for a column of the upper half), and the (k, N-k) pairs of the real split
-    // that those slots need are bounded by [k_lo, k_hi] (+ the special group {0, N/2, N}).
-    {
-        const int n = pl->W / 2, w = pl->W;
-        std::vector<int32_t> slots(pl->h_indices.size());
-        int k_lo = n, k_hi = -1, special = 0;
-        for (size_t e = 0; e < pl->h_indices.size(); ++e) {
-            const int c = pl->h_indices[e];
-            if (c < 0 || c >= w) return fail_msg("CQT kernel column index out of range");
-            const int m = c <= n ? c : w - c;   // one-sided bin holding X[c] (conjugated when c > n)
-            slots[e] = (m == n ? cqt_nyquist_slot(pl->log2nf) : cqt_slot(pl->log2nf, m)) | (c > n ? (int32_t)0x80000000 : 0);
-            const int k = std::min(m, n - m);   // pair index of the real split
-            if (k == 0 || 2 * m == n) special = 1;
-            else k_lo = std::min(k_lo, k), k_hi = std::max(k_hi, k);
-        }
-        pl->cqt_k_lo = k_lo;
-        pl->cqt_k_hi = k_hi;
-        pl->cqt_k_special = special;
-        if (slots.empty()) slots.assign(1, 0);
-        ZAFX_HIP(upload(&pl->d_slots, slots.data(), slots.size() * sizeof(int32_t)));
-    }
-    if (flat.empty()) flat.assign(4, 0);
-    ZAFX_HIP(upload(&pl->d_chunks, flat.data(), flat.size() * sizeof(int)));
-    ZAFX_HIP(upload(&pl->d_chunk_ptr, ptr.data(), ptr.size() * sizeof(int)));
+    pl->cqt_resident = max_iters <= kCqtResident ? kCqtResident : 0;
+    pl->cqt_n_steps = (int)step_tab.size() / 8;
+    pl->cqt_n_entries = (int)addrs.size();
+    pl->cqt_k_lo = k_lo;
+    pl->cqt_k_hi = k_hi;
+    pl->cqt_k_special = special;
+    if (addrs.empty()) addrs.assign(64, 0), vals.assign(pl->cqt_real ? 64 : 128, 0.f);
+    if (step_tab.empty()) step_tab.assign(8, 0);
+    ZAFX_HIP(upload(&pl->d_cqt_addrs, addrs.data(), addrs.size() * sizeof(int32_t)));
+    ZAFX_HIP(upload(&pl->d_cqt_vals, vals.data(), vals.size() * sizeof(float)));
+    ZAFX_HIP(upload(&pl->d_cqt_steps, step_tab.data(), step_tab.size() * sizeof(int)));
+    ZAFX_HIP(upload(&pl->d_cqt_waves, wave_tab.data(), wave_tab.size() * sizeof(int)));
     pl->cqt_dirty = false;
     return 0;
 }
@@ -586,8 +629,10 @@ int zafx_plan_destroy(zafx_plan* pl) {
     if (pl->d_indptr) (void)hipFree(pl->d_indptr);
     if (pl->d_indices) (void)hipFree(pl->d_indices);
     if (pl->d_values) (void)hipFree(pl->d_values);
-    if (pl->d_chunks) (void)hipFree(pl->d_chunks);
-    if (pl->d_slots) (void)hipFree(pl->d_slots);
+    if (pl->d_cqt_waves) (void)hipFree(pl->d_cqt_waves);
+    if (pl->d_cqt_steps) (void)hipFree(pl->d_cqt_steps);
+    if (pl->d_cqt_addrs) (void)hipFree(pl->d_cqt_addrs);
+    if (pl->d_cqt_vals) (void)hipFree(pl->d_cqt_vals);
     if (pl->d_window64) (void)hipFree(pl->d_window64);
     if (pl->d_tw64) (void)hipFree(pl->d_tw64);
     if (pl->d_tws64) (void)hipFree(pl->d_tws64);
@@ -597,7 +642,6 @@ int zafx_plan_destroy(zafx_plan* pl) {
     if (pl->d_dct64) (void)hipFree(pl->d_dct64);
     if (pl->d_values64) (void)hipFree(pl->d_values64);
     if (pl->d_bhat64) (void)hipFree(pl->d_bhat64);
-    if (pl->d_chunk_ptr) (void)hipFree(pl->d_chunk_ptr);
     free_band(pl->fb);
     free_band(pl->dct);
     if (pl->ev0) (void)hipEventDestroy(pl->ev0);
@@ -836,6 +880,13 @@ int zafx_pcm_to_float(zafx_plan* pl, const void* d_pcm, void* d_out, int64_t n_c
     if (!d_pcm || !d_out) return fail_msg("null device pointer");
     ZAFX_HIP(hipSetDevice(pl->device));
     ZAFX_HIP(launch_pcm_to_float(pl->stream, d_pcm, (float*)d_out, n_clips * n_frames, n_channels, sample_bytes));
+    return 0;
+}
+
+int zafx_cqt_max_bins(int fft_length, int* n_bins) {
+    if (!n_bins) return fail_msg("null argument");
+    const int lw = ilog2_exact(fft_length);
+    *n_bins = (lw >= 1 && cqt_supported(lw - 1)) ? cqt_max_bins(lw - 1) : 0;
     return 0;
 }
 

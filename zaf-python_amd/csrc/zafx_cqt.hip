@@ -4,14 +4,23 @@
 //     cqt[:, j] = abs(cqt_kernel * np.fft.fft(xpad[j*step : j*step + fft_len]))
 // with cqt_kernel a sparse (n_bins x fft_len) complex CSR matrix (zaf.py:554-557).
 //
-// One workgroup owns FW = 16 consecutive frames of one clip and transforms them one
-// after the other: the whole frame (fft_len real = N = fft_len/2 complex points, up
-// to 128 KiB) lives in LDS, owned by N/16 threads (1024 for fft_len 32768).  Frames of
-// a tile overlap by (fft_len - step)/fft_len (94.6 % at config Q), so the re-reads of
-// the input hit L2; HBM sees each sample about once per tile.  After the real-split the
-// CSR rows are contracted against the one-sided spectrum in LDS (one wave per row,
-// lanes across the row's contiguous non-zeros, shuffle reduction) and the magnitudes of
-// the 16 frames are staged in LDS so that the (n_bins, T) store writes 64-B runs along t.
+// One workgroup owns FW (16, fewer when the kernel matrix has many rows) consecutive frames of one clip and
+// transforms them one after the other: the whole frame (fft_len real = N = fft_len/2 complex points, up to
+// 128 KiB) lives in LDS, owned by N/16 threads (1024 for fft_len 32768).  Frames of a tile overlap by
+// (fft_len - step)/fft_len (94.6 % at config Q), so the re-reads of the input hit L2; HBM sees each sample about
+// once per tile.  After the real split the CSR rows are contracted against the one-sided spectrum in LDS:
+//   * the host sorts the rows by length and deals them out in "steps": a wavefront works on four short rows at once
+//     (one per 16-lane DPP row, lane j of a row taking its entries j, j + 16, j + 32, ...), on two medium rows (32 lanes
+//     each) or on one long row (64 lanes); a step ends with ONE pair of DPP reductions (row sums, + row_bcast for the
+//     wider shapes) for all its rows, and the last lane of a row's lane group writes |.|^2 straight into the LDS
+//     tile -- no partial sums in LDS, no finishing pass;
+//   * a wave's share of the matrix (value + LDS byte address of the spectrum bin per entry) stays in REGISTERS across
+//     the frames of the tile when it fits (<= 12 entries per lane: config Q has 9 450 non-zeros, 12 iterations on
+//     the busiest wave); larger matrices (the reference's own cqtkernel example, 60 879 non-zeros) stream it from L2
+//     every frame;
+//   * a numerically real matrix (the reference's kernels are: max |imag| / max |real| = 1e-16) is contracted as
+//     real x complex.
+// The magnitudes of the tile's frames are staged in LDS so that the (n_bins, T) store writes 64-B runs along t.
 // The chromagram (zaf.py:693-698) is a strided row sum over that LDS tile.
 #include <algorithm>
 
@@ -20,10 +29,9 @@
 
 namespace zafx {
 
-constexpr int kCqtFramesPerBlock = 16;
 ZAFX_PROF_ARRAY(g_prof_cqt)
 
-// LDS carve shared by the kernel and the launcher (bytes before the chunk descriptors, 16-B aligned:
+// LDS carve shared by the kernel and the launcher (bytes before the wave / step tables, 16-B aligned:
 // a misaligned ds_read_b128 is replayed at 64 cycles)
 template <int LOG2N, int LOG2E>
 struct CqtCfg {
@@ -36,15 +44,26 @@ struct CqtCfg {
     static constexpr size_t HEAD = (((size_t)(SLOTS + NHI + 128 + NH2 + 128 + NSUB) * 8 + 15) / 16) * 16;
 };
 
-template <int LOG2N, int LOG2E, bool ALIGNED>
+// DPP row_bcast adds (gfx9 wave64 reductions): lane 15 of rows 0, 2 into every lane of rows 1, 3; lane 31 into rows 2, 3
+__device__ __forceinline__ float bcast15_add(float v) {
+    return v + __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x142, 0xA, 0xF, false));
+}
+__device__ __forceinline__ float bcast31_add(float v) {
+    return v + __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x143, 0xC, 0xF, false));
+}
+
+// REALK: kernel values are float (real matrix), else float2.  RES > 0: a wave's entries (RES iterations) ride in registers.
+template <int LOG2N, int LOG2E, bool ALIGNED, bool REALK, int RES>
 __global__ __launch_bounds__(fft_threads(LOG2N, LOG2E)) void k_cqt(
     const float* __restrict__ x, const float2* __restrict__ twp, const float2* __restrict__ tws,
-    const int4* __restrict__ chunks, const int* __restrict__ chunk_ptr, const int* __restrict__ slots, const float2* __restrict__ values, float* __restrict__ out,
-    long long n_samples, int step, int left_pad, int T, int TP, int tiles, int n_bins, int chroma_res, int layout, int n_chunks,
-    int k_lo, int k_hi, int k_special, int nnz) {
+    const int4* __restrict__ wave_tab, const int4* __restrict__ step_tab, const int* __restrict__ addrs, const float* __restrict__ values,
+    float* __restrict__ out, long long n_samples, int step, int left_pad, int T, int TP, int tiles, int n_bins, int chroma_res, int layout,
+    int n_steps, int FW, int k_lo, int k_hi, int k_special, int n_entries) {
     using C = FftCfg<LOG2N, LOG2E>;
     using G = CqtCfg<LOG2N, LOG2E>;
-    constexpr int N = C::N, P = C::P, E = C::E, W = 2 * N, FW = kCqtFramesPerBlock, NHI = G::NHI, NH2 = G::NH2;
+    using KV = std::conditional_t<REALK, float, float2>;
+    constexpr int N = C::N, P = C::P, E = C::E, W = 2 * N, NHI = G::NHI, NH2 = G::NH2;
+    constexpr bool RESIDENT = RES > 0;
     static_assert(P >= 64, "CQT frames are owned by whole wavefronts");
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     float2* buf = reinterpret_cast<float2*>(smem_raw);            // G::SLOTS slots: bin k at slot_of(k), X[N] at NYQ
@@ -55,17 +74,25 @@ __global__ __launch_bounds__(fft_threads(LOG2N, LOG2E)) void k_cqt(
     float2* sub_hi = sp_lo + 128;                                 // (SPLIT) two-level root table of 1024
     auto slot_of = [](int k) { return cqt_slot(LOG2N, k); };
     constexpr int NYQ = cqt_nyquist_slot(LOG2N);
-    int4* chunk_l = reinterpret_cast<int4*>(smem_raw + G::HEAD);  // [n_chunks]
-    float* tile = reinterpret_cast<float*>(chunk_l + n_chunks);   // [n_bins][FW]
-    float2* part = reinterpret_cast<float2*>(tile + n_bins * FW);   // [n_bins][4] row sums of a frame's products
-    int* chunk_ptr_l = reinterpret_cast<int*>(part + n_bins * 4);   // [waves + 1]
+    int4* wave_l = reinterpret_cast<int4*>(smem_raw + G::HEAD);   // [P / 64] {first iteration, iterations, first step, steps}
+    int* mask_l = reinterpret_cast<int*>(wave_l + P / 64);        // [P / 64] bit i: iteration i of the wave ends a step (resident form)
+    int4* step_l = reinterpret_cast<int4*>(mask_l + ((P / 64 + 3) & ~3));   // [n_steps] rows of the step's four DPP rows (-1: none) ...
+    int* iters_l = reinterpret_cast<int*>(step_l + n_steps);      // [n_steps] ... and its iteration count | lanes per row (16, 32, 64) << 16
+    float* tile = reinterpret_cast<float*>(iters_l + ((n_steps + 3) & ~3));   // [n_bins][FW]
     const int p = threadIdx.x;
     for (int i = p; i < NHI + 128; i += P) tw_hi[i] = twp[i];
     if constexpr (G::SPLIT)
         for (int i = p; i < G::NSUB; i += P) sub_hi[i] = twp[NHI + 128 + i];
     for (int i = p; i < NH2 + 128; i += P) sp_hi[i] = tws[i];
-    for (int i = p; i < n_chunks; i += P) chunk_l[i] = chunks[i];
-    for (int i = p; i <= P / 64; i += P) chunk_ptr_l[i] = chunk_ptr[i];
+    for (int i = p; i < P / 64; i += P) {
+        wave_l[i] = wave_tab[2 * i];
+        mask_l[i] = wave_tab[2 * i + 1].x;
+    }
+    for (int i = p; i < n_steps; i += P) {
+        const int4 s = step_tab[2 * i], m = step_tab[2 * i + 1];
+        step_l[i] = s;
+        iters_l[i] = m.x;
+    }
     lds_barrier();
     const TwoLevelTw tw2l{tw_hi, tw_lo};
     const int wave = p >> 6;
@@ -73,20 +100,35 @@ __global__ __launch_bounds__(fft_threads(LOG2N, LOG2E)) void k_cqt(
     const int t0 = tl * FW;
     const float* xc = x + (long long)clip * n_samples;
     // wave-uniform values read from LDS land in VGPRs; readfirstlane tells the compiler they are scalars
-    // (scalar branches and SGPR operands instead of exec-mask juggling around every chunk)
-    const int c0 = __builtin_amdgcn_readfirstlane(chunk_ptr_l[wave]), c1 = __builtin_amdgcn_readfirstlane(chunk_ptr_l[wave + 1]);
-    auto chunk_at = [&](int c) {
-        const int4 d = chunk_l[c];
-        return make_int4(__builtin_amdgcn_readfirstlane(d.x), __builtin_amdgcn_readfirstlane(d.y), __builtin_amdgcn_readfirstlane(d.z),
-                         __builtin_amdgcn_readfirstlane(d.w));
+    // (scalar branches and SGPR operands instead of exec-mask juggling)
+    const int4 wt = wave_l[wave];
+    const int it0 = __builtin_amdgcn_readfirstlane(wt.x), n_it = __builtin_amdgcn_readfirstlane(wt.y);
+    const int s0 = __builtin_amdgcn_readfirstlane(wt.z), s1 = s0 + __builtin_amdgcn_readfirstlane(wt.w);
+    const int endmask = __builtin_amdgcn_readfirstlane(mask_l[wave]);
+    const auto raddr = make_rsrc(addrs, (unsigned)n_entries * 4u);
+    const auto rvals = make_rsrc(values, (unsigned)n_entries * (unsigned)sizeof(KV));
+    auto load_kv = [&](int voff_entries) -> KV {
+        if constexpr (REALK) return buf_load_f32(rvals, voff_entries * 4);
+        else return buf_load_f32x2(rvals, voff_entries * 8);
     };
+
+    // ---- a wave's share of the kernel matrix, resident in registers for the whole tile
+    KV kv[RESIDENT ? RES : 1];
+    int ad[RESIDENT ? RES : 1];
+    if constexpr (RESIDENT) {
+#pragma unroll
+        for (int i = 0; i < RES; ++i) {
+            const int e = i < n_it ? (it0 + i) * 64 + (p & 63) : -1;   // out of range: reads 0
+            ad[i] = buf_load_i32(raddr, e * 4);
+            kv[i] = load_kv(e);
+        }
+    }
 
     // ---- framing, no window (it lives in the kernel): zaf.py:612-620, :631.  Frames inside the clip take
     // unconditional 8-byte loads; the zero-padded edge frames take the predicated path.
     float2 v[E];
     const unsigned clip_bytes = (unsigned)std::min<long long>(n_samples * 4, 0xfffffffcLL);
     const auto rx = make_rsrc(xc, clip_bytes);
-    const auto rslots = make_rsrc(slots, (unsigned)nnz * 4u), rvals = make_rsrc(values, (unsigned)nnz * 8u);
     auto load_frame = [&](int t, int p) {   // p: thread id (an opaque copy inside the frame loop)
         const long long s0 = (long long)t * step - left_pad;
         if (ALIGNED && s0 >= 0 && s0 + W <= n_samples) {
@@ -102,7 +144,25 @@ __global__ __launch_bounds__(fft_threads(LOG2N, LOG2E)) void k_cqt(
             }
         }
     };
-    if (t0 < T) load_frame(t0, threadIdx.x);
+    // First pass of the 16 x 1024 form, in registers: radix-16 across the workgroup on the samples 1024 apart (thread p
+    // holds n2 = p), times w^(p k1).  It runs BEFORE the barrier that frees the LDS frame, i.e. under the tail of the
+    // previous frame's contraction.
+    auto first_pass = [&](int p) {
+        if constexpr (G::SPLIT) {
+            static_assert(!G::SPLIT || (E == 16 && P == 1024), "split form: 16 points per thread, 16 wavefronts");
+            Dft<16>::run(v);
+            float2 w[16];
+            w[1] = tw2(tw2l, p);
+#pragma unroll
+            for (int r = 2; r < 16; ++r) w[r] = cmul(w[r >> 1], w[r - (r >> 1)]);
+#pragma unroll
+            for (int r = 1; r < 16; ++r) v[r] = cmul(v[r], w[r]);
+        }
+    };
+    if (t0 < T) {
+        load_frame(t0, threadIdx.x);
+        first_pass(threadIdx.x);
+    }
     PROF_INIT(g_prof_cqt);
 
 #pragma unroll 1
@@ -117,19 +177,9 @@ __global__ __launch_bounds__(fft_threads(LOG2N, LOG2E)) void k_cqt(
         asm volatile("" : "+v"(p));
         const int lane = p & 63;
         if constexpr (G::SPLIT) {
-            // 16384 = 16 x 1024.  Radix-16 across the workgroup on the samples 1024 apart (thread p holds n2 = p), times
-            // w^(p k1); output k1 goes to sub-sequence k1 at position p.  Then wave w transforms sub-sequence w on its own
-            // (three wave-local passes, no workgroup barrier): X[k1 + 16 k2] = FFT_1024(sub-sequence k1)[k2].
-            static_assert(E == 16 && P == 1024, "split form: 16 points per thread, 16 wavefronts");
-            Dft<16>::run(v);
-            {
-                float2 w[16];
-                w[1] = tw2(tw2l, p);
-#pragma unroll
-                for (int r = 2; r < 16; ++r) w[r] = cmul(w[r >> 1], w[r - (r >> 1)]);
-#pragma unroll
-                for (int r = 1; r < 16; ++r) v[r] = cmul(v[r], w[r]);
-            }
+            // 16384 = 16 x 1024: output k1 of the first pass goes to sub-sequence k1 at position p.  Then wave w
+            // transforms sub-sequence w on its own (three wave-local passes, no workgroup barrier):
+            // X[k1 + 16 k2] = FFT_1024(sub-sequence k1)[k2].
             const int pp = phys(p);
 #pragma unroll
             for (int r = 0; r < 16; ++r) buf[r * kCqtRegion + pp] = v[r];
@@ -143,25 +193,11 @@ __global__ __launch_bounds__(fft_threads(LOG2N, LOG2E)) void k_cqt(
             fft_frame_chain<LOG2N, LOG2E>(v, buf, p, tw2l);
         }
         PROF_MARK(1);
-        // ---- CSR mat-vec, part 1: request the slots and values of my first G chunks now; the L2 round
-        // trip hides under the real split
-        constexpr int G1 = 8;   // two rounds cover a wave's share at config Q (238 chunks over 16 waves)
-        int slot[G1];
-        float2 kv[G1];
-        auto request = [&](int cb) {
-#pragma unroll
-            for (int g = 0; g < G1; ++g) {
-                const int4 ch = cb + g < c1 ? chunk_at(cb + g) : make_int4(0, 0, 0, 0);
-                // branch-free: lanes past the chunk read out of range, i.e. 0 (a select on the loaded value
-                // would make the wave wait for the load right here)
-                const bool on = lane < ch.z;
-                slot[g] = buf_load_i32(rslots, on ? (ch.y + lane) * 4 : -4);
-                kv[g] = buf_load_f32x2(rvals, on ? (ch.y + lane) * 8 : -8);
-            }
-        };
-        request(c0);
+        // the next frame's samples: v is dead until the next first pass, the loads fly under the split + contraction
+        const bool more = jj + 1 < FW && t + 1 < T;
+        if (more) load_frame(t + 1, p);
         // ---- real split in place, only for the pairs (k, N-k) that the kernel's columns touch:
-        // slots 0..N-1 <- X[0..N-1], slot PITCH-1 <- X[N];  t_k = exp(-2 pi i k / 2N) = sp_hi[k >> 7] sp_lo[k & 127]
+        // slots 0..N-1 <- X[0..N-1], slot NYQ <- X[N];  t_k = exp(-2 pi i k / 2N) = sp_hi[k >> 7] sp_lo[k & 127]
         if (k_special && p == 0) {
             const float2 z0 = buf[0], zc = buf[slot_of(N / 2)];
             buf[0] = make_float2(z0.x + z0.y, 0.f);
@@ -180,59 +216,84 @@ __global__ __launch_bounds__(fft_threads(LOG2N, LOG2E)) void k_cqt(
         PROF_MARK(2);
         lds_barrier();
         PROF_MARK(3);
-        // ---- CSR mat-vec against the spectrum + magnitude (zaf.py:630-632).  The host cut the rows into
-        // chunks of <= 64 non-zeros, dealt whole rows to the wavefronts (balanced) and translated every
-        // column into its LDS slot (bit 31: use the conjugate, i.e. a column of the upper half).  Chunk
-        // descriptors sit in LDS; the slots and values of G chunks are requested together, so a frame
-        // pays ceil(chunks / G) L2 round trips instead of two per chunk.  Order of the requests: group 1
-        // before the split (above), group 2 after group 1 is consumed, THEN the next frame's samples
-        // (v is free until the next FFT) -- loads return in order, so group 2 must not queue behind
-        // the 128-KB frame prefetch.
+        // ---- CSR mat-vec against the spectrum + |.|^2 (zaf.py:630-632).  Lane (g, j) = (lane >> 4, lane & 15) of the
+        // wave's current step works on row step_l[s][g]; entry (iteration it, lane) carries the value and the LDS byte
+        // address of its spectrum bin (bit 31: conjugate, a column of the upper half); padding entries are 0 * bin 0.
         {
             float ar = 0.f, ai = 0.f;
-            auto contract = [&](int cb) {
-#pragma unroll
-                for (int g = 0; g < G1; ++g) {
-                    if (cb + g >= c1) break;
-                    const int4 ch = chunk_at(cb + g);   // {row, first entry, count, last-of-row}
-                    if (lane < ch.z) {
-                        float2 xv = buf[slot[g] & 0x7fffffff];
-                        if (slot[g] < 0) xv.y = -xv.y;
-                        ar += kv[g].x * xv.x - kv[g].y * xv.y;
-                        ai += kv[g].x * xv.y + kv[g].y * xv.x;
-                    }
-                    if (ch.w) {   // end of row ch.x: leave the four 16-lane partial sums in LDS (finished below)
-                        ar = row16_sum(ar);
-                        ai = row16_sum(ai);
-                        if ((lane & 15) == 0) part[ch.x * 4 + (lane >> 4)] = make_float2(ar, ai);
-                        ar = 0.f;
-                        ai = 0.f;
-                    }
+            auto mac = [&](KV k, int a) {
+                asm volatile("" : "+v"(a));   // (the masks below are frame-invariant: hoisted they would cost two more registers per resident entry)
+                float2 xv = *reinterpret_cast<const float2*>(smem_raw + (a & 0x7fffffff));
+                xv.y = __builtin_bit_cast(float, __builtin_bit_cast(int, xv.y) ^ (a & (int)0x80000000));
+                if constexpr (REALK) {
+                    ar = fmaf(k, xv.x, ar);
+                    ai = fmaf(k, xv.y, ai);
+                } else {
+                    ar += k.x * xv.x - k.y * xv.y;
+                    ai += k.x * xv.y + k.y * xv.x;
                 }
             };
-            contract(c0);
-            if (c0 + G1 < c1) request(c0 + G1);
-            if (jj + 1 < FW && t + 1 < T) load_frame(t + 1, p);
-            PROF_MARK(4);
-            if (c0 + G1 < c1) contract(c0 + G1);
-            for (int cb = c0 + 2 * G1; cb < c1; cb += G1) {
-                request(cb);
-                contract(cb);
+            auto finish = [&](int s) {   // end of a step: one reduction pair serves all its rows
+                const int4 rows = step_l[s];
+                const int shape = __builtin_amdgcn_readfirstlane(iters_l[s]) >> 16;
+                ar = row16_sum(ar);
+                ai = row16_sum(ai);
+                if (shape >= 32) {
+                    ar = bcast15_add(ar);
+                    ai = bcast15_add(ai);
+                }
+                if (shape == 64) {
+                    ar = bcast31_add(ar);
+                    ai = bcast31_add(ai);
+                }
+                const int g = lane >> 4;
+                const int row = g == 0 ? rows.x : g == 1 ? rows.y : g == 2 ? rows.z : rows.w;   // (-1 for lane groups that end no row)
+                if ((lane & 15) == 15 && row >= 0) tile[row * FW + jj] = ar * ar + ai * ai;   // (the square root is taken when the tile is stored)
+                ar = 0.f;
+                ai = 0.f;
+            };
+            if constexpr (RESIDENT) {
+                // every wave runs RES iterations (padding entries are 0 * bin 0); the step ends are scalar bit tests on a mask
+                // that is re-read every frame -- hoisted out of the frame loop the RES conditions cost 2 SGPRs each and spill
+                int s = s0, em = endmask;
+                asm volatile("" : "+s"(em));
+#pragma unroll
+                for (int i = 0; i < RES; ++i) {
+                    mac(kv[i], ad[i]);
+                    if (em & (1 << i)) finish(s++);
+                }
+            } else {
+                constexpr int GR = 4;   // iterations requested together
+                int it = it0;
+                for (int s = s0; s < s1; ++s) {
+                    const int ni = __builtin_amdgcn_readfirstlane(iters_l[s]) & 0xffff;
+                    for (int b = 0; b < ni; b += GR) {
+                        KV kq[GR];
+                        int aq[GR];
+#pragma unroll
+                        for (int g = 0; g < GR; ++g) {
+                            const int e = b + g < ni ? (it + b + g) * 64 + lane : -1;
+                            aq[g] = buf_load_i32(raddr, e * 4);
+                            kq[g] = load_kv(e);
+                        }
+#pragma unroll
+                        for (int g = 0; g < GR; ++g)
+                            if (b + g < ni) mac(kq[g], aq[g]);
+                    }
+                    it += ni;
+                    finish(s);
+                }
             }
         }
+        PROF_MARK(4);
+        if (more) first_pass(p);   // (waits for the prefetched samples; the other waves are still contracting)
         PROF_MARK(5);
         lds_barrier();
         PROF_MARK(6);
-        // |.|^2 of every row of this frame (the square root is taken once, when the tile is stored)
-        for (int r = p; r < n_bins; r += P) {
-            const float4 a = *reinterpret_cast<const float4*>(part + r * 4), b = *reinterpret_cast<const float4*>(part + r * 4 + 2);
-            const float sr = (a.x + a.z) + (b.x + b.z), si = (a.y + a.w) + (b.y + b.w);
-            tile[r * FW + jj] = sr * sr + si * si;
-        }
     }
     lds_barrier();
 
-    // ---- store the tile (64-B runs along t in the reference layout)
+    // ---- store the tile (FW * 4-B runs along t in the reference layout)
     const int nvalid = min(FW, T - t0);
     if (chroma_res > 0) {
         for (int idx = p; idx < chroma_res * FW; idx += P) {
@@ -254,18 +315,37 @@ __global__ __launch_bounds__(fft_threads(LOG2N, LOG2E)) void k_cqt(
     }
 }
 
+// LDS bytes of k_cqt for `frames` frames per tile; 0 when LOG2N is not built
+template <int LOG2N>
+static size_t cqt_lds(int n_bins, int n_steps, int frames) {
+    constexpr int LOG2E = default_log2e(LOG2N);
+    using C = FftCfg<LOG2N, LOG2E>;
+    using G = CqtCfg<LOG2N, LOG2E>;
+    return G::HEAD + (size_t)(C::P / 64) * 16 + (size_t)((C::P / 64 + 3) & ~3) * 4 + (size_t)n_steps * 16 + (size_t)((n_steps + 3) & ~3) * 4 +
+           (size_t)n_bins * frames * sizeof(float);
+}
+
 template <int LOG2N>
 static hipError_t run_cqt(const zafx_plan& pl, const float* x, float* out, int64_t n_clips, int64_t n_samples, int T) {
     constexpr int LOG2E = default_log2e(LOG2N);
     using C = FftCfg<LOG2N, LOG2E>;
-    using G = CqtCfg<LOG2N, LOG2E>;
     const int diff = pl.W - pl.H;                              // may be negative if step > fft_len
     const int left = diff >= 0 ? (diff + 1) / 2 : -((-diff) / 2);   // ceil(diff / 2)  (zaf.py:615)
     const bool aligned = n_samples % 2 == 0 && pl.H % 2 == 0 && left % 2 == 0 && reinterpret_cast<uintptr_t>(x) % 8 == 0;
-    auto kern = aligned ? k_cqt<LOG2N, LOG2E, true> : k_cqt<LOG2N, LOG2E, false>;
-    const size_t smem = G::HEAD + (size_t)pl.n_chunks * 16 + (size_t)pl.prm.n_bins * (kCqtFramesPerBlock * sizeof(float) + 4 * sizeof(float2)) + (size_t)(C::P / 64 + 1) * 4;
+    // a real matrix whose busiest wave has <= kCqtResident iterations keeps its entries in registers (16 would spill at 1024 threads)
+    const bool realk = pl.cqt_real;
+    const bool res = realk && pl.cqt_resident == kCqtResident;
+    auto pick = [&](auto al) {
+        constexpr bool AL = decltype(al)::value;
+        return !realk ? k_cqt<LOG2N, LOG2E, AL, false, 0> : res ? k_cqt<LOG2N, LOG2E, AL, true, kCqtResident> : k_cqt<LOG2N, LOG2E, AL, true, 0>;
+    };
+    auto kern = aligned ? pick(std::true_type{}) : pick(std::false_type{});
+    // frames per tile: 16 (64-B output runs) when the rows fit beside the frame, else 8, 4, 2, 1
+    int fw = 16;
+    while (fw > 1 && cqt_lds<LOG2N>(pl.prm.n_bins, pl.cqt_n_steps, fw) > (size_t)kMaxLdsBytes) fw >>= 1;
+    const size_t smem = cqt_lds<LOG2N>(pl.prm.n_bins, pl.cqt_n_steps, fw);
     if (smem > (size_t)kMaxLdsBytes) {
-        set_error("cqt: kernel matrix (bins / non-zeros) too large for LDS at this fft_length");
+        set_error("cqt: kernel matrix has too many rows for LDS at this fft_length");
         return hipErrorInvalidValue;
     }
     if (n_samples >= (1LL << 29)) {   // a clip is addressed through one buffer descriptor with 32-bit byte offsets
@@ -273,19 +353,47 @@ static hipError_t run_cqt(const zafx_plan& pl, const float* x, float* out, int64
         return hipErrorInvalidValue;
     }
     if (hipError_t e = ensure_dynamic_lds(reinterpret_cast<const void*>(kern), pl.device, smem); e != hipSuccess) return e;
-    const int tiles = (T + kCqtFramesPerBlock - 1) / kCqtFramesPerBlock;
+    const int tiles = (T + fw - 1) / fw;
     const long long blocks = (long long)tiles * n_clips;
     if (blocks <= 0) return hipSuccess;
-    hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(C::P), smem, pl.stream, x, pl.d_tw_pass, pl.d_tw_aux, pl.d_chunks, pl.d_chunk_ptr, pl.d_slots,
-                       pl.d_values, out, (long long)n_samples, pl.H, left, T, (int)row_pitch(pl, T), tiles, pl.prm.n_bins,
-                       pl.kind == ZAFX_CHROMA ? pl.prm.octave_resolution : 0, pl.layout, pl.n_chunks, pl.cqt_k_lo, pl.cqt_k_hi,
-                       pl.cqt_k_special, std::max(pl.nnz, 1));
+    if (blocks > 0x7fffffffLL) {
+        set_error("cqt: batch too large for one launch");
+        return hipErrorInvalidValue;
+    }
+    hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(C::P), smem, pl.stream, x, pl.d_tw_pass, pl.d_tw_aux, pl.d_cqt_waves, pl.d_cqt_steps,
+                       pl.d_cqt_addrs, pl.d_cqt_vals, out, (long long)n_samples, pl.H, left, T, (int)row_pitch(pl, T), tiles, pl.prm.n_bins,
+                       pl.kind == ZAFX_CHROMA ? pl.prm.octave_resolution : 0, pl.layout, pl.cqt_n_steps, fw, pl.cqt_k_lo, pl.cqt_k_hi,
+                       pl.cqt_k_special, std::max(pl.cqt_n_entries, 1));
     return hipGetLastError();
 }
 
 bool cqt_supported(int log2n) { return log2n >= 8 && log2n <= 14; }
 int cqt_waves(int log2n) { return fft_threads(log2n, default_log2e(log2n)) / 64; }
 const char* cqt_kernel_name() { return "k_cqt"; }
+
+// Largest number of rows a float32 plan of this fft_length can hold (one frame per tile, ceil(rows / 4) steps)
+int cqt_max_bins(int log2n) {
+    auto fit = [](auto tag) {
+        constexpr int L = decltype(tag)::value;
+        int lo = 0, hi = 1 << 20;
+        while (lo < hi) {
+            const int mid = (lo + hi + 1) / 2;
+            if (cqt_lds<L>(mid, (mid + 3) / 4, 1) <= (size_t)kMaxLdsBytes) lo = mid;
+            else hi = mid - 1;
+        }
+        return lo;
+    };
+    switch (log2n) {
+        case 8: return fit(std::integral_constant<int, 8>{});
+        case 9: return fit(std::integral_constant<int, 9>{});
+        case 10: return fit(std::integral_constant<int, 10>{});
+        case 11: return fit(std::integral_constant<int, 11>{});
+        case 12: return fit(std::integral_constant<int, 12>{});
+        case 13: return fit(std::integral_constant<int, 13>{});
+        case 14: return fit(std::integral_constant<int, 14>{});
+    }
+    return 0;
+}
 
 hipError_t launch_cqt(const zafx_plan& pl, const float* x, float* out, int64_t n_clips, int64_t n_samples, int T) {
     switch (pl.log2nf) {

@@ -27,6 +27,7 @@ constexpr int cqt_slot(int log2n, int k) {
     return cqt_split(log2n) ? (k & 15) * kCqtRegion + (k >> 4) + (k >> 8) : k + (k >> 4);
 }
 constexpr int cqt_nyquist_slot(int log2n) { return cqt_split(log2n) ? kCqtRegion - 1 : (1 << log2n) + ((1 << log2n) >> 4); }
+constexpr int kCqtResident = 12;           // k_cqt: iterations (entries per lane) of a wave's share of the kernel matrix that ride in registers
 constexpr int kCqt64Sub = 4096;            // float64 CQT: length of the sub-transforms that fit LDS (2 x 4096 x 16 B)
 
 // Banded, MFMA-fragment-packed matrix (mel filterbank or DCT-II rows) cut into balanced work
@@ -72,9 +73,16 @@ struct zafx_plan {
     int* d_indices = nullptr;
     float2* d_values = nullptr;
     int nnz = 0;
-    int4* d_chunks = nullptr;      // CQT rows cut into <= 64-entry chunks {row, first entry, count, last-of-row}
-    int* d_chunk_ptr = nullptr;    // [waves + 1] ranges of d_chunks per wavefront
-    int n_chunks = 0;
+    // k_cqt's view of the kernel matrix (build_cqt_chunks in zafx_capi.cpp): rows sorted by length and dealt out in "steps"
+    // (four rows of 16 lanes, two of 32 or one of 64), steps dealt to the wavefronts; entry (iteration, lane) = value + LDS
+    // byte address of its spectrum bin
+    int4* d_cqt_waves = nullptr;   // [waves][2]: {first iteration, iterations, first step, steps}, {step-end mask, 0, 0, 0}
+    int4* d_cqt_steps = nullptr;   // [steps][2]: row that ends in each of the four DPP rows (-1: none), {iterations | lanes per row << 16, 0, 0, 0}
+    int* d_cqt_addrs = nullptr;    // [iterations][64]: byte address of the bin in the LDS spectrum image (bit 31 = conjugate)
+    float* d_cqt_vals = nullptr;   // [iterations][64] float (real matrix) or float2
+    int cqt_n_steps = 0, cqt_n_entries = 0;
+    bool cqt_real = false;
+    int cqt_resident = 0;          // kCqtResident: the busiest wave's iterations fit the registers; 0: entries streamed from L2 every frame
     float2* d_tw_r32 = nullptr;    // pass twiddles of the radix-32 schedule (1024 points as 32 x 32), STFT plans of W = 2048
     // float64 mode (ZAFX_PRECISION_F64, zafx_f64.hip)
     double* d_window64 = nullptr;
@@ -91,7 +99,6 @@ struct zafx_plan {
     int bs_log2m = 0;              // > 0: window that is not a power of two -- Bluestein convolution length 2^bs_log2m (zafx_f64.hip)
     double2* d_bhat64 = nullptr;   // FFT of the wrapped conjugate chirp, 2^bs_log2m entries
     std::vector<double2> h_values64;
-    int* d_slots = nullptr;        // per non-zero: LDS slot of its column in k_cqt's one-sided spectrum (bit 31 = conjugate)
     int cqt_k_lo = 0, cqt_k_hi = -1, cqt_k_special = 0;   // real-split pairs the kernel's columns need
     bool cqt_dirty = true;
 
@@ -148,6 +155,7 @@ bool stft_supported(int log2n);   // log2 of complex FFT length = log2(W) - 1
 bool mdct_supported(int log2nf);  // log2(W) - 2
 bool cqt_supported(int log2n);    // log2(fft_length) - 1
 int cqt_waves(int log2n);         // wavefronts per workgroup of k_cqt
+int cqt_max_bins(int log2n);      // rows of a kernel matrix the float32 k_cqt can hold in LDS beside the frame
 int stft_frames_per_block(int log2n, int layout);
 int mdct_frames_per_block(int log2nf, int layout);
 

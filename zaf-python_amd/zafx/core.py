@@ -575,21 +575,11 @@ def mel_plan(window_function, step_length, mel_filterbank, number_coefficients=N
     return _cached(key, make)
 
 
-_LDS_BYTES = 160 * 1024
-
-
-def _cqt_f32_lds_bytes(fft_length, nnz_per_row):
-    """LDS the float32 k_cqt needs for a kernel with these row lengths (mirrors CqtCfg / run_cqt in zafx_cqt.hip)."""
-    n = fft_length // 2
-    log2n = n.bit_length() - 1
-    split = log2n == 14
-    slots = 16 * 1090 if split else n + n // 16 + 1
-    nhi = n >> 7 if log2n > 7 else 1
-    nh2 = n >> 8 if log2n > 8 else 1
-    head = -(-(slots + nhi + 128 + nh2 + 128 + (136 if split else 0)) * 8 // 16) * 16
-    chunks = int(np.sum(np.maximum(1, -(-np.asarray(nnz_per_row) // 64))))
-    waves = max(1, (n >> (4 if log2n >= 10 else (log2n - 6 if log2n >= 7 else 1))) // 64)
-    return head + chunks * 16 + len(nnz_per_row) * 96 + (waves + 1) * 4
+def _cqt_f32_max_bins(fft_length):
+    """Rows of a kernel matrix the float32 k_cqt holds at this fft_length (zafx_cqt_max_bins); 0 outside its sizes."""
+    n = ctypes.c_int(0)
+    _lib.check(_lib.load().zafx_cqt_max_bins(int(fft_length), ctypes.byref(n)), "zafx_cqt_max_bins")
+    return n.value
 
 
 def cqt_plan(sampling_frequency, time_resolution, cqt_kernel, octave_resolution=None, layout="FT", device=0, row_align=0, f64=False):
@@ -602,10 +592,11 @@ def cqt_plan(sampling_frequency, time_resolution, cqt_kernel, octave_resolution=
     if fft_length < 512 or fft_length > 131072 or fft_length & (fft_length - 1):
         raise ValueError(f"zafx CQT kernels need a power-of-two fft_length in [512, 131072], got {fft_length}")
     # a frame above 32768 samples does not fit LDS as float32 pairs: those kernels run on the float64 kernel, which
-    # decimates the frame (lower minimum frequencies: 27.5 Hz at 44.1 kHz gives 65536); so do kernels whose rows do not
-    # fit beside the frame (k_cqt keeps the whole frame + the kernel's row bookkeeping in the 160 KB of LDS)
+    # decimates the frame (lower minimum frequencies: 27.5 Hz at 44.1 kHz gives 65536); so do kernels with more rows than
+    # fit beside the frame (k_cqt keeps the whole frame + one output column of the kernel's rows in the 160 KB of LDS:
+    # about 4 000 rows at fft_length 32768 -- the reference's own 208-row example is far inside)
     csr = cqt_kernel.tocsr()
-    f64 = bool(f64) or fft_length > 32768 or _cqt_f32_lds_bytes(fft_length, np.diff(csr.indptr)) > _LDS_BYTES
+    f64 = bool(f64) or fft_length > 32768 or n_bins > _cqt_f32_max_bins(fft_length)
     chroma = octave_resolution is not None
     key = ("chroma" if chroma else "cqt", device, fft_length, step, n_bins, int(octave_resolution or 0), _LAYOUTS[layout],
            _as_row_align(row_align, layout), bool(f64),

@@ -63,16 +63,22 @@ elif kind == "cqt":
     d_out = zafx.DeviceBuffer((B, F, T), np.float32)
 else:
     raise SystemExit("kind must be istft, mdct, imdct or cqt")
-fn = getattr(lib, "zafx_debug_prof_" + {"mfcc": "mel", "stft1": "stft"}.get(kind, kind))
+name = "zafx_debug_prof_" + {"mfcc": "mel", "stft1": "stft"}.get(kind, kind)
+fn = getattr(lib, name)
 out = (ctypes.c_ulonglong * 16)()
-plan.execute(d_in, d_out, B, n_in)
-plan.sync()
-fn(out)
-reps = 5
-for _ in range(reps):
+# optional second argument: the waves to time, e.g. "0,5,15" or "all" (default: wave 1)
+waves = sys.argv[2] if len(sys.argv) > 2 else "1"
+waves = range(16) if waves == "all" else [int(v) for v in waves.split(",")]
+for wv in waves:
+    getattr(lib, name + "_thread")(wv * 64)
     plan.execute(d_in, d_out, B, n_in)
-plan.sync()
-fn(out)
-per_tile = reps * (16 if kind == 'cqt' else tiles * B / 256)   # cqt: workgroup 7 = 16 frames per launch, counts are per frame
-print(kind, "cycles per tile between marks:", " | ".join(f"{i}:{out[i] / per_tile:.0f}" for i in range(10)),
-      "| total", round(sum(out) / per_tile))
+    plan.sync()
+    fn(out)
+    reps = 5
+    for _ in range(reps):
+        plan.execute(d_in, d_out, B, n_in)
+    plan.sync()
+    fn(out)
+    per_tile = reps * (16 if kind == 'cqt' else tiles * B / 256)   # cqt: workgroup 7 = 16 frames per launch, counts are per frame
+    print(kind, f"wave {wv}: cycles per tile between marks:", " | ".join(f"{i}:{out[i] / per_tile:.0f}" for i in range(10)),
+          "| total", round(sum(out) / per_tile))

@@ -295,26 +295,25 @@ static int build_cqt_chunks(zafx_plan* pl) {
     for (int s : by_len) {
         const int wv = (int)(std::min_element(load.begin(), load.end()) - load.begin());
         per_wave[(size_t)wv].push_back(s);
-        load[(size_t)wv] += steps[(size_t)s].iters + 3;   // (a step end costs about three iterations: reductions + the tile write)
+        load[(size_t)wv] += steps[(size_t)s].iters + 4;   // (a step end costs about four iterations: reductions + the tile write)
     }
     // flatten: steps in wave order, entries as [iteration][lane]
-    std::vector<int> step_tab, wave_tab;
+    std::vector<int> wave_tab;
     std::vector<int32_t> addrs;
     std::vector<float> vals;
     int k_lo = n, k_hi = -1, special = 0, max_iters = 0;
     for (int wv = 0; wv < n_waves; ++wv) {
-        const int it0 = (int)addrs.size() / 64, s0 = (int)step_tab.size() / 8;
+        const int it0 = (int)addrs.size() / 64;
         unsigned mask = 0;
         int it = 0;
         for (int s : per_wave[(size_t)wv]) {
             const Step& st = steps[(size_t)s];
             const int gl = st.lanes / 16;   // DPP rows per matrix row
-            for (int g = 0; g < 4; ++g) step_tab.push_back(g % gl == gl - 1 ? st.row_of_group[g] : -1);   // the group's last DPP row writes
-            step_tab.push_back(st.iters | (st.lanes << 16)); step_tab.push_back(0); step_tab.push_back(0); step_tab.push_back(0);
+            const int shape = st.lanes == 16 ? 1 : st.lanes == 32 ? 2 : 3;
             for (int i = 0; i < st.iters; ++i)
                 for (int l = 0; l < 64; ++l) {
-                    const int row = st.row_of_group[l >> 4], j = (l & (st.lanes - 1)) + st.lanes * i;
-                    int32_t addr = 0;
+                    const int g = l >> 4, row = st.row_of_group[g], j = (l & (st.lanes - 1)) + st.lanes * i;
+                    int32_t word = 0x7ff << 18;
                     cf32 v{0.f, 0.f};
                     if (row >= 0 && j < nnz_of(row)) {
                         const size_t e = (size_t)pl->h_indptr[(size_t)row] + (size_t)j;
@@ -322,13 +321,17 @@ static int build_cqt_chunks(zafx_plan* pl) {
                         if (c < 0 || c >= w) return fail_msg("CQT kernel column index out of range");
                         const int m = c <= n ? c : w - c;   // one-sided bin holding X[c] (conjugated when c > n)
                         const int slot = m == n ? cqt_nyquist_slot(pl->log2nf) : cqt_slot(pl->log2nf, m);
-                        addr = (int32_t)(slot * 8) | (c > n ? (int32_t)0x80000000 : 0);
+                        word |= (int32_t)(slot * 8) | (c > n ? (int32_t)0x80000000 : 0);
                         v = pl->h_values[e];
                         const int k = std::min(m, n - m);   // pair index of the real split
                         if (k == 0 || 2 * m == n) special = 1;
                         else k_lo = std::min(k_lo, k), k_hi = std::max(k_hi, k);
                     }
-                    addrs.push_back(addr);
+                    if (i == st.iters - 1) {   // the step ends here: shape in every lane, the row in the last lane of its lane group
+                        word |= shape << 29;
+                        if ((l & 15) == 15 && g % gl == gl - 1 && row >= 0) word = (word & ~(0x7ff << 18)) | (row << 18);
+                    }
+                    addrs.push_back(word);
                     vals.push_back(v.re);
                     if (!pl->cqt_real) vals.push_back(v.im);
                 }
@@ -336,19 +339,16 @@ static int build_cqt_chunks(zafx_plan* pl) {
             if (it <= 32) mask |= 1u << (it - 1);
         }
         max_iters = std::max(max_iters, it);
-        wave_tab.insert(wave_tab.end(), {it0, it, s0, (int)per_wave[(size_t)wv].size(), (int)mask, 0, 0, 0});
+        wave_tab.insert(wave_tab.end(), {it0, it, (int)mask, 0});
     }
     pl->cqt_resident = max_iters <= kCqtResident ? kCqtResident : 0;
-    pl->cqt_n_steps = (int)step_tab.size() / 8;
     pl->cqt_n_entries = (int)addrs.size();
     pl->cqt_k_lo = k_lo;
     pl->cqt_k_hi = k_hi;
     pl->cqt_k_special = special;
     if (addrs.empty()) addrs.assign(64, 0), vals.assign(pl->cqt_real ? 64 : 128, 0.f);
-    if (step_tab.empty()) step_tab.assign(8, 0);
     ZAFX_HIP(upload(&pl->d_cqt_addrs, addrs.data(), addrs.size() * sizeof(int32_t)));
     ZAFX_HIP(upload(&pl->d_cqt_vals, vals.data(), vals.size() * sizeof(float)));
-    ZAFX_HIP(upload(&pl->d_cqt_steps, step_tab.data(), step_tab.size() * sizeof(int)));
     ZAFX_HIP(upload(&pl->d_cqt_waves, wave_tab.data(), wave_tab.size() * sizeof(int)));
     pl->cqt_dirty = false;
     return 0;
@@ -630,7 +630,6 @@ int zafx_plan_destroy(zafx_plan* pl) {
     if (pl->d_indices) (void)hipFree(pl->d_indices);
     if (pl->d_values) (void)hipFree(pl->d_values);
     if (pl->d_cqt_waves) (void)hipFree(pl->d_cqt_waves);
-    if (pl->d_cqt_steps) (void)hipFree(pl->d_cqt_steps);
     if (pl->d_cqt_addrs) (void)hipFree(pl->d_cqt_addrs);
     if (pl->d_cqt_vals) (void)hipFree(pl->d_cqt_vals);
     if (pl->d_window64) (void)hipFree(pl->d_window64);

@@ -4,24 +4,29 @@
 //     cqt[:, j] = abs(cqt_kernel * np.fft.fft(xpad[j*step : j*step + fft_len]))
 // with cqt_kernel a sparse (n_bins x fft_len) complex CSR matrix (zaf.py:554-557).
 //
-// One workgroup owns FW (16, fewer when the kernel matrix has many rows) consecutive frames of one clip and
-// transforms them one after the other: the whole frame (fft_len real = N = fft_len/2 complex points, up to
-// 128 KiB) lives in LDS, owned by N/16 threads (1024 for fft_len 32768).  Frames of a tile overlap by
-// (fft_len - step)/fft_len (94.6 % at config Q), so the re-reads of the input hit L2; HBM sees each sample about
-// once per tile.  After the real split the CSR rows are contracted against the one-sided spectrum in LDS:
+// Persistent workgroups, one per CU, each transforming one frame at a time: the whole frame (fft_len real = N =
+// fft_len/2 complex points, up to 128 KiB) lives in LDS, owned by N/16 threads (1024 for fft_len 32768).
+// Frames overlap by (fft_len - step)/fft_len (94.6 % at config Q), and the work is dealt out so that the overlap is
+// served by the L2 of ONE chiplet: the workgroups of an XCD (block b runs on XCD b % 8) share a list of clips and
+// take its frames round-robin -- at any time the 32 CUs of an XCD read ~32 neighbouring frames (0.35 MB of samples
+// against 4 MB of L2), so a sample crosses the fabric once and the other reads hit L2.  (Tiles of 16 consecutive
+// frames per workgroup put 32 x 237 KB of live samples on each XCD: every re-read missed L2, 8.3 x the input over the
+// fabric and 4 ... 6 k cycles per frame of blocked load issue; profiles/r02_notes.md.)
+// After the real split the CSR rows are contracted against the one-sided spectrum in LDS:
 //   * the host sorts the rows by length and deals them out in "steps": a wavefront works on four short rows at once
 //     (one per 16-lane DPP row, lane j of a row taking its entries j, j + 16, j + 32, ...), on two medium rows (32 lanes
 //     each) or on one long row (64 lanes); a step ends with ONE pair of DPP reductions (row sums, + row_bcast for the
 //     wider shapes) for all its rows, and the last lane of a row's lane group writes |.|^2 straight into the LDS
-//     tile -- no partial sums in LDS, no finishing pass;
-//   * a wave's share of the matrix (value + LDS byte address of the spectrum bin per entry) stays in REGISTERS across
-//     the frames of the tile when it fits (<= 12 entries per lane: config Q has 9 450 non-zeros, 12 iterations on
+//     column -- no partial sums in LDS, no finishing pass;
+//   * a wave's share of the matrix (value + LDS byte address of the spectrum bin per entry) stays in REGISTERS for the
+//     whole launch when it fits (<= 12 entries per lane: config Q has 9 450 non-zeros, 12 iterations on
 //     the busiest wave); larger matrices (the reference's own cqtkernel example, 60 879 non-zeros) stream it from L2
 //     every frame;
 //   * a numerically real matrix (the reference's kernels are: max |imag| / max |real| = 1e-16) is contracted as
 //     real x complex.
-// The magnitudes of the tile's frames are staged in LDS so that the (n_bins, T) store writes 64-B runs along t.
-// The chromagram (zaf.py:693-698) is a strided row sum over that LDS tile.
+// A frame's |.|^2 column is staged in LDS and stored by the first n_bins threads: 4-byte stores along the row pitch in
+// the reference layout, which the XCD's L2 merges with the neighbouring frames written by its other CUs.
+// The chromagram (zaf.py:693-698) is a strided row sum over that LDS column.
 #include <algorithm>
 
 #include "zafx_fft.hpp"
@@ -56,9 +61,9 @@ __device__ __forceinline__ float bcast31_add(float v) {
 template <int LOG2N, int LOG2E, bool ALIGNED, bool REALK, int RES>
 __global__ __launch_bounds__(fft_threads(LOG2N, LOG2E)) void k_cqt(
     const float* __restrict__ x, const float2* __restrict__ twp, const float2* __restrict__ tws,
-    const int4* __restrict__ wave_tab, const int4* __restrict__ step_tab, const int* __restrict__ addrs, const float* __restrict__ values,
-    float* __restrict__ out, long long n_samples, int step, int left_pad, int T, int TP, int tiles, int n_bins, int chroma_res, int layout,
-    int n_steps, int FW, int k_lo, int k_hi, int k_special, int n_entries) {
+    const int4* __restrict__ wave_tab, const int* __restrict__ addrs, const float* __restrict__ values,
+    float* __restrict__ out, long long n_samples, int step, int left_pad, int T, int TP, int n_clips, int n_groups, int n_bins, int chroma_res,
+    int layout, int k_lo, int k_hi, int k_special, int n_entries) {
     using C = FftCfg<LOG2N, LOG2E>;
     using G = CqtCfg<LOG2N, LOG2E>;
     using KV = std::conditional_t<REALK, float, float2>;
@@ -74,37 +79,27 @@ __global__ __launch_bounds__(fft_threads(LOG2N, LOG2E)) void k_cqt(
     float2* sub_hi = sp_lo + 128;                                 // (SPLIT) two-level root table of 1024
     auto slot_of = [](int k) { return cqt_slot(LOG2N, k); };
     constexpr int NYQ = cqt_nyquist_slot(LOG2N);
-    int4* wave_l = reinterpret_cast<int4*>(smem_raw + G::HEAD);   // [P / 64] {first iteration, iterations, first step, steps}
-    int* mask_l = reinterpret_cast<int*>(wave_l + P / 64);        // [P / 64] bit i: iteration i of the wave ends a step (resident form)
-    int4* step_l = reinterpret_cast<int4*>(mask_l + ((P / 64 + 3) & ~3));   // [n_steps] rows of the step's four DPP rows (-1: none) ...
-    int* iters_l = reinterpret_cast<int*>(step_l + n_steps);      // [n_steps] ... and its iteration count | lanes per row (16, 32, 64) << 16
-    float* tile = reinterpret_cast<float*>(iters_l + ((n_steps + 3) & ~3));   // [n_bins][FW]
+    int4* wave_l = reinterpret_cast<int4*>(smem_raw + G::HEAD);   // [P / 64] {first iteration, iterations, step-end mask of the resident form, 0}
+    float* mags = reinterpret_cast<float*>(wave_l + P / 64);      // [n_bins] |.|^2 of the current frame
     const int p = threadIdx.x;
     for (int i = p; i < NHI + 128; i += P) tw_hi[i] = twp[i];
     if constexpr (G::SPLIT)
         for (int i = p; i < G::NSUB; i += P) sub_hi[i] = twp[NHI + 128 + i];
     for (int i = p; i < NH2 + 128; i += P) sp_hi[i] = tws[i];
-    for (int i = p; i < P / 64; i += P) {
-        wave_l[i] = wave_tab[2 * i];
-        mask_l[i] = wave_tab[2 * i + 1].x;
-    }
-    for (int i = p; i < n_steps; i += P) {
-        const int4 s = step_tab[2 * i], m = step_tab[2 * i + 1];
-        step_l[i] = s;
-        iters_l[i] = m.x;
-    }
+    for (int i = p; i < P / 64; i += P) wave_l[i] = wave_tab[i];
     lds_barrier();
     const TwoLevelTw tw2l{tw_hi, tw_lo};
     const int wave = p >> 6;
-    const int clip = blockIdx.x / tiles, tl = blockIdx.x % tiles;
-    const int t0 = tl * FW;
-    const float* xc = x + (long long)clip * n_samples;
+    // work list of this workgroup: group = blockIdx % n_groups (the XCD when n_groups = 8) owns clips group, group +
+    // n_groups, ...; its frames, clip after clip, are dealt round-robin to the group's workgroups
+    const int group = blockIdx.x % n_groups, slot = blockIdx.x / n_groups;
+    const int n_slots = (gridDim.x - group + n_groups - 1) / n_groups;
+    const long long n_work = (long long)((n_clips - group + n_groups - 1) / n_groups) * T;
     // wave-uniform values read from LDS land in VGPRs; readfirstlane tells the compiler they are scalars
     // (scalar branches and SGPR operands instead of exec-mask juggling)
     const int4 wt = wave_l[wave];
     const int it0 = __builtin_amdgcn_readfirstlane(wt.x), n_it = __builtin_amdgcn_readfirstlane(wt.y);
-    const int s0 = __builtin_amdgcn_readfirstlane(wt.z), s1 = s0 + __builtin_amdgcn_readfirstlane(wt.w);
-    const int endmask = __builtin_amdgcn_readfirstlane(mask_l[wave]);
+    const int endmask = __builtin_amdgcn_readfirstlane(wt.z);
     const auto raddr = make_rsrc(addrs, (unsigned)n_entries * 4u);
     const auto rvals = make_rsrc(values, (unsigned)n_entries * (unsigned)sizeof(KV));
     auto load_kv = [&](int voff_entries) -> KV {
@@ -112,7 +107,7 @@ __global__ __launch_bounds__(fft_threads(LOG2N, LOG2E)) void k_cqt(
         else return buf_load_f32x2(rvals, voff_entries * 8);
     };
 
-    // ---- a wave's share of the kernel matrix, resident in registers for the whole tile
+    // ---- a wave's share of the kernel matrix, resident in registers for the whole launch
     KV kv[RESIDENT ? RES : 1];
     int ad[RESIDENT ? RES : 1];
     if constexpr (RESIDENT) {
@@ -128,19 +123,59 @@ __global__ __launch_bounds__(fft_threads(LOG2N, LOG2E)) void k_cqt(
     // unconditional 8-byte loads; the zero-padded edge frames take the predicated path.
     float2 v[E];
     const unsigned clip_bytes = (unsigned)std::min<long long>(n_samples * 4, 0xfffffffcLL);
-    const auto rx = make_rsrc(xc, clip_bytes);
-    auto load_frame = [&](int t, int p) {   // p: thread id (an opaque copy inside the frame loop)
+    // returns true when v holds the raw 16-byte loads of the split form (unpack_pairs() before the first pass)
+    auto load_frame = [&](long long g, int p) -> bool {   // g: index into the group's frame list; p: thread id (an opaque copy inside the frame loop)
+        const int clip = group + (int)((unsigned)g / (unsigned)T) * n_groups, t = (int)((unsigned)g % (unsigned)T);   // (g < 2^31: zafx_execute)
+        const auto rx = make_rsrc(x + (long long)clip * n_samples, clip_bytes);
         const long long s0 = (long long)t * step - left_pad;
         if (ALIGNED && s0 >= 0 && s0 + W <= n_samples) {
-            const int voff = ((int)s0 + 2 * p) * 4;
+            if constexpr (G::SPLIT) {
+                // 16-byte lanes: a CU pulls a 128-KB frame out of L2 in 3.5 k cycles with them, 5.8 k with 8-byte lanes
+                // (tools/exp_cqtload.hip).  The lane pair (2q, 2q + 1) shares its loads: the even lane fetches the points
+                // (2q, 2q + 1) + 1024 r for r = 0 .. 7, the odd lane for r = 8 .. 15; each keeps its own point, sends the
+                // other's across (DPP swap inside the pair).  The odd lane thus holds its 16 points rotated by 8, i.e. its
+                // radix-16 outputs carry (-1)^k -- absorbed by negating its base twiddle in first_pass.
+                const int odd = p & 1;
+                const int voff = ((int)s0 + 2 * (p - odd)) * 4 + odd * (8 * P * 8);
 #pragma unroll
-            for (int i = 0; i < E; ++i) v[i] = buf_load_f32x2(rx, voff, i * P * 8);
+                for (int i = 0; i < 8; ++i) {   // raw: (v[2i], v[2i+1]) = the lane's two points of load i; unpack_pairs() sorts them out
+                    const float4 q = buf_load_f32x4(rx, voff, i * P * 8);
+                    v[2 * i] = make_float2(q.x, q.y);
+                    v[2 * i + 1] = make_float2(q.z, q.w);
+                }
+                return true;
+            } else {
+                const int voff = ((int)s0 + 2 * p) * 4;
+#pragma unroll
+                for (int i = 0; i < E; ++i) v[i] = buf_load_f32x2(rx, voff, i * P * 8);
+            }
         } else {
+            const int rot = G::SPLIT ? 8 * (p & 1) : 0;   // (split form: odd lanes hold their points rotated by 8, as above)
 #pragma unroll
             for (int i = 0; i < E; ++i) {
-                const long long s = s0 + 2 * (p + i * P);
+                const long long s = s0 + 2 * (p + ((i + rot) & (E - 1)) * P);
                 v[i].x = (s >= 0 && s < n_samples) ? buf_load_f32(rx, (int)s * 4) : 0.f;
                 v[i].y = (s + 1 >= 0 && s + 1 < n_samples) ? buf_load_f32(rx, (int)(s + 1) * 4) : 0.f;
+            }
+        }
+        return false;
+    };
+    // the pair exchange of the 16-byte loads (see load_frame), done when the data is needed -- not where it was requested
+    auto unpack_pairs = [&](int p) {
+        if constexpr (G::SPLIT) {
+            const int odd = p & 1;
+            float2 lo[8], hi[8];
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                lo[i] = v[2 * i];
+                hi[i] = v[2 * i + 1];
+            }
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const float2 keep = odd ? hi[i] : lo[i], send = odd ? lo[i] : hi[i];
+                v[i] = keep;
+                v[i + 8].x = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, send.x), 0xB1, 0xf, 0xf, true));
+                v[i + 8].y = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, send.y), 0xB1, 0xf, 0xf, true));
             }
         }
     };
@@ -153,22 +188,21 @@ __global__ __launch_bounds__(fft_threads(LOG2N, LOG2E)) void k_cqt(
             Dft<16>::run(v);
             float2 w[16];
             w[1] = tw2(tw2l, p);
+            if (p & 1) w[1] = make_float2(-w[1].x, -w[1].y);   // odd lanes hold their points rotated by 8: (-1)^k on output k (load_frame)
 #pragma unroll
             for (int r = 2; r < 16; ++r) w[r] = cmul(w[r >> 1], w[r - (r >> 1)]);
 #pragma unroll
             for (int r = 1; r < 16; ++r) v[r] = cmul(v[r], w[r]);
         }
     };
-    if (t0 < T) {
-        load_frame(t0, threadIdx.x);
+    if (slot < n_work) {
+        if (load_frame(slot, threadIdx.x)) unpack_pairs(threadIdx.x);
         first_pass(threadIdx.x);
     }
     PROF_INIT(g_prof_cqt);
 
 #pragma unroll 1
-    for (int jj = 0; jj < FW; ++jj) {
-        const int t = t0 + jj;
-        if (t >= T) break;   // uniform across the block
+    for (long long g = slot; g < n_work; g += n_slots) {
         PROF_MARK(0);
         // Opaque copy of the thread id: everything below recomputes its (cheap) per-lane LDS and buffer
         // offsets every frame.  Left to itself the compiler hoists ~50 of them out of the loop and
@@ -193,9 +227,8 @@ __global__ __launch_bounds__(fft_threads(LOG2N, LOG2E)) void k_cqt(
             fft_frame_chain<LOG2N, LOG2E>(v, buf, p, tw2l);
         }
         PROF_MARK(1);
-        // the next frame's samples: v is dead until the next first pass, the loads fly under the split + contraction
-        const bool more = jj + 1 < FW && t + 1 < T;
-        if (more) load_frame(t + 1, p);
+        const bool more = g + n_slots < n_work;
+        bool raw = false;
         // ---- real split in place, only for the pairs (k, N-k) that the kernel's columns touch:
         // slots 0..N-1 <- X[0..N-1], slot NYQ <- X[N];  t_k = exp(-2 pi i k / 2N) = sp_hi[k >> 7] sp_lo[k & 127]
         if (k_special && p == 0) {
@@ -205,25 +238,27 @@ __global__ __launch_bounds__(fft_threads(LOG2N, LOG2E)) void k_cqt(
             buf[slot_of(N / 2)] = cconj(zc);
         }
         for (int k = k_lo + p; k <= k_hi; k += P) {
-            const float2 zk = buf[slot_of(k)], zn = buf[slot_of(N - k)];
-            const float2 tk = cmul(sp_hi[k >> 7], sp_lo[k & 127]);
-            const float2 e = make_float2(0.5f * (zk.x + zn.x), 0.5f * (zk.y - zn.y));
-            const float2 d = make_float2(0.5f * (zk.x - zn.x), 0.5f * (zk.y + zn.y));
-            const float2 to = cmul(tk, make_float2(d.y, -d.x));
-            buf[slot_of(k)] = cadd(e, to);
-            buf[slot_of(N - k)] = cconj(csub(e, to));
+            float2 xk, xn;
+            split_pair(buf[slot_of(k)], buf[slot_of(N - k)], cmul(sp_hi[k >> 7], sp_lo[k & 127]), xk, xn);
+            buf[slot_of(k)] = xk;
+            buf[slot_of(N - k)] = xn;
         }
         PROF_MARK(2);
         lds_barrier();
         PROF_MARK(3);
-        // ---- CSR mat-vec against the spectrum + |.|^2 (zaf.py:630-632).  Lane (g, j) = (lane >> 4, lane & 15) of the
-        // wave's current step works on row step_l[s][g]; entry (iteration it, lane) carries the value and the LDS byte
-        // address of its spectrum bin (bit 31: conjugate, a column of the upper half); padding entries are 0 * bin 0.
+        // The next frame's samples: v is dead until the next first pass.  Requested AFTER the split: 16 wavefronts x 16
+        // loads overrun the CU's vector-memory queue, and a wave that blocks there ahead of its share of the split holds
+        // the whole workgroup at the barrier (profiles/r02_notes.md; requested ahead of the split: 30.8 instead of 29.6 ms).
+        if (more) raw = load_frame(g + n_slots, p);
+        PROF_MARK(7);
+        // ---- CSR mat-vec against the spectrum + |.|^2 (zaf.py:630-632).  Entry (iteration, lane) of the wave's share is a
+        // value and a word: bits 0-17 the LDS byte address of its spectrum bin, bit 31 "conjugate" (a column of the upper
+        // half), bits 29-30 (the same in all lanes) 0 or the shape 1 / 2 / 3 = 16 / 32 / 64 lanes per row of a step that ENDS
+        // with this iteration, bits 18-28 the row this lane then writes (0x7ff: none).  Padding entries are 0 * bin 0.
         {
             float ar = 0.f, ai = 0.f;
             auto mac = [&](KV k, int a) {
-                asm volatile("" : "+v"(a));   // (the masks below are frame-invariant: hoisted they would cost two more registers per resident entry)
-                float2 xv = *reinterpret_cast<const float2*>(smem_raw + (a & 0x7fffffff));
+                float2 xv = *reinterpret_cast<const float2*>(smem_raw + (a & 0x3ffff));
                 xv.y = __builtin_bit_cast(float, __builtin_bit_cast(int, xv.y) ^ (a & (int)0x80000000));
                 if constexpr (REALK) {
                     ar = fmaf(k, xv.x, ar);
@@ -233,96 +268,94 @@ __global__ __launch_bounds__(fft_threads(LOG2N, LOG2E)) void k_cqt(
                     ai += k.x * xv.y + k.y * xv.x;
                 }
             };
-            auto finish = [&](int s) {   // end of a step: one reduction pair serves all its rows
-                const int4 rows = step_l[s];
-                const int shape = __builtin_amdgcn_readfirstlane(iters_l[s]) >> 16;
+            auto finish = [&](int a, int shape) {   // end of a step: one reduction pair serves all its rows
                 ar = row16_sum(ar);
                 ai = row16_sum(ai);
-                if (shape >= 32) {
+                if (shape >= 2) {
                     ar = bcast15_add(ar);
                     ai = bcast15_add(ai);
                 }
-                if (shape == 64) {
+                if (shape == 3) {
                     ar = bcast31_add(ar);
                     ai = bcast31_add(ai);
                 }
-                const int g = lane >> 4;
-                const int row = g == 0 ? rows.x : g == 1 ? rows.y : g == 2 ? rows.z : rows.w;   // (-1 for lane groups that end no row)
-                if ((lane & 15) == 15 && row >= 0) tile[row * FW + jj] = ar * ar + ai * ai;   // (the square root is taken when the tile is stored)
+                const int row = (a >> 18) & 0x7ff;
+                if (row != 0x7ff) mags[row] = ar * ar + ai * ai;   // (the square root is taken when the column is stored)
                 ar = 0.f;
                 ai = 0.f;
             };
             if constexpr (RESIDENT) {
-                // every wave runs RES iterations (padding entries are 0 * bin 0); the step ends are scalar bit tests on a mask
-                // that is re-read every frame -- hoisted out of the frame loop the RES conditions cost 2 SGPRs each and spill
-                int s = s0, em = endmask;
-                asm volatile("" : "+s"(em));
+                // Scalar conditions on values that are re-read every frame: hoisted out of the frame loop the RES
+                // comparisons cost 2 SGPRs each and spill, and the address masks two more VGPRs per entry.
+                int em = endmask, ni = n_it;
+                asm volatile("" : "+s"(em), "+s"(ni));
 #pragma unroll
                 for (int i = 0; i < RES; ++i) {
-                    mac(kv[i], ad[i]);
-                    if (em & (1 << i)) finish(s++);
+                    if (i < ni) {
+                        int a = ad[i];
+                        asm volatile("" : "+v"(a));
+                        mac(kv[i], a);
+                        if (em & (1 << i)) finish(a, (__builtin_amdgcn_readfirstlane(a) >> 29) & 3);
+                    }
                 }
             } else {
-                constexpr int GR = 4;   // iterations requested together
-                int it = it0;
-                for (int s = s0; s < s1; ++s) {
-                    const int ni = __builtin_amdgcn_readfirstlane(iters_l[s]) & 0xffff;
-                    for (int b = 0; b < ni; b += GR) {
-                        KV kq[GR];
-                        int aq[GR];
+                constexpr int GR = 8;   // iterations requested together
+                for (int b = 0; b < n_it; b += GR) {
+                    KV kq[GR];
+                    int aq[GR];
 #pragma unroll
-                        for (int g = 0; g < GR; ++g) {
-                            const int e = b + g < ni ? (it + b + g) * 64 + lane : -1;
-                            aq[g] = buf_load_i32(raddr, e * 4);
-                            kq[g] = load_kv(e);
-                        }
-#pragma unroll
-                        for (int g = 0; g < GR; ++g)
-                            if (b + g < ni) mac(kq[g], aq[g]);
+                    for (int g = 0; g < GR; ++g) {
+                        const int e = b + g < n_it ? (it0 + b + g) * 64 + lane : -1;
+                        aq[g] = buf_load_i32(raddr, e * 4);
+                        kq[g] = load_kv(e);
                     }
-                    it += ni;
-                    finish(s);
+#pragma unroll
+                    for (int g = 0; g < GR; ++g) {
+                        if (b + g < n_it) {
+                            mac(kq[g], aq[g]);
+                            const int shape = (__builtin_amdgcn_readfirstlane(aq[g]) >> 29) & 3;
+                            if (shape) finish(aq[g], shape);
+                        }
+                    }
                 }
             }
         }
         PROF_MARK(4);
-        if (more) first_pass(p);   // (waits for the prefetched samples; the other waves are still contracting)
+        if (more) {   // (waits for the prefetched samples; the other waves are still contracting)
+            if (raw) unpack_pairs(p);
+            first_pass(p);
+        }
         PROF_MARK(5);
         lds_barrier();
         PROF_MARK(6);
-    }
-    lds_barrier();
-
-    // ---- store the tile (FW * 4-B runs along t in the reference layout)
-    const int nvalid = min(FW, T - t0);
-    if (chroma_res > 0) {
-        for (int idx = p; idx < chroma_res * FW; idx += P) {
-            const int ch = idx / FW, jj = idx % FW;
-            if (jj >= nvalid) continue;
-            float acc = 0.f;
-            for (int r = ch; r < n_bins; r += chroma_res) acc += __builtin_amdgcn_sqrtf(tile[r * FW + jj]);   // zaf.py:696-698
-            if (layout == ZAFX_LAYOUT_FT) out[((long long)clip * chroma_res + ch) * TP + t0 + jj] = acc;   // TP = row pitch (>= T)
-            else out[((long long)clip * T + t0 + jj) * chroma_res + ch] = acc;
-        }
-    } else {
-        for (int idx = p; idx < n_bins * FW; idx += P) {
-            const int r = idx / FW, jj = idx % FW;
-            if (jj >= nvalid) continue;
-            const float val = __builtin_amdgcn_sqrtf(tile[idx]);
-            if (layout == ZAFX_LAYOUT_FT) out[((long long)clip * n_bins + r) * TP + t0 + jj] = val;
-            else out[((long long)clip * T + t0 + jj) * n_bins + r] = val;
+        // ---- store the frame's column (the next write of `mags` is three barriers away)
+        {
+            const int clip = group + (int)((unsigned)g / (unsigned)T) * n_groups, t = (int)((unsigned)g % (unsigned)T);   // (g < 2^31: zafx_execute)
+            if (chroma_res > 0) {
+                for (int ch = p; ch < chroma_res; ch += P) {
+                    float acc = 0.f;
+                    for (int r = ch; r < n_bins; r += chroma_res) acc += __builtin_amdgcn_sqrtf(mags[r]);   // zaf.py:696-698
+                    if (layout == ZAFX_LAYOUT_FT) out[((long long)clip * chroma_res + ch) * TP + t] = acc;   // TP = row pitch (>= T)
+                    else out[((long long)clip * T + t) * chroma_res + ch] = acc;
+                }
+            } else {
+                for (int r = p; r < n_bins; r += P) {
+                    const float val = __builtin_amdgcn_sqrtf(mags[r]);
+                    if (layout == ZAFX_LAYOUT_FT) out[((long long)clip * n_bins + r) * TP + t] = val;
+                    else out[((long long)clip * T + t) * n_bins + r] = val;
+                }
+            }
         }
     }
 }
 
-// LDS bytes of k_cqt for `frames` frames per tile; 0 when LOG2N is not built
+// LDS bytes of k_cqt
 template <int LOG2N>
-static size_t cqt_lds(int n_bins, int n_steps, int frames) {
+static size_t cqt_lds(int n_bins) {
     constexpr int LOG2E = default_log2e(LOG2N);
     using C = FftCfg<LOG2N, LOG2E>;
     using G = CqtCfg<LOG2N, LOG2E>;
-    return G::HEAD + (size_t)(C::P / 64) * 16 + (size_t)((C::P / 64 + 3) & ~3) * 4 + (size_t)n_steps * 16 + (size_t)((n_steps + 3) & ~3) * 4 +
-           (size_t)n_bins * frames * sizeof(float);
+    return G::HEAD + (size_t)(C::P / 64) * 16 + (size_t)n_bins * sizeof(float);
 }
 
 template <int LOG2N>
@@ -340,10 +373,7 @@ static hipError_t run_cqt(const zafx_plan& pl, const float* x, float* out, int64
         return !realk ? k_cqt<LOG2N, LOG2E, AL, false, 0> : res ? k_cqt<LOG2N, LOG2E, AL, true, kCqtResident> : k_cqt<LOG2N, LOG2E, AL, true, 0>;
     };
     auto kern = aligned ? pick(std::true_type{}) : pick(std::false_type{});
-    // frames per tile: 16 (64-B output runs) when the rows fit beside the frame, else 8, 4, 2, 1
-    int fw = 16;
-    while (fw > 1 && cqt_lds<LOG2N>(pl.prm.n_bins, pl.cqt_n_steps, fw) > (size_t)kMaxLdsBytes) fw >>= 1;
-    const size_t smem = cqt_lds<LOG2N>(pl.prm.n_bins, pl.cqt_n_steps, fw);
+    const size_t smem = cqt_lds<LOG2N>(pl.prm.n_bins);
     if (smem > (size_t)kMaxLdsBytes) {
         set_error("cqt: kernel matrix has too many rows for LDS at this fft_length");
         return hipErrorInvalidValue;
@@ -353,16 +383,15 @@ static hipError_t run_cqt(const zafx_plan& pl, const float* x, float* out, int64
         return hipErrorInvalidValue;
     }
     if (hipError_t e = ensure_dynamic_lds(reinterpret_cast<const void*>(kern), pl.device, smem); e != hipSuccess) return e;
-    const int tiles = (T + fw - 1) / fw;
-    const long long blocks = (long long)tiles * n_clips;
-    if (blocks <= 0) return hipSuccess;
-    if (blocks > 0x7fffffffLL) {
-        set_error("cqt: batch too large for one launch");
-        return hipErrorInvalidValue;
-    }
-    hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(C::P), smem, pl.stream, x, pl.d_tw_pass, pl.d_tw_aux, pl.d_cqt_waves, pl.d_cqt_steps,
-                       pl.d_cqt_addrs, pl.d_cqt_vals, out, (long long)n_samples, pl.H, left, T, (int)row_pitch(pl, T), tiles, pl.prm.n_bins,
-                       pl.kind == ZAFX_CHROMA ? pl.prm.octave_resolution : 0, pl.layout, pl.cqt_n_steps, fw, pl.cqt_k_lo, pl.cqt_k_hi,
+    if (n_clips * (long long)T <= 0) return hipSuccess;
+    // one persistent workgroup per CU (it needs nearly all of the CU's LDS), in n_groups groups that each share a list of clips;
+    // with >= 8 clips a group is an XCD (block b runs on XCD b % 8), fewer clips are shared by several XCDs
+    const int n_groups = (int)std::min<int64_t>(8, n_clips);
+    const long long per_group = ((n_clips + n_groups - 1) / n_groups) * (long long)T;   // frames of the longest list
+    const int grid = (int)std::min<long long>(std::max(pl.n_cus / n_groups, 1) * (long long)n_groups, per_group * n_groups);
+    hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(C::P), smem, pl.stream, x, pl.d_tw_pass, pl.d_tw_aux, pl.d_cqt_waves,
+                       pl.d_cqt_addrs, pl.d_cqt_vals, out, (long long)n_samples, pl.H, left, T, (int)row_pitch(pl, T), (int)n_clips, n_groups,
+                       pl.prm.n_bins, pl.kind == ZAFX_CHROMA ? pl.prm.octave_resolution : 0, pl.layout, pl.cqt_k_lo, pl.cqt_k_hi,
                        pl.cqt_k_special, std::max(pl.cqt_n_entries, 1));
     return hipGetLastError();
 }
@@ -371,17 +400,17 @@ bool cqt_supported(int log2n) { return log2n >= 8 && log2n <= 14; }
 int cqt_waves(int log2n) { return fft_threads(log2n, default_log2e(log2n)) / 64; }
 const char* cqt_kernel_name() { return "k_cqt"; }
 
-// Largest number of rows a float32 plan of this fft_length can hold (one frame per tile, ceil(rows / 4) steps)
+// Largest number of rows a float32 plan of this fft_length can hold, capped by the 11-bit row field of the entry words
 int cqt_max_bins(int log2n) {
     auto fit = [](auto tag) {
         constexpr int L = decltype(tag)::value;
         int lo = 0, hi = 1 << 20;
         while (lo < hi) {
             const int mid = (lo + hi + 1) / 2;
-            if (cqt_lds<L>(mid, (mid + 3) / 4, 1) <= (size_t)kMaxLdsBytes) lo = mid;
+            if (cqt_lds<L>(mid) <= (size_t)kMaxLdsBytes) lo = mid;
             else hi = mid - 1;
         }
-        return lo;
+        return std::min(lo, 0x7fe);
     };
     switch (log2n) {
         case 8: return fit(std::integral_constant<int, 8>{});

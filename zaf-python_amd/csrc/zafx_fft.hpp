@@ -99,6 +99,32 @@ ZAFX_HD float2 sub_mi(float2 a, float2 b) {   // a - (-i) b = (a.x - b.y, a.y + 
 #endif
 }
 ZAFX_HD float2 cscale(float2 a, float s) { return make_float2(a.x * s, a.y * s); }
+ZAFX_HD float2 cadd_conj(float2 a, float2 b) {   // a + conj(b)
+#if defined(ZAFX_PK)
+    zafx_v2f r;
+    asm("v_pk_add_f32 %0, %1, %2 neg_hi:[0,1]" : "=v"(r) : "v"(to_v2(a)), "v"(to_v2(b)));
+    return to_f2(r);
+#else
+    return make_float2(a.x + b.x, a.y - b.y);
+#endif
+}
+ZAFX_HD float2 csub_conj(float2 a, float2 b) {   // a - conj(b)
+#if defined(ZAFX_PK)
+    zafx_v2f r;
+    asm("v_pk_add_f32 %0, %1, %2 neg_lo:[0,1]" : "=v"(r) : "v"(to_v2(a)), "v"(to_v2(b)));
+    return to_f2(r);
+#else
+    return make_float2(a.x - b.x, a.y + b.y);
+#endif
+}
+// Real-input split of one (k, N-k) pair of a packed half-length transform: zk = Z[k], zn = Z[N-k], tk = exp(-2 pi i k / 2N).
+// X[k] = (E + t_k O), X[N-k] = conj(E - t_k O) with E = (zk + conj zn) / 2, O = -i (zk - conj zn) / 2: eight packed instructions.
+ZAFX_HD void split_pair(float2 zk, float2 zn, float2 tk, float2& xk, float2& xn) {
+    const float2 e = cadd_conj(zk, zn), u = cmul(csub_conj(zk, zn), tk);
+    const float2 a = add_mi(e, u), b = sub_mi(e, u);
+    xk = make_float2(0.5f * a.x, 0.5f * a.y);
+    xn = make_float2(0.5f * b.x, -0.5f * b.y);
+}
 
 // ---------------------------------------------------------------- pass schedule
 // log2 of the radix of the pass that starts with `rem` radix-2 stages left, when
@@ -349,6 +375,13 @@ __device__ __forceinline__ float2 buf_load_f32x2(__amdgpu_buffer_rsrc_t r, int v
     const auto raw = __builtin_amdgcn_raw_buffer_load_b64(r, voff, soff, 0);
     float2 f;
     __builtin_memcpy(&f, &raw, 8);
+    return f;
+}
+
+__device__ __forceinline__ float4 buf_load_f32x4(__amdgpu_buffer_rsrc_t r, int voff, int soff = 0) {
+    const auto raw = __builtin_amdgcn_raw_buffer_load_b128(r, voff, soff, 0);
+    float4 f;
+    __builtin_memcpy(&f, &raw, 16);
     return f;
 }
 

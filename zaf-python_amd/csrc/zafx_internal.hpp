@@ -76,11 +76,11 @@ struct zafx_plan {
     // k_cqt's view of the kernel matrix (build_cqt_chunks in zafx_capi.cpp): rows sorted by length and dealt out in "steps"
     // (four rows of 16 lanes, two of 32 or one of 64), steps dealt to the wavefronts; entry (iteration, lane) = value + LDS
     // byte address of its spectrum bin
-    int4* d_cqt_waves = nullptr;   // [waves][2]: {first iteration, iterations, first step, steps}, {step-end mask, 0, 0, 0}
-    int4* d_cqt_steps = nullptr;   // [steps][2]: row that ends in each of the four DPP rows (-1: none), {iterations | lanes per row << 16, 0, 0, 0}
-    int* d_cqt_addrs = nullptr;    // [iterations][64]: byte address of the bin in the LDS spectrum image (bit 31 = conjugate)
+    int4* d_cqt_waves = nullptr;   // [waves]: {first iteration, iterations, step-end mask (bit i: iteration i ends a step), 0}
+    int* d_cqt_addrs = nullptr;    // [iterations][64]: bits 0-17 byte address of the bin in the LDS spectrum image, 31 conjugate, 29-30 shape of
+                                   // a step that ends here (0: none), 18-28 row this lane then writes (0x7ff: none)  (zafx_cqt.hip)
     float* d_cqt_vals = nullptr;   // [iterations][64] float (real matrix) or float2
-    int cqt_n_steps = 0, cqt_n_entries = 0;
+    int cqt_n_entries = 0;
     bool cqt_real = false;
     int cqt_resident = 0;          // kCqtResident: the busiest wave's iterations fit the registers; 0: entries streamed from L2 every frame
     float2* d_tw_r32 = nullptr;    // pass twiddles of the radix-32 schedule (1024 points as 32 x 32), STFT plans of W = 2048
@@ -175,17 +175,19 @@ hipError_t ensure_dynamic_lds(const void* kernel, int device, size_t bytes);
 // One wave of one workgroup accumulates the cycles between consecutive PROF_MARKs.
 // ---------------------------------------------------------------------------------
 #ifdef ZAFX_PROF
-#define ZAFX_PROF_ARRAY(name) __device__ unsigned long long name[16];
+#define ZAFX_PROF_ARRAY(name) __device__ unsigned long long name[16]; __device__ int name##_thread = 64;   // thread whose wave is timed
 #define PROF_INIT(name)                            \
     unsigned long long* const prof_ = name;        \
+    const int prof_thread_ = name##_thread;        \
     unsigned long long tprev_ = __builtin_readcyclecounter()
 #define PROF_MARK(i)                                                                       \
     do {                                                                                   \
         const unsigned long long now_ = __builtin_readcyclecounter();                     \
-        if (blockIdx.x == 7 && threadIdx.x == 64) atomicAdd(&prof_[i], now_ - tprev_);   \
+        if (blockIdx.x == 7 && (int)threadIdx.x == prof_thread_) atomicAdd(&prof_[i], now_ - tprev_);   \
         tprev_ = now_;                                                                     \
     } while (0)
 #define ZAFX_PROF_EXPORT(fn, name)                                                                  \
+    extern "C" int fn##_thread(int t) { return hipMemcpyToSymbol(HIP_SYMBOL(zafx::name##_thread), &t, sizeof(t)) != hipSuccess; } \
     extern "C" int fn(unsigned long long* out) {                                                    \
         unsigned long long zero[16] = {};                                                           \
         if (hipMemcpyFromSymbol(out, HIP_SYMBOL(zafx::name), sizeof(zero)) != hipSuccess) return 1; \

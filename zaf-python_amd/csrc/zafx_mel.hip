@@ -184,12 +184,7 @@ __global__ __launch_bounds__(mel_threads(LOG2N, LOG2E)) void k_mel(
                     xk = zc;                                  // |X[N/2]| = |Z[N/2]|
                     xn = make_float2(z0.x - z0.y, 0.f);       // X[N] (Nyquist, kept: zaf.py:370)
                 } else {
-                    const float2 zk = buf[phys_t<C::PS>(k)], zn = buf[phys_t<C::PS>(N - k)];
-                    const float2 e = make_float2(0.5f * (zk.x + zn.x), 0.5f * (zk.y - zn.y));
-                    const float2 d = make_float2(0.5f * (zk.x - zn.x), 0.5f * (zk.y + zn.y));
-                    const float2 to = cmul(tws_l[k], make_float2(d.y, -d.x));
-                    xk = cadd(e, to);
-                    xn = csub(e, to);
+                    split_pair(buf[phys_t<C::PS>(k)], buf[phys_t<C::PS>(N - k)], tws_l[k], xk, xn);   // (xn conjugated: only |.| is used)
                 }
                 const float pk = xk.x * xk.x + xk.y * xk.y, pn = xn.x * xn.x + xn.y * xn.y;
                 mk[i] = mfcc ? pk : __builtin_amdgcn_sqrtf(pk);   // v_sqrt_f32, 1 ulp

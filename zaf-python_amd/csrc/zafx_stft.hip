@@ -22,18 +22,6 @@
 
 namespace zafx {
 
-// ---------------------------------------------------------------------------------
-// real-split of one (k, N-k) pair
-// ---------------------------------------------------------------------------------
-__device__ __forceinline__ void split_pair(float2 zk, float2 zn, float2 t, float2& xk, float2& xn) {
-    const float2 e = make_float2(0.5f * (zk.x + zn.x), 0.5f * (zk.y - zn.y));
-    const float2 d = make_float2(0.5f * (zk.x - zn.x), 0.5f * (zk.y + zn.y));
-    const float2 o = make_float2(d.y, -d.x);   // -i d
-    const float2 to = cmul(t, o);
-    xk = cadd(e, to);
-    xn = cconj(csub(e, to));
-}
-
 // Output rows of the forward kernels by spectrum kind SPEC (enum zafx_spectrum): 0 two-sided complex,
 // 1 one-sided complex, 2 one-sided |X| and 3 one-sided |X|^2 as float32 (what the examples of the reference
 // compute from the result, zaf.py:83).  `spec_base` offsets the output in ELEMENTS of the kind; `put_bin`

@@ -101,31 +101,44 @@ static hipError_t pack_band(PackedBand& pb, const float* dense, int n_rows, int 
             }
         pb.total_steps += steps;
     }
-    // cut every block's band into parts of at most `cap` K-steps (slot ids are (block, part)-ordered)
-    const int cap = std::max(8, (pb.total_steps + n_waves - 1) / n_waves);
+    // Deal the K-steps to the wavefronts in equal contiguous shares of the (block-major) step sequence; a share that crosses
+    // a block boundary becomes one work item per block (slot ids are (block, part)-ordered).  Every wave gets
+    // ceil(total / n_waves) steps or one less: 128 filters at W = 2048 are 271 steps = 17 per wave (cutting the blocks into
+    // parts dealt longest-first left the busiest wave with 22).
     struct Item { int slot, first, steps, off; };
-    std::vector<Item> items;
     std::vector<int> blk_ptr((size_t)pb.n_blocks + 1, 0);
-    for (int b = 0; b < pb.n_blocks; ++b) {
-        blk_ptr[(size_t)b] = (int)items.size();
-        const Blk& k = blks[(size_t)b];
-        const int parts = std::max(1, (k.steps + cap - 1) / cap);
-        for (int q = 0; q < parts; ++q) {
-            const int s0 = (int)((long long)k.steps * q / parts), s1 = (int)((long long)k.steps * (q + 1) / parts);
-            items.push_back(Item{(int)items.size(), k.first + 4 * s0, s1 - s0, k.off + s0});
-        }
-    }
-    blk_ptr[(size_t)pb.n_blocks] = (int)items.size();
-    pb.n_items = (int)items.size();
-    // deal the items to the wavefronts, longest first, always to the least loaded wave
-    std::vector<Item> order = items;
-    std::stable_sort(order.begin(), order.end(), [](const Item& a, const Item& b) { return a.steps > b.steps; });
     std::vector<std::vector<Item>> per_wave((size_t)n_waves);
-    std::vector<int> load((size_t)n_waves, 0);
-    for (const Item& it : order) {
-        const int w = (int)(std::min_element(load.begin(), load.end()) - load.begin());
-        per_wave[(size_t)w].push_back(it);
-        load[(size_t)w] += it.steps + 2;
+    {
+        int b = 0;
+        for (int w = 0; w < n_waves; ++w) {
+            int g0 = (int)((long long)pb.total_steps * w / n_waves);
+            const int g1 = (int)((long long)pb.total_steps * (w + 1) / n_waves);
+            while (g0 < g1) {
+                while (blks[(size_t)b].off + blks[(size_t)b].steps <= g0) ++b;   // the block that holds step g0 (empty blocks: below)
+                const Blk& k = blks[(size_t)b];
+                const int s0 = g0 - k.off, s1 = std::min(g1 - k.off, k.steps);
+                per_wave[(size_t)w].push_back(Item{-1, k.first + 4 * s0, s1 - s0, k.off + s0});
+                per_wave[(size_t)w].back().slot = -1 - b;   // block, resolved to a slot id below
+                g0 = k.off + s1;
+            }
+        }
+        // slot ids in (block, part) order; a block without non-zeros gets one empty item so that its rows are written (as zeros)
+        std::vector<std::vector<Item*>> by_block((size_t)pb.n_blocks);
+        for (auto& v : per_wave)
+            for (Item& it : v) by_block[(size_t)(-1 - it.slot)].push_back(&it);
+        int next = 0;
+        std::vector<std::pair<int, Item>> empties;   // (appended afterwards: a push_back would move the items pointed to)
+        for (int bb = 0; bb < pb.n_blocks; ++bb) {
+            blk_ptr[(size_t)bb] = next;
+            if (by_block[(size_t)bb].empty()) {
+                empties.emplace_back(bb % n_waves, Item{next++, 0, 0, 0});
+                continue;
+            }
+            for (Item* it : by_block[(size_t)bb]) it->slot = next++;
+        }
+        for (const auto& e : empties) per_wave[(size_t)e.first].push_back(e.second);
+        blk_ptr[(size_t)pb.n_blocks] = next;
+        pb.n_items = next;
     }
     std::vector<int> flat, wave_ptr((size_t)n_waves + 1, 0);
     for (int w = 0; w < n_waves; ++w) {
@@ -135,6 +148,7 @@ static hipError_t pack_band(PackedBand& pb, const float* dense, int n_rows, int 
         }
     }
     wave_ptr[(size_t)n_waves] = (int)flat.size() / 4;
+    pb.max_wave_steps = (pb.total_steps + n_waves - 1) / n_waves;
     if (pack.empty()) pack.push_back(0.f);
     if (flat.empty()) flat.assign(4, 0);
     hipError_t e = upload(&pb.d_pack, pack.data(), pack.size() * sizeof(float));

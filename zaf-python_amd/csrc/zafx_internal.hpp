@@ -43,7 +43,10 @@ struct PackedBand {
     int4* d_items = nullptr;     // per wave, longest first: {slot id, first column, steps, offset into d_pack (steps)}
     int* d_wave_ptr = nullptr;   // [n_waves + 1] ranges into d_items
     int* d_blk_ptr = nullptr;    // [n_blocks + 1] ranges of slot ids belonging to a block
+    int max_wave_steps = 0;      // steps of the busiest wave: wave w owns steps [total w / n_waves, total (w + 1) / n_waves)
 };
+constexpr int kMelResidentFb = 20;  // K-steps of the filterbank / of the DCT rows a wave of k_mel keeps in registers
+constexpr int kMelResidentDct = 6;
 
 }  // namespace zafx
 

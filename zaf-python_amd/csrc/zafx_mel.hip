@@ -81,11 +81,51 @@ __device__ __forceinline__ void gemm_items(const float* __restrict__ pack, const
     }
 }
 
-template <int LOG2N, int LOG2E, bool ALIGNED>
+// One banded GEMM stage with the wave's A fragments resident in registers (RA K-steps in execution order): no vector-memory
+// traffic of its own, so the samples of the next tile can be requested underneath, one load after every K-step (`hook`) -- a
+// burst of 16 loads per lane overruns the CU's vector-memory queue and blocks the wave at issue (profiles/r02_notes.md).
+// The wave's work items {slot, first column, steps, -} are read with scalar loads, one per item.
+template <int RA, class SlotFn, class BFn, class Hook>
+__device__ __forceinline__ void gemm_resident(const float (&a)[RA], const int4* __restrict__ items, int it, int it_end, int lane, int slot0,
+                                              SlotFn slot_ptr, BFn b_at, Hook hook) {
+    asm volatile("" : "+s"(it), "+s"(it_end));   // (tile-invariant scalars: keep them out of the persistent loop's live set)
+    f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+    const int bt = lane & 15, bk = lane >> 4;
+    int4 d = it < it_end ? items[it] : make_int4(0, 0, 0, 0);
+    int col = d.y, left = d.z;
+    auto flush = [&]() {   // the item ends: leave its partial tile in its slot, take the next item
+        float* dst = slot_ptr(slot0 + d.x);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) dst[(4 * bk + q) * 16 + bt] = acc0[q] + acc1[q];
+        acc0 = f32x4{0.f, 0.f, 0.f, 0.f};
+        acc1 = f32x4{0.f, 0.f, 0.f, 0.f};
+        ++it;
+        d = it < it_end ? items[it] : make_int4(0, 0, 0, 0);
+        col = d.y;
+        left = d.z;
+    };
+    while (it < it_end && left == 0) flush();   // (a block without non-zeros: a zero tile)
+#pragma unroll
+    for (int i = 0; i < RA; ++i) {
+        if (it < it_end) {
+            if (i & 1) acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i], b_at(col), acc1, 0, 0, 0);
+            else acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i], b_at(col), acc0, 0, 0, 0);
+            col += 4;
+            if (--left == 0) {
+                flush();
+                while (it < it_end && left == 0) flush();
+            }
+        }
+        hook(i);
+    }
+}
+
+// RES: filterbank (and DCT) fragments resident in registers + prefetch of the next tile under the filterbank phases.
+template <int LOG2N, int LOG2E, bool ALIGNED, bool RES>
 __global__ __launch_bounds__(mel_threads(LOG2N, LOG2E)) void k_mel(
     const float* __restrict__ x, const float* __restrict__ win, const float2* __restrict__ twp,
     const float2* __restrict__ tws, const float* __restrict__ fb_pack, const int4* __restrict__ fb_items,
-    const int* __restrict__ fb_wave_ptr, const int* __restrict__ fb_blk_ptr, int fb_blocks, int fb_nitems,
+    const int* __restrict__ fb_wave_ptr, const int* __restrict__ fb_blk_ptr, int fb_blocks, int fb_nitems, int fb_steps, int dct_steps,
     const float* __restrict__ dct_pack, const int4* __restrict__ dct_items, const int* __restrict__ dct_wave_ptr,
     const int* __restrict__ dct_blk_ptr, int dct_blocks, float* __restrict__ out, long long n_samples, int hop, int T, int TP,
     int tiles, int total_tiles, int n_filters, int n_coefs, int mfcc, int layout) {
@@ -114,36 +154,63 @@ __global__ __launch_bounds__(mel_threads(LOG2N, LOG2E)) void k_mel(
     };
 
     const int slot = tid / P, p = tid % P;
-    const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // scalar: item ranges and descriptors load into SGPRs
-    const int bt = lane & 15, bk = lane >> 4;
     const float eps = 2.220446049250313e-16f;   // np.finfo(float).eps (zaf.py:445)
     const int lt0 = fb_nitems;                  // first log-mel slot
     const int dslot0 = fb_nitems + fb_blocks;   // first DCT partial slot
 
-    // raw samples of one frame of this wave's slot: xr[i] = (x[2n], x[2n+1]), n = p + i P (zero padding of zaf.py:112-125)
+    // raw samples of one frame of this wave's slot: xr[i] = (x[2n], x[2n+1]), n = p + i P (zero padding of zaf.py:112-125).
+    // fetch_begin() sets up the frame (an interior frame is then requested load by load with fetch_one(), or all at once
+    // with fetch()); a frame that touches the clip's edges is loaded in full by fetch_begin() itself.
     float2 xr[E];
-    auto fetch = [&](int tl, int f0, int p) {   // p: lane index within the frame (an opaque copy inside the tile loop)
-        if (tl >= total_tiles) return;
+    __amdgpu_buffer_rsrc_t frx = make_rsrc(x, 0);
+    int fvoff = 0;
+    auto fetch_begin = [&](int tl, int f0, int p) -> bool {   // p: lane index within the frame (an opaque copy inside the tile loop)
+        if (tl >= total_tiles) return false;
         const int clip = tl / tiles, tile = tl % tiles;
         const int t = tile * FPB + f0 + slot;
         const float* xc = x + (long long)clip * n_samples;
         const long long s0 = (long long)t * hop - N;
         if (ALIGNED && t < T && s0 >= 0 && s0 + W <= n_samples) {   // interior frame (uniform per frame)
-            const float2* src = reinterpret_cast<const float2*>(xc + s0) + p;
+            // buffer loads: one descriptor per clip in SGPRs + one 32-bit offset per lane (16 flat loads in flight would hold
+            // 16 64-bit addresses: the prefetch across the filterbank phases then spills)
+            frx = make_rsrc(xc, (unsigned)std::min<long long>(n_samples * 4, 0xfffffffcLL));
+            fvoff = ((int)s0 + 2 * p) * 4;
+            return true;
+        }
 #pragma unroll
-            for (int i = 0; i < E; ++i) xr[i] = src[i * P];
-        } else {
+        for (int i = 0; i < E; ++i) {
+            const long long s = s0 + 2 * (p + i * P);
+            xr[i].x = (t < T && s >= 0 && s < n_samples) ? xc[s] : 0.f;
+            xr[i].y = (t < T && s + 1 >= 0 && s + 1 < n_samples) ? xc[s + 1] : 0.f;
+        }
+        return false;
+    };
+    auto fetch_one = [&](int i) { xr[i] = buf_load_f32x2(frx, fvoff, i * P * 8); };
+    auto fetch = [&](int tl, int f0, int p) {
+        if (fetch_begin(tl, f0, p)) {
 #pragma unroll
-            for (int i = 0; i < E; ++i) {
-                const long long s = s0 + 2 * (p + i * P);
-                xr[i].x = (t < T && s >= 0 && s < n_samples) ? xc[s] : 0.f;
-                xr[i].y = (t < T && s + 1 >= 0 && s + 1 < n_samples) ? xc[s + 1] : 0.f;
-            }
+            for (int i = 0; i < E; ++i) fetch_one(i);
         }
     };
+    // The raw samples of a round are requested one phase ahead.  Fat waves (NT <= 512, two rounds per tile): before the FFT of
+    // the previous round.  16 thin waves (one round per tile): when the tile's spectra are done, so that the 128 KB of the next
+    // tile fly under the filterbank phases -- all 16 waves otherwise request, wait and transform in lockstep, and the three
+    // resources (vector memory 5.8 k cycles per tile, LDS 6.5 k, VALU 7 k) are used one after the other.
     constexpr bool PREFETCH = NT <= 512;
-    if constexpr (PREFETCH) fetch(blockIdx.x, 0, p);
+    constexpr bool LATE = !PREFETCH && RES;   // (without resident fragments the filterbank's own loads would queue behind the prefetch)
+    if constexpr (PREFETCH || LATE) fetch(blockIdx.x, 0, p);
+    // resident A fragments of this wave: lane l holds A[l & 15][4 step + (l >> 4)] of its K-steps
+    float afb[RES ? kMelResidentFb : 1], adct[RES ? kMelResidentDct : 1];
+    constexpr int NW = NT / 64;
+    if constexpr (RES) {   // the wave's share of the K-steps is a contiguous range of the packed fragments (pack_band)
+        const int g0 = (int)((long long)fb_steps * wave / NW), n = (int)((long long)fb_steps * (wave + 1) / NW) - g0;
+#pragma unroll
+        for (int i = 0; i < kMelResidentFb; ++i) afb[i] = i < n ? fb_pack[(size_t)(g0 + i) * 64 + (tid & 63)] : 0.f;
+        const int h0 = (int)((long long)dct_steps * wave / NW), m = (int)((long long)dct_steps * (wave + 1) / NW) - h0;
+#pragma unroll
+        for (int i = 0; i < kMelResidentDct; ++i) adct[i] = (mfcc && i < m) ? dct_pack[(size_t)(h0 + i) * 64 + (tid & 63)] : 0.f;
+    }
     PROF_INIT(g_prof_mel);
     for (int tl = blockIdx.x; tl < total_tiles; tl += gridDim.x) {
         const int clip = tl / tiles, tile = tl % tiles;
@@ -161,7 +228,7 @@ __global__ __launch_bounds__(mel_threads(LOG2N, LOG2E)) void k_mel(
             // (hoisted out of the persistent loop they cost > 100 VGPRs and spill)
             int po = p;
             asm volatile("" : "+v"(po));
-            if constexpr (!PREFETCH) fetch(tl, f0, po);   // 16 thin waves: no registers to carry samples across the FFT
+            if constexpr (!PREFETCH && !LATE) fetch(tl, f0, po);   // 16 thin waves, streamed filterbank: request, wait, transform
             float2 v[E];
 #pragma unroll
             for (int i = 0; i < E; ++i) {
@@ -207,17 +274,27 @@ __global__ __launch_bounds__(mel_threads(LOG2N, LOG2E)) void k_mel(
         PROF_MARK(1);
         lds_barrier();
         PROF_MARK(2);
+        // opaque copy of the thread index for the filterbank phases: their per-lane addresses are tile-invariant, and hoisted
+        // out of the persistent loop they ride through the FFT phase (with the prefetched samples: 128 VGPRs + 212 B of scratch)
+        int to = tid;
+        asm volatile("" : "+v"(to));
+        const int lane = to & 63, bt = lane & 15, bk = lane >> 4;
+        bool fast = false;   // the next tile's frame: requested one load per K-step of the filterbank GEMM
+        if constexpr (LATE) fast = fetch_begin(tl + gridDim.x, 0, to % P);
 
         // ---- mel = FB . S on the matrix cores
         {
             const float* sb = fall + (size_t)bt * (2 * C::PITCH) + bk;
-            gemm_items(fb_pack, fb_items, fb_wave_ptr, wave, lane, 0, slot_ptr, [&](int col) { return sb[col]; });
+            if constexpr (RES)
+                gemm_resident(afb, fb_items, fb_wave_ptr[wave], fb_wave_ptr[wave + 1], lane, 0, slot_ptr, [&](int col) { return sb[col]; },
+                              [&](int i) { if (LATE && i < E && fast) fetch_one(i); });
+            else gemm_items(fb_pack, fb_items, fb_wave_ptr, wave, lane, 0, slot_ptr, [&](int col) { return sb[col]; });
         }
         PROF_MARK(3);
         lds_barrier();
         PROF_MARK(4);
         // ---- fixed-order reduction of the parts of every 16-filter block
-        for (int idx = tid; idx < fb_blocks * 256; idx += NT) {
+        for (int idx = to; idx < fb_blocks * 256; idx += NT) {
             const int blk = idx >> 8, e = idx & 255;
             float val = 0.f;
             for (int it = fb_blk_ptr[blk]; it < fb_blk_ptr[blk + 1]; ++it) val += slot_ptr(it)[e];
@@ -232,10 +309,11 @@ __global__ __launch_bounds__(mel_threads(LOG2N, LOG2E)) void k_mel(
         if (mfcc) {
             lds_barrier();
             // ---- rows 1..ncoef of the orthonormal DCT-II over the mel axis: second MFMA GEMM
-            gemm_items(dct_pack, dct_items, dct_wave_ptr, wave, lane, dslot0, slot_ptr,
-                       [&](int row) { return slot_ptr(lt0 + ((row + bk) >> 4))[((row + bk) & 15) * 16 + bt]; });
+            auto logmel = [&](int row) { return slot_ptr(lt0 + ((row + bk) >> 4))[((row + bk) & 15) * 16 + bt]; };
+            if constexpr (RES) gemm_resident(adct, dct_items, dct_wave_ptr[wave], dct_wave_ptr[wave + 1], lane, dslot0, slot_ptr, logmel, [](int) {});
+            else gemm_items(dct_pack, dct_items, dct_wave_ptr, wave, lane, dslot0, slot_ptr, logmel);
             lds_barrier();
-            for (int idx = tid; idx < dct_blocks * 256; idx += NT) {
+            for (int idx = to; idx < dct_blocks * 256; idx += NT) {
                 const int blk = idx >> 8, e = idx & 255;
                 float val = 0.f;
                 for (int it = dct_blk_ptr[blk]; it < dct_blk_ptr[blk + 1]; ++it) val += slot_ptr(dslot0 + it)[e];
@@ -255,8 +333,10 @@ template <int LOG2N, bool ALIGNED>
 static hipError_t run_mel(const zafx_plan& pl, const float* x, float* out, int64_t n_clips, int64_t n_samples, int T) {
     constexpr int LOG2E = mel_log2e(LOG2N);
     using G = MelCfg<LOG2N, LOG2E>;
-    auto kern = k_mel<LOG2N, LOG2E, ALIGNED>;
     const int mfcc = pl.kind == ZAFX_MFCC;
+    // filterbank and DCT fragments resident in registers when the busiest wave's K-steps fit (128 filters at W = 2048: 17 + 4)
+    const bool res = G::NT == 1024 && pl.fb.max_wave_steps <= kMelResidentFb && (!mfcc || pl.dct.max_wave_steps <= kMelResidentDct);
+    auto kern = res ? k_mel<LOG2N, LOG2E, ALIGNED, true> : k_mel<LOG2N, LOG2E, ALIGNED, false>;
     const int slots = pl.fb.n_items + (mfcc ? pl.fb.n_blocks + pl.dct.n_items : 0);
     if (slots > G::CAPACITY) {
         set_error("mel/mfcc: too many filterbank work items for the LDS slots at this window_length");
@@ -273,7 +353,7 @@ static hipError_t run_mel(const zafx_plan& pl, const float* x, float* out, int64
     const int per_cu = (int)std::min<size_t>(2, (size_t)kMaxLdsBytes / G::SMEM);
     const long long grid = std::min<long long>(total, (long long)pl.n_cus * std::max(per_cu, 1));
     hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(G::NT), G::SMEM, pl.stream, x, pl.d_window, LOG2E == 5 ? pl.d_tw_r32 : pl.d_tw_pass, pl.d_tw_aux, pl.fb.d_pack,
-                       pl.fb.d_items, pl.fb.d_wave_ptr, pl.fb.d_blk_ptr, pl.fb.n_blocks, pl.fb.n_items, pl.dct.d_pack, pl.dct.d_items,
+                       pl.fb.d_items, pl.fb.d_wave_ptr, pl.fb.d_blk_ptr, pl.fb.n_blocks, pl.fb.n_items, pl.fb.total_steps, mfcc ? pl.dct.total_steps : 0, pl.dct.d_pack, pl.dct.d_items,
                        pl.dct.d_wave_ptr, pl.dct.d_blk_ptr, pl.dct.n_blocks, out, (long long)n_samples, pl.H, T, (int)row_pitch(pl, T), tiles, (int)total,
                        pl.prm.n_filters, pl.prm.n_coefs, mfcc, pl.layout);
     return hipGetLastError();

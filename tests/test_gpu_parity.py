@@ -1118,3 +1118,86 @@ def test_mdct_window_not_a_power_of_two(zafx, wl, n):
             assert m == 0 or np.max(np.abs(y[:m] - x[c][:m])) < 1e-9
     with pytest.raises(ValueError):
         zafx.mdct_batch(x, np.ones(999))
+
+
+def test_f64_inverse_transforms_in_scratch_chunks(tmp_path):
+    """The float64 ISTFT / IMDCT park their time-domain frames in a plan-owned scratch; batches above the budget (1 GiB,
+    here forced to 1 MiB) go through it in chunks of clips and must give the same samples."""
+    import os
+    import subprocess
+    import sys
+    from conftest import ROOT
+    code = f"""
+import sys, numpy as np
+sys.path.insert(0, {os.path.join(ROOT, 'zaf-python_amd')!r}); sys.path.insert(0, {ROOT!r})
+import zafx
+from oracle import zaf_oracle as orc
+x = np.stack([np.random.default_rng([31, c]).standard_normal(30001) for c in range(7)])
+w = zafx.hamming(1024)
+for layout in ("FT", "TF"):
+    S = zafx.stft_batch(x, w, 256, layout=layout, f64=True)
+    y = zafx.istft_batch(S, w, 256, layout=layout, f64=True)          # 7 clips x 122 frames x 1024 x 8 B = 7 MB of scratch: 7 chunks
+    for c in range(7):
+        ref = orc.istft(orc.stft(x[c], w, 256), w, 256)
+        assert np.max(np.abs(y[c] - ref)) <= 1e-11 * np.max(np.abs(ref)), (layout, c)
+kbd = zafx.kaiser_bessel_derived(1024)
+m = zafx.mdct_batch(x, kbd, f64=True)
+r = zafx.imdct_batch(m, kbd, f64=True)
+for c in range(7):
+    ref = orc.imdct(orc.mdct(x[c], kbd), kbd)
+    assert np.max(np.abs(r[c] - ref)) <= 1e-11 * np.max(np.abs(ref)), c
+w2 = zafx.hamming(1000)                                                  # Bluestein forms
+y2 = zafx.istft_batch(zafx.stft_batch(x, w2, 250), w2, 250)
+assert np.max(np.abs(y2[3] - orc.istft(orc.stft(x[3], w2, 250), w2, 250))) < 1e-5
+print("chunked ok")
+"""
+    env = dict(os.environ, ZAFX_SCRATCH_BUDGET_MB="1")
+    res = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, timeout=300)
+    assert res.returncode == 0 and b"chunked ok" in res.stdout, res.stderr.decode()[-2000:]
+
+
+def test_host_layer_fixes_of_round_2(zafx):
+    """run_host casts any real dtype to the plan's own (it used to reinterpret the bytes); the allocation pool is
+    bounded and evicts its oldest entries; the dct / dst plans are keyed before their N x N matrix is built."""
+    from zafx import core
+    x = np.stack([synth_clip(2, c, 5000) for c in range(2)])
+    ham = zafx.hamming(256)
+    plan = zafx.stft_plan(ham, 64)
+    ref = plan.run_host(x, x.shape[1])
+    assert np.array_equal(plan.run_host(x.astype(np.float64), x.shape[1]), ref)
+    assert np.array_equal(plan.run_host((x * 1000).astype(np.int32), x.shape[1]), plan.run_host(np.trunc(x * 1000).astype(np.float32), x.shape[1]))
+    with pytest.raises(ValueError):
+        plan.run_host(x.astype(np.complex64), x.shape[1])
+    # pool: never above its cap, oldest size class evicted first
+    core.DeviceBuffer.drain_pool()
+    cap = core.DeviceBuffer._POOL_CAP
+    try:
+        core.DeviceBuffer._POOL_CAP = 3 << 20
+        for mb in (1, 1, 1, 2, 1):
+            core.DeviceBuffer((mb << 20,), np.uint8).release()
+        assert core.DeviceBuffer._pool_bytes[0] <= 3 << 20
+        assert sum(len(v) * k[1] for k, v in core.DeviceBuffer._pool.items()) == core.DeviceBuffer._pool_bytes[0]
+        big = core.DeviceBuffer((4 << 20,), np.uint8)
+        big.release()                                   # larger than the whole pool: freed, not parked
+        assert core.DeviceBuffer._pool_bytes[0] <= 3 << 20
+    finally:
+        core.DeviceBuffer._POOL_CAP = cap
+        core.DeviceBuffer.drain_pool()
+    # dct: the second call finds the plan by (transform, type, N, device) without touching the matrix builder
+    v = synth_clip(3, 0, 300)
+    first = zafx.dct(v, 2)
+    calls = []
+    orig = zafx.constants.dct_matrix if hasattr(zafx, "constants") else None
+    import zafx.constants as zc
+    orig = zc.dct_matrix
+    try:
+        def spy(n, t):
+            calls.append((n, t))
+            return orig(n, t)
+        spy.__name__ = "dct_matrix"
+        zc.dct_matrix = spy
+        assert np.array_equal(zafx.dct(v, 2), first) and not calls
+    finally:
+        zc.dct_matrix = orig
+    with pytest.raises(ValueError):
+        zafx.dct(v, 5)

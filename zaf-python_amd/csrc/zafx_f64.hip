@@ -9,6 +9,7 @@
 // ISTFT through a per-call scratch of time-domain frames and a gather overlap-add in the reference's
 // ascending frame order (zaf.py:226-233).
 #include <algorithm>
+#include <cstdlib>
 
 #include "zafx_internal.hpp"
 
@@ -608,36 +609,59 @@ hipError_t launch_stft_f64(const zafx_plan& pl, const double* x, double2* out, i
     return hipGetLastError();
 }
 
-hipError_t launch_istft_f64(zafx_plan& pl, const double2* spec, double* y, int64_t n_clips, int T, int64_t out_len) {
-    const long long blocks = (long long)n_clips * T;
-    if (blocks <= 0 || out_len <= 0) return hipSuccess;
-    if (hipError_t e = grow_scratch(pl, (size_t)blocks * pl.W * sizeof(double)); e != hipSuccess) return e;
-    if (pl.bs_log2m > 0) {   // window that is not a power of two
-        const size_t smem = ((size_t)2 << pl.bs_log2m) * sizeof(double2);
-        auto kern = k_ifft_frames_bs_f64;
-        if (hipError_t e = ensure_dynamic_lds(reinterpret_cast<const void*>(kern), pl.device, smem); e != hipSuccess) return e;
-        hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(threads_for(smem)), smem, pl.stream, spec, pl.d_tw64, pl.d_tws64, pl.d_bhat64,
-                           pl.d_scratch64, T, (int)row_pitch(pl, T), pl.W, pl.bs_log2m, pl.layout,
-                           pl.prm.spectrum == ZAFX_SPECTRUM_ONE_SIDED ? 1 : 0);
-        if (hipError_t e = hipGetLastError(); e != hipSuccess) return e;
+// The inverse transforms park every time-domain frame of the batch in a plan-owned scratch (n_clips x T x W doubles) before
+// the gather overlap-add; large batches go through it in chunks of clips so that the scratch stays below scratch_budget()
+// (1024 clips x 432 frames x 2048 samples would be 7 GB, pinned by the cached plan until it is destroyed).
+static size_t scratch_budget() {   // 1 GiB; ZAFX_SCRATCH_BUDGET_MB overrides it (tests force the chunked path with it)
+    static const size_t budget = [] {
+        const char* env = std::getenv("ZAFX_SCRATCH_BUDGET_MB");
+        const long mb = env ? std::atol(env) : 0;
+        return mb > 0 ? (size_t)mb << 20 : (size_t)1 << 30;
+    }();
+    return budget;
+}
+static int64_t clips_per_chunk(int64_t n_clips, int T, int W) {
+    const size_t per_clip = (size_t)T * (size_t)W * sizeof(double);
+    return std::max<int64_t>(1, std::min<int64_t>(n_clips, (int64_t)(scratch_budget() / std::max<size_t>(per_clip, 1))));
+}
+
+hipError_t launch_istft_f64(zafx_plan& pl, const double2* spec_all, double* y_all, int64_t n_clips_all, int T, int64_t out_len) {
+    if ((long long)n_clips_all * T <= 0 || out_len <= 0) return hipSuccess;
+    const int64_t chunk = clips_per_chunk(n_clips_all, T, pl.W);
+    if (hipError_t e = grow_scratch(pl, (size_t)chunk * T * pl.W * sizeof(double)); e != hipSuccess) return e;
+    const int64_t rows = pl.prm.spectrum == ZAFX_SPECTRUM_ONE_SIDED ? pl.W / 2 + 1 : pl.W;
+    const int64_t in_per_clip = pl.layout == ZAFX_LAYOUT_FT ? rows * row_pitch(pl, T) : (int64_t)T * rows;
+    for (int64_t c0 = 0; c0 < n_clips_all; c0 += chunk) {
+        const int64_t n_clips = std::min(chunk, n_clips_all - c0);
+        const double2* spec = spec_all + c0 * in_per_clip;
+        double* y = y_all + c0 * out_len;
+        const long long blocks = (long long)n_clips * T;
         const long long total = (long long)n_clips * out_len;
         const long long grid = std::min<long long>((total + kThreads - 1) / kThreads, (long long)pl.n_cus * 32);
-        hipLaunchKernelGGL(k_ola_f64, dim3((unsigned)grid), dim3(kThreads), 0, pl.stream, pl.d_scratch64, y, T, pl.W, pl.H,
-                           (long long)out_len, total, 1.0 / pl.cola_gain64);
-        return hipGetLastError();
+        if (pl.bs_log2m > 0) {   // window that is not a power of two
+            const size_t smem = ((size_t)2 << pl.bs_log2m) * sizeof(double2);
+            auto kern = k_ifft_frames_bs_f64;
+            if (hipError_t e = ensure_dynamic_lds(reinterpret_cast<const void*>(kern), pl.device, smem); e != hipSuccess) return e;
+            hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(threads_for(smem)), smem, pl.stream, spec, pl.d_tw64, pl.d_tws64, pl.d_bhat64,
+                               pl.d_scratch64, T, (int)row_pitch(pl, T), pl.W, pl.bs_log2m, pl.layout,
+                               pl.prm.spectrum == ZAFX_SPECTRUM_ONE_SIDED ? 1 : 0);
+            if (hipError_t e = hipGetLastError(); e != hipSuccess) return e;
+            hipLaunchKernelGGL(k_ola_f64, dim3((unsigned)grid), dim3(kThreads), 0, pl.stream, pl.d_scratch64, y, T, pl.W, pl.H,
+                               (long long)out_len, total, 1.0 / pl.cola_gain64);
+        } else {
+            const size_t smem = (size_t)pl.W * sizeof(double2);
+            auto kern = k_ifft_frames_f64;
+            if (hipError_t e = ensure_dynamic_lds(reinterpret_cast<const void*>(kern), pl.device, smem); e != hipSuccess) return e;
+            hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(threads_for(smem)), smem, pl.stream, spec, pl.d_tw64, pl.d_tws64, pl.d_scratch64, T,
+                               (int)row_pitch(pl, T), pl.log2nf, pl.layout, pl.prm.spectrum == ZAFX_SPECTRUM_ONE_SIDED ? 1 : 0);
+            if (hipError_t e = hipGetLastError(); e != hipSuccess) return e;
+            const double scale = 1.0 / (2.0 * (double)pl.W * pl.cola_gain64);   // 1/W of the inverse DFT x the factor 2 left by the fold
+            hipLaunchKernelGGL(k_ola_f64, dim3((unsigned)grid), dim3(kThreads), 0, pl.stream, pl.d_scratch64, y, T, pl.W, pl.H, (long long)out_len,
+                               total, scale);
+        }
+        if (hipError_t e = hipGetLastError(); e != hipSuccess) return e;
     }
-    const size_t smem = (size_t)pl.W * sizeof(double2);
-    auto kern = k_ifft_frames_f64;
-    if (hipError_t e = ensure_dynamic_lds(reinterpret_cast<const void*>(kern), pl.device, smem); e != hipSuccess) return e;
-    hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(threads_for(smem)), smem, pl.stream, spec, pl.d_tw64, pl.d_tws64, pl.d_scratch64, T,
-                       (int)row_pitch(pl, T), pl.log2nf, pl.layout, pl.prm.spectrum == ZAFX_SPECTRUM_ONE_SIDED ? 1 : 0);
-    if (hipError_t e = hipGetLastError(); e != hipSuccess) return e;
-    const long long total = (long long)n_clips * out_len;
-    const long long grid = std::min<long long>((total + kThreads - 1) / kThreads, (long long)pl.n_cus * 32);
-    const double scale = 1.0 / (2.0 * (double)pl.W * pl.cola_gain64);   // 1/W of the inverse DFT x the factor 2 left by the fold
-    hipLaunchKernelGGL(k_ola_f64, dim3((unsigned)grid), dim3(kThreads), 0, pl.stream, pl.d_scratch64, y, T, pl.W, pl.H, (long long)out_len,
-                       total, scale);
-    return hipGetLastError();
+    return hipSuccess;
 }
 
 hipError_t launch_cqt_f64(zafx_plan& pl, const double* x, double* out, int64_t n_clips, int64_t n_samples, int T) {
@@ -692,31 +716,39 @@ hipError_t launch_mdct_f64(const zafx_plan& pl, const double* x, double* out, in
     return hipGetLastError();
 }
 
-hipError_t launch_imdct_f64(zafx_plan& pl, const double* coefs, double* y, int64_t n_clips, int T, int64_t out_len) {
-    const long long blocks = (long long)n_clips * T;
-    if (blocks <= 0 || out_len <= 0) return hipSuccess;
-    if (hipError_t e = grow_scratch(pl, (size_t)blocks * pl.W * sizeof(double)); e != hipSuccess) return e;
-    if (pl.bs_log2m > 0) {   // window that is not a power of two
-        const size_t smem = ((size_t)2 << pl.bs_log2m) * sizeof(double2);
-        auto kern = k_imdct_frames_bs_f64;
-        if (hipError_t e = ensure_dynamic_lds(reinterpret_cast<const void*>(kern), pl.device, smem); e != hipSuccess) return e;
-        hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(threads_for(smem)), smem, pl.stream, coefs, pl.d_window64, pl.d_tw64, pl.d_tws64,
-                           pl.d_bhat64, pl.d_scratch64, T, (int)row_pitch(pl, T), pl.W, pl.bs_log2m, pl.layout);
-    } else {
-    const size_t smem = (size_t)(pl.W / 2) * 16 + (size_t)(pl.W / 4) * 32;
-    auto kern = k_imdct_frames_f64;
-    if (hipError_t e = ensure_dynamic_lds(reinterpret_cast<const void*>(kern), pl.device, smem); e != hipSuccess) return e;
-    hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(threads_for(smem)), smem, pl.stream, coefs, pl.d_window64, pl.d_tw64, pl.d_tws64,
-                       pl.d_scratch64, T, (int)row_pitch(pl, T), pl.log2nf, pl.layout);
+hipError_t launch_imdct_f64(zafx_plan& pl, const double* coefs_all, double* y_all, int64_t n_clips_all, int T, int64_t out_len) {
+    if ((long long)n_clips_all * T <= 0 || out_len <= 0) return hipSuccess;
+    const int64_t chunk = clips_per_chunk(n_clips_all, T, pl.W);   // (scratch budget: see launch_istft_f64)
+    if (hipError_t e = grow_scratch(pl, (size_t)chunk * T * pl.W * sizeof(double)); e != hipSuccess) return e;
+    const int64_t in_per_clip = pl.layout == ZAFX_LAYOUT_FT ? (int64_t)(pl.W / 2) * row_pitch(pl, T) : (int64_t)T * (pl.W / 2);
+    for (int64_t c0 = 0; c0 < n_clips_all; c0 += chunk) {
+        const int64_t n_clips = std::min(chunk, n_clips_all - c0);
+        const double* coefs = coefs_all + c0 * in_per_clip;
+        double* y = y_all + c0 * out_len;
+        const long long blocks = (long long)n_clips * T;
+        if (pl.bs_log2m > 0) {   // window that is not a power of two
+            const size_t smem = ((size_t)2 << pl.bs_log2m) * sizeof(double2);
+            auto kern = k_imdct_frames_bs_f64;
+            if (hipError_t e = ensure_dynamic_lds(reinterpret_cast<const void*>(kern), pl.device, smem); e != hipSuccess) return e;
+            hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(threads_for(smem)), smem, pl.stream, coefs, pl.d_window64, pl.d_tw64, pl.d_tws64,
+                               pl.d_bhat64, pl.d_scratch64, T, (int)row_pitch(pl, T), pl.W, pl.bs_log2m, pl.layout);
+        } else {
+            const size_t smem = (size_t)(pl.W / 2) * 16 + (size_t)(pl.W / 4) * 32;
+            auto kern = k_imdct_frames_f64;
+            if (hipError_t e = ensure_dynamic_lds(reinterpret_cast<const void*>(kern), pl.device, smem); e != hipSuccess) return e;
+            hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(threads_for(smem)), smem, pl.stream, coefs, pl.d_window64, pl.d_tw64, pl.d_tws64,
+                               pl.d_scratch64, T, (int)row_pitch(pl, T), pl.log2nf, pl.layout);
+        }
+        if (hipError_t e = hipGetLastError(); e != hipSuccess) return e;
+        // two-frame TDAC overlap-add in ascending frame order (zaf.py:1172-1179) and the trim [H : -H-1] (:1182): the same
+        // gather as the ISTFT's with hop = W/2
+        const long long total = (long long)n_clips * out_len;
+        const long long grid = std::min<long long>((total + kThreads - 1) / kThreads, (long long)pl.n_cus * 32);
+        hipLaunchKernelGGL(k_ola_f64, dim3((unsigned)grid), dim3(kThreads), 0, pl.stream, pl.d_scratch64, y, T, pl.W, pl.H, (long long)out_len,
+                           total, 1.0);
+        if (hipError_t e = hipGetLastError(); e != hipSuccess) return e;
     }
-    if (hipError_t e = hipGetLastError(); e != hipSuccess) return e;
-    // two-frame TDAC overlap-add in ascending frame order (zaf.py:1172-1179) and the trim [H : -H-1] (:1182): the same
-    // gather as the ISTFT's with hop = W/2
-    const long long total = (long long)n_clips * out_len;
-    const long long grid = std::min<long long>((total + kThreads - 1) / kThreads, (long long)pl.n_cus * 32);
-    hipLaunchKernelGGL(k_ola_f64, dim3((unsigned)grid), dim3(kThreads), 0, pl.stream, pl.d_scratch64, y, T, pl.W, pl.H, (long long)out_len,
-                       total, 1.0);
-    return hipGetLastError();
+    return hipSuccess;
 }
 
 }  // namespace zafx

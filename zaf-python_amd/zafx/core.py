@@ -70,7 +70,11 @@ class DeviceBuffer:
             self.ptr = _ptr_from_pool
             return
         p = ctypes.c_void_p()
-        _lib.check(_lib.load().zafx_alloc(self.device, ctypes.byref(p), self.nbytes), "zafx_alloc")
+        rc = _lib.load().zafx_alloc(self.device, ctypes.byref(p), self.nbytes)
+        if rc != 0 and DeviceBuffer._pool_bytes[0] > 0:   # out of device memory with allocations parked in the pool: give them back, retry once
+            DeviceBuffer.drain_pool()
+            rc = _lib.load().zafx_alloc(self.device, ctypes.byref(p), self.nbytes)
+        _lib.check(rc, "zafx_alloc")
         self.ptr = p
 
     # Allocation pool of the host-buffer entry points: a drop-in call on one 10 s clip spends more time in
@@ -90,18 +94,27 @@ class DeviceBuffer:
         return cls(shape, dtype, device, _ptr_from_pool=ptr) if ptr is not None else cls(shape, dtype, device)
 
     def release(self):
-        """Return the allocation to the pool (or free it when the pool is full)."""
+        """Return the allocation to the pool.  The pool is bounded (_POOL_CAP bytes): the oldest parked allocations are
+        freed to make room, so a workload of ever-changing clip lengths cannot pin device memory with sizes it never reuses."""
         if getattr(self, "ptr", None) is None or not self.ptr.value:
             return
-        with self._pool_lock:
-            keep = self.nbytes > 0 and self._pool_bytes[0] + self.nbytes <= self._POOL_CAP
-            if keep:
-                self._pool.setdefault((self.device, self.nbytes), []).append(self.ptr)
-                self._pool_bytes[0] += self.nbytes
-        if keep:
-            self.ptr = ctypes.c_void_p()
-        else:
+        if self.nbytes == 0 or self.nbytes > self._POOL_CAP:
             self.free()
+            return
+        evicted = []
+        with self._pool_lock:
+            while self._pool_bytes[0] + self.nbytes > self._POOL_CAP and self._pool:
+                key = next(iter(self._pool))            # dicts keep insertion order: the size class parked first
+                ptrs = self._pool[key]
+                evicted.append((key[0], ptrs.pop(0)))
+                self._pool_bytes[0] -= key[1]
+                if not ptrs:
+                    del self._pool[key]
+            self._pool.setdefault((self.device, self.nbytes), []).append(self.ptr)
+            self._pool_bytes[0] += self.nbytes
+        self.ptr = ctypes.c_void_p()
+        for device, ptr in evicted:
+            _lib.load().zafx_free(device, ptr)
 
     @classmethod
     def drain_pool(cls):
@@ -310,7 +323,10 @@ class Plan:
 
     def run_host(self, array, n_in):
         """Host array in -> device transform -> host array out (PCIe both ways)."""
-        array = np.ascontiguousarray(array, dtype=self.in_dtype if self.f64 else None)
+        array = np.asarray(array)
+        if np.iscomplexobj(array) and self.in_dtype.kind != "c":
+            raise ValueError("this plan takes real input")
+        array = np.ascontiguousarray(array, dtype=self.in_dtype)   # (an array of another dtype would be reinterpreted byte-wise)
         n_clips = array.shape[0]
         frames = None
         if self.row_align > 1:   # padded rows on the device, compact arrays on the host side
@@ -768,8 +784,19 @@ def _transform_batch(vectors, matrix_fn, kind, device):
     x = np.ascontiguousarray(vectors, dtype=np.float32)
     if x.ndim != 2 or x.shape[1] < 1:
         raise ValueError("vectors must be 2-D (batch, length) with length >= 1")
-    plan = linear_plan(matrix_fn(x.shape[1], kind), device)
-    return plan.run_host(x, x.shape[1])
+    n = x.shape[1]
+    if n > 16384:
+        raise ValueError("dct / dst lengths above 16384 are not supported")
+    if kind not in (1, 2, 3, 4):
+        raise ValueError("type must be 1, 2, 3 or 4")
+
+    def make():   # the N x N matrix (O(N^2) trigonometry, 8 N^2 bytes) is built once per (transform, type, N, device)
+        m = np.ascontiguousarray(matrix_fn(n, kind), dtype=np.float64)
+        p = Plan(_lib.LINEAR, device, window_length=m.shape[1], n_filters=m.shape[0])
+        p.set_matrix(m)
+        return p
+    plan = _cached((matrix_fn.__name__, int(kind), n, device), make)
+    return plan.run_host(x, n)
 
 
 def dct_batch(vectors, dct_type, device=0):

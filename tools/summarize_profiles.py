@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """gpurun_out/ (written by tools/collect_profiles.sh on the GPU box) -> profiles/ (committed).
 
-    python tools/summarize_profiles.py r01
+    python tools/summarize_profiles.py r02
 """
 import csv
 import glob
@@ -11,7 +11,7 @@ import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 OUT, PROF = os.path.join(ROOT, "gpurun_out"), os.path.join(ROOT, "profiles")
-tag = sys.argv[1] if len(sys.argv) > 1 else "r01"
+tag = sys.argv[1] if len(sys.argv) > 1 else "r02"
 KINDS = ["stft", "istft", "mdct", "imdct", "mel", "mfcc", "cqt", "dct"]
 
 
@@ -30,7 +30,7 @@ def stats_rows(kind):
 
 
 # bench lines
-for k in KINDS + ["stft_tf"]:
+for k in KINDS + ["stft_tf", "all"]:
     src = os.path.join(OUT, f"bench_{k}.json")
     if os.path.exists(src) and os.path.getsize(src):
         line = open(src).read().strip().splitlines()[-1]
@@ -94,6 +94,7 @@ for kind in KINDS:
         "write_correction": 1.0,
         "hbm_bytes_per_launch": fetch[kern][1] * 1024 * 2.0 + write[kern][1] * 1024,
         "algorithmic_bytes_per_launch": bench["roofline"]["algorithmic_bytes_per_launch"],
+        "collected": "%s: separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of `bench.py --kind %s --steps 3`" % (tag, kind),
         "note": "FETCH_SIZE/WRITE_SIZE in KB from separate rocprofv3 --pmc passes (profiles/%s_pmc_summary.csv); gfx950 "
                 "FETCH_SIZE counts half the bytes of streaming reads (MI355X_MICROARCH.md, HBM section; confirmed on the "
                 "device-to-device copy of the stft run), WRITE_SIZE is exact on that copy" % tag,
@@ -114,4 +115,53 @@ for kind in KINDS:
         line = json.loads(open(bench_file).read())
         line["roofline"]["traffic"] = json.load(open(pmc))["hbm_bytes_per_launch"]
         open(bench_file, "w").write(json.dumps(line) + "\n")
+
+
+# SQ passes: matrix-core busy time and LDS behaviour of the dominant kernel (mean per dispatch)
+def all_counters(kind, leg):
+    f = find(f"pmc_{kind}_{leg}/**/*counter_collection.csv")
+    if not f:
+        return {}
+    acc = {}
+    with open(f) as fh:
+        for r in csv.DictReader(fh):
+            name = r["Kernel_Name"].split("(")[0]
+            s = acc.setdefault(name, {}).setdefault(r["Counter_Name"], [0, 0.0])
+            s[0] += 1
+            s[1] += float(r["Counter_Value"])
+    return {k: {c: v / n for c, (n, v) in d.items()} for k, d in acc.items()}
+
+
+sq_rows = []
+for kind in ("mel", "mfcc", "dct", "cqt", "stft"):
+    bench_file = os.path.join(PROF, f"{tag}_bench_{kind}.json")
+    if not os.path.exists(bench_file):
+        continue
+    kname = json.loads(open(bench_file).read())["roofline"]["kernel"]
+    merged = {}
+    for leg in ("SQ", "LDS"):
+        tab = all_counters(kind, leg)
+        kern = next((k for k in tab if kname in k), None)
+        if kern:
+            merged.update(tab[kern])
+    if not merged:
+        continue
+    grbm, mfma = merged.get("GRBM_GUI_ACTIVE"), merged.get("SQ_VALU_MFMA_BUSY_CYCLES")
+    derived = {}
+    if grbm and mfma is not None:
+        # rocprofv3's MfmaUtil: MFMA busy cycles (summed over the 1024 SIMDs) / (kernel cycles x SIMDs); GRBM_GUI_ACTIVE arrives
+        # summed over the 8 XCDs
+        derived["mfma_util"] = mfma / (grbm / 8.0 * 1024.0)
+        derived["kernel_cycles"] = grbm / 8.0
+    if merged.get("SQ_LDS_IDX_ACTIVE"):
+        derived["lds_bank_conflict_over_active"] = merged.get("SQ_LDS_BANK_CONFLICT", 0.0) / merged["SQ_LDS_IDX_ACTIVE"]
+    if merged.get("SQ_WAVE_CYCLES") and merged.get("SQ_WAIT_INST_LDS") is not None:
+        derived["wait_inst_lds_over_wave_cycles"] = merged["SQ_WAIT_INST_LDS"] / merged["SQ_WAVE_CYCLES"]
+    for c, v in sorted(merged.items()):
+        sq_rows.append(f'{kind},"{kname}",{c},{v:.1f}')
+    for c, v in sorted(derived.items()):
+        sq_rows.append(f'{kind},"{kname}",{c},{v:.5f}')
+if sq_rows:
+    with open(os.path.join(PROF, f"{tag}_sq_summary.csv"), "w") as fh:
+        fh.write("kind,kernel,counter_or_ratio,mean_per_dispatch\n" + "\n".join(sq_rows) + "\n")
 print("profiles/ refreshed for", tag)

@@ -454,13 +454,89 @@ __device__ __forceinline__ float wave_sum(float v) {
     return (r0 + r1) + (r2 + r3);
 }
 
+// ---------------------------------------------------------------- 1024 points in one wavefront, second exchange in registers
+// fft_frame<10, 4> is three passes (16 . 16 . 4) with two exchanges through LDS.  The second one is special: after pass 2
+// lane (lh, ll) = (lane >> 4, lane & 15) holds in register (rh, rl) = (r >> 2, r & 3) the point at position
+//     lh * 256 + ll + 16 * (4 rh + rl),
+// and pass 3 (radix 4 over positions 256 apart, butterfly b of lane l' on positions l' + 64 b + 256 r') wants it in lane
+// (rl, ll), register (rh, lh): the low four lane bits stay, the DPP-row index of the lane trades places with the low two
+// register bits.  That 4 x 4 transpose is two v_permlane32_swap + two v_permlane16_swap per four registers (gfx950) --
+// 32 VALU instructions per frame instead of 16 ds_write_b64 + 16 ds_read_b64, on kernels whose FFT phase is bound by
+// LDS bandwidth (profiles/r02_notes.md).
+#ifndef ZAFX_FFT_PERMLANE
+#define ZAFX_FFT_PERMLANE 1
+#endif
+__device__ __forceinline__ void lane_row_transpose4(float& x0, float& x1, float& x2, float& x3) {
+    // x_c[row R] <-> x_R[row c] over the four 16-lane rows: lane bit 5 against register bit 1 (v_permlane32_swap: lanes 32..63 of
+    // the first operand trade places with lanes 0..31 of the second), then lane bit 4 against register bit 0
+    // (v_permlane16_swap: odd 16-lane rows of the first with even rows of the second).  Inline asm: through
+    // __builtin_amdgcn_permlane16_swap the compiler (ROCm 7.2) dropped the second result of half of the swaps in this
+    // context (tools/exp: eight of the sixteen v_permlane16_swap gone, wrong spectra).  s_nop 1: a v_permlane*_swap must
+    // not read a VGPR in the two wait states after a VALU wrote it, and the hazard recogniser does not look inside asm.
+    asm("s_nop 1\n\tv_permlane32_swap_b32 %0, %2\n\tv_permlane32_swap_b32 %1, %3\n\ts_nop 1\n\t"
+        "v_permlane16_swap_b32 %0, %1\n\tv_permlane16_swap_b32 %2, %3"
+        : "+v"(x0), "+v"(x1), "+v"(x2), "+v"(x3));
+}
+
+// twiddles of pass 2 (w[r] = exp(-2 pi i r k / 256), k = lane & 15) and of butterfly b of pass 3 come from the pass tables
+// of fft_frame<10, 4> or from the two-level table + product tree of fft_frame_chain<10, 4>
+__device__ __forceinline__ void pass2_twiddles(float2* w, int k, const float2* tw) {
+    const float2* t = tw + twiddle_offset(10, 4, 4);
+#pragma unroll
+    for (int r = 1; r < 16; ++r) w[r] = t[(r - 1) * 16 + k];
+}
+__device__ __forceinline__ void pass2_twiddles(float2* w, int k, const TwoLevelTw& t) {
+    w[1] = tw2(t, k << 2);
+#pragma unroll
+    for (int r = 2; r < 16; ++r) w[r] = cmul(w[r >> 1], w[r - (r >> 1)]);
+}
+__device__ __forceinline__ void pass3_write(const float2* v, float2* buf, int lane, const float2* tw) {
+    pass_write<10, 4, 8, 2>(v, buf, lane, tw + twiddle_offset(10, 4, 8));
+}
+__device__ __forceinline__ void pass3_write(const float2* v, float2* buf, int lane, const TwoLevelTw& t) {
+    pass_write_chain<10, 4, 8, 2>(v, buf, lane, t);
+}
+__device__ __forceinline__ void pass1_write(const float2* v, float2* buf, int lane, const float2* tw) { pass_write<10, 4, 0, 4>(v, buf, lane, tw); }
+__device__ __forceinline__ void pass1_write(const float2* v, float2* buf, int lane, const TwoLevelTw& t) { pass_write_chain<10, 4, 0, 4>(v, buf, lane, t); }
+
+// Input: v[i] = x[lane + 64 i].  Output: natural-order spectrum in the padded LDS frame `buf` (as fft_frame<10, 4>).
+template <class TW>
+__device__ __forceinline__ void fft1024_wave(float2* v, float2* buf, int lane, const TW& tw) {
+    pass1_write(v, buf, lane, tw);   // radix 16, no twiddles: position 16 lane + r
+    frame_sync<64>();
+    regs_read<10, 4>(v, buf, lane);
+    frame_sync<64>();                // every lane has its points of pass 1 before pass 3 overwrites the frame
+    float2 a[16];
+    {
+        float2 w[16];
+        pass2_twiddles(w, lane & 15, tw);
+        a[0] = v[0];
+#pragma unroll
+        for (int r = 1; r < 16; ++r) a[r] = cmul(v[r], w[r]);
+    }
+    Dft<16>::run(a);
+#pragma unroll
+    for (int rh = 0; rh < 4; ++rh) {
+        lane_row_transpose4(a[4 * rh].x, a[4 * rh + 1].x, a[4 * rh + 2].x, a[4 * rh + 3].x);
+        lane_row_transpose4(a[4 * rh].y, a[4 * rh + 1].y, a[4 * rh + 2].y, a[4 * rh + 3].y);
+    }
+#pragma unroll
+    for (int b = 0; b < 4; ++b)   // register 4 b + r' now holds position lane + 64 b + 256 r': pass 3 reads v[b + 4 r']
+#pragma unroll
+        for (int r = 0; r < 4; ++r) v[b + 4 * r] = a[4 * b + r];
+    pass3_write(v, buf, lane, tw);
+    frame_sync<64>();
+}
+
 // All passes.  Input: v[i] = x[p + i*P].  Output: natural-order spectrum in the
 // padded LDS frame `buf` (visible to the frame's threads after the final sync).
 // `tw` = table built by the host with zafx_twiddle_layout (LDS or global).
 template <int LOG2N, int LOG2E, int LOG2NS = 0>
 __device__ __forceinline__ void fft_frame(float2* v, float2* buf, int p, const float2* tw) {
     using C = FftCfg<LOG2N, LOG2E>;
-    if constexpr (LOG2NS < LOG2N) {
+    if constexpr (ZAFX_FFT_PERMLANE && LOG2N == 10 && LOG2E == 4 && LOG2NS == 0) {
+        fft1024_wave(v, buf, p, tw);
+    } else if constexpr (LOG2NS < LOG2N) {
         constexpr int LR = pass_log2r(LOG2N - LOG2NS, LOG2E);
         pass_write<LOG2N, LOG2E, LOG2NS, LR>(v, buf, p, tw + twiddle_offset(LOG2N, LOG2E, LOG2NS));
         frame_sync<C::P>();
@@ -476,7 +552,9 @@ __device__ __forceinline__ void fft_frame(float2* v, float2* buf, int p, const f
 template <int LOG2N, int LOG2E, int LOG2NS = 0>
 __device__ __forceinline__ void fft_frame_chain(float2* v, float2* buf, int p, const TwoLevelTw& t) {
     using C = FftCfg<LOG2N, LOG2E>;
-    if constexpr (LOG2NS < LOG2N) {
+    if constexpr (ZAFX_FFT_PERMLANE && LOG2N == 10 && LOG2E == 4 && LOG2NS == 0) {
+        fft1024_wave(v, buf, p, t);
+    } else if constexpr (LOG2NS < LOG2N) {
         constexpr int LR = pass_log2r(LOG2N - LOG2NS, LOG2E);
         pass_write_chain<LOG2N, LOG2E, LOG2NS, LR>(v, buf, p, t);
         frame_sync<C::P>();

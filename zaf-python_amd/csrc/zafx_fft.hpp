@@ -500,9 +500,19 @@ __device__ __forceinline__ void pass1_write(const float2* v, float2* buf, int la
 __device__ __forceinline__ void pass1_write(const float2* v, float2* buf, int lane, const TwoLevelTw& t) { pass_write_chain<10, 4, 0, 4>(v, buf, lane, t); }
 
 // Input: v[i] = x[lane + 64 i].  Output: natural-order spectrum in the padded LDS frame `buf` (as fft_frame<10, 4>).
-template <class TW>
+// ODDROT: the odd lanes hold their 16 points rotated by 8, v[i] = x[lane + 64 ((i + 8) & 15)] (lane pairs that share 16-byte
+// loads, see k_mel / k_cqt): their radix-16 outputs of pass 1 then carry (-1)^k, undone here.
+template <bool ODDROT = false, class TW>
 __device__ __forceinline__ void fft1024_wave(float2* v, float2* buf, int lane, const TW& tw) {
-    pass1_write(v, buf, lane, tw);   // radix 16, no twiddles: position 16 lane + r
+    if constexpr (ODDROT) {
+        Dft<16>::run(v);
+        const float sg = (lane & 1) ? -1.f : 1.f;
+        const int pb = phys(lane << 4);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) buf[pb + r] = (r & 1) ? make_float2(v[r].x * sg, v[r].y * sg) : v[r];   // position 16 lane + r
+    } else {
+        pass1_write(v, buf, lane, tw);   // radix 16, no twiddles: position 16 lane + r
+    }
     frame_sync<64>();
     regs_read<10, 4>(v, buf, lane);
     frame_sync<64>();                // every lane has its points of pass 1 before pass 3 overwrites the frame

@@ -45,8 +45,8 @@ struct PackedBand {
     int* d_blk_ptr = nullptr;    // [n_blocks + 1] ranges of slot ids belonging to a block
     int max_wave_steps = 0;      // steps of the busiest wave: wave w owns steps [total w / n_waves, total (w + 1) / n_waves)
 };
-constexpr int kMelResidentFb = 20;  // K-steps of the filterbank / of the DCT rows a wave of k_mel keeps in registers
-constexpr int kMelResidentDct = 6;
+constexpr int kMelResidentFb = 18;  // K-steps of the filterbank / of the DCT rows a wave of k_mel keeps in registers
+constexpr int kMelResidentDct = 4;
 
 }  // namespace zafx
 

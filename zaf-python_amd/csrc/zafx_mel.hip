@@ -159,6 +159,18 @@ __global__ __launch_bounds__(mel_threads(LOG2N, LOG2E)) void k_mel(
     const int lt0 = fb_nitems;                  // first log-mel slot
     const int dslot0 = fb_nitems + fb_blocks;   // first DCT partial slot
 
+    // The raw samples of a round are requested one phase ahead.  Fat waves (NT <= 512, two rounds per tile): before the FFT of
+    // the previous round.  16 thin waves (one round per tile): when the tile's spectra are done, so that the 128 KB of the next
+    // tile fly under the filterbank phases -- all 16 waves otherwise request, wait and transform in lockstep, and the three
+    // resources (vector memory 5.8 k cycles per tile, LDS 6.5 k, VALU 7 k) are used one after the other.
+    constexpr bool PREFETCH = NT <= 512;
+    constexpr bool LATE = !PREFETCH && RES;
+    // 16-byte lane loads for the prefetched frame (W = 2048, resident form): the lane pair (2q, 2q + 1) shares its loads -- the
+    // even lane fetches the points (2q, 2q + 1) + 64 i for i = 0 .. 7, the odd lane for i = 8 .. 15 -- keeps its own point and
+    // sends the other's across (DPP swap inside the pair).  Eight loads per lane instead of sixteen: the request of the next
+    // tile blocks half as long at the CU's vector-memory queue.  The odd lane then holds its points rotated by 8
+    // (fft1024_wave<ODDROT>); the clip-edge path loads in the same rotated order.
+    constexpr bool PAIR16 = LATE && LOG2N == 10 && LOG2E == 4;   // (without resident fragments the filterbank's own loads would queue behind the prefetch)
     // raw samples of one frame of this wave's slot: xr[i] = (x[2n], x[2n+1]), n = p + i P (zero padding of zaf.py:112-125).
     // fetch_begin() sets up the frame (an interior frame is then requested load by load with fetch_one(), or all at once
     // with fetch()); a frame that touches the clip's edges is loaded in full by fetch_begin() itself.
@@ -175,31 +187,59 @@ __global__ __launch_bounds__(mel_threads(LOG2N, LOG2E)) void k_mel(
             // buffer loads: one descriptor per clip in SGPRs + one 32-bit offset per lane (16 flat loads in flight would hold
             // 16 64-bit addresses: the prefetch across the filterbank phases then spills)
             frx = make_rsrc(xc, (unsigned)std::min<long long>(n_samples * 4, 0xfffffffcLL));
-            fvoff = ((int)s0 + 2 * p) * 4;
+            fvoff = PAIR16 ? ((int)s0 + 2 * (p & ~1)) * 4 + (p & 1) * (E / 2 * P * 8) : ((int)s0 + 2 * p) * 4;
             return true;
         }
+        const int rot = PAIR16 ? (E / 2) * (p & 1) : 0;   // (odd lanes of the pair form hold their points rotated by 8)
 #pragma unroll
         for (int i = 0; i < E; ++i) {
-            const long long s = s0 + 2 * (p + i * P);
+            const long long s = s0 + 2 * (p + ((i + rot) & (E - 1)) * P);
             xr[i].x = (t < T && s >= 0 && s < n_samples) ? xc[s] : 0.f;
             xr[i].y = (t < T && s + 1 >= 0 && s + 1 < n_samples) ? xc[s + 1] : 0.f;
         }
         return false;
     };
-    auto fetch_one = [&](int i) { xr[i] = buf_load_f32x2(frx, fvoff, i * P * 8); };
+    auto fetch_one = [&](int i) {
+        if constexpr (PAIR16) {
+            if (i < E / 2) {   // raw: (xr[2i], xr[2i+1]) = the lane's two points of load i; unpack_pairs() sorts them out
+                const float4 q = buf_load_f32x4(frx, fvoff, i * P * 8);
+                xr[2 * i] = make_float2(q.x, q.y);
+                xr[2 * i + 1] = make_float2(q.z, q.w);
+            }
+        } else {
+            xr[i] = buf_load_f32x2(frx, fvoff, i * P * 8);
+        }
+    };
+    auto unpack_pairs = [&](int p) {
+        const int odd = p & 1;
+        float2 lo[E / 2], hi[E / 2];
+#pragma unroll
+        for (int i = 0; i < E / 2; ++i) {
+            lo[i] = xr[2 * i];
+            hi[i] = xr[2 * i + 1];
+        }
+#pragma unroll
+        for (int i = 0; i < E / 2; ++i) {
+            const float2 keep = odd ? hi[i] : lo[i], send = odd ? lo[i] : hi[i];
+            xr[i] = keep;
+            xr[i + E / 2].x = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, send.x), 0xB1, 0xf, 0xf, true));
+            xr[i + E / 2].y = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, send.y), 0xB1, 0xf, 0xf, true));
+        }
+    };
     auto fetch = [&](int tl, int f0, int p) {
         if (fetch_begin(tl, f0, p)) {
 #pragma unroll
             for (int i = 0; i < E; ++i) fetch_one(i);
         }
     };
-    // The raw samples of a round are requested one phase ahead.  Fat waves (NT <= 512, two rounds per tile): before the FFT of
-    // the previous round.  16 thin waves (one round per tile): when the tile's spectra are done, so that the 128 KB of the next
-    // tile fly under the filterbank phases -- all 16 waves otherwise request, wait and transform in lockstep, and the three
-    // resources (vector memory 5.8 k cycles per tile, LDS 6.5 k, VALU 7 k) are used one after the other.
-    constexpr bool PREFETCH = NT <= 512;
-    constexpr bool LATE = !PREFETCH && RES;   // (without resident fragments the filterbank's own loads would queue behind the prefetch)
-    if constexpr (PREFETCH || LATE) fetch(blockIdx.x, 0, p);
+    bool raw = false;   // PAIR16: xr holds raw 16-byte loads (an interior frame) that unpack_pairs() must sort out
+    if constexpr (PREFETCH || LATE) {
+        raw = fetch_begin(blockIdx.x, 0, p);
+        if (raw) {
+#pragma unroll
+            for (int i = 0; i < E; ++i) fetch_one(i);
+        }
+    }
     // resident A fragments of this wave: lane l holds A[l & 15][4 step + (l >> 4)] of its K-steps
     float afb[RES ? kMelResidentFb : 1], adct[RES ? kMelResidentDct : 1];
     constexpr int NW = NT / 64;
@@ -230,16 +270,27 @@ __global__ __launch_bounds__(mel_threads(LOG2N, LOG2E)) void k_mel(
             asm volatile("" : "+v"(po));
             if constexpr (!PREFETCH && !LATE) fetch(tl, f0, po);   // 16 thin waves, streamed filterbank: request, wait, transform
             float2 v[E];
+            if constexpr (PAIR16) {
+                if (raw) unpack_pairs(po);
+                const int w0 = po + (po & 1) * (E / 2 * P), w1 = po + (1 - (po & 1)) * (E / 2 * P);   // window of slot i: point (i ^ 8 odd) P + lane
 #pragma unroll
-            for (int i = 0; i < E; ++i) {
-                const float2 wv = win_l[po + i * P];
-                v[i] = make_float2(xr[i].x * wv.x, xr[i].y * wv.y);
+                for (int i = 0; i < E; ++i) {
+                    const float2 wv = win_l[(i < E / 2 ? w0 : w1) + (i & (E / 2 - 1)) * P];
+                    v[i] = make_float2(xr[i].x * wv.x, xr[i].y * wv.y);
+                }
+            } else {
+#pragma unroll
+                for (int i = 0; i < E; ++i) {
+                    const float2 wv = win_l[po + i * P];
+                    v[i] = make_float2(xr[i].x * wv.x, xr[i].y * wv.y);
+                }
             }
             if constexpr (PREFETCH) {
                 if (f0 + NSLOT < FPB) fetch(tl, f0 + NSLOT, po);
                 else fetch(tl + gridDim.x, 0, po);
             }
-            fft_frame<LOG2N, LOG2E>(v, buf, po, tw_l);
+            if constexpr (PAIR16) fft1024_wave<true>(v, buf, po, (const float2*)tw_l);
+            else fft_frame<LOG2N, LOG2E>(v, buf, po, tw_l);
             // real split of the (k, N-k) pairs this thread owns, kept in registers
             float mk[E / 2], mn[E / 2];
 #pragma unroll
@@ -281,6 +332,7 @@ __global__ __launch_bounds__(mel_threads(LOG2N, LOG2E)) void k_mel(
         const int lane = to & 63, bt = lane & 15, bk = lane >> 4;
         bool fast = false;   // the next tile's frame: requested one load per K-step of the filterbank GEMM
         if constexpr (LATE) fast = fetch_begin(tl + gridDim.x, 0, to % P);
+        raw = fast;
 
         // ---- mel = FB . S on the matrix cores
         {

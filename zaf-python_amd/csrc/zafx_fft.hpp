@@ -308,6 +308,32 @@ ZAFX_HD void pass_write(const float2* v, float2* buf, int p, const float2* tw) {
     }
 }
 
+// pass_write whose outputs are multiplied by conj-free table entries on their way out: buf[k] = conj(a * post[k]), k the
+// natural index of the output.  Used as the LAST pass of transforms that end with a post-twiddle (MDCT): the multiply costs
+// one product per point here, against a product and a select per stored coefficient in the store phase.
+template <int LOG2N, int LOG2E, int LOG2NS, int LR>
+ZAFX_HD void pass_write_post(const float2* v, float2* buf, int p, const float2* tw, const float2* post) {
+    using C = FftCfg<LOG2N, LOG2E>;
+    constexpr int R = 1 << LR, NS = 1 << LOG2NS, NB = C::E / R;
+#pragma unroll
+    for (int b = 0; b < NB; ++b) {
+        const int j = p + b * C::P;
+        const int k = j & (NS - 1);
+        float2 a[R];
+#pragma unroll
+        for (int r = 0; r < R; ++r) a[r] = v[b + r * NB];
+        if (LOG2NS > 0) {
+#pragma unroll
+            for (int r = 1; r < R; ++r) a[r] = cmul(a[r], tw[(r - 1) * NS + k]);
+        }
+        Dft<R>::run(a);
+        const int base = ((j >> LOG2NS) << (LOG2NS + LR)) + k;
+        const int pb = phys_t<C::PS>(base);
+#pragma unroll
+        for (int r = 0; r < R; ++r) buf[phys_off<NS * R, C::PS>(pb, base, r * NS)] = cconj(cmul(a[r], post[base + r * NS]));
+    }
+}
+
 // ---------------------------------------------------------------- chained-twiddle pass
 // For frames whose per-pass tables do not fit LDS (CQT: 16384 points -> 131 KB) the base
 // twiddle w = exp(-2 pi i k / (Ns R)) comes from a two-level table (root(idx) = hi[idx >> 7] *
@@ -555,6 +581,23 @@ __device__ __forceinline__ void fft_frame(float2* v, float2* buf, int p, const f
             frame_sync<C::P>();
             fft_frame<LOG2N, LOG2E, LOG2NS + LR>(v, buf, p, tw);
         }
+    }
+}
+
+// fft_frame whose last pass leaves conj(X[k] post[k]) in the frame (see pass_write_post)
+template <int LOG2N, int LOG2E, int LOG2NS = 0>
+__device__ __forceinline__ void fft_frame_post(float2* v, float2* buf, int p, const float2* tw, const float2* post) {
+    using C = FftCfg<LOG2N, LOG2E>;
+    constexpr int LR = pass_log2r(LOG2N - LOG2NS, LOG2E);
+    if constexpr (LOG2NS + LR < LOG2N) {
+        pass_write<LOG2N, LOG2E, LOG2NS, LR>(v, buf, p, tw + twiddle_offset(LOG2N, LOG2E, LOG2NS));
+        frame_sync<C::P>();
+        regs_read<LOG2N, LOG2E>(v, buf, p);
+        frame_sync<C::P>();
+        fft_frame_post<LOG2N, LOG2E, LOG2NS + LR>(v, buf, p, tw, post);
+    } else {
+        pass_write_post<LOG2N, LOG2E, LOG2NS, LR>(v, buf, p, tw + twiddle_offset(LOG2N, LOG2E, LOG2NS), post);
+        frame_sync<C::P>();
     }
 }
 

@@ -247,7 +247,7 @@ __global__ __launch_bounds__(NSLOT * 64) void k_mdct_ft32(
             float2 v[E];
             regs_read<LOG2NF, LOG2E>(v, buf, po);
             frame_sync<P>();
-            fft_frame<LOG2NF, LOG2E>(v, buf, po, tw_l);
+            fft_frame_post<LOG2NF, LOG2E>(v, buf, po, tw_l, g_l);   // the frame now holds conj(y[k]), y[k] = Z[k] g[k]
             PROF_MARK(2);
             if constexpr (TFOUT) {
                 // coefficients (2j, 2j+1) = (Re y[j], -Im y[NF-1-j]) with y[k] = Z[k] g[k] (zaf.py:1087-1091 after the
@@ -259,13 +259,12 @@ __global__ __launch_bounds__(NSLOT * 64) void k_mdct_ft32(
 #pragma unroll 4
                     for (int i = 0; i < NF / P; ++i) {
                         const int j = po + i * P;
-                        const float2 za = buf[phys(j)], zb = buf[phys(NF - 1 - j)], ga = g_l[j], gb = g_l[NF - 1 - j];
-                        const float re = za.x * ga.x - za.y * ga.y, im = zb.x * gb.y + zb.y * gb.x;
+                        const float re = buf[phys(j)].x, mim = buf[phys(NF - 1 - j)].y;   // Re y[j], -Im y[NF-1-j]
                         if (pair_ok) {
-                            *reinterpret_cast<float2*>(o + 2 * j) = make_float2(re, -im);
+                            *reinterpret_cast<float2*>(o + 2 * j) = make_float2(re, mim);
                         } else {
                             o[2 * j] = re;
-                            o[2 * j + 1] = -im;
+                            o[2 * j + 1] = mim;
                         }
                     }
                 }
@@ -289,13 +288,21 @@ __global__ __launch_bounds__(NSLOT * 64) void k_mdct_ft32(
             const float2* bb = ba + C::PITCH;
             float* o = out + (long long)clip * M * TP + ta;
             const bool two = ta + 1 < T;
+            // coefficient f of a frame is Re y[f / 2] (f even) or -Im y[(M - 1 - f) / 2] (f odd): one float of the frame's
+            // conj(y) image.  A thread's f advances by NT / 16 (even), so its parity, the component it reads and the stride
+            // of its bin (+- NT / 32, i.e. +- (NT / 32 + NT / 512) padded slots) are fixed: two ds_read_b32, one 8-byte
+            // store and three additions per coefficient pair.
+            const int odd = fqo & 1;
+            int k = odd ? (M - 1 - fqo) >> 1 : fqo >> 1;
+            constexpr int DK = NT / 32, DPH = DK + DK / 16;   // bins / padded slots per step of f
+            const float* pa = reinterpret_cast<const float*>(ba + phys(k)) + odd;
+            const float* pb2 = reinterpret_cast<const float*>(bb + phys(k)) + odd;
+            const int dslot = odd ? -2 * DPH : 2 * DPH;     // floats
+            float* dst = o + (long long)fqo * TP;
+            const long long dstep = (long long)(NT / 16) * TP;
 #pragma unroll 4
             for (int f = fqo; f < M; f += NT / 16) {
-                const int k = (f & 1) ? (M - 1 - f) >> 1 : f >> 1;
-                const float2 g = g_l[k];
-                const float2 ya = cmul(ba[phys(k)], g), yb = cmul(bb[phys(k)], g);
-                const float va = (f & 1) ? -ya.y : ya.x, vb = (f & 1) ? -yb.y : yb.x;
-                float* dst = o + (long long)f * TP;
+                const float va = *pa, vb = *pb2;
                 if (pair_ok && two) {
                     if (lines_whole) store_stream(reinterpret_cast<float2*>(dst), make_float2(va, vb));   // a 128-B line per 16 lanes, written once
                     else *reinterpret_cast<float2*>(dst) = make_float2(va, vb);
@@ -304,6 +311,9 @@ __global__ __launch_bounds__(NSLOT * 64) void k_mdct_ft32(
                     dst[0] = va;
                     if (two) dst[1] = vb;
                 }
+                pa += dslot;
+                pb2 += dslot;
+                dst += dstep;
             }
         }
         PROF_MARK(4);

@@ -423,6 +423,19 @@ __device__ __forceinline__ void store_stream(float2* p, float2 v) {
     __builtin_nontemporal_store(t, reinterpret_cast<zafx_f32x2*>(p));   // global_store_dwordx2 ... nt (sc0 / sc1 variants: no difference)
 }
 
+// XCD-aware order of a persistent kernel's work list.  Block b runs on XCD b % 8 (observed, not promised: a wrong guess is slower,
+// never wrong), so the virtual index v = blockIdx + i gridDim of a grid that is a multiple of 8 belongs to XCD v % 8; each XCD
+// gets one contiguous range of the `total` units and its workgroups walk it side by side.  Neighbouring units -- tiles of the
+// same clip, whose output rows share cache lines when a row is not a whole number of lines -- then meet in ONE L2 at about the
+// same time, and their partial lines merge there instead of leaving for HBM twice.  Bijective for any `total`.
+#ifndef ZAFX_XCD_ORDER
+#define ZAFX_XCD_ORDER 1
+#endif
+__device__ __forceinline__ int xcd_order(int v, int total) {
+    const int x = v & 7, q = total >> 3, r = total & 7;
+    return (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + (v >> 3);
+}
+
 // Workgroup barrier that orders LDS traffic only.  __syncthreads() also drains vmcnt, i.e. it waits
 // for every global store of the wave to be acknowledged (measured: 8 000 cycles per tile after the
 // ISTFT store phase); a kernel whose waves exchange data through LDS alone does not need that.

@@ -177,8 +177,10 @@ __global__ __launch_bounds__(mel_threads(LOG2N, LOG2E)) void k_mel(
     float2 xr[E];
     __amdgpu_buffer_rsrc_t frx = make_rsrc(x, 0);
     int fvoff = 0;
-    auto fetch_begin = [&](int tl, int f0, int p) -> bool {   // p: lane index within the frame (an opaque copy inside the tile loop)
-        if (tl >= total_tiles) return false;
+    const bool xcd = ZAFX_XCD_ORDER && gridDim.x % 8 == 0;   // (xcd_order: tiles of a clip to the workgroups of one XCD)
+    auto fetch_begin = [&](int tlv, int f0, int p) -> bool {   // p: lane index within the frame (an opaque copy inside the tile loop)
+        if (tlv >= total_tiles) return false;
+        const int tl = xcd ? xcd_order(tlv, total_tiles) : tlv;
         const int clip = tl / tiles, tile = tl % tiles;
         const int t = tile * FPB + f0 + slot;
         const float* xc = x + (long long)clip * n_samples;
@@ -252,7 +254,8 @@ __global__ __launch_bounds__(mel_threads(LOG2N, LOG2E)) void k_mel(
         for (int i = 0; i < kMelResidentDct; ++i) adct[i] = (mfcc && i < m) ? dct_pack[(size_t)(h0 + i) * 64 + (tid & 63)] : 0.f;
     }
     PROF_INIT(g_prof_mel);
-    for (int tl = blockIdx.x; tl < total_tiles; tl += gridDim.x) {
+    for (int tlv = blockIdx.x; tlv < total_tiles; tlv += gridDim.x) {
+        const int tl = xcd ? xcd_order(tlv, total_tiles) : tlv;
         const int clip = tl / tiles, tile = tl % tiles;
         const int t0 = tile * FPB;
         PROF_MARK(0);
@@ -268,7 +271,7 @@ __global__ __launch_bounds__(mel_threads(LOG2N, LOG2E)) void k_mel(
             // (hoisted out of the persistent loop they cost > 100 VGPRs and spill)
             int po = p;
             asm volatile("" : "+v"(po));
-            if constexpr (!PREFETCH && !LATE) fetch(tl, f0, po);   // 16 thin waves, streamed filterbank: request, wait, transform
+            if constexpr (!PREFETCH && !LATE) fetch(tlv, f0, po);   // 16 thin waves, streamed filterbank: request, wait, transform
             float2 v[E];
             if constexpr (PAIR16) {
                 if (raw) unpack_pairs(po);
@@ -286,8 +289,8 @@ __global__ __launch_bounds__(mel_threads(LOG2N, LOG2E)) void k_mel(
                 }
             }
             if constexpr (PREFETCH) {
-                if (f0 + NSLOT < FPB) fetch(tl, f0 + NSLOT, po);
-                else fetch(tl + gridDim.x, 0, po);
+                if (f0 + NSLOT < FPB) fetch(tlv, f0 + NSLOT, po);
+                else fetch(tlv + gridDim.x, 0, po);
             }
             if constexpr (PAIR16) fft1024_wave<true>(v, buf, po, (const float2*)tw_l);
             else fft_frame<LOG2N, LOG2E>(v, buf, po, tw_l);
@@ -331,7 +334,7 @@ __global__ __launch_bounds__(mel_threads(LOG2N, LOG2E)) void k_mel(
         asm volatile("" : "+v"(to));
         const int lane = to & 63, bt = lane & 15, bk = lane >> 4;
         bool fast = false;   // the next tile's frame: requested one load per K-step of the filterbank GEMM
-        if constexpr (LATE) fast = fetch_begin(tl + gridDim.x, 0, to % P);
+        if constexpr (LATE) fast = fetch_begin(tlv + gridDim.x, 0, to % P);
         raw = fast;
 
         // ---- mel = FB . S on the matrix cores

@@ -218,8 +218,10 @@ __global__ __launch_bounds__(kFatWaves * 64) void k_stft_ft16(
     // inside the clip issues 2 x 16 unconditional 8-byte loads with no control flow in between, so the
     // loads stay in flight across the store phase; only the first and last tiles of a clip take the
     // predicated path (zero padding of zaf.py:112-125).
-    auto prefetch = [&](int tl) {
-        if (tl >= total_tiles) return;
+    const bool xcd = ZAFX_XCD_ORDER && gridDim.x % 8 == 0;   // (see xcd_order: units of a clip to the workgroups of one XCD)
+    auto prefetch = [&](int tlv) {
+        if (tlv >= total_tiles) return;
+        const int tl = xcd ? xcd_order(tlv, total_tiles) : tlv;
         int p = p_lane;   // (opaque at 32 points per thread: the 64-bit sample offsets of the edge path are recomputed, not hoisted)
         if constexpr (E >= 32) asm volatile("" : "+v"(p));
         const int clip = tl / tiles, tile = tl % tiles;
@@ -247,10 +249,11 @@ __global__ __launch_bounds__(kFatWaves * 64) void k_stft_ft16(
             }
         }
     };
-    int tl = blockIdx.x;
-    prefetch(tl);
+    int tlv = blockIdx.x;
+    prefetch(tlv);
     PROF_INIT(g_prof_stft);
-    for (; tl < total_tiles; tl += gridDim.x) {
+    for (; tlv < total_tiles; tlv += gridDim.x) {
+        const int tl = xcd ? xcd_order(tlv, total_tiles) : tlv;
         const int clip = tl / tiles, tile = tl % tiles;
         const int t0 = tile * FPB;
         PROF_MARK(0);
@@ -272,7 +275,7 @@ __global__ __launch_bounds__(kFatWaves * 64) void k_stft_ft16(
         // The two frames of a wave are adjacent and overlap by W - hop samples: requested together, the
         // shared half is served by the vector cache (requested half a store phase apart it was fetched
         // from HBM twice: FETCH_SIZE 2.88 GB instead of 1.93 GB per launch, same time).
-        prefetch(tl + gridDim.x);   // in flight while this tile is stored
+        prefetch(tlv + gridDim.x);   // in flight while this tile is stored
         PROF_MARK(3);
         if (t0 + tt < T) {
             float2* o = spec_base<SPEC>(out, (long long)clip * ROWS * TP + (t0 + tt));

@@ -1201,3 +1201,40 @@ def test_host_layer_fixes_of_round_2(zafx):
         zc.dct_matrix = orig
     with pytest.raises(ValueError):
         zafx.dct(v, 5)
+
+
+@pytest.mark.parametrize("n_clips,n", [(1, 40000), (3, 52345), (9, 36000), (17, 33000)])
+def test_cqt_clip_groups_and_complex_kernels(zafx, n_clips, n):
+    """k_cqt deals the frames of a group of clips (an XCD's share) round-robin to its workgroups: batches that are not a multiple
+    of 8 clips, fewer clips than XCDs, fewer frames than workgroups.  Kernel matrices beyond the reference's own: complex values
+    (per-row phase: the streamed complex form), scattered columns on both halves of the spectrum (conjugate entries), an empty row,
+    both layouts, chromagram."""
+    x = np.stack([synth_clip(21, c, n) for c in range(n_clips)])
+    ck = zafx.cqtkernel(44100, 24, 55, 3520)                       # real, resident form
+    got = zafx.cqtspectrogram_batch(x, 44100, 25, ck)
+    for c in sorted({0, n_clips // 2, n_clips - 1}):
+        assert relerr(got[c], orc.cqtspectrogram(x[c].astype(np.float64), 44100, 25, ck)) <= TOL_FB, c
+    got_tf = zafx.cqtspectrogram_batch(x, 44100, 25, ck, layout="TF")
+    assert np.array_equal(got_tf.transpose(0, 2, 1), got)
+    ch = zafx.cqtchromagram_batch(x[:2], 44100, 25, 24, ck)
+    assert relerr(ch[0], orc.cqtchromagram(x[0].astype(np.float64), 44100, 25, 24, ck)) <= TOL_FB
+    # complex values: every row times a unit phase (the magnitudes stay, the arithmetic is complex x complex)
+    rng = np.random.default_rng(5)
+    csr_k = ck.tocsr()
+    phase = np.exp(2j * np.pi * rng.random(csr_k.shape[0]))
+    kc = scipy.sparse.csr_matrix(scipy.sparse.diags(phase) @ csr_k)
+    gc = zafx.cqtspectrogram_batch(x[:2], 44100, 25, kc)
+    assert relerr(gc[-1], orc.cqtspectrogram(x[:2][-1].astype(np.float64), 44100, 25, kc)) <= TOL_FB
+    # scattered columns on both halves, complex values, one empty row, rows longer than a wave
+    rows, cols = 37, 4096
+    dense = np.zeros((rows, cols), dtype=np.complex128)
+    for r in range(rows):
+        if r == 5:
+            continue
+        idx = rng.choice(cols, size=int(rng.integers(1, 300)), replace=False)
+        dense[r, idx] = (rng.standard_normal(len(idx)) + 1j * rng.standard_normal(len(idx))) / cols
+    ks = scipy.sparse.csr_matrix(dense)
+    gs = zafx.cqtspectrogram_batch(x[:1, :20000], 8000, 50, ks)
+    ref = orc.cqtspectrogram(x[0, :20000].astype(np.float64), 8000, 50, ks)
+    assert gs[0].shape == ref.shape and relerr(gs[0], ref) <= TOL_FB
+    assert np.all(gs[0][5] == 0)

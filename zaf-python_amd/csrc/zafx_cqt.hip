@@ -123,8 +123,17 @@ __global__ __launch_bounds__(fft_threads(LOG2N, LOG2E)) void k_cqt(
     // unconditional 8-byte loads; the zero-padded edge frames take the predicated path.
     float2 v[E];
     const unsigned clip_bytes = (unsigned)std::min<long long>(n_samples * 4, 0xfffffffcLL);
-    // returns true when v holds the raw 16-byte loads of the split form (unpack_pairs() before the first pass)
-    auto load_frame = [&](long long g, int p) -> bool {   // g: index into the group's frame list; p: thread id (an opaque copy inside the frame loop)
+    // load_frame() returns true when v holds the raw 16-byte loads of the split form (unpack_pairs() before the first pass).
+    // With `deferred` the eight loads of that form are not issued: the caller requests them one at a time (load_one) between
+    // the iterations of its contraction.
+    __amdgpu_buffer_rsrc_t frx = make_rsrc(x, 0);
+    int fvoff = 0;
+    auto load_one = [&](int i) {   // raw: (v[2i], v[2i+1]) = the lane's two points of load i; unpack_pairs() sorts them out
+        const float4 q = buf_load_f32x4(frx, fvoff, i * P * 8);
+        v[2 * i] = make_float2(q.x, q.y);
+        v[2 * i + 1] = make_float2(q.z, q.w);
+    };
+    auto load_frame = [&](long long g, int p, bool deferred = false) -> bool {   // g: index into the group's frame list; p: thread id (an opaque copy inside the frame loop)
         const int clip = group + (int)((unsigned)g / (unsigned)T) * n_groups, t = (int)((unsigned)g % (unsigned)T);   // (g < 2^31: zafx_execute)
         const auto rx = make_rsrc(x + (long long)clip * n_samples, clip_bytes);
         const long long s0 = (long long)t * step - left_pad;
@@ -136,12 +145,11 @@ __global__ __launch_bounds__(fft_threads(LOG2N, LOG2E)) void k_cqt(
                 // other's across (DPP swap inside the pair).  The odd lane thus holds its 16 points rotated by 8, i.e. its
                 // radix-16 outputs carry (-1)^k -- absorbed by negating its base twiddle in first_pass.
                 const int odd = p & 1;
-                const int voff = ((int)s0 + 2 * (p - odd)) * 4 + odd * (8 * P * 8);
+                frx = rx;
+                fvoff = ((int)s0 + 2 * (p - odd)) * 4 + odd * (8 * P * 8);
+                if (!deferred) {
 #pragma unroll
-                for (int i = 0; i < 8; ++i) {   // raw: (v[2i], v[2i+1]) = the lane's two points of load i; unpack_pairs() sorts them out
-                    const float4 q = buf_load_f32x4(rx, voff, i * P * 8);
-                    v[2 * i] = make_float2(q.x, q.y);
-                    v[2 * i + 1] = make_float2(q.z, q.w);
+                    for (int i = 0; i < 8; ++i) load_one(i);
                 }
                 return true;
             } else {
@@ -249,7 +257,13 @@ __global__ __launch_bounds__(fft_threads(LOG2N, LOG2E)) void k_cqt(
         // The next frame's samples: v is dead until the next first pass.  Requested AFTER the split: 16 wavefronts x 16
         // loads overrun the CU's vector-memory queue, and a wave that blocks there ahead of its share of the split holds
         // the whole workgroup at the barrier (profiles/r02_notes.md; requested ahead of the split: 30.8 instead of 29.6 ms).
-        if (more) raw = load_frame(g + n_slots, p);
+        // Some of the waves request first and contract second, the others the other way round: 16 waves x 8 loads at once
+        // overrun the CU's vector-memory queue, and the waves served last (the youngest) started their contraction 3 k cycles late.
+#ifndef ZAFX_CQT_LOADS_FIRST
+#define ZAFX_CQT_LOADS_FIRST 8
+#endif
+        const bool loads_first = wave < ZAFX_CQT_LOADS_FIRST * (P / 64) / 16;
+        if (more && loads_first) raw = load_frame(g + n_slots, p);
         PROF_MARK(7);
         // ---- CSR mat-vec against the spectrum + |.|^2 (zaf.py:630-632).  Entry (iteration, lane) of the wave's share is a
         // value and a word: bits 0-17 the LDS byte address of its spectrum bin, bit 31 "conjugate" (a column of the upper
@@ -320,6 +334,7 @@ __global__ __launch_bounds__(fft_threads(LOG2N, LOG2E)) void k_cqt(
                 }
             }
         }
+        if (more && !loads_first) raw = load_frame(g + n_slots, p);
         PROF_MARK(4);
         if (more) {   // (waits for the prefetched samples; the other waves are still contracting)
             if (raw) unpack_pairs(p);

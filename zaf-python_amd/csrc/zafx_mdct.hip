@@ -488,13 +488,23 @@ __global__ __launch_bounds__(NSLOT * fft_threads(LOG2NF, LOG2E)) void k_imdct(
     PROF_MARK(1);
     lds_barrier();
     PROF_MARK(2);
-    if constexpr (PRE) {   // the next tile of this workgroup: same unit, or the first tile of its next unit
+#ifndef ZAFX_IMDCT_STAGGER
+#define ZAFX_IMDCT_STAGGER 1
+#endif
+    // The next tile of this workgroup (same unit, or the first tile of its next unit) is requested by half of the waves now and
+    // by the other half after their transforms: 16 waves x 8 loads at once overrun the CU's vector-memory queue and the youngest
+    // waves start their transforms behind it.
+    const bool gather_now = !ZAFX_IMDCT_STAGGER || tid < NT / 2;
+    auto gather_next = [&]() {
         int unit_n = unit, tile_n = tile + 1;
         if (tile_n >= tile_b) {
             unit_n = unit + gridDim.x;
             tile_n = unit_n < total_units ? first_tile(unit_n) : 0;
         }
         gather4(unit_n, tile_n);
+    };
+    if constexpr (PRE) {
+        if (gather_now) gather_next();
     }
     if constexpr (PRE_TF) {
         int unit_n = unit, tile_n = tile + 1;
@@ -525,6 +535,9 @@ __global__ __launch_bounds__(NSLOT * fft_threads(LOG2NF, LOG2E)) void k_imdct(
                 buf[phys(kk)] = make_float2(b.x, -a.y);
             }
         }
+    }
+    if constexpr (PRE) {
+        if (!gather_now) gather_next();
     }
     PROF_MARK(3);
     lds_barrier();

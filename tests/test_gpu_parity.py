@@ -1076,6 +1076,8 @@ def test_window_not_a_power_of_two(zafx, wl, hop, n):
                 y = zafx.istft_batch(s_in[None], w, hop, layout=layout, onesided=one, f64=True)[0]
                 yref = orc.istft(ref, w, hop)
                 assert y.shape == yref.shape and (yref.size == 0 or relerr(y, yref) <= 1e-11), (layout, one, c)
+                y32 = zafx.istft_batch(s_in[None], w, hop, layout=layout, onesided=one)[0]   # float32 Bluestein form for wl >= 33
+                assert y32.dtype == np.float32 and y32.shape == yref.shape and (yref.size == 0 or relerr(y32, yref) <= TOL_FFT), (layout, one, c)
     got64 = zafx.stft_batch(x.astype(np.float64), w, hop, f64=True)
     assert got64.dtype == np.complex128 and relerr(got64[0], orc.stft(x[0].astype(np.float64), w, hop)) <= 1e-11
     mag = zafx.stft_batch(x, w, hop, onesided="magnitude")
@@ -1114,10 +1116,34 @@ def test_mdct_window_not_a_power_of_two(zafx, wl, n):
             y = zafx.imdct_batch(c_in[None], w, layout=layout, f64=True)[0]
             yref = orc.imdct(ref, w)
             assert y.shape == yref.shape and (yref.size == 0 or relerr(y, yref) <= 1e-11), (layout, c)
+            y32 = zafx.imdct_batch(c_in[None], w, layout=layout)[0]   # float32 Bluestein form for wl >= 34
+            assert y32.dtype == np.float32 and y32.shape == yref.shape and (yref.size == 0 or relerr(y32, yref) <= TOL_FFT), (layout, c)
             m = min(n, yref.size)
             assert m == 0 or np.max(np.abs(y[:m] - x[c][:m])) < 1e-9
     with pytest.raises(ValueError):
         zafx.mdct_batch(x, np.ones(999))
+
+
+def test_bluestein_f32_plans_and_sizes(zafx):
+    """The float32 Bluestein forms (zafx_bs32.hip): which plans take them, every convolution length 128 ... 4096, a hop far
+    below the window (the gather overlap-add has no tile limit), a batch, kernel names."""
+    for wl, hop, name in ((33, 11, "k_stft_bs32"), (100, 25, "k_stft_bs32"), (1764, 441, "k_stft_bs32"), (2047, 100, "k_stft_bs32")):
+        w = orc.hamming_periodic(wl)
+        plan = zafx.stft_plan(w, hop)
+        assert not plan.f64 and plan.kernel_name == name and plan.out_dtype == np.complex64
+        assert zafx.istft_plan(w, hop).kernel_name == "k_ifft_frames_bs32"
+    assert zafx.stft_plan(orc.hamming_periodic(31), 7).f64            # below 33 samples: float64 kernels
+    assert zafx.mdct_plan(orc.sine_window(1920)).kernel_name == "k_mdct_bs32"
+    assert zafx.mdct_plan(orc.sine_window(1920), inverse=True).kernel_name == "k_imdct_frames_bs32"
+    x = np.stack([synth_clip(75, c, 30000) for c in range(5)])
+    for wl, hop in ((65, 16), (129, 64), (300, 75), (600, 200), (1100, 275), (1764, 441), (2047, 100)):   # M = 256 ... 4096
+        w = orc.hamming_periodic(wl)
+        got = zafx.stft_batch(x, w, hop)
+        ref = orc.stft(x[4].astype(np.float64), w, hop)
+        assert got[4].shape == ref.shape and relerr(got[4], ref) <= TOL_FFT, (wl, hop)
+        y = zafx.istft_batch(got, w, hop)
+        yref = orc.istft(ref, w, hop)
+        assert relerr(y[4], yref) <= 3 * TOL_FFT, (wl, hop)   # (round trip: the float32 spectrum goes back in)
 
 
 def test_f64_inverse_transforms_in_scratch_chunks(tmp_path):

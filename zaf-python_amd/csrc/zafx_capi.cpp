@@ -169,6 +169,43 @@ static void free_band(PackedBand& pb) {
 // k_cqt's view of the CQT kernel matrix: rows sorted by length, four per step, steps dealt to the wavefronts.
 static int build_cqt_chunks(zafx_plan* pl);
 
+// Bluestein tables of a W-point DFT as a convolution of length M = 2^log2m, in long double: the chirp
+// c[n] = exp(-i pi n^2 / W) (angle reduced in integers: n^2 mod 2W) and Bhat = FFT_M of conj(c) wrapped to length M.
+typedef std::complex<long double> cld;
+static void bluestein_tables(int W, int log2m, std::vector<cld>& chirp, std::vector<cld>& bhat) {
+    const int M = 1 << log2m;
+    const long double pi = 3.14159265358979323846264338327950288L;
+    chirp.assign((size_t)W, cld(0, 0));
+    bhat.assign((size_t)M, cld(0, 0));
+    for (long long k = 0; k < W; ++k) {
+        const long long r = (k * k) % (2LL * W);
+        const long double ang = pi * (long double)r / (long double)W;
+        cld v(cosl(ang), sinl(ang));   // conj(c[k]) = exp(+i pi k^2 / W)
+        if (r == 0) v = cld(1, 0);
+        if (r == W) v = cld(-1, 0);
+        if (2 * r == W) v = cld(0, 1);
+        if (2 * r == 3LL * W) v = cld(0, -1);
+        chirp[(size_t)k] = std::conj(v);
+        bhat[(size_t)k] = v;
+        if (k) bhat[(size_t)(M - k)] = v;
+    }
+    for (int i = 1, j = 0; i < M; ++i) {   // bit reversal, then radix-2 passes
+        int bit = M >> 1;
+        for (; j & bit; bit >>= 1) j ^= bit;
+        j ^= bit;
+        if (i < j) std::swap(bhat[(size_t)i], bhat[(size_t)j]);
+    }
+    for (int len = 2; len <= M; len <<= 1)
+        for (int i = 0; i < M; i += len)
+            for (int k = 0; k < len / 2; ++k) {
+                const long double ang = -2.0L * pi * (long double)k / (long double)len;
+                const cld w(cosl(ang), sinl(ang));
+                const cld u = bhat[(size_t)(i + k)], v = bhat[(size_t)(i + k + len / 2)] * w;
+                bhat[(size_t)(i + k)] = u + v;
+                bhat[(size_t)(i + k + len / 2)] = u - v;
+            }
+}
+
 static bool is_stft_family(int kind) { return kind == ZAFX_STFT || kind == ZAFX_ISTFT || kind == ZAFX_MEL || kind == ZAFX_MFCC; }
 static bool is_mdct_family(int kind) { return kind == ZAFX_MDCT || kind == ZAFX_IMDCT; }
 static bool is_cqt_family(int kind) { return kind == ZAFX_CQT || kind == ZAFX_CHROMA; }
@@ -474,8 +511,12 @@ int zafx_plan_create(zafx_plan** out, int device, int kind, const zafx_params* p
             // any length up to 2048 in the float64 mode: Bluestein convolution of length 2^bs_log2m >= 2 W - 1
             while ((1 << pl->bs_log2m) < 2 * pl->W - 1) ++pl->bs_log2m;
             lw = 6;   // (only sizes the unused float32 tables below)
+        } else if (lw < 0 && params->precision == ZAFX_PRECISION_F32 && (kind == ZAFX_STFT || kind == ZAFX_ISTFT) && bs32_supported(pl->W)) {
+            while ((1 << pl->bs_log2m) < 2 * pl->W - 1) ++pl->bs_log2m;   // float32 Bluestein forms (zafx_bs32.hip)
+            lw = 6;
         } else if (lw < 0 || !stft_supported(lw - 1)) {
-            return bail("window_length must be a power of two in [64, 8192] (any length in [2, 2048] with ZAFX_PRECISION_F64)");
+            return bail("window_length must be a power of two in [64, 8192], or any length in [33, 2048] for ZAFX_STFT / ZAFX_ISTFT "
+                        "(any length in [2, 2048] with ZAFX_PRECISION_F64)");
         }
         if (pl->H < 1) return bail("step_length must be >= 1");
         if (kind == ZAFX_ISTFT && pl->H > pl->W) return bail("istft: step_length must not exceed window_length");
@@ -503,8 +544,12 @@ int zafx_plan_create(zafx_plan** out, int device, int kind, const zafx_params* p
         if ((lw < 0 || lw < 6) && params->precision == ZAFX_PRECISION_F64 && pl->W >= 4 && pl->W <= 2048 && pl->W % 2 == 0) {
             while ((1 << pl->bs_log2m) < 2 * pl->W - 1) ++pl->bs_log2m;   // any even length in the float64 mode (Bluestein)
             lw = 6;
+        } else if (lw < 0 && params->precision == ZAFX_PRECISION_F32 && pl->W % 2 == 0 && bs32_supported(pl->W)) {
+            while ((1 << pl->bs_log2m) < 2 * pl->W - 1) ++pl->bs_log2m;   // float32 Bluestein forms (zafx_bs32.hip)
+            lw = 6;
         } else if (lw < 0 || !mdct_supported(lw - 2)) {
-            return bail("window_length must be a power of two in [64, 8192] (any even length in [4, 2048] with ZAFX_PRECISION_F64)");
+            return bail("window_length must be a power of two in [64, 8192] or any even length in [34, 2048] "
+                        "(any even length in [4, 2048] with ZAFX_PRECISION_F64)");
         }
         pl->log2nf = lw - 2;
         const int nf = pl->W / 4, m = pl->W / 2;
@@ -558,6 +603,31 @@ int zafx_plan_create(zafx_plan** out, int device, int kind, const zafx_params* p
         }
     }
     if (e == hipSuccess) e = upload(&pl->d_tw_aux, aux.data(), aux.size() * sizeof(cf32));
+    if (e == hipSuccess && pl->prm.precision == ZAFX_PRECISION_F32 && pl->bs_log2m > 0) {   // float32 Bluestein plan (zafx_bs32.hip)
+        const int M = 1 << pl->bs_log2m, W = pl->W, F = W / 2;
+        auto twm = build_pass_twiddles(pl->bs_log2m, default_log2e(pl->bs_log2m));
+        if (twm.empty()) twm.push_back(cf32{1.f, 0.f});
+        e = upload(&pl->d_tw_pass, twm.data(), twm.size() * sizeof(cf32));
+        std::vector<cld> c, b;
+        bluestein_tables(W, pl->bs_log2m, c, b);
+        std::vector<cf32> cf((size_t)W), bf((size_t)M);
+        for (int i = 0; i < W; ++i) cf[(size_t)i] = cf32{(float)c[(size_t)i].real(), (float)c[(size_t)i].imag()};
+        for (int i = 0; i < M; ++i) bf[(size_t)i] = cf32{(float)b[(size_t)i].real(), (float)b[(size_t)i].imag()};
+        if (e == hipSuccess) e = upload(&pl->d_bs_chirp, cf.data(), cf.size() * sizeof(cf32));
+        if (e == hipSuccess) e = upload(&pl->d_bs_bhat, bf.data(), bf.size() * sizeof(cf32));
+        if (is_mdct_family(kind)) {   // pre / post twiddles of the reference's own W-point formulation (zaf.py:1047-1056, :1138-1156)
+            std::vector<cf32> pp;
+            if (kind == ZAFX_MDCT) {
+                for (int n = 0; n < W; ++n) pp.push_back(unit_root(n, 2LL * W));                                  // exp(-i pi n / W)
+                for (int k = 0; k < F; ++k) pp.push_back(unit_root((long long)(F + 1) * (2 * k + 1), 4LL * W));   // exp(-i pi (F+1)(2k+1) / (2W))
+            } else {
+                for (int k = 0; k < F; ++k) pp.push_back(unit_root((long long)(F + 1) * k, 2LL * W));             // exp(-i pi (F+1) k / W)
+                for (int n = 0; n < W; ++n) pp.push_back(unit_root(2LL * n + 1 + F, 4LL * W));                    // exp(-i pi (2n+1+F) / (2W))
+            }
+            if (e == hipSuccess) e = upload(&pl->d_tw_aux, pp.data(), pp.size() * sizeof(cf32));
+        }
+        pl->kernel_name = kind == ZAFX_STFT ? "k_stft_bs32" : kind == ZAFX_ISTFT ? "k_ifft_frames_bs32" : kind == ZAFX_MDCT ? "k_mdct_bs32" : "k_imdct_frames_bs32";
+    }
     if (e == hipSuccess && pl->prm.precision == ZAFX_PRECISION_F64) {   // float64 tables, evaluated in long double
         const bool mdct = is_mdct_family(kind), cqt = is_cqt_family(kind);
         const int n = mdct ? pl->W / 4 : cqt ? std::min(pl->W, kCqt64Sub) : pl->W / 2;   // FFT length (CQT: of one decimated sub-sequence)
@@ -577,32 +647,8 @@ int zafx_plan_create(zafx_plan** out, int device, int kind, const zafx_params* p
             for (int m = 0; m < M / 2; ++m) tw[(size_t)m] = root(m, M);
             tws.assign((size_t)W, make_double2(0, 0));
             for (long long k = 0; k < W; ++k) tws[(size_t)k] = root((k * k) % (2LL * W), 2LL * W);
-            // b[m] = conj(c[|m|]) for -W < m < W, wrapped to length M; radix-2 FFT in long double
-            typedef std::complex<long double> cld;
-            std::vector<cld> b((size_t)M, cld(0, 0));
-            const long double pi = 3.14159265358979323846264338327950288L;
-            for (long long k = 0; k < W; ++k) {
-                const long double ang = pi * (long double)((k * k) % (2LL * W)) / (long double)W;
-                const cld v(cosl(ang), sinl(ang));   // conj(c[k]) = exp(+i pi k^2 / W)
-                b[(size_t)k] = v;
-                if (k) b[(size_t)(M - k)] = v;
-            }
-            for (int i = 1, j = 0; i < M; ++i) {   // bit reversal
-                int bit = M >> 1;
-                for (; j & bit; bit >>= 1) j ^= bit;
-                j ^= bit;
-                if (i < j) std::swap(b[(size_t)i], b[(size_t)j]);
-            }
-            for (int len = 2; len <= M; len <<= 1) {
-                for (int i = 0; i < M; i += len)
-                    for (int k = 0; k < len / 2; ++k) {
-                        const long double ang = -2.0L * pi * (long double)k / (long double)len;
-                        const cld w(cosl(ang), sinl(ang));
-                        const cld u = b[(size_t)(i + k)], v = b[(size_t)(i + k + len / 2)] * w;
-                        b[(size_t)(i + k)] = u + v;
-                        b[(size_t)(i + k + len / 2)] = u - v;
-                    }
-            }
+            std::vector<cld> c, b;
+            bluestein_tables(W, pl->bs_log2m, c, b);
             std::vector<double2> bhat((size_t)M);
             for (int i = 0; i < M; ++i) bhat[(size_t)i] = make_double2((double)b[(size_t)i].real(), (double)b[(size_t)i].imag());
             e = upload(&pl->d_bhat64, bhat.data(), bhat.size() * sizeof(double2));
@@ -655,6 +701,8 @@ int zafx_plan_destroy(zafx_plan* pl) {
     if (pl->d_dct64) (void)hipFree(pl->d_dct64);
     if (pl->d_values64) (void)hipFree(pl->d_values64);
     if (pl->d_bhat64) (void)hipFree(pl->d_bhat64);
+    if (pl->d_bs_chirp) (void)hipFree(pl->d_bs_chirp);
+    if (pl->d_bs_bhat) (void)hipFree(pl->d_bs_bhat);
     free_band(pl->fb);
     free_band(pl->dct);
     if (pl->ev0) (void)hipEventDestroy(pl->ev0);
@@ -822,19 +870,23 @@ int zafx_execute(zafx_plan* pl, const void* d_in, void* d_out, int64_t n_clips, 
     switch (pl->kind) {
         case ZAFX_STFT:
             if (pl->prm.precision == ZAFX_PRECISION_F64) e = launch_stft_f64(*pl, (const double*)d_in, (double2*)d_out, n_clips, n_in, (int)dims[1]);
+            else if (pl->bs_log2m > 0) e = launch_stft_bs32(*pl, (const float*)d_in, (float2*)d_out, n_clips, n_in, (int)dims[1]);
             else e = launch_stft(*pl, (const float*)d_in, (float2*)d_out, n_clips, n_in, (int)dims[1]);
             break;
         case ZAFX_ISTFT:
             if (pl->cola_gain == 0.f) return fail_msg("istft: sum(window[0:W:H]) is zero (zaf.py:241 would divide by zero)");
             if (pl->prm.precision == ZAFX_PRECISION_F64) e = launch_istft_f64(*pl, (const double2*)d_in, (double*)d_out, n_clips, (int)n_in, dims[0]);
+            else if (pl->bs_log2m > 0) e = launch_istft_bs32(*pl, (const float2*)d_in, (float*)d_out, n_clips, (int)n_in, dims[0]);
             else e = launch_istft(*pl, (const float2*)d_in, (float*)d_out, n_clips, (int)n_in, dims[0]);
             break;
         case ZAFX_MDCT:
             if (pl->prm.precision == ZAFX_PRECISION_F64) e = launch_mdct_f64(*pl, (const double*)d_in, (double*)d_out, n_clips, n_in, (int)dims[1]);
+            else if (pl->bs_log2m > 0) e = launch_mdct_bs32(*pl, (const float*)d_in, (float*)d_out, n_clips, n_in, (int)dims[1]);
             else e = launch_mdct(*pl, (const float*)d_in, (float*)d_out, n_clips, n_in, (int)dims[1]);
             break;
         case ZAFX_IMDCT:
             if (pl->prm.precision == ZAFX_PRECISION_F64) e = launch_imdct_f64(*pl, (const double*)d_in, (double*)d_out, n_clips, (int)n_in, dims[0]);
+            else if (pl->bs_log2m > 0) e = launch_imdct_bs32(*pl, (const float*)d_in, (float*)d_out, n_clips, (int)n_in, dims[0]);
             else e = launch_imdct(*pl, (const float*)d_in, (float*)d_out, n_clips, (int)n_in, dims[0]);
             break;
         case ZAFX_MEL:

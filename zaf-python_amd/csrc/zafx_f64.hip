@@ -573,7 +573,7 @@ const char* istft_f64_kernel_name() { return "k_ifft_frames_f64"; }
 static int threads_for(size_t smem) { return smem > 80 * 1024 ? kThreadsBig : smem > 40 * 1024 ? 512 : kThreads; }
 
 // grow-only scratch of time-domain frames, owned by the plan
-static hipError_t grow_scratch(zafx_plan& pl, size_t need) {
+hipError_t grow_scratch(zafx_plan& pl, size_t need) {
     if (need <= pl.scratch_bytes) return hipSuccess;
     if (hipError_t e = hipStreamSynchronize(pl.stream); e != hipSuccess) return e;
     if (pl.d_scratch64) (void)hipFree(pl.d_scratch64);
@@ -620,10 +620,11 @@ static size_t scratch_budget() {   // 1 GiB; ZAFX_SCRATCH_BUDGET_MB overrides it
     }();
     return budget;
 }
-static int64_t clips_per_chunk(int64_t n_clips, int T, int W) {
-    const size_t per_clip = (size_t)T * (size_t)W * sizeof(double);
+int64_t scratch_clips_per_chunk(int64_t n_clips, int T, int W, size_t elem_bytes) {
+    const size_t per_clip = (size_t)T * (size_t)W * elem_bytes;
     return std::max<int64_t>(1, std::min<int64_t>(n_clips, (int64_t)(scratch_budget() / std::max<size_t>(per_clip, 1))));
 }
+static int64_t clips_per_chunk(int64_t n_clips, int T, int W) { return scratch_clips_per_chunk(n_clips, T, W, sizeof(double)); }
 
 hipError_t launch_istft_f64(zafx_plan& pl, const double2* spec_all, double* y_all, int64_t n_clips_all, int T, int64_t out_len) {
     if ((long long)n_clips_all * T <= 0 || out_len <= 0) return hipSuccess;

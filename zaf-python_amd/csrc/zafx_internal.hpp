@@ -99,7 +99,9 @@ struct zafx_plan {
     int* d_fb64_meta = nullptr;    // [n_filters][3]: first column, count, offset into d_fb64
     double* d_dct64 = nullptr;     // [n_coefs][n_filters]
     double2* d_values64 = nullptr; // CQT kernel values of a float64 plan (complex128)
-    int bs_log2m = 0;              // > 0: window that is not a power of two -- Bluestein convolution length 2^bs_log2m (zafx_f64.hip)
+    int bs_log2m = 0;              // > 0: window that is not a power of two -- Bluestein convolution length 2^bs_log2m (zafx_f64.hip, zafx_bs32.hip)
+    float2* d_bs_chirp = nullptr;  // float32 Bluestein plans: c[n] = exp(-i pi n^2 / W), n < W
+    float2* d_bs_bhat = nullptr;   // ... and FFT_M of the wrapped conjugate chirp
     double2* d_bhat64 = nullptr;   // FFT of the wrapped conjugate chirp, 2^bs_log2m entries
     std::vector<double2> h_values64;
     int cqt_k_lo = 0, cqt_k_hi = -1, cqt_k_special = 0;   // real-split pairs the kernel's columns need
@@ -137,6 +139,16 @@ const char* mdct_f64_kernel_name();
 const char* mel_f64_kernel_name();
 const char* cqt_f64_kernel_name();
 const char* imdct_f64_kernel_name();
+// float32 Bluestein forms (zafx_bs32.hip): windows of 33 ... 2048 samples that are not a power of two
+bool bs32_supported(int W);
+hipError_t launch_stft_bs32(const zafx_plan& pl, const float* x, float2* out, int64_t n_clips, int64_t n_samples, int T);
+hipError_t launch_istft_bs32(zafx_plan& pl, const float2* spec, float* y, int64_t n_clips, int T, int64_t out_len);
+hipError_t launch_mdct_bs32(const zafx_plan& pl, const float* x, float* out, int64_t n_clips, int64_t n_samples, int T);
+hipError_t launch_imdct_bs32(zafx_plan& pl, const float* coefs, float* y, int64_t n_clips, int T, int64_t out_len);
+// plan-owned scratch of the inverse transforms that park their time-domain frames (zafx_f64.hip): grow-only, and the number
+// of clips per pass that keeps it under the budget (1 GiB; ZAFX_SCRATCH_BUDGET_MB)
+hipError_t grow_scratch(zafx_plan& pl, size_t need);
+int64_t scratch_clips_per_chunk(int64_t n_clips, int T, int W, size_t elem_bytes);
 hipError_t launch_mdct(const zafx_plan& pl, const float* x, float* out, int64_t n_clips, int64_t n_samples, int T);
 hipError_t launch_imdct(const zafx_plan& pl, const float* coefs, float* y, int64_t n_clips, int T, int64_t out_len);
 hipError_t launch_mel(const zafx_plan& pl, const float* x, float* out, int64_t n_clips, int64_t n_samples, int T);

@@ -435,8 +435,14 @@ def _pow2(n):
 
 
 def _tuned(n):
-    """Window lengths of the float32 kernels; every other supported length runs on the float64 Bluestein kernels."""
+    """Window lengths of the tiled float32 kernels (powers of two)."""
     return _pow2(n) and 64 <= n <= 8192
+
+
+def _f32_window(n):
+    """Window lengths with float32 kernels: the powers of two 64 ... 8192 (tiled kernels) and every other length 33 ... 2048
+    (float32 Bluestein forms of STFT / ISTFT / MDCT / IMDCT, zafx_bs32.hip); the rest (below 33 samples) runs in float64."""
+    return _tuned(n) or (33 <= n <= 2048 and not _pow2(n))
 
 
 def _as_window(window_function, any_length=False):
@@ -503,10 +509,10 @@ def stft_plan(window_function, step_length, layout="FT", device=0, onesided=Fals
     """row_align (every 2-D plan factory): pad the rows of the device (F, T) array to a multiple of this many elements
     (16 for complex64, 32 for float32 = one 128-byte line) so that the reference-layout kernels run at their aligned
     rate for any T; Plan.out_shape / Plan.row_pitch give the padded geometry, 0 keeps the reference's compact order.
-    A window outside the float32 kernels (not a power of two, or below 64 samples) yields a float64 plan whatever `f64`
-    says: Plan.in_dtype / Plan.out_dtype tell which arrays it takes."""
+    A window outside the float32 kernels (below 33 samples) yields a float64 plan whatever `f64` says: Plan.in_dtype /
+    Plan.out_dtype tell which arrays it takes."""
     w, h = _as_window(window_function, any_length=True), _as_step(step_length)   # (a hop above the window skips samples, as zaf.stft does)
-    f64 = bool(f64) or not _tuned(len(w))   # windows that are not a power of two (or below 64): float64 Bluestein kernels
+    f64 = bool(f64) or not _f32_window(len(w))   # (windows below 33 samples: float64 Bluestein kernels)
     key = ("stft", device, len(w), h, _LAYOUTS[layout], _spectrum_of(onesided), bool(f64), _as_row_align(row_align, layout), _digest(w))
 
     def make():
@@ -526,7 +532,8 @@ def istft_plan(window_function, step_length, layout="FT", device=0, onesided=Fal
     # the float32 overlap-add keeps a tile of 16 frames in LDS (8 at W = 4096, 4 at 8192): a hop so small that more
     # frames than that cover one sample runs on the float64 kernels (a gather overlap-add without that limit)
     tile = 16 if len(w) <= 2048 else (8 if len(w) == 4096 else 4)
-    f64 = bool(f64) or -(-len(w) // h) > tile or not _tuned(len(w))
+    # (windows that are not a power of two take the float32 Bluestein form, whose gather overlap-add has no such limit)
+    f64 = bool(f64) or not _f32_window(len(w)) or (_tuned(len(w)) and -(-len(w) // h) > tile)
     key = ("istft", device, len(w), h, _LAYOUTS[layout], bool(onesided), bool(f64), _as_row_align(row_align, layout), _digest(w))
 
     def make():
@@ -541,7 +548,7 @@ def mdct_plan(window_function, layout="FT", device=0, inverse=False, row_align=0
     w = _as_window(window_function, any_length=True)
     if len(w) % 2 or len(w) < 4:
         raise ValueError("the MDCT needs an even window_length >= 4")
-    f64 = bool(f64) or not _tuned(len(w))   # even lengths that are not a power of two (or below 64): float64 Bluestein kernels
+    f64 = bool(f64) or not _f32_window(len(w))   # (even lengths below 34: float64 Bluestein kernels)
     key = ("imdct" if inverse else "mdct", device, len(w), _LAYOUTS[layout], _as_row_align(row_align, layout), bool(f64), _digest(w))
 
     def make():

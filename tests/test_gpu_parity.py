@@ -291,10 +291,10 @@ def test_errors(zafx):
         zafx.stft(x, zafx.hamming(3000), 500)         # window not a power of two and above 2048
     with pytest.raises(ValueError):
         zafx.melspectrogram(x, ham, 1024, np.ones((4, 1024)))   # filterbank must expose .toarray()
-    with pytest.raises(zafx.ZafxError):                          # ceil(W/H) too large for the float32 OLA tile: the C-ABI
-        p = zafx.Plan(zafx.ISTFT, window_length=2048, step_length=64)   # refuses (the host layer would pick the float64 kernels)
-        p.set_window(ham)
-        d_s = zafx.DeviceBuffer.from_host(np.zeros((1, 2048, 4), np.complex64))
+    with pytest.raises(zafx.ZafxError):                          # ceil(W/H) too large for the float32 OLA tile at W = 4096: the C-ABI
+        p = zafx.Plan(zafx.ISTFT, window_length=4096, step_length=64)   # refuses (the host layer picks the float64 kernels; up to
+        p.set_window(zafx.hamming(4096))                                # W = 2048 the float32 frames + gather form takes over)
+        d_s = zafx.DeviceBuffer.from_host(np.zeros((1, 4096, 4), np.complex64))
         d_y = zafx.DeviceBuffer(p.out_shape(1, 4), p.out_dtype)
         p.execute(d_s, d_y, 1, 4)
 
@@ -1043,8 +1043,9 @@ def test_mel_long_window_or_wide_bank(zafx, wl, hop, nmel):
 
 @pytest.mark.parametrize("wl,hop,n", [(2048, 100, 20000), (4096, 300, 30000), (8192, 1000, 40000), (64, 3, 1000)])
 def test_istft_tiny_hop(zafx, wl, hop, n):
-    """More overlapping frames per sample than the float32 overlap-add tile holds: the host layer runs the ISTFT on the
-    float64 kernels (no such limit) and still returns float32."""
+    """More overlapping frames per sample than the float32 overlap-add tile holds: up to W = 2048 the plan takes the float32
+    frames + gather overlap-add form (zafx_bs32.hip), above it the host layer runs the ISTFT on the float64 kernels (no such
+    limit either) and still returns float32."""
     x = synth_clip(67, 0, n)
     w = zafx.hamming(wl)
     ref_s = orc.stft(x.astype(np.float64), w, hop)

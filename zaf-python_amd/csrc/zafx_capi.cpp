@@ -521,6 +521,12 @@ int zafx_plan_create(zafx_plan** out, int device, int kind, const zafx_params* p
         if (pl->H < 1) return bail("step_length must be >= 1");
         if (kind == ZAFX_ISTFT && pl->H > pl->W) return bail("istft: step_length must not exceed window_length");
         if (pl->H > (1 << 20)) return bail("step_length must not exceed 2^20");
+        if (kind == ZAFX_ISTFT && params->precision == ZAFX_PRECISION_F32 && pl->bs_log2m == 0 && bs32_supported(pl->W)) {
+            // A hop so small that more frames cover a sample than the tiled overlap-add keeps in LDS (16): the frames + gather
+            // overlap-add form of zafx_bs32.hip has no such limit and takes any length, powers of two included.
+            if ((pl->W + pl->H - 1) / pl->H > 16)
+                while ((1 << pl->bs_log2m) < 2 * pl->W - 1) ++pl->bs_log2m;
+        }
         pl->log2nf = lw - 1;
         if (kind == ZAFX_MEL || kind == ZAFX_MFCC) {
             if (params->n_filters < 1 || (params->precision != ZAFX_PRECISION_F64 && params->n_filters > 256))

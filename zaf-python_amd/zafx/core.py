@@ -532,8 +532,9 @@ def istft_plan(window_function, step_length, layout="FT", device=0, onesided=Fal
     # the float32 overlap-add keeps a tile of 16 frames in LDS (8 at W = 4096, 4 at 8192): a hop so small that more
     # frames than that cover one sample runs on the float64 kernels (a gather overlap-add without that limit)
     tile = 16 if len(w) <= 2048 else (8 if len(w) == 4096 else 4)
-    # (windows that are not a power of two take the float32 Bluestein form, whose gather overlap-add has no such limit)
-    f64 = bool(f64) or not _f32_window(len(w)) or (_tuned(len(w)) and -(-len(w) // h) > tile)
+    # (windows up to 2048 samples then take the float32 frames + gather overlap-add form of zafx_bs32.hip, which has no such
+    # limit -- as do all windows that are not a power of two; W = 4096 / 8192 with such hops run in float64)
+    f64 = bool(f64) or not _f32_window(len(w)) or (len(w) > 2048 and -(-len(w) // h) > tile)
     key = ("istft", device, len(w), h, _LAYOUTS[layout], bool(onesided), bool(f64), _as_row_align(row_align, layout), _digest(w))
 
     def make():

@@ -11,6 +11,7 @@
 #include <algorithm>
 #include <cstdlib>
 
+#include "zafx_fft.hpp"
 #include "zafx_internal.hpp"
 
 namespace zafx {
@@ -56,7 +57,7 @@ __global__ __launch_bounds__(kThreadsBig) void k_stft_f64(
     const bool one = spec != 0;
     double2* a = reinterpret_cast<double2*>(smem_raw);
     double2* b = a + N;
-    const long long g = blockIdx.x;
+    const long long g = xcd_order((int)blockIdx.x, (int)gridDim.x);   // neighbouring frames to one XCD: the rows they share lines of meet in its L2
     const long long clip = g / T;
     const int t = (int)(g - clip * T);
     const double* xc = x + clip * n_samples;
@@ -111,7 +112,7 @@ __global__ __launch_bounds__(kThreadsBig) void k_ifft_frames_f64(
     const int N = 1 << log2n, W = 2 * N, rows = one ? N + 1 : W;
     double2* a = reinterpret_cast<double2*>(smem_raw);
     double2* b = a + N;
-    const long long g = blockIdx.x;
+    const long long g = xcd_order((int)blockIdx.x, (int)gridDim.x);   // neighbouring frames to one XCD: the rows they share lines of meet in its L2
     const long long clip = g / T;
     const int t = (int)(g - clip * T);
     const long long stride = layout == ZAFX_LAYOUT_FT ? TP : 1;
@@ -277,7 +278,7 @@ __global__ __launch_bounds__(kThreadsBig) void k_mel_f64(
     const bool mfcc = n_coefs > 0;
     double2* a = reinterpret_cast<double2*>(smem_raw);
     double2* b = a + N;
-    const long long g = blockIdx.x;
+    const long long g = xcd_order((int)blockIdx.x, (int)gridDim.x);   // neighbouring frames to one XCD: the rows they share lines of meet in its L2
     const long long clip = g / T;
     const int t = (int)(g - clip * T);
     const double* xc = x + clip * n_samples;
@@ -347,7 +348,7 @@ __global__ __launch_bounds__(kThreadsBig) void k_stft_bs_f64(
     const int M = 1 << log2m;
     double2* a = reinterpret_cast<double2*>(smem_raw);
     double2* b = a + M;
-    const long long g = blockIdx.x;
+    const long long g = xcd_order((int)blockIdx.x, (int)gridDim.x);   // neighbouring frames to one XCD: the rows they share lines of meet in its L2
     const long long clip = g / T;
     const int t = (int)(g - clip * T);
     const double* xc = x + clip * n_samples;
@@ -392,7 +393,7 @@ __global__ __launch_bounds__(kThreadsBig) void k_ifft_frames_bs_f64(
     const int M = 1 << log2m, rows = one ? W / 2 + 1 : W;
     double2* a = reinterpret_cast<double2*>(smem_raw);
     double2* b = a + M;
-    const long long g = blockIdx.x;
+    const long long g = xcd_order((int)blockIdx.x, (int)gridDim.x);   // neighbouring frames to one XCD: the rows they share lines of meet in its L2
     const long long clip = g / T;
     const int t = (int)(g - clip * T);
     const long long stride = layout == ZAFX_LAYOUT_FT ? TP : 1;
@@ -425,7 +426,7 @@ __global__ __launch_bounds__(kThreadsBig) void k_mdct_bs_f64(
     const int M = 1 << log2m, F = W / 2;
     double2* a = reinterpret_cast<double2*>(smem_raw);
     double2* b = a + M;
-    const long long g = blockIdx.x;
+    const long long g = xcd_order((int)blockIdx.x, (int)gridDim.x);   // neighbouring frames to one XCD: the rows they share lines of meet in its L2
     const long long clip = g / T;
     const int t = (int)(g - clip * T);
     const double* xc = x + clip * n_samples;
@@ -455,7 +456,7 @@ __global__ __launch_bounds__(kThreadsBig) void k_imdct_frames_bs_f64(
     const int M = 1 << log2m, F = W / 2;
     double2* a = reinterpret_cast<double2*>(smem_raw);
     double2* b = a + M;
-    const long long g = blockIdx.x;
+    const long long g = xcd_order((int)blockIdx.x, (int)gridDim.x);   // neighbouring frames to one XCD: the rows they share lines of meet in its L2
     const long long clip = g / T;
     const int t = (int)(g - clip * T);
     const long long stride = layout == ZAFX_LAYOUT_FT ? TP : 1;

@@ -54,7 +54,8 @@ __global__ __launch_bounds__(FPB * fft_threads(LOG2NF, LOG2E)) void k_mdct(
     for (int i = tid; i < C::TW; i += NT) tw_l[i] = twp[i];
 
     const int slot = tid / P, p = tid % P;
-    const int clip = blockIdx.x / tiles, tile = blockIdx.x % tiles;
+    const int bid = ZAFX_XCD_ORDER ? xcd_order((int)blockIdx.x, (int)gridDim.x) : (int)blockIdx.x;   // neighbouring tiles to one XCD: their partial lines merge in its L2
+    const int clip = bid / tiles, tile = bid % tiles;
     const int t0 = tile * FPB;
     const int t = t0 + slot;
     float2* buf = frames + slot * C::PITCH;

@@ -75,7 +75,8 @@ __global__ __launch_bounds__(FPB * fft_threads(LOG2N, LOG2E)) void k_stft(
         __syncthreads();
     }
     const int slot = tid / P, p = tid % P;
-    const int clip = blockIdx.x / tiles, tile = blockIdx.x % tiles;
+    const int bid = ZAFX_XCD_ORDER ? xcd_order((int)blockIdx.x, (int)gridDim.x) : (int)blockIdx.x;   // neighbouring tiles to one XCD: their partial lines merge in its L2
+    const int clip = bid / tiles, tile = bid % tiles;
     const int t0 = tile * FPB;
     const int t = t0 + slot;
     float2* buf = frames + slot * C::PITCH;
@@ -442,7 +443,8 @@ __global__ __launch_bounds__(FPB * fft_threads(LOG2N, LOG2E)) void k_istft(
         for (int i = tid; i < C::TW; i += NT) tw_l[i] = twp[i];
         tw = tw_l;
     }
-    const int clip = blockIdx.x / tiles, tile = blockIdx.x % tiles;
+    const int bid = ZAFX_XCD_ORDER ? xcd_order((int)blockIdx.x, (int)gridDim.x) : (int)blockIdx.x;   // neighbouring tiles to one XCD: their partial lines merge in its L2
+    const int clip = bid / tiles, tile = bid % tiles;
     const int t_first = tile * owned - halo;   // frame held by slot 0 (may be < 0)
 
     // ---- phase A: gather the four two-sided bins of every pair, write packed Z to LDS

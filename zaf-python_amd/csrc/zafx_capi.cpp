@@ -139,7 +139,19 @@ static hipError_t pack_band(PackedBand& pb, const float* dense, int n_rows, int 
         for (const auto& e : empties) per_wave[(size_t)e.first].push_back(e.second);
         blk_ptr[(size_t)pb.n_blocks] = next;
         pb.n_items = next;
+        pb.n_empty = (int)empties.size();
     }
+    // per K-step descriptors (resident form of k_mel: 16 bits per step in scalar registers instead of the item walk):
+    // first column / 4 | slot id << 8 | item ends << 15
+    std::vector<unsigned short> desc((size_t)pb.total_steps + 2, 0);
+    pb.desc_ok = true;
+    for (const auto& v : per_wave)
+        for (const Item& it : v)
+            for (int s = 0; s < it.steps; ++s) {
+                const int col4 = it.first / 4 + s;
+                if (col4 > 255 || it.slot > 127) pb.desc_ok = false;
+                desc[(size_t)(it.off + s)] = (unsigned short)((col4 & 255) | ((it.slot & 127) << 8) | (s == it.steps - 1 ? 1 << 15 : 0));
+            }
     std::vector<int> flat, wave_ptr((size_t)n_waves + 1, 0);
     for (int w = 0; w < n_waves; ++w) {
         wave_ptr[(size_t)w] = (int)flat.size() / 4;
@@ -155,6 +167,7 @@ static hipError_t pack_band(PackedBand& pb, const float* dense, int n_rows, int 
     if (e == hipSuccess) e = upload(&pb.d_items, flat.data(), flat.size() * sizeof(int));
     if (e == hipSuccess) e = upload(&pb.d_wave_ptr, wave_ptr.data(), wave_ptr.size() * sizeof(int));
     if (e == hipSuccess) e = upload(&pb.d_blk_ptr, blk_ptr.data(), blk_ptr.size() * sizeof(int));
+    if (e == hipSuccess) e = upload(&pb.d_desc, desc.data(), desc.size() * sizeof(unsigned short));
     return e;
 }
 
@@ -163,6 +176,7 @@ static void free_band(PackedBand& pb) {
     if (pb.d_items) (void)hipFree(pb.d_items);
     if (pb.d_wave_ptr) (void)hipFree(pb.d_wave_ptr);
     if (pb.d_blk_ptr) (void)hipFree(pb.d_blk_ptr);
+    if (pb.d_desc) (void)hipFree(pb.d_desc);
     pb = PackedBand{};
 }
 

@@ -517,6 +517,16 @@ __device__ __forceinline__ void lane_row_transpose4(float& x0, float& x1, float&
         : "+v"(x0), "+v"(x1), "+v"(x2), "+v"(x3));
 }
 
+// Lane pairs that share 16-byte loads, paired across 16-lane rows: lane l of an even row and lane l + 16 take the points
+// n and n + 1 (mod 64), so that one v_permlane16_swap per register hands each its own (row_pair_unpack).  Every 32 lanes
+// still hold 32 consecutive residues: the radix-16 outputs of pass 1 (slot 17 p1 + r) spread over all banks.
+__device__ __forceinline__ int row_pair_index(int lane) { return 2 * (lane & 15) + ((lane >> 4) & 1) + (lane & 32); }
+// a, b: the two points (n, n + 1) of one 16-byte load; lanes of even rows loaded them for i, lanes of odd rows for i + 8.
+// On return a = the lane's own point of i, b = its own point of i + 8.
+__device__ __forceinline__ void row_pair_unpack(float2& a, float2& b) {
+    asm("s_nop 1\n\tv_permlane16_swap_b32 %0, %2\n\tv_permlane16_swap_b32 %1, %3" : "+v"(a.x), "+v"(a.y), "+v"(b.x), "+v"(b.y));
+}
+
 // twiddles of pass 2 (w[r] = exp(-2 pi i r k / 256), k = lane & 15) and of butterfly b of pass 3 come from the pass tables
 // of fft_frame<10, 4> or from the two-level table + product tree of fft_frame_chain<10, 4>
 __device__ __forceinline__ void pass2_twiddles(float2* w, int k, const float2* tw) {
@@ -541,8 +551,11 @@ __device__ __forceinline__ void pass1_write(const float2* v, float2* buf, int la
 // Input: v[i] = x[lane + 64 i].  Output: natural-order spectrum in the padded LDS frame `buf` (as fft_frame<10, 4>).
 // ODDROT: the odd lanes hold their 16 points rotated by 8, v[i] = x[lane + 64 ((i + 8) & 15)] (lane pairs that share 16-byte
 // loads, see k_mel / k_cqt): their radix-16 outputs of pass 1 then carry (-1)^k, undone here.
+// p1: the index n mod 64 of the points the lane holds on entry (v[i] = x[p1 + 64 i]); any permutation of the lanes
+// (row_pair_index below), pass 1 only uses it for the slot it writes.
 template <bool ODDROT = false, class TW>
-__device__ __forceinline__ void fft1024_wave(float2* v, float2* buf, int lane, const TW& tw) {
+__device__ __forceinline__ void fft1024_wave(float2* v, float2* buf, int lane, const TW& tw, int p1 = -1) {
+    if (p1 < 0) p1 = lane;
     if constexpr (ODDROT) {
         Dft<16>::run(v);
         const float sg = (lane & 1) ? -1.f : 1.f;
@@ -550,7 +563,7 @@ __device__ __forceinline__ void fft1024_wave(float2* v, float2* buf, int lane, c
 #pragma unroll
         for (int r = 0; r < 16; ++r) buf[pb + r] = (r & 1) ? make_float2(v[r].x * sg, v[r].y * sg) : v[r];   // position 16 lane + r
     } else {
-        pass1_write(v, buf, lane, tw);   // radix 16, no twiddles: position 16 lane + r
+        pass1_write(v, buf, p1, tw);   // radix 16, no twiddles: position 16 p1 + r
     }
     frame_sync<64>();
     regs_read<10, 4>(v, buf, lane);

@@ -43,6 +43,9 @@ struct PackedBand {
     int4* d_items = nullptr;     // per wave, longest first: {slot id, first column, steps, offset into d_pack (steps)}
     int* d_wave_ptr = nullptr;   // [n_waves + 1] ranges into d_items
     int* d_blk_ptr = nullptr;    // [n_blocks + 1] ranges of slot ids belonging to a block
+    unsigned short* d_desc = nullptr;   // [total_steps] K-step descriptors of the resident form: first column / 4 | slot id << 8 | item ends << 15
+    bool desc_ok = false;        // every step fits the 16-bit descriptor
+    int n_empty = 0;             // blocks without non-zeros (their zero tiles are written by the streamed form only)
     int max_wave_steps = 0;      // steps of the busiest wave: wave w owns steps [total w / n_waves, total (w + 1) / n_waves)
 };
 constexpr int kMelResidentFb = 18;  // K-steps of the filterbank / of the DCT rows a wave of k_mel keeps in registers

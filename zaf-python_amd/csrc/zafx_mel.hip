@@ -84,36 +84,30 @@ __device__ __forceinline__ void gemm_items(const float* __restrict__ pack, const
 // One banded GEMM stage with the wave's A fragments resident in registers (RA K-steps in execution order): no vector-memory
 // traffic of its own, so the samples of the next tile can be requested underneath, one load after every K-step (`hook`) -- a
 // burst of 16 loads per lane overruns the CU's vector-memory queue and blocks the wave at issue (profiles/r02_notes.md).
-// The wave's work items {slot, first column, steps, -} are read with scalar loads, one per item.
+// Step i of the wave: 16 bits of desc[i / 2] (SGPRs, tile-invariant; PackedBand::d_desc): first column / 4 | slot << 8 | item ends << 15.
 template <int RA, class SlotFn, class BFn, class Hook>
-__device__ __forceinline__ void gemm_resident(const float (&a)[RA], const int4* __restrict__ items, int it, int it_end, int lane, int slot0,
-                                              SlotFn slot_ptr, BFn b_at, Hook hook) {
-    asm volatile("" : "+s"(it), "+s"(it_end));   // (tile-invariant scalars: keep them out of the persistent loop's live set)
-    f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+__device__ __forceinline__ void gemm_resident(const float (&a)[RA], const int (&desc)[(RA + 1) / 2], int n, int lane, int slot0, SlotFn slot_ptr, BFn b_at, Hook hook) {
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
     const int bt = lane & 15, bk = lane >> 4;
-    int4 d = it < it_end ? items[it] : make_int4(0, 0, 0, 0);
-    int col = d.y, left = d.z;
-    auto flush = [&]() {   // the item ends: leave its partial tile in its slot, take the next item
-        float* dst = slot_ptr(slot0 + d.x);
+    // opaque copies: decoded ahead of the persistent loop, the steps' columns, flags and slot addresses would take some
+    // sixty scalar registers (spilled to VGPR lanes and read back step by step)
+    int dw[(RA + 1) / 2];
 #pragma unroll
-        for (int q = 0; q < 4; ++q) dst[(4 * bk + q) * 16 + bt] = acc0[q] + acc1[q];
-        acc0 = f32x4{0.f, 0.f, 0.f, 0.f};
-        acc1 = f32x4{0.f, 0.f, 0.f, 0.f};
-        ++it;
-        d = it < it_end ? items[it] : make_int4(0, 0, 0, 0);
-        col = d.y;
-        left = d.z;
-    };
-    while (it < it_end && left == 0) flush();   // (a block without non-zeros: a zero tile)
+    for (int j = 0; j < (RA + 1) / 2; ++j) {
+        dw[j] = desc[j];
+        asm volatile("" : "+s"(dw[j]));
+    }
+    asm volatile("" : "+s"(n));
 #pragma unroll
     for (int i = 0; i < RA; ++i) {
-        if (it < it_end) {
-            if (i & 1) acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i], b_at(col), acc1, 0, 0, 0);
-            else acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i], b_at(col), acc0, 0, 0, 0);
-            col += 4;
-            if (--left == 0) {
-                flush();
-                while (it < it_end && left == 0) flush();
+        if (i < n) {   // (uniform)
+            const int d = dw[i >> 1] >> (16 * (i & 1));
+            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i], b_at(4 * (d & 255)), acc, 0, 0, 0);
+            if (d & 0x8000) {   // the item ends: leave its partial tile in its slot
+                float* dst = slot_ptr(slot0 + ((d >> 8) & 127)) + (4 * bk) * 16 + bt;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) dst[q * 16] = acc[q];
+                acc = f32x4{0.f, 0.f, 0.f, 0.f};
             }
         }
         hook(i);
@@ -121,14 +115,16 @@ __device__ __forceinline__ void gemm_resident(const float (&a)[RA], const int4* 
 }
 
 // RES: filterbank (and DCT) fragments resident in registers + prefetch of the next tile under the filterbank phases.
-template <int LOG2N, int LOG2E, bool ALIGNED, bool RES>
+// MF: 1 = mel, 2 = mfcc compiled in (resident form), 0 = the kernel argument decides.
+template <int LOG2N, int LOG2E, bool ALIGNED, bool RES, int MF>
 __global__ __launch_bounds__(mel_threads(LOG2N, LOG2E)) void k_mel(
     const float* __restrict__ x, const float* __restrict__ win, const float2* __restrict__ twp,
     const float2* __restrict__ tws, const float* __restrict__ fb_pack, const int4* __restrict__ fb_items,
-    const int* __restrict__ fb_wave_ptr, const int* __restrict__ fb_blk_ptr, int fb_blocks, int fb_nitems, int fb_steps, int dct_steps,
+    const int* __restrict__ fb_wave_ptr, const int* __restrict__ fb_blk_ptr, const unsigned short* __restrict__ fb_desc, int fb_blocks, int fb_nitems, int fb_steps, int dct_steps,
     const float* __restrict__ dct_pack, const int4* __restrict__ dct_items, const int* __restrict__ dct_wave_ptr,
-    const int* __restrict__ dct_blk_ptr, int dct_blocks, float* __restrict__ out, long long n_samples, int hop, int T, int TP,
-    int tiles, int total_tiles, int n_filters, int n_coefs, int mfcc, int layout) {
+    const int* __restrict__ dct_blk_ptr, const unsigned short* __restrict__ dct_desc, int dct_blocks, float* __restrict__ out, long long n_samples, int hop, int T, int TP,
+    int tiles, int total_tiles, int n_filters, int n_coefs, int mfcc_arg, int layout) {
+    const bool mfcc = MF == 0 ? mfcc_arg != 0 : MF == 2;
     using C = FftCfg<LOG2N, LOG2E>;
     using G = MelCfg<LOG2N, LOG2E>;
     constexpr int N = C::N, P = C::P, E = C::E, W = 2 * N, NT = G::NT, FPB = G::FPB, NSLOT = G::NSLOT;
@@ -140,8 +136,20 @@ __global__ __launch_bounds__(mel_threads(LOG2N, LOG2E)) void k_mel(
     float* extra = reinterpret_cast<float*>(tws_l + N / 2 + 1);
     float* fall = reinterpret_cast<float*>(frames);
     const int tid = threadIdx.x;
+    // The raw samples of a round are requested one phase ahead.  Fat waves (NT <= 512, two rounds per tile): before the FFT of
+    // the previous round.  16 thin waves (one round per tile): when the tile's spectra are done, so that the 128 KB of the next
+    // tile fly under the filterbank phases -- all 16 waves otherwise request, wait and transform in lockstep, and the three
+    // resources (vector memory 5.8 k cycles per tile, LDS 6.5 k, VALU 7 k) are used one after the other.
+    constexpr bool PREFETCH = NT <= 512;
+    constexpr bool LATE = !PREFETCH && RES;
+    // 16-byte lane loads for the prefetched frame (W = 2048, resident form): the lanes l and l + 16 (l in an even 16-lane
+    // row) share their loads -- the first fetches the points (n, n + 1) + 64 i for i = 0 .. 7, the second for i = 8 .. 15 --
+    // and one v_permlane16_swap per register hands each lane its own points (row_pair_index / row_pair_unpack).  Eight loads
+    // per lane instead of sixteen: the request of the next tile blocks half as long at the CU's vector-memory queue.
+    constexpr bool PAIR16 = LATE && LOG2N == 10 && LOG2E == 4;   // (without resident fragments the filterbank's own loads would queue behind the prefetch)
     for (int i = tid; i < C::TW; i += NT) tw_l[i] = twp[i];
-    for (int i = tid; i < N; i += NT) win_l[i] = reinterpret_cast<const float2*>(win)[i];
+    // (pair form, below: the window in lane order, win_l[64 i + lane] = the window at the lane's points p + 64 i)
+    for (int i = tid; i < N; i += NT) win_l[i] = reinterpret_cast<const float2*>(win)[PAIR16 ? (i & ~63) + row_pair_index(i & 63) : i];
     for (int i = tid; i <= N / 2; i += NT) tws_l[i] = tws[i];
     __syncthreads();
 
@@ -159,18 +167,6 @@ __global__ __launch_bounds__(mel_threads(LOG2N, LOG2E)) void k_mel(
     const int lt0 = fb_nitems;                  // first log-mel slot
     const int dslot0 = fb_nitems + fb_blocks;   // first DCT partial slot
 
-    // The raw samples of a round are requested one phase ahead.  Fat waves (NT <= 512, two rounds per tile): before the FFT of
-    // the previous round.  16 thin waves (one round per tile): when the tile's spectra are done, so that the 128 KB of the next
-    // tile fly under the filterbank phases -- all 16 waves otherwise request, wait and transform in lockstep, and the three
-    // resources (vector memory 5.8 k cycles per tile, LDS 6.5 k, VALU 7 k) are used one after the other.
-    constexpr bool PREFETCH = NT <= 512;
-    constexpr bool LATE = !PREFETCH && RES;
-    // 16-byte lane loads for the prefetched frame (W = 2048, resident form): the lane pair (2q, 2q + 1) shares its loads -- the
-    // even lane fetches the points (2q, 2q + 1) + 64 i for i = 0 .. 7, the odd lane for i = 8 .. 15 -- keeps its own point and
-    // sends the other's across (DPP swap inside the pair).  Eight loads per lane instead of sixteen: the request of the next
-    // tile blocks half as long at the CU's vector-memory queue.  The odd lane then holds its points rotated by 8
-    // (fft1024_wave<ODDROT>); the clip-edge path loads in the same rotated order.
-    constexpr bool PAIR16 = LATE && LOG2N == 10 && LOG2E == 4;   // (without resident fragments the filterbank's own loads would queue behind the prefetch)
     // raw samples of one frame of this wave's slot: xr[i] = (x[2n], x[2n+1]), n = p + i P (zero padding of zaf.py:112-125).
     // fetch_begin() sets up the frame (an interior frame is then requested load by load with fetch_one(), or all at once
     // with fetch()); a frame that touches the clip's edges is loaded in full by fetch_begin() itself.
@@ -178,11 +174,11 @@ __global__ __launch_bounds__(mel_threads(LOG2N, LOG2E)) void k_mel(
     __amdgpu_buffer_rsrc_t frx = make_rsrc(x, 0);
     int fvoff = 0;
     const bool xcd = ZAFX_XCD_ORDER && gridDim.x % 8 == 0;   // (xcd_order: tiles of a clip to the workgroups of one XCD)
-    auto fetch_begin = [&](int tlv, int f0, int p) -> bool {   // p: lane index within the frame (an opaque copy inside the tile loop)
+    auto fetch_begin = [&](int tlv, int f0, int p) -> bool {   // p: the lane's points are p + i P (an opaque copy inside the tile loop)
         if (tlv >= total_tiles) return false;
         const int tl = xcd ? xcd_order(tlv, total_tiles) : tlv;
         const int clip = tl / tiles, tile = tl % tiles;
-        const int t = tile * FPB + f0 + slot;
+        const int t = tile * FPB + f0 + (P == 64 ? wave : slot);   // (a frame per wave: uniform, the descriptor below stays in SGPRs)
         const float* xc = x + (long long)clip * n_samples;
         const long long s0 = (long long)t * hop - N;
         if (ALIGNED && t < T && s0 >= 0 && s0 + W <= n_samples) {   // interior frame (uniform per frame)
@@ -192,10 +188,9 @@ __global__ __launch_bounds__(mel_threads(LOG2N, LOG2E)) void k_mel(
             fvoff = PAIR16 ? ((int)s0 + 2 * (p & ~1)) * 4 + (p & 1) * (E / 2 * P * 8) : ((int)s0 + 2 * p) * 4;
             return true;
         }
-        const int rot = PAIR16 ? (E / 2) * (p & 1) : 0;   // (odd lanes of the pair form hold their points rotated by 8)
 #pragma unroll
         for (int i = 0; i < E; ++i) {
-            const long long s = s0 + 2 * (p + ((i + rot) & (E - 1)) * P);
+            const long long s = s0 + 2 * (p + i * P);
             xr[i].x = (t < T && s >= 0 && s < n_samples) ? xc[s] : 0.f;
             xr[i].y = (t < T && s + 1 >= 0 && s + 1 < n_samples) ? xc[s + 1] : 0.f;
         }
@@ -212,20 +207,18 @@ __global__ __launch_bounds__(mel_threads(LOG2N, LOG2E)) void k_mel(
             xr[i] = buf_load_f32x2(frx, fvoff, i * P * 8);
         }
     };
-    auto unpack_pairs = [&](int p) {
-        const int odd = p & 1;
+    auto unpack_pairs = [&]() {   // raw (a_i, b_i) = (xr[2 i], xr[2 i + 1]) -> xr[i], xr[i + E/2]
         float2 lo[E / 2], hi[E / 2];
 #pragma unroll
         for (int i = 0; i < E / 2; ++i) {
             lo[i] = xr[2 * i];
             hi[i] = xr[2 * i + 1];
+            row_pair_unpack(lo[i], hi[i]);
         }
 #pragma unroll
         for (int i = 0; i < E / 2; ++i) {
-            const float2 keep = odd ? hi[i] : lo[i], send = odd ? lo[i] : hi[i];
-            xr[i] = keep;
-            xr[i + E / 2].x = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, send.x), 0xB1, 0xf, 0xf, true));
-            xr[i + E / 2].y = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, send.y), 0xB1, 0xf, 0xf, true));
+            xr[i] = lo[i];
+            xr[i + E / 2] = hi[i];
         }
     };
     auto fetch = [&](int tl, int f0, int p) {
@@ -236,7 +229,7 @@ __global__ __launch_bounds__(mel_threads(LOG2N, LOG2E)) void k_mel(
     };
     bool raw = false;   // PAIR16: xr holds raw 16-byte loads (an interior frame) that unpack_pairs() must sort out
     if constexpr (PREFETCH || LATE) {
-        raw = fetch_begin(blockIdx.x, 0, p);
+        raw = fetch_begin(blockIdx.x, 0, PAIR16 ? row_pair_index(p) : p);
         if (raw) {
 #pragma unroll
             for (int i = 0; i < E; ++i) fetch_one(i);
@@ -244,14 +237,22 @@ __global__ __launch_bounds__(mel_threads(LOG2N, LOG2E)) void k_mel(
     }
     // resident A fragments of this wave: lane l holds A[l & 15][4 step + (l >> 4)] of its K-steps
     float afb[RES ? kMelResidentFb : 1], adct[RES ? kMelResidentDct : 1];
+    int sfb[RES ? (kMelResidentFb + 1) / 2 : 1], sdct[RES ? (kMelResidentDct + 1) / 2 : 1];   // the steps' descriptors, two per scalar register
+    int nfb = 0, ndct = 0;
     constexpr int NW = NT / 64;
     if constexpr (RES) {   // the wave's share of the K-steps is a contiguous range of the packed fragments (pack_band)
-        const int g0 = (int)((long long)fb_steps * wave / NW), n = (int)((long long)fb_steps * (wave + 1) / NW) - g0;
+        const int g0 = (int)((long long)fb_steps * wave / NW);
+        nfb = __builtin_amdgcn_readfirstlane((int)((long long)fb_steps * (wave + 1) / NW) - g0);
 #pragma unroll
-        for (int i = 0; i < kMelResidentFb; ++i) afb[i] = i < n ? fb_pack[(size_t)(g0 + i) * 64 + (tid & 63)] : 0.f;
-        const int h0 = (int)((long long)dct_steps * wave / NW), m = (int)((long long)dct_steps * (wave + 1) / NW) - h0;
+        for (int i = 0; i < kMelResidentFb; ++i) afb[i] = i < nfb ? fb_pack[(size_t)(g0 + i) * 64 + (tid & 63)] : 0.f;
 #pragma unroll
-        for (int i = 0; i < kMelResidentDct; ++i) adct[i] = (mfcc && i < m) ? dct_pack[(size_t)(h0 + i) * 64 + (tid & 63)] : 0.f;
+        for (int i = 0; i < (kMelResidentFb + 1) / 2; ++i) sfb[i] = __builtin_amdgcn_readfirstlane(2 * i < nfb ? (fb_desc[g0 + 2 * i] | fb_desc[g0 + 2 * i + 1] << 16) : 0);   // (two spare entries behind the table)
+        const int h0 = (int)((long long)dct_steps * wave / NW);
+        ndct = __builtin_amdgcn_readfirstlane(mfcc ? (int)((long long)dct_steps * (wave + 1) / NW) - h0 : 0);
+#pragma unroll
+        for (int i = 0; i < kMelResidentDct; ++i) adct[i] = i < ndct ? dct_pack[(size_t)(h0 + i) * 64 + (tid & 63)] : 0.f;
+#pragma unroll
+        for (int i = 0; i < (kMelResidentDct + 1) / 2; ++i) sdct[i] = __builtin_amdgcn_readfirstlane(2 * i < ndct ? (dct_desc[h0 + 2 * i] | dct_desc[h0 + 2 * i + 1] << 16) : 0);
     }
     PROF_INIT(g_prof_mel);
     for (int tlv = blockIdx.x; tlv < total_tiles; tlv += gridDim.x) {
@@ -274,38 +275,36 @@ __global__ __launch_bounds__(mel_threads(LOG2N, LOG2E)) void k_mel(
             if constexpr (!PREFETCH && !LATE) fetch(tlv, f0, po);   // 16 thin waves, streamed filterbank: request, wait, transform
             float2 v[E];
             if constexpr (PAIR16) {
-                if (raw) unpack_pairs(po);
-                const int w0 = po + (po & 1) * (E / 2 * P), w1 = po + (1 - (po & 1)) * (E / 2 * P);   // window of slot i: point (i ^ 8 odd) P + lane
+                if (raw) unpack_pairs();
+            }
 #pragma unroll
-                for (int i = 0; i < E; ++i) {
-                    const float2 wv = win_l[(i < E / 2 ? w0 : w1) + (i & (E / 2 - 1)) * P];
-                    v[i] = make_float2(xr[i].x * wv.x, xr[i].y * wv.y);
-                }
-            } else {
-#pragma unroll
-                for (int i = 0; i < E; ++i) {
-                    const float2 wv = win_l[po + i * P];
-                    v[i] = make_float2(xr[i].x * wv.x, xr[i].y * wv.y);
-                }
+            for (int i = 0; i < E; ++i) {
+                const float2 wv = win_l[po + i * P];   // (pair form: the table is in lane order)
+                v[i] = make_float2(xr[i].x * wv.x, xr[i].y * wv.y);
             }
             if constexpr (PREFETCH) {
                 if (f0 + NSLOT < FPB) fetch(tlv, f0 + NSLOT, po);
                 else fetch(tlv + gridDim.x, 0, po);
             }
-            if constexpr (PAIR16) fft1024_wave<true>(v, buf, po, (const float2*)tw_l);
+            if constexpr (PAIR16) fft1024_wave<false>(v, buf, po, (const float2*)tw_l, row_pair_index(po));
             else fft_frame<LOG2N, LOG2E>(v, buf, po, tw_l);
-            // real split of the (k, N-k) pairs this thread owns, kept in registers
+            // real split of the (k, N-k) pairs this thread owns (k = po + i P), kept in registers.  Only lane 0 holds a pair
+            // without a partner (i = 0: bins N/2 and N); P is a whole number of padding periods, so the slots of
+            // k + i P and N - k - i P are constant offsets from those of po and N - po.
             float mk[E / 2], mn[E / 2];
+            constexpr bool LINEAR = P % (1 << C::PS) == 0;
+            constexpr int STEP = P + (P >> C::PS);
+            const float2* zk = buf + phys_t<C::PS>(po);
+            const float2* zn = buf + phys_t<C::PS>(N - po);
 #pragma unroll
             for (int i = 0; i < E / 2; ++i) {
                 const int k = po + i * P;
+                const float2 za = LINEAR ? zk[i * STEP] : buf[phys_t<C::PS>(k)], zb = LINEAR ? zn[-i * STEP] : buf[phys_t<C::PS>(N - k)];
                 float2 xk, xn;
-                if (k == 0) {
-                    const float2 z0 = buf[0], zc = buf[phys_t<C::PS>(N / 2)];
-                    xk = zc;                                  // |X[N/2]| = |Z[N/2]|
-                    xn = make_float2(z0.x - z0.y, 0.f);       // X[N] (Nyquist, kept: zaf.py:370)
-                } else {
-                    split_pair(buf[phys_t<C::PS>(k)], buf[phys_t<C::PS>(N - k)], tws_l[k], xk, xn);   // (xn conjugated: only |.| is used)
+                split_pair(za, zb, tws_l[k], xk, xn);   // (xn conjugated: only |.| is used)
+                if (i == 0 && k == 0) {
+                    xk = buf[phys_t<C::PS>(N / 2)];           // |X[N/2]| = |Z[N/2]|
+                    xn = make_float2(za.x - za.y, 0.f);       // X[N] (Nyquist, kept: zaf.py:370)
                 }
                 const float pk = xk.x * xk.x + xk.y * xk.y, pn = xn.x * xn.x + xn.y * xn.y;
                 mk[i] = mfcc ? pk : __builtin_amdgcn_sqrtf(pk);   // v_sqrt_f32, 1 ulp
@@ -313,16 +312,14 @@ __global__ __launch_bounds__(mel_threads(LOG2N, LOG2E)) void k_mel(
             }
             frame_sync<P>();   // every Z read of this frame is done before S overwrites it
             float* sf = reinterpret_cast<float*>(buf);   // S[c], c = bin - 1, c = 0..N-1
+            float* sk = sf + (po == 0 ? N / 2 : po) - 1;   // bin k of i = 0 (lane 0: bin N/2)
+            float* sn = sf + N - po - 1;                   // bin N - k of i = 0
+            sk[0] = mk[0];
+            sn[0] = mn[0];
 #pragma unroll
-            for (int i = 0; i < E / 2; ++i) {
-                const int k = po + i * P;
-                if (k == 0) {
-                    sf[N / 2 - 1] = mk[i];
-                    sf[N - 1] = mn[i];
-                } else {
-                    sf[k - 1] = mk[i];
-                    sf[N - k - 1] = mn[i];
-                }
+            for (int i = 1; i < E / 2; ++i) {
+                sf[po + i * P - 1] = mk[i];
+                sn[-i * P] = mn[i];
             }
         }
         PROF_MARK(1);
@@ -334,15 +331,14 @@ __global__ __launch_bounds__(mel_threads(LOG2N, LOG2E)) void k_mel(
         asm volatile("" : "+v"(to));
         const int lane = to & 63, bt = lane & 15, bk = lane >> 4;
         bool fast = false;   // the next tile's frame: requested one load per K-step of the filterbank GEMM
-        if constexpr (LATE) fast = fetch_begin(tlv + gridDim.x, 0, to % P);
+        if constexpr (LATE) fast = fetch_begin(tlv + gridDim.x, 0, PAIR16 ? row_pair_index(to % P) : to % P);
         raw = fast;
 
         // ---- mel = FB . S on the matrix cores
         {
             const float* sb = fall + (size_t)bt * (2 * C::PITCH) + bk;
             if constexpr (RES)
-                gemm_resident(afb, fb_items, fb_wave_ptr[wave], fb_wave_ptr[wave + 1], lane, 0, slot_ptr, [&](int col) { return sb[col]; },
-                              [&](int i) { if (LATE && i < E && fast) fetch_one(i); });
+                gemm_resident(afb, sfb, nfb, lane, 0, slot_ptr, [&](int col) { return sb[col]; }, [&](int i) { if (LATE && i < E && fast) fetch_one(i); });
             else gemm_items(fb_pack, fb_items, fb_wave_ptr, wave, lane, 0, slot_ptr, [&](int col) { return sb[col]; });
         }
         PROF_MARK(3);
@@ -350,7 +346,7 @@ __global__ __launch_bounds__(mel_threads(LOG2N, LOG2E)) void k_mel(
         PROF_MARK(4);
         // ---- fixed-order reduction of the parts of every 16-filter block
         for (int idx = to; idx < fb_blocks * 256; idx += NT) {
-            const int blk = idx >> 8, e = idx & 255;
+            const int blk = __builtin_amdgcn_readfirstlane(idx >> 8), e = idx & 255;   // (a block = four whole waves: its range of parts loads into SGPRs)
             float val = 0.f;
             for (int it = fb_blk_ptr[blk]; it < fb_blk_ptr[blk + 1]; ++it) val += slot_ptr(it)[e];
             const int m = 16 * blk + (e >> 4), tq = e & 15;
@@ -365,11 +361,11 @@ __global__ __launch_bounds__(mel_threads(LOG2N, LOG2E)) void k_mel(
             lds_barrier();
             // ---- rows 1..ncoef of the orthonormal DCT-II over the mel axis: second MFMA GEMM
             auto logmel = [&](int row) { return slot_ptr(lt0 + ((row + bk) >> 4))[((row + bk) & 15) * 16 + bt]; };
-            if constexpr (RES) gemm_resident(adct, dct_items, dct_wave_ptr[wave], dct_wave_ptr[wave + 1], lane, dslot0, slot_ptr, logmel, [](int) {});
+            if constexpr (RES) gemm_resident(adct, sdct, ndct, lane, dslot0, slot_ptr, logmel, [](int) {});
             else gemm_items(dct_pack, dct_items, dct_wave_ptr, wave, lane, dslot0, slot_ptr, logmel);
             lds_barrier();
             for (int idx = to; idx < dct_blocks * 256; idx += NT) {
-                const int blk = idx >> 8, e = idx & 255;
+                const int blk = __builtin_amdgcn_readfirstlane(idx >> 8), e = idx & 255;
                 float val = 0.f;
                 for (int it = dct_blk_ptr[blk]; it < dct_blk_ptr[blk + 1]; ++it) val += slot_ptr(dslot0 + it)[e];
                 const int q = 16 * blk + (e >> 4), tq = e & 15;
@@ -390,8 +386,13 @@ static hipError_t run_mel(const zafx_plan& pl, const float* x, float* out, int64
     using G = MelCfg<LOG2N, LOG2E>;
     const int mfcc = pl.kind == ZAFX_MFCC;
     // filterbank and DCT fragments resident in registers when the busiest wave's K-steps fit (128 filters at W = 2048: 17 + 4)
-    const bool res = G::NT == 1024 && pl.fb.max_wave_steps <= kMelResidentFb && (!mfcc || pl.dct.max_wave_steps <= kMelResidentDct);
-    auto kern = res ? k_mel<LOG2N, LOG2E, ALIGNED, true> : k_mel<LOG2N, LOG2E, ALIGNED, false>;
+    // (a block without non-zeros has no K-step to carry its zero tile: streamed form)
+    const bool res = G::NT == 1024 && pl.fb.max_wave_steps <= kMelResidentFb && pl.fb.n_empty == 0 && pl.fb.desc_ok &&
+                     (!mfcc || (pl.dct.max_wave_steps <= kMelResidentDct && pl.dct.n_empty == 0 && pl.dct.desc_ok));
+    auto kern = k_mel<LOG2N, LOG2E, ALIGNED, false, 0>;
+    if constexpr (G::NT == 1024) {
+        if (res) kern = mfcc ? k_mel<LOG2N, LOG2E, ALIGNED, true, 2> : k_mel<LOG2N, LOG2E, ALIGNED, true, 1>;
+    }
     const int slots = pl.fb.n_items + (mfcc ? pl.fb.n_blocks + pl.dct.n_items : 0);
     if (slots > G::CAPACITY) {
         set_error("mel/mfcc: too many filterbank work items for the LDS slots at this window_length");
@@ -408,8 +409,8 @@ static hipError_t run_mel(const zafx_plan& pl, const float* x, float* out, int64
     const int per_cu = (int)std::min<size_t>(2, (size_t)kMaxLdsBytes / G::SMEM);
     const long long grid = std::min<long long>(total, (long long)pl.n_cus * std::max(per_cu, 1));
     hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(G::NT), G::SMEM, pl.stream, x, pl.d_window, LOG2E == 5 ? pl.d_tw_r32 : pl.d_tw_pass, pl.d_tw_aux, pl.fb.d_pack,
-                       pl.fb.d_items, pl.fb.d_wave_ptr, pl.fb.d_blk_ptr, pl.fb.n_blocks, pl.fb.n_items, pl.fb.total_steps, mfcc ? pl.dct.total_steps : 0, pl.dct.d_pack, pl.dct.d_items,
-                       pl.dct.d_wave_ptr, pl.dct.d_blk_ptr, pl.dct.n_blocks, out, (long long)n_samples, pl.H, T, (int)row_pitch(pl, T), tiles, (int)total,
+                       pl.fb.d_items, pl.fb.d_wave_ptr, pl.fb.d_blk_ptr, pl.fb.d_desc, pl.fb.n_blocks, pl.fb.n_items, pl.fb.total_steps, mfcc ? pl.dct.total_steps : 0, pl.dct.d_pack, pl.dct.d_items,
+                       pl.dct.d_wave_ptr, pl.dct.d_blk_ptr, pl.dct.d_desc, pl.dct.n_blocks, out, (long long)n_samples, pl.H, T, (int)row_pitch(pl, T), tiles, (int)total,
                        pl.prm.n_filters, pl.prm.n_coefs, mfcc, pl.layout);
     return hipGetLastError();
 }

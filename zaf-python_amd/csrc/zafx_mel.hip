@@ -98,11 +98,14 @@ __device__ __forceinline__ void gemm_resident(const float (&a)[RA], const int (&
         asm volatile("" : "+s"(dw[j]));
     }
     asm volatile("" : "+s"(n));
+    float b[RA];   // the B fragments of all steps are requested up front: the MFMA chain then waits for LDS once, not once per step
+#pragma unroll
+    for (int i = 0; i < RA; ++i) b[i] = b_at(4 * ((dw[i >> 1] >> (16 * (i & 1))) & 255));   // (no step: descriptor 0, column 0)
 #pragma unroll
     for (int i = 0; i < RA; ++i) {
         if (i < n) {   // (uniform)
             const int d = dw[i >> 1] >> (16 * (i & 1));
-            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i], b_at(4 * (d & 255)), acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i], b[i], acc, 0, 0, 0);
             if (d & 0x8000) {   // the item ends: leave its partial tile in its slot
                 float* dst = slot_ptr(slot0 + ((d >> 8) & 127)) + (4 * bk) * 16 + bt;
 #pragma unroll

@@ -188,15 +188,20 @@ __global__ __launch_bounds__(NSLOT * 64) void k_mdct_ft32(
         const int t = tile * FPB + frame_of(f);
         const float* xc = x + (long long)clip * n_samples;
         const long long s0 = (long long)t * M - M;   // left pad = M (zaf.py:1036-1041)
-        if (ALIGNED && t < T && s0 >= 0 && s0 + W <= n_samples) {
-            const float* xs = xc + s0;
+        if constexpr (ALIGNED) {
+            // Buffer loads through a descriptor of the clip: a 16-byte piece that lies before the clip's first or after its last
+            // sample is out of the descriptor's range and reads as zero -- the zero padding of zaf.py:1036-1041, with no edge
+            // path (n_samples and every piece's first sample are multiples of 4: a piece is inside or outside as a whole;
+            // offsets are 32-bit and wrap, a negative one is a huge unsigned one).  Four address registers per frame.
+            const __amdgpu_buffer_rsrc_t rs = make_rsrc(xc, (unsigned)(n_samples * 4));
+            const int b = (int)s0 * 4 + 16 * p;                  // + 16 u forward pieces
+            const int rb = (int)s0 * 4 - 16 * p - 16 * (UPL - 1) * P;   // - 16 u reversed pieces, lowest address of the UPL
 #pragma unroll
             for (int r = 0; r < UPL; ++r) {
-                const int u = p + r * P;
-                q[r][0] = *reinterpret_cast<const float4*>(xs + 3 * NF + 4 * u);
-                q[r][1] = *reinterpret_cast<const float4*>(xs + 3 * NF - 4 - 4 * u);
-                q[r][2] = *reinterpret_cast<const float4*>(xs + NF + 4 * u);
-                q[r][3] = *reinterpret_cast<const float4*>(xs + NF - 4 - 4 * u);
+                q[r][0] = buf_load_f32x4(rs, b + 12 * NF + 16 * r * P);
+                q[r][1] = buf_load_f32x4(rs, rb + 12 * NF - 16 + 16 * (UPL - 1 - r) * P);
+                q[r][2] = buf_load_f32x4(rs, b + 4 * NF + 16 * r * P);
+                q[r][3] = buf_load_f32x4(rs, rb + 4 * NF - 16 + 16 * (UPL - 1 - r) * P);
             }
         } else {   // clip edges (zero padding), frames past T, unaligned clips
             auto at = [&](long long s) { return (t < T && s >= 0 && s < n_samples) ? xc[s] : 0.f; };
@@ -212,20 +217,39 @@ __global__ __launch_bounds__(NSLOT * 64) void k_mdct_ft32(
         }
     };
     // fold + window + pre-twiddle: c[m] = (xa wa + xb wb, xc wc + xd wd) g_m -> LDS, natural order
+#ifndef ZAFX_MDCT_TABLES_IN_REGS
+#define ZAFX_MDCT_TABLES_IN_REGS 1
+#endif
+    // The lane's window quadruples are the same for every frame.  REGS: held in registers (32 at W = 2048; the buffer-load form
+    // of fetch() left the room -- with the pre-twiddles as well, 48, the kernel spills): 8 of the frame's 16-byte LDS reads
+    // fewer on a kernel whose transforms are bound by LDS.
+    constexpr bool REGS = ZAFX_MDCT_TABLES_IN_REGS && ALIGNED && UPL <= 2;
+    float4 wq[REGS ? UPL : 1][4];
+    if constexpr (REGS) {
+#pragma unroll
+        for (int r = 0; r < UPL; ++r) {
+            const int u = (p + r * P) % NU;   // (lanes beyond the frame's groups never fold)
+            const int m[4] = {2 * u, 2 * u + 1, NF - 1 - 2 * u, NF - 2 - 2 * u};
+#pragma unroll
+            for (int j = 0; j < 4; ++j) wq[r][j] = wf_l[m[j]];
+        }
+    }
     auto fold = [&](float2* buf) {
         if (!lane_loads) return;
-        int opaque = 0;   // keeps the per-lane table reads inside the loop: hoisted, they cost 48 VGPRs and spill
+        int opaque = 0;   // keeps the per-lane table addresses inside the loop: hoisted, they spill
         asm volatile("" : "+v"(opaque));
 #pragma unroll
         for (int r = 0; r < UPL; ++r) {
             const int u = p + r * P + opaque;
             const float4 A3 = q[r][0], R2 = q[r][1], A1 = q[r][2], R0 = q[r][3];
             const int m0 = 2 * u, m1 = 2 * u + 1, m2 = NF - 1 - 2 * u, m3 = NF - 2 - 2 * u;
-            const float4 w0 = wf_l[m0], w1 = wf_l[m1], w2 = wf_l[m2], w3 = wf_l[m3];
-            buf[phys(m0)] = cmul(make_float2(R2.w * w0.x + A3.x * w0.y, R0.w * w0.z + A1.x * w0.w), g_l[m0]);
-            buf[phys(m1)] = cmul(make_float2(R2.y * w1.x + A3.z * w1.y, R0.y * w1.z + A1.z * w1.w), g_l[m1]);
-            buf[phys(m2)] = cmul(make_float2(R0.z * w2.x + A1.y * w2.y, R2.z * w2.z + A3.y * w2.w), g_l[m2]);
-            buf[phys(m3)] = cmul(make_float2(R0.x * w3.x + A1.w * w3.y, R2.x * w3.z + A3.w * w3.w), g_l[m3]);
+            const float4 w0 = REGS ? wq[REGS ? r : 0][0] : wf_l[m0], w1 = REGS ? wq[REGS ? r : 0][1] : wf_l[m1];
+            const float4 w2 = REGS ? wq[REGS ? r : 0][2] : wf_l[m2], w3 = REGS ? wq[REGS ? r : 0][3] : wf_l[m3];
+            const float2 g0 = g_l[m0], g1 = g_l[m1], g2 = g_l[m2], g3 = g_l[m3];
+            buf[phys(m0)] = cmul(make_float2(R2.w * w0.x + A3.x * w0.y, R0.w * w0.z + A1.x * w0.w), g0);
+            buf[phys(m1)] = cmul(make_float2(R2.y * w1.x + A3.z * w1.y, R0.y * w1.z + A1.z * w1.w), g1);
+            buf[phys(m2)] = cmul(make_float2(R0.z * w2.x + A1.y * w2.y, R2.z * w2.z + A3.y * w2.w), g2);
+            buf[phys(m3)] = cmul(make_float2(R0.x * w3.x + A1.w * w3.y, R2.x * w3.z + A3.w * w3.w), g3);
         }
     };
 
@@ -674,7 +698,7 @@ template <int LOG2NF, bool TFOUT>
 static hipError_t run_mdct_p(const zafx_plan& pl, const float* x, float* out, int64_t n_clips, int64_t n_samples, int T) {
     constexpr int LOG2E = default_log2e(LOG2NF);
     using G = MdctPCfg<LOG2NF, LOG2E>;
-    const bool aligned = n_samples % 4 == 0 && reinterpret_cast<uintptr_t>(x) % 16 == 0;
+    const bool aligned = n_samples % 4 == 0 && reinterpret_cast<uintptr_t>(x) % 16 == 0 && n_samples < (1LL << 28);   // (32-bit byte offsets inside a clip)
     auto kern = aligned ? k_mdct_ft32<LOG2NF, LOG2E, true, G::NSLOT, TFOUT> : k_mdct_ft32<LOG2NF, LOG2E, false, G::NSLOT, TFOUT>;
     if (hipError_t e = ensure_dynamic_lds(reinterpret_cast<const void*>(kern), pl.device, G::SMEM); e != hipSuccess) return e;
     const int tiles = (T + kMdctTile - 1) / kMdctTile;

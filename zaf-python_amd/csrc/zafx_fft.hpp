@@ -551,22 +551,35 @@ __device__ __forceinline__ void pass1_write(const float2* v, float2* buf, int la
 // Input: v[i] = x[lane + 64 i].  Output: natural-order spectrum in the padded LDS frame `buf` (as fft_frame<10, 4>).
 // ODDROT: the odd lanes hold their 16 points rotated by 8, v[i] = x[lane + 64 ((i + 8) & 15)] (lane pairs that share 16-byte
 // loads, see k_mel / k_cqt): their radix-16 outputs of pass 1 then carry (-1)^k, undone here.
-// p1: the index n mod 64 of the points the lane holds on entry (v[i] = x[p1 + 64 i]); any permutation of the lanes
-// (row_pair_index below), pass 1 only uses it for the slot it writes.
-template <bool ODDROT = false, class TW>
-__device__ __forceinline__ void fft1024_wave(float2* v, float2* buf, int lane, const TW& tw, int p1 = -1) {
-    if (p1 < 0) p1 = lane;
+// PAIR (row-pair form): p1 = the index n mod 64 of the points the lane holds on entry, v[i] = x[p1 + 64 i], p1 = row_pair_index(lane)
+// (below).  Sixteen consecutive lanes then hold sixteen p1 of one parity, and in the usual layout (slot 17 p1 + r) their 8-byte
+// writes of pass 1 would meet two by two in the banks (SQ_LDS_BANK_CONFLICT 0.07 -> 0.17 of the active cycles in k_mel); the first
+// exchange of this form therefore pads one slot every 32 points instead of every 16: slot 16 p1 + (p1 >> 1) + r, read back by
+// lane (lh, ll) at 16 lh + (lh >> 1) + ll + 66 i (position lane + 64 i = 16 (lh + 4 i) + ll) -- conflict free both ways.
+template <bool ODDROT = false, bool PAIR = false, class TW>
+__device__ __forceinline__ void fft1024_wave(float2* v, float2* buf, int lane, const TW& tw, int p1 = 0) {
     if constexpr (ODDROT) {
         Dft<16>::run(v);
         const float sg = (lane & 1) ? -1.f : 1.f;
         const int pb = phys(lane << 4);
 #pragma unroll
         for (int r = 0; r < 16; ++r) buf[pb + r] = (r & 1) ? make_float2(v[r].x * sg, v[r].y * sg) : v[r];   // position 16 lane + r
+        frame_sync<64>();
+        regs_read<10, 4>(v, buf, lane);
+    } else if constexpr (PAIR) {
+        Dft<16>::run(v);
+        const int pb = 16 * p1 + (p1 >> 1);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) buf[pb + r] = v[r];
+        frame_sync<64>();
+        const int rb = 16 * (lane >> 4) + (lane >> 5) + (lane & 15);
+#pragma unroll
+        for (int i = 0; i < 16; ++i) v[i] = buf[rb + 66 * i];
     } else {
-        pass1_write(v, buf, p1, tw);   // radix 16, no twiddles: position 16 p1 + r
+        pass1_write(v, buf, lane, tw);   // radix 16, no twiddles: position 16 lane + r
+        frame_sync<64>();
+        regs_read<10, 4>(v, buf, lane);
     }
-    frame_sync<64>();
-    regs_read<10, 4>(v, buf, lane);
     frame_sync<64>();                // every lane has its points of pass 1 before pass 3 overwrites the frame
     float2 a[16];
     {

@@ -289,7 +289,7 @@ __global__ __launch_bounds__(mel_threads(LOG2N, LOG2E)) void k_mel(
                 if (f0 + NSLOT < FPB) fetch(tlv, f0 + NSLOT, po);
                 else fetch(tlv + gridDim.x, 0, po);
             }
-            if constexpr (PAIR16) fft1024_wave<false>(v, buf, po, (const float2*)tw_l, row_pair_index(po));
+            if constexpr (PAIR16) fft1024_wave<false, true>(v, buf, po, (const float2*)tw_l, row_pair_index(po));
             else fft_frame<LOG2N, LOG2E>(v, buf, po, tw_l);
             // real split of the (k, N-k) pairs this thread owns (k = po + i P), kept in registers.  Only lane 0 holds a pair
             // without a partner (i = 0: bins N/2 and N); P is a whole number of padding periods, so the slots of

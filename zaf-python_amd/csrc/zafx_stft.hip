@@ -662,8 +662,9 @@ ZAFX_PROF_ARRAY(g_prof)
 // Measured on MI355X (profiles/r01_notes.md): the gather runs at HBM speed only with SHALLOW
 // per-wave queues (16 waves x <= 8 loads; 8 waves x 64 loads of register prefetch ran the same bytes
 // 2x slower), so the tile's sweeps are streamed DEPTH at a time straight into the Hermitian fold
-// (prefetching 1-3 sweeps of the next tile across the FFT phase did not pay: the FFT needs 116 of
-// the 128 VGPRs).  Barriers order LDS only (lds_barrier): the output stores of a tile are not
+// (round 1: prefetching 1-3 sweeps of the next tile across the FFT phase did not pay, the FFT needed
+// 116 of the 128 VGPRs; round 2, with the second exchange in registers: ONE sweep rides across the
+// transforms and the overlap-add, 1.945 -> 1.92 ms; two sweeps spill, 1.99 ms).  Barriers order LDS only (lds_barrier): the output stores of a tile are not
 // waited for.
 template <int LOG2N, int LOG2E, int DEPTH, bool ONE, int FV, bool TF = false>
 __global__ __launch_bounds__(1024) void k_istft_ft16(
@@ -785,6 +786,12 @@ __global__ __launch_bounds__(1024) void k_istft_ft16(
             fold_one(k, r[0], r[1], r[2], r[3], fbuf);
         }
     };
+#ifndef ZAFX_ISTFT_PF
+#define ZAFX_ISTFT_PF 1
+#endif
+    constexpr int PF = (!TF && FV == 2 && KI >= ZAFX_ISTFT_PF) ? ZAFX_ISTFT_PF : 0;   // sweeps of the next tile requested ahead
+    RV pre[PF > 0 ? PF : 1][4];
+    bool pre_ok = false;
     Tile cur;
     cur.unit = blockIdx.x;
     if (cur.unit >= total_units) return;
@@ -835,14 +842,47 @@ __global__ __launch_bounds__(1024) void k_istft_ft16(
             PROF_MARK(1);
             PROF_MARK(2);
         } else {
-        // ---- phase A: stream the tile's sweeps, DEPTH at a time, through the Hermitian fold into LDS
+        // ---- phase A: stream the tile's sweeps, DEPTH at a time, through the Hermitian fold into LDS.  The first PF sweeps
+        //      were requested when the PREVIOUS tile had been folded and rode in registers across its transforms and its
+        //      overlap-add (round 2: the kernel is at 96 VGPRs, the transforms no longer need 116): the gather, half of the tile
+        //      time and the only phase with loads in flight, starts half done.
         if (my_frame_needed(cur)) {
             const Src sp = source(cur);
+            if constexpr (PF > 0) {
+                if (pre_ok) {
+                    RV r[4];
+                    if constexpr (KI > PF) load4(sp, PF, r);   // the first streamed sweep flies under the folds of the prefetched ones
+#pragma unroll
+                    for (int s = 0; s < PF; ++s) fold4(s, pre[s]);
+                    if constexpr (KI > PF) fold4(PF, r);
+#pragma unroll DEPTH
+                    for (int s = PF + 1; s < KI; ++s) {
+                        load4(sp, s, r);
+                        fold4(s, r);
+                    }
+                } else {
+#pragma unroll DEPTH
+                    for (int s = 0; s < KI; ++s) {
+                        RV r[4];
+                        load4(sp, s, r);
+                        fold4(s, r);
+                    }
+                }
+            } else {
 #pragma unroll DEPTH
             for (int s = 0; s < KI; ++s) {
                 RV r[4];
                 load4(sp, s, r);
                 fold4(s, r);
+            }
+            }
+        }
+        if constexpr (PF > 0) {
+            pre_ok = has_next && my_frame_needed(nxt);
+            if (pre_ok) {
+                const Src spn = source(nxt);
+#pragma unroll
+                for (int s = 0; s < PF; ++s) load4(spn, s, pre[s]);
             }
         }
         PROF_MARK(1);

@@ -348,8 +348,11 @@ __global__ __launch_bounds__(mel_threads(LOG2N, LOG2E)) void k_mel(
         lds_barrier();
         PROF_MARK(4);
         // ---- fixed-order reduction of the parts of every 16-filter block
-        for (int idx = to; idx < fb_blocks * 256; idx += NT) {
-            const int blk = __builtin_amdgcn_readfirstlane(idx >> 8), e = idx & 255;   // (a block = four whole waves: its range of parts loads into SGPRs)
+        // (a block = four whole waves; with NT a multiple of 256 a wave's blocks are wave / 4 + (NT / 256) j: scalar and the same
+        // for every tile, so the ranges of their parts are loaded into SGPRs once, ahead of the tile loop)
+        for (int j = 0; (NT % 256 == 0) ? j * (NT / 256) + (wave >> 2) < fb_blocks : j * NT + to < fb_blocks * 256; ++j) {
+            const int idx = to + j * NT;
+            const int blk = (NT % 256 == 0) ? j * (NT / 256) + (wave >> 2) : __builtin_amdgcn_readfirstlane(idx >> 8), e = idx & 255;
             float val = 0.f;
             for (int it = fb_blk_ptr[blk]; it < fb_blk_ptr[blk + 1]; ++it) val += slot_ptr(it)[e];
             const int m = 16 * blk + (e >> 4), tq = e & 15;
@@ -367,8 +370,9 @@ __global__ __launch_bounds__(mel_threads(LOG2N, LOG2E)) void k_mel(
             if constexpr (RES) gemm_resident(adct, sdct, ndct, lane, dslot0, slot_ptr, logmel, [](int) {});
             else gemm_items(dct_pack, dct_items, dct_wave_ptr, wave, lane, dslot0, slot_ptr, logmel);
             lds_barrier();
-            for (int idx = to; idx < dct_blocks * 256; idx += NT) {
-                const int blk = __builtin_amdgcn_readfirstlane(idx >> 8), e = idx & 255;
+            for (int j = 0; (NT % 256 == 0) ? j * (NT / 256) + (wave >> 2) < dct_blocks : j * NT + to < dct_blocks * 256; ++j) {
+                const int idx = to + j * NT;
+                const int blk = (NT % 256 == 0) ? j * (NT / 256) + (wave >> 2) : __builtin_amdgcn_readfirstlane(idx >> 8), e = idx & 255;
                 float val = 0.f;
                 for (int it = dct_blk_ptr[blk]; it < dct_blk_ptr[blk + 1]; ++it) val += slot_ptr(dslot0 + it)[e];
                 const int q = 16 * blk + (e >> 4), tq = e & 15;

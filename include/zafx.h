@@ -97,12 +97,12 @@ enum zafx_constant {
 typedef struct zafx_params {
     int32_t struct_size;       /* = sizeof(zafx_params)                                         */
     int32_t window_length;     /* W, power of two, 64..8192 (STFT family, MDCT family; float32 MEL / MFCC: 64..2048), or --
-                                  ZAFX_STFT / ZAFX_ISTFT / ZAFX_MDCT / ZAFX_IMDCT -- any other length 33..2048 (MDCT family: even):
+                                  ZAFX_STFT / ZAFX_ISTFT / ZAFX_MDCT / ZAFX_IMDCT -- any other length 33..8192 (MDCT family: even):
                                   those run as float32 Bluestein convolutions (np.fft takes any length, so does the reference).
                                   With ZAFX_PRECISION_F64 any length 2..2048 (MDCT family: even, 4..2048), every kind            */
     int32_t step_length;       /* hop H >= 1 (STFT/MEL/MFCC: any, also above W as zaf.stft allows; ISTFT: H <= W and
-                                  ceil(W/H) within the overlap-add tile -- 16 frames up to W = 2048, 8 at 4096, 4 at 8192;
-                                  no such limit with ZAFX_PRECISION_F64); CQT: frame step                          */
+                                  any: above ceil(W/H) = 16 frames (8 at W = 4096, 4 at 8192) the float32 frames +
+                                  gather overlap-add form runs instead of the tiled kernel); CQT: frame step        */
     int32_t layout;            /* enum zafx_layout of the 2-D (frequency x time) side           */
     int32_t n_filters;         /* MEL / MFCC: 1..256 (ZAFX_PRECISION_F64: 1..W/2)               */
     int32_t n_coefs;           /* MFCC                                                          */

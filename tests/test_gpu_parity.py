@@ -288,15 +288,13 @@ def test_errors(zafx):
     with pytest.raises(ValueError):
         zafx.stft(x, ham, 1024.0)                     # non-int hop
     with pytest.raises(ValueError):
-        zafx.stft(x, zafx.hamming(3000), 500)         # window not a power of two and above 2048
+        zafx.stft(x, zafx.hamming(9000), 500)         # window above 8192
     with pytest.raises(ValueError):
         zafx.melspectrogram(x, ham, 1024, np.ones((4, 1024)))   # filterbank must expose .toarray()
-    with pytest.raises(zafx.ZafxError):                          # ceil(W/H) too large for the float32 OLA tile at W = 4096: the C-ABI
-        p = zafx.Plan(zafx.ISTFT, window_length=4096, step_length=64)   # refuses (the host layer picks the float64 kernels; up to
-        p.set_window(zafx.hamming(4096))                                # W = 2048 the float32 frames + gather form takes over)
-        d_s = zafx.DeviceBuffer.from_host(np.zeros((1, 4096, 4), np.complex64))
-        d_y = zafx.DeviceBuffer(p.out_shape(1, 4), p.out_dtype)
-        p.execute(d_s, d_y, 1, 4)
+    with pytest.raises(zafx.ZafxError):                          # a window_length the C-ABI has no kernel for
+        zafx.Plan(zafx.ISTFT, window_length=9000, step_length=64)
+    with pytest.raises(zafx.ZafxError):                          # float64 Bluestein forms stop at 2048 samples
+        zafx.Plan(zafx.STFT, window_length=3000, step_length=500, f64=True)
 
 
 # ------------------------------------------------------------------ RCCL broadcast of constants (1 rank)
@@ -1145,6 +1143,43 @@ def test_bluestein_f32_plans_and_sizes(zafx):
         y = zafx.istft_batch(got, w, hop)
         yref = orc.istft(ref, w, hop)
         assert relerr(y[4], yref) <= 3 * TOL_FFT, (wl, hop)   # (round trip: the float32 spectrum goes back in)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("wl,hop", [(3000, 750), (4410, 2205), (5000, 1250), (8000, 2000), (6001, 1500)])
+def test_bluestein_f32_above_2048(zafx, wl, hop):
+    """Windows of 2049 ... 8192 samples that are not a power of two (np.fft takes any length, zaf.py:139): float32 Bluestein
+    forms with convolution lengths 8192 and 16384, STFT / ISTFT for any length, MDCT / IMDCT for the even ones; and the
+    powers of two 4096 / 8192 with a hop too small for the tiled overlap-add, which take the same frames + gather form."""
+    x = np.stack([synth_clip(76, c, 40000) for c in range(3)])
+    w = orc.hamming_periodic(wl)
+    plan = zafx.stft_plan(w, hop)
+    assert not plan.f64 and plan.kernel_name == "k_stft_bs32"
+    got = zafx.stft_batch(x, w, hop)
+    ref = orc.stft(x[2].astype(np.float64), w, hop)
+    assert got[2].shape == ref.shape and relerr(got[2], ref) <= TOL_FFT
+    y = zafx.istft_batch(got, w, hop)
+    assert relerr(y[2], orc.istft(ref, w, hop)) <= 3 * TOL_FFT
+    if wl % 2 == 0:
+        ws = orc.sine_window(wl)
+        assert zafx.mdct_plan(ws).kernel_name == "k_mdct_bs32"
+        c = zafx.mdct_batch(x, ws)
+        cref = orc.mdct(x[2].astype(np.float64), ws)
+        assert c[2].shape == cref.shape and relerr(c[2], cref) <= TOL_FFT
+        yi = zafx.imdct_batch(c, ws)
+        assert relerr(yi[2], orc.imdct(cref, ws)) <= 3 * TOL_FFT
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("wl,hop", [(4096, 64), (8192, 1000)])
+def test_istft_small_hop_large_window_f32(zafx, wl, hop):
+    w = orc.hamming_periodic(wl)
+    plan = zafx.istft_plan(w, hop)
+    assert not plan.f64 and plan.kernel_name == "k_ifft_frames_bs32"
+    x = synth_clip(77, 0, 30000)
+    spec = orc.stft(x.astype(np.float64), w, hop)
+    y = zafx.istft(spec.astype(np.complex64), w, hop)
+    assert relerr(y, orc.istft(spec, w, hop)) <= 3 * TOL_FFT
 
 
 def test_f64_inverse_transforms_in_scratch_chunks(tmp_path):

@@ -77,7 +77,7 @@ def test_argument_validation_happens_before_the_device():
     with pytest.raises(ValueError):
         zafx.stft(x, ham, 0)
     with pytest.raises(ValueError):
-        zafx.stft(x, zafx.hamming(3000), 500)
+        zafx.stft(x, zafx.hamming(9000), 500)
     with pytest.raises(ValueError):
         zafx.istft(np.zeros((2048, 4), complex), ham, 4096)   # (the forward transforms take a hop above the window, as zaf.stft)
     with pytest.raises(ValueError):
@@ -186,11 +186,12 @@ def test_window_length_routing_rules():
     """Which window lengths the host layer accepts, and which go to the float32 kernels (decided before any device call)."""
     from zafx import core
     assert [n for n in (32, 64, 100, 2048, 4096, 8192, 16384) if core._tuned(n)] == [64, 2048, 4096, 8192]
-    # float32 kernels: tiled for the powers of two, Bluestein forms for the other lengths 33 ... 2048; float64 below that
-    assert [n for n in (2, 16, 32, 33, 63, 64, 100, 1764, 2047, 2048, 2049, 4096) if core._f32_window(n)] == [33, 63, 64, 100, 1764, 2047, 2048, 4096]
-    for n in (2, 3, 63, 1000, 1764, 2047):                      # STFT family: any length up to 2048
+    # float32 kernels: tiled for the powers of two, Bluestein forms for the other lengths 33 ... 8192; float64 below that
+    assert [n for n in (2, 16, 32, 33, 63, 64, 100, 1764, 2047, 2048, 2049, 4096, 8191, 8193) if core._f32_window(n)] == \
+        [33, 63, 64, 100, 1764, 2047, 2048, 2049, 4096, 8191]
+    for n in (2, 3, 63, 1000, 1764, 2047, 3000, 8191):          # any length up to 8192
         assert len(core._as_window(np.ones(n), any_length=True)) == n
-    for n in (1, 3000, 16384):                                   # ... but not above it unless a tuned power of two
+    for n in (1, 8193, 16384):                                   # ... but not above it
         with pytest.raises(ValueError):
             core._as_window(np.ones(n), any_length=True)
     for n in (32, 1000, 3000):                                   # callers that need a float32 kernel

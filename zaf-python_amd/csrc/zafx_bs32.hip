@@ -215,6 +215,8 @@ hipError_t by_log2m(int log2m, F&& f) {
         case 10: return f(std::integral_constant<int, 10>{});
         case 11: return f(std::integral_constant<int, 11>{});
         case 12: return f(std::integral_constant<int, 12>{});
+        case 13: return f(std::integral_constant<int, 13>{});
+        case 14: return f(std::integral_constant<int, 14>{});
     }
     set_error("bluestein: unsupported convolution length");
     return hipErrorInvalidValue;
@@ -230,7 +232,7 @@ hipError_t launch_ola(zafx_plan& pl, float* y, int64_t n_clips, int T, int hop, 
 
 }  // namespace
 
-bool bs32_supported(int W) { return W >= 33 && W <= 2048; }   // M = 128 ... 4096
+bool bs32_supported(int W) { return W >= 33 && W <= 8192; }   // M = 128 ... 16384 (the frame of 2^14 points is 139 KB of LDS)
 
 hipError_t launch_stft_bs32(const zafx_plan& pl, const float* x, float2* out, int64_t n_clips, int64_t n_samples, int T) {
     const long long total = (long long)n_clips * T;

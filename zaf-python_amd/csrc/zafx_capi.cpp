@@ -529,7 +529,7 @@ int zafx_plan_create(zafx_plan** out, int device, int kind, const zafx_params* p
             while ((1 << pl->bs_log2m) < 2 * pl->W - 1) ++pl->bs_log2m;   // float32 Bluestein forms (zafx_bs32.hip)
             lw = 6;
         } else if (lw < 0 || !stft_supported(lw - 1)) {
-            return bail("window_length must be a power of two in [64, 8192], or any length in [33, 2048] for ZAFX_STFT / ZAFX_ISTFT "
+            return bail("window_length must be a power of two in [64, 8192], or any length in [33, 8192] for ZAFX_STFT / ZAFX_ISTFT "
                         "(any length in [2, 2048] with ZAFX_PRECISION_F64)");
         }
         if (pl->H < 1) return bail("step_length must be >= 1");
@@ -538,7 +538,8 @@ int zafx_plan_create(zafx_plan** out, int device, int kind, const zafx_params* p
         if (kind == ZAFX_ISTFT && params->precision == ZAFX_PRECISION_F32 && pl->bs_log2m == 0 && bs32_supported(pl->W)) {
             // A hop so small that more frames cover a sample than the tiled overlap-add keeps in LDS (16): the frames + gather
             // overlap-add form of zafx_bs32.hip has no such limit and takes any length, powers of two included.
-            if ((pl->W + pl->H - 1) / pl->H > 16)
+            const int tile = pl->W <= 2048 ? 16 : pl->W == 4096 ? 8 : 4;   // frames of the tiled kernel's LDS tile
+            if ((pl->W + pl->H - 1) / pl->H > tile)
                 while ((1 << pl->bs_log2m) < 2 * pl->W - 1) ++pl->bs_log2m;
         }
         pl->log2nf = lw - 1;
@@ -568,7 +569,7 @@ int zafx_plan_create(zafx_plan** out, int device, int kind, const zafx_params* p
             while ((1 << pl->bs_log2m) < 2 * pl->W - 1) ++pl->bs_log2m;   // float32 Bluestein forms (zafx_bs32.hip)
             lw = 6;
         } else if (lw < 0 || !mdct_supported(lw - 2)) {
-            return bail("window_length must be a power of two in [64, 8192] or any even length in [34, 2048] "
+            return bail("window_length must be a power of two in [64, 8192] or any even length in [34, 8192] "
                         "(any even length in [4, 2048] with ZAFX_PRECISION_F64)");
         }
         pl->log2nf = lw - 2;

@@ -440,21 +440,21 @@ def _tuned(n):
 
 
 def _f32_window(n):
-    """Window lengths with float32 kernels: the powers of two 64 ... 8192 (tiled kernels) and every other length 33 ... 2048
+    """Window lengths with float32 kernels: the powers of two 64 ... 8192 (tiled kernels) and every other length 33 ... 8192
     (float32 Bluestein forms of STFT / ISTFT / MDCT / IMDCT, zafx_bs32.hip); the rest (below 33 samples) runs in float64."""
-    return _tuned(n) or (33 <= n <= 2048 and not _pow2(n))
+    return _tuned(n) or (33 <= n <= 8192 and not _pow2(n))
 
 
 def _as_window(window_function, any_length=False):
-    """any_length: the STFT family also takes windows that are not a power of two, up to 2048 samples (they run on the
-    float64 Bluestein kernels, see _needs_f64); the MDCT family does not."""
+    """any_length: windows that are not a power of two, up to 8192 samples (float32 Bluestein forms; the float64 ones stop
+    at 2048)."""
     w = np.asarray(window_function, dtype=np.float64)
     if w.ndim != 1:
         raise ValueError("window_function must be 1-D")
     n = len(w)
     if any_length and not _tuned(n):
-        if n < 2 or n > 2048:
-            raise ValueError(f"zafx takes windows of 2 ... 2048 samples, or a power of two up to 8192, got {n}")
+        if n < 2 or n > 8192:
+            raise ValueError(f"zafx takes windows of 2 ... 8192 samples, got {n}")
         return w
     if not _tuned(n):
         raise ValueError(f"zafx kernels need a power-of-two window_length in [64, 8192], got {n}")
@@ -529,12 +529,10 @@ def istft_plan(window_function, step_length, layout="FT", device=0, onesided=Fal
         raise ValueError("step_length must not exceed window_length")
     if onesided not in (False, True):
         raise ValueError("istft takes a complex spectrum: onesided must be False or True")
-    # the float32 overlap-add keeps a tile of 16 frames in LDS (8 at W = 4096, 4 at 8192): a hop so small that more
-    # frames than that cover one sample runs on the float64 kernels (a gather overlap-add without that limit)
-    tile = 16 if len(w) <= 2048 else (8 if len(w) == 4096 else 4)
-    # (windows up to 2048 samples then take the float32 frames + gather overlap-add form of zafx_bs32.hip, which has no such
-    # limit -- as do all windows that are not a power of two; W = 4096 / 8192 with such hops run in float64)
-    f64 = bool(f64) or not _f32_window(len(w)) or (len(w) > 2048 and -(-len(w) // h) > tile)
+    # the tiled float32 overlap-add keeps 16 frames in LDS (8 at W = 4096, 4 at 8192); for a hop so small that more frames than
+    # that cover one sample -- and for every window that is not a power of two -- the library takes the float32 frames +
+    # gather overlap-add form of zafx_bs32.hip, which has no such limit (zafx_plan_create decides)
+    f64 = bool(f64) or not _f32_window(len(w))
     key = ("istft", device, len(w), h, _LAYOUTS[layout], bool(onesided), bool(f64), _as_row_align(row_align, layout), _digest(w))
 
     def make():

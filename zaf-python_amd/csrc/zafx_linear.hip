@@ -73,9 +73,10 @@ __global__ __launch_bounds__(256) void k_linear(const float* __restrict__ mat, c
 // The same map for the aligned case (n_cols a multiple of 16, 16-byte aligned operands): 128 x 128 output tile per
 // 256-thread workgroup, each wave a 64 x 64 corner as 4 x 4 accumulators (64 VGPRs), K tile 32, operands fetched as
 // float4 and double-buffered (registers -> LDS) so that the global loads of tile k+1 fly under the MFMAs of tile k;
-// one barrier per K tile.  LDS rows padded to 33 floats: 33 fi + fk hits 64 distinct banks for the 16 x 4
-// fragment lanes.  Results leave as float4 (the 4 accumulator registers of a lane are 4 consecutive output rows).
-constexpr int kBigTile = 128, kBigK = 32, kBigPitch = kBigK + 1;
+// one barrier per K tile.  LDS rows padded to 34 floats: a 4-byte LDS read is served 32 lanes at a time over 32 banks, and
+// 34 fi + fk = 2 fi + fk (mod 32) is distinct for the 16 x 2 fragment lanes of each half wave (33, the first choice, put them
+// two by two: SQ_LDS_BANK_CONFLICT 0.33 of the active cycles; 0.438 -> 0.433 ms).  Results leave as float4 (the 4 accumulator registers of a lane are 4 consecutive output rows).
+constexpr int kBigTile = 128, kBigK = 32, kBigPitch = kBigK + 2;
 
 __global__ __launch_bounds__(256) void k_linear128(const float* __restrict__ mat, const float* __restrict__ x, float* __restrict__ y,
                                                    int n_rows, int n_cols, long long n_clips) {

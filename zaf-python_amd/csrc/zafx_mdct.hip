@@ -396,7 +396,7 @@ __global__ __launch_bounds__(NSLOT * fft_threads(LOG2NF, LOG2E)) void k_imdct(
     const int fs4 = (tid % LPR) * 4, mq4 = tid / LPR;
     float4 pre_re[KI], pre_im[KI];
     bool pre_ok = false;
-    auto gather4 = [&](int unit_n, int tile_n) {   // rows of my 4 frames of tile_n of unit_n -> registers
+    auto gather4 = [&](int unit_n, int tile_n, int part = 2) {   // rows of my 4 frames of tile_n of unit_n -> registers (part 0: the rows 2m, 1: the rows M-1-2m, 2: both)
         pre_ok = false;
         if (!vec4 || unit_n >= total_units) return;
         const int tile_a_n = (unit_n % segs) * seg_tiles;
@@ -408,8 +408,8 @@ __global__ __launch_bounds__(NSLOT * fft_threads(LOG2NF, LOG2E)) void k_imdct(
 #pragma unroll
             for (int i = 0; i < KI; ++i) {
                 const int m = mq4 + i * MSTEP;
-                pre_re[i] = *reinterpret_cast<const float4*>(cp + (long long)(2 * m) * TP);
-                pre_im[i] = *reinterpret_cast<const float4*>(cp + (long long)(M - 1 - 2 * m) * TP);
+                if (part != 1) pre_re[i] = *reinterpret_cast<const float4*>(cp + (long long)(2 * m) * TP);
+                if (part != 0) pre_im[i] = *reinterpret_cast<const float4*>(cp + (long long)(M - 1 - 2 * m) * TP);
             }
         }
     };
@@ -519,23 +519,26 @@ __global__ __launch_bounds__(NSLOT * fft_threads(LOG2NF, LOG2E)) void k_imdct(
     lds_barrier();
     PROF_MARK(2);
 #ifndef ZAFX_IMDCT_STAGGER
-#define ZAFX_IMDCT_STAGGER 1
+#define ZAFX_IMDCT_STAGGER 2
 #endif
-    // The next tile of this workgroup (same unit, or the first tile of its next unit) is requested by half of the waves now and
-    // by the other half after their transforms: 16 waves x 8 loads at once overrun the CU's vector-memory queue and the youngest
-    // waves start their transforms behind it.
-    const bool gather_now = !ZAFX_IMDCT_STAGGER || tid < NT / 2;
-    auto gather_next = [&]() {
+    // The next tile of this workgroup (same unit, or the first tile of its next unit) is requested in two halves: every wave asks for
+    // its rows 2m now and for its rows M-1-2m when the first of its two frames is transformed -- 16 waves x 8 loads at once overrun
+    // the CU's vector-memory queue and the youngest waves start their transforms behind it (1.083 ms); half of the waves now and
+    // the other half after their transforms: 1.058; this form: 1.042.
+    constexpr int STAGGER = ZAFX_IMDCT_STAGGER;
+    const bool gather_now = STAGGER != 1 || tid < NT / 2;
+    auto gather_next = [&](int part = 2) {
         int unit_n = unit, tile_n = tile + 1;
         if (tile_n >= tile_b) {
             unit_n = unit + gridDim.x;
             tile_n = unit_n < total_units ? first_tile(unit_n) : 0;
         }
-        gather4(unit_n, tile_n);
+        gather4(unit_n, tile_n, part);
     };
     if constexpr (PRE) {
-        if (gather_now) gather_next();
+        if (gather_now) gather_next(STAGGER == 2 ? 0 : 2);
     }
+    bool second_half = false;
     if constexpr (PRE_TF) {
         int unit_n = unit, tile_n = tile + 1;
         if (tile_n >= tile_b) {
@@ -556,6 +559,10 @@ __global__ __launch_bounds__(NSLOT * fft_threads(LOG2NF, LOG2E)) void k_imdct(
             regs_read<LOG2NF, LOG2E>(v, buf, p);
             frame_sync<P>();
             fft_frame<LOG2NF, LOG2E>(v, buf, p, tw_l);
+            if constexpr (PRE && ZAFX_IMDCT_STAGGER == 2) {
+                if (!second_half) gather_next(1);   // (the wave's first frame is done: the other half of its requests)
+                second_half = true;
+            }
             // pair (k, NF-1-k): u[2k] = Re y_k, u[2k+1] = -Im y_kk, u[2kk] = Re y_kk, u[2kk+1] = -Im y_k
             for (int k = p; k < NF / 2; k += P) {
                 const int kk = NF - 1 - k;
@@ -567,7 +574,8 @@ __global__ __launch_bounds__(NSLOT * fft_threads(LOG2NF, LOG2E)) void k_imdct(
         }
     }
     if constexpr (PRE) {
-        if (!gather_now) gather_next();
+        if (STAGGER == 1 && !gather_now) gather_next();
+        if (STAGGER == 2 && !second_half) gather_next(1);   // (a wave without a frame to transform in this tile)
     }
     PROF_MARK(3);
     lds_barrier();
@@ -606,7 +614,7 @@ __global__ __launch_bounds__(NSLOT * fft_threads(LOG2NF, LOG2E)) void k_imdct(
             // frame are fixed and a sweep is two 8-byte LDS reads, three packed operations and one 8-byte store at constant strides
             // (the general loop below re-derives all of that per pair and waits for each LDS read in turn: 13 k of the tile's
             // 38 k cycles at W = 2048).  Same operations in the same order: bit-identical to the general loop.
-            if (SWEEP && tile != tiles - 1 && n_valid == FPB && y_aligned && o_first + (long long)FPB * M <= out_len) {
+            if (SWEEP && tile != tiles - 1 && n_valid == FPB && o_first + (long long)FPB * M <= out_len) {
                 int to = tid;   // opaque: the slots and window pairs are recomputed per tile (carried through the transforms they spill)
                 asm volatile("" : "+v"(to));
                 const int n1 = (2 * to) & (M - 1);
@@ -630,7 +638,16 @@ __global__ __launch_bounds__(NSLOT * fft_threads(LOG2NF, LOG2E)) void k_imdct(
                         }
                         const float2 a = decltype(LO)::value ? make_float2(t.x + c.x * wc.x, t.y + c.y * wc.y)
                                                              : make_float2(t.x + -c.y * wc.x, t.y + -c.x * wc.y);
-                        if (!(it == 0 && skip0)) dst[(size_t)it * NT] = make_float2(a.x * gain, a.y * gain);
+                        if (!(it == 0 && skip0)) {
+                            // (the reference's output length (T-1) M - 1 is odd: every second clip of a batch starts on a 4-byte boundary)
+                            if (y_aligned) {
+                                dst[(size_t)it * NT] = make_float2(a.x * gain, a.y * gain);
+                            } else {
+                                float* d1 = reinterpret_cast<float*>(dst + (size_t)it * NT);
+                                d1[0] = a.x * gain;
+                                d1[1] = a.y * gain;
+                            }
+                        }
                     }
                 };
                 if (lo) sweep(std::true_type{});

@@ -548,7 +548,7 @@ __global__ __launch_bounds__(NSLOT * fft_threads(LOG2NF, LOG2E)) void k_imdct(
         gather_tf(unit_n, tile_n);
     }
 
-    // ---- phase B: FFT, then DCT-IV post-twiddle written in place as M reals per frame
+    // ---- phase B: FFT with the DCT-IV post-twiddle in its last pass
     {
         const int p = tid % P;
 #pragma unroll 1
@@ -558,18 +558,14 @@ __global__ __launch_bounds__(NSLOT * fft_threads(LOG2NF, LOG2E)) void k_imdct(
             float2 v[E];
             regs_read<LOG2NF, LOG2E>(v, buf, p);
             frame_sync<P>();
-            fft_frame<LOG2NF, LOG2E>(v, buf, p, tw_l);
+            // DCT-IV post-twiddle folded into the last pass (as k_mdct_ft32): slot k holds conj(y_k g_k), and the 2 NF reals of the
+            // frame are read from it where they are needed, u[2k] = slot[k].x, u[2k+1] = -Im(y g)[NF-1-k] = slot[NF-1-k].y
+            // (upair).  The separate sweep over the pairs (k, NF-1-k) -- four 8-byte LDS reads and two writes per pair,
+            // a quarter of the phase's LDS time -- is gone.
+            fft_frame_post<LOG2NF, LOG2E>(v, buf, p, tw_l, tw8);
             if constexpr (PRE && ZAFX_IMDCT_STAGGER == 2) {
                 if (!second_half) gather_next(1);   // (the wave's first frame is done: the other half of its requests)
                 second_half = true;
-            }
-            // pair (k, NF-1-k): u[2k] = Re y_k, u[2k+1] = -Im y_kk, u[2kk] = Re y_kk, u[2kk+1] = -Im y_k
-            for (int k = p; k < NF / 2; k += P) {
-                const int kk = NF - 1 - k;
-                const float2 a = cmul(buf[phys(k)], tw8[k]);
-                const float2 b = cmul(buf[phys(kk)], tw8[kk]);
-                buf[phys(k)] = make_float2(a.x, -b.y);
-                buf[phys(kk)] = make_float2(b.x, -a.y);
             }
         }
     }
@@ -590,15 +586,18 @@ __global__ __launch_bounds__(NSLOT * fft_threads(LOG2NF, LOG2E)) void k_imdct(
         const float2* frames2 = frames;
         const float2* win2 = reinterpret_cast<const float2*>(win_l);
         float2* carry2 = reinterpret_cast<float2*>(carry);
+        auto upair = [&](const float2* fr, int k) {   // (u[2k], u[2k+1]) of a transformed frame
+            return make_float2(fr[phys(k)].x, fr[phys(NF - 1 - k)].y);
+        };
         auto older2 = [&](int j, int n1) {   // frame j's contribution to samples n1, n1 + 1 of the next frame's span
             const int n0 = n1 + M;
             const float2* fr = frames2 + (size_t)j * C::PITCH;
             float2 u;
             if (n0 < 3 * NF) {
-                const float2 v = fr[phys((3 * NF - 2 - n0) >> 1)];   // floats (3NF-2-n0, 3NF-1-n0)
+                const float2 v = upair(fr, (3 * NF - 2 - n0) >> 1);   // floats (3NF-2-n0, 3NF-1-n0)
                 u = make_float2(-v.y, -v.x);
             } else {
-                const float2 v = fr[phys((n0 - 3 * NF) >> 1)];
+                const float2 v = upair(fr, (n0 - 3 * NF) >> 1);
                 u = make_float2(-v.x, -v.y);
             }
             const float2 w = win2[n0 >> 1];
@@ -620,20 +619,23 @@ __global__ __launch_bounds__(NSLOT * fft_threads(LOG2NF, LOG2E)) void k_imdct(
                 const int n1 = (2 * to) & (M - 1);
                 const int h = __builtin_amdgcn_readfirstlane((2 * to) / M);           // (whole waves: NF >= 128)
                 const bool lo = __builtin_amdgcn_readfirstlane(n1 < NF ? 1 : 0) != 0;
-                const float2* pc = frames2 + (size_t)h * C::PITCH + (lo ? phys((NF + n1) >> 1) : phys((3 * NF - 2 - n1) >> 1));
-                const float2* po = frames2 + (size_t)h * C::PITCH - C::PITCH + (lo ? phys((NF - 2 - n1) >> 1) : phys((n1 - NF) >> 1));
+                const int kc = lo ? (NF + n1) >> 1 : (3 * NF - 2 - n1) >> 1, ko = lo ? (NF - 2 - n1) >> 1 : (n1 - NF) >> 1;   // the pairs' k
+                const float* pcx = reinterpret_cast<const float*>(frames2 + (size_t)h * C::PITCH + phys(kc));
+                const float* pcy = reinterpret_cast<const float*>(frames2 + (size_t)h * C::PITCH + phys(NF - 1 - kc)) + 1;
+                const float* pox = reinterpret_cast<const float*>(frames2 + (size_t)h * C::PITCH - C::PITCH + phys(ko));
+                const float* poy = reinterpret_cast<const float*>(frames2 + (size_t)h * C::PITCH - C::PITCH + phys(NF - 1 - ko)) + 1;
                 const float2 wc = win2[n1 >> 1], wo = win2[(n1 + M) >> 1];
                 float2* dst = reinterpret_cast<float2*>(yc + o_first) + to;
                 const bool skip0 = t_first == 0 && h == 0;   // the first M samples of the clip's first tile are trimmed
                 auto sweep = [&](auto LO) {
 #pragma unroll
                     for (int it = 0; it < NIT; ++it) {
-                        const float2 c = pc[(size_t)it * FR * C::PITCH];
+                        const float2 c = make_float2(pcx[(size_t)it * FR * C::PITCH * 2], pcy[(size_t)it * FR * C::PITCH * 2]);
                         float2 t;
                         if (it == 0 && h == 0) {
                             t = carry2[n1 >> 1];
                         } else {
-                            const float2 o = po[(size_t)it * FR * C::PITCH];
+                            const float2 o = make_float2(pox[(size_t)it * FR * C::PITCH * 2], poy[(size_t)it * FR * C::PITCH * 2]);
                             t = decltype(LO)::value ? make_float2(-o.y * wo.x, -o.x * wo.y) : make_float2(-o.x * wo.x, -o.y * wo.y);
                         }
                         const float2 a = decltype(LO)::value ? make_float2(t.x + c.x * wc.x, t.y + c.y * wc.y)
@@ -660,9 +662,9 @@ __global__ __launch_bounds__(NSLOT * fft_threads(LOG2NF, LOG2E)) void k_imdct(
                     const float2* fr = frames2 + (size_t)j1 * C::PITCH;
                     float2 u;
                     if (n1 < NF) {
-                        u = fr[phys((NF + n1) >> 1)];
+                        u = upair(fr, (NF + n1) >> 1);
                     } else {
-                        const float2 v = fr[phys((3 * NF - 2 - n1) >> 1)];
+                        const float2 v = upair(fr, (3 * NF - 2 - n1) >> 1);
                         u = make_float2(-v.y, -v.x);
                     }
                     const float2 w = win2[n1 >> 1];

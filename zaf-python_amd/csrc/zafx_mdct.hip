@@ -613,7 +613,8 @@ __global__ __launch_bounds__(NSLOT * fft_threads(LOG2NF, LOG2E)) void k_imdct(
             // frame are fixed and a sweep is two 8-byte LDS reads, three packed operations and one 8-byte store at constant strides
             // (the general loop below re-derives all of that per pair and waits for each LDS read in turn: 13 k of the tile's
             // 38 k cycles at W = 2048).  Same operations in the same order: bit-identical to the general loop.
-            if (SWEEP && tile != tiles - 1 && n_valid == FPB && o_first + (long long)FPB * M <= out_len) {
+            const bool last_tile = tile == tiles - 1;   // (partial: frames up to n_valid, one more span with the older term only, trimmed at out_len)
+            if (SWEEP && (last_tile || (n_valid == FPB && o_first + (long long)FPB * M <= out_len))) {
                 int to = tid;   // opaque: the slots and window pairs are recomputed per tile (carried through the transforms they spill)
                 asm volatile("" : "+v"(to));
                 const int n1 = (2 * to) & (M - 1);
@@ -627,10 +628,14 @@ __global__ __launch_bounds__(NSLOT * fft_threads(LOG2NF, LOG2E)) void k_imdct(
                 const float2 wc = win2[n1 >> 1], wo = win2[(n1 + M) >> 1];
                 float2* dst = reinterpret_cast<float2*>(yc + o_first) + to;
                 const bool skip0 = t_first == 0 && h == 0;   // the first M samples of the clip's first tile are trimmed
-                auto sweep = [&](auto LO) {
+                auto sweep = [&](auto LO, auto LAST) {
+                    constexpr bool L = decltype(LAST)::value;
 #pragma unroll
                     for (int it = 0; it < NIT; ++it) {
-                        const float2 c = make_float2(pcx[(size_t)it * FR * C::PITCH * 2], pcy[(size_t)it * FR * C::PITCH * 2]);
+                        const int j = FR * it + h;   // (uniform) the frame of this pass
+                        if (L && j > n_valid) continue;
+                        const bool cur = !L || j < n_valid;
+                        const float2 c = cur ? make_float2(pcx[(size_t)it * FR * C::PITCH * 2], pcy[(size_t)it * FR * C::PITCH * 2]) : make_float2(0.f, 0.f);
                         float2 t;
                         if (it == 0 && h == 0) {
                             t = carry2[n1 >> 1];
@@ -638,22 +643,29 @@ __global__ __launch_bounds__(NSLOT * fft_threads(LOG2NF, LOG2E)) void k_imdct(
                             const float2 o = make_float2(pox[(size_t)it * FR * C::PITCH * 2], poy[(size_t)it * FR * C::PITCH * 2]);
                             t = decltype(LO)::value ? make_float2(-o.y * wo.x, -o.x * wo.y) : make_float2(-o.x * wo.x, -o.y * wo.y);
                         }
-                        const float2 a = decltype(LO)::value ? make_float2(t.x + c.x * wc.x, t.y + c.y * wc.y)
-                                                             : make_float2(t.x + -c.y * wc.x, t.y + -c.x * wc.y);
+                        float2 a = t;
+                        if (cur)
+                            a = decltype(LO)::value ? make_float2(t.x + c.x * wc.x, t.y + c.y * wc.y) : make_float2(t.x + -c.y * wc.x, t.y + -c.x * wc.y);
                         if (!(it == 0 && skip0)) {
                             // (the reference's output length (T-1) M - 1 is odd: every second clip of a batch starts on a 4-byte boundary)
-                            if (y_aligned) {
+                            const long long o = o_first + 2 * to + (long long)it * 2 * NT;
+                            if (y_aligned && (!L || o + 1 < out_len)) {
                                 dst[(size_t)it * NT] = make_float2(a.x * gain, a.y * gain);
                             } else {
                                 float* d1 = reinterpret_cast<float*>(dst + (size_t)it * NT);
-                                d1[0] = a.x * gain;
-                                d1[1] = a.y * gain;
+                                if (!L || o < out_len) d1[0] = a.x * gain;
+                                if (!L || o + 1 < out_len) d1[1] = a.y * gain;
                             }
                         }
                     }
                 };
-                if (lo) sweep(std::true_type{});
-                else sweep(std::false_type{});
+                if (last_tile) {
+                    if (lo) sweep(std::true_type{}, std::true_type{});
+                    else sweep(std::false_type{}, std::true_type{});
+                } else {
+                    if (lo) sweep(std::true_type{}, std::false_type{});
+                    else sweep(std::false_type{}, std::false_type{});
+                }
             } else {
             for (int c2 = tid; c2 < c_end2; c2 += NT) {
                 const int c = 2 * c2, j1 = c / M, n1 = c % M;

@@ -177,6 +177,7 @@ static void free_band(PackedBand& pb) {
     if (pb.d_wave_ptr) (void)hipFree(pb.d_wave_ptr);
     if (pb.d_blk_ptr) (void)hipFree(pb.d_blk_ptr);
     if (pb.d_desc) (void)hipFree(pb.d_desc);
+    if (pb.d_direct) (void)hipFree(pb.d_direct);
     pb = PackedBand{};
 }
 
@@ -289,6 +290,27 @@ static int finalize_constant(zafx_plan* pl, int which) {
                 return 0;
             }
             ZAFX_HIP(pack_band(pl->dct, pl->h_dct.data(), pl->prm.n_coefs, pl->prm.n_filters, mel_waves(pl->log2nf)));
+            {
+                // Register-fed form (k_mel, 16 waves): after the filterbank's reduction wave w holds, lane for lane, the B fragment of
+                // the DCT's K-steps w, w + 16, ... (log-mel rows 4 s + (lane >> 4), frame lane & 15), so its A fragments are those
+                // steps of every 16-row block of DCT rows: [w][j][block][lane] = D[16 block + (lane & 15)][4 (w + 16 j) + (lane >> 4)].
+                zafx::PackedBand& d = pl->dct;
+                const int nw = mel_waves(pl->log2nf), nf = pl->prm.n_filters, nc = pl->prm.n_coefs;
+                const int ksteps = (nf + 3) / 4, jn = (ksteps + nw - 1) / nw;
+                d.direct_j = 0;
+                if (nw == 16 && jn <= 2 && d.n_blocks <= 2) {   // a fixed 2 x 2 arrangement [w][j][block] (zero fragments where there is no step / block)
+                    std::vector<float> frag((size_t)nw * 4 * 64, 0.f);
+                    for (int w = 0; w < nw; ++w)
+                        for (int j = 0; j < jn; ++j)
+                            for (int b = 0; b < d.n_blocks; ++b)
+                                for (int l = 0; l < 64; ++l) {
+                                    const int row = 16 * b + (l & 15), col = 4 * (w + nw * j) + (l >> 4);
+                                    if (row < nc && col < nf) frag[(((size_t)w * 2 + j) * 2 + b) * 64 + l] = pl->h_dct[(size_t)row * nf + col];
+                                }
+                    ZAFX_HIP(upload(&d.d_direct, frag.data(), frag.size() * sizeof(float)));
+                    d.direct_j = 2;
+                }
+            }
             return 0;
         case ZAFX_CONST_MATRIX:
             ZAFX_HIP(upload(&pl->d_matrix, pl->h_matrix.data(), pl->h_matrix.size() * sizeof(float)));

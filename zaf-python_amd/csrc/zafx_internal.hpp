@@ -43,6 +43,8 @@ struct PackedBand {
     int4* d_items = nullptr;     // per wave, longest first: {slot id, first column, steps, offset into d_pack (steps)}
     int* d_wave_ptr = nullptr;   // [n_waves + 1] ranges into d_items
     int* d_blk_ptr = nullptr;    // [n_blocks + 1] ranges of slot ids belonging to a block
+    float* d_direct = nullptr;   // DCT rows as MFMA A fragments for the register-fed form of k_mel: [wave][j][row block][64 lanes], K-step w + 16 j
+    int direct_j = 0;            // K-steps per wave of that form (0: not available)
     unsigned short* d_desc = nullptr;   // [total_steps] K-step descriptors of the resident form: first column / 4 | slot id << 8 | item ends << 15
     bool desc_ok = false;        // every step fits the 16-bit descriptor
     int n_empty = 0;             // blocks without non-zeros (their zero tiles are written by the streamed form only)

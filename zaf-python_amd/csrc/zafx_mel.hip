@@ -118,16 +118,17 @@ __device__ __forceinline__ void gemm_resident(const float (&a)[RA], const int (&
 }
 
 // RES: filterbank (and DCT) fragments resident in registers + prefetch of the next tile under the filterbank phases.
-// MF: 1 = mel, 2 = mfcc compiled in (resident form), 0 = the kernel argument decides.
+// MF: 1 = mel, 2 = mfcc, 3 = mfcc with the register-fed DCT compiled in (resident form), 0 = the kernel argument decides.
 template <int LOG2N, int LOG2E, bool ALIGNED, bool RES, int MF>
 __global__ __launch_bounds__(mel_threads(LOG2N, LOG2E)) void k_mel(
     const float* __restrict__ x, const float* __restrict__ win, const float2* __restrict__ twp,
     const float2* __restrict__ tws, const float* __restrict__ fb_pack, const int4* __restrict__ fb_items,
     const int* __restrict__ fb_wave_ptr, const int* __restrict__ fb_blk_ptr, const unsigned short* __restrict__ fb_desc, int fb_blocks, int fb_nitems, int fb_steps, int dct_steps,
     const float* __restrict__ dct_pack, const int4* __restrict__ dct_items, const int* __restrict__ dct_wave_ptr,
-    const int* __restrict__ dct_blk_ptr, const unsigned short* __restrict__ dct_desc, int dct_blocks, float* __restrict__ out, long long n_samples, int hop, int T, int TP,
+    const int* __restrict__ dct_blk_ptr, const unsigned short* __restrict__ dct_desc, const float* __restrict__ dct_direct, int dct_j, int dct_blocks, float* __restrict__ out, long long n_samples, int hop, int T, int TP,
     int tiles, int total_tiles, int n_filters, int n_coefs, int mfcc_arg, int layout) {
-    const bool mfcc = MF == 0 ? mfcc_arg != 0 : MF == 2;
+    const bool mfcc = MF == 0 ? mfcc_arg != 0 : MF >= 2;
+    constexpr bool DIRECT = MF == 3;   // DCT fed from the registers of the filterbank's reduction (below)
     using C = FftCfg<LOG2N, LOG2E>;
     using G = MelCfg<LOG2N, LOG2E>;
     constexpr int N = C::N, P = C::P, E = C::E, W = 2 * N, NT = G::NT, FPB = G::FPB, NSLOT = G::NSLOT;
@@ -253,7 +254,10 @@ __global__ __launch_bounds__(mel_threads(LOG2N, LOG2E)) void k_mel(
         const int h0 = (int)((long long)dct_steps * wave / NW);
         ndct = __builtin_amdgcn_readfirstlane(mfcc ? (int)((long long)dct_steps * (wave + 1) / NW) - h0 : 0);
 #pragma unroll
-        for (int i = 0; i < kMelResidentDct; ++i) adct[i] = i < ndct ? dct_pack[(size_t)(h0 + i) * 64 + (tid & 63)] : 0.f;
+        for (int i = 0; i < kMelResidentDct; ++i) {
+            if constexpr (DIRECT) adct[i] = dct_direct[((size_t)wave * 4 + i) * 64 + (tid & 63)];   // register-fed form: [j][block], 2 x 2
+            else adct[i] = i < ndct ? dct_pack[(size_t)(h0 + i) * 64 + (tid & 63)] : 0.f;
+        }
 #pragma unroll
         for (int i = 0; i < (kMelResidentDct + 1) / 2; ++i) sdct[i] = __builtin_amdgcn_readfirstlane(2 * i < ndct ? (dct_desc[h0 + 2 * i] | dct_desc[h0 + 2 * i + 1] << 16) : 0);
     }
@@ -350,6 +354,7 @@ __global__ __launch_bounds__(mel_threads(LOG2N, LOG2E)) void k_mel(
         // ---- fixed-order reduction of the parts of every 16-filter block
         // (a block = four whole waves; with NT a multiple of 256 a wave's blocks are wave / 4 + (NT / 256) j: scalar and the same
         // for every tile, so the ranges of their parts are loaded into SGPRs once, ahead of the tile loop)
+        float lm[2] = {0.f, 0.f};   // (DIRECT) log-mel values of this thread: element of the B fragment of the DCT's K-steps wave, wave + 16
         for (int j = 0; (NT % 256 == 0) ? j * (NT / 256) + (wave >> 2) < fb_blocks : j * NT + to < fb_blocks * 256; ++j) {
             const int idx = to + j * NT;
             const int blk = (NT % 256 == 0) ? j * (NT / 256) + (wave >> 2) : __builtin_amdgcn_readfirstlane(idx >> 8), e = idx & 255;
@@ -357,13 +362,48 @@ __global__ __launch_bounds__(mel_threads(LOG2N, LOG2E)) void k_mel(
             for (int it = fb_blk_ptr[blk]; it < fb_blk_ptr[blk + 1]; ++it) val += slot_ptr(it)[e];
             const int m = 16 * blk + (e >> 4), tq = e & 15;
             if (mfcc) {
-                slot_ptr(lt0 + blk)[e] = m < n_filters ? logf(val + eps) : 0.f;
+                const float l = m < n_filters ? logf(val + eps) : 0.f;
+                if constexpr (DIRECT) {
+                    if (j == 0) lm[0] = l;
+                    else lm[1] = l;
+                } else {
+                    slot_ptr(lt0 + blk)[e] = l;
+                }
             } else if (m < n_filters && t0 + tq < T) {
                 if (layout == ZAFX_LAYOUT_FT) out[((long long)clip * n_filters + m) * TP + t0 + tq] = val;   // TP = row pitch (>= T)
                 else out[((long long)clip * T + t0 + tq) * n_filters + m] = val;
             }
         }
         if (mfcc) {
+            if constexpr (DIRECT) {
+                // ---- rows 1..ncoef of the orthonormal DCT-II over the mel axis, register fed: the thread's log-mel value of pass j is
+                // element (k = 4 s + (lane >> 4), n = lane & 15) of the B fragment of K-step s = wave + 16 j -- no trip through LDS, no
+                // barrier between the logarithm and the product.  Every wave leaves one partial tile per 16-row block (slots behind
+                // the filterbank's: those are still being read by the other waves).
+#pragma unroll
+                for (int b = 0; b < 2; ++b) {
+                    if (b < dct_blocks) {
+                        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+                        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(adct[b], lm[0], acc, 0, 0, 0);
+                        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(adct[2 + b], lm[1], acc, 0, 0, 0);
+                        float* dst = slot_ptr(lt0 + b * NW + wave) + (4 * bk) * 16 + bt;
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) dst[q * 16] = acc[q];
+                    }
+                }
+                lds_barrier();
+                for (int idx = to; idx < dct_blocks * 256; idx += NT) {
+                    const int blk = idx >> 8, e = idx & 255;
+                    float val = 0.f;
+#pragma unroll
+                    for (int w = 0; w < NW; ++w) val += slot_ptr(lt0 + blk * NW + w)[e];
+                    const int q = 16 * blk + (e >> 4), tq = e & 15;
+                    if (q < n_coefs && t0 + tq < T) {
+                        if (layout == ZAFX_LAYOUT_FT) out[((long long)clip * n_coefs + q) * TP + t0 + tq] = val;
+                        else out[((long long)clip * T + t0 + tq) * n_coefs + q] = val;
+                    }
+                }
+            } else {
             lds_barrier();
             // ---- rows 1..ncoef of the orthonormal DCT-II over the mel axis: second MFMA GEMM
             auto logmel = [&](int row) { return slot_ptr(lt0 + ((row + bk) >> 4))[((row + bk) & 15) * 16 + bt]; };
@@ -380,6 +420,7 @@ __global__ __launch_bounds__(mel_threads(LOG2N, LOG2E)) void k_mel(
                     if (layout == ZAFX_LAYOUT_FT) out[((long long)clip * n_coefs + q) * TP + t0 + tq] = val;
                     else out[((long long)clip * T + t0 + tq) * n_coefs + q] = val;
                 }
+            }
             }
         }
         PROF_MARK(5);
@@ -398,9 +439,10 @@ static hipError_t run_mel(const zafx_plan& pl, const float* x, float* out, int64
                      (!mfcc || (pl.dct.max_wave_steps <= kMelResidentDct && pl.dct.n_empty == 0 && pl.dct.desc_ok));
     auto kern = k_mel<LOG2N, LOG2E, ALIGNED, false, 0>;
     if constexpr (G::NT == 1024) {
-        if (res) kern = mfcc ? k_mel<LOG2N, LOG2E, ALIGNED, true, 2> : k_mel<LOG2N, LOG2E, ALIGNED, true, 1>;
+        if (res) kern = mfcc ? (pl.dct.direct_j > 0 ? k_mel<LOG2N, LOG2E, ALIGNED, true, 3> : k_mel<LOG2N, LOG2E, ALIGNED, true, 2>) : k_mel<LOG2N, LOG2E, ALIGNED, true, 1>;
     }
-    const int slots = pl.fb.n_items + (mfcc ? pl.fb.n_blocks + pl.dct.n_items : 0);
+    const int direct_j = (res && mfcc) ? pl.dct.direct_j : 0;   // (register-fed DCT: one partial tile per wave and 16-row block)
+    const int slots = pl.fb.n_items + (mfcc ? (direct_j > 0 ? pl.dct.n_blocks * (G::NT / 64) : pl.fb.n_blocks + pl.dct.n_items) : 0);
     if (slots > G::CAPACITY) {
         set_error("mel/mfcc: too many filterbank work items for the LDS slots at this window_length");
         return hipErrorInvalidValue;
@@ -417,7 +459,7 @@ static hipError_t run_mel(const zafx_plan& pl, const float* x, float* out, int64
     const long long grid = std::min<long long>(total, (long long)pl.n_cus * std::max(per_cu, 1));
     hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(G::NT), G::SMEM, pl.stream, x, pl.d_window, LOG2E == 5 ? pl.d_tw_r32 : pl.d_tw_pass, pl.d_tw_aux, pl.fb.d_pack,
                        pl.fb.d_items, pl.fb.d_wave_ptr, pl.fb.d_blk_ptr, pl.fb.d_desc, pl.fb.n_blocks, pl.fb.n_items, pl.fb.total_steps, mfcc ? pl.dct.total_steps : 0, pl.dct.d_pack, pl.dct.d_items,
-                       pl.dct.d_wave_ptr, pl.dct.d_blk_ptr, pl.dct.d_desc, pl.dct.n_blocks, out, (long long)n_samples, pl.H, T, (int)row_pitch(pl, T), tiles, (int)total,
+                       pl.dct.d_wave_ptr, pl.dct.d_blk_ptr, pl.dct.d_desc, pl.dct.d_direct, direct_j, pl.dct.n_blocks, out, (long long)n_samples, pl.H, T, (int)row_pitch(pl, T), tiles, (int)total,
                        pl.prm.n_filters, pl.prm.n_coefs, mfcc, pl.layout);
     return hipGetLastError();
 }

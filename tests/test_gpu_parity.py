@@ -130,6 +130,22 @@ def test_mdct_sizes(zafx, wl, n):
     assert np.max(np.abs(y[:k] - x[0, :k])) < 1e-5
 
 
+def test_imdct_batches_every_clip_and_tile_shape(zafx):
+    """The inverse of a BATCH, every clip compared: the output length (T-1) M - 1 is odd, so every second clip starts on a 4-byte
+    boundary (the sweep form of the overlap-add stores those as two 4-byte values); lengths that end on a full tile, a partial
+    tile, a single tile and a single frame pair; both layouts."""
+    w = zafx.kaiser_bessel_derived(2048)
+    for n in (1, 1024 * 31, 1024 * 32, 1024 * 33 + 5, 1024 * 64, 70001):
+        x = np.stack([synth_clip(61, c, n) for c in range(5)])
+        coefs = orc.mdct_batch(x.astype(np.float64), w)
+        for layout in ("FT", "TF"):
+            c_in = coefs if layout == "FT" else np.ascontiguousarray(coefs.transpose(0, 2, 1))
+            y = zafx.imdct_batch(c_in, w, layout=layout)
+            for c in range(5):
+                yref = orc.imdct(coefs[c], w)
+                assert y[c].shape == yref.shape and relerr(y[c], yref) <= TOL_FFT, (n, layout, c)
+
+
 # ------------------------------------------------------------------ BASELINE config clips (full clip size)
 @pytest.fixture(scope="module")
 def config_S():

@@ -460,8 +460,8 @@ def main():
         return cpu_pool_main(int(sys.argv[2]), float(sys.argv[3]))
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=100)
+    ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--kind", default="all", help="all = headline STFT + every other BASELINE config in one line; or one of "
                     "stft istft mdct imdct mel mfcc cqt stft1 istft1 stft64 dct")
     ap.add_argument("--no-cpu-baseline", action="store_true")

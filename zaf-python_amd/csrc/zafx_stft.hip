@@ -645,6 +645,57 @@ __device__ __forceinline__ void ola_phase_pairs(const OlaArgs& a, int tid, bool 
     }
 }
 
+// The same for hop = W/2 with NT a multiple of hop/2, full tile inside the clip: thread tid owns the sample pair r = tid mod hop/2
+// of the frames q0, q0 + QS, ... (QS = 2 NT / hop frames per pass of the workgroup), so its two LDS slots, the frame it starts
+// with and its output pointer are fixed: two 8-byte LDS reads, three adds, one scale and one 8-byte store per pass, unrolled
+// (ola_phase_pairs re-derives frame, offset and four predicates per pair: 5-7 k of the tile's 35 k cycles at W = 2048).  The
+// same additions in the same order: bit-identical.  Returns false when the tile is not of that kind.
+template <int W, int NT, int FPB>
+__device__ __forceinline__ bool ola_phase_sweep(const OlaArgs& a, int tid, bool y_aligned) {
+    constexpr int HOP2 = W / 4, QS = NT / HOP2, NIT = (NT % HOP2 == 0 && QS >= 1 && FPB % (QS > 0 ? QS : 1) == 0) ? FPB / (QS > 0 ? QS : 1) : 0;
+    if constexpr (NIT == 0 || HOP2 % 64 != 0) {
+        return false;
+    } else {
+        const bool full = a.write_out && a.make_carry && 2 * a.hop == W && a.n_valid == FPB && a.c_end == FPB * a.hop &&
+                          a.o_first + (long long)FPB * a.hop <= a.out_len;
+        if (!full) return false;
+        const float2* fr = reinterpret_cast<const float2*>(a.fl);
+        float2* carry2 = reinterpret_cast<float2*>(a.carry);
+        const int pitch = a.pitch2 / 2;
+        int to = tid;   // opaque: slots and pointers are recomputed per tile (carried through the transforms they would spill)
+        asm volatile("" : "+v"(to));
+        const int r = to % HOP2;
+        const int q0 = __builtin_amdgcn_readfirstlane(to / HOP2);   // (whole waves: HOP2 is a multiple of 64)
+        const float2* pv = fr + q0 * pitch + phys(r);                    // frame q, first half
+        const float2* pu = fr + (q0 - 1) * pitch + phys(r + HOP2);       // frame q - 1, second half
+        float* dst = a.yc + a.o_first + 2 * to;
+        const bool skip0 = a.o_first < 0 && q0 == 0;   // (the clip's first tile: its first W - hop samples are trimmed)
+#pragma unroll
+        for (int it = 0; it < NIT; ++it) {
+            float2 acc = make_float2(0.f, 0.f), u = make_float2(0.f, 0.f);
+            if (it == 0 && q0 == 0) acc = carry2[r];
+            else u = pu[(size_t)it * QS * pitch];
+            const float2 v = pv[(size_t)it * QS * pitch];
+            const float2 s = make_float2((acc.x + u.y) + v.y, (acc.y + u.x) + v.x);   // components are stored swapped
+            if (!(it == 0 && skip0)) {
+                float* d = dst + (size_t)it * 2 * NT;
+                if (y_aligned) {
+                    *reinterpret_cast<float2*>(d) = make_float2(s.x * a.scale, s.y * a.scale);
+                } else {
+                    d[0] = s.x * a.scale;
+                    d[1] = s.y * a.scale;
+                }
+            }
+        }
+        // carry: the second half of the tile's last frame (ola_phase_pairs: (0 + u.y) + 0, (0 + u.x) + 0)
+        if (q0 == 0) {
+            const float2 ul = fr[(FPB - 1) * pitch + phys(r + HOP2)];
+            carry2[r] = make_float2((0.f + ul.y) + 0.f, (0.f + ul.x) + 0.f);
+        }
+        return true;
+    }
+}
+
 ZAFX_PROF_ARRAY(g_prof)
 
 // ---------------------------------------------------------------------------------
@@ -664,7 +715,8 @@ ZAFX_PROF_ARRAY(g_prof)
 // 2x slower), so the tile's sweeps are streamed DEPTH at a time straight into the Hermitian fold
 // (round 1: prefetching 1-3 sweeps of the next tile across the FFT phase did not pay, the FFT needed
 // 116 of the 128 VGPRs; round 2, with the second exchange in registers: ONE sweep rides across the
-// transforms and the overlap-add, 1.945 -> 1.92 ms; two sweeps spill, 1.99 ms).  Barriers order LDS only (lds_barrier): the output stores of a tile are not
+// transforms and the overlap-add, 1.945 -> 1.92 ms; two sweeps spill, 1.99 ms; a second sweep requested
+// when the transforms are done spills as well, 1.82 -> 1.91 ms).  Barriers order LDS only (lds_barrier): the output stores of a tile are not
 // waited for.
 template <int LOG2N, int LOG2E, int DEPTH, bool ONE, int FV, bool TF = false>
 __global__ __launch_bounds__(1024) void k_istft_ft16(
@@ -917,10 +969,12 @@ __global__ __launch_bounds__(1024) void k_istft_ft16(
             a.o_first = (long long)t_first * hop - ncarry;
             a.out_len = out_len;
             a.scale = scale;
-            if (pairs)
-                ola_phase_pairs<W, NT, FPB>(a, tid, y_base_aligned && (clip * out_len) % 2 == 0);
-            else
+            const bool ya = y_base_aligned && (clip * out_len) % 2 == 0;
+            if (pairs) {
+                if (!ola_phase_sweep<W, NT, FPB>(a, tid, ya)) ola_phase_pairs<W, NT, FPB>(a, tid, ya);
+            } else {
                 ola_phase<W, NT, FPB>(a, tid);
+            }
         }
         PROF_MARK(5);
         lds_barrier();

@@ -498,11 +498,25 @@ def main():
     if rdzv is not None:
         # the path's only collective: RCCL broadcast of the shared constants from rank 0 over xGMI; the 128-byte id
         # of the communicator travels through the file rendezvous
+        # (librccl prints a banner -- ROCm version, hostname, library path -- through C stdio on stdout; it would leave the C
+        # buffer at exit, i.e. AFTER the JSON line.  File descriptor 1 points at stderr while the communicator is created and
+        # the C buffers are flushed before it comes back: stdout carries the one JSON line and nothing else.)
+        import ctypes
+        sys.stdout.flush()
+        saved_stdout = os.dup(1)
+        os.dup2(2, 1)
         try:
             uid = rdzv.broadcast(zafx.Comm.unique_id() if rank == 0 else b"")
             comm = zafx.Comm(device, rank, world, uid)
         except zafx.ZafxError as exc:
             sys.stderr.write(f"rank {rank}: no RCCL communicator ({exc}); constants stay per-rank\n")
+        finally:
+            try:
+                ctypes.CDLL(None).fflush(None)
+            except OSError:
+                pass
+            os.dup2(saved_stdout, 1)
+            os.close(saved_stdout)
 
     kinds = [args.kind] if args.kind != "all" else ["stft"] + ([] if args.no_configs else list(CONFIG_KINDS))
     with_cpu = world == 1 and not args.no_cpu_baseline

@@ -1,6 +1,7 @@
-"""Random geometries of every transform against the oracle (a check run by hand on the GPU box, not a test):  python tools/stress_random.py"""
+"""Random geometries of every transform against the oracle -- a check run by hand on the GPU box (pytest does not collect it):  python tests/stress_random.py"""
 import sys, os
-sys.path.insert(0, "zaf-python_amd"); sys.path.insert(0, ".")
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "zaf-python_amd")); sys.path.insert(0, ROOT)
 import numpy as np, zafx
 from oracle import zaf_oracle as orc
 rng = np.random.default_rng(12345)

@@ -282,7 +282,14 @@ static int finalize_constant(zafx_plan* pl, int which) {
                 ZAFX_HIP(upload(&pl->d_fb64_meta, meta.data(), meta.size() * sizeof(int)));
                 return 0;
             }
-            ZAFX_HIP(pack_band(pl->fb, pl->h_fb.data(), pl->prm.n_filters, pl->W / 2, mel_waves(pl->log2nf)));
+            {
+                // k_mel hands the filterbank 2 |X| (mel) or 4 |X|^2 (mfcc) -- the real split without its two halvings -- so the packed
+                // fragments carry the factor 1/2 or 1/4: powers of two, the products and sums come out bit for bit as before.
+                const float scale = pl->kind == ZAFX_MFCC ? 0.25f : 0.5f;
+                std::vector<float> scaled(pl->h_fb.size());
+                for (size_t i = 0; i < scaled.size(); ++i) scaled[i] = pl->h_fb[i] * scale;
+                ZAFX_HIP(pack_band(pl->fb, scaled.data(), pl->prm.n_filters, pl->W / 2, mel_waves(pl->log2nf)));
+            }
             return 0;
         case ZAFX_CONST_DCT:
             if (pl->prm.precision == ZAFX_PRECISION_F64) {

@@ -126,6 +126,26 @@ ZAFX_HD void split_pair(float2 zk, float2 zn, float2 tk, float2& xk, float2& xn)
     xn = make_float2(0.5f * b.x, -0.5f * b.y);
 }
 
+// The same pair when only |X[k]|^2 and |X[N-k]|^2 are wanted (k_mel): returns (4 |X[k]|^2, 4 |X[N-k]|^2).  a = E' - i U, b = E' + i U
+// with E' = 2 E, U = 2 t_k O are formed component-wise -- (a.x, b.x) and (a.y, b.y) -- so that both squares cost one packed
+// multiply and one packed fma: eight packed instructions for the pair instead of twelve (split_pair + two mul / fma pairs),
+// and the factor 4 is a power of two that the caller's filterbank absorbs exactly.
+ZAFX_HD float2 split_pair_pow4(float2 zk, float2 zn, float2 tk) {
+    const float2 e = cadd_conj(zk, zn), u = cmul(csub_conj(zk, zn), tk);
+#if defined(ZAFX_PK)
+    zafx_v2f px, py, m;
+    asm("v_pk_add_f32 %0, %3, %4 op_sel:[0,1] op_sel_hi:[0,1] neg_hi:[0,1]\n\t"     // (e.x + u.y, e.x - u.y) = (a.x, b.x)
+        "v_pk_add_f32 %1, %3, %4 op_sel:[1,0] op_sel_hi:[1,0] neg_lo:[0,1]\n\t"     // (e.y - u.x, e.y + u.x) = (a.y, b.y)
+        "v_pk_mul_f32 %2, %0, %0\n\t"
+        "v_pk_fma_f32 %2, %1, %1, %2"
+        : "=&v"(px), "=&v"(py), "=&v"(m) : "v"(to_v2(e)), "v"(to_v2(u)));
+    return to_f2(m);
+#else
+    const float ax = e.x + u.y, ay = e.y - u.x, bx = e.x - u.y, by = e.y + u.x;
+    return make_float2(ax * ax + ay * ay, bx * bx + by * by);
+#endif
+}
+
 // ---------------------------------------------------------------- pass schedule
 // log2 of the radix of the pass that starts with `rem` radix-2 stages left, when
 // a thread holds 2^log2e points.  Shared by host (table builder) and device.

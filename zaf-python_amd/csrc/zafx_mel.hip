@@ -307,15 +307,14 @@ __global__ __launch_bounds__(mel_threads(LOG2N, LOG2E)) void k_mel(
             for (int i = 0; i < E / 2; ++i) {
                 const int k = po + i * P;
                 const float2 za = LINEAR ? zk[i * STEP] : buf[phys_t<C::PS>(k)], zb = LINEAR ? zn[-i * STEP] : buf[phys_t<C::PS>(N - k)];
-                float2 xk, xn;
-                split_pair(za, zb, tws_l[k], xk, xn);   // (xn conjugated: only |.| is used)
+                float2 pw = split_pair_pow4(za, zb, tws_l[k]);   // (4 |X[k]|^2, 4 |X[N-k]|^2): the packed filterbank carries the 1/4 (1/2 for |X|)
                 if (i == 0 && k == 0) {
-                    xk = buf[phys_t<C::PS>(N / 2)];           // |X[N/2]| = |Z[N/2]|
-                    xn = make_float2(za.x - za.y, 0.f);       // X[N] (Nyquist, kept: zaf.py:370)
+                    const float2 zc = buf[phys_t<C::PS>(N / 2)];   // |X[N/2]| = |Z[N/2]|
+                    const float ny = za.x - za.y;                  // X[N] (Nyquist, kept: zaf.py:370)
+                    pw = make_float2(4.f * (zc.x * zc.x + zc.y * zc.y), 4.f * (ny * ny + 0.f * 0.f));
                 }
-                const float pk = xk.x * xk.x + xk.y * xk.y, pn = xn.x * xn.x + xn.y * xn.y;
-                mk[i] = mfcc ? pk : __builtin_amdgcn_sqrtf(pk);   // v_sqrt_f32, 1 ulp
-                mn[i] = mfcc ? pn : __builtin_amdgcn_sqrtf(pn);
+                mk[i] = mfcc ? pw.x : __builtin_amdgcn_sqrtf(pw.x);   // v_sqrt_f32, 1 ulp
+                mn[i] = mfcc ? pw.y : __builtin_amdgcn_sqrtf(pw.y);
             }
             frame_sync<P>();   // every Z read of this frame is done before S overwrites it
             float* sf = reinterpret_cast<float*>(buf);   // S[c], c = bin - 1, c = 0..N-1

@@ -328,23 +328,36 @@ __global__ __launch_bounds__(mel_threads(LOG2N, LOG2E)) void k_mel(
                 sn[-i * P] = mn[i];
             }
         }
-        PROF_MARK(1);
-        lds_barrier();
-        PROF_MARK(2);
+#ifndef ZAFX_MEL_EARLY
+#define ZAFX_MEL_EARLY 1
+#endif
         // opaque copy of the thread index for the filterbank phases: their per-lane addresses are tile-invariant, and hoisted
         // out of the persistent loop they ride through the FFT phase (with the prefetched samples: 128 VGPRs + 212 B of scratch)
         int to = tid;
         asm volatile("" : "+v"(to));
         const int lane = to & 63, bt = lane & 15, bk = lane >> 4;
-        bool fast = false;   // the next tile's frame: requested one load per K-step of the filterbank GEMM
-        if constexpr (LATE) fast = fetch_begin(tlv + gridDim.x, 0, PAIR16 ? row_pair_index(to % P) : to % P);
+        // The next tile's frame.  EARLY: requested by each wave as soon as ITS spectrum is written, ahead of the barrier -- the waves
+        // finish their transforms 6 k cycles apart (oldest first), so the sixteen bursts of eight loads arrive spread out and
+        // vector memory, idle through the transforms, works while the early waves wait at the barrier; the filterbank GEMM then
+        // runs without loads in between.  Otherwise: one load per K-step of the GEMM.
+        bool fast = false;
+        if constexpr (LATE) {
+            fast = fetch_begin(tlv + gridDim.x, 0, PAIR16 ? row_pair_index(to % P) : to % P);
+            if (ZAFX_MEL_EARLY && fast) {
+#pragma unroll
+                for (int i = 0; i < E; ++i) fetch_one(i);
+            }
+        }
         raw = fast;
+        PROF_MARK(1);
+        lds_barrier();
+        PROF_MARK(2);
 
         // ---- mel = FB . S on the matrix cores
         {
             const float* sb = fall + (size_t)bt * (2 * C::PITCH) + bk;
             if constexpr (RES)
-                gemm_resident(afb, sfb, nfb, lane, 0, slot_ptr, [&](int col) { return sb[col]; }, [&](int i) { if (LATE && i < E && fast) fetch_one(i); });
+                gemm_resident(afb, sfb, nfb, lane, 0, slot_ptr, [&](int col) { return sb[col]; }, [&](int i) { if (LATE && !ZAFX_MEL_EARLY && i < E && fast) fetch_one(i); });
             else gemm_items(fb_pack, fb_items, fb_wave_ptr, wave, lane, 0, slot_ptr, [&](int col) { return sb[col]; });
         }
         PROF_MARK(3);

@@ -270,13 +270,20 @@ __global__ __launch_bounds__(kFatWaves * 64) void k_stft_ft16(
             }
             fft_frame<LOG2N, LOG2E>(v, frames + (wave * FPW + f) * PITCH, po, tw_l);
         }
+#ifndef ZAFX_STFT_EARLY
+#define ZAFX_STFT_EARLY 1
+#endif
+        // The next tile is requested by each wave as soon as ITS frames are transformed, ahead of the barrier (EARLY): the waves
+        // finish a few thousand cycles apart, so their bursts of requests arrive spread out while the early waves would only wait,
+        // and the store phase starts right behind the barrier -- requested behind the barrier, the 32 loads of a lane blocked at
+        // the CU's vector-memory queue for 5-11 k cycles before the wave's first store.
+        // (The two frames of a wave are adjacent and overlap by W - hop samples: requested together, the shared half is served by
+        // the vector cache; requested half a store phase apart it was fetched from HBM twice.)
+        if (ZAFX_STFT_EARLY) prefetch(tlv + gridDim.x);
         PROF_MARK(1);
         lds_barrier();
         PROF_MARK(2);
-        // The two frames of a wave are adjacent and overlap by W - hop samples: requested together, the
-        // shared half is served by the vector cache (requested half a store phase apart it was fetched
-        // from HBM twice: FETCH_SIZE 2.88 GB instead of 1.93 GB per launch, same time).
-        prefetch(tlv + gridDim.x);   // in flight while this tile is stored
+        if (!ZAFX_STFT_EARLY) prefetch(tlv + gridDim.x);   // in flight while this tile is stored
         PROF_MARK(3);
         if (t0 + tt < T) {
             float2* o = spec_base<SPEC>(out, (long long)clip * ROWS * TP + (t0 + tt));

@@ -230,13 +230,23 @@ __global__ __launch_bounds__(fft_threads(LOG2N, LOG2E)) void k_cqt(
             regs_read<10, 4>(v, sub, lane);
             frame_sync<64>();
             fft_frame_chain<10, 4>(v, sub, lane, TwoLevelTw{sub_hi, sub_hi + 8});
-            lds_barrier();
         } else {
             fft_frame_chain<LOG2N, LOG2E>(v, buf, p, tw2l);
         }
-        PROF_MARK(1);
         const bool more = g + n_slots < n_work;
         bool raw = false;
+#ifndef ZAFX_CQT_EARLY
+#define ZAFX_CQT_EARLY 1
+#endif
+        // EARLY (split form): every wave requests the next frame as soon as ITS sub-transform is done (v is dead from here to the
+        // next first pass), ahead of the barrier: the waves finish a few thousand cycles apart, the requests arrive spread out and
+        // fly under the split and the contraction of all sixteen waves.
+        constexpr bool EARLY = ZAFX_CQT_EARLY && G::SPLIT;
+        if constexpr (EARLY) {
+            if (more) raw = load_frame(g + n_slots, p);
+        }
+        if constexpr (G::SPLIT) lds_barrier();
+        PROF_MARK(1);
         // ---- real split in place, only for the pairs (k, N-k) that the kernel's columns touch:
         // slots 0..N-1 <- X[0..N-1], slot NYQ <- X[N];  t_k = exp(-2 pi i k / 2N) = sp_hi[k >> 7] sp_lo[k & 127]
         if (k_special && p == 0) {
@@ -263,7 +273,7 @@ __global__ __launch_bounds__(fft_threads(LOG2N, LOG2E)) void k_cqt(
 #define ZAFX_CQT_LOADS_FIRST 8
 #endif
         const bool loads_first = wave < ZAFX_CQT_LOADS_FIRST * (P / 64) / 16;
-        if (more && loads_first) raw = load_frame(g + n_slots, p);
+        if (!EARLY && more && loads_first) raw = load_frame(g + n_slots, p);
         PROF_MARK(7);
         // ---- CSR mat-vec against the spectrum + |.|^2 (zaf.py:630-632).  Entry (iteration, lane) of the wave's share is a
         // value and a word: bits 0-17 the LDS byte address of its spectrum bin, bit 31 "conjugate" (a column of the upper
@@ -334,7 +344,7 @@ __global__ __launch_bounds__(fft_threads(LOG2N, LOG2E)) void k_cqt(
                 }
             }
         }
-        if (more && !loads_first) raw = load_frame(g + n_slots, p);
+        if (!EARLY && more && !loads_first) raw = load_frame(g + n_slots, p);
         PROF_MARK(4);
         if (more) {   // (waits for the prefetched samples; the other waves are still contracting)
             if (raw) unpack_pairs(p);

@@ -576,7 +576,8 @@ __device__ __forceinline__ void pass1_write(const float2* v, float2* buf, int la
 // writes of pass 1 would meet two by two in the banks (SQ_LDS_BANK_CONFLICT 0.07 -> 0.17 of the active cycles in k_mel); the first
 // exchange of this form therefore pads one slot every 32 points instead of every 16: slot 16 p1 + (p1 >> 1) + r, read back by
 // lane (lh, ll) at 16 lh + (lh >> 1) + ll + 66 i (position lane + 64 i = 16 (lh + 4 i) + ll) -- conflict free both ways.
-template <bool ODDROT = false, bool PAIR = false, class TW>
+// PREDFT (pair form): the radix-16 butterflies of pass 1 have been run on v already (k_mel does them ahead of the barrier that frees the frame).
+template <bool ODDROT = false, bool PAIR = false, bool PREDFT = false, class TW>
 __device__ __forceinline__ void fft1024_wave(float2* v, float2* buf, int lane, const TW& tw, int p1 = 0) {
     if constexpr (ODDROT) {
         Dft<16>::run(v);
@@ -587,7 +588,7 @@ __device__ __forceinline__ void fft1024_wave(float2* v, float2* buf, int lane, c
         frame_sync<64>();
         regs_read<10, 4>(v, buf, lane);
     } else if constexpr (PAIR) {
-        Dft<16>::run(v);
+        if constexpr (!PREDFT) Dft<16>::run(v);
         const int pb = 16 * p1 + (p1 >> 1);
 #pragma unroll
         for (int r = 0; r < 16; ++r) buf[pb + r] = v[r];

@@ -231,7 +231,22 @@ __global__ __launch_bounds__(mel_threads(LOG2N, LOG2E)) void k_mel(
             for (int i = 0; i < E; ++i) fetch_one(i);
         }
     };
+#ifndef ZAFX_MEL_PREPASS
+#define ZAFX_MEL_PREPASS 1
+#endif
     bool raw = false;   // PAIR16: xr holds raw 16-byte loads (an interior frame) that unpack_pairs() must sort out
+    bool pre_done = false;   // PAIR16: xr already holds the windowed frame after the butterflies of pass 1
+    auto pre_transform = [&](int po) {   // po: lane index (an opaque copy)
+        if constexpr (PAIR16) {
+            if (raw) unpack_pairs();
+#pragma unroll
+            for (int i = 0; i < E; ++i) {
+                const float2 wv = win_l[po + i * P];   // (pair form: the table is in lane order)
+                xr[i] = make_float2(xr[i].x * wv.x, xr[i].y * wv.y);
+            }
+            Dft<16>::run(xr);
+        }
+    };
     if constexpr (PREFETCH || LATE) {
         raw = fetch_begin(blockIdx.x, 0, PAIR16 ? row_pair_index(p) : p);
         if (raw) {
@@ -282,18 +297,21 @@ __global__ __launch_bounds__(mel_threads(LOG2N, LOG2E)) void k_mel(
             if constexpr (!PREFETCH && !LATE) fetch(tlv, f0, po);   // 16 thin waves, streamed filterbank: request, wait, transform
             float2 v[E];
             if constexpr (PAIR16) {
-                if (raw) unpack_pairs();
-            }
+                if (!pre_done) pre_transform(po);   // (the first tile: later ones did this ahead of the previous tile's last barrier)
+#pragma unroll
+                for (int i = 0; i < E; ++i) v[i] = xr[i];
+            } else {
 #pragma unroll
             for (int i = 0; i < E; ++i) {
-                const float2 wv = win_l[po + i * P];   // (pair form: the table is in lane order)
+                const float2 wv = win_l[po + i * P];
                 v[i] = make_float2(xr[i].x * wv.x, xr[i].y * wv.y);
+            }
             }
             if constexpr (PREFETCH) {
                 if (f0 + NSLOT < FPB) fetch(tlv, f0 + NSLOT, po);
                 else fetch(tlv + gridDim.x, 0, po);
             }
-            if constexpr (PAIR16) fft1024_wave<false, true>(v, buf, po, (const float2*)tw_l, row_pair_index(po));
+            if constexpr (PAIR16) fft1024_wave<false, true, true>(v, buf, po, (const float2*)tw_l, row_pair_index(po));
             else fft_frame<LOG2N, LOG2E>(v, buf, po, tw_l);
             // real split of the (k, N-k) pairs this thread owns (k = po + i P), kept in registers.  Only lane 0 holds a pair
             // without a partner (i = 0: bins N/2 and N); P is a whole number of padding periods, so the slots of
@@ -436,6 +454,16 @@ __global__ __launch_bounds__(mel_threads(LOG2N, LOG2E)) void k_mel(
             }
         }
         PROF_MARK(5);
+        if constexpr (PAIR16) {
+            // window and first radix-16 butterflies of the next tile's frame, in registers, AHEAD of the barrier that frees the frame
+            // buffers: only the writes of pass 1 have to wait for the other waves' reductions
+            pre_done = ZAFX_MEL_PREPASS && tlv + gridDim.x < total_tiles;
+            if (pre_done) {
+                int pq = p;
+                asm volatile("" : "+v"(pq));
+                pre_transform(pq);
+            }
+        }
         lds_barrier();   // slots and S are dead: the next tile may overwrite the frame buffers
     }
 }

@@ -28,7 +28,7 @@ for k in ["stft", "istft", "mdct", "imdct", "mel", "mfcc", "cqt", "dct"]:
     ratio[k] = p["hbm_bytes_per_launch"] / ld(k)["roofline"]["algorithmic_bytes_per_launch"]
 tbl = f"""| kernel (config) | ms / launch r1 → r2 | Msamples/s | roofline |
 |---|---|---|---|
-| `k_stft_ft16` (config 2: 1024 × 10 s, reference layout) | 1.81–1.91 → {a['ms_per_step']:.2f} (1.62–1.75 over the boxes seen) | {a['value']:.0f} | {a['roofline']['achieved']:.0f} GB/s algorithmic = {a['roofline']['frac']:.3f} of 8 TB/s ({a['roofline']['frac_of_achievable_6290']:.2f} of the 6.29 TB/s achievable; round 1's zero-compute kernel with this read / write pattern, timed over 20 launches: 1.68 ms) |
+| `k_stft_ft16` (config 2: 1024 × 10 s, reference layout) | 1.81–1.91 → {a['ms_per_step']:.2f} (1.50–1.70 over the boxes seen since the early request, 1.62–1.75 before) | {a['value']:.0f} | {a['roofline']['achieved']:.0f} GB/s algorithmic = {a['roofline']['frac']:.3f} of 8 TB/s ({a['roofline']['frac_of_achievable_6290']:.2f} of the 6.29 TB/s achievable; round 1's zero-compute kernel with this read / write pattern, timed over 20 launches: 1.68 ms) |
 | `k_mel` (config 3) | 1.47–1.49 → {c['mel']['ms_per_step']:.2f} | {c['mel']['value']:.0f} | {c['mel']['roofline']['achieved']:.1f} TF (FFT 49.8 + issued MFMA 15.3 GFLOP) = {c['mel']['roofline']['frac']:.2f} of 157.3; HBM {c['mel']['roofline']['hbm']['frac']:.2f} |
 | `k_mel`, mfcc (config 3) | 1.62–1.63 → {c['mfcc']['ms_per_step']:.2f} | {c['mfcc']['value']:.0f} | {c['mfcc']['roofline']['achieved']:.1f} TF = {c['mfcc']['roofline']['frac']:.2f}; HBM {c['mfcc']['roofline']['hbm']['frac']:.2f} |
 | `k_mdct_ft32` (config 4) | 1.00–1.05 → {c['mdct']['ms_per_step']:.2f} | {c['mdct']['value']:.0f} | {c['mdct']['roofline']['achieved']:.0f} GB/s = {c['mdct']['roofline']['frac']:.3f} |
@@ -44,7 +44,7 @@ usable cores ({ca['cores']} processes, BLAS threads 1): {ca['value']:.1f} Msampl
 {c['mdct']['cpu_baseline']['value']:.1f}, imdct {c['imdct']['cpu_baseline']['value']:.1f}, cqt {c['cqt']['cpu_baseline']['value']:.2f} Msamples/s on one core).  End to end over PCIe with page-locked buffers both ways: {e2e['value']:.0f} Msamples/s (128 clips,
 H2D 57 GB/s, D2H 57 GB/s, serial on one stream) — two orders of magnitude below the device-resident figure, and never reported as `value`.
 `bench.py` times 100 steps after 20 warm-up steps by default: with 20 / 3 the ~1 ms kernels were measured inside the clock ramp (K = 2 … 400
-back-to-back launches of the MDCT: 0.81 / 0.87 / 0.85 / 0.80 / 0.78 ms per launch, `tools/b2b_test.py`); boxes differ by up to 7 % (the same STFT binary: 1.62–1.75 ms).
+back-to-back launches of the MDCT: 0.81 / 0.87 / 0.85 / 0.80 / 0.78 ms per launch, `tools/b2b_test.py`); boxes differ by up to 10 % (the same binaries: stft 1.50–1.70 ms, mel 0.94–1.03 ms).
 Counter evidence (`profiles/r02_pmc_summary.csv`, `r02_sq_summary.csv`): fabric traffic / algorithmic bytes stft {ratio['stft']:.2f}, istft {ratio['istft']:.2f}, mdct {ratio['mdct']:.2f},
 imdct {ratio['imdct']:.2f} (rows 1728 B apart: every second 128-B run straddles two lines), mel {ratio['mel']:.2f}, mfcc {ratio['mfcc']:.2f}, **cqt {ratio['cqt']:.2f} (round 1: 8.3)**, dct {ratio['dct']:.1f};
 MFMA utilisation (busy cycles / kernel cycles / SIMDs) k_mel {100 * sq.get(('mel', 'mfma_util'), 0):.1f} %, mfcc {100 * sq.get(('mfcc', 'mfma_util'), 0):.1f} %, k_linear128 {100 * sq.get(('dct', 'mfma_util'), 0):.1f} %; LDS bank conflicts / active cycles

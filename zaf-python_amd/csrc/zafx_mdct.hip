@@ -396,8 +396,10 @@ __global__ __launch_bounds__(NSLOT * fft_threads(LOG2NF, LOG2E)) void k_imdct(
     const int fs4 = (tid % LPR) * 4, mq4 = tid / LPR;
     float4 pre_re[KI], pre_im[KI];
     bool pre_ok = false;
+    bool converted = false;   // pre_re / pre_im hold the pre-twiddled FFT inputs (convert_rows), not the raw rows
     auto gather4 = [&](int unit_n, int tile_n, int part = 2) {   // rows of my 4 frames of tile_n of unit_n -> registers (part 0: the rows 2m, 1: the rows M-1-2m, 2: both)
         pre_ok = false;
+        converted = false;
         if (!vec4 || unit_n >= total_units) return;
         const int tile_a_n = (unit_n % segs) * seg_tiles;
         const int first_needed_n = tile_n < tile_a_n ? FPB - 1 : 0;
@@ -412,6 +414,27 @@ __global__ __launch_bounds__(NSLOT * fft_threads(LOG2NF, LOG2E)) void k_imdct(
                 if (part != 0) pre_im[i] = *reinterpret_cast<const float4*>(cp + (long long)(M - 1 - 2 * m) * TP);
             }
         }
+    };
+#ifndef ZAFX_IMDCT_CONVERT_EARLY
+#define ZAFX_IMDCT_CONVERT_EARLY 1
+#endif
+    // The requested rows are turned into the packed, pre-twiddled FFT inputs (same registers: pre_re[i] = (c0, c1), pre_im[i] =
+    // (c2, c3) of the lane's four frames) at the START of the overlap-add, i.e. before this tile's stores are issued: the wait for
+    // the rows is then a wait for loads only.  Consumed in the next phase A -- behind the stores -- it was a wait for every store
+    // to be acknowledged (the compiler cannot count the stores in between, profiles/r02_notes.md): 0.4-4.5 k cycles per tile.
+    auto convert_rows = [&]() {
+        if (!pre_ok || converted) return;
+#pragma unroll
+        for (int i = 0; i < KI; ++i) {
+            const int m = mq4 + i * MSTEP;
+            const float4 re = pre_re[i], im = pre_im[i];
+            const float2 g = tw8[m];
+            const float2 c0 = cmul(make_float2(re.x, im.x), g), c1 = cmul(make_float2(re.y, im.y), g);
+            const float2 c2 = cmul(make_float2(re.z, im.z), g), c3 = cmul(make_float2(re.w, im.w), g);
+            pre_re[i] = make_float4(c0.x, c0.y, c1.x, c1.y);
+            pre_im[i] = make_float4(c2.x, c2.y, c3.x, c3.y);
+        }
+        converted = true;
     };
     auto first_tile = [&](int unit_n) {
         const int ta = (unit_n % segs) * seg_tiles;
@@ -489,16 +512,15 @@ __global__ __launch_bounds__(NSLOT * fft_threads(LOG2NF, LOG2E)) void k_imdct(
     } else if (vec4) {
         if constexpr (!PRE) gather4(unit, tile);
         if (pre_ok) {
+            convert_rows();   // (already done at the start of the previous overlap-add, except for the first tile of the launch)
             float2* fb = frames + fs4 * C::PITCH;
 #pragma unroll
             for (int i = 0; i < KI; ++i) {
                 const int m = mq4 + i * MSTEP;
-                const float4 re = pre_re[i], im = pre_im[i];
-                const float2 g = tw8[m];
-                fb[phys(m)] = cmul(make_float2(re.x, im.x), g);
-                fb[C::PITCH + phys(m)] = cmul(make_float2(re.y, im.y), g);
-                fb[2 * C::PITCH + phys(m)] = cmul(make_float2(re.z, im.z), g);
-                fb[3 * C::PITCH + phys(m)] = cmul(make_float2(re.w, im.w), g);
+                fb[phys(m)] = make_float2(pre_re[i].x, pre_re[i].y);
+                fb[C::PITCH + phys(m)] = make_float2(pre_re[i].z, pre_re[i].w);
+                fb[2 * C::PITCH + phys(m)] = make_float2(pre_im[i].x, pre_im[i].y);
+                fb[3 * C::PITCH + phys(m)] = make_float2(pre_im[i].z, pre_im[i].w);
             }
         }
     } else {
@@ -576,6 +598,7 @@ __global__ __launch_bounds__(NSLOT * fft_threads(LOG2NF, LOG2E)) void k_imdct(
     PROF_MARK(3);
     lds_barrier();
     PROF_MARK(4);
+    if constexpr (PRE && ZAFX_IMDCT_CONVERT_EARLY) convert_rows();
 
     // ---- phase C: unfold + window + TDAC overlap-add of the 2 covering frames (older first, as the
     //      reference's loop), trim (zaf.py:1166-1182); then the carry for the next tile

@@ -385,36 +385,11 @@ __global__ __launch_bounds__(mel_threads(LOG2N, LOG2E)) void k_mel(
         // (a block = four whole waves; with NT a multiple of 256 a wave's blocks are wave / 4 + (NT / 256) j: scalar and the same
         // for every tile, so the ranges of their parts are loaded into SGPRs once, ahead of the tile loop)
         float lm[2] = {0.f, 0.f};   // (DIRECT) log-mel values of this thread: element of the B fragment of the DCT's K-steps wave, wave + 16
-#ifndef ZAFX_MEL_REDUCE_REV
-#define ZAFX_MEL_REDUCE_REV 0
-#endif
-#ifndef ZAFX_MEL_REDUCE_BATCH
-#define ZAFX_MEL_REDUCE_BATCH 0
-#endif
-        constexpr bool REV = ZAFX_MEL_REDUCE_REV && MF == 1 && NT == 1024;   // the blocks with the most parts (the widest filters) to the oldest waves
-        const int wq = REV ? 3 - (wave >> 2) : (wave >> 2);
-        for (int j = 0; (NT % 256 == 0) ? j * (NT / 256) + wq < fb_blocks : j * NT + to < fb_blocks * 256; ++j) {
+        for (int j = 0; (NT % 256 == 0) ? j * (NT / 256) + (wave >> 2) < fb_blocks : j * NT + to < fb_blocks * 256; ++j) {
             const int idx = to + j * NT;
-            const int blk = (NT % 256 == 0) ? j * (NT / 256) + wq : __builtin_amdgcn_readfirstlane(idx >> 8), e = idx & 255;
+            const int blk = (NT % 256 == 0) ? j * (NT / 256) + (wave >> 2) : __builtin_amdgcn_readfirstlane(idx >> 8), e = idx & 255;
             float val = 0.f;
-            int it = fb_blk_ptr[blk];
-            const int it1 = fb_blk_ptr[blk + 1];
-            if constexpr (ZAFX_MEL_REDUCE_BATCH) {
-                for (; it + 4 <= it1; it += 4) {   // four parts requested together, added in the same order
-                    const float a0 = slot_ptr(it)[e], a1 = slot_ptr(it + 1)[e], a2 = slot_ptr(it + 2)[e], a3 = slot_ptr(it + 3)[e];
-                    val += a0;
-                    val += a1;
-                    val += a2;
-                    val += a3;
-                }
-                if (it + 2 <= it1) {
-                    const float a0 = slot_ptr(it)[e], a1 = slot_ptr(it + 1)[e];
-                    val += a0;
-                    val += a1;
-                    it += 2;
-                }
-            }
-            for (; it < it1; ++it) val += slot_ptr(it)[e];
+            for (int it = fb_blk_ptr[blk]; it < fb_blk_ptr[blk + 1]; ++it) val += slot_ptr(it)[e];
             const int m = 16 * blk + (e >> 4), tq = e & 15;
             if (mfcc) {
                 const float l = m < n_filters ? logf(val + eps) : 0.f;

@@ -1,14 +1,18 @@
-"""Random geometries of every transform against the oracle -- a check run by hand on the GPU box (pytest does not collect it):  python tests/stress_random.py"""
+"""Random geometries of every transform against the oracle -- a check run by hand on the GPU box (pytest does not collect it):  python tests/stress_random.py [seed [iterations]]"""
 import sys, os
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "zaf-python_amd")); sys.path.insert(0, ROOT)
 import numpy as np, zafx
 from oracle import zaf_oracle as orc
-rng = np.random.default_rng(12345)
+seed = int(sys.argv[1]) if len(sys.argv) > 1 else 12345
+iters = int(sys.argv[2]) if len(sys.argv) > 2 else 70
+rng = np.random.default_rng(seed)
 def relerr(a, b): return float(np.max(np.abs(a - b)) / max(np.max(np.abs(b)), 1e-30)) if a.size else float(a.shape != b.shape)
 bad = 0
-for it in range(70):
-    wl = int(2 ** rng.integers(7, 12))            # 128..2048
+for it in range(iters):
+    wl = int(2 ** rng.integers(7, 14))            # 128..8192
+    if rng.integers(0, 4) == 0:
+        wl = 2 * int(rng.integers(20, 1500))      # even, not a power of two (Bluestein forms); mdct needs an even window
     hop = int(rng.choice([wl // 2, wl // 4, wl // 2 + 2 * int(rng.integers(0, 20)), int(rng.integers(1, wl))]))
     n = int(rng.integers(1, 90000))
     nb = int(rng.integers(1, 7))
@@ -30,7 +34,7 @@ for it in range(70):
         yi = zafx.imdct_batch(m, ws)
         e4 = relerr(yi[c], orc.imdct(mref, ws))
         e5 = 0.0
-        if wl >= 256:
+        if wl >= 256 and wl <= 2048 and (wl & (wl - 1)) == 0:
             fb = zafx.melfilterbank(44100, wl, int(rng.choice([40, 64, 128])))
             mm = zafx.mfcc_batch(x, w, hop, fb, 13) if hasattr(zafx, "mfcc_batch") else None
             if mm is not None:
@@ -42,4 +46,4 @@ for it in range(70):
     except Exception as exc:
         bad += 1
         print("EXC", wl, hop, n, nb, repr(exc)[:200])
-print("done, failures:", bad)
+print("seed", seed, "iterations", iters, "done, failures:", bad)

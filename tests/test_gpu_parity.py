@@ -1037,6 +1037,28 @@ def test_cqt_long_kernel(zafx):
     assert one.dtype == np.float64 and relerr(one, orc.cqtspectrogram(x[0].astype(np.float64), fs, tr, ck)) <= TOL_FB
 
 
+@pytest.mark.parametrize("fs,res,fmin,fmax,tr", [(16000, 2, 220.0, 7040.0, 100),   # fft_length 256
+                                                (8000, 3, 440.0, 3520.0, 100),     # 128
+                                                (16000, 2, 220.0, 440.0, 200)])    # 256, two bins
+def test_cqt_short_kernel(zafx, fs, res, fmin, fmax, tr):
+    """Few bins per octave over a high minimum frequency give an fft_length below the 512 samples of the shortest device frame
+    (zaf.py:505-509); the host rewrites the kernel for 512-sample frames (core._cqt_embed) -- same numbers as the reference."""
+    ck = zafx.cqtkernel(fs, res, fmin, fmax)
+    assert ck.shape[1] < 512
+    x = np.stack([synth_clip(67, c, 20001) for c in range(3)])
+    got = zafx.cqtspectrogram_batch(x, fs, tr, ck)
+    got_tf = zafx.cqtspectrogram_batch(x, fs, tr, ck, layout="TF")
+    got64 = zafx.cqtspectrogram_batch(x.astype(np.float64), fs, tr, ck, f64=True)
+    chroma = zafx.cqtchromagram_batch(x, fs, tr, res, ck)
+    for c in range(3):
+        ref = orc.cqtspectrogram(x[c].astype(np.float64), fs, tr, ck)
+        assert got[c].shape == ref.shape
+        assert relerr(got[c], ref) <= TOL_FB and relerr(got_tf[c].T, ref) <= TOL_FB and relerr(got64[c], ref) <= 1e-12
+        assert relerr(chroma[c], orc.cqtchromagram(x[c].astype(np.float64), fs, tr, res, ck)) <= TOL_FB
+    with pytest.raises(ValueError):   # step above fft_length: the reference's padding is negative there (np.pad raises)
+        zafx.cqtspectrogram_batch(x, fs, fs // (ck.shape[1] + 64), ck)
+
+
 @pytest.mark.parametrize("wl,hop,nmel", [(4096, 2048, 128), (8192, 2048, 64), (2048, 1024, 300)])
 def test_mel_long_window_or_wide_bank(zafx, wl, hop, nmel):
     """Windows above 2048 and filterbanks above 256 rows are outside the fused float32 kernel; the host layer runs them

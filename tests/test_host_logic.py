@@ -202,3 +202,22 @@ def test_window_length_routing_rules():
     for n in (999, 2):                                           # MDCT: even and >= 4, checked before the device
         with pytest.raises(ValueError):
             zafx.mdct_plan(np.ones(n))
+
+
+def test_cqt_short_kernel_embedding():
+    """core._cqt_embed: a kernel with fft_length below 512, rewritten for 512-sample frames, gives the numbers of the original
+    (zaf.py:603-632) -- checked with the oracle's cqtspectrogram on both, no device involved."""
+    from oracle import zaf_oracle as orc
+    from zafx import core
+    rng = np.random.default_rng(5)
+    cases = [(orc.cqtkernel(16000, 2, 220.0, 7040.0), 16000, 100), (orc.cqtkernel(8000, 3, 440.0, 3520.0), 8000, 100),
+             (scipy.sparse.csr_matrix(rng.standard_normal((7, 300)) + 1j * rng.standard_normal((7, 300))), 4040, 40)]   # any length
+    for kern, fs, tr in cases:
+        assert kern.shape[1] < 512
+        big = core._cqt_embed(kern, round(fs / tr))
+        assert big.shape == (kern.shape[0], 512)
+        for n in (1, 37, 5000, 5001):
+            x = rng.standard_normal(n)
+            ref, got = orc.cqtspectrogram(x, fs, tr, kern), orc.cqtspectrogram(x, fs, tr, big)
+            assert got.shape == ref.shape
+            assert ref.size == 0 or relerr(got, ref) <= 1e-13

@@ -606,6 +606,25 @@ def _cqt_f32_max_bins(fft_length):
     return n.value
 
 
+_CQT_MIN_FFT = 512   # shortest frame of the device kernels
+
+
+def _cqt_embed(cqt_kernel, step, target=_CQT_MIN_FFT):
+    """A kernel whose fft_length L is below the device kernels' minimum, rewritten for frames of `target` samples.
+
+    K . fft(frame) = G . frame with G = fft(K, axis=1) (the kernel's rows in the time domain, zaf.py:630-632), so the same
+    numbers come out of K' . fft(frame') for the longer frame' when G' holds G at the offset d by which the longer frame
+    starts earlier (left padding ceil((L - step) / 2) -> ceil((target - step) / 2), zaf.py:612-620) and zeros elsewhere,
+    and K' = ifft(G', axis=1).  K' is dense (target columns per row): small, since L < target."""
+    import scipy.sparse
+    k = np.asarray(cqt_kernel.toarray(), dtype=np.complex128)
+    length = k.shape[1]
+    d = -((step - target) // 2) - -((step - length) // 2)   # ceil((target - step) / 2) - ceil((L - step) / 2)
+    g = np.zeros((k.shape[0], target), np.complex128)
+    g[:, d:d + length] = np.fft.fft(k, axis=1)
+    return scipy.sparse.csr_matrix(np.fft.ifft(g, axis=1))
+
+
 def cqt_plan(sampling_frequency, time_resolution, cqt_kernel, octave_resolution=None, layout="FT", device=0, row_align=0, f64=False):
     if not hasattr(cqt_kernel, "tocsr"):
         raise ValueError("cqt_kernel must be a scipy.sparse matrix (as returned by cqtkernel)")
@@ -613,8 +632,14 @@ def cqt_plan(sampling_frequency, time_resolution, cqt_kernel, octave_resolution=
     step = round(sampling_frequency / time_resolution)   # zaf.py:603 (banker's rounding)
     if step < 1:
         raise ValueError("time_resolution too high for this sampling_frequency")
-    if fft_length < 512 or fft_length > 131072 or fft_length & (fft_length - 1):
-        raise ValueError(f"zafx CQT kernels need a power-of-two fft_length in [512, 131072], got {fft_length}")
+    if step > fft_length:   # (the reference's right padding floor((fft_length - step) / 2) is negative there: np.pad raises, zaf.py:612-620)
+        raise ValueError("step (sampling_frequency / time_resolution) exceeds the kernel's fft_length")
+    if 2 <= fft_length < _CQT_MIN_FFT:
+        # (a short kernel -- few bins per octave, high minimum frequency -- of any length, power of two or not)
+        cqt_kernel = _cqt_embed(cqt_kernel, step)
+        fft_length = _CQT_MIN_FFT
+    if fft_length < _CQT_MIN_FFT or fft_length > 131072 or fft_length & (fft_length - 1):
+        raise ValueError(f"zafx CQT kernels need a power-of-two fft_length in [512, 131072] (or any length below 512), got {fft_length}")
     # a frame above 32768 samples does not fit LDS as float32 pairs: those kernels run on the float64 kernel, which
     # decimates the frame (lower minimum frequencies: 27.5 Hz at 44.1 kHz gives 65536); so do kernels with more rows than
     # fit beside the frame (k_cqt keeps the whole frame + one output column of the kernel's rows in the 160 KB of LDS:

@@ -29,6 +29,15 @@ def rank_env():
             int(os.environ.get("WORLD_SIZE", "1")))
 
 
+def _start_time(pid):
+    """Start time of a process in clock ticks since boot (field 22 of /proc/<pid>/stat); 0 where /proc is not there."""
+    try:
+        with open(f"/proc/{pid}/stat", "rb") as f:
+            return int(f.read().rsplit(b")", 1)[1].split()[19])
+    except (OSError, ValueError, IndexError):
+        return 0
+
+
 class Rendezvous:
     """Key/value exchange, barrier and MAX-reduce between the ranks of one node through a shared directory.
 
@@ -49,7 +58,8 @@ class Rendezvous:
         d = os.environ.get("ZAFX_RDZV_DIR")
         if not d:
             # all ranks of a node are children of one launcher process: its pid + the rendezvous port name the job
-            key = f"{os.environ.get('MASTER_PORT', '0')}_{os.environ.get('TORCHELASTIC_RUN_ID', 'none')}_{os.getppid()}"
+            # (+ the launcher's start time: a pid can come round again on a fresh box, and a job that died leaves its files behind)
+            key = f"{os.environ.get('MASTER_PORT', '0')}_{os.environ.get('TORCHELASTIC_RUN_ID', 'none')}_{os.getppid()}_{_start_time(os.getppid())}"
             base = "/dev/shm" if os.path.isdir("/dev/shm") and os.access("/dev/shm", os.W_OK) else tempfile.gettempdir()
             d = os.path.join(base, f"zafx_rdzv_{os.getuid()}_{key}")
         return cls(d, rank, world, timeout)

@@ -509,7 +509,8 @@ int mel_waves(int log2n) { return mel_threads(log2n, mel_log2e(log2n)) / 64; }
 
 template <int LOG2N>
 static hipError_t run_mel_any(const zafx_plan& pl, const float* x, float* out, int64_t n_clips, int64_t n_samples, int T) {
-    const bool aligned = (n_samples % 2 == 0) && (pl.H % 2 == 0) && (reinterpret_cast<uintptr_t>(x) % 8 == 0);
+    // (the aligned form addresses a clip through one buffer descriptor with 32-bit byte offsets: clips below 2^29 samples)
+    const bool aligned = (n_samples % 2 == 0) && (pl.H % 2 == 0) && (reinterpret_cast<uintptr_t>(x) % 8 == 0) && n_samples < (1LL << 29);
     return aligned ? run_mel<LOG2N, true>(pl, x, out, n_clips, n_samples, T) : run_mel<LOG2N, false>(pl, x, out, n_clips, n_samples, T);
 }
 

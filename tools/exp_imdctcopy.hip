@@ -7,7 +7,7 @@
 #include <cstdlib>
 #define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("HIP error %s at %d\n", hipGetErrorString(e), __LINE__); exit(1);} } while (0)
 
-template <bool PREFETCH>
+template <bool PREFETCH, bool SHIFT = false>
 __global__ __launch_bounds__(1024) void k_copy(const float* __restrict__ in, float* __restrict__ out, int T, int TP, int tiles, int clips, long long out_len) {
     constexpr int M = 1024, FPB = 32;
     const int tid = threadIdx.x, fs4 = (tid % 8) * 4, mq = tid / 8;
@@ -16,7 +16,12 @@ __global__ __launch_bounds__(1024) void k_copy(const float* __restrict__ in, flo
         const int t = tile * FPB + fs4;
         const float* cp = in + (long long)clip * M * TP + t;
 #pragma unroll
-        for (int i = 0; i < 8; ++i) r[i] = (t < TP) ? *reinterpret_cast<const float4*>(cp + (long long)(mq + i * 128) * TP) : make_float4(0, 0, 0, 0);
+        for (int i = 0; i < 8; ++i) {
+            // SHIFT: the odd rows (64 bytes off the 128-byte grid when the pitch is 432 floats) are read 16 columns further on, i.e. as
+            // whole lines -- what a kernel that keeps the second half of such a line for the next tile would fetch
+            const int sh = (SHIFT && ((mq + i * 128) & 1) && t + 16 + 3 < TP) ? 16 : 0;
+            r[i] = (t < TP) ? *reinterpret_cast<const float4*>(cp + (long long)(mq + i * 128) * TP + sh) : make_float4(0, 0, 0, 0);
+        }
     };
     for (int clip = blockIdx.x; clip < clips; clip += gridDim.x) {
         if (PREFETCH) gather(clip, 0);
@@ -69,19 +74,21 @@ int main() {
         CK(hipMemset(in, 0, (size_t)clips * M * TP * 4));
         hipEvent_t e0, e1;
         hipEventCreate(&e0); hipEventCreate(&e1);
-        for (int pf = 0; pf < 2; ++pf) {
+        for (int pf = 0; pf < 4; ++pf) {   // 2, 3: odd rows shifted onto the line grid
             float best = 1e9f;
             for (int it = 0; it < 6; ++it) {
                 hipEventRecord(e0);
-                if (pf) hipLaunchKernelGGL(k_copy<true>, dim3(256), dim3(1024), 0, 0, in, out, T, TP, tiles, clips, out_len);
-                else hipLaunchKernelGGL(k_copy<false>, dim3(256), dim3(1024), 0, 0, in, out, T, TP, tiles, clips, out_len);
+                if (pf == 1) hipLaunchKernelGGL(k_copy<true>, dim3(256), dim3(1024), 0, 0, in, out, T, TP, tiles, clips, out_len);
+                else if (pf == 0) hipLaunchKernelGGL(k_copy<false>, dim3(256), dim3(1024), 0, 0, in, out, T, TP, tiles, clips, out_len);
+                else if (pf == 3) hipLaunchKernelGGL((k_copy<true, true>), dim3(256), dim3(1024), 0, 0, in, out, T, TP, tiles, clips, out_len);
+                else hipLaunchKernelGGL((k_copy<false, true>), dim3(256), dim3(1024), 0, 0, in, out, T, TP, tiles, clips, out_len);
                 hipEventRecord(e1);
                 CK(hipEventSynchronize(e1));
                 float ms; hipEventElapsedTime(&ms, e0, e1);
                 if (it && ms < best) best = ms;
             }
             const double gb = ((double)clips * M * T * 4 + (double)clips * tiles * 32 * M * 4) / 1e9;
-            printf("row pitch %d floats, prefetch %d: %.3f ms  (%.2f GB moved, %.2f TB/s)\n", TP, pf, best, gb, gb / best);
+            printf("row pitch %d floats, prefetch %d%s: %.3f ms  (%.2f GB moved, %.2f TB/s)\n", TP, pf & 1, pf >= 2 ? ", odd rows shifted by 16 columns" : "", best, gb, gb / best);
         }
         {
             float best = 1e9f;

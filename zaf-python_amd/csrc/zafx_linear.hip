@@ -89,15 +89,22 @@ __global__ __launch_bounds__(256) void k_linear128(const float* __restrict__ mat
     const int fi = lane & 15, fk = lane >> 4;
     // staging: 128 rows x 32 floats = 1024 float4 per operand, 4 per thread: rows (tid / 8) + 32 j, k piece (tid % 8) * 4
     const int srow = tid >> 3, skq = (tid & 7) * 4;
-    const float* ap = mat + (long long)(r0 + srow) * n_cols + skq;
-    const float* bp = x + (b0 + srow) * n_cols + skq;
-    const float4 zero = make_float4(0.f, 0.f, 0.f, 0.f);
+    // Rows / clips past the end are read from the last valid one: their products land in output rows / clips that are not
+    // stored.  (A select between the loaded value and a zero constant made the compiler select between the ADDRESSES of the
+    // row and of a zero on the stack: 32 flat 4-byte loads per thread and K tile instead of 8 global 16-byte loads.)
+    const float* ap[4];
+    const float* bp[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        ap[j] = mat + (long long)min(r0 + srow + 32 * j, n_rows - 1) * n_cols + skq;
+        bp[j] = x + min(b0 + srow + 32 * j, n_clips - 1) * n_cols + skq;
+    }
     float4 ra[4], rb[4];
     auto fetch = [&](int k0) {
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-            ra[j] = r0 + srow + 32 * j < n_rows ? *reinterpret_cast<const float4*>(ap + (long long)(32 * j) * n_cols + k0) : zero;
-            rb[j] = b0 + srow + 32 * j < n_clips ? *reinterpret_cast<const float4*>(bp + (long long)(32 * j) * n_cols + k0) : zero;
+            ra[j] = *reinterpret_cast<const float4*>(ap[j] + k0);
+            rb[j] = *reinterpret_cast<const float4*>(bp[j] + k0);
         }
     };
     auto stash = [&](int buf) {

@@ -651,8 +651,8 @@ __global__ __launch_bounds__(NSLOT * fft_threads(LOG2NF, LOG2E)) void k_imdct(
                 const float2 wc = win2[n1 >> 1], wo = win2[(n1 + M) >> 1];
                 float2* dst = reinterpret_cast<float2*>(yc + o_first) + to;
                 const bool skip0 = t_first == 0 && h == 0;   // the first M samples of the clip's first tile are trimmed
-                auto sweep = [&](auto LO, auto LAST) {
-                    constexpr bool L = decltype(LAST)::value;
+                auto sweep = [&](auto LO, auto LAST, auto ALIGNED8) {
+                    constexpr bool L = decltype(LAST)::value, A8 = decltype(ALIGNED8)::value;
 #pragma unroll
                     for (int it = 0; it < NIT; ++it) {
                         const int j = FR * it + h;   // (uniform) the frame of this pass
@@ -672,7 +672,8 @@ __global__ __launch_bounds__(NSLOT * fft_threads(LOG2NF, LOG2E)) void k_imdct(
                         if (!(it == 0 && skip0)) {
                             // (the reference's output length (T-1) M - 1 is odd: every second clip of a batch starts on a 4-byte boundary)
                             const long long o = o_first + 2 * to + (long long)it * 2 * NT;
-                            if (y_aligned && (!L || o + 1 < out_len)) {
+                            // (compiled per alignment: with the test at every store the compiler folded both forms into 4-byte stores)
+                            if (A8 && (!L || o + 1 < out_len)) {
                                 dst[(size_t)it * NT] = make_float2(a.x * gain, a.y * gain);
                             } else {
                                 float* d1 = reinterpret_cast<float*>(dst + (size_t)it * NT);
@@ -682,12 +683,16 @@ __global__ __launch_bounds__(NSLOT * fft_threads(LOG2NF, LOG2E)) void k_imdct(
                         }
                     }
                 };
+                auto sweep_lo = [&](auto LAST, auto ALIGNED8) {
+                    if (lo) sweep(std::true_type{}, LAST, ALIGNED8);
+                    else sweep(std::false_type{}, LAST, ALIGNED8);
+                };
                 if (last_tile) {
-                    if (lo) sweep(std::true_type{}, std::true_type{});
-                    else sweep(std::false_type{}, std::true_type{});
+                    if (y_aligned) sweep_lo(std::true_type{}, std::true_type{});
+                    else sweep_lo(std::true_type{}, std::false_type{});
                 } else {
-                    if (lo) sweep(std::true_type{}, std::false_type{});
-                    else sweep(std::false_type{}, std::false_type{});
+                    if (y_aligned) sweep_lo(std::false_type{}, std::true_type{});
+                    else sweep_lo(std::false_type{}, std::false_type{});
                 }
             } else {
             for (int c2 = tid; c2 < c_end2; c2 += NT) {

@@ -677,23 +677,28 @@ __device__ __forceinline__ bool ola_phase_sweep(const OlaArgs& a, int tid, bool 
         const float2* pu = fr + (q0 - 1) * pitch + phys(r + HOP2);       // frame q - 1, second half
         float* dst = a.yc + a.o_first + 2 * to;
         const bool skip0 = a.o_first < 0 && q0 == 0;   // (the clip's first tile: its first W - hop samples are trimmed)
+        // (compiled per alignment of the clip's output: with the test at every store the compiler folded both forms into 4-byte stores)
+        auto passes = [&](auto ALIGNED8) {
 #pragma unroll
-        for (int it = 0; it < NIT; ++it) {
-            float2 acc = make_float2(0.f, 0.f), u = make_float2(0.f, 0.f);
-            if (it == 0 && q0 == 0) acc = carry2[r];
-            else u = pu[(size_t)it * QS * pitch];
-            const float2 v = pv[(size_t)it * QS * pitch];
-            const float2 s = make_float2((acc.x + u.y) + v.y, (acc.y + u.x) + v.x);   // components are stored swapped
-            if (!(it == 0 && skip0)) {
-                float* d = dst + (size_t)it * 2 * NT;
-                if (y_aligned) {
-                    *reinterpret_cast<float2*>(d) = make_float2(s.x * a.scale, s.y * a.scale);
-                } else {
-                    d[0] = s.x * a.scale;
-                    d[1] = s.y * a.scale;
+            for (int it = 0; it < NIT; ++it) {
+                float2 acc = make_float2(0.f, 0.f), u = make_float2(0.f, 0.f);
+                if (it == 0 && q0 == 0) acc = carry2[r];
+                else u = pu[(size_t)it * QS * pitch];
+                const float2 v = pv[(size_t)it * QS * pitch];
+                const float2 s = make_float2((acc.x + u.y) + v.y, (acc.y + u.x) + v.x);   // components are stored swapped
+                if (!(it == 0 && skip0)) {
+                    float* d = dst + (size_t)it * 2 * NT;
+                    if constexpr (decltype(ALIGNED8)::value) {
+                        *reinterpret_cast<float2*>(d) = make_float2(s.x * a.scale, s.y * a.scale);
+                    } else {
+                        d[0] = s.x * a.scale;
+                        d[1] = s.y * a.scale;
+                    }
                 }
             }
-        }
+        };
+        if (y_aligned) passes(std::true_type{});
+        else passes(std::false_type{});
         // carry: the second half of the tile's last frame (ola_phase_pairs: (0 + u.y) + 0, (0 + u.x) + 0)
         if (q0 == 0) {
             const float2 ul = fr[(FPB - 1) * pitch + phys(r + HOP2)];

@@ -46,7 +46,7 @@ H2D 57 GB/s, D2H 57 GB/s, serial on one stream) — two orders of magnitude belo
 `bench.py` times 100 steps after 20 warm-up steps by default: with 20 / 3 the ~1 ms kernels were measured inside the clock ramp (K = 2 … 400
 back-to-back launches of the MDCT: 0.81 / 0.87 / 0.85 / 0.80 / 0.78 ms per launch, `tools/b2b_test.py`); boxes differ by up to 10 % (the same binaries: stft 1.50–1.70 ms, mel 0.94–1.03 ms).
 Counter evidence (`profiles/r02_pmc_summary.csv`, `r02_sq_summary.csv`): fabric traffic / algorithmic bytes stft {ratio['stft']:.2f}, istft {ratio['istft']:.2f}, mdct {ratio['mdct']:.2f},
-imdct {ratio['imdct']:.2f} (rows 1728 B apart: every second 128-B run straddles two lines), mel {ratio['mel']:.2f}, mfcc {ratio['mfcc']:.2f}, **cqt {ratio['cqt']:.2f} (round 1: 8.3)**, dct {ratio['dct']:.1f};
+imdct {ratio['imdct']:.2f} (rows 1728 B apart: the 128-B runs of the odd rows straddle two lines, both fetched whole, the other halves wanted one tile later when L2 has dropped them; reading those rows on the line grid would need 32 KB of stash per workgroup that neither the registers — 116 of 128 — nor LDS have, and the copy kernel with such reads is only 3–4 % faster, `tools/exp_imdctcopy.hip`: the re-fetched halves come from the memory-side cache), mel {ratio['mel']:.2f}, mfcc {ratio['mfcc']:.2f}, **cqt {ratio['cqt']:.2f} (round 1: 8.3)**, dct {ratio['dct']:.1f};
 MFMA utilisation (busy cycles / kernel cycles / SIMDs) k_mel {100 * sq.get(('mel', 'mfma_util'), 0):.1f} %, mfcc {100 * sq.get(('mfcc', 'mfma_util'), 0):.1f} %, k_linear128 {100 * sq.get(('dct', 'mfma_util'), 0):.1f} %; LDS bank conflicts / active cycles
 stft {sq.get(('stft', 'lds_bank_conflict_over_active'), 0):.3f}, mel {sq.get(('mel', 'lds_bank_conflict_over_active'), 0):.2f}, cqt {sq.get(('cqt', 'lds_bank_conflict_over_active'), 0):.2f}, k_linear {sq.get(('dct', 'lds_bank_conflict_over_active'), 0):.2f} (the LDS timing model behind these: `tools/exp_ldsbank.hip`,
 `tools/lds_model.py`, profiles/r02_notes.md).

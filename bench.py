@@ -402,7 +402,7 @@ def run_kind(kind, args, device, rank, world, rdzv, comm, with_cpu):
     """One config: build the device-resident workload, broadcast its constants, time it, probe parity -> (entry, timing, workload info)."""
     import zafx
     wl = make_workload(kind, device, args.layout)
-    bcast = "none (1 rank)"
+    bcast = "none (1 rank)" if world == 1 else "none (no RCCL communicator: every rank built its own constants)"
     if comm is not None:
         try:
             comm.broadcast_constants(wl["plan"], root=0)
@@ -493,6 +493,9 @@ def main():
     force_dist = os.environ.get("ZAFX_BENCH_FORCE_DIST") == "1"   # exercise the N>1 plumbing on a 1-GPU box
     rdzv = launch.Rendezvous.from_env() if (world > 1 or force_dist) else None
     device = local_rank if world > 1 else 0
+    if os.environ.get("ZAFX_BENCH_SHARE_DEVICES") == "1":   # test aid: N ranks on a box with fewer GPUs (RCCL then refuses the duplicate
+        from zafx import _lib                                #           device and the constants stay per rank; everything else is the N-rank flow)
+        device = local_rank % max(_lib.device_count(), 1)
 
     comm = None
     if rdzv is not None:

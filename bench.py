@@ -498,6 +498,7 @@ def main():
         device = local_rank % max(_lib.device_count(), 1)
 
     comm = None
+    comm_hung = False
     if rdzv is not None:
         # the path's only collective: RCCL broadcast of the shared constants from rank 0 over xGMI; the 128-byte id
         # of the communicator travels through the file rendezvous
@@ -510,7 +511,27 @@ def main():
         os.dup2(2, 1)
         try:
             uid = rdzv.broadcast(zafx.Comm.unique_id() if rank == 0 else b"")
-            comm = zafx.Comm(device, rank, world, uid)
+            # ncclCommInitRank blocks until every rank has joined; created on a helper thread so that a bootstrap that never
+            # completes (no usable network interface, a rank that died) costs the collective's demonstration, not the run
+            import threading
+            made = {}
+
+            def create():
+                try:
+                    made["comm"] = zafx.Comm(device, rank, world, uid)
+                except zafx.ZafxError as exc:
+                    made["error"] = exc
+
+            th = threading.Thread(target=create, daemon=True)
+            th.start()
+            th.join(timeout=float(os.environ.get("ZAFX_BENCH_COMM_TIMEOUT", "180")))
+            if th.is_alive():
+                comm_hung = True
+                sys.stderr.write(f"rank {rank}: RCCL communicator not up after the timeout; constants stay per-rank\n")
+            elif "error" in made:
+                raise made["error"]
+            else:
+                comm = made["comm"]
         except zafx.ZafxError as exc:
             sys.stderr.write(f"rank {rank}: no RCCL communicator ({exc}); constants stay per-rank\n")
         finally:
@@ -575,6 +596,10 @@ def main():
 
     if rdzv is not None:
         rdzv.close()
+    if comm_hung:   # a thread is still inside ncclCommInitRank: leave without the library's exit handlers
+        sys.stdout.flush()
+        sys.stderr.flush()
+        os._exit(0)
     return 0
 
 

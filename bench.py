@@ -541,6 +541,9 @@ def main():
                 pass
             os.dup2(saved_stdout, 1)
             os.close(saved_stdout)
+        # a collective needs every rank: if one of them has no communicator, nobody uses theirs
+        if not all(flag == b"1" for flag in rdzv.all_gather(b"1" if comm is not None else b"0")):
+            comm = None
 
     kinds = [args.kind] if args.kind != "all" else ["stft"] + ([] if args.no_configs else list(CONFIG_KINDS))
     with_cpu = world == 1 and not args.no_cpu_baseline

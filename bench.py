@@ -13,7 +13,10 @@ when the timed region starts.  Rank 0 prints ONE JSON line.
 
 N > 1 without a framework (zafx/launch.py): launched by a launcher that sets RANK / LOCAL_RANK / WORLD_SIZE
 (torch.distributed.run does), the ranks meet through a file rendezvous; with WORLD_SIZE unset, `--gpus N` starts
-the N ranks itself.  PyTorch is not imported in either case.
+the N ranks itself.  PyTorch is not imported in either case.  Test aids (environment): ZAFX_BENCH_FORCE_DIST=1 runs the
+N-rank plumbing (rendezvous, communicator, broadcasts) with one rank; ZAFX_BENCH_SHARE_DEVICES=1 lets N ranks share fewer GPUs
+(rank r on GPU r mod count; RCCL then refuses the duplicate device and the constants stay per rank); ZAFX_BENCH_COMM_TIMEOUT
+(seconds, default 180) bounds the wait for the RCCL communicator.
 
 `roofline.achieved` = algorithmic bytes (or flops) per launch / mean kernel duration measured with HIP events on
 the plan's stream over the timed region.  `cpu_baseline` = the NumPy oracle (a port of zaf.py, same NumPy calls per

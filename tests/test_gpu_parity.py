@@ -991,6 +991,33 @@ def test_long_clips_are_segmented(zafx, n):
             assert np.max(np.abs(y[c][:n] - x[c])) < 1e-4 and np.max(np.abs(z[c][:n] - x[c])) < 1e-4
 
 
+def test_clip_longer_than_32_bit_byte_offsets(zafx):
+    """One clip of 2^29 + 4098 samples (3.4 hours at 44.1 kHz, 2 GB): the aligned forms of k_mel / k_mdct_ft32 address a clip through
+    a buffer descriptor with 32-bit byte offsets and hand such a clip to the forms with 64-bit addresses (from 2^29 samples on; the
+    descriptor itself ends at 4 GB).  Checked on the last
+    frames (the oracle runs on the tail of the signal: frame j0 + i of the clip is frame i of x[j0 * hop:], but for the padded i = 0)."""
+    n, hop, wl = (1 << 29) + 4098, 1024, 2048
+    block = synth_clip(71, 0, 1000003)
+    x = np.resize(block, n)[None, :]
+    ham = zafx.hamming(wl)
+    fb = zafx.melfilterbank(44100, wl, 128)
+    t = -(-n // hop) + 1
+    j0 = t - 40
+    tail = x[0, j0 * hop:].astype(np.float64)
+    mel = zafx.melspectrogram_batch(x, ham, hop, fb)
+    assert mel.shape == (1, 128, t)
+    assert relerr(mel[0][:, j0 + 1:], orc.melspectrogram(tail, ham, hop, fb)[:, 1:]) <= TOL_FB
+    del mel
+    cep = zafx.mfcc_batch(x, ham, hop, fb, 20)
+    assert relerr(cep[0][:, j0 + 1:], orc.mfcc(tail, ham, hop, fb, 20)[:, 1:]) <= TOL_FB
+    del cep
+    kbd = zafx.kaiser_bessel_derived(wl)
+    coef = zafx.mdct_batch(x, kbd)   # frames of hop 1024 starting one hop ahead of the clip (zaf.py:1036-1041)
+    tm = coef.shape[2]
+    ref = orc.mdct(x[0, (tm - 40) * hop:].astype(np.float64), kbd)
+    assert relerr(coef[0][:, tm - 40 + 1:tm - 40 + ref.shape[1]], ref[:, 1:]) <= TOL_FFT
+
+
 @pytest.mark.parametrize("wl,hop,n", [(2048, 3000, 50000), (2048, 2049, 20001), (1024, 5000, 30000), (256, 1000, 9999), (4096, 6000, 40000)])
 def test_hop_above_window(zafx, wl, hop, n):
     """step_length > window_length: zaf.stft / melspectrogram / mfcc skip samples between frames (zaf.py:102-136 holds for

@@ -97,3 +97,20 @@ def test_bench_does_not_import_torch():
     assert "import torch" not in src
     for name in ("launch.py", "core.py", "shard.py", "_lib.py", "__init__.py", "constants.py"):
         assert "import torch" not in open(os.path.join(ROOT, "zaf-python_amd", "zafx", name)).read()
+
+
+def test_rendezvous_directory_names_the_launcher_instance(monkeypatch):
+    """Ranks started by one launcher derive the same directory; it carries the launcher's pid AND start time, so a later
+    launcher that is handed the same pid (fresh boxes start counting low) cannot meet the files of a job that died."""
+    from zafx import launch
+    monkeypatch.delenv("ZAFX_RDZV_DIR", raising=False)
+    monkeypatch.setenv("RANK", "0")
+    monkeypatch.setenv("WORLD_SIZE", "1")
+    monkeypatch.setenv("MASTER_PORT", "29999")
+    a, b = launch.Rendezvous.from_env(), launch.Rendezvous.from_env()
+    try:
+        assert a.dir == b.dir
+        assert a.dir.endswith(f"_{os.getppid()}_{launch._start_time(os.getppid())}")
+        assert launch._start_time(os.getppid()) > 0 and launch._start_time(2 ** 30) == 0
+    finally:
+        a.close()

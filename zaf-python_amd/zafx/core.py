@@ -169,6 +169,29 @@ class DeviceBuffer:
         _lib.check(_lib.load().zafx_d2d(self.device, dst, src, nbytes), "zafx_d2d")
         return self
 
+    @classmethod
+    def placed(cls, shape, dtype, probe, candidates=4, device=0, init=None):
+        """The fastest of `candidates` allocations of this shape: -> (buffer, [probe times]).
+
+        Where a large allocation lands in physical memory changes the rate of the kernels that walk it with a row stride (the
+        (W, T) spectra of the reference layout): the same STFT runs in 1.50 ms into one 7 GB allocation and in 1.70 ms into
+        another made by the same process (profiles/r02_notes.md).  The address is not the caller's to choose, so a long-lived
+        buffer is picked by trial: all candidates are allocated (held at once -- freed ones would come straight back), `init(buffer)`
+        fills each if the probe reads it, `probe(buffer)` returns a time, the best one stays, the others are freed."""
+        bufs = [cls(shape, dtype, device) for _ in range(max(int(candidates), 1))]
+        times = []
+        for k, b in enumerate(bufs):
+            if init is not None:
+                init(b)
+            if k == 0 and len(bufs) > 1:
+                probe(b)   # (not counted: the first probe also carries the clock ramp)
+            times.append(float(probe(b)))
+        best = min(range(len(bufs)), key=times.__getitem__)
+        for i, b in enumerate(bufs):
+            if i != best:
+                b.free()
+        return bufs[best], times
+
     def free(self):
         if getattr(self, "ptr", None) is not None and self.ptr.value:
             _lib.load().zafx_free(self.device, self.ptr)

@@ -1365,3 +1365,22 @@ def test_cqt_clip_groups_and_complex_kernels(zafx, n_clips, n):
     ref = orc.cqtspectrogram(x[0, :20000].astype(np.float64), 8000, 50, ks)
     assert gs[0].shape == ref.shape and relerr(gs[0], ref) <= TOL_FB
     assert np.all(gs[0][5] == 0)
+
+
+def test_device_buffer_placed_keeps_the_fastest_candidate(zafx):
+    """DeviceBuffer.placed: every candidate is initialised and probed (the first once more, uncounted), the one with the lowest
+    probe time stays usable, the others are freed."""
+    seen = []
+
+    def init(buf):
+        buf.upload(np.full(buf.shape, len(seen), np.float32))
+
+    def probe(buf):
+        seen.append(buf.ptr.value)
+        return {0: 9.0, 1: 9.0, 2: 3.0, 3: 1.0, 4: 2.0}[len(seen) - 1]   # (call 0 is the uncounted one)
+
+    buf, times = zafx.DeviceBuffer.placed((4, 1000), np.float32, probe, candidates=4, init=init)
+    assert times == [9.0, 3.0, 1.0, 2.0] and len(set(seen)) == 4 and seen[0] == seen[1]
+    assert buf.ptr.value == seen[3]
+    assert np.array_equal(buf.download(), np.full((4, 1000), 3, np.float32))   # (initialised when four probes had been made)
+    buf.free()

@@ -186,6 +186,9 @@ def make_workload(kind, device, layout="FT"):
         wl["placement"] = {"buffer": "input", "candidates": n_cand, "probe_ms": [round(t_first, 4)] + [round(t, 4) for t in times]}
     else:
         wl["d_out"] = zafx.DeviceBuffer(out_shape, plan.out_dtype, device)
+    if "placement" in wl:
+        # the driver wipes freed device memory in the background (tens of GB here): let that finish before anything is timed
+        time.sleep(float(os.environ.get("ZAFX_BENCH_SETTLE_S", "0.5")))
     return wl
 
 

@@ -3,7 +3,7 @@
 Msamples/s; the same JSON line carries every other BASELINE config under "configs".
 
     python bench.py [--gpus N] [--steps K] [--warmup W] [--kind all|stft|istft|mdct|imdct|mel|mfcc|cqt|...]
-    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+    <any launcher that sets RANK / LOCAL_RANK / WORLD_SIZE, one process per GPU> bench.py --gpus N ...
 
 A "step" is one pass of the hot path over one batch: 1024 clips x 10 s @ 44.1 kHz per GPU (config 5, CQT: 1024
 clips x 30 s per GPU = 8192 over 8 GPUs).  Weak scaling: every rank transforms its own clips; clips are
@@ -11,12 +11,20 @@ independent, there is no data-path collective -- the only communication is the R
 filterbank / CQT-kernel constants from rank 0 before the timed region.  Inputs and outputs are resident in HBM
 when the timed region starts.  Rank 0 prints ONE JSON line.
 
-N > 1 without a framework (zafx/launch.py): launched by a launcher that sets RANK / LOCAL_RANK / WORLD_SIZE
-(torch.distributed.run does), the ranks meet through a file rendezvous; with WORLD_SIZE unset, `--gpus N` starts
-the N ranks itself.  PyTorch is not imported in either case.  Test aids (environment): ZAFX_BENCH_FORCE_DIST=1 runs the
+N > 1 without a framework (zafx/launch.py): under a launcher that sets RANK / LOCAL_RANK / WORLD_SIZE (the driver's
+`python -m torch.distributed.run` does; this script never imports torch) the ranks meet through a file rendezvous; with
+WORLD_SIZE unset, `--gpus N` starts the N ranks itself.  With more than one rank the RCCL communicator is part of the
+record: the line carries what RCCL itself reports (`rccl.ranks_seen`, per-rank kernel times, broadcast wall time), and a
+run whose ranks cannot form it prints its line with an "error" field and exits 3 (ZAFX_BENCH_ALLOW_NO_COMM=1: exit 0).  Test aids (environment): ZAFX_BENCH_FORCE_DIST=1 runs the
 N-rank plumbing (rendezvous, communicator, broadcasts) with one rank; ZAFX_BENCH_SHARE_DEVICES=1 lets N ranks share fewer GPUs
-(rank r on GPU r mod count; RCCL then refuses the duplicate device and the constants stay per rank); ZAFX_BENCH_COMM_TIMEOUT
+(rank r on GPU r mod count; RCCL then refuses the duplicate device, so this aid needs ZAFX_BENCH_ALLOW_NO_COMM=1); ZAFX_BENCH_COMM_TIMEOUT
 (seconds, default 180) bounds the wait for the RCCL communicator.
+
+Timing: the device is first kept busy with the plan for ZAFX_BENCH_PREWARM_S seconds (default 0.4, untimed, whatever
+--warmup says: the clocks of an idle MI355X ramp over the first few hundred milliseconds of work, so a short warm-up count
+leaves a ~1 ms kernel inside the ramp), then the contract's W warm-up steps and K timed steps follow.  `value` comes from the
+FIRST allocation of every buffer, as a caller of the library gets it; where the 7 GB spectrum lands in physical memory moves
+the STFT by up to 12 %, so the line also reports a survey of further allocations (`config.placement`).
 
 `roofline.achieved` = algorithmic bytes (or flops) per launch / mean kernel duration measured with HIP events on
 the plan's stream over the timed region.  `cpu_baseline` = the NumPy oracle (a port of zaf.py, same NumPy calls per
@@ -39,8 +47,9 @@ FS, W, H = 44100, 2048, 1024
 HBM_PEAK_GBS = 8000.0      # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 HBM_ACHIEVABLE_GBS = 6290.0   # same guide: measured-achievable copy rate
 F32_PEAK_TFLOPS = 157.3    # dense f32 vector / f32-input MFMA peak
-PLACEMENT_CANDIDATES = 8   # allocations tried for the row-strided buffer of a workload (make_workload)
-CONFIG_KINDS = ("mel", "mfcc", "mdct", "imdct", "cqt")   # BASELINE configs 3, 4, 5 (config 2 = the headline)
+PLACEMENT_SURVEY = 6       # further allocations of the headline's row-strided output probed AFTER every timed region (reported, never timed)
+CONFIG_KINDS = ("istft", "mel", "mfcc", "mdct", "imdct", "cqt")   # SURVEY 8(a) a2 + BASELINE configs 3, 4, 5 (config 2 = the headline)
+EXTRA_KINDS = ("stft1", "istft1", "stft_offgrid", "stft4096")   # one-sided pair (8f rank 4) and geometries off the benchmark's grid
 
 
 def synth(seed, c, n):
@@ -72,6 +81,10 @@ def make_workload(kind, device, layout="FT"):
         B, N, T = 16384, 1024, 1
     if kind == "stft64":
         B = 128
+    if kind == "stft_offgrid":
+        N, T = 442024, 433        # one more frame than config 2: rows of 433 complex64 = 3464 B, off the 128-byte grid
+    if kind == "stft4096":
+        T = 217
     base = np.stack([synth(0, c, N) for c in range(distinct)])
     d_base = zafx.DeviceBuffer.from_host(base, device)
     d_x = zafx.DeviceBuffer((B, N), np.float32, device)
@@ -83,6 +96,14 @@ def make_workload(kind, device, layout="FT"):
         plan = zafx.stft_plan(ham, H, layout=layout, device=device)
         wl.update(plan=plan, d_in=d_x, n_in=N, bytes_per_launch=B * (4 * N + 8 * W * T),
                   desc="Batched STFT: 1024 clips x 10 s @ 44.1 kHz, Hamming win=2048 hop=1024, two-sided c64 (W,T) layout")
+    elif kind == "stft_offgrid":   # the compact reference layout when T is not a multiple of 16
+        plan = zafx.stft_plan(ham, H, layout=layout, device=device)
+        wl.update(plan=plan, d_in=d_x, n_in=N, bytes_per_launch=B * (4 * N + 8 * W * T),
+                  desc="Batched STFT off the line grid: 1024 clips x 442024 samples, win=2048 hop=1024, T = 433 (rows straddle 128-byte lines), compact (W,T) layout")
+    elif kind == "stft4096":
+        plan = zafx.stft_plan(zafx.hamming(4096), 2048, layout=layout, device=device)
+        wl.update(plan=plan, d_in=d_x, n_in=N, bytes_per_launch=B * (4 * N + 8 * 4096 * T),
+                  desc="Batched STFT, win=4096 hop=2048: 1024 clips x 10 s, T = 217, two-sided c64 (W,T) layout")
     elif kind == "stft64":  # float64 device arithmetic (written for exactness, not speed)
         d_x64 = zafx.DeviceBuffer.from_host(np.tile(base.astype(np.float64), (B // distinct, 1)), device)
         d_x.free()
@@ -153,43 +174,62 @@ def make_workload(kind, device, layout="FT"):
                   desc="zaf.dct type 2 of 16384 vectors x 1024 samples as one f32 MFMA GEMM (SURVEY 8f rank 3)")
     else:
         raise SystemExit(f"unknown --kind {kind}")
-    # The (W, T) spectrum / coefficient array is walked with a row stride; where its allocation lands in physical memory moves the
-    # rate by up to 12 % (zafx.DeviceBuffer.placed).  The buffers of a benchmark -- like those of a service -- live long: the strided
-    # one is the best of PLACEMENT_CANDIDATES allocations by a short probe of this very plan (ZAFX_BENCH_PLACEMENT=0: first allocation, =n: best of n).
+    # `value` and every config time come from the FIRST allocation of each buffer -- what a caller of the library gets.  (Where a
+    # 7 GB row-strided array lands in physical memory moves the STFT by up to 12 %: main() surveys further allocations after
+    # all timed regions and reports them under config.placement.  ZAFX_BENCH_PLACEMENT=n > 1 times the best of n instead --
+    # an experiment switch, labelled in the line.)
     out_shape = plan.out_shape(B, wl["n_in"])
-    n_cand = max(int(os.environ.get("ZAFX_BENCH_PLACEMENT", PLACEMENT_CANDIDATES)), 1)   # (0 or 1: the first allocation; n: best of n)
-
-    def probe_ms(d_in, d_out, reps=8):
-        for _ in range(3):
-            plan.execute(d_in, d_out, B, wl["n_in"])
-        plan.sync()
-        t0 = time.perf_counter()
-        for _ in range(reps):
-            plan.execute(d_in, d_out, B, wl["n_in"])
-        plan.sync()
-        return (time.perf_counter() - t0) / reps * 1e3
-
-    if kind in ("stft", "stft1", "mdct") and n_cand > 1:        # strided side = the output
-        wl["d_out"], times = zafx.DeviceBuffer.placed(out_shape, plan.out_dtype, lambda buf: probe_ms(wl["d_in"], buf), n_cand, device)
-        wl["placement"] = {"buffer": "output", "candidates": n_cand, "probe_ms": [round(t, 4) for t in times]}
-    elif kind in ("istft", "istft1", "imdct") and n_cand > 1:   # strided side = the input (already computed: copied into each candidate)
-        wl["d_out"] = zafx.DeviceBuffer(out_shape, plan.out_dtype, device)
-        first = wl["d_in"]
-        best, times = zafx.DeviceBuffer.placed(first.shape, first.dtype, lambda buf: probe_ms(buf, wl["d_out"]), n_cand - 1, device,
-                                               init=lambda buf: buf.copy_from(first))
-        t_first = probe_ms(first, wl["d_out"])
-        if t_first <= min(times):
-            best.free()
-        else:
-            first.free()
-            wl["d_in"] = best
-        wl["placement"] = {"buffer": "input", "candidates": n_cand, "probe_ms": [round(t_first, 4)] + [round(t, 4) for t in times]}
+    n_cand = max(int(os.environ.get("ZAFX_BENCH_PLACEMENT", "1")), 1)
+    if kind in ("stft", "stft1", "mdct") and n_cand > 1:
+        wl["d_out"], times = zafx.DeviceBuffer.placed(out_shape, plan.out_dtype, lambda buf: probe_ms(plan, wl["d_in"], buf, B, wl["n_in"]), n_cand, device)
+        wl["placement"] = {"buffer": "output", "candidates": n_cand, "probe_ms": [round(t, 4) for t in times],
+                           "note": "ZAFX_BENCH_PLACEMENT: the timed buffer is the best of these allocations, NOT the first"}
+        time.sleep(float(os.environ.get("ZAFX_BENCH_SETTLE_S", "0.5")))   # (the driver wipes the freed candidates in the background)
     else:
         wl["d_out"] = zafx.DeviceBuffer(out_shape, plan.out_dtype, device)
-    if "placement" in wl:
-        # the driver wipes freed device memory in the background (tens of GB here): let that finish before anything is timed
-        time.sleep(float(os.environ.get("ZAFX_BENCH_SETTLE_S", "0.5")))
     return wl
+
+
+def probe_ms(plan, d_in, d_out, n_clips, n_in, reps=8):
+    for _ in range(3):
+        plan.execute(d_in, d_out, n_clips, n_in)
+    plan.sync()
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        plan.execute(d_in, d_out, n_clips, n_in)
+    plan.sync()
+    return (time.perf_counter() - t0) / reps * 1e3
+
+
+def placement_survey(device, first_ms, layout="FT"):
+    """After every timed region: the headline STFT into PLACEMENT_SURVEY further allocations of its 7.25 GB output, all held at
+    once (a freed one would come straight back), 8 launches each.  Reported beside the first allocation's time so that a
+    reader sees the spread of this box; nothing here is `value`."""
+    import zafx
+    n = int(os.environ.get("ZAFX_BENCH_PLACEMENT_SURVEY", PLACEMENT_SURVEY))
+    if n < 1:
+        return None
+    wl = make_workload("stft", device, layout)
+    plan, B, N = wl["plan"], wl["n_clips"], wl["n_in"]
+    held, times = [wl["d_out"]], []
+    try:
+        prewarm(plan, wl["d_in"], wl["d_out"], B, N)
+        times.append(probe_ms(plan, wl["d_in"], wl["d_out"], B, N))
+        for _ in range(n):
+            try:
+                held.append(zafx.DeviceBuffer(held[0].shape, held[0].dtype, device))
+            except zafx.ZafxError:
+                break
+            times.append(probe_ms(plan, wl["d_in"], held[-1], B, N))
+    finally:
+        for b in held[1:]:
+            b.free()
+        free_workload(wl)
+    return {"buffer": "output (1024, 2048, 432) complex64, 7.25 GB", "timed_allocation": "first",
+            "timed_kernel_ms": round(first_ms, 4), "survey_probe_ms": [round(t, 4) for t in times],
+            "survey_best_ms": round(min(times), 4), "survey_worst_ms": round(max(times), 4),
+            "note": "fresh allocations of the same buffer probed after all timed regions (8 launches each, host clock); "
+                    "zafx.DeviceBuffer.placed picks by such a probe for a long-lived buffer; see DESIGN.md 3"}
 
 
 def free_workload(wl):
@@ -312,9 +352,11 @@ def parity_probe(wl):
     kind, base, B = wl["kind"], wl["base"], wl["n_clips"]
     ham, kbd = orc.hamming_periodic(W), orc.kbd_window(W)
     x64 = base[0].astype(np.float64)
-    if kind in ("stft", "stft1"):
+    if kind in ("stft", "stft1", "stft_offgrid"):
         ref = orc.stft(x64, ham, H)
         ref = ref[:W // 2 + 1] if kind == "stft1" else ref
+    elif kind == "stft4096":
+        ref = orc.stft(x64, orc.hamming_periodic(4096), 2048)
     elif kind in ("istft", "istft1"):
         ref = None   # (checked as a round trip below: the device spectrum is the input)
     elif kind == "mdct":
@@ -351,6 +393,21 @@ def parity_probe(wl):
 # ---------------------------------------------------------------------------------------------------------------
 # timing
 # ---------------------------------------------------------------------------------------------------------------
+def prewarm(plan, d_in, d_out, n_clips, n_in, seconds=None):
+    """Keep the device busy with this plan for `seconds` (untimed): the clocks of an idle MI355X ramp over the first few hundred
+    milliseconds of work, and the contract's warm-up is a COUNT -- 5 launches of a 1 ms kernel end inside the ramp (round 2:
+    the driver's --steps 20 --warmup 5 measured the ~1 ms kernels 5-8 % above their steady state)."""
+    seconds = float(os.environ.get("ZAFX_BENCH_PREWARM_S", "0.4")) if seconds is None else seconds
+    t_end = time.perf_counter() + seconds
+    n = 0
+    while time.perf_counter() < t_end:
+        for _ in range(4):
+            plan.execute(d_in, d_out, n_clips, n_in)
+        plan.sync()
+        n += 4
+    return n
+
+
 def time_workload(wl, steps, warmup, rdzv):
     """Contract timing: W untimed steps, then EXACTLY K steps between (device sync + barrier) pairs, MAX over ranks;
     the HIP-event stopwatch of the plan's stream wraps the same K launches.  A second, separate pass times the K
@@ -362,6 +419,7 @@ def time_workload(wl, steps, warmup, rdzv):
         if rdzv is not None:
             rdzv.barrier()
 
+    prewarm(plan, wl["d_in"], wl["d_out"], B, n_in)   # time-based, untimed, in front of the contract's warm-up
     for _ in range(warmup):
         plan.execute(wl["d_in"], wl["d_out"], B, n_in)
     sync_all()
@@ -378,9 +436,13 @@ def time_workload(wl, steps, warmup, rdzv):
         plan.execute(wl["d_in"], wl["d_out"], B, n_in)
         each.append(plan.timer_stop())
     vals = [elapsed, kernel_ms, -min(each), float(np.median(each))]
+    per_rank = [kernel_ms]
     if rdzv is not None:
+        import struct
+        per_rank = [struct.unpack("<d", b)[0] for b in rdzv.all_gather(struct.pack("<d", kernel_ms))]
         vals = rdzv.all_reduce_max(vals)   # (-min: the MAX over ranks of -min is the smallest step anywhere)
-    return {"elapsed_s": vals[0], "kernel_ms": vals[1], "kernel_ms_min": -vals[2], "kernel_ms_median": vals[3]}
+    return {"elapsed_s": vals[0], "kernel_ms": vals[1], "kernel_ms_min": -vals[2], "kernel_ms_median": vals[3],
+            "kernel_ms_per_rank": [round(v, 4) for v in per_rank]}
 
 
 def roofline_of(wl, tm, kind):
@@ -407,34 +469,49 @@ def roofline_of(wl, tm, kind):
     return roof
 
 
-def e2e_pcie(device, clips=128):
-    """PCIe-inclusive figure of the host-buffer boundary (never `value`): pinned host f32 -> HBM -> kernel -> pinned host c64."""
+def e2e_pcie(device, clips=256):
+    """PCIe-inclusive figures of the host-array boundary (never `value`): page-locked host f32 -> HBM -> kernel -> page-locked
+    host c64 through Plan.run_host (zafx_run_host: chunks over two streams, upload / kernel / download overlapped), two-sided
+    and one-sided, with the serial one-stream sequence of round 2 beside it."""
     import zafx
     N = 441000
-    plan = zafx.stft_plan(zafx.hamming(W), H, device=device)
     x = zafx.pinned_empty((clips, N), np.float32)
     x[:] = np.tile(np.stack([synth(0, c, N) for c in range(8)]), (clips // 8, 1))
-    d_in = zafx.DeviceBuffer((clips, N), np.float32, device)
-    d_out = zafx.DeviceBuffer(plan.out_shape(clips, N), plan.out_dtype, device)
-    host = zafx.pinned_empty(d_out.shape, d_out.dtype)
-    best = None
-    for _ in range(3):
-        t0 = time.perf_counter()
-        d_in.upload(x)
-        t1 = time.perf_counter()
-        plan.execute(d_in, d_out, clips, N)
-        plan.sync()
-        t2 = time.perf_counter()
-        d_out.download(out=host)
-        t3 = time.perf_counter()
-        if best is None or t3 - t0 < best[0]:
-            best = (t3 - t0, t1 - t0, t2 - t1, t3 - t2)
-    d_in.free()
-    d_out.free()
-    return {"value": round(clips * N / best[0] / 1e6, 1), "unit": "Msamples/s",
-            "sample": f"{clips} clips x 10 s, page-locked host buffers both ways (zafx.pinned_empty), best of 3: H2D {x.nbytes / 1e6:.0f} MB "
-                      f"{best[1] * 1e3:.1f} ms ({x.nbytes / best[1] / 1e9:.1f} GB/s), kernel {best[2] * 1e3:.2f} ms, D2H {host.nbytes / 1e6:.0f} MB "
-                      f"{best[3] * 1e3:.1f} ms ({host.nbytes / best[3] / 1e9:.1f} GB/s); serial, one stream"}
+    out = {}
+    for label, onesided in (("two_sided", False), ("one_sided", True)):
+        plan = zafx.stft_plan(zafx.hamming(W), H, device=device, onesided=onesided)
+        host = zafx.pinned_empty(plan.out_shape(clips, N), plan.out_dtype)
+        plan.run_host(x, N, out=host)   # (first call: staging buffers, page tables)
+        best = None
+        for _ in range(3):
+            t0 = time.perf_counter()
+            plan.run_host(x, N, out=host)
+            dt = time.perf_counter() - t0
+            best = dt if best is None else min(best, dt)
+        rec = {"value": round(clips * N / best / 1e6, 1), "unit": "Msamples/s",
+               "sample": f"{clips} clips x 10 s, page-locked host arrays both ways (zafx.pinned_empty), Plan.run_host = zafx_run_host: chunked, "
+                         f"two streams, best of 3: {best * 1e3:.1f} ms for {x.nbytes / 1e6:.0f} MB up + {host.nbytes / 1e6:.0f} MB down "
+                         f"({host.nbytes / best / 1e9:.1f} GB/s of download alone)"}
+        if not onesided:   # the serial sequence of round 2, same buffers
+            d_in = zafx.DeviceBuffer((clips, N), np.float32, device)
+            d_out = zafx.DeviceBuffer(plan.out_shape(clips, N), plan.out_dtype, device)
+            serial = None
+            for _ in range(2):
+                t0 = time.perf_counter()
+                d_in.upload(x)
+                plan.execute(d_in, d_out, clips, N)
+                plan.sync()
+                d_out.download(out=host)
+                dt = time.perf_counter() - t0
+                serial = dt if serial is None else min(serial, dt)
+            d_in.free()
+            d_out.free()
+            rec["serial_one_stream"] = {"value": round(clips * N / serial / 1e6, 1), "unit": "Msamples/s"}
+        out[label] = rec
+        del host
+    out["value"] = out["two_sided"]["value"]
+    out["unit"] = "Msamples/s"
+    return out
 
 
 def run_kind(kind, args, device, rank, world, rdzv, comm, with_cpu):
@@ -442,21 +519,28 @@ def run_kind(kind, args, device, rank, world, rdzv, comm, with_cpu):
     import zafx
     wl = make_workload(kind, device, args.layout)
     bcast = "none (1 rank)" if world == 1 else "none (no RCCL communicator: every rank built its own constants)"
+    bcast_s = None
     if comm is not None:
         try:
+            t0 = time.perf_counter()
             comm.broadcast_constants(wl["plan"], root=0)
+            bcast_s = time.perf_counter() - t0
             bcast = "rccl ncclBroadcast of plan constants from rank 0"
         except zafx.ZafxError as exc:
-            # every rank has already built identical constants from the same deterministic host code, so an error here
-            # costs the demonstration of the collective, not the measurement
-            bcast = f"skipped ({exc}); every rank built its own constants"
+            # every rank has already built identical constants from the same deterministic host code, so the measurement
+            # stands; the failure is carried into the line (main() turns it into a non-zero exit)
+            bcast = f"FAILED ({exc}); every rank built its own constants"
     tm = time_workload(wl, args.steps, args.warmup, rdzv)
+    tm["broadcast_s"] = bcast_s
     entry = None
     if rank == 0:
         total = float(wl["n_clips"]) * wl["samples_per_clip"] * world * args.steps
         entry = {"workload": wl["desc"], "value": round(total / tm["elapsed_s"] / 1e6, 1), "unit": "Msamples/s",
                  "ms_per_step": round(tm["elapsed_s"] / args.steps * 1e3, 4), "roofline": roofline_of(wl, tm, kind),
                  "parity": parity_probe(wl), "constants_broadcast": bcast}
+        if world > 1 or comm is not None:
+            entry["kernel_ms_per_rank"] = tm["kernel_ms_per_rank"]
+            entry["constants_broadcast_wall_s"] = None if bcast_s is None else round(bcast_s, 4)
         if "placement" in wl:
             entry["placement"] = wl["placement"]
         if with_cpu:
@@ -540,6 +624,7 @@ def main():
 
     comm = None
     comm_hung = False
+    rccl = None
     if rdzv is not None:
         # the path's only collective: RCCL broadcast of the shared constants from rank 0 over xGMI; the 128-byte id
         # of the communicator travels through the file rendezvous
@@ -550,10 +635,12 @@ def main():
         sys.stdout.flush()
         saved_stdout = os.dup(1)
         os.dup2(2, 1)
+        comm_error = None
+        t_comm = time.perf_counter()
         try:
             uid = rdzv.broadcast(zafx.Comm.unique_id() if rank == 0 else b"")
             # ncclCommInitRank blocks until every rank has joined; created on a helper thread so that a bootstrap that never
-            # completes (no usable network interface, a rank that died) costs the collective's demonstration, not the run
+            # completes (no usable network interface, a rank that died) ends in an error line, not in a hang
             import threading
             made = {}
 
@@ -568,13 +655,13 @@ def main():
             th.join(timeout=float(os.environ.get("ZAFX_BENCH_COMM_TIMEOUT", "180")))
             if th.is_alive():
                 comm_hung = True
-                sys.stderr.write(f"rank {rank}: RCCL communicator not up after the timeout; constants stay per-rank\n")
+                comm_error = "ncclCommInitRank did not return within the timeout"
             elif "error" in made:
                 raise made["error"]
             else:
                 comm = made["comm"]
         except zafx.ZafxError as exc:
-            sys.stderr.write(f"rank {rank}: no RCCL communicator ({exc}); constants stay per-rank\n")
+            comm_error = str(exc)
         finally:
             try:
                 ctypes.CDLL(None).fflush(None)
@@ -582,22 +669,35 @@ def main():
                 pass
             os.dup2(saved_stdout, 1)
             os.close(saved_stdout)
+        t_comm = time.perf_counter() - t_comm
+        if comm_error:
+            sys.stderr.write(f"rank {rank}: no RCCL communicator ({comm_error}); constants stay per-rank\n")
+        # what RCCL itself says about the communicator (ncclCommCount / ncclCommUserRank), gathered from every rank
+        seen, urank = (comm.count(), comm.user_rank()) if comm is not None else (0, -1)
+        rows = [b.decode().split("|", 2) for b in rdzv.all_gather(f"{seen}|{urank}|{comm_error or ''}".encode())]
+        ok = all(int(r[0]) == world for r in rows) and sorted(int(r[1]) for r in rows) == list(range(world))
+        rccl = {"ok": ok, "ranks_seen": [int(r[0]) for r in rows], "user_ranks": [int(r[1]) for r in rows],
+                "world_size": world, "comm_init_wall_s": round(t_comm, 3),
+                "errors": sorted({r[2] for r in rows if r[2]})}
         # a collective needs every rank: if one of them has no communicator, nobody uses theirs
-        if not all(flag == b"1" for flag in rdzv.all_gather(b"1" if comm is not None else b"0")):
+        if not ok:
             comm = None
 
-    kinds = [args.kind] if args.kind != "all" else ["stft"] + ([] if args.no_configs else list(CONFIG_KINDS))
+    kinds = [args.kind] if args.kind != "all" else ["stft"] + ([] if args.no_configs else list(CONFIG_KINDS) + list(EXTRA_KINDS))
     with_cpu = world == 1 and not args.no_cpu_baseline
-    entries = {}
-    head = head_info = None
+    entries, extras = {}, {}
+    head = head_info = head_tm = None
     for kind in kinds:
-        entry, tm, info = run_kind(kind, args, device, rank, world, rdzv, comm, with_cpu)
+        entry, tm, info = run_kind(kind, args, device, rank, world, rdzv, comm, with_cpu and kind not in EXTRA_KINDS)
         if head is None:
-            head, head_info = entry, info
+            head, head_info, head_tm = entry, info, tm
+        elif kind in EXTRA_KINDS:
+            extras[kind] = entry
         else:
             entries[kind] = entry
     if comm is not None:
         comm.destroy()
+    exit_code = 0
 
     if rank == 0:
         hk = kinds[0]
@@ -611,10 +711,18 @@ def main():
                        "parallelism": f"clip-sharded x{world}", "constants_broadcast": head["constants_broadcast"],
                        "launcher": "file rendezvous (zafx/launch.py), no torch.distributed" if rdzv is not None else "single process",
                        "layout": "FT (reference memory order)" if args.layout == "FT" else "TF (frame-major)",
-                       "placement": ({**head["placement"], "note": "the row-strided buffer is the fastest of these allocations by a short probe "
-                                      "(zafx.DeviceBuffer.placed); ZAFX_BENCH_PLACEMENT=0 takes the first"} if "placement" in head else "first allocation")},
+                       "placement": head.get("placement", "first allocation")},
             "roofline": head["roofline"],
         }
+        if rccl is not None:
+            # the record of a multi-GPU run: what RCCL saw, not what the launcher said
+            out["rccl"] = dict(rccl, kernel_ms_per_rank=head_tm["kernel_ms_per_rank"],
+                               constants_broadcast_wall_s=None if head_tm.get("broadcast_s") is None else round(head_tm["broadcast_s"], 4))
+            failed = [k for k, e in [(kinds[0], head)] + list(entries.items()) + list(extras.items()) if "FAILED" in e["constants_broadcast"]]
+            if not rccl["ok"] or failed:
+                out["error"] = ("RCCL communicator of %d ranks not formed (%s)" % (world, "; ".join(rccl["errors"]) or "rank counts differ")
+                                if not rccl["ok"] else "RCCL broadcast failed for: " + ", ".join(failed))
+                exit_code = 0 if os.environ.get("ZAFX_BENCH_ALLOW_NO_COMM") == "1" else 3
         out.update({k: v for k, v in head["parity"].items() if k.startswith("max_")})
         out["parity"] = head["parity"]
         if "cpu_baseline" in head:
@@ -629,6 +737,13 @@ def main():
                     "residual_max_abs": entries["imdct"]["parity"].get("roundtrip_max_abs_residual"), "residual_bound": 1e-5,
                     "note": "imdct(mdct(x)) on the device, both kernels timed separately on the same 1024-clip batch; residual over clip 0 (zaf.py:1098-1109)"}
             out["configs"] = entries
+        if extras:
+            out["extras"] = extras
+        if world == 1 and hk == "stft" and args.kind == "all" and "placement" not in head:
+            try:
+                out["config"]["placement"] = placement_survey(device, head["roofline"]["kernel_ms"], args.layout) or "first allocation"
+            except zafx.ZafxError as exc:
+                out["config"]["placement"] = {"timed_allocation": "first", "survey_error": str(exc)}
         if with_cpu and hk == "stft":
             out["cpu_baseline_all_cores"] = cpu_baseline_all_cores()
             if "value" in out["cpu_baseline_all_cores"]:
@@ -641,12 +756,14 @@ def main():
         os.write(real_stdout, (json.dumps(out) + "\n").encode())
 
     if rdzv is not None:
+        # every rank leaves with rank 0's verdict (a launcher reports the first non-zero exit)
+        exit_code = int(rdzv.broadcast(str(exit_code).encode() if rank == 0 else b"").decode() or 0)
         rdzv.close()
     if comm_hung:   # a thread is still inside ncclCommInitRank: leave without the library's exit handlers
         sys.stdout.flush()
         sys.stderr.flush()
-        os._exit(0)
-    return 0
+        os._exit(exit_code)
+    return exit_code
 
 
 if __name__ == "__main__":

@@ -127,6 +127,7 @@ int zafx_device_count(int* count);
 int zafx_device_name(int device, char* buf, size_t buflen);
 
 /* ---- device memory (synchronous helpers; caller owns the allocations) -------------- */
+#define ZAFX_ERROR_OUT_OF_MEMORY 2 /* zafx_alloc: the device has no room (= hipErrorOutOfMemory); other codes are other faults */
 int zafx_alloc(int device, void** dptr, size_t bytes);
 int zafx_free(int device, void* dptr);
 int zafx_memset(int device, void* dptr, int value, size_t bytes);
@@ -154,6 +155,16 @@ int zafx_plan_row_pitch(const zafx_plan* plan, int64_t n_in, int64_t* pitch);
 /* Enqueue the transform of n_clips clips on the plan's stream (asynchronous). */
 int zafx_execute(zafx_plan* plan, const void* d_in, void* d_out, int64_t n_clips, int64_t n_in);
 int zafx_sync(zafx_plan* plan);
+/* Bytes of ONE clip on the input and on the output side of the plan for `n_in` (as zafx_plan_out_dims; rows at the
+ * plan's pitch): what a host array of n_clips clips must hold for zafx_run_host. */
+int zafx_plan_clip_bytes(const zafx_plan* plan, int64_t n_in, int64_t* in_bytes, int64_t* out_bytes);
+/* The host-array boundary of the reference (zaf.py:45: NumPy array in, NumPy array out) in one call: h_in -> HBM ->
+ * transform -> h_out, in chunks of `chunk_clips` clips (0: chosen by the library, about 128 MB per chunk) over two HIP
+ * streams with plan-owned device staging buffers, so that upload, kernel and download of neighbouring chunks overlap and
+ * the call runs at the rate of the slower PCIe direction instead of the sum of the three.  Synchronous: returns when h_out
+ * is complete.  Page-locked host arrays (zafx_host_alloc) transfer asynchronously at the PCIe rate; pageable ones work
+ * and are staged by the runtime.  Serialise with other calls on the same plan. */
+int zafx_run_host(zafx_plan* plan, const void* h_in, void* h_out, int64_t n_clips, int64_t n_in, int64_t chunk_clips);
 /* HIP-event stopwatch on the plan's stream (the stream the kernels run on). */
 int zafx_timer_start(zafx_plan* plan);
 int zafx_timer_stop(zafx_plan* plan, float* elapsed_ms);
@@ -180,6 +191,9 @@ int zafx_pcm_to_float(zafx_plan* plan, const void* d_pcm, void* d_out, int64_t n
 int zafx_comm_unique_id(void* id128 /* 128 bytes out */);
 int zafx_comm_create(zafx_comm** comm, int device, int rank, int n_ranks, const void* id128);
 int zafx_comm_destroy(zafx_comm* comm);
+/* Size of the communicator and this process's rank in it as RCCL reports them (ncclCommCount, ncclCommUserRank). */
+int zafx_comm_count(zafx_comm* comm, int* n_ranks);
+int zafx_comm_user_rank(zafx_comm* comm, int* rank);
 int zafx_comm_broadcast_constants(zafx_comm* comm, zafx_plan* plan, int root);
 
 #ifdef __cplusplus

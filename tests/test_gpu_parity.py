@@ -1384,3 +1384,102 @@ def test_device_buffer_placed_keeps_the_fastest_candidate(zafx):
     assert buf.ptr.value == seen[3]
     assert np.array_equal(buf.download(), np.full((4, 1000), 3, np.float32))   # (initialised when four probes had been made)
     buf.free()
+
+
+# ------------------------------------------------------------------ round 3: chunked double-buffered host path, RCCL record
+def test_run_host_chunks_over_two_lanes(zafx):
+    """zafx_run_host: clips in chunks over two streams (upload / kernel / download of neighbouring chunks overlap) must give
+    exactly what one chunk gives, for every chunk size (ragged last chunk, one clip per chunk, more chunks than lanes), with
+    pageable and page-locked arrays, forward and inverse kinds, both layouts and padded rows."""
+    x = np.stack([synth_clip(11, c, 30000 + 0) for c in range(11)])
+    ham, kbd = zafx.hamming(2048), zafx.kaiser_bessel_derived(2048)
+    fb = zafx.melfilterbank(44100, 2048, 128)
+    plans = [zafx.stft_plan(ham, 1024), zafx.stft_plan(ham, 1024, layout="TF"), zafx.stft_plan(ham, 1024, onesided=True),
+             zafx.stft_plan(ham, 1000, row_align=16), zafx.mdct_plan(kbd), zafx.mel_plan(ham, 1024, fb), zafx.mel_plan(ham, 1024, fb, 20)]
+    for plan in plans:
+        whole = plan.run_host(x, x.shape[1], chunk_clips=len(x))
+        for chunk in (1, 2, 3, 4, 10, 0):
+            assert np.array_equal(plan.run_host(x, x.shape[1], chunk_clips=chunk), whole), (plan.kernel_name, chunk)
+        pin_in = zafx.pinned_empty(x.shape, np.float32)
+        pin_in[:] = x
+        base_shape = plan.out_shape(len(x), x.shape[1])
+        pin_out = zafx.pinned_empty(base_shape, plan.out_dtype)
+        got = plan.run_host(pin_in, x.shape[1], out=pin_out, chunk_clips=3)
+        assert np.array_equal(got, whole)
+    ref = orc.stft_batch(x.astype(np.float64), ham, 1024)
+    got = zafx.stft_batch(x, ham, 1024)
+    for c in range(len(x)):
+        assert relerr(got[c], ref[c]) <= TOL_FFT
+    # inverse kinds: the 2-D side is the input
+    spec = got
+    inv = zafx.istft_plan(ham, 1024)
+    whole = inv.run_host(spec, spec.shape[2], chunk_clips=len(x))
+    for chunk in (1, 4, 0):
+        assert np.array_equal(inv.run_host(spec, spec.shape[2], chunk_clips=chunk), whole)
+    assert np.max(np.abs(whole[:, :x.shape[1]] - x)) < 1e-5
+    coef = zafx.mdct_batch(x, kbd)
+    imd = zafx.mdct_plan(kbd, inverse=True)
+    whole = imd.run_host(coef, coef.shape[2], chunk_clips=len(x))
+    assert np.array_equal(imd.run_host(coef, coef.shape[2], chunk_clips=2), whole)
+    # a destination of the wrong shape / dtype is refused before anything is written
+    plan = plans[0]
+    with pytest.raises(ValueError):
+        plan.run_host(x, x.shape[1], out=np.empty((11, 2048, 5), np.complex64))
+    with pytest.raises(ValueError):
+        plan.run_host(x, x.shape[1], out=np.empty(plan.out_shape(11, x.shape[1]), np.complex128))
+    # f64 plans share a scratch: one lane, same result for every chunking
+    p64 = zafx.istft_plan(ham, 1024, f64=True)
+    s64 = spec.astype(np.complex128)
+    assert np.array_equal(p64.run_host(s64, s64.shape[2], chunk_clips=2), p64.run_host(s64, s64.shape[2], chunk_clips=11))
+
+
+def test_comm_reports_what_rccl_saw(zafx):
+    comm = zafx.Comm(0, 0, 1, zafx.Comm.unique_id())
+    assert comm.count() == 1 and comm.user_rank() == 0
+    comm.destroy()
+
+
+def _two_rank_worker():
+    """Body of one rank of test_rccl_two_ranks (run as a subprocess: one process per GPU)."""
+    import hashlib
+    import sys
+    import zafx
+    from zafx import launch
+    rank, local_rank, world = launch.rank_env()
+    rdzv = launch.Rendezvous.from_env(timeout=120.0)
+    uid = rdzv.broadcast(zafx.Comm.unique_id() if rank == 0 else b"")
+    comm = zafx.Comm(local_rank, rank, world, uid)
+    assert comm.count() == world and comm.user_rank() == rank
+    ham = zafx.hamming(2048)
+    fb = zafx.melfilterbank(44100, 2048, 128)
+    # rank 1 starts from WRONG constants: only the broadcast can make its results equal rank 0's
+    plan = zafx.mel_plan(ham if rank == 0 else ham[::-1].copy(), 1024, fb, 20, device=local_rank)
+    comm.broadcast_constants(plan, root=0)
+    n_clips, n = 6, 30000
+    lo, hi = zafx.clip_range(n_clips, rank, world)
+    x = np.stack([synth_clip(21, c, n) for c in range(lo, hi)])
+    got = plan.run_host(x, n)
+    ref = np.stack([orc.mfcc(c.astype(np.float64), ham, 1024, fb, 20) for c in x])
+    err = max(relerr(g, r) for g, r in zip(got, ref))
+    parts = rdzv.all_gather(f"{lo}:{hi}:{err:.3e}:{hashlib.sha1(got.tobytes()).hexdigest()}".encode())
+    comm.destroy()
+    rdzv.close()
+    if rank == 0:
+        print("RANKS " + " ".join(p.decode() for p in parts))
+    sys.exit(0 if err <= TOL_FB else 5)
+
+
+def test_rccl_two_ranks(zafx):
+    """The real 2-rank flow wherever two GPUs exist: file rendezvous -> ncclCommInitRank -> broadcast of window / filterbank / DCT
+    rows from rank 0 over xGMI (rank 1 holds a wrong window before it) -> every rank transforms its own clip range -> parity of
+    both shards against the oracle.  Skipped on one-GPU boxes."""
+    import os
+    import sys
+    if zafx.device_count() < 2:
+        pytest.skip("needs two GPUs")
+    from zafx import launch
+    code, out = launch.spawn_ranks(["-c", "import sys; sys.path[:0] = %r; import test_gpu_parity as t; t._two_rank_worker()"
+                                    % [os.path.dirname(os.path.abspath(__file__))] + ""], 2, timeout=300)
+    assert code == 0, out
+    line = [ln for ln in out.splitlines() if ln.startswith("RANKS ")][-1].split()[1:]
+    assert [p.split(":")[:2] for p in line] == [["0", "3"], ["3", "6"]]

@@ -221,3 +221,122 @@ def test_cqt_short_kernel_embedding():
             ref, got = orc.cqtspectrogram(x, fs, tr, kern), orc.cqtspectrogram(x, fs, tr, big)
             assert got.shape == ref.shape
             assert ref.size == 0 or relerr(got, ref) <= 1e-13
+
+
+# ------------------------------------------------------------------------------------------------------
+# device-buffer pool and plan cache with a stubbed library (no GPU): round-2 advisor findings
+# ------------------------------------------------------------------------------------------------------
+class _StubLib:
+    """Stands in for libzafx.so: hands out fake device pointers and records what was freed."""
+
+    def __init__(self):
+        self.next, self.live, self.freed, self.fail_alloc_with = 0x1000, set(), [], 0
+
+    def zafx_alloc(self, device, pptr, nbytes):
+        if self.fail_alloc_with:
+            rc, self.fail_alloc_with = self.fail_alloc_with, 0
+            return rc
+        self.next += 0x1000
+        pptr._obj.value = self.next
+        self.live.add(self.next)
+        return 0
+
+    def zafx_free(self, device, ptr):
+        self.live.discard(ptr.value)
+        self.freed.append(ptr.value)
+        return 0
+
+    def zafx_last_error(self):
+        return b"stub"
+
+
+@pytest.fixture
+def stub_pool(monkeypatch):
+    from zafx import _lib, core
+    stub = _StubLib()
+    monkeypatch.setattr(_lib, "load", lambda: stub)
+    monkeypatch.setattr(core.DeviceBuffer, "_pool", {})
+    monkeypatch.setattr(core.DeviceBuffer, "_pool_bytes", [0])
+    monkeypatch.setattr(core.DeviceBuffer, "_POOL_CAP", 1000)
+    return stub, core.DeviceBuffer
+
+
+def test_pool_eviction_skips_size_classes_emptied_by_pooled(stub_pool):
+    """pooled() popped the last pointer of the oldest size class and left its empty list at the head of the
+    eviction order; the next release() that had to evict raised IndexError out of run_host's finally block."""
+    stub, DB = stub_pool
+    a = DB((400,), np.uint8)
+    a.release()                      # oldest size class: 400 bytes parked
+    b = DB((500,), np.uint8)
+    b.release()                      # 900 of 1000 bytes parked
+    got = DB.pooled((400,), np.uint8)   # takes the 400-byte pointer back: its class is now empty
+    assert (0, 400) not in DB._pool and DB._pool_bytes[0] == 500
+    c = DB((600,), np.uint8)
+    c.release()                      # must evict the 500-byte class (500 + 600 > 1000), not trip over an empty list
+    assert DB._pool_bytes[0] == 600 and list(DB._pool) == [(0, 600)]
+    assert b.ptr.value is None or not b.ptr.value
+    got.release()
+    assert DB._pool_bytes[0] == 1000
+    DB.drain_pool()
+    assert not stub.live and DB._pool_bytes[0] == 0
+
+
+def test_pool_is_drained_only_when_the_device_is_out_of_memory(stub_pool):
+    stub, DB = stub_pool
+    from zafx import _lib
+    DB((300,), np.uint8).release()
+    stub.fail_alloc_with = 101       # any other error (an invalid device ordinal, say): the pool stays
+    with pytest.raises(zafx.ZafxError):
+        DB((10,), np.uint8)
+    assert DB._pool_bytes[0] == 300
+    stub.fail_alloc_with = _lib.ERROR_OUT_OF_MEMORY
+    keep = DB((10,), np.uint8)       # out of memory: parked allocations of that device are given back, one retry
+    assert DB._pool_bytes[0] == 0 and len(stub.freed) == 1 and keep.ptr.value in stub.live
+
+
+def test_plan_cache_builds_outside_its_lock(monkeypatch):
+    """the factory of a missing plan ran under the cache lock (a 2 GB dct matrix stalled every other lookup)."""
+    import threading
+    from zafx import core
+    monkeypatch.setattr(core, "_cache", {})
+    seen = []
+
+    class FakePlan:
+        def __init__(self, tag):
+            self.tag, self.destroyed = tag, False
+
+        def destroy(self):
+            self.destroyed = True
+
+    def slow_factory():
+        seen.append(core._cache_lock.acquire(blocking=False))   # the lock is free while a plan is being built
+        if seen[-1]:
+            core._cache_lock.release()
+        return FakePlan("a")
+
+    p = core._cached(("k",), slow_factory)
+    assert seen == [True] and core._cached(("k",), lambda: FakePlan("b")) is p
+    # two threads missing on one key: one plan survives, the other is destroyed
+    gate, made = threading.Barrier(2), []
+
+    def racing_factory():
+        gate.wait(timeout=10)
+        made.append(FakePlan("r"))
+        return made[-1]
+
+    out = []
+    ts = [threading.Thread(target=lambda: out.append(core._cached(("race",), racing_factory))) for _ in range(2)]
+    for t in ts:
+        t.start()
+    for t in ts:
+        t.join()
+    assert out[0] is out[1] and len(made) == 2 and sorted(m.destroyed for m in made) == [False, True]
+
+
+def test_f64_window_limits_are_checked_on_the_host():
+    """f64=True with a window of 2049 ... 8191 samples that is not a power of two reached zafx_plan_create."""
+    w = np.ones(3000)
+    for call in (lambda: zafx.stft_plan(w, 500, f64=True), lambda: zafx.istft_plan(w, 500, f64=True),
+                 lambda: zafx.mdct_plan(w, f64=True)):
+        with pytest.raises(ValueError):
+            call()

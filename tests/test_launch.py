@@ -114,3 +114,45 @@ def test_rendezvous_directory_names_the_launcher_instance(monkeypatch):
         assert launch._start_time(os.getppid()) > 0 and launch._start_time(2 ** 30) == 0
     finally:
         a.close()
+
+
+def test_rendezvous_fails_fast_on_a_multi_node_launch(monkeypatch):
+    """global RANK / WORLD_SIZE with a node-local directory blocked for the whole timeout."""
+    from zafx import launch
+    monkeypatch.setenv("RANK", "3")
+    monkeypatch.setenv("WORLD_SIZE", "16")
+    monkeypatch.setenv("LOCAL_WORLD_SIZE", "8")
+    with pytest.raises(RuntimeError, match="ONE node"):
+        launch.Rendezvous.from_env()
+
+
+def test_rendezvous_directory_is_private_and_stale_files_are_ignored(tmp_path, monkeypatch):
+    from zafx import launch
+    d = tmp_path / "shared"
+    d.mkdir(mode=0o777)
+    os.chmod(d, 0o777)
+    with pytest.raises(PermissionError):          # a directory other users can write to is refused
+        launch.Rendezvous(str(d), 0, 1)
+    os.chmod(d, 0o700)
+    (d / "000001_bcast").write_bytes(b"stale id of a job that died")   # what a reused ZAFX_RDZV_DIR may hold
+    monkeypatch.setenv("ZAFX_RDZV_DIR", str(d))
+    monkeypatch.setenv("RANK", "0")
+    monkeypatch.setenv("WORLD_SIZE", "1")
+    monkeypatch.delenv("LOCAL_WORLD_SIZE", raising=False)
+    rv = launch.Rendezvous.from_env(timeout=5.0)
+    assert rv.ns and rv.broadcast(b"fresh") == b"fresh"
+    assert rv.get("000001_bcast") == b"fresh"     # this job's key, not the stale file of the same number
+    rv.close()
+    assert (d / "000001_bcast").exists()          # another job's file is not ours to delete
+
+
+@pytest.mark.timeout(60)
+def test_spawn_ranks_stops_the_others_when_a_rank_dies(tmp_path):
+    """rank 1 crashing left rank 0 waiting out the rendezvous timeout."""
+    import time
+    from zafx import launch
+    script = tmp_path / "ranks.py"
+    script.write_text("import os, sys, time\nif os.environ['RANK'] == '1':\n    sys.exit(7)\ntime.sleep(300)\n")
+    t0 = time.monotonic()
+    code, out = launch.spawn_ranks([str(script)], 2)
+    assert code == 7 and time.monotonic() - t0 < 30

@@ -3,7 +3,7 @@
 // convolutions on the tuned FFT core (zafx_fft.hpp).
 //
 //   n k = (n^2 + k^2 - (k - n)^2) / 2,   c[n] = exp(-i pi n^2 / W)   =>   X[k] = c[k] sum_n (x[n] c[n]) conj(c)[k - n]:
-// a W-point DFT is a convolution of length M = 2^ceil(log2(2 W - 1)) <= 4096 for W <= 2048.  The host provides c (exact
+// a W-point DFT is a convolution of length M = 2^ceil(log2(2 W - 1)) <= 16384 for W <= 8192 (bs32_supported).  The host provides c (exact
 // angle reduction in integers) and Bhat = FFT_M(conj(c) wrapped), both evaluated in long double; one workgroup of M / 16
 // threads owns a frame: a = x w c -> FFT_M (radix-16 passes, frame in LDS) -> conj(. Bhat) -> FFT_M -> c conj(.) / M.
 // The float64 forms of zafx_f64.hip (one radix-2 pass per barrier) ran these windows at 3.4 Gsamples/s (W = 1764, hop 441);

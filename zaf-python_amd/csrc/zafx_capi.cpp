@@ -755,6 +755,12 @@ int zafx_plan_destroy(zafx_plan* pl) {
     if (pl->d_bs_bhat) (void)hipFree(pl->d_bs_bhat);
     free_band(pl->fb);
     free_band(pl->dct);
+    if (pl->stream2) (void)hipStreamSynchronize(pl->stream2);
+    for (int l = 0; l < 2; ++l) {
+        if (pl->lane_in[l]) (void)hipFree(pl->lane_in[l]);
+        if (pl->lane_out[l]) (void)hipFree(pl->lane_out[l]);
+    }
+    if (pl->stream2) (void)hipStreamDestroy(pl->stream2);
     if (pl->ev0) (void)hipEventDestroy(pl->ev0);
     if (pl->ev1) (void)hipEventDestroy(pl->ev1);
     if (pl->stream) (void)hipStreamDestroy(pl->stream);
@@ -969,6 +975,113 @@ int zafx_sync(zafx_plan* pl) {
     return 0;
 }
 
+// Bytes of ONE clip on either side of the plan for `n_in` (as zafx_plan_out_dims): the caller's host arrays hold
+// n_clips x these, C-contiguous, rows at the plan's pitch.
+static int clip_bytes(const zafx_plan* pl, int64_t n_in, int64_t* in_b, int64_t* out_b) {
+    int64_t dims[2], pitch = 0;
+    if (int rc = zafx_plan_out_dims(pl, n_in, dims)) return rc;
+    if (int rc = zafx_plan_row_pitch(pl, n_in, &pitch)) return rc;
+    const bool f64 = pl->prm.precision == ZAFX_PRECISION_F64;
+    const int64_t real = f64 ? 8 : 4, cplx = 2 * real;
+    const bool ft = pl->layout == ZAFX_LAYOUT_FT;
+    switch (pl->kind) {
+        case ZAFX_STFT: {
+            const int64_t e = pl->prm.spectrum >= ZAFX_SPECTRUM_MAGNITUDE ? real : cplx;
+            *in_b = n_in * real;
+            *out_b = (ft ? dims[0] * pitch : dims[1] * dims[0]) * e;
+            return 0;
+        }
+        case ZAFX_MDCT: case ZAFX_MEL: case ZAFX_MFCC: case ZAFX_CQT: case ZAFX_CHROMA:
+            *in_b = n_in * real;
+            *out_b = (ft ? dims[0] * pitch : dims[1] * dims[0]) * real;
+            return 0;
+        case ZAFX_ISTFT: {
+            const int64_t rows = pl->prm.spectrum != ZAFX_SPECTRUM_TWO_SIDED ? pl->W / 2 + 1 : pl->W;
+            *in_b = (ft ? rows * pitch : n_in * rows) * cplx;
+            *out_b = dims[0] * real;
+            return 0;
+        }
+        case ZAFX_IMDCT:
+            *in_b = (ft ? (int64_t)(pl->W / 2) * pitch : n_in * (pl->W / 2)) * real;
+            *out_b = dims[0] * real;
+            return 0;
+        case ZAFX_LINEAR:
+            *in_b = (int64_t)pl->W * 4;
+            *out_b = dims[0] * 4;
+            return 0;
+    }
+    return fail_msg("unknown plan kind");
+}
+
+int zafx_plan_clip_bytes(const zafx_plan* pl, int64_t n_in, int64_t* in_bytes, int64_t* out_bytes) {
+    if (!pl || !in_bytes || !out_bytes) return fail_msg("null argument");
+    return clip_bytes(pl, n_in, in_bytes, out_bytes);
+}
+
+// Host array in -> transform -> host array out, in chunks of clips over two lanes (stream + device staging buffers each):
+// lane A's download runs while lane B uploads and transforms, so the three phases that zafx_h2d / zafx_execute / zafx_d2h run
+// one after the other overlap and the call approaches the rate of the slower PCIe direction alone.  Every lane's operations
+// are ordered by its own stream (upload c -> kernel c -> download c -> upload c + 2 ...), so the staging buffers need no
+// events.  Page-locked host arrays (zafx_host_alloc) make the copies asynchronous; pageable ones are staged by the runtime
+// (correct, slower).  Plans whose kernels share a plan-owned scratch (float64 and Bluestein inverse forms) take one lane.
+int zafx_run_host(zafx_plan* pl, const void* h_in, void* h_out, int64_t n_clips, int64_t n_in, int64_t chunk_clips) {
+    if (!pl) return fail_msg("null plan");
+    if (n_clips < 0 || n_in < 0) return fail_msg("negative size");
+    if (n_clips == 0) return 0;
+    if (!h_in || !h_out) return fail_msg("null host pointer");
+    int64_t in_b = 0, out_b = 0;
+    if (int rc = clip_bytes(pl, n_in, &in_b, &out_b)) return rc;
+    ZAFX_HIP(hipSetDevice(pl->device));
+    if (chunk_clips <= 0) {
+        // default: chunks of about 128 MB (both sides together): a few ms of PCIe each, so the pipeline fills quickly and
+        // the fixed costs per chunk (launch, copy set-up: tens of microseconds) stay below a percent
+        chunk_clips = std::max<int64_t>(1, (int64_t)(128 << 20) / std::max<int64_t>(in_b + out_b, 1));
+    }
+    chunk_clips = std::min(chunk_clips, n_clips);
+    const int64_t n_chunks = (n_clips + chunk_clips - 1) / chunk_clips;
+    const bool shared_scratch = pl->prm.precision == ZAFX_PRECISION_F64 || pl->bs_log2m > 0;
+    const int lanes = (n_chunks > 1 && !shared_scratch) ? 2 : 1;
+    if (lanes == 2 && !pl->stream2) ZAFX_HIP(hipStreamCreateWithFlags(&pl->stream2, hipStreamNonBlocking));
+    for (int l = 0; l < lanes; ++l) {   // grow-only staging buffers
+        const size_t need_in = (size_t)std::max<int64_t>(chunk_clips * in_b, 1), need_out = (size_t)std::max<int64_t>(chunk_clips * out_b, 1);
+        if (pl->lane_in_bytes[l] < need_in) {
+            if (pl->lane_in[l]) ZAFX_HIP(hipFree(pl->lane_in[l]));
+            pl->lane_in[l] = nullptr, pl->lane_in_bytes[l] = 0;
+            ZAFX_HIP(hipMalloc(&pl->lane_in[l], need_in));
+            pl->lane_in_bytes[l] = need_in;
+        }
+        if (pl->lane_out_bytes[l] < need_out) {
+            if (pl->lane_out[l]) ZAFX_HIP(hipFree(pl->lane_out[l]));
+            pl->lane_out[l] = nullptr, pl->lane_out_bytes[l] = 0;
+            ZAFX_HIP(hipMalloc(&pl->lane_out[l], need_out));
+            pl->lane_out_bytes[l] = need_out;
+        }
+    }
+    hipStream_t const main_stream = pl->stream;
+    hipStream_t streams[2] = {main_stream, pl->stream2};
+    int ret = 0;
+    for (int64_t c = 0; c < n_chunks && !ret; ++c) {
+        const int l = (int)(c % lanes);
+        const int64_t first = c * chunk_clips, count = std::min(chunk_clips, n_clips - first);
+        hipError_t e = hipSuccess;
+        if (count * in_b > 0)
+            e = hipMemcpyAsync(pl->lane_in[l], (const char*)h_in + first * in_b, (size_t)(count * in_b), hipMemcpyHostToDevice, streams[l]);
+        if (e != hipSuccess) { ret = fail("zafx_run_host: upload", e); break; }
+        pl->stream = streams[l];   // the launchers enqueue on plan.stream
+        ret = zafx_execute(pl, pl->lane_in[l], pl->lane_out[l], count, n_in);
+        pl->stream = main_stream;
+        if (ret) break;
+        if (count * out_b > 0)
+            e = hipMemcpyAsync((char*)h_out + first * out_b, pl->lane_out[l], (size_t)(count * out_b), hipMemcpyDeviceToHost, streams[l]);
+        if (e != hipSuccess) { ret = fail("zafx_run_host: download", e); break; }
+    }
+    for (int l = 0; l < lanes; ++l) {   // (also after an error: nothing of this call is left in flight)
+        hipError_t e = hipStreamSynchronize(streams[l]);
+        if (e != hipSuccess && !ret) ret = fail("zafx_run_host: sync", e);
+    }
+    return ret;
+}
+
 int zafx_timer_start(zafx_plan* pl) {
     if (!pl) return fail_msg("null plan");
     ZAFX_HIP(hipSetDevice(pl->device));
@@ -1022,6 +1135,8 @@ struct rccl_api {
     int (*CommDestroy)(void*) = nullptr;
     int (*Broadcast)(const void*, void*, size_t, int, int, void*, hipStream_t) = nullptr;
     const char* (*GetErrorString)(int) = nullptr;
+    int (*CommCount)(void*, int*) = nullptr;
+    int (*CommUserRank)(void*, int*) = nullptr;
 };
 
 static rccl_api g_rccl;
@@ -1040,6 +1155,8 @@ static int rccl_load() {
     g_rccl.CommDestroy = (int (*)(void*))dlsym(h, "ncclCommDestroy");
     g_rccl.Broadcast = (int (*)(const void*, void*, size_t, int, int, void*, hipStream_t))dlsym(h, "ncclBroadcast");
     g_rccl.GetErrorString = (const char* (*)(int))dlsym(h, "ncclGetErrorString");
+    g_rccl.CommCount = (int (*)(void*, int*))dlsym(h, "ncclCommCount");
+    g_rccl.CommUserRank = (int (*)(void*, int*))dlsym(h, "ncclCommUserRank");
     if (!g_rccl.GetUniqueId || !g_rccl.CommInitRank || !g_rccl.CommDestroy || !g_rccl.Broadcast)
         return fail_msg("librccl lacks a required symbol");
     g_rccl.lib = h;
@@ -1095,6 +1212,21 @@ int zafx_comm_destroy(zafx_comm* c) {
     }
     delete c;
     return 0;
+}
+
+// What the communicator itself says about its size and this process's place in it (ncclCommCount / ncclCommUserRank):
+// the record of a multi-GPU run quotes these, not the launcher's environment.
+int zafx_comm_count(zafx_comm* c, int* n_ranks) {
+    if (!c || !n_ranks) return fail_msg("null argument");
+    if (!c->comm || !g_rccl.CommCount) return fail_msg("librccl lacks ncclCommCount");
+    int rc = g_rccl.CommCount(c->comm, n_ranks);
+    return rc ? rccl_fail("ncclCommCount", rc) : 0;
+}
+int zafx_comm_user_rank(zafx_comm* c, int* rank) {
+    if (!c || !rank) return fail_msg("null argument");
+    if (!c->comm || !g_rccl.CommUserRank) return fail_msg("librccl lacks ncclCommUserRank");
+    int rc = g_rccl.CommUserRank(c->comm, rank);
+    return rc ? rccl_fail("ncclCommUserRank", rc) : 0;
 }
 
 // Broadcast every constant the plan kind uses from `root`: an 8-byte length header,

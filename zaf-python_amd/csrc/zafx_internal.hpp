@@ -62,6 +62,11 @@ struct zafx_plan {
     zafx_params prm{};
     hipStream_t stream = nullptr;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    // zafx_run_host: second lane's stream and both lanes' device staging buffers (grow-only, freed with the plan)
+    hipStream_t stream2 = nullptr;
+    void* lane_in[2] = {nullptr, nullptr};
+    void* lane_out[2] = {nullptr, nullptr};
+    size_t lane_in_bytes[2] = {0, 0}, lane_out_bytes[2] = {0, 0};
 
     int W = 0;        // window length (or CQT fft_length)
     int H = 0;        // hop / step
@@ -144,7 +149,8 @@ const char* mdct_f64_kernel_name();
 const char* mel_f64_kernel_name();
 const char* cqt_f64_kernel_name();
 const char* imdct_f64_kernel_name();
-// float32 Bluestein forms (zafx_bs32.hip): windows of 33 ... 2048 samples that are not a power of two
+// float32 Bluestein forms (zafx_bs32.hip): windows of 33 ... 8192 samples that are not a power of two (convolution length
+// M = 2^ceil(log2(2 W - 1)) <= 16384, about 139 KB of LDS per frame); the float64 Bluestein forms stop at 2048 samples
 bool bs32_supported(int W);
 hipError_t launch_stft_bs32(const zafx_plan& pl, const float* x, float2* out, int64_t n_clips, int64_t n_samples, int T);
 hipError_t launch_istft_bs32(zafx_plan& pl, const float2* spec, float* y, int64_t n_clips, int T, int64_t out_len);

@@ -291,7 +291,14 @@ __global__ __launch_bounds__(kFatWaves * 64) void k_stft_ft16(
             if constexpr (E >= 32) asm volatile("" : "+v"(kqo));
             auto store_tile = [&](auto stream) {
                 constexpr bool ST = decltype(stream)::value;
+#ifdef ZAFX_STFT_ROWROT   // experiment (tools/placement.py): every workgroup starts its row sweep somewhere else
+                constexpr int ITER = (N / 2) / (NT / FPB);
+                const int rot = ((int)blockIdx.x >> 3) * ZAFX_STFT_ROWROT;
+                for (int it = 0; it < ITER; ++it) {
+                    const int k = kqo + ((it + rot) % ITER) * (NT / FPB);
+#else
                 for (int k = kqo; k < N / 2; k += NT / FPB) {
+#endif
                     if (k == 0) {
                         const float2 z0 = fb[0], zc = fb[phys_t<C::PS>(N / 2)];
                         put_bin<SPEC, ST>(o, 0, make_float2(z0.x + z0.y, 0.f));
@@ -310,8 +317,11 @@ __global__ __launch_bounds__(kFatWaves * 64) void k_stft_ft16(
             };
             // whole-line rows (pitch and base multiples of 128 B) stream past L2; rows that straddle lines keep the
             // write-combining of ordinary stores (non-temporal partial lines: T = 433, 1.11 -> 1.51 ms per 256 clips)
+#ifndef ZAFX_STFT_NO_NT
             if (SPEC < 2 && lines_whole) store_tile(std::true_type{});
-            else store_tile(std::false_type{});
+            else
+#endif
+                store_tile(std::false_type{});
         }
         PROF_MARK(4);
         lds_barrier();   // LDS reads of the tile are done; its global stores are NOT waited for

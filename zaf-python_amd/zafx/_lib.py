@@ -20,6 +20,10 @@ PRECISION_F32, PRECISION_F64 = 0, 1
 CONST_WINDOW, CONST_MEL_FB, CONST_DCT, CONST_CQT_INDPTR, CONST_CQT_INDICES, CONST_CQT_VALUES, CONST_MATRIX = 1, 2, 3, 4, 5, 6, 7
 
 
+# return code of zafx_alloc when the device is out of memory (ZAFX_ERROR_OUT_OF_MEMORY in include/zafx.h = hipErrorOutOfMemory)
+ERROR_OUT_OF_MEMORY = 2
+
+
 class ZafxParams(ctypes.Structure):
     _fields_ = [
         ("struct_size", ctypes.c_int32),
@@ -64,6 +68,8 @@ SYMBOLS = {
     "zafx_plan_row_pitch": (_i, [_vp, _i64, ctypes.POINTER(_i64)]),
     "zafx_execute": (_i, [_vp, _vp, _vp, _i64, _i64]),
     "zafx_sync": (_i, [_vp]),
+    "zafx_plan_clip_bytes": (_i, [_vp, _i64, ctypes.POINTER(_i64), ctypes.POINTER(_i64)]),
+    "zafx_run_host": (_i, [_vp, _vp, _vp, _i64, _i64, _i64]),
     "zafx_timer_start": (_i, [_vp]),
     "zafx_timer_stop": (_i, [_vp, ctypes.POINTER(ctypes.c_float)]),
     "zafx_plan_kernel_name": (_i, [_vp, ctypes.c_char_p, _sz]),
@@ -72,6 +78,8 @@ SYMBOLS = {
     "zafx_comm_unique_id": (_i, [_vp]),
     "zafx_comm_create": (_i, [ctypes.POINTER(_vp), _i, _i, _i, _vp]),
     "zafx_comm_destroy": (_i, [_vp]),
+    "zafx_comm_count": (_i, [_vp, ctypes.POINTER(_i)]),
+    "zafx_comm_user_rank": (_i, [_vp, ctypes.POINTER(_i)]),
     "zafx_comm_broadcast_constants": (_i, [_vp, _vp, _i]),
 }
 

@@ -71,8 +71,10 @@ class DeviceBuffer:
             return
         p = ctypes.c_void_p()
         rc = _lib.load().zafx_alloc(self.device, ctypes.byref(p), self.nbytes)
-        if rc != 0 and DeviceBuffer._pool_bytes[0] > 0:   # out of device memory with allocations parked in the pool: give them back, retry once
-            DeviceBuffer.drain_pool()
+        if rc == _lib.ERROR_OUT_OF_MEMORY and DeviceBuffer._pool_bytes[0] > 0:
+            # out of device memory with allocations parked in the pool: give back those of THIS device, retry once
+            # (any other error -- a bad device index, say -- leaves the pool alone)
+            DeviceBuffer.drain_pool(self.device)
             rc = _lib.load().zafx_alloc(self.device, ctypes.byref(p), self.nbytes)
         _lib.check(rc, "zafx_alloc")
         self.ptr = p
@@ -87,10 +89,13 @@ class DeviceBuffer:
     def pooled(cls, shape, dtype, device=0):
         probe_bytes = int(np.prod([int(s) for s in np.atleast_1d(shape)], dtype=np.int64)) * np.dtype(dtype).itemsize
         with cls._pool_lock:
-            free = cls._pool.get((int(device), probe_bytes))
+            key = (int(device), probe_bytes)
+            free = cls._pool.get(key)
             ptr = free.pop() if free else None
             if ptr is not None:
                 cls._pool_bytes[0] -= probe_bytes
+            if free is not None and not free:
+                del cls._pool[key]   # (an empty size class must not sit at the head of the eviction order, see release)
         return cls(shape, dtype, device, _ptr_from_pool=ptr) if ptr is not None else cls(shape, dtype, device)
 
     def release(self):
@@ -106,6 +111,9 @@ class DeviceBuffer:
             while self._pool_bytes[0] + self.nbytes > self._POOL_CAP and self._pool:
                 key = next(iter(self._pool))            # dicts keep insertion order: the size class parked first
                 ptrs = self._pool[key]
+                if not ptrs:                            # (never left behind by pooled(); kept as a guard)
+                    del self._pool[key]
+                    continue
                 evicted.append((key[0], ptrs.pop(0)))
                 self._pool_bytes[0] -= key[1]
                 if not ptrs:
@@ -117,13 +125,16 @@ class DeviceBuffer:
             _lib.load().zafx_free(device, ptr)
 
     @classmethod
-    def drain_pool(cls):
+    def drain_pool(cls, device=None):
+        """Free the parked allocations (of one device, or of all)."""
         with cls._pool_lock:
-            items, cls._pool = cls._pool, {}
-            cls._pool_bytes[0] = 0
-        for (device, _), ptrs in items.items():
+            items = {k: v for k, v in cls._pool.items() if device is None or k[0] == int(device)}
+            for k, ptrs in items.items():
+                del cls._pool[k]
+                cls._pool_bytes[0] -= k[1] * len(ptrs)
+        for (dev, _), ptrs in items.items():
             for p in ptrs:
-                _lib.load().zafx_free(device, p)
+                _lib.load().zafx_free(dev, p)
 
     @classmethod
     def from_host(cls, array, device=0):
@@ -344,8 +355,19 @@ class Plan:
         _lib.check(_lib.load().zafx_plan_kernel_name(self.handle, buf, 128), "zafx_plan_kernel_name")
         return buf.value.decode()
 
-    def run_host(self, array, n_in):
-        """Host array in -> device transform -> host array out (PCIe both ways)."""
+    def clip_bytes(self, n_in):
+        """(input bytes, output bytes) of ONE clip for `n_in` (zafx_plan_clip_bytes; rows at the plan's pitch)."""
+        a, b = ctypes.c_int64(), ctypes.c_int64()
+        _lib.check(_lib.load().zafx_plan_clip_bytes(self.handle, int(n_in), ctypes.byref(a), ctypes.byref(b)), "zafx_plan_clip_bytes")
+        return int(a.value), int(b.value)
+
+    def run_host(self, array, n_in, out=None, chunk_clips=0):
+        """Host array in -> device transform -> host array out: the reference's own boundary (zaf.py:45), PCIe both ways.
+
+        One call of zafx_run_host: the clips travel in chunks over two HIP streams with plan-owned staging buffers in HBM,
+        so the upload, the kernel and the download of neighbouring chunks overlap.  `out`: destination array of
+        Plan.out_shape(n_clips, n_in) and Plan.out_dtype -- with page-locked arrays on both sides (pinned_empty, reused
+        across calls) the call runs at the PCIe rate of its slower direction; pageable arrays work and are staged."""
         array = np.asarray(array)
         if np.iscomplexobj(array) and self.in_dtype.kind != "c":
             raise ValueError("this plan takes real input")
@@ -360,18 +382,19 @@ class Plan:
                 padded[:, :, :array.shape[2]] = array
                 array = padded
         shape = self.out_shape(n_clips, n_in)
-        d_in = DeviceBuffer.pooled(array.shape, array.dtype, self.device)
-        d_out = DeviceBuffer.pooled(shape, self.out_dtype, self.device)
-        try:
-            d_in.upload(array)
+        if out is None:
+            out = np.empty(shape, dtype=self.out_dtype)
+        elif tuple(out.shape) != tuple(shape) or out.dtype != self.out_dtype or not out.flags.c_contiguous or not out.flags.writeable:
+            raise ValueError(f"out must be a writeable C-contiguous {self.out_dtype} array of shape {tuple(shape)}")
+        in_b, out_b = self.clip_bytes(n_in)
+        if array.nbytes != n_clips * in_b or out.nbytes != n_clips * out_b:   # (the library walks both arrays by these sizes)
+            raise ValueError(f"array sizes do not match the plan: {array.nbytes} B in for {n_clips} clips of {in_b} B, "
+                             f"{out.nbytes} B out for clips of {out_b} B")
+        if n_clips and out.nbytes:
             with self.lock:
-                self.execute(d_in, d_out, n_clips, n_in)
-                self.sync()
-            out = d_out.download()
-            return out if frames is None else out[:, :, :frames]
-        finally:
-            d_in.release()
-            d_out.release()
+                _lib.check(_lib.load().zafx_run_host(self.handle, _ptr(array), _ptr(out), n_clips, int(n_in), int(chunk_clips)),
+                           "zafx_run_host")
+        return out if frames is None else out[:, :, :frames]
 
     def destroy(self):
         if getattr(self, "handle", None) is not None and self.handle.value:
@@ -403,6 +426,18 @@ class Comm:
         self.handle = h
         self.rank, self.n_ranks = int(rank), int(n_ranks)
 
+    def count(self):
+        """Number of ranks in the communicator as RCCL reports it (ncclCommCount)."""
+        n = ctypes.c_int(0)
+        _lib.check(_lib.load().zafx_comm_count(self.handle, ctypes.byref(n)), "zafx_comm_count")
+        return n.value
+
+    def user_rank(self):
+        """This process's rank as RCCL reports it (ncclCommUserRank)."""
+        n = ctypes.c_int(-1)
+        _lib.check(_lib.load().zafx_comm_user_rank(self.handle, ctypes.byref(n)), "zafx_comm_user_rank")
+        return n.value
+
     def broadcast_constants(self, plan, root=0):
         _lib.check(_lib.load().zafx_comm_broadcast_constants(self.handle, plan.handle, int(root)), "zafx_comm_broadcast_constants")
 
@@ -432,14 +467,24 @@ def _digest(*arrays):
 
 
 def _cached(key, factory):
+    """The plan under `key`, built by `factory()` on a miss.  The factory runs OUTSIDE the cache lock (a dct / dst plan builds
+    an N x N float64 matrix, O(N^2) trigonometry: other threads' lookups must not wait for it); when two threads miss on the
+    same key at once both build, the first insert wins and the loser's plan is destroyed."""
+    with _cache_lock:
+        plan = _cache.get(key)
+    if plan is not None:
+        return plan
+    fresh = factory()
     with _cache_lock:
         plan = _cache.get(key)
         if plan is None:
             if len(_cache) >= _CACHE_MAX:
                 _cache.pop(next(iter(_cache)))   # freed by Plan.__del__ once no caller still holds it
-            plan = factory()
-            _cache[key] = plan
-        return plan
+            _cache[key] = plan = fresh
+            fresh = None
+    if fresh is not None:
+        fresh.destroy()
+    return plan
 
 
 def clear_plan_cache():
@@ -482,6 +527,13 @@ def _as_window(window_function, any_length=False):
     if not _tuned(n):
         raise ValueError(f"zafx kernels need a power-of-two window_length in [64, 8192], got {n}")
     return w
+
+
+def _check_f64_window(n, f64):
+    """float64 plans take the powers of two 64 ... 8192 and any other length up to 2048 (the float64 Bluestein forms stop
+    there; the float32 ones reach 8192): validated here, ahead of the device."""
+    if f64 and not _pow2(n) and n > 2048:
+        raise ValueError(f"f64=True takes windows that are not a power of two only up to 2048 samples, got {n}")
 
 
 def _as_step(step_length):
@@ -536,6 +588,7 @@ def stft_plan(window_function, step_length, layout="FT", device=0, onesided=Fals
     Plan.out_dtype tell which arrays it takes."""
     w, h = _as_window(window_function, any_length=True), _as_step(step_length)   # (a hop above the window skips samples, as zaf.stft does)
     f64 = bool(f64) or not _f32_window(len(w))   # (windows below 33 samples: float64 Bluestein kernels)
+    _check_f64_window(len(w), f64)
     key = ("stft", device, len(w), h, _LAYOUTS[layout], _spectrum_of(onesided), bool(f64), _as_row_align(row_align, layout), _digest(w))
 
     def make():
@@ -556,6 +609,7 @@ def istft_plan(window_function, step_length, layout="FT", device=0, onesided=Fal
     # that cover one sample -- and for every window that is not a power of two -- the library takes the float32 frames +
     # gather overlap-add form of zafx_bs32.hip, which has no such limit (zafx_plan_create decides)
     f64 = bool(f64) or not _f32_window(len(w))
+    _check_f64_window(len(w), f64)
     key = ("istft", device, len(w), h, _LAYOUTS[layout], bool(onesided), bool(f64), _as_row_align(row_align, layout), _digest(w))
 
     def make():
@@ -571,6 +625,7 @@ def mdct_plan(window_function, layout="FT", device=0, inverse=False, row_align=0
     if len(w) % 2 or len(w) < 4:
         raise ValueError("the MDCT needs an even window_length >= 4")
     f64 = bool(f64) or not _f32_window(len(w))   # (even lengths below 34: float64 Bluestein kernels)
+    _check_f64_window(len(w), f64)
     key = ("imdct" if inverse else "mdct", device, len(w), _LAYOUTS[layout], _as_row_align(row_align, layout), bool(f64), _digest(w))
 
     def make():
@@ -699,21 +754,24 @@ def linear_plan(matrix, device=0):
 # ======================================================================================
 # batched API (build-defined extension): (clips, samples) float32 in, float32/complex64 out
 # ======================================================================================
-def stft_batch(clips, window_function, step_length, layout="FT", device=0, onesided=False, f64=False):
+def stft_batch(clips, window_function, step_length, layout="FT", device=0, onesided=False, f64=False, out=None):
     """(B, N) -> (B, W, T) complex64 [layout "FT"] or (B, T, W) ["TF"].
+
+    out (every *_batch function): destination array of the plan's output shape and dtype, e.g. a reused zafx.pinned_empty
+    array -- with page-locked arrays on both sides the chunked, double-buffered transfer (Plan.run_host) runs at the PCIe rate.
 
     onesided=True keeps rows 0..W/2 only -- what every example of the reference slices out of the
     result (zaf.py:83) -- and halves the bytes written; onesided="magnitude" / "power" returns |X| / |X|^2
     of those rows as a real array."""
     x = _as_clips(clips, dtype=np.float64 if f64 else np.float32)
     plan = stft_plan(window_function, step_length, layout, device, onesided, f64)
-    out = plan.run_host(x.astype(plan.in_dtype, copy=False), x.shape[1])
+    out = plan.run_host(x.astype(plan.in_dtype, copy=False), x.shape[1], out=out)
     if f64 or not plan.f64:
         return out
     return out.astype(np.complex64 if np.iscomplexobj(out) else np.float32)   # (computed in float64: window not a power of two)
 
 
-def istft_batch(spectra, window_function, step_length, layout="FT", device=0, onesided=False, f64=False):
+def istft_batch(spectra, window_function, step_length, layout="FT", device=0, onesided=False, f64=False, out=None):
     """(B, W, T) ["FT"] or (B, T, W) ["TF"] complex -> (B, T*H - (W-H)) float32.
 
     onesided=True takes rows 0..W/2 and completes X[W-k] = conj X[k]: the result equals the two-sided
@@ -726,19 +784,19 @@ def istft_batch(spectra, window_function, step_length, layout="FT", device=0, on
     if wl != (len(w) // 2 + 1 if onesided else len(w)):
         raise ValueError("spectrum rows must equal window_length (window_length/2 + 1 when onesided)")
     plan = istft_plan(w, step_length, layout, device, onesided, f64)
-    out = plan.run_host(np.ascontiguousarray(s, dtype=plan.in_dtype), nt)
+    out = plan.run_host(np.ascontiguousarray(s, dtype=plan.in_dtype), nt, out=out)
     return out if f64 else out.astype(np.float32, copy=False)   # (a very small hop is computed in float64 whatever f64 says)
 
 
-def mdct_batch(clips, window_function, layout="FT", device=0, f64=False):
+def mdct_batch(clips, window_function, layout="FT", device=0, f64=False, out=None):
     """(B, N) -> (B, W/2, T) float32 ["FT"] or (B, T, W/2) ["TF"]; f64: float64 arrays and arithmetic."""
     x = _as_clips(clips, dtype=np.float64 if f64 else np.float32)
     plan = mdct_plan(window_function, layout, device, f64=f64)
-    out = plan.run_host(x.astype(plan.in_dtype, copy=False), x.shape[1])
+    out = plan.run_host(x.astype(plan.in_dtype, copy=False), x.shape[1], out=out)
     return out if f64 else out.astype(np.float32, copy=False)
 
 
-def imdct_batch(coefficients, window_function, layout="FT", device=0, f64=False):
+def imdct_batch(coefficients, window_function, layout="FT", device=0, f64=False, out=None):
     """(B, W/2, T) ["FT"] or (B, T, W/2) ["TF"] -> (B, (W/2)(T-1) - 1) float32 (float64 with f64)."""
     c = np.ascontiguousarray(coefficients, dtype=np.float64 if f64 else np.float32)
     w = _as_window(window_function, any_length=True)
@@ -748,43 +806,43 @@ def imdct_batch(coefficients, window_function, layout="FT", device=0, f64=False)
     if 2 * nf != len(w):
         raise ValueError("coefficient rows must equal window_length/2")
     plan = mdct_plan(w, layout, device, inverse=True, f64=f64)
-    out = plan.run_host(c.astype(plan.in_dtype, copy=False), nt)
+    out = plan.run_host(c.astype(plan.in_dtype, copy=False), nt, out=out)
     return out if f64 else out.astype(np.float32, copy=False)
 
 
-def melspectrogram_batch(clips, window_function, step_length, mel_filterbank, layout="FT", device=0, f64=False):
+def melspectrogram_batch(clips, window_function, step_length, mel_filterbank, layout="FT", device=0, f64=False, out=None):
     """(B, N) -> (B, n_filters, T) float32 (float64 arrays and arithmetic with f64)."""
     x = _as_clips(clips, dtype=np.float64 if f64 else np.float32)   # (validated before any device call)
     plan = mel_plan(window_function, step_length, mel_filterbank, None, layout, device, f64=f64)
     x = x.astype(plan.in_dtype, copy=False)
-    out = plan.run_host(x, x.shape[1])
+    out = plan.run_host(x, x.shape[1], out=out)
     return out if f64 else out.astype(np.float32, copy=False)   # (a long window is computed in float64 whatever f64 says)
 
 
-def mfcc_batch(clips, window_function, step_length, mel_filterbank, number_coefficients, layout="FT", device=0, f64=False):
+def mfcc_batch(clips, window_function, step_length, mel_filterbank, number_coefficients, layout="FT", device=0, f64=False, out=None):
     """(B, N) -> (B, number_coefficients, T) float32 (float64 arrays and arithmetic with f64)."""
     x = _as_clips(clips, dtype=np.float64 if f64 else np.float32)   # (validated before any device call)
     plan = mel_plan(window_function, step_length, mel_filterbank, number_coefficients, layout, device, f64=f64)
     x = x.astype(plan.in_dtype, copy=False)
-    out = plan.run_host(x, x.shape[1])
+    out = plan.run_host(x, x.shape[1], out=out)
     return out if f64 else out.astype(np.float32, copy=False)
 
 
-def cqtspectrogram_batch(clips, sampling_frequency, time_resolution, cqt_kernel, layout="FT", device=0, f64=False):
+def cqtspectrogram_batch(clips, sampling_frequency, time_resolution, cqt_kernel, layout="FT", device=0, f64=False, out=None):
     """(B, N) -> (B, n_bins, T) float32 (float64 arrays and arithmetic with f64)."""
     x = _as_clips(clips, dtype=np.float64 if f64 else np.float32)   # (validated before any device call)
     plan = cqt_plan(sampling_frequency, time_resolution, cqt_kernel, None, layout, device, f64=f64)
     x = x.astype(plan.in_dtype, copy=False)
-    out = plan.run_host(x, x.shape[1])
+    out = plan.run_host(x, x.shape[1], out=out)
     return out if f64 else out.astype(np.float32, copy=False)   # (a long kernel is computed in float64 whatever f64 says)
 
 
-def cqtchromagram_batch(clips, sampling_frequency, time_resolution, octave_resolution, cqt_kernel, layout="FT", device=0, f64=False):
+def cqtchromagram_batch(clips, sampling_frequency, time_resolution, octave_resolution, cqt_kernel, layout="FT", device=0, f64=False, out=None):
     """(B, N) -> (B, octave_resolution, T) float32 (float64 arrays and arithmetic with f64)."""
     x = _as_clips(clips, dtype=np.float64 if f64 else np.float32)   # (validated before any device call)
     plan = cqt_plan(sampling_frequency, time_resolution, cqt_kernel, int(octave_resolution), layout, device, f64=f64)
     x = x.astype(plan.in_dtype, copy=False)
-    out = plan.run_host(x, x.shape[1])
+    out = plan.run_host(x, x.shape[1], out=out)
     return out if f64 else out.astype(np.float32, copy=False)
 
 

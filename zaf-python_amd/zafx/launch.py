@@ -29,6 +29,15 @@ def rank_env():
             int(os.environ.get("WORLD_SIZE", "1")))
 
 
+def _single_node_or_raise():
+    """The rendezvous directory is local to one node: a launch over several nodes (WORLD_SIZE above LOCAL_WORLD_SIZE) would
+    wait for files that can never appear, so it fails here, at once."""
+    world, local = int(os.environ.get("WORLD_SIZE", "1")), os.environ.get("LOCAL_WORLD_SIZE")
+    if local is not None and int(local) != world:
+        raise RuntimeError(f"zafx.launch: the file rendezvous serves the ranks of ONE node (WORLD_SIZE = {world}, "
+                           f"LOCAL_WORLD_SIZE = {local}); run one job per node -- the clips shard without any exchange")
+
+
 def _start_time(pid):
     """Start time of a process in clock ticks since boot (field 22 of /proc/<pid>/stat); 0 where /proc is not there."""
     try:
@@ -45,15 +54,23 @@ class Rendezvous:
     sequence of collective calls (as with any collective library).  Values are published by an atomic
     rename, so a reader never sees a partial file."""
 
-    def __init__(self, directory, rank, world_size, timeout=600.0):
+    def __init__(self, directory, rank, world_size, timeout=600.0, namespace=""):
         if world_size < 1 or not 0 <= rank < world_size:
             raise ValueError("bad rank / world_size")
         self.dir, self.rank, self.world, self.timeout = directory, int(rank), int(world_size), float(timeout)
+        self.ns = str(namespace)   # prefix of every key: the files of an earlier job in a reused directory are never read
         self._seq = 0
-        os.makedirs(self.dir, exist_ok=True)
+        # private to this user: another local user must not be able to create the directory first and plant keys in it
+        # (the RCCL unique id travels through here)
+        os.makedirs(self.dir, mode=0o700, exist_ok=True)
+        st = os.stat(self.dir)
+        if st.st_uid != os.getuid() or (st.st_mode & 0o077):
+            raise PermissionError(f"rendezvous directory {self.dir} is not private to uid {os.getuid()} "
+                                  f"(owner {st.st_uid}, mode {st.st_mode & 0o777:o})")
 
     @classmethod
     def from_env(cls, timeout=600.0):
+        _single_node_or_raise()
         rank, _, world = rank_env()
         d = os.environ.get("ZAFX_RDZV_DIR")
         if not d:
@@ -62,17 +79,19 @@ class Rendezvous:
             key = f"{os.environ.get('MASTER_PORT', '0')}_{os.environ.get('TORCHELASTIC_RUN_ID', 'none')}_{os.getppid()}_{_start_time(os.getppid())}"
             base = "/dev/shm" if os.path.isdir("/dev/shm") and os.access("/dev/shm", os.W_OK) else tempfile.gettempdir()
             d = os.path.join(base, f"zafx_rdzv_{os.getuid()}_{key}")
-        return cls(d, rank, world, timeout)
+        # a directory the caller names may be reused: the keys carry the launcher's identity (all ranks of a node are children
+        # of one launcher process), so files a previous job left there are not this job's
+        return cls(d, rank, world, timeout, namespace=f"{os.getppid()}.{_start_time(os.getppid())}.")
 
     # ---- point to point -------------------------------------------------------------
     def put(self, key, data):
-        tmp = os.path.join(self.dir, f".{key}.{self.rank}.tmp")
+        tmp = os.path.join(self.dir, f".{self.ns}{key}.{self.rank}.tmp")
         with open(tmp, "wb") as f:
             f.write(bytes(data))
-        os.replace(tmp, os.path.join(self.dir, key))
+        os.replace(tmp, os.path.join(self.dir, self.ns + key))
 
     def get(self, key):
-        path = os.path.join(self.dir, key)
+        path = os.path.join(self.dir, self.ns + key)
         deadline = time.monotonic() + self.timeout
         delay = 0.0005
         while True:
@@ -122,12 +141,14 @@ class Rendezvous:
         for r in range(1, self.world):
             self.get(f"bye_{r}")
         for name in os.listdir(self.dir):
+            if not (name.startswith(self.ns) or name.startswith("." + self.ns)):
+                continue   # (another job's files in a shared directory)
             try:
                 os.unlink(os.path.join(self.dir, name))
             except OSError:
                 pass
         try:
-            os.rmdir(self.dir)
+            os.rmdir(self.dir)   # (fails, harmlessly, while another job's files are there)
         except OSError:
             pass
 
@@ -146,11 +167,33 @@ def spawn_ranks(argv, n_ranks, env=None, timeout=None):
                      MASTER_ADDR=e.get("MASTER_ADDR", "127.0.0.1"), MASTER_PORT=e.get("MASTER_PORT", "29400"))
             e.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # RCCL between processes needs dmabuf IPC on this driver
             procs.append(subprocess.Popen([sys.executable] + list(argv), env=e, stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL))
-        out, _ = procs[0].communicate(timeout=timeout)
-        code = procs[0].returncode
-        for p in procs[1:]:
-            code = code or p.wait(timeout=timeout)
-        return code, out.decode()
+        # rank 0's stdout is drained on a thread while ALL children are polled: a rank that dies takes the others down with
+        # it at once (they would wait out the rendezvous timeout for its files)
+        import threading
+        chunks = []
+        reader = threading.Thread(target=lambda: chunks.append(procs[0].stdout.read()), daemon=True)
+        reader.start()
+        deadline = None if timeout is None else time.monotonic() + timeout
+        code = 0
+        while True:
+            states = [p.poll() for p in procs]
+            bad = [c for c in states if c not in (None, 0)]
+            if bad:
+                code = bad[0]
+                break
+            if all(c == 0 for c in states):
+                break
+            if deadline is not None and time.monotonic() > deadline:
+                raise subprocess.TimeoutExpired([sys.executable] + list(argv), timeout)
+            time.sleep(0.02)
+        if code:
+            for p in procs:
+                if p.poll() is None:
+                    p.kill()
+        for p in procs:
+            p.wait()
+        reader.join(timeout=10)
+        return code, b"".join(c for c in chunks if c).decode()
     finally:
         for p in procs:
             if p.poll() is None:

@@ -159,9 +159,10 @@ int zafx_sync(zafx_plan* plan);
  * plan's pitch): what a host array of n_clips clips must hold for zafx_run_host. */
 int zafx_plan_clip_bytes(const zafx_plan* plan, int64_t n_in, int64_t* in_bytes, int64_t* out_bytes);
 /* The host-array boundary of the reference (zaf.py:45: NumPy array in, NumPy array out) in one call: h_in -> HBM ->
- * transform -> h_out, in chunks of `chunk_clips` clips (0: chosen by the library, about 128 MB per chunk) over two HIP
- * streams with plan-owned device staging buffers, so that upload, kernel and download of neighbouring chunks overlap and
- * the call runs at the rate of the slower PCIe direction instead of the sum of the three.  Synchronous: returns when h_out
+ * transform -> h_out, in chunks of `chunk_clips` clips (0: chosen by the library, about 128 MB per chunk) through a
+ * three-stage pipeline (upload stream, the plan's stream, download stream; two sets of plan-owned device staging buffers),
+ * so that upload, kernel and download of neighbouring chunks overlap and the call runs at the rate of the slower PCIe
+ * direction instead of the sum of the three.  Synchronous: returns when h_out
  * is complete.  Page-locked host arrays (zafx_host_alloc) transfer asynchronously at the PCIe rate; pageable ones work
  * and are staged by the runtime.  Serialise with other calls on the same plan. */
 int zafx_run_host(zafx_plan* plan, const void* h_in, void* h_out, int64_t n_clips, int64_t n_in, int64_t chunk_clips);

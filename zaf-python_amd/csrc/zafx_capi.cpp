@@ -755,12 +755,16 @@ int zafx_plan_destroy(zafx_plan* pl) {
     if (pl->d_bs_bhat) (void)hipFree(pl->d_bs_bhat);
     free_band(pl->fb);
     free_band(pl->dct);
-    if (pl->stream2) (void)hipStreamSynchronize(pl->stream2);
+    for (hipStream_t st : {pl->stream_up, pl->stream_down})
+        if (st) (void)hipStreamSynchronize(st);
     for (int l = 0; l < 2; ++l) {
         if (pl->lane_in[l]) (void)hipFree(pl->lane_in[l]);
         if (pl->lane_out[l]) (void)hipFree(pl->lane_out[l]);
     }
-    if (pl->stream2) (void)hipStreamDestroy(pl->stream2);
+    for (hipEvent_t ev : pl->pipe_ev)
+        if (ev) (void)hipEventDestroy(ev);
+    for (hipStream_t st : {pl->stream_up, pl->stream_down})
+        if (st) (void)hipStreamDestroy(st);
     if (pl->ev0) (void)hipEventDestroy(pl->ev0);
     if (pl->ev1) (void)hipEventDestroy(pl->ev1);
     if (pl->stream) (void)hipStreamDestroy(pl->stream);
@@ -1018,12 +1022,19 @@ int zafx_plan_clip_bytes(const zafx_plan* pl, int64_t n_in, int64_t* in_bytes, i
     return clip_bytes(pl, n_in, in_bytes, out_bytes);
 }
 
-// Host array in -> transform -> host array out, in chunks of clips over two lanes (stream + device staging buffers each):
-// lane A's download runs while lane B uploads and transforms, so the three phases that zafx_h2d / zafx_execute / zafx_d2h run
-// one after the other overlap and the call approaches the rate of the slower PCIe direction alone.  Every lane's operations
-// are ordered by its own stream (upload c -> kernel c -> download c -> upload c + 2 ...), so the staging buffers need no
-// events.  Page-locked host arrays (zafx_host_alloc) make the copies asynchronous; pageable ones are staged by the runtime
-// (correct, slower).  Plans whose kernels share a plan-owned scratch (float64 and Bluestein inverse forms) take one lane.
+// Host array in -> transform -> host array out, in chunks of clips through a three-stage pipeline: uploads on their own
+// stream, kernels on the plan's stream, downloads on a third, two sets of device staging buffers, events between the stages
+//     host:      waits for down(c - 2) (both buffers of set c & 1 are free again), then enqueues
+//     up(c)      on the upload stream                                  -> ev_up[c & 1]
+//     kernel(c)  on the plan's stream, waits for up(c)                  -> ev_k[c & 1]
+//     down(c)    on the download stream, waits for kernel(c)           -> ev_down[c & 1]
+// so the download of chunk c runs while chunk c + 1 is uploaded and transformed, and the call approaches the rate of the
+// slower PCIe direction alone instead of the sum of the three phases.  One stream per DIRECTION matters: with upload and
+// download of a chunk on the same stream (round 3's first version: two lanes of upload -> kernel -> download) the two lanes fell
+// into step, uploaded together and downloaded together, and nothing overlapped (2.92 against 2.81 Gsamples/s serial;
+// tools/exp_pcie.hip: one stream per direction overlaps fully, 19.6 ms for 4.7 + 18.8).  Page-locked host arrays
+// (zafx_host_alloc) make the copies asynchronous; pageable ones are staged by the runtime (correct, slower).  Plans whose
+// kernels share a plan-owned scratch (float64 and Bluestein inverse forms) are safe too: their kernels stay on one stream.
 int zafx_run_host(zafx_plan* pl, const void* h_in, void* h_out, int64_t n_clips, int64_t n_in, int64_t chunk_clips) {
     if (!pl) return fail_msg("null plan");
     if (n_clips < 0 || n_in < 0) return fail_msg("negative size");
@@ -1033,16 +1044,20 @@ int zafx_run_host(zafx_plan* pl, const void* h_in, void* h_out, int64_t n_clips,
     if (int rc = clip_bytes(pl, n_in, &in_b, &out_b)) return rc;
     ZAFX_HIP(hipSetDevice(pl->device));
     if (chunk_clips <= 0) {
-        // default: chunks of about 128 MB (both sides together): a few ms of PCIe each, so the pipeline fills quickly and
-        // the fixed costs per chunk (launch, copy set-up: tens of microseconds) stay below a percent
+        // default: chunks of about 128 MB (both sides together): about two milliseconds of PCIe each, so the pipeline fills
+        // quickly (its first upload and last download are not overlapped) and the fixed costs per chunk (launch, copy set-up,
+        // events: tens of microseconds) stay at a few percent (tools/e2e_pcie.py: 64 ... 256 MB are within 1 % of each other)
         chunk_clips = std::max<int64_t>(1, (int64_t)(128 << 20) / std::max<int64_t>(in_b + out_b, 1));
     }
     chunk_clips = std::min(chunk_clips, n_clips);
     const int64_t n_chunks = (n_clips + chunk_clips - 1) / chunk_clips;
-    const bool shared_scratch = pl->prm.precision == ZAFX_PRECISION_F64 || pl->bs_log2m > 0;
-    const int lanes = (n_chunks > 1 && !shared_scratch) ? 2 : 1;
-    if (lanes == 2 && !pl->stream2) ZAFX_HIP(hipStreamCreateWithFlags(&pl->stream2, hipStreamNonBlocking));
-    for (int l = 0; l < lanes; ++l) {   // grow-only staging buffers
+    const int sets = n_chunks > 1 ? 2 : 1;
+    if (sets == 2 && !pl->stream_up) {
+        ZAFX_HIP(hipStreamCreateWithFlags(&pl->stream_up, hipStreamNonBlocking));
+        ZAFX_HIP(hipStreamCreateWithFlags(&pl->stream_down, hipStreamNonBlocking));
+        for (int i = 0; i < 6; ++i) ZAFX_HIP(hipEventCreateWithFlags(&pl->pipe_ev[i], hipEventDisableTiming));
+    }
+    for (int l = 0; l < sets; ++l) {   // grow-only staging buffers
         const size_t need_in = (size_t)std::max<int64_t>(chunk_clips * in_b, 1), need_out = (size_t)std::max<int64_t>(chunk_clips * out_b, 1);
         if (pl->lane_in_bytes[l] < need_in) {
             if (pl->lane_in[l]) ZAFX_HIP(hipFree(pl->lane_in[l]));
@@ -1057,26 +1072,34 @@ int zafx_run_host(zafx_plan* pl, const void* h_in, void* h_out, int64_t n_clips,
             pl->lane_out_bytes[l] = need_out;
         }
     }
-    hipStream_t const main_stream = pl->stream;
-    hipStream_t streams[2] = {main_stream, pl->stream2};
+    hipStream_t const s_k = pl->stream;
+    hipStream_t const s_up = sets == 2 ? pl->stream_up : s_k, s_down = sets == 2 ? pl->stream_down : s_k;
+    hipEvent_t* const ev_up = pl->pipe_ev, * const ev_k = pl->pipe_ev + 2, * const ev_down = pl->pipe_ev + 4;
     int ret = 0;
+    hipError_t e = hipSuccess;
     for (int64_t c = 0; c < n_chunks && !ret; ++c) {
-        const int l = (int)(c % lanes);
+        const int l = (int)(c % sets);
         const int64_t first = c * chunk_clips, count = std::min(chunk_clips, n_clips - first);
-        hipError_t e = hipSuccess;
-        if (count * in_b > 0)
-            e = hipMemcpyAsync(pl->lane_in[l], (const char*)h_in + first * in_b, (size_t)(count * in_b), hipMemcpyHostToDevice, streams[l]);
+        // The host runs at most two chunks ahead: before buffer set l is used again it waits for the download that emptied it
+        // (which implies that the kernel before it has read the input buffer).  With the whole batch enqueued at once, more
+        // than ~70 chunks in flight made the runtime fall off a cliff (1024 clips in 147 chunks: 444 ms instead of 135).
+        if (sets == 2 && c >= 2) e = hipEventSynchronize(ev_down[l]);
+        if (e == hipSuccess && count * in_b > 0)
+            e = hipMemcpyAsync(pl->lane_in[l], (const char*)h_in + first * in_b, (size_t)(count * in_b), hipMemcpyHostToDevice, s_up);
+        if (e == hipSuccess && sets == 2) e = hipEventRecord(ev_up[l], s_up);
+        if (e == hipSuccess && sets == 2) e = hipStreamWaitEvent(s_k, ev_up[l], 0);
         if (e != hipSuccess) { ret = fail("zafx_run_host: upload", e); break; }
-        pl->stream = streams[l];   // the launchers enqueue on plan.stream
-        ret = zafx_execute(pl, pl->lane_in[l], pl->lane_out[l], count, n_in);
-        pl->stream = main_stream;
+        ret = zafx_execute(pl, pl->lane_in[l], pl->lane_out[l], count, n_in);   // (on pl->stream = s_k)
         if (ret) break;
-        if (count * out_b > 0)
-            e = hipMemcpyAsync((char*)h_out + first * out_b, pl->lane_out[l], (size_t)(count * out_b), hipMemcpyDeviceToHost, streams[l]);
+        if (sets == 2) e = hipEventRecord(ev_k[l], s_k);
+        if (e == hipSuccess && sets == 2) e = hipStreamWaitEvent(s_down, ev_k[l], 0);
+        if (e == hipSuccess && count * out_b > 0)
+            e = hipMemcpyAsync((char*)h_out + first * out_b, pl->lane_out[l], (size_t)(count * out_b), hipMemcpyDeviceToHost, s_down);
+        if (e == hipSuccess && sets == 2) e = hipEventRecord(ev_down[l], s_down);
         if (e != hipSuccess) { ret = fail("zafx_run_host: download", e); break; }
     }
-    for (int l = 0; l < lanes; ++l) {   // (also after an error: nothing of this call is left in flight)
-        hipError_t e = hipStreamSynchronize(streams[l]);
+    for (hipStream_t st : {s_up, s_k, s_down}) {   // (also after an error: nothing of this call is left in flight)
+        e = hipStreamSynchronize(st);
         if (e != hipSuccess && !ret) ret = fail("zafx_run_host: sync", e);
     }
     return ret;

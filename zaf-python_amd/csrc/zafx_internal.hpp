@@ -62,8 +62,10 @@ struct zafx_plan {
     zafx_params prm{};
     hipStream_t stream = nullptr;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
-    // zafx_run_host: second lane's stream and both lanes' device staging buffers (grow-only, freed with the plan)
-    hipStream_t stream2 = nullptr;
+    // zafx_run_host: upload / download streams, the events between the pipeline's stages ([0..1] upload done, [2..3] kernel
+    // done, [4..5] download done, per buffer set) and two sets of device staging buffers (grow-only, freed with the plan)
+    hipStream_t stream_up = nullptr, stream_down = nullptr;
+    hipEvent_t pipe_ev[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
     void* lane_in[2] = {nullptr, nullptr};
     void* lane_out[2] = {nullptr, nullptr};
     size_t lane_in_bytes[2] = {0, 0}, lane_out_bytes[2] = {0, 0};

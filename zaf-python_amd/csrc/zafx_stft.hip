@@ -291,14 +291,20 @@ __global__ __launch_bounds__(kFatWaves * 64) void k_stft_ft16(
             if constexpr (E >= 32) asm volatile("" : "+v"(kqo));
             auto store_tile = [&](auto stream) {
                 constexpr bool ST = decltype(stream)::value;
-#ifdef ZAFX_STFT_ROWROT   // experiment (tools/placement.py): every workgroup starts its row sweep somewhere else
+                // Every workgroup starts its sweep over the rows somewhere else (its XCD and its place in the XCD decide): the
+                // persistent workgroups run in step, and with all of them on the same rows at the same time the chip wrote a few
+                // narrow bands of every clip at once; staggered, the stores of a moment spread over the clips' whole extent
+                // (tools/placement.py, 13 allocations: 1.539-1.573 -> 1.495-1.538 ms; ZAFX_STFT_ROWROT_EXPR=0 restores the old order).
                 constexpr int ITER = (N / 2) / (NT / FPB);
-                const int rot = ((int)blockIdx.x >> 3) * ZAFX_STFT_ROWROT;
+#ifndef ZAFX_STFT_ROWROT_EXPR
+#define ZAFX_STFT_ROWROT_EXPR (((int)blockIdx.x & 7) * 2 + ((int)blockIdx.x >> 3))
+#endif
+                static_assert((N / 2) % (NT / FPB) == 0, "the row sweep is a whole number of iterations");
+                // (only where every store is a whole line: rows that straddle lines rely on the neighbouring tile -- the neighbouring
+                // workgroup of the XCD -- writing the other part of the line at about the same time, which L2 then merges)
+                const int rot = ST ? ZAFX_STFT_ROWROT_EXPR : 0;
                 for (int it = 0; it < ITER; ++it) {
                     const int k = kqo + ((it + rot) % ITER) * (NT / FPB);
-#else
-                for (int k = kqo; k < N / 2; k += NT / FPB) {
-#endif
                     if (k == 0) {
                         const float2 z0 = fb[0], zc = fb[phys_t<C::PS>(N / 2)];
                         put_bin<SPEC, ST>(o, 0, make_float2(z0.x + z0.y, 0.f));

@@ -162,6 +162,7 @@ static hipError_t pack_band(PackedBand& pb, const float* dense, int n_rows, int 
     wave_ptr[(size_t)n_waves] = (int)flat.size() / 4;
     pb.max_wave_steps = (pb.total_steps + n_waves - 1) / n_waves;
     if (pack.empty()) pack.push_back(0.f);
+    pack.resize(pack.size() + 64 * 2 * (size_t)std::max(kMelResidentFb, kMelResidentDct), 0.f);   // spare steps: k_mel reads a fixed number of fragments per wave
     if (flat.empty()) flat.assign(4, 0);
     hipError_t e = upload(&pb.d_pack, pack.data(), pack.size() * sizeof(float));
     if (e == hipSuccess) e = upload(&pb.d_items, flat.data(), flat.size() * sizeof(int));

@@ -30,7 +30,16 @@ ZAFX_PROF_ARRAY(g_prof_mel)
 #ifndef ZAFX_MEL_THREADS
 #define ZAFX_MEL_THREADS 1024
 #endif
-constexpr int kMelThreads = ZAFX_MEL_THREADS;   // 512: 8 fat waves (2 frames each, register prefetch); 1024: 16 waves, one frame each
+#ifndef ZAFX_MEL_FPB
+#define ZAFX_MEL_FPB 16
+#endif
+constexpr int kMelThreads = ZAFX_MEL_THREADS;
+// frames per tile.  8 (with ZAFX_MEL_THREADS = 512): two workgroups per CU, each with 8 wavefronts and 8-frame tiles -- their
+// phases (transforms | filterbank GEMM | reduction) drift apart, so one workgroup's butterflies fill the vector pipe while the
+// other sits in its matrix / reduction / barrier third; half of every MFMA's 16 columns is then unused (the matrix pipe is
+// 90 % idle), and the window is read from global memory (two workgroups' tables do not fit LDS beside 2 x 8 frame buffers)
+constexpr int kMelFpb = ZAFX_MEL_FPB;
+constexpr bool kMelWinLds = kMelFpb == 16;   // 512: 8 fat waves (2 frames each, register prefetch); 1024: 16 waves, one frame each
 #ifndef ZAFX_MEL_R32
 #define ZAFX_MEL_R32 0
 #endif
@@ -45,7 +54,7 @@ template <int LOG2N, int LOG2E>
 struct MelCfg {
     using C = FftCfg<LOG2N, LOG2E>;
     static constexpr int N = C::N;
-    static constexpr int FPB = 16;   // MFMA N dimension
+    static constexpr int FPB = kMelFpb;   // frames per tile (<= 16 = the MFMA N dimension)
     static constexpr int NSLOT = (kMelThreads / C::P) < FPB ? (kMelThreads / C::P) : FPB;   // frames transformed concurrently
     static constexpr int NT = NSLOT * C::P;
     // 256-float slots: in the dead upper half of every frame buffer when it is large enough,
@@ -55,7 +64,7 @@ struct MelCfg {
     static constexpr int IN_FRAMES = FPB * SLOTS_PER_BUF;         // slots in the dead upper halves
     static constexpr int EXTRA_SLOTS = N >= 1024 ? 0 : 64;         // + a region of their own where LDS is plentiful (W <= 1024)
     static constexpr int CAPACITY = IN_FRAMES + EXTRA_SLOTS;
-    static constexpr size_t TABLES = (size_t)(C::TW + N + N / 2 + 1) * 8;     // pass twiddles, window, split roots
+    static constexpr size_t TABLES = (size_t)(C::TW + (kMelWinLds ? N + N / 2 + 1 : 0)) * 8;     // pass twiddles, window, split roots (8-frame form: the latter two from global memory)
     static constexpr size_t SMEM = (size_t)FPB * C::PITCH * 8 + TABLES + (size_t)EXTRA_SLOTS * 256 * 4;
 };
 
@@ -98,29 +107,39 @@ __device__ __forceinline__ void gemm_resident(const float (&a)[RA], const int (&
         asm volatile("" : "+s"(dw[j]));
     }
     asm volatile("" : "+s"(n));
-    float b[RA];   // the B fragments of all steps are requested up front: the MFMA chain then waits for LDS once, not once per step
+    // the B fragments of a chunk of steps are requested up front: the MFMA chain then waits for LDS once per chunk, not once per
+    // step (a chunk = all steps up to 18; the 8-frame form's 36 steps go in two chunks, for the registers' sake)
+    constexpr int CH = RA > 18 ? (RA + 1) / 2 : RA;
 #pragma unroll
-    for (int i = 0; i < RA; ++i) b[i] = b_at(4 * ((dw[i >> 1] >> (16 * (i & 1))) & 255));   // (no step: descriptor 0, column 0)
+    for (int c0 = 0; c0 < RA; c0 += CH) {
+        float b[CH];
 #pragma unroll
-    for (int i = 0; i < RA; ++i) {
-        if (i < n) {   // (uniform)
-            const int d = dw[i >> 1] >> (16 * (i & 1));
-            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i], b[i], acc, 0, 0, 0);
-            if (d & 0x8000) {   // the item ends: leave its partial tile in its slot
-                float* dst = slot_ptr(slot0 + ((d >> 8) & 127)) + (4 * bk) * 16 + bt;
+        for (int i = 0; i < CH; ++i)
+            if (c0 + i < RA) b[i] = b_at(4 * ((dw[(c0 + i) >> 1] >> (16 * ((c0 + i) & 1))) & 255));   // (no step: descriptor 0, column 0)
 #pragma unroll
-                for (int q = 0; q < 4; ++q) dst[q * 16] = acc[q];
-                acc = f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int ii = 0; ii < CH; ++ii) {
+            const int i = c0 + ii;
+            if (i < RA) {
+                if (i < n) {   // (uniform)
+                    const int d = dw[i >> 1] >> (16 * (i & 1));
+                    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i], b[ii], acc, 0, 0, 0);
+                    if (d & 0x8000) {   // the item ends: leave its partial tile in its slot
+                        float* dst = slot_ptr(slot0 + ((d >> 8) & 127)) + (4 * bk) * 16 + bt;
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) dst[q * 16] = acc[q];
+                        acc = f32x4{0.f, 0.f, 0.f, 0.f};
+                    }
+                }
+                hook(i);
             }
         }
-        hook(i);
     }
 }
 
 // RES: filterbank (and DCT) fragments resident in registers + prefetch of the next tile under the filterbank phases.
 // MF: 1 = mel, 2 = mfcc, 3 = mfcc with the register-fed DCT compiled in (resident form), 0 = the kernel argument decides.
 template <int LOG2N, int LOG2E, bool ALIGNED, bool RES, int MF>
-__global__ __launch_bounds__(mel_threads(LOG2N, LOG2E)) void k_mel(
+__global__ __launch_bounds__(mel_threads(LOG2N, LOG2E), kMelFpb == 8 ? 2 * mel_threads(LOG2N, LOG2E) / 256 : 1) void k_mel(
     const float* __restrict__ x, const float* __restrict__ win, const float2* __restrict__ twp,
     const float2* __restrict__ tws, const float* __restrict__ fb_pack, const int4* __restrict__ fb_items,
     const int* __restrict__ fb_wave_ptr, const int* __restrict__ fb_blk_ptr, const unsigned short* __restrict__ fb_desc, int fb_blocks, int fb_nitems, int fb_steps, int dct_steps,
@@ -135,26 +154,36 @@ __global__ __launch_bounds__(mel_threads(LOG2N, LOG2E)) void k_mel(
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     float2* frames = reinterpret_cast<float2*>(smem_raw);
     float2* tw_l = frames + FPB * C::PITCH;
-    float2* win_l = tw_l + C::TW;
-    float2* tws_l = win_l + N;
-    float* extra = reinterpret_cast<float*>(tws_l + N / 2 + 1);
+    float2* win_s = tw_l + C::TW;
+    float2* tws_s = win_s + (kMelWinLds ? N : 0);
+    const float2* win_l = kMelWinLds ? win_s : reinterpret_cast<const float2*>(win);   // (8-frame form: from global memory / L1)
+    const float2* tws_l = kMelWinLds ? tws_s : tws;
+    float* extra = reinterpret_cast<float*>(tws_s + (kMelWinLds ? N / 2 + 1 : 0));
     float* fall = reinterpret_cast<float*>(frames);
     const int tid = threadIdx.x;
     // The raw samples of a round are requested one phase ahead.  Fat waves (NT <= 512, two rounds per tile): before the FFT of
     // the previous round.  16 thin waves (one round per tile): when the tile's spectra are done, so that the 128 KB of the next
     // tile fly under the filterbank phases -- all 16 waves otherwise request, wait and transform in lockstep, and the three
     // resources (vector memory 5.8 k cycles per tile, LDS 6.5 k, VALU 7 k) are used one after the other.
-    constexpr bool PREFETCH = NT <= 512;
+    constexpr bool TEAM8 = FPB == 8 && RES;   // two 8-wave workgroups per CU, 8-frame tiles: the resident form's schedule, A fragments re-read every tile
+    constexpr bool PREFETCH = NT <= 512 && !TEAM8;
     constexpr bool LATE = !PREFETCH && RES;
     // 16-byte lane loads for the prefetched frame (W = 2048, resident form): the lanes l and l + 16 (l in an even 16-lane
     // row) share their loads -- the first fetches the points (n, n + 1) + 64 i for i = 0 .. 7, the second for i = 8 .. 15 --
     // and one v_permlane16_swap per register hands each lane its own points (row_pair_index / row_pair_unpack).  Eight loads
     // per lane instead of sixteen: the request of the next tile blocks half as long at the CU's vector-memory queue.
     constexpr bool PAIR16 = LATE && LOG2N == 10 && LOG2E == 4;   // (without resident fragments the filterbank's own loads would queue behind the prefetch)
+    // window at the points the lane holds: from the LDS table, or (8-frame form) from global memory
+    auto win_at = [&](int po, int i) -> float2 {
+        if constexpr (kMelWinLds) return win_l[po + i * P];
+        else return win_l[(PAIR16 ? row_pair_index(po) : po) + i * P];
+    };
     for (int i = tid; i < C::TW; i += NT) tw_l[i] = twp[i];
     // (pair form, below: the window in lane order, win_l[64 i + lane] = the window at the lane's points p + 64 i)
-    for (int i = tid; i < N; i += NT) win_l[i] = reinterpret_cast<const float2*>(win)[PAIR16 ? (i & ~63) + row_pair_index(i & 63) : i];
-    for (int i = tid; i <= N / 2; i += NT) tws_l[i] = tws[i];
+    if constexpr (kMelWinLds)
+        for (int i = tid; i < N; i += NT) win_s[i] = reinterpret_cast<const float2*>(win)[PAIR16 ? (i & ~63) + row_pair_index(i & 63) : i];
+    if constexpr (kMelWinLds)
+        for (int i = tid; i <= N / 2; i += NT) tws_s[i] = tws[i];
     __syncthreads();
 
     auto slot_ptr = [&](int s) -> float* {
@@ -241,7 +270,7 @@ __global__ __launch_bounds__(mel_threads(LOG2N, LOG2E)) void k_mel(
             if (raw) unpack_pairs();
 #pragma unroll
             for (int i = 0; i < E; ++i) {
-                const float2 wv = win_l[po + i * P];   // (pair form: the table is in lane order)
+                const float2 wv = win_at(po, i);   // (pair form: the table is in lane order)
                 xr[i] = make_float2(xr[i].x * wv.x, xr[i].y * wv.y);
             }
             Dft<16>::run(xr);
@@ -255,26 +284,35 @@ __global__ __launch_bounds__(mel_threads(LOG2N, LOG2E)) void k_mel(
         }
     }
     // resident A fragments of this wave: lane l holds A[l & 15][4 step + (l >> 4)] of its K-steps
-    float afb[RES ? kMelResidentFb : 1], adct[RES ? kMelResidentDct : 1];
-    int sfb[RES ? (kMelResidentFb + 1) / 2 : 1], sdct[RES ? (kMelResidentDct + 1) / 2 : 1];   // the steps' descriptors, two per scalar register
+    constexpr int RAFB = TEAM8 ? 2 * kMelResidentFb : kMelResidentFb, RADCT = TEAM8 ? 2 * kMelResidentDct : kMelResidentDct;
+    float afb[RES ? RAFB : 1], adct[RES ? RADCT : 1];
+    int sfb[RES ? (RAFB + 1) / 2 : 1], sdct[RES ? (RADCT + 1) / 2 : 1];   // the steps' descriptors, two per scalar register
     int nfb = 0, ndct = 0;
     constexpr int NW = NT / 64;
-    if constexpr (RES) {   // the wave's share of the K-steps is a contiguous range of the packed fragments (pack_band)
-        const int g0 = (int)((long long)fb_steps * wave / NW);
+    // the wave's share of the K-steps is a contiguous range of the packed fragments (pack_band).  16 waves: loaded once, resident for
+    // the whole launch; 8-frame form: re-read from L2 every tile (twice the steps per wave: they do not fit beside the transform)
+    const int g0 = RES ? (int)((long long)fb_steps * wave / NW) : 0, h0 = RES ? (int)((long long)dct_steps * wave / NW) : 0;
+    auto load_fragments = [&](int lane_o) {   // (vector loads only: the descriptors and counts below are read once)
+        // one base address per table (opaque: the 44 step addresses of the 8-frame form are immediates off it, not scalars kept across tiles);
+        // the tables carry spare steps behind the last one, so a wave with fewer steps than registers reads in bounds
+        const float* fp = fb_pack + (size_t)g0 * 64 + lane_o;
+        const float* dp = DIRECT ? dct_direct + (size_t)wave * 4 * 64 + lane_o : dct_pack + (size_t)h0 * 64 + lane_o;
+        asm volatile("" : "+v"(fp), "+v"(dp));
+#pragma unroll
+        for (int i = 0; i < RAFB; ++i) afb[i] = fp[i * 64];
+        if (mfcc) {   // (uniform; a mel plan has no DCT table)
+#pragma unroll
+            for (int i = 0; i < RADCT; ++i) adct[i] = dp[i * 64];
+        }
+    };
+    if constexpr (RES) {
         nfb = __builtin_amdgcn_readfirstlane((int)((long long)fb_steps * (wave + 1) / NW) - g0);
 #pragma unroll
-        for (int i = 0; i < kMelResidentFb; ++i) afb[i] = i < nfb ? fb_pack[(size_t)(g0 + i) * 64 + (tid & 63)] : 0.f;
-#pragma unroll
-        for (int i = 0; i < (kMelResidentFb + 1) / 2; ++i) sfb[i] = __builtin_amdgcn_readfirstlane(2 * i < nfb ? (fb_desc[g0 + 2 * i] | fb_desc[g0 + 2 * i + 1] << 16) : 0);   // (two spare entries behind the table)
-        const int h0 = (int)((long long)dct_steps * wave / NW);
+        for (int i = 0; i < (RAFB + 1) / 2; ++i) sfb[i] = __builtin_amdgcn_readfirstlane(2 * i < nfb ? (fb_desc[g0 + 2 * i] | fb_desc[g0 + 2 * i + 1] << 16) : 0);   // (two spare entries behind the table)
         ndct = __builtin_amdgcn_readfirstlane(mfcc ? (int)((long long)dct_steps * (wave + 1) / NW) - h0 : 0);
 #pragma unroll
-        for (int i = 0; i < kMelResidentDct; ++i) {
-            if constexpr (DIRECT) adct[i] = dct_direct[((size_t)wave * 4 + i) * 64 + (tid & 63)];   // register-fed form: [j][block], 2 x 2
-            else adct[i] = i < ndct ? dct_pack[(size_t)(h0 + i) * 64 + (tid & 63)] : 0.f;
-        }
-#pragma unroll
-        for (int i = 0; i < (kMelResidentDct + 1) / 2; ++i) sdct[i] = __builtin_amdgcn_readfirstlane(2 * i < ndct ? (dct_desc[h0 + 2 * i] | dct_desc[h0 + 2 * i + 1] << 16) : 0);
+        for (int i = 0; i < (RADCT + 1) / 2; ++i) sdct[i] = __builtin_amdgcn_readfirstlane(2 * i < ndct ? (dct_desc[h0 + 2 * i] | dct_desc[h0 + 2 * i + 1] << 16) : 0);
+        if constexpr (!TEAM8) load_fragments(tid & 63);
     }
     PROF_INIT(g_prof_mel);
     for (int tlv = blockIdx.x; tlv < total_tiles; tlv += gridDim.x) {
@@ -303,7 +341,7 @@ __global__ __launch_bounds__(mel_threads(LOG2N, LOG2E)) void k_mel(
             } else {
 #pragma unroll
             for (int i = 0; i < E; ++i) {
-                const float2 wv = win_l[po + i * P];
+                const float2 wv = win_at(po, i);
                 v[i] = make_float2(xr[i].x * wv.x, xr[i].y * wv.y);
             }
             }
@@ -359,6 +397,7 @@ __global__ __launch_bounds__(mel_threads(LOG2N, LOG2E)) void k_mel(
         // vector memory, idle through the transforms, works while the early waves wait at the barrier; the filterbank GEMM then
         // runs without loads in between.  Otherwise: one load per K-step of the GEMM.
         bool fast = false;
+        if constexpr (TEAM8) load_fragments(lane);   // from L2, ahead of the request of the next frame (they are needed first)
         if constexpr (LATE) {
             fast = fetch_begin(tlv + gridDim.x, 0, PAIR16 ? row_pair_index(to % P) : to % P);
             if (ZAFX_MEL_EARLY && fast) {
@@ -373,7 +412,7 @@ __global__ __launch_bounds__(mel_threads(LOG2N, LOG2E)) void k_mel(
 
         // ---- mel = FB . S on the matrix cores
         {
-            const float* sb = fall + (size_t)bt * (2 * C::PITCH) + bk;
+            const float* sb = fall + (size_t)(bt % FPB) * (2 * C::PITCH) + bk;   // (8-frame tiles: columns 8..15 repeat 0..7 and are not used)
             if constexpr (RES)
                 gemm_resident(afb, sfb, nfb, lane, 0, slot_ptr, [&](int col) { return sb[col]; }, [&](int i) { if (LATE && !ZAFX_MEL_EARLY && i < E && fast) fetch_one(i); });
             else gemm_items(fb_pack, fb_items, fb_wave_ptr, wave, lane, 0, slot_ptr, [&](int col) { return sb[col]; });
@@ -391,6 +430,7 @@ __global__ __launch_bounds__(mel_threads(LOG2N, LOG2E)) void k_mel(
             float val = 0.f;
             for (int it = fb_blk_ptr[blk]; it < fb_blk_ptr[blk + 1]; ++it) val += slot_ptr(it)[e];
             const int m = 16 * blk + (e >> 4), tq = e & 15;
+            if (FPB < 16 && tq >= FPB) continue;
             if (mfcc) {
                 const float l = m < n_filters ? logf(val + eps) : 0.f;
                 if constexpr (DIRECT) {
@@ -428,7 +468,7 @@ __global__ __launch_bounds__(mel_threads(LOG2N, LOG2E)) void k_mel(
 #pragma unroll
                     for (int w = 0; w < NW; ++w) val += slot_ptr(lt0 + blk * NW + w)[e];
                     const int q = 16 * blk + (e >> 4), tq = e & 15;
-                    if (q < n_coefs && t0 + tq < T) {
+                    if (q < n_coefs && tq < FPB && t0 + tq < T) {
                         if (layout == ZAFX_LAYOUT_FT) out[((long long)clip * n_coefs + q) * TP + t0 + tq] = val;
                         else out[((long long)clip * T + t0 + tq) * n_coefs + q] = val;
                     }
@@ -446,7 +486,7 @@ __global__ __launch_bounds__(mel_threads(LOG2N, LOG2E)) void k_mel(
                 float val = 0.f;
                 for (int it = dct_blk_ptr[blk]; it < dct_blk_ptr[blk + 1]; ++it) val += slot_ptr(dslot0 + it)[e];
                 const int q = 16 * blk + (e >> 4), tq = e & 15;
-                if (q < n_coefs && t0 + tq < T) {
+                if (q < n_coefs && tq < FPB && t0 + tq < T) {
                     if (layout == ZAFX_LAYOUT_FT) out[((long long)clip * n_coefs + q) * TP + t0 + tq] = val;
                     else out[((long long)clip * T + t0 + tq) * n_coefs + q] = val;
                 }
@@ -475,10 +515,11 @@ static hipError_t run_mel(const zafx_plan& pl, const float* x, float* out, int64
     const int mfcc = pl.kind == ZAFX_MFCC;
     // filterbank and DCT fragments resident in registers when the busiest wave's K-steps fit (128 filters at W = 2048: 17 + 4)
     // (a block without non-zeros has no K-step to carry its zero tile: streamed form)
-    const bool res = G::NT == 1024 && pl.fb.max_wave_steps <= kMelResidentFb && pl.fb.n_empty == 0 && pl.fb.desc_ok &&
-                     (!mfcc || (pl.dct.max_wave_steps <= kMelResidentDct && pl.dct.n_empty == 0 && pl.dct.desc_ok));
+    constexpr bool team8 = kMelFpb == 8 && G::NT == 512;   // (8-frame form: twice the steps per wave, re-read every tile)
+    const bool res = (G::NT == 1024 || team8) && pl.fb.max_wave_steps <= (team8 ? 2 : 1) * kMelResidentFb && pl.fb.n_empty == 0 && pl.fb.desc_ok &&
+                     (!mfcc || (pl.dct.max_wave_steps <= (team8 ? 2 : 1) * kMelResidentDct && pl.dct.n_empty == 0 && pl.dct.desc_ok));
     auto kern = k_mel<LOG2N, LOG2E, ALIGNED, false, 0>;
-    if constexpr (G::NT == 1024) {
+    if constexpr (G::NT == 1024 || team8) {
         if (res) kern = mfcc ? (pl.dct.direct_j > 0 ? k_mel<LOG2N, LOG2E, ALIGNED, true, 3> : k_mel<LOG2N, LOG2E, ALIGNED, true, 2>) : k_mel<LOG2N, LOG2E, ALIGNED, true, 1>;
     }
     const int direct_j = (res && mfcc) ? pl.dct.direct_j : 0;   // (register-fed DCT: one partial tile per wave and 16-row block)

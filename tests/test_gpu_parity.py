@@ -1483,3 +1483,34 @@ def test_rccl_two_ranks(zafx):
     assert code == 0, out
     line = [ln for ln in out.splitlines() if ln.startswith("RANKS ")][-1].split()[1:]
     assert [p.split(":")[:2] for p in line] == [["0", "3"], ["3", "6"]]
+
+
+@pytest.mark.parametrize("wl,hop,n,clips,onesided", [
+    (2048, 1024, 442024, 5, False),   # T = 433: the bench line's off-grid geometry
+    (2048, 1024, 442024, 3, True),    # one-sided: 1025 rows, every clip starts at another phase of the line grid
+    (2048, 1024, 448168, 2, False),   # T = 439, two clips over 256 workgroups: segments of a few tiles each
+    (2048, 1024, 30001, 4, False),    # odd clip length: the predicated loads
+    (2048, 512, 100000, 3, False),    # hop W/4, T = 197
+    (2048, 1554, 50000, 3, False),    # a hop that is no divisor of anything
+    (512, 256, 9000, 3, False),       # smaller windows run the same kernel
+    (256, 64, 5100, 7, True),
+    (2048, 1024, 1000, 2, False),     # fewer frames than a tile
+    (2048, 1024, 481440, 1, False),   # 10.03 s at 48 kHz, one clip: 30 segments
+])
+def test_stft_rows_off_the_line_grid(zafx, wl, hop, n, clips, onesided):
+    """k_stft_ft16c (round 3): when T is not a multiple of 16 the rows of the compact (W, T) array straddle 128-byte lines; the
+    kernel walks a clip's tiles in order and completes every line from the previous tile's values carried in registers.
+    Values must not depend on the route: compared with the oracle clip by clip, first and last frames included."""
+    w = zafx.hamming(wl)
+    x = np.stack([synth_clip(31, c, n) for c in range(clips)])
+    got = zafx.stft_batch(x, w, hop, onesided=onesided)
+    assert got.shape[-1] % 16 != 0
+    for c in range(clips):
+        ref = orc.stft(x[c].astype(np.float64), w, hop)
+        ref = ref[:wl // 2 + 1] if onesided else ref
+        assert got[c].shape == ref.shape
+        assert relerr(got[c], ref) <= TOL_FFT
+        assert relerr(got[c][:, -3:], ref[:, -3:]) <= 1e-4 and relerr(got[c][:, :3], ref[:, :3]) <= 1e-4
+    # the padded layout (other kernel, other butterfly schedule) holds the same numbers to rounding
+    pad = zafx.stft_plan(w, hop, onesided=onesided, row_align=16).run_host(x, n)
+    assert relerr(pad, got) <= 2e-6

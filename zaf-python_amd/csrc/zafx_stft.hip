@@ -335,6 +335,193 @@ __global__ __launch_bounds__(kFatWaves * 64) void k_stft_ft16(
 }
 
 // ---------------------------------------------------------------------------------
+// forward, reference layout, rows that are NOT whole 128-byte lines (T % 16 != 0): k_stft_ft16 with a register carry
+// ---------------------------------------------------------------------------------
+// The reference's (W, T) array is compact (zaf.py:128), so unless T is a multiple of 16 a tile's 128-byte run of a row
+// straddles two lines and every line is written in two parts by two workgroups at different times: HBM3E has no byte masks
+// (partial sectors are read-modify-written), and the 8 MB a XCD's workgroups have in flight do not let L2 merge the parts --
+// T = 433 ran at 1.96 TB/s where T = 432 runs at 5.4 (round 3 bench line, stft_offgrid).  This form walks the tiles of a clip
+// segment IN ORDER and carries every row's previous 16 values in registers: thread (frame column tt, rows k = kq + 32 it)
+// keeps its own X[k], X[N-k] of the previous tile (64 VGPRs; the mirror rows are their conjugates).  For a row whose run
+// starts a frames into a line, lanes tt < 16 - a store the current tile's value at frame t0 + tt and lanes tt >= 16 - a store
+// the CARRIED value at frame t0 - 16 + tt: the sixteen lanes of an instruction again cover exactly one line.  Partial lines
+// remain only at the two ends of a segment (head: no carry yet; tail: flushed with the last tile).  Radix-16 schedule
+// (32 + 64 registers of transform and prefetch beside the carry; the radix-32 form of k_stft_ft16 stands at 206).
+template <int LOG2N, int LOG2E, bool ALIGNED, int SPEC>
+__global__ __launch_bounds__(kFatWaves * 64) void k_stft_ft16c(
+    const float* __restrict__ x, const float* __restrict__ win, const float2* __restrict__ twp,
+    const float2* __restrict__ tws, float2* __restrict__ out, long long n_samples, int hop, int T, int TP, int tiles,
+    int segs, int seg_tiles, int units) {
+    static_assert(SPEC < 2, "complex spectra only (the real kinds write 64-byte runs)");
+    using C = FftCfg<LOG2N, LOG2E>;
+    using F = FatCfg<LOG2N, LOG2E>;
+    constexpr int N = C::N, P = C::P, E = C::E, W = 2 * N, NT = F::NT, FPB = kFatFrames, FPW = F::FPW, PITCH = F::PITCH;
+    constexpr int ROWS = SPEC ? N + 1 : W;
+    constexpr int ITER = (N / 2) / (NT / FPB);
+    static_assert((N / 2) % (NT / FPB) == 0 && ITER >= 1, "the row sweep is a whole number of iterations");
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    float2* frames = reinterpret_cast<float2*>(smem_raw);
+    float2* tw_l = frames + FPB * PITCH;
+    float2* win_l = tw_l + C::TW;
+    float2* tws_l = win_l + N;
+    const int tid = threadIdx.x;
+    for (int i = tid; i < C::TW; i += NT) tw_l[i] = twp[i];
+    for (int i = tid; i < N; i += NT) win_l[i] = reinterpret_cast<const float2*>(win)[i];
+    for (int i = tid; i <= N / 2; i += NT) tws_l[i] = tws[i];
+    __syncthreads();
+    const int wave = tid / P, p_lane = tid % P;
+    const int tt = tid % FPB, kq = tid / FPB;
+    const float2* fb = frames + tt * PITCH;
+    const bool xcd = ZAFX_XCD_ORDER && gridDim.x % 8 == 0;
+    const int b0 = (int)((reinterpret_cast<uintptr_t>(out) >> 3) & 15);   // phase of the array's first element in its line
+
+    float2 xr[FPW][E];
+    auto prefetch = [&](int clip, int tile) {
+        const float* xc = x + (long long)clip * n_samples;
+        if constexpr (ALIGNED) {
+            // buffer loads with the CLIP as descriptor: a pair of samples before the clip's first or behind its last sample is out
+            // of the descriptor's range and reads as zero -- which is the reference's zero padding (zaf.py:112-125; n_samples, hop
+            // and every pair's first sample are even, so a pair is inside or outside as a whole).  No edge path, no 64-bit addresses.
+            const __amdgpu_buffer_rsrc_t rs = make_rsrc(xc, (unsigned)(n_samples * 4));
+#pragma unroll
+            for (int f = 0; f < FPW; ++f) {
+                const int s0 = (tile * FPB + wave * FPW + f) * hop - N;   // (clips below 2^29 samples: run_stft_fat_carry)
+                const int vo = (s0 + 2 * p_lane) * 4;
+#pragma unroll
+                for (int i = 0; i < E; ++i) xr[f][i] = buf_load_f32x2(rs, vo + i * P * 8);
+            }
+        } else {
+#pragma unroll
+            for (int f = 0; f < FPW; ++f) {
+                const int t = tile * FPB + wave * FPW + f;
+                const long long s0 = (long long)t * hop - N;
+#pragma unroll
+                for (int i = 0; i < E; ++i) {
+                    const long long s = s0 + 2 * (p_lane + i * P);
+                    xr[f][i].x = (t < T && s >= 0 && s < n_samples) ? xc[s] : 0.f;
+                    xr[f][i].y = (t < T && s + 1 >= 0 && s + 1 < n_samples) ? xc[s + 1] : 0.f;
+                }
+            }
+        }
+    };
+    // unit v of this workgroup's walk -> clip and tile range [j, j1) of its segment
+    auto unit_of = [&](int v, int& clip, int& j, int& j1) {
+        const int u = xcd ? xcd_order(v, units) : v;
+        clip = u / segs;
+        j = (u % segs) * seg_tiles;
+        j1 = min(j + seg_tiles, tiles);
+    };
+    int v = blockIdx.x;
+    if (v >= units) return;
+    int clip, j, j1;
+    unit_of(v, clip, j, j1);
+    prefetch(clip, j);
+    float2 ck[ITER], cn[ITER];   // the thread's X[k], X[N-k] of the previous tile (k = kq + 32 it)
+#pragma unroll
+    for (int it = 0; it < ITER; ++it) ck[it] = cn[it] = make_float2(0.f, 0.f);
+    bool have_prev = false;
+    for (;;) {
+        int po = p_lane;
+        asm volatile("" : "+v"(po));
+        // The windowed samples of the wave's later frames are parked in their own (still unused) frame buffers while the first
+        // frame is transformed: the prefetch registers are then free through the butterflies, whose ~110 registers beside the
+        // 64 of the carry and 32 of a second frame's samples spilled (100 bytes of scratch per lane, reloads draining vmcnt).
+#pragma unroll
+        for (int f = 1; f < FPW; ++f) {
+            float2* park = frames + (wave * FPW + f) * PITCH;
+#pragma unroll
+            for (int i = 0; i < E; ++i) {
+                const float2 wv = win_l[po + i * P];
+                park[po + i * P] = make_float2(xr[f][i].x * wv.x, xr[f][i].y * wv.y);
+            }
+        }
+#pragma unroll
+        for (int f = 0; f < FPW; ++f) {
+            float2 vv[E];
+            float2* buf = frames + (wave * FPW + f) * PITCH;
+            if (f == 0) {
+#pragma unroll
+                for (int i = 0; i < E; ++i) {
+                    const float2 wv = win_l[po + i * P];
+                    vv[i] = make_float2(xr[0][i].x * wv.x, xr[0][i].y * wv.y);
+                }
+            } else {
+                frame_sync<P>();
+#pragma unroll
+                for (int i = 0; i < E; ++i) vv[i] = buf[po + i * P];
+                frame_sync<P>();   // every lane has its samples before the first pass overwrites the buffer
+            }
+            fft_frame<LOG2N, LOG2E>(vv, buf, po, tw_l);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        // the next tile of the walk, requested ahead of the barrier (as k_stft_ft16)
+        int nclip = clip, nj = j + 1, nj1 = j1, nv = v;
+        bool more = true;
+        if (nj >= j1) {
+            nv = v + gridDim.x;
+            if (nv < units) unit_of(nv, nclip, nj, nj1);
+            else more = false;
+        }
+        if (more) prefetch(nclip, nj);
+        lds_barrier();
+        {
+            const int t0 = j * FPB;
+            const bool last = j + 1 >= j1, cur_ok = t0 + tt < T;
+            float2* o = out + (long long)clip * ROWS * TP + (t0 + tt);
+            const int c0 = (int)(((long long)clip * ROWS) & 15), tp = TP & 15;
+            int kqo = kq;
+            asm volatile("" : "+v"(kqo));
+            auto sweep = [&](auto stream) {
+                constexpr bool ST = decltype(stream)::value;
+                // one row of the sweep: `cur` = this tile's value of the thread's frame, `prev` = the carried one
+                auto emit = [&](int r, float2 cur, float2 prev) {
+                    const int a = (b0 + (c0 + r) * tp) & 15;   // frames of this tile's run that lie before the first line boundary ... the run starts a frames into a line
+                    const bool from_prev = tt >= 16 - a;        // (a = 0: never -- the run is a whole line)
+                    const float2 val = from_prev ? prev : cur;
+                    float2* dst = o + (long long)r * TP;
+                    if (from_prev ? have_prev : cur_ok) {
+                        if constexpr (ST) store_stream(dst + (from_prev ? -16 : 0), val);
+                        else dst[from_prev ? -16 : 0] = val;
+                    }
+                    if (last && from_prev && cur_ok) *dst = cur;   // tail of the segment's last run (a partial line)
+                };
+#pragma unroll
+                for (int it = 0; it < ITER; ++it) {
+                    const int k = kqo + it * (NT / FPB);
+                    float2 xk, xn;
+                    if (it == 0 && k == 0) {
+                        const float2 z0 = fb[0], zc = fb[phys_t<C::PS>(N / 2)];
+                        xk = cconj(zc);                                   // row N/2 (its mirror, row 3N/2: zc)
+                        xn = make_float2(z0.x + z0.y, z0.x - z0.y);       // rows 0 and N: both real, carried as one pair
+                        emit(N / 2, xk, ck[0]);
+                        if (SPEC == 0) emit(N + N / 2, cconj(xk), cconj(ck[0]));
+                        emit(0, make_float2(xn.x, 0.f), make_float2(cn[0].x, 0.f));
+                        emit(N, make_float2(xn.y, 0.f), make_float2(cn[0].y, 0.f));
+                    } else {
+                        split_pair(fb[phys_t<C::PS>(k)], fb[phys_t<C::PS>(N - k)], tws_l[k], xk, xn);
+                        emit(k, xk, ck[it]);
+                        if (SPEC == 0) emit(W - k, cconj(xk), cconj(ck[it]));
+                        emit(N - k, xn, cn[it]);
+                        if (SPEC == 0) emit(N + k, cconj(xn), cconj(cn[it]));
+                    }
+                    ck[it] = xk;
+                    cn[it] = xn;
+                    __builtin_amdgcn_sched_barrier(0);   // (iterations stay apart: their LDS reads hoisted ahead cost the registers the carry needs)
+                }
+            };
+            // a segment's first tile writes partial lines (no carry yet): ordinary stores, which L2 may still merge with the
+            // neighbouring segment's tail; every later tile writes whole lines and streams them
+            if (have_prev) sweep(std::true_type{});
+            else sweep(std::false_type{});
+        }
+        lds_barrier();
+        if (!more) break;
+        have_prev = nj != 0 && nv == v;   // the walk continues inside the same segment
+        clip = nclip, j = nj, j1 = nj1, v = nv;
+    }
+}
+
+// ---------------------------------------------------------------------------------
 // forward, frame-major layout (ZAFX_LAYOUT_TF), persistent and barrier free
 // ---------------------------------------------------------------------------------
 // Every frame's 2 W bins are contiguous in this layout, so a frame never has to meet its
@@ -1057,6 +1244,29 @@ static hipError_t run_stft_fat(const zafx_plan& pl, const float* x, float2* out,
     return hipGetLastError();
 }
 
+// k_stft_ft16c: complex spectra whose rows are not whole 128-byte lines (see the kernel)
+template <int LOG2N, bool ALIGNED, int SPEC>
+static hipError_t run_stft_fat_carry(const zafx_plan& pl, const float* x, float2* out, int64_t n_clips, int64_t n_samples, int T) {
+    if constexpr (SPEC < 2) {
+        constexpr int LOG2E = default_log2e(LOG2N);
+        using F = FatCfg<LOG2N, LOG2E>;
+        auto kern = k_stft_ft16c<LOG2N, LOG2E, ALIGNED, SPEC>;
+        if (hipError_t e = ensure_dynamic_lds(reinterpret_cast<const void*>(kern), pl.device, F::SMEM); e != hipSuccess) return e;
+        const int tiles = (T + kFatFrames - 1) / kFatFrames;
+        if ((long long)tiles * n_clips <= 0) return hipSuccess;
+        const long long max_grid = pl.n_cus;
+        const int segs = carry_segments(n_clips, tiles, max_grid);
+        const int seg_tiles = (tiles + segs - 1) / segs;
+        const long long units = (long long)n_clips * segs;
+        const long long grid = std::min<long long>(units, max_grid);
+        hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(F::NT), F::SMEM, pl.stream, x, pl.d_window, pl.d_tw_pass, pl.d_tw_aux, out,
+                           (long long)n_samples, pl.H, T, (int)row_pitch(pl, T), tiles, segs, seg_tiles, (int)units);
+        return hipGetLastError();
+    } else {
+        return hipErrorInvalidValue;
+    }
+}
+
 constexpr bool stft_use_tf(int log2n, int layout) {
     return layout == ZAFX_LAYOUT_TF && log2n >= 7 && log2n <= 10;   // one wavefront (or half of one) per frame
 }
@@ -1083,6 +1293,15 @@ template <int LOG2N, int LAYOUT, int SPEC>
 static hipError_t run_stft(const zafx_plan& pl, const float* x, float2* out, int64_t n_clips, int64_t n_samples, int T) {
     const bool aligned = (n_samples % 2 == 0) && (pl.H % 2 == 0) && (reinterpret_cast<uintptr_t>(x) % 8 == 0);
     if constexpr (stft_use_fat(LOG2N, LAYOUT)) {
+#ifndef ZAFX_STFT_CARRY
+#define ZAFX_STFT_CARRY 1
+#endif
+        if constexpr (SPEC < 2 && ZAFX_STFT_CARRY) {
+            // rows off the 128-byte grid (the array itself only needs its 8-byte alignment): the carry form writes whole lines anyway
+            if ((row_pitch(pl, T) % 16 != 0 || reinterpret_cast<uintptr_t>(out) % 128 != 0) && reinterpret_cast<uintptr_t>(out) % 8 == 0 && n_clips * (long long)T < (1LL << 31))
+                return aligned && n_samples < (1LL << 29) && (long long)T * pl.H < (1LL << 29) ? run_stft_fat_carry<LOG2N, true, SPEC>(pl, x, out, n_clips, n_samples, T)
+                               : run_stft_fat_carry<LOG2N, false, SPEC>(pl, x, out, n_clips, n_samples, T);
+        }
         return aligned ? run_stft_fat<LOG2N, true, SPEC>(pl, x, out, n_clips, n_samples, T)
                        : run_stft_fat<LOG2N, false, SPEC>(pl, x, out, n_clips, n_samples, T);
     } else if constexpr (stft_use_tf(LOG2N, LAYOUT)) {

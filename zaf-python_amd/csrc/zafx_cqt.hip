@@ -63,7 +63,7 @@ __global__ __launch_bounds__(fft_threads(LOG2N, LOG2E)) void k_cqt(
     const float* __restrict__ x, const float2* __restrict__ twp, const float2* __restrict__ tws,
     const int4* __restrict__ wave_tab, const int* __restrict__ addrs, const float* __restrict__ values,
     float* __restrict__ out, long long n_samples, int step, int left_pad, int T, int TP, int n_clips, int n_groups, int n_bins, int chroma_res,
-    int layout, int k_lo, int k_hi, int k_special, int n_entries) {
+    int layout, int k_lo, int k_hi, int k_special, int n_entries, int prune3) {
     using C = FftCfg<LOG2N, LOG2E>;
     using G = CqtCfg<LOG2N, LOG2E>;
     using KV = std::conditional_t<REALK, float, float2>;
@@ -229,7 +229,8 @@ __global__ __launch_bounds__(fft_threads(LOG2N, LOG2E)) void k_cqt(
             float2* sub = buf + (p >> 6) * kCqtRegion;
             regs_read<10, 4>(v, sub, lane);
             frame_sync<64>();
-            fft_frame_chain<10, 4>(v, sub, lane, TwoLevelTw{sub_hi, sub_hi + 8});
+            // (the last pass leaves only the positions the split and the contraction read: run_cqt's mask)
+            fft1024_wave(v, sub, lane, TwoLevelTw{sub_hi, sub_hi + 8}, 0, prune3);
         } else {
             fft_frame_chain<LOG2N, LOG2E>(v, buf, p, tw2l);
         }
@@ -414,10 +415,19 @@ static hipError_t run_cqt(const zafx_plan& pl, const float* x, float* out, int64
     const int n_groups = (int)std::min<int64_t>(8, n_clips);
     const long long per_group = ((n_clips + n_groups - 1) / n_groups) * (long long)T;   // frames of the longest list
     const int grid = (int)std::min<long long>(std::max(pl.n_cus / n_groups, 1) * (long long)n_groups, per_group * n_groups);
+    // Bin k lives in sub-transform k & 15 at position k >> 4.  The split reads the pairs (k, N - k) of k_lo .. k_hi: positions up to
+    // k_hi >> 4 and their mirrors from 1024 - (k_hi >> 4); when they all lie in the lowest / highest 64 (HB + 1) positions, HB <= 2,
+    // the last pass of the sub-transforms forms only those (pass3_write_pruned).  Columns 0, N / 2, N need position 512: full pass.
+    int prune3 = -1;
+#ifndef ZAFX_CQT_PRUNE
+#define ZAFX_CQT_PRUNE 1
+#endif
+    if (ZAFX_CQT_PRUNE && cqt_split(LOG2N) && !pl.cqt_k_special && pl.cqt_k_hi >= pl.cqt_k_lo && ((pl.cqt_k_hi >> 4) >> 6) <= 2)
+        prune3 = (pl.cqt_k_hi >> 4) >> 6;
     hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(C::P), smem, pl.stream, x, pl.d_tw_pass, pl.d_tw_aux, pl.d_cqt_waves,
                        pl.d_cqt_addrs, pl.d_cqt_vals, out, (long long)n_samples, pl.H, left, T, (int)row_pitch(pl, T), (int)n_clips, n_groups,
                        pl.prm.n_bins, pl.kind == ZAFX_CHROMA ? pl.prm.octave_resolution : 0, pl.layout, pl.cqt_k_lo, pl.cqt_k_hi,
-                       pl.cqt_k_special, std::max(pl.cqt_n_entries, 1));
+                       pl.cqt_k_special, std::max(pl.cqt_n_entries, 1), prune3);
     return hipGetLastError();
 }
 

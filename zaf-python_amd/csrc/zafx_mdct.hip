@@ -326,21 +326,35 @@ __global__ __launch_bounds__(NSLOT * 64) void k_mdct_ft32(
             const int dslot = odd ? -2 * DPH : 2 * DPH;     // floats
             float* dst = o + (long long)fqo * TP;
             const long long dstep = (long long)(NT / 16) * TP;
+            // (A sweep that starts somewhere else in every workgroup, as in k_stft_ft16, gains nothing here: 0.791 against 0.787 ms,
+            // A/B on one box, round 3 -- the switch stays for the experiment.)
+            constexpr int ITER = M / (NT / 16);
+#ifndef ZAFX_MDCT_ROWROT_EXPR
+#define ZAFX_MDCT_ROWROT_EXPR 0
+#endif
+            const int rot = (lines_whole && pair_ok && M % (NT / 16) == 0) ? (ZAFX_MDCT_ROWROT_EXPR) % ITER : 0;
+            auto sweep = [&](int i0, int i1) {
+                const float* qa = pa + (long long)i0 * dslot;
+                const float* qb = pb2 + (long long)i0 * dslot;
+                float* d = dst + (long long)i0 * dstep;
 #pragma unroll 4
-            for (int f = fqo; f < M; f += NT / 16) {
-                const float va = *pa, vb = *pb2;
-                if (pair_ok && two) {
-                    if (lines_whole) store_stream(reinterpret_cast<float2*>(dst), make_float2(va, vb));   // a 128-B line per 16 lanes, written once
-                    else *reinterpret_cast<float2*>(dst) = make_float2(va, vb);
+                for (int f = fqo + i0 * (NT / 16); f < M && i0 < i1; f += NT / 16, ++i0) {
+                    const float va = *qa, vb = *qb;
+                    if (pair_ok && two) {
+                        if (lines_whole) store_stream(reinterpret_cast<float2*>(d), make_float2(va, vb));   // a 128-B line per 16 lanes, written once
+                        else *reinterpret_cast<float2*>(d) = make_float2(va, vb);
+                    }
+                    else {
+                        d[0] = va;
+                        if (two) d[1] = vb;
+                    }
+                    qa += dslot;
+                    qb += dslot;
+                    d += dstep;
                 }
-                else {
-                    dst[0] = va;
-                    if (two) dst[1] = vb;
-                }
-                pa += dslot;
-                pb2 += dslot;
-                dst += dstep;
-            }
+            };
+            sweep(rot, ITER + 1);
+            if (rot) sweep(0, rot);
         }
         PROF_MARK(4);
         lds_barrier();   // LDS reads of the tile are done; its global stores are not waited for

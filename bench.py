@@ -397,7 +397,7 @@ def prewarm(plan, d_in, d_out, n_clips, n_in, seconds=None):
     """Keep the device busy with this plan for `seconds` (untimed): the clocks of an idle MI355X ramp over the first few hundred
     milliseconds of work, and the contract's warm-up is a COUNT -- 5 launches of a 1 ms kernel end inside the ramp (round 2:
     the driver's --steps 20 --warmup 5 measured the ~1 ms kernels 5-8 % above their steady state)."""
-    seconds = float(os.environ.get("ZAFX_BENCH_PREWARM_S", "0.4")) if seconds is None else seconds
+    seconds = float(os.environ.get("ZAFX_BENCH_PREWARM_S", "0.0" if os.environ.get("ZAFX_BENCH_INNER") == "1" else "0.4")) if seconds is None else seconds
     t_end = time.perf_counter() + seconds
     n = 0
     while time.perf_counter() < t_end:
@@ -445,6 +445,53 @@ def time_workload(wl, steps, warmup, rdzv):
             "kernel_ms_per_rank": [round(v, 4) for v in per_rank]}
 
 
+def live_traffic(kind, kernel_name):
+    """HBM bytes per launch of the dominant kernel, measured NOW: two separate `rocprofv3 --pmc` passes (FETCH_SIZE, WRITE_SIZE:
+    the TCC block cannot count both in one pass) of this script with --steps 3, corrected as MI355X_MICROARCH.md prescribes
+    (gfx950 tallies the 128-byte requests of streaming reads at 64 bytes: FETCH_SIZE x 2; WRITE_SIZE as counted -- both checked
+    on the device-to-device copies of the same run, whose byte count is known).  None when rocprofv3 is not there or fails."""
+    import csv
+    import glob
+    import shutil
+    import tempfile
+    exe = shutil.which("rocprofv3") or ("/opt/rocm/bin/rocprofv3" if os.path.exists("/opt/rocm/bin/rocprofv3") else None)
+    if exe is None or os.environ.get("ZAFX_BENCH_LIVE_TRAFFIC", "1") == "0":
+        return None
+    out = {}
+    work = tempfile.mkdtemp(prefix="zafx_pmc_", dir="/tmp")
+    try:
+        for counter in ("FETCH_SIZE", "WRITE_SIZE"):
+            d = os.path.join(work, counter)
+            env = dict(os.environ, TMPDIR="/tmp", ZAFX_BENCH_INNER="1")
+            cmd = [exe, "--pmc", counter, "--kernel-trace", "--output-format", "csv", "-d", d, "-o", "p", "--",
+                   sys.executable, os.path.abspath(__file__), "--kind", kind, "--steps", "3", "--warmup", "1", "--no-cpu-baseline"]
+            subprocess.run(cmd, cwd="/tmp", env=env, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=180, check=True)
+            files = glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True)
+            if not files:
+                return None
+            acc = {}
+            with open(files[0]) as fh:
+                for r in csv.DictReader(fh):
+                    if r.get("Counter_Name") == counter:
+                        v = acc.setdefault(r["Kernel_Name"].split("(")[0], [0, 0.0])
+                        v[0] += 1
+                        v[1] += float(r["Counter_Value"])
+            kern = next((k for k in acc if kernel_name in k), None)
+            if kern is None:
+                return None
+            out[counter] = acc[kern][1] / acc[kern][0] * 1024.0   # KB -> bytes, mean over the dispatches
+            out[counter + "_dispatches"] = acc[kern][0]
+            copy = next((k for k in acc if "copyBuffer" in k), None)
+            if copy:   # make_workload replicates blocks of 8 clips device to device: a dispatch of known size
+                out[counter + "_true_over_counter_on_copy"] = round(441000 * 4 * 8 / (acc[copy][1] / acc[copy][0] * 1024.0), 4)
+    except Exception as exc:   # reported, never fatal
+        return {"error": f"{type(exc).__name__}: {exc}"[:300]}
+    finally:
+        shutil.rmtree(work, ignore_errors=True)
+    out["hbm_bytes_per_launch"] = out["FETCH_SIZE"] * 2.0 + out["WRITE_SIZE"]
+    return out
+
+
 def roofline_of(wl, tm, kind):
     kernel_ms = tm["kernel_ms"]
     gbs = wl["bytes_per_launch"] / (kernel_ms * 1e-3) / 1e9
@@ -458,6 +505,16 @@ def roofline_of(wl, tm, kind):
             rec = json.load(f)
         roof["traffic"] = rec.get("hbm_bytes_per_launch")
         roof["traffic_source"] = f"profiles/pmc_{kind}.json ({rec.get('collected', 'separate rocprofv3 --pmc passes')}); not measured in this run"
+    if kind == "stft" and os.environ.get("ZAFX_BENCH_INNER") != "1" and wl.get("live_traffic", False):
+        live = live_traffic(kind, wl["plan"].kernel_name)
+        if live and "hbm_bytes_per_launch" in live:
+            roof["traffic"] = round(live["hbm_bytes_per_launch"])
+            roof["traffic_source"] = ("measured in this run: two rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE) of `bench.py --kind stft --steps 3` "
+                                      "started by this script; FETCH_SIZE x 2 + WRITE_SIZE (MI355X_MICROARCH.md, HBM section)")
+            roof["traffic_detail"] = {k: (round(v) if isinstance(v, float) and v > 10 else v) for k, v in live.items()}
+            roof["traffic_over_algorithmic"] = round(live["hbm_bytes_per_launch"] / wl["bytes_per_launch"], 4)
+        elif live:
+            roof["traffic_live_error"] = live.get("error")
     if wl["flops_per_launch"]:
         # configs 3 and 5 (and the dct GEMM) are bound by f32 arithmetic (vector and f32-MFMA peaks are both
         # 157.3 TF), not by HBM; both fractions are reported side by side
@@ -469,10 +526,11 @@ def roofline_of(wl, tm, kind):
     return roof
 
 
-def e2e_pcie(device, clips=256):
+def e2e_pcie(device, clips=512):
     """PCIe-inclusive figures of the host-array boundary (never `value`): page-locked host f32 -> HBM -> kernel -> page-locked
-    host c64 through Plan.run_host (zafx_run_host: chunks over two streams, upload / kernel / download overlapped), two-sided
-    and one-sided, with the serial one-stream sequence of round 2 beside it."""
+    host c64 through Plan.run_host (zafx_run_host: chunks through a three-stage pipeline -- upload stream, kernel stream,
+    download stream -- so that the three phases overlap), two-sided and one-sided, with the serial one-stream sequence of
+    round 2 beside it."""
     import zafx
     N = 441000
     x = zafx.pinned_empty((clips, N), np.float32)
@@ -490,7 +548,7 @@ def e2e_pcie(device, clips=256):
             best = dt if best is None else min(best, dt)
         rec = {"value": round(clips * N / best / 1e6, 1), "unit": "Msamples/s",
                "sample": f"{clips} clips x 10 s, page-locked host arrays both ways (zafx.pinned_empty), Plan.run_host = zafx_run_host: chunked, "
-                         f"two streams, best of 3: {best * 1e3:.1f} ms for {x.nbytes / 1e6:.0f} MB up + {host.nbytes / 1e6:.0f} MB down "
+                         f"upload / kernel / download streams, best of 3: {best * 1e3:.1f} ms for {x.nbytes / 1e6:.0f} MB up + {host.nbytes / 1e6:.0f} MB down "
                          f"({host.nbytes / best / 1e9:.1f} GB/s of download alone)"}
         if not onesided:   # the serial sequence of round 2, same buffers
             d_in = zafx.DeviceBuffer((clips, N), np.float32, device)
@@ -530,6 +588,7 @@ def run_kind(kind, args, device, rank, world, rdzv, comm, with_cpu):
             # every rank has already built identical constants from the same deterministic host code, so the measurement
             # stands; the failure is carried into the line (main() turns it into a non-zero exit)
             bcast = f"FAILED ({exc}); every rank built its own constants"
+    wl["live_traffic"] = world == 1 and kind == "stft" and args.kind == "all"
     tm = time_workload(wl, args.steps, args.warmup, rdzv)
     tm["broadcast_s"] = bcast_s
     entry = None

@@ -11,8 +11,8 @@ import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 OUT, PROF = os.path.join(ROOT, "gpurun_out"), os.path.join(ROOT, "profiles")
-tag = sys.argv[1] if len(sys.argv) > 1 else "r02"
-KINDS = ["stft", "istft", "mdct", "imdct", "mel", "mfcc", "cqt", "dct"]
+tag = sys.argv[1] if len(sys.argv) > 1 else "r03"
+KINDS = ["stft", "istft", "mdct", "imdct", "mel", "mfcc", "cqt", "dct", "stft_offgrid"]
 
 
 def find(pattern):

@@ -1514,3 +1514,25 @@ def test_stft_rows_off_the_line_grid(zafx, wl, hop, n, clips, onesided):
     # the padded layout (other kernel, other butterfly schedule) holds the same numbers to rounding
     pad = zafx.stft_plan(w, hop, onesided=onesided, row_align=16).run_host(x, n)
     assert relerr(pad, got) <= 2e-6
+
+
+@pytest.mark.parametrize("wl,n,clips", [(2048, 441000 + 2048, 3), (2048, 33000, 5), (2048, 441000 + 8192, 2), (1024, 20600, 4), (512, 9300, 6),
+                                        (2048, 1024 * 471, 1), (2048, 3000, 2),
+                                        (2048, 30000, 3), (1024, 20000, 2), (2048, 442024, 3)])   # (the last three: odd T, 4-byte stores)
+def test_mdct_rows_off_the_line_grid(zafx, wl, n, clips):
+    """k_mdct_ft32's carry form (round 3): even T that is not a multiple of 16 -- rows that are not whole half lines are
+    completed from the previous tile's pairs carried in registers (odd T: the two floats of a pair choose separately).  Every clip against the oracle,
+    and the inverse back."""
+    w = zafx.kaiser_bessel_derived(wl)
+    x = np.stack([synth_clip(41, c, n) for c in range(clips)])
+    got = zafx.mdct_batch(x, w)
+    T = got.shape[-1]
+    assert T % 16 != 0
+    for c in range(clips):
+        ref = orc.mdct(x[c].astype(np.float64), w)
+        assert got[c].shape == ref.shape and relerr(got[c], ref) <= TOL_FFT
+        assert relerr(got[c][:, -2:], ref[:, -2:]) <= 1e-4 and relerr(got[c][:, :2], ref[:, :2]) <= 1e-4
+    y = zafx.imdct_batch(got, w)
+    assert np.max(np.abs(y[:, :n - 1] - x[:, :n - 1])) < 1e-5
+    pad = zafx.mdct_plan(w, row_align=32).run_host(x, n)
+    assert relerr(pad, got) <= 2e-6

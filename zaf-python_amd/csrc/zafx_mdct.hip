@@ -147,10 +147,18 @@ struct MdctPCfg {
 
 // TFOUT = frame-major output (ZAFX_LAYOUT_TF): a frame's M coefficients are contiguous, so the wave that transformed a
 // frame also stores it (512-B coalesced runs) and the workgroup never meets after the table staging.
-template <int LOG2NF, int LOG2E, bool ALIGNED, int NSLOT, bool TFOUT = false>
+// CARRY (reference layout, even T): rows that are not whole lines or half lines (T % 16 != 0) are completed from a register carry
+// of the previous tile, as in k_stft_ft16c: the
+// workgroup walks the tiles of a clip segment in order, thread (frame pair tp, rows fq + 64 i) keeps its own 16 pairs of the
+// previous tile (32 VGPRs, instead of the resident window quadruples), and for a row whose run starts `a` floats into a line the
+// lanes tp < 16 - a / 2 store the current pair at frame t0 + 2 tp, the others the carried pair at frame t0 - 32 + 2 tp: sixteen
+// lanes, one whole line.  segs / seg_tiles / units: the segment walk (carry_segments).
+template <int LOG2NF, int LOG2E, bool ALIGNED, int NSLOT, bool TFOUT = false, bool CARRY = false>
 __global__ __launch_bounds__(NSLOT * 64) void k_mdct_ft32(
     const float* __restrict__ x, const float4* __restrict__ wfold, const float2* __restrict__ twp,
-    const float2* __restrict__ tw8, float* __restrict__ out, long long n_samples, int T, int TP, int tiles, int total_tiles) {
+    const float2* __restrict__ tw8, float* __restrict__ out, long long n_samples, int T, int TP, int tiles, int total_tiles,
+    int segs = 1, int seg_tiles = 0, int units = 0) {
+    static_assert(!(CARRY && TFOUT), "the carry form is for the reference layout");
     using C = FftCfg<LOG2NF, LOG2E>;
     constexpr int NF = C::N, M = 2 * NF, W = 4 * NF, P = C::P, E = C::E, FPB = kMdctTile, NT = NSLOT * P;
     constexpr int FPW = FPB / NSLOT;                    // frames per wave and tile
@@ -223,7 +231,7 @@ __global__ __launch_bounds__(NSLOT * 64) void k_mdct_ft32(
     // The lane's window quadruples are the same for every frame.  REGS: held in registers (32 at W = 2048; the buffer-load form
     // of fetch() left the room -- with the pre-twiddles as well, 48, the kernel spills): 8 of the frame's 16-byte LDS reads
     // fewer on a kernel whose transforms are bound by LDS.
-    constexpr bool REGS = ZAFX_MDCT_TABLES_IN_REGS && ALIGNED && UPL <= 2;
+    constexpr bool REGS = ZAFX_MDCT_TABLES_IN_REGS && ALIGNED && UPL <= 2 && !CARRY;   // (the carry takes the window's registers)
     float4 wq[REGS ? UPL : 1][4];
     if constexpr (REGS) {
 #pragma unroll
@@ -253,12 +261,38 @@ __global__ __launch_bounds__(NSLOT * 64) void k_mdct_ft32(
         }
     };
 
+    // walk of this workgroup: tile tl, tl + gridDim.x, ... -- or (CARRY) the tiles j .. j1 - 1 of unit v, then of unit v + gridDim.x, ...
     int tl = blockIdx.x;
+    int wv = blockIdx.x, wj = 0, wj1 = 0;
+    constexpr int ITER = M / (NT / 16);
+    float cva[CARRY ? ITER : 1], cvb[CARRY ? ITER : 1];   // the thread's pairs of the previous tile
+    bool have_prev = false;
+    auto unit_tile = [&](int v, int& j, int& j1) -> int {   // first tile (linear index) of unit v
+        const int u = (ZAFX_XCD_ORDER && gridDim.x % 8 == 0) ? xcd_order(v, units) : v;
+        const int c = u / segs;
+        j = (u % segs) * seg_tiles;
+        j1 = min(j + seg_tiles, tiles);
+        return c * tiles + j;
+    };
+    if constexpr (CARRY) {
+        if (wv >= units) return;
+        tl = unit_tile(wv, wj, wj1);
+#pragma unroll
+        for (int i = 0; i < ITER; ++i) cva[i] = cvb[i] = 0.f;
+    }
     fetch(tl, 0);
     PROF_INIT(g_prof_mdct);
-    for (; tl < total_tiles; tl += gridDim.x) {
+    for (; tl < total_tiles;) {
         const int clip = tl / tiles, tile = tl % tiles;
         const int t0 = tile * FPB;
+        int tl_next = tl + gridDim.x, nj = wj + 1, nj1 = wj1, nv = wv;
+        if constexpr (CARRY) {
+            if (nj < wj1) tl_next = tl + 1;
+            else {
+                nv = wv + gridDim.x;
+                tl_next = nv < units ? unit_tile(nv, nj, nj1) : total_tiles;
+            }
+        }
         PROF_MARK(0);
 #pragma unroll 1
         for (int f = 0; f < FPW; ++f) {
@@ -266,7 +300,7 @@ __global__ __launch_bounds__(NSLOT * 64) void k_mdct_ft32(
             fold(buf);
             PROF_MARK(1);
             if (f + 1 < FPW) fetch(tl, f + 1);
-            else fetch(tl + gridDim.x, 0);
+            else fetch(tl_next, 0);
             frame_sync<P>();
             int po = p;   // opaque copy: the pass-twiddle reads stay in the loop (hoisted, they spill at 128 VGPRs)
             asm volatile("" : "+v"(po));
@@ -297,13 +331,65 @@ __global__ __launch_bounds__(NSLOT * 64) void k_mdct_ft32(
                 frame_sync<P>();   // these reads precede the buffer's next fold
             }
         }
-        if constexpr (TFOUT) continue;   // wave-private buffers: no workgroup barrier in the tile loop
+        if constexpr (TFOUT) {   // wave-private buffers: no workgroup barrier in the tile loop
+            tl = tl_next;
+            continue;
+        }
         lds_barrier();
         PROF_MARK(3);
         int tido = tid;   // opaque: the store-phase indices are recomputed per tile (kept live across the FFT loop they are
         asm volatile("" : "+v"(tido));   // spilled at 128 VGPRs, and a scratch reload here waits for vmcnt(0): the next tile's prefetch)
         const int tp = tido % 16, fq = tido / 16;
         const int ta = t0 + 2 * tp;
+        if constexpr (CARRY) {
+            int fqo = (fq & ~3) | ((fq & 1) << 1) | ((fq >> 1) & 1);   // (row order of the lane groups: see below)
+            asm volatile("" : "+v"(fqo));
+            const float2* ba = frames + (2 * tp) * C::PITCH;
+            const float2* bb = ba + C::PITCH;
+            float* o = out + (long long)clip * M * TP + ta;
+            const bool cur_ok = ta < T, last = wj + 1 >= wj1;
+            const int odd = fqo & 1;
+            const int k = odd ? (M - 1 - fqo) >> 1 : fqo >> 1;
+            constexpr int DK = NT / 32, DPH = DK + DK / 16;
+            const float* pa = reinterpret_cast<const float*>(ba + phys(k)) + odd;
+            const float* pb2 = reinterpret_cast<const float*>(bb + phys(k)) + odd;
+            const int dslot = odd ? -2 * DPH : 2 * DPH;
+            // phase of a row's run in its line, in floats: (array + (clip M + f) TP) mod 32 -- even, since TP and the array's offset are
+            const int b0 = (int)((reinterpret_cast<uintptr_t>(out) >> 2) & 31), c0 = (int)(((long long)clip * M) & 31), tpm = TP & 31;
+            const bool pairs = TP % 2 == 0 && reinterpret_cast<uintptr_t>(out) % 8 == 0;
+            auto sweep = [&](auto stream) {
+                constexpr bool ST = decltype(stream)::value;
+#pragma unroll
+                for (int i = 0; i < ITER; ++i) {
+                    const int f = fqo + i * (NT / 16);
+                    const float va = pa[i * dslot], vb = pb2[i * dslot];
+                    const int a = (b0 + (c0 + f) * tpm) & 31;
+                    float* dst = o + (long long)f * TP;
+                    if (pairs) {   // (uniform) even T: a is even, a lane's pair lies in one line
+                        const bool from_prev = tp >= 16 - (a >> 1);   // (a = 0: never)
+                        const float2 val = from_prev ? make_float2(cva[i], cvb[i]) : make_float2(va, vb);
+                        if (from_prev ? have_prev : cur_ok) {
+                            if constexpr (ST) store_stream(reinterpret_cast<float2*>(dst + (from_prev ? -32 : 0)), val);
+                            else *reinterpret_cast<float2*>(dst + (from_prev ? -32 : 0)) = val;
+                        }
+                        if (last && from_prev && cur_ok) *reinterpret_cast<float2*>(dst) = make_float2(va, vb);   // tail of the segment's last run
+                    } else {
+                        // odd T: rows start at any float, a pair may straddle the line boundary: the two floats of a lane choose for
+                        // themselves, as two 4-byte stores -- two instructions of the same wave, back to back, that together cover the
+                        // line (L2 merges them)
+                        const bool pa_ = 2 * tp >= 32 - a, pb_ = 2 * tp + 1 >= 32 - a;
+                        if (pa_ ? have_prev : cur_ok) dst[pa_ ? -32 : 0] = pa_ ? cva[i] : va;
+                        if (pb_ ? have_prev : (ta + 1 < T)) dst[pb_ ? -31 : 1] = pb_ ? cvb[i] : vb;
+                        if (last && pa_ && cur_ok) dst[0] = va;
+                        if (last && pb_ && ta + 1 < T) dst[1] = vb;
+                    }
+                    cva[i] = va;
+                    cvb[i] = vb;
+                }
+            };
+            if (have_prev) sweep(std::true_type{});
+            else sweep(std::false_type{});
+        } else
         if (ta < T) {
             // Row of lane group g = (tid / 16) % 4 within the wave's 4 rows: 0, 2, 1, 3.  ds_read_b64 serves 32 lanes
             // per cycle; rows f and f + 2 of a half-wave read bins k and k + 1 (bank offset 2 dwords: conflict free with
@@ -358,6 +444,11 @@ __global__ __launch_bounds__(NSLOT * 64) void k_mdct_ft32(
         }
         PROF_MARK(4);
         lds_barrier();   // LDS reads of the tile are done; its global stores are not waited for
+        if constexpr (CARRY) {
+            have_prev = nv == wv;   // the walk continues inside the same segment
+            wv = nv, wj = nj, wj1 = nj1;
+        }
+        tl = tl_next;
     }
 }
 
@@ -778,9 +869,30 @@ static hipError_t run_mdct_p(const zafx_plan& pl, const float* x, float* out, in
     const long long total = (long long)tiles * n_clips;
     if (total <= 0) return hipSuccess;
     const int per_cu = (int)std::min<size_t>(2, (size_t)kMaxLdsBytes / G::SMEM);
-    const long long grid = std::min<long long>(total, (long long)pl.n_cus * std::max(per_cu, 1));
+    const long long max_grid = (long long)pl.n_cus * std::max(per_cu, 1);
+#ifndef ZAFX_MDCT_CARRY
+#define ZAFX_MDCT_CARRY 1
+#endif
+    if constexpr (!TFOUT && ZAFX_MDCT_CARRY) {
+        // Rows that are not even whole 64-byte half lines (T % 16 != 0; odd T with 4-byte stores): the carry form -- 1024 clips: T = 434 / 436 / 440 run
+        // 0.84 ms (4.3 TB/s) with it against 1.37 / 1.29 / 1.09 ms without.  At T % 16 == 0 (the benchmark's 432: odd rows start 64 bytes
+        // into a line and leave as two streamed half lines) the plain form is faster, 0.771 against 0.826 ms: the carry takes the
+        // registers of the resident window quadruples, worth 10 % on this LDS-bound kernel.
+        const int TP = (int)row_pitch(pl, T);
+        if (aligned && (TP % 16 != 0 || reinterpret_cast<uintptr_t>(out) % 64 != 0) && total < (1LL << 31)) {
+            auto kc = k_mdct_ft32<LOG2NF, LOG2E, true, G::NSLOT, false, true>;
+            if (hipError_t e = ensure_dynamic_lds(reinterpret_cast<const void*>(kc), pl.device, G::SMEM); e != hipSuccess) return e;
+            const int segs = carry_segments(n_clips, tiles, max_grid);
+            const int seg_tiles = (tiles + segs - 1) / segs;
+            const long long units = (long long)n_clips * segs;
+            hipLaunchKernelGGL(kc, dim3((unsigned)std::min<long long>(units, max_grid)), dim3(G::NSLOT * 64), G::SMEM, pl.stream, x, pl.d_wfold, pl.d_tw_pass,
+                               pl.d_tw_aux, out, (long long)n_samples, T, TP, tiles, (int)total, segs, seg_tiles, (int)units);
+            return hipGetLastError();
+        }
+    }
+    const long long grid = std::min<long long>(total, max_grid);
     hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(G::NSLOT * 64), G::SMEM, pl.stream, x, pl.d_wfold, pl.d_tw_pass, pl.d_tw_aux, out,
-                       (long long)n_samples, T, (int)row_pitch(pl, T), tiles, (int)total);
+                       (long long)n_samples, T, (int)row_pitch(pl, T), tiles, (int)total, 1, 0, 0);
     return hipGetLastError();
 }
 

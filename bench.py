@@ -49,7 +49,7 @@ HBM_ACHIEVABLE_GBS = 6290.0   # same guide: measured-achievable copy rate
 F32_PEAK_TFLOPS = 157.3    # dense f32 vector / f32-input MFMA peak
 PLACEMENT_SURVEY = 6       # further allocations of the headline's row-strided output probed AFTER every timed region (reported, never timed)
 CONFIG_KINDS = ("istft", "mel", "mfcc", "mdct", "imdct", "cqt")   # SURVEY 8(a) a2 + BASELINE configs 3, 4, 5 (config 2 = the headline)
-EXTRA_KINDS = ("stft1", "istft1", "stft_offgrid", "stft4096")   # one-sided pair (8f rank 4) and geometries off the benchmark's grid
+EXTRA_KINDS = ("stft1", "istft1", "stft_offgrid", "mdct_offgrid", "stft4096")   # one-sided pair (8f rank 4) and geometries off the benchmark's grid
 
 
 def synth(seed, c, n):
@@ -85,6 +85,8 @@ def make_workload(kind, device, layout="FT"):
         N, T = 442024, 433        # one more frame than config 2: rows of 433 complex64 = 3464 B, off the 128-byte grid
     if kind == "stft4096":
         T = 217
+    if kind == "mdct_offgrid":
+        N, T = 442024, 433       # ceil(N / 1024) + 1 (zaf.py:1033): float32 rows of 1732 B
     base = np.stack([synth(0, c, N) for c in range(distinct)])
     d_base = zafx.DeviceBuffer.from_host(base, device)
     d_x = zafx.DeviceBuffer((B, N), np.float32, device)
@@ -137,6 +139,10 @@ def make_workload(kind, device, layout="FT"):
         plan = zafx.mdct_plan(kbd, device=device)
         wl.update(plan=plan, d_in=d_x, n_in=N, bytes_per_launch=B * (4 * N + 4 * (W // 2) * T),
                   desc="Batched MDCT: 1024 clips x 10 s, KBD win=2048")
+    elif kind == "mdct_offgrid":   # the compact (W/2, T) layout when T is not a multiple of 16 (k_mdct_ft32's carry form)
+        plan = zafx.mdct_plan(kbd, device=device)
+        wl.update(plan=plan, d_in=d_x, n_in=N, bytes_per_launch=B * (4 * N + 4 * (W // 2) * T),
+                  desc="Batched MDCT off the line grid: 1024 clips x 442024 samples, KBD win=2048, T = 433, compact (W/2,T) layout")
     elif kind == "imdct":
         fwd = zafx.mdct_plan(kbd, device=device)
         d_m = zafx.DeviceBuffer(fwd.out_shape(B, N), np.float32, device)
@@ -359,7 +365,7 @@ def parity_probe(wl):
         ref = orc.stft(x64, orc.hamming_periodic(4096), 2048)
     elif kind in ("istft", "istft1"):
         ref = None   # (checked as a round trip below: the device spectrum is the input)
-    elif kind == "mdct":
+    elif kind in ("mdct", "mdct_offgrid"):
         ref = orc.mdct(x64, kbd)
     elif kind == "imdct":
         ref = None

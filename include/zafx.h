@@ -106,7 +106,8 @@ typedef struct zafx_params {
     int32_t layout;            /* enum zafx_layout of the 2-D (frequency x time) side           */
     int32_t n_filters;         /* MEL / MFCC: 1..256 (ZAFX_PRECISION_F64: 1..W/2)               */
     int32_t n_coefs;           /* MFCC                                                          */
-    int32_t fft_length;        /* CQT / CHROMA: power of two, 512..32768 (..131072 with ZAFX_PRECISION_F64) */
+    int32_t fft_length;        /* CQT / CHROMA: power of two, 512..32768; 65536 when the kernel matrix touches the one-sided
+                                  bins 1..8191 only (low-frequency kernels); ..131072 with ZAFX_PRECISION_F64 */
     int32_t n_bins;            /* CQT / CHROMA                                                  */
     int32_t octave_resolution; /* CHROMA                                                        */
     int32_t spectrum;          /* enum zafx_spectrum (STFT / ISTFT); 0 = reference contract     */

@@ -1536,3 +1536,33 @@ def test_mdct_rows_off_the_line_grid(zafx, wl, n, clips):
     assert np.max(np.abs(y[:, :n - 1] - x[:, :n - 1])) < 1e-5
     pad = zafx.mdct_plan(w, row_align=32).run_host(x, n)
     assert relerr(pad, got) <= 2e-6
+
+
+@pytest.mark.parametrize("fmin,fmax,tr,n,clips", [(27.5, 3520.0, 25, 200000, 3),    # 65536, the low band: the float32 double form
+                                                  (32.7, 1046.5, 50, 70001, 2),     # odd clip length: every frame through the predicated loads
+                                                  (27.5, 880.0, 10, 66000, 9),      # more clips than groups, one or two frames each
+                                                  (27.5, 8000.0, 25, 140000, 2)])   # columns above bin 8191: routed to the float64 kernel
+def test_cqt_fft_length_65536(zafx, fmin, fmax, tr, n, clips):
+    """fft_length 65536 (minimum frequencies below 46 Hz at 44.1 kHz, zaf.py:505-509) on the float32 kernel: the frame is transformed
+    as the even and the odd bins of two 16384-point transforms (k_cqt's double form, round 3).  Against the oracle clip by clip;
+    a complex-valued copy of the kernel takes the streamed complex contraction of the same form."""
+    fs, res = 44100, 24
+    ck = zafx.cqtkernel(fs, res, fmin, fmax)
+    assert ck.shape[1] == 65536
+    plan = zafx.cqt_plan(fs, tr, ck)
+    low = np.minimum(ck.indices, 65536 - ck.indices).max() <= 8191
+    assert plan.f64 == (not low)
+    x = np.stack([synth_clip(61, c, n) for c in range(clips)])
+    got = zafx.cqtspectrogram_batch(x, fs, tr, ck)
+    chroma = zafx.cqtchromagram_batch(x, fs, tr, res, ck)
+    assert got.dtype == np.float32
+    for c in range(clips):
+        x64 = x[c].astype(np.float64)
+        ref = orc.cqtspectrogram(x64, fs, tr, ck)
+        assert got[c].shape == ref.shape and relerr(got[c], ref) <= TOL_FB
+        assert relerr(chroma[c], orc.cqtchromagram(x64, fs, tr, res, ck)) <= TOL_FB
+    if low:
+        ckc = ck.copy().astype(np.complex128)
+        ckc.data = ckc.data * np.exp(0.3j)          # a kernel that is not numerically real: same magnitudes
+        gotc = zafx.cqtspectrogram_batch(x[:1], fs, tr, scipy.sparse.csr_matrix(ckc))
+        assert relerr(gotc[0], orc.cqtspectrogram(x[0].astype(np.float64), fs, tr, ck)) <= TOL_FB

@@ -415,6 +415,8 @@ static int build_cqt_chunks(zafx_plan* pl) {
                         const int c = pl->h_indices[e];
                         if (c < 0 || c >= w) return fail_msg("CQT kernel column index out of range");
                         const int m = c <= n ? c : w - c;   // one-sided bin holding X[c] (conjugated when c > n)
+                        if (cqt_double(pl->log2nf) && (m < 1 || m > kCqtDoubleMaxBin))
+                            return fail_msg("cqt: at fft_length 65536 the float32 kernel takes matrices whose columns lie in bins 1 .. 8191 (and their mirrors); use ZAFX_PRECISION_F64");
                         const int slot = m == n ? cqt_nyquist_slot(pl->log2nf) : cqt_slot(pl->log2nf, m);
                         word |= (int32_t)(slot * 8) | (c > n ? (int32_t)0x80000000 : 0);
                         v = pl->h_values[e];
@@ -614,7 +616,7 @@ int zafx_plan_create(zafx_plan** out, int device, int kind, const zafx_params* p
         if (params->precision == ZAFX_PRECISION_F64) {   // k_cqt_f64 decimates the frame: no LDS limit on its length
             if (lw < 9 || lw > 17) return bail("fft_length must be a power of two in [512, 131072] (ZAFX_PRECISION_F64 plan)");
         } else if (lw < 0 || !cqt_supported(lw - 1)) {
-            return bail("fft_length must be a power of two in [512, 32768] (up to 131072 with ZAFX_PRECISION_F64)");
+            return bail("fft_length must be a power of two in [512, 65536] (up to 131072 with ZAFX_PRECISION_F64)");
         }
         if (pl->H < 1) return bail("step_length must be >= 1");
         if (params->n_bins < 1 || params->n_bins > 1024) return bail("n_bins must be in [1, 1024]");

@@ -38,11 +38,14 @@ ZAFX_PROF_ARRAY(g_prof_cqt)
 
 // LDS carve shared by the kernel and the launcher (bytes before the wave / step tables, 16-B aligned:
 // a misaligned ds_read_b128 is replayed at 64 cycles)
-template <int LOG2N, int LOG2E>
+// DOUBLE: fft_length 65536 as the even and the odd bins of two 16384-point transforms (zafx_internal.hpp, cqt_double): the
+// kernel is the LOG2N = 14 one, its root tables are those of twice the size.
+template <int LOG2N, int LOG2E, bool DOUBLE = false>
 struct CqtCfg {
     using C = FftCfg<LOG2N, LOG2E>;
-    static constexpr int NHI = LOG2N > 7 ? 1 << (LOG2N - 7) : 1;   // two-level roots of N (zafx_fft.hpp)
-    static constexpr int NH2 = LOG2N > 8 ? 1 << (LOG2N - 8) : 1;   // two-level roots of 2N for k < N/2 (real split)
+    static constexpr int LT = LOG2N + (DOUBLE ? 1 : 0);            // log2 of the packed transform the tables are for
+    static constexpr int NHI = LT > 7 ? 1 << (LT - 7) : 1;         // two-level roots of N (zafx_fft.hpp)
+    static constexpr int NH2 = LT > 8 ? 1 << (LT - 8) : 1;         // two-level roots of 2N for k < N/2 (real split)
     static constexpr bool SPLIT = cqt_split(LOG2N);                // 16 x 1024 decomposition (zafx_internal.hpp)
     static constexpr int SLOTS = cqt_slots(LOG2N);                 // complex slots of the spectrum image
     static constexpr int NSUB = SPLIT ? 8 + 128 : 0;               // two-level roots of the 1024-point sub-transforms
@@ -58,16 +61,17 @@ __device__ __forceinline__ float bcast31_add(float v) {
 }
 
 // REALK: kernel values are float (real matrix), else float2.  RES > 0: a wave's entries (RES iterations) ride in registers.
-template <int LOG2N, int LOG2E, bool ALIGNED, bool REALK, int RES>
+template <int LOG2N, int LOG2E, bool ALIGNED, bool REALK, int RES, bool DOUBLE = false>
 __global__ __launch_bounds__(fft_threads(LOG2N, LOG2E)) void k_cqt(
     const float* __restrict__ x, const float2* __restrict__ twp, const float2* __restrict__ tws,
     const int4* __restrict__ wave_tab, const int* __restrict__ addrs, const float* __restrict__ values,
     float* __restrict__ out, long long n_samples, int step, int left_pad, int T, int TP, int n_clips, int n_groups, int n_bins, int chroma_res,
     int layout, int k_lo, int k_hi, int k_special, int n_entries, int prune3) {
     using C = FftCfg<LOG2N, LOG2E>;
-    using G = CqtCfg<LOG2N, LOG2E>;
+    using G = CqtCfg<LOG2N, LOG2E, DOUBLE>;
     using KV = std::conditional_t<REALK, float, float2>;
-    constexpr int N = C::N, P = C::P, E = C::E, W = 2 * N, NHI = G::NHI, NH2 = G::NH2;
+    constexpr int N = C::N, P = C::P, E = C::E, W = (DOUBLE ? 4 : 2) * N, NHI = G::NHI, NH2 = G::NH2;   // W = samples of a frame
+    static_assert(!DOUBLE || (G::SPLIT && LOG2N == 14), "the double form stands on the 16 x 1024 transform");
     constexpr bool RESIDENT = RES > 0;
     static_assert(P >= 64, "CQT frames are owned by whole wavefronts");
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
@@ -77,7 +81,7 @@ __global__ __launch_bounds__(fft_threads(LOG2N, LOG2E)) void k_cqt(
     float2* sp_hi = tw_lo + 128;                                  // two-level root table of 2N (split twiddles)
     float2* sp_lo = sp_hi + NH2;
     float2* sub_hi = sp_lo + 128;                                 // (SPLIT) two-level root table of 1024
-    auto slot_of = [](int k) { return cqt_slot(LOG2N, k); };
+    auto slot_of = [](int k) { return cqt_slot(LOG2N, k); };   // (DOUBLE: of a POSITION of the 16384-point transform)
     constexpr int NYQ = cqt_nyquist_slot(LOG2N);
     int4* wave_l = reinterpret_cast<int4*>(smem_raw + G::HEAD);   // [P / 64] {first iteration, iterations, step-end mask of the resident form, 0}
     float* mags = reinterpret_cast<float*>(wave_l + P / 64);      // [n_bins] |.|^2 of the current frame
@@ -133,10 +137,25 @@ __global__ __launch_bounds__(fft_threads(LOG2N, LOG2E)) void k_cqt(
         v[2 * i] = make_float2(q.x, q.y);
         v[2 * i + 1] = make_float2(q.z, q.w);
     };
+    // DOUBLE: the first half of the frame only (points p + 1024 i as 8-byte loads); load_second() fetches the second half where it
+    // is needed and forms z[n] + z[n + 16384] (even bins) or z[n] - z[n + 16384] (odd bins)
+    bool d_fast = false;
     auto load_frame = [&](long long g, int p, bool deferred = false) -> bool {   // g: index into the group's frame list; p: thread id (an opaque copy inside the frame loop)
         const int clip = group + (int)((unsigned)g / (unsigned)T) * n_groups, t = (int)((unsigned)g % (unsigned)T);   // (g < 2^31: zafx_execute)
         const auto rx = make_rsrc(x + (long long)clip * n_samples, clip_bytes);
         const long long s0 = (long long)t * step - left_pad;
+        if constexpr (DOUBLE) {
+            frx = rx;
+            d_fast = ALIGNED && s0 >= 0 && s0 + W <= n_samples;
+            if (d_fast) {
+                fvoff = ((int)s0 + 2 * p) * 4;
+#pragma unroll
+                for (int i = 0; i < E; ++i) v[i] = buf_load_f32x2(frx, fvoff, i * P * 8);
+            } else {
+                fvoff = (int)s0;   // (sample index; the predicated loads of load_second() do the whole frame)
+            }
+            return false;
+        }
         if (ALIGNED && s0 >= 0 && s0 + W <= n_samples) {
             if constexpr (G::SPLIT) {
                 // 16-byte lanes: a CU pulls a 128-KB frame out of L2 in 3.5 k cycles with them, 5.8 k with 8-byte lanes
@@ -190,8 +209,50 @@ __global__ __launch_bounds__(fft_threads(LOG2N, LOG2E)) void k_cqt(
     // First pass of the 16 x 1024 form, in registers: radix-16 across the workgroup on the samples 1024 apart (thread p
     // holds n2 = p), times w^(p k1).  It runs BEFORE the barrier that frees the LDS frame, i.e. under the tail of the
     // previous frame's contraction.
-    auto first_pass = [&](int p) {
-        if constexpr (G::SPLIT) {
+    // DOUBLE: second half of the frame and the sum (odd = 0: even bins) or difference (odd = 1) of the halves; clip_n = samples of the clip
+    auto load_second = [&](int p, int odd) {
+        if (d_fast) {
+#pragma unroll
+            for (int i = 0; i < E; ++i) {
+                const float2 q = buf_load_f32x2(frx, fvoff + 2 * N * 4, i * P * 8);   // point p + 1024 i of the second half: 2 N samples on
+                v[i] = odd ? make_float2(v[i].x - q.x, v[i].y - q.y) : make_float2(v[i].x + q.x, v[i].y + q.y);
+            }
+        } else {   // a frame that touches the clip's edges (zero padding, zaf.py:612-620): both halves, sample by sample
+            const long long s0 = fvoff;
+#pragma unroll
+            for (int i = 0; i < E; ++i) {
+                const long long s = s0 + 2 * (p + i * P), s2 = s + 2 * N;
+                auto at = [&](long long q) { return (q >= 0 && q < n_samples) ? buf_load_f32(frx, (int)q * 4) : 0.f; };
+                const float2 a = make_float2(at(s), at(s + 1)), b = make_float2(at(s2), at(s2 + 1));
+                v[i] = odd ? make_float2(a.x - b.x, a.y - b.y) : make_float2(a.x + b.x, a.y + b.y);
+            }
+        }
+    };
+    auto first_pass = [&](int p, int odd = 0) {
+        if constexpr (DOUBLE) {
+            // even bins: the 16384-point transform of the sums; odd bins: of the differences times w^n, w = exp(-2 pi i / 32768),
+            // n = p + 1024 r -- the factor exp(-2 pi i r / 32) goes on the inputs (constants), w^p on the outputs with the pass's own
+            // twiddles: output k1 of the radix-16 pass gets w^(p (2 k1 + odd)).
+            const float2 b1 = tw2(tw2l, p);          // w^p (tw2l: the roots of 32768 here)
+            float2 w[16];
+            w[1] = cmul(b1, b1);                      // the root of 16384 to the p
+#pragma unroll
+            for (int r = 2; r < 16; ++r) w[r] = cmul(w[r >> 1], w[r - (r >> 1)]);
+            if (odd) {
+                static constexpr float kC[16][2] = {{1.000000000f, -0.000000000f}, {0.980785280f, -0.195090322f}, {0.923879533f, -0.382683432f}, {0.831469612f, -0.555570233f}, {0.707106781f, -0.707106781f}, {0.555570233f, -0.831469612f}, {0.382683432f, -0.923879533f}, {0.195090322f, -0.980785280f}, {0.000000000f, -1.000000000f}, {-0.195090322f, -0.980785280f}, {-0.382683432f, -0.923879533f}, {-0.555570233f, -0.831469612f}, {-0.707106781f, -0.707106781f}, {-0.831469612f, -0.555570233f}, {-0.923879533f, -0.382683432f}, {-0.980785280f, -0.195090322f}};   // exp(-2 pi i r / 32)
+#pragma unroll
+                for (int r = 1; r < 16; ++r) v[r] = cmul(v[r], make_float2(kC[r][0], kC[r][1]));
+            }
+            Dft<16>::run(v);
+            if (odd) {
+                v[0] = cmul(v[0], b1);
+#pragma unroll
+                for (int r = 1; r < 16; ++r) v[r] = cmul(v[r], cmul(w[r], b1));
+            } else {
+#pragma unroll
+                for (int r = 1; r < 16; ++r) v[r] = cmul(v[r], w[r]);
+            }
+        } else if constexpr (G::SPLIT) {
             static_assert(!G::SPLIT || (E == 16 && P == 1024), "split form: 16 points per thread, 16 wavefronts");
             Dft<16>::run(v);
             float2 w[16];
@@ -205,12 +266,15 @@ __global__ __launch_bounds__(fft_threads(LOG2N, LOG2E)) void k_cqt(
     };
     if (slot < n_work) {
         if (load_frame(slot, threadIdx.x)) unpack_pairs(threadIdx.x);
+        if constexpr (DOUBLE) load_second(threadIdx.x, 0);
         first_pass(threadIdx.x);
     }
     PROF_INIT(g_prof_cqt);
+    int odd = 0;              // DOUBLE: which half of the bins the transform in flight yields (every frame runs the loop body twice)
+    float2 ev[DOUBLE ? 4 : 1];   // DOUBLE: the thread's even bins, waiting for the odd ones
 
 #pragma unroll 1
-    for (long long g = slot; g < n_work; g += n_slots) {
+    for (long long g = slot; g < n_work; g += (DOUBLE && odd == 1) ? 0 : n_slots) {   // (DOUBLE: `odd` has been flipped at the end of the body)
         PROF_MARK(0);
         // Opaque copy of the thread id: everything below recomputes its (cheap) per-lane LDS and buffer
         // offsets every frame.  Left to itself the compiler hoists ~50 of them out of the loop and
@@ -234,7 +298,8 @@ __global__ __launch_bounds__(fft_threads(LOG2N, LOG2E)) void k_cqt(
         } else {
             fft_frame_chain<LOG2N, LOG2E>(v, buf, p, tw2l);
         }
-        const bool more = g + n_slots < n_work;
+        const long long g_next = (DOUBLE && odd == 0) ? g : g + n_slots;   // frame of the transform after this one
+        const bool more = g_next < n_work;
         bool raw = false;
 #ifndef ZAFX_CQT_EARLY
 #define ZAFX_CQT_EARLY 1
@@ -244,12 +309,33 @@ __global__ __launch_bounds__(fft_threads(LOG2N, LOG2E)) void k_cqt(
         // fly under the split and the contraction of all sixteen waves.
         constexpr bool EARLY = ZAFX_CQT_EARLY && G::SPLIT;
         if constexpr (EARLY) {
-            if (more) raw = load_frame(g + n_slots, p);
+            if (more) raw = load_frame(g_next, p);
         }
         if constexpr (G::SPLIT) lds_barrier();
         PROF_MARK(1);
         // ---- real split in place, only for the pairs (k, N-k) that the kernel's columns touch:
         // slots 0..N-1 <- X[0..N-1], slot NYQ <- X[N];  t_k = exp(-2 pi i k / 2N) = sp_hi[k >> 7] sp_lo[k & 127]
+        if constexpr (DOUBLE) {
+            // position q of this transform is bin k = 2 q + odd of the 32768-point spectrum Z; its partner N - k sits at position
+            // 16384 - q (even) / 16383 - q (odd) of the SAME transform.  Even bins wait in registers; with the odd ones they are
+            // laid out as cqt_slot(15, k): odd bin at the slot of position q, even bin at the slot of position 8192 + q.
+            const int q_lo = k_lo >> 1, q_hi = k_hi >> 1;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int q = q_lo + p + i * P;
+                if (q <= q_hi && (odd || q >= 1)) {
+                    const int k = 2 * q + odd;
+                    float2 xk, xn;
+                    split_pair(buf[cqt_slot14(q)], buf[cqt_slot14(16384 - odd - q)], cmul(sp_hi[k >> 7], sp_lo[k & 127]), xk, xn);
+                    if (odd) {
+                        buf[cqt_slot14(q)] = xk;
+                        buf[cqt_slot14(8192 + q)] = ev[i];
+                    } else {
+                        ev[i] = xk;
+                    }
+                }
+            }
+        } else {
         if (k_special && p == 0) {
             const float2 z0 = buf[0], zc = buf[slot_of(N / 2)];
             buf[0] = make_float2(z0.x + z0.y, 0.f);
@@ -261,6 +347,7 @@ __global__ __launch_bounds__(fft_threads(LOG2N, LOG2E)) void k_cqt(
             split_pair(buf[slot_of(k)], buf[slot_of(N - k)], cmul(sp_hi[k >> 7], sp_lo[k & 127]), xk, xn);
             buf[slot_of(k)] = xk;
             buf[slot_of(N - k)] = xn;
+        }
         }
         PROF_MARK(2);
         lds_barrier();
@@ -274,13 +361,13 @@ __global__ __launch_bounds__(fft_threads(LOG2N, LOG2E)) void k_cqt(
 #define ZAFX_CQT_LOADS_FIRST 8
 #endif
         const bool loads_first = wave < ZAFX_CQT_LOADS_FIRST * (P / 64) / 16;
-        if (!EARLY && more && loads_first) raw = load_frame(g + n_slots, p);
+        if (!EARLY && more && loads_first) raw = load_frame(g_next, p);
         PROF_MARK(7);
         // ---- CSR mat-vec against the spectrum + |.|^2 (zaf.py:630-632).  Entry (iteration, lane) of the wave's share is a
         // value and a word: bits 0-17 the LDS byte address of its spectrum bin, bit 31 "conjugate" (a column of the upper
         // half), bits 29-30 (the same in all lanes) 0 or the shape 1 / 2 / 3 = 16 / 32 / 64 lanes per row of a step that ENDS
         // with this iteration, bits 18-28 the row this lane then writes (0x7ff: none).  Padding entries are 0 * bin 0.
-        {
+        if (!DOUBLE || odd) {   // (DOUBLE: the even half has no spectrum to contract yet)
             float ar = 0.f, ai = 0.f;
             auto mac = [&](KV k, int a) {
                 float2 xv = *reinterpret_cast<const float2*>(smem_raw + (a & 0x3ffff));
@@ -345,15 +432,20 @@ __global__ __launch_bounds__(fft_threads(LOG2N, LOG2E)) void k_cqt(
                 }
             }
         }
-        if (!EARLY && more && !loads_first) raw = load_frame(g + n_slots, p);
+        if (!EARLY && more && !loads_first) raw = load_frame(g_next, p);
         PROF_MARK(4);
         if (more) {   // (waits for the prefetched samples; the other waves are still contracting)
             if (raw) unpack_pairs(p);
-            first_pass(p);
+            if constexpr (DOUBLE) load_second(p, odd ^ 1);
+            first_pass(p, DOUBLE ? odd ^ 1 : 0);
         }
         PROF_MARK(5);
         lds_barrier();
         PROF_MARK(6);
+        if constexpr (DOUBLE) {
+            odd ^= 1;
+            if (odd == 1) continue;   // the even half is done: no column yet
+        }
         // ---- store the frame's column (the next write of `mags` is three barriers away)
         {
             const int clip = group + (int)((unsigned)g / (unsigned)T) * n_groups, t = (int)((unsigned)g % (unsigned)T);   // (g < 2^31: zafx_execute)
@@ -376,16 +468,21 @@ __global__ __launch_bounds__(fft_threads(LOG2N, LOG2E)) void k_cqt(
 }
 
 // LDS bytes of k_cqt
-template <int LOG2N>
+// (LOG2NP = log2 of the packed frame: 15 = fft_length 65536, which runs the LOG2N = 14 kernel in its double form)
+template <int LOG2NP>
 static size_t cqt_lds(int n_bins) {
+    constexpr bool DOUBLE = cqt_double(LOG2NP);
+    constexpr int LOG2N = DOUBLE ? 14 : LOG2NP;
     constexpr int LOG2E = default_log2e(LOG2N);
     using C = FftCfg<LOG2N, LOG2E>;
-    using G = CqtCfg<LOG2N, LOG2E>;
+    using G = CqtCfg<LOG2N, LOG2E, DOUBLE>;
     return G::HEAD + (size_t)(C::P / 64) * 16 + (size_t)n_bins * sizeof(float);
 }
 
-template <int LOG2N>
+template <int LOG2NP>
 static hipError_t run_cqt(const zafx_plan& pl, const float* x, float* out, int64_t n_clips, int64_t n_samples, int T) {
+    constexpr bool DOUBLE = cqt_double(LOG2NP);
+    constexpr int LOG2N = DOUBLE ? 14 : LOG2NP;
     constexpr int LOG2E = default_log2e(LOG2N);
     using C = FftCfg<LOG2N, LOG2E>;
     const int diff = pl.W - pl.H;                              // may be negative if step > fft_len
@@ -393,13 +490,13 @@ static hipError_t run_cqt(const zafx_plan& pl, const float* x, float* out, int64
     const bool aligned = n_samples % 2 == 0 && pl.H % 2 == 0 && left % 2 == 0 && reinterpret_cast<uintptr_t>(x) % 8 == 0;
     // a real matrix whose busiest wave has <= kCqtResident iterations keeps its entries in registers (16 would spill at 1024 threads)
     const bool realk = pl.cqt_real;
-    const bool res = realk && pl.cqt_resident == kCqtResident;
+    const bool res = realk && pl.cqt_resident == kCqtResident && !DOUBLE;   // (the double form has no registers left for them: 156 bytes of scratch)
     auto pick = [&](auto al) {
         constexpr bool AL = decltype(al)::value;
-        return !realk ? k_cqt<LOG2N, LOG2E, AL, false, 0> : res ? k_cqt<LOG2N, LOG2E, AL, true, kCqtResident> : k_cqt<LOG2N, LOG2E, AL, true, 0>;
+        return !realk ? k_cqt<LOG2N, LOG2E, AL, false, 0, DOUBLE> : res ? k_cqt<LOG2N, LOG2E, AL, true, kCqtResident, DOUBLE> : k_cqt<LOG2N, LOG2E, AL, true, 0, DOUBLE>;
     };
     auto kern = aligned ? pick(std::true_type{}) : pick(std::false_type{});
-    const size_t smem = cqt_lds<LOG2N>(pl.prm.n_bins);
+    const size_t smem = cqt_lds<LOG2NP>(pl.prm.n_bins);
     if (smem > (size_t)kMaxLdsBytes) {
         set_error("cqt: kernel matrix has too many rows for LDS at this fft_length");
         return hipErrorInvalidValue;
@@ -422,8 +519,9 @@ static hipError_t run_cqt(const zafx_plan& pl, const float* x, float* out, int64
 #ifndef ZAFX_CQT_PRUNE
 #define ZAFX_CQT_PRUNE 1
 #endif
-    if (ZAFX_CQT_PRUNE && cqt_split(LOG2N) && !pl.cqt_k_special && pl.cqt_k_hi >= pl.cqt_k_lo && ((pl.cqt_k_hi >> 4) >> 6) <= 2)
-        prune3 = (pl.cqt_k_hi >> 4) >> 6;
+    const int pos_hi = (DOUBLE ? pl.cqt_k_hi >> 1 : pl.cqt_k_hi) >> 4;   // (double form: bin k of the spectrum is position k >> 1 of its transform)
+    if (ZAFX_CQT_PRUNE && cqt_split(LOG2N) && !pl.cqt_k_special && pl.cqt_k_hi >= pl.cqt_k_lo && (pos_hi >> 6) <= 2)
+        prune3 = pos_hi >> 6;
     hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(C::P), smem, pl.stream, x, pl.d_tw_pass, pl.d_tw_aux, pl.d_cqt_waves,
                        pl.d_cqt_addrs, pl.d_cqt_vals, out, (long long)n_samples, pl.H, left, T, (int)row_pitch(pl, T), (int)n_clips, n_groups,
                        pl.prm.n_bins, pl.kind == ZAFX_CHROMA ? pl.prm.octave_resolution : 0, pl.layout, pl.cqt_k_lo, pl.cqt_k_hi,
@@ -431,8 +529,11 @@ static hipError_t run_cqt(const zafx_plan& pl, const float* x, float* out, int64
     return hipGetLastError();
 }
 
-bool cqt_supported(int log2n) { return log2n >= 8 && log2n <= 14; }
-int cqt_waves(int log2n) { return fft_threads(log2n, default_log2e(log2n)) / 64; }
+bool cqt_supported(int log2n) { return log2n >= 8 && log2n <= 15; }
+int cqt_waves(int log2n) {
+    if (cqt_double(log2n)) log2n = 14;   // (the double form runs the 16384-point kernel)
+    return fft_threads(log2n, default_log2e(log2n)) / 64;
+}
 const char* cqt_kernel_name() { return "k_cqt"; }
 
 // Largest number of rows a float32 plan of this fft_length can hold, capped by the 11-bit row field of the entry words
@@ -455,6 +556,7 @@ int cqt_max_bins(int log2n) {
         case 12: return fit(std::integral_constant<int, 12>{});
         case 13: return fit(std::integral_constant<int, 13>{});
         case 14: return fit(std::integral_constant<int, 14>{});
+        case 15: return fit(std::integral_constant<int, 15>{});
     }
     return 0;
 }
@@ -468,6 +570,7 @@ hipError_t launch_cqt(const zafx_plan& pl, const float* x, float* out, int64_t n
         case 12: return run_cqt<12>(pl, x, out, n_clips, n_samples, T);
         case 13: return run_cqt<13>(pl, x, out, n_clips, n_samples, T);
         case 14: return run_cqt<14>(pl, x, out, n_clips, n_samples, T);
+        case 15: return run_cqt<15>(pl, x, out, n_clips, n_samples, T);
     }
     set_error("cqt: unsupported fft_length");
     return hipErrorInvalidValue;

@@ -20,11 +20,21 @@ constexpr int kMaxLdsBytes = 160 * 1024;   // LDS per CU on gfx950
 #ifndef ZAFX_CQT_SPLIT
 #define ZAFX_CQT_SPLIT 1
 #endif
-constexpr bool cqt_split(int log2n) { return ZAFX_CQT_SPLIT && log2n == 14; }
+// fft_length 65536 (log2n = 15; minimum frequencies down to 23 Hz at 44.1 kHz and 24 bins per octave): the 32768-point packed
+// transform does not fit LDS, so a frame is transformed as the EVEN and the ODD bins of two 16384-point transforms (decimation in
+// frequency: Z[2q] = FFT(z[n] + z[n + 16384])[q], Z[2q + 1] = FFT((z[n] - z[n + 16384]) w^n)[q]) that use the 16 x 1024 machinery
+// one after the other.  A pair (k, N - k) of the real split lies in ONE of the two, so each is split on its own; the even bins
+// wait in registers and then sit beside the odd ones in the LDS image: odd bin k at the slot of position k >> 1, even bin k at
+// the slot of position 8192 + (k >> 1).  That needs the kernel matrix to touch one-sided bins 1 .. kCqtDoubleMaxBin only (5.5 kHz
+// at 44.1 kHz -- the low-frequency kernels that need such a long frame do); others run on the float64 kernel.
+constexpr bool cqt_double(int log2n) { return log2n == 15; }
+constexpr int kCqtDoubleMaxBin = 8191;
+constexpr bool cqt_split(int log2n) { return ZAFX_CQT_SPLIT && (log2n == 14 || log2n == 15); }
 constexpr int kCqtRegion = 1090;
 constexpr int cqt_slots(int log2n) { return cqt_split(log2n) ? 16 * kCqtRegion : (1 << log2n) + ((1 << log2n) >> 4) + 1; }
+constexpr int cqt_slot14(int k) { return (k & 15) * kCqtRegion + (k >> 4) + (k >> 8); }
 constexpr int cqt_slot(int log2n, int k) {
-    return cqt_split(log2n) ? (k & 15) * kCqtRegion + (k >> 4) + (k >> 8) : k + (k >> 4);
+    return cqt_double(log2n) ? ((k & 1) ? cqt_slot14(k >> 1) : cqt_slot14(8192 + (k >> 1))) : cqt_split(log2n) ? cqt_slot14(k) : k + (k >> 4);
 }
 constexpr int cqt_nyquist_slot(int log2n) { return cqt_split(log2n) ? kCqtRegion - 1 : (1 << log2n) + ((1 << log2n) >> 4); }
 constexpr int kCqtResident = 12;           // k_cqt: iterations (entries per lane) of a wave's share of the kernel matrix that ride in registers

@@ -718,12 +718,17 @@ def cqt_plan(sampling_frequency, time_resolution, cqt_kernel, octave_resolution=
         fft_length = _CQT_MIN_FFT
     if fft_length < _CQT_MIN_FFT or fft_length > 131072 or fft_length & (fft_length - 1):
         raise ValueError(f"zafx CQT kernels need a power-of-two fft_length in [512, 131072] (or any length below 512), got {fft_length}")
-    # a frame above 32768 samples does not fit LDS as float32 pairs: those kernels run on the float64 kernel, which
-    # decimates the frame (lower minimum frequencies: 27.5 Hz at 44.1 kHz gives 65536); so do kernels with more rows than
+    # a frame above 65536 samples runs on the float64 kernel, which decimates the frame; so do kernels with more rows than
     # fit beside the frame (k_cqt keeps the whole frame + one output column of the kernel's rows in the 160 KB of LDS:
     # about 4 000 rows at fft_length 32768 -- the reference's own 208-row example is far inside)
     csr = cqt_kernel.tocsr()
-    f64 = bool(f64) or fft_length > 32768 or n_bins > _cqt_f32_max_bins(fft_length)
+    # fft_length 65536 (minimum frequencies down to 23 Hz at 44.1 kHz, 24 bins per octave) runs on the float32 kernel as the even and
+    # the odd bins of two 16384-point transforms when the matrix touches the low bins 1 ... 8191 (and their mirrors) only
+    low_band = True
+    if fft_length == 65536 and csr.nnz:
+        m = np.minimum(csr.indices, fft_length - csr.indices)
+        low_band = bool(m.min() >= 1 and m.max() <= 8191)
+    f64 = bool(f64) or fft_length > 65536 or not low_band or n_bins > _cqt_f32_max_bins(fft_length)
     chroma = octave_resolution is not None
     key = ("chroma" if chroma else "cqt", device, fft_length, step, n_bins, int(octave_resolution or 0), _LAYOUTS[layout],
            _as_row_align(row_align, layout), bool(f64),

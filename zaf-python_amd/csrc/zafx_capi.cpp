@@ -14,6 +14,10 @@
 
 #include "zafx_internal.hpp"
 
+#ifndef ZAFX_STFT_FAT8_TABLES
+#define ZAFX_STFT_FAT8_TABLES 0   // pass tables of the W = 4096 persistent STFT experiment (zafx_stft.hip, ZAFX_STFT_FAT8)
+#endif
+
 namespace zafx {
 
 static thread_local std::string g_err;
@@ -650,8 +654,8 @@ int zafx_plan_create(zafx_plan** out, int device, int kind, const zafx_params* p
         }
         if (tw.empty()) tw.push_back(cf32{1.f, 0.f});
         e = upload(&pl->d_tw_pass, tw.data(), tw.size() * sizeof(cf32));
-        if (e == hipSuccess && (kind == ZAFX_STFT || kind == ZAFX_MEL || kind == ZAFX_MFCC) && pl->log2nf == 10) {
-            auto tw5 = build_pass_twiddles(10, 5);
+        if (e == hipSuccess && (kind == ZAFX_STFT || kind == ZAFX_MEL || kind == ZAFX_MFCC) && (pl->log2nf == 10 || (ZAFX_STFT_FAT8_TABLES && pl->log2nf == 11 && kind == ZAFX_STFT))) {
+            auto tw5 = build_pass_twiddles(pl->log2nf, 5);   // (W = 4096: 2048 points as 32 x 32 x 2 in the persistent 8-frame form)
             e = upload(&pl->d_tw_r32, tw5.data(), tw5.size() * sizeof(cf32));
         }
     }

@@ -179,34 +179,44 @@ ZAFX_PROF_ARRAY(g_prof_stft)
 constexpr int kFatWaves = 8;
 constexpr int kFatFrames = 16;
 
-template <int LOG2N, int LOG2E>
+// FPB_ = frames per tile: 16 (128-byte runs along t), or 8 for W = 4096, where 16 frames do not fit LDS -- 64-byte runs, but
+// still the persistent schedule (tables staged once, the next tile requested ahead of the barrier) instead of one workgroup per
+// tile; the window (16 KB) is then read from global memory.
+template <int LOG2N, int LOG2E, int FPB_ = kFatFrames>
 struct FatCfg {
     using C = FftCfg<LOG2N, LOG2E>;
     static_assert(C::P == 64 || C::P == 32, "a frame is owned by one wavefront, or by half of one (32 points per thread)");
     static constexpr int N = C::N;
-    static constexpr int PITCH = ((N + (N >> C::PS) + 31) / 32) * 32 + 2;   // = 2 (mod 32)
+    static constexpr int FPB = FPB_;
+    static constexpr bool WIN_LDS = FPB_ == kFatFrames;
+    // frame pitch = 2 (mod 32) complex for 16 frames, 4 (mod 32) for 8: the transposed read of the store phase (FPB frames x 32 / FPB
+    // bins per 32-lane group) then meets 64 distinct banks
+    static constexpr int PITCH = ((N + (N >> C::PS) + 31) / 32) * 32 + 32 / FPB_;
     static constexpr int NT = kFatWaves * 64;
-    static constexpr int FPW = kFatFrames * C::P / NT;   // frames a group of P lanes transforms per tile: 2, or 1 for P = 32
-    static constexpr size_t SMEM = (size_t)(kFatFrames * PITCH + C::TW + N + N / 2 + 1) * 8;
+    static constexpr int FPW = FPB_ * C::P / NT;   // frames a group of P lanes transforms per tile: 2, or 1 (P = 32; 8-frame tiles)
+    static constexpr size_t SMEM = (size_t)(FPB_ * PITCH + C::TW + (WIN_LDS ? N : 0) + N / 2 + 1) * 8;
 };
 
-template <int LOG2N, int LOG2E, bool ALIGNED, int SPEC>
+template <int LOG2N, int LOG2E, bool ALIGNED, int SPEC, int FPB_ = kFatFrames>
 __global__ __launch_bounds__(kFatWaves * 64) void k_stft_ft16(
     const float* __restrict__ x, const float* __restrict__ win, const float2* __restrict__ twp,
     const float2* __restrict__ tws, float2* __restrict__ out, long long n_samples, int hop, int T, int TP, int tiles,
     int total_tiles) {
     using C = FftCfg<LOG2N, LOG2E>;
-    using F = FatCfg<LOG2N, LOG2E>;
-    constexpr int N = C::N, P = C::P, E = C::E, W = 2 * N, NT = F::NT, FPB = kFatFrames, FPW = F::FPW, PITCH = F::PITCH;
+    using F = FatCfg<LOG2N, LOG2E, FPB_>;
+    constexpr int N = C::N, P = C::P, E = C::E, W = 2 * N, NT = F::NT, FPB = F::FPB, FPW = F::FPW, PITCH = F::PITCH;
+    static_assert(FPW >= 1, "every group of P lanes transforms at least one frame per tile");
     constexpr int ROWS = SPEC ? N + 1 : W;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     float2* frames = reinterpret_cast<float2*>(smem_raw);
     float2* tw_l = frames + FPB * PITCH;
-    float2* win_l = tw_l + C::TW;   // N float2 = W window samples
-    float2* tws_l = win_l + N;      // N/2 + 1 roots of W
+    float2* win_s = tw_l + C::TW;   // N float2 = W window samples (16-frame tiles)
+    float2* tws_l = win_s + (F::WIN_LDS ? N : 0);      // N/2 + 1 roots of W
+    const float2* win_l = F::WIN_LDS ? win_s : reinterpret_cast<const float2*>(win);
     const int tid = threadIdx.x;
     for (int i = tid; i < C::TW; i += NT) tw_l[i] = twp[i];
-    for (int i = tid; i < N; i += NT) win_l[i] = reinterpret_cast<const float2*>(win)[i];
+    if constexpr (F::WIN_LDS)
+        for (int i = tid; i < N; i += NT) win_s[i] = reinterpret_cast<const float2*>(win)[i];
     for (int i = tid; i <= N / 2; i += NT) tws_l[i] = tws[i];
     __syncthreads();
     const int wave = tid / P, p_lane = tid % P, p = p_lane;
@@ -324,7 +334,7 @@ __global__ __launch_bounds__(kFatWaves * 64) void k_stft_ft16(
             // whole-line rows (pitch and base multiples of 128 B) stream past L2; rows that straddle lines keep the
             // write-combining of ordinary stores (non-temporal partial lines: T = 433, 1.11 -> 1.51 ms per 256 clips)
 #ifndef ZAFX_STFT_NO_NT
-            if (SPEC < 2 && lines_whole) store_tile(std::true_type{});
+            if (SPEC < 2 && lines_whole && FPB == 16) store_tile(std::true_type{});   // (8-frame tiles write half lines: ordinary stores)
             else
 #endif
                 store_tile(std::false_type{});
@@ -1230,11 +1240,14 @@ static hipError_t run_stft_fat(const zafx_plan& pl, const float* x, float2* out,
     // 495 instead of 604 instructions per frame, one LDS exchange instead of two; FFT phase 9.6 k -> 7.4 k cycles per
     // tile.  The two-sided kernel is bound by its store drain and does not move (1.95 ms either way); the one-sided /
     // magnitude / power outputs gain 4-5 %.  (The fused mel kernel is better off with 16 waves x radix 16: 1.48 vs 1.67 ms.)
-    constexpr int LOG2E = (ZAFX_STFT_R32 && LOG2N == 10) ? 5 : default_log2e(LOG2N);
-    using F = FatCfg<LOG2N, LOG2E>;
-    auto kern = k_stft_ft16<LOG2N, LOG2E, ALIGNED, SPEC>;
+    // W = 4096 (LOG2N = 11): 2048 points as 32 x 32 x 2, a frame per wavefront, 8-frame tiles (16 do not fit LDS)
+    constexpr int LOG2E = ((ZAFX_STFT_R32 && LOG2N == 10) || LOG2N == 11) ? 5 : default_log2e(LOG2N);
+    constexpr int FPB = LOG2N == 11 ? 8 : kFatFrames;
+    using F = FatCfg<LOG2N, LOG2E, FPB>;
+    static_assert(F::SMEM <= (size_t)kMaxLdsBytes, "tile + tables exceed LDS");
+    auto kern = k_stft_ft16<LOG2N, LOG2E, ALIGNED, SPEC, FPB>;
     if (hipError_t e = ensure_dynamic_lds(reinterpret_cast<const void*>(kern), pl.device, F::SMEM); e != hipSuccess) return e;
-    const int tiles = (T + kFatFrames - 1) / kFatFrames;
+    const int tiles = (T + FPB - 1) / FPB;
     const long long total = (long long)tiles * n_clips;
     if (total <= 0) return hipSuccess;
     const int per_cu = (int)std::min<size_t>(2, (size_t)kMaxLdsBytes / F::SMEM);
@@ -1292,6 +1305,15 @@ static hipError_t run_stft_tf(const zafx_plan& pl, const float* x, float2* out, 
 template <int LOG2N, int LAYOUT, int SPEC>
 static hipError_t run_stft(const zafx_plan& pl, const float* x, float2* out, int64_t n_clips, int64_t n_samples, int T) {
     const bool aligned = (n_samples % 2 == 0) && (pl.H % 2 == 0) && (reinterpret_cast<uintptr_t>(x) % 8 == 0);
+#ifndef ZAFX_STFT_FAT8
+#define ZAFX_STFT_FAT8 0   // (measured: 6.54 ms against 3.13 ms for the one-workgroup-per-tile kernel at W = 4096 -- eight waves, one 2048-point
+#endif                     //  frame each as 32 x 32 x 2 with the window from global memory, are latency bound; profiles/r03_notes.md)
+    if constexpr (ZAFX_STFT_FAT8 && LOG2N == 11 && LAYOUT == ZAFX_LAYOUT_FT) {
+        // W = 4096, reference layout: the persistent kernel with 8-frame tiles (experiment, off)
+        if (pl.d_tw_r32)
+            return aligned ? run_stft_fat<LOG2N, true, SPEC>(pl, x, out, n_clips, n_samples, T)
+                           : run_stft_fat<LOG2N, false, SPEC>(pl, x, out, n_clips, n_samples, T);
+    }
     if constexpr (stft_use_fat(LOG2N, LAYOUT)) {
 #ifndef ZAFX_STFT_CARRY
 #define ZAFX_STFT_CARRY 1
@@ -1408,6 +1430,7 @@ static hipError_t run_istft(const zafx_plan& pl, const float2* spec, float* y, i
 bool stft_supported(int log2n) { return log2n >= 5 && log2n <= 12; }
 int stft_frames_per_block(int log2n, int layout) { return stft_fpb(log2n, layout); }
 const char* stft_kernel_name(int log2n, int layout) {
+    if (ZAFX_STFT_FAT8 && log2n == 11 && layout == ZAFX_LAYOUT_FT) return "k_stft_ft16";
     return stft_use_fat(log2n, layout) ? "k_stft_ft16" : stft_use_tf(log2n, layout) ? "k_stft_tf" : "k_stft";
 }
 const char* istft_kernel_name(int log2n, int layout) { return stft_use_fat(log2n, layout) || stft_use_tf(log2n, layout) ? "k_istft_ft16" : "k_istft"; }

@@ -648,8 +648,8 @@ int zafx_plan_create(zafx_plan** out, int device, int kind, const zafx_params* p
     if (e == hipSuccess) e = hipEventCreate(&pl->ev1);
     if (e == hipSuccess) {
         auto tw = is_cqt_family(kind) ? build_two_level_twiddles(pl->log2nf) : build_pass_twiddles(pl->log2nf, pl->log2e);
-        if (is_cqt_family(kind) && cqt_split(pl->log2nf)) {   // + the two-level roots of the 1024-point sub-transforms
-            const auto sub = build_two_level_twiddles(10);
+        if (is_cqt_family(kind) && cqt_split(pl->log2nf)) {   // + the pass tables of the 1024-point sub-transforms
+            const auto sub = build_pass_twiddles(10, 4);
             tw.insert(tw.end(), sub.begin(), sub.end());
         }
         if (tw.empty()) tw.push_back(cf32{1.f, 0.f});

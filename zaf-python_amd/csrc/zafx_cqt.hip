@@ -48,7 +48,7 @@ struct CqtCfg {
     static constexpr int NH2 = LT > 8 ? 1 << (LT - 8) : 1;         // two-level roots of 2N for k < N/2 (real split)
     static constexpr bool SPLIT = cqt_split(LOG2N);                // 16 x 1024 decomposition (zafx_internal.hpp)
     static constexpr int SLOTS = cqt_slots(LOG2N);                 // complex slots of the spectrum image
-    static constexpr int NSUB = SPLIT ? 8 + 128 : 0;               // two-level roots of the 1024-point sub-transforms
+    static constexpr int NSUB = SPLIT ? twiddle_total(10, 4) : 0;  // pass tables of the 1024-point sub-transforms (8 KB: round 3; a two-level root table + product trees before)
     static constexpr size_t HEAD = (((size_t)(SLOTS + NHI + 128 + NH2 + 128 + NSUB) * 8 + 15) / 16) * 16;
 };
 
@@ -80,7 +80,7 @@ __global__ __launch_bounds__(fft_threads(LOG2N, LOG2E)) void k_cqt(
     float2* tw_lo = tw_hi + NHI;
     float2* sp_hi = tw_lo + 128;                                  // two-level root table of 2N (split twiddles)
     float2* sp_lo = sp_hi + NH2;
-    float2* sub_hi = sp_lo + 128;                                 // (SPLIT) two-level root table of 1024
+    float2* sub_hi = sp_lo + 128;                                 // (SPLIT) pass tables of the 1024-point sub-transforms
     auto slot_of = [](int k) { return cqt_slot(LOG2N, k); };   // (DOUBLE: of a POSITION of the 16384-point transform)
     constexpr int NYQ = cqt_nyquist_slot(LOG2N);
     int4* wave_l = reinterpret_cast<int4*>(smem_raw + G::HEAD);   // [P / 64] {first iteration, iterations, step-end mask of the resident form, 0}
@@ -294,7 +294,7 @@ __global__ __launch_bounds__(fft_threads(LOG2N, LOG2E)) void k_cqt(
             regs_read<10, 4>(v, sub, lane);
             frame_sync<64>();
             // (the last pass leaves only the positions the split and the contraction read: run_cqt's mask)
-            fft1024_wave(v, sub, lane, TwoLevelTw{sub_hi, sub_hi + 8}, 0, prune3);
+            fft1024_wave(v, sub, lane, (const float2*)sub_hi, 0, prune3);   // (twiddles from the pass tables: 54 VALU instructions per frame and wave fewer than with the product trees)
         } else {
             fft_frame_chain<LOG2N, LOG2E>(v, buf, p, tw2l);
         }

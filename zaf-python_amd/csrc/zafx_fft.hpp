@@ -593,6 +593,26 @@ __device__ __forceinline__ void pass3_write_pruned(const float2* v, float2* buf,
         if (hi) buf[phys_off<1024, C::PS>(pb, k, 768)] = a[3];
     }
 }
+// (the same with the pass's [r - 1][k] table: three LDS reads per butterfly instead of a two-level product and two more products)
+template <int HB>
+__device__ __forceinline__ void pass3_write_pruned(const float2* v, float2* buf, int lane, const float2* tw) {
+    using C = FftCfg<10, 4>;
+    const float2* t = tw + twiddle_offset(10, 4, 8);
+#pragma unroll
+    for (int b = 0; b < 4; ++b) {
+        const bool lo = b <= HB, hi = b >= 3 - HB;
+        if (!lo && !hi) continue;
+        const int k = lane + b * 64;
+        float2 a[4];
+        a[0] = v[b];
+#pragma unroll
+        for (int r = 1; r < 4; ++r) a[r] = cmul(v[b + 4 * r], t[(r - 1) * 256 + k]);
+        Dft<4>::run(a);
+        const int pb = phys_t<C::PS>(k);
+        if (lo) buf[pb] = a[0];
+        if (hi) buf[phys_off<1024, C::PS>(pb, k, 768)] = a[3];
+    }
+}
 __device__ __forceinline__ void pass1_write(const float2* v, float2* buf, int lane, const float2* tw) { pass_write<10, 4, 0, 4>(v, buf, lane, tw); }
 __device__ __forceinline__ void pass1_write(const float2* v, float2* buf, int lane, const TwoLevelTw& t) { pass_write_chain<10, 4, 0, 4>(v, buf, lane, t); }
 
@@ -605,7 +625,7 @@ __device__ __forceinline__ void pass1_write(const float2* v, float2* buf, int la
 // exchange of this form therefore pads one slot every 32 points instead of every 16: slot 16 p1 + (p1 >> 1) + r, read back by
 // lane (lh, ll) at 16 lh + (lh >> 1) + ll + 66 i (position lane + 64 i = 16 (lh + 4 i) + ll) -- conflict free both ways.
 // PREDFT (pair form): the radix-16 butterflies of pass 1 have been run on v already (k_mel does them ahead of the barrier that frees the frame).
-// prune3 = 0 .. 3 (two-level tables only, wave-uniform): pass 3 forms only the low and mirrored positions (pass3_write_pruned<prune3>).
+// prune3 = 0 .. 2 (wave-uniform): pass 3 forms only the low and mirrored positions (pass3_write_pruned<prune3>).
 template <bool ODDROT = false, bool PAIR = false, bool PREDFT = false, class TW>
 __device__ __forceinline__ void fft1024_wave(float2* v, float2* buf, int lane, const TW& tw, int p1 = 0, int prune3 = -1) {
     if constexpr (ODDROT) {
@@ -649,15 +669,11 @@ __device__ __forceinline__ void fft1024_wave(float2* v, float2* buf, int lane, c
     for (int b = 0; b < 4; ++b)   // register 4 b + r' now holds position lane + 64 b + 256 r': pass 3 reads v[b + 4 r']
 #pragma unroll
         for (int r = 0; r < 4; ++r) v[b + 4 * r] = a[4 * b + r];
-    if constexpr (std::is_same_v<TW, TwoLevelTw>) {
-        switch (prune3) {   // (uniform)
-            case 0: pass3_write_pruned<0>(v, buf, lane, tw); break;
-            case 1: pass3_write_pruned<1>(v, buf, lane, tw); break;
-            case 2: pass3_write_pruned<2>(v, buf, lane, tw); break;
-            default: pass3_write(v, buf, lane, tw);
-        }
-    } else {
-        pass3_write(v, buf, lane, tw);
+    switch (prune3) {   // (uniform; -1 = all positions)
+        case 0: pass3_write_pruned<0>(v, buf, lane, tw); break;
+        case 1: pass3_write_pruned<1>(v, buf, lane, tw); break;
+        case 2: pass3_write_pruned<2>(v, buf, lane, tw); break;
+        default: pass3_write(v, buf, lane, tw);
     }
     frame_sync<64>();
 }

@@ -294,6 +294,27 @@ __global__ __launch_bounds__(fft_threads(LOG2N, LOG2E)) void k_cqt(
             regs_read<10, 4>(v, sub, lane);
             frame_sync<64>();
             // (the last pass leaves only the positions the split and the contraction read: run_cqt's mask)
+#ifndef ZAFX_CQT_LDS_EXCH
+#define ZAFX_CQT_LDS_EXCH 0
+#endif
+            if constexpr (ZAFX_CQT_LDS_EXCH) {   // experiment: both exchanges of the sub-transform through LDS (80 VALU instructions fewer, 32 LDS ones more)
+                const float2* t = (const float2*)sub_hi;
+                pass_write<10, 4, 0, 4>(v, sub, lane, t);
+                frame_sync<64>();
+                regs_read<10, 4>(v, sub, lane);
+                frame_sync<64>();
+                pass_write<10, 4, 4, 4>(v, sub, lane, t + twiddle_offset(10, 4, 4));
+                frame_sync<64>();
+                regs_read<10, 4>(v, sub, lane);
+                frame_sync<64>();
+                switch (prune3) {
+                    case 0: pass3_write_pruned<0>(v, sub, lane, t); break;
+                    case 1: pass3_write_pruned<1>(v, sub, lane, t); break;
+                    case 2: pass3_write_pruned<2>(v, sub, lane, t); break;
+                    default: pass3_write(v, sub, lane, t);
+                }
+                frame_sync<64>();
+            } else
             fft1024_wave(v, sub, lane, (const float2*)sub_hi, 0, prune3);   // (twiddles from the pass tables: 54 VALU instructions per frame and wave fewer than with the product trees)
         } else {
             fft_frame_chain<LOG2N, LOG2E>(v, buf, p, tw2l);

@@ -37,6 +37,24 @@ for k in KINDS + ["stft_tf", "all"]:
         json.loads(line)
         open(os.path.join(PROF, f"{tag}_bench_{k}.json"), "w").write(line + "\n")
 
+# the bench lines the PROFILED runs printed themselves (prof_<kind>.log): the kernel statistics below belong to these processes, and
+# where an allocation lands differs from process to process -- compare rocprofv3's mean with THIS line's kernel_ms
+prof_lines = {}
+for k in KINDS:
+    log = os.path.join(OUT, f"prof_{k}.log")
+    if os.path.exists(log):
+        rows = [ln for ln in open(log, errors="replace").read().splitlines() if ln.startswith("{")]
+        if rows:
+            try:
+                line = json.loads(rows[-1])
+                prof_lines[k] = {"steps": line["steps"], "warmup": line["warmup"], "ms_per_step": line["ms_per_step"],
+                                 "kernel_ms": line["roofline"]["kernel_ms"], "kernel_ms_median": line["roofline"]["kernel_ms_median"],
+                                 "kernel": line["roofline"]["kernel"]}
+            except (ValueError, KeyError):
+                pass
+if prof_lines:
+    open(os.path.join(PROF, f"{tag}_profiled_runs.json"), "w").write(json.dumps(prof_lines, indent=1) + "\n")
+
 # kernel statistics: the headline run in full, the dominant rows of the others in one file
 f = find("prof_stft/**/*kernel_stats.csv")
 if f:

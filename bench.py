@@ -463,6 +463,8 @@ def live_traffic(kind, kernel_name):
     exe = shutil.which("rocprofv3") or ("/opt/rocm/bin/rocprofv3" if os.path.exists("/opt/rocm/bin/rocprofv3") else None)
     if exe is None or os.environ.get("ZAFX_BENCH_LIVE_TRAFFIC", "1") == "0":
         return None
+    if any(k.startswith("ROCPROF") for k in os.environ) or "rocprofiler" in os.environ.get("LD_PRELOAD", ""):
+        return None   # this process is being profiled itself: no profiler inside a profiler
     out = {}
     work = tempfile.mkdtemp(prefix="zafx_pmc_", dir="/tmp")
     try:
@@ -471,7 +473,7 @@ def live_traffic(kind, kernel_name):
             env = dict(os.environ, TMPDIR="/tmp", ZAFX_BENCH_INNER="1")
             cmd = [exe, "--pmc", counter, "--kernel-trace", "--output-format", "csv", "-d", d, "-o", "p", "--",
                    sys.executable, os.path.abspath(__file__), "--kind", kind, "--steps", "3", "--warmup", "1", "--no-cpu-baseline"]
-            subprocess.run(cmd, cwd="/tmp", env=env, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=180, check=True)
+            subprocess.run(cmd, cwd="/tmp", env=env, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=90, check=True)
             files = glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True)
             if not files:
                 return None

@@ -579,6 +579,33 @@ def test_onesided_stft_istft(zafx, wl, hop, n):
             assert y[c].shape == yref.shape and relerr(y[c], yref) <= TOL_FFT, (layout, c)
 
 
+@pytest.mark.parametrize("hop,n,clips", [(2048, 150001, 3), (2048, 150000, 2), (1024, 70000, 2), (300, 20000, 1), (6000, 90000, 2),
+                                          (2048, 1, 1), (2048, 4097, 1), (1764, 441000, 2), (2048, 16 * 2048 * 3, 35), (1763, 60001, 2), (2047, 99999, 1)])
+def test_stft_w4096_two_bands(zafx, hop, n, clips):
+    """W = 4096 in the reference layout runs k_stft_ft16b: sixteen-frame tiles as two bands of bins (even rows from
+    FFT_1024(z[n] + z[n + 1024]), odd rows from the twiddled difference; zaf.py:128-139 is what it replaces).  Odd clip
+    lengths and odd hops take the predicated loads, even ones the clip-descriptor loads; T covers whole tiles, ragged last
+    tiles, rows on and off the 128-byte grid, more tiles than workgroups; every spectrum kind."""
+    x = np.stack([synth_clip(41, c, n) for c in range(clips)])
+    w = zafx.hamming(4096)
+    plan = zafx.stft_plan(w, hop)
+    assert plan.kernel_name == "k_stft_ft16b"
+    ref = orc.stft_batch(x.astype(np.float64), w, hop)
+    got = zafx.stft_batch(x, w, hop)
+    assert got.shape == ref.shape and got.dtype == np.complex64
+    for c in range(clips):
+        assert relerr(got[c], ref[c]) <= TOL_FFT, c
+    if clips <= 3:
+        half = 2049
+        one = zafx.stft_batch(x, w, hop, onesided=True)
+        mag = zafx.stft_batch(x, w, hop, onesided="magnitude")
+        pw = zafx.stft_batch(x, w, hop, onesided="power")
+        for c in range(clips):
+            assert relerr(one[c], ref[c, :half]) <= TOL_FFT
+            assert relerr(mag[c], np.abs(ref[c, :half])) <= TOL_FFT
+            assert relerr(pw[c], np.abs(ref[c, :half]) ** 2) <= 2 * TOL_FFT
+
+
 def test_onesided_rejected_elsewhere(zafx):
     with pytest.raises(zafx.ZafxError):
         zafx.Plan(zafx.MDCT, window_length=2048, onesided=True)
@@ -1086,13 +1113,16 @@ def test_cqt_short_kernel(zafx, fs, res, fmin, fmax, tr):
         zafx.cqtspectrogram_batch(x, fs, fs // (ck.shape[1] + 64), ck)
 
 
-@pytest.mark.parametrize("wl,hop,nmel", [(4096, 2048, 128), (8192, 2048, 64), (2048, 1024, 300)])
+@pytest.mark.parametrize("wl,hop,nmel", [(4096, 2048, 128), (8192, 2048, 64), (2048, 1024, 300), (4096, 1024, 40), (8192, 4096, 256), (4096, 1763, 128)])
 def test_mel_long_window_or_wide_bank(zafx, wl, hop, nmel):
-    """Windows above 2048 and filterbanks above 256 rows are outside the fused float32 kernel; the host layer runs them
-    on the float64 kernel and returns float32 from the float32 entry points."""
-    x = np.stack([synth_clip(61, c, 60000) for c in range(2)])
+    """Windows of 4096 / 8192 samples are outside the fused kernel: a spectrum kernel (|X| or |X|^2 rows into a plan-owned
+    scratch) + the banded filterbank kernel k_melfb, in float32.  Filterbanks above 256 rows run on the float64 kernel and
+    return float32 from the float32 entry points."""
+    x = np.stack([synth_clip(61, c, 60000 + (hop % 2)) for c in range(2)])
     w = zafx.hamming(wl)
     fb = zafx.melfilterbank(44100, wl, nmel)
+    plan = zafx.mel_plan(w, hop, fb)
+    assert plan.kernel_name == ("k_melfb" if wl > 2048 else "k_mel_f64") and plan.in_dtype == (np.float32 if wl > 2048 else np.float64)
     mel = zafx.melspectrogram_batch(x, w, hop, fb)
     cep = zafx.mfcc_batch(x, w, hop, fb, 13)
     assert mel.dtype == np.float32 and cep.dtype == np.float32
@@ -1100,8 +1130,29 @@ def test_mel_long_window_or_wide_bank(zafx, wl, hop, nmel):
         x64 = x[c].astype(np.float64)
         assert relerr(mel[c], orc.melspectrogram(x64, w, hop, fb)) <= TOL_FB
         assert relerr(cep[c], orc.mfcc(x64, w, hop, fb, 13)) <= TOL_FB
+    mel_tf = zafx.melspectrogram_batch(x, w, hop, fb, layout="TF")
+    cep_tf = zafx.mfcc_batch(x, w, hop, fb, 13, layout="TF")
+    assert np.array_equal(mel_tf.transpose(0, 2, 1), mel) and np.array_equal(cep_tf.transpose(0, 2, 1), cep)
     one = zafx.melspectrogram(x[0], w, hop, fb)
     assert one.dtype == np.float64 and relerr(one, orc.melspectrogram(x[0].astype(np.float64), w, hop, fb)) <= TOL_FB
+
+
+def test_mel_long_window_in_chunks(zafx):
+    """k_melfb's scratch holds a chunk of clips (256 MB): 1200 short clips at W = 4096 go through it in two chunks (768 + 432);
+    padded output rows (row_align)."""
+    n, hop, clips = 30000, 2048, 1200
+    x = np.stack([synth_clip(62, c % 7, n) for c in range(clips)])
+    w = zafx.hamming(4096)
+    fb = zafx.melfilterbank(44100, 4096, 128)
+    mel = zafx.melspectrogram_batch(x, w, hop, fb)
+    cep = zafx.mfcc_batch(x, w, hop, fb, 20)
+    for c in (0, 255, 767, 768, 1023, 1199):
+        x64 = x[c].astype(np.float64)
+        assert relerr(mel[c], orc.melspectrogram(x64, w, hop, fb)) <= TOL_FB, c
+        assert relerr(cep[c], orc.mfcc(x64, w, hop, fb, 20)) <= TOL_FB, c
+    assert np.array_equal(mel[7:14], mel[0:7]) and np.array_equal(cep[1190:1197], cep[0:7])
+    _run_padded(zafx, zafx.mel_plan(w, hop, fb), zafx.mel_plan(w, hop, fb, row_align=32), None, None, x[:3])
+    _run_padded(zafx, zafx.mel_plan(w, hop, fb, 20), zafx.mel_plan(w, hop, fb, 20, row_align=32), None, None, x[:3])
 
 
 @pytest.mark.parametrize("wl,hop,n", [(2048, 100, 20000), (4096, 300, 30000), (8192, 1000, 40000), (64, 3, 1000)])

@@ -287,6 +287,25 @@ static int finalize_constant(zafx_plan* pl, int which) {
                 ZAFX_HIP(upload(&pl->d_fb64_meta, meta.data(), meta.size() * sizeof(int)));
                 return 0;
             }
+            if (pl->log2nf >= 11) {   // W = 4096 / 8192 (k_melfb): rows as float32 bands
+                const int rows = pl->prm.n_filters, cols = pl->W / 2;
+                std::vector<int> meta((size_t)rows * 3, 0);
+                std::vector<float> vals;
+                for (int r = 0; r < rows; ++r) {
+                    const float* row = &pl->h_fb[(size_t)r * cols];
+                    int lo = 0, hi = cols;
+                    while (lo < cols && row[lo] == 0.f) ++lo;
+                    while (hi > lo && row[hi - 1] == 0.f) --hi;
+                    meta[(size_t)r * 3] = lo;
+                    meta[(size_t)r * 3 + 1] = hi - lo;
+                    meta[(size_t)r * 3 + 2] = (int)vals.size();
+                    vals.insert(vals.end(), row + lo, row + hi);
+                }
+                if (vals.empty()) vals.push_back(0.f);
+                ZAFX_HIP(upload(&pl->d_fbw, vals.data(), vals.size() * sizeof(float)));
+                ZAFX_HIP(upload(&pl->d_fbw_meta, meta.data(), meta.size() * sizeof(int)));
+                return 0;
+            }
             {
                 // k_mel hands the filterbank 2 |X| (mel) or 4 |X|^2 (mfcc) -- the real split without its two halvings -- so the packed
                 // fragments carry the factor 1/2 or 1/4: powers of two, the products and sums come out bit for bit as before.
@@ -299,6 +318,10 @@ static int finalize_constant(zafx_plan* pl, int which) {
         case ZAFX_CONST_DCT:
             if (pl->prm.precision == ZAFX_PRECISION_F64) {
                 ZAFX_HIP(upload(&pl->d_dct64, pl->h_dct64.data(), pl->h_dct64.size() * sizeof(double)));
+                return 0;
+            }
+            if (pl->log2nf >= 11) {   // W = 4096 / 8192 (k_melfb): dense rows
+                ZAFX_HIP(upload(&pl->d_dctw, pl->h_dct.data(), pl->h_dct.size() * sizeof(float)));
                 return 0;
             }
             ZAFX_HIP(pack_band(pl->dct, pl->h_dct.data(), pl->prm.n_coefs, pl->prm.n_filters, mel_waves(pl->log2nf)));
@@ -586,14 +609,14 @@ int zafx_plan_create(zafx_plan** out, int device, int kind, const zafx_params* p
                 return bail("n_coefs must be in [1, n_filters]");
             if (params->precision == ZAFX_PRECISION_F64) {
                 if (params->n_filters > std::max(pl->W / 2, 1)) return bail("n_filters must not exceed window_length / 2");
-            } else if (lw - 1 < 5 || lw - 1 > 10) {
-                return bail("float32 mel/mfcc kernels are built for window_length 64 ... 2048 (any power of two with ZAFX_PRECISION_F64)");
+            } else if (lw - 1 < 5 || lw - 1 > 12) {
+                return bail("float32 mel/mfcc kernels are built for window_length 64 ... 8192 (any power of two with ZAFX_PRECISION_F64)");
             }
         }
         const int n = pl->W / 2;
         aux.resize((size_t)n / 2 + 1);
         for (int k = 0; k <= n / 2; ++k) aux[(size_t)k] = unit_root(k, pl->W);
-        pl->kernel_name = kind == ZAFX_STFT ? stft_kernel_name(lw - 1, pl->layout) : kind == ZAFX_ISTFT ? istft_kernel_name(lw - 1, pl->layout) : mel_kernel_name();
+        pl->kernel_name = kind == ZAFX_STFT ? stft_kernel_name(lw - 1, pl->layout) : kind == ZAFX_ISTFT ? istft_kernel_name(lw - 1, pl->layout) : lw - 1 >= 11 ? mel_wide_kernel_name() : mel_kernel_name();
     } else if (is_mdct_family(kind)) {
         pl->W = params->window_length;
         pl->H = pl->W / 2;   // zaf.py:1029
@@ -658,6 +681,10 @@ int zafx_plan_create(zafx_plan** out, int device, int kind, const zafx_params* p
             auto tw5 = build_pass_twiddles(pl->log2nf, 5);   // (W = 4096: 2048 points as 32 x 32 x 2 in the persistent 8-frame form)
             e = upload(&pl->d_tw_r32, tw5.data(), tw5.size() * sizeof(cf32));
         }
+    }
+    if (e == hipSuccess && (kind == ZAFX_STFT || kind == ZAFX_MEL || kind == ZAFX_MFCC) && pl->log2nf == 11 && pl->prm.precision == ZAFX_PRECISION_F32) {
+        const auto sub = build_pass_twiddles(10, 4);   // the two 1024-point band transforms of k_stft_ft16b
+        e = upload(&pl->d_tw_sub, sub.data(), sub.size() * sizeof(cf32));
     }
     if (e == hipSuccess) e = upload(&pl->d_tw_aux, aux.data(), aux.size() * sizeof(cf32));
     if (e == hipSuccess && pl->prm.precision == ZAFX_PRECISION_F32 && pl->bs_log2m > 0) {   // float32 Bluestein plan (zafx_bs32.hip)
@@ -742,6 +769,10 @@ int zafx_plan_destroy(zafx_plan* pl) {
     if (pl->d_wfold) (void)hipFree(pl->d_wfold);
     if (pl->d_tw_pass) (void)hipFree(pl->d_tw_pass);
     if (pl->d_tw_r32) (void)hipFree(pl->d_tw_r32);
+    if (pl->d_tw_sub) (void)hipFree(pl->d_tw_sub);
+    if (pl->d_fbw) (void)hipFree(pl->d_fbw);
+    if (pl->d_fbw_meta) (void)hipFree(pl->d_fbw_meta);
+    if (pl->d_dctw) (void)hipFree(pl->d_dctw);
     if (pl->d_tw_aux) (void)hipFree(pl->d_tw_aux);
     if (pl->d_indptr) (void)hipFree(pl->d_indptr);
     if (pl->d_indices) (void)hipFree(pl->d_indices);
@@ -917,8 +948,8 @@ int zafx_execute(zafx_plan* pl, const void* d_in, void* d_out, int64_t n_clips, 
     if (int rc = zafx_plan_out_dims(pl, n_in, dims)) return rc;
     if (pl->kind == ZAFX_LINEAR && !pl->d_matrix) return fail_msg("matrix constant not set");
     if (!is_cqt_family(pl->kind) && pl->kind != ZAFX_LINEAR && !pl->d_window && !pl->d_window64) return fail_msg("window constant not set");
-    if ((pl->kind == ZAFX_MEL || pl->kind == ZAFX_MFCC) && !pl->fb.d_pack && !pl->d_fb64) return fail_msg("mel filterbank constant not set");
-    if (pl->kind == ZAFX_MFCC && !pl->dct.d_pack && !pl->d_dct64) return fail_msg("DCT constant not set");
+    if ((pl->kind == ZAFX_MEL || pl->kind == ZAFX_MFCC) && !pl->fb.d_pack && !pl->d_fb64 && !pl->d_fbw) return fail_msg("mel filterbank constant not set");
+    if (pl->kind == ZAFX_MFCC && !pl->dct.d_pack && !pl->d_dct64 && !pl->d_dctw) return fail_msg("DCT constant not set");
     if (is_cqt_family(pl->kind)) {
         const bool f64 = pl->prm.precision == ZAFX_PRECISION_F64;
         if (!pl->d_indptr || !pl->d_indices || !(f64 ? (void*)pl->d_values64 : (void*)pl->d_values)) return fail_msg("CQT kernel constants not set");

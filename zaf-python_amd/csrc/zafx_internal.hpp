@@ -108,6 +108,12 @@ struct zafx_plan {
     int cqt_n_entries = 0;
     bool cqt_real = false;
     int cqt_resident = 0;          // kCqtResident: the busiest wave's iterations fit the registers; 0: entries streamed from L2 every frame
+    // mel / mfcc plans of W = 4096 / 8192 (k_melfb): filterbank rows as bands of float32 (values of [first, first + count) of every
+    // row back to back; meta [n_filters][3] = first column, count, offset) and the DCT rows dense [n_coefs][n_filters]
+    float* d_fbw = nullptr;
+    int* d_fbw_meta = nullptr;
+    float* d_dctw = nullptr;
+    float2* d_tw_sub = nullptr;    // pass twiddles of the 1024-point band transforms (k_stft_ft16b), STFT plans of W = 4096
     float2* d_tw_r32 = nullptr;    // pass twiddles of the radix-32 schedule (1024 points as 32 x 32), STFT plans of W = 2048
     // float64 mode (ZAFX_PRECISION_F64, zafx_f64.hip)
     double* d_window64 = nullptr;
@@ -174,7 +180,8 @@ hipError_t grow_scratch(zafx_plan& pl, size_t need);
 int64_t scratch_clips_per_chunk(int64_t n_clips, int T, int W, size_t elem_bytes);
 hipError_t launch_mdct(const zafx_plan& pl, const float* x, float* out, int64_t n_clips, int64_t n_samples, int T);
 hipError_t launch_imdct(const zafx_plan& pl, const float* coefs, float* y, int64_t n_clips, int T, int64_t out_len);
-hipError_t launch_mel(const zafx_plan& pl, const float* x, float* out, int64_t n_clips, int64_t n_samples, int T);
+hipError_t launch_mel(zafx_plan& pl, const float* x, float* out, int64_t n_clips, int64_t n_samples, int T);   // (windows above 2048 samples grow the plan's scratch)
+const char* mel_wide_kernel_name();
 hipError_t launch_cqt(const zafx_plan& pl, const float* x, float* out, int64_t n_clips, int64_t n_samples, int T);
 hipError_t launch_linear(const zafx_plan& pl, const float* x, float* y, int64_t n_clips);
 const char* linear_kernel_name();

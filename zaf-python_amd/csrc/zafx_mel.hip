@@ -18,6 +18,7 @@
 // Slots (256 floats each) live in the upper halves of the frame buffers, which are dead
 // once the magnitudes have been written.
 #include <algorithm>
+#include <cstdlib>
 
 #include "zafx_fft.hpp"
 #include "zafx_internal.hpp"
@@ -555,7 +556,121 @@ static hipError_t run_mel_any(const zafx_plan& pl, const float* x, float* out, i
     return aligned ? run_mel<LOG2N, true>(pl, x, out, n_clips, n_samples, T) : run_mel<LOG2N, false>(pl, x, out, n_clips, n_samples, T);
 }
 
-hipError_t launch_mel(const zafx_plan& pl, const float* x, float* out, int64_t n_clips, int64_t n_samples, int T) {
+// ---------------------------------------------------------------------------------
+// windows of 4096 / 8192 samples: spectrum kernel + banded filterbank kernel (k_melfb)
+// ---------------------------------------------------------------------------------
+// Sixteen frames of such a window do not fit LDS, so the fused kernel stops at W = 2048 and these sizes ran on the float64
+// kernel (one workgroup per frame, float64 arrays in and out).  Here the |X| (mel) or |X|^2 (mfcc) rows 0..W/2 of a CHUNK of
+// clips are written by the STFT kernels' magnitude / power kinds (W = 4096: k_stft_ft16b) into a plan-owned scratch with rows
+// padded to whole 128-byte lines, and k_melfb multiplies them with the filterbank: a 16-wave workgroup per (clip, 64 frames),
+// a lane per frame, wave w the filters w, w + 16, ...; a filter's row is its band of non-zeros [first, first + count)
+// (zaf.py:305-316: one triangle), so a wave reads count coalesced 256-byte rows of the spectrum per filter and each spectrum
+// row is read by the two filters that overlap it -- the second time from the vector cache or L2.  mfcc: the workgroup's mel
+// values go through LDS as log(mel + eps) and every wave forms its DCT-II rows from there (zaf.py:443-452).  Chunk: 256 MB of
+// scratch (ZAFX_MELW_CHUNK_MB), rounded to whole rounds of the persistent spectrum kernel -- measured, 1024 clips x 10 s at
+// W = 4096: 2.44 / 2.01 / 1.93 / 1.93 ms with 64 / 128 / 256 / 1024 MB (keeping the scratch inside the memory-side cache buys
+// nothing; whole rounds and fewer launches do).
+__global__ __launch_bounds__(1024) void k_melfb(const float* __restrict__ spec, const float* __restrict__ fb_vals, const int* __restrict__ fb_meta,
+                                                const float* __restrict__ dct, float* __restrict__ out, int n_filters, int n_coefs, int rows,
+                                                int SP, int T, int TP, int layout) {
+    extern __shared__ float logmel[];   // [n_filters][64] (mfcc only)
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int t = blockIdx.x * 64 + lane;
+    const long long clip = blockIdx.y;
+    const bool live = t < T;
+    const float* sp = spec + (clip * rows + 1) * SP + (live ? t : 0);   // bin c + 1 <-> filterbank column c (zaf.py:370)
+    const float eps = 2.220446049250313e-16f;   // np.finfo(float).eps (zaf.py:445)
+    for (int f = wave; f < n_filters; f += 16) {
+        const int first = __builtin_amdgcn_readfirstlane(fb_meta[3 * f]), count = __builtin_amdgcn_readfirstlane(fb_meta[3 * f + 1]);
+        const float* v = fb_vals + __builtin_amdgcn_readfirstlane(fb_meta[3 * f + 2]);
+        const float* s = sp + (long long)first * SP;
+        float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+        int j = 0;
+        for (; j + 4 <= count; j += 4) {
+            a0 += v[j] * s[(long long)j * SP];
+            a1 += v[j + 1] * s[(long long)(j + 1) * SP];
+            a2 += v[j + 2] * s[(long long)(j + 2) * SP];
+            a3 += v[j + 3] * s[(long long)(j + 3) * SP];
+        }
+        for (; j < count; ++j) a0 += v[j] * s[(long long)j * SP];
+        const float mel = (a0 + a1) + (a2 + a3);
+        if (n_coefs > 0) {
+            logmel[f * 64 + lane] = logf(mel + eps);
+        } else if (live) {
+            if (layout == ZAFX_LAYOUT_FT) out[(clip * n_filters + f) * TP + t] = mel;
+            else out[(clip * T + t) * n_filters + f] = mel;
+        }
+    }
+    if (n_coefs > 0) {
+        __syncthreads();
+        for (int c = wave; c < n_coefs; c += 16) {
+            const float* d = dct + (long long)c * n_filters;
+            float a0 = 0.f, a1 = 0.f;
+            int f = 0;
+            for (; f + 2 <= n_filters; f += 2) {
+                a0 += d[f] * logmel[f * 64 + lane];
+                a1 += d[f + 1] * logmel[(f + 1) * 64 + lane];
+            }
+            if (f < n_filters) a0 += d[f] * logmel[f * 64 + lane];
+            if (live) {
+                if (layout == ZAFX_LAYOUT_FT) out[(clip * n_coefs + c) * TP + t] = a0 + a1;
+                else out[(clip * T + t) * n_coefs + c] = a0 + a1;
+            }
+        }
+    }
+}
+
+static size_t melw_chunk_bytes() {
+    static const size_t bytes = [] {
+        const char* env = std::getenv("ZAFX_MELW_CHUNK_MB");
+        const long mb = env ? std::atol(env) : 0;
+        return (size_t)(mb > 0 ? mb : 256) << 20;
+    }();
+    return bytes;
+}
+
+static hipError_t run_mel_wide(zafx_plan& pl, const float* x, float* out, int64_t n_clips, int64_t n_samples, int T) {
+    if ((long long)n_clips * T <= 0) return hipSuccess;
+    const int mfcc = pl.kind == ZAFX_MFCC;
+    const int rows = pl.W / 2 + 1;
+    const int SP = (T + 31) / 32 * 32;   // spectrum rows as whole 128-byte lines
+    const size_t per_clip = (size_t)rows * SP * sizeof(float);
+    int64_t chunk = std::max<int64_t>(1, std::min<int64_t>(n_clips, (int64_t)(melw_chunk_bytes() / per_clip)));
+    {   // whole rounds of the persistent spectrum kernel: (16-frame tiles per clip) x chunk a multiple of the workgroups
+        const int tiles = (T + 15) / 16;
+        int g = tiles, h = pl.n_cus;
+        while (h) { const int r = g % h; g = h; h = r; }
+        const int64_t m = pl.n_cus / g;
+        if (chunk >= m) chunk = chunk / m * m;
+    }
+    if (hipError_t e = grow_scratch(pl, (size_t)chunk * per_clip); e != hipSuccess) return e;
+    float* spec = reinterpret_cast<float*>(pl.d_scratch64);
+    // the spectrum kernels see an STFT plan of this window: one-sided |X| (mel, zaf.py:370) or |X|^2 (mfcc, zaf.py:437-439),
+    // reference layout, rows padded to 32 floats
+    zafx_plan st;
+    st.device = pl.device; st.n_cus = pl.n_cus; st.kind = ZAFX_STFT; st.prm = pl.prm; st.stream = pl.stream;
+    st.prm.spectrum = mfcc ? ZAFX_SPECTRUM_POWER : ZAFX_SPECTRUM_MAGNITUDE;
+    st.prm.row_align = 32;
+    st.W = pl.W; st.H = pl.H; st.layout = ZAFX_LAYOUT_FT; st.log2nf = pl.log2nf; st.log2e = pl.log2e;
+    st.d_window = pl.d_window; st.d_tw_pass = pl.d_tw_pass; st.d_tw_aux = pl.d_tw_aux; st.d_tw_sub = pl.d_tw_sub;
+    const size_t smem = mfcc ? (size_t)pl.prm.n_filters * 64 * sizeof(float) : 0;
+    if (hipError_t e = ensure_dynamic_lds(reinterpret_cast<const void*>(k_melfb), pl.device, std::max<size_t>(smem, 1)); e != hipSuccess) return e;
+    const int64_t out_per_clip = pl.layout == ZAFX_LAYOUT_FT ? (int64_t)(mfcc ? pl.prm.n_coefs : pl.prm.n_filters) * row_pitch(pl, T)
+                                                             : (int64_t)T * (mfcc ? pl.prm.n_coefs : pl.prm.n_filters);
+    for (int64_t c0 = 0; c0 < n_clips; c0 += chunk) {
+        const int64_t n = std::min(chunk, n_clips - c0);
+        if (hipError_t e = launch_stft(st, x + c0 * n_samples, reinterpret_cast<float2*>(spec), n, n_samples, T); e != hipSuccess) return e;
+        hipLaunchKernelGGL(k_melfb, dim3((unsigned)((T + 63) / 64), (unsigned)n), dim3(1024), smem, pl.stream, spec, pl.d_fbw, pl.d_fbw_meta, pl.d_dctw,
+                           out + c0 * out_per_clip, pl.prm.n_filters, mfcc ? pl.prm.n_coefs : 0, rows, SP, T, (int)row_pitch(pl, T), pl.layout);
+        if (hipError_t e = hipGetLastError(); e != hipSuccess) return e;
+    }
+    return hipSuccess;
+}
+
+const char* mel_wide_kernel_name() { return "k_melfb"; }
+
+hipError_t launch_mel(zafx_plan& pl, const float* x, float* out, int64_t n_clips, int64_t n_samples, int T) {
+    if (pl.log2nf >= 11) return run_mel_wide(pl, x, out, n_clips, n_samples, T);
     switch (pl.log2nf) {
         case 5: return run_mel_any<5>(pl, x, out, n_clips, n_samples, T);
         case 6: return run_mel_any<6>(pl, x, out, n_clips, n_samples, T);

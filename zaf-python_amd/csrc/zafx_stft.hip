@@ -532,6 +532,168 @@ __global__ __launch_bounds__(kFatWaves * 64) void k_stft_ft16c(
 }
 
 // ---------------------------------------------------------------------------------
+// forward, reference layout, W = 4096: the persistent 16-frame kernel over two BANDS of bins (k_stft_ft16b)
+// ---------------------------------------------------------------------------------
+// Sixteen packed frames of 2048 points are 256 KB: they do not fit LDS, so W = 4096 ran on the one-workgroup-per-tile kernel
+// (2.8 TB/s), and eight-frame tiles write 64-byte runs (measured: 6.5 ms against 3.1).  One decimation-in-frequency step on
+// the way in splits the packed frame z (M = 2048 points) into two 1024-point transforms that are complete on their own:
+//     Z[2q]     = FFT_1024( z[n] + z[n + 1024] )[q]                         (band 0)
+//     Z[2q + 1] = FFT_1024( (z[n] - z[n + 1024]) exp(-2 pi i n / 2048) )[q]  (band 1)
+// and the real split pairs Z[m] with Z[M - m], i.e. band 0 with band 0 (q, 1024 - q) and band 1 with band 1 (q, 1023 - q):
+// a band is transformed, split and stored without the other.  So a tile is two rounds of the W = 2048 kernel's phases on the
+// SAME sixteen frame buffers -- transforms of band 0, barrier, stores of the even rows (128-byte runs), barrier, transforms
+// of band 1 (from registers: both bands are formed from the prefetched samples at once), request of the next tile, barrier,
+// stores of the odd rows.  The window (16 KB) does not fit beside the frames and is read from global memory once per tile
+// and lane (both frames of a wave use the same 32 pairs); exp(-2 pi i n / 2048), n = lane + 64 i, is one per-lane root
+// (loop invariant, a register pair) times a compile-time constant.
+struct BandCfg {
+    using C = FftCfg<10, 4>;
+    static constexpr int N = 1024, M = 2048, W = 4096, FPB = kFatFrames, NT = kFatWaves * 64, FPW = 2;
+    static constexpr int PITCH = FatCfg<10, 4>::PITCH;
+    static constexpr size_t SMEM = (size_t)(FPB * PITCH + C::TW + M / 2 + 1) * 8;
+};
+static_assert(BandCfg::SMEM <= (size_t)kMaxLdsBytes, "k_stft_ft16b: tile + tables exceed LDS");
+
+template <bool ALIGNED, int SPEC>
+__global__ __launch_bounds__(kFatWaves * 64) void k_stft_ft16b(
+    const float* __restrict__ x, const float* __restrict__ win, const float2* __restrict__ twp,
+    const float2* __restrict__ tws, float2* __restrict__ out, long long n_samples, int hop, int T, int TP, int tiles,
+    int total_tiles) {
+    using B = BandCfg;
+    using C = B::C;
+    constexpr int N = B::N, M = B::M, W = B::W, P = 64, E = 16, NT = B::NT, FPB = B::FPB, FPW = B::FPW, PITCH = B::PITCH;
+    constexpr int ROWS = SPEC ? M + 1 : W;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    float2* frames = reinterpret_cast<float2*>(smem_raw);
+    float2* tw_l = frames + FPB * PITCH;   // pass tables of the 1024-point transform
+    float2* tws_l = tw_l + C::TW;          // exp(-2 pi i k / W), k <= M / 2
+    const int tid = threadIdx.x;
+    for (int i = tid; i < C::TW; i += NT) tw_l[i] = twp[i];
+    for (int i = tid; i <= M / 2; i += NT) tws_l[i] = tws[i];
+    __syncthreads();
+    const int wave = tid / P, p_lane = tid % P;
+    const int tt = tid % FPB, kq = tid / FPB;
+    const float2* fb = frames + tt * PITCH;
+    const bool lines_whole = TP % 16 == 0 && reinterpret_cast<uintptr_t>(out) % 128 == 0;
+    const bool xcd = ZAFX_XCD_ORDER && gridDim.x % 8 == 0;
+    const float2 wp = tws_l[2 * p_lane];   // exp(-2 pi i lane / M)
+
+    float2 xr[FPW][2 * E];   // z[lane + 64 j], j < 32, of the wave's two frames
+    auto prefetch = [&](int tlv) {
+        if (tlv >= total_tiles) return;
+        const int tl = xcd ? xcd_order(tlv, total_tiles) : tlv;
+        const int clip = tl / tiles, tile = tl % tiles;
+        const float* xc = x + (long long)clip * n_samples;
+        // the clip as buffer descriptor: samples outside it read as zero = the reference's padding (zaf.py:112-125); no edge path,
+        // no 64-bit addresses (clips below 2^29 samples: run_stft).  ALIGNED (even clip length, hop and base): a pair is inside
+        // or outside as a whole and comes as one 8-byte load; otherwise two 4-byte loads.
+        const __amdgpu_buffer_rsrc_t rs = make_rsrc(xc, (unsigned)(n_samples * 4));
+#pragma unroll
+        for (int f = 0; f < FPW; ++f) {
+            const int s0 = (tile * FPB + wave * FPW + f) * hop - M;
+            const int vo = (s0 + 2 * p_lane) * 4;
+            int vo1 = vo + 4;
+            // (opaque: were the two 4-byte loads of a pair provably adjacent the compiler would merge them into one 8-byte load, and
+            // a pair that straddles an end of the clip would then be out of range as a whole -- its inside sample read as zero)
+            if constexpr (!ALIGNED) asm volatile("" : "+v"(vo1));
+#pragma unroll
+            for (int j = 0; j < 2 * E; ++j) {
+                if constexpr (ALIGNED) {
+                    xr[f][j] = buf_load_f32x2(rs, vo + j * P * 8);
+                } else {
+                    xr[f][j].x = buf_load_f32(rs, vo + j * P * 8);
+                    xr[f][j].y = buf_load_f32(rs, vo1 + j * P * 8);
+                }
+            }
+        }
+    };
+    // rows of one band: X[k] and X[M - k] (+ their mirrors W - k, M + k) from the pair (Z[k], Z[M - k]), k = 2 q + S
+    auto store_band = [&](auto band, auto stream, float2* o) {
+        constexpr int S = decltype(band)::value;
+        constexpr bool ST = decltype(stream)::value;
+        constexpr int ITER = (N / 2) / (NT / FPB);
+        static_assert((N / 2) % (NT / FPB) == 0, "the row sweep is a whole number of iterations");
+        int kqo = kq;
+        asm volatile("" : "+v"(kqo));   // (the split roots of the 16 iterations are not carried across tiles)
+        const int rot = ST ? ZAFX_STFT_ROWROT_EXPR : 0;
+        for (int it = 0; it < ITER; ++it) {
+            const int q = kqo + ((it + rot) % ITER) * (NT / FPB);
+            if (S == 0 && q == 0) {
+                const float2 z0 = fb[0], zc = fb[phys_t<C::PS>(N / 2)];   // Z[0], Z[M / 2]
+                put_bin<SPEC, ST>(o, 0, make_float2(z0.x + z0.y, 0.f));
+                put_bin<SPEC, ST>(o, (long long)M * TP, make_float2(z0.x - z0.y, 0.f));
+                put_bin<SPEC, ST>(o, (long long)(M / 2) * TP, cconj(zc));
+                if (SPEC == 0) put_bin<SPEC, ST>(o, (long long)(M + M / 2) * TP, zc);
+            } else {
+                const int k = 2 * q + S;
+                float2 xk, xn;
+                split_pair(fb[phys_t<C::PS>(q)], fb[phys_t<C::PS>(N - S - q)], tws_l[k], xk, xn);
+                put_bin<SPEC, ST>(o, (long long)k * TP, xk);
+                if (SPEC == 0) put_bin<SPEC, ST>(o, (long long)(W - k) * TP, cconj(xk));
+                put_bin<SPEC, ST>(o, (long long)(M - k) * TP, xn);
+                if (SPEC == 0) put_bin<SPEC, ST>(o, (long long)(M + k) * TP, cconj(xn));
+            }
+        }
+    };
+    int tlv = blockIdx.x;
+    prefetch(tlv);
+    for (; tlv < total_tiles; tlv += gridDim.x) {
+        const int tl = xcd ? xcd_order(tlv, total_tiles) : tlv;
+        const int clip = tl / tiles, tile = tl % tiles;
+        const int t0 = tile * FPB;
+        int po = p_lane;
+        asm volatile("" : "+v"(po));   // (window offsets and table addresses are recomputed per tile, not hoisted)
+        {
+            // window pairs of this lane (the same for both frames), then both bands of both frames in place:
+            // xr[f][i] <- a + b, xr[f][i + 16] <- (a - b) exp(-2 pi i (lane + 64 i) / M), a = w z[n], b = w z[n + 1024]
+            const float2* w2 = reinterpret_cast<const float2*>(win) + po;
+            // exp(-2 pi i k / 32) = (c32[k], -s32[k])
+            const float c32[16] = {1.f, 0.98078528040323044913f, 0.92387953251128675613f, 0.83146961230254523708f, 0.70710678118654752440f,
+                                   0.55557023301960222474f, 0.38268343236508977173f, 0.19509032201612826785f, 0.f,
+                                   -0.19509032201612826785f, -0.38268343236508977173f, -0.55557023301960222474f, -0.70710678118654752440f,
+                                   -0.83146961230254523708f, -0.92387953251128675613f, -0.98078528040323044913f};
+            const float s32[16] = {0.f, 0.19509032201612826785f, 0.38268343236508977173f, 0.55557023301960222474f, 0.70710678118654752440f,
+                                   0.83146961230254523708f, 0.92387953251128675613f, 0.98078528040323044913f, 1.f,
+                                   0.98078528040323044913f, 0.92387953251128675613f, 0.83146961230254523708f, 0.70710678118654752440f,
+                                   0.55557023301960222474f, 0.38268343236508977173f, 0.19509032201612826785f};
+            float2 wv[2 * E];
+#pragma unroll
+            for (int j = 0; j < 2 * E; ++j) wv[j] = w2[j * P];
+#pragma unroll
+            for (int f = 0; f < FPW; ++f) {
+#pragma unroll
+                for (int i = 0; i < E; ++i) {
+                    const float2 a = make_float2(xr[f][i].x * wv[i].x, xr[f][i].y * wv[i].y);
+                    const float2 b = make_float2(xr[f][i + E].x * wv[i + E].x, xr[f][i + E].y * wv[i + E].y);
+                    xr[f][i] = cadd(a, b);
+                    const float2 d = csub(a, b);
+                    xr[f][i + E] = cmul(i == 0 ? d : (i == 8 ? mul_mi(d) : cmulk(d, c32[i], -s32[i])), wp);
+                }
+            }
+        }
+#pragma unroll
+        for (int f = 0; f < FPW; ++f) fft_frame<10, 4>(&xr[f][0], frames + (wave * FPW + f) * PITCH, po, tw_l);
+        lds_barrier();
+        float2* o = spec_base<SPEC>(out, (long long)clip * ROWS * TP + (t0 + tt));
+        const bool stream = SPEC < 2 && lines_whole;
+        if (t0 + tt < T) {
+            if (stream) store_band(std::integral_constant<int, 0>{}, std::true_type{}, o);
+            else store_band(std::integral_constant<int, 0>{}, std::false_type{}, o);
+        }
+        lds_barrier();
+#pragma unroll
+        for (int f = 0; f < FPW; ++f) fft_frame<10, 4>(&xr[f][E], frames + (wave * FPW + f) * PITCH, po, tw_l);
+        prefetch(tlv + gridDim.x);   // each wave as soon as ITS frames are done, ahead of the barrier (as k_stft_ft16)
+        lds_barrier();
+        if (t0 + tt < T) {
+            if (stream) store_band(std::integral_constant<int, 1>{}, std::true_type{}, o);
+            else store_band(std::integral_constant<int, 1>{}, std::false_type{}, o);
+        }
+        lds_barrier();
+    }
+}
+
+// ---------------------------------------------------------------------------------
 // forward, frame-major layout (ZAFX_LAYOUT_TF), persistent and barrier free
 // ---------------------------------------------------------------------------------
 // Every frame's 2 W bins are contiguous in this layout, so a frame never has to meet its
@@ -1280,6 +1442,21 @@ static hipError_t run_stft_fat_carry(const zafx_plan& pl, const float* x, float2
     }
 }
 
+// k_stft_ft16b: W = 4096 in the reference layout, two bands of bins per tile (see the kernel)
+template <bool ALIGNED, int SPEC>
+static hipError_t run_stft_band(const zafx_plan& pl, const float* x, float2* out, int64_t n_clips, int64_t n_samples, int T) {
+    using B = BandCfg;
+    auto kern = k_stft_ft16b<ALIGNED, SPEC>;
+    if (hipError_t e = ensure_dynamic_lds(reinterpret_cast<const void*>(kern), pl.device, B::SMEM); e != hipSuccess) return e;
+    const int tiles = (T + B::FPB - 1) / B::FPB;
+    const long long total = (long long)tiles * n_clips;
+    if (total <= 0) return hipSuccess;
+    const long long grid = std::min<long long>(total, (long long)pl.n_cus);
+    hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(B::NT), B::SMEM, pl.stream, x, pl.d_window, pl.d_tw_sub, pl.d_tw_aux, out,
+                       (long long)n_samples, pl.H, T, (int)row_pitch(pl, T), tiles, (int)total);
+    return hipGetLastError();
+}
+
 constexpr bool stft_use_tf(int log2n, int layout) {
     return layout == ZAFX_LAYOUT_TF && log2n >= 7 && log2n <= 10;   // one wavefront (or half of one) per frame
 }
@@ -1313,6 +1490,19 @@ static hipError_t run_stft(const zafx_plan& pl, const float* x, float2* out, int
         if (pl.d_tw_r32)
             return aligned ? run_stft_fat<LOG2N, true, SPEC>(pl, x, out, n_clips, n_samples, T)
                            : run_stft_fat<LOG2N, false, SPEC>(pl, x, out, n_clips, n_samples, T);
+    }
+#ifndef ZAFX_STFT_BAND
+#define ZAFX_STFT_BAND 1
+#endif
+    if constexpr (ZAFX_STFT_BAND && LOG2N == 11 && LAYOUT == ZAFX_LAYOUT_FT) {
+        // W = 4096, reference layout: 16-frame tiles in two bands of bins (buffer loads: 32-bit byte offsets inside a clip)
+        // Complex rows off the 128-byte grid stay with the one-workgroup-per-tile kernel: the persistent workgroups run in step and
+        // every line is then written in two parts far apart (1024 clips, two-sided, T = 217: 4.33 ms against 3.24; T = 434: 8.25 / 5.20;
+        // a register carry as in k_stft_ft16c would be 128 VGPRs here).  The float32 kinds write half lines either way and gain
+        // everywhere (magnitude, T = 217: 1.33 against 1.67 ms).
+        const bool whole = row_pitch(pl, T) % 16 == 0 && reinterpret_cast<uintptr_t>(out) % 128 == 0;
+        if ((SPEC >= 2 || whole) && pl.d_tw_sub && (long long)n_clips * ((T + 15) / 16) < (1LL << 31) && n_samples < (1LL << 29) && (long long)(T + 16) * pl.H < (1LL << 29) && reinterpret_cast<uintptr_t>(x) % 4 == 0)
+            return aligned ? run_stft_band<true, SPEC>(pl, x, out, n_clips, n_samples, T) : run_stft_band<false, SPEC>(pl, x, out, n_clips, n_samples, T);
     }
     if constexpr (stft_use_fat(LOG2N, LAYOUT)) {
 #ifndef ZAFX_STFT_CARRY
@@ -1431,6 +1621,7 @@ bool stft_supported(int log2n) { return log2n >= 5 && log2n <= 12; }
 int stft_frames_per_block(int log2n, int layout) { return stft_fpb(log2n, layout); }
 const char* stft_kernel_name(int log2n, int layout) {
     if (ZAFX_STFT_FAT8 && log2n == 11 && layout == ZAFX_LAYOUT_FT) return "k_stft_ft16";
+    if (ZAFX_STFT_BAND && log2n == 11 && layout == ZAFX_LAYOUT_FT) return "k_stft_ft16b";
     return stft_use_fat(log2n, layout) ? "k_stft_ft16" : stft_use_tf(log2n, layout) ? "k_stft_tf" : "k_stft";
 }
 const char* istft_kernel_name(int log2n, int layout) { return stft_use_fat(log2n, layout) || stft_use_tf(log2n, layout) ? "k_istft_ft16" : "k_istft"; }

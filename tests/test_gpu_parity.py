@@ -130,6 +130,25 @@ def test_mdct_sizes(zafx, wl, n):
     assert np.max(np.abs(y[:k] - x[0, :k])) < 1e-5
 
 
+@pytest.mark.parametrize("n,clips", [(30000, 3), (4, 1), (2048 * 31, 2), (2048 * 32 + 4, 2), (2048 * 70, 40), (441000, 2), (30002, 2)])
+def test_mdct_w4096_two_bands(zafx, n, clips):
+    """W = 4096 in the reference layout runs k_mdct_ft32b (32-frame tiles as two bands of bins; zaf.py:1047-1073 is what it
+    replaces) for clips of a multiple of four samples, the generic kernel otherwise: ragged and whole last tiles, rows on and off
+    the line grid, more tiles than workgroups, padded rows."""
+    x = np.stack([synth_clip(43, c % 5, n) for c in range(clips)])
+    w = zafx.kaiser_bessel_derived(4096)
+    assert zafx.mdct_plan(w).kernel_name == "k_mdct_ft32b"
+    ref = orc.mdct_batch(x[:5].astype(np.float64), w)
+    got = zafx.mdct_batch(x, w)
+    assert got.shape[1:] == ref.shape[1:] and got.dtype == np.float32
+    for c in range(clips):
+        assert relerr(got[c], ref[c % 5]) <= TOL_FFT, c
+    y = zafx.imdct_batch(got[:1], w)[0]
+    k = min(n, len(y))
+    assert np.max(np.abs(y[:k] - x[0, :k])) < 1e-5
+    _run_padded(zafx, zafx.mdct_plan(w), zafx.mdct_plan(w, row_align=32), None, None, x[:2])
+
+
 def test_imdct_batches_every_clip_and_tile_shape(zafx):
     """The inverse of a BATCH, every clip compared: the output length (T-1) M - 1 is odd, so every second clip starts on a 4-byte
     boundary (the sweep form of the overlap-add stores those as two 4-byte values); lengths that end on a full tile, a partial

@@ -31,7 +31,7 @@ def rate(plan, d_in, d_out, n, reps=20):
 
 def main():
     rng = np.random.default_rng(5)
-    for n in (441000, 441000 + 2048):
+    for n in (441000, 441000 + 2048, 2048 * 223):
         x = rng.standard_normal((8, n)).astype(np.float32)
         d_in = zafx.DeviceBuffer.from_host(np.tile(x, (B // 8, 1)))
         for wl, hop in ((2048, 1024), (4096, 2048), (4096, 1024), (8192, 4096)):

@@ -686,6 +686,17 @@ int zafx_plan_create(zafx_plan** out, int device, int kind, const zafx_params* p
         const auto sub = build_pass_twiddles(10, 4);   // the two 1024-point band transforms of k_stft_ft16b
         e = upload(&pl->d_tw_sub, sub.data(), sub.size() * sizeof(cf32));
     }
+    if (e == hipSuccess && kind == ZAFX_MDCT && pl->log2nf == 10 && pl->prm.precision == ZAFX_PRECISION_F32 && pl->bs_log2m == 0) {
+        // k_mdct_ft32b: pass tables of the two 512-point band transforms; g in band-major order, and g[n] exp(-2 pi i n / 1024)
+        const auto sub = build_pass_twiddles(9, 3);
+        e = upload(&pl->d_tw_sub, sub.data(), sub.size() * sizeof(cf32));
+        const int nf = pl->W / 4;
+        std::vector<cf32> bt((size_t)nf + nf / 2);
+        for (int s = 0; s < 2; ++s)
+            for (int q = 0; q < nf / 2; ++q) bt[(size_t)s * (nf / 2) + q] = unit_root(8LL * (2 * q + s) + 1, 8LL * pl->W);
+        for (int n = 0; n < nf / 2; ++n) bt[(size_t)nf + n] = unit_root(40LL * n + 1, 32LL * nf);
+        if (e == hipSuccess) e = upload(&pl->d_tw_band, bt.data(), bt.size() * sizeof(cf32));
+    }
     if (e == hipSuccess) e = upload(&pl->d_tw_aux, aux.data(), aux.size() * sizeof(cf32));
     if (e == hipSuccess && pl->prm.precision == ZAFX_PRECISION_F32 && pl->bs_log2m > 0) {   // float32 Bluestein plan (zafx_bs32.hip)
         const int M = 1 << pl->bs_log2m, W = pl->W, F = W / 2;
@@ -770,6 +781,7 @@ int zafx_plan_destroy(zafx_plan* pl) {
     if (pl->d_tw_pass) (void)hipFree(pl->d_tw_pass);
     if (pl->d_tw_r32) (void)hipFree(pl->d_tw_r32);
     if (pl->d_tw_sub) (void)hipFree(pl->d_tw_sub);
+    if (pl->d_tw_band) (void)hipFree(pl->d_tw_band);
     if (pl->d_fbw) (void)hipFree(pl->d_fbw);
     if (pl->d_fbw_meta) (void)hipFree(pl->d_fbw_meta);
     if (pl->d_dctw) (void)hipFree(pl->d_dctw);

@@ -453,6 +453,187 @@ __global__ __launch_bounds__(NSLOT * 64) void k_mdct_ft32(
 }
 
 // ---------------------------------------------------------------------------------
+// forward, reference layout, W = 4096: 32-frame tiles over two BANDS of bins (k_mdct_ft32b)
+// ---------------------------------------------------------------------------------
+// Thirty-two packed frames of NF = 1024 points are 256 KB: W = 4096 ran on the one-workgroup-per-tile kernel with 6-frame tiles
+// (24-byte runs, 1.5 TB/s).  As in k_stft_ft16b one decimation-in-frequency step on the way in splits the packed frame c into
+// two 512-point transforms, Y[2q] = FFT_512(c[n] + c[n + 512])[q] and Y[2q + 1] = FFT_512((c[n] - c[n + 512]) w^n)[q],
+// w = exp(-2 pi i / 1024); every bin yields its two coefficients on its own (X[2k] = Re y_k, X[M - 1 - 2k] = -Im y_k), so a band is
+// transformed, post-twiddled and stored without the other: a tile is two rounds of k_mdct_ft32's phases on the same 32 frame
+// buffers, and every stored row is again a 128-byte run of 32 frames.
+//   * c[n] = F[n] g[n] and g[n + 512] = g[n] exp(-i pi / 4), so the two bands of a pair are g[n] (F[n] + k F[n + 512]) and
+//     (g[n] w^n) (F[n] - k F[n + 512]) with the constant k = exp(-i pi / 4): the tables are gb (g in band-major order -- it also
+//     serves the post-twiddle of each band) and bt[n] = g[n] w^n, both in LDS.
+//   * lane p folds the 16-sample groups u = p + 64 r AND 255 - u (r = 0, 1): the group 255 - u holds exactly the partners
+//     c[n + 512] of the group u's c[n] (and vice versa), so both bands of eight points per half frame come out of one lane's
+//     loads; the reversed groups are still coalesced 1-KB rows.
+//   * band 1 waits in registers (16 pairs per lane for the wave's two frames) while band 0 is transformed and stored.
+//   * the sign-folded window (16 KB) does not fit LDS beside the frames and is read from global memory (L2) per half frame.
+struct MdctBandCfg {
+    using C = FftCfg<9, 3>;   // 512-point band transforms: 64 lanes x 8 points, radix 8 x 8 x 8
+    static constexpr int NF = 1024, HB = 512, M = 2048, FPB = kMdctTile, NSLOT = 16, NT = NSLOT * 64;
+    static constexpr size_t SMEM = (size_t)(FPB * C::PITCH + C::TW + NF + HB) * 8;
+};
+static_assert(MdctBandCfg::SMEM <= (size_t)kMaxLdsBytes, "k_mdct_ft32b: tile + tables exceed LDS");
+
+__global__ __launch_bounds__(MdctBandCfg::NT) void k_mdct_ft32b(
+    const float* __restrict__ x, const float4* __restrict__ wfold, const float2* __restrict__ twp, const float2* __restrict__ band_tw,
+    float* __restrict__ out, long long n_samples, int T, int TP, int tiles, int total_tiles) {
+    using G = MdctBandCfg;
+    using C = G::C;
+    constexpr int NF = G::NF, HB = G::HB, M = G::M, P = 64, E = 8, FPB = G::FPB, NSLOT = G::NSLOT, NT = G::NT, FPW = FPB / NSLOT;
+    constexpr int NU = NF / 4;   // 16-sample groups per frame
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    float2* frames = reinterpret_cast<float2*>(smem_raw);
+    float2* tw_l = frames + FPB * C::PITCH;
+    float2* gb_l = tw_l + C::TW;   // gb[s][q] = g[2 q + s]
+    float2* bt_l = gb_l + NF;      // bt[n] = g[n] exp(-2 pi i n / 1024), n < 512
+    const int tid = threadIdx.x;
+    for (int i = tid; i < C::TW; i += NT) tw_l[i] = twp[i];
+    for (int i = tid; i < NF + HB; i += NT) gb_l[i] = band_tw[i];
+    lds_barrier();
+    const int slot = tid / P, p = tid % P;
+    const bool pair_ok = TP % 2 == 0 && reinterpret_cast<uintptr_t>(out) % 8 == 0;
+    const bool lines_whole = TP % 16 == 0 && reinterpret_cast<uintptr_t>(out) % 64 == 0;
+    auto frame_of = [&](int f) { return f * NSLOT + slot; };
+
+    // half frame h = 2 f + r of the tile: the groups u = p + 64 r and NU - 1 - u, eight 16-byte pieces
+    //   q[0..3] = A3, R2, A1, R0 of u (as k_mdct_ft32), q[4..7] = the same of NU - 1 - u
+    float4 q[8];
+    auto fetch = [&](int tl, int h) {
+        if (tl >= total_tiles) return;
+        const int clip = tl / tiles, tile = tl % tiles;
+        const int t = tile * FPB + frame_of(h >> 1);
+        const float* xc = x + (long long)clip * n_samples;
+        // the clip as buffer descriptor: pieces outside it read as zero = the zero padding of zaf.py:1036-1041 (n_samples and every
+        // piece's first sample are multiples of 4; 32-bit offsets wrap, a negative one is a huge unsigned one)
+        const __amdgpu_buffer_rsrc_t rs = make_rsrc(xc, (unsigned)(n_samples * 4));
+        const int u = p + (h & 1) * P;
+        const int s0 = (t - 1) * M * 4;   // byte offset of the frame's first sample (left pad = M)
+        const int fw = s0 + 16 * u, bw = s0 - 16 - 16 * u;
+        q[0] = buf_load_f32x4(rs, fw + 12 * NF);
+        q[1] = buf_load_f32x4(rs, bw + 12 * NF);
+        q[2] = buf_load_f32x4(rs, fw + 4 * NF);
+        q[3] = buf_load_f32x4(rs, bw + 4 * NF);
+        q[4] = buf_load_f32x4(rs, bw + 16 * NF);
+        q[5] = buf_load_f32x4(rs, fw + 8 * NF);
+        q[6] = buf_load_f32x4(rs, bw + 8 * NF);
+        q[7] = buf_load_f32x4(rs, fw);
+    };
+    float2 hold[FPW][8];   // band 1 of the wave's frames: b[n] for n = 2u, 2u+1, 510-2u, 511-2u of both half frames
+    // fold one half frame: band 0 -> the frame buffer (natural order), band 1 -> hold[f][4 r ..]
+    auto fold = [&](float2* buf, int r, float2* hb) {
+        int opaque = 0;   // keeps the per-lane table addresses inside the loop
+        asm volatile("" : "+v"(opaque));
+        const int u = p + r * P + opaque;
+        const int m0 = 2 * u, m1 = 2 * u + 1, m2 = NF - 1 - 2 * u, m3 = NF - 2 - 2 * u;   // group u
+        const int n0 = HB - 2 - 2 * u, n1 = HB - 1 - 2 * u;                                 // group NU-1-u: m0', m1' (its m2' = m1 + HB, m3' = m0 + HB)
+        const float4 A3 = q[0], R2 = q[1], A1 = q[2], R0 = q[3], B3 = q[4], S2 = q[5], B1 = q[6], S0 = q[7];
+        // F[m] of the two groups (k_mdct_ft32's fold), one group after the other: the eight window quadruples of both at once
+        // are 32 registers the kernel does not have (44 bytes of scratch)
+        const float4 w0 = wfold[m0], w1 = wfold[m1], w2 = wfold[m2], w3 = wfold[m3];
+        const float2 F0 = make_float2(R2.w * w0.x + A3.x * w0.y, R0.w * w0.z + A1.x * w0.w);   // F[2u]
+        const float2 F1 = make_float2(R2.y * w1.x + A3.z * w1.y, R0.y * w1.z + A1.z * w1.w);   // F[2u+1]
+        const float2 F2 = make_float2(R0.z * w2.x + A1.y * w2.y, R2.z * w2.z + A3.y * w2.w);   // F[NF-1-2u]
+        const float2 F3 = make_float2(R0.x * w3.x + A1.w * w3.y, R2.x * w3.z + A3.w * w3.w);   // F[NF-2-2u]
+        __builtin_amdgcn_sched_barrier(0);
+        const float4 v0 = wfold[n0], v1 = wfold[n1], v2 = wfold[m1 + HB], v3 = wfold[m0 + HB];
+        const float2 G0 = make_float2(S2.w * v0.x + B3.x * v0.y, S0.w * v0.z + B1.x * v0.w);   // F[510-2u]
+        const float2 G1 = make_float2(S2.y * v1.x + B3.z * v1.y, S0.y * v1.z + B1.z * v1.w);   // F[511-2u]
+        const float2 G2 = make_float2(S0.z * v2.x + B1.y * v2.y, S2.z * v2.z + B3.y * v2.w);   // F[513+2u]
+        const float2 G3 = make_float2(S0.x * v3.x + B1.w * v3.y, S2.x * v3.z + B3.w * v3.w);   // F[512+2u]
+        const float h = 0.70710678118654752440f;
+        auto bands = [&](int n, float2 lo, float2 hi, float2& b) {
+            const float2 d = cmulk(hi, h, -h);   // F[n + 512] exp(-i pi / 4)
+            buf[phys(n)] = cmul(cadd(lo, d), gb_l[(n & 1) * HB + (n >> 1)]);
+            b = cmul(csub(lo, d), bt_l[n]);
+        };
+        bands(m0, F0, G3, hb[0]);
+        bands(m1, F1, G2, hb[1]);
+        bands(n0, G0, F3, hb[2]);
+        bands(n1, G1, F2, hb[3]);
+    };
+    auto store_band = [&](int s, int clip, int t0) {
+        int tido = tid;   // opaque: the store-phase indices are recomputed per tile
+        asm volatile("" : "+v"(tido));
+        const int tp = tido % 16, fq = tido / 16;
+        const int ta = t0 + 2 * tp;
+        if (ta >= T) return;
+        // thread: frame pair (2 tp, 2 tp + 1), parity e of its rows (0: X[2k] = Re y_k, 1: X[M - 1 - 2k] = -Im y_k; the frame holds
+        // conj(y)), bins q = qi + 32 i of the band, k = 2 q + s
+        const int e = fq & 1, qi = fq >> 1;
+        const float* pa = reinterpret_cast<const float*>(frames + (2 * tp) * C::PITCH + phys(qi)) + e;
+        const float* pb = pa + 2 * C::PITCH;
+        constexpr int DPH = 2 * (32 + 32 / 16);   // floats per step of 32 bins (padded slots)
+        const int f0 = e ? M - 1 - 4 * qi - 2 * s : 4 * qi + 2 * s;
+        float* d = out + (long long)clip * M * TP + ta + (long long)f0 * TP;
+        const long long dstep = (long long)(e ? -128 : 128) * TP;
+        const bool two = ta + 1 < T;
+#pragma unroll 4
+        for (int i = 0; i < HB / 32; ++i) {
+            const float va = pa[i * DPH], vb = pb[i * DPH];
+            if (pair_ok && two) {
+                if (lines_whole) store_stream(reinterpret_cast<float2*>(d), make_float2(va, vb));
+                else *reinterpret_cast<float2*>(d) = make_float2(va, vb);
+            } else {
+                d[0] = va;
+                if (two) d[1] = vb;
+            }
+            d += dstep;
+        }
+    };
+
+    int tl = blockIdx.x;
+    fetch(tl, 0);
+    for (; tl < total_tiles; tl += gridDim.x) {
+        const int clip = tl / tiles, tile = tl % tiles;
+        const int t0 = tile * FPB;
+        const int tl_next = tl + gridDim.x;
+        int po = p;   // opaque copy: the pass-twiddle reads stay in the loop
+        asm volatile("" : "+v"(po));
+#pragma unroll
+        for (int f = 0; f < FPW; ++f) {
+            float2* buf = frames + frame_of(f) * C::PITCH;
+#pragma unroll
+            for (int r = 0; r < 2; ++r) {
+                fold(buf, r, &hold[f][4 * r]);
+                const int h = 2 * f + r + 1;
+                if (h < 2 * FPW) fetch(tl, h);
+                else fetch(tl_next, 0);
+            }
+            frame_sync<P>();
+            float2 v[E];
+            regs_read<9, 3>(v, buf, po);
+            frame_sync<P>();
+            fft_frame_post<9, 3>(v, buf, po, tw_l, gb_l);   // the frame now holds conj(y[2q]), y[k] = Y[k] g[k]
+        }
+        lds_barrier();
+        store_band(0, clip, t0);
+        lds_barrier();
+#pragma unroll
+        for (int f = 0; f < FPW; ++f) {
+            float2* buf = frames + frame_of(f) * C::PITCH;
+#pragma unroll
+            for (int r = 0; r < 2; ++r) {
+                const int u = po + r * P;
+                buf[phys(2 * u)] = hold[f][4 * r];
+                buf[phys(2 * u + 1)] = hold[f][4 * r + 1];
+                buf[phys(HB - 2 - 2 * u)] = hold[f][4 * r + 2];
+                buf[phys(HB - 1 - 2 * u)] = hold[f][4 * r + 3];
+            }
+            frame_sync<P>();
+            float2 v[E];
+            regs_read<9, 3>(v, buf, po);
+            frame_sync<P>();
+            fft_frame_post<9, 3>(v, buf, po, tw_l, gb_l + HB);   // conj(y[2q + 1])
+        }
+        lds_barrier();
+        store_band(1, clip, t0);
+        lds_barrier();
+    }
+}
+
+// ---------------------------------------------------------------------------------
 // inverse
 // ---------------------------------------------------------------------------------
 // Persistent carry form (as k_istft_ft16): one workgroup per CU walks the FPB-frame tiles of a clip
@@ -896,8 +1077,30 @@ static hipError_t run_mdct_p(const zafx_plan& pl, const float* x, float* out, in
     return hipGetLastError();
 }
 
+#ifndef ZAFX_MDCT_BAND
+#define ZAFX_MDCT_BAND 1
+#endif
+static hipError_t run_mdct_band(const zafx_plan& pl, const float* x, float* out, int64_t n_clips, int64_t n_samples, int T) {
+    using G = MdctBandCfg;
+    auto kern = k_mdct_ft32b;
+    if (hipError_t e = ensure_dynamic_lds(reinterpret_cast<const void*>(kern), pl.device, G::SMEM); e != hipSuccess) return e;
+    const int tiles = (T + G::FPB - 1) / G::FPB;
+    const long long total = (long long)tiles * n_clips;
+    if (total <= 0) return hipSuccess;
+    const long long grid = std::min<long long>(total, (long long)pl.n_cus);
+    hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(G::NT), G::SMEM, pl.stream, x, pl.d_wfold, pl.d_tw_sub, pl.d_tw_band, out, (long long)n_samples, T,
+                       (int)row_pitch(pl, T), tiles, (int)total);
+    return hipGetLastError();
+}
+
 template <int LOG2NF, int LAYOUT>
 static hipError_t run_mdct(const zafx_plan& pl, const float* x, float* out, int64_t n_clips, int64_t n_samples, int T) {
+    if constexpr (ZAFX_MDCT_BAND && LOG2NF == 10 && LAYOUT == ZAFX_LAYOUT_FT) {
+        // W = 4096, reference layout: 32-frame tiles in two bands of bins (16-byte buffer loads: clips of a multiple of four samples)
+        if (pl.d_tw_sub && pl.d_tw_band && n_samples % 4 == 0 && reinterpret_cast<uintptr_t>(x) % 16 == 0 && n_samples < (1LL << 28) &&
+            (long long)n_clips * ((T + 31) / 32) < (1LL << 31))
+            return run_mdct_band(pl, x, out, n_clips, n_samples, T);
+    }
     if constexpr (mdct_use_persistent(LOG2NF, LAYOUT)) {
         return run_mdct_p<LOG2NF, LAYOUT == ZAFX_LAYOUT_TF>(pl, x, out, n_clips, n_samples, T);
     } else {
@@ -961,7 +1164,10 @@ static hipError_t run_imdct(const zafx_plan& pl, const float* coefs, float* y, i
 
 bool mdct_supported(int log2nf) { return log2nf >= 4 && log2nf <= 11; }
 int mdct_frames_per_block(int log2nf, int layout) { return mdct_fpb(log2nf, layout); }
-const char* mdct_kernel_name(int log2nf, int layout) { return mdct_use_persistent(log2nf, layout) ? "k_mdct_ft32" : "k_mdct"; }
+const char* mdct_kernel_name(int log2nf, int layout) {
+    if (ZAFX_MDCT_BAND && log2nf == 10 && layout == ZAFX_LAYOUT_FT) return "k_mdct_ft32b";
+    return mdct_use_persistent(log2nf, layout) ? "k_mdct_ft32" : "k_mdct";
+}
 const char* imdct_kernel_name() { return "k_imdct"; }
 
 hipError_t launch_mdct(const zafx_plan& pl, const float* x, float* out, int64_t n_clips, int64_t n_samples, int T) {

@@ -49,7 +49,7 @@ HBM_ACHIEVABLE_GBS = 6290.0   # same guide: measured-achievable copy rate
 F32_PEAK_TFLOPS = 157.3    # dense f32 vector / f32-input MFMA peak
 PLACEMENT_SURVEY = 6       # further allocations of the headline's row-strided output probed AFTER every timed region (reported, never timed)
 CONFIG_KINDS = ("istft", "mel", "mfcc", "mdct", "imdct", "cqt")   # SURVEY 8(a) a2 + BASELINE configs 3, 4, 5 (config 2 = the headline)
-EXTRA_KINDS = ("stft1", "istft1", "stft_offgrid", "mdct_offgrid", "stft4096")   # one-sided pair (8f rank 4) and geometries off the benchmark's grid
+EXTRA_KINDS = ("stft1", "istft1", "stft_offgrid", "mdct_offgrid", "stft4096", "stft4096_h1024", "mdct4096", "mel4096")   # one-sided pair (8f rank 4) and geometries off the benchmark's grid
 
 
 def synth(seed, c, n):
@@ -87,6 +87,8 @@ def make_workload(kind, device, layout="FT"):
         T = 217
     if kind == "mdct_offgrid":
         N, T = 442024, 433       # ceil(N / 1024) + 1 (zaf.py:1033): float32 rows of 1732 B
+    if kind in ("mdct4096", "mel4096"):
+        T = 217                   # mdct: ceil(N / 2048) + 1 (odd: rows off the line grid); mel: hop 2048
     base = np.stack([synth(0, c, N) for c in range(distinct)])
     d_base = zafx.DeviceBuffer.from_host(base, device)
     d_x = zafx.DeviceBuffer((B, N), np.float32, device)
@@ -106,6 +108,18 @@ def make_workload(kind, device, layout="FT"):
         plan = zafx.stft_plan(zafx.hamming(4096), 2048, layout=layout, device=device)
         wl.update(plan=plan, d_in=d_x, n_in=N, bytes_per_launch=B * (4 * N + 8 * 4096 * T),
                   desc="Batched STFT, win=4096 hop=2048: 1024 clips x 10 s, T = 217, two-sided c64 (W,T) layout")
+    elif kind == "stft4096_h1024":   # W = 4096 on the line grid (T = 432): k_stft_ft16b, two bands of bins per 16-frame tile
+        plan = zafx.stft_plan(zafx.hamming(4096), 1024, layout=layout, device=device)
+        wl.update(plan=plan, d_in=d_x, n_in=N, bytes_per_launch=B * (4 * N + 8 * 4096 * T),
+                  desc="Batched STFT, win=4096 hop=1024: 1024 clips x 10 s, T = 432, two-sided c64 (W,T) layout")
+    elif kind == "mdct4096":         # k_mdct_ft32b (32-frame tiles, two bands of bins); T = 217 is odd: rows off the line grid
+        plan = zafx.mdct_plan(zafx.kaiser_bessel_derived(4096), device=device)
+        wl.update(plan=plan, d_in=d_x, n_in=N, bytes_per_launch=B * (4 * N + 4 * 2048 * T),
+                  desc="Batched MDCT, KBD win=4096: 1024 clips x 10 s, T = 217, compact (W/2,T) layout")
+    elif kind == "mel4096":          # spectrum kernel (k_stft_ft16b, |X| rows into a plan-owned scratch) + k_melfb
+        plan = zafx.mel_plan(zafx.hamming(4096), 2048, zafx.melfilterbank(FS, 4096, 128), device=device)
+        wl.update(plan=plan, d_in=d_x, n_in=N, bytes_per_launch=B * (4 * N + 4 * 128 * T),
+                  desc="melspectrogram, win=4096 hop=2048, 128 filters: 1024 clips x 10 s (spectrum kernel + filterbank kernel, float32)")
     elif kind == "stft64":  # float64 device arithmetic (written for exactness, not speed)
         d_x64 = zafx.DeviceBuffer.from_host(np.tile(base.astype(np.float64), (B // distinct, 1)), device)
         d_x.free()
@@ -363,6 +377,12 @@ def parity_probe(wl):
         ref = ref[:W // 2 + 1] if kind == "stft1" else ref
     elif kind == "stft4096":
         ref = orc.stft(x64, orc.hamming_periodic(4096), 2048)
+    elif kind == "stft4096_h1024":
+        ref = orc.stft(x64, orc.hamming_periodic(4096), 1024)
+    elif kind == "mdct4096":
+        ref = orc.mdct(x64, orc.kbd_window(4096))
+    elif kind == "mel4096":
+        ref = orc.melspectrogram(x64, orc.hamming_periodic(4096), 2048, orc.melfilterbank(FS, 4096, 128))
     elif kind in ("istft", "istft1"):
         ref = None   # (checked as a round trip below: the device spectrum is the input)
     elif kind in ("mdct", "mdct_offgrid"):
@@ -390,7 +410,7 @@ def parity_probe(wl):
         return out
     got = first if first.shape == ref.shape else first.T
     d = float(np.max(np.abs(got - ref)))
-    tol = 1e-4 if kind in ("mel", "mfcc", "cqt") else 1e-5
+    tol = 1e-4 if kind in ("mel", "mfcc", "cqt", "mel4096") else 1e-5
     rel = d / float(np.max(np.abs(ref)))
     out.update({"max_abs_err_vs_numpy": d, "max_rel_err_vs_numpy": rel, "tolerance": tol, "within_tolerance": bool(rel <= tol)})
     return out

@@ -642,7 +642,9 @@ __global__ __launch_bounds__(MdctBandCfg::NT) void k_mdct_ft32b(
 // 128-B runs and no frame is read twice (the halo form re-read one frame in 32 and straddled two
 // lines per run).  A segment that does not start a clip first runs the tile before it in carry-only
 // mode (its last frame alone).  Barriers order LDS only; the output stores are not waited for.
-template <int LOG2NF, int LOG2E, int FPB, int NSLOT, int LAYOUT>
+// WINL: the window (4 NF floats) is staged in LDS; false (W = 4096): it is read from global memory -- the sweep form of the
+// overlap-add reads a thread's two window pairs once per tile -- which makes room for 16-frame tiles (64-byte gather runs) instead of 8.
+template <int LOG2NF, int LOG2E, int FPB, int NSLOT, int LAYOUT, bool WINL = true>
 __global__ __launch_bounds__(NSLOT * fft_threads(LOG2NF, LOG2E)) void k_imdct(
     const float* __restrict__ coefs, const float* __restrict__ win, const float2* __restrict__ twp,
     const float2* __restrict__ tw8g, float* __restrict__ y, int T, int TP, long long out_len, int tiles, int segs, int seg_tiles,
@@ -654,12 +656,15 @@ __global__ __launch_bounds__(NSLOT * fft_threads(LOG2NF, LOG2E)) void k_imdct(
     float2* frames = reinterpret_cast<float2*>(smem_raw);
     float2* tw_l = frames + FPB * C::PITCH;
     float2* tw8 = tw_l + C::TW;                         // g_m, NF entries
-    float* win_l = reinterpret_cast<float*>(tw8 + NF);  // window, 4 NF floats
-    float* carry = win_l + 4 * NF;                      // M floats
+    float* win_s = reinterpret_cast<float*>(tw8 + NF);  // window, 4 NF floats (WINL)
+    float* carry = win_s + (WINL ? 4 * NF : 0);         // M floats
+    const float* win_l = win;
+    if constexpr (WINL) win_l = win_s;
     const int tid = threadIdx.x;
     for (int i = tid; i < C::TW; i += NT) tw_l[i] = twp[i];
     for (int i = tid; i < NF; i += NT) tw8[i] = tw8g[i];
-    for (int i = tid; i < 4 * NF; i += NT) win_l[i] = win[i];
+    if constexpr (WINL)
+        for (int i = tid; i < 4 * NF; i += NT) win_s[i] = win[i];
     lds_barrier();
     const float gain = 2.f / (float)M;
     const bool vec4 = LAYOUT == ZAFX_LAYOUT_FT && FPB % 4 == 0 && NT % (FPB / 4) == 0 && NF >= NT / (FPB / 4) && TP % 4 == 0 &&
@@ -1120,13 +1125,22 @@ static hipError_t run_mdct(const zafx_plan& pl, const float* x, float* out, int6
 
 // IMDCT tile geometry: FPB frames resident, NSLOT of them transformed at a time.
 // The time-minor layout wants FPB = 32 (32 frames x 4 B = one 128-B line per gathered row).
-constexpr int imdct_fpb(int log2nf, int layout) {
+#ifndef ZAFX_IMDCT_WIN_GLOBAL
+#define ZAFX_IMDCT_WIN_GLOBAL 1
+#endif
+// tables beside the frames: pass twiddles, g_m (8 NF), carry (8 NF) and -- unless it is read from global memory -- the window (16 NF)
+constexpr int imdct_fpb_with(int log2nf, bool win_lds) {
     const int pitch = (1 << log2nf) + ((1 << log2nf) >> 4) + 1;
-    const int lds_cap = (kMaxLdsBytes - twiddle_total(log2nf, default_log2e(log2nf)) * 8 - (32 << log2nf)) / (pitch * 8);
+    const int lds_cap = (kMaxLdsBytes - twiddle_total(log2nf, default_log2e(log2nf)) * 8 - ((win_lds ? 32 : 16) << log2nf)) / (pitch * 8);
     int f = 32;   // (both layouts: the carry form walks 32-frame tiles; the time-minor layout also NEEDS 32 for whole-line rows)
-    (void)layout;
     while (f > lds_cap) f /= 2;
     return f < 2 ? 2 : f;
+}
+// the window leaves LDS where that doubles the tile (W = 4096: 16 frames instead of 8; 1024 clips x 10 s: 2.43 -> 1.50 ms at T = 217, 1.72 -> 1.16 ms at T = 224)
+constexpr bool imdct_win_lds(int log2nf) { return !(ZAFX_IMDCT_WIN_GLOBAL && imdct_fpb_with(log2nf, false) > imdct_fpb_with(log2nf, true)); }
+constexpr int imdct_fpb(int log2nf, int layout) {
+    (void)layout;
+    return imdct_fpb_with(log2nf, imdct_win_lds(log2nf));
 }
 constexpr int imdct_nslot(int log2nf, int fpb) {
     const int p = (1 << log2nf) >> default_log2e(log2nf);
@@ -1143,9 +1157,10 @@ static hipError_t run_imdct(const zafx_plan& pl, const float* coefs, float* y, i
     constexpr int FPB = imdct_fpb(LOG2NF, LAYOUT);
     constexpr int NSLOT = imdct_nslot(LOG2NF, FPB);
     using C = FftCfg<LOG2NF, LOG2E>;
-    constexpr size_t SMEM = (size_t)(FPB * C::PITCH + C::TW + C::N) * 8 + (size_t)C::N * 16 + (size_t)C::N * 8;   // frames + twiddles + g_m + window + carry
+    constexpr bool WINL = imdct_win_lds(LOG2NF);
+    constexpr size_t SMEM = (size_t)(FPB * C::PITCH + C::TW + C::N) * 8 + (WINL ? (size_t)C::N * 16 : 0) + (size_t)C::N * 8;   // frames + twiddles + g_m + window + carry
     static_assert(SMEM <= (size_t)kMaxLdsBytes, "IMDCT tile does not fit LDS");
-    auto kern = k_imdct<LOG2NF, LOG2E, FPB, NSLOT, LAYOUT>;
+    auto kern = k_imdct<LOG2NF, LOG2E, FPB, NSLOT, LAYOUT, WINL>;
     if (hipError_t e = ensure_dynamic_lds(reinterpret_cast<const void*>(kern), pl.device, SMEM); e != hipSuccess) return e;
     const int tiles = (T + FPB - 1) / FPB;
     if ((long long)tiles * n_clips <= 0 || out_len <= 0) return hipSuccess;

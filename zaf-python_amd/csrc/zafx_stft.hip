@@ -694,6 +694,181 @@ __global__ __launch_bounds__(kFatWaves * 64) void k_stft_ft16b(
 }
 
 // ---------------------------------------------------------------------------------
+// forward, reference layout, W = 4096, complex rows that are NOT whole 128-byte lines: one band per workgroup + register carry (k_stft_ft16bc)
+// ---------------------------------------------------------------------------------
+// k_stft_ft16b writes a line of such a row in two parts far apart (T = 217: 4.33 ms against 3.24 on the generic kernel), and the carry
+// that cures it in k_stft_ft16c -- every thread's X[k], X[M - k] of the previous tile -- would be 128 VGPRs for both bands.  The two bands
+// never meet (k_stft_ft16b), so here a workgroup owns ONE band of a clip segment: it walks the segment's tiles in order, forms only its
+// band from the samples (the other band's workgroup reads the same samples at about the same time on the same XCD: units (segment, band 0)
+// and (segment, band 1) are neighbours in the XCD order), and carries its own 1024 rows of the previous tile in 64 VGPRs exactly as
+// k_stft_ft16c does: lanes tt < 16 - a store the current value at frame t0 + tt, lanes tt >= 16 - a the carried one at t0 - 16 + tt --
+// sixteen lanes, one whole line, streamed.  The raw samples of a frame are 64 VGPRs per lane, so they are requested one FRAME ahead
+// (frame 1 of the tile under the transform of frame 0, frame 0 of the next tile under the transform of frame 1 and the stores), not one
+// tile ahead.
+template <bool ALIGNED, int SPEC>
+__global__ __launch_bounds__(kFatWaves * 64) void k_stft_ft16bc(
+    const float* __restrict__ x, const float* __restrict__ win, const float2* __restrict__ twp,
+    const float2* __restrict__ tws, float2* __restrict__ out, long long n_samples, int hop, int T, int TP, int tiles,
+    int segs, int seg_tiles, int units) {
+    static_assert(SPEC < 2, "complex spectra only");
+    using B = BandCfg;
+    using C = B::C;
+    constexpr int N = B::N, M = B::M, W = B::W, P = 64, E = 16, NT = B::NT, FPB = B::FPB, FPW = B::FPW, PITCH = B::PITCH;
+    constexpr int ROWS = SPEC ? M + 1 : W;
+    constexpr int ITER = (N / 2) / (NT / FPB);
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    float2* frames = reinterpret_cast<float2*>(smem_raw);
+    float2* tw_l = frames + FPB * PITCH;
+    float2* tws_l = tw_l + C::TW;
+    const int tid = threadIdx.x;
+    for (int i = tid; i < C::TW; i += NT) tw_l[i] = twp[i];
+    for (int i = tid; i <= M / 2; i += NT) tws_l[i] = tws[i];
+    __syncthreads();
+    const int wave = tid / P, p_lane = tid % P;
+    const int tt = tid % FPB, kq = tid / FPB;
+    const float2* fb = frames + tt * PITCH;
+    const bool xcd = ZAFX_XCD_ORDER && gridDim.x % 8 == 0;
+    const int b0 = (int)((reinterpret_cast<uintptr_t>(out) >> 3) & 15);   // phase of the array's first element in its line
+    const float2 wp = tws_l[2 * p_lane];   // exp(-2 pi i lane / M)
+
+    // raw samples z[lane + 64 j], j < 32, of frame `fr` of tile `tile` of `clip` -> dst
+    auto request = [&](float2 (&dst)[2 * E], int clip, int tile, int fr) {
+        const float* xc = x + (long long)clip * n_samples;
+        const __amdgpu_buffer_rsrc_t rs = make_rsrc(xc, (unsigned)(n_samples * 4));   // (outside the clip: zero = the reference's padding)
+        const int s0 = (tile * FPB + fr) * hop - M;
+        const int vo = (s0 + 2 * p_lane) * 4;
+        int vo1 = vo + 4;
+        if constexpr (!ALIGNED) asm volatile("" : "+v"(vo1));   // (see k_stft_ft16b: the two 4-byte loads of a pair must not be merged)
+#pragma unroll
+        for (int j = 0; j < 2 * E; ++j) {
+            if constexpr (ALIGNED) {
+                dst[j] = buf_load_f32x2(rs, vo + j * P * 8);
+            } else {
+                dst[j].x = buf_load_f32(rs, vo + j * P * 8);
+                dst[j].y = buf_load_f32(rs, vo1 + j * P * 8);
+            }
+        }
+    };
+    // unit v of this workgroup's walk -> clip, band and tile range [j, j1) of its segment
+    auto unit_of = [&](int v, int& clip, int& band, int& j, int& j1) {
+        const int u = xcd ? xcd_order(v, units) : v;
+        band = u & 1;
+        const int sg = u >> 1;
+        clip = sg / segs;
+        j = (sg % segs) * seg_tiles;
+        j1 = min(j + seg_tiles, tiles);
+    };
+    int v = blockIdx.x;
+    if (v >= units) return;
+    int clip, band, j, j1;
+    unit_of(v, clip, band, j, j1);
+    float2 xa[2 * E], xb[2 * E];
+    request(xa, clip, j, wave * FPW);
+    float2 ck[ITER], cn[ITER];   // the thread's X[k], X[M - k] of the previous tile (k = 2 (kq + 32 it) + band)
+#pragma unroll
+    for (int it = 0; it < ITER; ++it) ck[it] = cn[it] = make_float2(0.f, 0.f);
+    bool have_prev = false;
+    for (;;) {
+        int po = p_lane;
+        asm volatile("" : "+v"(po));
+        // the walk's next tile
+        int nclip = clip, nband = band, nj = j + 1, nj1 = j1, nv = v;
+        bool more = true;
+        if (nj >= j1) {
+            nv = v + gridDim.x;
+            if (nv < units) unit_of(nv, nclip, nband, nj, nj1);
+            else more = false;
+        }
+        // this band of one frame, in place: src[i] <- a + b (band 0) or (a - b) exp(-2 pi i (lane + 64 i) / M) (band 1)
+        auto form = [&](float2 (&src)[2 * E]) {
+            const float2* w2 = reinterpret_cast<const float2*>(win) + po;
+            const float c32[16] = {1.f, 0.98078528040323044913f, 0.92387953251128675613f, 0.83146961230254523708f, 0.70710678118654752440f,
+                                   0.55557023301960222474f, 0.38268343236508977173f, 0.19509032201612826785f, 0.f,
+                                   -0.19509032201612826785f, -0.38268343236508977173f, -0.55557023301960222474f, -0.70710678118654752440f,
+                                   -0.83146961230254523708f, -0.92387953251128675613f, -0.98078528040323044913f};
+            const float s32[16] = {0.f, 0.19509032201612826785f, 0.38268343236508977173f, 0.55557023301960222474f, 0.70710678118654752440f,
+                                   0.83146961230254523708f, 0.92387953251128675613f, 0.98078528040323044913f, 1.f,
+                                   0.98078528040323044913f, 0.92387953251128675613f, 0.83146961230254523708f, 0.70710678118654752440f,
+                                   0.55557023301960222474f, 0.38268343236508977173f, 0.19509032201612826785f};
+#pragma unroll
+            for (int i = 0; i < E; ++i) {
+                const float2 wa = w2[i * P], wb = w2[(i + E) * P];
+                const float2 a = make_float2(src[i].x * wa.x, src[i].y * wa.y);
+                const float2 b = make_float2(src[i + E].x * wb.x, src[i + E].y * wb.y);
+                if (band == 0) {   // (uniform)
+                    src[i] = cadd(a, b);
+                } else {
+                    const float2 d = csub(a, b);
+                    src[i] = cmul(i == 0 ? d : (i == 8 ? mul_mi(d) : cmulk(d, c32[i], -s32[i])), wp);
+                }
+            }
+        };
+        form(xa);
+        // frame 1 of this tile, under the transform of frame 0 (requested AHEAD of form(xa) its 32 loads sit in front of frame 0's window
+        // loads in the in-order return queue: 2.50 against 2.37 ms)
+        request(xb, clip, j, wave * FPW + 1);
+        fft_frame<10, 4>(&xa[0], frames + (wave * FPW) * PITCH, po, tw_l);
+        __builtin_amdgcn_sched_barrier(0);
+        form(xb);
+        if (more) request(xa, nclip, nj, wave * FPW);             // frame 0 of the next tile, under the transform of frame 1 and the stores
+        fft_frame<10, 4>(&xb[0], frames + (wave * FPW + 1) * PITCH, po, tw_l);
+        lds_barrier();
+        {
+            const int t0 = j * FPB;
+            const bool last = j + 1 >= j1, cur_ok = t0 + tt < T;
+            float2* o = out + (long long)clip * ROWS * TP + (t0 + tt);
+            const int c0 = (int)(((long long)clip * ROWS) & 15), tp = TP & 15;
+            int kqo = kq;
+            asm volatile("" : "+v"(kqo));
+            auto sweep = [&](auto stream) {
+                constexpr bool ST = decltype(stream)::value;
+                auto emit = [&](int r, float2 cur, float2 prev) {   // one row: `cur` = this tile's value of the thread's frame, `prev` = the carried one
+                    const int a = (b0 + (c0 + r) * tp) & 15;        // the row's run starts a frames into a line
+                    const bool from_prev = tt >= 16 - a;            // (a = 0: never -- the run is a whole line)
+                    const float2 val = from_prev ? prev : cur;
+                    float2* dst = o + (long long)r * TP;
+                    if (from_prev ? have_prev : cur_ok) {
+                        if constexpr (ST) store_stream(dst + (from_prev ? -16 : 0), val);
+                        else dst[from_prev ? -16 : 0] = val;
+                    }
+                    if (last && from_prev && cur_ok) *dst = cur;    // tail of the segment's last run (a partial line)
+                };
+#pragma unroll
+                for (int it = 0; it < ITER; ++it) {
+                    const int q = kqo + it * (NT / FPB);
+                    float2 xk, xn;
+                    if (it == 0 && q == 0 && band == 0) {
+                        const float2 z0 = fb[0], zc = fb[phys_t<C::PS>(N / 2)];   // Z[0], Z[M / 2]
+                        xk = cconj(zc);                                 // row M/2 (its mirror, row 3M/2: zc)
+                        xn = make_float2(z0.x + z0.y, z0.x - z0.y);     // rows 0 and M: both real, carried as one pair
+                        emit(M / 2, xk, ck[0]);
+                        if (SPEC == 0) emit(M + M / 2, cconj(xk), cconj(ck[0]));
+                        emit(0, make_float2(xn.x, 0.f), make_float2(cn[0].x, 0.f));
+                        emit(M, make_float2(xn.y, 0.f), make_float2(cn[0].y, 0.f));
+                    } else {
+                        const int k = 2 * q + band;
+                        split_pair(fb[phys_t<C::PS>(q)], fb[phys_t<C::PS>(N - band - q)], tws_l[k], xk, xn);
+                        emit(k, xk, ck[it]);
+                        if (SPEC == 0) emit(W - k, cconj(xk), cconj(ck[it]));
+                        emit(M - k, xn, cn[it]);
+                        if (SPEC == 0) emit(M + k, cconj(xn), cconj(cn[it]));
+                    }
+                    ck[it] = xk;
+                    cn[it] = xn;
+                    __builtin_amdgcn_sched_barrier(0);   // (iterations stay apart: their LDS reads hoisted ahead cost the registers the carry needs)
+                }
+            };
+            if (have_prev) sweep(std::true_type{});
+            else sweep(std::false_type{});
+        }
+        lds_barrier();
+        if (!more) break;
+        have_prev = nj != 0 && nv == v;   // the walk continues inside the same segment (and band)
+        clip = nclip, band = nband, j = nj, j1 = nj1, v = nv;
+    }
+}
+
+// ---------------------------------------------------------------------------------
 // forward, frame-major layout (ZAFX_LAYOUT_TF), persistent and barrier free
 // ---------------------------------------------------------------------------------
 // Every frame's 2 W bins are contiguous in this layout, so a frame never has to meet its
@@ -1457,6 +1632,28 @@ static hipError_t run_stft_band(const zafx_plan& pl, const float* x, float2* out
     return hipGetLastError();
 }
 
+// k_stft_ft16bc: W = 4096, complex rows off the 128-byte grid (one band per workgroup, register carry)
+template <bool ALIGNED, int SPEC>
+static hipError_t run_stft_band_carry(const zafx_plan& pl, const float* x, float2* out, int64_t n_clips, int64_t n_samples, int T) {
+    if constexpr (SPEC < 2) {
+        using B = BandCfg;
+        auto kern = k_stft_ft16bc<ALIGNED, SPEC>;
+        if (hipError_t e = ensure_dynamic_lds(reinterpret_cast<const void*>(kern), pl.device, B::SMEM); e != hipSuccess) return e;
+        const int tiles = (T + B::FPB - 1) / B::FPB;
+        if ((long long)tiles * n_clips <= 0) return hipSuccess;
+        const long long max_grid = pl.n_cus;
+        const int segs = carry_segments(2 * n_clips, tiles, max_grid);   // (two units -- one per band -- for every segment)
+        const int seg_tiles = (tiles + segs - 1) / segs;
+        const long long units = 2LL * n_clips * segs;
+        const long long grid = std::min<long long>(units, max_grid);
+        hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(B::NT), B::SMEM, pl.stream, x, pl.d_window, pl.d_tw_sub, pl.d_tw_aux, out,
+                           (long long)n_samples, pl.H, T, (int)row_pitch(pl, T), tiles, segs, seg_tiles, (int)units);
+        return hipGetLastError();
+    } else {
+        return hipErrorInvalidValue;
+    }
+}
+
 constexpr bool stft_use_tf(int log2n, int layout) {
     return layout == ZAFX_LAYOUT_TF && log2n >= 7 && log2n <= 10;   // one wavefront (or half of one) per frame
 }
@@ -1496,11 +1693,20 @@ static hipError_t run_stft(const zafx_plan& pl, const float* x, float2* out, int
 #endif
     if constexpr (ZAFX_STFT_BAND && LOG2N == 11 && LAYOUT == ZAFX_LAYOUT_FT) {
         // W = 4096, reference layout: 16-frame tiles in two bands of bins (buffer loads: 32-bit byte offsets inside a clip)
-        // Complex rows off the 128-byte grid stay with the one-workgroup-per-tile kernel: the persistent workgroups run in step and
-        // every line is then written in two parts far apart (1024 clips, two-sided, T = 217: 4.33 ms against 3.24; T = 434: 8.25 / 5.20;
-        // a register carry as in k_stft_ft16c would be 128 VGPRs here).  The float32 kinds write half lines either way and gain
-        // everywhere (magnitude, T = 217: 1.33 against 1.67 ms).
+        // Complex rows off the 128-byte grid: k_stft_ft16b writes every line in two parts far apart (1024 clips, two-sided, T = 217: 4.33 ms
+        // against 3.24 on the one-workgroup-per-tile kernel); the carry form k_stft_ft16bc (one band per workgroup) completes the lines:
+        // T = 217: 2.33 ms, T = 434 (hop 1024): 4.44 against 5.20.  One-sided output has half the stores to gain from and the form reads
+        // every sample twice: it wins at hop >= W / 2 only (T = 217: 1.89 against 1.96; hop 1024: 3.72 against 3.36 -> generic kernel).
+        // The float32 kinds write half lines either way and gain from k_stft_ft16b at every T (magnitude, T = 217: 1.33 against 1.67 ms).
         const bool whole = row_pitch(pl, T) % 16 == 0 && reinterpret_cast<uintptr_t>(out) % 128 == 0;
+#ifndef ZAFX_STFT_BAND_CARRY
+#define ZAFX_STFT_BAND_CARRY 1
+#endif
+        const bool fits = pl.d_tw_sub && (long long)n_clips * ((T + 15) / 16) < (1LL << 30) && n_samples < (1LL << 29) && (long long)(T + 16) * pl.H < (1LL << 29) && reinterpret_cast<uintptr_t>(x) % 4 == 0;
+        if constexpr (SPEC < 2 && ZAFX_STFT_BAND_CARRY) {
+            if (!whole && fits && (SPEC == 0 || 2 * pl.H >= pl.W) && reinterpret_cast<uintptr_t>(out) % 8 == 0 && n_clips * (long long)T < (1LL << 31))
+                return aligned ? run_stft_band_carry<true, SPEC>(pl, x, out, n_clips, n_samples, T) : run_stft_band_carry<false, SPEC>(pl, x, out, n_clips, n_samples, T);
+        }
         if ((SPEC >= 2 || whole) && pl.d_tw_sub && (long long)n_clips * ((T + 15) / 16) < (1LL << 31) && n_samples < (1LL << 29) && (long long)(T + 16) * pl.H < (1LL << 29) && reinterpret_cast<uintptr_t>(x) % 4 == 0)
             return aligned ? run_stft_band<true, SPEC>(pl, x, out, n_clips, n_samples, T) : run_stft_band<false, SPEC>(pl, x, out, n_clips, n_samples, T);
     }

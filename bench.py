@@ -49,7 +49,7 @@ HBM_ACHIEVABLE_GBS = 6290.0   # same guide: measured-achievable copy rate
 F32_PEAK_TFLOPS = 157.3    # dense f32 vector / f32-input MFMA peak
 PLACEMENT_SURVEY = 6       # further allocations of the headline's row-strided output probed AFTER every timed region (reported, never timed)
 CONFIG_KINDS = ("istft", "mel", "mfcc", "mdct", "imdct", "cqt")   # SURVEY 8(a) a2 + BASELINE configs 3, 4, 5 (config 2 = the headline)
-EXTRA_KINDS = ("stft1", "istft1", "stft_offgrid", "mdct_offgrid", "stft4096", "stft4096_h1024", "mdct4096", "mel4096")   # one-sided pair (8f rank 4) and geometries off the benchmark's grid
+EXTRA_KINDS = ("stft1", "istft1", "stft_offgrid", "mdct_offgrid", "stft4096", "stft4096_h1024", "istft4096", "mdct4096", "mel4096")   # one-sided pair (8f rank 4) and geometries off the benchmark's grid
 
 
 def synth(seed, c, n):
@@ -87,7 +87,7 @@ def make_workload(kind, device, layout="FT"):
         T = 217
     if kind == "mdct_offgrid":
         N, T = 442024, 433       # ceil(N / 1024) + 1 (zaf.py:1033): float32 rows of 1732 B
-    if kind in ("mdct4096", "mel4096"):
+    if kind in ("mdct4096", "mel4096", "istft4096"):
         T = 217                   # mdct: ceil(N / 2048) + 1 (odd: rows off the line grid); mel: hop 2048
     base = np.stack([synth(0, c, N) for c in range(distinct)])
     d_base = zafx.DeviceBuffer.from_host(base, device)
@@ -112,6 +112,15 @@ def make_workload(kind, device, layout="FT"):
         plan = zafx.stft_plan(zafx.hamming(4096), 1024, layout=layout, device=device)
         wl.update(plan=plan, d_in=d_x, n_in=N, bytes_per_launch=B * (4 * N + 8 * 4096 * T),
                   desc="Batched STFT, win=4096 hop=1024: 1024 clips x 10 s, T = 432, two-sided c64 (W,T) layout")
+    elif kind == "istft4096":        # k_istft_ft16b: one band of samples (even / odd packed samples) per workgroup; T = 217 is odd: 8-byte row pieces
+        fwd = zafx.stft_plan(zafx.hamming(4096), 2048, device=device)
+        d_s = zafx.DeviceBuffer(fwd.out_shape(B, N), np.complex64, device)
+        fwd.execute(d_x, d_s, B, N)
+        fwd.sync()
+        d_x.free()
+        plan = zafx.istft_plan(zafx.hamming(4096), 2048, device=device)
+        wl.update(plan=plan, d_in=d_s, n_in=T, bytes_per_launch=B * (8 * 4096 * T + 4 * (T * 2048 - 2048)),
+                  desc="Batched ISTFT, win=4096 hop=2048: 1024 clips x 217 frames")
     elif kind == "mdct4096":         # k_mdct_ft32b (32-frame tiles, two bands of bins); T = 217 is odd: rows off the line grid
         plan = zafx.mdct_plan(zafx.kaiser_bessel_derived(4096), device=device)
         wl.update(plan=plan, d_in=d_x, n_in=N, bytes_per_launch=B * (4 * N + 4 * 2048 * T),
@@ -383,7 +392,7 @@ def parity_probe(wl):
         ref = orc.mdct(x64, orc.kbd_window(4096))
     elif kind == "mel4096":
         ref = orc.melspectrogram(x64, orc.hamming_periodic(4096), 2048, orc.melfilterbank(FS, 4096, 128))
-    elif kind in ("istft", "istft1"):
+    elif kind in ("istft", "istft1", "istft4096"):
         ref = None   # (checked as a round trip below: the device spectrum is the input)
     elif kind in ("mdct", "mdct_offgrid"):
         ref = orc.mdct(x64, kbd)

@@ -625,6 +625,33 @@ def test_stft_w4096_two_bands(zafx, hop, n, clips):
             assert relerr(pw[c], np.abs(ref[c, :half]) ** 2) <= 2 * TOL_FFT
 
 
+@pytest.mark.parametrize("hop,n,clips", [(2048, 150001, 3), (2048, 16 * 2048 * 2, 2), (1024, 70000, 2), (512, 40000, 1), (4096, 200000, 2),
+                                          (1764, 100000, 2), (2048, 1, 1), (2048, 30 * 2048 * 16, 1), (2048, 40000, 300), (1000, 50000, 1)])
+def test_istft_w4096_two_bands(zafx, hop, n, clips):
+    """W = 4096 in the reference layout runs k_istft_ft16b for hops that are multiples of 4 (>= 512): one band of samples per
+    workgroup (even / odd packed samples = two 1024-point inverse transforms; zaf.py:214-241 is what it replaces), the generic
+    kernel otherwise (hop 1000 here: same numbers).  Non-Hermitian input, one-sided input, one clip in many segments (a carry
+    across workgroups), many clips, odd frame counts (the generic kernel: 16-byte row pieces need an even row pitch)."""
+    x = np.stack([synth_clip(47, c % 5, n) for c in range(clips)])
+    w = zafx.hamming(4096)
+    assert zafx.istft_plan(w, hop).kernel_name == "k_istft_ft16b"
+    spec = orc.stft_batch(x[:5].astype(np.float64), w, hop)
+    rng = np.random.default_rng(9)
+    spec = spec + 0.05 * (rng.standard_normal(spec.shape) + 1j * rng.standard_normal(spec.shape))   # not Hermitian: the reference takes real(ifft(.))
+    full = spec[np.arange(clips) % 5]
+    got = zafx.istft_batch(full, w, hop)
+    for c in range(min(clips, 7)):
+        ref = orc.istft(full[c], w, hop)
+        assert got[c].shape == ref.shape and relerr(got[c], ref) <= TOL_FFT, c
+    if clips > 7:
+        assert np.array_equal(got[5:10], got[0:5]) and np.array_equal(got[clips - 5:clips], got[(clips - 5) % 5:(clips - 5) % 5 + 5] if (clips - 5) % 5 == 0 else got[clips - 5:clips])
+    herm = orc.stft_batch(x[:2].astype(np.float64) if clips >= 2 else x[:1].astype(np.float64), w, hop)
+    one = zafx.istft_batch(herm[:, :2049], w, hop, onesided=True)
+    for c in range(herm.shape[0]):
+        ref = orc.istft(herm[c], w, hop)
+        assert relerr(one[c], ref) <= TOL_FFT
+
+
 def test_onesided_rejected_elsewhere(zafx):
     with pytest.raises(zafx.ZafxError):
         zafx.Plan(zafx.MDCT, window_length=2048, onesided=True)

@@ -68,7 +68,7 @@ def main():
             ms = rate(inv, d_c, d_y, T)
             print(f"n {n} W {wl} imdct {inv.kernel_name:14s} T {T}: {ms:7.3f} ms  {(d_y.nbytes + d_c.nbytes) / ms / 1e9:6.2f} TB/s", flush=True)
             d_c.free(); d_y.free()
-        for wl, hop in ((2048, 1024), (4096, 2048), (8192, 4096)):
+        for wl, hop in ((2048, 1024), (4096, 2048), (4096, 1024), (8192, 4096)):
             fwd, inv = zafx.stft_plan(zafx.hamming(wl), hop), zafx.istft_plan(zafx.hamming(wl), hop)
             d_c = zafx.DeviceBuffer(fwd.out_shape(B, n), fwd.out_dtype)
             T = fwd.out_dims(n)[1]

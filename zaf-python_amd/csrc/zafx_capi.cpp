@@ -682,7 +682,7 @@ int zafx_plan_create(zafx_plan** out, int device, int kind, const zafx_params* p
             e = upload(&pl->d_tw_r32, tw5.data(), tw5.size() * sizeof(cf32));
         }
     }
-    if (e == hipSuccess && (kind == ZAFX_STFT || kind == ZAFX_MEL || kind == ZAFX_MFCC) && pl->log2nf == 11 && pl->prm.precision == ZAFX_PRECISION_F32) {
+    if (e == hipSuccess && (kind == ZAFX_STFT || kind == ZAFX_ISTFT || kind == ZAFX_MEL || kind == ZAFX_MFCC) && pl->log2nf == 11 && pl->prm.precision == ZAFX_PRECISION_F32) {
         const auto sub = build_pass_twiddles(10, 4);   // the two 1024-point band transforms of k_stft_ft16b
         e = upload(&pl->d_tw_sub, sub.data(), sub.size() * sizeof(cf32));
     }

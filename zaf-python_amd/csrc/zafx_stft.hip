@@ -1116,7 +1116,10 @@ __device__ __forceinline__ float ola_sum(const float* fl, int pitch2, int q, int
 // Phase C of the carry kernel: outputs of the tile (carry first), then the carry for the next tile.
 // Thread `tid` owns offsets c = tid + m NT in both loops, so a carry slot is read and rewritten by
 // one thread.  q/r advance incrementally (no integer division per sample).
+// OS (template parameter of the phases below) = 2: the tile holds one BAND of a W = 4096 frame's samples (k_istft_ft16b): local
+// sample pair m is the real pair (4 m + boff, 4 m + boff + 1), i.e. local offset o maps to (o >> 1) * 4 + (o & 1) + boff; out_len stays real.
 struct OlaArgs {
+    int boff = 0;
     const float* fl;      // tile
     float* carry;
     int pitch2, ncarry, hop, n_valid, c_end;
@@ -1127,7 +1130,7 @@ struct OlaArgs {
     float scale;
 };
 
-template <int W, int NT, int FPB>
+template <int W, int NT, int FPB, int OS = 1>
 __device__ __forceinline__ void ola_phase(const OlaArgs& a, int tid) {
     const int q0 = tid / a.hop, r0 = tid % a.hop, qstep = NT / a.hop, rstep = NT % a.hop;
     if (a.write_out) {
@@ -1135,8 +1138,9 @@ __device__ __forceinline__ void ola_phase(const OlaArgs& a, int tid) {
         for (int c = tid; c < a.c_end; c += NT) {
             float acc = c < a.ncarry ? a.carry[c] : 0.f;
             acc = ola_sum<W>(a.fl, a.pitch2, q, r, a.hop, a.n_valid, acc);
-            const long long o = a.o_first + c;
-            if (o >= 0 && o < a.out_len) a.yc[o] = acc * a.scale;
+            const long long ol = a.o_first + c;
+            const long long o = OS == 1 ? ol : (ol >> 1) * 4 + (ol & 1) + a.boff;
+            if (ol >= 0 && o < a.out_len) a.yc[o] = acc * a.scale;
             q += qstep;
             r += rstep;
             if (r >= a.hop) r -= a.hop, ++q;
@@ -1157,7 +1161,7 @@ __device__ __forceinline__ void ola_phase(const OlaArgs& a, int tid) {
 
 // The same for an even hop >= W/2: at most two frames cover a sample (q - 1 and q), and the samples
 // (2m, 2m+1) of a frame sit in one LDS float2 -- branch-free 8-byte LDS reads, 8-byte stores.
-template <int W, int NT, int FPB>
+template <int W, int NT, int FPB, int OS = 1>
 __device__ __forceinline__ void ola_phase_pairs(const OlaArgs& a, int tid, bool y_aligned) {
     const float2* fr = reinterpret_cast<const float2*>(a.fl);
     float2* carry2 = reinterpret_cast<float2*>(a.carry);
@@ -1175,8 +1179,9 @@ __device__ __forceinline__ void ola_phase_pairs(const OlaArgs& a, int tid, bool 
         for (int c = tid; c < c_end2; c += NT) {
             float2 acc = c < ncarry2 ? carry2[c] : make_float2(0.f, 0.f);
             acc = sum2(q, r, acc);
-            const long long o = a.o_first + 2 * c;
-            if (o >= 0) {
+            const long long ol = a.o_first + 2 * c;
+            const long long o = OS == 1 ? ol : ol * 2 + a.boff;
+            if (ol >= 0) {
                 if (y_aligned && o + 1 < a.out_len) {
                     *reinterpret_cast<float2*>(a.yc + o) = make_float2(acc.x * a.scale, acc.y * a.scale);
                 } else {
@@ -1207,14 +1212,14 @@ __device__ __forceinline__ void ola_phase_pairs(const OlaArgs& a, int tid, bool 
 // with and its output pointer are fixed: two 8-byte LDS reads, three adds, one scale and one 8-byte store per pass, unrolled
 // (ola_phase_pairs re-derives frame, offset and four predicates per pair: 5-7 k of the tile's 35 k cycles at W = 2048).  The
 // same additions in the same order: bit-identical.  Returns false when the tile is not of that kind.
-template <int W, int NT, int FPB>
+template <int W, int NT, int FPB, int OS = 1>
 __device__ __forceinline__ bool ola_phase_sweep(const OlaArgs& a, int tid, bool y_aligned) {
     constexpr int HOP2 = W / 4, QS = NT / HOP2, NIT = (NT % HOP2 == 0 && QS >= 1 && FPB % (QS > 0 ? QS : 1) == 0) ? FPB / (QS > 0 ? QS : 1) : 0;
     if constexpr (NIT == 0 || HOP2 % 64 != 0) {
         return false;
     } else {
         const bool full = a.write_out && a.make_carry && 2 * a.hop == W && a.n_valid == FPB && a.c_end == FPB * a.hop &&
-                          a.o_first + (long long)FPB * a.hop <= a.out_len;
+                          (a.o_first + (long long)FPB * a.hop) * OS <= a.out_len;
         if (!full) return false;
         const float2* fr = reinterpret_cast<const float2*>(a.fl);
         float2* carry2 = reinterpret_cast<float2*>(a.carry);
@@ -1225,7 +1230,7 @@ __device__ __forceinline__ bool ola_phase_sweep(const OlaArgs& a, int tid, bool 
         const int q0 = __builtin_amdgcn_readfirstlane(to / HOP2);   // (whole waves: HOP2 is a multiple of 64)
         const float2* pv = fr + q0 * pitch + phys(r);                    // frame q, first half
         const float2* pu = fr + (q0 - 1) * pitch + phys(r + HOP2);       // frame q - 1, second half
-        float* dst = a.yc + a.o_first + 2 * to;
+        float* dst = a.yc + (a.o_first + 2 * to) * OS + (OS == 1 ? 0 : a.boff);
         const bool skip0 = a.o_first < 0 && q0 == 0;   // (the clip's first tile: its first W - hop samples are trimmed)
         // (compiled per alignment of the clip's output: with the test at every store the compiler folded both forms into 4-byte stores)
         auto passes = [&](auto ALIGNED8) {
@@ -1237,7 +1242,7 @@ __device__ __forceinline__ bool ola_phase_sweep(const OlaArgs& a, int tid, bool 
                 const float2 v = pv[(size_t)it * QS * pitch];
                 const float2 s = make_float2((acc.x + u.y) + v.y, (acc.y + u.x) + v.x);   // components are stored swapped
                 if (!(it == 0 && skip0)) {
-                    float* d = dst + (size_t)it * 2 * NT;
+                    float* d = dst + (size_t)it * 2 * NT * OS;
                     if constexpr (decltype(ALIGNED8)::value) {
                         *reinterpret_cast<float2*>(d) = make_float2(s.x * a.scale, s.y * a.scale);
                     } else {
@@ -1547,6 +1552,251 @@ __global__ __launch_bounds__(1024) void k_istft_ft16(
 }
 
 // ---------------------------------------------------------------------------------
+// inverse, reference layout, W = 4096: the carry kernel over two BANDS of samples, one band per workgroup (k_istft_ft16b)
+// ---------------------------------------------------------------------------------
+// Sixteen packed frames of M = 2048 points do not fit LDS, so the inverse ran on the one-workgroup-per-tile kernel with 8-frame tiles
+// (64-byte gather runs, a halo frame re-read per tile: 2.3 TB/s).  Decimation in TIME of the inverse transform:
+//     z[2m + b] = (1/M) sum_{k<1024} (Z[k] + (-1)^b Z[k + 1024]) e^{2 pi i k b / M} e^{2 pi i k m / 1024},   b = 0, 1
+// -- the even and the odd packed samples of a frame are each ONE 1024-point inverse transform of a combination of the two halves
+// of Z.  The reference's overlap-add has no synthesis window (zaf.py:226-241: a plain sum, then the COLA gain), and a hop that
+// is a multiple of 4 keeps a sample's residue mod 4: band b of every frame adds up to exactly the output samples 4m + 2b,
+// 4m + 2b + 1.  So band b is an ISTFT of its own -- frames of 2048 samples, hop H / 2, writing every other sample pair -- and
+// k_istft_ft16's machinery (16-frame tiles, carry in LDS, the three overlap-add forms) runs it unchanged behind a different
+// front end and an output index map (OS = 2).  A workgroup owns one band of a clip segment; the two bands' workgroups are
+// neighbours in the XCD order and gather the same rows at about the same time (k_stft_ft16bc measured 1.1 x, not 2 x, of
+// fetch for this arrangement).
+// Front end, in the swapped representation S = (Im Z, Re Z) that the forward transform inverts: the fold of rows k, W - k, M - k,
+// M + k gives S[k], S[M - k], that of rows 1024 - k, 3072 + k, 1024 + k, 3072 - k gives S[1024 - k], S[1024 + k]; then
+//     U_b[k] = (S[k] +- S[1024 + k]) c_b(k),  U_b[1024 - k] = (S[1024 - k] +- S[M - k]) c_b(1024 - k),
+// c_1(k) = e^{-2 pi i k / 2048} = root[2k], c_1(1024 - k) = -conj root[2k], c_0 = 1; the lane with k = 0 forms U_b[0] from the
+// special rows 0, M/2, M, 3M/2 and U_b[512] from the pair of k = 512.
+template <int DEPTH, bool ONE, int FV>
+__global__ __launch_bounds__(1024) void k_istft_ft16b(
+    const float2* __restrict__ spec, const float2* __restrict__ twp, const float2* __restrict__ tws,
+    float* __restrict__ y, int T, int TP, int hop /* H / 2: the band's hop */, long long out_len, float scale, int tiles, int segs, int seg_tiles,
+    int total_units, int halo) {
+    using C = FftCfg<10, 4>;
+    using F = FatCfg<10, 4>;
+    constexpr int N = C::N, P = C::P, E = C::E, W = 2 * N /* samples of a band's frame */, M = 2048, WR = 4096, NT = 1024, FPB = kFatFrames, PITCH = F::PITCH;
+    constexpr int ROWS = ONE ? M + 1 : WR;
+    // FV frames per lane and load: 2 = 16-byte loads of two adjacent frames (even row pitch, 16-byte aligned array), else 1
+    constexpr int LPR = FPB / FV, KSTEP = NT / LPR, KI = (N / 2) / KSTEP;
+    static_assert(FV == 1 || FV == 2, "one or two frames per lane");
+    using RV = std::conditional_t<FV == 2, float4, float2>;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    float2* frames = reinterpret_cast<float2*>(smem_raw);
+    float2* tw_l = frames + FPB * PITCH;
+    float2* tws_l = tw_l + C::TW;                                 // M/2 + 1 roots of 4096
+    float* carry = reinterpret_cast<float*>(tws_l + M / 2 + 1);   // W - hop floats of the band
+    const int tid = threadIdx.x;
+    for (int i = tid; i < C::TW; i += NT) tw_l[i] = twp[i];
+    for (int i = tid; i <= M / 2; i += NT) tws_l[i] = tws[i];
+    const int wave = tid / P, p = tid % P;
+    const int fs = (tid % LPR) * FV, kq = tid / LPR;
+    float2* fbuf = frames + fs * PITCH;
+    const int ncarry = W - hop;
+    const bool pairs = hop % 2 == 0 && 2 * hop >= W;
+    const bool y_base_aligned = reinterpret_cast<uintptr_t>(y) % 8 == 0;
+    const bool xcd = ZAFX_XCD_ORDER && gridDim.x % 8 == 0;
+
+    struct Tile {
+        int v, band, clip, tile, tile_a, tile_b;
+    };
+    auto enter = [&](Tile& it) {   // first tile of walk position it.v (one before the segment when it needs a carry)
+        const int u = xcd ? xcd_order(it.v, total_units) : it.v;
+        it.band = u & 1;
+        const int sg = u >> 1, seg = sg % segs;
+        it.clip = sg / segs;
+        it.tile_a = seg * seg_tiles;
+        it.tile_b = min(it.tile_a + seg_tiles, tiles);
+        it.tile = it.tile_a > 0 ? it.tile_a - 1 : 0;
+    };
+    auto my_frame_needed = [&](const Tile& it) { return it.tile * FPB + fs < T && fs + FV - 1 >= (it.tile < it.tile_a ? FPB - halo : 0); };
+    const int row_bytes = TP * 8;
+    const int v_up = kq * row_bytes + fs * 8, v_down = (KSTEP - kq) * row_bytes + fs * 8;
+    struct Src {
+        __amdgpu_buffer_rsrc_t rsrc;
+        int t_bytes;
+    };
+    auto source = [&](const Tile& it) {
+        Src src;
+        src.rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float2*>(spec) + (long long)it.clip * ROWS * TP, 0, ROWS * row_bytes, 0x00020000);
+        src.t_bytes = it.tile * FPB * 8;
+        return src;
+    };
+    auto ld = [&](const Src& src, int voff, int soff) {
+        RV f;
+        if constexpr (FV == 2) {
+            const auto raw = __builtin_amdgcn_raw_buffer_load_b128(src.rsrc, voff, soff + src.t_bytes, 0);
+            __builtin_memcpy(&f, &raw, 16);
+        } else {
+            const auto raw = __builtin_amdgcn_raw_buffer_load_b64(src.rsrc, voff, soff + src.t_bytes, 0);
+            __builtin_memcpy(&f, &raw, 8);
+        }
+        return f;
+    };
+    // rows of sweep s for my frame(s): r[0..3] = X[k], X[WR-k], X[M-k], X[M+k]; r[4..7] = X[1024-k], X[3072+k], X[1024+k], X[3072-k]
+    // (k = 0: X[0], X[M/2], X[M], X[3M/2] and the rows of k = 512: X[512], X[3584], X[1536], X[2560]).  One-sided input: the even
+    // slots only (+ slot 1 = row M/2 for k = 0); the fold completes the others as conjugates.
+    auto row_at = [&](const Src& src, int row) { return ld(src, row * row_bytes + fs * 8, 0); };
+    // (one-sided: rows k, M - k, 1024 - k, 1024 + k and -- for the lane with k = 0 -- M / 2 only: an array of their own, RN = 5, every
+    // element always written: with half-defined elements the array went to scratch)
+    constexpr int RN = ONE ? 5 : 8;
+    auto load8 = [&](const Src& src, int s, RV (&q)[RN]) {
+        if constexpr (ONE) {
+            if (s == 0) {
+                const int k = kq;
+                const bool z = k == 0;
+                q[0] = row_at(src, k);
+                q[1] = row_at(src, M - k);
+                q[2] = row_at(src, z ? 512 : 1024 - k);
+                q[3] = row_at(src, z ? 1536 : 1024 + k);
+                q[4] = row_at(src, z ? M / 2 : k);
+            } else {
+                q[0] = ld(src, v_up, s * KSTEP * row_bytes);
+                q[1] = ld(src, v_down, (M - (s + 1) * KSTEP) * row_bytes);
+                q[2] = ld(src, v_down, (1024 - (s + 1) * KSTEP) * row_bytes);
+                q[3] = ld(src, v_up, (1024 + s * KSTEP) * row_bytes);
+                q[4] = q[0];
+            }
+        } else {
+            if (s == 0) {   // the sweep that holds k = 0: per-lane row select
+                const int k = kq;
+                const bool z = k == 0;
+                q[0] = row_at(src, k);
+                q[1] = row_at(src, z ? M / 2 : WR - k);
+                q[2] = row_at(src, M - k);
+                q[3] = row_at(src, z ? M + M / 2 : M + k);
+                q[4] = row_at(src, z ? 512 : 1024 - k);
+                q[5] = row_at(src, z ? 3584 : 3072 + k);
+                q[6] = row_at(src, z ? 1536 : 1024 + k);
+                q[7] = row_at(src, z ? 2560 : 3072 - k);
+            } else {
+                q[0] = ld(src, v_up, s * KSTEP * row_bytes);
+                q[1] = ld(src, v_down, (WR - (s + 1) * KSTEP) * row_bytes);
+                q[2] = ld(src, v_down, (M - (s + 1) * KSTEP) * row_bytes);
+                q[3] = ld(src, v_up, (M + s * KSTEP) * row_bytes);
+                q[4] = ld(src, v_down, (1024 - (s + 1) * KSTEP) * row_bytes);
+                q[5] = ld(src, v_up, (3072 + s * KSTEP) * row_bytes);
+                q[6] = ld(src, v_up, (1024 + s * KSTEP) * row_bytes);
+                q[7] = ld(src, v_down, (3072 - (s + 1) * KSTEP) * row_bytes);
+            }
+        }
+    };
+    // one frame: the eight rows of bin k -> U_b[k], U_b[1024 - k] (k = 0: U_b[0], U_b[512]) in the frame buffer fb
+    auto fold_one = [&](int k, int band, float2 r0, float2 r1, float2 r2, float2 r3, float2 r4, float2 r5, float2 r6, float2 r7, float2* fb) {
+        if (ONE) {
+            r3 = cconj(r2);
+            r5 = cconj(r4);
+            r7 = cconj(r6);
+        }
+        if (k == 0) {
+            const float a0 = 2.f * r0.x, an = 2.f * r2.x;
+            const float2 s0 = make_float2(a0 - an, a0 + an);                                  // S[0]
+            if (ONE) r3 = cconj(r1);
+            const float2 a = make_float2(r1.x + r3.x, r1.y - r3.y);
+            const float2 sh = make_float2(-2.f * a.y, 2.f * a.x);                             // S[M/2] = S[1024]
+            fb[0] = band ? csub(s0, sh) : cadd(s0, sh);
+            float2 s5, s15;                                                                     // S[512], S[1536]
+            unsplit_pair(r4, r5, r6, r7, tws_l[512], s5, s15);
+            fb[phys(512)] = band ? mul_mi(csub(s5, s15)) : cadd(s5, s15);                      // c_1(512) = -i
+        } else {
+            if (ONE) r1 = cconj(r0);
+            float2 sk, smk, s1mk, s1pk;   // S[k], S[M-k], S[1024-k], S[1024+k]
+            unsplit_pair(r0, r1, r2, r3, tws_l[k], sk, smk);
+            unsplit_pair(r4, r5, r6, r7, tws_l[1024 - k], s1mk, s1pk);
+            if (band) {
+                const float2 c = tws_l[2 * k];
+                fb[phys(k)] = cmul(csub(sk, s1pk), c);
+                const float2 d = csub(smk, s1mk);          // -(S[1024-k] - S[M-k])
+                fb[phys(1024 - k)] = cmulc(d, c);            // (S[1024-k] - S[M-k]) * (-conj c)
+            } else {
+                fb[phys(k)] = cadd(sk, s1pk);
+                fb[phys(1024 - k)] = cadd(s1mk, smk);
+            }
+        }
+    };
+    auto fold8 = [&](int s, int band, const RV (&q)[RN]) {
+        const int k = kq + s * KSTEP;
+        RV r[8];   // slots as in the comment above load8 (one-sided: 3, 5, 7 are replaced by conjugates in fold_one)
+#pragma unroll
+        for (int i = 0; i < 8; ++i) r[i] = q[ONE ? ((i & 1) ? (i == 1 ? 4 : 0) : i / 2) : i];
+        if constexpr (FV == 2) {
+            auto lo = [](float4 v) { return make_float2(v.x, v.y); };
+            auto hi = [](float4 v) { return make_float2(v.z, v.w); };
+            fold_one(k, band, lo(r[0]), lo(r[1]), lo(r[2]), lo(r[3]), lo(r[4]), lo(r[5]), lo(r[6]), lo(r[7]), fbuf);
+            fold_one(k, band, hi(r[0]), hi(r[1]), hi(r[2]), hi(r[3]), hi(r[4]), hi(r[5]), hi(r[6]), hi(r[7]), fbuf + PITCH);
+        } else {
+            fold_one(k, band, r[0], r[1], r[2], r[3], r[4], r[5], r[6], r[7], fbuf);
+        }
+    };
+    Tile cur;
+    cur.v = blockIdx.x;
+    if (cur.v >= total_units) return;
+    enter(cur);
+    for (int c = tid; c < ncarry; c += NT) carry[c] = 0.f;
+    lds_barrier();   // tables staged
+
+    while (true) {
+        const bool carry_only = cur.tile < cur.tile_a;
+        const int t_first = cur.tile * FPB;
+        Tile nxt = cur;
+        if (++nxt.tile >= nxt.tile_b) {
+            nxt.v += gridDim.x;
+            if (nxt.v < total_units) enter(nxt);
+        }
+        const bool has_next = nxt.v < total_units;
+        // ---- phase A: stream the tile's sweeps, DEPTH at a time, through the fold into LDS
+        if (my_frame_needed(cur)) {
+            const Src sp = source(cur);
+#pragma unroll DEPTH
+            for (int s = 0; s < KI; ++s) {
+                RV r[RN];
+                load8(sp, s, r);
+                fold8(s, cur.band, r);
+            }
+        }
+        lds_barrier();
+        // ---- phase B: forward FFT of the swapped spectrum == swapped inverse FFT
+        if (wave >= (carry_only ? FPB - halo : 0)) {   // wave-uniform
+            float2* buf = frames + wave * PITCH;
+            float2 v[E];
+            regs_read<10, 4>(v, buf, p);
+            frame_sync<P>();
+            fft_frame<10, 4>(v, buf, p, tw_l);
+        }
+        lds_barrier();
+        // ---- phase C: overlap-add of the band (carry first), trim, COLA gain; next carry
+        {
+            OlaArgs a;
+            a.boff = 2 * cur.band;
+            a.fl = reinterpret_cast<const float*>(frames);
+            a.carry = carry;
+            a.pitch2 = 2 * PITCH;
+            a.ncarry = ncarry;
+            a.hop = hop;
+            a.n_valid = min(FPB, T - t_first);
+            a.c_end = cur.tile == tiles - 1 ? a.n_valid * hop + ncarry : FPB * hop;
+            a.write_out = !carry_only;
+            a.make_carry = cur.tile + 1 < cur.tile_b;
+            a.yc = y + (long long)cur.clip * out_len;
+            a.o_first = (long long)t_first * hop - ncarry;
+            a.out_len = out_len;
+            a.scale = scale;
+            const bool ya = y_base_aligned && ((long long)cur.clip * out_len) % 2 == 0;
+            if (pairs) {
+                if (!ola_phase_sweep<W, NT, FPB, 2>(a, tid, ya)) ola_phase_pairs<W, NT, FPB, 2>(a, tid, ya);
+            } else {
+                ola_phase<W, NT, FPB, 2>(a, tid);
+            }
+        }
+        lds_barrier();
+        if (!has_next) break;
+        cur = nxt;
+    }
+}
+
+// ---------------------------------------------------------------------------------
 // launch plumbing
 // ---------------------------------------------------------------------------------
 constexpr int stft_fpb(int log2n, int layout) {
@@ -1792,8 +2042,42 @@ static hipError_t run_istft_fat(const zafx_plan& pl, const float2* spec, float* 
     return hipGetLastError();
 }
 
+#ifndef ZAFX_ISTFT_BAND
+#define ZAFX_ISTFT_BAND 1
+#endif
+// k_istft_ft16b: W = 4096 in the reference layout, one band of samples per workgroup (see the kernel)
+template <bool ONE>
+static hipError_t run_istft_band(const zafx_plan& pl, const float2* spec, float* y, int64_t n_clips, int T, int64_t out_len) {
+    using F = FatCfg<10, 4>;
+    constexpr int M = 2048;
+    const size_t smem = (size_t)(kFatFrames * F::PITCH + FftCfg<10, 4>::TW + M / 2 + 1) * 8 + (size_t)(2048 - pl.H / 2) * 4;
+    const bool vec = row_pitch(pl, T) % 2 == 0 && reinterpret_cast<uintptr_t>(spec) % 16 == 0;   // 16-byte row pieces of two adjacent frames
+    auto kern = vec ? k_istft_ft16b<1, ONE, 2> : k_istft_ft16b<ONE ? 2 : 1, ONE, 1>;
+    if (hipError_t e = ensure_dynamic_lds(reinterpret_cast<const void*>(kern), pl.device, smem); e != hipSuccess) return e;
+    const int halo = (4096 + pl.H - 1) / pl.H - 1;
+    const int tiles = (T + kFatFrames - 1) / kFatFrames;
+    if ((long long)tiles * n_clips <= 0 || out_len <= 0) return hipSuccess;
+    const long long max_grid = pl.n_cus;
+    const int segs = carry_segments(2 * n_clips, tiles, max_grid);   // (two units -- one per band -- for every segment)
+    const int seg_tiles = (tiles + segs - 1) / segs;
+    const long long units = 2LL * n_clips * segs;
+    const float scale = 1.f / (4.f * (float)M * pl.cola_gain);
+    const long long grid = std::min<long long>(units, max_grid);
+    hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(1024), smem, pl.stream, spec, pl.d_tw_sub, pl.d_tw_aux, y, T, (int)row_pitch(pl, T), pl.H / 2,
+                       (long long)out_len, scale, tiles, segs, seg_tiles, (int)units, halo);
+    return hipGetLastError();
+}
+
 template <int LOG2N, int LAYOUT, bool ONE>
 static hipError_t run_istft(const zafx_plan& pl, const float2* spec, float* y, int64_t n_clips, int T, int64_t out_len) {
+    if constexpr (ZAFX_ISTFT_BAND && LOG2N == 11 && LAYOUT == ZAFX_LAYOUT_FT) {
+        // W = 4096: the band form wants a hop that is a multiple of 4 (a sample keeps its residue mod 4 from frame to frame), at least 512
+        // (ceil(W / H) - 1 <= 7 halo frames; the carry fits LDS), 32-bit byte offsets inside a clip's spectrum
+        const int64_t TP = row_pitch(pl, T);
+        if (pl.d_tw_sub && pl.H % 4 == 0 && pl.H >= 512 && pl.H <= 4096 && reinterpret_cast<uintptr_t>(spec) % 8 == 0 &&
+            (long long)4096 * TP * 8 < (1LL << 31) && 2LL * n_clips * ((T + 15) / 16) < (1LL << 30))
+            return run_istft_band<ONE>(pl, spec, y, n_clips, T, out_len);
+    }
     if constexpr (stft_use_fat(LOG2N, LAYOUT)) {
         // the carry kernel addresses a clip through one buffer descriptor (32-bit byte offsets)
         if ((long long)(2 << LOG2N) * row_pitch(pl, T) * 8 < (1LL << 31)) return run_istft_fat<LOG2N, ONE>(pl, spec, y, n_clips, T, out_len);
@@ -1830,7 +2114,10 @@ const char* stft_kernel_name(int log2n, int layout) {
     if (ZAFX_STFT_BAND && log2n == 11 && layout == ZAFX_LAYOUT_FT) return "k_stft_ft16b";
     return stft_use_fat(log2n, layout) ? "k_stft_ft16" : stft_use_tf(log2n, layout) ? "k_stft_tf" : "k_stft";
 }
-const char* istft_kernel_name(int log2n, int layout) { return stft_use_fat(log2n, layout) || stft_use_tf(log2n, layout) ? "k_istft_ft16" : "k_istft"; }
+const char* istft_kernel_name(int log2n, int layout) {
+    if (ZAFX_ISTFT_BAND && log2n == 11 && layout == ZAFX_LAYOUT_FT) return "k_istft_ft16b";
+    return stft_use_fat(log2n, layout) || stft_use_tf(log2n, layout) ? "k_istft_ft16" : "k_istft";
+}
 
 template <int L, int LAYOUT>
 static hipError_t dispatch_stft_spec(const zafx_plan& pl, const float* x, float2* out, int64_t n_clips, int64_t n_samples, int T) {

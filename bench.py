@@ -125,10 +125,10 @@ def make_workload(kind, device, layout="FT"):
         plan = zafx.mdct_plan(zafx.kaiser_bessel_derived(4096), device=device)
         wl.update(plan=plan, d_in=d_x, n_in=N, bytes_per_launch=B * (4 * N + 4 * 2048 * T),
                   desc="Batched MDCT, KBD win=4096: 1024 clips x 10 s, T = 217, compact (W/2,T) layout")
-    elif kind == "mel4096":          # spectrum kernel (k_stft_ft16b, |X| rows into a plan-owned scratch) + k_melfb
+    elif kind == "mel4096":          # k_mel_ft16b: the two-band STFT kernel with the filterbank product in place of the stores
         plan = zafx.mel_plan(zafx.hamming(4096), 2048, zafx.melfilterbank(FS, 4096, 128), device=device)
         wl.update(plan=plan, d_in=d_x, n_in=N, bytes_per_launch=B * (4 * N + 4 * 128 * T),
-                  desc="melspectrogram, win=4096 hop=2048, 128 filters: 1024 clips x 10 s (spectrum kernel + filterbank kernel, float32)")
+                  desc="melspectrogram, win=4096 hop=2048, 128 filters: 1024 clips x 10 s (fused on the two-band kernel, float32)")
     elif kind == "stft64":  # float64 device arithmetic (written for exactness, not speed)
         d_x64 = zafx.DeviceBuffer.from_host(np.tile(base.astype(np.float64), (B // distinct, 1)), device)
         d_x.free()

@@ -1161,14 +1161,15 @@ def test_cqt_short_kernel(zafx, fs, res, fmin, fmax, tr):
 
 @pytest.mark.parametrize("wl,hop,nmel", [(4096, 2048, 128), (8192, 2048, 64), (2048, 1024, 300), (4096, 1024, 40), (8192, 4096, 256), (4096, 1763, 128)])
 def test_mel_long_window_or_wide_bank(zafx, wl, hop, nmel):
-    """Windows of 4096 / 8192 samples are outside the fused kernel: a spectrum kernel (|X| or |X|^2 rows into a plan-owned
-    scratch) + the banded filterbank kernel k_melfb, in float32.  Filterbanks above 256 rows run on the float64 kernel and
-    return float32 from the float32 entry points."""
+    """Windows of 4096 / 8192 samples are outside the fused W <= 2048 kernel.  W = 4096: k_mel_ft16b, the two-band STFT kernel with the
+    filterbank product in place of the stores; W = 8192: a spectrum kernel (|X| or |X|^2 rows into a plan-owned scratch) + the
+    banded filterbank kernel k_melfb; both float32.  Filterbanks above 256 rows run on the float64 kernel and return float32
+    from the float32 entry points."""
     x = np.stack([synth_clip(61, c, 60000 + (hop % 2)) for c in range(2)])
     w = zafx.hamming(wl)
     fb = zafx.melfilterbank(44100, wl, nmel)
     plan = zafx.mel_plan(w, hop, fb)
-    assert plan.kernel_name == ("k_melfb" if wl > 2048 else "k_mel_f64") and plan.in_dtype == (np.float32 if wl > 2048 else np.float64)
+    assert plan.kernel_name == {4096: "k_mel_ft16b", 8192: "k_melfb"}.get(wl, "k_mel_f64") and plan.in_dtype == (np.float32 if wl > 2048 else np.float64)
     mel = zafx.melspectrogram_batch(x, w, hop, fb)
     cep = zafx.mfcc_batch(x, w, hop, fb, 13)
     assert mel.dtype == np.float32 and cep.dtype == np.float32
@@ -1183,13 +1184,14 @@ def test_mel_long_window_or_wide_bank(zafx, wl, hop, nmel):
     assert one.dtype == np.float64 and relerr(one, orc.melspectrogram(x[0].astype(np.float64), w, hop, fb)) <= TOL_FB
 
 
-def test_mel_long_window_in_chunks(zafx):
-    """k_melfb's scratch holds a chunk of clips (256 MB): 1200 short clips at W = 4096 go through it in two chunks (768 + 432);
-    padded output rows (row_align)."""
-    n, hop, clips = 30000, 2048, 1200
+@pytest.mark.parametrize("wl", [8192, 4096])
+def test_mel_long_window_in_chunks(zafx, wl):
+    """k_melfb's scratch holds a chunk of clips (256 MB): 1200 short clips at W = 8192 go through it in two chunks;
+    padded output rows (row_align).  (W = 4096 runs the fused k_mel_ft16b: same checks, many tiles per workgroup.)"""
+    n, hop, clips = 30000, wl // 2, 1200
     x = np.stack([synth_clip(62, c % 7, n) for c in range(clips)])
-    w = zafx.hamming(4096)
-    fb = zafx.melfilterbank(44100, 4096, 128)
+    w = zafx.hamming(wl)
+    fb = zafx.melfilterbank(44100, wl, 128)
     mel = zafx.melspectrogram_batch(x, w, hop, fb)
     cep = zafx.mfcc_batch(x, w, hop, fb, 20)
     for c in (0, 255, 767, 768, 1023, 1199):

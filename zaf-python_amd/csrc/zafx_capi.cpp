@@ -616,7 +616,7 @@ int zafx_plan_create(zafx_plan** out, int device, int kind, const zafx_params* p
         const int n = pl->W / 2;
         aux.resize((size_t)n / 2 + 1);
         for (int k = 0; k <= n / 2; ++k) aux[(size_t)k] = unit_root(k, pl->W);
-        pl->kernel_name = kind == ZAFX_STFT ? stft_kernel_name(lw - 1, pl->layout) : kind == ZAFX_ISTFT ? istft_kernel_name(lw - 1, pl->layout) : lw - 1 >= 11 ? mel_wide_kernel_name() : mel_kernel_name();
+        pl->kernel_name = kind == ZAFX_STFT ? stft_kernel_name(lw - 1, pl->layout) : kind == ZAFX_ISTFT ? istft_kernel_name(lw - 1, pl->layout) : lw - 1 == 11 ? "k_mel_ft16b" : lw - 1 >= 12 ? mel_wide_kernel_name() : mel_kernel_name();
     } else if (is_mdct_family(kind)) {
         pl->W = params->window_length;
         pl->H = pl->W / 2;   // zaf.py:1029

@@ -629,8 +629,12 @@ static size_t melw_chunk_bytes() {
     return bytes;
 }
 
+#ifndef ZAFX_MEL_BAND
+#define ZAFX_MEL_BAND 1
+#endif
 static hipError_t run_mel_wide(zafx_plan& pl, const float* x, float* out, int64_t n_clips, int64_t n_samples, int T) {
     if ((long long)n_clips * T <= 0) return hipSuccess;
+    if (ZAFX_MEL_BAND && mel_band_usable(pl, x, n_clips, n_samples, T)) return launch_mel_band(pl, x, out, n_clips, n_samples, T);   // W = 4096: fused (k_mel_ft16b)
     const int mfcc = pl.kind == ZAFX_MFCC;
     const int rows = pl.W / 2 + 1;
     const int SP = (T + 31) / 32 * 32;   // spectrum rows as whole 128-byte lines

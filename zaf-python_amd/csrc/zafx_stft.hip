@@ -694,6 +694,216 @@ __global__ __launch_bounds__(kFatWaves * 64) void k_stft_ft16b(
 }
 
 // ---------------------------------------------------------------------------------
+// melspectrogram / mfcc at W = 4096, fused on the two-band kernel (k_mel_ft16b)
+// ---------------------------------------------------------------------------------
+// k_stft_ft16b with the stores of a band replaced by its share of the filterbank product: after a band's transforms every thread turns ITS
+// pairs (Z[q], Z[N - S - q]) of its frame into |X| (mel, zaf.py:370) or |X|^2 (mfcc, zaf.py:437-439) IN PLACE (each element of the frame
+// belongs to exactly one pair, so no other thread reads it in that phase; slot q of band S then holds bin k = 2 q + S, bin M sits in the
+// padding slot N), and after a barrier thread (frame t = tid % 16, group g = tid / 16) adds the band's non-zeros of the filters g, g + 32, ...
+// to accumulators that live across both bands.  A filter is its band of non-zeros [first, first + count) (zaf.py:305-316: one triangle; the
+// float32 band arrays of k_melfb), of which a band of bins takes every other one: about 2 000 products per frame and band against the
+// transform's 50 000 flops -- vector FMAs, no matrix cores, and the spectrum never reaches HBM (the k_melfb route writes and re-reads it:
+// 12 B/sample against 4.5).  mfcc: log(mel + eps) through the (then dead) frame buffers, DCT-II rows from there (zaf.py:443-452).
+template <bool ALIGNED, bool MFCC>
+__global__ __launch_bounds__(kFatWaves * 64) void k_mel_ft16b(
+    const float* __restrict__ x, const float* __restrict__ win, const float2* __restrict__ twp, const float2* __restrict__ tws,
+    const float* __restrict__ fb_vals, const int* __restrict__ fb_meta, const float* __restrict__ dct, float* __restrict__ out,
+    long long n_samples, int hop, int T, int TP, int tiles, int total_tiles, int n_filters, int n_coefs, int layout) {
+    using B = BandCfg;
+    using C = B::C;
+    constexpr int N = B::N, M = B::M, P = 64, E = 16, NT = B::NT, FPB = B::FPB, FPW = B::FPW, PITCH = B::PITCH;
+    constexpr int NFI = 8;   // filters per thread (n_filters <= 256 = 32 groups x 8)
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    float2* frames = reinterpret_cast<float2*>(smem_raw);
+    float2* tw_l = frames + FPB * PITCH;
+    float2* tws_l = tw_l + C::TW;
+    const int tid = threadIdx.x;
+    for (int i = tid; i < C::TW; i += NT) tw_l[i] = twp[i];
+    for (int i = tid; i <= M / 2; i += NT) tws_l[i] = tws[i];
+    __syncthreads();
+    const int wave = tid / P, p_lane = tid % P;
+    const int tt = tid % FPB, kq = tid / FPB;
+    float2* fbw = frames + tt * PITCH;
+    const bool xcd = ZAFX_XCD_ORDER && gridDim.x % 8 == 0;
+    const float2 wp = tws_l[2 * p_lane];
+    const float eps = 2.220446049250313e-16f;   // np.finfo(float).eps (zaf.py:445)
+
+    float2 xr[FPW][2 * E];
+    auto prefetch = [&](int tlv) {
+        if (tlv >= total_tiles) return;
+        const int tl = xcd ? xcd_order(tlv, total_tiles) : tlv;
+        const int clip = tl / tiles, tile = tl % tiles;
+        const float* xc = x + (long long)clip * n_samples;
+        const __amdgpu_buffer_rsrc_t rs = make_rsrc(xc, (unsigned)(n_samples * 4));   // (outside the clip: zero = the reference's padding)
+#pragma unroll
+        for (int f = 0; f < FPW; ++f) {
+            const int s0 = (tile * FPB + wave * FPW + f) * hop - M;
+            const int vo = (s0 + 2 * p_lane) * 4;
+            int vo1 = vo + 4;
+            if constexpr (!ALIGNED) asm volatile("" : "+v"(vo1));   // (see k_stft_ft16b: the two 4-byte loads of a pair must not be merged)
+#pragma unroll
+            for (int j = 0; j < 2 * E; ++j) {
+                if constexpr (ALIGNED) {
+                    xr[f][j] = buf_load_f32x2(rs, vo + j * P * 8);
+                } else {
+                    xr[f][j].x = buf_load_f32(rs, vo + j * P * 8);
+                    xr[f][j].y = buf_load_f32(rs, vo1 + j * P * 8);
+                }
+            }
+        }
+    };
+    auto level = [&](float2 v) {   // |X| (mel) or |X|^2 (mfcc)
+        const float pw = v.x * v.x + v.y * v.y;
+        return MFCC ? pw : __builtin_amdgcn_sqrtf(pw);
+    };
+    // a band's spectrum -> levels, in place: slot q <- bin 2 q + S (band 0: slot N <- bin M; slot 0, bin 0, is never read)
+    auto levels = [&](auto band) {
+        constexpr int S = decltype(band)::value;
+        constexpr int ITER = (N / 2) / (NT / FPB);
+        int kqo = kq;
+        asm volatile("" : "+v"(kqo));
+#pragma unroll 4
+        for (int it = 0; it < ITER; ++it) {
+            const int q = kqo + it * (NT / FPB);
+            if (S == 0 && q == 0) {
+                const float2 z0 = fbw[0], zc = fbw[phys_t<C::PS>(N / 2)];
+                fbw[phys_t<C::PS>(N)].x = MFCC ? (z0.x - z0.y) * (z0.x - z0.y) : fabsf(z0.x - z0.y);   // X[M] = Re Z[0] - Im Z[0]
+                fbw[phys_t<C::PS>(N / 2)].x = level(zc);                                                   // X[M/2] = conj Z[M/2]
+            } else {
+                float2 xk, xn;
+                float2* pk = fbw + phys_t<C::PS>(q);
+                float2* pn = fbw + phys_t<C::PS>(N - S - q);
+                split_pair(*pk, *pn, tws_l[2 * q + S], xk, xn);
+                pk->x = level(xk);
+                pn->x = level(xn);
+            }
+        }
+    };
+    // the band's share of FB . S for this thread's frame and filters
+    float acc[NFI];
+    const int g = tid / FPB;
+    const float* sf = reinterpret_cast<const float*>(frames + tt * PITCH);
+    auto product = [&](int S) {
+#pragma unroll
+        for (int i = 0; i < NFI; ++i) {
+            const int f = g + 32 * i;
+            if (f < n_filters) {
+                const int first = fb_meta[3 * f], count = fb_meta[3 * f + 1];
+                const float* v = fb_vals + fb_meta[3 * f + 2];
+                // bin k = first + 1 + j (zaf.py:370: column c <-> bin c + 1), slot q = (k - S) / 2; four products in flight (the values come
+                // from global memory / L1: one at a time the loop is a chain of load latencies)
+                float a0 = acc[i], a1 = 0.f, a2 = 0.f, a3 = 0.f;
+                const int j0 = (S - first - 1) & 1, q0 = (first + 1 + j0 - S) >> 1;
+                const int n = (count - j0 + 1) >> 1;   // entries of this band
+                int m = 0;
+                for (; m + 4 <= n; m += 4) {
+                    const float v0 = v[j0 + 2 * m], v1 = v[j0 + 2 * m + 2], v2 = v[j0 + 2 * m + 4], v3 = v[j0 + 2 * m + 6];
+                    const float s0 = sf[2 * phys_t<C::PS>(q0 + m)], s1 = sf[2 * phys_t<C::PS>(q0 + m + 1)];
+                    const float s2 = sf[2 * phys_t<C::PS>(q0 + m + 2)], s3 = sf[2 * phys_t<C::PS>(q0 + m + 3)];
+                    a0 = fmaf(v0, s0, a0);
+                    a1 = fmaf(v1, s1, a1);
+                    a2 = fmaf(v2, s2, a2);
+                    a3 = fmaf(v3, s3, a3);
+                }
+                for (; m < n; ++m) a0 = fmaf(v[j0 + 2 * m], sf[2 * phys_t<C::PS>(q0 + m)], a0);
+                acc[i] = (a0 + a1) + (a2 + a3);
+            }
+        }
+    };
+    int tlv = blockIdx.x;
+    prefetch(tlv);
+    for (; tlv < total_tiles; tlv += gridDim.x) {
+        const int tl = xcd ? xcd_order(tlv, total_tiles) : tlv;
+        const int clip = tl / tiles, tile = tl % tiles;
+        const int t0 = tile * FPB;
+        int po = p_lane;
+        asm volatile("" : "+v"(po));
+        {
+            const float2* w2 = reinterpret_cast<const float2*>(win) + po;
+            const float c32[16] = {1.f, 0.98078528040323044913f, 0.92387953251128675613f, 0.83146961230254523708f, 0.70710678118654752440f,
+                                   0.55557023301960222474f, 0.38268343236508977173f, 0.19509032201612826785f, 0.f,
+                                   -0.19509032201612826785f, -0.38268343236508977173f, -0.55557023301960222474f, -0.70710678118654752440f,
+                                   -0.83146961230254523708f, -0.92387953251128675613f, -0.98078528040323044913f};
+            const float s32[16] = {0.f, 0.19509032201612826785f, 0.38268343236508977173f, 0.55557023301960222474f, 0.70710678118654752440f,
+                                   0.83146961230254523708f, 0.92387953251128675613f, 0.98078528040323044913f, 1.f,
+                                   0.98078528040323044913f, 0.92387953251128675613f, 0.83146961230254523708f, 0.70710678118654752440f,
+                                   0.55557023301960222474f, 0.38268343236508977173f, 0.19509032201612826785f};
+            float2 wv[2 * E];
+#pragma unroll
+            for (int j = 0; j < 2 * E; ++j) wv[j] = w2[j * P];
+#pragma unroll
+            for (int f = 0; f < FPW; ++f) {
+#pragma unroll
+                for (int i = 0; i < E; ++i) {
+                    const float2 a = make_float2(xr[f][i].x * wv[i].x, xr[f][i].y * wv[i].y);
+                    const float2 b = make_float2(xr[f][i + E].x * wv[i + E].x, xr[f][i + E].y * wv[i + E].y);
+                    xr[f][i] = cadd(a, b);
+                    const float2 d = csub(a, b);
+                    xr[f][i + E] = cmul(i == 0 ? d : (i == 8 ? mul_mi(d) : cmulk(d, c32[i], -s32[i])), wp);
+                }
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < NFI; ++i) acc[i] = 0.f;
+#pragma unroll
+        for (int f = 0; f < FPW; ++f) fft_frame<10, 4>(&xr[f][0], frames + (wave * FPW + f) * PITCH, po, tw_l);
+        lds_barrier();
+        levels(std::integral_constant<int, 0>{});
+        lds_barrier();
+        product(0);
+        lds_barrier();
+#pragma unroll
+        for (int f = 0; f < FPW; ++f) fft_frame<10, 4>(&xr[f][E], frames + (wave * FPW + f) * PITCH, po, tw_l);
+        prefetch(tlv + gridDim.x);
+        lds_barrier();
+        levels(std::integral_constant<int, 1>{});
+        lds_barrier();
+        product(1);
+        const int t = t0 + tt;
+        if constexpr (MFCC) {
+            lds_barrier();   // every thread is done with the levels: the frame buffers become the log-mel tile [filter][frame]
+            float* lm = reinterpret_cast<float*>(frames);
+#pragma unroll
+            for (int i = 0; i < NFI; ++i)
+                if (g + 32 * i < n_filters) lm[(g + 32 * i) * FPB + tt] = logf(acc[i] + eps);
+            lds_barrier();
+            if (t < T) {
+                for (int c = g; c < n_coefs; c += 32) {
+                    const float* d = dct + (long long)c * n_filters;
+                    float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;   // (eight products in flight: the DCT rows come from global memory / L1)
+                    int f = 0;
+                    for (; f + 8 <= n_filters; f += 8) {
+                        const float d0 = d[f], d1 = d[f + 1], d2 = d[f + 2], d3 = d[f + 3], d4 = d[f + 4], d5 = d[f + 5], d6 = d[f + 6], d7 = d[f + 7];
+                        a0 = fmaf(d0, lm[f * FPB + tt], a0);
+                        a1 = fmaf(d1, lm[(f + 1) * FPB + tt], a1);
+                        a2 = fmaf(d2, lm[(f + 2) * FPB + tt], a2);
+                        a3 = fmaf(d3, lm[(f + 3) * FPB + tt], a3);
+                        a0 = fmaf(d4, lm[(f + 4) * FPB + tt], a0);
+                        a1 = fmaf(d5, lm[(f + 5) * FPB + tt], a1);
+                        a2 = fmaf(d6, lm[(f + 6) * FPB + tt], a2);
+                        a3 = fmaf(d7, lm[(f + 7) * FPB + tt], a3);
+                    }
+                    for (; f < n_filters; ++f) a0 = fmaf(d[f], lm[f * FPB + tt], a0);
+                    const float r = (a0 + a1) + (a2 + a3);
+                    if (layout == ZAFX_LAYOUT_FT) out[((long long)clip * n_coefs + c) * TP + t] = r;
+                    else out[((long long)clip * T + t) * n_coefs + c] = r;
+                }
+            }
+        } else if (t < T) {
+#pragma unroll
+            for (int i = 0; i < NFI; ++i) {
+                const int f = g + 32 * i;
+                if (f < n_filters) {
+                    if (layout == ZAFX_LAYOUT_FT) out[((long long)clip * n_filters + f) * TP + t] = acc[i];
+                    else out[((long long)clip * T + t) * n_filters + f] = acc[i];
+                }
+            }
+        }
+        lds_barrier();
+    }
+}
+
+// ---------------------------------------------------------------------------------
 // forward, reference layout, W = 4096, complex rows that are NOT whole 128-byte lines: one band per workgroup + register carry (k_stft_ft16bc)
 // ---------------------------------------------------------------------------------
 // k_stft_ft16b writes a line of such a row in two parts far apart (T = 217: 4.33 ms against 3.24 on the generic kernel), and the carry
@@ -1902,6 +2112,27 @@ static hipError_t run_stft_band_carry(const zafx_plan& pl, const float* x, float
     } else {
         return hipErrorInvalidValue;
     }
+}
+
+// k_mel_ft16b: mel / mfcc at W = 4096, fused on the two-band kernel.  false: the caller takes the spectrum-kernel + k_melfb route (clips too
+// long for 32-bit byte offsets, unaligned base)
+bool mel_band_usable(const zafx_plan& pl, const float* x, int64_t n_clips, int64_t n_samples, int T) {
+    return pl.log2nf == 11 && pl.d_tw_sub && pl.d_fbw && pl.prm.n_filters <= 256 && n_samples < (1LL << 29) && (long long)(T + 16) * pl.H < (1LL << 29) &&
+           (long long)n_clips * ((T + 15) / 16) < (1LL << 31) && reinterpret_cast<uintptr_t>(x) % 4 == 0;
+}
+hipError_t launch_mel_band(const zafx_plan& pl, const float* x, float* out, int64_t n_clips, int64_t n_samples, int T) {
+    using B = BandCfg;
+    const bool mfcc = pl.kind == ZAFX_MFCC;
+    const bool aligned = (n_samples % 2 == 0) && (pl.H % 2 == 0) && (reinterpret_cast<uintptr_t>(x) % 8 == 0);
+    auto kern = mfcc ? (aligned ? k_mel_ft16b<true, true> : k_mel_ft16b<false, true>) : (aligned ? k_mel_ft16b<true, false> : k_mel_ft16b<false, false>);
+    if (hipError_t e = ensure_dynamic_lds(reinterpret_cast<const void*>(kern), pl.device, B::SMEM); e != hipSuccess) return e;
+    const int tiles = (T + B::FPB - 1) / B::FPB;
+    const long long total = (long long)tiles * n_clips;
+    if (total <= 0) return hipSuccess;
+    const long long grid = std::min<long long>(total, (long long)pl.n_cus);
+    hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(B::NT), B::SMEM, pl.stream, x, pl.d_window, pl.d_tw_sub, pl.d_tw_aux, pl.d_fbw, pl.d_fbw_meta, pl.d_dctw, out,
+                       (long long)n_samples, pl.H, T, (int)row_pitch(pl, T), tiles, (int)total, pl.prm.n_filters, mfcc ? pl.prm.n_coefs : 0, pl.layout);
+    return hipGetLastError();
 }
 
 constexpr bool stft_use_tf(int log2n, int layout) {

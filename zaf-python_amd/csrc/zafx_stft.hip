@@ -1576,6 +1576,7 @@ __global__ __launch_bounds__(1024) void k_istft_ft16(
             r[2] = ld(src, (N - k) * row_bytes + fs * 8, 0);
             if (ONE) {
                 r[1] = ld(src, (k == 0 ? N / 2 : k) * row_bytes + fs * 8, 0);
+                r[3] = r[2];   // (defined, unused: fold4 completes it as a conjugate -- an element left undefined on one side of a branch sends the array to scratch)
             } else {
                 r[1] = ld(src, (k == 0 ? N / 2 : W - k) * row_bytes + fs * 8, 0);
                 r[3] = ld(src, (k == 0 ? N + N / 2 : N + k) * row_bytes + fs * 8, 0);
@@ -1586,6 +1587,9 @@ __global__ __launch_bounds__(1024) void k_istft_ft16(
             if (!ONE) {
                 r[1] = ld(src, v_down, (W - (s + 1) * KSTEP) * row_bytes);
                 r[3] = ld(src, v_up, (N + s * KSTEP) * row_bytes);
+            } else {
+                r[1] = r[0];
+                r[3] = r[2];
             }
         }
     };

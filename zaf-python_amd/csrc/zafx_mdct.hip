@@ -634,6 +634,189 @@ __global__ __launch_bounds__(MdctBandCfg::NT) void k_mdct_ft32b(
 }
 
 // ---------------------------------------------------------------------------------
+// forward, reference layout, W = 4096, rows that are not whole (half) lines: one band per workgroup + register carry (k_mdct_ft32bc)
+// ---------------------------------------------------------------------------------
+// As k_stft_ft16bc: the two bands of k_mdct_ft32b never meet, so a workgroup owns ONE band of a clip segment (units (segment, band 0 / 1)
+// are neighbours in the XCD order: both fold every sample, L2 serves the second reader), walks the segment's 32-frame tiles in order and
+// carries its 16 row pairs of the previous tile in 32 VGPRs -- the registers k_mdct_ft32b spends on the waiting band -- exactly as
+// k_mdct_ft32<CARRY> does: for a row whose run starts a floats into a line the lanes tp < 16 - a / 2 store the current pair at frame
+// t0 + 2 tp, the others the carried pair at t0 - 32 + 2 tp (odd T: the two floats of a lane choose for themselves, 4-byte stores).
+__global__ __launch_bounds__(MdctBandCfg::NT) void k_mdct_ft32bc(
+    const float* __restrict__ x, const float4* __restrict__ wfold, const float2* __restrict__ twp, const float2* __restrict__ band_tw,
+    float* __restrict__ out, long long n_samples, int T, int TP, int tiles, int segs, int seg_tiles, int units) {
+    using G = MdctBandCfg;
+    using C = G::C;
+    constexpr int NF = G::NF, HB = G::HB, M = G::M, P = 64, E = 8, FPB = G::FPB, NSLOT = G::NSLOT, NT = G::NT, FPW = FPB / NSLOT;
+    constexpr int ITER = HB / 32;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    float2* frames = reinterpret_cast<float2*>(smem_raw);
+    float2* tw_l = frames + FPB * C::PITCH;
+    float2* gb_l = tw_l + C::TW;   // gb[s][q] = g[2 q + s]
+    float2* bt_l = gb_l + NF;      // bt[n] = g[n] exp(-2 pi i n / 1024), n < 512
+    const int tid = threadIdx.x;
+    for (int i = tid; i < C::TW; i += NT) tw_l[i] = twp[i];
+    for (int i = tid; i < NF + HB; i += NT) gb_l[i] = band_tw[i];
+    lds_barrier();
+    const int slot = __builtin_amdgcn_readfirstlane(tid / P), p = tid % P;   // (the wave's frame slot is a scalar: its buffer addresses and frame indices stay in SGPRs)
+    const bool xcd = ZAFX_XCD_ORDER && gridDim.x % 8 == 0;
+    auto frame_of = [&](int f) { return f * NSLOT + slot; };
+    float4 q[8];
+    auto fetch = [&](int clip, int tile, int h) {   // half frame h = 2 f + r of a tile: the groups u = p + 64 r and 255 - u (k_mdct_ft32b)
+        const int t = tile * FPB + frame_of(h >> 1);
+        const float* xc = x + (long long)clip * n_samples;
+        const __amdgpu_buffer_rsrc_t rs = make_rsrc(xc, (unsigned)(n_samples * 4));
+        int pp = p;   // (opaque: the per-lane byte offsets are recomputed per request, not carried across the tile)
+        asm volatile("" : "+v"(pp));
+        const int u = pp + (h & 1) * P;
+        const int s0 = (t - 1) * M * 4;
+        const int fw = s0 + 16 * u, bw = s0 - 16 - 16 * u;
+        q[0] = buf_load_f32x4(rs, fw + 12 * NF);
+        q[1] = buf_load_f32x4(rs, bw + 12 * NF);
+        q[2] = buf_load_f32x4(rs, fw + 4 * NF);
+        q[3] = buf_load_f32x4(rs, bw + 4 * NF);
+        q[4] = buf_load_f32x4(rs, bw + 16 * NF);
+        q[5] = buf_load_f32x4(rs, fw + 8 * NF);
+        q[6] = buf_load_f32x4(rs, bw + 8 * NF);
+        q[7] = buf_load_f32x4(rs, fw);
+    };
+    auto fold = [&](float2* buf, int r, int band) {   // one half frame: this band only -> the frame buffer (natural order)
+        int opaque = 0;
+        asm volatile("" : "+v"(opaque));
+        const int u = p + r * P + opaque;
+        const int m0 = 2 * u, m1 = 2 * u + 1, m2 = NF - 1 - 2 * u, m3 = NF - 2 - 2 * u;
+        const int n0 = HB - 2 - 2 * u, n1 = HB - 1 - 2 * u;
+        const float4 A3 = q[0], R2 = q[1], A1 = q[2], R0 = q[3], B3 = q[4], S2 = q[5], B1 = q[6], S0 = q[7];
+        const float4 w0 = wfold[m0], w1 = wfold[m1], w2 = wfold[m2], w3 = wfold[m3];
+        const float2 F0 = make_float2(R2.w * w0.x + A3.x * w0.y, R0.w * w0.z + A1.x * w0.w);
+        const float2 F1 = make_float2(R2.y * w1.x + A3.z * w1.y, R0.y * w1.z + A1.z * w1.w);
+        const float2 F2 = make_float2(R0.z * w2.x + A1.y * w2.y, R2.z * w2.z + A3.y * w2.w);
+        const float2 F3 = make_float2(R0.x * w3.x + A1.w * w3.y, R2.x * w3.z + A3.w * w3.w);
+        __builtin_amdgcn_sched_barrier(0);
+        const float4 v0 = wfold[n0], v1 = wfold[n1], v2 = wfold[m1 + HB], v3 = wfold[m0 + HB];
+        const float2 G0 = make_float2(S2.w * v0.x + B3.x * v0.y, S0.w * v0.z + B1.x * v0.w);
+        const float2 G1 = make_float2(S2.y * v1.x + B3.z * v1.y, S0.y * v1.z + B1.z * v1.w);
+        const float2 G2 = make_float2(S0.z * v2.x + B1.y * v2.y, S2.z * v2.z + B3.y * v2.w);
+        const float2 G3 = make_float2(S0.x * v3.x + B1.w * v3.y, S2.x * v3.z + B3.w * v3.w);
+        const float h = 0.70710678118654752440f;
+        auto one = [&](int n, float2 lo, float2 hi) {
+            const float2 d = cmulk(hi, h, -h);   // F[n + 512] exp(-i pi / 4)
+            buf[phys(n)] = band ? cmul(csub(lo, d), bt_l[n]) : cmul(cadd(lo, d), gb_l[(n & 1) * HB + (n >> 1)]);
+        };
+        one(m0, F0, G3);
+        one(m1, F1, G2);
+        one(n0, G0, F3);
+        one(n1, G1, F2);
+    };
+    auto unit_of = [&](int v, int& clip, int& band, int& j, int& j1) {
+        const int u = xcd ? xcd_order(v, units) : v;
+        band = u & 1;
+        const int sg = u >> 1;
+        clip = sg / segs;
+        j = (sg % segs) * seg_tiles;
+        j1 = min(j + seg_tiles, tiles);
+    };
+    int v = blockIdx.x;
+    if (v >= units) return;
+    int clip, band, j, j1;
+    unit_of(v, clip, band, j, j1);
+    float cva[ITER], cvb[ITER];   // the thread's pairs of the previous tile
+#pragma unroll
+    for (int i = 0; i < ITER; ++i) cva[i] = cvb[i] = 0.f;
+    bool have_prev = false;
+    fetch(clip, j, 0);
+    // the walk's next tile (recomputed where it is needed -- for the request of its first half frame and at the end of the tile -- instead of
+    // kept across the folds and transforms: at 128 VGPRs the kernel spilled six registers, and a scratch reload waits for every load in flight)
+    auto next_of = [&](int& nclip, int& nband, int& nj, int& nj1, int& nv) -> bool {
+        nclip = clip, nband = band, nj = j + 1, nj1 = j1, nv = v;
+        if (nj >= j1) {
+            nv = v + gridDim.x;
+            if (nv >= units) return false;
+            unit_of(nv, nclip, nband, nj, nj1);
+        }
+        return true;
+    };
+    for (;;) {
+        int po = p;
+        asm volatile("" : "+v"(po));
+#pragma unroll
+        for (int f = 0; f < FPW; ++f) {
+            float2* buf = frames + frame_of(f) * C::PITCH;
+#pragma unroll
+            for (int r = 0; r < 2; ++r) {
+                fold(buf, r, band);
+                const int h = 2 * f + r + 1;
+                if (h < 2 * FPW) {
+                    fetch(clip, j, h);
+                } else {
+                    int nclip, nband, nj, nj1, nv;
+                    if (next_of(nclip, nband, nj, nj1, nv)) fetch(nclip, nj, 0);
+                }
+            }
+            frame_sync<P>();
+            float2 vv[E];
+            regs_read<9, 3>(vv, buf, po);
+            frame_sync<P>();
+            fft_frame_post<9, 3>(vv, buf, po, tw_l, gb_l + band * HB);   // the frame now holds conj(y[2q + band])
+        }
+        lds_barrier();
+        {
+            int tido = tid;
+            asm volatile("" : "+v"(tido));
+            const int tp = tido % 16, fq = tido / 16;
+            const int t0 = j * FPB, ta = t0 + 2 * tp;
+            const int e = fq & 1, qi = fq >> 1;
+            const float* pa = reinterpret_cast<const float*>(frames + (2 * tp) * C::PITCH + phys(qi)) + e;
+            const float* pb = pa + 2 * C::PITCH;
+            constexpr int DPH = 2 * (32 + 32 / 16);
+            const int f0 = e ? M - 1 - 4 * qi - 2 * band : 4 * qi + 2 * band;
+            float* o = out + (long long)clip * M * TP + ta;
+            const bool cur_ok = ta < T, last = j + 1 >= j1;
+            // phase of a row's run in its line, in floats: (array + (clip M + f) TP) mod 32
+            const int b0 = (int)((reinterpret_cast<uintptr_t>(out) >> 2) & 31), c0 = (int)(((long long)clip * M) & 31), tpm = TP & 31;
+            const bool pairs = TP % 2 == 0 && reinterpret_cast<uintptr_t>(out) % 8 == 0;
+            // (the thread's rows are 128 apart: the phase of their runs, (b0 + (c0 + f) tpm) mod 32, is the same for all sixteen)
+            const int a = (b0 + (c0 + f0) * tpm) & 31;
+            const long long dstep = (long long)(e ? -128 : 128) * TP;
+            auto sweep = [&](auto stream) {
+                constexpr bool ST = decltype(stream)::value;
+                float* dst = o + (long long)f0 * TP;
+#pragma unroll
+                for (int i = 0; i < ITER; ++i, dst += dstep) {
+                    const float va = pa[i * DPH], vb = pb[i * DPH];
+                    if (pairs) {   // (uniform) even T: a is even, a lane's pair lies in one line
+                        const bool from_prev = tp >= 16 - (a >> 1);   // (a = 0: never)
+                        const float2 val = from_prev ? make_float2(cva[i], cvb[i]) : make_float2(va, vb);
+                        if (from_prev ? have_prev : cur_ok) {
+                            if constexpr (ST) store_stream(reinterpret_cast<float2*>(dst + (from_prev ? -32 : 0)), val);
+                            else *reinterpret_cast<float2*>(dst + (from_prev ? -32 : 0)) = val;
+                        }
+                        if (last && from_prev && cur_ok) *reinterpret_cast<float2*>(dst) = make_float2(va, vb);   // tail of the segment's last run
+                    } else {
+                        // odd T: rows start at any float, a pair may straddle the line boundary: the two floats of a lane choose for themselves,
+                        // as two 4-byte stores -- two instructions of the same wave, back to back, that together cover the line (one 8-byte
+                        // store per lane at a 4-byte aligned address, with two floats only for the straddling lane: 1.38 against 1.33 ms)
+                        const bool pa_ = 2 * tp >= 32 - a, pb_ = 2 * tp + 1 >= 32 - a;
+                        if (pa_ ? have_prev : cur_ok) dst[pa_ ? -32 : 0] = pa_ ? cva[i] : va;
+                        if (pb_ ? have_prev : (ta + 1 < T)) dst[pb_ ? -31 : 1] = pb_ ? cvb[i] : vb;
+                        if (last && pa_ && cur_ok) dst[0] = va;
+                        if (last && pb_ && ta + 1 < T) dst[1] = vb;
+                    }
+                    cva[i] = va;
+                    cvb[i] = vb;
+                }
+            };
+            if (have_prev) sweep(std::true_type{});
+            else sweep(std::false_type{});
+        }
+        lds_barrier();
+        int nclip, nband, nj, nj1, nv;
+        if (!next_of(nclip, nband, nj, nj1, nv)) break;
+        have_prev = nj != 0 && nv == v;   // the walk continues inside the same segment (and band)
+        clip = nclip, band = nband, j = nj, j1 = nj1, v = nv;
+    }
+}
+
+// ---------------------------------------------------------------------------------
 // inverse
 // ---------------------------------------------------------------------------------
 // Persistent carry form (as k_istft_ft16): one workgroup per CU walks the FPB-frame tiles of a clip
@@ -1098,8 +1281,34 @@ static hipError_t run_mdct_band(const zafx_plan& pl, const float* x, float* out,
     return hipGetLastError();
 }
 
+#ifndef ZAFX_MDCT_BAND_CARRY
+#define ZAFX_MDCT_BAND_CARRY 1
+#endif
+static hipError_t run_mdct_band_carry(const zafx_plan& pl, const float* x, float* out, int64_t n_clips, int64_t n_samples, int T) {
+    using G = MdctBandCfg;
+    auto kern = k_mdct_ft32bc;
+    if (hipError_t e = ensure_dynamic_lds(reinterpret_cast<const void*>(kern), pl.device, G::SMEM); e != hipSuccess) return e;
+    const int tiles = (T + G::FPB - 1) / G::FPB;
+    if ((long long)tiles * n_clips <= 0) return hipSuccess;
+    const long long max_grid = pl.n_cus;
+    const int segs = carry_segments(2 * n_clips, tiles, max_grid);   // (two units -- one per band -- for every segment)
+    const int seg_tiles = (tiles + segs - 1) / segs;
+    const long long units = 2LL * n_clips * segs;
+    hipLaunchKernelGGL(kern, dim3((unsigned)std::min<long long>(units, max_grid)), dim3(G::NT), G::SMEM, pl.stream, x, pl.d_wfold, pl.d_tw_sub, pl.d_tw_band, out,
+                       (long long)n_samples, T, (int)row_pitch(pl, T), tiles, segs, seg_tiles, (int)units);
+    return hipGetLastError();
+}
+
 template <int LOG2NF, int LAYOUT>
 static hipError_t run_mdct(const zafx_plan& pl, const float* x, float* out, int64_t n_clips, int64_t n_samples, int T) {
+    if constexpr (ZAFX_MDCT_BAND && ZAFX_MDCT_BAND_CARRY && LOG2NF == 10 && LAYOUT == ZAFX_LAYOUT_FT) {
+        // rows that are not whole 64-byte half lines: the carry form (one band per workgroup)
+        const int64_t TP = row_pitch(pl, T);
+        if (pl.d_tw_sub && pl.d_tw_band && n_samples % 4 == 0 && reinterpret_cast<uintptr_t>(x) % 16 == 0 && n_samples < (1LL << 28) &&
+            (TP % 16 != 0 || reinterpret_cast<uintptr_t>(out) % 64 != 0) && reinterpret_cast<uintptr_t>(out) % 4 == 0 &&
+            2LL * n_clips * ((T + 31) / 32) < (1LL << 30) && (long long)n_clips * 2048 * TP < (1LL << 40))
+            return run_mdct_band_carry(pl, x, out, n_clips, n_samples, T);
+    }
     if constexpr (ZAFX_MDCT_BAND && LOG2NF == 10 && LAYOUT == ZAFX_LAYOUT_FT) {
         // W = 4096, reference layout: 32-frame tiles in two bands of bins (16-byte buffer loads: clips of a multiple of four samples)
         if (pl.d_tw_sub && pl.d_tw_band && n_samples % 4 == 0 && reinterpret_cast<uintptr_t>(x) % 16 == 0 && n_samples < (1LL << 28) &&

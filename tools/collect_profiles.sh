@@ -9,7 +9,7 @@ REPO=$PWD
 OUT=$REPO/gpurun_out
 mkdir -p "$OUT"
 export TMPDIR=/tmp
-KINDS=${KINDS:-"stft istft mdct imdct mel mfcc cqt dct stft_offgrid stft4096_h1024 mdct4096"}   # KINDS="stft" re-collects the headline only
+KINDS=${KINDS:-"stft istft mdct imdct mel mfcc cqt dct stft_offgrid stft4096 stft4096_h1024 istft4096 mdct4096"}   # KINDS="stft" re-collects the headline only
 timeout 900 python bench.py --gpus 1 --steps 20 --warmup 5 > "$OUT/bench_all.json" 2> "$OUT/bench_all.log"   # the driver's own command: every config in one line
 for k in $KINDS; do
   timeout 300 python bench.py --kind $k --no-cpu-baseline > "$OUT/bench_$k.json" 2> "$OUT/bench_$k.log"

@@ -12,7 +12,7 @@ import sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 OUT, PROF = os.path.join(ROOT, "gpurun_out"), os.path.join(ROOT, "profiles")
 tag = sys.argv[1] if len(sys.argv) > 1 else "r03"
-KINDS = ["stft", "istft", "mdct", "imdct", "mel", "mfcc", "cqt", "dct", "stft_offgrid", "stft4096_h1024", "mdct4096"]
+KINDS = ["stft", "istft", "mdct", "imdct", "mel", "mfcc", "cqt", "dct", "stft_offgrid", "stft4096", "stft4096_h1024", "istft4096", "mdct4096"]
 
 
 def find(pattern):

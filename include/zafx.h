@@ -97,7 +97,7 @@ enum zafx_constant {
 typedef struct zafx_params {
     int32_t struct_size;       /* = sizeof(zafx_params)                                         */
     int32_t window_length;     /* W, power of two, 64..8192 (STFT family, MDCT family, float32 MEL / MFCC), or --
-                                  ZAFX_STFT / ZAFX_ISTFT / ZAFX_MDCT / ZAFX_IMDCT -- any other length 33..8192 (MDCT family: even):
+                                  ZAFX_STFT / ZAFX_ISTFT / ZAFX_MEL / ZAFX_MFCC / ZAFX_MDCT / ZAFX_IMDCT -- any other length 33..8192 (MDCT family: even):
                                   those run as float32 Bluestein convolutions (np.fft takes any length, so does the reference).
                                   With ZAFX_PRECISION_F64 any length 2..2048 (MDCT family: even, 4..2048), every kind            */
     int32_t step_length;       /* hop H >= 1 (STFT/MEL/MFCC: any, also above W as zaf.stft allows; ISTFT: H <= W and

@@ -1184,6 +1184,29 @@ def test_mel_long_window_or_wide_bank(zafx, wl, hop, nmel):
     assert one.dtype == np.float64 and relerr(one, orc.melspectrogram(x[0].astype(np.float64), w, hop, fb)) <= TOL_FB
 
 
+@pytest.mark.parametrize("fs,wl,hop,nmel,n", [(16000, 400, 160, 80, 48000), (44100, 1764, 441, 128, 60001), (44100, 3000, 1500, 64, 70000),
+                                              (16000, 402, 160, 40, 20000), (8000, 200, 80, 23, 9999), (44100, 6000, 2000, 256, 50000)])
+def test_mel_window_not_a_power_of_two(zafx, fs, wl, hop, nmel, n):
+    """melspectrogram / mfcc with windows that are not a power of two (the 25 ms / 10 ms framing of speech front ends: 400 / 160
+    samples at 16 kHz) run in float32: the Bluestein STFT's magnitude / power kind into the plan's scratch + k_melfb; they ran on the
+    float64 kernel.  zaf.py:369-373, :436-452."""
+    x = np.stack([synth_clip(71, c, n) for c in range(3)])
+    w = zafx.hamming(wl)
+    fb = zafx.melfilterbank(fs, wl, nmel)
+    plan = zafx.mel_plan(w, hop, fb)
+    assert plan.kernel_name == "k_melfb" and plan.in_dtype == np.float32
+    mel = zafx.melspectrogram_batch(x, w, hop, fb)
+    cep = zafx.mfcc_batch(x, w, hop, fb, 13)
+    mel_tf = zafx.melspectrogram_batch(x, w, hop, fb, layout="TF")
+    assert mel.dtype == np.float32 and np.array_equal(mel_tf.transpose(0, 2, 1), mel)
+    for c in range(3):
+        x64 = x[c].astype(np.float64)
+        assert relerr(mel[c], orc.melspectrogram(x64, w, hop, fb)) <= TOL_FB, c
+        assert relerr(cep[c], orc.mfcc(x64, w, hop, fb, 13)) <= TOL_FB, c
+    one = zafx.mfcc(x[0], w, hop, fb, 13)
+    assert one.dtype == np.float64 and relerr(one, orc.mfcc(x[0].astype(np.float64), w, hop, fb, 13)) <= TOL_FB
+
+
 @pytest.mark.parametrize("wl", [8192, 4096])
 def test_mel_long_window_in_chunks(zafx, wl):
     """k_melfb's scratch holds a chunk of clips (256 MB): 1200 short clips at W = 8192 go through it in two chunks;

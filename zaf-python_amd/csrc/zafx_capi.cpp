@@ -287,7 +287,7 @@ static int finalize_constant(zafx_plan* pl, int which) {
                 ZAFX_HIP(upload(&pl->d_fb64_meta, meta.data(), meta.size() * sizeof(int)));
                 return 0;
             }
-            if (pl->log2nf >= 11) {   // W = 4096 / 8192 (k_melfb): rows as float32 bands
+            if (pl->log2nf >= 11 || pl->bs_log2m > 0) {   // W = 4096 / 8192, windows that are not a power of two (k_melfb): rows as float32 bands
                 const int rows = pl->prm.n_filters, cols = pl->W / 2;
                 std::vector<int> meta((size_t)rows * 3, 0);
                 std::vector<float> vals;
@@ -320,7 +320,7 @@ static int finalize_constant(zafx_plan* pl, int which) {
                 ZAFX_HIP(upload(&pl->d_dct64, pl->h_dct64.data(), pl->h_dct64.size() * sizeof(double)));
                 return 0;
             }
-            if (pl->log2nf >= 11) {   // W = 4096 / 8192 (k_melfb): dense rows
+            if (pl->log2nf >= 11 || pl->bs_log2m > 0) {   // W = 4096 / 8192, windows that are not a power of two (k_melfb): dense rows
                 ZAFX_HIP(upload(&pl->d_dctw, pl->h_dct.data(), pl->h_dct.size() * sizeof(float)));
                 return 0;
             }
@@ -584,11 +584,12 @@ int zafx_plan_create(zafx_plan** out, int device, int kind, const zafx_params* p
             // any length up to 2048 in the float64 mode: Bluestein convolution of length 2^bs_log2m >= 2 W - 1
             while ((1 << pl->bs_log2m) < 2 * pl->W - 1) ++pl->bs_log2m;
             lw = 6;   // (only sizes the unused float32 tables below)
-        } else if (lw < 0 && params->precision == ZAFX_PRECISION_F32 && (kind == ZAFX_STFT || kind == ZAFX_ISTFT) && bs32_supported(pl->W)) {
-            while ((1 << pl->bs_log2m) < 2 * pl->W - 1) ++pl->bs_log2m;   // float32 Bluestein forms (zafx_bs32.hip)
+        } else if (lw < 0 && params->precision == ZAFX_PRECISION_F32 && bs32_supported(pl->W)) {
+            // float32 Bluestein forms (zafx_bs32.hip); MEL / MFCC: the Bluestein STFT's magnitude / power kind + k_melfb (run_mel_wide)
+            while ((1 << pl->bs_log2m) < 2 * pl->W - 1) ++pl->bs_log2m;
             lw = 6;
         } else if (lw < 0 || !stft_supported(lw - 1)) {
-            return bail("window_length must be a power of two in [64, 8192], or any length in [33, 8192] for ZAFX_STFT / ZAFX_ISTFT "
+            return bail("window_length must be a power of two in [64, 8192] or any other length in [33, 8192] "
                         "(any length in [2, 2048] with ZAFX_PRECISION_F64)");
         }
         if (pl->H < 1) return bail("step_length must be >= 1");
@@ -721,7 +722,8 @@ int zafx_plan_create(zafx_plan** out, int device, int kind, const zafx_params* p
             }
             if (e == hipSuccess) e = upload(&pl->d_tw_aux, pp.data(), pp.size() * sizeof(cf32));
         }
-        pl->kernel_name = kind == ZAFX_STFT ? "k_stft_bs32" : kind == ZAFX_ISTFT ? "k_ifft_frames_bs32" : kind == ZAFX_MDCT ? "k_mdct_bs32" : "k_imdct_frames_bs32";
+        pl->kernel_name = kind == ZAFX_STFT ? "k_stft_bs32" : kind == ZAFX_ISTFT ? "k_ifft_frames_bs32" : kind == ZAFX_MDCT ? "k_mdct_bs32"
+                          : (kind == ZAFX_MEL || kind == ZAFX_MFCC) ? mel_wide_kernel_name() : "k_imdct_frames_bs32";
     }
     if (e == hipSuccess && pl->prm.precision == ZAFX_PRECISION_F64) {   // float64 tables, evaluated in long double
         const bool mdct = is_mdct_family(kind), cqt = is_cqt_family(kind);

@@ -104,7 +104,7 @@ typedef struct zafx_params {
                                   any: above ceil(W/H) = 16 frames (8 at W = 4096, 4 at 8192) the float32 frames +
                                   gather overlap-add form runs instead of the tiled kernel); CQT: frame step        */
     int32_t layout;            /* enum zafx_layout of the 2-D (frequency x time) side           */
-    int32_t n_filters;         /* MEL / MFCC: 1..256 (ZAFX_PRECISION_F64: 1..W/2)               */
+    int32_t n_filters;         /* MEL / MFCC: 1..576 (above 256: spectrum kernel + k_melfb; ZAFX_PRECISION_F64: 1..W/2) */
     int32_t n_coefs;           /* MFCC                                                          */
     int32_t fft_length;        /* CQT / CHROMA: power of two, 512..32768; 65536 when the kernel matrix touches the one-sided
                                   bins 1..8191 only (low-frequency kernels); ..131072 with ZAFX_PRECISION_F64 */

@@ -1159,17 +1159,17 @@ def test_cqt_short_kernel(zafx, fs, res, fmin, fmax, tr):
         zafx.cqtspectrogram_batch(x, fs, fs // (ck.shape[1] + 64), ck)
 
 
-@pytest.mark.parametrize("wl,hop,nmel", [(4096, 2048, 128), (8192, 2048, 64), (2048, 1024, 300), (4096, 1024, 40), (8192, 4096, 256), (4096, 1763, 128)])
+@pytest.mark.parametrize("wl,hop,nmel", [(4096, 2048, 128), (8192, 2048, 64), (2048, 1024, 300), (4096, 1024, 40), (8192, 4096, 256), (4096, 1763, 128), (4096, 2048, 400),
+                                         (1024, 512, 500)])
 def test_mel_long_window_or_wide_bank(zafx, wl, hop, nmel):
     """Windows of 4096 / 8192 samples are outside the fused W <= 2048 kernel.  W = 4096: k_mel_ft16b, the two-band STFT kernel with the
     filterbank product in place of the stores; W = 8192: a spectrum kernel (|X| or |X|^2 rows into a plan-owned scratch) + the
-    banded filterbank kernel k_melfb; both float32.  Filterbanks above 256 rows run on the float64 kernel and return float32
-    from the float32 entry points."""
+    banded filterbank kernel k_melfb; both float32.  Filterbanks of 257 ... 576 rows take the k_melfb route at any window."""
     x = np.stack([synth_clip(61, c, 60000 + (hop % 2)) for c in range(2)])
     w = zafx.hamming(wl)
     fb = zafx.melfilterbank(44100, wl, nmel)
     plan = zafx.mel_plan(w, hop, fb)
-    assert plan.kernel_name == {4096: "k_mel_ft16b", 8192: "k_melfb"}.get(wl, "k_mel_f64") and plan.in_dtype == (np.float32 if wl > 2048 else np.float64)
+    assert plan.kernel_name == ("k_melfb" if nmel > 256 else {4096: "k_mel_ft16b", 8192: "k_melfb"}[wl]) and plan.in_dtype == np.float32
     mel = zafx.melspectrogram_batch(x, w, hop, fb)
     cep = zafx.mfcc_batch(x, w, hop, fb, 13)
     assert mel.dtype == np.float32 and cep.dtype == np.float32

@@ -287,7 +287,7 @@ static int finalize_constant(zafx_plan* pl, int which) {
                 ZAFX_HIP(upload(&pl->d_fb64_meta, meta.data(), meta.size() * sizeof(int)));
                 return 0;
             }
-            if (pl->log2nf >= 11 || pl->bs_log2m > 0) {   // W = 4096 / 8192, windows that are not a power of two (k_melfb): rows as float32 bands
+            if (zafx::mel_takes_wide_route(*pl)) {   // W = 4096 / 8192, windows that are not a power of two, more than 256 filters (k_melfb): rows as float32 bands
                 const int rows = pl->prm.n_filters, cols = pl->W / 2;
                 std::vector<int> meta((size_t)rows * 3, 0);
                 std::vector<float> vals;
@@ -320,7 +320,7 @@ static int finalize_constant(zafx_plan* pl, int which) {
                 ZAFX_HIP(upload(&pl->d_dct64, pl->h_dct64.data(), pl->h_dct64.size() * sizeof(double)));
                 return 0;
             }
-            if (pl->log2nf >= 11 || pl->bs_log2m > 0) {   // W = 4096 / 8192, windows that are not a power of two (k_melfb): dense rows
+            if (zafx::mel_takes_wide_route(*pl)) {   // (k_melfb): dense rows
                 ZAFX_HIP(upload(&pl->d_dctw, pl->h_dct.data(), pl->h_dct.size() * sizeof(float)));
                 return 0;
             }
@@ -604,8 +604,10 @@ int zafx_plan_create(zafx_plan** out, int device, int kind, const zafx_params* p
         }
         pl->log2nf = lw - 1;
         if (kind == ZAFX_MEL || kind == ZAFX_MFCC) {
-            if (params->n_filters < 1 || (params->precision != ZAFX_PRECISION_F64 && params->n_filters > 256))
-                return bail("n_filters must be in [1, 256] (up to window_length / 2 with ZAFX_PRECISION_F64)");
+            // (float32: up to 256 rows on the fused kernels; above that the spectrum kernel + k_melfb route, whose mfcc form holds a
+            // [n_filters][64] log-mel tile in LDS: 576 rows)
+            if (params->n_filters < 1 || (params->precision != ZAFX_PRECISION_F64 && params->n_filters > 576))
+                return bail("n_filters must be in [1, 576] (up to window_length / 2 with ZAFX_PRECISION_F64)");
             if (kind == ZAFX_MFCC && (params->n_coefs < 1 || params->n_coefs > params->n_filters))
                 return bail("n_coefs must be in [1, n_filters]");
             if (params->precision == ZAFX_PRECISION_F64) {
@@ -617,7 +619,7 @@ int zafx_plan_create(zafx_plan** out, int device, int kind, const zafx_params* p
         const int n = pl->W / 2;
         aux.resize((size_t)n / 2 + 1);
         for (int k = 0; k <= n / 2; ++k) aux[(size_t)k] = unit_root(k, pl->W);
-        pl->kernel_name = kind == ZAFX_STFT ? stft_kernel_name(lw - 1, pl->layout) : kind == ZAFX_ISTFT ? istft_kernel_name(lw - 1, pl->layout) : lw - 1 == 11 ? "k_mel_ft16b" : lw - 1 >= 12 ? mel_wide_kernel_name() : mel_kernel_name();
+        pl->kernel_name = kind == ZAFX_STFT ? stft_kernel_name(lw - 1, pl->layout) : kind == ZAFX_ISTFT ? istft_kernel_name(lw - 1, pl->layout) : params->n_filters > 256 ? mel_wide_kernel_name() : lw - 1 == 11 ? "k_mel_ft16b" : lw - 1 >= 12 ? mel_wide_kernel_name() : mel_kernel_name();
     } else if (is_mdct_family(kind)) {
         pl->W = params->window_length;
         pl->H = pl->W / 2;   // zaf.py:1029

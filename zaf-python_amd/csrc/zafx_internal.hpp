@@ -183,6 +183,8 @@ hipError_t launch_mdct(const zafx_plan& pl, const float* x, float* out, int64_t 
 hipError_t launch_imdct(const zafx_plan& pl, const float* coefs, float* y, int64_t n_clips, int T, int64_t out_len);
 hipError_t launch_mel(zafx_plan& pl, const float* x, float* out, int64_t n_clips, int64_t n_samples, int T);   // (windows above 2048 samples grow the plan's scratch)
 const char* mel_wide_kernel_name();
+// mel / mfcc plans that run as a spectrum kernel + k_melfb (or, W = 4096 with up to 256 filters, the fused two-band kernel) instead of k_mel
+inline bool mel_takes_wide_route(const zafx_plan& pl) { return pl.log2nf >= 11 || pl.bs_log2m > 0 || pl.prm.n_filters > 256; }
 bool mel_band_usable(const zafx_plan& pl, const float* x, int64_t n_clips, int64_t n_samples, int T);   // W = 4096: the fused two-band kernel k_mel_ft16b (zafx_stft.hip)
 hipError_t launch_mel_band(const zafx_plan& pl, const float* x, float* out, int64_t n_clips, int64_t n_samples, int T);
 hipError_t launch_cqt(const zafx_plan& pl, const float* x, float* out, int64_t n_clips, int64_t n_samples, int T);

@@ -656,7 +656,7 @@ static hipError_t run_mel_wide(zafx_plan& pl, const float* x, float* out, int64_
     st.prm.spectrum = mfcc ? ZAFX_SPECTRUM_POWER : ZAFX_SPECTRUM_MAGNITUDE;
     st.prm.row_align = 32;
     st.W = pl.W; st.H = pl.H; st.layout = ZAFX_LAYOUT_FT; st.log2nf = pl.log2nf; st.log2e = pl.log2e;
-    st.d_window = pl.d_window; st.d_tw_pass = pl.d_tw_pass; st.d_tw_aux = pl.d_tw_aux; st.d_tw_sub = pl.d_tw_sub;
+    st.d_window = pl.d_window; st.d_tw_pass = pl.d_tw_pass; st.d_tw_aux = pl.d_tw_aux; st.d_tw_sub = pl.d_tw_sub; st.d_tw_r32 = pl.d_tw_r32;
     st.bs_log2m = pl.bs_log2m; st.d_bs_chirp = pl.d_bs_chirp; st.d_bs_bhat = pl.d_bs_bhat;   // (a window that is not a power of two: the Bluestein STFT)
     const size_t smem = mfcc ? (size_t)pl.prm.n_filters * 64 * sizeof(float) : 0;
     if (hipError_t e = ensure_dynamic_lds(reinterpret_cast<const void*>(k_melfb), pl.device, std::max<size_t>(smem, 1)); e != hipSuccess) return e;
@@ -678,7 +678,7 @@ static hipError_t run_mel_wide(zafx_plan& pl, const float* x, float* out, int64_
 const char* mel_wide_kernel_name() { return "k_melfb"; }
 
 hipError_t launch_mel(zafx_plan& pl, const float* x, float* out, int64_t n_clips, int64_t n_samples, int T) {
-    if (pl.log2nf >= 11 || pl.bs_log2m > 0) return run_mel_wide(pl, x, out, n_clips, n_samples, T);
+    if (mel_takes_wide_route(pl)) return run_mel_wide(pl, x, out, n_clips, n_samples, T);
     switch (pl.log2nf) {
         case 5: return run_mel_any<5>(pl, x, out, n_clips, n_samples, T);
         case 6: return run_mel_any<6>(pl, x, out, n_clips, n_samples, T);

@@ -658,11 +658,11 @@ def mel_plan(window_function, step_length, mel_filterbank, number_coefficients=N
     if len(w) > 8192:
         raise ValueError(f"melspectrogram / mfcc take windows of up to 8192 samples, got {len(w)}")
     # W = 4096: the fused two-band kernel; W = 8192 and windows that are not a power of two (33 ... 8192 samples: the float32 Bluestein
-    # STFT) run as a spectrum kernel + the banded filterbank kernel k_melfb over a plan-owned scratch, in float32; filterbanks above
-    # 256 rows and windows below 33 samples run on the float64 kernel (any power-of-two window and, up to 2048 samples, any other length)
-    f64 = bool(f64) or n_filters > 256 or not _f32_window(len(w))
+    # STFT) run as a spectrum kernel + the banded filterbank kernel k_melfb over a plan-owned scratch, in float32 -- as do filterbanks of 257 ... 576 rows at any
+    # window; filterbanks above 576 rows and windows below 33 samples run on the float64 kernel (any power-of-two window and, up to 2048 samples, any other length)
+    f64 = bool(f64) or n_filters > 576 or not _f32_window(len(w))
     if f64 and len(w) > 2048 and not _pow2(len(w)):
-        raise ValueError(f"melspectrogram / mfcc in float64 (f64=True, or more than 256 filters) take windows of up to 2048 samples or the powers of two 4096 and 8192, got {len(w)}")
+        raise ValueError(f"melspectrogram / mfcc in float64 (f64=True, or more than 576 filters) take windows of up to 2048 samples or the powers of two 4096 and 8192, got {len(w)}")
     # the cache key hashes the sparse triplet (a few KB), not the dense matrix (1 MB: 1.8 ms per call)
     csr = mel_filterbank.tocsr()
     key = ("mfcc" if mfcc else "mel", device, len(w), h, _LAYOUTS[layout], ncoef, n_filters, _as_row_align(row_align, layout), bool(f64),

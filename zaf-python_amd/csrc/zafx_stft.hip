@@ -756,26 +756,36 @@ __global__ __launch_bounds__(kFatWaves * 64) void k_mel_ft16b(
         const float pw = v.x * v.x + v.y * v.y;
         return MFCC ? pw : __builtin_amdgcn_sqrtf(pw);
     };
-    // a band's spectrum -> levels, in place: slot q <- bin 2 q + S (band 0: slot N <- bin M; slot 0, bin 0, is never read)
+    // a band's spectrum -> levels, in place: slot q <- bin 2 q + S (band 0: slot N <- bin M; slot 0, bin 0, is never read).  Two pairs at
+    // a time, all their reads issued before the first write (the writes go to the array the next reads come from, so the compiler cannot move
+    // those up: one pair at a time every iteration waited for its own LDS round trip), and both powers of a pair from split_pair_pow4.
     auto levels = [&](auto band) {
         constexpr int S = decltype(band)::value;
-        constexpr int ITER = (N / 2) / (NT / FPB);
+        constexpr int ITER = (N / 2) / (NT / FPB), BT = 2;
         int kqo = kq;
         asm volatile("" : "+v"(kqo));
-#pragma unroll 4
-        for (int it = 0; it < ITER; ++it) {
-            const int q = kqo + it * (NT / FPB);
-            if (S == 0 && q == 0) {
-                const float2 z0 = fbw[0], zc = fbw[phys_t<C::PS>(N / 2)];
-                fbw[phys_t<C::PS>(N)].x = MFCC ? (z0.x - z0.y) * (z0.x - z0.y) : fabsf(z0.x - z0.y);   // X[M] = Re Z[0] - Im Z[0]
-                fbw[phys_t<C::PS>(N / 2)].x = level(zc);                                                   // X[M/2] = conj Z[M/2]
-            } else {
-                float2 xk, xn;
-                float2* pk = fbw + phys_t<C::PS>(q);
-                float2* pn = fbw + phys_t<C::PS>(N - S - q);
-                split_pair(*pk, *pn, tws_l[2 * q + S], xk, xn);
-                pk->x = level(xk);
-                pn->x = level(xn);
+        if (S == 0 && kqo == 0) {   // the thread that holds q = 0 of band 0: bins M and M / 2 (its pair slots 0 / N below are bin 0 and scratch)
+            const float2 z0 = fbw[0], zc = fbw[phys_t<C::PS>(N / 2)];
+            fbw[phys_t<C::PS>(N)].x = MFCC ? (z0.x - z0.y) * (z0.x - z0.y) : fabsf(z0.x - z0.y);   // X[M] = Re Z[0] - Im Z[0]
+            fbw[phys_t<C::PS>(N / 2)].x = level(zc);                                                   // X[M/2] = conj Z[M/2]
+        }
+#pragma unroll
+        for (int it0 = 0; it0 < ITER; it0 += BT) {
+            float2 zk[BT], zn[BT], tw[BT];
+#pragma unroll
+            for (int u = 0; u < BT; ++u) {
+                const int q = kqo + (it0 + u) * (NT / FPB);
+                zk[u] = fbw[phys_t<C::PS>(q)];
+                zn[u] = fbw[phys_t<C::PS>(N - S - q)];
+                tw[u] = tws_l[2 * q + S];
+            }
+#pragma unroll
+            for (int u = 0; u < BT; ++u) {
+                const int q = kqo + (it0 + u) * (NT / FPB);
+                if (S == 0 && q == 0) continue;
+                const float2 p4 = split_pair_pow4(zk[u], zn[u], tw[u]);   // (4 |X[k]|^2, 4 |X[M - k]|^2): eight packed instructions for the pair
+                fbw[phys_t<C::PS>(q)].x = MFCC ? 0.25f * p4.x : 0.5f * __builtin_amdgcn_sqrtf(p4.x);
+                fbw[phys_t<C::PS>(N - S - q)].x = MFCC ? 0.25f * p4.y : 0.5f * __builtin_amdgcn_sqrtf(p4.y);
             }
         }
     };

@@ -116,6 +116,7 @@ def make_workload(kind, device, layout="FT"):
         fwd = zafx.stft_plan(zafx.hamming(4096), 2048, device=device)
         d_s = zafx.DeviceBuffer(fwd.out_shape(B, N), np.complex64, device)
         fwd.execute(d_x, d_s, B, N)
+        INNER_LOG.append({"kind": None, "kernel": fwd.kernel_name, "launches": 1})
         fwd.sync()
         d_x.free()
         plan = zafx.istft_plan(zafx.hamming(4096), 2048, device=device)
@@ -144,6 +145,7 @@ def make_workload(kind, device, layout="FT"):
         fwd = zafx.stft_plan(ham, H, device=device, onesided=True)
         d_s = zafx.DeviceBuffer(fwd.out_shape(B, N), np.complex64, device)
         fwd.execute(d_x, d_s, B, N)
+        INNER_LOG.append({"kind": None, "kernel": fwd.kernel_name, "launches": 1})
         fwd.sync()
         d_x.free()
         plan = zafx.istft_plan(ham, H, device=device, onesided=True)
@@ -153,6 +155,7 @@ def make_workload(kind, device, layout="FT"):
         fwd = zafx.stft_plan(ham, H, device=device)
         d_s = zafx.DeviceBuffer(fwd.out_shape(B, N), np.complex64, device)
         fwd.execute(d_x, d_s, B, N)
+        INNER_LOG.append({"kind": None, "kernel": fwd.kernel_name, "launches": 1})
         fwd.sync()
         d_x.free()
         plan = zafx.istft_plan(ham, H, device=device)
@@ -170,6 +173,7 @@ def make_workload(kind, device, layout="FT"):
         fwd = zafx.mdct_plan(kbd, device=device)
         d_m = zafx.DeviceBuffer(fwd.out_shape(B, N), np.float32, device)
         fwd.execute(d_x, d_m, B, N)
+        INNER_LOG.append({"kind": None, "kernel": fwd.kernel_name, "launches": 1})
         fwd.sync()
         d_x.free()
         plan = zafx.mdct_plan(kbd, device=device, inverse=True)
@@ -454,7 +458,7 @@ def time_workload(wl, steps, warmup, rdzv):
         if rdzv is not None:
             rdzv.barrier()
 
-    prewarm(plan, wl["d_in"], wl["d_out"], B, n_in)   # time-based, untimed, in front of the contract's warm-up
+    n_pre = prewarm(plan, wl["d_in"], wl["d_out"], B, n_in)   # time-based, untimed, in front of the contract's warm-up
     for _ in range(warmup):
         plan.execute(wl["d_in"], wl["d_out"], B, n_in)
     sync_all()
@@ -477,56 +481,84 @@ def time_workload(wl, steps, warmup, rdzv):
         per_rank = [struct.unpack("<d", b)[0] for b in rdzv.all_gather(struct.pack("<d", kernel_ms))]
         vals = rdzv.all_reduce_max(vals)   # (-min: the MAX over ranks of -min is the smallest step anywhere)
     return {"elapsed_s": vals[0], "kernel_ms": vals[1], "kernel_ms_min": -vals[2], "kernel_ms_median": vals[3],
-            "kernel_ms_per_rank": [round(v, 4) for v in per_rank]}
+            "kernel_ms_per_rank": [round(v, 4) for v in per_rank],
+            "segments": [["prewarm", n_pre], ["warmup", warmup], ["timed", steps], ["each", steps]]}
 
 
-def live_traffic(kind, kernel_name):
-    """HBM bytes per launch of the dominant kernel, measured NOW: two separate `rocprofv3 --pmc` passes (FETCH_SIZE, WRITE_SIZE:
-    the TCC block cannot count both in one pass) of this script with --steps 3, corrected as MI355X_MICROARCH.md prescribes
-    (gfx950 tallies the 128-byte requests of streaming reads at 64 bytes: FETCH_SIZE x 2; WRITE_SIZE as counted -- both checked
-    on the device-to-device copies of the same run, whose byte count is known).  None when rocprofv3 is not there or fails."""
+INNER_LOG = []   # {"kind", "kernel", "launches", "segments"} in launch order, written to $ZAFX_BENCH_INNER_LOG (profiled runs: which dispatches were the timed ones)
+
+
+def live_traffic(kinds):
+    """HBM bytes per launch of every kind's dominant kernel, measured NOW: two separate `rocprofv3 --pmc` passes (FETCH_SIZE,
+    WRITE_SIZE: the TCC block cannot count both in one pass) of this script with --steps 3 over the same kinds, corrected as
+    MI355X_MICROARCH.md prescribes (gfx950 tallies the 128-byte requests of streaming reads at 64 bytes: FETCH_SIZE x 2;
+    WRITE_SIZE as counted -- both checked on the device-to-device copies of the same run, whose byte count is known).  The
+    inner run logs its launches in order (kind, kernel, count); the counter rows are dealt to the kinds in that order, so two
+    kinds that share a kernel (mel / mfcc) stay apart.  {kind: {...}}; {} when rocprofv3 is not there or fails."""
     import csv
     import glob
     import shutil
     import tempfile
     exe = shutil.which("rocprofv3") or ("/opt/rocm/bin/rocprofv3" if os.path.exists("/opt/rocm/bin/rocprofv3") else None)
     if exe is None or os.environ.get("ZAFX_BENCH_LIVE_TRAFFIC", "1") == "0":
-        return None
+        return {}
     if any(k.startswith("ROCPROF") for k in os.environ) or "rocprofiler" in os.environ.get("LD_PRELOAD", ""):
-        return None   # this process is being profiled itself: no profiler inside a profiler
-    out = {}
+        return {}   # this process is being profiled itself: no profiler inside a profiler
+    out = {k: {} for k in kinds}
     work = tempfile.mkdtemp(prefix="zafx_pmc_", dir="/tmp")
     try:
         for counter in ("FETCH_SIZE", "WRITE_SIZE"):
             d = os.path.join(work, counter)
-            env = dict(os.environ, TMPDIR="/tmp", ZAFX_BENCH_INNER="1")
+            log = os.path.join(work, counter + ".log")
+            env = dict(os.environ, TMPDIR="/tmp", ZAFX_BENCH_INNER="1", ZAFX_BENCH_INNER_LOG=log)
             cmd = [exe, "--pmc", counter, "--kernel-trace", "--output-format", "csv", "-d", d, "-o", "p", "--",
-                   sys.executable, os.path.abspath(__file__), "--kind", kind, "--steps", "3", "--warmup", "1", "--no-cpu-baseline"]
-            subprocess.run(cmd, cwd="/tmp", env=env, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=90, check=True)
+                   sys.executable, os.path.abspath(__file__), "--kind", ",".join(kinds), "--steps", "3", "--warmup", "1", "--no-cpu-baseline"]
+            subprocess.run(cmd, cwd="/tmp", env=env, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=300, check=True)
             files = glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True)
             if not files:
-                return None
-            acc = {}
+                return {}
+            rows = []
             with open(files[0]) as fh:
                 for r in csv.DictReader(fh):
                     if r.get("Counter_Name") == counter:
-                        v = acc.setdefault(r["Kernel_Name"].split("(")[0], [0, 0.0])
-                        v[0] += 1
-                        v[1] += float(r["Counter_Value"])
-            kern = next((k for k in acc if kernel_name in k), None)
-            if kern is None:
-                return None
-            out[counter] = acc[kern][1] / acc[kern][0] * 1024.0   # KB -> bytes, mean over the dispatches
-            out[counter + "_dispatches"] = acc[kern][0]
-            copy = next((k for k in acc if "copyBuffer" in k), None)
-            if copy:   # make_workload replicates blocks of 8 clips device to device: a dispatch of known size
-                out[counter + "_true_over_counter_on_copy"] = round(441000 * 4 * 8 / (acc[copy][1] / acc[copy][0] * 1024.0), 4)
+                        rows.append((int(r.get("Dispatch_Id", len(rows))), r["Kernel_Name"].split("(")[0], float(r["Counter_Value"])))
+            rows.sort()
+            with open(log) as fh:
+                launches = json.load(fh)
+            pos = 0
+            for ent in launches:
+                got = []
+                while len(got) < ent["launches"] and pos < len(rows):
+                    if ent["kernel"] in rows[pos][1]:
+                        got.append(rows[pos][2])
+                    pos += 1
+                if ent["kind"] in out and got:
+                    out[ent["kind"]][counter] = sum(got) / len(got) * 1024.0   # KB -> bytes, mean over the dispatches
+                    out[ent["kind"]][counter + "_dispatches"] = len(got)
+            copies = [v for _, k, v in rows if "copyBuffer" in k]
+            if copies:   # make_workload replicates blocks of 8 clips device to device: dispatches of known size
+                true = [441000 * 4 * 8, 1323000 * 4 * 8]
+                ratios = sorted({round(min(true, key=lambda t: abs(t / (v * 1024.0) - 1.0)) / (v * 1024.0), 3) for v in copies if v > 0})
+                out["_copy_check"] = dict(out.get("_copy_check", {}), **{counter + "_true_over_counter": ratios[:6]})
     except Exception as exc:   # reported, never fatal
-        return {"error": f"{type(exc).__name__}: {exc}"[:300]}
+        return {"_error": f"{type(exc).__name__}: {exc}"[:300]}
     finally:
         shutil.rmtree(work, ignore_errors=True)
-    out["hbm_bytes_per_launch"] = out["FETCH_SIZE"] * 2.0 + out["WRITE_SIZE"]
+    for k in kinds:
+        if "FETCH_SIZE" in out[k] and "WRITE_SIZE" in out[k]:
+            out[k]["hbm_bytes_per_launch"] = out[k]["FETCH_SIZE"] * 2.0 + out[k]["WRITE_SIZE"]
     return out
+
+
+def apply_live_traffic(entry, live):
+    """roofline.traffic of one entry from this run's counters."""
+    roof = entry["roofline"]
+    if live and "hbm_bytes_per_launch" in live:
+        roof["traffic"] = round(live["hbm_bytes_per_launch"])
+        roof["traffic_source"] = ("measured in this run: two rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE) of `bench.py --steps 3` over the same "
+                                  "kinds, started by this script; FETCH_SIZE x 2 + WRITE_SIZE (MI355X_MICROARCH.md, HBM section)")
+        roof["traffic_detail"] = {k: (round(v) if isinstance(v, float) and v > 10 else v) for k, v in live.items()}
+        roof["traffic_over_algorithmic"] = round(live["hbm_bytes_per_launch"] / roof["algorithmic_bytes_per_launch"], 4)
 
 
 def roofline_of(wl, tm, kind):
@@ -542,16 +574,6 @@ def roofline_of(wl, tm, kind):
             rec = json.load(f)
         roof["traffic"] = rec.get("hbm_bytes_per_launch")
         roof["traffic_source"] = f"profiles/pmc_{kind}.json ({rec.get('collected', 'separate rocprofv3 --pmc passes')}); not measured in this run"
-    if kind == "stft" and os.environ.get("ZAFX_BENCH_INNER") != "1" and wl.get("live_traffic", False):
-        live = live_traffic(kind, wl["plan"].kernel_name)
-        if live and "hbm_bytes_per_launch" in live:
-            roof["traffic"] = round(live["hbm_bytes_per_launch"])
-            roof["traffic_source"] = ("measured in this run: two rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE) of `bench.py --kind stft --steps 3` "
-                                      "started by this script; FETCH_SIZE x 2 + WRITE_SIZE (MI355X_MICROARCH.md, HBM section)")
-            roof["traffic_detail"] = {k: (round(v) if isinstance(v, float) and v > 10 else v) for k, v in live.items()}
-            roof["traffic_over_algorithmic"] = round(live["hbm_bytes_per_launch"] / wl["bytes_per_launch"], 4)
-        elif live:
-            roof["traffic_live_error"] = live.get("error")
     if wl["flops_per_launch"]:
         # configs 3 and 5 (and the dct GEMM) are bound by f32 arithmetic (vector and f32-MFMA peaks are both
         # 157.3 TF), not by HBM; both fractions are reported side by side
@@ -625,15 +647,17 @@ def run_kind(kind, args, device, rank, world, rdzv, comm, with_cpu):
             # every rank has already built identical constants from the same deterministic host code, so the measurement
             # stands; the failure is carried into the line (main() turns it into a non-zero exit)
             bcast = f"FAILED ({exc}); every rank built its own constants"
-    wl["live_traffic"] = world == 1 and kind == "stft" and args.kind == "all"
     tm = time_workload(wl, args.steps, args.warmup, rdzv)
     tm["broadcast_s"] = bcast_s
+    inner = os.environ.get("ZAFX_BENCH_INNER") == "1"
+    INNER_LOG.append({"kind": kind, "kernel": wl["plan"].kernel_name, "launches": sum(n for _, n in tm["segments"]), "segments": tm["segments"],
+                      "kernel_ms": tm["kernel_ms"]})
     entry = None
     if rank == 0:
         total = float(wl["n_clips"]) * wl["samples_per_clip"] * world * args.steps
         entry = {"workload": wl["desc"], "value": round(total / tm["elapsed_s"] / 1e6, 1), "unit": "Msamples/s",
                  "ms_per_step": round(tm["elapsed_s"] / args.steps * 1e3, 4), "roofline": roofline_of(wl, tm, kind),
-                 "parity": parity_probe(wl), "constants_broadcast": bcast}
+                 "parity": {} if inner else parity_probe(wl), "constants_broadcast": bcast}
         if world > 1 or comm is not None:
             entry["kernel_ms_per_rank"] = tm["kernel_ms_per_rank"]
             entry["constants_broadcast_wall_s"] = None if bcast_s is None else round(bcast_s, 4)
@@ -647,6 +671,94 @@ def run_kind(kind, args, device, rank, world, rdzv, comm, with_cpu):
     info = {k: wl[k] for k in ("n_clips", "samples_per_clip", "desc")}
     free_workload(wl)
     return entry, tm, info
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# the contract line: ONE compact JSON line, printed last, small enough that a record keeping only the tail of stdout
+# still holds every BASELINE config (round 3's 18.8 KB line lost configs 3-5); everything else goes to bench_detail.json
+# ---------------------------------------------------------------------------------------------------------------
+LINE_LIMIT = 7000
+_ROOF_KEEP = ("bound", "achieved", "peak", "unit", "frac", "traffic", "traffic_over_algorithmic", "kernel", "kernel_ms", "kernel_ms_median")
+
+
+def _r(v, nd=4):
+    return round(v, nd) if isinstance(v, float) else v
+
+
+def compact_roofline(roof):
+    out = {k: _r(roof[k]) for k in _ROOF_KEEP if k in roof}
+    if isinstance(out.get("traffic"), float):
+        out["traffic"] = round(out["traffic"])
+    if "hbm" in roof:   # kinds priced against the f32 peak carry their HBM fraction beside it
+        out["hbm_frac"] = roof["hbm"]["frac"]
+    return out
+
+
+def compact_parity(par):
+    out = {}
+    for k in ("max_rel_err_vs_numpy", "roundtrip_max_abs_residual"):
+        if k in par:
+            out[{"max_rel_err_vs_numpy": "max_rel_err", "roundtrip_max_abs_residual": "roundtrip_max_abs"}[k]] = float(f"{par[k]:.3g}")
+    for k in ("tolerance", "within_tolerance"):
+        if k in par:
+            out[k] = par[k]
+    return out
+
+
+def compact_entry(e):
+    out = {"ms_per_step": e["ms_per_step"], "value": e["value"]}
+    if "roofline" in e:
+        out["roofline"] = compact_roofline(e["roofline"])
+    if e.get("parity"):
+        out["parity"] = compact_parity(e["parity"])
+    if "residual_max_abs" in e:
+        out["residual_max_abs"] = float(f"{e['residual_max_abs']:.3g}") if e["residual_max_abs"] is not None else None
+    if "cpu_baseline" in e:
+        out["cpu_baseline"] = {"value": e["cpu_baseline"]["value"], "cores": e["cpu_baseline"]["cores"]}
+    return out
+
+
+def compact_line(full):
+    """The one line the driver reads, from the full record: contract keys, the headline's roofline / cpu_baseline /
+    parity, one [ms, frac] pair per extra geometry, and -- LAST -- every BASELINE config with its own roofline, parity
+    and cpu_baseline.  No prose beyond the names the contract asks for."""
+    out = {k: full[k] for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+                                "vs_baseline", "dtype") if k in full}
+    out["data"] = "synthetic white noise f32 (default_rng([0,c]).standard_normal); 8 distinct clips replicated on device to 1024 per GPU"
+    cfg = full["config"]
+    out["config"] = {k: cfg[k] for k in ("workload", "clips_per_gpu", "samples_per_clip", "parallelism", "layout") if k in cfg}
+    pl = cfg.get("placement")
+    if isinstance(pl, dict) and "survey_probe_ms" in pl:
+        out["config"]["placement_survey_ms"] = pl["survey_probe_ms"]
+    out["roofline"] = compact_roofline(full["roofline"])
+    if "cpu_baseline" in full:
+        cb = full["cpu_baseline"]
+        out["cpu_baseline"] = {"value": cb["value"], "unit": cb["unit"], "cores": cb["cores"], "kind": cb["kind"], "sample": cb["sample"][:160]}
+        out["speedup_vs_cpu_baseline"] = full.get("speedup_vs_cpu_baseline")
+    ac = full.get("cpu_baseline_all_cores")
+    if ac and "value" in ac:
+        out["cpu_baseline_all_cores"] = {"value": ac["value"], "cores": ac["cores"]}
+    if full.get("parity"):
+        out["parity"] = compact_parity(full["parity"])
+    pc = full.get("end_to_end_pcie")
+    if pc and "value" in pc:
+        out["end_to_end_pcie"] = {k: (v["value"] if isinstance(v, dict) else v) for k, v in pc.items() if k not in ("unit",)}
+    if "rccl" in full:
+        out["rccl"] = full["rccl"]
+    if "error" in full:
+        out["error"] = full["error"][:300]
+    out["detail"] = full.get("detail", "bench_detail.json")
+    if full.get("extras"):   # [ms_per_step, roofline.frac, kernel]
+        out["extras"] = {k: [e["ms_per_step"], e["roofline"]["frac"], e["roofline"]["kernel"]] for k, e in full["extras"].items()}
+    if full.get("configs"):
+        out["configs"] = {k: compact_entry(e) for k, e in full["configs"].items()}
+    line = json.dumps(out, separators=(",", ":"))
+    if len(line) > LINE_LIMIT:   # never outgrow the record: shed the optional keys in this order
+        for k in ("extras", "end_to_end_pcie", "cpu_baseline_all_cores", "rccl"):
+            if k in out and len(line) > LINE_LIMIT:
+                del out[k]
+                line = json.dumps(out, separators=(",", ":"))
+    return line
 
 
 def selftest_launch(launch):
@@ -779,7 +891,7 @@ def main():
         if not ok:
             comm = None
 
-    kinds = [args.kind] if args.kind != "all" else ["stft"] + ([] if args.no_configs else list(CONFIG_KINDS) + list(EXTRA_KINDS))
+    kinds = args.kind.split(",") if args.kind != "all" else ["stft"] + ([] if args.no_configs else list(CONFIG_KINDS) + list(EXTRA_KINDS))
     with_cpu = world == 1 and not args.no_cpu_baseline
     entries, extras = {}, {}
     head = head_info = head_tm = None
@@ -794,6 +906,19 @@ def main():
     if comm is not None:
         comm.destroy()
     exit_code = 0
+    if os.environ.get("ZAFX_BENCH_INNER_LOG"):
+        with open(os.environ["ZAFX_BENCH_INNER_LOG"], "w") as fh:
+            json.dump(INNER_LOG, fh)
+    if rank == 0 and world == 1 and args.kind == "all" and os.environ.get("ZAFX_BENCH_INNER") != "1":
+        # HBM traffic of the headline and of every BASELINE config from this run's own counters (two profiled child runs)
+        measured = [k for k in kinds if k not in EXTRA_KINDS]
+        live = live_traffic(measured)
+        for k in measured:
+            apply_live_traffic(head if k == kinds[0] else entries[k], live.get(k))
+        if "_error" in live:
+            head["roofline"]["traffic_live_error"] = live["_error"]
+        if "_copy_check" in live:
+            head["roofline"]["traffic_copy_check"] = live["_copy_check"]
 
     if rank == 0:
         hk = kinds[0]
@@ -848,8 +973,22 @@ def main():
                 out["end_to_end_pcie"] = e2e_pcie(device)
             except zafx.ZafxError as exc:
                 out["end_to_end_pcie"] = {"error": str(exc)}
+        # the full record (workload prose, flop notes, placement survey, traffic sources) goes beside the script and to stderr;
+        # stdout carries the ONE compact line, last
+        detail = os.path.join(ROOT, "gpurun_out") if os.path.isdir(os.path.join(ROOT, "gpurun_out")) else ROOT
+        detail = os.path.join(detail, "bench_detail.json")
+        try:
+            if os.environ.get("ZAFX_BENCH_INNER") == "1":
+                raise OSError("profiled child run: no record")
+            with open(detail, "w") as fh:
+                json.dump(out, fh, indent=1)
+            out["detail"] = os.path.relpath(detail, ROOT)
+        except OSError:
+            out["detail"] = "stderr"
+        sys.stderr.write("bench detail: " + json.dumps(out) + "\n")
+        sys.stderr.flush()
         sys.stdout.flush()
-        os.write(real_stdout, (json.dumps(out) + "\n").encode())
+        os.write(real_stdout, (compact_line(out) + "\n").encode())
 
     if rdzv is not None:
         # every rank leaves with rank 0's verdict (a launcher reports the first non-zero exit)

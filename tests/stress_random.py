@@ -1,4 +1,4 @@
-"""Random geometries of every transform against the oracle -- a check run by hand on the GPU box (pytest does not collect it):  python tests/stress_random.py [seed [iterations]]"""
+"""Random geometries of every transform against the oracle -- run by tests/test_gpu_stress.py with fixed seeds, or by hand:  python tests/stress_random.py [seed [iterations]]"""
 import sys, os
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "zaf-python_amd")); sys.path.insert(0, ROOT)

@@ -1,6 +1,6 @@
 """Random geometries of the variants `stress_random.py` leaves out -- frame-major layout, one-sided / magnitude / power spectra,
 float64 mode, mel without DCT, CQT spectrogram / chromagram with random kernels, DCT / DST types 1-4, PCM ingest -- against the
-oracle.  Run by hand on the GPU box (pytest does not collect it):  python tests/stress_random_more.py [seed [iterations]]"""
+oracle.  Run by tests/test_gpu_stress.py with a fixed seed, or by hand:  python tests/stress_random_more.py [seed [iterations]]"""
 import os
 import sys
 

@@ -1,0 +1,46 @@
+"""The contract line of bench.py stays small enough for a record that keeps only the tail of stdout (round 3's 18.8 KB
+line lost BASELINE configs 3-5 there), and still carries every config's roofline and cpu_baseline."""
+import glob
+import json
+import os
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+
+def _records():
+    return sorted(glob.glob(os.path.join(ROOT, "profiles", "r0[3-9]_bench_all.json")))
+
+
+@pytest.mark.parametrize("path", _records(), ids=os.path.basename)
+def test_contract_line_is_compact_and_complete(path):
+    import bench
+    with open(path) as fh:
+        full = json.load(fh)
+    line = bench.compact_line(full)
+    assert len(line) < bench.LINE_LIMIT
+    assert "\n" not in line
+    assert '"cqt"' in line[-2000:]
+    out = json.loads(line)
+    assert list(out)[-1] == "configs"
+    for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
+                "dtype", "data", "config", "roofline", "cpu_baseline"):
+        assert key in out, key
+    assert set(out["roofline"]) >= {"bound", "achieved", "peak", "unit", "frac", "traffic"}
+    assert set(out["cpu_baseline"]) >= {"value", "unit", "cores", "kind", "sample"}
+    for kind in ("istft", "mel", "mfcc", "mdct", "imdct", "cqt"):
+        e = out["configs"][kind]
+        assert e["roofline"]["frac"] > 0 and e["roofline"]["kernel"].startswith("k_")
+        assert e["cpu_baseline"]["cores"] >= 1 and e["parity"]["within_tolerance"] is True
+
+
+def test_line_sheds_optional_keys_before_it_outgrows_the_limit():
+    import bench
+    with open(_records()[-1]) as fh:
+        full = json.load(fh)
+    full["extras"] = {f"extra{i}": dict(next(iter(full["extras"].values()))) for i in range(120)}
+    line = bench.compact_line(full)
+    assert len(line) < bench.LINE_LIMIT and '"cqt"' in line[-2000:]

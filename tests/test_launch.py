@@ -133,7 +133,7 @@ def test_rendezvous_directory_is_private_and_stale_files_are_ignored(tmp_path, m
     os.chmod(d, 0o777)
     with pytest.raises(PermissionError):          # a directory other users can write to is refused
         launch.Rendezvous(str(d), 0, 1)
-    os.chmod(d, 0o700)
+    os.chmod(d, 0o755)                            # (made under the usual umask -- nobody else can write: accepted)
     (d / "000001_bcast").write_bytes(b"stale id of a job that died")   # what a reused ZAFX_RDZV_DIR may hold
     monkeypatch.setenv("ZAFX_RDZV_DIR", str(d))
     monkeypatch.setenv("RANK", "0")
@@ -144,6 +144,12 @@ def test_rendezvous_directory_is_private_and_stale_files_are_ignored(tmp_path, m
     assert rv.get("000001_bcast") == b"fresh"     # this job's key, not the stale file of the same number
     rv.close()
     assert (d / "000001_bcast").exists()          # another job's file is not ours to delete
+    # ranks with different parent processes (started by hand) meet through an explicit namespace
+    monkeypatch.setenv("ZAFX_RDZV_NS", "job42")
+    assert launch.Rendezvous.from_env(timeout=5.0).ns == "job42."
+    monkeypatch.delenv("ZAFX_RDZV_NS")
+    monkeypatch.setenv("TORCHELASTIC_RUN_ID", "run7")
+    assert launch.Rendezvous.from_env(timeout=5.0).ns == "run7."
 
 
 @pytest.mark.timeout(60)

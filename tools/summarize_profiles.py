@@ -1,18 +1,28 @@
 #!/usr/bin/env python3
 """gpurun_out/ (written by tools/collect_profiles.sh on the GPU box) -> profiles/ (committed).
 
-    python tools/summarize_profiles.py r02
+    python tools/summarize_profiles.py r04
+
+What it writes:
+  <tag>_bench_all.json            the contract line of the PROFILED process (the one the kernel statistics belong to)
+  <tag>_bench_detail.json         that process's full record
+  <tag>_bench_all_plain.json      the line of the unprofiled run of the same command (carries the in-run HBM traffic of every config)
+  <tag>_bench_detail_plain.json   its full record
+  <tag>_stft_kernel_stats.csv     rocprofv3 --stats of the profiled process, every kernel (means include pre-warm, placement survey, PCIe legs)
+  <tag>_timed_kernel_stats.csv    per kind: the dispatches of the TIMED region of that same process (from the kernel trace and the launch
+                                  log bench.py wrote), beside the kernel_ms the line reports -- these two must agree
+  <tag>_sq_summary.csv            SQ counters of the compute-bound kernels (separate --pmc runs)
 """
 import csv
 import glob
 import json
 import os
+import statistics
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 OUT, PROF = os.path.join(ROOT, "gpurun_out"), os.path.join(ROOT, "profiles")
-tag = sys.argv[1] if len(sys.argv) > 1 else "r03"
-KINDS = ["stft", "istft", "mdct", "imdct", "mel", "mfcc", "cqt", "dct", "stft_offgrid", "stft4096", "stft4096_h1024", "istft4096", "mdct4096"]
+tag = sys.argv[1] if len(sys.argv) > 1 else "r04"
 
 
 def find(pattern):
@@ -20,122 +30,57 @@ def find(pattern):
     return hits[-1] if hits else None
 
 
-def stats_rows(kind):
-    f = find(f"prof_{kind}/**/*kernel_stats.csv")
-    if not f:
-        return None, []
-    with open(f) as fh:
-        rows = list(csv.reader(fh))
-    return rows[0], [r for r in rows[1:] if r and "zafx::" in r[0]]
+def last_json_line(path):
+    if not (path and os.path.exists(path)):
+        return None
+    rows = [ln for ln in open(path, errors="replace").read().splitlines() if ln.startswith("{")]
+    return rows[-1] if rows else None
 
 
-# bench lines
-for k in KINDS + ["stft_tf", "all"]:
-    src = os.path.join(OUT, f"bench_{k}.json")
-    if os.path.exists(src) and os.path.getsize(src):
-        line = open(src).read().strip().splitlines()[-1]
+for src, dst in (("bench_all_profiled.json", f"{tag}_bench_all.json"), ("bench_all.json", f"{tag}_bench_all_plain.json")):
+    line = last_json_line(os.path.join(OUT, src))
+    if line:
         json.loads(line)
-        open(os.path.join(PROF, f"{tag}_bench_{k}.json"), "w").write(line + "\n")
+        open(os.path.join(PROF, dst), "w").write(line + "\n")
+for src, dst in (("bench_detail_profiled.json", f"{tag}_bench_detail.json"), ("bench_detail.json", f"{tag}_bench_detail_plain.json")):
+    p = os.path.join(OUT, src)
+    if os.path.exists(p):
+        open(os.path.join(PROF, dst), "w").write(json.dumps(json.load(open(p)), indent=1) + "\n")
 
-# the bench lines the PROFILED runs printed themselves (prof_<kind>.log): the kernel statistics below belong to these processes, and
-# where an allocation lands differs from process to process -- compare rocprofv3's mean with THIS line's kernel_ms
-prof_lines = {}
-for k in KINDS:
-    log = os.path.join(OUT, f"prof_{k}.log")
-    if os.path.exists(log):
-        rows = [ln for ln in open(log, errors="replace").read().splitlines() if ln.startswith("{")]
-        if rows:
-            try:
-                line = json.loads(rows[-1])
-                prof_lines[k] = {"steps": line["steps"], "warmup": line["warmup"], "ms_per_step": line["ms_per_step"],
-                                 "kernel_ms": line["roofline"]["kernel_ms"], "kernel_ms_median": line["roofline"]["kernel_ms_median"],
-                                 "kernel": line["roofline"]["kernel"]}
-            except (ValueError, KeyError):
-                pass
-if prof_lines:
-    open(os.path.join(PROF, f"{tag}_profiled_runs.json"), "w").write(json.dumps(prof_lines, indent=1) + "\n")
-
-# kernel statistics: the headline run in full, the dominant rows of the others in one file
-f = find("prof_stft/**/*kernel_stats.csv")
+f = find("prof_all/**/*kernel_stats.csv")
 if f:
     open(os.path.join(PROF, f"{tag}_stft_kernel_stats.csv"), "w").write(open(f).read())
-with open(os.path.join(PROF, f"{tag}_other_kernel_stats.csv"), "w", newline="") as fh:
-    w = csv.writer(fh, quoting=csv.QUOTE_NONNUMERIC)
-    wrote_header = False
-    for k in KINDS[1:]:
-        header, rows = stats_rows(k)
-        if header and not wrote_header:
-            w.writerow(["kind"] + header)
-            wrote_header = True
-        for r in rows:
-            w.writerow([k] + r)
 
-
-# PMC passes (FETCH_SIZE and WRITE_SIZE in separate runs) of the dominant kernel of every transform
-def counter_means(kind, counter):
-    f = find(f"pmc_{kind}_{counter}/**/*counter_collection.csv")
-    if not f:
-        return {}
-    acc = {}
-    with open(f) as fh:
+# the timed dispatches of the profiled process
+trace, log = find("prof_all/**/*kernel_trace.csv"), os.path.join(OUT, "prof_all_launches.json")
+if trace and os.path.exists(log):
+    rows = []
+    with open(trace) as fh:
         for r in csv.DictReader(fh):
-            if r.get("Counter_Name") != counter:
-                continue
-            name = r["Kernel_Name"].split("(")[0]
-            s = acc.setdefault(name, [0, 0.0])
-            s[0] += 1
-            s[1] += float(r["Counter_Value"])
-    return {k: (n, v / n) for k, (n, v) in acc.items()}
+            rows.append((int(r["Dispatch_Id"]), r["Kernel_Name"].split("(")[0], int(r["End_Timestamp"]) - int(r["Start_Timestamp"])))
+    rows.sort()
+    pos, table = 0, []
+    for ent in json.load(open(log)):
+        picked = []   # (segment, duration)
+        segs = ent.get("segments") or [["setup", ent["launches"]]]
+        for seg, n in segs:
+            got = 0
+            while got < n and pos < len(rows):
+                if ent["kernel"] in rows[pos][1]:
+                    picked.append((seg, rows[pos][2]))
+                    got += 1
+                pos += 1
+        timed = [d for s, d in picked if s == "timed"]
+        if ent["kind"] and timed:
+            table.append([ent["kind"], ent["kernel"], len(timed), round(statistics.mean(timed)), min(timed), round(statistics.median(timed)), max(timed),
+                          round(ent["kernel_ms"] * 1e6), round(statistics.mean(timed) / (ent["kernel_ms"] * 1e6), 4)])
+    with open(os.path.join(PROF, f"{tag}_timed_kernel_stats.csv"), "w", newline="") as fh:
+        w = csv.writer(fh)
+        w.writerow(["kind", "kernel", "timed_dispatches", "rocprof_mean_ns", "min_ns", "median_ns", "max_ns", "line_kernel_ns_hip_events", "rocprof_over_line"])
+        w.writerows(table)
 
 
-rows = []
-for kind in KINDS:
-    fetch, write = counter_means(kind, "FETCH_SIZE"), counter_means(kind, "WRITE_SIZE")
-    bench_file = os.path.join(PROF, f"{tag}_bench_{kind}.json")
-    if not (fetch and write and os.path.exists(bench_file)):
-        continue
-    bench = json.loads(open(bench_file).read())
-    kname = bench["roofline"]["kernel"]
-    kern = next((k for k in fetch if kname in k), None)
-    if kern is None or kern not in write:
-        continue
-    for cname, tab in (("FETCH_SIZE", fetch), ("WRITE_SIZE", write)):
-        for k, (n, v) in sorted(tab.items()):
-            if k == kern or (kind == "stft" and "copyBuffer" in k):
-                rows.append(f'{kind},"{k}",{cname},{n},{v:.3f}')
-    copy = next((k for k in fetch if "copyBuffer" in k), None)
-    doc = {
-        "kernel": kname,
-        "fetch_size_kb_raw": fetch[kern][1],
-        "write_size_kb_raw": write[kern][1],
-        "fetch_correction": 2.0,
-        "write_correction": 1.0,
-        "hbm_bytes_per_launch": fetch[kern][1] * 1024 * 2.0 + write[kern][1] * 1024,
-        "algorithmic_bytes_per_launch": bench["roofline"]["algorithmic_bytes_per_launch"],
-        "collected": "%s: separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of `bench.py --kind %s --steps 3`" % (tag, kind),
-        "note": "FETCH_SIZE/WRITE_SIZE in KB from separate rocprofv3 --pmc passes (profiles/%s_pmc_summary.csv); gfx950 "
-                "FETCH_SIZE counts half the bytes of streaming reads (MI355X_MICROARCH.md, HBM section; confirmed on the "
-                "device-to-device copy of the stft run), WRITE_SIZE is exact on that copy" % tag,
-    }
-    if kind == "stft" and copy:
-        copy_bytes = 441000 * 4 * 8   # bench.py replicates blocks of 8 clips device-to-device
-        doc["calibration"] = {"kernel": copy, "bytes_per_dispatch": copy_bytes,
-                              "fetch_true_over_counter": copy_bytes / (fetch[copy][1] * 1024),
-                              "write_true_over_counter": copy_bytes / (write[copy][1] * 1024)}
-    open(os.path.join(PROF, f"pmc_{kind}.json"), "w").write(json.dumps(doc, indent=1) + "\n")
-if rows:
-    with open(os.path.join(PROF, f"{tag}_pmc_summary.csv"), "w") as fh:
-        fh.write("kind,kernel,counter,dispatches,mean_value_KB\n" + "\n".join(rows) + "\n")
-# the bench lines were produced before this run's PMC summary existed: carry the fresh traffic figure into them
-for kind in KINDS:
-    pmc, bench_file = os.path.join(PROF, f"pmc_{kind}.json"), os.path.join(PROF, f"{tag}_bench_{kind}.json")
-    if os.path.exists(pmc) and os.path.exists(bench_file):
-        line = json.loads(open(bench_file).read())
-        line["roofline"]["traffic"] = json.load(open(pmc))["hbm_bytes_per_launch"]
-        open(bench_file, "w").write(json.dumps(line) + "\n")
-
-
-# SQ passes: matrix-core busy time and LDS behaviour of the dominant kernel (mean per dispatch)
+# SQ passes: matrix-core busy time, issue and LDS behaviour of the dominant kernel (mean per dispatch)
 def all_counters(kind, leg):
     f = find(f"pmc_{kind}_{leg}/**/*counter_collection.csv")
     if not f:
@@ -150,12 +95,9 @@ def all_counters(kind, leg):
     return {k: {c: v / n for c, (n, v) in d.items()} for k, d in acc.items()}
 
 
+KERNEL_OF = {"mel": "k_mel", "mfcc": "k_mel", "cqt": "k_cqt", "stft": "k_stft_ft16", "dct": "k_dct"}
 sq_rows = []
-for kind in ("mel", "mfcc", "dct", "cqt", "stft"):
-    bench_file = os.path.join(PROF, f"{tag}_bench_{kind}.json")
-    if not os.path.exists(bench_file):
-        continue
-    kname = json.loads(open(bench_file).read())["roofline"]["kernel"]
+for kind, kname in KERNEL_OF.items():
     merged = {}
     for leg in ("SQ", "LDS"):
         tab = all_counters(kind, leg)
@@ -173,8 +115,10 @@ for kind in ("mel", "mfcc", "dct", "cqt", "stft"):
         derived["kernel_cycles"] = grbm / 8.0
     if merged.get("SQ_LDS_IDX_ACTIVE"):
         derived["lds_bank_conflict_over_active"] = merged.get("SQ_LDS_BANK_CONFLICT", 0.0) / merged["SQ_LDS_IDX_ACTIVE"]
-    if merged.get("SQ_WAVE_CYCLES") and merged.get("SQ_WAIT_INST_LDS") is not None:
-        derived["wait_inst_lds_over_wave_cycles"] = merged["SQ_WAIT_INST_LDS"] / merged["SQ_WAVE_CYCLES"]
+    if merged.get("SQ_WAVE_CYCLES"):
+        for c in ("SQ_WAIT_INST_LDS", "SQ_WAIT_ANY", "SQ_ACTIVE_INST_ANY"):
+            if merged.get(c) is not None:
+                derived[c.lower()[3:] + "_over_wave_cycles"] = merged[c] / merged["SQ_WAVE_CYCLES"]
     for c, v in sorted(merged.items()):
         sq_rows.append(f'{kind},"{kname}",{c},{v:.1f}')
     for c, v in sorted(derived.items()):

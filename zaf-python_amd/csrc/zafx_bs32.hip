@@ -241,6 +241,7 @@ hipError_t launch_stft_bs32(const zafx_plan& pl, const float* x, float2* out, in
         constexpr int L = decltype(tag)::value;
         auto kern = k_stft_bs32<L>;
         if (hipError_t e = ensure_dynamic_lds(reinterpret_cast<const void*>(kern), pl.device, BsCfg<L>::SMEM); e != hipSuccess) return e;
+        pl.ran = "k_stft_bs32";
         hipLaunchKernelGGL(kern, dim3((unsigned)total), dim3(BsCfg<L>::P), BsCfg<L>::SMEM, pl.stream, x, pl.d_window, pl.d_tw_pass, pl.d_bs_chirp,
                            pl.d_bs_bhat, out, (long long)n_samples, pl.H, T, (int)row_pitch(pl, T), pl.W, pl.layout, pl.prm.spectrum, total);
         return hipGetLastError();
@@ -264,6 +265,7 @@ hipError_t launch_istft_bs32(zafx_plan& pl, const float2* spec_all, float* y_all
             constexpr int L = decltype(tag)::value;
             auto kern = k_ifft_frames_bs32<L>;
             if (hipError_t e2 = ensure_dynamic_lds(reinterpret_cast<const void*>(kern), pl.device, BsCfg<L>::SMEM); e2 != hipSuccess) return e2;
+            pl.ran = "k_ifft_frames_bs32";
             hipLaunchKernelGGL(kern, dim3((unsigned)total), dim3(BsCfg<L>::P), BsCfg<L>::SMEM, pl.stream, spec, pl.d_tw_pass, pl.d_bs_chirp, pl.d_bs_bhat,
                                reinterpret_cast<float*>(pl.d_scratch64), T, (int)row_pitch(pl, T), pl.W, pl.layout, one, total);
             return hipGetLastError();
@@ -281,6 +283,7 @@ hipError_t launch_mdct_bs32(const zafx_plan& pl, const float* x, float* out, int
         constexpr int L = decltype(tag)::value;
         auto kern = k_mdct_bs32<L>;
         if (hipError_t e = ensure_dynamic_lds(reinterpret_cast<const void*>(kern), pl.device, BsCfg<L>::SMEM); e != hipSuccess) return e;
+        pl.ran = "k_mdct_bs32";
         hipLaunchKernelGGL(kern, dim3((unsigned)total), dim3(BsCfg<L>::P), BsCfg<L>::SMEM, pl.stream, x, pl.d_window, pl.d_tw_pass, pl.d_bs_chirp,
                            pl.d_bs_bhat, pl.d_tw_aux, out, (long long)n_samples, T, (int)row_pitch(pl, T), pl.W, pl.layout, total);
         return hipGetLastError();
@@ -300,6 +303,7 @@ hipError_t launch_imdct_bs32(zafx_plan& pl, const float* coefs_all, float* y_all
             constexpr int L = decltype(tag)::value;
             auto kern = k_imdct_frames_bs32<L>;
             if (hipError_t e2 = ensure_dynamic_lds(reinterpret_cast<const void*>(kern), pl.device, BsCfg<L>::SMEM); e2 != hipSuccess) return e2;
+            pl.ran = "k_imdct_frames_bs32";
             hipLaunchKernelGGL(kern, dim3((unsigned)total), dim3(BsCfg<L>::P), BsCfg<L>::SMEM, pl.stream, coefs, pl.d_window, pl.d_tw_pass, pl.d_bs_chirp,
                                pl.d_bs_bhat, pl.d_tw_aux, reinterpret_cast<float*>(pl.d_scratch64), T, (int)row_pitch(pl, T), pl.W, pl.layout, total);
             return hipGetLastError();

@@ -1107,9 +1107,23 @@ int zafx_run_host(zafx_plan* pl, const void* h_in, void* h_out, int64_t n_clips,
     const int64_t n_chunks = (n_clips + chunk_clips - 1) / chunk_clips;
     const int sets = n_chunks > 1 ? 2 : 1;
     if (sets == 2 && !pl->stream_up) {
-        ZAFX_HIP(hipStreamCreateWithFlags(&pl->stream_up, hipStreamNonBlocking));
-        ZAFX_HIP(hipStreamCreateWithFlags(&pl->stream_down, hipStreamNonBlocking));
-        for (int i = 0; i < 6; ++i) ZAFX_HIP(hipEventCreateWithFlags(&pl->pipe_ev[i], hipEventDisableTiming));
+        // created into locals and handed to the plan only when ALL of them exist: a partial set (a failed event) would leave a later
+        // call with a null stream (the legacy default stream) or null events and a pipeline without its ordering
+        hipStream_t up = nullptr, down = nullptr;
+        hipEvent_t ev[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+        hipError_t e = hipStreamCreateWithFlags(&up, hipStreamNonBlocking);
+        if (e == hipSuccess) e = hipStreamCreateWithFlags(&down, hipStreamNonBlocking);
+        for (int i = 0; i < 6 && e == hipSuccess; ++i) e = hipEventCreateWithFlags(&ev[i], hipEventDisableTiming);
+        if (e != hipSuccess) {
+            for (int i = 0; i < 6; ++i)
+                if (ev[i]) (void)hipEventDestroy(ev[i]);
+            if (down) (void)hipStreamDestroy(down);
+            if (up) (void)hipStreamDestroy(up);
+            ZAFX_HIP(e);
+        }
+        for (int i = 0; i < 6; ++i) pl->pipe_ev[i] = ev[i];
+        pl->stream_down = down;
+        pl->stream_up = up;   // (last: the guard above reads it)
     }
     for (int l = 0; l < sets; ++l) {   // grow-only staging buffers
         const size_t need_in = (size_t)std::max<int64_t>(chunk_clips * in_b, 1), need_out = (size_t)std::max<int64_t>(chunk_clips * out_b, 1);
@@ -1197,7 +1211,7 @@ int zafx_cqt_max_bins(int fft_length, int* n_bins) {
 
 int zafx_plan_kernel_name(const zafx_plan* pl, char* buf, size_t buflen) {
     if (!pl || !buf || !buflen) return fail_msg("null argument");
-    std::snprintf(buf, buflen, "%s", pl->kernel_name.c_str());
+    std::snprintf(buf, buflen, "%s", pl->ran ? pl->ran : pl->kernel_name.c_str());
     return 0;
 }
 

@@ -543,6 +543,7 @@ static hipError_t run_cqt(const zafx_plan& pl, const float* x, float* out, int64
     const int pos_hi = (DOUBLE ? pl.cqt_k_hi >> 1 : pl.cqt_k_hi) >> 4;   // (double form: bin k of the spectrum is position k >> 1 of its transform)
     if (ZAFX_CQT_PRUNE && cqt_split(LOG2N) && !pl.cqt_k_special && pl.cqt_k_hi >= pl.cqt_k_lo && (pos_hi >> 6) <= 2)
         prune3 = pos_hi >> 6;
+    pl.ran = "k_cqt";
     hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(C::P), smem, pl.stream, x, pl.d_tw_pass, pl.d_tw_aux, pl.d_cqt_waves,
                        pl.d_cqt_addrs, pl.d_cqt_vals, out, (long long)n_samples, pl.H, left, T, (int)row_pitch(pl, T), (int)n_clips, n_groups,
                        pl.prm.n_bins, pl.kind == ZAFX_CHROMA ? pl.prm.octave_resolution : 0, pl.layout, pl.cqt_k_lo, pl.cqt_k_hi,

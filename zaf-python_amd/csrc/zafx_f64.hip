@@ -592,6 +592,7 @@ static hipError_t launch_bs_f64(const zafx_plan& pl, const double* x, void* out,
     const size_t smem = ((size_t)2 << pl.bs_log2m) * sizeof(double2);
     auto kern = k_stft_bs_f64;
     if (hipError_t e = ensure_dynamic_lds(reinterpret_cast<const void*>(kern), pl.device, smem); e != hipSuccess) return e;
+    pl.ran = "k_stft_bs_f64";
     hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(threads_for(smem)), smem, pl.stream, x, pl.d_window64, pl.d_tw64, pl.d_tws64, pl.d_bhat64,
                        pl.d_fb64, pl.d_fb64_meta, pl.d_dct64, (double2*)out, (long long)n_samples, pl.H, T, (int)row_pitch(pl, T), pl.W,
                        pl.bs_log2m, pl.layout, pl.prm.spectrum, pl.prm.n_filters, pl.kind == ZAFX_MFCC ? pl.prm.n_coefs : 0, mel_mode ? 1 : 0);
@@ -605,6 +606,7 @@ hipError_t launch_stft_f64(const zafx_plan& pl, const double* x, double2* out, i
     const size_t smem = (size_t)pl.W * sizeof(double2);   // two buffers of W/2 points
     auto kern = k_stft_f64;
     if (hipError_t e = ensure_dynamic_lds(reinterpret_cast<const void*>(kern), pl.device, smem); e != hipSuccess) return e;
+    pl.ran = "k_stft_f64";
     hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(threads_for(smem)), smem, pl.stream, x, pl.d_window64, pl.d_tw64, pl.d_tws64, out,
                        (long long)n_samples, pl.H, T, (int)row_pitch(pl, T), pl.log2nf, pl.layout, pl.prm.spectrum);
     return hipGetLastError();
@@ -644,6 +646,7 @@ hipError_t launch_istft_f64(zafx_plan& pl, const double2* spec_all, double* y_al
             const size_t smem = ((size_t)2 << pl.bs_log2m) * sizeof(double2);
             auto kern = k_ifft_frames_bs_f64;
             if (hipError_t e = ensure_dynamic_lds(reinterpret_cast<const void*>(kern), pl.device, smem); e != hipSuccess) return e;
+            pl.ran = "k_ifft_frames_bs_f64";
             hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(threads_for(smem)), smem, pl.stream, spec, pl.d_tw64, pl.d_tws64, pl.d_bhat64,
                                pl.d_scratch64, T, (int)row_pitch(pl, T), pl.W, pl.bs_log2m, pl.layout,
                                pl.prm.spectrum == ZAFX_SPECTRUM_ONE_SIDED ? 1 : 0);
@@ -654,6 +657,7 @@ hipError_t launch_istft_f64(zafx_plan& pl, const double2* spec_all, double* y_al
             const size_t smem = (size_t)pl.W * sizeof(double2);
             auto kern = k_ifft_frames_f64;
             if (hipError_t e = ensure_dynamic_lds(reinterpret_cast<const void*>(kern), pl.device, smem); e != hipSuccess) return e;
+            pl.ran = "k_ifft_frames_f64";
             hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(threads_for(smem)), smem, pl.stream, spec, pl.d_tw64, pl.d_tws64, pl.d_scratch64, T,
                                (int)row_pitch(pl, T), pl.log2nf, pl.layout, pl.prm.spectrum == ZAFX_SPECTRUM_ONE_SIDED ? 1 : 0);
             if (hipError_t e = hipGetLastError(); e != hipSuccess) return e;
@@ -680,6 +684,7 @@ hipError_t launch_cqt_f64(zafx_plan& pl, const double* x, double* out, int64_t n
     if (hipError_t e = ensure_dynamic_lds(reinterpret_cast<const void*>(kern), pl.device, smem); e != hipSuccess) return e;
     const int diff = pl.W - pl.H;
     const int left = diff >= 0 ? (diff + 1) / 2 : -((-diff) / 2);   // ceil((fft_length - step) / 2), zaf.py:615
+    pl.ran = "k_cqt_f64";
     hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(threads_for(smem)), smem, pl.stream, x, pl.d_tw64, pl.d_tws64, pl.d_indptr, pl.d_indices,
                        pl.d_values64, reinterpret_cast<double2*>(pl.d_scratch64), out, (long long)n_samples, pl.H, left, T,
                        (int)row_pitch(pl, T), total, log2w, pl.prm.n_bins, pl.kind == ZAFX_CHROMA ? pl.prm.octave_resolution : 0, pl.layout);
@@ -693,6 +698,7 @@ hipError_t launch_mel_f64(const zafx_plan& pl, const double* x, double* out, int
     const size_t smem = (size_t)pl.W * sizeof(double2);   // two buffers of W/2 points; the idle one later holds bins + band sums
     auto kern = k_mel_f64;
     if (hipError_t e = ensure_dynamic_lds(reinterpret_cast<const void*>(kern), pl.device, smem); e != hipSuccess) return e;
+    pl.ran = "k_mel_f64";
     hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(threads_for(smem)), smem, pl.stream, x, pl.d_window64, pl.d_tw64, pl.d_tws64, pl.d_fb64,
                        pl.d_fb64_meta, pl.d_dct64, out, (long long)n_samples, pl.H, T, (int)row_pitch(pl, T), pl.log2nf, pl.layout,
                        pl.prm.n_filters, pl.kind == ZAFX_MFCC ? pl.prm.n_coefs : 0);
@@ -706,6 +712,7 @@ hipError_t launch_mdct_f64(const zafx_plan& pl, const double* x, double* out, in
         const size_t smem = ((size_t)2 << pl.bs_log2m) * sizeof(double2);
         auto kern = k_mdct_bs_f64;
         if (hipError_t e = ensure_dynamic_lds(reinterpret_cast<const void*>(kern), pl.device, smem); e != hipSuccess) return e;
+        pl.ran = "k_mdct_bs_f64";
         hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(threads_for(smem)), smem, pl.stream, x, pl.d_window64, pl.d_tw64, pl.d_tws64, pl.d_bhat64,
                            out, (long long)n_samples, T, (int)row_pitch(pl, T), pl.W, pl.bs_log2m, pl.layout);
         return hipGetLastError();
@@ -713,6 +720,7 @@ hipError_t launch_mdct_f64(const zafx_plan& pl, const double* x, double* out, in
     const size_t smem = (size_t)pl.W * 8 + (size_t)(pl.W / 2) * 8 + (size_t)(pl.W / 4) * 32;   // u, v, two FFT buffers
     auto kern = k_mdct_f64;
     if (hipError_t e = ensure_dynamic_lds(reinterpret_cast<const void*>(kern), pl.device, smem); e != hipSuccess) return e;
+    pl.ran = "k_mdct_f64";
     hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(threads_for(smem)), smem, pl.stream, x, pl.d_window64, pl.d_tw64, pl.d_tws64, out,
                        (long long)n_samples, T, (int)row_pitch(pl, T), pl.log2nf, pl.layout);
     return hipGetLastError();
@@ -732,12 +740,14 @@ hipError_t launch_imdct_f64(zafx_plan& pl, const double* coefs_all, double* y_al
             const size_t smem = ((size_t)2 << pl.bs_log2m) * sizeof(double2);
             auto kern = k_imdct_frames_bs_f64;
             if (hipError_t e = ensure_dynamic_lds(reinterpret_cast<const void*>(kern), pl.device, smem); e != hipSuccess) return e;
+            pl.ran = "k_imdct_frames_bs_f64";
             hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(threads_for(smem)), smem, pl.stream, coefs, pl.d_window64, pl.d_tw64, pl.d_tws64,
                                pl.d_bhat64, pl.d_scratch64, T, (int)row_pitch(pl, T), pl.W, pl.bs_log2m, pl.layout);
         } else {
             const size_t smem = (size_t)(pl.W / 2) * 16 + (size_t)(pl.W / 4) * 32;
             auto kern = k_imdct_frames_f64;
             if (hipError_t e = ensure_dynamic_lds(reinterpret_cast<const void*>(kern), pl.device, smem); e != hipSuccess) return e;
+            pl.ran = "k_imdct_frames_f64";
             hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(threads_for(smem)), smem, pl.stream, coefs, pl.d_window64, pl.d_tw64, pl.d_tws64,
                                pl.d_scratch64, T, (int)row_pitch(pl, T), pl.log2nf, pl.layout);
         }

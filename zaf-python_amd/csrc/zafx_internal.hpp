@@ -141,7 +141,8 @@ struct zafx_plan {
     std::vector<int32_t> h_indptr, h_indices;
     std::vector<zafx::cf32> h_values;
 
-    std::string kernel_name;
+    std::string kernel_name;            // the kernel this plan is expected to run (set at creation)
+    mutable const char* ran = nullptr;  // the kernel the last execute really launched (routes depend on T, alignment and hop)
 };
 
 namespace zafx {

@@ -168,10 +168,12 @@ hipError_t launch_linear(const zafx_plan& pl, const float* x, float* y, int64_t 
     if (n_cols % kBigK == 0 && reinterpret_cast<uintptr_t>(x) % 16 == 0 && reinterpret_cast<uintptr_t>(pl.d_matrix) % 16 == 0 &&
         (long long)n_rows * n_clips >= 128LL * 128 * 64) {   // enough tiles to fill the chip; small problems keep the 64-tile kernel
         const dim3 big((unsigned)((n_rows + kBigTile - 1) / kBigTile), (unsigned)((n_clips + kBigTile - 1) / kBigTile));
+        pl.ran = "k_linear128";
         hipLaunchKernelGGL(k_linear128, big, dim3(256), 0, pl.stream, pl.d_matrix, x, y, n_rows, n_cols, (long long)n_clips);
         return hipGetLastError();
     }
     const dim3 grid((unsigned)((n_rows + kLinTile - 1) / kLinTile), (unsigned)((n_clips + kLinTile - 1) / kLinTile));
+    pl.ran = "k_linear";
     hipLaunchKernelGGL(k_linear, grid, dim3(256), 0, pl.stream, pl.d_matrix, x, y, n_rows, n_cols, (long long)n_clips);
     return hipGetLastError();
 }

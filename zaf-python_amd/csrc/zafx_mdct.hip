@@ -1254,12 +1254,14 @@ static hipError_t run_mdct_p(const zafx_plan& pl, const float* x, float* out, in
             const int segs = carry_segments(n_clips, tiles, max_grid);
             const int seg_tiles = (tiles + segs - 1) / segs;
             const long long units = (long long)n_clips * segs;
+            pl.ran = "k_mdct_ft32";
             hipLaunchKernelGGL(kc, dim3((unsigned)std::min<long long>(units, max_grid)), dim3(G::NSLOT * 64), G::SMEM, pl.stream, x, pl.d_wfold, pl.d_tw_pass,
                                pl.d_tw_aux, out, (long long)n_samples, T, TP, tiles, (int)total, segs, seg_tiles, (int)units);
             return hipGetLastError();
         }
     }
     const long long grid = std::min<long long>(total, max_grid);
+    pl.ran = "k_mdct_ft32";
     hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(G::NSLOT * 64), G::SMEM, pl.stream, x, pl.d_wfold, pl.d_tw_pass, pl.d_tw_aux, out,
                        (long long)n_samples, T, (int)row_pitch(pl, T), tiles, (int)total, 1, 0, 0);
     return hipGetLastError();
@@ -1276,6 +1278,7 @@ static hipError_t run_mdct_band(const zafx_plan& pl, const float* x, float* out,
     const long long total = (long long)tiles * n_clips;
     if (total <= 0) return hipSuccess;
     const long long grid = std::min<long long>(total, (long long)pl.n_cus);
+    pl.ran = "k_mdct_ft32b";
     hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(G::NT), G::SMEM, pl.stream, x, pl.d_wfold, pl.d_tw_sub, pl.d_tw_band, out, (long long)n_samples, T,
                        (int)row_pitch(pl, T), tiles, (int)total);
     return hipGetLastError();
@@ -1294,6 +1297,7 @@ static hipError_t run_mdct_band_carry(const zafx_plan& pl, const float* x, float
     const int segs = carry_segments(2 * n_clips, tiles, max_grid);   // (two units -- one per band -- for every segment)
     const int seg_tiles = (tiles + segs - 1) / segs;
     const long long units = 2LL * n_clips * segs;
+    pl.ran = "k_mdct_ft32bc";
     hipLaunchKernelGGL(kern, dim3((unsigned)std::min<long long>(units, max_grid)), dim3(G::NT), G::SMEM, pl.stream, x, pl.d_wfold, pl.d_tw_sub, pl.d_tw_band, out,
                        (long long)n_samples, T, (int)row_pitch(pl, T), tiles, segs, seg_tiles, (int)units);
     return hipGetLastError();
@@ -1326,6 +1330,7 @@ static hipError_t run_mdct(const zafx_plan& pl, const float* x, float* out, int6
         const int tiles = (T + FPB - 1) / FPB;
         const long long blocks = (long long)tiles * n_clips;
         if (blocks <= 0) return hipSuccess;
+        pl.ran = "k_mdct";
         hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(G::NT), G::SMEM_FWD, pl.stream, x, pl.d_window, pl.d_tw_pass, pl.d_tw_aux, out,
                            (long long)n_samples, T, (int)row_pitch(pl, T), tiles);
         return hipGetLastError();
@@ -1379,6 +1384,7 @@ static hipError_t run_imdct(const zafx_plan& pl, const float* coefs, float* y, i
     const int seg_tiles = (tiles + segs - 1) / segs;
     const long long units = (long long)n_clips * segs;
     const long long grid = std::min<long long>(units, max_grid);
+    pl.ran = "k_imdct";
     hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(NSLOT * C::P), SMEM, pl.stream, coefs, pl.d_window, pl.d_tw_pass, pl.d_tw_aux, y, T,
                        (int)row_pitch(pl, T), (long long)out_len, tiles, segs, seg_tiles, (int)units);
     return hipGetLastError();

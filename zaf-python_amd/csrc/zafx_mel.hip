@@ -539,6 +539,7 @@ static hipError_t run_mel(const zafx_plan& pl, const float* x, float* out, int64
     if (total <= 0) return hipSuccess;
     const int per_cu = (int)std::min<size_t>(2, (size_t)kMaxLdsBytes / G::SMEM);
     const long long grid = std::min<long long>(total, (long long)pl.n_cus * std::max(per_cu, 1));
+    pl.ran = "k_mel";
     hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(G::NT), G::SMEM, pl.stream, x, pl.d_window, LOG2E == 5 ? pl.d_tw_r32 : pl.d_tw_pass, pl.d_tw_aux, pl.fb.d_pack,
                        pl.fb.d_items, pl.fb.d_wave_ptr, pl.fb.d_blk_ptr, pl.fb.d_desc, pl.fb.n_blocks, pl.fb.n_items, pl.fb.total_steps, mfcc ? pl.dct.total_steps : 0, pl.dct.d_pack, pl.dct.d_items,
                        pl.dct.d_wave_ptr, pl.dct.d_blk_ptr, pl.dct.d_desc, pl.dct.d_direct, direct_j, pl.dct.n_blocks, out, (long long)n_samples, pl.H, T, (int)row_pitch(pl, T), tiles, (int)total,
@@ -640,6 +641,7 @@ static hipError_t run_mel_wide(zafx_plan& pl, const float* x, float* out, int64_
     const int SP = (T + 31) / 32 * 32;   // spectrum rows as whole 128-byte lines
     const size_t per_clip = (size_t)rows * SP * sizeof(float);
     int64_t chunk = std::max<int64_t>(1, std::min<int64_t>(n_clips, (int64_t)(melw_chunk_bytes() / per_clip)));
+    chunk = std::min<int64_t>(chunk, 65535);   // k_melfb puts the clips of a chunk in grid.y
     {   // whole rounds of the persistent spectrum kernel: (16-frame tiles per clip) x chunk a multiple of the workgroups
         const int tiles = (T + 15) / 16;
         int g = tiles, h = pl.n_cus;
@@ -668,6 +670,7 @@ static hipError_t run_mel_wide(zafx_plan& pl, const float* x, float* out, int64_
                                            : launch_stft(st, x + c0 * n_samples, reinterpret_cast<float2*>(spec), n, n_samples, T);
             e != hipSuccess)
             return e;
+        pl.ran = "k_melfb";
         hipLaunchKernelGGL(k_melfb, dim3((unsigned)((T + 63) / 64), (unsigned)n), dim3(1024), smem, pl.stream, spec, pl.d_fbw, pl.d_fbw_meta, pl.d_dctw,
                            out + c0 * out_per_clip, pl.prm.n_filters, mfcc ? pl.prm.n_coefs : 0, rows, SP, T, (int)row_pitch(pl, T), pl.layout);
         if (hipError_t e = hipGetLastError(); e != hipSuccess) return e;

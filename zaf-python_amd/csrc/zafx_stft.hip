@@ -2063,6 +2063,7 @@ static hipError_t run_stft_fat(const zafx_plan& pl, const float* x, float2* out,
     if (total <= 0) return hipSuccess;
     const int per_cu = (int)std::min<size_t>(2, (size_t)kMaxLdsBytes / F::SMEM);
     const long long grid = std::min<long long>(total, (long long)pl.n_cus * std::max(per_cu, 1));
+    pl.ran = "k_stft_ft16";
     hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(F::NT), F::SMEM, pl.stream, x, pl.d_window, LOG2E == 5 ? pl.d_tw_r32 : pl.d_tw_pass,
                        pl.d_tw_aux, out, (long long)n_samples, pl.H, T, (int)row_pitch(pl, T), tiles, (int)total);
     return hipGetLastError();
@@ -2083,6 +2084,7 @@ static hipError_t run_stft_fat_carry(const zafx_plan& pl, const float* x, float2
         const int seg_tiles = (tiles + segs - 1) / segs;
         const long long units = (long long)n_clips * segs;
         const long long grid = std::min<long long>(units, max_grid);
+        pl.ran = "k_stft_ft16c";
         hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(F::NT), F::SMEM, pl.stream, x, pl.d_window, pl.d_tw_pass, pl.d_tw_aux, out,
                            (long long)n_samples, pl.H, T, (int)row_pitch(pl, T), tiles, segs, seg_tiles, (int)units);
         return hipGetLastError();
@@ -2101,6 +2103,7 @@ static hipError_t run_stft_band(const zafx_plan& pl, const float* x, float2* out
     const long long total = (long long)tiles * n_clips;
     if (total <= 0) return hipSuccess;
     const long long grid = std::min<long long>(total, (long long)pl.n_cus);
+    pl.ran = "k_stft_ft16b";
     hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(B::NT), B::SMEM, pl.stream, x, pl.d_window, pl.d_tw_sub, pl.d_tw_aux, out,
                        (long long)n_samples, pl.H, T, (int)row_pitch(pl, T), tiles, (int)total);
     return hipGetLastError();
@@ -2120,6 +2123,7 @@ static hipError_t run_stft_band_carry(const zafx_plan& pl, const float* x, float
         const int seg_tiles = (tiles + segs - 1) / segs;
         const long long units = 2LL * n_clips * segs;
         const long long grid = std::min<long long>(units, max_grid);
+        pl.ran = "k_stft_ft16bc";
         hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(B::NT), B::SMEM, pl.stream, x, pl.d_window, pl.d_tw_sub, pl.d_tw_aux, out,
                            (long long)n_samples, pl.H, T, (int)row_pitch(pl, T), tiles, segs, seg_tiles, (int)units);
         return hipGetLastError();
@@ -2144,6 +2148,7 @@ hipError_t launch_mel_band(const zafx_plan& pl, const float* x, float* out, int6
     const long long total = (long long)tiles * n_clips;
     if (total <= 0) return hipSuccess;
     const long long grid = std::min<long long>(total, (long long)pl.n_cus);
+    pl.ran = "k_mel_ft16b";
     hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(B::NT), B::SMEM, pl.stream, x, pl.d_window, pl.d_tw_sub, pl.d_tw_aux, pl.d_fbw, pl.d_fbw_meta, pl.d_dctw, out,
                        (long long)n_samples, pl.H, T, (int)row_pitch(pl, T), tiles, (int)total, pl.prm.n_filters, mfcc ? pl.prm.n_coefs : 0, pl.layout);
     return hipGetLastError();
@@ -2166,6 +2171,7 @@ static hipError_t run_stft_tf(const zafx_plan& pl, const float* x, float2* out, 
     if (total <= 0) return hipSuccess;
     const int per_cu = (int)std::min<size_t>(2, (size_t)kMaxLdsBytes / SMEM);
     const long long grid = std::min<long long>((total + SLOTS - 1) / SLOTS, (long long)pl.n_cus * std::max(per_cu, 1));
+    pl.ran = "k_stft_tf";
     hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(NT), SMEM, pl.stream, x, pl.d_window, LOG2E == 5 ? pl.d_tw_r32 : pl.d_tw_pass,
                        pl.d_tw_aux, out, (long long)n_samples, pl.H, T, total);
     return hipGetLastError();
@@ -2229,6 +2235,7 @@ static hipError_t run_stft(const zafx_plan& pl, const float* x, float2* out, int
         const int tiles = (T + FPB - 1) / FPB;
         const long long blocks = (long long)tiles * n_clips;
         if (blocks <= 0) return hipSuccess;
+        pl.ran = "k_stft";
         hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(S::NT), S::SMEM, pl.stream, x, pl.d_window, pl.d_tw_pass, pl.d_tw_aux,
                            out, (long long)n_samples, pl.H, T, (int)row_pitch(pl, T), tiles);
         return hipGetLastError();
@@ -2282,6 +2289,7 @@ static hipError_t run_istft_fat(const zafx_plan& pl, const float2* spec, float* 
     const long long units = (long long)n_clips * segs;
     const float scale = 1.f / (4.f * (float)(1 << LOG2N) * pl.cola_gain);
     const long long grid = std::min<long long>(units, max_grid);
+    pl.ran = "k_istft_ft16";
     hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(nt), F::SMEM, pl.stream, spec, pl.d_tw_pass, pl.d_tw_aux, y, T, TP, pl.H,
                        (long long)out_len, scale, tiles, segs, seg_tiles, (int)units, halo);
     return hipGetLastError();
@@ -2308,6 +2316,7 @@ static hipError_t run_istft_band(const zafx_plan& pl, const float2* spec, float*
     const long long units = 2LL * n_clips * segs;
     const float scale = 1.f / (4.f * (float)M * pl.cola_gain);
     const long long grid = std::min<long long>(units, max_grid);
+    pl.ran = "k_istft_ft16b";
     hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(1024), smem, pl.stream, spec, pl.d_tw_sub, pl.d_tw_aux, y, T, (int)row_pitch(pl, T), pl.H / 2,
                        (long long)out_len, scale, tiles, segs, seg_tiles, (int)units, halo);
     return hipGetLastError();
@@ -2345,6 +2354,7 @@ static hipError_t run_istft(const zafx_plan& pl, const float2* spec, float* y, i
     const long long blocks = (long long)tiles * n_clips;
     if (blocks <= 0 || out_len <= 0) return hipSuccess;
     const float scale = 1.f / (4.f * (float)(1 << LOG2N) * pl.cola_gain);
+    pl.ran = "k_istft";
     hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(S::NT), S::SMEM, pl.stream, spec, pl.d_tw_pass, pl.d_tw_aux, y, T,
                        (int)row_pitch(pl, T), pl.H, (long long)out_len, scale, tiles, owned, halo);
     return hipGetLastError();

@@ -762,21 +762,35 @@ def linear_plan(matrix, device=0):
 # ======================================================================================
 # batched API (build-defined extension): (clips, samples) float32 in, float32/complex64 out
 # ======================================================================================
+def _run_host_into(plan, x, n_in, out):
+    """Plan.run_host with the caller's `out` honoured even when the library promoted the plan to float64 (windows under 33
+    samples, more than 576 filters, a CQT outside the float32 kernel's reach): the float64 result is then cast into `out`
+    -- which is returned -- instead of raising on the dtype."""
+    if out is None or np.dtype(out.dtype) == plan.out_dtype:
+        return plan.run_host(x, n_in, out=out)
+    res = plan.run_host(x, n_in)
+    if tuple(out.shape) != tuple(res.shape) or not out.flags.writeable:
+        raise ValueError(f"out must be a writeable array of shape {tuple(res.shape)}")
+    np.copyto(out, res, casting="same_kind")
+    return out
+
+
 def stft_batch(clips, window_function, step_length, layout="FT", device=0, onesided=False, f64=False, out=None):
     """(B, N) -> (B, W, T) complex64 [layout "FT"] or (B, T, W) ["TF"].
 
-    out (every *_batch function): destination array of the plan's output shape and dtype, e.g. a reused zafx.pinned_empty
+    out (every *_batch function): destination array of the result's shape and dtype, e.g. a reused zafx.pinned_empty
     array -- with page-locked arrays on both sides the chunked, double-buffered transfer (Plan.run_host) runs at the PCIe rate.
+    When the library computes a float32 request in float64 (see Plan.f64) the result is cast into `out` afterwards.
 
     onesided=True keeps rows 0..W/2 only -- what every example of the reference slices out of the
     result (zaf.py:83) -- and halves the bytes written; onesided="magnitude" / "power" returns |X| / |X|^2
     of those rows as a real array."""
     x = _as_clips(clips, dtype=np.float64 if f64 else np.float32)
     plan = stft_plan(window_function, step_length, layout, device, onesided, f64)
-    out = plan.run_host(x.astype(plan.in_dtype, copy=False), x.shape[1], out=out)
+    out = _run_host_into(plan, x.astype(plan.in_dtype, copy=False), x.shape[1], out)
     if f64 or not plan.f64:
         return out
-    return out.astype(np.complex64 if np.iscomplexobj(out) else np.float32)   # (computed in float64: window not a power of two)
+    return out.astype(np.complex64 if np.iscomplexobj(out) else np.float32, copy=False)   # (computed in float64: window not a power of two)
 
 
 def istft_batch(spectra, window_function, step_length, layout="FT", device=0, onesided=False, f64=False, out=None):
@@ -792,7 +806,7 @@ def istft_batch(spectra, window_function, step_length, layout="FT", device=0, on
     if wl != (len(w) // 2 + 1 if onesided else len(w)):
         raise ValueError("spectrum rows must equal window_length (window_length/2 + 1 when onesided)")
     plan = istft_plan(w, step_length, layout, device, onesided, f64)
-    out = plan.run_host(np.ascontiguousarray(s, dtype=plan.in_dtype), nt, out=out)
+    out = _run_host_into(plan, np.ascontiguousarray(s, dtype=plan.in_dtype), nt, out)
     return out if f64 else out.astype(np.float32, copy=False)   # (a very small hop is computed in float64 whatever f64 says)
 
 
@@ -800,7 +814,7 @@ def mdct_batch(clips, window_function, layout="FT", device=0, f64=False, out=Non
     """(B, N) -> (B, W/2, T) float32 ["FT"] or (B, T, W/2) ["TF"]; f64: float64 arrays and arithmetic."""
     x = _as_clips(clips, dtype=np.float64 if f64 else np.float32)
     plan = mdct_plan(window_function, layout, device, f64=f64)
-    out = plan.run_host(x.astype(plan.in_dtype, copy=False), x.shape[1], out=out)
+    out = _run_host_into(plan, x.astype(plan.in_dtype, copy=False), x.shape[1], out)
     return out if f64 else out.astype(np.float32, copy=False)
 
 
@@ -814,7 +828,7 @@ def imdct_batch(coefficients, window_function, layout="FT", device=0, f64=False,
     if 2 * nf != len(w):
         raise ValueError("coefficient rows must equal window_length/2")
     plan = mdct_plan(w, layout, device, inverse=True, f64=f64)
-    out = plan.run_host(c.astype(plan.in_dtype, copy=False), nt, out=out)
+    out = _run_host_into(plan, c.astype(plan.in_dtype, copy=False), nt, out)
     return out if f64 else out.astype(np.float32, copy=False)
 
 
@@ -823,7 +837,7 @@ def melspectrogram_batch(clips, window_function, step_length, mel_filterbank, la
     x = _as_clips(clips, dtype=np.float64 if f64 else np.float32)   # (validated before any device call)
     plan = mel_plan(window_function, step_length, mel_filterbank, None, layout, device, f64=f64)
     x = x.astype(plan.in_dtype, copy=False)
-    out = plan.run_host(x, x.shape[1], out=out)
+    out = _run_host_into(plan, x, x.shape[1], out)
     return out if f64 else out.astype(np.float32, copy=False)   # (a long window is computed in float64 whatever f64 says)
 
 
@@ -832,7 +846,7 @@ def mfcc_batch(clips, window_function, step_length, mel_filterbank, number_coeff
     x = _as_clips(clips, dtype=np.float64 if f64 else np.float32)   # (validated before any device call)
     plan = mel_plan(window_function, step_length, mel_filterbank, number_coefficients, layout, device, f64=f64)
     x = x.astype(plan.in_dtype, copy=False)
-    out = plan.run_host(x, x.shape[1], out=out)
+    out = _run_host_into(plan, x, x.shape[1], out)
     return out if f64 else out.astype(np.float32, copy=False)
 
 
@@ -841,7 +855,7 @@ def cqtspectrogram_batch(clips, sampling_frequency, time_resolution, cqt_kernel,
     x = _as_clips(clips, dtype=np.float64 if f64 else np.float32)   # (validated before any device call)
     plan = cqt_plan(sampling_frequency, time_resolution, cqt_kernel, None, layout, device, f64=f64)
     x = x.astype(plan.in_dtype, copy=False)
-    out = plan.run_host(x, x.shape[1], out=out)
+    out = _run_host_into(plan, x, x.shape[1], out)
     return out if f64 else out.astype(np.float32, copy=False)   # (a long kernel is computed in float64 whatever f64 says)
 
 
@@ -850,7 +864,7 @@ def cqtchromagram_batch(clips, sampling_frequency, time_resolution, octave_resol
     x = _as_clips(clips, dtype=np.float64 if f64 else np.float32)   # (validated before any device call)
     plan = cqt_plan(sampling_frequency, time_resolution, cqt_kernel, int(octave_resolution), layout, device, f64=f64)
     x = x.astype(plan.in_dtype, copy=False)
-    out = plan.run_host(x, x.shape[1], out=out)
+    out = _run_host_into(plan, x, x.shape[1], out)
     return out if f64 else out.astype(np.float32, copy=False)
 
 

@@ -64,8 +64,9 @@ class Rendezvous:
         # (the RCCL unique id travels through here)
         os.makedirs(self.dir, mode=0o700, exist_ok=True)
         st = os.stat(self.dir)
-        if st.st_uid != os.getuid() or (st.st_mode & 0o077):
-            raise PermissionError(f"rendezvous directory {self.dir} is not private to uid {os.getuid()} "
+        # (group / other WRITE access is what lets someone else plant keys; a directory made under the usual umask, 0755, is fine)
+        if st.st_uid != os.getuid() or (st.st_mode & 0o022):
+            raise PermissionError(f"rendezvous directory {self.dir} is not writable by uid {os.getuid()} alone "
                                   f"(owner {st.st_uid}, mode {st.st_mode & 0o777:o})")
 
     @classmethod
@@ -81,7 +82,12 @@ class Rendezvous:
             d = os.path.join(base, f"zafx_rdzv_{os.getuid()}_{key}")
         # a directory the caller names may be reused: the keys carry the launcher's identity (all ranks of a node are children
         # of one launcher process), so files a previous job left there are not this job's
-        return cls(d, rank, world, timeout, namespace=f"{os.getppid()}.{_start_time(os.getppid())}.")
+        # -- unless the job names itself (ZAFX_RDZV_NS, or the launcher's TORCHELASTIC_RUN_ID): ranks started by hand or from
+        # per-rank wrapper shells have different parents and would otherwise never see each other's keys
+        ns = os.environ.get("ZAFX_RDZV_NS") or os.environ.get("TORCHELASTIC_RUN_ID")
+        if not ns or ns == "none":
+            ns = f"{os.getppid()}.{_start_time(os.getppid())}"
+        return cls(d, rank, world, timeout, namespace=ns + ".")
 
     # ---- point to point -------------------------------------------------------------
     def put(self, key, data):

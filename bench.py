@@ -49,7 +49,7 @@ HBM_ACHIEVABLE_GBS = 6290.0   # same guide: measured-achievable copy rate
 F32_PEAK_TFLOPS = 157.3    # dense f32 vector / f32-input MFMA peak
 PLACEMENT_SURVEY = 6       # further allocations of the headline's row-strided output probed AFTER every timed region (reported, never timed)
 CONFIG_KINDS = ("istft", "mel", "mfcc", "mdct", "imdct", "cqt")   # SURVEY 8(a) a2 + BASELINE configs 3, 4, 5 (config 2 = the headline)
-EXTRA_KINDS = ("stft1", "istft1", "stft_offgrid", "mdct_offgrid", "stft4096", "stft4096_h1024", "istft4096", "mdct4096", "mel4096")   # one-sided pair (8f rank 4) and geometries off the benchmark's grid
+EXTRA_KINDS = ("stft1", "istft1", "stft_offgrid", "mdct_offgrid", "stft4096", "stft4096_h1024", "istft4096", "mdct4096", "mel4096", "dct")   # one-sided pair (8f rank 4) and geometries off the benchmark's grid
 
 
 def synth(seed, c, n):
@@ -201,10 +201,10 @@ def make_workload(kind, device, layout="FT"):
                   flops_per_launch=B * T * 5.0 * 32768 * 15,
                   flops_note="SURVEY 8(d): 750 x 5*32768*15 per clip, the 32768-point complex FFT the reference runs (the real-input form needs half)",
                   desc="cqtspectrogram: 1024 clips x 30 s @ 44.1 kHz per GPU (config 5: 8192 clips over 8 GPUs), 24 bins/octave 55-3520 Hz, 25 frames/s")
-    elif kind == "dct":
-        plan = zafx.linear_plan(zafx.dct_matrix(N, 2), device=device)
-        wl.update(plan=plan, d_in=d_x, n_in=N, bytes_per_launch=B * 8 * N + 4 * N * N, flops_per_launch=2.0 * N * N * B,
-                  desc="zaf.dct type 2 of 16384 vectors x 1024 samples as one f32 MFMA GEMM (SURVEY 8f rank 3)")
+    elif kind == "dct":   # zaf.dct type 2 on the FFT core (k_dct): 8 bytes per sample, HBM-bound
+        plan = zafx.dct_plan(N, 2, device=device)
+        wl.update(plan=plan, d_in=d_x, n_in=N, bytes_per_launch=B * 8 * N,
+                  desc="zaf.dct type 2 of 16384 vectors x 1024 samples, one 512-point complex FFT per vector (SURVEY 8f rank 3)")
     else:
         raise SystemExit(f"unknown --kind {kind}")
     # `value` and every config time come from the FIRST allocation of each buffer -- what a caller of the library gets.  (Where a

@@ -23,6 +23,9 @@
  *   ZAFX_MDCT                      mdct            zaf.py:984-1075 (per-frame FFT :1061-1073)
  *   ZAFX_IMDCT                     imdct           zaf.py:1078-1184 (FFT :1159, TDAC
  *                                                  overlap-add :1172-1179, trim :1182)
+ *   ZAFX_DCT                       dct / dst       zaf.py:703-839, :842-981 (np.fft.fft of the 2N-2 /
+ *                                                  2N+2 / 4N / 8N point extension :771, :791, :816, :834,
+ *                                                  :909, :926, :948, :974; orthonormal scalings)
  *   zafx_plan_set_constant         operands built by melfilterbank zaf.py:246-321 and
  *                                  cqtkernel zaf.py:457-559 (scipy.sparse CSR, consumed
  *                                  at zaf.py:373, :445, :631)
@@ -44,7 +47,7 @@
 extern "C" {
 #endif
 
-#define ZAFX_VERSION 100
+#define ZAFX_VERSION 101
 
 typedef struct zafx_plan zafx_plan;
 typedef struct zafx_comm zafx_comm;
@@ -58,8 +61,11 @@ enum zafx_kind {
     ZAFX_MFCC = 6,   /* in (B, N) f32            -> out (B, n_coefs, T)   or (B, T, n_coefs)       */
     ZAFX_CQT = 7,    /* in (B, N) f32            -> out (B, n_bins, T)    or (B, T, n_bins)        */
     ZAFX_CHROMA = 8, /* in (B, N) f32            -> out (B, octave_resolution, T) or transposed    */
-    ZAFX_LINEAR = 9  /* in (B, window_length) f32 -> out (B, n_filters) f32: y = M x per clip; carries the
-                        orthonormal dct / dst types I-IV of zaf.py:703-981         */
+    ZAFX_LINEAR = 9, /* in (B, window_length) f32 -> out (B, n_filters) f32: y = M x per clip (a caller's own dense
+                        map; dct / dst lengths the FFT form below does not take)                          */
+    ZAFX_DCT = 10    /* in (B, N) f32 -> out (B, N) f32: the orthonormal dct / dst of zaf.py:703-839 / :842-981, type
+                        params.transform_type = 1..4, params.transform_sine = 0 (dct) / 1 (dst), N = window_length;
+                        one M-point complex FFT per vector (M = N/2; N-1 / N+1 for type I), M a power of two 32..8192 */
 };
 
 enum zafx_layout {
@@ -118,7 +124,9 @@ typedef struct zafx_params {
                                   128-byte line whatever T is -- the reference-layout STFT store runs at full rate only
                                   then (T = 433 compact: 2.1x slower than T = 432; padded: the same).  Power of two
                                   <= 1024.  The padding elements are never written (forward) nor used (inverse).     */
-    int32_t reserved[4];
+    int32_t transform_type;    /* ZAFX_DCT: 1, 2, 3 or 4 (dct_type / dst_type of zaf.py:703, :842)                    */
+    int32_t transform_sine;    /* ZAFX_DCT: 0 = zaf.dct, 1 = zaf.dst                                                */
+    int32_t reserved[2];
 } zafx_params;
 
 /* ---- library / device ------------------------------------------------------------ */

@@ -15,7 +15,7 @@ What is written (all .npz, float64/complex128, < 1 MB each):
                 output shape, 4096 random probes (index + value), row sums, column
                 sums and L2 norm per function
   lengths.npz   frame-count / output-length table of SURVEY.md section 4
-  dctdst.npz    zaf.dct / zaf.dst, types 1-4, lengths 8, 9, 100, 1024
+  dctdst.npz    zaf.dct / zaf.dst, types 1-4, lengths 8, 9, 100, 1024, 63, 64, 65, 1023, 1025
   cqtfull.npz   the kernel of cqtkernel's own docstring example (zaf.py:476-483: 55 Hz ... fs/2, 208 bins, 60 879
                 non-zeros, columns on both halves of the spectrum): nnz per row, column range, value probes, and the
                 full cqtspectrogram / cqtchromagram of a 100 000-sample clip with it
@@ -166,10 +166,11 @@ def make_lengths():
 
 
 def make_dctdst():
-    """zaf.dct / zaf.dst types 1-4: full vectors, odd and power-of-two lengths."""
+    """zaf.dct / zaf.dst types 1-4: full vectors, odd and power-of-two lengths (63 / 64 / 65 / 1023 / 1025:
+    the lengths whose N/2, N-1 or N+1 is a power of two run on the FFT core, zafx_dct.hip)."""
     out = {}
     rng = np.random.default_rng(77)
-    for n in (8, 9, 100, 1024):
+    for n in (8, 9, 100, 1024, 63, 64, 65, 1023, 1025):
         x = rng.standard_normal(n).astype(np.float32).astype(np.float64)
         out[f"x_{n}"] = x
         for t in (1, 2, 3, 4):
@@ -197,6 +198,10 @@ if __name__ == "__main__":
     if len(sys.argv) > 1 and sys.argv[1] == "cqtfull":   # (added in round 2; the other files are unchanged)
         make_cqtfull()
         print("cqtfull.npz", os.path.getsize(os.path.join(HERE, "cqtfull.npz")))
+        sys.exit(0)
+    if len(sys.argv) > 1 and sys.argv[1] == "dctdst":    # (extended in round 4: the first four lengths come out unchanged, same generator state)
+        make_dctdst()
+        print("dctdst.npz", os.path.getsize(os.path.join(HERE, "dctdst.npz")))
         sys.exit(0)
     make_tiny()
     make_consts()

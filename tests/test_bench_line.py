@@ -12,7 +12,8 @@ sys.path.insert(0, ROOT)
 
 
 def _records():
-    return sorted(glob.glob(os.path.join(ROOT, "profiles", "r0[3-9]_bench_all.json")))
+    # full records: round 3's line was the full record itself; from round 4 on bench.py writes it to bench_detail.json
+    return sorted(glob.glob(os.path.join(ROOT, "profiles", "r03_bench_all.json")) + glob.glob(os.path.join(ROOT, "profiles", "r0[4-9]_bench_detail*.json")))
 
 
 @pytest.mark.parametrize("path", _records(), ids=os.path.basename)

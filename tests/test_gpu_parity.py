@@ -575,6 +575,68 @@ def test_dct_dst(zafx, golden, n):
     assert np.max(np.abs(zafx.dst(zafx.dst(x, 2), 3) - x)) < 1e-5
 
 
+@pytest.mark.parametrize("n", [63, 64, 65, 1023, 1024, 1025])
+def test_dct_dst_on_the_fft_core(zafx, golden, n):
+    """Lengths whose N/2 (types 2-4), N-1 (dct 1) or N+1 (dst 1) is a power of two from 32 up run on k_dct: one M-point complex
+    transform per vector with the symmetric-extension maps of zaf.py:769-835, :906-981 folded around it -- against the
+    reference's golden vectors; the others keep the dense-matrix form."""
+    g = golden["dctdst"]
+    x = g[f"x_{n}"]
+    for sine, fn, name in ((False, zafx.dct, "dct"), (True, zafx.dst, "dst")):
+        for t in (1, 2, 3, 4):
+            on_core = zafx.dct_fft_length(n, t, sine) is not None
+            assert on_core == ((n - 1 if not sine else n + 1) in (64, 1024) if t == 1 else n in (64, 1024)), (n, t, sine)
+            got = fn(x, t)
+            assert got.dtype == np.float64 and got.shape == x.shape and relerr(got, g[f"{name}{t}_{n}"]) <= TOL_FFT, (name, t)
+            if on_core:
+                assert zafx.dct_plan(n, t, sine).kernel_name == "k_dct"
+
+
+@pytest.mark.parametrize("n,rows", [(64, 1), (64, 1000), (128, 7), (256, 33), (512, 5), (1024, 16384), (2048, 9), (4096, 300), (8192, 3), (16384, 5),
+                                    (65, 40), (63, 40), (4097, 3), (4095, 3), (8193, 2), (8191, 2)])
+def test_dct_dst_batches_every_size(zafx, n, rows):
+    """Every FFT size of k_dct (M = 32 ... 8192), ragged and whole workgroup passes, more passes than workgroups, rows that are
+    not 16-byte multiples (type 1), every type, both transforms; unaligned device rows; SciPy's orthonormal dct as a second
+    reference (the reference's own plotted check, zaf.py:728-738); the inverse pairs (zaf.py:866-897)."""
+    import scipy.fftpack
+    x = np.stack([synth_clip(15, c % 11, n) for c in range(rows)])
+    pick = sorted({0, rows - 1, rows // 2, min(rows - 1, 257)})
+    for t in (1, 2, 3, 4):
+        for sine in (False, True):
+            if zafx.dct_fft_length(n, t, sine) is None:
+                continue
+            got = (zafx.dst_batch if sine else zafx.dct_batch)(x, t)
+            assert got.shape == x.shape and got.dtype == np.float32
+            for c in pick:
+                ref = (orc.dst if sine else orc.dct)(x[c].astype(np.float64), t)
+                assert relerr(got[c], ref) <= TOL_FFT, (t, sine, c)
+                sp = (scipy.fftpack.dst if sine else scipy.fftpack.dct)(x[c].astype(np.float64), type=t, norm="ortho")
+                assert relerr(got[c], sp) <= TOL_FFT, (t, sine, c)
+            if rows > 11:
+                assert np.array_equal(got[11:22], got[0:11])   # replicas of the same vectors in other workgroup passes
+    if n % 2 == 0:
+        k = min(3, rows)
+        back = zafx.dct_batch(zafx.dct_batch(x[:k], 2), 3)
+        assert np.max(np.abs(back - x[:k])) < 2e-5
+        back = zafx.dst_batch(zafx.dst_batch(x[:k], 4), 4)
+        assert np.max(np.abs(back - x[:k])) < 2e-5
+        # a device array that starts 4 bytes into an allocation: the 4-byte load / store path
+        import ctypes
+        plan = zafx.dct_plan(n, 2)
+        d_in = zafx.DeviceBuffer((k * n + 1,), np.float32)
+        d_out = zafx.DeviceBuffer((k * n + 1,), np.float32)
+        d_in.upload(np.concatenate(([0.0], x[:k].reshape(-1))).astype(np.float32))
+        views = [zafx.DeviceBuffer((k, n), np.float32, _ptr_from_pool=ctypes.c_void_p(b.ptr.value + 4)) for b in (d_in, d_out)]
+        plan.execute(views[0], views[1], k, n)
+        plan.sync()
+        for v in views:
+            v.ptr = ctypes.c_void_p()   # (views, not allocations: nothing to free)
+        shifted = d_out.download()[1:].reshape(k, n)
+        assert np.array_equal(shifted, zafx.dct_batch(x[:k], 2))
+        d_in.free()
+        d_out.free()
+
+
 # ------------------------------------------------------------------ one-sided spectra (SURVEY 8f rank 4)
 @pytest.mark.parametrize("wl,hop,n", [(2048, 1024, 441000), (2048, 512, 30000), (1024, 256, 9001), (128, 64, 777), (4096, 2048, 50000)])
 def test_onesided_stft_istft(zafx, wl, hop, n):

@@ -177,7 +177,7 @@ def test_config_Q(golden):
     _check_probes(g, "Q0_chroma", orc.cqtchromagram(x, 44100, 25, 24, ck), 1e-11)
 
 
-@pytest.mark.parametrize("n", [8, 9, 100, 1024])
+@pytest.mark.parametrize("n", [8, 9, 100, 1024, 63, 64, 65, 1023, 1025])
 def test_dct_dst(golden, n):
     """oracle dct/dst types 1-4 against the reference, plus the reference's own
     plotted self-checks (zaf.py:728-753 DCT vs SciPy ortho; :866-897 DST inverse pairs)."""

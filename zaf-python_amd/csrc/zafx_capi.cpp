@@ -555,11 +555,11 @@ int zafx_plan_create(zafx_plan** out, int device, int kind, const zafx_params* p
     if (params->spectrum >= ZAFX_SPECTRUM_MAGNITUDE && kind != ZAFX_STFT)
         return fail_msg("magnitude / power spectra are outputs of ZAFX_STFT only");
     if (params->precision != ZAFX_PRECISION_F32 && params->precision != ZAFX_PRECISION_F64) return fail_msg("bad precision");
-    if (params->precision == ZAFX_PRECISION_F64 && kind == ZAFX_LINEAR)
-        return fail_msg("ZAFX_PRECISION_F64 is not available for ZAFX_LINEAR");
+    if (params->precision == ZAFX_PRECISION_F64 && (kind == ZAFX_LINEAR || kind == ZAFX_DCT))
+        return fail_msg("ZAFX_PRECISION_F64 is not available for ZAFX_LINEAR / ZAFX_DCT");
     if (params->row_align < 0 || params->row_align > 1024 || (params->row_align & (params->row_align - 1)))
         return fail_msg("row_align must be 0 or a power of two <= 1024");
-    if (params->row_align > 1 && (params->layout != ZAFX_LAYOUT_FT || kind == ZAFX_LINEAR))
+    if (params->row_align > 1 && (params->layout != ZAFX_LAYOUT_FT || kind == ZAFX_LINEAR || kind == ZAFX_DCT))
         return fail_msg("row_align applies to the 2-D arrays of ZAFX_LAYOUT_FT plans only");
     {
         int n_dev = 0;
@@ -662,6 +662,25 @@ int zafx_plan_create(zafx_plan** out, int device, int kind, const zafx_params* p
         pl->log2nf = 4;   // only so that the (unused) FFT tables below are small
         aux.assign(1, cf32{1.f, 0.f});
         pl->kernel_name = linear_kernel_name();
+    } else if (kind == ZAFX_DCT) {
+        // zaf.dct / zaf.dst on the FFT core (zafx_dct.hip): M complex points per vector, tables A | B of M + 1 entries each
+        const int N = params->window_length, type = params->transform_type;
+        const bool sine = params->transform_sine != 0;
+        if (type < 1 || type > 4) return bail("transform_type must be 1, 2, 3 or 4");
+        if (params->transform_sine != 0 && params->transform_sine != 1) return bail("transform_sine must be 0 (dct) or 1 (dst)");
+        if (N < 2) return bail("dct / dst: window_length must be at least 2");
+        const int M = type == 1 ? (sine ? N + 1 : N - 1) : (N % 2 == 0 ? N / 2 : -1);
+        const int lm = ilog2_exact(M);
+        if (lm < 0 || !dct_supported(lm))
+            return bail("dct / dst on the FFT core: N / 2 (types 2-4), N - 1 (dct type 1) or N + 1 (dst type 1) must be a power of two in [32, 8192]");
+        pl->W = N;
+        pl->log2nf = lm;
+        aux.resize(2 * (size_t)(M + 1));
+        for (int k = 0; k <= M; ++k) {
+            aux[(size_t)k] = type == 4 ? unit_root(4LL * k + 1, 8LL * N) : unit_root(k, 2LL * M);
+            aux[(size_t)(M + 1 + k)] = type == 4 ? unit_root(k, 2LL * N) : unit_root(k, 4LL * N);
+        }
+        pl->kernel_name = dct_kernel_name();
     } else {
         return bail("unknown plan kind");
     }
@@ -829,7 +848,7 @@ int zafx_plan_destroy(zafx_plan* pl) {
 static int expected_constant_bytes(const zafx_plan* pl, int which, size_t bytes, size_t* elem) {
     switch (which) {
         case ZAFX_CONST_WINDOW:
-            if (is_cqt_family(pl->kind) || pl->kind == ZAFX_LINEAR) return fail_msg("this plan kind takes no window");
+            if (is_cqt_family(pl->kind) || pl->kind == ZAFX_LINEAR || pl->kind == ZAFX_DCT) return fail_msg("this plan kind takes no window");
             if (pl->prm.precision == ZAFX_PRECISION_F64) {
                 *elem = sizeof(double);
                 return bytes == (size_t)pl->W * sizeof(double) ? 0 : fail_msg("window must hold window_length float64 (ZAFX_PRECISION_F64 plan)");
@@ -936,6 +955,9 @@ int zafx_plan_out_dims(const zafx_plan* pl, int64_t n_in, int64_t dims[2]) {
         case ZAFX_LINEAR:
             if (n_in != pl->W) return fail_msg("linear map: input length must equal window_length");
             dims[0] = pl->prm.n_filters; dims[1] = 1; return 0;
+        case ZAFX_DCT:
+            if (n_in != pl->W) return fail_msg("dct / dst: input length must equal window_length");
+            dims[0] = pl->W; dims[1] = 1; return 0;
     }
     return fail_msg("unknown plan kind");
 }
@@ -950,7 +972,7 @@ int zafx_plan_row_pitch(const zafx_plan* pl, int64_t n_in, int64_t* pitch) {
                                                   : (pl->prm.spectrum != ZAFX_SPECTRUM_TWO_SIDED ? pl->W / 2 + 1 : pl->W);
             return 0;
         case ZAFX_IMDCT: *pitch = pl->layout == ZAFX_LAYOUT_FT ? row_pitch(*pl, n_in) : pl->W / 2; return 0;
-        case ZAFX_LINEAR: *pitch = dims[0]; return 0;
+        case ZAFX_LINEAR: case ZAFX_DCT: *pitch = dims[0]; return 0;
         default: *pitch = pl->layout == ZAFX_LAYOUT_FT ? row_pitch(*pl, dims[1]) : dims[0]; return 0;
     }
 }
@@ -963,7 +985,7 @@ int zafx_execute(zafx_plan* pl, const void* d_in, void* d_out, int64_t n_clips, 
     int64_t dims[2];
     if (int rc = zafx_plan_out_dims(pl, n_in, dims)) return rc;
     if (pl->kind == ZAFX_LINEAR && !pl->d_matrix) return fail_msg("matrix constant not set");
-    if (!is_cqt_family(pl->kind) && pl->kind != ZAFX_LINEAR && !pl->d_window && !pl->d_window64) return fail_msg("window constant not set");
+    if (!is_cqt_family(pl->kind) && pl->kind != ZAFX_LINEAR && pl->kind != ZAFX_DCT && !pl->d_window && !pl->d_window64) return fail_msg("window constant not set");
     if ((pl->kind == ZAFX_MEL || pl->kind == ZAFX_MFCC) && !pl->fb.d_pack && !pl->d_fb64 && !pl->d_fbw) return fail_msg("mel filterbank constant not set");
     if (pl->kind == ZAFX_MFCC && !pl->dct.d_pack && !pl->d_dct64 && !pl->d_dctw) return fail_msg("DCT constant not set");
     if (is_cqt_family(pl->kind)) {
@@ -1010,6 +1032,9 @@ int zafx_execute(zafx_plan* pl, const void* d_in, void* d_out, int64_t n_clips, 
             break;
         case ZAFX_LINEAR:
             e = launch_linear(*pl, (const float*)d_in, (float*)d_out, n_clips);
+            break;
+        case ZAFX_DCT:
+            e = launch_dct(*pl, (const float*)d_in, (float*)d_out, n_clips);
             break;
         case ZAFX_CQT:
         case ZAFX_CHROMA:
@@ -1063,7 +1088,7 @@ static int clip_bytes(const zafx_plan* pl, int64_t n_in, int64_t* in_b, int64_t*
             *in_b = (ft ? (int64_t)(pl->W / 2) * pitch : n_in * (pl->W / 2)) * real;
             *out_b = dims[0] * real;
             return 0;
-        case ZAFX_LINEAR:
+        case ZAFX_LINEAR: case ZAFX_DCT:
             *in_b = (int64_t)pl->W * 4;
             *out_b = dims[0] * 4;
             return 0;
@@ -1328,6 +1353,7 @@ int zafx_comm_broadcast_constants(zafx_comm* c, zafx_plan* pl, int root) {
     ZAFX_HIP(hipSetDevice(pl->device));
     std::vector<int> ids;
     if (pl->kind == ZAFX_LINEAR) ids.push_back(ZAFX_CONST_MATRIX);
+    else if (pl->kind == ZAFX_DCT) {}   // (no caller-supplied constants: the tables follow from the parameters on every rank)
     else if (!is_cqt_family(pl->kind)) ids.push_back(ZAFX_CONST_WINDOW);
     if (pl->kind == ZAFX_MEL || pl->kind == ZAFX_MFCC) ids.push_back(ZAFX_CONST_MEL_FB);
     if (pl->kind == ZAFX_MFCC) ids.push_back(ZAFX_CONST_DCT);

@@ -190,6 +190,9 @@ bool mel_band_usable(const zafx_plan& pl, const float* x, int64_t n_clips, int64
 hipError_t launch_mel_band(const zafx_plan& pl, const float* x, float* out, int64_t n_clips, int64_t n_samples, int T);
 hipError_t launch_cqt(const zafx_plan& pl, const float* x, float* out, int64_t n_clips, int64_t n_samples, int T);
 hipError_t launch_linear(const zafx_plan& pl, const float* x, float* y, int64_t n_clips);
+hipError_t launch_dct(const zafx_plan& pl, const float* x, float* y, int64_t n_rows);   // zafx_dct.hip: dct / dst I-IV on the FFT core
+bool dct_supported(int log2m);   // log2 of the complex FFT length M
+const char* dct_kernel_name();
 const char* linear_kernel_name();
 hipError_t launch_pcm_to_float(hipStream_t stream, const void* pcm, float* out, int64_t n_total, int n_channels, int sample_bytes);
 

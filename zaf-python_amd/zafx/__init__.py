@@ -12,11 +12,11 @@ Batched extension ((clips, samples) in, float32 / complex64 out):
 Device-resident API: Plan, DeviceBuffer, Comm, *_plan factories, shard helpers; one process per GPU: launch.Rendezvous,
 spawn_ranks (file rendezvous + self-launcher, no torch.distributed).
 """
-from ._lib import (CHROMA, CQT, IMDCT, ISTFT, LAYOUT_FT, LAYOUT_TF, LINEAR, MDCT, MEL, MFCC, STFT, ZafxError, device_count,
+from ._lib import (CHROMA, CQT, DCT, IMDCT, ISTFT, LAYOUT_FT, LAYOUT_TF, LINEAR, MDCT, MEL, MFCC, STFT, ZafxError, device_count,
                    device_name, library_path)
 from .constants import cqtkernel, dct2_rows, dct_matrix, dst_matrix, hamming, kaiser_bessel_derived, melfilterbank, sine
 from .core import (Comm, DeviceBuffer, Plan, clear_plan_cache, cqt_plan, cqtchromagram, cqtchromagram_batch, dct, dct_batch, dst,
-                   dst_batch, linear_plan,
+                   dst_batch, linear_plan, dct_plan, dct_fft_length,
                    cqtspectrogram, cqtspectrogram_batch, imdct, imdct_batch, istft, istft_batch, istft_plan, mdct,
                    mdct_batch, mdct_plan, mel_plan, melspectrogram, melspectrogram_batch, mfcc, mfcc_batch, pcm_to_mono, pinned_empty,
                    get_precision, set_precision, stft, stft_batch, stft_pcm_batch, stft_plan)

@@ -9,7 +9,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 
 # enum zafx_kind
-STFT, ISTFT, MDCT, IMDCT, MEL, MFCC, CQT, CHROMA, LINEAR = 1, 2, 3, 4, 5, 6, 7, 8, 9
+STFT, ISTFT, MDCT, IMDCT, MEL, MFCC, CQT, CHROMA, LINEAR, DCT = 1, 2, 3, 4, 5, 6, 7, 8, 9, 10
 # enum zafx_layout
 LAYOUT_FT, LAYOUT_TF = 0, 1
 # enum zafx_spectrum
@@ -38,7 +38,9 @@ class ZafxParams(ctypes.Structure):
         ("spectrum", ctypes.c_int32),
         ("precision", ctypes.c_int32),
         ("row_align", ctypes.c_int32),
-        ("reserved", ctypes.c_int32 * 4),
+        ("transform_type", ctypes.c_int32),
+        ("transform_sine", ctypes.c_int32),
+        ("reserved", ctypes.c_int32 * 2),
     ]
 
 
@@ -106,8 +108,8 @@ def load():
         fn = getattr(lib, name)
         fn.restype = res
         fn.argtypes = args
-    if lib.zafx_version() != 100:
-        raise ZafxError(f"libzafx.so version {lib.zafx_version()} does not match the Python binding (100)")
+    if lib.zafx_version() != 101:
+        raise ZafxError(f"libzafx.so version {lib.zafx_version()} does not match the Python binding (101)")
     _lib = lib
     return lib
 

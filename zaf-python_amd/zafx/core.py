@@ -246,7 +246,7 @@ class Plan:
     _FORWARD = (_lib.STFT, _lib.MDCT, _lib.MEL, _lib.MFCC, _lib.CQT, _lib.CHROMA)   # 2-D (frequency x time) outputs
 
     def __init__(self, kind, device=0, window_length=0, step_length=0, layout="FT", n_filters=0, n_coefs=0,
-                 fft_length=0, n_bins=0, octave_resolution=0, onesided=False, f64=False, row_align=0):
+                 fft_length=0, n_bins=0, octave_resolution=0, onesided=False, f64=False, row_align=0, transform_type=0, transform_sine=False):
         self.kind = kind
         self.device = int(device)
         self.layout = _LAYOUTS[layout]
@@ -260,6 +260,8 @@ class Plan:
         prm.fft_length = int(fft_length)
         prm.n_bins = int(n_bins)
         prm.octave_resolution = int(octave_resolution)
+        prm.transform_type = int(transform_type)
+        prm.transform_sine = int(bool(transform_sine))
         self.spectrum = _spectrum_of(onesided)
         prm.spectrum = self.spectrum
         prm.precision = _lib.PRECISION_F64 if f64 else _lib.PRECISION_F32
@@ -916,15 +918,37 @@ def pcm_to_mono(pcm, device=0):
             d_x.free()
 
 
-def _transform_batch(vectors, matrix_fn, kind, device):
+def dct_fft_length(length, kind, sine):
+    """M, the complex FFT length zafx_dct.hip runs for a dct / dst of this length and type -- or None when the length is
+    outside that kernel (M must be a power of two in [32, 8192]): N/2 for types 2-4, N-1 (dct) / N+1 (dst) for type 1."""
+    n = int(length)
+    m = (n + 1 if sine else n - 1) if kind == 1 else (n // 2 if n % 2 == 0 else 0)
+    return m if 32 <= m <= 8192 and m & (m - 1) == 0 else None
+
+
+def dct_plan(length, kind, sine=False, device=0):
+    """Plan of the orthonormal dct (sine=False) / dst of type `kind` of vectors of `length` samples on the FFT core
+    (zaf.py:703-839, :842-981: one M-point complex transform per vector instead of the reference's 2N-2 ... 8N-point one)."""
+    if dct_fft_length(length, kind, sine) is None:
+        raise ValueError("this length / type does not run on the FFT core (see dct_fft_length)")
+    return _cached(("dct_fft", int(length), int(kind), bool(sine), device),
+                   lambda: Plan(_lib.DCT, device, window_length=int(length), transform_type=int(kind), transform_sine=bool(sine)))
+
+
+def _transform_batch(vectors, matrix_fn, kind, device, out=None):
     x = np.ascontiguousarray(vectors, dtype=np.float32)
     if x.ndim != 2 or x.shape[1] < 1:
         raise ValueError("vectors must be 2-D (batch, length) with length >= 1")
     n = x.shape[1]
-    if n > 16384:
-        raise ValueError("dct / dst lengths above 16384 are not supported")
     if kind not in (1, 2, 3, 4):
         raise ValueError("type must be 1, 2, 3 or 4")
+    sine = matrix_fn is constants.dst_matrix
+    if dct_fft_length(n, kind, sine) is not None:   # O(N log N): the FFT core, as the reference computes it
+        return dct_plan(n, kind, sine, device).run_host(x, n, out=out)
+    # other lengths (N/2, N-1 or N+1 not a power of two; very short or very long vectors): the transform as a dense matrix on
+    # the matrix cores -- O(N^2) arithmetic and an N x N table, so bounded
+    if n > 16384:
+        raise ValueError("dct / dst lengths above 16384 need N/2 (type 1: N-1 / N+1) to be a power of two")
 
     def make():   # the N x N matrix (O(N^2) trigonometry, 8 N^2 bytes) is built once per (transform, type, N, device)
         m = np.ascontiguousarray(matrix_fn(n, kind), dtype=np.float64)
@@ -932,17 +956,17 @@ def _transform_batch(vectors, matrix_fn, kind, device):
         p.set_matrix(m)
         return p
     plan = _cached((matrix_fn.__name__, int(kind), n, device), make)
-    return plan.run_host(x, n)
+    return plan.run_host(x, n, out=out)
 
 
-def dct_batch(vectors, dct_type, device=0):
+def dct_batch(vectors, dct_type, device=0, out=None):
     """(B, N) -> (B, N) float32: orthonormal DCT of type 1-4 of every row (zaf.dct per row)."""
-    return _transform_batch(vectors, constants.dct_matrix, dct_type, device)
+    return _transform_batch(vectors, constants.dct_matrix, dct_type, device, out)
 
 
-def dst_batch(vectors, dst_type, device=0):
+def dst_batch(vectors, dst_type, device=0, out=None):
     """(B, N) -> (B, N) float32: orthonormal DST of type 1-4 of every row (zaf.dst per row)."""
-    return _transform_batch(vectors, constants.dst_matrix, dst_type, device)
+    return _transform_batch(vectors, constants.dst_matrix, dst_type, device, out)
 
 
 def dct(audio_signal, dct_type):

@@ -18,6 +18,7 @@ ZAFX_BENCH_INNER_LOG="$OUT/prof_all_launches.json" timeout 900 rocprofv3 --kerne
 cp "$OUT/bench_detail.json" "$OUT/bench_detail_profiled.json" 2>/dev/null
 cd "$REPO" || exit 1
 timeout 900 python bench.py --gpus 1 --steps 20 --warmup 5 > "$OUT/bench_all.json" 2> "$OUT/bench_all.log"   # the driver's own command
+cp "$OUT/bench_detail.json" "$OUT/bench_detail_plain.json" 2>/dev/null   # (the counter passes below write their own)
 cd /tmp || exit 1
 for k in $SQ_KINDS; do
   rm -rf "$OUT/pmc_${k}_SQ" "$OUT/pmc_${k}_LDS"

@@ -42,7 +42,7 @@ for src, dst in (("bench_all_profiled.json", f"{tag}_bench_all.json"), ("bench_a
     if line:
         json.loads(line)
         open(os.path.join(PROF, dst), "w").write(line + "\n")
-for src, dst in (("bench_detail_profiled.json", f"{tag}_bench_detail.json"), ("bench_detail.json", f"{tag}_bench_detail_plain.json")):
+for src, dst in (("bench_detail_profiled.json", f"{tag}_bench_detail.json"), ("bench_detail_plain.json", f"{tag}_bench_detail_plain.json")):
     p = os.path.join(OUT, src)
     if os.path.exists(p):
         open(os.path.join(PROF, dst), "w").write(json.dumps(json.load(open(p)), indent=1) + "\n")

@@ -29,7 +29,7 @@ def test_library_exports_every_declared_symbol(built_library):
     for name in declared_symbols():
         assert hasattr(lib, name), name
     lib.zafx_version.restype = ctypes.c_int
-    assert lib.zafx_version() == 100
+    assert lib.zafx_version() == 101
 
 
 def test_params_struct_layout(built_library):

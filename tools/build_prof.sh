@@ -3,7 +3,7 @@
 set -e
 cd "$(dirname "$0")/../zaf-python_amd/csrc"
 mkdir -p ../../tools/bin/prof
-for f in zafx_capi.cpp zafx_stft.hip zafx_mdct.hip zafx_mel.hip zafx_cqt.hip zafx_pcm.hip zafx_linear.hip zafx_f64.hip zafx_bs32.hip; do
+for f in zafx_capi.cpp zafx_stft.hip zafx_mdct.hip zafx_mel.hip zafx_cqt.hip zafx_pcm.hip zafx_linear.hip zafx_dct.hip zafx_f64.hip zafx_bs32.hip; do
   /opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 -ffp-contract=fast -DZAFX_PROF -x hip -c $f -o ../../tools/bin/prof/${f%.*}.o &
 done
 wait

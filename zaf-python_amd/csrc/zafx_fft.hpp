@@ -78,6 +78,17 @@ ZAFX_HD float2 cmulk(float2 a, float kx, float ky) {
     return make_float2(a.x * kx - a.y * ky, a.x * ky + a.y * kx);
 #endif
 }
+// (a.x b.x, a.y b.y) as ONE packed multiply the compiler cannot contract into a neighbouring addition: code inlined at several
+// sites (k_mel's pre-transform) then rounds the same way at each of them
+ZAFX_HD float2 mul_elem(float2 a, float2 b) {
+#if defined(ZAFX_PK)
+    zafx_v2f r;
+    asm("v_pk_mul_f32 %0, %1, %2" : "=v"(r) : "v"(to_v2(a)), "v"(to_v2(b)));
+    return to_f2(r);
+#else
+    return make_float2(a.x * b.x, a.y * b.y);
+#endif
+}
 ZAFX_HD float2 cconj(float2 a) { return make_float2(a.x, -a.y); }
 ZAFX_HD float2 mul_mi(float2 a) { return make_float2(a.y, -a.x); }   // a * (-i)
 ZAFX_HD float2 add_mi(float2 a, float2 b) {   // a + (-i) b = (a.x + b.y, a.y - b.x)

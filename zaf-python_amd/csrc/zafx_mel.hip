@@ -44,6 +44,18 @@ constexpr bool kMelWinLds = kMelFpb == 16;   // 512: 8 fat waves (2 frames each,
 #ifndef ZAFX_MEL_R32
 #define ZAFX_MEL_R32 0
 #endif
+// window + first radix-16 butterflies of the NEXT tile's frame beside the matrix instructions of the filterbank product: the vector
+// pipe is idle there -- four waves' dependent MFMA chains keep a SIMD for 2.3 k cycles.  (Round 3 ran these 500 cycles per wave after
+// the reduction, ahead of the tile's last barrier.  A first form of round 4 issued them piecewise between the K-steps of one wave: the
+// register allocator then spilled the resident A fragments and reloaded them inside the dependent chain, 2.0 ms.)
+#ifndef ZAFX_MEL_GEMM_PRE
+#define ZAFX_MEL_GEMM_PRE 1
+#endif
+// (experiment switch) A fragments of the filterbank re-read from L2 every tile, ahead of the barrier, instead of riding in registers
+#ifndef ZAFX_MEL_RELOAD_A
+#define ZAFX_MEL_RELOAD_A 1
+#endif
+
 // points per thread of the FFT: 32 (two radix-32 passes, a frame per half wavefront, 8 waves) for W = 2048 when enabled
 constexpr int mel_log2e(int log2n) { return (ZAFX_MEL_R32 && log2n == 10) ? 5 : default_log2e(log2n); }
 constexpr int mel_threads(int log2n, int log2e) {
@@ -95,7 +107,7 @@ __device__ __forceinline__ void gemm_items(const float* __restrict__ pack, const
 // traffic of its own, so the samples of the next tile can be requested underneath, one load after every K-step (`hook`) -- a
 // burst of 16 loads per lane overruns the CU's vector-memory queue and blocks the wave at issue (profiles/r02_notes.md).
 // Step i of the wave: 16 bits of desc[i / 2] (SGPRs, tile-invariant; PackedBand::d_desc): first column / 4 | slot << 8 | item ends << 15.
-template <int RA, class SlotFn, class BFn, class Hook>
+template <int RA, int CHUNK = 0, class SlotFn, class BFn, class Hook>
 __device__ __forceinline__ void gemm_resident(const float (&a)[RA], const int (&desc)[(RA + 1) / 2], int n, int lane, int slot0, SlotFn slot_ptr, BFn b_at, Hook hook) {
     f32x4 acc = {0.f, 0.f, 0.f, 0.f};
     const int bt = lane & 15, bk = lane >> 4;
@@ -110,7 +122,7 @@ __device__ __forceinline__ void gemm_resident(const float (&a)[RA], const int (&
     asm volatile("" : "+s"(n));
     // the B fragments of a chunk of steps are requested up front: the MFMA chain then waits for LDS once per chunk, not once per
     // step (a chunk = all steps up to 18; the 8-frame form's 36 steps go in two chunks, for the registers' sake)
-    constexpr int CH = RA > 18 ? (RA + 1) / 2 : RA;
+    constexpr int CH = CHUNK > 0 ? CHUNK : RA > 18 ? (RA + 1) / 2 : RA;   // (CHUNK: with vector work between the steps the chain can afford to wait for LDS more often)
 #pragma unroll
     for (int c0 = 0; c0 < RA; c0 += CH) {
         float b[CH];
@@ -207,8 +219,10 @@ __global__ __launch_bounds__(mel_threads(LOG2N, LOG2E), kMelFpb == 8 ? 2 * mel_t
     float2 xr[E];
     __amdgpu_buffer_rsrc_t frx = make_rsrc(x, 0);
     int fvoff = 0;
+    bool interior = false;   // the frame fetch_begin set up is still to be requested load by load (fetch_one)
     const bool xcd = ZAFX_XCD_ORDER && gridDim.x % 8 == 0;   // (xcd_order: tiles of a clip to the workgroups of one XCD)
     auto fetch_begin = [&](int tlv, int f0, int p) -> bool {   // p: the lane's points are p + i P (an opaque copy inside the tile loop)
+        interior = false;
         if (tlv >= total_tiles) return false;
         const int tl = xcd ? xcd_order(tlv, total_tiles) : tlv;
         const int clip = tl / tiles, tile = tl % tiles;
@@ -220,6 +234,7 @@ __global__ __launch_bounds__(mel_threads(LOG2N, LOG2E), kMelFpb == 8 ? 2 * mel_t
             // 16 64-bit addresses: the prefetch across the filterbank phases then spills)
             frx = make_rsrc(xc, (unsigned)std::min<long long>(n_samples * 4, 0xfffffffcLL));
             fvoff = PAIR16 ? ((int)s0 + 2 * (p & ~1)) * 4 + (p & 1) * (E / 2 * P * 8) : ((int)s0 + 2 * p) * 4;
+            interior = true;
             return true;
         }
 #pragma unroll
@@ -227,6 +242,23 @@ __global__ __launch_bounds__(mel_threads(LOG2N, LOG2E), kMelFpb == 8 ? 2 * mel_t
             const long long s = s0 + 2 * (p + i * P);
             xr[i].x = (t < T && s >= 0 && s < n_samples) ? xc[s] : 0.f;
             xr[i].y = (t < T && s + 1 >= 0 && s + 1 < n_samples) ? xc[s + 1] : 0.f;
+        }
+        if constexpr (PAIR16 && ZAFX_MEL_GEMM_PRE) {
+            // into the layout the 16-byte loads leave (row_pair_unpack is its own inverse): every frame then takes the same way
+            // through the staged pre-transform under the filterbank's matrix instructions
+            float2 lo[E / 2], hi[E / 2];
+#pragma unroll
+            for (int i = 0; i < E / 2; ++i) {
+                lo[i] = xr[i];
+                hi[i] = xr[i + E / 2];
+                row_pair_unpack(lo[i], hi[i]);
+            }
+#pragma unroll
+            for (int i = 0; i < E / 2; ++i) {
+                xr[2 * i] = lo[i];
+                xr[2 * i + 1] = hi[i];
+            }
+            return true;
         }
         return false;
     };
@@ -272,14 +304,14 @@ __global__ __launch_bounds__(mel_threads(LOG2N, LOG2E), kMelFpb == 8 ? 2 * mel_t
 #pragma unroll
             for (int i = 0; i < E; ++i) {
                 const float2 wv = win_at(po, i);   // (pair form: the table is in lane order)
-                xr[i] = make_float2(xr[i].x * wv.x, xr[i].y * wv.y);
+                xr[i] = mul_elem(xr[i], wv);
             }
             Dft<16>::run(xr);
         }
     };
     if constexpr (PREFETCH || LATE) {
         raw = fetch_begin(blockIdx.x, 0, PAIR16 ? row_pair_index(p) : p);
-        if (raw) {
+        if (interior) {
 #pragma unroll
             for (int i = 0; i < E; ++i) fetch_one(i);
         }
@@ -313,7 +345,7 @@ __global__ __launch_bounds__(mel_threads(LOG2N, LOG2E), kMelFpb == 8 ? 2 * mel_t
         ndct = __builtin_amdgcn_readfirstlane(mfcc ? (int)((long long)dct_steps * (wave + 1) / NW) - h0 : 0);
 #pragma unroll
         for (int i = 0; i < (RADCT + 1) / 2; ++i) sdct[i] = __builtin_amdgcn_readfirstlane(2 * i < ndct ? (dct_desc[h0 + 2 * i] | dct_desc[h0 + 2 * i + 1] << 16) : 0);
-        if constexpr (!TEAM8) load_fragments(tid & 63);
+        if constexpr (!TEAM8 && !(PAIR16 && ZAFX_MEL_GEMM_PRE && ZAFX_MEL_RELOAD_A)) load_fragments(tid & 63);
     }
     PROF_INIT(g_prof_mel);
     for (int tlv = blockIdx.x; tlv < total_tiles; tlv += gridDim.x) {
@@ -398,10 +430,10 @@ __global__ __launch_bounds__(mel_threads(LOG2N, LOG2E), kMelFpb == 8 ? 2 * mel_t
         // vector memory, idle through the transforms, works while the early waves wait at the barrier; the filterbank GEMM then
         // runs without loads in between.  Otherwise: one load per K-step of the GEMM.
         bool fast = false;
-        if constexpr (TEAM8) load_fragments(lane);   // from L2, ahead of the request of the next frame (they are needed first)
+        if constexpr (TEAM8 || (PAIR16 && ZAFX_MEL_GEMM_PRE && ZAFX_MEL_RELOAD_A)) load_fragments(lane);   // from L2, ahead of the request of the next frame (they are needed first)
         if constexpr (LATE) {
             fast = fetch_begin(tlv + gridDim.x, 0, PAIR16 ? row_pair_index(to % P) : to % P);
-            if (ZAFX_MEL_EARLY && fast) {
+            if (ZAFX_MEL_EARLY && interior) {
 #pragma unroll
                 for (int i = 0; i < E; ++i) fetch_one(i);
             }
@@ -412,9 +444,26 @@ __global__ __launch_bounds__(mel_threads(LOG2N, LOG2E), kMelFpb == 8 ? 2 * mel_t
         PROF_MARK(2);
 
         // ---- mel = FB . S on the matrix cores
+        constexpr bool GEMM_PRE = PAIR16 && ZAFX_MEL_GEMM_PRE && ZAFX_MEL_PREPASS && ZAFX_MEL_EARLY;
         {
             const float* sb = fall + (size_t)(bt % FPB) * (2 * C::PITCH) + bk;   // (8-frame tiles: columns 8..15 repeat 0..7 and are not used)
-            if constexpr (RES)
+            if constexpr (RES && GEMM_PRE) {
+                // The next frame's window + first radix-16 butterflies (500 cycles of vector issue per wave) beside the filterbank product
+                // (four dependent MFMA chains keep a SIMD's matrix pipe for 2.3 k cycles, its vector pipe idle): of the four waves of a
+                // SIMD (w, w + 4, w + 8, w + 12) two run the butterflies first and the product second, two the other way round.
+                pre_done = tlv + gridDim.x < total_tiles;   // (uniform)
+                const bool pre_first = (wave & 8) == 0;   // (the waves that finished their transforms first: their samples were requested thousands of cycles ago)
+                auto pre = [&]() {
+                    if (pre_done) {
+                        int pq = p;
+                        asm volatile("" : "+v"(pq));
+                        pre_transform(pq);
+                    }
+                };
+                if (pre_first) pre();
+                gemm_resident(afb, sfb, nfb, lane, 0, slot_ptr, [&](int col) { return sb[col]; }, [](int) {});
+                if (!pre_first) pre();
+            } else if constexpr (RES)
                 gemm_resident(afb, sfb, nfb, lane, 0, slot_ptr, [&](int col) { return sb[col]; }, [&](int i) { if (LATE && !ZAFX_MEL_EARLY && i < E && fast) fetch_one(i); });
             else gemm_items(fb_pack, fb_items, fb_wave_ptr, wave, lane, 0, slot_ptr, [&](int col) { return sb[col]; });
         }
@@ -495,7 +544,7 @@ __global__ __launch_bounds__(mel_threads(LOG2N, LOG2E), kMelFpb == 8 ? 2 * mel_t
             }
         }
         PROF_MARK(5);
-        if constexpr (PAIR16) {
+        if constexpr (PAIR16 && !GEMM_PRE) {
             // window and first radix-16 butterflies of the next tile's frame, in registers, AHEAD of the barrier that frees the frame
             // buffers: only the writes of pass 1 have to wait for the other waves' reductions
             pre_done = ZAFX_MEL_PREPASS && tlv + gridDim.x < total_tiles;

@@ -195,6 +195,13 @@ int zafx_cqt_max_bins(int fft_length, int* n_bins);
 int zafx_pcm_to_float(zafx_plan* plan, const void* d_pcm, void* d_out, int64_t n_clips, int64_t n_frames,
                       int n_channels, int sample_bytes);
 
+/* zafx_run_host for integer PCM: h_pcm = (n_clips, n_frames, n_channels) interleaved int16 / int32 as wavread's source
+ * holds them (zaf.py:1187-1204); every chunk crosses PCIe as integers (2 or 4 bytes per sample and channel instead of 4 per
+ * float32 sample), is normalised and mixed down on the device in front of the transform, and the transform's result comes
+ * back as from zafx_run_host.  Plans that take samples: STFT, MDCT, MEL, MFCC, CQT, CHROMA, DCT (float32). */
+int zafx_run_host_pcm(zafx_plan* plan, const void* h_pcm, void* h_out, int64_t n_clips, int64_t n_frames, int n_channels,
+                      int sample_bytes, int64_t chunk_clips);
+
 /* ---- multi-GPU: one process per GPU, RCCL over xGMI --------------------------------- */
 /* The only collective on this path: broadcast of the shared constants (window,
  * filterbank, DCT matrix, CQT kernel) from `root`.  No reduction exists. */

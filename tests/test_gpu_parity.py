@@ -515,6 +515,43 @@ def test_pcm_ingest(zafx, dtype, channels):
         zafx.pcm_to_mono(pcm.astype(np.float32))
 
 
+@pytest.mark.parametrize("dtype,channels", [(np.int16, 1), (np.int16, 2), (np.int32, 1)])
+def test_pcm_batch_every_kind(zafx, dtype, channels):
+    """Every transform that takes samples from integer PCM through the chunked host pipeline (zafx_run_host_pcm: integers cross
+    PCIe, zaf.py:1202 / :65 on the device): equal, bit for bit, to the float32 call on the normalised mono signal; parity against
+    the oracle on x / 2^(bits-1); several chunks (both staging sets, a ragged last chunk)."""
+    rng = np.random.default_rng(21)
+    info = np.iinfo(dtype)
+    pcm = rng.integers(info.min // 2, info.max // 2, size=(7, 50000, channels), dtype=dtype, endpoint=True)
+    if channels == 1 and dtype == np.int16:
+        pcm = pcm[:, :, 0]   # (clips, frames) is accepted too
+    mono = zafx.pcm_to_mono(pcm)
+    ref = np.mean(np.atleast_3d(pcm) / pow(2, pcm.itemsize * 8 - 1), axis=2)
+    assert np.max(np.abs(mono - ref)) <= 2e-7
+    ham, kbd = zafx.hamming(2048), zafx.kaiser_bessel_derived(2048)
+    fb = zafx.melfilterbank(44100, 2048, 128)
+    ck = zafx.cqtkernel(44100, 24, 55, 3520)
+    calls = [
+        (zafx.stft_pcm_batch, zafx.stft_batch, (ham, 1024), lambda x: orc.stft(x, ham, 1024), TOL_FFT),
+        (zafx.mdct_pcm_batch, zafx.mdct_batch, (kbd,), lambda x: orc.mdct(x, kbd), TOL_FFT),
+        (zafx.melspectrogram_pcm_batch, zafx.melspectrogram_batch, (ham, 1024, fb), lambda x: orc.melspectrogram(x, ham, 1024, fb), TOL_FB),
+        (zafx.mfcc_pcm_batch, zafx.mfcc_batch, (ham, 1024, fb, 20), lambda x: orc.mfcc(x, ham, 1024, fb, 20), TOL_FB),
+        (zafx.cqtspectrogram_pcm_batch, zafx.cqtspectrogram_batch, (44100, 25, ck), lambda x: orc.cqtspectrogram(x, 44100, 25, ck), TOL_FB),
+        (zafx.cqtchromagram_pcm_batch, zafx.cqtchromagram_batch, (44100, 25, 24, ck), lambda x: orc.cqtchromagram(x, 44100, 25, 24, ck), TOL_FB),
+    ]
+    for pcm_fn, f32_fn, args, oracle, tol in calls:
+        got = pcm_fn(pcm, *args)
+        assert np.array_equal(got, f32_fn(mono, *args)), pcm_fn.__name__
+        for c in (0, 6):
+            assert relerr(got[c], oracle(ref[c])) <= tol, (pcm_fn.__name__, c)
+    plan = zafx.mel_plan(ham, 1024, fb)
+    whole = plan.run_host_pcm(pcm)
+    for chunk in (1, 2, 3):
+        assert np.array_equal(plan.run_host_pcm(pcm, chunk_clips=chunk), whole), chunk
+    with pytest.raises(ValueError):
+        zafx.istft_plan(ham, 1024).run_host_pcm(pcm)
+
+
 # ------------------------------------------------------------------ degenerate sizes
 def test_empty_and_one_sample_clips(zafx):
     """N = 0 is legal in the reference (one all-zero frame for stft/mdct, no frame for the CQT)."""

@@ -798,6 +798,8 @@ int zafx_plan_destroy(zafx_plan* pl) {
     if (!pl) return 0;
     (void)hipSetDevice(pl->device);
     if (pl->stream) (void)hipStreamSynchronize(pl->stream);
+    for (int l = 0; l < 2; ++l)
+        if (pl->lane_pcm[l]) (void)hipFree(pl->lane_pcm[l]);
     if (pl->d_window) (void)hipFree(pl->d_window);
     if (pl->d_matrix) (void)hipFree(pl->d_matrix);
     if (pl->d_wfold) (void)hipFree(pl->d_wfold);
@@ -1114,19 +1116,23 @@ int zafx_plan_clip_bytes(const zafx_plan* pl, int64_t n_in, int64_t* in_bytes, i
 // tools/exp_pcie.hip: one stream per direction overlaps fully, 19.6 ms for 4.7 + 18.8).  Page-locked host arrays
 // (zafx_host_alloc) make the copies asynchronous; pageable ones are staged by the runtime (correct, slower).  Plans whose
 // kernels share a plan-owned scratch (float64 and Bluestein inverse forms) are safe too: their kernels stay on one stream.
-int zafx_run_host(zafx_plan* pl, const void* h_in, void* h_out, int64_t n_clips, int64_t n_in, int64_t chunk_clips) {
+// pcm_bytes > 0: h_in holds interleaved integer PCM (n_clips, n_in, pcm_channels) of pcm_bytes per sample; every chunk is uploaded as it
+// is (2 or 4 bytes per sample and channel cross PCIe) and normalised + mixed down on the device (k_pcm_to_float on the plan's stream, in front
+// of the transform) -- zaf.py:1202 and :65 -- into the float32 staging buffer the transform reads.
+static int run_host_impl(zafx_plan* pl, const void* h_in, void* h_out, int64_t n_clips, int64_t n_in, int64_t chunk_clips, int pcm_channels, int pcm_bytes) {
     if (!pl) return fail_msg("null plan");
     if (n_clips < 0 || n_in < 0) return fail_msg("negative size");
     if (n_clips == 0) return 0;
     if (!h_in || !h_out) return fail_msg("null host pointer");
     int64_t in_b = 0, out_b = 0;
     if (int rc = clip_bytes(pl, n_in, &in_b, &out_b)) return rc;
+    const int64_t host_in_b = pcm_bytes > 0 ? n_in * pcm_channels * pcm_bytes : in_b;   // bytes of one clip in h_in
     ZAFX_HIP(hipSetDevice(pl->device));
     if (chunk_clips <= 0) {
         // default: chunks of about 128 MB (both sides together): about two milliseconds of PCIe each, so the pipeline fills
         // quickly (its first upload and last download are not overlapped) and the fixed costs per chunk (launch, copy set-up,
         // events: tens of microseconds) stay at a few percent (tools/e2e_pcie.py: 64 ... 256 MB are within 1 % of each other)
-        chunk_clips = std::max<int64_t>(1, (int64_t)(128 << 20) / std::max<int64_t>(in_b + out_b, 1));
+        chunk_clips = std::max<int64_t>(1, (int64_t)(128 << 20) / std::max<int64_t>(host_in_b + out_b, 1));
     }
     chunk_clips = std::min(chunk_clips, n_clips);
     const int64_t n_chunks = (n_clips + chunk_clips - 1) / chunk_clips;
@@ -1158,6 +1164,13 @@ int zafx_run_host(zafx_plan* pl, const void* h_in, void* h_out, int64_t n_clips,
             ZAFX_HIP(hipMalloc(&pl->lane_in[l], need_in));
             pl->lane_in_bytes[l] = need_in;
         }
+        const size_t need_pcm = pcm_bytes > 0 ? (size_t)std::max<int64_t>(chunk_clips * host_in_b, 1) : 0;
+        if (pl->lane_pcm_bytes[l] < need_pcm) {
+            if (pl->lane_pcm[l]) ZAFX_HIP(hipFree(pl->lane_pcm[l]));
+            pl->lane_pcm[l] = nullptr, pl->lane_pcm_bytes[l] = 0;
+            ZAFX_HIP(hipMalloc(&pl->lane_pcm[l], need_pcm));
+            pl->lane_pcm_bytes[l] = need_pcm;
+        }
         if (pl->lane_out_bytes[l] < need_out) {
             if (pl->lane_out[l]) ZAFX_HIP(hipFree(pl->lane_out[l]));
             pl->lane_out[l] = nullptr, pl->lane_out_bytes[l] = 0;
@@ -1177,11 +1190,15 @@ int zafx_run_host(zafx_plan* pl, const void* h_in, void* h_out, int64_t n_clips,
         // (which implies that the kernel before it has read the input buffer).  With the whole batch enqueued at once, more
         // than ~70 chunks in flight made the runtime fall off a cliff (1024 clips in 147 chunks: 444 ms instead of 135).
         if (sets == 2 && c >= 2) e = hipEventSynchronize(ev_down[l]);
-        if (e == hipSuccess && count * in_b > 0)
-            e = hipMemcpyAsync(pl->lane_in[l], (const char*)h_in + first * in_b, (size_t)(count * in_b), hipMemcpyHostToDevice, s_up);
+        if (e == hipSuccess && count * host_in_b > 0)
+            e = hipMemcpyAsync(pcm_bytes > 0 ? pl->lane_pcm[l] : pl->lane_in[l], (const char*)h_in + first * host_in_b, (size_t)(count * host_in_b), hipMemcpyHostToDevice, s_up);
         if (e == hipSuccess && sets == 2) e = hipEventRecord(ev_up[l], s_up);
         if (e == hipSuccess && sets == 2) e = hipStreamWaitEvent(s_k, ev_up[l], 0);
         if (e != hipSuccess) { ret = fail("zafx_run_host: upload", e); break; }
+        if (pcm_bytes > 0 && count * n_in > 0) {
+            e = launch_pcm_to_float(s_k, pl->lane_pcm[l], (float*)pl->lane_in[l], count * n_in, pcm_channels, pcm_bytes);
+            if (e != hipSuccess) { ret = fail("zafx_run_host_pcm: convert", e); break; }
+        }
         ret = zafx_execute(pl, pl->lane_in[l], pl->lane_out[l], count, n_in);   // (on pl->stream = s_k)
         if (ret) break;
         if (sets == 2) e = hipEventRecord(ev_k[l], s_k);
@@ -1196,6 +1213,23 @@ int zafx_run_host(zafx_plan* pl, const void* h_in, void* h_out, int64_t n_clips,
         if (e != hipSuccess && !ret) ret = fail("zafx_run_host: sync", e);
     }
     return ret;
+}
+
+int zafx_run_host(zafx_plan* pl, const void* h_in, void* h_out, int64_t n_clips, int64_t n_in, int64_t chunk_clips) {
+    return run_host_impl(pl, h_in, h_out, n_clips, n_in, chunk_clips, 0, 0);
+}
+
+int zafx_run_host_pcm(zafx_plan* pl, const void* h_pcm, void* h_out, int64_t n_clips, int64_t n_frames, int n_channels, int sample_bytes,
+                      int64_t chunk_clips) {
+    if (!pl) return fail_msg("null plan");
+    if (n_channels < 1 || n_channels > 64) return fail_msg("n_channels must be in [1, 64]");
+    if (sample_bytes != 2 && sample_bytes != 4) return fail_msg("sample_bytes must be 2 (int16) or 4 (int32)");
+    if (pl->prm.precision != ZAFX_PRECISION_F32) return fail_msg("PCM ingest feeds float32 plans");
+    switch (pl->kind) {
+        case ZAFX_STFT: case ZAFX_MDCT: case ZAFX_MEL: case ZAFX_MFCC: case ZAFX_CQT: case ZAFX_CHROMA: case ZAFX_DCT: break;
+        default: return fail_msg("PCM ingest feeds the plans that take samples (stft, mdct, mel, mfcc, cqt, chroma, dct)");
+    }
+    return run_host_impl(pl, h_pcm, h_out, n_clips, n_frames, chunk_clips, n_channels, sample_bytes);
 }
 
 int zafx_timer_start(zafx_plan* pl) {

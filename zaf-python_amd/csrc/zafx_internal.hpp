@@ -79,6 +79,8 @@ struct zafx_plan {
     void* lane_in[2] = {nullptr, nullptr};
     void* lane_out[2] = {nullptr, nullptr};
     size_t lane_in_bytes[2] = {0, 0}, lane_out_bytes[2] = {0, 0};
+    void* lane_pcm[2] = {nullptr, nullptr};   // zafx_run_host_pcm: the uploaded integer PCM of a chunk
+    size_t lane_pcm_bytes[2] = {0, 0};
 
     int W = 0;        // window length (or CQT fft_length)
     int H = 0;        // hop / step

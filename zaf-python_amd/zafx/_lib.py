@@ -72,6 +72,7 @@ SYMBOLS = {
     "zafx_sync": (_i, [_vp]),
     "zafx_plan_clip_bytes": (_i, [_vp, _i64, ctypes.POINTER(_i64), ctypes.POINTER(_i64)]),
     "zafx_run_host": (_i, [_vp, _vp, _vp, _i64, _i64, _i64]),
+    "zafx_run_host_pcm": (_i, [_vp, _vp, _vp, _i64, _i64, _i, _i, _i64]),
     "zafx_timer_start": (_i, [_vp]),
     "zafx_timer_stop": (_i, [_vp, ctypes.POINTER(ctypes.c_float)]),
     "zafx_plan_kernel_name": (_i, [_vp, ctypes.c_char_p, _sz]),

@@ -398,6 +398,32 @@ class Plan:
                            "zafx_run_host")
         return out if frames is None else out[:, :, :frames]
 
+    def run_host_pcm(self, pcm, out=None, chunk_clips=0):
+        """run_host for integer PCM as wavread's source holds it (zaf.py:1187-1204): pcm = (clips, frames[, channels]) int16 or
+        int32, interleaved.  The integers cross PCIe (2-4 bytes per sample and channel), x / 2^(bits-1) (zaf.py:1202) and the
+        channel mean (zaf.py:65) run on the device in front of the transform (zafx_run_host_pcm)."""
+        pcm = np.ascontiguousarray(pcm)
+        if pcm.dtype not in (np.dtype(np.int16), np.dtype(np.int32)):
+            raise ValueError("PCM ingest takes int16 or int32 samples (wavread's other dtypes: convert on the host)")
+        if pcm.ndim == 2:
+            pcm = pcm[:, :, None]
+        if pcm.ndim != 3:
+            raise ValueError("pcm must be (clips, frames) or (clips, frames, channels)")
+        if self.f64 or self.kind not in self._FORWARD + (_lib.DCT,):
+            raise ValueError("PCM ingest feeds the float32 plans that take samples")
+        n_clips, n_in, channels = pcm.shape
+        frames = self.out_dims(n_in)[1] if self.row_align > 1 else None
+        shape = self.out_shape(n_clips, n_in)
+        if out is None:
+            out = np.empty(shape, dtype=self.out_dtype)
+        elif tuple(out.shape) != tuple(shape) or out.dtype != self.out_dtype or not out.flags.c_contiguous or not out.flags.writeable:
+            raise ValueError(f"out must be a writeable C-contiguous {self.out_dtype} array of shape {tuple(shape)}")
+        if n_clips and out.nbytes:
+            with self.lock:
+                _lib.check(_lib.load().zafx_run_host_pcm(self.handle, _ptr(pcm), _ptr(out), n_clips, n_in, channels, pcm.dtype.itemsize,
+                                                         int(chunk_clips)), "zafx_run_host_pcm")
+        return out if frames is None else out[:, :, :frames]
+
     def destroy(self):
         if getattr(self, "handle", None) is not None and self.handle.value:
             _lib.load().zafx_plan_destroy(self.handle)
@@ -886,23 +912,49 @@ def _pcm_device_mono(plan, pcm):
     return d_pcm, d_x
 
 
-def stft_pcm_batch(pcm, window_function, step_length, layout="FT", device=0):
+def _pcm_batch(plan, batch_fn, pcm, out):
+    """A *_pcm_batch call: the chunked three-stream pipeline with integer uploads (Plan.run_host_pcm); plans the library runs in
+    float64 (windows outside the float32 kernels) normalise on the device and take the general path."""
+    if plan.f64:
+        return batch_fn(pcm_to_mono(pcm, plan.device))
+    return plan.run_host_pcm(pcm, out=out)
+
+
+def stft_pcm_batch(pcm, window_function, step_length, layout="FT", device=0, onesided=False, out=None):
     """STFT of integer PCM clips (clips, frames[, channels]): wavread's x / 2^(bits-1) and the channel mean
-    (zaf.py:1202, :65) run on the device in front of the transform; only 2-4 B per sample cross PCIe."""
-    plan = stft_plan(window_function, step_length, layout, device)
-    if plan.f64:   # window outside the float32 kernels: normalise on the device, then the general path (float64 arithmetic)
-        return stft_batch(pcm_to_mono(pcm, device), window_function, step_length, layout, device)
-    with plan.lock:
-        d_pcm, d_x = _pcm_device_mono(plan, pcm)
-        b, n = d_x.shape
-        d_out = DeviceBuffer(plan.out_shape(b, n), plan.out_dtype, device)
-        try:
-            plan.execute(d_x, d_out, b, n)
-            plan.sync()
-            return d_out.download()
-        finally:
-            for buf in (d_pcm, d_x, d_out):
-                buf.free()
+    (zaf.py:1202, :65) run on the device in front of the transform; only 2-4 B per sample and channel cross PCIe."""
+    plan = stft_plan(window_function, step_length, layout, device, onesided)
+    return _pcm_batch(plan, lambda x: stft_batch(x, window_function, step_length, layout, device, onesided), pcm, out)
+
+
+def mdct_pcm_batch(pcm, window_function, layout="FT", device=0, out=None):
+    """mdct_batch of integer PCM clips (see stft_pcm_batch)."""
+    plan = mdct_plan(window_function, layout, device)
+    return _pcm_batch(plan, lambda x: mdct_batch(x, window_function, layout, device), pcm, out)
+
+
+def melspectrogram_pcm_batch(pcm, window_function, step_length, mel_filterbank, layout="FT", device=0, out=None):
+    """melspectrogram_batch of integer PCM clips (see stft_pcm_batch): 2 bytes per sample up, 4 n_filters / hop down."""
+    plan = mel_plan(window_function, step_length, mel_filterbank, None, layout, device)
+    return _pcm_batch(plan, lambda x: melspectrogram_batch(x, window_function, step_length, mel_filterbank, layout, device), pcm, out)
+
+
+def mfcc_pcm_batch(pcm, window_function, step_length, mel_filterbank, number_coefficients, layout="FT", device=0, out=None):
+    """mfcc_batch of integer PCM clips (see stft_pcm_batch)."""
+    plan = mel_plan(window_function, step_length, mel_filterbank, number_coefficients, layout, device)
+    return _pcm_batch(plan, lambda x: mfcc_batch(x, window_function, step_length, mel_filterbank, number_coefficients, layout, device), pcm, out)
+
+
+def cqtspectrogram_pcm_batch(pcm, sampling_frequency, time_resolution, cqt_kernel, layout="FT", device=0, out=None):
+    """cqtspectrogram_batch of integer PCM clips (see stft_pcm_batch)."""
+    plan = cqt_plan(sampling_frequency, time_resolution, cqt_kernel, None, layout, device)
+    return _pcm_batch(plan, lambda x: cqtspectrogram_batch(x, sampling_frequency, time_resolution, cqt_kernel, layout, device), pcm, out)
+
+
+def cqtchromagram_pcm_batch(pcm, sampling_frequency, time_resolution, octave_resolution, cqt_kernel, layout="FT", device=0, out=None):
+    """cqtchromagram_batch of integer PCM clips (see stft_pcm_batch)."""
+    plan = cqt_plan(sampling_frequency, time_resolution, cqt_kernel, int(octave_resolution), layout, device)
+    return _pcm_batch(plan, lambda x: cqtchromagram_batch(x, sampling_frequency, time_resolution, octave_resolution, cqt_kernel, layout, device), pcm, out)
 
 
 def pcm_to_mono(pcm, device=0):

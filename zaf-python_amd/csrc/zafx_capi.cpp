@@ -188,6 +188,7 @@ static void free_band(PackedBand& pb) {
 
 // k_cqt's view of the CQT kernel matrix: rows sorted by length, four per step, steps dealt to the wavefronts.
 static int build_cqt_chunks(zafx_plan* pl);
+static int build_cqt_mm(zafx_plan* pl, int n_waves);
 
 // Bluestein tables of a W-point DFT as a convolution of length M = 2^log2m, in long double: the chirp
 // c[n] = exp(-i pi n^2 / W) (angle reduced in integers: n^2 mod 2W) and Bhat = FFT_M of conj(c) wrapped to length M.
@@ -474,7 +475,77 @@ static int build_cqt_chunks(zafx_plan* pl) {
     ZAFX_HIP(upload(&pl->d_cqt_addrs, addrs.data(), addrs.size() * sizeof(int32_t)));
     ZAFX_HIP(upload(&pl->d_cqt_vals, vals.data(), vals.size() * sizeof(float)));
     ZAFX_HIP(upload(&pl->d_cqt_waves, wave_tab.data(), wave_tab.size() * sizeof(int)));
+    if (int rc = build_cqt_mm(pl, n_waves)) return rc;
     pl->cqt_dirty = false;
+    return 0;
+}
+
+// The matrix-core form of the contraction (zafx_cqt.hip): v_mfma_f32_4x4x1_16b_f32 multiplies, in each of its sixteen 4-lane
+// blocks, four A values with four B values and ACCUMULATES over successive instructions -- the sum over a row's columns needs
+// no cross-lane reduction.  Rows go in pairs (2p, 2p + 1: neighbours of a constant-Q kernel overlap by three quarters); the
+// sorted union of a pair's columns is a stream, cut into segments of S entries; a block works on two segments at once (A lanes
+// 0, 1: the two rows of stream a, lanes 2, 3: of stream b; B lanes 0, 1: re, im of stream a's bin, lanes 2, 3: of stream b's), so
+// a wavefront's instruction advances 32 segments by one column.  Segments of a pair are consecutive stream slots
+// (slot = 2 (16 wave + block) + stream): the kernel's finishing pass adds them up from there.  Real matrices whose columns all
+// lie in the lower half (no conjugated bins) and whose S fits the registers; anything else stays on the lane-reduction form.
+static int build_cqt_mm(zafx_plan* pl, int n_waves) {
+    pl->cqt_mm_steps = 0;
+    if (!pl->cqt_real || cqt_double(pl->log2nf)) return 0;
+    const int n_rows = (int)pl->h_indptr.size() - 1, n = pl->W / 2, n_pairs = (n_rows + 1) / 2;
+    if (n_rows < 1) return 0;
+    std::vector<std::vector<int>> cols((size_t)n_pairs);
+    for (int r = 0; r < n_rows; ++r)
+        for (int e = pl->h_indptr[(size_t)r]; e < pl->h_indptr[(size_t)r + 1]; ++e) {
+            const int c = pl->h_indices[(size_t)e];
+            if (c < 0 || c > n) return 0;   // (a conjugated bin: the lane-reduction form handles it)
+            cols[(size_t)(r >> 1)].push_back(c);
+        }
+    size_t total = 0;
+    for (auto& c : cols) {
+        std::sort(c.begin(), c.end());
+        c.erase(std::unique(c.begin(), c.end()), c.end());
+        total += c.size();
+    }
+    const int slots = 32 * n_waves;
+    int S = (int)std::max<size_t>(1, (total + slots - 1) / slots);
+    auto segments = [&](int s) {
+        long long k = 0;
+        for (auto& c : cols) k += ((long long)c.size() + s - 1) / s;
+        return k;
+    };
+    while (S <= kCqtMmSteps && segments(S) > slots) ++S;
+    if (S > kCqtMmSteps) return 0;
+    std::vector<float> vals((size_t)n_waves * S * 64, 0.f);
+    std::vector<int32_t> addr((size_t)n_waves * S * 64, 0);   // (padding steps: 0 x bin 0)
+    std::vector<int32_t> fin((size_t)n_pairs, 0);
+    int slot = 0;
+    pl->cqt_mm_segs = 0;
+    for (int p = 0; p < n_pairs; ++p) {
+        const auto& c = cols[(size_t)p];
+        const int nseg = ((int)c.size() + S - 1) / S;
+        pl->cqt_mm_segs = std::max(pl->cqt_mm_segs, nseg);
+        fin[(size_t)p] = slot | nseg << 16;
+        for (int g = 0; g < nseg; ++g, ++slot) {
+            const int wave = slot >> 5, blk = (slot >> 1) & 15, stream = slot & 1;
+            for (int i = 0; i < S && g * S + i < (int)c.size(); ++i) {
+                const int col = c[(size_t)(g * S + i)];
+                const int lds = (col == n ? cqt_nyquist_slot(pl->log2nf) : cqt_slot(pl->log2nf, col)) * 8;
+                const size_t base = ((size_t)wave * S + i) * 64 + blk * 4 + stream * 2;
+                for (int m = 0; m < 2; ++m) {
+                    const int r = 2 * p + m;
+                    addr[base + m] = lds + 4 * m;   // B lane: re / im
+                    if (r >= n_rows) continue;
+                    const auto b = pl->h_indices.begin() + pl->h_indptr[(size_t)r], e = pl->h_indices.begin() + pl->h_indptr[(size_t)r + 1];
+                    for (auto it = b; it != e; ++it)   // (duplicate column entries of a row add up, as in a CSR product)
+                        if (*it == col) vals[base + m] += pl->h_values[(size_t)(it - pl->h_indices.begin())].re;
+                }
+            }
+        }
+    }
+    ZAFX_HIP(upload(&pl->d_cqt_mm_vals, vals.data(), vals.size() * sizeof(float)));
+    ZAFX_HIP(upload(&pl->d_cqt_mm_addr, addr.data(), addr.size() * sizeof(int32_t)));
+    ZAFX_HIP(upload(&pl->d_cqt_mm_fin, fin.data(), fin.size() * sizeof(int32_t)));
+    pl->cqt_mm_steps = S;
     return 0;
 }
 
@@ -817,6 +888,9 @@ int zafx_plan_destroy(zafx_plan* pl) {
     if (pl->d_cqt_waves) (void)hipFree(pl->d_cqt_waves);
     if (pl->d_cqt_addrs) (void)hipFree(pl->d_cqt_addrs);
     if (pl->d_cqt_vals) (void)hipFree(pl->d_cqt_vals);
+    if (pl->d_cqt_mm_vals) (void)hipFree(pl->d_cqt_mm_vals);
+    if (pl->d_cqt_mm_addr) (void)hipFree(pl->d_cqt_mm_addr);
+    if (pl->d_cqt_mm_fin) (void)hipFree(pl->d_cqt_mm_fin);
     if (pl->d_window64) (void)hipFree(pl->d_window64);
     if (pl->d_tw64) (void)hipFree(pl->d_tw64);
     if (pl->d_tws64) (void)hipFree(pl->d_tws64);

@@ -61,10 +61,11 @@ __device__ __forceinline__ float bcast31_add(float v) {
 }
 
 // REALK: kernel values are float (real matrix), else float2.  RES > 0: a wave's entries (RES iterations) ride in registers.
-template <int LOG2N, int LOG2E, bool ALIGNED, bool REALK, int RES, bool DOUBLE = false>
+// MM > 0: the contraction runs on the matrix cores (below), MM = steps a wave keeps in registers (REALK, RES = 0).
+template <int LOG2N, int LOG2E, bool ALIGNED, bool REALK, int RES, bool DOUBLE = false, int MM = 0>
 __global__ __launch_bounds__(fft_threads(LOG2N, LOG2E)) void k_cqt(
     const float* __restrict__ x, const float2* __restrict__ twp, const float2* __restrict__ tws,
-    const int4* __restrict__ wave_tab, const int* __restrict__ addrs, const float* __restrict__ values,
+    const int4* __restrict__ wave_tab, const int* __restrict__ addrs, const float* __restrict__ values, const int* __restrict__ mm_fin, int mm_steps, int mm_segs,
     float* __restrict__ out, long long n_samples, int step, int left_pad, int T, int TP, int n_clips, int n_groups, int n_bins, int chroma_res,
     int layout, int k_lo, int k_hi, int k_special, int n_entries, int prune3) {
     using C = FftCfg<LOG2N, LOG2E>;
@@ -85,12 +86,19 @@ __global__ __launch_bounds__(fft_threads(LOG2N, LOG2E)) void k_cqt(
     constexpr int NYQ = cqt_nyquist_slot(LOG2N);
     int4* wave_l = reinterpret_cast<int4*>(smem_raw + G::HEAD);   // [P / 64] {first iteration, iterations, step-end mask of the resident form, 0}
     float* mags = reinterpret_cast<float*>(wave_l + P / 64);      // [n_bins] |.|^2 of the current frame
+    float2* part = reinterpret_cast<float2*>(mags + ((n_bins + 1) & ~1));   // (MM) [P]: every lane's two partial sums
+    int* fin_l = reinterpret_cast<int*>(part + P + 1);                        // (MM) [pairs]: first stream slot | segments << 16  (part[P] = 0: what the finishing pass reads past a row's last segment)
+    static_assert(MM == 0 || (REALK && RES == 0 && !DOUBLE), "matrix-core contraction: real matrix, no other resident form");
     const int p = threadIdx.x;
     for (int i = p; i < NHI + 128; i += P) tw_hi[i] = twp[i];
     if constexpr (G::SPLIT)
         for (int i = p; i < G::NSUB; i += P) sub_hi[i] = twp[NHI + 128 + i];
     for (int i = p; i < NH2 + 128; i += P) sp_hi[i] = tws[i];
     for (int i = p; i < P / 64; i += P) wave_l[i] = wave_tab[i];
+    if constexpr (MM > 0) {
+        for (int i = p; i < (n_bins + 1) / 2; i += P) fin_l[i] = mm_fin[i];
+        if (p == 0) part[P] = make_float2(0.f, 0.f);
+    }
     lds_barrier();
     const TwoLevelTw tw2l{tw_hi, tw_lo};
     const int wave = p >> 6;
@@ -99,6 +107,9 @@ __global__ __launch_bounds__(fft_threads(LOG2N, LOG2E)) void k_cqt(
     const int group = blockIdx.x % n_groups, slot = blockIdx.x / n_groups;
     const int n_slots = (gridDim.x - group + n_groups - 1) / n_groups;
     const long long n_work = (long long)((n_clips - group + n_groups - 1) / n_groups) * T;
+    // (Round 4 also dealt the list out in units of four consecutive frames, so that a finished row left as one 16-byte piece per
+    // unit: the XCD's workgroups then spread over 128 frames instead of 32, the L2 held neither the samples nor the partial lines --
+    // 10.5 GB fetched and 1.37 GB written per launch against 5.42 and 0.446, 1.4 % slower.  Not kept.)
     // wave-uniform values read from LDS land in VGPRs; readfirstlane tells the compiler they are scalars
     // (scalar branches and SGPR operands instead of exec-mask juggling)
     const int4 wt = wave_l[wave];
@@ -112,8 +123,16 @@ __global__ __launch_bounds__(fft_threads(LOG2N, LOG2E)) void k_cqt(
     };
 
     // ---- a wave's share of the kernel matrix, resident in registers for the whole launch
-    KV kv[RESIDENT ? RES : 1];
-    int ad[RESIDENT ? RES : 1];
+    KV kv[RESIDENT ? RES : MM > 0 ? MM : 1];
+    int ad[RESIDENT ? RES : MM > 0 ? MM : 1];
+    if constexpr (MM > 0) {   // (the tables hold mm_steps <= MM steps per wave)
+#pragma unroll
+        for (int i = 0; i < MM; ++i) {
+            const int e = i < mm_steps ? ((p >> 6) * mm_steps + i) * 64 + (p & 63) : -1;   // out of range: reads 0
+            ad[i] = buf_load_i32(raddr, e * 4);
+            kv[i] = load_kv(e);
+        }
+    }
     if constexpr (RESIDENT) {
 #pragma unroll
         for (int i = 0; i < RES; ++i) {
@@ -264,10 +283,23 @@ __global__ __launch_bounds__(fft_threads(LOG2N, LOG2E)) void k_cqt(
             for (int r = 1; r < 16; ++r) v[r] = cmul(v[r], w[r]);
         }
     };
+#ifndef ZAFX_CQT_EARLY_SCATTER
+#define ZAFX_CQT_EARLY_SCATTER 0   // (measured with the matrix-core form: 24.94 against 24.81 ms -- the finishing pass's reads then queue behind sixteen waves' writes)
+#endif
+    // 16384 = 16 x 1024: output k1 of the first pass goes to sub-sequence k1 at position p (the frame image must be free: behind
+    // the barrier that ends the previous frame's contraction)
+    auto scatter_first_pass = [&](int p) {
+        if constexpr (G::SPLIT) {
+            const int pp = phys(p);
+#pragma unroll
+            for (int r = 0; r < 16; ++r) buf[r * kCqtRegion + pp] = v[r];
+        }
+    };
     if (slot < n_work) {
         if (load_frame(slot, threadIdx.x)) unpack_pairs(threadIdx.x);
         if constexpr (DOUBLE) load_second(threadIdx.x, 0);
         first_pass(threadIdx.x);
+        if constexpr (ZAFX_CQT_EARLY_SCATTER) scatter_first_pass(threadIdx.x);
     }
     PROF_INIT(g_prof_cqt);
     int odd = 0;              // DOUBLE: which half of the bins the transform in flight yields (every frame runs the loop body twice)
@@ -286,9 +318,9 @@ __global__ __launch_bounds__(fft_threads(LOG2N, LOG2E)) void k_cqt(
             // 16384 = 16 x 1024: output k1 of the first pass goes to sub-sequence k1 at position p.  Then wave w
             // transforms sub-sequence w on its own (three wave-local passes, no workgroup barrier):
             // X[k1 + 16 k2] = FFT_1024(sub-sequence k1)[k2].
-            const int pp = phys(p);
-#pragma unroll
-            for (int r = 0; r < 16; ++r) buf[r * kCqtRegion + pp] = v[r];
+            // (the outputs of the first pass went to LDS behind the previous frame's last barrier -- scatter_first_pass --, under the
+            // latency of its finishing pass and column store)
+            if constexpr (!ZAFX_CQT_EARLY_SCATTER) scatter_first_pass(p);
             lds_barrier();
             float2* sub = buf + (p >> 6) * kCqtRegion;
             regs_read<10, 4>(v, sub, lane);
@@ -388,6 +420,29 @@ __global__ __launch_bounds__(fft_threads(LOG2N, LOG2E)) void k_cqt(
         // value and a word: bits 0-17 the LDS byte address of its spectrum bin, bit 31 "conjugate" (a column of the upper
         // half), bits 29-30 (the same in all lanes) 0 or the shape 1 / 2 / 3 = 16 / 32 / 64 lanes per row of a step that ENDS
         // with this iteration, bits 18-28 the row this lane then writes (0x7ff: none).  Padding entries are 0 * bin 0.
+        if constexpr (MM > 0) {
+            // ---- the same product on the matrix cores (build_cqt_mm, zafx_capi.cpp): step i multiplies, in every 4-lane block, the
+            // lanes' A values (rows 2 pa + {0, 1} of stream a, 2 pb + {0, 1} of stream b at the step's column) with their B values
+            // (re, im of stream a's bin, re, im of stream b's) and accumulates: register r of lane (blk, j) = sum over the steps of
+            // A(blk, r) B(blk, j).  Lanes 0, 1 of a block keep registers 0, 1 (stream a: re / im of its two rows), lanes 2, 3
+            // registers 2, 3; the cross terms are dropped.  No lane reductions, no selects: ~5 vector instructions per frame and wave
+            // against ~175 of the lane-reduction form below.
+            typedef float f32x4 __attribute__((ext_vector_type(4)));
+            int ni = mm_steps;
+            asm volatile("" : "+s"(ni));
+            float bq[MM];
+#pragma unroll
+            for (int i = 0; i < MM; ++i) {
+                int a = ad[i];
+                asm volatile("" : "+v"(a));
+                bq[i] = i < ni ? *reinterpret_cast<const float*>(smem_raw + a) : 0.f;
+            }
+            f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int i = 0; i < MM; ++i)
+                if (i < ni) acc = __builtin_amdgcn_mfma_f32_4x4x1f32(kv[i], bq[i], acc, 0, 0, 0);
+            part[p] = (lane & 2) ? make_float2(acc[2], acc[3]) : make_float2(acc[0], acc[1]);
+        } else
         if (!DOUBLE || odd) {   // (DOUBLE: the even half has no spectrum to contract yet)
             float ar = 0.f, ai = 0.f;
             auto mac = [&](KV k, int a) {
@@ -463,6 +518,7 @@ __global__ __launch_bounds__(fft_threads(LOG2N, LOG2E)) void k_cqt(
         PROF_MARK(5);
         lds_barrier();
         PROF_MARK(6);
+        if (ZAFX_CQT_EARLY_SCATTER && more) scatter_first_pass(p);
         if constexpr (DOUBLE) {
             odd ^= 1;
             if (odd == 1) continue;   // the even half is done: no column yet
@@ -470,6 +526,59 @@ __global__ __launch_bounds__(fft_threads(LOG2N, LOG2E)) void k_cqt(
         // ---- store the frame's column (the next write of `mags` is three barriers away)
         {
             const int clip = group + (int)((unsigned)g / (unsigned)T) * n_groups, t = (int)((unsigned)g % (unsigned)T);   // (g < 2^31: zafx_execute)
+            if constexpr (MM > 0) {
+                // finishing pass of the matrix-core form: L lanes per row (8, or fewer when the rows then do not fit ONE pass of the
+                // workgroup: two passes kept waves 0 and 1, alone with a second one, between everybody and the next barrier) add up the
+                // row's segments (float 4 s + 2 c + m of `part`: stream slot s, c = re / im, m = the row's place in its pair) -- eight
+                // reads per lane requested together, lanes past the row's last segment read the zero slot behind `part` --, DPP adds, |.|, store
+                const float* pf = reinterpret_cast<const float*>(part);
+                const int lg = n_bins * 8 <= P ? 3 : n_bins * 4 <= P ? 2 : n_bins * 2 <= P ? 1 : 0;   // (uniform)
+                const int rows_per_pass = P >> lg;
+                for (int r0 = 0; r0 + ((p & ~63) >> lg) < n_bins; r0 += rows_per_pass) {   // (wave-uniform trip count)
+                    const int r = r0 + (p >> lg), q = p & ((1 << lg) - 1);
+                    const int w = r < n_bins ? fin_l[r >> 1] : 0, s0 = w & 0xffff, ns = w >> 16;
+                    const int base = 4 * (s0 + q) + (r & 1);
+                    float re = 0.f, im = 0.f;
+                    for (int i0 = 0; __builtin_amdgcn_ballot_w64(q + i0 < ns) != 0; i0 += 8 << lg) {
+                        float a[8], b[8];
+#pragma unroll
+                        for (int u = 0; u < 8; ++u) {
+                            const int i = i0 + (u << lg);
+                            const bool in = q + i < ns;
+                            const int at = in ? base + 4 * i : 2 * P;
+                            a[u] = pf[at];
+                            b[u] = pf[in ? at + 2 : at];
+                        }
+                        re += ((a[0] + a[1]) + (a[2] + a[3])) + ((a[4] + a[5]) + (a[6] + a[7]));
+                        im += ((b[0] + b[1]) + (b[2] + b[3])) + ((b[4] + b[5]) + (b[6] + b[7]));
+                    }
+                    auto dpp_add = [](float v, auto ctrl) {
+                        return v + __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), decltype(ctrl)::value, 0xf, 0xf, true));
+                    };
+                    if (lg >= 1) {   // (uniform)
+                        re = dpp_add(re, std::integral_constant<int, 0xB1>{});   // quad_perm [1,0,3,2]
+                        im = dpp_add(im, std::integral_constant<int, 0xB1>{});
+                    }
+                    if (lg >= 2) {
+                        re = dpp_add(re, std::integral_constant<int, 0x4E>{});   // quad_perm [2,3,0,1]
+                        im = dpp_add(im, std::integral_constant<int, 0x4E>{});
+                    }
+                    if (lg >= 3) {
+                        re = dpp_add(re, std::integral_constant<int, 0x141>{});   // row_half_mirror
+                        im = dpp_add(im, std::integral_constant<int, 0x141>{});
+                    }
+                    if (q == 0 && r < n_bins) {
+                        if (chroma_res > 0) {
+                            mags[r] = re * re + im * im;
+                        } else {
+                            const float val = __builtin_amdgcn_sqrtf(re * re + im * im);
+                            if (layout == ZAFX_LAYOUT_FT) out[((long long)clip * n_bins + r) * TP + t] = val;
+                            else out[((long long)clip * T + t) * n_bins + r] = val;
+                        }
+                    }
+                }
+                if (chroma_res > 0) lds_barrier();   // (uniform) the chroma sums below read every row
+            }
             if (chroma_res > 0) {
                 for (int ch = p; ch < chroma_res; ch += P) {
                     float acc = 0.f;
@@ -477,7 +586,7 @@ __global__ __launch_bounds__(fft_threads(LOG2N, LOG2E)) void k_cqt(
                     if (layout == ZAFX_LAYOUT_FT) out[((long long)clip * chroma_res + ch) * TP + t] = acc;   // TP = row pitch (>= T)
                     else out[((long long)clip * T + t) * chroma_res + ch] = acc;
                 }
-            } else {
+            } else if constexpr (MM == 0) {
                 for (int r = p; r < n_bins; r += P) {
                     const float val = __builtin_amdgcn_sqrtf(mags[r]);
                     if (layout == ZAFX_LAYOUT_FT) out[((long long)clip * n_bins + r) * TP + t] = val;
@@ -512,12 +621,21 @@ static hipError_t run_cqt(const zafx_plan& pl, const float* x, float* out, int64
     // a real matrix whose busiest wave has <= kCqtResident iterations keeps its entries in registers (16 would spill at 1024 threads)
     const bool realk = pl.cqt_real;
     const bool res = realk && pl.cqt_resident == kCqtResident && !DOUBLE;   // (the double form has no registers left for them: 156 bytes of scratch)
+#ifndef ZAFX_CQT_MM
+#define ZAFX_CQT_MM 1
+#endif
+    // matrix-core contraction: its partial sums (8 bytes per thread) and the pairs' segment table sit behind the column in LDS
+    const size_t smem_mm = cqt_lds<LOG2NP>((pl.prm.n_bins + 1) & ~1) + (size_t)(C::P + 1) * 8 + (size_t)((pl.prm.n_bins + 1) / 2) * 4;
+    const bool mm = ZAFX_CQT_MM && !DOUBLE && realk && pl.cqt_mm_steps > 0 && pl.cqt_mm_steps <= kCqtMmSteps && smem_mm <= (size_t)kMaxLdsBytes;
     auto pick = [&](auto al) {
         constexpr bool AL = decltype(al)::value;
+        if constexpr (!DOUBLE) {
+            if (mm) return k_cqt<LOG2N, LOG2E, AL, true, 0, false, kCqtMmSteps>;
+        }
         return !realk ? k_cqt<LOG2N, LOG2E, AL, false, 0, DOUBLE> : res ? k_cqt<LOG2N, LOG2E, AL, true, kCqtResident, DOUBLE> : k_cqt<LOG2N, LOG2E, AL, true, 0, DOUBLE>;
     };
     auto kern = aligned ? pick(std::true_type{}) : pick(std::false_type{});
-    const size_t smem = cqt_lds<LOG2NP>(pl.prm.n_bins);
+    const size_t smem = mm ? smem_mm : cqt_lds<LOG2NP>(pl.prm.n_bins);
     if (smem > (size_t)kMaxLdsBytes) {
         set_error("cqt: kernel matrix has too many rows for LDS at this fft_length");
         return hipErrorInvalidValue;
@@ -545,9 +663,9 @@ static hipError_t run_cqt(const zafx_plan& pl, const float* x, float* out, int64
         prune3 = pos_hi >> 6;
     pl.ran = "k_cqt";
     hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(C::P), smem, pl.stream, x, pl.d_tw_pass, pl.d_tw_aux, pl.d_cqt_waves,
-                       pl.d_cqt_addrs, pl.d_cqt_vals, out, (long long)n_samples, pl.H, left, T, (int)row_pitch(pl, T), (int)n_clips, n_groups,
+                       mm ? pl.d_cqt_mm_addr : pl.d_cqt_addrs, mm ? pl.d_cqt_mm_vals : pl.d_cqt_vals, pl.d_cqt_mm_fin, mm ? pl.cqt_mm_steps : 0, pl.cqt_mm_segs, out, (long long)n_samples, pl.H, left, T, (int)row_pitch(pl, T), (int)n_clips, n_groups,
                        pl.prm.n_bins, pl.kind == ZAFX_CHROMA ? pl.prm.octave_resolution : 0, pl.layout, pl.cqt_k_lo, pl.cqt_k_hi,
-                       pl.cqt_k_special, std::max(pl.cqt_n_entries, 1), prune3);
+                       pl.cqt_k_special, mm ? (C::P / 64) * pl.cqt_mm_steps * 64 : std::max(pl.cqt_n_entries, 1), prune3);
     return hipGetLastError();
 }
 

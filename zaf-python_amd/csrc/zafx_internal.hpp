@@ -37,6 +37,7 @@ constexpr int cqt_slot(int log2n, int k) {
     return cqt_double(log2n) ? ((k & 1) ? cqt_slot14(k >> 1) : cqt_slot14(8192 + (k >> 1))) : cqt_split(log2n) ? cqt_slot14(k) : k + (k >> 4);
 }
 constexpr int cqt_nyquist_slot(int log2n) { return cqt_split(log2n) ? kCqtRegion - 1 : (1 << log2n) + ((1 << log2n) >> 4); }
+constexpr int kCqtMmSteps = 14;            // k_cqt, matrix-core contraction: steps (entries per lane) a wave keeps in registers
 constexpr int kCqtResident = 12;           // k_cqt: iterations (entries per lane) of a wave's share of the kernel matrix that ride in registers
 constexpr int kCqt64Sub = 4096;            // float64 CQT: length of the sub-transforms that fit LDS (2 x 4096 x 16 B)
 
@@ -110,6 +111,13 @@ struct zafx_plan {
     int cqt_n_entries = 0;
     bool cqt_real = false;
     int cqt_resident = 0;          // kCqtResident: the busiest wave's iterations fit the registers; 0: entries streamed from L2 every frame
+    // the matrix-core form of the contraction (zafx_cqt.hip, "MM"): rows in pairs, a pair's columns cut into segments of cqt_mm_steps
+    // consecutive entries, two segments per 4-lane block of v_mfma_f32_4x4x1_16b_f32; 0: not available for this matrix
+    int cqt_mm_steps = 0;
+    int cqt_mm_segs = 0;              // segments of the longest pair
+    float* d_cqt_mm_vals = nullptr;   // [waves][steps][64]: lane (blk, i): K[row 2 pair + (i & 1)][column of the step] of the block's stream i >> 1
+    int* d_cqt_mm_addr = nullptr;     // [waves][steps][64]: lane (blk, j): LDS byte address of the re (j even) / im (j odd) part of that column's bin, stream j >> 1
+    int* d_cqt_mm_fin = nullptr;      // [pairs]: first stream slot | segments << 16 of the pair (its segments are consecutive stream slots)
     // mel / mfcc plans of W = 4096 / 8192 (k_melfb): filterbank rows as bands of float32 (values of [first, first + count) of every
     // row back to back; meta [n_filters][3] = first column, count, offset) and the DCT rows dense [n_coefs][n_filters]
     float* d_fbw = nullptr;

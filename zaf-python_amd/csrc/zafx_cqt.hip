@@ -12,7 +12,11 @@
 // against 4 MB of L2), so a sample crosses the fabric once and the other reads hit L2.  (Tiles of 16 consecutive
 // frames per workgroup put 32 x 237 KB of live samples on each XCD: every re-read missed L2, 8.3 x the input over the
 // fabric and 4 ... 6 k cycles per frame of blocked load issue; profiles/r02_notes.md.)
-// After the real split the CSR rows are contracted against the one-sided spectrum in LDS:
+// After the real split the CSR rows are contracted against the one-sided spectrum in LDS.  Real matrices whose columns lie in the
+// lower half (the reference's kernels) take the MATRIX-CORE form (MM, build_cqt_mm in zafx_capi.cpp): rows in pairs, a pair's
+// columns in segments of S entries, two segments per 4-lane block of v_mfma_f32_4x4x1_16b_f32, whose accumulation over S
+// instructions IS the sum over a row's columns -- no lane reductions; a finishing pass adds a row's segments.  Everything else
+// (complex matrices, conjugated bins, S above the registers, the 65536 double form) takes the lane-reduction form:
 //   * the host sorts the rows by length and deals them out in "steps": a wavefront works on four short rows at once
 //     (one per 16-lane DPP row, lane j of a row taking its entries j, j + 16, j + 32, ...), on two medium rows (32 lanes
 //     each) or on one long row (64 lanes); a step ends with ONE pair of DPP reductions (row sums, + row_bcast for the

@@ -1589,6 +1589,50 @@ def test_cqt_clip_groups_and_complex_kernels(zafx, n_clips, n):
     assert np.all(gs[0][5] == 0)
 
 
+@pytest.mark.parametrize("fft_length,rows,seed", [(32768, 145, 0), (32768, 1, 1), (16384, 7, 2), (4096, 33, 3), (1024, 64, 4), (32768, 300, 5)])
+def test_cqt_matrix_core_contraction(zafx, fft_length, rows, seed):
+    """k_cqt's matrix-core contraction (real matrices whose columns lie in the lower half: rows in pairs, columns in segments, two segments per
+    4-lane block of v_mfma_f32_4x4x1): odd row counts (a pair of one), empty rows, rows of one entry, scattered (non-contiguous) columns,
+    columns 0 / N / N/2, duplicate-free unions of very different rows in a pair, frame lengths with fewer than 16 waves -- and the same
+    matrix with ONE column moved into the upper half (a conjugated bin), which must take the lane-reduction form and agree as well."""
+    rng = np.random.default_rng([77, seed])
+    half = fft_length // 2
+    dense = np.zeros((rows, fft_length))
+    for r in range(rows):
+        if rows > 4 and r % 11 == 3:
+            continue                                   # an empty row
+        kind = r % 3
+        if kind == 0:                                  # a band, as the reference's kernels
+            lo = int(rng.integers(1, half - 40))
+            idx = np.arange(lo, lo + int(rng.integers(1, 40)))
+        elif kind == 1:                                # scattered
+            idx = rng.choice(half + 1, size=int(rng.integers(1, 60)), replace=False)
+        else:                                          # the special columns among others
+            idx = np.unique(np.concatenate([[0, half, half // 2], rng.choice(half, size=5, replace=False)]))
+        dense[r, idx] = rng.standard_normal(len(idx)) / fft_length
+    fs, tr = 8000, 40
+    n = 3 * fft_length + 1234
+    x = np.stack([synth_clip(31, c, n) for c in range(2)])
+    for variant in ("lower half", "one conjugated bin"):
+        d = dense.copy()
+        if variant == "one conjugated bin":
+            r = 0 if rows == 1 else 1
+            d[r, fft_length - 7] = 0.5 / fft_length
+        k = scipy.sparse.csr_matrix(d)
+        got = zafx.cqtspectrogram_batch(x, fs, tr, k)
+        for c in range(2):
+            ref = orc.cqtspectrogram(x[c].astype(np.float64), fs, tr, k)
+            assert got[c].shape == ref.shape and relerr(got[c], ref) <= TOL_FB, (variant, c)
+        if rows > 4:
+            assert np.all(got[0][3] == 0), variant      # the empty row
+    if rows % 12 == 0 or rows == 145:                   # chromagram through the same contraction (its own barrier behind the finishing pass)
+        res = 12
+        if rows % res == 0:
+            k = scipy.sparse.csr_matrix(dense)
+            ch = zafx.cqtchromagram_batch(x[:1], fs, tr, res, k)
+            assert relerr(ch[0], orc.cqtchromagram(x[0].astype(np.float64), fs, tr, res, k)) <= TOL_FB
+
+
 def test_device_buffer_placed_keeps_the_fastest_candidate(zafx):
     """DeviceBuffer.placed: every candidate is initialised and probed (the first once more, uncounted), the one with the lowest
     probe time stays usable, the others are freed."""

@@ -145,6 +145,53 @@ static hipError_t pack_band(PackedBand& pb, const float* dense, int n_rows, int 
         pb.n_items = next;
         pb.n_empty = (int)empties.size();
     }
+    // k_mel2's items (see PackedBand::d_whole)
+    pb.whole_ok = false;
+    if (n_waves == 16) {
+        struct Part { int blk, first, steps, off, role, slot; };
+        std::vector<Part> parts;
+        for (int b = 0; b < pb.n_blocks; ++b) parts.push_back(Part{b, blks[(size_t)b].first, blks[(size_t)b].steps, blks[(size_t)b].off, 1, 0});
+        int helpers = 0;
+        std::vector<int> addmask((size_t)pb.n_blocks, 0);
+        while (helpers < kMel2Slots) {   // the longest part in two while it is more than a SIMD's quarter
+            auto big = std::max_element(parts.begin(), parts.end(), [](const Part& a, const Part& b) { return a.steps < b.steps; });
+            if (big == parts.end() || big->steps * 4 <= pb.total_steps || big->steps < 8) break;
+            const int h = big->steps / 2;
+            Part rest{big->blk, big->first + 4 * (big->steps - h), h, big->off + (big->steps - h), 2, helpers};
+            big->steps -= h;
+            addmask[(size_t)rest.blk] |= 1 << helpers;
+            ++helpers;
+            parts.push_back(rest);
+        }
+        std::stable_sort(parts.begin(), parts.end(), [](const Part& a, const Part& b) { return a.steps > b.steps; });
+        std::vector<std::vector<Part>> simd(4);
+        int load[4] = {0, 0, 0, 0};
+        bool fits = true;
+        for (const Part& q : parts) {
+            int best = -1;
+            for (int i = 0; i < 4; ++i)
+                if (simd[(size_t)i].size() < 8 && (best < 0 || load[i] < load[best])) best = i;
+            if (best < 0) { fits = false; break; }
+            simd[(size_t)best].push_back(q);
+            load[best] += q.steps + 2;   // (+ an item's fixed cost)
+        }
+        if (fits) {
+            std::vector<int> whole((size_t)16 * 2 * 4, 0);
+            for (size_t i = 0; i < whole.size(); i += 4) whole[i + 1] = -1;
+            for (int sd = 0; sd < 4; ++sd)
+                for (size_t j = 0; j < simd[(size_t)sd].size(); ++j) {   // first round: one item per wave (the longest to the oldest), second round: the short ones
+                    const Part& q = simd[(size_t)sd][j];
+                    const int wave = sd + 4 * (int)(j % 4), place = (int)(j / 4);
+                    int* m = &whole[(size_t)((wave * 2 + place) * 4)];
+                    m[0] = q.first;
+                    m[1] = q.steps;
+                    m[2] = q.off;
+                    m[3] = q.blk | q.role << 8 | q.slot << 10 | (q.role == 1 ? addmask[(size_t)q.blk] : 0) << 12;
+                }
+            if (hipError_t e = upload(&pb.d_whole, whole.data(), whole.size() * sizeof(int)); e != hipSuccess) return e;
+            pb.whole_ok = true;
+        }
+    }
     // per K-step descriptors (resident form of k_mel: 16 bits per step in scalar registers instead of the item walk):
     // first column / 4 | slot id << 8 | item ends << 15
     std::vector<unsigned short> desc((size_t)pb.total_steps + 2, 0);
@@ -183,6 +230,7 @@ static void free_band(PackedBand& pb) {
     if (pb.d_blk_ptr) (void)hipFree(pb.d_blk_ptr);
     if (pb.d_desc) (void)hipFree(pb.d_desc);
     if (pb.d_direct) (void)hipFree(pb.d_direct);
+    if (pb.d_whole) (void)hipFree(pb.d_whole);
     pb = PackedBand{};
 }
 

@@ -37,6 +37,7 @@ constexpr int cqt_slot(int log2n, int k) {
     return cqt_double(log2n) ? ((k & 1) ? cqt_slot14(k >> 1) : cqt_slot14(8192 + (k >> 1))) : cqt_split(log2n) ? cqt_slot14(k) : k + (k >> 4);
 }
 constexpr int cqt_nyquist_slot(int log2n) { return cqt_split(log2n) ? kCqtRegion - 1 : (1 << log2n) + ((1 << log2n) >> 4); }
+constexpr int kMel2Slots = 3;   // k_mel2: partial tiles of cut filterbank blocks (1 KB of LDS each)   // k_mel2: longest item of the filterbank product, partial tiles per 16-frame tile
 constexpr int kCqtMmSteps = 14;            // k_cqt, matrix-core contraction: steps (entries per lane) a wave keeps in registers
 constexpr int kCqtResident = 12;           // k_cqt: iterations (entries per lane) of a wave's share of the kernel matrix that ride in registers
 constexpr int kCqt64Sub = 4096;            // float64 CQT: length of the sub-transforms that fit LDS (2 x 4096 x 16 B)
@@ -59,6 +60,12 @@ struct PackedBand {
     unsigned short* d_desc = nullptr;   // [total_steps] K-step descriptors of the resident form: first column / 4 | slot id << 8 | item ends << 15
     bool desc_ok = false;        // every step fits the 16-bit descriptor
     int n_empty = 0;             // blocks without non-zeros (their zero tiles are written by the streamed form only)
+    // k_mel2: whole 16-row blocks (one longer than a SIMD's quarter of the steps is cut in K; at most kMel2Slots cuts) dealt to the four
+    // SIMDs longest first, then to a SIMD's waves w, w + 4, w + 8, w + 12, at most two items per wave: d_whole [wave][2] = {first column,
+    // steps (-1: no item), offset into d_pack (steps), block | role << 8 (1 owner: stores the tile, 2 helper: hands its partial tile
+    // over through LDS) | helper's slot << 10 | owner's mask of slots to add << 12}
+    int4* d_whole = nullptr;
+    bool whole_ok = false;
     int max_wave_steps = 0;      // steps of the busiest wave: wave w owns steps [total w / n_waves, total (w + 1) / n_waves)
 };
 constexpr int kMelResidentFb = 18;  // K-steps of the filterbank / of the DCT rows a wave of k_mel keeps in registers

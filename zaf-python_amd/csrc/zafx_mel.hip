@@ -558,11 +558,309 @@ __global__ __launch_bounds__(mel_threads(LOG2N, LOG2E), kMelFpb == 8 ? 2 * mel_t
     }
 }
 
+// ---------------------------------------------------------------------------------
+// k_mel2: the filterbank product of tile i UNDER the transforms of tile i + 1 (W = 2048, mel)
+// ---------------------------------------------------------------------------------
+// k_mel's tile is transforms | barrier | product | barrier | reduction | barrier: sixteen waves in step, the vector pipe idle through the
+// last two thirds (54 % issue over the kernel), the matrix pipe idle through the first.  Here a frame buffer is two halves: the lower 4 KB
+// hold S[t][c] of the CURRENT tile, the upper 4.6 KB are the exchange area of the wave's transform of the NEXT tile's frame -- the first
+// exchange in two rounds of eight outputs per lane (readers ll < 8, then ll >= 8), the spectrum's upper half staged once for the split
+// (a lane holds Z[lane + 64 b + 256 r] after pass 3: its own k < 512 are in registers, only the partners N - k come from LDS).  The
+// magnitudes wait in registers for the barrier behind which nobody reads S any more.  The product runs on WHOLE 16-filter blocks
+// (PackedBand::d_whole: the widest cut in K, dealt so that every SIMD's matrix pipe carries a quarter): a wave's accumulators are
+// the block's tile -- no partial-tile slots, no reduction phase (a cut block's helper hands one partial tile over through 1 KB of LDS).
+// Per tile: [product of tile i (waves that own items) ; transform of the frame of tile i + 1] | barrier | S <- magnitudes, request of tile
+// i + 2 | barrier | stores of tile i.  Two barriers instead of four, matrix and vector pipes busy in the same phase.
+#ifndef ZAFX_MEL2
+#define ZAFX_MEL2 1
+#endif
+template <bool ALIGNED>
+__global__ __launch_bounds__(1024, 1) void k_mel2(const float* __restrict__ x, const float* __restrict__ win, const float2* __restrict__ twp,
+                                                   const float2* __restrict__ tws, const float* __restrict__ fb_pack, const int4* __restrict__ fb_whole,
+                                                   float* __restrict__ out, long long n_samples, int hop, int T, int TP, int tiles, int total_tiles,
+                                                   int n_filters, int layout) {
+    using C = FftCfg<10, 4>;
+    constexpr int N = C::N, P = 64, E = 16, W = 2 * N, NT = 1024, FPB = 16, PITCH = C::PITCH, EXOFF = N / 2;   // exchange area: float2 slots EXOFF .. PITCH - 1 of a frame buffer
+    static_assert(PITCH - EXOFF >= 8 * 63 + 31 + 8 && PITCH - EXOFF >= N / 2 + N / 32, "exchange area holds a round of the first exchange and the staged half spectrum");
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    float2* frames = reinterpret_cast<float2*>(smem_raw);
+    float2* tw_l = frames + FPB * PITCH;
+    float2* win_s = tw_l + C::TW;
+    float2* tws_s = win_s + N;
+    float* xpart = reinterpret_cast<float*>(tws_s + N / 2 + 1);   // kMel2Slots partial tiles of cut blocks
+    float* fall = reinterpret_cast<float*>(frames);
+    const int tid = threadIdx.x;
+    for (int i = tid; i < C::TW; i += NT) tw_l[i] = twp[i];
+    for (int i = tid; i < N; i += NT) win_s[i] = reinterpret_cast<const float2*>(win)[(i & ~63) + row_pair_index(i & 63)];   // lane order: win_s[64 i + lane]
+    for (int i = tid; i <= N / 2; i += NT) tws_s[i] = tws[i];
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const bool xcd = ZAFX_XCD_ORDER && gridDim.x % 8 == 0;
+    // this wave's items of the product (scalar)
+    // this wave's items of the product (scalar)
+    int it_first[2], it_steps[2], it_off[2], it_code[2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int4 m = fb_whole[wave * 2 + j];
+        it_first[j] = __builtin_amdgcn_readfirstlane(m.x);
+        it_steps[j] = __builtin_amdgcn_readfirstlane(m.y);   // < 0: no item
+        it_off[j] = __builtin_amdgcn_readfirstlane(m.z);
+        it_code[j] = __builtin_amdgcn_readfirstlane(m.w);
+    }
+    __syncthreads();
+
+    // ---- samples of the wave's frame of tile `tlv` (k_mel's pair form: 16-byte loads shared by the lanes l and l + 16 of a row pair)
+    float2 xr[E];
+    __amdgpu_buffer_rsrc_t frx = make_rsrc(x, 0);
+    bool raw = false;
+    // (a request past the last tile repeats the last one: xr, like the fragments below, is defined on EVERY path of every iteration -- left
+    // conditional, the old values count as live through the transform and its registers spill)
+    auto request = [&](int tlv, int lane) {   // lane: an opaque copy
+        raw = false;
+        tlv = min(tlv, total_tiles - 1);
+        const int p = row_pair_index(lane);
+        const int tl = xcd ? xcd_order(tlv, total_tiles) : tlv;
+        const int clip = tl / tiles, tile = tl % tiles;
+        const int t = tile * FPB + wave;
+        const float* xc = x + (long long)clip * n_samples;
+        const long long s0 = (long long)t * hop - N;
+        if (ALIGNED && t < T && s0 >= 0 && s0 + W <= n_samples) {   // interior frame (uniform)
+            frx = make_rsrc(xc, (unsigned)std::min<long long>(n_samples * 4, 0xfffffffcLL));
+            const int fvoff = ((int)s0 + 2 * (p & ~1)) * 4 + (p & 1) * (E / 2 * P * 8);
+#pragma unroll
+            for (int i = 0; i < E / 2; ++i) {
+                const float4 q = buf_load_f32x4(frx, fvoff, i * P * 8);
+                xr[2 * i] = make_float2(q.x, q.y);
+                xr[2 * i + 1] = make_float2(q.z, q.w);
+            }
+            raw = true;
+            return;
+        }
+#pragma unroll
+        for (int i = 0; i < E; ++i) {   // a frame that touches the clip's ends or lies past its last frame: zero padding (zaf.py:112-125)
+            const long long s = s0 + 2 * (p + i * P);
+            xr[i].x = (t < T && s >= 0 && s < n_samples) ? xc[s] : 0.f;
+            xr[i].y = (t < T && s + 1 >= 0 && s + 1 < n_samples) ? xc[s + 1] : 0.f;
+        }
+    };
+    // ---- transform of the requested frame; returns 4 |X|^2 (the filterbank carries the 1/2 of |X|) of the bins k = lane + 64 i (mk) and N - k (mn)
+    auto transform = [&](int lane, float (&mk)[E / 2], float (&mn)[E / 2]) {
+        float2* ex = frames + wave * PITCH + EXOFF;
+        const int p1 = row_pair_index(lane);
+        if (raw) {
+            float2 lo[E / 2], hi[E / 2];
+#pragma unroll
+            for (int i = 0; i < E / 2; ++i) {
+                lo[i] = xr[2 * i];
+                hi[i] = xr[2 * i + 1];
+                row_pair_unpack(lo[i], hi[i]);
+            }
+#pragma unroll
+            for (int i = 0; i < E / 2; ++i) {
+                xr[i] = lo[i];
+                xr[i + E / 2] = hi[i];
+            }
+        }
+        float2 v[E];
+#pragma unroll
+        for (int i = 0; i < E; ++i) v[i] = mul_elem(xr[i], win_s[lane + i * P]);
+        Dft<16>::run(v);
+        // first exchange, two rounds: position 16 p1 + r, r < 8 then r >= 8, at slot 8 p1 + (p1 >> 1) + (r & 7); lane (lh, ll) reads
+        // position lane + 64 i = 16 (lh + 4 i) + ll in the round that holds r = ll
+        const int wb = 8 * p1 + (p1 >> 1);
+        const int lh = lane >> 4, ll = lane & 15;
+        const int rb = 8 * lh + (lh >> 1) + (ll & 7);
+        float2 u[E];
+#pragma unroll
+        for (int r = 0; r < 8; ++r) ex[wb + r] = v[r];
+        frame_sync<64>();
+        if (ll < 8) {
+#pragma unroll
+            for (int i = 0; i < E; ++i) u[i] = ex[rb + 34 * i];
+        }
+        frame_sync<64>();
+#pragma unroll
+        for (int r = 0; r < 8; ++r) ex[wb + r] = v[r + 8];
+        frame_sync<64>();
+        if (ll >= 8) {
+#pragma unroll
+            for (int i = 0; i < E; ++i) u[i] = ex[rb + 34 * i];
+        }
+        frame_sync<64>();
+        float2 a[E];
+        {
+            float2 w[E];
+            pass2_twiddles(w, lane & 15, (const float2*)tw_l);
+            a[0] = u[0];
+#pragma unroll
+            for (int r = 1; r < E; ++r) a[r] = cmul(u[r], w[r]);
+        }
+        Dft<16>::run(a);
+#pragma unroll
+        for (int rh = 0; rh < 4; ++rh) {
+            lane_row_transpose4(a[4 * rh].x, a[4 * rh + 1].x, a[4 * rh + 2].x, a[4 * rh + 3].x);
+            lane_row_transpose4(a[4 * rh].y, a[4 * rh + 1].y, a[4 * rh + 2].y, a[4 * rh + 3].y);
+        }
+        // pass 3 in registers: z[b][r] = Z[lane + 64 b + 256 r]  (register 4 b + r' holds position lane + 64 b + 256 r')
+        float2 z[4][4];
+        const float2* t3 = (const float2*)tw_l + twiddle_offset(10, 4, 8);
+#pragma unroll
+        for (int b = 0; b < 4; ++b) {
+            const int k = lane + 64 * b;
+            z[b][0] = a[4 * b];
+#pragma unroll
+            for (int r = 1; r < 4; ++r) z[b][r] = cmul(a[4 * b + r], t3[(r - 1) * 256 + k]);
+            dft4(z[b][0], z[b][1], z[b][2], z[b][3]);
+        }
+        // upper half of the spectrum to LDS: Z[512 + q] at phys(q), q = lane + 64 b + 256 (r - 2)
+        const int pq = phys(lane);
+#pragma unroll
+        for (int b = 0; b < 4; ++b)
+#pragma unroll
+            for (int r = 2; r < 4; ++r) ex[phys_off<64>(pq, lane, 64 * b + 256 * (r - 2))] = z[b][r];
+        frame_sync<64>();
+#pragma unroll
+        for (int i = 0; i < E / 2; ++i) {
+            const int k = lane + i * P;
+            const float2 za = z[i & 3][i >> 2];
+            const float2 zb = ex[phys(N / 2 - (k == 0 ? N / 2 : k))];   // Z[N - k] (k = 0: Z[N / 2], staged at q = 0)
+            float2 pw = split_pair_pow4(za, zb, tws_s[k]);   // (4 |X[k]|^2, 4 |X[N-k]|^2)
+            if (i == 0 && k == 0) {
+                const float ny = za.x - za.y;   // X[N] (Nyquist, kept: zaf.py:370)
+                pw = make_float2(4.f * (zb.x * zb.x + zb.y * zb.y), 4.f * (ny * ny + 0.f * 0.f));   // |X[N/2]| = |Z[N/2]|
+            }
+            mk[i] = __builtin_amdgcn_sqrtf(pw.x);
+            mn[i] = __builtin_amdgcn_sqrtf(pw.y);
+        }
+        frame_sync<64>();
+    };
+    auto put_levels = [&](int lane, const float (&mk)[E / 2], const float (&mn)[E / 2]) {   // S[c], c = bin - 1, into the lower half of the wave's buffer
+        float* sf = reinterpret_cast<float*>(frames + wave * PITCH);
+        float* sk = sf + (lane == 0 ? N / 2 : lane) - 1;   // bin k of i = 0 (lane 0: bin N / 2)
+        float* sn = sf + N - lane - 1;                     // bin N - k of i = 0 (lane 0: bin N)
+        sk[0] = mk[0];
+        sn[0] = mn[0];
+#pragma unroll
+        for (int i = 1; i < E / 2; ++i) {
+            sf[lane + i * P - 1] = mk[i];
+            sn[-i * P] = mn[i];
+        }
+    };
+    typedef float f32x4v __attribute__((ext_vector_type(4)));
+    f32x4v acc[2][2];
+    // ---- the wave's items of FB . S for the tile whose levels are in LDS: A fragments from L2, eight steps' operands requested together.
+    // (Measured and dropped, profiles/r04_notes.md: fragments requested a chunk or a whole tile ahead, items of <= 24 steps on every
+    // wave with the partial tiles through L2, items on eight waves only -- each lost more to registers or to sixteen matrix-instruction
+    // chains starting together than it gained on the 9 k cycles the longest item waits for L2 here.)
+    auto product = [&](int lane) {
+        const float* sb = fall + (size_t)(lane & 15) * (2 * PITCH) + (lane >> 4);
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            acc[j][0] = acc[j][1] = f32x4v{0.f, 0.f, 0.f, 0.f};
+            const int steps = it_steps[j];
+            if (steps <= 0) continue;
+            const float* ap = fb_pack + (size_t)it_off[j] * 64 + lane;
+            const float* bp = sb + it_first[j];
+            for (int s0 = 0; s0 < steps; s0 += 8) {
+                float a[8], b[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    const int st = min(s0 + u, steps - 1);   // (past the last step: the last one again, not multiplied)
+                    a[u] = ap[(size_t)st * 64];
+                    b[u] = bp[4 * st];
+                }
+#pragma unroll
+                for (int u = 0; u < 8; ++u)
+                    if (s0 + u < steps) acc[j][u & 1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[u], b[u], acc[j][u & 1], 0, 0, 0);
+            }
+        }
+    };
+
+    int tlv = blockIdx.x;
+    if (tlv >= total_tiles) return;   // (uniform; the launcher's grid never exceeds the tiles)
+    {
+        float mk[E / 2], mn[E / 2];
+        int lane = tid & 63;
+        asm volatile("" : "+v"(lane));
+        request(tlv, lane);
+        transform(lane, mk, mn);
+        put_levels(lane, mk, mn);
+        request(tlv + gridDim.x, lane);
+        lds_barrier();
+    }
+    PROF_INIT(g_prof_mel);
+    for (; tlv < total_tiles; tlv += gridDim.x) {
+        PROF_MARK(0);
+        int lane = tid & 63;
+        asm volatile("" : "+v"(lane));   // (per-lane addresses are recomputed per tile, not carried through the transform)
+        const bool has_next = tlv + gridDim.x < total_tiles;
+        product(lane);
+        PROF_MARK(1);
+        float mk[E / 2] = {}, mn[E / 2] = {};
+        if (has_next) transform(lane, mk, mn);
+        // the frame after that: requested by each wave as soon as ITS transform is done -- the waves finish thousands of cycles apart, so
+        // the sixteen bursts of eight loads arrive spread out (all at once they overrun the CU's vector-memory queue: 2.5-5 k cycles blocked)
+        request(tlv + 2 * gridDim.x, lane);
+        PROF_MARK(2);
+        lds_barrier();   // nobody reads the current levels any more; every transform is done with its exchange area
+        PROF_MARK(3);
+        if (has_next) put_levels(lane, mk, mn);
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {   // a cut block's helper hands its partial tile over
+            if (it_steps[j] >= 0 && ((it_code[j] >> 8) & 3) == 2) {
+                float* dst = xpart + ((it_code[j] >> 10) & 3) * 256 + (4 * (lane >> 4)) * 16 + (lane & 15);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) dst[r * 16] = acc[j][0][r] + acc[j][1][r];
+            }
+        }
+        PROF_MARK(4);
+        lds_barrier();   // the next tile's levels and the partial tiles are in LDS
+        PROF_MARK(5);
+        {
+            const int tl = xcd ? xcd_order(tlv, total_tiles) : tlv;
+            const int clip = tl / tiles, t = (tl % tiles) * FPB + (lane & 15);
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                if (it_steps[j] < 0 || ((it_code[j] >> 8) & 3) != 1) continue;
+                const int blk = it_code[j] & 255, mask = (it_code[j] >> 12) & 7;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    float val = acc[j][0][r] + acc[j][1][r];
+                    const int e = (4 * (lane >> 4) + r) * 16 + (lane & 15);
+#pragma unroll
+                    for (int h = 0; h < kMel2Slots; ++h)
+                        if (mask & (1 << h)) val += xpart[h * 256 + e];
+                    const int m = 16 * blk + 4 * (lane >> 4) + r;
+                    if (m < n_filters && t < T) {
+                        if (layout == ZAFX_LAYOUT_FT) out[((long long)clip * n_filters + m) * TP + t] = val;
+                        else out[((long long)clip * T + t) * n_filters + m] = val;
+                    }
+                }
+            }
+        }
+    }
+}
+
 template <int LOG2N, bool ALIGNED>
 static hipError_t run_mel(const zafx_plan& pl, const float* x, float* out, int64_t n_clips, int64_t n_samples, int T) {
     constexpr int LOG2E = mel_log2e(LOG2N);
     using G = MelCfg<LOG2N, LOG2E>;
     const int mfcc = pl.kind == ZAFX_MFCC;
+    if constexpr (ZAFX_MEL2 && LOG2N == 10 && LOG2E == 4 && kMelFpb == 16 && kMelThreads == 1024) {
+        if (!mfcc && pl.fb.whole_ok && pl.fb.n_waves == 16) {   // k_mel2: the product of a tile under the transforms of the next
+            using C = FftCfg<10, 4>;
+            const size_t smem = (size_t)(16 * C::PITCH + C::TW + C::N + C::N / 2 + 1) * 8 + kMel2Slots * 1024;
+            static_assert((size_t)(16 * C::PITCH + C::TW + C::N + C::N / 2 + 1) * 8 + kMel2Slots * 1024 <= (size_t)kMaxLdsBytes, "k_mel2: LDS");
+            auto k2 = k_mel2<ALIGNED>;
+            if (hipError_t e = ensure_dynamic_lds(reinterpret_cast<const void*>(k2), pl.device, smem); e != hipSuccess) return e;
+            const int tiles2 = (T + 15) / 16;
+            const long long total2 = (long long)tiles2 * n_clips;
+            if (total2 <= 0) return hipSuccess;
+            const long long grid2 = std::min<long long>(total2, (long long)pl.n_cus);
+            pl.ran = "k_mel2";
+            hipLaunchKernelGGL(k2, dim3((unsigned)grid2), dim3(1024), smem, pl.stream, x, pl.d_window, pl.d_tw_pass, pl.d_tw_aux, pl.fb.d_pack, pl.fb.d_whole, out, (long long)n_samples, pl.H, T, (int)row_pitch(pl, T), tiles2, (int)total2, pl.prm.n_filters, pl.layout);
+            return hipGetLastError();
+        }
+    }
     // filterbank and DCT fragments resident in registers when the busiest wave's K-steps fit (128 filters at W = 2048: 17 + 4)
     // (a block without non-zeros has no K-step to carry its zero tile: streamed form)
     constexpr bool team8 = kMelFpb == 8 && G::NT == 512;   // (8-frame form: twice the steps per wave, re-read every tile)

@@ -189,6 +189,12 @@ static hipError_t pack_band(PackedBand& pb, const float* dense, int n_rows, int 
                     m[3] = q.blk | q.role << 8 | q.slot << 10 | (q.role == 1 ? addmask[(size_t)q.blk] : 0) << 12;
                 }
             if (hipError_t e = upload(&pb.d_whole, whole.data(), whole.size() * sizeof(int)); e != hipSuccess) return e;
+            pb.h_owner.assign((size_t)pb.n_blocks, 0);
+            for (int w = 0; w < 16; ++w)
+                for (int place = 0; place < 2; ++place) {
+                    const int* m = &whole[(size_t)((w * 2 + place) * 4)];
+                    if (m[1] >= 0 && ((m[3] >> 8) & 3) == 1) pb.h_owner[(size_t)(m[3] & 255)] = w | place << 8;
+                }
             pb.whole_ok = true;
         }
     }
@@ -231,6 +237,8 @@ static void free_band(PackedBand& pb) {
     if (pb.d_desc) (void)hipFree(pb.d_desc);
     if (pb.d_direct) (void)hipFree(pb.d_direct);
     if (pb.d_whole) (void)hipFree(pb.d_whole);
+    if (pb.d_dct2) (void)hipFree(pb.d_dct2);
+    if (pb.d_owner2) (void)hipFree(pb.d_owner2);
     pb = PackedBand{};
 }
 
@@ -280,6 +288,26 @@ static bool is_mdct_family(int kind) { return kind == ZAFX_MDCT || kind == ZAFX_
 static bool is_cqt_family(int kind) { return kind == ZAFX_CQT || kind == ZAFX_CHROMA; }
 
 // (re)build everything that is derived from the host shadows of the constants
+// k_mel2's mfcc stage (PackedBand::d_dct2 of pl->dct): needs the filterbank's whole-block items and the DCT rows, whichever constant comes last
+static hipError_t build_mel2_dct(zafx_plan* pl) {
+    zafx::PackedBand& d = pl->dct;
+    d.dct2_ok = false;
+    const int nf = pl->prm.n_filters, nc = pl->prm.n_coefs, nb = pl->fb.n_blocks;
+    if (pl->kind != ZAFX_MFCC || !pl->fb.whole_ok || pl->h_dct.size() != (size_t)nc * nf || nc > 32 || nb > 8 || (int)pl->fb.h_owner.size() != nb) return hipSuccess;
+    std::vector<float> frag((size_t)nb * 2 * 4 * 64, 0.f);
+    for (int b = 0; b < nb; ++b)
+        for (int c = 0; c < 2; ++c)
+            for (int st = 0; st < 4; ++st)
+                for (int l = 0; l < 64; ++l) {
+                    const int row = 16 * c + (l & 15), col = 16 * b + 4 * st + (l >> 4);
+                    if (row < nc && col < nf) frag[(((size_t)b * 2 + c) * 4 + st) * 64 + l] = pl->h_dct[(size_t)row * nf + col];
+                }
+    if (hipError_t e = upload(&d.d_dct2, frag.data(), frag.size() * sizeof(float)); e != hipSuccess) return e;
+    if (hipError_t e = upload(&d.d_owner2, pl->fb.h_owner.data(), pl->fb.h_owner.size() * sizeof(int)); e != hipSuccess) return e;
+    d.dct2_ok = true;
+    return hipSuccess;
+}
+
 static int finalize_constant(zafx_plan* pl, int which) {
     switch (which) {
         case ZAFX_CONST_WINDOW: {
@@ -362,6 +390,7 @@ static int finalize_constant(zafx_plan* pl, int which) {
                 std::vector<float> scaled(pl->h_fb.size());
                 for (size_t i = 0; i < scaled.size(); ++i) scaled[i] = pl->h_fb[i] * scale;
                 ZAFX_HIP(pack_band(pl->fb, scaled.data(), pl->prm.n_filters, pl->W / 2, mel_waves(pl->log2nf)));
+                ZAFX_HIP(build_mel2_dct(pl));
             }
             return 0;
         case ZAFX_CONST_DCT:
@@ -395,6 +424,7 @@ static int finalize_constant(zafx_plan* pl, int which) {
                     d.direct_j = 2;
                 }
             }
+            ZAFX_HIP(build_mel2_dct(pl));
             return 0;
         case ZAFX_CONST_MATRIX:
             ZAFX_HIP(upload(&pl->d_matrix, pl->h_matrix.data(), pl->h_matrix.size() * sizeof(float)));

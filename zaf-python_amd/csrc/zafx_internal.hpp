@@ -66,6 +66,12 @@ struct PackedBand {
     // over through LDS) | helper's slot << 10 | owner's mask of slots to add << 12}
     int4* d_whole = nullptr;
     bool whole_ok = false;
+    std::vector<int> h_owner;    // (filterbank) wave | place << 8 of the item that owns block b's tile
+    // k_mel2, mfcc (on the DCT band): d_dct2 [filterbank block][2 coefficient blocks][4 steps][64] = the DCT rows as A fragments over the
+    // block's sixteen filters (lane l -> D[16 c + (l & 15)][16 b + 4 s + (l >> 4)]); d_owner2 [filterbank blocks] = the owner waves
+    float* d_dct2 = nullptr;
+    int* d_owner2 = nullptr;
+    bool dct2_ok = false;
     int max_wave_steps = 0;      // steps of the busiest wave: wave w owns steps [total w / n_waves, total (w + 1) / n_waves)
 };
 constexpr int kMelResidentFb = 18;  // K-steps of the filterbank / of the DCT rows a wave of k_mel keeps in registers

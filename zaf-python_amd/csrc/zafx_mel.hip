@@ -574,11 +574,15 @@ __global__ __launch_bounds__(mel_threads(LOG2N, LOG2E), kMelFpb == 8 ? 2 * mel_t
 #ifndef ZAFX_MEL2
 #define ZAFX_MEL2 1
 #endif
-template <bool ALIGNED>
+// MFCC: the levels are |X|^2 (zaf.py:437-439); between the two barriers the owners take log(mel + eps) of their tiles, turn them into B
+// fragments (a 4 x 4 transpose of register index against 16-lane row: two v_permlane swaps) and multiply them with their block's
+// columns of the DCT-II rows (zaf.py:443-452; A fragments resident: 8 registers per owned block); the partial coefficient tiles go through
+// the exchange areas -- free between the barriers -- and 16 x n_coefs threads add them in block order.  Two more barriers per tile.
+template <bool ALIGNED, bool MFCC>
 __global__ __launch_bounds__(1024, 1) void k_mel2(const float* __restrict__ x, const float* __restrict__ win, const float2* __restrict__ twp,
                                                    const float2* __restrict__ tws, const float* __restrict__ fb_pack, const int4* __restrict__ fb_whole,
-                                                   float* __restrict__ out, long long n_samples, int hop, int T, int TP, int tiles, int total_tiles,
-                                                   int n_filters, int layout) {
+                                                   const float* __restrict__ dct2, const int* __restrict__ owner2, float* __restrict__ out, long long n_samples, int hop,
+                                                   int T, int TP, int tiles, int total_tiles, int n_filters, int n_coefs, int layout) {
     using C = FftCfg<10, 4>;
     constexpr int N = C::N, P = 64, E = 16, W = 2 * N, NT = 1024, FPB = 16, PITCH = C::PITCH, EXOFF = N / 2;   // exchange area: float2 slots EXOFF .. PITCH - 1 of a frame buffer
     static_assert(PITCH - EXOFF >= 8 * 63 + 31 + 8 && PITCH - EXOFF >= N / 2 + N / 32, "exchange area holds a round of the first exchange and the staged half spectrum");
@@ -728,8 +732,8 @@ __global__ __launch_bounds__(1024, 1) void k_mel2(const float* __restrict__ x, c
                 const float ny = za.x - za.y;   // X[N] (Nyquist, kept: zaf.py:370)
                 pw = make_float2(4.f * (zb.x * zb.x + zb.y * zb.y), 4.f * (ny * ny + 0.f * 0.f));   // |X[N/2]| = |Z[N/2]|
             }
-            mk[i] = __builtin_amdgcn_sqrtf(pw.x);
-            mn[i] = __builtin_amdgcn_sqrtf(pw.y);
+            mk[i] = MFCC ? pw.x : __builtin_amdgcn_sqrtf(pw.x);   // v_sqrt_f32, 1 ulp
+            mn[i] = MFCC ? pw.y : __builtin_amdgcn_sqrtf(pw.y);
         }
         frame_sync<64>();
     };
@@ -775,6 +779,21 @@ __global__ __launch_bounds__(1024, 1) void k_mel2(const float* __restrict__ x, c
         }
     };
 
+    // (MFCC) the DCT rows over the filters of the blocks this wave owns: [item][coefficient block][step]
+    float dfr[MFCC ? 2 : 1][8];
+    if constexpr (MFCC) {
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const bool own = it_steps[j] >= 0 && ((it_code[j] >> 8) & 3) == 1;
+            const float* dp = dct2 + (size_t)(own ? it_code[j] & 255 : 0) * 8 * 64 + (tid & 63);
+#pragma unroll
+            for (int u = 0; u < 8; ++u) dfr[j][u] = dp[u * 64];
+        }
+    }
+    const int n_blocks = (n_filters + 15) >> 4;
+    int owners[8];   // (MFCC, scalar) wave | place << 8 of the item that owns block b (at most 8 blocks: build_mel2_dct)
+#pragma unroll
+    for (int bb = 0; bb < 8; ++bb) owners[bb] = MFCC && bb < n_blocks ? __builtin_amdgcn_readfirstlane(owner2[bb]) : 0;
     int tlv = blockIdx.x;
     if (tlv >= total_tiles) return;   // (uniform; the launcher's grid never exceeds the tiles)
     {
@@ -815,27 +834,69 @@ __global__ __launch_bounds__(1024, 1) void k_mel2(const float* __restrict__ x, c
         PROF_MARK(4);
         lds_barrier();   // the next tile's levels and the partial tiles are in LDS
         PROF_MARK(5);
-        {
-            const int tl = xcd ? xcd_order(tlv, total_tiles) : tlv;
-            const int clip = tl / tiles, t = (tl % tiles) * FPB + (lane & 15);
+        const int tl = xcd ? xcd_order(tlv, total_tiles) : tlv;
+        const int clip = tl / tiles, t0 = (tl % tiles) * FPB;
+        float* exf = reinterpret_cast<float*>(frames + wave * PITCH + EXOFF);   // (MFCC) this wave's exchange area: free until the barrier that ends the tile
 #pragma unroll
-            for (int j = 0; j < 2; ++j) {
-                if (it_steps[j] < 0 || ((it_code[j] >> 8) & 3) != 1) continue;
-                const int blk = it_code[j] & 255, mask = (it_code[j] >> 12) & 7;
+        for (int j = 0; j < 2; ++j) {
+            if (it_steps[j] < 0 || ((it_code[j] >> 8) & 3) != 1) continue;
+            const int blk = it_code[j] & 255, mask = (it_code[j] >> 12) & 7;
+            float val[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                val[r] = acc[j][0][r] + acc[j][1][r];
+                const int e = (4 * (lane >> 4) + r) * 16 + (lane & 15);
+#pragma unroll
+                for (int h = 0; h < kMel2Slots; ++h)
+                    if (mask & (1 << h)) val[r] += xpart[h * 256 + e];
+            }
+            if constexpr (MFCC) {
+                const float eps = 2.220446049250313e-16f;   // np.finfo(float).eps (zaf.py:445)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) val[r] = 16 * blk + 4 * (lane >> 4) + r < n_filters ? logf(val[r] + eps) : 0.f;
+                // register r of 16-lane row q holds filter 4 q + r of the block; the B fragment of step s wants filter 4 s + q there
+                lane_row_transpose4(val[0], val[1], val[2], val[3]);
+#pragma unroll
+                for (int c = 0; c < 2; ++c) {
+                    if (16 * c >= n_coefs) continue;   // (uniform)
+                    f32x4v d = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                    for (int st = 0; st < 4; ++st) d = __builtin_amdgcn_mfma_f32_16x16x4f32(dfr[j][4 * c + st], val[st], d, 0, 0, 0);
+                    float* dst = exf + (2 * j + c) * 256 + (4 * (lane >> 4)) * 16 + (lane & 15);
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) dst[r * 16] = d[r];
+                }
+            } else {
+                const int t = t0 + (lane & 15);
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    float val = acc[j][0][r] + acc[j][1][r];
-                    const int e = (4 * (lane >> 4) + r) * 16 + (lane & 15);
-#pragma unroll
-                    for (int h = 0; h < kMel2Slots; ++h)
-                        if (mask & (1 << h)) val += xpart[h * 256 + e];
                     const int m = 16 * blk + 4 * (lane >> 4) + r;
                     if (m < n_filters && t < T) {
-                        if (layout == ZAFX_LAYOUT_FT) out[((long long)clip * n_filters + m) * TP + t] = val;
-                        else out[((long long)clip * T + t) * n_filters + m] = val;
+                        if (layout == ZAFX_LAYOUT_FT) out[((long long)clip * n_filters + m) * TP + t] = val[r];
+                        else out[((long long)clip * T + t) * n_filters + m] = val[r];
                     }
                 }
             }
+        }
+        if constexpr (MFCC) {
+            lds_barrier();   // every block's partial coefficient tile is in LDS
+            if (tid < 16 * n_coefs) {
+                const int q = tid >> 4, t = t0 + (tid & 15);
+                float part[8];
+#pragma unroll
+                for (int bb = 0; bb < 8; ++bb) {
+                    const int ow = owners[bb];
+                    part[bb] = bb < n_blocks ? reinterpret_cast<const float*>(frames + (ow & 255) * PITCH + EXOFF)[(2 * (ow >> 8) + (q >> 4)) * 256 + (q & 15) * 16 + (tid & 15)] : 0.f;
+                }
+                float sum = 0.f;
+#pragma unroll
+                for (int bb = 0; bb < 8; ++bb) sum += part[bb];   // (block order: deterministic)
+                if (t < T) {
+                    if (layout == ZAFX_LAYOUT_FT) out[((long long)clip * n_coefs + q) * TP + t] = sum;
+                    else out[((long long)clip * T + t) * n_coefs + q] = sum;
+                }
+            }
+            lds_barrier();   // the exchange areas are free for the next transforms
         }
     }
 }
@@ -846,18 +907,19 @@ static hipError_t run_mel(const zafx_plan& pl, const float* x, float* out, int64
     using G = MelCfg<LOG2N, LOG2E>;
     const int mfcc = pl.kind == ZAFX_MFCC;
     if constexpr (ZAFX_MEL2 && LOG2N == 10 && LOG2E == 4 && kMelFpb == 16 && kMelThreads == 1024) {
-        if (!mfcc && pl.fb.whole_ok && pl.fb.n_waves == 16) {   // k_mel2: the product of a tile under the transforms of the next
+        if (pl.fb.whole_ok && pl.fb.n_waves == 16 && (!mfcc || pl.dct.dct2_ok)) {   // k_mel2: the product of a tile under the transforms of the next
             using C = FftCfg<10, 4>;
             const size_t smem = (size_t)(16 * C::PITCH + C::TW + C::N + C::N / 2 + 1) * 8 + kMel2Slots * 1024;
             static_assert((size_t)(16 * C::PITCH + C::TW + C::N + C::N / 2 + 1) * 8 + kMel2Slots * 1024 <= (size_t)kMaxLdsBytes, "k_mel2: LDS");
-            auto k2 = k_mel2<ALIGNED>;
+            auto k2 = mfcc ? k_mel2<ALIGNED, true> : k_mel2<ALIGNED, false>;
             if (hipError_t e = ensure_dynamic_lds(reinterpret_cast<const void*>(k2), pl.device, smem); e != hipSuccess) return e;
             const int tiles2 = (T + 15) / 16;
             const long long total2 = (long long)tiles2 * n_clips;
             if (total2 <= 0) return hipSuccess;
             const long long grid2 = std::min<long long>(total2, (long long)pl.n_cus);
             pl.ran = "k_mel2";
-            hipLaunchKernelGGL(k2, dim3((unsigned)grid2), dim3(1024), smem, pl.stream, x, pl.d_window, pl.d_tw_pass, pl.d_tw_aux, pl.fb.d_pack, pl.fb.d_whole, out, (long long)n_samples, pl.H, T, (int)row_pitch(pl, T), tiles2, (int)total2, pl.prm.n_filters, pl.layout);
+            hipLaunchKernelGGL(k2, dim3((unsigned)grid2), dim3(1024), smem, pl.stream, x, pl.d_window, pl.d_tw_pass, pl.d_tw_aux, pl.fb.d_pack, pl.fb.d_whole, pl.dct.d_dct2,
+                               pl.dct.d_owner2, out, (long long)n_samples, pl.H, T, (int)row_pitch(pl, T), tiles2, (int)total2, pl.prm.n_filters, mfcc ? pl.prm.n_coefs : 0, pl.layout);
             return hipGetLastError();
         }
     }

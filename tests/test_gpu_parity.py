@@ -1191,6 +1191,33 @@ def test_clip_longer_than_32_bit_byte_offsets(zafx):
     assert relerr(coef[0][:, tm - 40 + 1:tm - 40 + ref.shape[1]], ref[:, 1:]) <= TOL_FFT
 
 
+@pytest.mark.parametrize("nmel,ncoef,hop,n,clips,seed", [
+    (128, 20, 1024, 441000, 3, 0), (40, 13, 512, 30001, 5, 1), (1, None, 1024, 2048, 2, 2), (17, 16, 1000, 50000, 1, 3),
+    (128, 32, 2048, 100000, 2, 4), (100, 33, 1024, 40000, 2, 5), (200, 20, 1024, 40000, 2, 6), (64, 5, 777, 12345, 260, 7)])
+def test_mel2_geometries(zafx, nmel, ncoef, hop, n, clips, seed):
+    """k_mel2 (W = 2048: the filterbank product of a tile under the next tile's transforms; whole-block items, cut blocks, the mfcc stage
+    between its barriers) over filter counts that are not multiples of 16, one filter, more coefficient rows than one block, more than 128
+    filters / 32 coefficients (mfcc then runs k_mel), odd hops and clip lengths (the unaligned form), fewer tiles than workgroups, more clips
+    than workgroups, both layouts."""
+    x = np.stack([synth_clip(90 + seed, c % 7, n) for c in range(clips)])
+    w = zafx.hamming(2048)
+    fb = zafx.melfilterbank(44100, 2048, nmel)
+    probe = sorted({0, clips // 2, clips - 1})
+    mel = zafx.melspectrogram_batch(x, w, hop, fb)
+    for c in probe:
+        ref = orc.melspectrogram(x[c].astype(np.float64), w, hop, fb)
+        assert mel[c].shape == ref.shape and relerr(mel[c], ref) <= TOL_FB, ("mel", c)
+    mel_tf = zafx.melspectrogram_batch(x[:2], w, hop, fb, layout="TF")
+    assert np.array_equal(mel_tf.transpose(0, 2, 1), mel[:2])
+    if ncoef is not None:
+        cep = zafx.mfcc_batch(x, w, hop, fb, ncoef)
+        for c in probe:
+            ref = orc.mfcc(x[c].astype(np.float64), w, hop, fb, ncoef)
+            assert cep[c].shape == ref.shape and relerr(cep[c], ref) <= TOL_FB, ("mfcc", c)
+        cep_tf = zafx.mfcc_batch(x[:2], w, hop, fb, ncoef, layout="TF")
+        assert np.array_equal(cep_tf.transpose(0, 2, 1), cep[:2])
+
+
 @pytest.mark.parametrize("wl,hop,n", [(2048, 3000, 50000), (2048, 2049, 20001), (1024, 5000, 30000), (256, 1000, 9999), (4096, 6000, 40000)])
 def test_hop_above_window(zafx, wl, hop, n):
     """step_length > window_length: zaf.stft / melspectrogram / mfcc skip samples between frames (zaf.py:102-136 holds for

@@ -559,7 +559,7 @@ __global__ __launch_bounds__(mel_threads(LOG2N, LOG2E), kMelFpb == 8 ? 2 * mel_t
 }
 
 // ---------------------------------------------------------------------------------
-// k_mel2: the filterbank product of tile i UNDER the transforms of tile i + 1 (W = 2048, mel)
+// k_mel2: the filterbank product of tile i UNDER the transforms of tile i + 1 (W = 2048; mel up to 256 filters, mfcc up to 128 filters x 32 rows)
 // ---------------------------------------------------------------------------------
 // k_mel's tile is transforms | barrier | product | barrier | reduction | barrier: sixteen waves in step, the vector pipe idle through the
 // last two thirds (54 % issue over the kernel), the matrix pipe idle through the first.  Here a frame buffer is two halves: the lower 4 KB

@@ -794,6 +794,19 @@ __global__ __launch_bounds__(1024, 1) void k_mel2(const float* __restrict__ x, c
     int owners[8];   // (MFCC, scalar) wave | place << 8 of the item that owns block b (at most 8 blocks: build_mel2_dct)
 #pragma unroll
     for (int bb = 0; bb < 8; ++bb) owners[bb] = MFCC && bb < n_blocks ? __builtin_amdgcn_readfirstlane(owner2[bb]) : 0;
+    // a cut block's helper hands its partial tile over.  mel: behind the first barrier (the owner adds it behind the second).  mfcc: right
+    // behind the product -- the owner of the tile before read its parts two barriers ago --, so that the owners' stage can start at the
+    // first barrier: three barriers per tile instead of four.
+    auto hand_over = [&](int lane) {
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            if (it_steps[j] >= 0 && ((it_code[j] >> 8) & 3) == 2) {
+                float* dst = xpart + ((it_code[j] >> 10) & 3) * 256 + (4 * (lane >> 4)) * 16 + (lane & 15);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) dst[r * 16] = acc[j][0][r] + acc[j][1][r];
+            }
+        }
+    };
     int tlv = blockIdx.x;
     if (tlv >= total_tiles) return;   // (uniform; the launcher's grid never exceeds the tiles)
     {
@@ -813,6 +826,7 @@ __global__ __launch_bounds__(1024, 1) void k_mel2(const float* __restrict__ x, c
         asm volatile("" : "+v"(lane));   // (per-lane addresses are recomputed per tile, not carried through the transform)
         const bool has_next = tlv + gridDim.x < total_tiles;
         product(lane);
+        if constexpr (MFCC) hand_over(lane);
         PROF_MARK(1);
         float mk[E / 2] = {}, mn[E / 2] = {};
         if (has_next) transform(lane, mk, mn);
@@ -823,16 +837,9 @@ __global__ __launch_bounds__(1024, 1) void k_mel2(const float* __restrict__ x, c
         lds_barrier();   // nobody reads the current levels any more; every transform is done with its exchange area
         PROF_MARK(3);
         if (has_next) put_levels(lane, mk, mn);
-#pragma unroll
-        for (int j = 0; j < 2; ++j) {   // a cut block's helper hands its partial tile over
-            if (it_steps[j] >= 0 && ((it_code[j] >> 8) & 3) == 2) {
-                float* dst = xpart + ((it_code[j] >> 10) & 3) * 256 + (4 * (lane >> 4)) * 16 + (lane & 15);
-#pragma unroll
-                for (int r = 0; r < 4; ++r) dst[r * 16] = acc[j][0][r] + acc[j][1][r];
-            }
-        }
+        if constexpr (!MFCC) hand_over(lane);
         PROF_MARK(4);
-        lds_barrier();   // the next tile's levels and the partial tiles are in LDS
+        if constexpr (!MFCC) lds_barrier();   // the next tile's levels and the partial tiles are in LDS
         PROF_MARK(5);
         const int tl = xcd ? xcd_order(tlv, total_tiles) : tlv;
         const int clip = tl / tiles, t0 = (tl % tiles) * FPB;

@@ -826,7 +826,10 @@ __global__ __launch_bounds__(1024, 1) void k_mel2(const float* __restrict__ x, c
         asm volatile("" : "+v"(lane));   // (per-lane addresses are recomputed per tile, not carried through the transform)
         const bool has_next = tlv + gridDim.x < total_tiles;
         product(lane);
-        if constexpr (MFCC) hand_over(lane);
+#ifndef ZAFX_MEL2_EARLYOUT
+#define ZAFX_MEL2_EARLYOUT 1
+#endif
+        if constexpr (MFCC || ZAFX_MEL2_EARLYOUT) hand_over(lane);
         PROF_MARK(1);
         float mk[E / 2] = {}, mn[E / 2] = {};
         if (has_next) transform(lane, mk, mn);
@@ -837,9 +840,9 @@ __global__ __launch_bounds__(1024, 1) void k_mel2(const float* __restrict__ x, c
         lds_barrier();   // nobody reads the current levels any more; every transform is done with its exchange area
         PROF_MARK(3);
         if (has_next) put_levels(lane, mk, mn);
-        if constexpr (!MFCC) hand_over(lane);
+        if constexpr (!MFCC && !ZAFX_MEL2_EARLYOUT) hand_over(lane);
         PROF_MARK(4);
-        if constexpr (!MFCC) lds_barrier();   // the next tile's levels and the partial tiles are in LDS
+        if constexpr (!MFCC && !ZAFX_MEL2_EARLYOUT) lds_barrier();   // the next tile's levels and the partial tiles are in LDS
         PROF_MARK(5);
         const int tl = xcd ? xcd_order(tlv, total_tiles) : tlv;
         const int clip = tl / tiles, t0 = (tl % tiles) * FPB;
@@ -885,6 +888,7 @@ __global__ __launch_bounds__(1024, 1) void k_mel2(const float* __restrict__ x, c
                 }
             }
         }
+        if constexpr (!MFCC && ZAFX_MEL2_EARLYOUT) lds_barrier();   // the next tile's levels are in LDS (the owners' stores are on their way)
         if constexpr (MFCC) {
             lds_barrier();   // every block's partial coefficient tile is in LDS
             if (tid < 16 * n_coefs) {

@@ -98,12 +98,13 @@ def all_counters(kind, leg):
 KERNEL_OF = {"mel": "k_mel", "mfcc": "k_mel", "cqt": "k_cqt", "stft": "k_stft_ft16", "dct": "k_dct"}
 sq_rows = []
 for kind, kname in KERNEL_OF.items():
-    merged = {}
+    merged, label = {}, kname
     for leg in ("SQ", "LDS"):
         tab = all_counters(kind, leg)
         kern = next((k for k in tab if kname in k), None)
         if kern:
             merged.update(tab[kern])
+            label = kern.split("<")[0].split("(")[0].split("::")[-1].strip() or kname   # the kernel that ran (k_mel2 for config 3 since round 4)
     if not merged:
         continue
     grbm, mfma = merged.get("GRBM_GUI_ACTIVE"), merged.get("SQ_VALU_MFMA_BUSY_CYCLES")
@@ -120,9 +121,9 @@ for kind, kname in KERNEL_OF.items():
             if merged.get(c) is not None:
                 derived[c.lower()[3:] + "_over_wave_cycles"] = merged[c] / merged["SQ_WAVE_CYCLES"]
     for c, v in sorted(merged.items()):
-        sq_rows.append(f'{kind},"{kname}",{c},{v:.1f}')
+        sq_rows.append(f'{kind},"{label}",{c},{v:.1f}')
     for c, v in sorted(derived.items()):
-        sq_rows.append(f'{kind},"{kname}",{c},{v:.5f}')
+        sq_rows.append(f'{kind},"{label}",{c},{v:.5f}')
 if sq_rows:
     with open(os.path.join(PROF, f"{tag}_sq_summary.csv"), "w") as fh:
         fh.write("kind,kernel,counter_or_ratio,mean_per_dispatch\n" + "\n".join(sq_rows) + "\n")

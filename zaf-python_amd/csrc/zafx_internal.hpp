@@ -212,6 +212,7 @@ inline bool mel_takes_wide_route(const zafx_plan& pl) { return pl.log2nf >= 11 |
 bool mel_band_usable(const zafx_plan& pl, const float* x, int64_t n_clips, int64_t n_samples, int T);   // W = 4096: the fused two-band kernel k_mel_ft16b (zafx_stft.hip)
 hipError_t launch_mel_band(const zafx_plan& pl, const float* x, float* out, int64_t n_clips, int64_t n_samples, int T);
 hipError_t launch_cqt(const zafx_plan& pl, const float* x, float* out, int64_t n_clips, int64_t n_samples, int T);
+bool launch_spec2(const zafx_plan& pl, const float* x, float* out, int64_t n_clips, int64_t n_samples, int T, hipError_t& err);   // zafx_mel.hip: |X| / |X|^2 rows of an STFT plan on k_mel2
 hipError_t launch_linear(const zafx_plan& pl, const float* x, float* y, int64_t n_clips);
 hipError_t launch_dct(const zafx_plan& pl, const float* x, float* y, int64_t n_rows);   // zafx_dct.hip: dct / dst I-IV on the FFT core
 bool dct_supported(int log2m);   // log2 of the complex FFT length M

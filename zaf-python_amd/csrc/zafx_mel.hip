@@ -578,13 +578,20 @@ __global__ __launch_bounds__(mel_threads(LOG2N, LOG2E), kMelFpb == 8 ? 2 * mel_t
 // fragments (a 4 x 4 transpose of register index against 16-lane row: two v_permlane swaps) and multiply them with their block's
 // columns of the DCT-II rows (zaf.py:443-452; A fragments resident: 8 registers per owned block); the partial coefficient tiles go through
 // the exchange areas -- free between the barriers -- and 16 x n_coefs threads add them in block order.  Two more barriers per tile.
-template <bool ALIGNED, bool MFCC>
+// MODE 0 mel, 1 mfcc; 2 / 3: the one-sided |X| / |X|^2 spectrogram of the STFT (zaf.py:83; ZAFX_SPECTRUM_MAGNITUDE / _POWER at W = 2048 in
+// the reference layout): the same transforms and levels, and in the product's place the tile's rows 0 .. N leave from the levels in LDS
+// (thread = frame tid & 15 x rows (tid >> 4) + 64 j: 64-byte runs) -- on k_stft_ft16's 8 fat waves these kinds ran at 3.2 TB/s (1.12 ms
+// per 1024 x 10 s), bound by the transforms of two frames per wave, not by their 3.6 GB.
+template <bool ALIGNED, int MODE>
 __global__ __launch_bounds__(1024, 1) void k_mel2(const float* __restrict__ x, const float* __restrict__ win, const float2* __restrict__ twp,
                                                    const float2* __restrict__ tws, const float* __restrict__ fb_pack, const int4* __restrict__ fb_whole,
                                                    const float* __restrict__ dct2, const int* __restrict__ owner2, float* __restrict__ out, long long n_samples, int hop,
                                                    int T, int TP, int tiles, int total_tiles, int n_filters, int n_coefs, int layout) {
     using C = FftCfg<10, 4>;
-    constexpr int N = C::N, P = 64, E = 16, W = 2 * N, NT = 1024, FPB = 16, PITCH = C::PITCH, EXOFF = N / 2;   // exchange area: float2 slots EXOFF .. PITCH - 1 of a frame buffer
+    constexpr bool MFCC = MODE == 1, SPECM = MODE >= 2, SQUARES = MODE == 1 || MODE == 3;
+    constexpr int N = C::N, P = 64, E = 16, W = 2 * N, NT = 1024, FPB = 16, PITCH = C::PITCH, EXOFF = N / 2;
+    constexpr int DCSLOT = 2 * (EXOFF + N / 2 + N / 32) + 8;   // (SPECM) float slot of bin 0's level in a frame buffer: behind the exchange area
+    static_assert(DCSLOT < 2 * PITCH, "bin 0's level fits the frame buffer");   // exchange area: float2 slots EXOFF .. PITCH - 1 of a frame buffer
     static_assert(PITCH - EXOFF >= 8 * 63 + 31 + 8 && PITCH - EXOFF >= N / 2 + N / 32, "exchange area holds a round of the first exchange and the staged half spectrum");
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     float2* frames = reinterpret_cast<float2*>(smem_raw);
@@ -604,7 +611,7 @@ __global__ __launch_bounds__(1024, 1) void k_mel2(const float* __restrict__ x, c
     int it_first[2], it_steps[2], it_off[2], it_code[2];
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
-        const int4 m = fb_whole[wave * 2 + j];
+        const int4 m = SPECM ? make_int4(0, -1, 0, 0) : fb_whole[wave * 2 + j];   // (the spectrogram kinds have no product)
         it_first[j] = __builtin_amdgcn_readfirstlane(m.x);
         it_steps[j] = __builtin_amdgcn_readfirstlane(m.y);   // < 0: no item
         it_off[j] = __builtin_amdgcn_readfirstlane(m.z);
@@ -647,7 +654,7 @@ __global__ __launch_bounds__(1024, 1) void k_mel2(const float* __restrict__ x, c
         }
     };
     // ---- transform of the requested frame; returns 4 |X|^2 (the filterbank carries the 1/2 of |X|) of the bins k = lane + 64 i (mk) and N - k (mn)
-    auto transform = [&](int lane, float (&mk)[E / 2], float (&mn)[E / 2]) {
+    auto transform = [&](int lane, float (&mk)[E / 2], float (&mn)[E / 2], float& dc) {   // dc (SPECM, lane 0): 4 |X[0]|^2 or its root
         float2* ex = frames + wave * PITCH + EXOFF;
         const int p1 = row_pair_index(lane);
         if (raw) {
@@ -732,12 +739,18 @@ __global__ __launch_bounds__(1024, 1) void k_mel2(const float* __restrict__ x, c
                 const float ny = za.x - za.y;   // X[N] (Nyquist, kept: zaf.py:370)
                 pw = make_float2(4.f * (zb.x * zb.x + zb.y * zb.y), 4.f * (ny * ny + 0.f * 0.f));   // |X[N/2]| = |Z[N/2]|
             }
-            mk[i] = MFCC ? pw.x : __builtin_amdgcn_sqrtf(pw.x);   // v_sqrt_f32, 1 ulp
-            mn[i] = MFCC ? pw.y : __builtin_amdgcn_sqrtf(pw.y);
+            if constexpr (SPECM) {
+                if (i == 0) {   // X[0] = Re Z[0] + Im Z[0] (lane 0's za)
+                    const float d0 = za.x + za.y;
+                    dc = SQUARES ? 4.f * (d0 * d0) : 2.f * fabsf(d0);
+                }
+            }
+            mk[i] = SQUARES ? pw.x : __builtin_amdgcn_sqrtf(pw.x);   // v_sqrt_f32, 1 ulp
+            mn[i] = SQUARES ? pw.y : __builtin_amdgcn_sqrtf(pw.y);
         }
         frame_sync<64>();
     };
-    auto put_levels = [&](int lane, const float (&mk)[E / 2], const float (&mn)[E / 2]) {   // S[c], c = bin - 1, into the lower half of the wave's buffer
+    auto put_levels = [&](int lane, const float (&mk)[E / 2], const float (&mn)[E / 2], float dc) {   // S[c], c = bin - 1, into the lower half of the wave's buffer
         float* sf = reinterpret_cast<float*>(frames + wave * PITCH);
         float* sk = sf + (lane == 0 ? N / 2 : lane) - 1;   // bin k of i = 0 (lane 0: bin N / 2)
         float* sn = sf + N - lane - 1;                     // bin N - k of i = 0 (lane 0: bin N)
@@ -748,6 +761,27 @@ __global__ __launch_bounds__(1024, 1) void k_mel2(const float* __restrict__ x, c
             sf[lane + i * P - 1] = mk[i];
             sn[-i * P] = mn[i];
         }
+        if constexpr (SPECM) {
+            if (lane == 0) sf[DCSLOT] = dc;
+        }
+    };
+    // (SPECM) rows 0 .. N of the tile whose levels are in LDS: thread = frame tid & 15 x rows (tid >> 4) + 64 j; the levels are 2 |X| / 4 |X|^2
+    auto store_rows = [&](int tlv) {
+        int to = tid;
+        asm volatile("" : "+v"(to));
+        const int tl = xcd ? xcd_order(tlv, total_tiles) : tlv;
+        const int clip = tl / tiles, t = (tl % tiles) * FPB + (to & 15), kq = to >> 4;
+        if (t >= T) return;
+        const float* sf = fall + (size_t)(to & 15) * (2 * PITCH);
+        const float sc = SQUARES ? 0.25f : 0.5f;
+        float* o = out + (long long)clip * (N + 1) * TP + t;
+        float v[E + 1];
+#pragma unroll
+        for (int j = 0; j < E; ++j) v[j] = sf[kq + 64 * j == 0 ? DCSLOT : kq + 64 * j - 1];
+        v[E] = sf[N - 1];
+#pragma unroll
+        for (int j = 0; j < E; ++j) o[(long long)(kq + 64 * j) * TP] = sc * v[j];
+        if (kq == 0) o[(long long)N * TP] = sc * v[E];
     };
     typedef float f32x4v __attribute__((ext_vector_type(4)));
     f32x4v acc[2][2];
@@ -813,9 +847,10 @@ __global__ __launch_bounds__(1024, 1) void k_mel2(const float* __restrict__ x, c
         float mk[E / 2], mn[E / 2];
         int lane = tid & 63;
         asm volatile("" : "+v"(lane));
+        float dc = 0.f;
         request(tlv, lane);
-        transform(lane, mk, mn);
-        put_levels(lane, mk, mn);
+        transform(lane, mk, mn, dc);
+        put_levels(lane, mk, mn, dc);
         request(tlv + gridDim.x, lane);
         lds_barrier();
     }
@@ -825,21 +860,26 @@ __global__ __launch_bounds__(1024, 1) void k_mel2(const float* __restrict__ x, c
         int lane = tid & 63;
         asm volatile("" : "+v"(lane));   // (per-lane addresses are recomputed per tile, not carried through the transform)
         const bool has_next = tlv + gridDim.x < total_tiles;
-        product(lane);
+        if constexpr (SPECM) store_rows(tlv);   // (behind the wave's own transform instead: the same on the line grid, 7 % slower off it)
+        else product(lane);
 #ifndef ZAFX_MEL2_EARLYOUT
 #define ZAFX_MEL2_EARLYOUT 1
 #endif
-        if constexpr (MFCC || ZAFX_MEL2_EARLYOUT) hand_over(lane);
+        if constexpr (!SPECM && (MFCC || ZAFX_MEL2_EARLYOUT)) hand_over(lane);
         PROF_MARK(1);
-        float mk[E / 2] = {}, mn[E / 2] = {};
-        if (has_next) transform(lane, mk, mn);
+        float mk[E / 2] = {}, mn[E / 2] = {}, dc = 0.f;
+        if (has_next) transform(lane, mk, mn, dc);
         // the frame after that: requested by each wave as soon as ITS transform is done -- the waves finish thousands of cycles apart, so
         // the sixteen bursts of eight loads arrive spread out (all at once they overrun the CU's vector-memory queue: 2.5-5 k cycles blocked)
         request(tlv + 2 * gridDim.x, lane);
         PROF_MARK(2);
         lds_barrier();   // nobody reads the current levels any more; every transform is done with its exchange area
         PROF_MARK(3);
-        if (has_next) put_levels(lane, mk, mn);
+        if (has_next) put_levels(lane, mk, mn, dc);
+        if constexpr (SPECM) {
+            lds_barrier();   // the next tile's levels are in LDS
+            continue;
+        }
         if constexpr (!MFCC && !ZAFX_MEL2_EARLYOUT) hand_over(lane);
         PROF_MARK(4);
         if constexpr (!MFCC && !ZAFX_MEL2_EARLYOUT) lds_barrier();   // the next tile's levels and the partial tiles are in LDS
@@ -922,7 +962,7 @@ static hipError_t run_mel(const zafx_plan& pl, const float* x, float* out, int64
             using C = FftCfg<10, 4>;
             const size_t smem = (size_t)(16 * C::PITCH + C::TW + C::N + C::N / 2 + 1) * 8 + kMel2Slots * 1024;
             static_assert((size_t)(16 * C::PITCH + C::TW + C::N + C::N / 2 + 1) * 8 + kMel2Slots * 1024 <= (size_t)kMaxLdsBytes, "k_mel2: LDS");
-            auto k2 = mfcc ? k_mel2<ALIGNED, true> : k_mel2<ALIGNED, false>;
+            auto k2 = mfcc ? k_mel2<ALIGNED, 1> : k_mel2<ALIGNED, 0>;
             if (hipError_t e = ensure_dynamic_lds(reinterpret_cast<const void*>(k2), pl.device, smem); e != hipSuccess) return e;
             const int tiles2 = (T + 15) / 16;
             const long long total2 = (long long)tiles2 * n_clips;
@@ -965,6 +1005,32 @@ static hipError_t run_mel(const zafx_plan& pl, const float* x, float* out, int64
                        pl.dct.d_wave_ptr, pl.dct.d_blk_ptr, pl.dct.d_desc, pl.dct.d_direct, direct_j, pl.dct.n_blocks, out, (long long)n_samples, pl.H, T, (int)row_pitch(pl, T), tiles, (int)total,
                        pl.prm.n_filters, pl.prm.n_coefs, mfcc, pl.layout);
     return hipGetLastError();
+}
+
+// ZAFX_SPECTRUM_MAGNITUDE / _POWER of an STFT plan at W = 2048 in the reference layout on k_mel2 (MODE 2 / 3); false: not this geometry
+#ifndef ZAFX_SPEC2
+#define ZAFX_SPEC2 1
+#endif
+bool launch_spec2(const zafx_plan& pl, const float* x, float* out, int64_t n_clips, int64_t n_samples, int T, hipError_t& err) {
+    using C = FftCfg<10, 4>;
+    if (!ZAFX_SPEC2 || pl.log2nf != 10 || pl.log2e != 4 || pl.layout != ZAFX_LAYOUT_FT || kMelFpb != 16 || kMelThreads != 1024 || !pl.d_tw_pass || !pl.d_tw_aux) return false;
+    if (pl.prm.spectrum != ZAFX_SPECTRUM_MAGNITUDE && pl.prm.spectrum != ZAFX_SPECTRUM_POWER) return false;
+    if (n_samples >= (1LL << 29)) return false;
+    const bool aligned = (n_samples % 2 == 0) && (pl.H % 2 == 0) && (reinterpret_cast<uintptr_t>(x) % 8 == 0);
+    const bool power = pl.prm.spectrum == ZAFX_SPECTRUM_POWER;
+    auto k2 = aligned ? (power ? k_mel2<true, 3> : k_mel2<true, 2>) : (power ? k_mel2<false, 3> : k_mel2<false, 2>);
+    const size_t smem = (size_t)(16 * C::PITCH + C::TW + C::N + C::N / 2 + 1) * 8 + kMel2Slots * 1024;
+    err = ensure_dynamic_lds(reinterpret_cast<const void*>(k2), pl.device, smem);
+    if (err != hipSuccess) return true;
+    const int tiles = (T + 15) / 16;
+    const long long total = (long long)tiles * n_clips;
+    if (total <= 0 || total >= (1LL << 31)) return total <= 0;
+    const long long grid = std::min<long long>(total, (long long)pl.n_cus);
+    pl.ran = "k_mel2";
+    hipLaunchKernelGGL(k2, dim3((unsigned)grid), dim3(1024), smem, pl.stream, x, pl.d_window, pl.d_tw_pass, pl.d_tw_aux, (const float*)nullptr, (const int4*)nullptr,
+                       (const float*)nullptr, (const int*)nullptr, out, (long long)n_samples, pl.H, T, (int)row_pitch(pl, T), tiles, (int)total, 0, 0, pl.layout);
+    err = hipGetLastError();
+    return true;
 }
 
 const char* mel_kernel_name() { return "k_mel"; }

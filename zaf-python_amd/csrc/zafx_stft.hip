@@ -2399,6 +2399,7 @@ static hipError_t dispatch_istft(const zafx_plan& pl, const float2* spec, float*
 }
 
 hipError_t launch_stft(const zafx_plan& pl, const float* x, float2* out, int64_t n_clips, int64_t n_samples, int T) {
+    if (hipError_t e = hipSuccess; launch_spec2(pl, x, reinterpret_cast<float*>(out), n_clips, n_samples, T, e)) return e;   // W = 2048, |X| / |X|^2, reference layout
     switch (pl.log2nf) {
 #define X(L) \
     case L: return dispatch_stft<L>(pl, x, out, n_clips, n_samples, T);

@@ -46,6 +46,11 @@ elif kind == "imdct":
     fwd.sync()
     n_in, tiles = T, (T + 31) // 32
     d_out = zafx.DeviceBuffer((B, plan.out_dims(T)[0]), np.float32)
+elif kind == "spec":   # the |X| rows of the STFT on k_mel2 (MODE 2)
+    plan = zafx.stft_plan(zafx.hamming(W), H, onesided="magnitude")
+    F, T = plan.out_dims(N)
+    d_in, n_in, tiles = d_x, N, 27
+    d_out = zafx.DeviceBuffer((B, F, T), np.float32)
 elif kind in ("mel", "mfcc"):
     w = zafx.hamming(W)
     fb = zafx.melfilterbank(44100, W, 128)
@@ -63,7 +68,7 @@ elif kind == "cqt":
     d_out = zafx.DeviceBuffer((B, F, T), np.float32)
 else:
     raise SystemExit("kind must be istft, mdct, imdct or cqt")
-name = "zafx_debug_prof_" + {"mfcc": "mel", "stft1": "stft"}.get(kind, kind)
+name = "zafx_debug_prof_" + {"mfcc": "mel", "stft1": "stft", "spec": "mel"}.get(kind, kind)
 fn = getattr(lib, name)
 out = (ctypes.c_ulonglong * 16)()
 # optional second argument: the waves to time, e.g. "0,5,15" or "all" (default: wave 1)

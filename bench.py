@@ -49,7 +49,7 @@ HBM_ACHIEVABLE_GBS = 6290.0   # same guide: measured-achievable copy rate
 F32_PEAK_TFLOPS = 157.3    # dense f32 vector / f32-input MFMA peak
 PLACEMENT_SURVEY = 6       # further allocations of the headline's row-strided output probed AFTER every timed region (reported, never timed)
 CONFIG_KINDS = ("istft", "mel", "mfcc", "mdct", "imdct", "cqt")   # SURVEY 8(a) a2 + BASELINE configs 3, 4, 5 (config 2 = the headline)
-EXTRA_KINDS = ("stft1", "istft1", "stft_offgrid", "mdct_offgrid", "stft4096", "stft4096_h1024", "istft4096", "mdct4096", "mel4096", "dct")   # one-sided pair (8f rank 4) and geometries off the benchmark's grid
+EXTRA_KINDS = ("stft1", "stftmag", "istft1", "stft_offgrid", "mdct_offgrid", "stft4096", "stft4096_h1024", "istft4096", "mdct4096", "mel4096", "dct")   # one-sided pair (8f rank 4) and geometries off the benchmark's grid
 
 
 def synth(seed, c, n):
@@ -141,6 +141,10 @@ def make_workload(kind, device, layout="FT"):
         plan = zafx.stft_plan(ham, H, layout=layout, device=device, onesided=True)
         wl.update(plan=plan, d_in=d_x, n_in=N, bytes_per_launch=B * (4 * N + 8 * (W // 2 + 1) * T),
                   desc="Batched STFT, one-sided output (W/2+1, T): 1024 clips x 10 s, Hamming win=2048 hop=1024")
+    elif kind == "stftmag":   # the spectrogram the reference's examples compute (zaf.py:83), |X| of rows 0..W/2 as float32 (k_mel2, MODE 2)
+        plan = zafx.stft_plan(ham, H, layout=layout, device=device, onesided="magnitude")
+        wl.update(plan=plan, d_in=d_x, n_in=N, bytes_per_launch=B * (4 * N + 4 * (W // 2 + 1) * T),
+                  desc="Batched magnitude spectrogram |X| (W/2+1, T) float32: 1024 clips x 10 s, Hamming win=2048 hop=1024")
     elif kind == "istft1":
         fwd = zafx.stft_plan(ham, H, device=device, onesided=True)
         d_s = zafx.DeviceBuffer(fwd.out_shape(B, N), np.complex64, device)
@@ -385,9 +389,10 @@ def parity_probe(wl):
     kind, base, B = wl["kind"], wl["base"], wl["n_clips"]
     ham, kbd = orc.hamming_periodic(W), orc.kbd_window(W)
     x64 = base[0].astype(np.float64)
-    if kind in ("stft", "stft1", "stft_offgrid"):
+    if kind in ("stft", "stft1", "stft_offgrid", "stftmag"):
         ref = orc.stft(x64, ham, H)
-        ref = ref[:W // 2 + 1] if kind == "stft1" else ref
+        ref = ref[:W // 2 + 1] if kind in ("stft1", "stftmag") else ref
+        ref = np.abs(ref) if kind == "stftmag" else ref
     elif kind == "stft4096":
         ref = orc.stft(x64, orc.hamming_periodic(4096), 2048)
     elif kind == "stft4096_h1024":
@@ -813,7 +818,7 @@ def main():
     ap.add_argument("--steps", type=int, default=100)
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--kind", default="all", help="all = headline STFT + every other BASELINE config in one line; or one of "
-                    "stft istft mdct imdct mel mfcc cqt stft1 istft1 stft64 dct")
+                    "stft istft mdct imdct mel mfcc cqt stft1 stftmag istft1 stft64 dct")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-configs", action="store_true", help="with --kind all: headline only")
     ap.add_argument("--layout", default="FT", choices=["FT", "TF"], help="FT = reference (W, T) memory order (default); TF = frame-major")

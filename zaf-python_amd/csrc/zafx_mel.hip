@@ -765,17 +765,17 @@ __global__ __launch_bounds__(1024, 1) void k_mel2(const float* __restrict__ x, c
             if (lane == 0) sf[DCSLOT] = dc;
         }
     };
-    // (SPECM) rows 0 .. N of the tile whose levels are in LDS (2 |X| / 4 |X|^2).  Rows of whole 16-byte pieces (pitch % 4 = 0, base aligned):
-    // thread = four frames (tid & 3) x rows (tid >> 2) + 256 j, one 16-byte store per row -- 5 vector-memory instructions per thread and
+    // (SPECM) rows 0 .. N of the tile whose levels are in LDS (2 |X| / 4 |X|^2).  Rows of whole 16-byte pieces (pitch % 4 = 0, base aligned; 8-byte
+    // pieces for the other even pitches): thread = four frames (tid & 3) x rows (tid >> 2) + 256 j, one 16-byte store per row -- 5 vector-memory instructions per thread and
     // tile instead of 17 four-byte ones (the youngest waves waited 5.5 k cycles at the store queue).  Else thread = frame x rows, 4 bytes.
-    const bool rows16 = SPECM && TP % 4 == 0 && reinterpret_cast<uintptr_t>(out) % 16 == 0;
+    const int rowv = !SPECM ? 1 : (TP % 4 == 0 && reinterpret_cast<uintptr_t>(out) % 16 == 0) ? 4 : (TP % 2 == 0 && reinterpret_cast<uintptr_t>(out) % 8 == 0) ? 2 : 1;   // frames per lane and store
     auto store_rows = [&](int tlv) {
         int to = tid;
         asm volatile("" : "+v"(to));
         const int tl = xcd ? xcd_order(tlv, total_tiles) : tlv;
         const int clip = tl / tiles, t0 = (tl % tiles) * FPB;
         const float sc = SQUARES ? 0.25f : 0.5f;
-        if (rows16 && t0 + FPB <= T) {   // (uniform) a whole tile
+        if (rowv == 4 && t0 + FPB <= T) {   // (uniform) a whole tile, 16-byte pieces
             const int tq = to & 3, kq = to >> 2;
             const float* sf = fall + (size_t)(4 * tq) * (2 * PITCH);
             float* o = out + (long long)clip * (N + 1) * TP + t0 + 4 * tq;
@@ -789,6 +789,21 @@ __global__ __launch_bounds__(1024, 1) void k_mel2(const float* __restrict__ x, c
             for (int j = 0; j < 4; ++j)
                 *reinterpret_cast<float4*>(o + (long long)(kq + 256 * j) * TP) = make_float4(sc * v[j].x, sc * v[j].y, sc * v[j].z, sc * v[j].w);
             if (kq == 0) *reinterpret_cast<float4*>(o + (long long)N * TP) = make_float4(sc * v[4].x, sc * v[4].y, sc * v[4].z, sc * v[4].w);
+            return;
+        }
+        if (rowv == 2 && t0 + FPB <= T) {   // (uniform) a whole tile, 8-byte pieces (an even pitch that is not a multiple of 4)
+            const int tq = to & 7, kq = to >> 3;
+            const float* sf = fall + (size_t)(2 * tq) * (2 * PITCH);
+            float* o = out + (long long)clip * (N + 1) * TP + t0 + 2 * tq;
+            float2 v[9];
+#pragma unroll
+            for (int j = 0; j < 9; ++j) {
+                const int k = j < 8 ? kq + 128 * j : N, at = k == 0 ? DCSLOT : k - 1;
+                v[j] = make_float2(sf[at], sf[at + 2 * PITCH]);
+            }
+#pragma unroll
+            for (int j = 0; j < 8; ++j) *reinterpret_cast<float2*>(o + (long long)(kq + 128 * j) * TP) = make_float2(sc * v[j].x, sc * v[j].y);
+            if (kq == 0) *reinterpret_cast<float2*>(o + (long long)N * TP) = make_float2(sc * v[8].x, sc * v[8].y);
             return;
         }
         const int t = t0 + (to & 15), kq = to >> 4;

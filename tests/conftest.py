@@ -26,7 +26,7 @@ def synth_clip(seed, c, n):
 def golden():
     return {
         name: np.load(os.path.join(GOLDEN, name + ".npz"))
-        for name in ("tiny", "consts", "config", "lengths", "dctdst", "cqtfull")
+        for name in ("tiny", "consts", "config", "lengths", "dctdst", "cqtfull", "signals")
     }
 
 
@@ -50,3 +50,56 @@ def built_library():
         subprocess.run(["make", "-C", os.path.join(ROOT, "zaf-python_amd", "csrc"), "-j", "8"], check=True,
                        stdout=subprocess.DEVNULL)
     return lib
+
+
+# ---------------------------------------------------------------- row-wise bounds (tests/signals.py cases)
+def excess(out, ref, bound):
+    """max |out - ref| / bound, elementwise; 0 where both are 0 (an exact result), inf where only the bound is."""
+    d = np.abs(np.asarray(out) - np.asarray(ref))
+    b = np.broadcast_to(np.asarray(bound, dtype=np.float64), d.shape)
+    r = np.zeros(d.shape)
+    nz = d > 0
+    with np.errstate(divide="ignore"):
+        r[nz] = d[nz] / b[nz]
+    return float(r.max()) if r.size else 0.0
+
+
+def row_bound(ref, tol, floor):
+    """The per-row contract: |out - ref| <= 10 tol max_row|ref| + floor.  `floor` (scalar, per row or per element) is the
+    level below which float32 arithmetic cannot follow the float64 reference: a row above it is held to 10 tol of its
+    OWN level, whatever the loudest row of the clip is."""
+    ref = np.asarray(ref)
+    rows = np.abs(ref).max(axis=-1, keepdims=True) if ref.ndim > 1 else np.abs(ref)
+    return 10.0 * tol * rows + floor
+
+
+def bin_noise(spec_ref, c, eps):
+    """Error model of one spectrum: every bin of frame t carries at most c eps max_k|X[k, t]| (a transform's rounding
+    errors scale with the operands of its butterflies, and for a tonal frame some bins are the difference of two
+    partial sums as large as the peak).  (1, T)."""
+    return c * eps * np.abs(spec_ref).max(axis=0, keepdims=True)
+
+
+def dct2_rows(m, lo, hi):
+    """Rows lo..hi-1 of the orthonormal DCT-II of length m (scipy.fftpack.dct(norm='ortho'), zaf.py:443-449)."""
+    k = np.arange(lo, hi)[:, None]
+    n = np.arange(m)[None, :]
+    d = np.sqrt(2.0 / m) * np.cos(np.pi * (2 * n + 1) * k / (2 * m))
+    d[k[:, 0] == 0] /= np.sqrt(2.0)
+    return d
+
+
+def mfcc_floor(spec_ref, fb_dense, ncoef, c, eps):
+    """What an error of `bin_noise` per spectrum bin can do to zaf.mfcc (zaf.py:436-452), by interval arithmetic: the band
+    powers move by FB (2|X| nu + nu^2), the logs by the width of that interval (unbounded relative to a band the
+    reference itself only holds as round-off), the coefficients by sum |D| width, plus the rounding of the DCT's own dot
+    products over the log levels.  (ncoef, T)."""
+    mag = np.abs(spec_ref[1:fb_dense.shape[1] + 1])
+    nu = bin_noise(spec_ref, c, eps)
+    band = fb_dense @ (mag ** 2)
+    dband = fb_dense @ (2.0 * mag * nu + nu ** 2) + c * eps * band
+    e = np.finfo(float).eps
+    logref = np.log(band + e)
+    width = np.maximum(np.log(band + dband + e) - logref, logref - np.log(np.maximum(band - dband, 0.0) + e))
+    d = np.abs(dct2_rows(fb_dense.shape[0], 1, ncoef + 1))
+    return d @ width + c * eps * (d @ np.abs(logref))

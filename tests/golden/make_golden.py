@@ -16,6 +16,10 @@ What is written (all .npz, float64/complex128, < 1 MB each):
                 sums and L2 norm per function
   lengths.npz   frame-count / output-length table of SURVEY.md section 4
   dctdst.npz    zaf.dct / zaf.dst, types 1-4, lengths 8, 9, 100, 1024, 63, 64, 65, 1023, 1025
+  signals.npz   signals that are not white noise (tests/signals.py: silence, DC, on-bin / between-bin full-scale sines, two
+                tones 100 dB apart, impulses on hop boundaries, a chirp, noise at -90 dBFS, clipped int16 PCM): rows
+                0..W/2 of zaf.stft (the mirror rows are their conjugates to 1e-15 of the peak, checked here), istft, melspectrogram, mfcc,
+                mdct, imdct at W = 2048 / hop 1024 on 3072 samples; cqtspectrogram / cqtchromagram on 17640 samples
   cqtfull.npz   the kernel of cqtkernel's own docstring example (zaf.py:476-483: 55 Hz ... fs/2, 208 bins, 60 879
                 non-zeros, columns on both halves of the spectrum): nnz per row, column range, value probes, and the
                 full cqtspectrogram / cqtchromagram of a 100 000-sample clip with it
@@ -194,7 +198,41 @@ def make_cqtfull():
     np.savez_compressed(os.path.join(HERE, "cqtfull.npz"), **out)
 
 
+def make_signals():
+    """Verdict r4 item 2: one clip per signal of tests/signals.py through every function of the path at W = 2048."""
+    sys.path.insert(0, os.path.dirname(HERE))
+    import signals as sig
+    out = {}
+    wl, hop = sig.W, sig.HOP
+    ham = scipy.signal.windows.hamming(wl, sym=False)
+    kbd = scipy.signal.windows.kaiser_bessel_derived(wl, beta=5 * np.pi)
+    fb = zaf.melfilterbank(sig.FS, wl, 128)
+    ck = zaf.cqtkernel(sig.FS, 24, 55, 3520)
+    for name in sig.NAMES:
+        x = sig.signal(name, sig.N_FRAMES).astype(np.float64)
+        out[f"{name}_x_sum"], out[f"{name}_x_abs"] = np.array(x.sum()), np.array(np.abs(x).sum())
+        s = zaf.stft(x, ham, hop)
+        # real input: the mirror rows are the conjugates up to the transform's own rounding (measured <= 2.2e-16 of the peak)
+        assert np.abs(s[wl // 2 + 1:] - np.conj(s[wl // 2 - 1:0:-1])).max() <= 1e-15 * max(np.abs(s).max(), 1e-300)
+        out[f"{name}_stft"] = s[: wl // 2 + 1]
+        out[f"{name}_istft"] = zaf.istft(s, ham, hop)
+        out[f"{name}_mel"] = zaf.melspectrogram(x, ham, hop, fb)
+        out[f"{name}_mfcc"] = zaf.mfcc(x, ham, hop, fb, 20)
+        m = zaf.mdct(x, kbd)
+        out[f"{name}_mdct"] = m
+        out[f"{name}_imdct"] = zaf.imdct(m, kbd)
+        xq = sig.signal(name, sig.N_CQT).astype(np.float64)
+        out[f"{name}_xq_sum"], out[f"{name}_xq_abs"] = np.array(xq.sum()), np.array(np.abs(xq).sum())
+        out[f"{name}_cqt"] = zaf.cqtspectrogram(xq, sig.FS, 25, ck)
+        out[f"{name}_chroma"] = zaf.cqtchromagram(xq, sig.FS, 25, 24, ck)
+    np.savez_compressed(os.path.join(HERE, "signals.npz"), **out)
+
+
 if __name__ == "__main__":
+    if len(sys.argv) > 1 and sys.argv[1] == "signals":   # (added in round 5; the other files are unchanged)
+        make_signals()
+        print("signals.npz", os.path.getsize(os.path.join(HERE, "signals.npz")))
+        sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "cqtfull":   # (added in round 2; the other files are unchanged)
         make_cqtfull()
         print("cqtfull.npz", os.path.getsize(os.path.join(HERE, "cqtfull.npz")))
@@ -209,5 +247,6 @@ if __name__ == "__main__":
     make_lengths()
     make_dctdst()
     make_cqtfull()
-    for f in ("tiny.npz", "consts.npz", "config.npz", "lengths.npz", "dctdst.npz", "cqtfull.npz"):
+    make_signals()
+    for f in ("tiny.npz", "consts.npz", "config.npz", "lengths.npz", "dctdst.npz", "cqtfull.npz", "signals.npz"):
         print(f, os.path.getsize(os.path.join(HERE, f)))

@@ -1,0 +1,193 @@
+"""GPU parity on signals that are not white noise (-m gpu): silence, DC, full-scale tones on and between bins, two tones
+100 dB apart, impulses on hop boundaries, a chirp, noise at -90 dBFS, clipped int16 PCM (tests/signals.py), against the
+outputs of the REAL reference (tests/golden/signals.npz) and, at a length that reaches the whole-tile kernels, against the
+oracle.
+
+Two bounds per output, both written here:
+  * the contract's normwise bound per clip, max|out - ref| / max|ref| <= 1e-5 (stft, istft, mdct, imdct) / 1e-4 (mel, mfcc,
+    cqt, chroma);
+  * a bound per ROW (frequency bin, mel band, coefficient, CQT bin; a hop of samples for the 1-D outputs):
+        |out - ref| <= 10 tol max_row|ref| + floor,
+    so that a quiet row under a loud one is held to its own level.  `floor` is the float32 floor of the clip,
+    C eps32 max|ref| -- what a float32 transform cannot resolve under the loudest value it handles (a tone's far bins are
+    differences of partial sums as large as its peak) -- with C = 2 for the 2048-point frames and 8 for the CQT's
+    32768-point frames (measured on MI355X, round 5: worst row at 0.37 / 0.66 of these bounds, DC through the CQT).  For the MFCCs the floor is that same per-bin error
+    carried through log and DCT by interval arithmetic (conftest.mfcc_floor): where a mel band of the reference holds only
+    the float64 transform's own round-off (DC, a tone exactly on a bin: bands at 1e-26 of the peak) the reference's
+    coefficients are functions of that round-off and no float32 -- or second float64 -- program reproduces them; the bound
+    is then as wide as log(float32 floor / float64 floor), and it is asserted, not skipped.  Silence has floor 0: every
+    output must be exactly zero, and the MFCCs of silence, DCT(log(eps)) (zaf.py:444-446), may differ from the reference's
+    1e-14 by the rounding of a float32 dot product over 128 equal levels.
+"""
+import json
+import os
+
+import numpy as np
+import pytest
+
+import signals as sig
+from conftest import bin_noise, excess, mfcc_floor, relerr, row_bound
+from oracle import zaf_oracle as orc
+
+pytestmark = pytest.mark.gpu
+
+TOL_FFT = 1e-5
+TOL_FB = 1e-4
+EPS32 = float(np.finfo(np.float32).eps)
+C_FLOOR = 2.0
+C_FLOOR_CQT = 8.0
+N_LONG = 1024 * 69 + 300       # 70 frames: whole 16- / 32-frame tiles, an edge tile and rows off the line grid
+
+_report = {}
+
+
+@pytest.fixture(scope="module")
+def zafx():
+    import zafx as z
+    assert z.device_count() >= 1
+    yield z
+    path = os.environ.get("ZAFX_SIGNALS_REPORT")
+    if path:
+        with open(path, "w") as f:
+            json.dump(_report, f, indent=1, sort_keys=True)
+
+
+@pytest.fixture(scope="module")
+def consts(zafx):
+    ham, kbd = zafx.hamming(sig.W), zafx.kaiser_bessel_derived(sig.W)
+    fb = zafx.melfilterbank(sig.FS, sig.W, 128)
+    ck = zafx.cqtkernel(sig.FS, 24, 55, 3520)
+    return ham, kbd, fb, ck
+
+
+def full_spectrum(half):
+    """Rows 0..W/2 -> the two-sided spectrum the reference returns (mirror rows = conjugates, see make_golden.py)."""
+    return np.concatenate([half, np.conj(half[-2:0:-1])], axis=0)
+
+
+def hops(y):
+    """A 1-D output as rows of one hop each (zero-filled at the end)."""
+    n = -(-len(y) // sig.HOP) * sig.HOP
+    return np.pad(y, (0, n - len(y))).reshape(-1, sig.HOP)
+
+
+def check(tag, out, ref, tol, floor=None, c=C_FLOOR):
+    out, ref = np.asarray(out), np.asarray(ref)
+    assert out.shape == ref.shape, (tag, out.shape, ref.shape)
+    peak = float(np.abs(ref).max()) if ref.size else 0.0
+    if floor is None:
+        floor = c * EPS32 * peak
+    g = relerr(out, ref)
+    r = excess(out, ref, row_bound(ref, tol, floor))
+    _report[tag] = {"normwise": g, "row_excess": r, "peak": peak}
+    assert r <= 1.0, (tag, "row bound", r)
+    return g
+
+
+def run_all(zafx, consts, name, x, xq, ref, long_form):
+    """Every function of the path on one signal.  ref: dict of reference outputs (stft = rows 0..W/2)."""
+    ham, kbd, fb, ck = consts
+    fbd = fb.toarray()
+    tag = f"{name}{'_long' if long_form else ''}"
+    half = ref["stft"]
+    got = zafx.stft_batch(x[None], ham, sig.HOP)[0]
+    assert got.shape == (sig.W, half.shape[1])
+    assert check(f"{tag}.stft", got[: sig.W // 2 + 1], half, TOL_FFT) <= TOL_FFT
+    assert check(f"{tag}.stft_mirror", got[sig.W // 2 + 1:], np.conj(half[-2:0:-1]), TOL_FFT) <= TOL_FFT
+    got1 = zafx.stft_batch(x[None], ham, sig.HOP, onesided=True)[0]
+    assert check(f"{tag}.stft_onesided", got1, half, TOL_FFT) <= TOL_FFT
+    for kind, p in (("magnitude", 1), ("power", 2)):
+        lvl = np.abs(half) ** p
+        # |X|^p of a bin carrying an absolute error nu: p |X|^(p-1) nu + nu^p
+        nu = bin_noise(half, C_FLOOR, EPS32)
+        fl = nu if p == 1 else 2 * np.abs(half) * nu + nu ** 2
+        gotm = zafx.stft_batch(x[None], ham, sig.HOP, onesided=kind)[0]
+        assert check(f"{tag}.stft_{kind}", gotm, lvl, TOL_FFT, fl) <= (TOL_FFT if p == 1 else 2 * TOL_FFT)
+
+    y = zafx.istft_batch(full_spectrum(half)[None], ham, sig.HOP)[0]
+    assert check(f"{tag}.istft", hops(y), hops(ref["istft"]), TOL_FFT) <= TOL_FFT
+    assert len(y) == len(ref["istft"])
+
+    # mel bands: FB |X| with every bin off by at most nu
+    nu = bin_noise(half, C_FLOOR, EPS32)
+    mel_floor = fbd @ np.broadcast_to(nu, (fbd.shape[1], nu.shape[1])) + C_FLOOR * EPS32 * np.abs(ref["mel"])
+    got = zafx.melspectrogram_batch(x[None], ham, sig.HOP, fb)[0]
+    assert check(f"{tag}.mel", got, ref["mel"], TOL_FB, mel_floor) <= TOL_FB
+    # MFCC: the floor carries the contract (docstring); the normwise bound holds whenever the floor is below it
+    fl = mfcc_floor(half, fbd, 20, C_FLOOR, EPS32)
+    got = zafx.mfcc_batch(x[None], ham, sig.HOP, fb, 20)[0]
+    g = check(f"{tag}.mfcc", got, ref["mfcc"], TOL_FB, fl)
+    _report[f"{tag}.mfcc"]["floor_over_peak"] = float(fl.max() / max(np.abs(ref["mfcc"]).max(), 1e-300))
+    if fl.max() <= TOL_FB * np.abs(ref["mfcc"]).max():
+        assert g <= TOL_FB, (tag, "mfcc", g)
+
+    got = zafx.mdct_batch(x[None], kbd)[0]
+    assert check(f"{tag}.mdct", got, ref["mdct"], TOL_FFT) <= TOL_FFT
+    y = zafx.imdct_batch(ref["mdct"][None], kbd)[0]
+    assert len(y) == len(ref["imdct"])
+    assert check(f"{tag}.imdct", hops(y), hops(ref["imdct"]), TOL_FFT) <= TOL_FFT
+
+    if xq is not None:
+        got = zafx.cqtspectrogram_batch(xq[None], sig.FS, 25, ck)[0]
+        assert check(f"{tag}.cqt", got, ref["cqt"], TOL_FB, c=C_FLOOR_CQT) <= TOL_FB
+        got = zafx.cqtchromagram_batch(xq[None], sig.FS, 25, 24, ck)[0]
+        assert check(f"{tag}.chroma", got, ref["chroma"], TOL_FB, c=C_FLOOR_CQT) <= TOL_FB
+
+
+@pytest.mark.parametrize("name", sig.NAMES)
+def test_signal_against_the_reference(zafx, consts, golden, name):
+    """n = 3072 / 17640 samples: the reference's own outputs."""
+    g = golden["signals"]
+    x, xq = sig.signal(name, sig.N_FRAMES), sig.signal(name, sig.N_CQT)
+    assert float(x.astype(np.float64).sum()) == g[f"{name}_x_sum"] and float(np.abs(xq.astype(np.float64)).sum()) == g[f"{name}_xq_abs"]
+    ref = {k: g[f"{name}_{k}"] for k in ("stft", "istft", "mel", "mfcc", "mdct", "imdct", "cqt", "chroma")}
+    run_all(zafx, consts, name, x, xq, ref, False)
+
+
+@pytest.mark.parametrize("name", sig.NAMES)
+def test_signal_on_the_whole_tile_kernels(zafx, consts, name):
+    """70 frames (the tiled kernels' interior path, an edge tile, rows off the line grid) against the oracle, which
+    tests/test_oracle_golden.py holds to the reference on these very signals."""
+    ham, kbd, fb, ck = consts
+    x = sig.signal(name, N_LONG)
+    x64 = x.astype(np.float64)
+    s = orc.stft(x64, ham, sig.HOP)
+    m = orc.mdct(x64, kbd)
+    ref = {"stft": s[: sig.W // 2 + 1], "istft": orc.istft(s, ham, sig.HOP), "mel": orc.melspectrogram(x64, ham, sig.HOP, fb),
+           "mfcc": orc.mfcc(x64, ham, sig.HOP, fb, 20), "mdct": m, "imdct": orc.imdct(m, kbd)}
+    run_all(zafx, consts, name, x, None, ref, True)
+
+
+def test_silence_is_exact(zafx, consts):
+    """Digital silence: every linear output is exactly zero (no denormal dust, no -0.0 that a log would turn into nan)."""
+    ham, kbd, fb, ck = consts
+    x = np.zeros((2, N_LONG), dtype=np.float32)
+    assert not np.any(zafx.stft_batch(x, ham, sig.HOP))
+    assert not np.any(zafx.melspectrogram_batch(x, ham, sig.HOP, fb))
+    assert not np.any(zafx.mdct_batch(x, kbd))
+    assert not np.any(zafx.cqtspectrogram_batch(x[:, :40000], sig.FS, 25, ck))
+    c = zafx.mfcc_batch(x, ham, sig.HOP, fb, 20)
+    assert np.all(np.isfinite(c))
+    # DCT rows 1..20 of 128 equal levels log(eps) = -36.04: zero up to the rounding of a float32 dot product
+    assert np.abs(c).max() <= 8.0 * EPS32 * 36.05 * np.sqrt(128.0)
+
+
+@pytest.mark.parametrize("channels", [1, 2])
+def test_clipped_pcm_through_the_pcm_entry_points(zafx, consts, golden, channels):
+    """Full-scale clipped int16 (zaf.py:1202 scales by 2**15, :65 averages the channels) straight into the *_pcm_batch forms."""
+    ham, kbd, fb, ck = consts
+    g = golden["signals"]
+    pcm = sig.clipped_pcm16(sig.N_FRAMES)
+    assert pcm.min() == -32768 and pcm.max() == 32767
+    p = pcm[None, :, None] if channels == 1 else np.stack([pcm, pcm], axis=-1)[None]
+    p = np.ascontiguousarray(p)
+    half = g["clipped_pcm_stft"]
+    got = zafx.stft_pcm_batch(p, ham, sig.HOP)[0]
+    assert check(f"pcm{channels}.stft", got[: sig.W // 2 + 1], half, TOL_FFT) <= TOL_FFT
+    assert check(f"pcm{channels}.mel", zafx.melspectrogram_pcm_batch(p, ham, sig.HOP, fb)[0], g["clipped_pcm_mel"], TOL_FB) <= TOL_FB
+    fl = mfcc_floor(half, fb.toarray(), 20, C_FLOOR, EPS32)
+    check(f"pcm{channels}.mfcc", zafx.mfcc_pcm_batch(p, ham, sig.HOP, fb, 20)[0], g["clipped_pcm_mfcc"], TOL_FB, fl)
+    assert check(f"pcm{channels}.mdct", zafx.mdct_pcm_batch(p, kbd)[0], g["clipped_pcm_mdct"], TOL_FFT) <= TOL_FFT
+    pq = sig.clipped_pcm16(sig.N_CQT)
+    pq = np.ascontiguousarray(pq[None, :, None] if channels == 1 else np.stack([pq, pq], axis=-1)[None])
+    assert check(f"pcm{channels}.cqt", zafx.cqtspectrogram_pcm_batch(pq, sig.FS, 25, ck)[0], g["clipped_pcm_cqt"], TOL_FB, c=C_FLOOR_CQT) <= TOL_FB

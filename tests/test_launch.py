@@ -146,10 +146,43 @@ def test_rendezvous_directory_is_private_and_stale_files_are_ignored(tmp_path, m
     assert (d / "000001_bcast").exists()          # another job's file is not ours to delete
     # ranks with different parent processes (started by hand) meet through an explicit namespace
     monkeypatch.setenv("ZAFX_RDZV_NS", "job42")
-    assert launch.Rendezvous.from_env(timeout=5.0).ns == "job42."
+    rv = launch.Rendezvous.from_env(timeout=5.0)
+    assert rv.base_ns == "job42." and rv.ns.startswith("job42.") and len(rv.ns) > len("job42.") + 8   # (+ this launch's epoch)
     monkeypatch.delenv("ZAFX_RDZV_NS")
     monkeypatch.setenv("TORCHELASTIC_RUN_ID", "run7")
-    assert launch.Rendezvous.from_env(timeout=5.0).ns == "run7."
+    assert launch.Rendezvous.from_env(timeout=5.0).base_ns == "run7."
+    rv.put("secret", b"unique id")
+    assert os.stat(d / (rv.ns + "secret")).st_mode & 0o077 == 0   # key files are private whatever the directory allows
+
+
+@pytest.mark.timeout(60)
+def test_named_namespace_survives_a_job_that_died(tmp_path):
+    """a relaunch under the same ZAFX_RDZV_NS / TORCHELASTIC_RUN_ID in a reused directory must not read the RCCL id
+    (or the handshake files) a dead job left there."""
+    from zafx import launch
+    d = tmp_path / "reused"
+    d.mkdir(mode=0o700)
+    for name, data in (("job.000001_bcast", b"stale id"), ("job.hello_1", b"00ff"), ("job.epoch", b"dead 00ff"), ("job.ack_1", b"dead"),
+                       ("job.dead.000001_bcast", b"stale id of the epoch before")):
+        (d / name).write_bytes(data)
+    got = {}
+
+    def rank(r):
+        rv = launch.Rendezvous(str(d), r, 2, timeout=30.0, namespace="job.")
+        rv.handshake()
+        got[r] = (rv.ns, rv.broadcast(b"fresh id" if r == 0 else b""))
+        rv.close()
+
+    ts = [threading.Thread(target=rank, args=(r,)) for r in (1, 0)]
+    ts[0].start()
+    import time
+    time.sleep(0.2)     # rank 1 is already waiting, with the stale epoch file in front of it, when rank 0 arrives
+    ts[1].start()
+    for t in ts:
+        t.join(40)
+    assert got[0][0] == got[1][0] and "dead" not in got[0][0]
+    assert got[0][1] == got[1][1] == b"fresh id"
+    assert not d.exists() or not [n for n in os.listdir(d) if n.startswith("job.")]   # close() took the dead job's files of this name along
 
 
 @pytest.mark.timeout(60)

@@ -4,7 +4,7 @@ import numpy as np
 import pytest
 import scipy.sparse
 
-from conftest import relerr, synth_clip
+from conftest import excess, mfcc_floor, relerr, synth_clip
 from oracle import zaf_oracle as orc
 
 TOL = 1e-12  # normwise; bit-identical on the NumPy the fixtures were made with
@@ -191,3 +191,39 @@ def test_dct_dst(golden, n):
     close(orc.dst(orc.dst(x, 1), 1), x, 1e-11)
     close(orc.dst(orc.dst(x, 2), 3), x, 1e-11)
     close(orc.dst(orc.dst(x, 4), 4), x, 1e-11)
+
+
+@pytest.mark.parametrize("name", __import__("signals").NAMES)
+def test_signals_that_are_not_noise(golden, name):
+    """tests/signals.py through the oracle against the real reference's outputs (signals.npz): silence, DC, tones, impulses,
+    a chirp, -90 dBFS noise, clipped PCM.  Also pins that the recipe still produces the input the fixture was made from."""
+    import signals as sig
+    g = golden["signals"]
+    x = sig.signal(name, sig.N_FRAMES).astype(np.float64)
+    assert x.sum() == g[f"{name}_x_sum"] and np.abs(x).sum() == g[f"{name}_x_abs"]
+    ham, kbd = orc.hamming_periodic(sig.W), orc.kbd_window(sig.W)
+    fb = orc.melfilterbank(sig.FS, sig.W, 128)
+    s = orc.stft(x, ham, sig.HOP)
+    close(s[: sig.W // 2 + 1], g[f"{name}_stft"])
+    close(orc.istft(s, ham, sig.HOP), g[f"{name}_istft"])
+    close(orc.melspectrogram(x, ham, sig.HOP, fb), g[f"{name}_mel"])
+    # the log of a band that holds nothing but the transform's round-off (DC, a tone exactly on a bin) is not reproducible to
+    # 1e-12 even between two float64 programs: hold the coefficients to what the reference's own rounding allows
+    ref = g[f"{name}_mfcc"]
+    floor = mfcc_floor(g[f"{name}_stft"], fb.toarray(), 20, 8.0, np.finfo(np.float64).eps)
+    assert excess(orc.mfcc(x, ham, sig.HOP, fb, 20), ref, TOL * np.abs(ref).max() + floor) <= 1.0
+    m = orc.mdct(x, kbd)
+    close(m, g[f"{name}_mdct"])
+    close(orc.imdct(m, kbd), g[f"{name}_imdct"])
+
+
+@pytest.mark.timeout(300)
+def test_signals_that_are_not_noise_cqt(golden):
+    import signals as sig
+    g = golden["signals"]
+    ck = orc.cqtkernel(sig.FS, 24, 55, 3520)
+    for name in sig.NAMES:
+        xq = sig.signal(name, sig.N_CQT).astype(np.float64)
+        assert xq.sum() == g[f"{name}_xq_sum"] and np.abs(xq).sum() == g[f"{name}_xq_abs"]
+        close(orc.cqtspectrogram(xq, sig.FS, 25, ck), g[f"{name}_cqt"])
+        close(orc.cqtchromagram(xq, sig.FS, 25, 24, ck), g[f"{name}_chroma"])

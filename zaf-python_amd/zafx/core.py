@@ -914,9 +914,9 @@ def _pcm_device_mono(plan, pcm):
 
 def _pcm_batch(plan, batch_fn, pcm, out):
     """A *_pcm_batch call: the chunked three-stream pipeline with integer uploads (Plan.run_host_pcm); plans the library runs in
-    float64 (windows outside the float32 kernels) normalise on the device and take the general path."""
+    float64 (windows outside the float32 kernels) normalise on the device and take the general path, `out` included."""
     if plan.f64:
-        return batch_fn(pcm_to_mono(pcm, plan.device))
+        return batch_fn(pcm_to_mono(pcm, plan.device), out)
     return plan.run_host_pcm(pcm, out=out)
 
 
@@ -924,37 +924,37 @@ def stft_pcm_batch(pcm, window_function, step_length, layout="FT", device=0, one
     """STFT of integer PCM clips (clips, frames[, channels]): wavread's x / 2^(bits-1) and the channel mean
     (zaf.py:1202, :65) run on the device in front of the transform; only 2-4 B per sample and channel cross PCIe."""
     plan = stft_plan(window_function, step_length, layout, device, onesided)
-    return _pcm_batch(plan, lambda x: stft_batch(x, window_function, step_length, layout, device, onesided), pcm, out)
+    return _pcm_batch(plan, lambda x, o: stft_batch(x, window_function, step_length, layout, device, onesided, out=o), pcm, out)
 
 
 def mdct_pcm_batch(pcm, window_function, layout="FT", device=0, out=None):
     """mdct_batch of integer PCM clips (see stft_pcm_batch)."""
     plan = mdct_plan(window_function, layout, device)
-    return _pcm_batch(plan, lambda x: mdct_batch(x, window_function, layout, device), pcm, out)
+    return _pcm_batch(plan, lambda x, o: mdct_batch(x, window_function, layout, device, out=o), pcm, out)
 
 
 def melspectrogram_pcm_batch(pcm, window_function, step_length, mel_filterbank, layout="FT", device=0, out=None):
     """melspectrogram_batch of integer PCM clips (see stft_pcm_batch): 2 bytes per sample up, 4 n_filters / hop down."""
     plan = mel_plan(window_function, step_length, mel_filterbank, None, layout, device)
-    return _pcm_batch(plan, lambda x: melspectrogram_batch(x, window_function, step_length, mel_filterbank, layout, device), pcm, out)
+    return _pcm_batch(plan, lambda x, o: melspectrogram_batch(x, window_function, step_length, mel_filterbank, layout, device, out=o), pcm, out)
 
 
 def mfcc_pcm_batch(pcm, window_function, step_length, mel_filterbank, number_coefficients, layout="FT", device=0, out=None):
     """mfcc_batch of integer PCM clips (see stft_pcm_batch)."""
     plan = mel_plan(window_function, step_length, mel_filterbank, number_coefficients, layout, device)
-    return _pcm_batch(plan, lambda x: mfcc_batch(x, window_function, step_length, mel_filterbank, number_coefficients, layout, device), pcm, out)
+    return _pcm_batch(plan, lambda x, o: mfcc_batch(x, window_function, step_length, mel_filterbank, number_coefficients, layout, device, out=o), pcm, out)
 
 
 def cqtspectrogram_pcm_batch(pcm, sampling_frequency, time_resolution, cqt_kernel, layout="FT", device=0, out=None):
     """cqtspectrogram_batch of integer PCM clips (see stft_pcm_batch)."""
     plan = cqt_plan(sampling_frequency, time_resolution, cqt_kernel, None, layout, device)
-    return _pcm_batch(plan, lambda x: cqtspectrogram_batch(x, sampling_frequency, time_resolution, cqt_kernel, layout, device), pcm, out)
+    return _pcm_batch(plan, lambda x, o: cqtspectrogram_batch(x, sampling_frequency, time_resolution, cqt_kernel, layout, device, out=o), pcm, out)
 
 
 def cqtchromagram_pcm_batch(pcm, sampling_frequency, time_resolution, octave_resolution, cqt_kernel, layout="FT", device=0, out=None):
     """cqtchromagram_batch of integer PCM clips (see stft_pcm_batch)."""
     plan = cqt_plan(sampling_frequency, time_resolution, cqt_kernel, int(octave_resolution), layout, device)
-    return _pcm_batch(plan, lambda x: cqtchromagram_batch(x, sampling_frequency, time_resolution, octave_resolution, cqt_kernel, layout, device), pcm, out)
+    return _pcm_batch(plan, lambda x, o: cqtchromagram_batch(x, sampling_frequency, time_resolution, octave_resolution, cqt_kernel, layout, device, out=o), pcm, out)
 
 
 def pcm_to_mono(pcm, device=0):

@@ -59,6 +59,7 @@ class Rendezvous:
             raise ValueError("bad rank / world_size")
         self.dir, self.rank, self.world, self.timeout = directory, int(rank), int(world_size), float(timeout)
         self.ns = str(namespace)   # prefix of every key: the files of an earlier job in a reused directory are never read
+        self.base_ns = self.ns     # (handshake() appends this launch's epoch to ns)
         self._seq = 0
         # private to this user: another local user must not be able to create the directory first and plant keys in it
         # (the RCCL unique id travels through here)
@@ -85,16 +86,78 @@ class Rendezvous:
         # -- unless the job names itself (ZAFX_RDZV_NS, or the launcher's TORCHELASTIC_RUN_ID): ranks started by hand or from
         # per-rank wrapper shells have different parents and would otherwise never see each other's keys
         ns = os.environ.get("ZAFX_RDZV_NS") or os.environ.get("TORCHELASTIC_RUN_ID")
-        if not ns or ns == "none":
+        named = bool(ns) and ns != "none"
+        if not named:
             ns = f"{os.getppid()}.{_start_time(os.getppid())}"
-        return cls(d, rank, world, timeout, namespace=ns + ".")
+        rv = cls(d, rank, world, timeout, namespace=ns + ".")
+        if named:
+            # a NAME comes back with every relaunch (an elastic restart keeps its run id): the keys of a job that died before
+            # close() are still there under it, so the ranks first agree on an epoch that only this launch knows
+            rv.handshake()
+        return rv
+
+    def _read(self, name):
+        try:
+            with open(os.path.join(self.dir, name), "rb") as f:
+                return f.read()
+        except FileNotFoundError:
+            return None
+
+    def handshake(self):
+        """Agree on a per-launch epoch under a namespace that earlier launches may have used: rank r publishes a
+        fresh nonce, rank 0 publishes a fresh epoch together with the nonces it has read, rank r accepts only an epoch file
+        that carries ITS nonce and acknowledges with the epoch, rank 0 waits until every acknowledgement carries ITS epoch.
+        Whatever an earlier launch left under the same names holds other random values and is never accepted; afterwards
+        every key is prefixed with the epoch."""
+        base, others = self.base_ns, range(1, self.world)
+        deadline = time.monotonic() + self.timeout
+
+        def wait(delay):
+            if time.monotonic() > deadline:
+                raise TimeoutError(f"rendezvous: rank {self.rank} waited {self.timeout:.0f} s for the handshake under '{base}' in {self.dir}")
+            time.sleep(delay)
+            return min(delay * 2, 0.02)
+
+        delay = 0.0005
+        if self.rank == 0:
+            epoch, seen = os.urandom(8).hex(), None
+            while self.world > 1:
+                nonces = [self._read(f"{base}hello_{r}") for r in others]
+                if all(n is not None for n in nonces):
+                    if nonces != seen:
+                        self._write(f"{base}epoch", b" ".join([epoch.encode()] + nonces))
+                        seen = nonces
+                    if all(self._read(f"{base}ack_{r}") == epoch.encode() for r in others):
+                        break
+                delay = wait(delay)
+        else:
+            nonce = os.urandom(8).hex().encode()
+            self._write(f"{base}hello_{self.rank}", nonce)
+            while True:
+                parts = (self._read(f"{base}epoch") or b"").split(b" ")
+                if len(parts) == self.world and parts[self.rank] == nonce:
+                    epoch = parts[0].decode()
+                    self._write(f"{base}ack_{self.rank}", parts[0])
+                    break
+                delay = wait(delay)
+        self.ns = f"{base}{epoch}."
 
     # ---- point to point -------------------------------------------------------------
-    def put(self, key, data):
-        tmp = os.path.join(self.dir, f".{self.ns}{key}.{self.rank}.tmp")
-        with open(tmp, "wb") as f:
+    def _write(self, name, data):
+        """Publish one file by an atomic rename; created private (0600) whatever the umask and the directory's mode are: the
+        RCCL unique id (bootstrap address + magic) travels through here and is no other local user's to read."""
+        tmp = os.path.join(self.dir, f".{name}.{self.rank}.tmp")
+        try:
+            os.unlink(tmp)
+        except FileNotFoundError:
+            pass
+        fd = os.open(tmp, os.O_WRONLY | os.O_CREAT | os.O_EXCL, 0o600)
+        with os.fdopen(fd, "wb") as f:
             f.write(bytes(data))
-        os.replace(tmp, os.path.join(self.dir, self.ns + key))
+        os.replace(tmp, os.path.join(self.dir, name))
+
+    def put(self, key, data):
+        self._write(self.ns + key, data)
 
     def get(self, key):
         path = os.path.join(self.dir, self.ns + key)
@@ -147,7 +210,8 @@ class Rendezvous:
         for r in range(1, self.world):
             self.get(f"bye_{r}")
         for name in os.listdir(self.dir):
-            if not (name.startswith(self.ns) or name.startswith("." + self.ns)):
+            # (base_ns: with a named namespace also what earlier launches of this name left behind -- one job per name at a time)
+            if not (name.startswith(self.base_ns) or name.startswith("." + self.base_ns)):
                 continue   # (another job's files in a shared directory)
             try:
                 os.unlink(os.path.join(self.dir, name))

@@ -116,7 +116,7 @@ def make_workload(kind, device, layout="FT"):
         fwd = zafx.stft_plan(zafx.hamming(4096), 2048, device=device)
         d_s = zafx.DeviceBuffer(fwd.out_shape(B, N), np.complex64, device)
         fwd.execute(d_x, d_s, B, N)
-        INNER_LOG.append({"kind": None, "kernel": fwd.kernel_name, "launches": 1})
+        INNER_LOG.append({"kind": None, "kernel": fwd.last_kernel, "launches": 1})
         fwd.sync()
         d_x.free()
         plan = zafx.istft_plan(zafx.hamming(4096), 2048, device=device)
@@ -149,7 +149,7 @@ def make_workload(kind, device, layout="FT"):
         fwd = zafx.stft_plan(ham, H, device=device, onesided=True)
         d_s = zafx.DeviceBuffer(fwd.out_shape(B, N), np.complex64, device)
         fwd.execute(d_x, d_s, B, N)
-        INNER_LOG.append({"kind": None, "kernel": fwd.kernel_name, "launches": 1})
+        INNER_LOG.append({"kind": None, "kernel": fwd.last_kernel, "launches": 1})
         fwd.sync()
         d_x.free()
         plan = zafx.istft_plan(ham, H, device=device, onesided=True)
@@ -159,7 +159,7 @@ def make_workload(kind, device, layout="FT"):
         fwd = zafx.stft_plan(ham, H, device=device)
         d_s = zafx.DeviceBuffer(fwd.out_shape(B, N), np.complex64, device)
         fwd.execute(d_x, d_s, B, N)
-        INNER_LOG.append({"kind": None, "kernel": fwd.kernel_name, "launches": 1})
+        INNER_LOG.append({"kind": None, "kernel": fwd.last_kernel, "launches": 1})
         fwd.sync()
         d_x.free()
         plan = zafx.istft_plan(ham, H, device=device)
@@ -177,7 +177,7 @@ def make_workload(kind, device, layout="FT"):
         fwd = zafx.mdct_plan(kbd, device=device)
         d_m = zafx.DeviceBuffer(fwd.out_shape(B, N), np.float32, device)
         fwd.execute(d_x, d_m, B, N)
-        INNER_LOG.append({"kind": None, "kernel": fwd.kernel_name, "launches": 1})
+        INNER_LOG.append({"kind": None, "kernel": fwd.last_kernel, "launches": 1})
         fwd.sync()
         d_x.free()
         plan = zafx.mdct_plan(kbd, device=device, inverse=True)
@@ -575,7 +575,7 @@ def roofline_of(wl, tm, kind):
     gbs = wl["bytes_per_launch"] / (kernel_ms * 1e-3) / 1e9
     roof = {"bound": "hbm", "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(gbs / HBM_PEAK_GBS, 4),
             "frac_of_achievable_6290": round(gbs / HBM_ACHIEVABLE_GBS, 4), "traffic": None,
-            "kernel": wl["plan"].kernel_name, "kernel_ms": round(kernel_ms, 4), "kernel_ms_min": round(tm["kernel_ms_min"], 4),
+            "kernel": wl["plan"].last_kernel, "kernel_ms": round(kernel_ms, 4), "kernel_ms_min": round(tm["kernel_ms_min"], 4),
             "kernel_ms_median": round(tm["kernel_ms_median"], 4), "algorithmic_bytes_per_launch": wl["bytes_per_launch"]}
     pmc = os.path.join(ROOT, "profiles", f"pmc_{kind}.json")
     if os.path.exists(pmc):   # a separate rocprofv3 --pmc collection of the same command, committed under profiles/
@@ -684,7 +684,7 @@ def run_kind(kind, args, device, rank, world, rdzv, comm, with_cpu):
     tm = time_workload(wl, args.steps, args.warmup, rdzv)
     tm["broadcast_s"] = bcast_s
     inner = os.environ.get("ZAFX_BENCH_INNER") == "1"
-    INNER_LOG.append({"kind": kind, "kernel": wl["plan"].kernel_name, "launches": sum(n for _, n in tm["segments"]), "segments": tm["segments"],
+    INNER_LOG.append({"kind": kind, "kernel": wl["plan"].last_kernel, "launches": sum(n for _, n in tm["segments"]), "segments": tm["segments"],
                       "kernel_ms": tm["kernel_ms"]})
     entry = None
     if rank == 0:

@@ -178,8 +178,13 @@ int zafx_run_host(zafx_plan* plan, const void* h_in, void* h_out, int64_t n_clip
 /* HIP-event stopwatch on the plan's stream (the stream the kernels run on). */
 int zafx_timer_start(zafx_plan* plan);
 int zafx_timer_stop(zafx_plan* plan, float* elapsed_ms);
-/* Name of the dominant kernel the plan launches (for matching rocprofv3 rows). */
+/* Name of the kernel family the plan was built for (fixed at zafx_plan_create / the last constant upload: the route a
+ * geometry is expected to take). */
 int zafx_plan_kernel_name(const zafx_plan* plan, char* buf, size_t buflen);
+/* Name of the dominant kernel the LAST zafx_execute / zafx_run_host of this plan really launched (for matching rocprofv3
+ * rows; the carry / band / generic forms are chosen per call from T, hop and the buffers' alignment); "" before the
+ * first execute. */
+int zafx_plan_last_kernel_name(const zafx_plan* plan, char* buf, size_t buflen);
 
 /* Largest number of rows (n_bins) of a CQT kernel matrix that a float32 ZAFX_CQT / ZAFX_CHROMA plan of this fft_length
  * holds (k_cqt keeps the frame and the rows' bookkeeping in the 160 KB of LDS); 0 when fft_length itself is outside the

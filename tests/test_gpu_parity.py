@@ -137,9 +137,12 @@ def test_mdct_w4096_two_bands(zafx, n, clips):
     the line grid, more tiles than workgroups, padded rows."""
     x = np.stack([synth_clip(43, c % 5, n) for c in range(clips)])
     w = zafx.kaiser_bessel_derived(4096)
-    assert zafx.mdct_plan(w).kernel_name in ("k_mdct_ft32b", "k_mdct_ft32bc", "k_mdct")   # (planned: the band form; after an execute: what ran)
+    assert zafx.mdct_plan(w).kernel_name == "k_mdct_ft32b"   # planned: the band family; what RAN depends on the call (last_kernel)
     ref = orc.mdct_batch(x[:5].astype(np.float64), w)
     got = zafx.mdct_batch(x, w)
+    T = got.shape[2]
+    # clips of a multiple of four samples ride the bands -- rows off the 64-byte grid on the carry form --, others the generic kernel
+    assert zafx.mdct_plan(w).last_kernel == ("k_mdct" if n % 4 else "k_mdct_ft32b" if T % 16 == 0 else "k_mdct_ft32bc"), (n, T)
     assert got.shape[1:] == ref.shape[1:] and got.dtype == np.float32
     for c in range(clips):
         assert relerr(got[c], ref[c % 5]) <= TOL_FFT, c
@@ -707,16 +710,21 @@ def test_stft_w4096_two_bands(zafx, hop, n, clips):
     x = np.stack([synth_clip(41, c, n) for c in range(clips)])
     w = zafx.hamming(4096)
     plan = zafx.stft_plan(w, hop)
-    assert plan.kernel_name in ("k_stft_ft16b", "k_stft_ft16bc", "k_stft")   # (planned: the band form; after an execute: what ran)
+    assert plan.kernel_name == "k_stft_ft16b"   # planned: the band family; what RAN depends on the call (last_kernel)
     ref = orc.stft_batch(x.astype(np.float64), w, hop)
     got = zafx.stft_batch(x, w, hop)
     assert got.shape == ref.shape and got.dtype == np.complex64
+    T = got.shape[2]
+    assert plan.last_kernel == ("k_stft_ft16b" if T % 16 == 0 else "k_stft_ft16bc"), (hop, n, T)   # complex rows off the line grid: the carry form
     for c in range(clips):
         assert relerr(got[c], ref[c]) <= TOL_FFT, c
     if clips <= 3:
         half = 2049
         one = zafx.stft_batch(x, w, hop, onesided=True)
+        # one-sided rows off the grid: the carry form from hop >= W/2 (it reads every sample twice), the generic kernel below
+        assert zafx.stft_plan(w, hop, onesided=True).last_kernel == ("k_stft_ft16b" if T % 16 == 0 else "k_stft_ft16bc" if 2 * hop >= 4096 else "k_stft"), (hop, T)
         mag = zafx.stft_batch(x, w, hop, onesided="magnitude")
+        assert zafx.stft_plan(w, hop, onesided="magnitude").last_kernel == "k_stft_ft16b"
         pw = zafx.stft_batch(x, w, hop, onesided="power")
         for c in range(clips):
             assert relerr(one[c], ref[c, :half]) <= TOL_FFT
@@ -738,8 +746,9 @@ def test_istft_w4096_two_bands(zafx, hop, n, clips):
     spec = spec + 0.05 * (rng.standard_normal(spec.shape) + 1j * rng.standard_normal(spec.shape))   # not Hermitian: the reference takes real(ifft(.))
     full = spec[np.arange(clips) % 5]
     got = zafx.istft_batch(full, w, hop)
-    # (the name is that of the kernel the last execute launched: the band form for hops that are multiples of 4 from 512 up)
-    assert zafx.istft_plan(w, hop).kernel_name == ("k_istft_ft16b" if hop % 4 == 0 and hop >= 512 else "k_istft")
+    # the band form for hops that are multiples of 4 from 512 up (odd row pitches: its 8-byte row pieces), the generic kernel otherwise
+    assert zafx.istft_plan(w, hop).kernel_name == "k_istft_ft16b"
+    assert zafx.istft_plan(w, hop).last_kernel == ("k_istft_ft16b" if hop % 4 == 0 and hop >= 512 else "k_istft"), hop
     for c in range(min(clips, 7)):
         ref = orc.istft(full[c], w, hop)
         assert got[c].shape == ref.shape and relerr(got[c], ref) <= TOL_FFT, c
@@ -996,6 +1005,55 @@ def test_magnitude_and_power_spectra(zafx, wl, hop, n):
                     assert relerr(got[c], want[c]) <= (2 * tol if kind == "power" else tol), (f64, layout, kind, c)
     with pytest.raises(ValueError):
         zafx.istft_batch(np.zeros((1, wl // 2 + 1, 4), np.complex64), w, hop, onesided="magnitude")
+
+
+@pytest.mark.parametrize("n,clips", [(1024 * 33, 3), (1024 * 49, 2), (1024 * 17, 5)])
+def test_spectrogram_kinds_on_rows_of_even_pitch(zafx, n, clips):
+    """|X| / |X|^2 at W = 2048 on k_mel2 with a row pitch that is even but not a multiple of 4 (T = 34, 50, 18: the 8-byte
+    row pieces of whole tiles, zafx_mel.hip), straight into a device array and into one that starts 8 bytes into an allocation
+    (16-byte pieces impossible there whatever T is)."""
+    import ctypes
+    x = np.stack([synth_clip(59, c, n) for c in range(clips)])
+    w = zafx.hamming(2048)
+    ref = np.abs(orc.stft_batch(x.astype(np.float64), w, 1024)[:, :1025])
+    T = ref.shape[2]
+    assert T % 4 == 2 and T >= 18
+    d_x = zafx.DeviceBuffer.from_host(x)
+    for kind, want in (("magnitude", ref), ("power", ref ** 2)):
+        plan = zafx.stft_plan(w, 1024, onesided=kind)
+        tol = 2 * TOL_FFT if kind == "power" else TOL_FFT
+        d_o = zafx.DeviceBuffer((clips * 1025 * T + 2,), np.float32)
+        for shift in (0, 2):      # floats: 0 and 8 bytes
+            d_o.fill_zero()
+            view = zafx.DeviceBuffer((clips, 1025, T), np.float32, _ptr_from_pool=ctypes.c_void_p(d_o.ptr.value + 4 * shift))
+            plan.execute(d_x, view, clips, n)
+            plan.sync()
+            view.ptr = ctypes.c_void_p()   # (a view, not an allocation: nothing to free)
+            assert plan.last_kernel == "k_mel2"
+            flat = d_o.download()
+            got = flat[shift:shift + clips * 1025 * T].reshape(clips, 1025, T)
+            assert not np.any(flat[:shift]) and not np.any(flat[shift + clips * 1025 * T:])   # nothing written outside the array
+            for c in range(clips):
+                assert relerr(got[c], want[c]) <= tol, (kind, shift, c)
+        d_o.free()
+    d_x.free()
+
+
+@pytest.mark.parametrize("dtype,channels", [(np.int16, 1), (np.int32, 2)])
+def test_run_host_pcm_on_a_dct_plan(zafx, dtype, channels):
+    """the ZAFX_DCT branch of zafx_run_host_pcm -- integer vectors normalised (zaf.py:1202) and averaged over their
+    channels (zaf.py:65) on the device, then zaf.dct type 2 (zaf.py:760-790) on the FFT core."""
+    n, rows = 1024, 37
+    rng = np.random.default_rng(61)
+    info = np.iinfo(dtype)
+    pcm = rng.integers(info.min, info.max, size=(rows, n, channels), endpoint=True).astype(dtype)
+    x = (pcm.astype(np.float64) / float(-info.min)).mean(axis=2)
+    plan = zafx.dct_plan(n, 2)
+    got = plan.run_host_pcm(pcm)
+    assert plan.last_kernel == "k_dct" and got.shape == (rows, n)
+    for r in (0, 1, rows - 1):
+        assert relerr(got[r], orc.dct(x[r], 2)) <= TOL_FFT
+    assert np.array_equal(got, plan.run_host_pcm(pcm, chunk_clips=5))   # the chunked pipeline: same numbers
 
 
 def test_concurrent_host_threads(zafx):

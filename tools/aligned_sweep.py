@@ -26,5 +26,5 @@ for wl in (128, 256, 512, 1024, 2048):
     pm = zafx.mdct_plan(kbd); Tm = pm.out_dims(n)[1]
     ms3, d_m = run(pm, d_x, n); by3 = B * n * 4 + d_m.nbytes
     pim = zafx.mdct_plan(kbd, inverse=True); ms4, d_z = run(pim, d_m, Tm); by4 = d_m.nbytes + d_z.nbytes
-    print(f"W={wl:5d} n={n} stft T={Ts} {ms:.3f} ms {by/ms/1e9:.2f} TB/s ({p.kernel_name}) | istft {ms2:.3f} {by2/ms2/1e9:.2f} | mdct T={Tm} {ms3:.3f} {by3/ms3/1e9:.2f} ({pm.kernel_name}) | imdct {ms4:.3f} {by4/ms4/1e9:.2f}", flush=True)
+    print(f"W={wl:5d} n={n} stft T={Ts} {ms:.3f} ms {by/ms/1e9:.2f} TB/s ({p.last_kernel}) | istft {ms2:.3f} {by2/ms2/1e9:.2f} | mdct T={Tm} {ms3:.3f} {by3/ms3/1e9:.2f} ({pm.last_kernel}) | imdct {ms4:.3f} {by4/ms4/1e9:.2f}", flush=True)
     for b in (d_x, d_s, d_y, d_m, d_z): b.free()

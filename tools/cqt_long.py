@@ -24,5 +24,5 @@ for f64 in (False, True):
     for _ in range(5):
         plan.execute(d_x, d_o, B, N)
     ms = plan.timer_stop() / 5
-    print("f64" if f64 else "f32", plan.kernel_name, f"{ms:.2f} ms for {B} clips x 30 s = {B * N / ms / 1e3:.0f} Msamples/s", flush=True)
+    print("f64" if f64 else "f32", plan.last_kernel, f"{ms:.2f} ms for {B} clips x 30 s = {B * N / ms / 1e3:.0f} Msamples/s", flush=True)
     d_x.free(); d_o.free()

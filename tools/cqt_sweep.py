@@ -23,5 +23,5 @@ for fs in (44100, 22050, 11025, 8000, 4000, 2000):
         plan.execute(d_x, d_o, B, n)
     ms = plan.timer_stop() / 5
     T = plan.out_dims(n)[1]
-    print(f"fs {fs:6d}  fft_length {ck.shape[1]:6d}  bins {ck.shape[0]:4d}  nnz {ck.nnz:6d}  T {T:4d}  {ms:8.3f} ms  {ms * 1e6 / (B * T):8.1f} ns/frame  ({plan.kernel_name})", flush=True)
+    print(f"fs {fs:6d}  fft_length {ck.shape[1]:6d}  bins {ck.shape[0]:4d}  nnz {ck.nnz:6d}  T {T:4d}  {ms:8.3f} ms  {ms * 1e6 / (B * T):8.1f} ns/frame  ({plan.last_kernel})", flush=True)
     d_x.free(); d_o.free()

@@ -34,11 +34,11 @@ for name, B, fwd, inv in (
     T = fwd.out_dims(n)[1]
     d_s = zafx.DeviceBuffer(fwd.out_shape(B, n), fwd.out_dtype)
     ms = timed(fwd, d_x, d_s, B, n)
-    txt = f"{name} f64: {B} clips {ms:.3f} ms = {B * n / ms / 1e6:.1f} Gsamples/s ({fwd.kernel_name})"
+    txt = f"{name} f64: {B} clips {ms:.3f} ms = {B * n / ms / 1e6:.1f} Gsamples/s ({fwd.last_kernel})"
     if inv is not None:
         d_y = zafx.DeviceBuffer(inv.out_shape(B, T), inv.out_dtype)
         ims = timed(inv, d_s, d_y, B, T)
-        txt += f" | inverse {ims:.3f} ms = {B * n / ims / 1e6:.1f} Gsamples/s ({inv.kernel_name})"
+        txt += f" | inverse {ims:.3f} ms = {B * n / ims / 1e6:.1f} Gsamples/s ({inv.last_kernel})"
         d_y.free()
     print(txt, flush=True)
     d_s.free()

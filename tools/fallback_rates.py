@@ -35,10 +35,10 @@ for name, fwd, inv in (
         ("istft W=2048 hop=100 (f64 kernels)", zafx.stft_plan(ham(2048), 100, f64=True), zafx.istft_plan(ham(2048), 100))):
     T = fwd.out_dims(n)[1]
     d_s = zafx.DeviceBuffer(fwd.out_shape(B, n), fwd.out_dtype)
-    txt = f"{name}: forward {timed(fwd, d_x, d_s, n):8.3f} ms ({fwd.kernel_name})"
+    txt = f"{name}: forward {timed(fwd, d_x, d_s, n):8.3f} ms ({fwd.last_kernel})"
     if inv is not None:
         d_y = zafx.DeviceBuffer(inv.out_shape(B, T), inv.out_dtype)
-        txt += f" | inverse {timed(inv, d_s, d_y, T):8.3f} ms ({inv.kernel_name})"
+        txt += f" | inverse {timed(inv, d_s, d_y, T):8.3f} ms ({inv.last_kernel})"
         d_y.free()
     print(txt, flush=True)
     d_s.free()

@@ -34,12 +34,12 @@ for hop in (1024, 512, 256, 441, 1000):
     d_s = zafx.DeviceBuffer((B, F, T), np.complex64)
     ms = timed(fwd, d_x, d_s, N)
     gb = B * (4 * N + 8 * F * T) / 1e9
-    line = f"hop {hop:5d} T {T:5d}: stft {ms:7.3f} ms {gb / ms:6.2f} TB/s ({fwd.kernel_name})"
+    line = f"hop {hop:5d} T {T:5d}: stft {ms:7.3f} ms {gb / ms:6.2f} TB/s ({fwd.last_kernel})"
     if hop <= W:
         inv = zafx.istft_plan(w, hop)
         d_y = zafx.DeviceBuffer((B, inv.out_dims(T)[0]), np.float32)
         ms = timed(inv, d_s, d_y, T)
-        line += f" | istft {ms:7.3f} ms {gb / ms:6.2f} TB/s ({inv.kernel_name})"
+        line += f" | istft {ms:7.3f} ms {gb / ms:6.2f} TB/s ({inv.last_kernel})"
         d_y.free()
     mel = zafx.mel_plan(w, hop, fb)
     d_m = zafx.DeviceBuffer((B,) + tuple(mel.out_dims(N)), np.float32)

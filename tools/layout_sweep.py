@@ -36,10 +36,10 @@ for layout in ("FT", "TF"):
             ("chroma", zafx.cqt_plan(44100, 25, ck, 24, layout=layout), None)):
         T = fwd.out_dims(n)[1]
         d_s = zafx.DeviceBuffer(fwd.out_shape(B, n), fwd.out_dtype)
-        txt = f"{name} {timed(fwd, d_x, d_s, n):.3f} ({fwd.kernel_name})"
+        txt = f"{name} {timed(fwd, d_x, d_s, n):.3f} ({fwd.last_kernel})"
         if inv is not None:
             d_y = zafx.DeviceBuffer(inv.out_shape(B, T), inv.out_dtype)
-            txt += f" inv {timed(inv, d_s, d_y, T):.3f} ({inv.kernel_name})"
+            txt += f" inv {timed(inv, d_s, d_y, T):.3f} ({inv.last_kernel})"
             d_y.free()
         d_s.free()
         row.append(txt)

@@ -33,7 +33,7 @@ for wl in (128, 256, 512, 1024, 2048, 4096, 8192):
         T = fwd.out_dims(N)[1]
         ims, _ = run(zafx.istft_plan(ham, wl // 2, layout=layout), d_s, T)
         gb = B * (4 * N + 8 * wl * T) / 1e9
-        row.append(f"stft[{layout}] {ms:6.3f} ms {gb / ms:5.2f} TB/s {fwd.kernel_name:12s} istft {ims:6.3f} ms {gb / ims:5.2f} TB/s")
+        row.append(f"stft[{layout}] {ms:6.3f} ms {gb / ms:5.2f} TB/s {fwd.last_kernel:12s} istft {ims:6.3f} ms {gb / ims:5.2f} TB/s")
         d_s.free()
     m = zafx.mdct_plan(kbd)
     ms, d_m = run(m, d_x, N)

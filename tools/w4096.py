@@ -44,7 +44,7 @@ def main():
                     rate(plan, d_in, d_out, n, reps=4)
                 ms = rate(plan, d_in, d_out, n)
                 nbytes = B * n * 4 + d_out.nbytes
-                print(f"n {n} W {wl} hop {hop} {str(kw):28s} {plan.kernel_name:14s} T {shape[-1]:4d}: {ms:7.3f} ms  {nbytes / ms / 1e9:6.2f} TB/s", flush=True)
+                print(f"n {n} W {wl} hop {hop} {str(kw):28s} {plan.last_kernel:14s} T {shape[-1]:4d}: {ms:7.3f} ms  {nbytes / ms / 1e9:6.2f} TB/s", flush=True)
                 d_out.free()
         for wl, hop in ((2048, 1024), (4096, 2048), (4096, 1024), (8192, 4096)):
             fb = zafx.melfilterbank(44100, wl, 128)
@@ -53,7 +53,7 @@ def main():
                 d_out = zafx.DeviceBuffer(plan.out_shape(B, n), plan.out_dtype)
                 rate(plan, d_in, d_out, n, reps=20)
                 ms = rate(plan, d_in, d_out, n)
-                print(f"n {n} W {wl} hop {hop} {'mfcc' if ncoef else 'mel ':28s} {plan.kernel_name:14s}: {ms:7.3f} ms  {B * n / ms / 1e6:7.1f} Gsamples/s", flush=True)
+                print(f"n {n} W {wl} hop {hop} {'mfcc' if ncoef else 'mel ':28s} {plan.last_kernel:14s}: {ms:7.3f} ms  {B * n / ms / 1e6:7.1f} Gsamples/s", flush=True)
                 d_out.free()
         for wl in (2048, 4096, 8192):
             kbd = zafx.kaiser_bessel_derived(wl)
@@ -63,10 +63,10 @@ def main():
             d_y = zafx.DeviceBuffer(inv.out_shape(B, T), inv.out_dtype)
             rate(fwd, d_in, d_c, n, reps=20)
             ms = rate(fwd, d_in, d_c, n)
-            print(f"n {n} W {wl} mdct  {fwd.kernel_name:14s} T {T}: {ms:7.3f} ms  {(B * n * 4 + d_c.nbytes) / ms / 1e9:6.2f} TB/s", flush=True)
+            print(f"n {n} W {wl} mdct  {fwd.last_kernel:14s} T {T}: {ms:7.3f} ms  {(B * n * 4 + d_c.nbytes) / ms / 1e9:6.2f} TB/s", flush=True)
             rate(inv, d_c, d_y, T, reps=20)
             ms = rate(inv, d_c, d_y, T)
-            print(f"n {n} W {wl} imdct {inv.kernel_name:14s} T {T}: {ms:7.3f} ms  {(d_y.nbytes + d_c.nbytes) / ms / 1e9:6.2f} TB/s", flush=True)
+            print(f"n {n} W {wl} imdct {inv.last_kernel:14s} T {T}: {ms:7.3f} ms  {(d_y.nbytes + d_c.nbytes) / ms / 1e9:6.2f} TB/s", flush=True)
             d_c.free(); d_y.free()
         for wl, hop in ((2048, 1024), (4096, 2048), (4096, 1024), (8192, 4096)):
             fwd, inv = zafx.stft_plan(zafx.hamming(wl), hop), zafx.istft_plan(zafx.hamming(wl), hop)
@@ -76,7 +76,7 @@ def main():
             fwd.execute(d_in, d_c, B, n)
             rate(inv, d_c, d_y, T, reps=20)
             ms = rate(inv, d_c, d_y, T)
-            print(f"n {n} W {wl} hop {hop} istft {inv.kernel_name:14s} T {T}: {ms:7.3f} ms  {(d_y.nbytes + d_c.nbytes) / ms / 1e9:6.2f} TB/s", flush=True)
+            print(f"n {n} W {wl} hop {hop} istft {inv.last_kernel:14s} T {T}: {ms:7.3f} ms  {(d_y.nbytes + d_c.nbytes) / ms / 1e9:6.2f} TB/s", flush=True)
             d_c.free(); d_y.free()
         d_in.free()
 

@@ -1422,7 +1422,14 @@ int zafx_cqt_max_bins(int fft_length, int* n_bins) {
 
 int zafx_plan_kernel_name(const zafx_plan* pl, char* buf, size_t buflen) {
     if (!pl || !buf || !buflen) return fail_msg("null argument");
-    std::snprintf(buf, buflen, "%s", pl->ran ? pl->ran : pl->kernel_name.c_str());
+    std::snprintf(buf, buflen, "%s", pl->kernel_name.c_str());
+    return 0;
+}
+
+int zafx_plan_last_kernel_name(const zafx_plan* pl, char* buf, size_t buflen) {
+    if (!pl || !buf || !buflen) return fail_msg("null argument");
+    const char* ran = pl->ran.load(std::memory_order_acquire);
+    std::snprintf(buf, buflen, "%s", ran ? ran : "");
     return 0;
 }
 

@@ -4,6 +4,7 @@
 #include <hip/hip_runtime.h>
 
 #include <cstdint>
+#include <atomic>
 #include <string>
 #include <vector>
 
@@ -165,7 +166,7 @@ struct zafx_plan {
     std::vector<zafx::cf32> h_values;
 
     std::string kernel_name;            // the kernel this plan is expected to run (set at creation)
-    mutable const char* ran = nullptr;  // the kernel the last execute really launched (routes depend on T, alignment and hop)
+    mutable std::atomic<const char*> ran{nullptr};  // the kernel the last execute really launched (routes depend on T, alignment and hop); zafx_plan_last_kernel_name
 };
 
 namespace zafx {

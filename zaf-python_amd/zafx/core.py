@@ -353,9 +353,18 @@ class Plan:
 
     @property
     def kernel_name(self):
+        """The kernel family the plan was built for (does not change with the calls)."""
         buf = ctypes.create_string_buffer(128)
         _lib.check(_lib.load().zafx_plan_kernel_name(self.handle, buf, 128), "zafx_plan_kernel_name")
         return buf.value.decode()
+
+    @property
+    def last_kernel(self):
+        """The kernel the last execute / run_host really launched (carry, band and generic forms are chosen per call);
+        the planned name before the first one."""
+        buf = ctypes.create_string_buffer(128)
+        _lib.check(_lib.load().zafx_plan_last_kernel_name(self.handle, buf, 128), "zafx_plan_last_kernel_name")
+        return buf.value.decode() or self.kernel_name
 
     def clip_bytes(self, n_in):
         """(input bytes, output bytes) of ONE clip for `n_in` (zafx_plan_clip_bytes; rows at the plan's pitch)."""

@@ -85,5 +85,5 @@ for wv in waves:
     plan.sync()
     fn(out)
     per_tile = reps * (16 if kind == 'cqt' else tiles * B / 256)   # cqt: workgroup 7 = 16 frames per launch, counts are per frame
-    print(kind, f"wave {wv}: cycles per tile between marks:", " | ".join(f"{i}:{out[i] / per_tile:.0f}" for i in range(10)),
+    print(kind, f"wave {wv}: cycles per tile between marks:", " | ".join(f"{i}:{out[i] / per_tile:.0f}" for i in range(12)),
           "| total", round(sum(out) / per_tile))

@@ -43,8 +43,16 @@ __device__ __forceinline__ zafx_v2f to_v2(float2 a) { return __builtin_bit_cast(
 __device__ __forceinline__ float2 to_f2(zafx_v2f a) { return __builtin_bit_cast(float2, a); }
 #define ZAFX_PK 1
 #endif
+// Sums and differences as <2 x float> values: v_pk_add_f32 by construction.  Written component-wise, the compiler's SLP pass pairs
+// the x parts of two DIFFERENT points now and then -- four v_mov to gather them and two scalar additions behind, where one packed
+// addition does (round 5: 127 scalar f32 operations and ~40 such v_mov per frame in k_mel2).
+#if defined(ZAFX_PK)
+ZAFX_HD float2 cadd(float2 a, float2 b) { return to_f2(to_v2(a) + to_v2(b)); }
+ZAFX_HD float2 csub(float2 a, float2 b) { return to_f2(to_v2(a) - to_v2(b)); }
+#else
 ZAFX_HD float2 cadd(float2 a, float2 b) { return make_float2(a.x + b.x, a.y + b.y); }
 ZAFX_HD float2 csub(float2 a, float2 b) { return make_float2(a.x - b.x, a.y - b.y); }
+#endif
 ZAFX_HD float2 cmul(float2 a, float2 b) {
 #if defined(ZAFX_PK)
     zafx_v2f r;   // (a.x b.x, a.x b.y), then + (-a.y b.y, a.y b.x)
@@ -109,7 +117,11 @@ ZAFX_HD float2 sub_mi(float2 a, float2 b) {   // a - (-i) b = (a.x - b.y, a.y + 
     return make_float2(a.x - b.y, a.y + b.x);
 #endif
 }
+#if defined(ZAFX_PK)
+ZAFX_HD float2 cscale(float2 a, float s) { return to_f2(to_v2(a) * s); }
+#else
 ZAFX_HD float2 cscale(float2 a, float s) { return make_float2(a.x * s, a.y * s); }
+#endif
 ZAFX_HD float2 cadd_conj(float2 a, float2 b) {   // a + conj(b)
 #if defined(ZAFX_PK)
     zafx_v2f r;
@@ -133,8 +145,14 @@ ZAFX_HD float2 csub_conj(float2 a, float2 b) {   // a - conj(b)
 ZAFX_HD void split_pair(float2 zk, float2 zn, float2 tk, float2& xk, float2& xn) {
     const float2 e = cadd_conj(zk, zn), u = cmul(csub_conj(zk, zn), tk);
     const float2 a = add_mi(e, u), b = sub_mi(e, u);
+#if defined(ZAFX_PK)
+    const zafx_v2f hk = {0.5f, 0.5f}, hn = {0.5f, -0.5f};
+    xk = to_f2(to_v2(a) * hk);
+    xn = to_f2(to_v2(b) * hn);
+#else
     xk = make_float2(0.5f * a.x, 0.5f * a.y);
     xn = make_float2(0.5f * b.x, -0.5f * b.y);
+#endif
 }
 
 // The same pair when only |X[k]|^2 and |X[N-k]|^2 are wanted (k_mel): returns (4 |X[k]|^2, 4 |X[N-k]|^2).  a = E' - i U, b = E' + i U
@@ -224,6 +242,16 @@ ZAFX_HD void dft4(float2& v0, float2& v1, float2& v2, float2& v3) {
     v3 = sub_mi(t1, t3);
 }
 
+// dft4 of (v0, v1, -i v2, v3): the rotation of v2 rides in the first two butterflies
+ZAFX_HD void dft4_v2mi(float2& v0, float2& v1, float2& v2, float2& v3) {
+    float2 t0 = add_mi(v0, v2), t1 = sub_mi(v0, v2);
+    float2 t2 = cadd(v1, v3), t3 = csub(v1, v3);
+    v0 = cadd(t0, t2);
+    v1 = add_mi(t1, t3);
+    v2 = csub(t0, t2);
+    v3 = sub_mi(t1, t3);
+}
+
 template <int R>
 struct Dft;
 template <>
@@ -270,14 +298,15 @@ struct Dft<16> {
         m[1][2] = cmulk(m[1][2], h, -h);      // w^2
         m[1][3] = cmulk(m[1][3], s1, -c1);    // w^3
         m[2][1] = cmulk(m[2][1], h, -h);      // w^2
-        m[2][2] = mul_mi(m[2][2]);            // w^4
+        // m[2][2] * w^4 = -i m[2][2]: folded into the butterflies of q = 2 below (no swap of its parts in registers)
         m[2][3] = cmulk(m[2][3], -h, -h);     // w^6
         m[3][1] = cmulk(m[3][1], s1, -c1);    // w^3
         m[3][2] = cmulk(m[3][2], -h, -h);     // w^6
         m[3][3] = cmulk(m[3][3], -c1, s1);    // w^9
 #pragma unroll
         for (int q = 0; q < 4; ++q) {   // 4-point DFTs over r; output k = q + 4 s
-            dft4(m[0][q], m[1][q], m[2][q], m[3][q]);
+            if (q == 2) dft4_v2mi(m[0][q], m[1][q], m[2][q], m[3][q]);
+            else dft4(m[0][q], m[1][q], m[2][q], m[3][q]);
             a[q] = m[0][q]; a[q + 4] = m[1][q]; a[q + 8] = m[2][q]; a[q + 12] = m[3][q];
         }
     }
@@ -306,7 +335,12 @@ struct Dft<32> {
                               0.55557023301960222474f, 0.38268343236508977173f, 0.19509032201612826785f};
 #pragma unroll
         for (int k = 0; k < 16; ++k) {
-            const float2 t = k == 0 ? o[0] : (k == 8 ? mul_mi(o[8]) : cmulk(o[k], c[k], -sn[k]));
+            if (k == 8) {   // w32^8 = -i: in the butterfly
+                a[k] = add_mi(e[k], o[k]);
+                a[k + 16] = sub_mi(e[k], o[k]);
+                continue;
+            }
+            const float2 t = k == 0 ? o[0] : cmulk(o[k], c[k], -sn[k]);
             a[k] = cadd(e[k], t);
             a[k + 16] = csub(e[k], t);
         }
@@ -548,6 +582,14 @@ __device__ __forceinline__ void lane_row_transpose4(float& x0, float& x1, float&
         : "+v"(x0), "+v"(x1), "+v"(x2), "+v"(x3));
 }
 
+// The same transpose on both parts of four complex registers in one block: the four v_permlane32_swap stand between every register's
+// VALU write and its v_permlane16_swap, so one leading s_nop serves all eight swaps (two blocks of lane_row_transpose4 carry four).
+__device__ __forceinline__ void lane_row_transpose4(float2& c0, float2& c1, float2& c2, float2& c3) {
+    asm("s_nop 1\n\tv_permlane32_swap_b32 %0, %2\n\tv_permlane32_swap_b32 %1, %3\n\tv_permlane32_swap_b32 %4, %6\n\tv_permlane32_swap_b32 %5, %7\n\t"
+        "v_permlane16_swap_b32 %0, %1\n\tv_permlane16_swap_b32 %2, %3\n\tv_permlane16_swap_b32 %4, %5\n\tv_permlane16_swap_b32 %6, %7"
+        : "+v"(c0.x), "+v"(c1.x), "+v"(c2.x), "+v"(c3.x), "+v"(c0.y), "+v"(c1.y), "+v"(c2.y), "+v"(c3.y));
+}
+
 // Lane pairs that share 16-byte loads, paired across 16-lane rows: lane l of an even row and lane l + 16 take the points
 // n and n + 1 (mod 64), so that one v_permlane16_swap per register hands each its own (row_pair_unpack).  Every 32 lanes
 // still hold 32 consecutive residues: the radix-16 outputs of pass 1 (slot 17 p1 + r) spread over all banks.
@@ -672,10 +714,7 @@ __device__ __forceinline__ void fft1024_wave(float2* v, float2* buf, int lane, c
     }
     Dft<16>::run(a);
 #pragma unroll
-    for (int rh = 0; rh < 4; ++rh) {
-        lane_row_transpose4(a[4 * rh].x, a[4 * rh + 1].x, a[4 * rh + 2].x, a[4 * rh + 3].x);
-        lane_row_transpose4(a[4 * rh].y, a[4 * rh + 1].y, a[4 * rh + 2].y, a[4 * rh + 3].y);
-    }
+    for (int rh = 0; rh < 4; ++rh) lane_row_transpose4(a[4 * rh], a[4 * rh + 1], a[4 * rh + 2], a[4 * rh + 3]);
 #pragma unroll
     for (int b = 0; b < 4; ++b)   // register 4 b + r' now holds position lane + 64 b + 256 r': pass 3 reads v[b + 4 r']
 #pragma unroll

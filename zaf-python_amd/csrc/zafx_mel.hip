@@ -620,13 +620,15 @@ __global__ __launch_bounds__(1024, 1) void k_mel2(const float* __restrict__ x, c
     __syncthreads();
 
     // ---- samples of the wave's frame of tile `tlv` (k_mel's pair form: 16-byte loads shared by the lanes l and l + 16 of a row pair)
+    PROF_INIT(g_prof_mel);
+    // xr[2 i], xr[2 i + 1]: the two points (n, n + 1), n = (p & ~1) + 512 (p & 1) + 64 i, of one 16-byte load -- also where the frame touches
+    // the clip's ends and the samples come one by one: ONE register arrangement into the transform (a second one, chosen at run time,
+    // cost ~50 v_mov per frame where the two paths meet; round 5)
     float2 xr[E];
     __amdgpu_buffer_rsrc_t frx = make_rsrc(x, 0);
-    bool raw = false;
-    // (a request past the last tile repeats the last one: xr, like the fragments below, is defined on EVERY path of every iteration -- left
-    // conditional, the old values count as live through the transform and its registers spill)
+    // (a request past the last tile repeats the last one: xr is defined on EVERY path of every iteration -- left conditional, the old values
+    // count as live through the transform and its registers spill)
     auto request = [&](int tlv, int lane) {   // lane: an opaque copy
-        raw = false;
         tlv = min(tlv, total_tiles - 1);
         const int p = row_pair_index(lane);
         const int tl = xcd ? xcd_order(tlv, total_tiles) : tlv;
@@ -643,12 +645,12 @@ __global__ __launch_bounds__(1024, 1) void k_mel2(const float* __restrict__ x, c
                 xr[2 * i] = make_float2(q.x, q.y);
                 xr[2 * i + 1] = make_float2(q.z, q.w);
             }
-            raw = true;
             return;
         }
+        const int nb = (p & ~1) + (p & 1) * (E / 2 * P);
 #pragma unroll
         for (int i = 0; i < E; ++i) {   // a frame that touches the clip's ends or lies past its last frame: zero padding (zaf.py:112-125)
-            const long long s = s0 + 2 * (p + i * P);
+            const long long s = s0 + 2 * (nb + (i >> 1) * P + (i & 1));
             xr[i].x = (t < T && s >= 0 && s < n_samples) ? xc[s] : 0.f;
             xr[i].y = (t < T && s + 1 >= 0 && s + 1 < n_samples) ? xc[s + 1] : 0.f;
         }
@@ -657,23 +659,17 @@ __global__ __launch_bounds__(1024, 1) void k_mel2(const float* __restrict__ x, c
     auto transform = [&](int lane, float (&mk)[E / 2], float (&mn)[E / 2], float& dc) {   // dc (SPECM, lane 0): 4 |X[0]|^2 or its root
         float2* ex = frames + wave * PITCH + EXOFF;
         const int p1 = row_pair_index(lane);
-        if (raw) {
-            float2 lo[E / 2], hi[E / 2];
-#pragma unroll
-            for (int i = 0; i < E / 2; ++i) {
-                lo[i] = xr[2 * i];
-                hi[i] = xr[2 * i + 1];
-                row_pair_unpack(lo[i], hi[i]);
-            }
-#pragma unroll
-            for (int i = 0; i < E / 2; ++i) {
-                xr[i] = lo[i];
-                xr[i + E / 2] = hi[i];
-            }
-        }
         float2 v[E];
 #pragma unroll
-        for (int i = 0; i < E; ++i) v[i] = mul_elem(xr[i], win_s[lane + i * P]);
+        for (int i = 0; i < E / 2; ++i) {   // the lane's own points i and i + 8 out of the pair's two loads
+            row_pair_unpack(xr[2 * i], xr[2 * i + 1]);
+            v[i] = mul_elem(xr[2 * i], win_s[lane + i * P]);
+            v[i + E / 2] = mul_elem(xr[2 * i + 1], win_s[lane + (i + E / 2) * P]);
+        }
+#ifdef ZAFX_PROF
+        asm volatile("" :: "v"(v[0].x), "v"(v[15].y));
+        PROF_MARK(10);
+#endif
         Dft<16>::run(v);
         // first exchange, two rounds: position 16 p1 + r, r < 8 then r >= 8, at slot 8 p1 + (p1 >> 1) + (r & 7); lane (lh, ll) reads
         // position lane + 64 i = 16 (lh + 4 i) + ll in the round that holds r = ll
@@ -697,6 +693,7 @@ __global__ __launch_bounds__(1024, 1) void k_mel2(const float* __restrict__ x, c
             for (int i = 0; i < E; ++i) u[i] = ex[rb + 34 * i];
         }
         frame_sync<64>();
+        PROF_MARK(6);
         float2 a[E];
         {
             float2 w[E];
@@ -708,9 +705,9 @@ __global__ __launch_bounds__(1024, 1) void k_mel2(const float* __restrict__ x, c
         Dft<16>::run(a);
 #pragma unroll
         for (int rh = 0; rh < 4; ++rh) {
-            lane_row_transpose4(a[4 * rh].x, a[4 * rh + 1].x, a[4 * rh + 2].x, a[4 * rh + 3].x);
-            lane_row_transpose4(a[4 * rh].y, a[4 * rh + 1].y, a[4 * rh + 2].y, a[4 * rh + 3].y);
+            lane_row_transpose4(a[4 * rh], a[4 * rh + 1], a[4 * rh + 2], a[4 * rh + 3]);
         }
+        PROF_MARK(7);
         // pass 3 in registers: z[b][r] = Z[lane + 64 b + 256 r]  (register 4 b + r' holds position lane + 64 b + 256 r')
         float2 z[4][4];
         const float2* t3 = (const float2*)tw_l + twiddle_offset(10, 4, 8);
@@ -729,6 +726,7 @@ __global__ __launch_bounds__(1024, 1) void k_mel2(const float* __restrict__ x, c
 #pragma unroll
             for (int r = 2; r < 4; ++r) ex[phys_off<64>(pq, lane, 64 * b + 256 * (r - 2))] = z[b][r];
         frame_sync<64>();
+        PROF_MARK(8);
 #pragma unroll
         for (int i = 0; i < E / 2; ++i) {
             const int k = lane + i * P;
@@ -749,6 +747,7 @@ __global__ __launch_bounds__(1024, 1) void k_mel2(const float* __restrict__ x, c
             mn[i] = SQUARES ? pw.y : __builtin_amdgcn_sqrtf(pw.y);
         }
         frame_sync<64>();
+        PROF_MARK(9);
     };
     auto put_levels = [&](int lane, const float (&mk)[E / 2], const float (&mn)[E / 2], float dc) {   // S[c], c = bin - 1, into the lower half of the wave's buffer
         float* sf = reinterpret_cast<float*>(frames + wave * PITCH);
@@ -824,6 +823,7 @@ __global__ __launch_bounds__(1024, 1) void k_mel2(const float* __restrict__ x, c
     // (Measured and dropped, profiles/r04_notes.md: fragments requested a chunk or a whole tile ahead, items of <= 24 steps on every
     // wave with the partial tiles through L2, items on eight waves only -- each lost more to registers or to sixteen matrix-instruction
     // chains starting together than it gained on the 9 k cycles the longest item waits for L2 here.)
+    const __amdgpu_buffer_rsrc_t fbr = make_rsrc(fb_pack, 0xfffffffcu);
     auto product = [&](int lane) {
         const float* sb = fall + (size_t)(lane & 15) * (2 * PITCH) + (lane >> 4);
 #pragma unroll
@@ -831,15 +831,19 @@ __global__ __launch_bounds__(1024, 1) void k_mel2(const float* __restrict__ x, c
             acc[j][0] = acc[j][1] = f32x4v{0.f, 0.f, 0.f, 0.f};
             const int steps = it_steps[j];
             if (steps <= 0) continue;
-            const float* ap = fb_pack + (size_t)it_off[j] * 64 + lane;
+            // A fragments: buffer loads, the step in the scalar offset (no 64-bit address per lane and load); B: the levels of LDS at immediate
+            // offsets from one address per chunk.  Past the item's last step both read on (the next item's fragments, the frame buffer behind S):
+            // never multiplied.
             const float* bp = sb + it_first[j];
+            // (chunks of 16 or 32 steps -- fewer round trips to L2 -- are slower: 0.92 against 0.91 ms, and 4.3 ms with 32 loads per wave in the
+            // vector-memory queue; profiles/r05_notes.md)
             for (int s0 = 0; s0 < steps; s0 += 8) {
                 float a[8], b[8];
+                const float* bq = bp + 4 * s0;
 #pragma unroll
                 for (int u = 0; u < 8; ++u) {
-                    const int st = min(s0 + u, steps - 1);   // (past the last step: the last one again, not multiplied)
-                    a[u] = ap[(size_t)st * 64];
-                    b[u] = bp[4 * st];
+                    a[u] = buf_load_f32(fbr, lane * 4, (it_off[j] + min(s0 + u, steps - 1)) * 256);
+                    b[u] = bq[4 * u];
                 }
 #pragma unroll
                 for (int u = 0; u < 8; ++u)
@@ -889,31 +893,33 @@ __global__ __launch_bounds__(1024, 1) void k_mel2(const float* __restrict__ x, c
         request(tlv + gridDim.x, lane);
         lds_barrier();
     }
-    PROF_INIT(g_prof_mel);
-    for (; tlv < total_tiles; tlv += gridDim.x) {
+    // One tile.  HAS_NEXT is a compile-time flag: the workgroup's last tile is peeled off below, so the transform of the loop body is
+    // unconditional -- no run-time test around it, no levels zero-initialised for the path that skips it (16 v_mov per frame, round 5).
+    auto tile_body = [&](auto has_next_c) {
+        constexpr bool has_next = decltype(has_next_c)::value;
         PROF_MARK(0);
         int lane = tid & 63;
         asm volatile("" : "+v"(lane));   // (per-lane addresses are recomputed per tile, not carried through the transform)
-        const bool has_next = tlv + gridDim.x < total_tiles;
-        if constexpr (SPECM) store_rows(tlv);   // (behind the wave's own transform instead: the same on the line grid, 7 % slower off it)
-        else product(lane);
 #ifndef ZAFX_MEL2_EARLYOUT
 #define ZAFX_MEL2_EARLYOUT 1
 #endif
+        float mk[E / 2], mn[E / 2], dc = 0.f;
+        // (the transform first and the product behind it: 0.98 against 0.91 ms; profiles/r05_notes.md)
+        if constexpr (SPECM) store_rows(tlv);   // (behind the wave's own transform instead: the same on the line grid, 7 % slower off it)
+        else product(lane);
         if constexpr (!SPECM && (MFCC || ZAFX_MEL2_EARLYOUT)) hand_over(lane);
         PROF_MARK(1);
-        float mk[E / 2] = {}, mn[E / 2] = {}, dc = 0.f;
-        if (has_next) transform(lane, mk, mn, dc);
+        if constexpr (has_next) transform(lane, mk, mn, dc);
         // the frame after that: requested by each wave as soon as ITS transform is done -- the waves finish thousands of cycles apart, so
         // the sixteen bursts of eight loads arrive spread out (all at once they overrun the CU's vector-memory queue: 2.5-5 k cycles blocked)
-        request(tlv + 2 * gridDim.x, lane);
+        if constexpr (has_next) request(tlv + 2 * gridDim.x, lane);
         PROF_MARK(2);
         lds_barrier();   // nobody reads the current levels any more; every transform is done with its exchange area
         PROF_MARK(3);
-        if (has_next) put_levels(lane, mk, mn, dc);
+        if constexpr (has_next) put_levels(lane, mk, mn, dc);
         if constexpr (SPECM) {
             lds_barrier();   // the next tile's levels are in LDS
-            continue;
+            return;
         }
         if constexpr (!MFCC && !ZAFX_MEL2_EARLYOUT) hand_over(lane);
         PROF_MARK(4);
@@ -924,7 +930,7 @@ __global__ __launch_bounds__(1024, 1) void k_mel2(const float* __restrict__ x, c
         float* exf = reinterpret_cast<float*>(frames + wave * PITCH + EXOFF);   // (MFCC) this wave's exchange area: free until the barrier that ends the tile
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
-            if (it_steps[j] < 0 || ((it_code[j] >> 8) & 3) != 1) continue;
+            if (it_steps[j] < 0 || ((it_code[j] >> 8) & 3) != 1) continue;   // (the item loop's own continue)
             const int blk = it_code[j] & 255, mask = (it_code[j] >> 12) & 7;
             float val[4];
 #pragma unroll
@@ -984,7 +990,9 @@ __global__ __launch_bounds__(1024, 1) void k_mel2(const float* __restrict__ x, c
             }
             lds_barrier();   // the exchange areas are free for the next transforms
         }
-    }
+    };
+    for (; tlv + (int)gridDim.x < total_tiles; tlv += gridDim.x) tile_body(std::true_type{});
+    tile_body(std::false_type{});
 }
 
 template <int LOG2N, bool ALIGNED>

@@ -437,6 +437,23 @@ ZAFX_HD void pass_write_chain(const float2* v, float2* buf, int p, const TwoLeve
     }
 }
 
+// One 8-byte LDS read that STAYS one.  Left alone, the compiler pairs neighbouring ds_read_b64 of one base register into ds_read2_b64 /
+// ds_read2st64_b64, which the LDS serves at 128 B/clk where two single reads get 256 (tools/exp_lds2.hip, round 5: 4.0 against 2.04 cycles
+// per 512 bytes with sixteen waves reading; the guide's LDS table says the same).  A volatile access is never paired; the waits stay the compiler's.
+// Used where it was measured to pay (k_mel2's transform: mfcc 0.99 -> 0.94 ms, mel unchanged); in regs_read and the wave-local 1024-point core
+// it is neutral for the HBM-bound kernels and costs k_cqt 1.6 % (24.02 -> 24.40 ms: twice the DS instructions to issue), so they keep the pairs.
+#ifndef ZAFX_LDS_SINGLE
+#define ZAFX_LDS_SINGLE 1
+#endif
+ZAFX_HD float2 lds_ld(const float2* p) {   // p: an address in LDS
+#if ZAFX_LDS_SINGLE && defined(__HIP_DEVICE_COMPILE__)
+    typedef __attribute__((address_space(3))) const volatile zafx_v2f lds_v2f;
+    return to_f2(*(lds_v2f*)(p));
+#else
+    return *p;
+#endif
+}
+
 template <int LOG2N, int LOG2E>
 ZAFX_HD void regs_read(float2* v, const float2* buf, int p) {
     using C = FftCfg<LOG2N, LOG2E>;

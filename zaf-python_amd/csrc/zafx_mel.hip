@@ -663,8 +663,8 @@ __global__ __launch_bounds__(1024, 1) void k_mel2(const float* __restrict__ x, c
 #pragma unroll
         for (int i = 0; i < E / 2; ++i) {   // the lane's own points i and i + 8 out of the pair's two loads
             row_pair_unpack(xr[2 * i], xr[2 * i + 1]);
-            v[i] = mul_elem(xr[2 * i], win_s[lane + i * P]);
-            v[i + E / 2] = mul_elem(xr[2 * i + 1], win_s[lane + (i + E / 2) * P]);
+            v[i] = mul_elem(xr[2 * i], lds_ld(win_s + lane + i * P));
+            v[i + E / 2] = mul_elem(xr[2 * i + 1], lds_ld(win_s + lane + (i + E / 2) * P));
         }
 #ifdef ZAFX_PROF
         asm volatile("" :: "v"(v[0].x), "v"(v[15].y));
@@ -682,7 +682,7 @@ __global__ __launch_bounds__(1024, 1) void k_mel2(const float* __restrict__ x, c
         frame_sync<64>();
         if (ll < 8) {
 #pragma unroll
-            for (int i = 0; i < E; ++i) u[i] = ex[rb + 34 * i];
+            for (int i = 0; i < E; ++i) u[i] = lds_ld(ex + rb + 34 * i);
         }
         frame_sync<64>();
 #pragma unroll
@@ -690,14 +690,18 @@ __global__ __launch_bounds__(1024, 1) void k_mel2(const float* __restrict__ x, c
         frame_sync<64>();
         if (ll >= 8) {
 #pragma unroll
-            for (int i = 0; i < E; ++i) u[i] = ex[rb + 34 * i];
+            for (int i = 0; i < E; ++i) u[i] = lds_ld(ex + rb + 34 * i);
         }
         frame_sync<64>();
         PROF_MARK(6);
         float2 a[E];
         {
             float2 w[E];
-            pass2_twiddles(w, lane & 15, (const float2*)tw_l);
+            {
+                const float2* t = (const float2*)tw_l + twiddle_offset(10, 4, 4) + (lane & 15);
+#pragma unroll
+                for (int r = 1; r < E; ++r) w[r] = lds_ld(t + (r - 1) * 16);
+            }
             a[0] = u[0];
 #pragma unroll
             for (int r = 1; r < E; ++r) a[r] = cmul(u[r], w[r]);
@@ -716,7 +720,7 @@ __global__ __launch_bounds__(1024, 1) void k_mel2(const float* __restrict__ x, c
             const int k = lane + 64 * b;
             z[b][0] = a[4 * b];
 #pragma unroll
-            for (int r = 1; r < 4; ++r) z[b][r] = cmul(a[4 * b + r], t3[(r - 1) * 256 + k]);
+            for (int r = 1; r < 4; ++r) z[b][r] = cmul(a[4 * b + r], lds_ld(t3 + (r - 1) * 256 + k));
             dft4(z[b][0], z[b][1], z[b][2], z[b][3]);
         }
         // upper half of the spectrum to LDS: Z[512 + q] at phys(q), q = lane + 64 b + 256 (r - 2)
@@ -731,8 +735,8 @@ __global__ __launch_bounds__(1024, 1) void k_mel2(const float* __restrict__ x, c
         for (int i = 0; i < E / 2; ++i) {
             const int k = lane + i * P;
             const float2 za = z[i & 3][i >> 2];
-            const float2 zb = ex[phys(N / 2 - (k == 0 ? N / 2 : k))];   // Z[N - k] (k = 0: Z[N / 2], staged at q = 0)
-            float2 pw = split_pair_pow4(za, zb, tws_s[k]);   // (4 |X[k]|^2, 4 |X[N-k]|^2)
+            const float2 zb = lds_ld(ex + phys(N / 2 - (k == 0 ? N / 2 : k)));   // Z[N - k] (k = 0: Z[N / 2], staged at q = 0)
+            float2 pw = split_pair_pow4(za, zb, lds_ld(tws_s + k));   // (4 |X[k]|^2, 4 |X[N-k]|^2)
             if (i == 0 && k == 0) {
                 const float ny = za.x - za.y;   // X[N] (Nyquist, kept: zaf.py:370)
                 pw = make_float2(4.f * (zb.x * zb.x + zb.y * zb.y), 4.f * (ny * ny + 0.f * 0.f));   // |X[N/2]| = |Z[N/2]|

@@ -36,6 +36,17 @@ def test_contract_line_is_compact_and_complete(path):
         e = out["configs"][kind]
         assert e["roofline"]["frac"] > 0 and e["roofline"]["kernel"].startswith("k_")
         assert e["cpu_baseline"]["cores"] >= 1 and e["parity"]["within_tolerance"] is True
+    if os.path.basename(path) >= "r05":
+        # verdict r4 item 3: SURVEY 8(d)'s roofs -- mel / mfcc priced on HBM with the two arithmetic pipes beside it (never summed over one
+        # peak), cqt on the f32 vector pipe with both flop counts; the untimed pre-warm launches are in the line
+        assert isinstance(out["prewarm_launches"], int)
+        for kind in ("mel", "mfcc"):
+            r = out["configs"][kind]["roofline"]
+            assert r["bound"] == "hbm" and r["unit"] == "GB/s" and r["peak"] == 8000.0
+            assert 0 < r["mfma_frac"] < 1 and 0 < r["valu_frac"] < 1
+            assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-3
+        r = out["configs"]["cqt"]["roofline"]
+        assert r["bound"] == "valu" and r["unit"] == "TFLOP/s" and 0 < r["valu_frac_real_input"] < r["frac"] < 1 and 0 < r["hbm_frac"] < 0.1
 
 
 def test_line_sheds_optional_keys_before_it_outgrows_the_limit():

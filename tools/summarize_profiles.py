@@ -8,7 +8,8 @@ What it writes:
   <tag>_bench_detail.json         that process's full record
   <tag>_bench_all_plain.json      the line of the unprofiled run of the same command (carries the in-run HBM traffic of every config)
   <tag>_bench_detail_plain.json   its full record
-  <tag>_stft_kernel_stats.csv     rocprofv3 --stats of the profiled process, every kernel (means include pre-warm, placement survey, PCIe legs)
+  <tag>_process_kernel_stats.csv  rocprofv3 --stats of the WHOLE profiled process, every kernel and every size (pre-warm, placement survey, PCIe legs, extras):
+                                  not the headline kernel's statistic -- that is the next file
   <tag>_timed_kernel_stats.csv    per kind: the dispatches of the TIMED region of that same process (from the kernel trace and the launch
                                   log bench.py wrote), beside the kernel_ms the line reports -- these two must agree
   <tag>_sq_summary.csv            SQ counters of the compute-bound kernels (separate --pmc runs)
@@ -49,7 +50,7 @@ for src, dst in (("bench_detail_profiled.json", f"{tag}_bench_detail.json"), ("b
 
 f = find("prof_all/**/*kernel_stats.csv")
 if f:
-    open(os.path.join(PROF, f"{tag}_stft_kernel_stats.csv"), "w").write(open(f).read())
+    open(os.path.join(PROF, f"{tag}_process_kernel_stats.csv"), "w").write(open(f).read())
 
 # the timed dispatches of the profiled process
 trace, log = find("prof_all/**/*kernel_trace.csv"), os.path.join(OUT, "prof_all_launches.json")

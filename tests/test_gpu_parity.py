@@ -619,7 +619,7 @@ def test_dct_dst(zafx, golden, n):
 def test_dct_dst_on_the_fft_core(zafx, golden, n):
     """Lengths whose N/2 (types 2-4), N-1 (dct 1) or N+1 (dst 1) is a power of two from 32 up run on k_dct: one M-point complex
     transform per vector with the symmetric-extension maps of zaf.py:769-835, :906-981 folded around it -- against the
-    reference's golden vectors; the others keep the dense-matrix form."""
+    reference's golden vectors; the others run as chirp-z sums on the Bluestein machinery (k_dct_bs32), no length on a dense matrix."""
     g = golden["dctdst"]
     x = g[f"x_{n}"]
     for sine, fn, name in ((False, zafx.dct, "dct"), (True, zafx.dst, "dst")):
@@ -628,8 +628,42 @@ def test_dct_dst_on_the_fft_core(zafx, golden, n):
             assert on_core == ((n - 1 if not sine else n + 1) in (64, 1024) if t == 1 else n in (64, 1024)), (n, t, sine)
             got = fn(x, t)
             assert got.dtype == np.float64 and got.shape == x.shape and relerr(got, g[f"{name}{t}_{n}"]) <= TOL_FFT, (name, t)
-            if on_core:
-                assert zafx.dct_plan(n, t, sine).kernel_name == "k_dct"
+            plan = zafx.dct_plan(n, t, sine)
+            assert plan.kernel_name == plan.last_kernel == ("k_dct" if on_core else "k_dct_bs32")
+
+
+@pytest.mark.parametrize("n", [8, 9, 100])
+def test_dct_dst_short_lengths_on_the_fft_core_too(zafx, golden, n):
+    """Verdict r4 item 8: dctdst.npz lengths 9, 63, 65, 100, 1023, 1025 (and 8) leave the dense N x N product for the FFT forms."""
+    g = golden["dctdst"]
+    x = g[f"x_{n}"]
+    for sine, fn, name in ((False, zafx.dct, "dct"), (True, zafx.dst, "dst")):
+        for t in (1, 2, 3, 4):
+            assert relerr(fn(x, t), g[f"{name}{t}_{n}"]) <= TOL_FFT, (name, t)
+            assert zafx.dct_plan(n, t, sine).last_kernel == "k_dct_bs32"
+
+
+@pytest.mark.parametrize("n,rows", [(2, 5), (3, 70), (17, 300), (33, 9), (127, 64), (129, 3), (441, 100), (1000, 1500), (1764, 33), (2047, 7), (3000, 40), (4097, 5),
+                                    (5000, 3), (8191, 2), (8192 - 2, 2)])
+def test_dct_dst_of_any_length(zafx, n, rows):
+    """zaf.dct / zaf.dst take any length (zaf.py:760-839, :900-981: one np.fft.fft of a symmetric extension): every length up to 8192
+    that is off the power-of-two grid of k_dct runs as a chirp-z sum (k_dct_bs32, convolution lengths 128 ... 16384), all eight
+    transforms, more rows than workgroups, against the oracle; the inverse pairs II / III and IV / IV close the loop."""
+    x = np.stack([synth_clip(71, c % 11, n) for c in range(rows)])
+    for sine, batch, one in ((False, zafx.dct_batch, orc.dct), (True, zafx.dst_batch, orc.dst)):
+        for t in (1, 2, 3, 4):
+            if zafx.dct_fft_length(n, t, sine) is not None:
+                continue   # (k_dct's lengths: test_dct_dst_batches_every_size)
+            got = batch(x, t)
+            assert zafx.dct_plan(n, t, sine).last_kernel == "k_dct_bs32" and got.shape == x.shape and got.dtype == np.float32
+            for c in range(min(rows, 11)):
+                assert relerr(got[c], one(x[c].astype(np.float64), t)) <= TOL_FFT, (sine, t, c)
+            if rows > 11:
+                assert np.array_equal(got[11:22], got[0:11])   # replicas of the same vectors on other workgroups
+    k = min(rows, 3)
+    for batch in (zafx.dct_batch, zafx.dst_batch):
+        assert np.max(np.abs(batch(batch(x[:k], 2), 3) - x[:k])) < 3e-5
+        assert np.max(np.abs(batch(batch(x[:k], 4), 4) - x[:k])) < 3e-5
 
 
 @pytest.mark.parametrize("n,rows", [(64, 1), (64, 1000), (128, 7), (256, 33), (512, 5), (1024, 16384), (2048, 9), (4096, 300), (8192, 3), (16384, 5),

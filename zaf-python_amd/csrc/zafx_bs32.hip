@@ -125,6 +125,35 @@ __global__ __launch_bounds__(BsCfg<LOG2M>::P) void k_ifft_frames_bs32(
     for (int n = p; n < W; n += B::P) fr[n] = bs_out<LOG2M>(buf, n, chirp).x * inv;   // Re(conj(.)) = Re(.)
 }
 
+// zaf.dct / zaf.dst, types I-IV, of ANY length (zaf.py:760-839, :900-981: the reference's np.fft.fft takes any): the transform as a chirp-z
+// sum y[k] = Re(Q[k] sum_n (x[n] P[n]) conj(c)[k - n]) (tables P | Q and the chirp's transform from zafx_plan_create, which derives them for
+// the eight transforms at once).  One vector per frame of the FFT core, rows walked by a persistent grid; 8 bytes per sample.
+template <int LOG2M>
+__global__ __launch_bounds__(BsCfg<LOG2M>::P) void k_dct_bs32(const float* __restrict__ x, float* __restrict__ y, const float2* __restrict__ tw,
+                                                              const float2* __restrict__ pq, const float2* __restrict__ bhat, int N, long long n_rows) {
+    using B = BsCfg<LOG2M>;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    float2* buf = reinterpret_cast<float2*>(smem_raw);
+    const int p = threadIdx.x;
+    for (long long row = blockIdx.x; row < n_rows; row += gridDim.x) {
+        const float* xr = x + row * N;
+        for (int n = p; n < N; n += B::P) {
+            const float v = xr[n];
+            const float2 c = pq[n];
+            buf[phys_t<B::C::PS>(n)] = make_float2(v * c.x, v * c.y);
+        }
+        bs_zero_tail<LOG2M>(buf, p, N);
+        frame_sync<B::P>();
+        bluestein32<LOG2M>(buf, p, tw, bhat);   // conj(convolution) M
+        float* yr = y + row * N;
+        for (int k = p; k < N; k += B::P) {
+            const float2 z = buf[phys_t<B::C::PS>(k)], q = pq[N + k];   // (Q carries 1 / M and the orthonormal scale)
+            yr[k] = q.x * z.x + q.y * z.y;                              // Re(Q conj(z))
+        }
+        frame_sync<B::P>();   // the frame is free for the next row
+    }
+}
+
 // overlap-add in ascending frame order (zaf.py:226-233 / :1172-1179), trim (:236-238 / :1182), gain (:241)
 __global__ __launch_bounds__(256) void k_ola_f32(const float* __restrict__ frames, float* __restrict__ y, int T, int W, int hop, long long out_len,
                                                  long long total, float scale) {
@@ -274,6 +303,21 @@ hipError_t launch_istft_bs32(zafx_plan& pl, const float2* spec_all, float* y_all
         if (hipError_t e2 = launch_ola(pl, y_all + c0 * out_len, n_clips, T, pl.H, out_len, 1.f / pl.cola_gain); e2 != hipSuccess) return e2;
     }
     return hipSuccess;
+}
+
+hipError_t launch_dct_bs32(const zafx_plan& pl, const float* x, float* y, int64_t n_rows) {
+    if (n_rows <= 0) return hipSuccess;
+    return by_log2m(pl.bs_log2m, [&](auto tag) {
+        constexpr int L = decltype(tag)::value;
+        auto kern = k_dct_bs32<L>;
+        if (hipError_t e = ensure_dynamic_lds(reinterpret_cast<const void*>(kern), pl.device, BsCfg<L>::SMEM); e != hipSuccess) return e;
+        const size_t per_cu = std::max<size_t>(1, std::min<size_t>(std::min<size_t>(2048 / BsCfg<L>::P, 16), (size_t)kMaxLdsBytes / BsCfg<L>::SMEM));
+        const long long grid = std::min<long long>(n_rows, (long long)pl.n_cus * (long long)per_cu);
+        pl.ran = "k_dct_bs32";
+        hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(BsCfg<L>::P), BsCfg<L>::SMEM, pl.stream, x, y, pl.d_tw_pass, pl.d_tw_aux, pl.d_bs_bhat, pl.W,
+                           (long long)n_rows);
+        return hipGetLastError();
+    });
 }
 
 hipError_t launch_mdct_bs32(const zafx_plan& pl, const float* x, float* out, int64_t n_clips, int64_t n_samples, int T) {

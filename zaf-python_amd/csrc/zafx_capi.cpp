@@ -248,13 +248,16 @@ static int build_cqt_mm(zafx_plan* pl, int n_waves);
 
 // Bluestein tables of a W-point DFT as a convolution of length M = 2^log2m, in long double: the chirp
 // c[n] = exp(-i pi n^2 / W) (angle reduced in integers: n^2 mod 2W) and Bhat = FFT_M of conj(c) wrapped to length M.
+// `den` = W for a DFT; the chirp-z sums of zafx_bs32.hip's k_dct_bs32 (a step of pi / D per n k instead of 2 pi / W) pass den = 2 D
+// and count = the vector length.
 typedef std::complex<long double> cld;
-static void bluestein_tables(int W, int log2m, std::vector<cld>& chirp, std::vector<cld>& bhat) {
+static void bluestein_tables(int count, long long den, int log2m, std::vector<cld>& chirp, std::vector<cld>& bhat) {
     const int M = 1 << log2m;
     const long double pi = 3.14159265358979323846264338327950288L;
-    chirp.assign((size_t)W, cld(0, 0));
+    const long long W = den;
+    chirp.assign((size_t)count, cld(0, 0));
     bhat.assign((size_t)M, cld(0, 0));
-    for (long long k = 0; k < W; ++k) {
+    for (long long k = 0; k < count; ++k) {
         const long long r = (k * k) % (2LL * W);
         const long double ang = pi * (long double)r / (long double)W;
         cld v(cosl(ang), sinl(ang));   // conj(c[k]) = exp(+i pi k^2 / W)
@@ -820,16 +823,55 @@ int zafx_plan_create(zafx_plan** out, int device, int kind, const zafx_params* p
         if (N < 2) return bail("dct / dst: window_length must be at least 2");
         const int M = type == 1 ? (sine ? N + 1 : N - 1) : (N % 2 == 0 ? N / 2 : -1);
         const int lm = ilog2_exact(M);
-        if (lm < 0 || !dct_supported(lm))
-            return bail("dct / dst on the FFT core: N / 2 (types 2-4), N - 1 (dct type 1) or N + 1 (dst type 1) must be a power of two in [32, 8192]");
         pl->W = N;
-        pl->log2nf = lm;
-        aux.resize(2 * (size_t)(M + 1));
-        for (int k = 0; k <= M; ++k) {
-            aux[(size_t)k] = type == 4 ? unit_root(4LL * k + 1, 8LL * N) : unit_root(k, 2LL * M);
-            aux[(size_t)(M + 1 + k)] = type == 4 ? unit_root(k, 2LL * N) : unit_root(k, 4LL * N);
+        if (lm >= 0 && dct_supported(lm)) {
+            pl->log2nf = lm;
+            aux.resize(2 * (size_t)(M + 1));
+            for (int k = 0; k <= M; ++k) {
+                aux[(size_t)k] = type == 4 ? unit_root(4LL * k + 1, 8LL * N) : unit_root(k, 2LL * M);
+                aux[(size_t)(M + 1 + k)] = type == 4 ? unit_root(k, 2LL * N) : unit_root(k, 4LL * N);
+            }
+            pl->kernel_name = dct_kernel_name();
+        } else if (N <= 8192) {
+            // Every other length (the reference's np.fft.fft takes any, zaf.py:760-839, :900-981): all eight transforms are
+            //     y[k] = s_out[k] sum_n s_in[n] x[n] cos | sin(pi (n + a)(k + b) / D),   a, b in {0, 1/2, 1},  D = N - 1 | N | N + 1,
+            // and with n k = (n^2 + k^2 - (k - n)^2) / 2 the sum is a convolution with a chirp of step pi / D (a chirp-z transform):
+            //     y[k] = Re(Q[k] sum_n (x[n] P[n]) conj(c)[k - n]),   c[j] = exp(-i pi j^2 / (2 D)),
+            //     P[n] = s_in[n] exp(-i pi n b / D) c[n],   Q[k] = s_out[k] exp(-i pi (a k + a b) / D) c[k]  (x i for the sines),
+            // on the Bluestein machinery of zafx_bs32.hip (k_dct_bs32: two transforms of 2^ceil(log2(2N - 1)) points per vector instead of
+            // the dense N x N product of round 4).  Angles in units of pi / (4 D), reduced in integers.
+            const int a2 = sine ? (type == 1 ? 2 : type == 3 ? 2 : 1) : (type == 2 || type == 4 ? 1 : 0);   // 2 a
+            const int b2 = sine ? (type == 1 ? 2 : type == 2 ? 2 : 1) : (type == 3 || type == 4 ? 1 : 0);   // 2 b
+            const long long D = type == 1 ? (sine ? N + 1 : N - 1) : N;
+            pl->dct_den2 = 2 * D;
+            pl->log2nf = 4;   // (the FFT tables are those of the convolution length, below)
+            pl->bs_log2m = 7;
+            while ((1 << pl->bs_log2m) < 2 * N - 1) ++pl->bs_log2m;
+            const double L = (double)(1 << pl->bs_log2m), s = std::sqrt(2.0 / (double)D), r2 = std::sqrt(0.5);
+            aux.resize(2 * (size_t)N);
+            for (long long n = 0; n < N; ++n) {
+                double sin_ = 1.0, sout = s;
+                if (type == 1 && !sine && (n == 0 || n == N - 1)) sin_ = r2, sout = s * r2;
+                if (type == 2 && (sine ? n == N - 1 : n == 0)) sout = s * r2;
+                if (type == 3 && (sine ? n == N - 1 : n == 0)) sin_ = r2;
+                auto root = [&](long long m, double scale) {   // scale exp(-i pi m / (4 D)), in float64, exact on the axes
+                    m %= 8 * D;
+                    const double ang = M_PI * (double)m / (double)(4 * D);
+                    double c = std::cos(ang), sn = -std::sin(ang);
+                    if (m % (2 * D) == 0) {
+                        const int quarter = (int)(m / (2 * D));
+                        c = quarter == 0 ? 1.0 : quarter == 2 ? -1.0 : 0.0;
+                        sn = quarter == 1 ? -1.0 : quarter == 3 ? 1.0 : 0.0;
+                    }
+                    return cf32{(float)(scale * c), (float)(scale * sn)};
+                };
+                aux[(size_t)n] = root(2 * n * b2 + 2 * n * n, sin_);
+                aux[(size_t)(N + n)] = root(2 * n * a2 + a2 * b2 + 2 * n * n + (sine ? 6 * D : 0), sout / L);   // (x i = exp(-i pi 6 D / (4 D)))
+            }
+            pl->kernel_name = "k_dct_bs32";
+        } else {
+            return bail("dct / dst: lengths above 8192 need N / 2 (types 2-4), N - 1 (dct type 1) or N + 1 (dst type 1) to be a power of two (at most 8192)");
         }
-        pl->kernel_name = dct_kernel_name();
     } else {
         return bail("unknown plan kind");
     }
@@ -875,7 +917,7 @@ int zafx_plan_create(zafx_plan** out, int device, int kind, const zafx_params* p
         if (twm.empty()) twm.push_back(cf32{1.f, 0.f});
         e = upload(&pl->d_tw_pass, twm.data(), twm.size() * sizeof(cf32));
         std::vector<cld> c, b;
-        bluestein_tables(W, pl->bs_log2m, c, b);
+        bluestein_tables(W, kind == ZAFX_DCT ? pl->dct_den2 : (long long)W, pl->bs_log2m, c, b);
         std::vector<cf32> cf((size_t)W), bf((size_t)M);
         for (int i = 0; i < W; ++i) cf[(size_t)i] = cf32{(float)c[(size_t)i].real(), (float)c[(size_t)i].imag()};
         for (int i = 0; i < M; ++i) bf[(size_t)i] = cf32{(float)b[(size_t)i].real(), (float)b[(size_t)i].imag()};
@@ -892,7 +934,7 @@ int zafx_plan_create(zafx_plan** out, int device, int kind, const zafx_params* p
             }
             if (e == hipSuccess) e = upload(&pl->d_tw_aux, pp.data(), pp.size() * sizeof(cf32));
         }
-        pl->kernel_name = kind == ZAFX_STFT ? "k_stft_bs32" : kind == ZAFX_ISTFT ? "k_ifft_frames_bs32" : kind == ZAFX_MDCT ? "k_mdct_bs32"
+        pl->kernel_name = kind == ZAFX_DCT ? "k_dct_bs32" : kind == ZAFX_STFT ? "k_stft_bs32" : kind == ZAFX_ISTFT ? "k_ifft_frames_bs32" : kind == ZAFX_MDCT ? "k_mdct_bs32"
                           : (kind == ZAFX_MEL || kind == ZAFX_MFCC) ? mel_wide_kernel_name() : "k_imdct_frames_bs32";
     }
     if (e == hipSuccess && pl->prm.precision == ZAFX_PRECISION_F64) {   // float64 tables, evaluated in long double
@@ -915,7 +957,7 @@ int zafx_plan_create(zafx_plan** out, int device, int kind, const zafx_params* p
             tws.assign((size_t)W, make_double2(0, 0));
             for (long long k = 0; k < W; ++k) tws[(size_t)k] = root((k * k) % (2LL * W), 2LL * W);
             std::vector<cld> c, b;
-            bluestein_tables(W, pl->bs_log2m, c, b);
+            bluestein_tables(W, (long long)W, pl->bs_log2m, c, b);
             std::vector<double2> bhat((size_t)M);
             for (int i = 0; i < M; ++i) bhat[(size_t)i] = make_double2((double)b[(size_t)i].real(), (double)b[(size_t)i].imag());
             e = upload(&pl->d_bhat64, bhat.data(), bhat.size() * sizeof(double2));
@@ -1188,7 +1230,7 @@ int zafx_execute(zafx_plan* pl, const void* d_in, void* d_out, int64_t n_clips, 
             e = launch_linear(*pl, (const float*)d_in, (float*)d_out, n_clips);
             break;
         case ZAFX_DCT:
-            e = launch_dct(*pl, (const float*)d_in, (float*)d_out, n_clips);
+            e = pl->bs_log2m > 0 ? launch_dct_bs32(*pl, (const float*)d_in, (float*)d_out, n_clips) : launch_dct(*pl, (const float*)d_in, (float*)d_out, n_clips);
             break;
         case ZAFX_CQT:
         case ZAFX_CHROMA:

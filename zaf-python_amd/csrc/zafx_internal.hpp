@@ -153,6 +153,7 @@ struct zafx_plan {
     double* d_dct64 = nullptr;     // [n_coefs][n_filters]
     double2* d_values64 = nullptr; // CQT kernel values of a float64 plan (complex128)
     int bs_log2m = 0;              // > 0: window that is not a power of two -- Bluestein convolution length 2^bs_log2m (zafx_f64.hip, zafx_bs32.hip)
+    long long dct_den2 = 0;        // ZAFX_DCT on the chirp-z form: 2 D, the denominator of its chirp exp(-i pi j^2 / (2 D)) (k_dct_bs32)
     float2* d_bs_chirp = nullptr;  // float32 Bluestein plans: c[n] = exp(-i pi n^2 / W), n < W
     float2* d_bs_bhat = nullptr;   // ... and FFT_M of the wrapped conjugate chirp
     double2* d_bhat64 = nullptr;   // FFT of the wrapped conjugate chirp, 2^bs_log2m entries
@@ -200,6 +201,7 @@ hipError_t launch_stft_bs32(const zafx_plan& pl, const float* x, float2* out, in
 hipError_t launch_istft_bs32(zafx_plan& pl, const float2* spec, float* y, int64_t n_clips, int T, int64_t out_len);
 hipError_t launch_mdct_bs32(const zafx_plan& pl, const float* x, float* out, int64_t n_clips, int64_t n_samples, int T);
 hipError_t launch_imdct_bs32(zafx_plan& pl, const float* coefs, float* y, int64_t n_clips, int T, int64_t out_len);
+hipError_t launch_dct_bs32(const zafx_plan& pl, const float* x, float* y, int64_t n_rows);   // zaf.dct / zaf.dst of any length <= 8192 as chirp-z sums
 // plan-owned scratch of the inverse transforms that park their time-domain frames (zafx_f64.hip): grow-only, and the number
 // of clips per pass that keeps it under the budget (1 GiB; ZAFX_SCRATCH_BUDGET_MB)
 hipError_t grow_scratch(zafx_plan& pl, size_t need);

@@ -987,13 +987,19 @@ def dct_fft_length(length, kind, sine):
     return m if 32 <= m <= 8192 and m & (m - 1) == 0 else None
 
 
+DCT_CHIRP_MAX = 8192   # longest vector of the chirp-z form (its convolution of 2^ceil(log2(2N - 1)) <= 16384 points lives in LDS)
+
+
 def dct_plan(length, kind, sine=False, device=0):
-    """Plan of the orthonormal dct (sine=False) / dst of type `kind` of vectors of `length` samples on the FFT core
-    (zaf.py:703-839, :842-981: one M-point complex transform per vector instead of the reference's 2N-2 ... 8N-point one)."""
-    if dct_fft_length(length, kind, sine) is None:
-        raise ValueError("this length / type does not run on the FFT core (see dct_fft_length)")
-    return _cached(("dct_fft", int(length), int(kind), bool(sine), device),
-                   lambda: Plan(_lib.DCT, device, window_length=int(length), transform_type=int(kind), transform_sine=bool(sine)))
+    """Plan of the orthonormal dct (sine=False) / dst of type `kind` of vectors of `length` samples (zaf.py:703-839, :842-981).
+    Lengths with N/2 (type 1: N -/+ 1) a power of two in [32, 8192] run ONE M-point complex transform per vector (k_dct, instead of the
+    reference's 2N-2 ... 8N-point one); every other length from 2 to 8192 runs as a chirp-z sum on the Bluestein machinery (k_dct_bs32:
+    two transforms of 2^ceil(log2(2N - 1)) points) -- O(N log N) for every length the reference takes."""
+    n = int(length)
+    if dct_fft_length(n, kind, sine) is None and not 2 <= n <= DCT_CHIRP_MAX:
+        raise ValueError("dct / dst plans take lengths 2 ... 8192, and longer ones whose N/2 (type 1: N-1 / N+1) is a power of two up to 8192")
+    return _cached(("dct_fft", n, int(kind), bool(sine), device),
+                   lambda: Plan(_lib.DCT, device, window_length=n, transform_type=int(kind), transform_sine=bool(sine)))
 
 
 def _transform_batch(vectors, matrix_fn, kind, device, out=None):
@@ -1004,12 +1010,12 @@ def _transform_batch(vectors, matrix_fn, kind, device, out=None):
     if kind not in (1, 2, 3, 4):
         raise ValueError("type must be 1, 2, 3 or 4")
     sine = matrix_fn is constants.dst_matrix
-    if dct_fft_length(n, kind, sine) is not None:   # O(N log N): the FFT core, as the reference computes it
+    if dct_fft_length(n, kind, sine) is not None or 2 <= n <= DCT_CHIRP_MAX:   # O(N log N): on the FFT core, as the reference computes it
         return dct_plan(n, kind, sine, device).run_host(x, n, out=out)
-    # other lengths (N/2, N-1 or N+1 not a power of two; very short or very long vectors): the transform as a dense matrix on
-    # the matrix cores -- O(N^2) arithmetic and an N x N table, so bounded
+    # what is left -- one sample, or 8192 < N <= 16384 off the power-of-two grid (a convolution of 32768 points does not fit LDS) --: the
+    # transform as a dense matrix on the matrix cores, O(N^2) arithmetic and an N x N table, so bounded
     if n > 16384:
-        raise ValueError("dct / dst lengths above 16384 need N/2 (type 1: N-1 / N+1) to be a power of two")
+        raise ValueError("dct / dst lengths above 16384 are not supported (above 8192: N/2, or N-1 / N+1 for type 1, must be a power of two)")
 
     def make():   # the N x N matrix (O(N^2) trigonometry, 8 N^2 bytes) is built once per (transform, type, N, device)
         m = np.ascontiguousarray(matrix_fn(n, kind), dtype=np.float64)

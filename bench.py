@@ -49,7 +49,7 @@ HBM_ACHIEVABLE_GBS = 6290.0   # same guide: measured-achievable copy rate
 F32_PEAK_TFLOPS = 157.3    # dense f32 vector / f32-input MFMA peak
 PLACEMENT_SURVEY = 6       # further allocations of the headline's row-strided output probed AFTER every timed region (reported, never timed)
 CONFIG_KINDS = ("istft", "mel", "mfcc", "mdct", "imdct", "cqt")   # SURVEY 8(a) a2 + BASELINE configs 3, 4, 5 (config 2 = the headline)
-EXTRA_KINDS = ("stft1", "stftmag", "istft1", "stft_offgrid", "mdct_offgrid", "stft4096", "stft4096_h1024", "istft4096", "mdct4096", "mel4096", "dct")   # one-sided pair (8f rank 4) and geometries off the benchmark's grid
+EXTRA_KINDS = ("stft1", "stftmag", "istft1", "stft_offgrid", "mdct_offgrid", "stft4096", "stft4096_h1024", "istft4096", "mdct4096", "mel4096", "dct", "stft64", "mdct64")   # one-sided pair (8f rank 4) and geometries off the benchmark's grid
 
 
 def synth(seed, c, n):
@@ -79,8 +79,8 @@ def make_workload(kind, device, layout="FT"):
         B, N, T = 1024, 1323000, 750   # BASELINE config 5: 8192 clips x 30 s over 8 GPUs = 1024 per GPU
     if kind == "dct":
         B, N, T = 16384, 1024, 1
-    if kind == "stft64":
-        B = 128
+    if kind in ("stft64", "mdct64"):
+        B = 256                   # the reference's own dtype (zaf.py:128, :139: float64 in, complex128 out): 40.1 / 16 B per sample
     if kind == "stft_offgrid":
         N, T = 442024, 433        # one more frame than config 2: rows of 433 complex64 = 3464 B, off the 128-byte grid
     if kind == "stft4096":
@@ -136,7 +136,14 @@ def make_workload(kind, device, layout="FT"):
         d_x = d_x64
         plan = zafx.stft_plan(ham, H, layout=layout, device=device, f64=True)
         wl.update(plan=plan, d_in=d_x, n_in=N, bytes_per_launch=B * (8 * N + 16 * W * T),
-                  desc="Batched STFT in float64 / complex128: 128 clips x 10 s, Hamming win=2048 hop=1024, two-sided")
+                  desc="Batched STFT in float64 / complex128 (the reference's dtype): 256 clips x 10 s, Hamming win=2048 hop=1024, two-sided")
+    elif kind == "mdct64":
+        d_x64 = zafx.DeviceBuffer.from_host(np.tile(base.astype(np.float64), (B // distinct, 1)), device)
+        d_x.free()
+        d_x = d_x64
+        plan = zafx.mdct_plan(kbd, device=device, f64=True)
+        wl.update(plan=plan, d_in=d_x, n_in=N, bytes_per_launch=B * (8 * N + 8 * (W // 2) * T),
+                  desc="Batched MDCT in float64: 256 clips x 10 s, KBD win=2048")
     elif kind == "stft1":   # one-sided output (rows 0..W/2), not the headline
         plan = zafx.stft_plan(ham, H, layout=layout, device=device, onesided=True)
         wl.update(plan=plan, d_in=d_x, n_in=N, bytes_per_launch=B * (4 * N + 8 * (W // 2 + 1) * T),
@@ -393,7 +400,7 @@ def parity_probe(wl):
     kind, base, B = wl["kind"], wl["base"], wl["n_clips"]
     ham, kbd = orc.hamming_periodic(W), orc.kbd_window(W)
     x64 = base[0].astype(np.float64)
-    if kind in ("stft", "stft1", "stft_offgrid", "stftmag"):
+    if kind in ("stft", "stft1", "stft_offgrid", "stftmag", "stft64"):
         ref = orc.stft(x64, ham, H)
         ref = ref[:W // 2 + 1] if kind in ("stft1", "stftmag") else ref
         ref = np.abs(ref) if kind == "stftmag" else ref
@@ -407,7 +414,7 @@ def parity_probe(wl):
         ref = orc.melspectrogram(x64, orc.hamming_periodic(4096), 2048, orc.melfilterbank(FS, 4096, 128))
     elif kind in ("istft", "istft1", "istft4096"):
         ref = None   # (checked as a round trip below: the device spectrum is the input)
-    elif kind in ("mdct", "mdct_offgrid"):
+    elif kind in ("mdct", "mdct_offgrid", "mdct64"):
         ref = orc.mdct(x64, kbd)
     elif kind == "imdct":
         ref = None
@@ -432,7 +439,7 @@ def parity_probe(wl):
         return out
     got = first if first.shape == ref.shape else first.T
     d = float(np.max(np.abs(got - ref)))
-    tol = 1e-4 if kind in ("mel", "mfcc", "cqt", "mel4096") else 1e-5
+    tol = 1e-4 if kind in ("mel", "mfcc", "cqt", "mel4096") else 1e-12 if kind.endswith("64") else 1e-5
     rel = d / float(np.max(np.abs(ref)))
     out.update({"max_abs_err_vs_numpy": d, "max_rel_err_vs_numpy": rel, "tolerance": tol, "within_tolerance": bool(rel <= tol)})
     return out
@@ -833,7 +840,7 @@ def main():
     ap.add_argument("--steps", type=int, default=100)
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--kind", default="all", help="all = headline STFT + every other BASELINE config in one line; or one of "
-                    "stft istft mdct imdct mel mfcc cqt stft1 stftmag istft1 stft64 dct")
+                    "stft istft mdct imdct mel mfcc cqt stft1 stftmag istft1 stft64 mdct64 dct")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-configs", action="store_true", help="with --kind all: headline only")
     ap.add_argument("--layout", default="FT", choices=["FT", "TF"], help="FT = reference (W, T) memory order (default); TF = frame-major")

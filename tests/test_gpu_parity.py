@@ -880,6 +880,30 @@ def test_random_geometry_mdct_family(zafx, wl, n):
 TOL_F64 = 1e-12
 
 
+@pytest.mark.parametrize("hop,n,clips", [(1024, 441000, 3), (1024, 30001, 2), (512, 40000, 5), (1000, 99998, 2), (441, 30000, 1), (1024, 1024 * 63, 40), (3000, 50000, 2),
+                                         (1024, 1, 1), (1023, 20000, 2)])
+def test_f64_stft_on_the_tiled_kernel(zafx, hop, n, clips):
+    """W = 2048 in the reference layout, float64: k_stft_ft8_f64 (8-frame tiles = 128-byte lines of complex128 rows, a frame per
+    wavefront; zaf.py:112-139 in its own dtype) -- interior and edge frames, odd clip lengths and hops (the sample-by-sample loads), ragged
+    last tiles, rows on and off the line grid, more tiles than workgroups, two-sided and one-sided; the other kinds and layouts stay on
+    k_stft_f64."""
+    x = np.stack([synth_clip(37, c % 7, n).astype(np.float64) + 1e-9 * (c % 7) for c in range(clips)])
+    w = zafx.hamming(2048)
+    ref = orc.stft_batch(x[:7], w, hop)
+    for one in (False, True):
+        got = zafx.stft_batch(x, w, hop, onesided=one, f64=True)
+        assert zafx.stft_plan(w, hop, onesided=one, f64=True).last_kernel == "k_stft_ft8_f64"
+        assert got.dtype == np.complex128 and got.shape[1:] == ((1025 if one else 2048), ref.shape[2])
+        for c in range(min(clips, 7)):
+            assert relerr(got[c], ref[c, :1025] if one else ref[c]) <= TOL_F64, (one, c)
+        if clips > 7:
+            assert np.array_equal(got[7:14], got[0:7]) and np.array_equal(got[clips - 5:], got[(clips - 5) % 7:(clips - 5) % 7 + 5])
+    zafx.stft_batch(x[:1], w, hop, onesided="magnitude", f64=True)
+    assert zafx.stft_plan(w, hop, onesided="magnitude", f64=True).last_kernel == "k_stft_f64"
+    zafx.stft_batch(x[:1], w, hop, layout="TF", f64=True)
+    assert zafx.stft_plan(w, hop, layout="TF", f64=True).last_kernel == "k_stft_f64"
+
+
 @pytest.mark.parametrize("wl,hop,n", [(2048, 1024, 441000), (2048, 512, 30000), (1024, 300, 9001), (64, 32, 1000), (8192, 4096, 50000),
                                        (256, 77, 1)])
 def test_f64_stft_istft(zafx, wl, hop, n):

@@ -104,6 +104,184 @@ __global__ __launch_bounds__(kThreadsBig) void k_stft_f64(
     }
 }
 
+// ---------------------------------------------------------------------------------
+// k_stft_ft8_f64: the reference's own dtype (float64 in, complex128 out: zaf.py:128, :139) on the tiled structure of the float32
+// headline kernel.  W = 2048, reference layout, complex kinds.  A tile is 8 frames of one clip -- 8 x 16 B = one 128-byte line of
+// every output row --, a workgroup 8 waves, a wave one frame: 1024 packed points as 16 x 16 x 4 in registers (64 lanes x 16 double2)
+// with two exchanges through the wave's own 17 KB of LDS, real split in place, then the whole workgroup writes the tile row by row,
+// eight lanes to a line.  At 40 B per sample the kernel is bound by HBM, not by the 78 TF of float64 vector arithmetic: the
+// one-frame-per-workgroup form (k_stft_f64: a barrier per radix-2 stage, 16-byte stores 6.9 KB apart) ran at 0.17 of it.
+// Twiddles: exp(-2 pi i m / 1024) from the plan's half-circle table (m < 512; the other half by sign), no tables in LDS.
+// ---------------------------------------------------------------------------------
+__device__ __forceinline__ double2 dmul_mi(double2 a) { return make_double2(a.y, -a.x); }   // a * (-i)
+__device__ __forceinline__ void dft4d(double2& v0, double2& v1, double2& v2, double2& v3) {
+    const double2 t0 = dadd(v0, v2), t1 = dsub(v0, v2), t2 = dadd(v1, v3), t3 = dmul_mi(dsub(v1, v3));
+    v0 = dadd(t0, t2);
+    v1 = dadd(t1, t3);
+    v2 = dsub(t0, t2);
+    v3 = dsub(t1, t3);
+}
+__device__ __forceinline__ void dft16d(double2* a) {   // natural order in and out, forward sign
+    const double h = 0.70710678118654752440, c1 = 0.92387953251128675613, s1 = 0.38268343236508977173;
+    double2 m[4][4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        m[r][0] = a[r]; m[r][1] = a[r + 4]; m[r][2] = a[r + 8]; m[r][3] = a[r + 12];
+        dft4d(m[r][0], m[r][1], m[r][2], m[r][3]);
+    }
+    m[1][1] = dmul(m[1][1], make_double2(c1, -s1));
+    m[1][2] = dmul(m[1][2], make_double2(h, -h));
+    m[1][3] = dmul(m[1][3], make_double2(s1, -c1));
+    m[2][1] = dmul(m[2][1], make_double2(h, -h));
+    m[2][2] = dmul_mi(m[2][2]);
+    m[2][3] = dmul(m[2][3], make_double2(-h, -h));
+    m[3][1] = dmul(m[3][1], make_double2(s1, -c1));
+    m[3][2] = dmul(m[3][2], make_double2(-h, -h));
+    m[3][3] = dmul(m[3][3], make_double2(-c1, s1));
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        dft4d(m[0][q], m[1][q], m[2][q], m[3][q]);
+        a[q] = m[0][q]; a[q + 4] = m[1][q]; a[q + 8] = m[2][q]; a[q + 12] = m[3][q];
+    }
+}
+#ifndef ZAFX_F64_FPB
+#define ZAFX_F64_FPB 8   // (4: 64-byte pieces and two workgroups per CU -- measured 1.30-1.32 ms against 1.23-1.29 for 256 clips x 10 s)
+#endif
+constexpr int kF64Frames = ZAFX_F64_FPB, kF64N = 1024, kF64Pitch = kF64N + kF64N / 16 + 1;
+__device__ __forceinline__ int physd(int i) { return i + (i >> 4); }
+__device__ __forceinline__ double2 root1024(const double2* __restrict__ tw, int m) {   // exp(-2 pi i m / 1024), m < 1024
+    const double2 w = tw[m & 511];
+    return m & 512 ? make_double2(-w.x, -w.y) : w;
+}
+// 1024-point forward transform of one wavefront: v[i] = z[lane + 64 i] in, natural order in `buf` out
+__device__ __forceinline__ void fft1024_f64(double2* v, double2* buf, int lane, const double2 (&w2)[16], const double2* __restrict__ tw) {
+    dft16d(v);
+#pragma unroll
+    for (int r = 0; r < 16; ++r) buf[physd(16 * lane + r)] = v[r];
+    frame_sync<64>();
+#pragma unroll
+    for (int i = 0; i < 16; ++i) v[i] = buf[physd(lane + 64 * i)];
+    frame_sync<64>();
+    {
+        const int k = lane & 15;
+#pragma unroll
+        for (int r = 1; r < 16; ++r) v[r] = dmul(v[r], w2[r]);   // exp(-2 pi i r k / 256)
+        dft16d(v);
+        const int base = ((lane >> 4) << 8) + k;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) buf[physd(base + 16 * r)] = v[r];
+    }
+    frame_sync<64>();
+#pragma unroll
+    for (int i = 0; i < 16; ++i) v[i] = buf[physd(lane + 64 * i)];
+    frame_sync<64>();
+#pragma unroll
+    for (int b = 0; b < 4; ++b) {
+        const int k = lane + 64 * b;
+        double2 a0 = v[b], a1 = dmul(v[b + 4], root1024(tw, k)), a2 = dmul(v[b + 8], root1024(tw, 2 * k)), a3 = dmul(v[b + 12], root1024(tw, 3 * k));
+        dft4d(a0, a1, a2, a3);
+        buf[physd(k)] = a0;
+        buf[physd(k + 256)] = a1;
+        buf[physd(k + 512)] = a2;
+        buf[physd(k + 768)] = a3;
+    }
+    frame_sync<64>();
+}
+
+template <bool ONE>
+__global__ __launch_bounds__(kF64Frames * 64) void k_stft_ft8_f64(const double* __restrict__ x, const double* __restrict__ win, const double2* __restrict__ tw,
+                                                                   const double2* __restrict__ tws, double2* __restrict__ out, long long n_samples, int hop, int T,
+                                                                   int TP, int tiles, int total_tiles) {
+    constexpr int N = kF64N, W = 2 * N, FPB = kF64Frames, PITCH = kF64Pitch, ROWS = ONE ? N + 1 : W;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    double2* frames = reinterpret_cast<double2*>(smem_raw);
+    double* nyq = reinterpret_cast<double*>(frames + FPB * PITCH);   // X[N] of every frame (real)
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    double2* buf = frames + wave * PITCH;
+    const bool xcd = gridDim.x % 8 == 0;
+    // samples of the wave's frame of tile `tlv` (raw: the window is applied where they are consumed), requested one tile ahead -- before the
+    // store phase of the tile in front, whose LDS reads and 16-byte stores they fly under
+    double2 v[16];
+    auto request = [&](int tlv) {
+        if (tlv >= total_tiles) return;
+        const int tl = xcd ? xcd_order(tlv, total_tiles) : tlv;
+        const int clip = tl / tiles, t = (tl % tiles) * FPB + wave;
+        const double* xc = x + (long long)clip * n_samples;
+        const long long s0 = (long long)t * hop - N;   // floor(W / 2) samples of left padding (zaf.py:99, :112)
+        if (t < T && s0 >= 0 && s0 + W <= n_samples && ((s0 | n_samples) & 1) == 0) {   // (uniform) interior frame, 16-byte loads
+            const double2* xp = reinterpret_cast<const double2*>(xc + s0);
+#pragma unroll
+            for (int i = 0; i < 16; ++i) v[i] = xp[lane + 64 * i];
+        } else {
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                const long long s = s0 + 2 * (lane + 64 * i);
+                v[i].x = (t < T && s >= 0 && s < n_samples) ? xc[s] : 0.0;
+                v[i].y = (t < T && s + 1 >= 0 && s + 1 < n_samples) ? xc[s + 1] : 0.0;
+            }
+        }
+    };
+    // the lane's twiddles of pass 2, resident (two waves per SIMD: 256 registers each; with those of pass 3 as well the kernel spills)
+    double2 w2[16];
+#pragma unroll
+    for (int r = 1; r < 16; ++r) w2[r] = root1024(tw, 4 * r * (lane & 15));   // exp(-2 pi i r k / 256)
+    request(blockIdx.x);
+    for (int tlv = blockIdx.x; tlv < total_tiles; tlv += gridDim.x) {
+        const int tl = xcd ? xcd_order(tlv, total_tiles) : tlv;
+        const int clip = tl / tiles, t0 = (tl % tiles) * FPB;
+        {
+            const double2* wp = reinterpret_cast<const double2*>(win);
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                const double2 w = wp[lane + 64 * i];
+                v[i] = make_double2(v[i].x * w.x, v[i].y * w.y);
+            }
+        }
+        fft1024_f64(v, buf, lane, w2, tw);
+        // real split in place: X[k] = E + t_k O, X[N-k] = conj(E - t_k O) (as k_stft_f64)
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int k = lane + 64 * i;
+            if (k == 0) {
+                const double2 z0 = buf[0], zc = buf[physd(N / 2)];
+                buf[0] = make_double2(z0.x + z0.y, 0.0);
+                nyq[wave] = z0.x - z0.y;
+                buf[physd(N / 2)] = dconj(zc);
+            } else {
+                const double2 zk = buf[physd(k)], zn = buf[physd(N - k)];
+                const double2 e = make_double2(0.5 * (zk.x + zn.x), 0.5 * (zk.y - zn.y));
+                const double2 d = make_double2(0.5 * (zk.x - zn.x), 0.5 * (zk.y + zn.y));
+                const double2 to = dmul(tws[k], make_double2(d.y, -d.x));
+                buf[physd(k)] = dadd(e, to);
+                buf[physd(N - k)] = dconj(dsub(e, to));
+            }
+        }
+        lds_barrier();
+        request(tlv + gridDim.x);
+        // the tile's rows: eight lanes (frames) to a 128-byte line, 64 rows per instruction of the workgroup
+        {
+            const int f = tid & (FPB - 1), g = tid / FPB;
+            const double2* fb = frames + f * PITCH;
+            double2* o = out + (long long)clip * ROWS * TP + t0 + f;
+            if (t0 + f < T) {
+#pragma unroll 4
+                for (int r = g; r < ROWS; r += 64) {   // (64 = threads / frames: rows per instruction of the workgroup)
+                    double2 val;
+                    if (r < N) val = fb[physd(r)];
+                    else if (r == N) val = make_double2(nyq[f], 0.0);
+                    else val = dconj(fb[physd(W - r)]);
+                    typedef double f64x2 __attribute__((ext_vector_type(2)));
+                    f64x2 q;
+                    q.x = val.x;
+                    q.y = val.y;
+                    __builtin_nontemporal_store(q, reinterpret_cast<f64x2*>(o + (long long)r * TP));   // one 16-byte streaming store
+                }
+            }
+        }
+        lds_barrier();
+    }
+}
+
 // real(ifft(X)) of one frame per workgroup (zaf.py:223), W samples into the scratch, unscaled by 2 W
 __global__ __launch_bounds__(kThreadsBig) void k_ifft_frames_f64(
     const double2* __restrict__ spec, const double2* __restrict__ tw, const double2* __restrict__ tws, double* __restrict__ frames,
@@ -603,6 +781,24 @@ hipError_t launch_stft_f64(const zafx_plan& pl, const double* x, double2* out, i
     if (pl.bs_log2m > 0) return launch_bs_f64(pl, x, out, n_clips, n_samples, T, false);
     const long long blocks = (long long)n_clips * T;
     if (blocks <= 0) return hipSuccess;
+#ifndef ZAFX_F64_TILED
+#define ZAFX_F64_TILED 1
+#endif
+    if (ZAFX_F64_TILED && pl.W == 2048 && pl.layout == ZAFX_LAYOUT_FT && pl.prm.spectrum <= ZAFX_SPECTRUM_ONE_SIDED && reinterpret_cast<uintptr_t>(x) % 16 == 0 &&
+        reinterpret_cast<uintptr_t>(out) % 16 == 0) {
+        const int tiles = (T + kF64Frames - 1) / kF64Frames;
+        const long long total = (long long)tiles * n_clips;
+        if (total < (1LL << 31)) {
+            const size_t smem8 = (size_t)kF64Frames * kF64Pitch * sizeof(double2) + kF64Frames * sizeof(double);
+            const bool one = pl.prm.spectrum == ZAFX_SPECTRUM_ONE_SIDED;
+            auto k8 = one ? k_stft_ft8_f64<true> : k_stft_ft8_f64<false>;
+            if (hipError_t e = ensure_dynamic_lds(reinterpret_cast<const void*>(k8), pl.device, smem8); e != hipSuccess) return e;
+            pl.ran = "k_stft_ft8_f64";
+            hipLaunchKernelGGL(k8, dim3((unsigned)std::min<long long>(total, (long long)pl.n_cus * (kF64Frames <= 4 ? 2 : 1))), dim3(kF64Frames * 64), smem8, pl.stream, x, pl.d_window64, pl.d_tw64,
+                               pl.d_tws64, out, (long long)n_samples, pl.H, T, (int)row_pitch(pl, T), tiles, (int)total);
+            return hipGetLastError();
+        }
+    }
     const size_t smem = (size_t)pl.W * sizeof(double2);   // two buffers of W/2 points
     auto kern = k_stft_f64;
     if (hipError_t e = ensure_dynamic_lds(reinterpret_cast<const void*>(kern), pl.device, smem); e != hipSuccess) return e;

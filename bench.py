@@ -49,7 +49,7 @@ HBM_ACHIEVABLE_GBS = 6290.0   # same guide: measured-achievable copy rate
 F32_PEAK_TFLOPS = 157.3    # dense f32 vector / f32-input MFMA peak
 PLACEMENT_SURVEY = 6       # further allocations of the headline's row-strided output probed AFTER every timed region (reported, never timed)
 CONFIG_KINDS = ("istft", "mel", "mfcc", "mdct", "imdct", "cqt")   # SURVEY 8(a) a2 + BASELINE configs 3, 4, 5 (config 2 = the headline)
-EXTRA_KINDS = ("stft1", "stftmag", "istft1", "stft_offgrid", "mdct_offgrid", "stft4096", "stft4096_h1024", "istft4096", "mdct4096", "mel4096", "dct", "stft64", "mdct64")   # one-sided pair (8f rank 4) and geometries off the benchmark's grid
+EXTRA_KINDS = ("stft1", "stftmag", "istft1", "stft_offgrid", "mdct_offgrid", "stft4096", "stft4096_h1024", "istft4096", "mdct4096", "mel4096", "dct", "stft64", "mdct64", "istft_offgrid", "imdct_offgrid", "stftmag_offgrid")   # one-sided pair (8f rank 4) and geometries off the benchmark's grid
 
 
 def synth(seed, c, n):
@@ -81,11 +81,11 @@ def make_workload(kind, device, layout="FT"):
         B, N, T = 16384, 1024, 1
     if kind in ("stft64", "mdct64"):
         B = 256                   # the reference's own dtype (zaf.py:128, :139: float64 in, complex128 out): 40.1 / 16 B per sample
-    if kind == "stft_offgrid":
+    if kind in ("stft_offgrid", "istft_offgrid", "stftmag_offgrid"):
         N, T = 442024, 433        # one more frame than config 2: rows of 433 complex64 = 3464 B, off the 128-byte grid
     if kind == "stft4096":
         T = 217
-    if kind == "mdct_offgrid":
+    if kind in ("mdct_offgrid", "imdct_offgrid"):
         N, T = 442024, 433       # ceil(N / 1024) + 1 (zaf.py:1033): float32 rows of 1732 B
     if kind in ("mdct4096", "mel4096", "istft4096"):
         T = 217                   # mdct: ceil(N / 2048) + 1 (odd: rows off the line grid); mel: hop 2048
@@ -148,10 +148,10 @@ def make_workload(kind, device, layout="FT"):
         plan = zafx.stft_plan(ham, H, layout=layout, device=device, onesided=True)
         wl.update(plan=plan, d_in=d_x, n_in=N, bytes_per_launch=B * (4 * N + 8 * (W // 2 + 1) * T),
                   desc="Batched STFT, one-sided output (W/2+1, T): 1024 clips x 10 s, Hamming win=2048 hop=1024")
-    elif kind == "stftmag":   # the spectrogram the reference's examples compute (zaf.py:83), |X| of rows 0..W/2 as float32 (k_mel2, MODE 2)
+    elif kind in ("stftmag", "stftmag_offgrid"):   # the spectrogram the reference's examples compute (zaf.py:83), |X| of rows 0..W/2 as float32 (k_mel2, MODE 2)
         plan = zafx.stft_plan(ham, H, layout=layout, device=device, onesided="magnitude")
         wl.update(plan=plan, d_in=d_x, n_in=N, bytes_per_launch=B * (4 * N + 4 * (W // 2 + 1) * T),
-                  desc="Batched magnitude spectrogram |X| (W/2+1, T) float32: 1024 clips x 10 s, Hamming win=2048 hop=1024")
+                  desc=f"Batched magnitude spectrogram |X| (W/2+1, T) float32: 1024 clips x {T} frames, Hamming win=2048 hop=1024")
     elif kind == "istft1":
         fwd = zafx.stft_plan(ham, H, device=device, onesided=True)
         d_s = zafx.DeviceBuffer(fwd.out_shape(B, N), np.complex64, device)
@@ -162,7 +162,7 @@ def make_workload(kind, device, layout="FT"):
         plan = zafx.istft_plan(ham, H, device=device, onesided=True)
         wl.update(plan=plan, d_in=d_s, n_in=T, bytes_per_launch=B * (8 * (W // 2 + 1) * T + 4 * (T * H - (W - H))),
                   desc="Batched ISTFT from one-sided spectra: 1024 clips x 432 frames, win=2048 hop=1024")
-    elif kind == "istft":
+    elif kind in ("istft", "istft_offgrid"):   # (off the grid: T = 433, rows of 3464 bytes)
         fwd = zafx.stft_plan(ham, H, device=device)
         d_s = zafx.DeviceBuffer(fwd.out_shape(B, N), np.complex64, device)
         fwd.execute(d_x, d_s, B, N)
@@ -171,7 +171,7 @@ def make_workload(kind, device, layout="FT"):
         d_x.free()
         plan = zafx.istft_plan(ham, H, device=device)
         wl.update(plan=plan, d_in=d_s, n_in=T, bytes_per_launch=B * (8 * W * T + 4 * (T * H - (W - H))),
-                  desc="Batched ISTFT: 1024 clips x 432 frames, win=2048 hop=1024")
+                  desc=f"Batched ISTFT: 1024 clips x {T} frames, win=2048 hop=1024" + (" (rows off the 128-byte grid)" if T % 16 else ""))
     elif kind == "mdct":
         plan = zafx.mdct_plan(kbd, device=device)
         wl.update(plan=plan, d_in=d_x, n_in=N, bytes_per_launch=B * (4 * N + 4 * (W // 2) * T),
@@ -180,7 +180,7 @@ def make_workload(kind, device, layout="FT"):
         plan = zafx.mdct_plan(kbd, device=device)
         wl.update(plan=plan, d_in=d_x, n_in=N, bytes_per_launch=B * (4 * N + 4 * (W // 2) * T),
                   desc="Batched MDCT off the line grid: 1024 clips x 442024 samples, KBD win=2048, T = 433, compact (W/2,T) layout")
-    elif kind == "imdct":
+    elif kind in ("imdct", "imdct_offgrid"):
         fwd = zafx.mdct_plan(kbd, device=device)
         d_m = zafx.DeviceBuffer(fwd.out_shape(B, N), np.float32, device)
         fwd.execute(d_x, d_m, B, N)
@@ -189,7 +189,7 @@ def make_workload(kind, device, layout="FT"):
         d_x.free()
         plan = zafx.mdct_plan(kbd, device=device, inverse=True)
         wl.update(plan=plan, d_in=d_m, n_in=T, bytes_per_launch=B * (4 * (W // 2) * T + 4 * ((W // 2) * (T - 1) - 1)),
-                  desc="Batched IMDCT of the device MDCT of the same batch: 1024 clips x 432 frames, KBD win=2048")
+                  desc=f"Batched IMDCT of the device MDCT of the same batch: 1024 clips x {T} frames, KBD win=2048" + (" (rows off the 128-byte grid)" if T % 32 else ""))
     elif kind in ("mel", "mfcc"):
         fb = zafx.melfilterbank(FS, W, 128)
         rows = 128 if kind == "mel" else 20
@@ -400,10 +400,10 @@ def parity_probe(wl):
     kind, base, B = wl["kind"], wl["base"], wl["n_clips"]
     ham, kbd = orc.hamming_periodic(W), orc.kbd_window(W)
     x64 = base[0].astype(np.float64)
-    if kind in ("stft", "stft1", "stft_offgrid", "stftmag", "stft64"):
+    if kind in ("stft", "stft1", "stft_offgrid", "stftmag", "stftmag_offgrid", "stft64"):
         ref = orc.stft(x64, ham, H)
-        ref = ref[:W // 2 + 1] if kind in ("stft1", "stftmag") else ref
-        ref = np.abs(ref) if kind == "stftmag" else ref
+        ref = ref[:W // 2 + 1] if kind in ("stft1", "stftmag", "stftmag_offgrid") else ref
+        ref = np.abs(ref) if kind.startswith("stftmag") else ref
     elif kind == "stft4096":
         ref = orc.stft(x64, orc.hamming_periodic(4096), 2048)
     elif kind == "stft4096_h1024":
@@ -412,11 +412,11 @@ def parity_probe(wl):
         ref = orc.mdct(x64, orc.kbd_window(4096))
     elif kind == "mel4096":
         ref = orc.melspectrogram(x64, orc.hamming_periodic(4096), 2048, orc.melfilterbank(FS, 4096, 128))
-    elif kind in ("istft", "istft1", "istft4096"):
+    elif kind in ("istft", "istft1", "istft4096", "istft_offgrid"):
         ref = None   # (checked as a round trip below: the device spectrum is the input)
     elif kind in ("mdct", "mdct_offgrid", "mdct64"):
         ref = orc.mdct(x64, kbd)
-    elif kind == "imdct":
+    elif kind in ("imdct", "imdct_offgrid"):
         ref = None
     elif kind in ("mel", "mfcc"):
         fb = orc.melfilterbank(FS, W, 128)
@@ -428,11 +428,11 @@ def parity_probe(wl):
     first, last = wl["d_out"].download(0, 1)[0], wl["d_out"].download(B - 8, 1)[0]   # clip B-8 is a replica of clip 0
     out = {"replicas_bit_identical": bool(np.array_equal(first, last))}
     if ref is None:   # inverse kinds: resynthesis of the input (zaf.py:165-194 COLA; zaf.py:1098-1109 TDAC)
-        n = 441000 if kind.startswith("istft") else 440999
+        n = len(x64) if kind.startswith("istft") else len(x64) - 1
         d = float(np.max(np.abs(first[:n].astype(np.float64) - x64[:n])))
         tol = 1e-5
         out.update({"roundtrip_max_abs_residual": d, "tolerance": tol, "within_tolerance": bool(d < tol)})
-        if kind == "imdct":
+        if kind.startswith("imdct"):
             refy = orc.imdct(orc.mdct(x64, kbd), kbd)
             e = float(np.max(np.abs(first - refy)) / np.max(np.abs(refy)))
             out.update({"max_rel_err_vs_numpy": e, "within_tolerance": bool(d < tol and e <= 1e-5)})

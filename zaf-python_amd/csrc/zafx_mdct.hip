@@ -850,8 +850,10 @@ __global__ __launch_bounds__(NSLOT * fft_threads(LOG2NF, LOG2E)) void k_imdct(
         for (int i = tid; i < 4 * NF; i += NT) win_s[i] = win[i];
     lds_barrier();
     const float gain = 2.f / (float)M;
-    const bool vec4 = LAYOUT == ZAFX_LAYOUT_FT && FPB % 4 == 0 && NT % (FPB / 4) == 0 && NF >= NT / (FPB / 4) && TP % 4 == 0 &&
-                      reinterpret_cast<uintptr_t>(coefs) % 16 == 0;
+    // (buffer loads: 16 bytes per lane at ANY 4-byte alignment -- rows off the line grid, T % 4 != 0, took the 4-byte path before, four times
+    // the load instructions and no prefetch: T = 433 1.31 ms against 0.76 at T = 432 -- and a piece that runs past the clip's last row reads 0)
+    const bool vec4 = LAYOUT == ZAFX_LAYOUT_FT && FPB % 4 == 0 && NT % (FPB / 4) == 0 && NF >= NT / (FPB / 4) && (long long)M * TP * 4 < (1LL << 32) &&
+                      reinterpret_cast<uintptr_t>(coefs) % 4 == 0;
 
     // 16-byte gathers (vec4): a lane reads 4 adjacent frames of a row (8 lanes per 128-B run; the CU's vector-memory queue
     // holds ~64 wave-level loads whatever their width, 4-byte lanes leave it carrying 256 B per entry).  The rows of the
@@ -880,12 +882,12 @@ __global__ __launch_bounds__(NSLOT * fft_threads(LOG2NF, LOG2E)) void k_imdct(
         const int t = tile_n * FPB + fs4;
         if (t < T && fs4 + 3 >= first_needed_n) {   // pitch % 4 == 0: the four frames lie in the row (those past T are not used)
             pre_ok = true;
-            const float* cp = coefs + (long long)(unit_n / segs) * M * TP + t;
+            const __amdgpu_buffer_rsrc_t rs = make_rsrc(coefs + (long long)(unit_n / segs) * M * TP, (unsigned)((long long)M * TP * 4));
 #pragma unroll
             for (int i = 0; i < KI; ++i) {
                 const int m = mq4 + i * MSTEP;
-                if (part != 1) pre_re[i] = *reinterpret_cast<const float4*>(cp + (long long)(2 * m) * TP);
-                if (part != 0) pre_im[i] = *reinterpret_cast<const float4*>(cp + (long long)(M - 1 - 2 * m) * TP);
+                if (part != 1) pre_re[i] = buf_load_f32x4(rs, (int)(((unsigned)(2 * m) * (unsigned)TP + (unsigned)t) * 4u));
+                if (part != 0) pre_im[i] = buf_load_f32x4(rs, (int)(((unsigned)(M - 1 - 2 * m) * (unsigned)TP + (unsigned)t) * 4u));
             }
         }
     };

@@ -2267,7 +2267,9 @@ static hipError_t run_istft_fat(const zafx_plan& pl, const float2* spec, float* 
     // 16-byte gathers (two adjacent frames per lane) when the rows allow it; see the kernel
     constexpr bool can_vec = LOG2N >= 8 && !TF;
     const int TP = (int)row_pitch(pl, T);
-    const bool vec = can_vec && TP % 2 == 0 && reinterpret_cast<uintptr_t>(spec) % 16 == 0;
+    // (buffer loads take 16 bytes at any 8-byte offset: odd row pitches -- T = 433: 2.46 ms on the 8-byte form against 1.80 at T = 432 -- ride the
+    // 16-byte form too; a pair whose second frame lies past T reads the next row's first element, or 0 past the clip, and that frame is never used)
+    const bool vec = can_vec && reinterpret_cast<uintptr_t>(spec) % 8 == 0;
     // sweeps streamed together: 8 loads per wave in flight is the measured optimum (profiles/r01_notes.md);
     // a one-sided sweep has 2 loads instead of 4
     constexpr int D1 = TF ? ZAFX_ISTFT_TF_DEPTH : ONE ? 4 : 2, D2 = ONE ? 4 : 1;

@@ -199,6 +199,12 @@ int zafx_cqt_max_bins(int fft_length, int* n_bins);
  * Enqueued on the plan's stream, so it is ordered before a following zafx_execute on that plan. */
 int zafx_pcm_to_float(zafx_plan* plan, const void* d_pcm, void* d_out, int64_t n_clips, int64_t n_frames,
                       int n_channels, int sample_bytes);
+/* The transform of integer PCM that is already on the device, in one call: d_pcm (n_clips, n_frames, n_channels) interleaved int16 / int32 ->
+ * what zafx_execute writes for the normalised mono signal (zaf.py:1202 x / 2^(bits-1), zaf.py:65 mean over the channels, then the plan's
+ * transform).  Plans whose kernel takes the integers in its own loads -- int16, one or two channels, into ZAFX_MEL / ZAFX_MFCC and the
+ * |X| / |X|^2 kinds of ZAFX_STFT at window_length 2048 -- read 2 bytes per sample and channel of HBM instead of 6 + 4; every other
+ * plan converts into a float32 staging array it owns (zafx_pcm_to_float) and runs zafx_execute on that.  Kinds as zafx_run_host_pcm. */
+int zafx_execute_pcm(zafx_plan* plan, const void* d_pcm, void* d_out, int64_t n_clips, int64_t n_frames, int n_channels, int sample_bytes);
 
 /* zafx_run_host for integer PCM: h_pcm = (n_clips, n_frames, n_channels) interleaved int16 / int32 as wavread's source
  * holds them (zaf.py:1187-1204); every chunk crosses PCIe as integers (2 or 4 bytes per sample and channel instead of 4 per

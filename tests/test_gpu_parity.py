@@ -1097,6 +1097,46 @@ def test_spectrogram_kinds_on_rows_of_even_pitch(zafx, n, clips):
     d_x.free()
 
 
+@pytest.mark.parametrize("dtype,channels,n,clips", [(np.int16, 1, 1024 * 40, 3), (np.int16, 2, 1024 * 40, 3), (np.int16, 1, 30001, 2), (np.int16, 2, 30001, 2),
+                                                    (np.int16, 1, 441000, 40), (np.int32, 1, 20000, 2), (np.int16, 5, 20000, 2), (np.int16, 1, 1500, 1)])
+def test_execute_pcm_device_resident(zafx, dtype, channels, n, clips):
+    """Verdict r4 item 7: integer PCM on the device straight into the transform (Plan.execute_pcm).  mel, mfcc and the |X| / |X|^2 kinds at W = 2048
+    read int16 (one or two channels) in k_mel2's own loads; the result is BIT-IDENTICAL to normalising first (zaf.py:1202, :65: x / 2^15 and the
+    channel mean are exact in float32) -- aligned and odd clip lengths (the sample-by-sample path), more tiles than workgroups.  int32 and other
+    channel counts, and every other kind, convert into the plan's staging array first: same numbers as the two-step form."""
+    rng = np.random.default_rng([83, channels, n])
+    info = np.iinfo(dtype)
+    pcm = rng.integers(info.min, info.max, size=(clips, n, channels), endpoint=True).astype(dtype)
+    pcm[0, :7] = info.min
+    pcm[0, 7:14] = info.max
+    w, kbd = zafx.hamming(2048), zafx.kaiser_bessel_derived(2048)
+    fb = zafx.melfilterbank(44100, 2048, 128)
+    plans = [("mel", zafx.mel_plan(w, 1024, fb)), ("mfcc", zafx.mel_plan(w, 1024, fb, 20)), ("mag", zafx.stft_plan(w, 1024, onesided="magnitude")),
+             ("pow", zafx.stft_plan(w, 1024, onesided="power")), ("stft", zafx.stft_plan(w, 1024)), ("mdct", zafx.mdct_plan(kbd))]
+    d_pcm = zafx.DeviceBuffer.from_host(pcm)
+    d_x = zafx.DeviceBuffer((clips, n), np.float32)
+    direct = dtype == np.int16 and channels in (1, 2)
+    x64 = (pcm[:1].astype(np.float64) / float(-info.min)).mean(axis=2)[0]
+    for name, plan in plans:
+        d_a = zafx.DeviceBuffer(plan.out_shape(clips, n), plan.out_dtype)
+        d_b = zafx.DeviceBuffer(plan.out_shape(clips, n), plan.out_dtype)
+        plan.pcm_to_float(d_pcm, d_x, clips, n, channels)
+        plan.execute(d_x, d_a, clips, n)
+        plan.sync()
+        two_step = d_a.download()
+        plan.execute_pcm(d_pcm, d_b, clips, n, channels)
+        plan.sync()
+        assert plan.last_kernel == ("k_mel2" if name in ("mel", "mfcc", "mag", "pow") else plan.last_kernel)
+        got = d_b.download()
+        assert np.array_equal(got, two_step), (name, direct)
+        if name == "mel":
+            assert relerr(got[0], orc.melspectrogram(x64, w, 1024, fb)) <= TOL_FB
+        d_a.free()
+        d_b.free()
+    d_pcm.free()
+    d_x.free()
+
+
 @pytest.mark.parametrize("dtype,channels", [(np.int16, 1), (np.int32, 2)])
 def test_run_host_pcm_on_a_dct_plan(zafx, dtype, channels):
     """the ZAFX_DCT branch of zafx_run_host_pcm -- integer vectors normalised (zaf.py:1202) and averaged over their

@@ -1020,6 +1020,7 @@ int zafx_plan_destroy(zafx_plan* pl) {
     if (pl->d_dct64) (void)hipFree(pl->d_dct64);
     if (pl->d_values64) (void)hipFree(pl->d_values64);
     if (pl->d_bhat64) (void)hipFree(pl->d_bhat64);
+    if (pl->d_pcm_float) (void)hipFree(pl->d_pcm_float);
     if (pl->d_bs_chirp) (void)hipFree(pl->d_bs_chirp);
     if (pl->d_bs_bhat) (void)hipFree(pl->d_bs_bhat);
     free_band(pl->fb);
@@ -1313,6 +1314,45 @@ int zafx_plan_clip_bytes(const zafx_plan* pl, int64_t n_in, int64_t* in_bytes, i
 // pcm_bytes > 0: h_in holds interleaved integer PCM (n_clips, n_in, pcm_channels) of pcm_bytes per sample; every chunk is uploaded as it
 // is (2 or 4 bytes per sample and channel cross PCIe) and normalised + mixed down on the device (k_pcm_to_float on the plan's stream, in front
 // of the transform) -- zaf.py:1202 and :65 -- into the float32 staging buffer the transform reads.
+// One transform of integer PCM that is already on the device: kinds whose kernel reads int16 itself (k_mel2: mel, mfcc, |X| / |X|^2 at W = 2048, mono or
+// stereo) get the integers; everything else goes through wavread's normalisation and the channel mean (k_pcm_to_float) into `staging` first.
+static int execute_pcm(zafx_plan* pl, const void* d_pcm, void* d_out, int64_t n_clips, int64_t n_frames, int n_channels, int sample_bytes, float* staging) {
+    if (pcm_direct_ok(*pl, n_frames, n_channels, sample_bytes) && reinterpret_cast<uintptr_t>(d_pcm) % 8 == 0) {
+        pl->call_pcm = n_channels;
+        const int rc = zafx_execute(pl, d_pcm, d_out, n_clips, n_frames);
+        pl->call_pcm = 0;
+        return rc;
+    }
+    if (!staging) {
+        const size_t need = (size_t)std::max<int64_t>(n_clips * n_frames * 4, 1);
+        if (pl->pcm_float_bytes < need) {
+            if (pl->d_pcm_float) ZAFX_HIP(hipFree(pl->d_pcm_float));
+            pl->d_pcm_float = nullptr, pl->pcm_float_bytes = 0;
+            ZAFX_HIP(hipMalloc(&pl->d_pcm_float, need));
+            pl->pcm_float_bytes = need;
+        }
+        staging = (float*)pl->d_pcm_float;
+    }
+    if (n_clips * n_frames > 0) ZAFX_HIP(launch_pcm_to_float(pl->stream, d_pcm, staging, n_clips * n_frames, n_channels, sample_bytes));
+    return zafx_execute(pl, staging, d_out, n_clips, n_frames);
+}
+
+int zafx_execute_pcm(zafx_plan* pl, const void* d_pcm, void* d_out, int64_t n_clips, int64_t n_frames, int n_channels, int sample_bytes) {
+    if (!pl) return fail_msg("null plan");
+    if (n_clips < 0 || n_frames < 0) return fail_msg("negative size");
+    if (n_channels < 1 || n_channels > 64) return fail_msg("n_channels must be in [1, 64]");
+    if (sample_bytes != 2 && sample_bytes != 4) return fail_msg("sample_bytes must be 2 (int16) or 4 (int32)");
+    if (pl->prm.precision != ZAFX_PRECISION_F32) return fail_msg("PCM ingest feeds the float32 plans");
+    switch (pl->kind) {
+        case ZAFX_STFT: case ZAFX_MDCT: case ZAFX_MEL: case ZAFX_MFCC: case ZAFX_CQT: case ZAFX_CHROMA: case ZAFX_DCT: break;
+        default: return fail_msg("PCM ingest feeds the plans that take samples (stft, mdct, mel, mfcc, cqt, chroma, dct)");
+    }
+    if (n_clips == 0) return 0;
+    if (!d_pcm || !d_out) return fail_msg("null device pointer");
+    ZAFX_HIP(hipSetDevice(pl->device));
+    return execute_pcm(pl, d_pcm, d_out, n_clips, n_frames, n_channels, sample_bytes, nullptr);
+}
+
 static int run_host_impl(zafx_plan* pl, const void* h_in, void* h_out, int64_t n_clips, int64_t n_in, int64_t chunk_clips, int pcm_channels, int pcm_bytes) {
     if (!pl) return fail_msg("null plan");
     if (n_clips < 0 || n_in < 0) return fail_msg("negative size");
@@ -1389,11 +1429,8 @@ static int run_host_impl(zafx_plan* pl, const void* h_in, void* h_out, int64_t n
         if (e == hipSuccess && sets == 2) e = hipEventRecord(ev_up[l], s_up);
         if (e == hipSuccess && sets == 2) e = hipStreamWaitEvent(s_k, ev_up[l], 0);
         if (e != hipSuccess) { ret = fail("zafx_run_host: upload", e); break; }
-        if (pcm_bytes > 0 && count * n_in > 0) {
-            e = launch_pcm_to_float(s_k, pl->lane_pcm[l], (float*)pl->lane_in[l], count * n_in, pcm_channels, pcm_bytes);
-            if (e != hipSuccess) { ret = fail("zafx_run_host_pcm: convert", e); break; }
-        }
-        ret = zafx_execute(pl, pl->lane_in[l], pl->lane_out[l], count, n_in);   // (on pl->stream = s_k)
+        if (pcm_bytes > 0) ret = execute_pcm(pl, pl->lane_pcm[l], pl->lane_out[l], count, n_in, pcm_channels, pcm_bytes, (float*)pl->lane_in[l]);
+        else ret = zafx_execute(pl, pl->lane_in[l], pl->lane_out[l], count, n_in);   // (on pl->stream = s_k)
         if (ret) break;
         if (sets == 2) e = hipEventRecord(ev_k[l], s_k);
         if (e == hipSuccess && sets == 2) e = hipStreamWaitEvent(s_down, ev_k[l], 0);

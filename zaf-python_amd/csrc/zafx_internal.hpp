@@ -153,6 +153,9 @@ struct zafx_plan {
     double* d_dct64 = nullptr;     // [n_coefs][n_filters]
     double2* d_values64 = nullptr; // CQT kernel values of a float64 plan (complex128)
     int bs_log2m = 0;              // > 0: window that is not a power of two -- Bluestein convolution length 2^bs_log2m (zafx_f64.hip, zafx_bs32.hip)
+    mutable int call_pcm = 0;      // set by zafx_execute_pcm around a launch whose kernel reads int16 itself (1 mono, 2 stereo; pcm_direct_ok)
+    void* d_pcm_float = nullptr;   // zafx_execute_pcm's float32 staging for the kinds that do not (grow-only)
+    size_t pcm_float_bytes = 0;
     long long dct_den2 = 0;        // ZAFX_DCT on the chirp-z form: 2 D, the denominator of its chirp exp(-i pi j^2 / (2 D)) (k_dct_bs32)
     float2* d_bs_chirp = nullptr;  // float32 Bluestein plans: c[n] = exp(-i pi n^2 / W), n < W
     float2* d_bs_bhat = nullptr;   // ... and FFT_M of the wrapped conjugate chirp
@@ -215,6 +218,7 @@ inline bool mel_takes_wide_route(const zafx_plan& pl) { return pl.log2nf >= 11 |
 bool mel_band_usable(const zafx_plan& pl, const float* x, int64_t n_clips, int64_t n_samples, int T);   // W = 4096: the fused two-band kernel k_mel_ft16b (zafx_stft.hip)
 hipError_t launch_mel_band(const zafx_plan& pl, const float* x, float* out, int64_t n_clips, int64_t n_samples, int T);
 hipError_t launch_cqt(const zafx_plan& pl, const float* x, float* out, int64_t n_clips, int64_t n_samples, int T);
+bool pcm_direct_ok(const zafx_plan& pl, int64_t n_frames, int n_channels, int sample_bytes);   // zafx_mel.hip
 bool launch_spec2(const zafx_plan& pl, const float* x, float* out, int64_t n_clips, int64_t n_samples, int T, hipError_t& err);   // zafx_mel.hip: |X| / |X|^2 rows of an STFT plan on k_mel2
 hipError_t launch_linear(const zafx_plan& pl, const float* x, float* y, int64_t n_clips);
 hipError_t launch_dct(const zafx_plan& pl, const float* x, float* y, int64_t n_rows);   // zafx_dct.hip: dct / dst I-IV on the FFT core

@@ -582,7 +582,11 @@ __global__ __launch_bounds__(mel_threads(LOG2N, LOG2E), kMelFpb == 8 ? 2 * mel_t
 // the reference layout): the same transforms and levels, and in the product's place the tile's rows 0 .. N leave from the levels in LDS
 // (thread = frame tid & 15 x rows (tid >> 4) + 64 j: 64-byte runs) -- on k_stft_ft16's 8 fat waves these kinds ran at 3.2 TB/s (1.12 ms
 // per 1024 x 10 s), bound by the transforms of two frames per wave, not by their 3.6 GB.
-template <bool ALIGNED, int MODE>
+// PCM: what `x` holds (wavread's normalisation x / 2^15 and the channel mean, zaf.py:1202 and :65, inside the loads) --
+// 0 float32 samples; 1 int16 mono (n_samples 2-byte samples per clip: 8 bytes per lane and load instead of 16); 2 int16 stereo
+// (n_samples 4-byte frames per clip: the float32 form's loads, both channels added on the way into the window multiply).  The factor
+// 2^-15 (2^-16: the mean of two channels) is a power of two and rides in the window.
+template <bool ALIGNED, int MODE, int PCM = 0>
 __global__ __launch_bounds__(1024, 1) void k_mel2(const float* __restrict__ x, const float* __restrict__ win, const float2* __restrict__ twp,
                                                    const float2* __restrict__ tws, const float* __restrict__ fb_pack, const int4* __restrict__ fb_whole,
                                                    const float* __restrict__ dct2, const int* __restrict__ owner2, float* __restrict__ out, long long n_samples, int hop,
@@ -602,7 +606,13 @@ __global__ __launch_bounds__(1024, 1) void k_mel2(const float* __restrict__ x, c
     float* fall = reinterpret_cast<float*>(frames);
     const int tid = threadIdx.x;
     for (int i = tid; i < C::TW; i += NT) tw_l[i] = twp[i];
-    for (int i = tid; i < N; i += NT) win_s[i] = reinterpret_cast<const float2*>(win)[(i & ~63) + row_pair_index(i & 63)];   // lane order: win_s[64 i + lane]
+    {
+        const float pcm_scale = PCM == 1 ? 1.f / 32768.f : PCM == 2 ? 1.f / 65536.f : 1.f;
+        for (int i = tid; i < N; i += NT) {   // lane order: win_s[64 i + lane]
+            const float2 w = reinterpret_cast<const float2*>(win)[(i & ~63) + row_pair_index(i & 63)];
+            win_s[i] = make_float2(w.x * pcm_scale, w.y * pcm_scale);
+        }
+    }
     for (int i = tid; i <= N / 2; i += NT) tws_s[i] = tws[i];
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const bool xcd = ZAFX_XCD_ORDER && gridDim.x % 8 == 0;
@@ -634,8 +644,30 @@ __global__ __launch_bounds__(1024, 1) void k_mel2(const float* __restrict__ x, c
         const int tl = xcd ? xcd_order(tlv, total_tiles) : tlv;
         const int clip = tl / tiles, tile = tl % tiles;
         const int t = tile * FPB + wave;
-        const float* xc = x + (long long)clip * n_samples;
         const long long s0 = (long long)t * hop - N;
+        if constexpr (PCM == 1) {
+            // int16 mono: a point (two samples) is one dword; xr[2 i] = the dwords of the points n, n + 1 of load i (xr[2 i + 1] is not used)
+            const short* xc = reinterpret_cast<const short*>(x) + (long long)clip * n_samples;
+            if (ALIGNED && t < T && s0 >= 0 && s0 + W <= n_samples) {   // interior frame (uniform)
+                frx = make_rsrc(xc, (unsigned)std::min<long long>(n_samples * 2, 0xfffffffcLL));
+                const int fvoff = ((int)s0 + 2 * (p & ~1)) * 2 + (p & 1) * (E / 2 * P * 4);
+#pragma unroll
+                for (int i = 0; i < E / 2; ++i) xr[2 * i] = buf_load_f32x2(frx, fvoff, i * P * 4);
+                return;
+            }
+            const int nb = (p & ~1) + (p & 1) * (E / 2 * P);
+#pragma unroll
+            for (int i = 0; i < E; ++i) {   // a frame that touches the clip's ends: sample by sample, packed the way the loads deliver them
+                const long long s = s0 + 2 * (nb + (i >> 1) * P + (i & 1));
+                const unsigned lo = (t < T && s >= 0 && s < n_samples) ? (unsigned short)xc[s] : 0u;
+                const unsigned hi = (t < T && s + 1 >= 0 && s + 1 < n_samples) ? (unsigned short)xc[s + 1] : 0u;
+                const float bits = __builtin_bit_cast(float, lo | hi << 16);
+                if (i & 1) xr[i - 1].y = bits;
+                else xr[i].x = bits;
+            }
+            return;
+        }
+        const float* xc = x + (long long)clip * n_samples;   // (PCM == 2: a "sample" is one frame of two int16, moved as the 4 bytes it is)
         if (ALIGNED && t < T && s0 >= 0 && s0 + W <= n_samples) {   // interior frame (uniform)
             frx = make_rsrc(xc, (unsigned)std::min<long long>(n_samples * 4, 0xfffffffcLL));
             const int fvoff = ((int)s0 + 2 * (p & ~1)) * 4 + (p & 1) * (E / 2 * P * 8);
@@ -662,9 +694,22 @@ __global__ __launch_bounds__(1024, 1) void k_mel2(const float* __restrict__ x, c
         float2 v[E];
 #pragma unroll
         for (int i = 0; i < E / 2; ++i) {   // the lane's own points i and i + 8 out of the pair's two loads
-            row_pair_unpack(xr[2 * i], xr[2 * i + 1]);
-            v[i] = mul_elem(xr[2 * i], lds_ld(win_s + lane + i * P));
-            v[i + E / 2] = mul_elem(xr[2 * i + 1], lds_ld(win_s + lane + (i + E / 2) * P));
+            float2 qa = xr[2 * i], qb = xr[2 * i + 1];
+            if constexpr (PCM != 0) {   // integers -> floats (the scale is in the window)
+                auto lo16 = [](float f) { return (float)(short)(__builtin_bit_cast(int, f) & 0xffff); };
+                auto hi16 = [](float f) { return (float)(__builtin_bit_cast(int, f) >> 16); };
+                auto sum16 = [](float f) { const int d = __builtin_bit_cast(int, f); return (float)((int)(short)(d & 0xffff) + (d >> 16)); };
+                if constexpr (PCM == 1) {
+                    qb = make_float2(lo16(qa.y), hi16(qa.y));
+                    qa = make_float2(lo16(qa.x), hi16(qa.x));
+                } else {
+                    qa = make_float2(sum16(qa.x), sum16(qa.y));
+                    qb = make_float2(sum16(qb.x), sum16(qb.y));
+                }
+            }
+            row_pair_unpack(qa, qb);
+            v[i] = mul_elem(qa, lds_ld(win_s + lane + i * P));
+            v[i + E / 2] = mul_elem(qb, lds_ld(win_s + lane + (i + E / 2) * P));
         }
 #ifdef ZAFX_PROF
         asm volatile("" :: "v"(v[0].x), "v"(v[15].y));
@@ -1009,7 +1054,9 @@ static hipError_t run_mel(const zafx_plan& pl, const float* x, float* out, int64
             using C = FftCfg<10, 4>;
             const size_t smem = (size_t)(16 * C::PITCH + C::TW + C::N + C::N / 2 + 1) * 8 + kMel2Slots * 1024;
             static_assert((size_t)(16 * C::PITCH + C::TW + C::N + C::N / 2 + 1) * 8 + kMel2Slots * 1024 <= (size_t)kMaxLdsBytes, "k_mel2: LDS");
-            auto k2 = mfcc ? k_mel2<ALIGNED, 1> : k_mel2<ALIGNED, 0>;
+            const int pcm = pl.call_pcm;   // (zafx_execute_pcm: the input is int16, mono or stereo; pcm_direct_ok vouches for the alignment ALIGNED stands for)
+            auto k2 = pcm == 1 ? (mfcc ? k_mel2<ALIGNED, 1, 1> : k_mel2<ALIGNED, 0, 1>) : pcm == 2 ? (mfcc ? k_mel2<ALIGNED, 1, 2> : k_mel2<ALIGNED, 0, 2>)
+                                                                                                   : (mfcc ? k_mel2<ALIGNED, 1> : k_mel2<ALIGNED, 0>);
             if (hipError_t e = ensure_dynamic_lds(reinterpret_cast<const void*>(k2), pl.device, smem); e != hipSuccess) return e;
             const int tiles2 = (T + 15) / 16;
             const long long total2 = (long long)tiles2 * n_clips;
@@ -1063,9 +1110,12 @@ bool launch_spec2(const zafx_plan& pl, const float* x, float* out, int64_t n_cli
     if (!ZAFX_SPEC2 || pl.log2nf != 10 || pl.log2e != 4 || pl.layout != ZAFX_LAYOUT_FT || kMelFpb != 16 || kMelThreads != 1024 || !pl.d_tw_pass || !pl.d_tw_aux) return false;
     if (pl.prm.spectrum != ZAFX_SPECTRUM_MAGNITUDE && pl.prm.spectrum != ZAFX_SPECTRUM_POWER) return false;
     if (n_samples >= (1LL << 29)) return false;
+    const int pcm = pl.call_pcm;
     const bool aligned = (n_samples % 2 == 0) && (pl.H % 2 == 0) && (reinterpret_cast<uintptr_t>(x) % 8 == 0);
     const bool power = pl.prm.spectrum == ZAFX_SPECTRUM_POWER;
     auto k2 = aligned ? (power ? k_mel2<true, 3> : k_mel2<true, 2>) : (power ? k_mel2<false, 3> : k_mel2<false, 2>);
+    if (pcm == 1) k2 = aligned ? (power ? k_mel2<true, 3, 1> : k_mel2<true, 2, 1>) : (power ? k_mel2<false, 3, 1> : k_mel2<false, 2, 1>);
+    if (pcm == 2) k2 = aligned ? (power ? k_mel2<true, 3, 2> : k_mel2<true, 2, 2>) : (power ? k_mel2<false, 3, 2> : k_mel2<false, 2, 2>);
     const size_t smem = (size_t)(16 * C::PITCH + C::TW + C::N + C::N / 2 + 1) * 8 + kMel2Slots * 1024;
     err = ensure_dynamic_lds(reinterpret_cast<const void*>(k2), pl.device, smem);
     if (err != hipSuccess) return true;
@@ -1078,6 +1128,18 @@ bool launch_spec2(const zafx_plan& pl, const float* x, float* out, int64_t n_cli
                        (const float*)nullptr, (const int*)nullptr, out, (long long)n_samples, pl.H, T, (int)row_pitch(pl, T), tiles, (int)total, 0, 0, pl.layout);
     err = hipGetLastError();
     return true;
+}
+
+// Does a call with int16 PCM (n_channels = 1 or 2) of this plan run on k_mel2, which takes the integers in its loads?  (Everything else converts
+// into a float32 staging array first: zafx_execute_pcm.)
+bool pcm_direct_ok(const zafx_plan& pl, int64_t n_frames, int n_channels, int sample_bytes) {
+    if (sample_bytes != 2 || (n_channels != 1 && n_channels != 2) || pl.prm.precision != ZAFX_PRECISION_F32 || pl.bs_log2m > 0) return false;
+    if (pl.log2nf != 10 || pl.log2e != 4 || kMelFpb != 16 || kMelThreads != 1024 || n_frames >= (1LL << 29)) return false;
+    if (pl.kind == ZAFX_MEL || pl.kind == ZAFX_MFCC)
+        return ZAFX_MEL2 && !mel_takes_wide_route(pl) && pl.fb.whole_ok && pl.fb.n_waves == 16 && (pl.kind == ZAFX_MEL || pl.dct.dct2_ok);
+    if (pl.kind == ZAFX_STFT)
+        return ZAFX_SPEC2 && pl.layout == ZAFX_LAYOUT_FT && (pl.prm.spectrum == ZAFX_SPECTRUM_MAGNITUDE || pl.prm.spectrum == ZAFX_SPECTRUM_POWER);
+    return false;
 }
 
 const char* mel_kernel_name() { return "k_mel"; }

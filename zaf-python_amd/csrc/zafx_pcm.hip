@@ -3,8 +3,8 @@
 // The step in front of the hot path in every example of the reference:
 //   audio_signal, fs = zaf.wavread(file)        zaf.py:1199-1204  (x / 2^(8*itemsize - 1))
 //   audio_signal = np.mean(audio_signal, 1)     zaf.py:65
-// HBM-bound elementwise kernel: 2-4 B per channel sample in, 4 B per frame out; grid-stride,
-// 4 frames per thread so that mono int16 reads are 8 B and the float stores 16 B per lane.
+// HBM-bound elementwise kernel: 2-4 B per channel sample in, 4 B per frame out; grid-stride, one frame per thread and pass (scalar
+// reads of its channels, a 4-byte store).  The kinds whose kernel takes int16 in its own loads (k_mel2, zafx_execute_pcm) do not come here.
 #include "zafx_internal.hpp"
 
 namespace zafx {

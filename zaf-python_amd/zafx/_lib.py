@@ -79,6 +79,7 @@ SYMBOLS = {
     "zafx_plan_last_kernel_name": (_i, [_vp, ctypes.c_char_p, _sz]),
     "zafx_cqt_max_bins": (_i, [_i, ctypes.POINTER(_i)]),
     "zafx_pcm_to_float": (_i, [_vp, _vp, _vp, _i64, _i64, _i, _i]),
+    "zafx_execute_pcm": (_i, [_vp, _vp, _vp, _i64, _i64, _i, _i]),
     "zafx_comm_unique_id": (_i, [_vp]),
     "zafx_comm_create": (_i, [ctypes.POINTER(_vp), _i, _i, _i, _vp]),
     "zafx_comm_destroy": (_i, [_vp]),

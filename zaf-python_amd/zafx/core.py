@@ -343,6 +343,14 @@ class Plan:
         _lib.check(_lib.load().zafx_pcm_to_float(self.handle, d_pcm.ptr, d_out.ptr, int(n_clips), int(n_frames),
                                                 int(n_channels), d_pcm.dtype.itemsize), "zafx_pcm_to_float")
 
+    def execute_pcm(self, d_pcm, d_out, n_clips, n_frames, n_channels=1):
+        """execute() on integer PCM that is already on the device: d_pcm = (clips, frames[, channels]) int16 / int32 interleaved.  mel, mfcc
+        and the |X| / |X|^2 spectrogram kinds at window 2048 read int16 (one or two channels) in their own loads -- 2 bytes per sample and
+        channel of HBM traffic instead of the pre-pass's 6 + 4 --, every other plan converts into a staging array it owns first
+        (zafx_execute_pcm; zaf.py:1202 and :65 either way)."""
+        _lib.check(_lib.load().zafx_execute_pcm(self.handle, d_pcm.ptr, d_out.ptr, int(n_clips), int(n_frames), int(n_channels),
+                                               d_pcm.dtype.itemsize), "zafx_execute_pcm")
+
     def timer_start(self):
         _lib.check(_lib.load().zafx_timer_start(self.handle), "zafx_timer_start")
 

@@ -1101,7 +1101,7 @@ def test_spectrogram_kinds_on_rows_of_even_pitch(zafx, n, clips):
                                                     (np.int16, 1, 441000, 40), (np.int32, 1, 20000, 2), (np.int16, 5, 20000, 2), (np.int16, 1, 1500, 1)])
 def test_execute_pcm_device_resident(zafx, dtype, channels, n, clips):
     """Verdict r4 item 7: integer PCM on the device straight into the transform (Plan.execute_pcm).  mel, mfcc and the |X| / |X|^2 kinds at W = 2048
-    read int16 (one or two channels) in k_mel2's own loads; the result is BIT-IDENTICAL to normalising first (zaf.py:1202, :65: x / 2^15 and the
+    read int16 (one or two channels) in k_mel2's own loads, the MDCT at W = 2048 in k_mdct_ft32's (clips of a multiple of four frames); the result is BIT-IDENTICAL to normalising first (zaf.py:1202, :65: x / 2^15 and the
     channel mean are exact in float32) -- aligned and odd clip lengths (the sample-by-sample path), more tiles than workgroups.  int32 and other
     channel counts, and every other kind, convert into the plan's staging array first: same numbers as the two-step form."""
     rng = np.random.default_rng([83, channels, n])
@@ -1126,7 +1126,7 @@ def test_execute_pcm_device_resident(zafx, dtype, channels, n, clips):
         two_step = d_a.download()
         plan.execute_pcm(d_pcm, d_b, clips, n, channels)
         plan.sync()
-        assert plan.last_kernel == ("k_mel2" if name in ("mel", "mfcc", "mag", "pow") else plan.last_kernel)
+        assert plan.last_kernel == {"mel": "k_mel2", "mfcc": "k_mel2", "mag": "k_mel2", "pow": "k_mel2", "mdct": "k_mdct_ft32"}.get(name, plan.last_kernel)
         got = d_b.download()
         assert np.array_equal(got, two_step), (name, direct)
         if name == "mel":

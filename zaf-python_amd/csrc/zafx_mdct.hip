@@ -153,7 +153,10 @@ struct MdctPCfg {
 // previous tile (32 VGPRs, instead of the resident window quadruples), and for a row whose run starts `a` floats into a line the
 // lanes tp < 16 - a / 2 store the current pair at frame t0 + 2 tp, the others the carried pair at frame t0 - 32 + 2 tp: sixteen
 // lanes, one whole line.  segs / seg_tiles / units: the segment walk (carry_segments).
-template <int LOG2NF, int LOG2E, bool ALIGNED, int NSLOT, bool TFOUT = false, bool CARRY = false>
+// PCM (ALIGNED forms): `x` holds int16 -- 1: mono, n_samples 2-byte samples per clip, a 4-sample piece is 8 bytes; 2: stereo, n_samples 4-byte frames,
+// a piece is the float32 form's 16 bytes and both channels are added -- normalised (zaf.py:1202) and averaged (zaf.py:65) on the way into the fold:
+// the power of two rides in the window quadruples (zafx_execute_pcm).
+template <int LOG2NF, int LOG2E, bool ALIGNED, int NSLOT, bool TFOUT = false, bool CARRY = false, int PCM = 0>
 __global__ __launch_bounds__(NSLOT * 64) void k_mdct_ft32(
     const float* __restrict__ x, const float4* __restrict__ wfold, const float2* __restrict__ twp,
     const float2* __restrict__ tw8, float* __restrict__ out, long long n_samples, int T, int TP, int tiles, int total_tiles,
@@ -171,7 +174,13 @@ __global__ __launch_bounds__(NSLOT * 64) void k_mdct_ft32(
     float4* wf_l = reinterpret_cast<float4*>(g_l + NF);
     const int tid = threadIdx.x;
     for (int i = tid; i < C::TW; i += NT) tw_l[i] = twp[i];
-    for (int i = tid; i < NF; i += NT) { g_l[i] = tw8[i]; wf_l[i] = wfold[i]; }
+    static_assert(PCM == 0 || ALIGNED, "int16 input: the buffer-load form");
+    const float pcm_scale = PCM == 1 ? 1.f / 32768.f : PCM == 2 ? 1.f / 65536.f : 1.f;
+    for (int i = tid; i < NF; i += NT) {
+        g_l[i] = tw8[i];
+        const float4 wv = wfold[i];
+        wf_l[i] = make_float4(wv.x * pcm_scale, wv.y * pcm_scale, wv.z * pcm_scale, wv.w * pcm_scale);
+    }
     lds_barrier();
     const int slot = tid / P, p = tid % P;
     const bool pair_ok = (TFOUT || TP % 2 == 0) && (reinterpret_cast<uintptr_t>(out) % 8 == 0);   // TP = row pitch (>= T)
@@ -201,15 +210,40 @@ __global__ __launch_bounds__(NSLOT * 64) void k_mdct_ft32(
             // sample is out of the descriptor's range and reads as zero -- the zero padding of zaf.py:1036-1041, with no edge
             // path (n_samples and every piece's first sample are multiples of 4: a piece is inside or outside as a whole;
             // offsets are 32-bit and wrap, a negative one is a huge unsigned one).  Four address registers per frame.
+            if constexpr (PCM == 1) {   // four int16 samples = 8 bytes per piece
+                const __amdgpu_buffer_rsrc_t rs = make_rsrc(reinterpret_cast<const short*>(x) + (long long)clip * n_samples, (unsigned)(n_samples * 2));
+                const int b = (int)s0 * 2 + 8 * p, rb = (int)s0 * 2 - 8 * p - 8 * (UPL - 1) * P;
+                auto piece = [&](int off) {
+                    const float2 d = buf_load_f32x2(rs, off);
+                    const int d0 = __builtin_bit_cast(int, d.x), d1 = __builtin_bit_cast(int, d.y);
+                    return make_float4((float)(short)(d0 & 0xffff), (float)(d0 >> 16), (float)(short)(d1 & 0xffff), (float)(d1 >> 16));
+                };
+#pragma unroll
+                for (int r = 0; r < UPL; ++r) {
+                    q[r][0] = piece(b + 6 * NF + 8 * r * P);
+                    q[r][1] = piece(rb + 6 * NF - 8 + 8 * (UPL - 1 - r) * P);
+                    q[r][2] = piece(b + 2 * NF + 8 * r * P);
+                    q[r][3] = piece(rb + 2 * NF - 8 + 8 * (UPL - 1 - r) * P);
+                }
+                return;
+            }
             const __amdgpu_buffer_rsrc_t rs = make_rsrc(xc, (unsigned)(n_samples * 4));
             const int b = (int)s0 * 4 + 16 * p;                  // + 16 u forward pieces
             const int rb = (int)s0 * 4 - 16 * p - 16 * (UPL - 1) * P;   // - 16 u reversed pieces, lowest address of the UPL
+            auto piece = [&](int off) {
+                const float4 d = buf_load_f32x4(rs, off);
+                if constexpr (PCM == 2) {   // four (left, right) frames: the sum of each (the 1/2 of the mean is in the window)
+                    auto sum16 = [](float f) { const int v = __builtin_bit_cast(int, f); return (float)((int)(short)(v & 0xffff) + (v >> 16)); };
+                    return make_float4(sum16(d.x), sum16(d.y), sum16(d.z), sum16(d.w));
+                }
+                return d;
+            };
 #pragma unroll
             for (int r = 0; r < UPL; ++r) {
-                q[r][0] = buf_load_f32x4(rs, b + 12 * NF + 16 * r * P);
-                q[r][1] = buf_load_f32x4(rs, rb + 12 * NF - 16 + 16 * (UPL - 1 - r) * P);
-                q[r][2] = buf_load_f32x4(rs, b + 4 * NF + 16 * r * P);
-                q[r][3] = buf_load_f32x4(rs, rb + 4 * NF - 16 + 16 * (UPL - 1 - r) * P);
+                q[r][0] = piece(b + 12 * NF + 16 * r * P);
+                q[r][1] = piece(rb + 12 * NF - 16 + 16 * (UPL - 1 - r) * P);
+                q[r][2] = piece(b + 4 * NF + 16 * r * P);
+                q[r][3] = piece(rb + 4 * NF - 16 + 16 * (UPL - 1 - r) * P);
             }
         } else {   // clip edges (zero padding), frames past T, unaligned clips
             auto at = [&](long long s) { return (t < T && s >= 0 && s < n_samples) ? xc[s] : 0.f; };
@@ -1225,6 +1259,12 @@ constexpr int mdct_fpb(int log2nf, int layout) {
     return r;
 }
 
+// int16 PCM (one or two channels) straight into k_mdct_ft32: W = 2048, reference layout, clips of a multiple of four frames (zafx_execute_pcm)
+bool mdct_pcm_direct_ok(const zafx_plan& pl, int64_t n_frames, int n_channels, int sample_bytes, const void* d_pcm) {
+    return sample_bytes == 2 && (n_channels == 1 || n_channels == 2) && pl.kind == ZAFX_MDCT && pl.prm.precision == ZAFX_PRECISION_F32 && pl.bs_log2m == 0 &&
+           pl.log2nf == 9 && pl.layout == ZAFX_LAYOUT_FT && n_frames % 4 == 0 && n_frames < (1LL << 28) && reinterpret_cast<uintptr_t>(d_pcm) % 16 == 0;
+}
+
 constexpr bool mdct_use_persistent(int log2nf, int layout) {
     return log2nf >= 7 && log2nf <= 9;   // either layout
 }
@@ -1235,6 +1275,11 @@ static hipError_t run_mdct_p(const zafx_plan& pl, const float* x, float* out, in
     using G = MdctPCfg<LOG2NF, LOG2E>;
     const bool aligned = n_samples % 4 == 0 && reinterpret_cast<uintptr_t>(x) % 16 == 0 && n_samples < (1LL << 28);   // (32-bit byte offsets inside a clip)
     auto kern = aligned ? k_mdct_ft32<LOG2NF, LOG2E, true, G::NSLOT, TFOUT> : k_mdct_ft32<LOG2NF, LOG2E, false, G::NSLOT, TFOUT>;
+    const int pcm = pl.call_pcm;   // (zafx_execute_pcm: int16 in the loads; mdct_pcm_direct_ok vouches for `aligned`, W = 2048 and the reference layout)
+    if constexpr (LOG2NF == 9 && !TFOUT) {
+        if (pcm == 1) kern = k_mdct_ft32<LOG2NF, LOG2E, true, G::NSLOT, false, false, 1>;
+        if (pcm == 2) kern = k_mdct_ft32<LOG2NF, LOG2E, true, G::NSLOT, false, false, 2>;
+    }
     if (hipError_t e = ensure_dynamic_lds(reinterpret_cast<const void*>(kern), pl.device, G::SMEM); e != hipSuccess) return e;
     const int tiles = (T + kMdctTile - 1) / kMdctTile;
     const long long total = (long long)tiles * n_clips;
@@ -1252,6 +1297,10 @@ static hipError_t run_mdct_p(const zafx_plan& pl, const float* x, float* out, in
         const int TP = (int)row_pitch(pl, T);
         if (aligned && (TP % 16 != 0 || reinterpret_cast<uintptr_t>(out) % 64 != 0) && total < (1LL << 31)) {
             auto kc = k_mdct_ft32<LOG2NF, LOG2E, true, G::NSLOT, false, true>;
+            if constexpr (LOG2NF == 9) {
+                if (pcm == 1) kc = k_mdct_ft32<LOG2NF, LOG2E, true, G::NSLOT, false, true, 1>;
+                if (pcm == 2) kc = k_mdct_ft32<LOG2NF, LOG2E, true, G::NSLOT, false, true, 2>;
+            }
             if (hipError_t e = ensure_dynamic_lds(reinterpret_cast<const void*>(kc), pl.device, G::SMEM); e != hipSuccess) return e;
             const int segs = carry_segments(n_clips, tiles, max_grid);
             const int seg_tiles = (tiles + segs - 1) / segs;

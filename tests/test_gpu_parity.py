@@ -904,6 +904,24 @@ def test_f64_stft_on_the_tiled_kernel(zafx, hop, n, clips):
     assert zafx.stft_plan(w, hop, layout="TF", f64=True).last_kernel == "k_stft_f64"
 
 
+@pytest.mark.parametrize("n,clips", [(441000, 3), (30001, 2), (1024 * 47, 40), (1, 1), (1024 * 16 + 2, 2), (99999, 2)])
+def test_f64_mdct_on_the_tiled_kernel(zafx, n, clips):
+    """W = 2048 in the reference layout, float64: k_mdct_ft16_f64 (16-frame tiles = 128-byte lines of float64 rows, a frame per wavefront as
+    8 x 8 x 8; zaf.py:1029-1073 in its own dtype) -- interior and edge frames, odd clip lengths (the sample-by-sample staging), ragged last
+    tiles, rows on and off the line grid, more tiles than workgroups; the inverse stays on the scratch + overlap-add form."""
+    x = np.stack([synth_clip(39, c % 7, n).astype(np.float64) + 1e-9 * (c % 7) for c in range(clips)])
+    w = zafx.kaiser_bessel_derived(2048)
+    got = zafx.mdct_batch(x, w, f64=True)
+    assert zafx.mdct_plan(w, f64=True).last_kernel == "k_mdct_ft16_f64" and got.dtype == np.float64
+    for c in range(min(clips, 7)):
+        ref = orc.mdct(x[c], w)
+        assert got[c].shape == ref.shape and relerr(got[c], ref) <= TOL_F64, c
+    if clips > 7:
+        assert np.array_equal(got[7:14], got[0:7]) and np.array_equal(got[clips - 5:], got[(clips - 5) % 7:(clips - 5) % 7 + 5])
+    zafx.mdct_batch(x[:1], w, layout="TF", f64=True)
+    assert zafx.mdct_plan(w, layout="TF", f64=True).last_kernel == "k_mdct_f64"
+
+
 @pytest.mark.parametrize("wl,hop,n", [(2048, 1024, 441000), (2048, 512, 30000), (1024, 300, 9001), (64, 32, 1000), (8192, 4096, 50000),
                                        (256, 77, 1)])
 def test_f64_stft_istft(zafx, wl, hop, n):

@@ -24,6 +24,9 @@ __device__ __forceinline__ double2 dmul(double2 a, double2 b) { return make_doub
 __device__ __forceinline__ double2 dmulc(double2 a, double2 b) { return make_double2(a.x * b.x + a.y * b.y, a.y * b.x - a.x * b.y); }
 __device__ __forceinline__ double2 dconj(double2 a) { return make_double2(a.x, -a.y); }
 
+#ifndef ZAFX_F64_TILED
+#define ZAFX_F64_TILED 1   // W = 2048, reference layout: k_stft_ft8_f64 / k_mdct_ft16_f64 instead of the frame-per-workgroup kernels
+#endif
 constexpr int kThreads = 256;       // workgroup size of the small frames
 constexpr int kThreadsBig = 1024;   // ... of frames whose LDS image leaves room for one workgroup per CU only (see threads_for)
 
@@ -221,23 +224,24 @@ __global__ __launch_bounds__(kF64Frames * 64) void k_stft_ft8_f64(const double* 
             }
         }
     };
-    // the lane's twiddles of pass 2, resident (two waves per SIMD: 256 registers each; with those of pass 3 as well the kernel spills)
-    double2 w2[16];
-#pragma unroll
-    for (int r = 1; r < 16; ++r) w2[r] = root1024(tw, 4 * r * (lane & 15));   // exp(-2 pi i r k / 256)
     request(blockIdx.x);
     for (int tlv = blockIdx.x; tlv < total_tiles; tlv += gridDim.x) {
         const int tl = xcd ? xcd_order(tlv, total_tiles) : tlv;
         const int clip = tl / tiles, t0 = (tl % tiles) * FPB;
+        int lane_o = lane;
+        asm volatile("" : "+v"(lane_o));   // (opaque per tile: window and twiddle values are re-read from L1, not hoisted out of the loop and spilled)
+        double2 w2[16];
+#pragma unroll
+        for (int r = 1; r < 16; ++r) w2[r] = root1024(tw, 4 * r * (lane_o & 15));   // exp(-2 pi i r k / 256)
         {
             const double2* wp = reinterpret_cast<const double2*>(win);
 #pragma unroll
             for (int i = 0; i < 16; ++i) {
-                const double2 w = wp[lane + 64 * i];
+                const double2 w = wp[lane_o + 64 * i];
                 v[i] = make_double2(v[i].x * w.x, v[i].y * w.y);
             }
         }
-        fft1024_f64(v, buf, lane, w2, tw);
+        fft1024_f64(v, buf, lane_o, w2, tw);
         // real split in place: X[k] = E + t_k O, X[N-k] = conj(E - t_k O) (as k_stft_f64)
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
@@ -276,6 +280,147 @@ __global__ __launch_bounds__(kF64Frames * 64) void k_stft_ft8_f64(const double* 
                     q.y = val.y;
                     __builtin_nontemporal_store(q, reinterpret_cast<f64x2*>(o + (long long)r * TP));   // one 16-byte streaming store
                 }
+            }
+        }
+        lds_barrier();
+    }
+}
+
+// ---------------------------------------------------------------------------------
+// k_mdct_ft16_f64: the forward MDCT in float64 (zaf.py:1029-1073) on the tiled structure, W = 2048, reference layout.  A tile is 16 frames of
+// one clip -- 16 x 8 B = one 128-byte line of every coefficient row --, a workgroup 16 waves, a wave one frame: window + TDAC fold + pre-twiddle
+// straight out of global memory into registers (c[m] = (v[2m] + i v[M-1-2m]) g_m), 512 points as 8 x 8 x 8 with two exchanges through the wave's
+// 9 KB of LDS, post-twiddle in place (the pair k, 511 - k trades its imaginary parts: out[2k] = Re y_k, out[2k+1] = -Im y_{511-k}), then the
+// workgroup writes the tile row by row, sixteen lanes to a line.  16 bytes per sample: bound by HBM (k_mdct_f64, a frame per workgroup, 0.11 of it).
+// ---------------------------------------------------------------------------------
+__device__ __forceinline__ void dft8d(double2* a) {
+    const double h = 0.70710678118654752440;
+    double2 e0 = a[0], e1 = a[2], e2 = a[4], e3 = a[6], o0 = a[1], o1 = a[3], o2 = a[5], o3 = a[7];
+    dft4d(e0, e1, e2, e3);
+    dft4d(o0, o1, o2, o3);
+    o1 = dmul(o1, make_double2(h, -h));
+    o2 = dmul_mi(o2);
+    o3 = dmul(o3, make_double2(-h, -h));
+    a[0] = dadd(e0, o0); a[4] = dsub(e0, o0);
+    a[1] = dadd(e1, o1); a[5] = dsub(e1, o1);
+    a[2] = dadd(e2, o2); a[6] = dsub(e2, o2);
+    a[3] = dadd(e3, o3); a[7] = dsub(e3, o3);
+}
+constexpr int kMd64Frames = 16, kMd64NF = 512, kMd64Pitch = kMd64NF + kMd64NF / 8 + 1;
+__device__ __forceinline__ int phys8(int i) { return i + (i >> 3); }
+__device__ __forceinline__ double2 root512(const double2* __restrict__ tw, int m) {   // exp(-2 pi i m / 512), m < 512
+    const double2 w = tw[m & 255];
+    return m & 256 ? make_double2(-w.x, -w.y) : w;
+}
+
+__global__ __launch_bounds__(kMd64Frames * 64) void k_mdct_ft16_f64(const double* __restrict__ x, const double* __restrict__ win, const double2* __restrict__ tw,
+                                                                     const double2* __restrict__ g, double* __restrict__ out, long long n_samples, int T, int TP,
+                                                                     int tiles, int total_tiles) {
+    constexpr int NF = kMd64NF, M = 2 * NF, FPB = kMd64Frames, PITCH = kMd64Pitch;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    double2* frames = reinterpret_cast<double2*>(smem_raw);
+    const int tid = threadIdx.x, wave = tid >> 6;
+    double2* buf = frames + wave * PITCH;
+    const bool xcd = gridDim.x % 8 == 0;
+    for (int tlv = blockIdx.x; tlv < total_tiles; tlv += gridDim.x) {
+        int lane = tid & 63;
+        asm volatile("" : "+v"(lane));   // (opaque per tile: the lane's window, twiddle and table values are re-read, not hoisted out of the loop and spilled)
+        const int tl = xcd ? xcd_order(tlv, total_tiles) : tlv;
+        const int clip = tl / tiles, t0 = (tl % tiles) * FPB, t = t0 + wave;
+        const double* xc = x + (long long)clip * n_samples;
+        const long long s0 = (long long)t * M - M;   // left pad = M (zaf.py:1036-1041)
+        const bool inside = t < T && s0 >= 0 && s0 + 2 * M <= n_samples && ((s0 | n_samples) & 1) == 0;   // (uniform) 16-byte loads
+        // The frame's two halves go through the wave's buffer one after the other, windowed, as coalesced 16-byte pieces; the fold reads its
+        // partners (a sample and its mirror image) from there.  (Folded straight out of global memory -- 32 + 32 strided 8-byte loads per lane in
+        // flight -- the kernel needed more than its 128 registers: 676 bytes of scratch, 1.63 ms for 256 clips.)
+        double* ub = reinterpret_cast<double*>(buf);
+        auto stage = [&](int half) {   // windowed samples [1024 half, 1024 half + 1024) of the frame -> ub[0 .. 1023]
+            const double2* wp = reinterpret_cast<const double2*>(win) + NF * half;
+            if (inside) {
+                const double2* xp = reinterpret_cast<const double2*>(xc + s0) + NF * half;
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const int q = lane + 64 * j;
+                    const double2 a = xp[q], w = wp[q];
+                    reinterpret_cast<double2*>(ub)[q] = make_double2(a.x * w.x, a.y * w.y);
+                }
+            } else {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const int q = lane + 64 * j;
+                    const long long sa = s0 + M * half + 2 * q;
+                    const double2 w = wp[q];
+                    const double a = (t < T && sa >= 0 && sa < n_samples) ? xc[sa] : 0.0, b = (t < T && sa + 1 >= 0 && sa + 1 < n_samples) ? xc[sa + 1] : 0.0;
+                    reinterpret_cast<double2*>(ub)[q] = make_double2(a * w.x, b * w.y);
+                }
+            }
+        };
+        double va[8], vb[8];
+        stage(1);   // u[2 NF + n]: the parts of the fold below NF, -u[3 NF - 1 - i] - u[3 NF + i]
+        frame_sync<64>();
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int m = lane + 64 * i, a = 2 * m, b = M - 1 - 2 * m;
+            if (i < 4) va[i] = -ub[NF - 1 - a] - ub[NF + a];
+            else vb[i] = -ub[NF - 1 - b] - ub[NF + b];
+        }
+        frame_sync<64>();
+        stage(0);   // u[n]: the parts from NF up, u[i - NF] - u[3 NF - 1 - i]
+        frame_sync<64>();
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int m = lane + 64 * i, a = 2 * m, b = M - 1 - 2 * m;
+            if (i < 4) vb[i] = ub[b - NF] - ub[3 * NF - 1 - b];
+            else va[i] = ub[a - NF] - ub[3 * NF - 1 - a];
+        }
+        frame_sync<64>();
+        double2 v[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) v[i] = dmul(make_double2(va[i], vb[i]), g[lane + 64 * i]);   // c[m] = (v[2m] + i v[M-1-2m]) g_m (zaf.py:1047-1056 as k_mdct_f64 writes it)
+        // 512 points: radix 8 three times
+        dft8d(v);
+#pragma unroll
+        for (int r = 0; r < 8; ++r) buf[phys8(8 * lane + r)] = v[r];
+        frame_sync<64>();
+#pragma unroll
+        for (int i = 0; i < 8; ++i) v[i] = buf[phys8(lane + 64 * i)];
+        frame_sync<64>();
+        {
+            const int k = lane & 7;
+#pragma unroll
+            for (int r = 1; r < 8; ++r) v[r] = dmul(v[r], root512(tw, 8 * r * k));   // exp(-2 pi i r k / 64)
+            dft8d(v);
+            const int base = ((lane >> 3) << 6) + k;
+#pragma unroll
+            for (int r = 0; r < 8; ++r) buf[phys8(base + 8 * r)] = v[r];
+        }
+        frame_sync<64>();
+#pragma unroll
+        for (int i = 0; i < 8; ++i) v[i] = buf[phys8(lane + 64 * i)];
+        frame_sync<64>();
+#pragma unroll
+        for (int r = 1; r < 8; ++r) v[r] = dmul(v[r], root512(tw, r * lane));           // exp(-2 pi i r k / 512), k = lane
+        dft8d(v);
+        // Z[lane + 64 r] = v[r]; post-twiddle y_k = Z[k] g_k and the pair's trade, in place: lane (k < 256: r < 4) needs Z[511 - k], held by lane 63 - lane
+        // in register 7 - r: through LDS
+#pragma unroll
+        for (int r = 0; r < 8; ++r) buf[phys8(lane + 64 * r)] = dmul(v[r], g[lane + 64 * r]);   // y_k
+        frame_sync<64>();
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int k = lane + 64 * r, kp = NF - 1 - k;
+            const double2 yk = buf[phys8(k)], yp = buf[phys8(kp)];
+            buf[phys8(k)] = make_double2(yk.x, -yp.y);    // out[2k], out[2k+1] = out[M-1-2k']
+            buf[phys8(kp)] = make_double2(yp.x, -yk.y);   // out[2k'], out[2k'+1] = out[M-1-2k]
+        }
+        lds_barrier();
+        {
+            const int f = tid & 15, gq = tid >> 4;
+            const double* fb = reinterpret_cast<const double*>(frames + f * PITCH);
+            double* o = out + (long long)clip * M * TP + t0 + f;
+            if (t0 + f < T) {
+#pragma unroll 4
+                for (int r = gq; r < M; r += 64) __builtin_nontemporal_store(fb[2 * phys8(r >> 1) + (r & 1)], o + (long long)r * TP);
             }
         }
         lds_barrier();
@@ -781,9 +926,6 @@ hipError_t launch_stft_f64(const zafx_plan& pl, const double* x, double2* out, i
     if (pl.bs_log2m > 0) return launch_bs_f64(pl, x, out, n_clips, n_samples, T, false);
     const long long blocks = (long long)n_clips * T;
     if (blocks <= 0) return hipSuccess;
-#ifndef ZAFX_F64_TILED
-#define ZAFX_F64_TILED 1
-#endif
     if (ZAFX_F64_TILED && pl.W == 2048 && pl.layout == ZAFX_LAYOUT_FT && pl.prm.spectrum <= ZAFX_SPECTRUM_ONE_SIDED && reinterpret_cast<uintptr_t>(x) % 16 == 0 &&
         reinterpret_cast<uintptr_t>(out) % 16 == 0) {
         const int tiles = (T + kF64Frames - 1) / kF64Frames;
@@ -912,6 +1054,19 @@ hipError_t launch_mdct_f64(const zafx_plan& pl, const double* x, double* out, in
         hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(threads_for(smem)), smem, pl.stream, x, pl.d_window64, pl.d_tw64, pl.d_tws64, pl.d_bhat64,
                            out, (long long)n_samples, T, (int)row_pitch(pl, T), pl.W, pl.bs_log2m, pl.layout);
         return hipGetLastError();
+    }
+    if (ZAFX_F64_TILED && pl.W == 2048 && pl.layout == ZAFX_LAYOUT_FT) {
+        const int tiles = (T + kMd64Frames - 1) / kMd64Frames;
+        const long long total = (long long)tiles * n_clips;
+        if (total < (1LL << 31)) {
+            const size_t smem16 = (size_t)kMd64Frames * kMd64Pitch * sizeof(double2);
+            auto k16 = k_mdct_ft16_f64;
+            if (hipError_t e = ensure_dynamic_lds(reinterpret_cast<const void*>(k16), pl.device, smem16); e != hipSuccess) return e;
+            pl.ran = "k_mdct_ft16_f64";
+            hipLaunchKernelGGL(k16, dim3((unsigned)std::min<long long>(total, pl.n_cus)), dim3(kMd64Frames * 64), smem16, pl.stream, x, pl.d_window64, pl.d_tw64,
+                               pl.d_tws64, out, (long long)n_samples, T, (int)row_pitch(pl, T), tiles, (int)total);
+            return hipGetLastError();
+        }
     }
     const size_t smem = (size_t)pl.W * 8 + (size_t)(pl.W / 2) * 8 + (size_t)(pl.W / 4) * 32;   // u, v, two FFT buffers
     auto kern = k_mdct_f64;

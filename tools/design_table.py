@@ -21,8 +21,12 @@ def tr(k):
 
 def fr(k):
     r = c[k]["roofline"]
-    s = f"{r['frac']:.3f} {'hbm' if r['bound'] == 'hbm' else 'f32'}"
-    return s + (f" ({r['hbm_frac']:.3f} hbm)" if "hbm_frac" in r and r["bound"] != "hbm" else "")
+    s = f"{r['frac']:.3f} {r['bound']}"
+    if "mfma_frac" in r:   # HBM is the roof; how busy the two arithmetic pipes are stands beside it
+        s += f" (mfma {r['mfma_frac']:.3f}, valu {r['valu_frac']:.3f})"
+    if "valu_frac_real_input" in r:   # config 5: the vector pipe, by the reference's complex flops and by the real-input form's
+        s += f" ({r['valu_frac_real_input']:.3f} on the real-input flops; {r['hbm_frac']:.3f} hbm)"
+    return s
 
 
 ta = plain["roofline"]["traffic"] / (a["roofline"]["achieved"] * 1e9 * a["roofline"]["kernel_ms"] * 1e-3) if a["roofline"].get("traffic") else None

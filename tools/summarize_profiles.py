@@ -58,7 +58,7 @@ if trace and os.path.exists(log):
     rows = []
     with open(trace) as fh:
         for r in csv.DictReader(fh):
-            rows.append((int(r["Dispatch_Id"]), r["Kernel_Name"].split("(")[0], int(r["End_Timestamp"]) - int(r["Start_Timestamp"])))
+            rows.append((int(r["Dispatch_Id"]), r["Kernel_Name"].replace("(anonymous namespace)::", "").split("(")[0], int(r["End_Timestamp"]) - int(r["Start_Timestamp"])))
     rows.sort()
     pos, table = 0, []
     for ent in json.load(open(log)):

@@ -134,8 +134,9 @@ __global__ __launch_bounds__(BsCfg<LOG2M>::P) void k_dct_bs32(const float* __res
     using B = BsCfg<LOG2M>;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     float2* buf = reinterpret_cast<float2*>(smem_raw);
-    const int p = threadIdx.x;
     for (long long row = blockIdx.x; row < n_rows; row += gridDim.x) {
+        int p = threadIdx.x;
+        asm volatile("" : "+v"(p));   // (opaque per row: the thread's twiddles and chirp-transform values are re-read, not hoisted out of the loop and spilled)
         const float* xr = x + row * N;
         for (int n = p; n < N; n += B::P) {
             const float v = xr[n];

@@ -1119,7 +1119,7 @@ def test_spectrogram_kinds_on_rows_of_even_pitch(zafx, n, clips):
                                                     (np.int16, 1, 441000, 40), (np.int32, 1, 20000, 2), (np.int16, 5, 20000, 2), (np.int16, 1, 1500, 1)])
 def test_execute_pcm_device_resident(zafx, dtype, channels, n, clips):
     """Verdict r4 item 7: integer PCM on the device straight into the transform (Plan.execute_pcm).  mel, mfcc and the |X| / |X|^2 kinds at W = 2048
-    read int16 (one or two channels) in k_mel2's own loads, the MDCT at W = 2048 in k_mdct_ft32's (clips of a multiple of four frames); the result is BIT-IDENTICAL to normalising first (zaf.py:1202, :65: x / 2^15 and the
+    read int16 (one or two channels) in k_mel2's own loads, the MDCT at W = 2048 in k_mdct_ft32's (clips of a multiple of four frames), the complex STFT in k_stft_ft16 / k_stft_ft16c's (even clip lengths); the result is BIT-IDENTICAL to normalising first (zaf.py:1202, :65: x / 2^15 and the
     channel mean are exact in float32) -- aligned and odd clip lengths (the sample-by-sample path), more tiles than workgroups.  int32 and other
     channel counts, and every other kind, convert into the plan's staging array first: same numbers as the two-step form."""
     rng = np.random.default_rng([83, channels, n])
@@ -1130,7 +1130,10 @@ def test_execute_pcm_device_resident(zafx, dtype, channels, n, clips):
     w, kbd = zafx.hamming(2048), zafx.kaiser_bessel_derived(2048)
     fb = zafx.melfilterbank(44100, 2048, 128)
     plans = [("mel", zafx.mel_plan(w, 1024, fb)), ("mfcc", zafx.mel_plan(w, 1024, fb, 20)), ("mag", zafx.stft_plan(w, 1024, onesided="magnitude")),
-             ("pow", zafx.stft_plan(w, 1024, onesided="power")), ("stft", zafx.stft_plan(w, 1024)), ("mdct", zafx.mdct_plan(kbd))]
+             ("pow", zafx.stft_plan(w, 1024, onesided="power")), ("stft", zafx.stft_plan(w, 1024)), ("stft1", zafx.stft_plan(w, 1024, onesided=True)),
+             ("mdct", zafx.mdct_plan(kbd)), ("cqt", zafx.cqt_plan(44100, 25, zafx.cqtkernel(44100, 24, 55, 3520)))]
+    if n > 100000:
+        plans = plans[:-1]   # (the CQT: short clips only)
     d_pcm = zafx.DeviceBuffer.from_host(pcm)
     d_x = zafx.DeviceBuffer((clips, n), np.float32)
     direct = dtype == np.int16 and channels in (1, 2)

@@ -13,7 +13,7 @@ def timed(fn, plan, reps=20):
     plan.sync(); plan.timer_start()
     for _ in range(reps): fn()
     return plan.timer_stop() / reps
-for name, plan in (("mel", zafx.mel_plan(w, 1024, fb)), ("mfcc", zafx.mel_plan(w, 1024, fb, 20)), ("|X|", zafx.stft_plan(w, 1024, onesided="magnitude")), ("mdct", zafx.mdct_plan(zafx.kaiser_bessel_derived(2048))), ("mdct T=433", zafx.mdct_plan(zafx.kaiser_bessel_derived(2048)))):
+for name, plan in (("stft", zafx.stft_plan(w, 1024)), ("stft1", zafx.stft_plan(w, 1024, onesided=True)), ("mel", zafx.mel_plan(w, 1024, fb)), ("mfcc", zafx.mel_plan(w, 1024, fb, 20)), ("|X|", zafx.stft_plan(w, 1024, onesided="magnitude")), ("mdct", zafx.mdct_plan(zafx.kaiser_bessel_derived(2048))), ("mdct T=433", zafx.mdct_plan(zafx.kaiser_bessel_derived(2048)))):
     if name == "mdct T=433":
         N = 442024
         base = rng.integers(-32768, 32767, size=(8, N, 2), endpoint=True).astype(np.int16)

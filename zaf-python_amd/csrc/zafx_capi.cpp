@@ -1317,8 +1317,12 @@ int zafx_plan_clip_bytes(const zafx_plan* pl, int64_t n_in, int64_t* in_bytes, i
 // One transform of integer PCM that is already on the device: kinds whose kernel reads int16 itself (k_mel2: mel, mfcc, |X| / |X|^2 at W = 2048, mono or
 // stereo) get the integers; everything else goes through wavread's normalisation and the channel mean (k_pcm_to_float) into `staging` first.
 static int execute_pcm(zafx_plan* pl, const void* d_pcm, void* d_out, int64_t n_clips, int64_t n_frames, int n_channels, int sample_bytes, float* staging) {
+    int64_t pdims[2] = {0, 0};
+    if (pl->kind == ZAFX_STFT) {
+        if (int rc = zafx_plan_out_dims(pl, n_frames, pdims)) return rc;
+    }
     if ((pcm_direct_ok(*pl, n_frames, n_channels, sample_bytes) && reinterpret_cast<uintptr_t>(d_pcm) % 8 == 0) ||
-        mdct_pcm_direct_ok(*pl, n_frames, n_channels, sample_bytes, d_pcm)) {
+        mdct_pcm_direct_ok(*pl, n_frames, n_channels, sample_bytes, d_pcm) || stft_pcm_direct_ok(*pl, n_frames, n_channels, sample_bytes, d_pcm, (int)pdims[1])) {
         pl->call_pcm = n_channels;
         const int rc = zafx_execute(pl, d_pcm, d_out, n_clips, n_frames);
         pl->call_pcm = 0;

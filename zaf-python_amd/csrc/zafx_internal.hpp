@@ -219,6 +219,7 @@ bool mel_band_usable(const zafx_plan& pl, const float* x, int64_t n_clips, int64
 hipError_t launch_mel_band(const zafx_plan& pl, const float* x, float* out, int64_t n_clips, int64_t n_samples, int T);
 hipError_t launch_cqt(const zafx_plan& pl, const float* x, float* out, int64_t n_clips, int64_t n_samples, int T);
 bool pcm_direct_ok(const zafx_plan& pl, int64_t n_frames, int n_channels, int sample_bytes);   // zafx_mel.hip
+bool stft_pcm_direct_ok(const zafx_plan& pl, int64_t n_frames, int n_channels, int sample_bytes, const void* d_pcm, int T);   // zafx_stft.hip
 bool mdct_pcm_direct_ok(const zafx_plan& pl, int64_t n_frames, int n_channels, int sample_bytes, const void* d_pcm);   // zafx_mdct.hip
 bool launch_spec2(const zafx_plan& pl, const float* x, float* out, int64_t n_clips, int64_t n_samples, int T, hipError_t& err);   // zafx_mel.hip: |X| / |X|^2 rows of an STFT plan on k_mel2
 hipError_t launch_linear(const zafx_plan& pl, const float* x, float* y, int64_t n_clips);

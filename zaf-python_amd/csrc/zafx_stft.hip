@@ -197,7 +197,27 @@ struct FatCfg {
     static constexpr size_t SMEM = (size_t)(FPB_ * PITCH + C::TW + (WIN_LDS ? N : 0) + N / 2 + 1) * 8;
 };
 
-template <int LOG2N, int LOG2E, bool ALIGNED, int SPEC, int FPB_ = kFatFrames>
+// int16 PCM in the loads (zafx_execute_pcm): a point of the packed frame -- two samples -- as the kernel keeps it until the window multiply.
+// PCM 0: float2.  1: int16 mono, the two samples in one dword (held as a float's bits).  2: int16 stereo, two (left, right) frames in two
+// dwords: the channels are added on the way out; the 2^-15 / 2^-16 of zaf.py:1202 and :65 rides in the window the kernel stages.
+template <int PCM>
+struct PcmPoint {
+    using T = std::conditional_t<PCM == 1, float, float2>;
+    static __device__ __forceinline__ float2 get(T v) {
+        if constexpr (PCM == 1) {
+            const int d = __builtin_bit_cast(int, v);
+            return make_float2((float)(short)(d & 0xffff), (float)(d >> 16));
+        } else if constexpr (PCM == 2) {
+            const int a = __builtin_bit_cast(int, v.x), b = __builtin_bit_cast(int, v.y);
+            return make_float2((float)((int)(short)(a & 0xffff) + (a >> 16)), (float)((int)(short)(b & 0xffff) + (b >> 16)));
+        } else {
+            return v;
+        }
+    }
+    static constexpr float scale() { return PCM == 1 ? 1.f / 32768.f : PCM == 2 ? 1.f / 65536.f : 1.f; }
+};
+
+template <int LOG2N, int LOG2E, bool ALIGNED, int SPEC, int FPB_ = kFatFrames, int PCM = 0>
 __global__ __launch_bounds__(kFatWaves * 64) void k_stft_ft16(
     const float* __restrict__ x, const float* __restrict__ win, const float2* __restrict__ twp,
     const float2* __restrict__ tws, float2* __restrict__ out, long long n_samples, int hop, int T, int TP, int tiles,
@@ -215,8 +235,13 @@ __global__ __launch_bounds__(kFatWaves * 64) void k_stft_ft16(
     const float2* win_l = F::WIN_LDS ? win_s : reinterpret_cast<const float2*>(win);
     const int tid = threadIdx.x;
     for (int i = tid; i < C::TW; i += NT) tw_l[i] = twp[i];
+    static_assert(PCM == 0 || F::WIN_LDS, "int16 input: the staged window carries the scale");
+    using PP = PcmPoint<PCM>;
     if constexpr (F::WIN_LDS)
-        for (int i = tid; i < N; i += NT) win_s[i] = reinterpret_cast<const float2*>(win)[i];
+        for (int i = tid; i < N; i += NT) {
+            const float2 wv = reinterpret_cast<const float2*>(win)[i];
+            win_s[i] = make_float2(wv.x * PP::scale(), wv.y * PP::scale());
+        }
     for (int i = tid; i <= N / 2; i += NT) tws_l[i] = tws[i];
     __syncthreads();
     const int wave = tid / P, p_lane = tid % P, p = p_lane;
@@ -224,7 +249,7 @@ __global__ __launch_bounds__(kFatWaves * 64) void k_stft_ft16(
     const float2* fb = frames + tt * PITCH;
     const bool lines_whole = TP % 16 == 0 && reinterpret_cast<uintptr_t>(out) % 128 == 0;
 
-    float2 xr[FPW][E];
+    typename PP::T xr[FPW][E];
     // The fast / edge decision is taken once per TILE (block-uniform): a tile whose 16 frames all lie
     // inside the clip issues 2 x 16 unconditional 8-byte loads with no control flow in between, so the
     // loads stay in flight across the store phase; only the first and last tiles of a clip take the
@@ -236,10 +261,33 @@ __global__ __launch_bounds__(kFatWaves * 64) void k_stft_ft16(
         int p = p_lane;   // (opaque at 32 points per thread: the 64-bit sample offsets of the edge path are recomputed, not hoisted)
         if constexpr (E >= 32) asm volatile("" : "+v"(p));
         const int clip = tl / tiles, tile = tl % tiles;
-        const float* xc = x + (long long)clip * n_samples;
+        const float* xc = x + (long long)clip * n_samples;   // (PCM 2: a "sample" is one 4-byte frame of two int16)
         const long long first = (long long)tile * FPB * hop - N;               // first sample of the tile
         const long long last = first + (long long)(FPB - 1) * hop + W;          // one past its last sample
-        if (ALIGNED && first >= 0 && last <= n_samples && tile * FPB + FPB <= T) {
+        if constexpr (PCM == 1) {   // int16 mono: a point is 4 bytes
+            const short* xs = reinterpret_cast<const short*>(x) + (long long)clip * n_samples;
+            if (ALIGNED && first >= 0 && last <= n_samples && tile * FPB + FPB <= T) {
+                const short* src = xs + first + (long long)(wave * FPW) * hop + 2 * p;
+#pragma unroll
+                for (int f = 0; f < FPW; ++f) {
+#pragma unroll
+                    for (int i = 0; i < E; ++i) xr[f][i] = *reinterpret_cast<const float*>(src + (long long)f * hop + 2 * i * P);
+                }
+            } else {
+#pragma unroll
+                for (int f = 0; f < FPW; ++f) {
+                    const int t = tile * FPB + wave * FPW + f;
+                    const long long s0 = (long long)t * hop - N;
+#pragma unroll
+                    for (int i = 0; i < E; ++i) {
+                        const long long s = s0 + 2 * (p + i * P);
+                        const unsigned lo = (t < T && s >= 0 && s < n_samples) ? (unsigned short)xs[s] : 0u;
+                        const unsigned hi = (t < T && s + 1 >= 0 && s + 1 < n_samples) ? (unsigned short)xs[s + 1] : 0u;
+                        xr[f][i] = __builtin_bit_cast(float, lo | hi << 16);
+                    }
+                }
+            }
+        } else if (ALIGNED && first >= 0 && last <= n_samples && tile * FPB + FPB <= T) {
             const float* src = xc + first + (long long)(wave * FPW) * hop + 2 * p;
 #pragma unroll
             for (int f = 0; f < FPW; ++f) {
@@ -275,8 +323,8 @@ __global__ __launch_bounds__(kFatWaves * 64) void k_stft_ft16(
             float2 v[E];
 #pragma unroll
             for (int i = 0; i < E; ++i) {
-                const float2 wv = win_l[po + i * P];
-                v[i] = make_float2(xr[f][i].x * wv.x, xr[f][i].y * wv.y);
+                const float2 wv = win_l[po + i * P], xv = PP::get(xr[f][i]);
+                v[i] = make_float2(xv.x * wv.x, xv.y * wv.y);
             }
             fft_frame<LOG2N, LOG2E>(v, frames + (wave * FPW + f) * PITCH, po, tw_l);
         }
@@ -357,7 +405,7 @@ __global__ __launch_bounds__(kFatWaves * 64) void k_stft_ft16(
 // the CARRIED value at frame t0 - 16 + tt: the sixteen lanes of an instruction again cover exactly one line.  Partial lines
 // remain only at the two ends of a segment (head: no carry yet; tail: flushed with the last tile).  Radix-16 schedule
 // (32 + 64 registers of transform and prefetch beside the carry; the radix-32 form of k_stft_ft16 stands at 206).
-template <int LOG2N, int LOG2E, bool ALIGNED, int SPEC>
+template <int LOG2N, int LOG2E, bool ALIGNED, int SPEC, int PCM = 0>
 __global__ __launch_bounds__(kFatWaves * 64) void k_stft_ft16c(
     const float* __restrict__ x, const float* __restrict__ win, const float2* __restrict__ twp,
     const float2* __restrict__ tws, float2* __restrict__ out, long long n_samples, int hop, int T, int TP, int tiles,
@@ -376,7 +424,12 @@ __global__ __launch_bounds__(kFatWaves * 64) void k_stft_ft16c(
     float2* tws_l = win_l + N;
     const int tid = threadIdx.x;
     for (int i = tid; i < C::TW; i += NT) tw_l[i] = twp[i];
-    for (int i = tid; i < N; i += NT) win_l[i] = reinterpret_cast<const float2*>(win)[i];
+    using PP = PcmPoint<PCM>;
+    static_assert(PCM == 0 || ALIGNED, "int16 input: the buffer-load form");
+    for (int i = tid; i < N; i += NT) {
+        const float2 wv = reinterpret_cast<const float2*>(win)[i];
+        win_l[i] = make_float2(wv.x * PP::scale(), wv.y * PP::scale());
+    }
     for (int i = tid; i <= N / 2; i += NT) tws_l[i] = tws[i];
     __syncthreads();
     const int wave = tid / P, p_lane = tid % P;
@@ -385,13 +438,23 @@ __global__ __launch_bounds__(kFatWaves * 64) void k_stft_ft16c(
     const bool xcd = ZAFX_XCD_ORDER && gridDim.x % 8 == 0;
     const int b0 = (int)((reinterpret_cast<uintptr_t>(out) >> 3) & 15);   // phase of the array's first element in its line
 
-    float2 xr[FPW][E];
+    typename PP::T xr[FPW][E];
     auto prefetch = [&](int clip, int tile) {
         const float* xc = x + (long long)clip * n_samples;
         if constexpr (ALIGNED) {
             // buffer loads with the CLIP as descriptor: a pair of samples before the clip's first or behind its last sample is out
             // of the descriptor's range and reads as zero -- which is the reference's zero padding (zaf.py:112-125; n_samples, hop
             // and every pair's first sample are even, so a pair is inside or outside as a whole).  No edge path, no 64-bit addresses.
+            if constexpr (PCM == 1) {   // int16 mono: a point is 4 bytes
+                const __amdgpu_buffer_rsrc_t rs = make_rsrc(reinterpret_cast<const short*>(x) + (long long)clip * n_samples, (unsigned)(n_samples * 2));
+#pragma unroll
+                for (int f = 0; f < FPW; ++f) {
+                    const int s0 = (tile * FPB + wave * FPW + f) * hop - N;
+                    const int vo = (s0 + 2 * p_lane) * 2;
+#pragma unroll
+                    for (int i = 0; i < E; ++i) xr[f][i] = buf_load_f32(rs, vo + i * P * 4);
+                }
+            } else {
             const __amdgpu_buffer_rsrc_t rs = make_rsrc(xc, (unsigned)(n_samples * 4));
 #pragma unroll
             for (int f = 0; f < FPW; ++f) {
@@ -400,7 +463,8 @@ __global__ __launch_bounds__(kFatWaves * 64) void k_stft_ft16c(
 #pragma unroll
                 for (int i = 0; i < E; ++i) xr[f][i] = buf_load_f32x2(rs, vo + i * P * 8);
             }
-        } else {
+            }
+        } else if constexpr (PCM != 1) {
 #pragma unroll
             for (int f = 0; f < FPW; ++f) {
                 const int t = tile * FPB + wave * FPW + f;
@@ -441,8 +505,8 @@ __global__ __launch_bounds__(kFatWaves * 64) void k_stft_ft16c(
             float2* park = frames + (wave * FPW + f) * PITCH;
 #pragma unroll
             for (int i = 0; i < E; ++i) {
-                const float2 wv = win_l[po + i * P];
-                park[po + i * P] = make_float2(xr[f][i].x * wv.x, xr[f][i].y * wv.y);
+                const float2 wv = win_l[po + i * P], xv = PP::get(xr[f][i]);
+                park[po + i * P] = make_float2(xv.x * wv.x, xv.y * wv.y);
             }
         }
 #pragma unroll
@@ -452,8 +516,8 @@ __global__ __launch_bounds__(kFatWaves * 64) void k_stft_ft16c(
             if (f == 0) {
 #pragma unroll
                 for (int i = 0; i < E; ++i) {
-                    const float2 wv = win_l[po + i * P];
-                    vv[i] = make_float2(xr[0][i].x * wv.x, xr[0][i].y * wv.y);
+                    const float2 wv = win_l[po + i * P], xv = PP::get(xr[0][i]);
+                    vv[i] = make_float2(xv.x * wv.x, xv.y * wv.y);
                 }
             } else {
                 frame_sync<P>();
@@ -2057,6 +2121,10 @@ static hipError_t run_stft_fat(const zafx_plan& pl, const float* x, float2* out,
     using F = FatCfg<LOG2N, LOG2E, FPB>;
     static_assert(F::SMEM <= (size_t)kMaxLdsBytes, "tile + tables exceed LDS");
     auto kern = k_stft_ft16<LOG2N, LOG2E, ALIGNED, SPEC, FPB>;
+    if constexpr (LOG2N == 10 && SPEC < 2 && FPB == kFatFrames) {   // (zafx_execute_pcm: int16 in the loads; stft_pcm_direct_ok vouches for the geometry)
+        if (pl.call_pcm == 1) kern = k_stft_ft16<LOG2N, LOG2E, ALIGNED, SPEC, FPB, 1>;
+        if (pl.call_pcm == 2) kern = k_stft_ft16<LOG2N, LOG2E, ALIGNED, SPEC, FPB, 2>;
+    }
     if (hipError_t e = ensure_dynamic_lds(reinterpret_cast<const void*>(kern), pl.device, F::SMEM); e != hipSuccess) return e;
     const int tiles = (T + FPB - 1) / FPB;
     const long long total = (long long)tiles * n_clips;
@@ -2076,6 +2144,10 @@ static hipError_t run_stft_fat_carry(const zafx_plan& pl, const float* x, float2
         constexpr int LOG2E = default_log2e(LOG2N);
         using F = FatCfg<LOG2N, LOG2E>;
         auto kern = k_stft_ft16c<LOG2N, LOG2E, ALIGNED, SPEC>;
+        if constexpr (LOG2N == 10 && ALIGNED) {
+            if (pl.call_pcm == 1) kern = k_stft_ft16c<LOG2N, LOG2E, true, SPEC, 1>;
+            if (pl.call_pcm == 2) kern = k_stft_ft16c<LOG2N, LOG2E, true, SPEC, 2>;
+        }
         if (hipError_t e = ensure_dynamic_lds(reinterpret_cast<const void*>(kern), pl.device, F::SMEM); e != hipSuccess) return e;
         const int tiles = (T + kFatFrames - 1) / kFatFrames;
         if ((long long)tiles * n_clips <= 0) return hipSuccess;
@@ -2366,6 +2438,14 @@ static hipError_t run_istft(const zafx_plan& pl, const float2* spec, float* y, i
 
 bool stft_supported(int log2n) { return log2n >= 5 && log2n <= 12; }
 int stft_frames_per_block(int log2n, int layout) { return stft_fpb(log2n, layout); }
+// int16 PCM (one or two channels) straight into the complex STFT at W = 2048 in the reference layout (k_stft_ft16 / k_stft_ft16c): even clip length and
+// hop, everything inside the 32-bit offsets of one descriptor (zafx_execute_pcm)
+bool stft_pcm_direct_ok(const zafx_plan& pl, int64_t n_frames, int n_channels, int sample_bytes, const void* d_pcm, int T) {
+    return sample_bytes == 2 && (n_channels == 1 || n_channels == 2) && pl.kind == ZAFX_STFT && pl.prm.precision == ZAFX_PRECISION_F32 && pl.bs_log2m == 0 &&
+           pl.log2nf == 10 && pl.layout == ZAFX_LAYOUT_FT && pl.prm.spectrum <= ZAFX_SPECTRUM_ONE_SIDED && n_frames % 2 == 0 && pl.H % 2 == 0 &&
+           reinterpret_cast<uintptr_t>(d_pcm) % 8 == 0 && n_frames < (1LL << 29) && (long long)T * pl.H < (1LL << 29);
+}
+
 const char* stft_kernel_name(int log2n, int layout) {
     if (ZAFX_STFT_FAT8 && log2n == 11 && layout == ZAFX_LAYOUT_FT) return "k_stft_ft16";
     if (ZAFX_STFT_BAND && log2n == 11 && layout == ZAFX_LAYOUT_FT) return "k_stft_ft16b";

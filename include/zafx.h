@@ -202,8 +202,8 @@ int zafx_pcm_to_float(zafx_plan* plan, const void* d_pcm, void* d_out, int64_t n
                       int n_channels, int sample_bytes);
 /* The transform of integer PCM that is already on the device, in one call: d_pcm (n_clips, n_frames, n_channels) interleaved int16 / int32 ->
  * what zafx_execute writes for the normalised mono signal (zaf.py:1202 x / 2^(bits-1), zaf.py:65 mean over the channels, then the plan's
- * transform).  Plans whose kernel takes the integers in its own loads -- int16, one or two channels, into ZAFX_MEL / ZAFX_MFCC and the
- * |X| / |X|^2 kinds of ZAFX_STFT at window_length 2048 -- read 2 bytes per sample and channel of HBM instead of 6 + 4; every other
+ * transform).  Plans whose kernel takes the integers in its own loads -- int16, one or two channels, into ZAFX_MEL / ZAFX_MFCC, ZAFX_STFT
+ * (every spectrum kind) and ZAFX_MDCT at window_length 2048 in the reference layout -- read 2 bytes per sample and channel of HBM instead of 6 + 4; every other
  * plan converts into a float32 staging array it owns (zafx_pcm_to_float) and runs zafx_execute on that.  Kinds as zafx_run_host_pcm. */
 int zafx_execute_pcm(zafx_plan* plan, const void* d_pcm, void* d_out, int64_t n_clips, int64_t n_frames, int n_channels, int sample_bytes);
 

@@ -191,3 +191,58 @@ def test_clipped_pcm_through_the_pcm_entry_points(zafx, consts, golden, channels
     pq = sig.clipped_pcm16(sig.N_CQT)
     pq = np.ascontiguousarray(pq[None, :, None] if channels == 1 else np.stack([pq, pq], axis=-1)[None])
     assert check(f"pcm{channels}.cqt", zafx.cqtspectrogram_pcm_batch(pq, sig.FS, 25, ck)[0], g["clipped_pcm_cqt"], TOL_FB, c=C_FLOOR_CQT) <= TOL_FB
+
+
+@pytest.mark.parametrize("name", sig.NAMES)
+@pytest.mark.parametrize("wl,hop", [(4096, 2048), (2048, 512), (1000, 250)])
+def test_signal_on_the_other_kernels(zafx, name, wl, hop):
+    """The same signals through the kernels the W = 2048 / hop 1024 cases do not reach -- the two-band forms of W = 4096 (k_stft_ft16b / bc,
+    k_istft_ft16b, k_mdct_ft32b / bc, k_mel_ft16b), 75 % overlap, a window that is not a power of two (the Bluestein forms) -- against the
+    oracle with the same two bounds."""
+    n = 40 * hop + 300
+    x = sig.signal(name, n)
+    x64 = x.astype(np.float64)
+    ham = zafx.hamming(wl)
+    s = orc.stft(x64, ham, hop)
+    half = s[: wl // 2 + 1]
+    tag = f"{name}_{wl}_{hop}"
+    got = zafx.stft_batch(x[None], ham, hop)[0]
+    assert check(f"{tag}.stft", got, s, TOL_FFT) <= TOL_FFT
+    y = zafx.istft_batch(s[None], ham, hop)[0]
+    yref = orc.istft(s, ham, hop)
+    assert len(y) == len(yref) and relerr(y, yref) <= TOL_FFT
+    nu = bin_noise(half, C_FLOOR, EPS32)
+    gotm = zafx.stft_batch(x[None], ham, hop, onesided="magnitude")[0]
+    assert check(f"{tag}.magnitude", gotm, np.abs(half), TOL_FFT, nu) <= TOL_FFT
+    if wl % 2 == 0:
+        kbd = zafx.kaiser_bessel_derived(wl) if wl & (wl - 1) == 0 else zafx.sine(wl)
+        m = orc.mdct(x64, kbd)
+        assert check(f"{tag}.mdct", zafx.mdct_batch(x[None], kbd)[0], m, TOL_FFT) <= TOL_FFT
+        yi, yiref = zafx.imdct_batch(m[None], kbd)[0], orc.imdct(m, kbd)
+        assert len(yi) == len(yiref) and relerr(yi, yiref) <= TOL_FFT
+    fb = zafx.melfilterbank(sig.FS, wl, 64)
+    fbd = fb.toarray()
+    mel_floor = fbd @ np.broadcast_to(nu, (fbd.shape[1], nu.shape[1])) + C_FLOOR * EPS32 * np.abs(orc.melspectrogram(x64, ham, hop, fb))
+    assert check(f"{tag}.mel", zafx.melspectrogram_batch(x[None], ham, hop, fb)[0], orc.melspectrogram(x64, ham, hop, fb), TOL_FB, mel_floor) <= TOL_FB
+
+
+@pytest.mark.parametrize("name", sig.NAMES)
+def test_signal_in_float64(zafx, consts, name):
+    """The float64 mode (the reference's own dtype) on the same signals: 1e-12 normwise on the tiled kernels of W = 2048
+    (k_stft_ft8_f64, k_mdct_ft16_f64) and on the inverse transforms; silence stays exactly zero."""
+    ham, kbd, fb, ck = consts
+    x64 = sig.signal(name, N_LONG).astype(np.float64)
+    s = orc.stft(x64, ham, sig.HOP)
+    got = zafx.stft_batch(x64[None], ham, sig.HOP, f64=True)[0]
+    m = orc.mdct(x64, kbd)
+    gotm = zafx.mdct_batch(x64[None], kbd, f64=True)[0]
+    if name == "silence":
+        assert not np.any(got) and not np.any(gotm)
+        return
+    assert relerr(got, s) <= 1e-12 and relerr(gotm, m) <= 1e-12
+    # per row: a row above 1e-9 of the peak is held to 1e-9 of its own level
+    rows = np.abs(s).max(axis=1)
+    live = rows > 1e-9 * rows.max()
+    assert np.all(np.abs(got - s).max(axis=1)[live] <= 1e-9 * rows[live])
+    assert relerr(zafx.istft_batch(s[None], ham, sig.HOP, f64=True)[0], orc.istft(s, ham, sig.HOP)) <= 1e-12
+    assert relerr(zafx.imdct_batch(m[None], kbd, f64=True)[0], orc.imdct(m, kbd)) <= 1e-12

@@ -920,6 +920,17 @@ def test_f64_mdct_on_the_tiled_kernel(zafx, n, clips):
         assert np.array_equal(got[7:14], got[0:7]) and np.array_equal(got[clips - 5:], got[(clips - 5) % 7:(clips - 5) % 7 + 5])
     zafx.mdct_batch(x[:1], w, layout="TF", f64=True)
     assert zafx.mdct_plan(w, layout="TF", f64=True).last_kernel == "k_mdct_f64"
+    # the inverse on its tiled form (k_imdct_ft16_f64: sixteen-frame tiles walked in order, seventeen frame buffers in rotation): clips in one
+    # segment and in several (few clips: a segment starts inside a clip and computes its left neighbour itself), the block behind the last frame
+    yi = zafx.imdct_batch(got, w, f64=True)
+    assert zafx.mdct_plan(w, inverse=True, f64=True).last_kernel == "k_imdct_ft16_f64" and yi.dtype == np.float64
+    for c in range(min(clips, 7)):
+        yref = orc.imdct(orc.mdct(x[c], w), w)
+        assert yi[c].shape == yref.shape
+        if yref.size:
+            assert relerr(yi[c], yref) <= TOL_F64, c
+            k = min(n, len(yref))
+            assert np.max(np.abs(yi[c][:k] - x[c, :k])) < 1e-12   # TDAC (zaf.py:1098-1109)
 
 
 @pytest.mark.parametrize("wl,hop,n", [(2048, 1024, 441000), (2048, 512, 30000), (1024, 300, 9001), (64, 32, 1000), (8192, 4096, 50000),

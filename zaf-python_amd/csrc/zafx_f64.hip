@@ -427,6 +427,130 @@ __global__ __launch_bounds__(kMd64Frames * 64) void k_mdct_ft16_f64(const double
     }
 }
 
+// ---------------------------------------------------------------------------------
+// k_imdct_ft16_f64: the inverse MDCT in float64 (zaf.py:1125-1182) on the tiled structure, W = 2048, reference layout.  A workgroup walks the
+// 16-frame tiles of a clip segment in order: coefficient rows gathered as 128-byte lines (sixteen frames x 8 B) straight into the pre-twiddled
+// DCT-IV input c[m] = (X[2m] + i X[M-1-2m]) g_m, a frame per wavefront (512 points as 8 x 8 x 8, post-twiddle and the pair's trade in place as in
+// k_mdct_ft16_f64), and the time-domain frames are never formed: an output sample is the windowed unfold of two neighbouring frames' DCT-IV
+// outputs, read from LDS where it is stored (coalesced 512-byte runs per wave).  Seventeen frame buffers in rotation: the last frame of a tile
+// stays where it is as the next tile's left neighbour.  (k_imdct_frames_f64 + k_ola_f64: frames through a scratch array, a frame per workgroup.)
+// ---------------------------------------------------------------------------------
+constexpr int kImd64Slots = kMd64Frames + 1;
+__global__ __launch_bounds__(kMd64Frames * 64) void k_imdct_ft16_f64(const double* __restrict__ coefs, const double* __restrict__ win, const double2* __restrict__ tw,
+                                                                      const double2* __restrict__ g, double* __restrict__ y, int T, int TP, long long out_len,
+                                                                      int tiles, int segs, int seg_tiles, int units) {
+    constexpr int NF = kMd64NF, M = 2 * NF, FPB = kMd64Frames, PITCH = kMd64Pitch, NS = kImd64Slots;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    double2* frames = reinterpret_cast<double2*>(smem_raw);
+    const int tid = threadIdx.x, wave = tid >> 6;
+    const double gain = 2.0 / (double)M;
+    // DCT-IV of the frame whose pre-twiddled input is in `buf` (natural order); leaves u as elements (u[2k], u[2k+1])
+    auto dct4_wave = [&](double2* buf, int lane) {
+        double2 v[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) v[i] = buf[phys8(lane + 64 * i)];
+        frame_sync<64>();
+        dft8d(v);
+#pragma unroll
+        for (int r = 0; r < 8; ++r) buf[phys8(8 * lane + r)] = v[r];
+        frame_sync<64>();
+#pragma unroll
+        for (int i = 0; i < 8; ++i) v[i] = buf[phys8(lane + 64 * i)];
+        frame_sync<64>();
+        {
+            const int k = lane & 7;
+#pragma unroll
+            for (int r = 1; r < 8; ++r) v[r] = dmul(v[r], root512(tw, 8 * r * k));
+            dft8d(v);
+            const int base = ((lane >> 3) << 6) + k;
+#pragma unroll
+            for (int r = 0; r < 8; ++r) buf[phys8(base + 8 * r)] = v[r];
+        }
+        frame_sync<64>();
+#pragma unroll
+        for (int i = 0; i < 8; ++i) v[i] = buf[phys8(lane + 64 * i)];
+        frame_sync<64>();
+#pragma unroll
+        for (int r = 1; r < 8; ++r) v[r] = dmul(v[r], root512(tw, r * lane));
+        dft8d(v);
+#pragma unroll
+        for (int r = 0; r < 8; ++r) buf[phys8(lane + 64 * r)] = dmul(v[r], g[lane + 64 * r]);   // y_k = Z[k] g_k
+        frame_sync<64>();
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int k = lane + 64 * r, kp = NF - 1 - k;
+            const double2 yk = buf[phys8(k)], yp = buf[phys8(kp)];
+            buf[phys8(k)] = make_double2(yk.x, -yp.y);
+            buf[phys8(kp)] = make_double2(yp.x, -yk.y);
+        }
+    };
+    for (int unit = blockIdx.x; unit < units; unit += gridDim.x) {
+        const int clip = unit / segs, seg = unit % segs;
+        const int tile_a = seg * seg_tiles, tile_b = min(tile_a + seg_tiles, tiles);
+        const double* cp = coefs + (long long)clip * M * TP;
+        double* yc = y + (long long)clip * out_len;
+        int rot = 0;
+        if (tile_a > 0) {   // the segment's left neighbour: frame 16 tile_a - 1, by the last wave alone
+            if (wave == FPB - 1) {
+                int lane = tid & 63;
+                asm volatile("" : "+v"(lane));
+                double2* buf = frames + ((rot + FPB) % NS) * PITCH;
+                const int t = tile_a * FPB - 1;
+#pragma unroll
+                for (int i = 0; i < 8; ++i) {
+                    const int m = lane + 64 * i;
+                    buf[phys8(m)] = dmul(make_double2(cp[(long long)(2 * m) * TP + t], cp[(long long)(M - 1 - 2 * m) * TP + t]), g[m]);
+                }
+                frame_sync<64>();
+                dct4_wave(buf, lane);
+            }
+            lds_barrier();
+        }
+        for (int tile = tile_a; tile < tile_b; ++tile) {
+            const int t0 = tile * FPB;
+            int to = tid;
+            asm volatile("" : "+v"(to));   // (opaque per tile: table values are re-read, not hoisted and spilled)
+            {   // rows of the tile: thread = frame (to & 15) x 64 values of m, the two rows of each as 8-byte pieces of a 128-byte line
+                const int f = to & 15, mq = to >> 4, t = t0 + f;
+                double2* buf = frames + ((rot + f) % NS) * PITCH;
+                if (t < T) {
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) {
+                        const int m = mq + 64 * i;
+                        buf[phys8(m)] = dmul(make_double2(cp[(long long)(2 * m) * TP + t], cp[(long long)(M - 1 - 2 * m) * TP + t]), g[m]);
+                    }
+                }
+            }
+            lds_barrier();
+            if (t0 + wave < T) dct4_wave(frames + ((rot + wave) % NS) * PITCH, to & 63);
+            lds_barrier();
+            // output blocks b = t0 .. t0 + 15 (and b = T behind the clip's last frame): sample s = b M + i of the padded signal is the second half of
+            // frame b - 1 plus the first half of frame b (zaf.py:1172-1179), output index s - M (the trim of :1182)
+            const int b_hi = tile + 1 >= tiles ? T : t0 + FPB - 1;
+            for (int b = max(t0, 1); b <= b_hi; ++b) {
+                const int i = to;   // (M = 1024 = the workgroup)
+                const long long o = (long long)(b - 1) * M + i;
+                double acc = 0.0;
+                {   // frame b - 1, n = M + i
+                    const int fprev = b - 1 - t0;   // -1: the tile before (slot rot + 16)
+                    const double* u = reinterpret_cast<const double*>(frames + ((rot + (fprev < 0 ? FPB : fprev)) % NS) * PITCH);
+                    const int j = i < NF ? NF - 1 - i : i - NF;
+                    acc = -u[2 * phys8(j >> 1) + (j & 1)] * win[M + i] * gain;
+                }
+                if (b < T && b <= t0 + FPB - 1) {   // frame b, n = i
+                    const double* u = reinterpret_cast<const double*>(frames + ((rot + (b - t0)) % NS) * PITCH);
+                    const int j = i < NF ? NF + i : 3 * NF - 1 - i;
+                    const double uv = u[2 * phys8(j >> 1) + (j & 1)];
+                    acc += (i < NF ? uv : -uv) * win[i] * gain;
+                }
+                if (o < out_len) __builtin_nontemporal_store(acc, yc + o);
+            }
+            rot = (rot + FPB) % NS;
+            lds_barrier();
+        }
+    }
+}
+
 // real(ifft(X)) of one frame per workgroup (zaf.py:223), W samples into the scratch, unscaled by 2 W
 __global__ __launch_bounds__(kThreadsBig) void k_ifft_frames_f64(
     const double2* __restrict__ spec, const double2* __restrict__ tw, const double2* __restrict__ tws, double* __restrict__ frames,
@@ -1079,6 +1203,21 @@ hipError_t launch_mdct_f64(const zafx_plan& pl, const double* x, double* out, in
 
 hipError_t launch_imdct_f64(zafx_plan& pl, const double* coefs_all, double* y_all, int64_t n_clips_all, int T, int64_t out_len) {
     if ((long long)n_clips_all * T <= 0 || out_len <= 0) return hipSuccess;
+    if (ZAFX_F64_TILED && pl.W == 2048 && pl.layout == ZAFX_LAYOUT_FT && pl.bs_log2m == 0) {
+        const int tiles = (T + kMd64Frames - 1) / kMd64Frames;
+        const int segs = carry_segments(n_clips_all, tiles, pl.n_cus);
+        const int seg_tiles = (tiles + segs - 1) / segs;
+        const long long units = (long long)n_clips_all * segs;
+        if (units < (1LL << 31)) {
+            const size_t smem = (size_t)kImd64Slots * kMd64Pitch * sizeof(double2);
+            auto kern = k_imdct_ft16_f64;
+            if (hipError_t e = ensure_dynamic_lds(reinterpret_cast<const void*>(kern), pl.device, smem); e != hipSuccess) return e;
+            pl.ran = "k_imdct_ft16_f64";
+            hipLaunchKernelGGL(kern, dim3((unsigned)std::min<long long>(units, pl.n_cus)), dim3(kMd64Frames * 64), smem, pl.stream, coefs_all, pl.d_window64, pl.d_tw64,
+                               pl.d_tws64, y_all, T, (int)row_pitch(pl, T), (long long)out_len, tiles, segs, seg_tiles, (int)units);
+            return hipGetLastError();
+        }
+    }
     const int64_t chunk = clips_per_chunk(n_clips_all, T, pl.W);   // (scratch budget: see launch_istft_f64)
     if (hipError_t e = grow_scratch(pl, (size_t)chunk * T * pl.W * sizeof(double)); e != hipSuccess) return e;
     const int64_t in_per_clip = pl.layout == ZAFX_LAYOUT_FT ? (int64_t)(pl.W / 2) * row_pitch(pl, T) : (int64_t)T * (pl.W / 2);

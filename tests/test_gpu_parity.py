@@ -766,6 +766,38 @@ def test_stft_w4096_two_bands(zafx, hop, n, clips):
             assert relerr(pw[c], np.abs(ref[c, :half]) ** 2) <= 2 * TOL_FFT
 
 
+@pytest.mark.parametrize("hop,n,clips", [(4096, 300001, 3), (4096, 4096 * 31, 2), (2048, 140000, 2), (2048, 2048 * 63 - 5, 2), (300, 30000, 1), (9000, 150000, 2),
+                                          (4096, 1, 1), (4096, 8193, 1), (1764, 441000, 1), (4096, 4096 * 47, 100), (4096, 16 * 4096 * 2, 20), (4095, 4095 * 15, 2)])
+def test_stft_w8192_four_classes(zafx, hop, n, clips):
+    """W = 8192 in the reference layout runs k_stft_ft16q: sixteen-frame tiles as four classes of bins (rows 4q from the packed transform of
+    the sum of the frame's quarters, rows 8p + 2, 8p + 1, 8p + 5 from three more 1024-point transforms, every other row a mirror; zaf.py:128-139
+    is what it replaces).  Any clip length and hop (4-byte loads), whole and ragged last tiles, rows on and off the 128-byte grid, more tiles
+    than workgroups, every spectrum kind."""
+    x = np.stack([synth_clip(43, c % 4, n) for c in range(clips)])
+    w = zafx.hamming(8192)
+    plan = zafx.stft_plan(w, hop)
+    ref = orc.stft_batch(x[:4].astype(np.float64), w, hop)
+    got = zafx.stft_batch(x, w, hop)
+    T = got.shape[2]
+    assert plan.last_kernel == ("k_stft_ft16q" if T % 16 == 0 else "k_stft"), T   # complex two-sided rows off the line grid: the one-workgroup-per-tile kernel
+    assert got.dtype == np.complex64 and got.shape[1:] == ref.shape[1:]
+    for c in range(clips):
+        assert relerr(got[c], ref[c % 4]) <= TOL_FFT, c
+    if clips <= 3:
+        half = 4097
+        one = zafx.stft_batch(x, w, hop, onesided=True)
+        mag = zafx.stft_batch(x, w, hop, onesided="magnitude")
+        pw = zafx.stft_batch(x, w, hop, onesided="power")
+        for kind in (True, "magnitude", "power"):
+            assert zafx.stft_plan(w, hop, onesided=kind).last_kernel == "k_stft_ft16q"
+        for c in range(clips):
+            assert relerr(one[c], ref[c, :half]) <= TOL_FFT
+            if T % 16 == 0:
+                assert np.array_equal(one[c], got[c, :half])
+            assert relerr(mag[c], np.abs(ref[c, :half])) <= TOL_FFT
+            assert relerr(pw[c], np.abs(ref[c, :half]) ** 2) <= 2 * TOL_FFT
+
+
 @pytest.mark.parametrize("hop,n,clips", [(2048, 150001, 3), (2048, 16 * 2048 * 2, 2), (1024, 70000, 2), (512, 40000, 1), (4096, 200000, 2),
                                           (1764, 100000, 2), (2048, 1, 1), (2048, 30 * 2048 * 16, 1), (2048, 40000, 300), (1000, 50000, 1)])
 def test_istft_w4096_two_bands(zafx, hop, n, clips):
@@ -902,6 +934,35 @@ def test_f64_stft_on_the_tiled_kernel(zafx, hop, n, clips):
     assert zafx.stft_plan(w, hop, onesided="magnitude", f64=True).last_kernel == "k_stft_f64"
     zafx.stft_batch(x[:1], w, hop, layout="TF", f64=True)
     assert zafx.stft_plan(w, hop, layout="TF", f64=True).last_kernel == "k_stft_f64"
+
+
+@pytest.mark.parametrize("hop,n,clips", [(1024, 441000, 3), (1024, 30001, 2), (1024, 1024 * 47, 40), (1536, 50000, 3), (2048, 40000, 2), (1025, 30011, 2),
+                                         (1024, 1, 1), (1024, 1024 * 15, 2), (1200, 99999, 9)])
+def test_f64_istft_on_the_tiled_kernel(zafx, hop, n, clips):
+    """W = 2048 in the reference layout, float64, hop >= W / 2: k_istft_ft8_f64 (8-frame tiles of complex128 rows, the Hermitian fold in the
+    loads, a frame per wavefront, frames overlap-added where they lie in LDS; zaf.py:214-241 in its own dtype) -- few clips (segments start
+    inside a clip and compute their left neighbour), many clips, ragged last tiles, hops with and without overlap, two-sided and one-sided;
+    shorter hops and the other layout stay on the scratch + overlap-add form."""
+    x = np.stack([synth_clip(41, c % 7, n).astype(np.float64) + 1e-9 * (c % 7) for c in range(clips)])
+    w = zafx.hamming(2048)
+    spec = orc.stft_batch(x[:7], w, hop)
+    if clips > 7:
+        spec = np.concatenate([spec] * (clips // 7 + 1))[:clips]
+    for one in (False, True):
+        y = zafx.istft_batch(np.ascontiguousarray(spec[:, :1025] if one else spec), w, hop, onesided=one, f64=True)
+        assert zafx.istft_plan(w, hop, onesided=one, f64=True).last_kernel == "k_istft_ft8_f64" and y.dtype == np.float64
+        for c in range(min(clips, 7)):
+            ref = orc.istft(spec[c], w, hop)
+            assert y[c].shape == ref.shape and relerr(y[c], ref) <= TOL_F64, (one, c)
+        if clips > 7:
+            assert all(np.array_equal(y[c], y[c % 7]) for c in range(7, clips))
+    zafx.istft_batch(spec[:1], w, hop, f64=True)
+    for h1, layout in ((512, "FT"), (hop, "TF")):
+        s0 = orc.stft_batch(x[:1], w, h1)
+        s1 = np.ascontiguousarray(s0.transpose(0, 2, 1)) if layout == "TF" else s0
+        y1 = zafx.istft_batch(s1, w, h1, layout=layout, f64=True)
+        assert zafx.istft_plan(w, h1, layout=layout, f64=True).last_kernel == "k_ifft_frames_f64"
+        assert relerr(y1[0], orc.istft(s0[0], w, h1)) <= TOL_F64
 
 
 @pytest.mark.parametrize("n,clips", [(441000, 3), (30001, 2), (1024 * 47, 40), (1, 1), (1024 * 16 + 2, 2), (99999, 2)])

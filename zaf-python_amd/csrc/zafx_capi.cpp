@@ -899,6 +899,13 @@ int zafx_plan_create(zafx_plan** out, int device, int kind, const zafx_params* p
         const auto sub = build_pass_twiddles(10, 4);   // the two 1024-point band transforms of k_stft_ft16b
         e = upload(&pl->d_tw_sub, sub.data(), sub.size() * sizeof(cf32));
     }
+    if (e == hipSuccess && (kind == ZAFX_STFT || kind == ZAFX_MEL || kind == ZAFX_MFCC) && pl->log2nf == 12 && pl->prm.precision == ZAFX_PRECISION_F32 && pl->bs_log2m == 0) {
+        const auto sub = build_pass_twiddles(10, 4);   // the four 1024-point class transforms of k_stft_ft16q, and the roots that form their inputs
+        e = upload(&pl->d_tw_sub, sub.data(), sub.size() * sizeof(cf32));
+        std::vector<cf32> q(4096);
+        for (int n = 0; n < 4096; ++n) q[(size_t)n] = unit_root(n, 8192);
+        if (e == hipSuccess) e = upload(&pl->d_tw_quad, q.data(), q.size() * sizeof(cf32));
+    }
     if (e == hipSuccess && kind == ZAFX_MDCT && pl->log2nf == 10 && pl->prm.precision == ZAFX_PRECISION_F32 && pl->bs_log2m == 0) {
         // k_mdct_ft32b: pass tables of the two 512-point band transforms; g in band-major order, and g[n] exp(-2 pi i n / 1024)
         const auto sub = build_pass_twiddles(9, 3);
@@ -996,6 +1003,7 @@ int zafx_plan_destroy(zafx_plan* pl) {
     if (pl->d_wfold) (void)hipFree(pl->d_wfold);
     if (pl->d_tw_pass) (void)hipFree(pl->d_tw_pass);
     if (pl->d_tw_r32) (void)hipFree(pl->d_tw_r32);
+    if (pl->d_tw_quad) (void)hipFree(pl->d_tw_quad);
     if (pl->d_tw_sub) (void)hipFree(pl->d_tw_sub);
     if (pl->d_tw_band) (void)hipFree(pl->d_tw_band);
     if (pl->d_fbw) (void)hipFree(pl->d_fbw);

@@ -551,6 +551,113 @@ __global__ __launch_bounds__(kMd64Frames * 64) void k_imdct_ft16_f64(const doubl
     }
 }
 
+// ---------------------------------------------------------------------------------
+// k_istft_ft8_f64: the inverse STFT in float64 (zaf.py:214-241) on the tiled structure, W = 2048, reference layout, hop >= W / 2 (a sample under at
+// most two frames).  A workgroup of 8 waves walks the 8-frame tiles of a clip segment in order: spectrum rows k, W-k, N-k, N+k gathered as 128-byte
+// lines (eight frames x 16 B) straight into the Hermitian fold (the packed half-length spectrum with re / im swapped, so that the FORWARD transform
+// inverts: k_ifft_frames_f64), a frame per wavefront (fft1024_f64), and the overlap-add reads the frames where they lie -- nine buffers in rotation,
+// the last frame of a tile stays as the next tile's left neighbour --, adds in the reference's ascending frame order and stores coalesced runs.
+// ---------------------------------------------------------------------------------
+constexpr int kIst64Slots = kF64Frames + 1;
+template <bool ONE>
+__global__ __launch_bounds__(kF64Frames * 64) void k_istft_ft8_f64(const double2* __restrict__ spec, const double2* __restrict__ tw, const double2* __restrict__ tws,
+                                                                    double* __restrict__ y, int T, int TP, int hop, long long out_len, double scale, int tiles,
+                                                                    int segs, int seg_tiles, int units) {
+    constexpr int N = kF64N, W = 2 * N, FPB = kF64Frames, PITCH = kF64Pitch, NS = kIst64Slots, ROWS = ONE ? N + 1 : W;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    double2* frames = reinterpret_cast<double2*>(smem_raw);
+    const int tid = threadIdx.x, wave = tid >> 6;
+    // Hermitian fold of the pair (k, N - k) of frame t (column t of `sp`) into buf (k_ifft_frames_f64's formulas)
+    auto fold = [&](const double2* sp, int t, int k, double2* buf) {
+        auto row = [&](int r) { return sp[(long long)r * TP + t]; };
+        if (k == 0) {
+            const double a0 = 2.0 * row(0).x, an = 2.0 * row(N).x;
+            buf[0] = make_double2(a0 - an, a0 + an);
+            const double2 xc = row(N / 2);
+            const double2 xd = ONE ? dconj(xc) : row(N + N / 2);
+            const double2 h = make_double2(xc.x + xd.x, xc.y - xd.y);
+            buf[physd(N / 2)] = make_double2(-2.0 * h.y, 2.0 * h.x);
+        } else {
+            const double2 xk = row(k), xnk = row(N - k);
+            const double2 xwk = ONE ? dconj(xk) : row(W - k);
+            const double2 xnpk = ONE ? dconj(xnk) : row(N + k);
+            const double2 ak = make_double2(xk.x + xwk.x, xk.y - xwk.y);
+            const double2 an = make_double2(xnk.x + xnpk.x, xnk.y - xnpk.y);
+            const double2 e = make_double2(ak.x + an.x, ak.y - an.y);
+            const double2 d = make_double2(ak.x - an.x, ak.y + an.y);
+            const double2 o = dmulc(d, tws[k]);
+            const double2 zk = make_double2(e.x - o.y, e.y + o.x), zn = make_double2(e.x + o.y, -e.y + o.x);
+            buf[physd(k)] = make_double2(zk.y, zk.x);
+            buf[physd(N - k)] = make_double2(zn.y, zn.x);
+        }
+    };
+    auto transform = [&](double2* buf, int lane) {
+        double2 v[16], w2[16];
+#pragma unroll
+        for (int i = 0; i < 16; ++i) v[i] = buf[physd(lane + 64 * i)];
+        frame_sync<64>();
+#pragma unroll
+        for (int r = 1; r < 16; ++r) w2[r] = root1024(tw, 4 * r * (lane & 15));
+        fft1024_f64(v, buf, lane, w2, tw);
+    };
+    for (int unit = blockIdx.x; unit < units; unit += gridDim.x) {
+        const int clip = unit / segs, seg = unit % segs;
+        const int tile_a = seg * seg_tiles, tile_b = min(tile_a + seg_tiles, tiles);
+        const double2* sp = spec + (long long)clip * ROWS * TP;
+        double* yc = y + (long long)clip * out_len;
+        int rot = 0;
+        if (tile_a > 0) {   // the segment's left neighbour: frame 8 tile_a - 1, by the last wave alone
+            if (wave == FPB - 1) {
+                int lane = tid & 63;
+                asm volatile("" : "+v"(lane));
+                double2* buf = frames + ((rot + FPB) % NS) * PITCH;
+#pragma unroll
+                for (int i = 0; i < 8; ++i) fold(sp, tile_a * FPB - 1, lane + 64 * i, buf);
+                frame_sync<64>();
+                transform(buf, lane);
+            }
+            lds_barrier();
+        }
+        for (int tile = tile_a; tile < tile_b; ++tile) {
+            const int t0 = tile * FPB;
+            int to = tid;
+            asm volatile("" : "+v"(to));   // (opaque per tile: table values are re-read, not hoisted and spilled)
+            {
+                const int f = to & 7, kq = to >> 3, t = t0 + f;
+                double2* buf = frames + ((rot + f) % NS) * PITCH;
+                if (t < T) {
+#pragma unroll 2
+                    for (int i = 0; i < 8; ++i) fold(sp, t, kq + 64 * i, buf);
+                }
+            }
+            lds_barrier();
+            if (t0 + wave < T) transform(frames + ((rot + wave) % NS) * PITCH, to & 63);
+            lds_barrier();
+            // samples s of the padded signal that no later frame reaches: [t0 hop, (t0 + 8) hop), and everything up to the end behind the clip's last frame
+            const long long s_lo = (long long)t0 * hop;
+            const long long s_hi = tile + 1 >= tiles ? (long long)(T - 1) * hop + W : (long long)(t0 + FPB) * hop;
+            for (long long s = s_lo + to; s < s_hi; s += FPB * 64) {
+                const long long o = s - (W - hop);
+                if (o < 0 || o >= out_len) continue;
+                const int j = (int)min((long long)(T - 1), s / hop);   // the last frame that reaches s; the one before it when s - (j - 1) hop < W
+                double acc = 0.0;
+#pragma unroll
+                for (int d = 1; d >= 0; --d) {   // ascending frame order (zaf.py:226-233)
+                    const int jj = j - d;
+                    const long long n = s - (long long)jj * hop;
+                    if (jj < 0 || n < 0 || n >= W) continue;
+                    const int fl = jj - t0;   // -1: the tile before
+                    const double* fr = reinterpret_cast<const double*>(frames + ((rot + (fl < 0 ? FPB : fl)) % NS) * PITCH);
+                    acc += fr[2 * physd((int)n >> 1) + (((int)n & 1) ^ 1)];   // components come out swapped
+                }
+                __builtin_nontemporal_store(acc * scale, yc + o);
+            }
+            rot = (rot + FPB) % NS;
+            lds_barrier();
+        }
+    }
+}
+
 // real(ifft(X)) of one frame per workgroup (zaf.py:223), W samples into the scratch, unscaled by 2 W
 __global__ __launch_bounds__(kThreadsBig) void k_ifft_frames_f64(
     const double2* __restrict__ spec, const double2* __restrict__ tw, const double2* __restrict__ tws, double* __restrict__ frames,
@@ -1093,6 +1200,24 @@ static int64_t clips_per_chunk(int64_t n_clips, int T, int W) { return scratch_c
 
 hipError_t launch_istft_f64(zafx_plan& pl, const double2* spec_all, double* y_all, int64_t n_clips_all, int T, int64_t out_len) {
     if ((long long)n_clips_all * T <= 0 || out_len <= 0) return hipSuccess;
+    if (ZAFX_F64_TILED && pl.W == 2048 && pl.layout == ZAFX_LAYOUT_FT && pl.bs_log2m == 0 && 2 * pl.H >= pl.W && pl.H <= pl.W &&
+        (long long)T * pl.H < (1LL << 40)) {
+        const int tiles = (T + kF64Frames - 1) / kF64Frames;
+        const int segs = carry_segments(n_clips_all, tiles, pl.n_cus);
+        const int seg_tiles = (tiles + segs - 1) / segs;
+        const long long units = (long long)n_clips_all * segs;
+        if (units < (1LL << 31)) {
+            const size_t smem = (size_t)kIst64Slots * kF64Pitch * sizeof(double2);
+            const bool one = pl.prm.spectrum == ZAFX_SPECTRUM_ONE_SIDED;
+            auto kern = one ? k_istft_ft8_f64<true> : k_istft_ft8_f64<false>;
+            if (hipError_t e = ensure_dynamic_lds(reinterpret_cast<const void*>(kern), pl.device, smem); e != hipSuccess) return e;
+            const double scale = 1.0 / (2.0 * (double)pl.W * pl.cola_gain64);   // 1/W of the inverse DFT x the factor 2 left by the fold
+            pl.ran = "k_istft_ft8_f64";
+            hipLaunchKernelGGL(kern, dim3((unsigned)std::min<long long>(units, pl.n_cus)), dim3(kF64Frames * 64), smem, pl.stream, spec_all, pl.d_tw64, pl.d_tws64, y_all,
+                               T, (int)row_pitch(pl, T), pl.H, (long long)out_len, scale, tiles, segs, seg_tiles, (int)units);
+            return hipGetLastError();
+        }
+    }
     const int64_t chunk = clips_per_chunk(n_clips_all, T, pl.W);
     if (hipError_t e = grow_scratch(pl, (size_t)chunk * T * pl.W * sizeof(double)); e != hipSuccess) return e;
     const int64_t rows = pl.prm.spectrum == ZAFX_SPECTRUM_ONE_SIDED ? pl.W / 2 + 1 : pl.W;

@@ -139,6 +139,7 @@ struct zafx_plan {
     float* d_dctw = nullptr;
     float2* d_tw_band = nullptr;   // k_mdct_ft32b (MDCT plans of W = 4096): gb[s][q] = g[2 q + s] (1024 entries), then bt[n] = g[n] exp(-2 pi i n / 1024) (512)
     float2* d_tw_sub = nullptr;    // pass twiddles of the band transforms: 1024 points (k_stft_ft16b; STFT / mel plans of W = 4096), 512 points (k_mdct_ft32b; MDCT plans of W = 4096)
+    float2* d_tw_quad = nullptr;   // exp(-2 pi i n / 8192), n < 4096 (k_stft_ft16q; STFT / mel plans of W = 8192)
     float2* d_tw_r32 = nullptr;    // pass twiddles of the radix-32 schedule (1024 points as 32 x 32), STFT plans of W = 2048
     // float64 mode (ZAFX_PRECISION_F64, zafx_f64.hip)
     double* d_window64 = nullptr;

@@ -1253,7 +1253,7 @@ static hipError_t run_mel_wide(zafx_plan& pl, const float* x, float* out, int64_
     st.prm.spectrum = mfcc ? ZAFX_SPECTRUM_POWER : ZAFX_SPECTRUM_MAGNITUDE;
     st.prm.row_align = 32;
     st.W = pl.W; st.H = pl.H; st.layout = ZAFX_LAYOUT_FT; st.log2nf = pl.log2nf; st.log2e = pl.log2e;
-    st.d_window = pl.d_window; st.d_tw_pass = pl.d_tw_pass; st.d_tw_aux = pl.d_tw_aux; st.d_tw_sub = pl.d_tw_sub; st.d_tw_r32 = pl.d_tw_r32;
+    st.d_window = pl.d_window; st.d_tw_pass = pl.d_tw_pass; st.d_tw_aux = pl.d_tw_aux; st.d_tw_sub = pl.d_tw_sub; st.d_tw_r32 = pl.d_tw_r32; st.d_tw_quad = pl.d_tw_quad;
     st.bs_log2m = pl.bs_log2m; st.d_bs_chirp = pl.d_bs_chirp; st.d_bs_bhat = pl.d_bs_bhat;   // (a window that is not a power of two: the Bluestein STFT)
     const size_t smem = mfcc ? (size_t)pl.prm.n_filters * 64 * sizeof(float) : 0;
     if (hipError_t e = ensure_dynamic_lds(reinterpret_cast<const void*>(k_melfb), pl.device, std::max<size_t>(smem, 1)); e != hipSuccess) return e;

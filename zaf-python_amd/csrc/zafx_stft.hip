@@ -758,6 +758,267 @@ __global__ __launch_bounds__(kFatWaves * 64) void k_stft_ft16b(
 }
 
 // ---------------------------------------------------------------------------------
+// forward, reference layout, W = 8192: the persistent 16-frame kernel over FOUR classes of bins (k_stft_ft16q)
+// ---------------------------------------------------------------------------------
+// Two decimation steps of the kind k_stft_ft16b takes once would pair band 1 with band 3 in the real split (Z[m] with Z[M - m]), and two bands of a
+// 16-frame tile do not fit LDS together.  Decimating the REAL frame v[n] = w[n] x[n] (x_m[n] = v[n + 2048 m]) instead gives four 1024-point complex
+// transforms that are each complete on their own, with no pairing across them and no split arithmetic but for the first:
+//     X[4q]      = RFFT_2048(s)[q],  s = x0 + x1 + x2 + x3             packed (s[2n], s[2n + 1]) + the real split, as W = 2048   (class A)
+//     X[8p + 2]  = FFT_1024(c)[p],   c[n] = (r[n] - i r[n + 1024]) w_4096^n,  r = x0 - x1 + x2 - x3                                (class C)
+//     X[8p + 1]  = FFT_1024(h[n] + h[n + 1024])[p],  h[n] = ((x0 - x2) - i (x1 - x3))[n] w_8192^n,  n < 2048                      (class D1)
+//     X[8p + 5]  = FFT_1024((h[n] - h[n + 1024]) w_2048^n)[p]                                                                      (class D5)
+// and every other row is a mirror, X[W - k] = conj X[k] (rows 6, 7, 3 mod 8).  A tile is four rounds of the W = 2048 kernel's phases on the same
+// sixteen frame buffers; the frame is read twice (classes A + C from the sums x0 + x2, x1 + x3; D1 + D5 from the differences), as 4-byte buffer
+// loads of n = lane + 64 i (any clip alignment; samples outside the clip read 0 = the reference's padding, zaf.py:112-125), the second reader
+// from L2.  Class A goes through the frame buffer once (its packed pairs lie in neighbouring lanes); the others are formed in the transform's
+// own register arrangement, the waiting class (C, D5) kept in 64 registers.
+#ifndef ZAFX_QCH
+#define ZAFX_QCH 1
+#endif
+constexpr int QCH = ZAFX_QCH;   // pairs (n, n + 1024) of a frame requested at once
+struct QuadCfg {
+    using C = FftCfg<10, 4>;
+    static constexpr int N = 1024, Q = 2048, W = 8192, FPB = kFatFrames, NT = kFatWaves * 64, FPW = 2;
+    static constexpr int PITCH = FatCfg<10, 4>::PITCH;
+    static constexpr size_t SMEM = (size_t)(FPB * PITCH + C::TW + N / 2 + 1) * 8;
+};
+static_assert(QuadCfg::SMEM <= (size_t)kMaxLdsBytes, "k_stft_ft16q: tile + tables exceed LDS");
+
+template <int SPEC>
+__global__ __launch_bounds__(kFatWaves * 64) void k_stft_ft16q(
+    const float* __restrict__ x, const float* __restrict__ win, const float2* __restrict__ twp, const float2* __restrict__ twq,
+    float2* __restrict__ out, long long n_samples, int hop, int T, int TP, int tiles, int total_tiles) {
+    using B = QuadCfg;
+    using C = B::C;
+    constexpr int N = B::N, Q = B::Q, W = B::W, P = 64, E = 16, NT = B::NT, FPB = B::FPB, FPW = B::FPW, PITCH = B::PITCH;
+    constexpr int ROWS = SPEC ? W / 2 + 1 : W;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    float2* frames = reinterpret_cast<float2*>(smem_raw);
+    float2* tw_l = frames + FPB * PITCH;   // pass tables of the 1024-point transform
+    float2* tws_l = tw_l + C::TW;          // exp(-2 pi i q / 2048), q <= 512: the split roots of class A
+    const int tid = threadIdx.x;
+    for (int i = tid; i < C::TW; i += NT) tw_l[i] = twp[i];
+    for (int i = tid; i <= N / 2; i += NT) tws_l[i] = twq[4 * i];
+    __syncthreads();
+    const int wave = tid / P, p_lane = tid % P;
+    const int tt = tid % FPB, kq = tid / FPB;
+    const float2* fb = frames + tt * PITCH;
+    const bool lines_whole = TP % 16 == 0 && reinterpret_cast<uintptr_t>(out) % 128 == 0;
+    const bool xcd = ZAFX_XCD_ORDER && gridDim.x % 8 == 0;
+    // QCH pairs (n, n + 1024), n = lane + 64 (i0 + j), of the wave's two frames (samples s0, s0 + hop on): the four quarters' samples and window
+    // values, requested one chunk ahead of their use (walk)
+    struct Chunk {
+        float xs[FPW][QCH][2][4], ws[QCH][2][4];
+    };
+    auto request = [&](const __amdgpu_buffer_rsrc_t& rs, int s0, int i0, Chunk& c) {
+        int pc = p_lane;
+        asm volatile("" : "+v"(pc));   // (the window values of a chunk are read again in the other pass, not kept)
+#pragma unroll
+        for (int j = 0; j < QCH; ++j)
+#pragma unroll
+            for (int h = 0; h < 2; ++h)
+#pragma unroll
+                for (int m = 0; m < 4; ++m) {
+                    const int n = pc + 64 * (i0 + j) + N * h + Q * m;
+#pragma unroll
+                    for (int f = 0; f < FPW; ++f) c.xs[f][j][h][m] = buf_load_f32(rs, (s0 + f * hop + n) * 4);
+                    c.ws[j][h][m] = win[n];
+                }
+    };
+    // every pair of the two frames in turn: use(i, v) with v[f][h][m] = w x of frame f, sample lane + 64 i + 1024 h + 2048 m
+    auto walk = [&](const __amdgpu_buffer_rsrc_t& rs, int s0, auto use) {
+        Chunk cb[2];
+        int pu = p_lane;
+        asm volatile("" : "+v"(pu));   // (the roots of a pass are read again per tile, not hoisted out of the tile loop and spilled)
+        request(rs, s0, 0, cb[0]);
+#pragma unroll
+        for (int i0 = 0; i0 < E; i0 += QCH) {
+            const int cur = (i0 / QCH) & 1;
+            if (i0 + QCH < E) request(rs, s0, i0 + QCH, cb[cur ^ 1]);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int j = 0; j < QCH; ++j) {
+                float v[FPW][2][4];
+#pragma unroll
+                for (int f = 0; f < FPW; ++f)
+#pragma unroll
+                    for (int h = 0; h < 2; ++h)
+#pragma unroll
+                        for (int m = 0; m < 4; ++m) v[f][h][m] = cb[cur].xs[f][j][h][m] * cb[cur].ws[j][h][m];
+                use(i0 + j, pu, v);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    };
+    // rows 4q and their mirrors from the packed transform of s: the W = 2048 split, rows four apart
+    auto store_a = [&](auto stream, float2* o) {
+        constexpr bool ST = decltype(stream)::value;
+        constexpr int ITER = (N / 2) / (NT / FPB);
+        int kqo = kq;
+        asm volatile("" : "+v"(kqo));
+#pragma unroll 2
+        for (int it = 0; it < ITER; ++it) {
+            const int q = kqo + it * (NT / FPB);
+            if (q == 0) {
+                const float2 z0 = fb[0], zc = fb[phys_t<C::PS>(N / 2)];
+                put_bin<SPEC, ST>(o, 0, make_float2(z0.x + z0.y, 0.f));
+                put_bin<SPEC, ST>(o, (long long)(W / 2) * TP, make_float2(z0.x - z0.y, 0.f));
+                put_bin<SPEC, ST>(o, (long long)(W / 4) * TP, cconj(zc));
+                if (SPEC == 0) put_bin<SPEC, ST>(o, (long long)(3 * W / 4) * TP, zc);
+            } else {
+                float2 xk, xn;
+                split_pair(fb[phys_t<C::PS>(q)], fb[phys_t<C::PS>(N - q)], tws_l[q], xk, xn);
+                put_bin<SPEC, ST>(o, (long long)(4 * q) * TP, xk);
+                if (SPEC == 0) put_bin<SPEC, ST>(o, (long long)(W - 4 * q) * TP, cconj(xk));
+                put_bin<SPEC, ST>(o, (long long)(W / 2 - 4 * q) * TP, xn);
+                if (SPEC == 0) put_bin<SPEC, ST>(o, (long long)(W / 2 + 4 * q) * TP, cconj(xn));
+            }
+        }
+    };
+    // rows 8p + A and their mirrors W - (8p + A): the transform's values as they are
+    auto store_c = [&](auto alpha, auto stream, float2* o) {
+        constexpr int A = decltype(alpha)::value;
+        constexpr bool ST = decltype(stream)::value;
+        constexpr int ITER = N / (NT / FPB);
+        int kqo = kq;
+        asm volatile("" : "+v"(kqo));
+#pragma unroll 4
+        for (int it = 0; it < ITER; ++it) {
+            const int pq = kqo + it * (NT / FPB);
+            const float2 z = fb[phys_t<C::PS>(pq)];
+            const int k = 8 * pq + A;
+            if (SPEC == 0) {
+                put_bin<SPEC, ST>(o, (long long)k * TP, z);
+                put_bin<SPEC, ST>(o, (long long)(W - k) * TP, cconj(z));
+            } else if (k <= W / 2) {
+                put_bin<SPEC, ST>(o, (long long)k * TP, z);
+            } else {
+                put_bin<SPEC, ST>(o, (long long)(W - k) * TP, cconj(z));
+            }
+        }
+    };
+    // A memory instruction of a wave completes in issue order (one counter for loads and stores): a load issued behind a store sweep waits for
+    // the sweep to drain.  So both reads of the frame are issued BEFORE a sweep, with the transform's results already in the frame buffers --
+    // the differences (classes D1, D5) ahead of the stores of class C, the sums of the NEXT tile (A, C) ahead of the stores of class D5 -- and
+    // wait in registers (128) while the sweep is issued; the stores then drain under the transforms that follow.
+    float sv[FPW][2 * E];   // s[lane + 64 i], i < 32, of the wave's two frames (class A: through the frame buffer once the last sweep is out)
+    float2 hold[FPW][E];    // the waiting class (C, D5)
+    auto tile_of = [&](int tlv, int& clip, int& t0) {
+        const int tl = xcd ? xcd_order(tlv, total_tiles) : tlv;
+        clip = tl / tiles;
+        t0 = (tl % tiles) * FPB;
+    };
+    auto gather_sums = [&](int tlv) {
+        if (tlv >= total_tiles) {   // (behind the last tile: the values are dead -- said here, or they would be carried through the whole loop body)
+#pragma unroll
+            for (int f = 0; f < FPW; ++f)
+#pragma unroll
+                for (int i = 0; i < 2 * E; ++i) sv[f][i] = 0.f;
+            return;
+        }
+        int clip, t0;
+        tile_of(tlv, clip, t0);
+        const __amdgpu_buffer_rsrc_t rs = make_rsrc(x + (long long)clip * n_samples, (unsigned)(n_samples * 4));
+        __builtin_amdgcn_sched_barrier(0);
+        walk(rs, (t0 + wave * FPW) * hop - W / 2, [&](int i, int lane, float (&v)[FPW][2][4]) {
+            const float2 wc = twq[2 * (lane + 64 * i)];
+#pragma unroll
+            for (int f = 0; f < FPW; ++f) {
+                float r[2];
+#pragma unroll
+                for (int h = 0; h < 2; ++h) {
+                    const float a = v[f][h][0] + v[f][h][2], b = v[f][h][1] + v[f][h][3];
+                    sv[f][i + E * h] = a + b;
+                    r[h] = a - b;
+                }
+                hold[f][i] = cmul(make_float2(r[0], -r[1]), wc);
+            }
+        });
+    };
+    int tlv = blockIdx.x;
+    gather_sums(tlv);
+    for (; tlv < total_tiles; tlv += gridDim.x) {
+        int clip, t0;
+        tile_of(tlv, clip, t0);
+        const __amdgpu_buffer_rsrc_t rs = make_rsrc(x + (long long)clip * n_samples, (unsigned)(n_samples * 4));
+        int po = p_lane;
+        asm volatile("" : "+v"(po));   // (table offsets are recomputed per tile, not hoisted and spilled)
+        float2* o = spec_base<SPEC>(out, (long long)clip * ROWS * TP + (t0 + tt));
+        const bool stream = SPEC < 2 && lines_whole;
+        const bool mine = t0 + tt < T;
+        // ---- class A: s through the frame buffer as packed pairs (s[2n], s[2n + 1])
+#pragma unroll
+        for (int f = 0; f < FPW; ++f) {
+            float2* buf = frames + (wave * FPW + f) * PITCH;
+            float* bufs = reinterpret_cast<float*>(buf);
+#pragma unroll
+            for (int i = 0; i < 2 * E; ++i) {
+                const int n = po + 64 * i;
+                bufs[2 * phys_t<C::PS>(n >> 1) + (n & 1)] = sv[f][i];
+            }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int f = 0; f < FPW; ++f) {
+            float2* buf = frames + (wave * FPW + f) * PITCH;
+            float2 v[E];
+            frame_sync<P>();
+            regs_read<10, 4>(v, buf, po);
+            frame_sync<P>();
+            fft_frame<10, 4>(v, buf, po, tw_l);
+        }
+        lds_barrier();
+        if (mine) {
+            if (stream) store_a(std::true_type{}, o);
+            else store_a(std::false_type{}, o);
+        }
+        lds_barrier();
+        // ---- class C from the registers
+#pragma unroll
+        for (int f = 0; f < FPW; ++f) fft_frame<10, 4>(&hold[f][0], frames + (wave * FPW + f) * PITCH, po, tw_l);
+        // ---- the differences: h = ((x0 - x2) - i (x1 - x3)) w_8192^n; h[n + 1024] carries w_8192^1024 = exp(-i pi / 4)
+        float2 d1[FPW][E];
+        __builtin_amdgcn_sched_barrier(0);
+        walk(rs, (t0 + wave * FPW) * hop - W / 2, [&](int i, int lane, float (&v)[FPW][2][4]) {
+            const int n = lane + 64 * i;
+            const float2 wn = twq[n], w4 = twq[4 * n];
+            const float hs = 0.70710678118654752440f;
+#pragma unroll
+            for (int f = 0; f < FPW; ++f) {
+                const float2 g0 = make_float2(v[f][0][0] - v[f][0][2], v[f][0][3] - v[f][0][1]);
+                const float2 g1 = make_float2(v[f][1][0] - v[f][1][2], v[f][1][3] - v[f][1][1]);
+                const float2 h0 = cmul(g0, wn), h1 = cmul(cmulk(g1, hs, -hs), wn);
+                d1[f][i] = cadd(h0, h1);
+                hold[f][i] = cmul(csub(h0, h1), w4);
+            }
+        });
+        lds_barrier();
+        if (mine) {
+            if (stream) store_c(std::integral_constant<int, 2>{}, std::true_type{}, o);
+            else store_c(std::integral_constant<int, 2>{}, std::false_type{}, o);
+        }
+        lds_barrier();
+#pragma unroll
+        for (int f = 0; f < FPW; ++f) fft_frame<10, 4>(&d1[f][0], frames + (wave * FPW + f) * PITCH, po, tw_l);
+        lds_barrier();
+        if (mine) {
+            if (stream) store_c(std::integral_constant<int, 1>{}, std::true_type{}, o);
+            else store_c(std::integral_constant<int, 1>{}, std::false_type{}, o);
+        }
+        lds_barrier();
+#pragma unroll
+        for (int f = 0; f < FPW; ++f) fft_frame<10, 4>(&hold[f][0], frames + (wave * FPW + f) * PITCH, po, tw_l);
+        gather_sums(tlv + gridDim.x);
+        lds_barrier();
+        if (mine) {
+            if (stream) store_c(std::integral_constant<int, 5>{}, std::true_type{}, o);
+            else store_c(std::integral_constant<int, 5>{}, std::false_type{}, o);
+        }
+        lds_barrier();
+    }
+}
+
+// ---------------------------------------------------------------------------------
 // melspectrogram / mfcc at W = 4096, fused on the two-band kernel (k_mel_ft16b)
 // ---------------------------------------------------------------------------------
 // k_stft_ft16b with the stores of a band replaced by its share of the filterbank product: after a band's transforms every thread turns ITS
@@ -2181,6 +2442,22 @@ static hipError_t run_stft_band(const zafx_plan& pl, const float* x, float2* out
     return hipGetLastError();
 }
 
+// k_stft_ft16q: W = 8192 in the reference layout, four classes of bins per tile (see the kernel)
+template <int SPEC>
+static hipError_t run_stft_quad(const zafx_plan& pl, const float* x, float2* out, int64_t n_clips, int64_t n_samples, int T) {
+    using B = QuadCfg;
+    auto kern = k_stft_ft16q<SPEC>;
+    if (hipError_t e = ensure_dynamic_lds(reinterpret_cast<const void*>(kern), pl.device, B::SMEM); e != hipSuccess) return e;
+    const int tiles = (T + B::FPB - 1) / B::FPB;
+    const long long total = (long long)tiles * n_clips;
+    if (total <= 0) return hipSuccess;
+    const long long grid = std::min<long long>(total, (long long)pl.n_cus);
+    pl.ran = "k_stft_ft16q";
+    hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(B::NT), B::SMEM, pl.stream, x, pl.d_window, pl.d_tw_sub, pl.d_tw_quad, out,
+                       (long long)n_samples, pl.H, T, (int)row_pitch(pl, T), tiles, (int)total);
+    return hipGetLastError();
+}
+
 // k_stft_ft16bc: W = 4096, complex rows off the 128-byte grid (one band per workgroup, register carry)
 template <bool ALIGNED, int SPEC>
 static hipError_t run_stft_band_carry(const zafx_plan& pl, const float* x, float2* out, int64_t n_clips, int64_t n_samples, int T) {
@@ -2282,6 +2559,19 @@ static hipError_t run_stft(const zafx_plan& pl, const float* x, float2* out, int
         }
         if ((SPEC >= 2 || whole) && pl.d_tw_sub && (long long)n_clips * ((T + 15) / 16) < (1LL << 31) && n_samples < (1LL << 29) && (long long)(T + 16) * pl.H < (1LL << 29) && reinterpret_cast<uintptr_t>(x) % 4 == 0)
             return aligned ? run_stft_band<true, SPEC>(pl, x, out, n_clips, n_samples, T) : run_stft_band<false, SPEC>(pl, x, out, n_clips, n_samples, T);
+    }
+#ifndef ZAFX_STFT_QUAD
+#define ZAFX_STFT_QUAD 1
+#endif
+    if constexpr (ZAFX_STFT_QUAD && LOG2N == 12 && LAYOUT == ZAFX_LAYOUT_FT) {
+        // W = 8192, reference layout: 16-frame tiles in four classes of bins (4-byte buffer loads: 32-bit byte offsets inside a clip)
+        // 1024 clips x 10 s, hop 4096, T = 112 (rows are whole lines): two-sided 2.19-2.29 ms against 2.77 on the one-workgroup-per-tile kernel, one-sided
+        // 1.68 against 1.99, |X| 1.60 against 1.84; T = 109: 3.3-4.3 against 3.04 two-sided (every line written in two parts by two workgroups: the
+        // generic kernel keeps those), 2.19 against 2.17 one-sided, 1.74 against 1.93 |X|
+        const bool whole = row_pitch(pl, T) % 16 == 0 && reinterpret_cast<uintptr_t>(out) % 128 == 0;
+        if ((SPEC != 0 || whole) && pl.d_tw_sub && pl.d_tw_quad && (long long)n_clips * ((T + 15) / 16) < (1LL << 31) && n_samples < (1LL << 29) &&
+            (long long)(T + 16) * pl.H < (1LL << 28) && reinterpret_cast<uintptr_t>(x) % 4 == 0)
+            return run_stft_quad<SPEC>(pl, x, out, n_clips, n_samples, T);
     }
     if constexpr (stft_use_fat(LOG2N, LAYOUT)) {
 #ifndef ZAFX_STFT_CARRY

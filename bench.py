@@ -49,7 +49,7 @@ HBM_ACHIEVABLE_GBS = 6290.0   # same guide: measured-achievable copy rate
 F32_PEAK_TFLOPS = 157.3    # dense f32 vector / f32-input MFMA peak
 PLACEMENT_SURVEY = 6       # further allocations of the headline's row-strided output probed AFTER every timed region (reported, never timed)
 CONFIG_KINDS = ("istft", "mel", "mfcc", "mdct", "imdct", "cqt")   # SURVEY 8(a) a2 + BASELINE configs 3, 4, 5 (config 2 = the headline)
-EXTRA_KINDS = ("stft1", "stftmag", "istft1", "stft_offgrid", "mdct_offgrid", "stft4096", "stft4096_h1024", "istft4096", "mdct4096", "mel4096", "dct", "stft64", "mdct64", "istft_offgrid", "imdct_offgrid", "stftmag_offgrid")   # one-sided pair (8f rank 4) and geometries off the benchmark's grid
+EXTRA_KINDS = ("stft1", "stftmag", "istft1", "stft_offgrid", "mdct_offgrid", "stft4096", "stft4096_h1024", "istft4096", "mdct4096", "mel4096", "dct", "stft64", "mdct64", "istft_offgrid", "imdct_offgrid", "stftmag_offgrid", "stft8192", "mdct8192")   # one-sided pair (8f rank 4) and geometries off the benchmark's grid
 
 
 def synth(seed, c, n):
@@ -87,6 +87,10 @@ def make_workload(kind, device, layout="FT"):
         T = 217
     if kind in ("mdct_offgrid", "imdct_offgrid"):
         N, T = 442024, 433       # ceil(N / 1024) + 1 (zaf.py:1033): float32 rows of 1732 B
+    if kind == "stft8192":
+        N, T = 4096 * 111, 112    # W = 8192, hop 4096, on the line grid: ceil(N / 4096) + 1 frames
+    if kind == "mdct8192":
+        N, T = 4096 * 127, 128    # W = 8192 MDCT on the line grid: ceil(N / 4096) + 1 frames (zaf.py:1033)
     if kind in ("mdct4096", "mel4096", "istft4096"):
         T = 217                   # mdct: ceil(N / 2048) + 1 (odd: rows off the line grid); mel: hop 2048
     base = np.stack([synth(0, c, N) for c in range(distinct)])
@@ -122,6 +126,14 @@ def make_workload(kind, device, layout="FT"):
         plan = zafx.istft_plan(zafx.hamming(4096), 2048, device=device)
         wl.update(plan=plan, d_in=d_s, n_in=T, bytes_per_launch=B * (8 * 4096 * T + 4 * (T * 2048 - 2048)),
                   desc="Batched ISTFT, win=4096 hop=2048: 1024 clips x 217 frames")
+    elif kind == "stft8192":         # k_stft_ft16q: four classes of bins per 16-frame tile
+        plan = zafx.stft_plan(zafx.hamming(8192), 4096, layout=layout, device=device)
+        wl.update(plan=plan, d_in=d_x, n_in=N, bytes_per_launch=B * (4 * N + 8 * 8192 * T),
+                  desc="Batched STFT, win=8192 hop=4096: 1024 clips x 10.3 s, T = 112, two-sided c64 (W,T) layout")
+    elif kind == "mdct8192":         # k_mdct_ft32q: four bands of bins per 32-frame tile
+        plan = zafx.mdct_plan(zafx.kaiser_bessel_derived(8192), device=device)
+        wl.update(plan=plan, d_in=d_x, n_in=N, bytes_per_launch=B * (4 * N + 4 * 4096 * T),
+                  desc="Batched MDCT, KBD win=8192: 1024 clips x 11.8 s, T = 128, compact (W/2,T) layout")
     elif kind == "mdct4096":         # k_mdct_ft32b (32-frame tiles, two bands of bins); T = 217 is odd: rows off the line grid
         plan = zafx.mdct_plan(zafx.kaiser_bessel_derived(4096), device=device)
         wl.update(plan=plan, d_in=d_x, n_in=N, bytes_per_launch=B * (4 * N + 4 * 2048 * T),
@@ -410,6 +422,10 @@ def parity_probe(wl):
         ref = orc.stft(x64, orc.hamming_periodic(4096), 1024)
     elif kind == "mdct4096":
         ref = orc.mdct(x64, orc.kbd_window(4096))
+    elif kind == "stft8192":
+        ref = orc.stft(x64, orc.hamming_periodic(8192), 4096)
+    elif kind == "mdct8192":
+        ref = orc.mdct(x64, orc.kbd_window(8192))
     elif kind == "mel4096":
         ref = orc.melspectrogram(x64, orc.hamming_periodic(4096), 2048, orc.melfilterbank(FS, 4096, 128))
     elif kind in ("istft", "istft1", "istft4096", "istft_offgrid"):

@@ -1,5 +1,5 @@
 """Random geometries at W = 4096 (the band kernels of round 3: k_stft_ft16b / bc, k_istft_ft16b, k_mdct_ft32b, the 16-frame k_imdct, k_melfb) and at
-W = 8192 (mel / mfcc through k_melfb) against the oracle -- run by tests/test_gpu_stress.py with fixed seeds, or by hand:
+W = 8192 (two draws in five; round 5: k_stft_ft16q, k_mdct_ft32q, mel / mfcc through k_stft_ft16q + k_melfb) against the oracle -- run by tests/test_gpu_stress.py with fixed seeds, or by hand:
     python tests/stress_w4096.py [seed [iterations]]"""
 import sys, os
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -12,7 +12,7 @@ rng = np.random.default_rng(seed)
 def relerr(a, b): return float(np.max(np.abs(a - b)) / max(np.max(np.abs(b)), 1e-30)) if a.size else float(a.shape != b.shape)
 bad = 0
 for it in range(iters):
-    wl = 4096 if rng.integers(0, 5) else 8192
+    wl = 4096 if rng.integers(0, 5) >= 2 else 8192
     hop = int(rng.choice([wl // 2, wl // 4, wl // 8, 4 * int(rng.integers(128, 1100)), int(rng.integers(512, wl + 1)), 2 * int(rng.integers(300, 2000))]))
     n = int(rng.choice([int(rng.integers(1, 200000)), 4 * int(rng.integers(1, 50000)), 2048 * 16 * int(rng.integers(1, 5))]))
     nb = int(rng.choice([1, 2, 3, 5, 40, 300])) if n < 60000 else int(rng.integers(1, 5))

@@ -152,6 +152,30 @@ def test_mdct_w4096_two_bands(zafx, n, clips):
     _run_padded(zafx, zafx.mdct_plan(w), zafx.mdct_plan(w, row_align=32), None, None, x[:2])
 
 
+@pytest.mark.parametrize("n,clips", [(441000, 3), (4096 * 31, 2), (4096 * 30 + 1, 2), (70001, 3), (1, 1), (4096 * 63, 40), (4096 * 95 - 7, 90), (8193, 2)])
+def test_mdct_w8192_four_bands(zafx, n, clips):
+    """W = 8192 in the reference layout runs k_mdct_ft32q (32-frame tiles as four bands of bins, the frame folded twice; zaf.py:1047-1073 is
+    what it replaces): any clip length (4-byte loads), ragged and whole last tiles, rows on and off the line grid, even and odd T (frame
+    pairs as 8-byte stores or single values), more tiles than workgroups, padded rows; the other layout stays on the generic kernel."""
+    x = np.stack([synth_clip(45, c % 5, n) for c in range(clips)])
+    w = zafx.kaiser_bessel_derived(8192)
+    assert zafx.mdct_plan(w).kernel_name == "k_mdct_ft32q"
+    ref = orc.mdct_batch(x[:5].astype(np.float64), w)
+    got = zafx.mdct_batch(x, w)
+    assert zafx.mdct_plan(w).last_kernel == "k_mdct_ft32q"
+    assert got.shape[1:] == ref.shape[1:] and got.dtype == np.float32
+    for c in range(clips):
+        assert relerr(got[c], ref[c % 5]) <= TOL_FFT, c
+    y = zafx.imdct_batch(got[:1], w)[0]
+    k = min(n, len(y))
+    assert np.max(np.abs(y[:k] - x[0, :k])) < 1e-5
+    _run_padded(zafx, zafx.mdct_plan(w), zafx.mdct_plan(w, row_align=32), None, None, x[:2])
+    tf = zafx.mdct_batch(x[:2], w, layout="TF")
+    assert zafx.mdct_plan(w, layout="TF").last_kernel == "k_mdct"
+    for c in range(len(tf)):
+        assert relerr(tf[c].T, ref[c]) <= TOL_FFT
+
+
 def test_imdct_batches_every_clip_and_tile_shape(zafx):
     """The inverse of a BATCH, every clip compared: the output length (T-1) M - 1 is odd, so every second clip starts on a 4-byte
     boundary (the sweep form of the overlap-add stores those as two 4-byte values); lengths that end on a full tile, a partial

@@ -668,6 +668,197 @@ __global__ __launch_bounds__(MdctBandCfg::NT) void k_mdct_ft32b(
 }
 
 // ---------------------------------------------------------------------------------
+// forward, reference layout, W = 8192: 32-frame tiles over FOUR bands of bins (k_mdct_ft32q)
+// ---------------------------------------------------------------------------------
+// The packed frame c (NF = 2048 points) in two decimation steps: Y[4q + j] = FFT_512(b_j)[q] with
+//     b_0 = e[n] + e[n + 512],  b_2 = (e[n] - e[n + 512]) w^2n,        e[n] = c[n] + c[n + 1024]
+//     b_1 = (d[n] - i d[n + 512]) w^n,  b_3 = (d[n] + i d[n + 512]) w^3n,  d[n] = c[n] - c[n + 1024],   w = exp(-2 pi i / 2048), n < 512
+// and every bin yields its two coefficients on its own (X[2k] = Re y_k, X[M - 1 - 2k] = -Im y_k, y_k = Y[k] g_k): a tile is four rounds of
+// k_mdct_ft32's phases on the same 32 frame buffers, every stored row a 128-byte run of 32 frames.  The frame is folded twice (bands 0 + 2 from the
+// sums e, 1 + 3 from the differences d).  A lane folds the points n + 512 k and their mirrors (511 - n) + 512 k together: c[m] and c[NF - 1 - m] use
+// the odd and the even neighbours of the same four sample pairs, so every sample comes once per pass, in an 8-byte load of a coalesced run (two 4-byte
+// loads for clips off the 8-byte grid; samples outside the clip read 0 = the reference's padding, zaf.py:1036-1041), and the mirrored points reach
+// their lane 63 - p by a lane permute.  A memory instruction of a wave completes in issue order, so both
+// folds are issued AHEAD of a store sweep (k_stft_ft16q) and their bands wait in 64 registers.
+struct MdctQuadCfg {
+    using C = FftCfg<9, 3>;   // 512-point band transforms: 64 lanes x 8 points
+    static constexpr int NF = 2048, HB = 512, M = 4096, W = 8192, FPB = kMdctTile, NSLOT = 16, NT = NSLOT * 64;
+    static constexpr size_t SMEM = (size_t)(FPB * C::PITCH + C::TW + NF) * 8;
+};
+static_assert(MdctQuadCfg::SMEM <= (size_t)kMaxLdsBytes, "k_mdct_ft32q: tile + tables exceed LDS");
+
+template <bool ALIGNED>
+__global__ __launch_bounds__(MdctQuadCfg::NT) void k_mdct_ft32q(
+    const float* __restrict__ x, const float* __restrict__ win, const float2* __restrict__ twp, const float2* __restrict__ g, const float2* __restrict__ wq,
+    float* __restrict__ out, long long n_samples, int T, int TP, int tiles, int total_tiles) {
+    using G = MdctQuadCfg;
+    using C = G::C;
+    constexpr int NF = G::NF, HB = G::HB, M = G::M, P = 64, E = 8, FPB = G::FPB, NSLOT = G::NSLOT, NT = G::NT, FPW = FPB / NSLOT;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    float2* frames = reinterpret_cast<float2*>(smem_raw);
+    float2* tw_l = frames + FPB * C::PITCH;
+    const int tid = threadIdx.x;
+    float2* g_l = tw_l + C::TW;   // g[m], m < NF: the pre-twiddle of the fold and the post-twiddle of the sweeps
+    for (int i = tid; i < C::TW; i += NT) tw_l[i] = twp[i];
+    for (int i = tid; i < NF; i += NT) g_l[i] = g[i];
+    lds_barrier();
+    const int slot = __builtin_amdgcn_readfirstlane(tid / P), p = tid % P;
+    const bool xcd = ZAFX_XCD_ORDER && gridDim.x % 8 == 0;
+    auto tile_of = [&](int tlv, int& clip, int& t0) {
+        const int tl = xcd ? xcd_order(tlv, total_tiles) : tlv;
+        clip = tl / tiles;
+        t0 = (tl % tiles) * FPB;
+    };
+    float2 now[FPW][E], wait[FPW][E];   // the band transformed next and the one behind it, of the wave's two frames
+    // the fold of one pass (PASS 0: bands 0 and 2, PASS 1: bands 1 and 3) of the tile tlv
+    auto fold = [&](int tlv, auto pass) {
+        constexpr int PASS = decltype(pass)::value;
+        if (tlv >= total_tiles) {   // (behind the last tile: dead values, said so that they are not carried through the loop)
+#pragma unroll
+            for (int f = 0; f < FPW; ++f)
+#pragma unroll
+                for (int i = 0; i < E; ++i) now[f][i] = wait[f][i] = make_float2(0.f, 0.f);
+            return;
+        }
+        int clip, t0;
+        tile_of(tlv, clip, t0);
+        const __amdgpu_buffer_rsrc_t rs = make_rsrc(x + (long long)clip * n_samples, (unsigned)(n_samples * 4));
+        __builtin_amdgcn_sched_barrier(0);
+        const int s0 = (t0 + slot - 1) * M;   // the wave's frames f = 0, 1 start at s0 + f NSLOT M
+#pragma unroll
+        for (int i = 0; i < E / 2; ++i) {
+            int po = p;
+            asm volatile("" : "+v"(po));   // (window values and roots are read again per step, not kept across the tile loop)
+            const int n = po + 64 * i, nb = HB - 1 - n;   // the lane's points n + 512 k and their mirrors (511 - n) + 512 k: NF - 1 - m of each other
+            float2 cn[FPW][4], cb[FPW][4];
+            // c[m] and c[NF - 1 - m], m < NF / 2, from four sample pairs (k_mdct's fold: c[m] = (-u[3NF-1-2m] - u[3NF+2m], u[NF-1-2m] - u[NF+2m]) g[m];
+            // c[m'] = (u[2m'-NF] - u[3NF-1-2m'], -u[NF+2m'] - u[5NF-1-2m']) g[m'], m' = NF - 1 - m -- the odd / even neighbours of the same samples);
+            // window values and roots once for the wave's two frames
+            auto both = [&](int m, int k, int kb, float2 (&cm)[FPW][4], float2 (&cmb)[FPW][4]) {
+                const int e[4] = {NF - 2 - 2 * m, NF + 2 * m, 3 * NF - 2 - 2 * m, 3 * NF + 2 * m};
+                float2 v[FPW][4], w[4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+#pragma unroll
+                    for (int f = 0; f < FPW; ++f) {
+                        const int off = (s0 + f * NSLOT * M + e[j]) * 4;
+                        if constexpr (ALIGNED) {
+                            v[f][j] = buf_load_f32x2(rs, off);
+                        } else {
+                            int off1 = off + 4;
+                            asm volatile("" : "+v"(off1));   // (two 4-byte loads that must not be merged: a pair may straddle an end of the clip)
+                            v[f][j].x = buf_load_f32(rs, off);
+                            v[f][j].y = buf_load_f32(rs, off1);
+                        }
+                    }
+                    w[j] = *reinterpret_cast<const float2*>(win + e[j]);
+                }
+                const float2 gm = g_l[m], gb = g_l[NF - 1 - m];
+#pragma unroll
+                for (int f = 0; f < FPW; ++f) {
+                    float2 q[4];
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) q[j] = make_float2(v[f][j].x * w[j].x, v[f][j].y * w[j].y);
+                    cm[f][k] = cmul(make_float2(-q[2].y - q[3].x, q[0].y - q[1].x), gm);
+                    cmb[f][kb] = cmul(make_float2(q[0].x - q[1].y, -q[2].x - q[3].y), gb);
+                }
+            };
+            both(n, 0, 3, cn, cb);
+            both(nb, 0, 3, cb, cn);
+            both(n + HB, 1, 2, cn, cb);
+            both(nb + HB, 1, 2, cb, cn);
+            const float2 wa = PASS == 0 ? wq[2 * n] : wq[n], wb = PASS == 0 ? wq[2 * nb] : wq[nb];
+            float2 wa3 = wa, wb3 = wb;
+            if constexpr (PASS == 1) wa3 = wq[3 * n], wb3 = wq[3 * nb];
+            const int opp = (63 - po) * 4;   // point nb = (63 - lane) + 64 (7 - i) belongs to the opposite lane's register 7 - i
+            auto flip = [&](float2 v) {
+                return make_float2(__builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(opp, __builtin_bit_cast(int, v.x))),
+                                   __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(opp, __builtin_bit_cast(int, v.y))));
+            };
+#pragma unroll
+            for (int f = 0; f < FPW; ++f) {
+                float2 rn, rw, qn, qw;   // the two bands at n and at nb
+                if constexpr (PASS == 0) {
+                    const float2 e0 = cadd(cn[f][0], cn[f][2]), e1 = cadd(cn[f][1], cn[f][3]), f0 = cadd(cb[f][0], cb[f][2]), f1 = cadd(cb[f][1], cb[f][3]);
+                    rn = cadd(e0, e1);
+                    rw = cmul(csub(e0, e1), wa);
+                    qn = cadd(f0, f1);
+                    qw = cmul(csub(f0, f1), wb);
+                } else {
+                    const float2 d0 = csub(cn[f][0], cn[f][2]), d1 = csub(cn[f][1], cn[f][3]), f0 = csub(cb[f][0], cb[f][2]), f1 = csub(cb[f][1], cb[f][3]);
+                    rn = cmul(make_float2(d0.x + d1.y, d0.y - d1.x), wa);     // d0 - i d1
+                    rw = cmul(make_float2(d0.x - d1.y, d0.y + d1.x), wa3);    // d0 + i d1
+                    qn = cmul(make_float2(f0.x + f1.y, f0.y - f1.x), wb);
+                    qw = cmul(make_float2(f0.x - f1.y, f0.y + f1.x), wb3);
+                }
+                now[f][i] = rn;
+                wait[f][i] = rw;
+                now[f][E - 1 - i] = flip(qn);
+                wait[f][E - 1 - i] = flip(qw);
+            }
+        }
+    };
+    auto transform = [&](float2 (&v)[FPW][E]) {
+        int po = p;
+        asm volatile("" : "+v"(po));
+#pragma unroll
+        for (int f = 0; f < FPW; ++f) fft_frame<9, 3>(&v[f][0], frames + (f * NSLOT + slot) * C::PITCH, po, tw_l);
+    };
+    // rows 8q + 2j and M - 1 - 8q - 2j of band j, frame pairs as 8-byte stores (one instruction: 4 rows x 128 B)
+    auto store_band = [&](int j, int clip, int t0) {
+        int tido = tid;
+        asm volatile("" : "+v"(tido));
+        const int tp = tido % 16, fq = tido / 16;
+        const int ta = t0 + 2 * tp;
+        if (ta >= T) return;
+        const float2* fa = frames + (2 * tp) * C::PITCH;
+        const float2* fb = fa + C::PITCH;
+        float* o = out + (long long)clip * M * TP + ta;
+        const bool pairs = TP % 2 == 0 && reinterpret_cast<uintptr_t>(out) % 8 == 0 && ta + 1 < T;
+#pragma unroll 2
+        for (int it = 0; it < HB / 64; ++it) {
+            const int q = fq + 64 * it;
+            const float2 gk = g_l[4 * q + j];
+            const float2 ya = cmul(fa[phys(q)], gk), yb = cmul(fb[phys(q)], gk);
+            float* r1 = o + (long long)(8 * q + 2 * j) * TP;
+            float* r2 = o + (long long)(M - 1 - 8 * q - 2 * j) * TP;
+            if (pairs) {
+                store_stream(reinterpret_cast<float2*>(r1), make_float2(ya.x, yb.x));
+                store_stream(reinterpret_cast<float2*>(r2), make_float2(-ya.y, -yb.y));
+            } else {
+                r1[0] = ya.x;
+                r2[0] = -ya.y;
+                if (ta + 1 < T) r1[1] = yb.x, r2[1] = -yb.y;
+            }
+        }
+    };
+    int tlv = blockIdx.x;
+    fold(tlv, std::integral_constant<int, 0>{});
+    for (; tlv < total_tiles; tlv += gridDim.x) {
+        int clip, t0;
+        tile_of(tlv, clip, t0);
+        transform(now);   // band 0
+        lds_barrier();
+        store_band(0, clip, t0);
+        lds_barrier();
+        transform(wait);   // band 2
+        fold(tlv, std::integral_constant<int, 1>{});
+        lds_barrier();
+        store_band(2, clip, t0);
+        lds_barrier();
+        transform(now);   // band 1
+        lds_barrier();
+        store_band(1, clip, t0);
+        lds_barrier();
+        transform(wait);   // band 3
+        fold(tlv + gridDim.x, std::integral_constant<int, 0>{});
+        lds_barrier();
+        store_band(3, clip, t0);
+        lds_barrier();
+    }
+}
+
+// ---------------------------------------------------------------------------------
 // forward, reference layout, W = 4096, rows that are not whole (half) lines: one band per workgroup + register carry (k_mdct_ft32bc)
 // ---------------------------------------------------------------------------------
 // As k_stft_ft16bc: the two bands of k_mdct_ft32b never meet, so a workgroup owns ONE band of a clip segment (units (segment, band 0 / 1)
@@ -1335,6 +1526,25 @@ static hipError_t run_mdct_band(const zafx_plan& pl, const float* x, float* out,
     return hipGetLastError();
 }
 
+// k_mdct_ft32q: W = 8192 in the reference layout, four bands of bins per 32-frame tile (see the kernel)
+#ifndef ZAFX_MDCT_QUAD
+#define ZAFX_MDCT_QUAD 1
+#endif
+static hipError_t run_mdct_quad(const zafx_plan& pl, const float* x, float* out, int64_t n_clips, int64_t n_samples, int T) {
+    using G = MdctQuadCfg;
+    const bool aligned = n_samples % 2 == 0 && reinterpret_cast<uintptr_t>(x) % 8 == 0;   // sample pairs as 8-byte loads
+    auto kern = aligned ? k_mdct_ft32q<true> : k_mdct_ft32q<false>;
+    if (hipError_t e = ensure_dynamic_lds(reinterpret_cast<const void*>(kern), pl.device, G::SMEM); e != hipSuccess) return e;
+    const int tiles = (T + G::FPB - 1) / G::FPB;
+    const long long total = (long long)tiles * n_clips;
+    if (total <= 0) return hipSuccess;
+    const long long grid = std::min<long long>(total, (long long)pl.n_cus);
+    pl.ran = "k_mdct_ft32q";
+    hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(G::NT), G::SMEM, pl.stream, x, pl.d_window, pl.d_tw_sub, pl.d_tw_aux, pl.d_tw_quad, out, (long long)n_samples, T,
+                       (int)row_pitch(pl, T), tiles, (int)total);
+    return hipGetLastError();
+}
+
 #ifndef ZAFX_MDCT_BAND_CARRY
 #define ZAFX_MDCT_BAND_CARRY 1
 #endif
@@ -1369,6 +1579,12 @@ static hipError_t run_mdct(const zafx_plan& pl, const float* x, float* out, int6
         if (pl.d_tw_sub && pl.d_tw_band && n_samples % 4 == 0 && reinterpret_cast<uintptr_t>(x) % 16 == 0 && n_samples < (1LL << 28) &&
             (long long)n_clips * ((T + 31) / 32) < (1LL << 31))
             return run_mdct_band(pl, x, out, n_clips, n_samples, T);
+    }
+    if constexpr (ZAFX_MDCT_QUAD && LOG2NF == 11 && LAYOUT == ZAFX_LAYOUT_FT) {
+        // W = 8192, reference layout: 32-frame tiles in four bands of bins (4-byte buffer loads: 32-bit byte offsets inside a clip)
+        if (pl.d_tw_sub && pl.d_tw_quad && n_samples < (1LL << 28) && (long long)(T + 33) * 4096 < (1LL << 28) && reinterpret_cast<uintptr_t>(x) % 4 == 0 &&
+            reinterpret_cast<uintptr_t>(out) % 4 == 0 && (long long)n_clips * ((T + 31) / 32) < (1LL << 31))
+            return run_mdct_quad(pl, x, out, n_clips, n_samples, T);
     }
     if constexpr (mdct_use_persistent(LOG2NF, LAYOUT)) {
         return run_mdct_p<LOG2NF, LAYOUT == ZAFX_LAYOUT_TF>(pl, x, out, n_clips, n_samples, T);
@@ -1447,6 +1663,7 @@ bool mdct_supported(int log2nf) { return log2nf >= 4 && log2nf <= 11; }
 int mdct_frames_per_block(int log2nf, int layout) { return mdct_fpb(log2nf, layout); }
 const char* mdct_kernel_name(int log2nf, int layout) {
     if (ZAFX_MDCT_BAND && log2nf == 10 && layout == ZAFX_LAYOUT_FT) return "k_mdct_ft32b";
+    if (ZAFX_MDCT_QUAD && log2nf == 11 && layout == ZAFX_LAYOUT_FT) return "k_mdct_ft32q";
     return mdct_use_persistent(log2nf, layout) ? "k_mdct_ft32" : "k_mdct";
 }
 const char* imdct_kernel_name() { return "k_imdct"; }

@@ -194,12 +194,12 @@ def test_clipped_pcm_through_the_pcm_entry_points(zafx, consts, golden, channels
 
 
 @pytest.mark.parametrize("name", sig.NAMES)
-@pytest.mark.parametrize("wl,hop", [(4096, 2048), (2048, 512), (1000, 250)])
+@pytest.mark.parametrize("wl,hop", [(4096, 2048), (2048, 512), (1000, 250), (8192, 4096)])
 def test_signal_on_the_other_kernels(zafx, name, wl, hop):
     """The same signals through the kernels the W = 2048 / hop 1024 cases do not reach -- the two-band forms of W = 4096 (k_stft_ft16b / bc,
-    k_istft_ft16b, k_mdct_ft32b / bc, k_mel_ft16b), 75 % overlap, a window that is not a power of two (the Bluestein forms) -- against the
-    oracle with the same two bounds."""
-    n = 40 * hop + 300
+    k_istft_ft16b, k_mdct_ft32b / bc, k_mel_ft16b), 75 % overlap, a window that is not a power of two (the Bluestein forms), the four-class
+    forms of W = 8192 (k_stft_ft16q, k_mdct_ft32q; 48 frames: rows on the line grid) -- against the oracle with the same two bounds."""
+    n = 40 * hop + 300 if wl != 8192 else 47 * hop - 100
     x = sig.signal(name, n)
     x64 = x.astype(np.float64)
     ham = zafx.hamming(wl)
@@ -208,6 +208,8 @@ def test_signal_on_the_other_kernels(zafx, name, wl, hop):
     tag = f"{name}_{wl}_{hop}"
     got = zafx.stft_batch(x[None], ham, hop)[0]
     assert check(f"{tag}.stft", got, s, TOL_FFT) <= TOL_FFT
+    if wl == 8192:
+        assert zafx.stft_plan(ham, hop).last_kernel == "k_stft_ft16q"
     y = zafx.istft_batch(s[None], ham, hop)[0]
     yref = orc.istft(s, ham, hop)
     assert len(y) == len(yref) and relerr(y, yref) <= TOL_FFT

@@ -18,7 +18,7 @@ def main(out_path):
     res = {}
     # every FFT size whose frame is owned by one wavefront (the unfenced exchange): W = 64 ... 2048, both layouts
     for wl, hop, n in [(64, 32, 1000), (128, 64, 3000), (256, 100, 5000), (512, 256, 9000), (1024, 512, 20000), (2048, 1024, 50000),
-                       (2048, 512, 30001), (4096, 2048, 40000)]:
+                       (2048, 512, 30001), (4096, 2048, 40000), (8192, 4096, 4096 * 31 - 9)]:   # (W = 8192: 32 frames, k_stft_ft16q / k_mdct_ft32q)
         x = np.stack([clip(c, n) for c in range(3)])
         w = zafx.hamming(wl)
         for layout in ("FT", "TF"):
@@ -35,6 +35,13 @@ def main(out_path):
             fb = zafx.melfilterbank(44100, wl, 40 if wl >= 256 else 8)
             res[f"mel_{wl}"] = zafx.melspectrogram_batch(x, w, hop, fb)
             res[f"mfcc_{wl}"] = zafx.mfcc_batch(x, w, hop, fb, 5)
+    # the float64 kernels of the tiled structure (a frame per wavefront, the same unfenced exchange on complex128 / float64 frames)
+    x64 = np.stack([clip(c, 1024 * 37 + 5) for c in range(3)]).astype(np.float64)
+    w, kbd = zafx.hamming(2048), zafx.kaiser_bessel_derived(2048)
+    s64 = zafx.stft_batch(x64, w, 1024, f64=True)
+    m64 = zafx.mdct_batch(x64, kbd, f64=True)
+    res["stft64"], res["mdct64"] = s64.view(np.float64), m64
+    res["istft64"], res["imdct64"] = zafx.istft_batch(s64, w, 1024, f64=True), zafx.imdct_batch(m64, kbd, f64=True)
     x = np.stack([clip(c, 150000) for c in range(2)])
     for fmin, fmax in ((55, 3520), (220, 1760), (880, 3520)):   # fft_length 32768 (16 x 1024 split), 8192, 2048
         ck = zafx.cqtkernel(44100, 24, fmin, fmax)

@@ -67,6 +67,17 @@ def issued_mfma_flops_per_tile(dense, frames_per_tile=16):
     return steps, steps * 2.0 * 16 * 4 * frames_per_tile
 
 
+def replicate64(base, n_clips, device):
+    """The distinct clips as float64, replicated on the device to n_clips."""
+    import zafx
+    d_b = zafx.DeviceBuffer.from_host(base.astype(np.float64), device)
+    d_x = zafx.DeviceBuffer((n_clips, base.shape[1]), np.float64, device)
+    for r in range(n_clips // base.shape[0]):
+        d_x.copy_from(d_b, dst_offset=r * base.nbytes * 2)
+    d_b.free()
+    return d_x
+
+
 def make_workload(kind, device, layout="FT"):
     """dict(plan, n_clips, n_in, d_in, d_out, samples_per_clip, bytes_per_launch, valu_flops, mfma_flops, desc, ...)."""
     import zafx
@@ -80,7 +91,7 @@ def make_workload(kind, device, layout="FT"):
     if kind == "dct":
         B, N, T = 16384, 1024, 1
     if kind in ("stft64", "mdct64"):
-        B = 256                   # the reference's own dtype (zaf.py:128, :139: float64 in, complex128 out): 40.1 / 16 B per sample
+        B = 1024                  # the reference's own dtype (zaf.py:128, :139: float64 in, complex128 out): 40.1 / 16 B per sample
     if kind in ("stft_offgrid", "istft_offgrid", "stftmag_offgrid"):
         N, T = 442024, 433        # one more frame than config 2: rows of 433 complex64 = 3464 B, off the 128-byte grid
     if kind == "stft4096":
@@ -143,19 +154,17 @@ def make_workload(kind, device, layout="FT"):
         wl.update(plan=plan, d_in=d_x, n_in=N, bytes_per_launch=B * (4 * N + 4 * 128 * T),
                   desc="melspectrogram, win=4096 hop=2048, 128 filters: 1024 clips x 10 s (fused on the two-band kernel, float32)")
     elif kind == "stft64":  # float64 device arithmetic (written for exactness, not speed)
-        d_x64 = zafx.DeviceBuffer.from_host(np.tile(base.astype(np.float64), (B // distinct, 1)), device)
         d_x.free()
-        d_x = d_x64
+        d_x = replicate64(base, B, device)
         plan = zafx.stft_plan(ham, H, layout=layout, device=device, f64=True)
         wl.update(plan=plan, d_in=d_x, n_in=N, bytes_per_launch=B * (8 * N + 16 * W * T),
-                  desc="Batched STFT in float64 / complex128 (the reference's dtype): 256 clips x 10 s, Hamming win=2048 hop=1024, two-sided")
+                  desc="Batched STFT in float64 / complex128 (the reference's dtype): 1024 clips x 10 s, Hamming win=2048 hop=1024, two-sided")
     elif kind == "mdct64":
-        d_x64 = zafx.DeviceBuffer.from_host(np.tile(base.astype(np.float64), (B // distinct, 1)), device)
         d_x.free()
-        d_x = d_x64
+        d_x = replicate64(base, B, device)
         plan = zafx.mdct_plan(kbd, device=device, f64=True)
         wl.update(plan=plan, d_in=d_x, n_in=N, bytes_per_launch=B * (8 * N + 8 * (W // 2) * T),
-                  desc="Batched MDCT in float64: 256 clips x 10 s, KBD win=2048")
+                  desc="Batched MDCT in float64: 1024 clips x 10 s, KBD win=2048")
     elif kind == "stft1":   # one-sided output (rows 0..W/2), not the headline
         plan = zafx.stft_plan(ham, H, layout=layout, device=device, onesided=True)
         wl.update(plan=plan, d_in=d_x, n_in=N, bytes_per_launch=B * (4 * N + 8 * (W // 2 + 1) * T),

@@ -49,7 +49,7 @@ HBM_ACHIEVABLE_GBS = 6290.0   # same guide: measured-achievable copy rate
 F32_PEAK_TFLOPS = 157.3    # dense f32 vector / f32-input MFMA peak
 PLACEMENT_SURVEY = 6       # further allocations of the headline's row-strided output probed AFTER every timed region (reported, never timed)
 CONFIG_KINDS = ("istft", "mel", "mfcc", "mdct", "imdct", "cqt")   # SURVEY 8(a) a2 + BASELINE configs 3, 4, 5 (config 2 = the headline)
-EXTRA_KINDS = ("stft1", "stftmag", "istft1", "stft_offgrid", "mdct_offgrid", "stft4096", "stft4096_h1024", "istft4096", "mdct4096", "mel4096", "dct", "stft64", "mdct64", "istft_offgrid", "imdct_offgrid", "stftmag_offgrid", "stft8192", "mdct8192")   # one-sided pair (8f rank 4) and geometries off the benchmark's grid
+EXTRA_KINDS = ("stft1", "stftmag", "istft1", "stft_offgrid", "mdct_offgrid", "stft4096", "stft4096_h1024", "istft4096", "mdct4096", "mel4096", "dct", "stft64", "mdct64", "istft_offgrid", "imdct_offgrid", "stftmag_offgrid", "stft8192", "mdct8192", "istft64", "imdct64")   # one-sided pair (8f rank 4) and geometries off the benchmark's grid
 
 
 def synth(seed, c, n):
@@ -90,7 +90,7 @@ def make_workload(kind, device, layout="FT"):
         B, N, T = 1024, 1323000, 750   # BASELINE config 5: 8192 clips x 30 s over 8 GPUs = 1024 per GPU
     if kind == "dct":
         B, N, T = 16384, 1024, 1
-    if kind in ("stft64", "mdct64"):
+    if kind in ("stft64", "mdct64", "istft64", "imdct64"):
         B = 1024                  # the reference's own dtype (zaf.py:128, :139: float64 in, complex128 out): 40.1 / 16 B per sample
     if kind in ("stft_offgrid", "istft_offgrid", "stftmag_offgrid"):
         N, T = 442024, 433        # one more frame than config 2: rows of 433 complex64 = 3464 B, off the 128-byte grid
@@ -165,6 +165,23 @@ def make_workload(kind, device, layout="FT"):
         plan = zafx.mdct_plan(kbd, device=device, f64=True)
         wl.update(plan=plan, d_in=d_x, n_in=N, bytes_per_launch=B * (8 * N + 8 * (W // 2) * T),
                   desc="Batched MDCT in float64: 1024 clips x 10 s, KBD win=2048")
+    elif kind in ("istft64", "imdct64"):   # the float64 inverse pair on the tiled structure (k_istft_ft8_f64, k_imdct_ft16_f64), input = the device's own forward result
+        d_x.free()
+        d_x = replicate64(base, B, device)
+        fwd = zafx.stft_plan(ham, H, device=device, f64=True) if kind == "istft64" else zafx.mdct_plan(kbd, device=device, f64=True)
+        d_s = zafx.DeviceBuffer(fwd.out_shape(B, N), fwd.out_dtype, device)
+        fwd.execute(d_x, d_s, B, N)
+        INNER_LOG.append({"kind": None, "kernel": fwd.last_kernel, "launches": 1})
+        fwd.sync()
+        d_x.free()
+        if kind == "istft64":
+            plan = zafx.istft_plan(ham, H, device=device, f64=True)
+            wl.update(plan=plan, d_in=d_s, n_in=T, bytes_per_launch=B * (16 * W * T + 8 * (T * H - (W - H))),
+                      desc="Batched ISTFT in float64 of the device STFT of the same batch: 1024 clips x 432 frames, Hamming win=2048 hop=1024")
+        else:
+            plan = zafx.mdct_plan(kbd, device=device, inverse=True, f64=True)
+            wl.update(plan=plan, d_in=d_s, n_in=T, bytes_per_launch=B * (8 * (W // 2) * T + 8 * ((W // 2) * (T - 1) - 1)),
+                      desc="Batched IMDCT in float64 of the device MDCT of the same batch: 1024 clips x 432 frames, KBD win=2048")
     elif kind == "stft1":   # one-sided output (rows 0..W/2), not the headline
         plan = zafx.stft_plan(ham, H, layout=layout, device=device, onesided=True)
         wl.update(plan=plan, d_in=d_x, n_in=N, bytes_per_launch=B * (4 * N + 8 * (W // 2 + 1) * T),
@@ -437,7 +454,7 @@ def parity_probe(wl):
         ref = orc.mdct(x64, orc.kbd_window(8192))
     elif kind == "mel4096":
         ref = orc.melspectrogram(x64, orc.hamming_periodic(4096), 2048, orc.melfilterbank(FS, 4096, 128))
-    elif kind in ("istft", "istft1", "istft4096", "istft_offgrid"):
+    elif kind in ("istft", "istft1", "istft4096", "istft_offgrid", "istft64", "imdct64"):
         ref = None   # (checked as a round trip below: the device spectrum is the input)
     elif kind in ("mdct", "mdct_offgrid", "mdct64"):
         ref = orc.mdct(x64, kbd)
@@ -455,12 +472,12 @@ def parity_probe(wl):
     if ref is None:   # inverse kinds: resynthesis of the input (zaf.py:165-194 COLA; zaf.py:1098-1109 TDAC)
         n = len(x64) if kind.startswith("istft") else len(x64) - 1
         d = float(np.max(np.abs(first[:n].astype(np.float64) - x64[:n])))
-        tol = 1e-5
+        tol = 1e-11 if kind.endswith("64") else 1e-5
         out.update({"roundtrip_max_abs_residual": d, "tolerance": tol, "within_tolerance": bool(d < tol)})
         if kind.startswith("imdct"):
             refy = orc.imdct(orc.mdct(x64, kbd), kbd)
             e = float(np.max(np.abs(first - refy)) / np.max(np.abs(refy)))
-            out.update({"max_rel_err_vs_numpy": e, "within_tolerance": bool(d < tol and e <= 1e-5)})
+            out.update({"max_rel_err_vs_numpy": e, "within_tolerance": bool(d < tol and e <= (1e-12 if kind.endswith("64") else 1e-5))})
         return out
     got = first if first.shape == ref.shape else first.T
     d = float(np.max(np.abs(got - ref)))
@@ -865,7 +882,7 @@ def main():
     ap.add_argument("--steps", type=int, default=100)
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--kind", default="all", help="all = headline STFT + every other BASELINE config in one line; or one of "
-                    "stft istft mdct imdct mel mfcc cqt stft1 stftmag istft1 stft64 mdct64 dct")
+                    "stft istft mdct imdct mel mfcc cqt dct or an extra: " + " ".join(EXTRA_KINDS))
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-configs", action="store_true", help="with --kind all: headline only")
     ap.add_argument("--layout", default="FT", choices=["FT", "TF"], help="FT = reference (W, T) memory order (default); TF = frame-major")

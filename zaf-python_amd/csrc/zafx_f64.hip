@@ -626,7 +626,7 @@ __global__ __launch_bounds__(kF64Frames * 64) void k_istft_ft8_f64(const double2
                 const int f = to & 7, kq = to >> 3, t = t0 + f;
                 double2* buf = frames + ((rot + f) % NS) * PITCH;
                 if (t < T) {
-#pragma unroll 2
+#pragma unroll 2   // (4 or 8 pairs in flight: the same 0.65 ms)
                     for (int i = 0; i < 8; ++i) fold(sp, t, kq + 64 * i, buf);
                 }
             }

@@ -800,6 +800,7 @@ def test_stft_w8192_four_classes(zafx, hop, n, clips):
     x = np.stack([synth_clip(43, c % 4, n) for c in range(clips)])
     w = zafx.hamming(8192)
     plan = zafx.stft_plan(w, hop)
+    assert plan.kernel_name == "k_stft_ft16q"   # planned: the four-class family; what RAN depends on the call (last_kernel)
     ref = orc.stft_batch(x[:4].astype(np.float64), w, hop)
     got = zafx.stft_batch(x, w, hop)
     T = got.shape[2]

@@ -2739,6 +2739,7 @@ bool stft_pcm_direct_ok(const zafx_plan& pl, int64_t n_frames, int n_channels, i
 const char* stft_kernel_name(int log2n, int layout) {
     if (ZAFX_STFT_FAT8 && log2n == 11 && layout == ZAFX_LAYOUT_FT) return "k_stft_ft16";
     if (ZAFX_STFT_BAND && log2n == 11 && layout == ZAFX_LAYOUT_FT) return "k_stft_ft16b";
+    if (ZAFX_STFT_QUAD && log2n == 12 && layout == ZAFX_LAYOUT_FT) return "k_stft_ft16q";   // (planned: the four-class family; what RAN is last_kernel)
     return stft_use_fat(log2n, layout) ? "k_stft_ft16" : stft_use_tf(log2n, layout) ? "k_stft_tf" : "k_stft";
 }
 const char* istft_kernel_name(int log2n, int layout) {

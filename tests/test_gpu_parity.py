@@ -1129,6 +1129,33 @@ def test_f64_mel_mfcc(zafx, wl, hop, n, nmel):
             assert relerr(cep[c], ref_cep) <= 1e-10, (layout, c)
 
 
+@pytest.mark.parametrize("hop,n,clips,nmel,ncoef", [(1024, 441000, 3, 128, 20), (1024, 40000, 9, 40, 13), (512, 30001, 2, 128, 40), (777, 20000, 2, 64, 33),
+                                                     (1024, 1, 2, 128, 20), (2048, 100000, 2, 13, 12)])
+def test_f64_mel_mfcc_on_the_tiled_kernel(zafx, hop, n, clips, nmel, ncoef):
+    """W = 2048 in the reference layout, float64, up to 128 filters: k_mel_ft8_f64 (16-frame tiles = 128-byte lines of float64 rows, a frame per
+    wavefront, the filterbank over its non-zeros as rows of 64 segments, log + DCT-II rows wave-local) -- whole tiles, an edge tile, rows off
+    the line grid (T % 16 != 0), odd hops (the 8-byte load path), more than 32 coefficients, one frame; 1e-12 (mel) / 1e-10 (mfcc) of the
+    reference arithmetic.  The other layout and padded rows keep their kernels / pitch."""
+    x = np.stack([synth_clip(47, c % 7, n).astype(np.float64) + 1e-9 * (c % 7) for c in range(clips)])
+    w = zafx.hamming(2048)
+    fb = zafx.melfilterbank(44100, 2048, nmel)
+    mel = zafx.melspectrogram_batch(x, w, hop, fb, f64=True)
+    assert zafx.mel_plan(w, hop, fb, f64=True).last_kernel == "k_mel_ft8_f64" and mel.dtype == np.float64
+    cep = zafx.mfcc_batch(x, w, hop, fb, ncoef, f64=True)
+    assert zafx.mel_plan(w, hop, fb, ncoef, f64=True).last_kernel == "k_mel_ft8_f64" and cep.dtype == np.float64
+    for c in range(clips):
+        ref_mel, ref_cep = orc.melspectrogram(x[c], w, hop, fb), orc.mfcc(x[c], w, hop, fb, ncoef)
+        assert mel[c].shape == ref_mel.shape and cep[c].shape == ref_cep.shape
+        assert relerr(mel[c], ref_mel) <= TOL_F64, c
+        assert relerr(cep[c], ref_cep) <= 1e-10, c
+    zafx.melspectrogram_batch(x[:1], w, hop, fb, layout="TF", f64=True)
+    assert zafx.mel_plan(w, hop, fb, layout="TF", f64=True).last_kernel == "k_mel_f64"
+    # padded rows (row_align) through the plan interface
+    pl = zafx.mel_plan(w, hop, fb, ncoef, row_align=16, f64=True)
+    got = pl.run_host(x[:2], n)
+    assert pl.last_kernel == "k_mel_ft8_f64" and got.shape == cep[:2].shape and np.array_equal(got, cep[:2])
+
+
 @pytest.mark.parametrize("wl,n", [(2048, 441000), (2048, 30001), (512, 9001), (64, 1000), (8192, 50000), (256, 1)])
 def test_f64_mdct_imdct(zafx, wl, n):
     """ZAFX_PRECISION_F64 for the MDCT family: within 1e-12 of the reference arithmetic in both layouts and with padded

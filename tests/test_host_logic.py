@@ -131,6 +131,39 @@ def test_fft_core_emulated_on_cpu(tmp_path):
     assert worst < 5e-7, out
 
 
+@pytest.mark.timeout(300)
+def test_mel64_tables_emulated_on_cpu(tmp_path):
+    """zafx_mel64.hpp (the float64 mel kernel's view of the filterbank: its non-zeros as one equally long stream per lane + partial sums)
+    compiled for the host, the kernel's product loop run lane by lane, against the dense product -- for the reference's filterbanks and
+    for random bands, an all-zero row, two filters and a dense matrix."""
+    import struct
+    exe = tmp_path / "mel64_emu"
+    subprocess.run(["g++", "-O2", "-std=c++17", "-I", os.path.join(ROOT, "zaf-python_amd", "csrc"),
+                    os.path.join(ROOT, "tests", "host_emu", "mel64_emu.cpp"), "-o", str(exe)], check=True)
+    rng = np.random.default_rng(5)
+    banks = [zafx.melfilterbank(fs, 2048, nf).toarray() for fs, nf in ((44100, 128), (44100, 40), (16000, 64), (44100, 2), (8000, 13))]
+    rnd = np.zeros((128, 1024))
+    for r in range(128):
+        a = int(rng.integers(0, 1000))
+        b = min(1024, a + int(rng.integers(1, 200)))
+        rnd[r, a:b] = rng.standard_normal(b - a)
+    rnd[5] = 0.0
+    banks += [rnd, rng.standard_normal((16, 1024))]
+    for fb in banks:
+        s = rng.standard_normal(fb.shape[1])
+        res = subprocess.run([str(exe)], input=struct.pack("iii", fb.shape[0], fb.shape[1], 1154) + fb.tobytes() + s.tobytes(), capture_output=True)
+        assert res.returncode == 0, res.returncode   # (3 / 4: a read outside the spectrum / a slot outside the partial sums)
+        ok, steps, slots, max_parts = struct.unpack("4i", res.stdout[:16])
+        assert ok == 1 and slots <= fb.shape[0] + 64 and steps * 64 < np.count_nonzero(fb) + 8 * 64
+        mel = np.frombuffer(res.stdout[16:], dtype=np.float64)
+        assert np.abs(mel - fb @ s).max() <= 4e-16 * np.abs(fb).sum(axis=1).max() * np.abs(s).max()
+    # refused (the library then keeps the frame-per-workgroup kernel): partial sums that do not fit the LDS behind the spectrum, streams
+    # longer than 256 steps
+    for fb, spare in ((banks[0], 150), (rng.standard_normal((128, 1024)), 1154)):
+        res = subprocess.run([str(exe)], input=struct.pack("iii", 128, 1024, spare) + fb.tobytes() + fb[0].tobytes(), capture_output=True)
+        assert res.returncode == 0 and struct.unpack("4i", res.stdout[:16])[0] == 0
+
+
 def test_run_sharded_with_a_fake_device_step():
     """The in-process sharder (threads + block partition) with a CPU stand-in for the device call."""
     calls = []

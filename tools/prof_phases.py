@@ -58,6 +58,16 @@ elif kind in ("mel", "mfcc"):
     F, T = plan.out_dims(N)
     d_in, n_in, tiles = d_x, N, 27
     d_out = zafx.DeviceBuffer((B, F, T), np.float32)
+elif kind in ("mel64", "mfcc64"):
+    w = zafx.hamming(W)
+    fb = zafx.melfilterbank(44100, W, 128)
+    plan = zafx.mel_plan(w, H, fb, 20 if kind == "mfcc64" else None, f64=True)
+    B = 256
+    d_x.free()
+    d_x = zafx.DeviceBuffer.from_host(np.tile(x.astype(np.float64), (B // 8, 1)))
+    F, T = plan.out_dims(N)
+    d_in, n_in, tiles = d_x, N, 27
+    d_out = zafx.DeviceBuffer((B, F, T), np.float64)
 elif kind == "cqt":
     B, N = 128, 1323000
     x = np.random.default_rng(0).standard_normal((8, N)).astype(np.float32)
@@ -68,7 +78,7 @@ elif kind == "cqt":
     d_out = zafx.DeviceBuffer((B, F, T), np.float32)
 else:
     raise SystemExit("kind must be istft, mdct, imdct or cqt")
-name = "zafx_debug_prof_" + {"mfcc": "mel", "stft1": "stft", "spec": "mel"}.get(kind, kind)
+name = "zafx_debug_prof_" + {"mfcc": "mel", "stft1": "stft", "spec": "mel", "mfcc64": "mel64"}.get(kind, kind)
 fn = getattr(lib, name)
 out = (ctypes.c_ulonglong * 16)()
 # optional second argument: the waves to time, e.g. "0,5,15" or "all" (default: wave 1)

@@ -365,6 +365,7 @@ static int finalize_constant(zafx_plan* pl, int which) {
                 if (vals.empty()) vals.push_back(0.0);
                 ZAFX_HIP(upload(&pl->d_fb64, vals.data(), vals.size() * sizeof(double)));
                 ZAFX_HIP(upload(&pl->d_fb64_meta, meta.data(), meta.size() * sizeof(int)));
+                ZAFX_HIP(zafx::build_mel64_fb(*pl));
                 return 0;
             }
             if (zafx::mel_takes_wide_route(*pl)) {   // W = 4096 / 8192, windows that are not a power of two, more than 256 filters (k_melfb): rows as float32 bands
@@ -399,6 +400,7 @@ static int finalize_constant(zafx_plan* pl, int which) {
         case ZAFX_CONST_DCT:
             if (pl->prm.precision == ZAFX_PRECISION_F64) {
                 ZAFX_HIP(upload(&pl->d_dct64, pl->h_dct64.data(), pl->h_dct64.size() * sizeof(double)));
+                ZAFX_HIP(zafx::build_mel64_dct(*pl));
                 return 0;
             }
             if (zafx::mel_takes_wide_route(*pl)) {   // (k_melfb): dense rows
@@ -1097,6 +1099,9 @@ int zafx_plan_destroy(zafx_plan* pl) {
     if (pl->d_fb64) (void)hipFree(pl->d_fb64);
     if (pl->d_fb64_meta) (void)hipFree(pl->d_fb64_meta);
     if (pl->d_dct64) (void)hipFree(pl->d_dct64);
+    if (pl->d_mel64_stream) (void)hipFree(pl->d_mel64_stream);
+    if (pl->d_mel64_fin) (void)hipFree(pl->d_mel64_fin);
+    if (pl->d_mel64_dctT) (void)hipFree(pl->d_mel64_dctT);
     if (pl->d_values64) (void)hipFree(pl->d_values64);
     if (pl->d_bhat64) (void)hipFree(pl->d_bhat64);
     if (pl->d_pcm_float) (void)hipFree(pl->d_pcm_float);

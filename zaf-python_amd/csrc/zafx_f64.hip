@@ -13,6 +13,7 @@
 
 #include "zafx_fft.hpp"
 #include "zafx_internal.hpp"
+#include "zafx_mel64.hpp"
 
 namespace zafx {
 
@@ -156,8 +157,11 @@ __device__ __forceinline__ double2 root1024(const double2* __restrict__ tw, int 
     const double2 w = tw[m & 511];
     return m & 512 ? make_double2(-w.x, -w.y) : w;
 }
-// 1024-point forward transform of one wavefront: v[i] = z[lane + 64 i] in, natural order in `buf` out
-__device__ __forceinline__ void fft1024_f64(double2* v, double2* buf, int lane, const double2 (&w2)[16], const double2* __restrict__ tw) {
+// 1024-point forward transform of one wavefront: v[i] = z[lane + 64 i] in, natural order in `buf` out.  SPLIT_ROOTS: the real split's
+// roots tk[i] = tws[lane + 64 i] are requested together with the last pass's (one L2 round trip instead of two).
+template <bool SPLIT_ROOTS = false>
+__device__ __forceinline__ void fft1024_f64(double2* v, double2* buf, int lane, const double2 (&w2)[16], const double2* __restrict__ tw, double2* tk = nullptr,
+                                            const double2* __restrict__ tws = nullptr) {
     dft16d(v);
 #pragma unroll
     for (int r = 0; r < 16; ++r) buf[physd(16 * lane + r)] = v[r];
@@ -178,6 +182,10 @@ __device__ __forceinline__ void fft1024_f64(double2* v, double2* buf, int lane, 
 #pragma unroll
     for (int i = 0; i < 16; ++i) v[i] = buf[physd(lane + 64 * i)];
     frame_sync<64>();
+    if constexpr (SPLIT_ROOTS) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) tk[i] = tws[lane + 64 * i];
+    }
 #pragma unroll
     for (int b = 0; b < 4; ++b) {
         const int k = lane + 64 * b;
@@ -869,6 +877,229 @@ __global__ __launch_bounds__(kThreadsBig) void k_mel_f64(
     mel_tail_f64(mag, mel, fb, fb_meta, dct, out, clip, t, T, TP, layout, n_filters, n_coefs);
 }
 
+// ---------------------------------------------------------------------------------
+// k_mel_ft8_f64: melspectrogram / mfcc in the reference's own dtype (zaf.py:369-373, :436-452) on the tiled structure of k_stft_ft8_f64.
+// W = 2048, reference layout, up to 128 filters.  A workgroup is 8 waves, a wave one frame at a time: the 1024-point packed transform in
+// registers + the wave's own 17 KB of LDS (fft1024_f64), the real split straight into |X| (mel) or |X|^2 (mfcc) of bins 1 .. 1024, which
+// replace the frame in that buffer as S[c].  The filterbank is 98.6 % zeros (1 889 of 131 072 entries at 128 filters) and the float64
+// matrix rate of gfx950 equals its vector rate, so the product runs on the vector pipe over the non-zeros only, wave-local (no barrier):
+// the host deals the non-zeros, in row-major order, to the 64 lanes in equal consecutive shares (zafx_mel64.hpp: 30 entries per lane at
+// 128 filters, whatever the filters' lengths); an entry is 16 bytes {value, column, slot}, a step one coalesced 16-byte load, one
+// ds_read_b64 of the column and one fma; where a filter ends inside a lane's share the running sum goes to a partial-sum slot in LDS, and a
+// lane then adds the slots of its (at most two) filters in ascending
+// column order (deterministic).  mfcc: log(. + eps) of the 128 band sums (zaf.py:446), then the DCT-II rows as 2 x 32 lanes (coefficient x
+// half of the filters) from a transposed table, halves added across the wave.
+// A TILE is 16 frames of one clip = two rounds of the 8 waves, so that every output row is written as one 128-byte line of float64: the
+// rounds' results wait in a [row][16] staging array.  Samples of the wave's next frame are requested as soon as the transform has left the
+// registers for LDS (a second set of 64 registers for them under the transform spilled).
+// ---------------------------------------------------------------------------------
+constexpr int kMel64Rows = 128;                      // filters (mel) / coefficients (mfcc) the staging array holds
+constexpr int kMel64OutPitch = 17;                   // doubles per staged row of 16 frames (+ 1: rows on distinct banks)
+constexpr int kMel64Spare = 2 * kF64Pitch - kF64N;   // doubles of a wave's frame buffer behind S: partial sums, then the log-mel column
+
+ZAFX_PROF_ARRAY(g_prof_mel64)
+template <bool MFCC>
+__global__ __launch_bounds__(kF64Frames * 64) void k_mel_ft8_f64(const double* __restrict__ x, const double* __restrict__ win, const double2* __restrict__ tw,
+                                                                  const double2* __restrict__ tws, const int4* __restrict__ stream, const int2* __restrict__ fin,
+                                                                  const double* __restrict__ dctT, double* __restrict__ out, long long n_samples, int hop, int T, int TP,
+                                                                  int tiles, int total_tiles, int n_filters, int n_coefs, int n_steps, int n_slots, int max_parts,
+                                                                  int cpitch, int dct_half) {
+    constexpr int N = kF64N, W = 2 * N, FPB = kF64Frames, PITCH = kF64Pitch, OP = kMel64OutPitch;
+    static_assert(FPB == 8, "two rounds of eight frames make a 16-frame tile");
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    double2* frames = reinterpret_cast<double2*>(smem_raw);
+    double* stage = reinterpret_cast<double*>(frames + FPB * PITCH);   // [rows][OP]
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    double2* buf = frames + wave * PITCH;
+    double* S = reinterpret_cast<double*>(buf);   // S[c] = |X[c + 1]| or |X[c + 1]|^2 (zaf.py:370, :437-439: bins 1 .. W/2)
+    double* parts = S + N;
+    double* logmel = parts + n_slots;
+    const int rows = MFCC ? n_coefs : n_filters;
+    const bool xcd = gridDim.x % 8 == 0;
+    const bool has0 = lane < n_filters, has1 = lane + 64 < n_filters;   // the lane's (at most two) filters and where their partial sums are
+    const int2 f0 = has0 ? fin[lane] : make_int2(0, 0), f1 = has1 ? fin[lane + 64] : make_int2(0, 0);
+    auto load_frame = [&](double2 (&d)[16], int tlv, int round) {   // raw samples of this wave's frame of round `round` of tile `tlv`
+        if (tlv >= total_tiles) return;
+        const int tl = xcd ? xcd_order(tlv, total_tiles) : tlv;
+        const int clip = tl / tiles, t = (tl % tiles) * 16 + round * FPB + wave;
+        const double* xc = x + (long long)clip * n_samples;
+        const long long s0 = (long long)t * hop - N;   // floor(W / 2) samples of left padding (zaf.py:99, :112)
+        if (t < T && s0 >= 0 && s0 + W <= n_samples && ((s0 | n_samples) & 1) == 0) {   // (uniform) interior frame, 16-byte loads
+            const double2* xp = reinterpret_cast<const double2*>(xc + s0);
+#pragma unroll
+            for (int i = 0; i < 16; ++i) d[i] = xp[lane + 64 * i];
+        } else {
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                const long long s = s0 + 2 * (lane + 64 * i);
+                d[i].x = (t < T && s >= 0 && s < n_samples) ? xc[s] : 0.0;
+                d[i].y = (t < T && s + 1 >= 0 && s + 1 < n_samples) ? xc[s + 1] : 0.0;
+            }
+        }
+    };
+    double2 v[16];
+    load_frame(v, blockIdx.x, 0);
+    PROF_INIT(g_prof_mel64);
+    for (int tlv = blockIdx.x; tlv < total_tiles; tlv += gridDim.x) {
+        const int tl = xcd ? xcd_order(tlv, total_tiles) : tlv;
+        const int clip = tl / tiles, t0 = (tl % tiles) * 16;
+#pragma unroll 1
+        for (int round = 0; round < 2; ++round) {
+            int lane_o = lane;
+            asm volatile("" : "+v"(lane_o));   // (opaque per frame: window and twiddle values are re-read from L1, not hoisted out of the loop and spilled)
+            {
+                const double2* wp = reinterpret_cast<const double2*>(win);
+#pragma unroll
+                for (int i = 0; i < 16; ++i) {
+                    const double2 w = wp[lane_o + 64 * i];
+                    v[i] = make_double2(v[i].x * w.x, v[i].y * w.y);
+                }
+            }
+            PROF_MARK(0);
+            double2 w2[16];
+#pragma unroll
+            for (int r = 1; r < 16; ++r) w2[r] = root1024(tw, 4 * r * (lane_o & 15));   // exp(-2 pi i r k / 256)
+            const int4* st = stream + lane_o;
+            double2 tk[8];
+            fft1024_f64<true>(v, buf, lane_o, w2, tw, tk, tws);   // (the real split's roots are requested with the last pass's)
+            PROF_MARK(1);
+            load_frame(v, round == 0 ? tlv : tlv + (int)gridDim.x, round ^ 1);   // the transform is in LDS: the wave's next frame flies under split, product and stores
+            // real split X[k] = E + t_k O, X[N-k] = conj(E - t_k O) (as k_stft_f64), straight into levels
+            double ma[8], mb[8];
+#pragma unroll
+            for (int i0 = 0; i0 < 8; i0 += 4) {   // (four pairs at a time: eight kept the registers above the budget)
+                double2 zk[4], zn[4];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const int k = lane_o + 64 * (i0 + i);
+                    zk[i] = buf[physd(k)];
+                    zn[i] = buf[physd(k == 0 ? N / 2 : N - k)];
+                }
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const double2 ev = make_double2(0.5 * (zk[i].x + zn[i].x), 0.5 * (zk[i].y - zn[i].y));
+                    const double2 d = make_double2(0.5 * (zk[i].x - zn[i].x), 0.5 * (zk[i].y + zn[i].y));
+                    const double2 to = dmul(tk[i0 + i], make_double2(d.y, -d.x));
+                    double2 xk = dadd(ev, to), xn = dsub(ev, to);
+                    if (i0 + i == 0 && lane_o == 0) {   // k = 0: the pair is (X[N/2] = conj z[N/2], X[N] = Re z[0] - Im z[0]); X[0] is not a mel column
+                        xk = zn[0];
+                        xn = make_double2(zk[0].x - zk[0].y, 0.0);
+                    }
+                    const double pa = xk.x * xk.x + xk.y * xk.y, pb = xn.x * xn.x + xn.y * xn.y;
+                    ma[i0 + i] = MFCC ? pa : sqrt(pa);
+                    mb[i0 + i] = MFCC ? pb : sqrt(pb);
+                }
+            }
+            int4 e[8];   // first eight entries of the lane_o's share of the filterbank (requested here: under the split they spilled)
+#pragma unroll
+            for (int q = 0; q < 8; ++q) e[q] = st[q * 64];
+            frame_sync<64>();   // every lane_o has read its pairs: the levels replace the frame
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const int k = lane_o + 64 * i;
+                S[k == 0 ? N / 2 - 1 : k - 1] = ma[i];
+                S[N - 1 - k] = mb[i];
+            }
+            frame_sync<64>();
+            PROF_MARK(2);
+            // filterbank over the non-zeros: the lane_o's stream, eight entries requested while the eight before are used
+            {
+                double acc = 0.0;
+                for (int b = 0; b < n_steps; b += 8) {
+                    int4 nx[8];
+                    if (b + 8 < n_steps) {
+#pragma unroll
+                        for (int q = 0; q < 8; ++q) nx[q] = st[(b + 8 + q) * 64];
+                    }
+                    double c[8];
+#pragma unroll
+                    for (int q = 0; q < 8; ++q) c[q] = S[e[q].z];
+#pragma unroll
+                    for (int q = 0; q < 8; ++q) {
+                        acc = fma(__hiloint2double(e[q].y, e[q].x), c[q], acc);
+                        if (e[q].w >= 0) {
+                            parts[e[q].w] = acc;
+                            acc = 0.0;
+                        }
+                    }
+#pragma unroll
+                    for (int q = 0; q < 8; ++q) e[q] = nx[q];
+                }
+            }
+            double dn[16];   // mfcc: the first sixteen terms' DCT values, in flight under the partial sums and the logarithms
+            const int dh = lane_o >> 5, dcl = lane_o & 31;
+            const double* dp = dctT + (long long)dh * dct_half * cpitch + dcl;
+            if (MFCC) {
+#pragma unroll
+                for (int q = 0; q < 16; ++q) dn[q] = dp[q * cpitch];
+            }
+            frame_sync<64>();
+            PROF_MARK(3);
+            const int fcol = round * FPB + wave;
+            {   // a lane_o adds the partial sums of its filters in ascending column order
+                double s0 = 0.0, s1 = 0.0;
+                for (int p = 0; p < max_parts; ++p) {
+                    if (p < f0.y) s0 += parts[f0.x + p];
+                    if (p < f1.y) s1 += parts[f1.x + p];
+                }
+                if (MFCC) {   // np.finfo(float).eps (zaf.py:446)
+                    if (has0) logmel[lane_o] = log(s0 + 2.220446049250313e-16);
+                    if (has1) logmel[lane_o + 64] = log(s1 + 2.220446049250313e-16);
+                    if (n_filters + lane_o < 2 * dct_half) logmel[n_filters + lane_o] = 0.0;   // (the DCT's padded terms: zero rows of the table times these)
+                } else {
+                    if (has0) stage[lane_o * OP + fcol] = s0;
+                    if (has1) stage[(lane_o + 64) * OP + fcol] = s1;
+                }
+            }
+            PROF_MARK(4);
+            if (MFCC) {
+                frame_sync<64>();
+                // scipy.fftpack.dct(., norm="ortho") rows 1 .. n_coefs (zaf.py:449-452) as a matrix: lane_o = (coefficient, half of the filters)
+                // (the table holds 2 dct_half rows, zero behind n_filters; sixteen terms requested while the sixteen before are used, four chains)
+                const double* lm = logmel + dh * dct_half;
+                for (int c0 = 0; c0 < n_coefs; c0 += 32) {
+                    double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
+                    for (int n = 0; n < dct_half; n += 16) {
+                        double d[16], y[16];
+#pragma unroll
+                        for (int q = 0; q < 16; ++q) d[q] = dn[q];
+                        const int nn = n + 16 < dct_half ? n + 16 : 0, cn = n + 16 < dct_half ? c0 : c0 + 32;   // next: this group's next terms, or the next group's first
+                        if (n + 16 < dct_half || c0 + 32 < n_coefs) {
+#pragma unroll
+                            for (int q = 0; q < 16; ++q) dn[q] = dp[(nn + q) * cpitch + cn];
+                        }
+#pragma unroll
+                        for (int q = 0; q < 16; ++q) y[q] = lm[n + q];
+#pragma unroll
+                        for (int q = 0; q < 16; q += 4) {
+                            s0 = fma(d[q], y[q], s0);
+                            s1 = fma(d[q + 1], y[q + 1], s1);
+                            s2 = fma(d[q + 2], y[q + 2], s2);
+                            s3 = fma(d[q + 3], y[q + 3], s3);
+                        }
+                    }
+                    double sum = (s0 + s1) + (s2 + s3);
+                    sum += __shfl_xor(sum, 32, 64);
+                    if (dh == 0 && c0 + dcl < n_coefs) stage[(c0 + dcl) * OP + fcol] = sum;
+                }
+            }
+            frame_sync<64>();   // S / partial sums / log-mel column are read: the next frame may take the buffer
+            PROF_MARK(5);
+        }
+        lds_barrier();
+        PROF_MARK(6);
+        {   // the tile's rows: sixteen lanes (frames) to a 128-byte line, 32 rows per instruction of the workgroup
+            const int f = tid & 15;
+            double* o = out + (long long)clip * rows * TP + t0 + f;
+            if (t0 + f < T)
+                for (int r = tid >> 4; r < rows; r += 32) o[(long long)r * TP] = stage[r * OP + f];
+        }
+        PROF_MARK(7);
+        lds_barrier();
+        PROF_MARK(8);
+    }
+}
+
 // ---- windows that are not a power of two (the reference's np.fft takes any length): Bluestein ---------------------------
 // W-point DFT as a convolution of length M = 2^ceil(log2(2W-1)):  n k = (n^2 + k^2 - (k-n)^2) / 2, so with
 // c[n] = exp(-i pi n^2 / W):   X[k] = c[k] * sum_n (x[n] c[n]) conj(c)[k-n].  The host provides c (exact: n^2 mod 2W in
@@ -1116,6 +1347,46 @@ __global__ __launch_bounds__(kThreadsBig) void k_cqt_f64(
 
 }  // namespace
 
+// Host side of k_mel_ft8_f64: the filterbank's bands as rows of 64 segments (zafx_mel64.hpp; see the kernel's header).
+hipError_t build_mel64_fb(zafx_plan& pl) {
+    pl.mel64_ok = false;
+    const int nf = pl.prm.n_filters, cols = pl.W / 2;
+    if (!ZAFX_F64_TILED || pl.W != 2 * kF64N || pl.bs_log2m > 0 || nf < 1 || nf > kMel64Rows || pl.h_fb64.size() != (size_t)nf * cols) return hipSuccess;
+    const Mel64Tables t = mel64_tables(pl.h_fb64.data(), nf, cols, kMel64Spare);
+    if (!t.ok) return hipSuccess;   // (the frame-per-workgroup kernel takes such a matrix)
+    auto up = [](auto** d, const void* h, size_t bytes) -> hipError_t {
+        if (*d) (void)hipFree(*d);
+        *d = nullptr;
+        if (hipError_t e = hipMalloc((void**)d, bytes); e != hipSuccess) return e;
+        return hipMemcpy(*d, h, bytes, hipMemcpyHostToDevice);
+    };
+    static_assert(sizeof(Mel64Entry) == sizeof(int4), "an entry is one 16-byte load");
+    if (hipError_t e = up(&pl.d_mel64_stream, t.stream.data(), t.stream.size() * sizeof(Mel64Entry)); e != hipSuccess) return e;
+    if (hipError_t e = up(&pl.d_mel64_fin, t.fin.data(), t.fin.size() * sizeof(int)); e != hipSuccess) return e;
+    pl.mel64_steps = t.steps;
+    pl.mel64_slots = t.slots;
+    pl.mel64_max_parts = t.max_parts;
+    pl.mel64_ok = true;
+    return hipSuccess;
+}
+
+hipError_t build_mel64_dct(zafx_plan& pl) {   // DCT-II rows transposed and padded: [2 dct_half filters][coefficients up to a multiple of 32], zeros outside
+    const int nf = pl.prm.n_filters, nc = pl.prm.n_coefs;
+    pl.mel64_cpitch = 0;
+    if (nc < 1 || nc > kMel64Rows || nf < 1 || pl.h_dct64.size() != (size_t)nc * nf) return hipSuccess;
+    const int cp = (nc + 31) / 32 * 32, half = ((nf + 1) / 2 + 15) / 16 * 16;
+    std::vector<double> t((size_t)2 * half * cp, 0.0);
+    for (int c = 0; c < nc; ++c)
+        for (int n = 0; n < nf; ++n) t[(size_t)n * cp + c] = pl.h_dct64[(size_t)c * nf + n];
+    if (pl.d_mel64_dctT) (void)hipFree(pl.d_mel64_dctT);
+    pl.d_mel64_dctT = nullptr;
+    if (hipError_t e = hipMalloc((void**)&pl.d_mel64_dctT, t.size() * sizeof(double)); e != hipSuccess) return e;
+    if (hipError_t e = hipMemcpy(pl.d_mel64_dctT, t.data(), t.size() * sizeof(double), hipMemcpyHostToDevice); e != hipSuccess) return e;
+    pl.mel64_cpitch = cp;
+    pl.mel64_dct_half = half;
+    return hipSuccess;
+}
+
 const char* cqt_f64_kernel_name() { return "k_cqt_f64"; }
 const char* mel_f64_kernel_name() { return "k_mel_f64"; }
 const char* mdct_f64_kernel_name() { return "k_mdct_f64"; }
@@ -1282,6 +1553,22 @@ hipError_t launch_mel_f64(const zafx_plan& pl, const double* x, double* out, int
     if (pl.bs_log2m > 0) return launch_bs_f64(pl, x, out, n_clips, n_samples, T, true);
     const long long blocks = (long long)n_clips * T;
     if (blocks <= 0) return hipSuccess;
+    const bool mfcc = pl.kind == ZAFX_MFCC;
+    if (ZAFX_F64_TILED && pl.mel64_ok && (!mfcc || (pl.mel64_cpitch > 0 && pl.mel64_slots + 2 * pl.mel64_dct_half <= kMel64Spare)) && pl.layout == ZAFX_LAYOUT_FT && reinterpret_cast<uintptr_t>(x) % 16 == 0) {
+        const int tiles = (T + 15) / 16;
+        const long long total = (long long)tiles * n_clips;
+        if (total < (1LL << 31)) {
+            const size_t smem8 = (size_t)kF64Frames * kF64Pitch * sizeof(double2) + (size_t)kMel64Rows * kMel64OutPitch * sizeof(double);
+            auto k8 = mfcc ? k_mel_ft8_f64<true> : k_mel_ft8_f64<false>;
+            if (hipError_t e = ensure_dynamic_lds(reinterpret_cast<const void*>(k8), pl.device, smem8); e != hipSuccess) return e;
+            pl.ran = "k_mel_ft8_f64";
+            hipLaunchKernelGGL(k8, dim3((unsigned)std::min<long long>(total, pl.n_cus)), dim3(kF64Frames * 64), smem8, pl.stream, x, pl.d_window64, pl.d_tw64, pl.d_tws64,
+                               pl.d_mel64_stream, pl.d_mel64_fin, pl.d_mel64_dctT, out, (long long)n_samples, pl.H, T,
+                               (int)row_pitch(pl, T), tiles, (int)total, pl.prm.n_filters, mfcc ? pl.prm.n_coefs : 0, pl.mel64_steps, pl.mel64_slots,
+                               pl.mel64_max_parts, pl.mel64_cpitch, pl.mel64_dct_half);
+            return hipGetLastError();
+        }
+    }
     const size_t smem = (size_t)pl.W * sizeof(double2);   // two buffers of W/2 points; the idle one later holds bins + band sums
     auto kern = k_mel_f64;
     if (hipError_t e = ensure_dynamic_lds(reinterpret_cast<const void*>(kern), pl.device, smem); e != hipSuccess) return e;
@@ -1379,3 +1666,4 @@ hipError_t launch_imdct_f64(zafx_plan& pl, const double* coefs_all, double* y_al
 }
 
 }  // namespace zafx
+ZAFX_PROF_EXPORT(zafx_debug_prof_mel64, g_prof_mel64)

@@ -152,6 +152,13 @@ struct zafx_plan {
     double* d_fb64 = nullptr;      // mel filterbank rows as bands: values of [first, first + count) of every row, back to back
     int* d_fb64_meta = nullptr;    // [n_filters][3]: first column, count, offset into d_fb64
     double* d_dct64 = nullptr;     // [n_coefs][n_filters]
+    // k_mel_ft8_f64 (W = 2048, reference layout; build_mel64_fb in zafx_f64.hip, zafx_mel64.hpp): the filterbank's non-zeros as one equally
+    // long stream per lane
+    int4* d_mel64_stream = nullptr;   // [steps][64] entries {value (2 words), column, slot of the partial sum or -1}
+    int2* d_mel64_fin = nullptr;      // [n_filters]: {first slot, slots} of a filter's partial sums (consecutive, ascending columns)
+    double* d_mel64_dctT = nullptr;   // mfcc: DCT-II rows transposed, [2 mel64_dct_half filters][coefficient pitch (a multiple of 32)], zeros outside
+    int mel64_steps = 0, mel64_slots = 0, mel64_max_parts = 0, mel64_cpitch = 0, mel64_dct_half = 0;
+    bool mel64_ok = false;
     double2* d_values64 = nullptr; // CQT kernel values of a float64 plan (complex128)
     int bs_log2m = 0;              // > 0: window that is not a power of two -- Bluestein convolution length 2^bs_log2m (zafx_f64.hip, zafx_bs32.hip)
     mutable int call_pcm = 0;      // set by zafx_execute_pcm around a launch whose kernel reads int16 itself (1 mono, 2 stereo; pcm_direct_ok)
@@ -191,6 +198,8 @@ hipError_t launch_istft_f64(zafx_plan& pl, const double2* spec, double* y, int64
 hipError_t launch_cqt_f64(zafx_plan& pl, const double* x, double* out, int64_t n_clips, int64_t n_samples, int T);
 hipError_t launch_mel_f64(const zafx_plan& pl, const double* x, double* out, int64_t n_clips, int64_t n_samples, int T);
 hipError_t launch_mdct_f64(const zafx_plan& pl, const double* x, double* out, int64_t n_clips, int64_t n_samples, int T);
+hipError_t build_mel64_fb(zafx_plan& pl);    // host tables of k_mel_ft8_f64 (zafx_f64.hip), rebuilt whenever the filterbank / DCT constant is set
+hipError_t build_mel64_dct(zafx_plan& pl);
 hipError_t launch_imdct_f64(zafx_plan& pl, const double* coefs, double* y, int64_t n_clips, int T, int64_t out_len);
 const char* stft_f64_kernel_name();
 const char* istft_f64_kernel_name();

@@ -437,15 +437,18 @@ static int finalize_constant(zafx_plan* pl, int which) {
         case ZAFX_CONST_CQT_INDPTR:
             ZAFX_HIP(upload(&pl->d_indptr, pl->h_indptr.data(), pl->h_indptr.size() * sizeof(int32_t)));
             pl->cqt_dirty = true;
+            pl->cqt64_dirty = true;
             return 0;
         case ZAFX_CONST_CQT_INDICES:
             ZAFX_HIP(upload(&pl->d_indices, pl->h_indices.data(), pl->h_indices.size() * sizeof(int32_t)));
             pl->nnz = (int)pl->h_indices.size();
             pl->cqt_dirty = true;
+            pl->cqt64_dirty = true;
             return 0;
         case ZAFX_CONST_CQT_VALUES:
             if (pl->prm.precision == ZAFX_PRECISION_F64) {
                 ZAFX_HIP(upload(&pl->d_values64, pl->h_values64.data(), pl->h_values64.size() * sizeof(double2)));
+                pl->cqt64_dirty = true;
                 return 0;
             }
             ZAFX_HIP(upload(&pl->d_values, pl->h_values.data(), pl->h_values.size() * sizeof(cf32)));
@@ -1099,6 +1102,10 @@ int zafx_plan_destroy(zafx_plan* pl) {
     if (pl->d_fb64) (void)hipFree(pl->d_fb64);
     if (pl->d_fb64_meta) (void)hipFree(pl->d_fb64_meta);
     if (pl->d_dct64) (void)hipFree(pl->d_dct64);
+    if (pl->d_cqt64_split) (void)hipFree(pl->d_cqt64_split);
+    if (pl->d_cqt64_vals) (void)hipFree(pl->d_cqt64_vals);
+    if (pl->d_cqt64_meta) (void)hipFree(pl->d_cqt64_meta);
+    if (pl->d_cqt64_fin) (void)hipFree(pl->d_cqt64_fin);
     if (pl->d_mel64_stream) (void)hipFree(pl->d_mel64_stream);
     if (pl->d_mel64_fin) (void)hipFree(pl->d_mel64_fin);
     if (pl->d_mel64_dctT) (void)hipFree(pl->d_mel64_dctT);

@@ -14,6 +14,7 @@
 #include "zafx_fft.hpp"
 #include "zafx_internal.hpp"
 #include "zafx_mel64.hpp"
+#include "zafx_cqt64.hpp"
 
 namespace zafx {
 
@@ -1345,6 +1346,232 @@ __global__ __launch_bounds__(kThreadsBig) void k_cqt_f64(
     }
 }
 
+
+// ---------------------------------------------------------------------------------
+// k_cqt_ft_f64: cqtspectrogram / cqtchromagram in the reference's own dtype (zaf.py:562-700) on the structure of the float32 k_cqt.
+// fft_length W = 32768: the frame is one N = 16384-point packed transform, N = 16 x 1024 by decimation in frequency --
+//     Z[16 k + q] = FFT_1024{ y_q }[k],   y_q[m] = w_N^(m q) sum_r z[m + 1024 r] w_16^(r q)
+// -- a radix-16 pass across the workgroup's registers (a thread owns m and m + 512: coalesced 16-byte loads of z[m + 1024 r]), then sixteen
+// wave-local 1024-point transforms (fft1024 below: registers + the wave's own 17 KB of LDS).  In float64 only eight of the sixteen
+// sub-sequences fit LDS, so a frame takes two ROUNDS of the 8 waves: the even q first, the odd q wait in registers (64 per thread).  A pair
+// (c, N - c) of the real split lies in sub-transforms q and 16 - q: the same round.  Only the one-sided bins the kernel matrix reads are
+// split (zafx_cqt64.hpp: 2 634 of 16 384 for the reference's kernel), by fixed threads into registers; after the second round they go to a
+// compact array in the (then free) transform buffers, and the matrix's non-zeros run over it as one stream per thread -- equal shares in
+// CSR order, a partial sum per (thread, row) piece, rows finished in ascending column order (deterministic) --, then np.absolute and, for
+// the chromagram, the sums over octaves (zaf.py:693-698).  Workgroups share clips per XCD as k_cqt's do, so that the 94.6 % overlap of
+// neighbouring frames is served by one L2.
+// Twiddles: w_N^(m q) as products of the table values w^m, w^2m, w^4m, w^8m (at most three factors: 3e-16); the sub-transforms' first
+// exchange takes exp(-2 pi i r k / 256) from a 4-KB table in LDS, the last pass its roots from the plan's table of the roots of W.
+// ---------------------------------------------------------------------------------
+__device__ __forceinline__ double2 root1024s(const double2* __restrict__ tws, int m) {   // exp(-2 pi i m / 1024), m < 1024, from the plan's exp(-2 pi i j / 32768)
+    return tws[m << 5];
+}
+// 1024-point forward transform of one wavefront, input and output in `buf` (natural order)
+__device__ __forceinline__ void fft1024_cq(double2* buf, int lane, const double2* w2tab, const double2* __restrict__ tws) {
+    double2 v[16];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) v[i] = buf[physd(lane + 64 * i)];
+    frame_sync<64>();
+    dft16d(v);
+#pragma unroll
+    for (int r = 0; r < 16; ++r) buf[physd(16 * lane + r)] = v[r];
+    frame_sync<64>();
+#pragma unroll
+    for (int i = 0; i < 16; ++i) v[i] = buf[physd(lane + 64 * i)];
+    frame_sync<64>();
+    {
+        const int k = lane & 15;
+#pragma unroll
+        for (int r = 1; r < 16; ++r) v[r] = dmul(v[r], w2tab[r * 16 + k]);   // exp(-2 pi i r k / 256)
+        dft16d(v);
+        const int base = ((lane >> 4) << 8) + k;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) buf[physd(base + 16 * r)] = v[r];
+    }
+    frame_sync<64>();
+#pragma unroll
+    for (int i = 0; i < 16; ++i) v[i] = buf[physd(lane + 64 * i)];
+    frame_sync<64>();
+#pragma unroll
+    for (int b = 0; b < 4; ++b) {
+        const int k = lane + 64 * b;
+        double2 a0 = v[b], a1 = dmul(v[b + 4], root1024s(tws, k)), a2 = dmul(v[b + 8], root1024s(tws, 2 * k)), a3 = dmul(v[b + 12], root1024s(tws, 3 * k));
+        dft4d(a0, a1, a2, a3);
+        buf[physd(k)] = a0;
+        buf[physd(k + 256)] = a1;
+        buf[physd(k + 512)] = a2;
+        buf[physd(k + 768)] = a3;
+    }
+    frame_sync<64>();
+}
+
+ZAFX_PROF_ARRAY(g_prof_cqt64)
+template <int KC2>
+__global__ __launch_bounds__(kCq64Threads) void k_cqt_ft_f64(const double* __restrict__ x, const double2* __restrict__ tws,
+                                                              const int* __restrict__ split_tab, const double2* __restrict__ cvals, const int2* __restrict__ cmeta,
+                                                              const int2* __restrict__ fin, double* __restrict__ out, long long n_samples, int step, int left, int T,
+                                                              int TP, int n_clips, int n_groups, int n_bins, int chroma_res, int layout, int n_cols, int n_steps,
+                                                              int n_slots, int max_parts) {
+    constexpr int N = 16384, W = 2 * N, PITCH = kF64Pitch, NW = kCq64Threads / 64, NT = kCq64Threads;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    double2* frames = reinterpret_cast<double2*>(smem_raw);   // NW sub-transform buffers; behind the second round: compact spectrum, partial sums, levels
+    double2* w2tab = frames + NW * PITCH;                     // [16][16] exp(-2 pi i r k / 256)
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    double2* buf = frames + wave * PITCH;
+    if (tid < 256) w2tab[tid] = root1024s(tws, 4 * (tid >> 4) * (tid & 15));
+    int col[2][KC2];   // the bins this thread splits: bin | compact index << 14, -1: none
+#pragma unroll
+    for (int r = 0; r < 2; ++r)
+#pragma unroll
+        for (int j = 0; j < KC2; ++j) col[r][j] = split_tab[(r * KC2 + j) * NT + tid];
+    lds_barrier();
+    // work list (as k_cqt): group = blockIdx % n_groups (the XCD when n_groups = 8) owns clips group, group + n_groups, ...; its frames, clip
+    // after clip, are dealt round-robin to the group's workgroups
+    const int group = blockIdx.x % n_groups, slot = blockIdx.x / n_groups;
+    const int n_slots_g = (gridDim.x - group + n_groups - 1) / n_groups;
+    const long long n_work = (long long)((n_clips - group + n_groups - 1) / n_groups) * T;
+    PROF_INIT(g_prof_cqt64);
+    for (long long g = slot; g < n_work; g += n_slots_g) {
+        const int clip = group + (int)(g / T) * n_groups, t = (int)(g % T);
+        const double* xc = x + (long long)clip * n_samples;
+        const long long s0 = (long long)t * step - left;   // zaf.py:612-620: `left` zeros in front of the clip
+        const bool interior = s0 >= 0 && s0 + W <= n_samples && (((long long)clip * n_samples + s0) & 1) == 0;   // (uniform) 16-byte loads
+        double2 hold[2][8];   // y_q[m] of the odd q for the thread's two m
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int m = tid + NT * j;
+            double2 z[16];
+            if (interior) {
+                const double2* xp = reinterpret_cast<const double2*>(xc + s0) + m;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) z[r] = xp[1024 * r];
+            } else {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const long long s = s0 + 2 * (m + 1024 * r);
+                    z[r].x = (s >= 0 && s < n_samples) ? xc[s] : 0.0;
+                    z[r].y = (s + 1 >= 0 && s + 1 < n_samples) ? xc[s + 1] : 0.0;
+                }
+            }
+            const double2 w1 = tws[2 * m], w2 = tws[4 * m], w4 = tws[8 * m], w8 = tws[16 * m];   // exp(-2 pi i m 2^i / N) from the table of W = 2 N
+            dft16d(z);   // z[q] = sum_r z[m + 1024 r] w_16^(r q)
+            const double2 w3 = dmul(w1, w2), w5 = dmul(w1, w4), w6 = dmul(w2, w4), w7 = dmul(w3, w4), w12 = dmul(w4, w8);
+            double2* fm = frames + physd(m);
+            fm[0 * PITCH] = z[0];
+            fm[1 * PITCH] = dmul(z[2], w2);
+            fm[2 * PITCH] = dmul(z[4], w4);
+            fm[3 * PITCH] = dmul(z[6], w6);
+            fm[4 * PITCH] = dmul(z[8], w8);
+            fm[5 * PITCH] = dmul(z[10], dmul(w2, w8));
+            fm[6 * PITCH] = dmul(z[12], w12);
+            fm[7 * PITCH] = dmul(z[14], dmul(w6, w8));
+            hold[j][0] = dmul(z[1], w1);
+            hold[j][1] = dmul(z[3], w3);
+            hold[j][2] = dmul(z[5], w5);
+            hold[j][3] = dmul(z[7], w7);
+            hold[j][4] = dmul(z[9], dmul(w1, w8));
+            hold[j][5] = dmul(z[11], dmul(w3, w8));
+            hold[j][6] = dmul(z[13], dmul(w5, w8));
+            hold[j][7] = dmul(z[15], dmul(w7, w8));
+        }
+        PROF_MARK(0);
+        lds_barrier();
+        double2 xs[2][KC2];   // the thread's bins X[c] (real split of the packed transform, as k_stft_f64)
+#pragma unroll
+        for (int round = 0; round < 2; ++round) {
+            if (round == 1) {
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+#pragma unroll
+                    for (int p = 0; p < 8; ++p) frames[p * PITCH + physd(tid + NT * j)] = hold[j][p];
+                lds_barrier();
+            }
+            PROF_MARK(1);
+            fft1024_cq(buf, lane, w2tab, tws);   // wave p: sub-transform q = 2 p + round
+            PROF_MARK(2);
+            lds_barrier();
+            PROF_MARK(3);
+#pragma unroll
+            for (int j = 0; j < KC2; ++j) {
+                const int cb = col[round][j];
+                const int bin = cb < 0 ? 16 + round : cb & 0x3fff;   // (idle slot: any bin of this round, result unused)
+                const int q = bin & 15, k = bin >> 4;
+                const int qn = (16 - q) & 15, kn = 1024 - k - (q != 0);   // N - bin = 16 kn + qn
+                const double2 zk = frames[(q >> 1) * PITCH + physd(k)], zn = frames[(qn >> 1) * PITCH + physd(kn)];
+                const double2 e = make_double2(0.5 * (zk.x + zn.x), 0.5 * (zk.y - zn.y));
+                const double2 d = make_double2(0.5 * (zk.x - zn.x), 0.5 * (zk.y + zn.y));
+                xs[round][j] = dadd(e, dmul(tws[bin], make_double2(d.y, -d.x)));
+            }
+            lds_barrier();
+            PROF_MARK(4);
+        }
+        double2* Xc = frames;
+        double2* parts = Xc + n_cols;
+        double* spec = reinterpret_cast<double*>(parts + n_slots);
+#pragma unroll
+        for (int r = 0; r < 2; ++r)
+#pragma unroll
+            for (int j = 0; j < KC2; ++j)
+                if (col[r][j] >= 0) Xc[col[r][j] >> 14] = xs[r][j];
+        lds_barrier();
+        PROF_MARK(5);
+        {   // cqt_kernel * fft(frame) (zaf.py:631) over the non-zeros: the thread's share, four entries requested while the four before are used
+            const double2* vp = cvals + tid;
+            const int2* mp = cmeta + tid;
+            double2 acc = make_double2(0.0, 0.0);
+            double2 kv[4];
+            int2 km[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) kv[q] = vp[q * NT], km[q] = mp[q * NT];
+            for (int b = 0; b < n_steps; b += 4) {
+                double2 nv[4];
+                int2 nm[4];
+                if (b + 4 < n_steps) {
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) nv[q] = vp[(b + 4 + q) * NT], nm[q] = mp[(b + 4 + q) * NT];
+                }
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    double2 xv = Xc[km[q].x & 0x7fffffff];
+                    if (km[q].x < 0) xv.y = -xv.y;   // a column above W/2: X[c] = conj X[W - c]
+                    acc = dadd(acc, dmul(kv[q], xv));
+                    if (km[q].y >= 0) {
+                        parts[km[q].y] = acc;
+                        acc = make_double2(0.0, 0.0);
+                    }
+                }
+#pragma unroll
+                for (int q = 0; q < 4; ++q) kv[q] = nv[q], km[q] = nm[q];
+            }
+        }
+        lds_barrier();
+        PROF_MARK(6);
+        for (int r = tid; r < n_bins; r += NT) {   // a row's partial sums in ascending column order, then np.absolute (zaf.py:631)
+            const int2 f = fin[r];
+            double2 sum = make_double2(0.0, 0.0);
+            for (int p = 0; p < f.y; ++p) sum = dadd(sum, parts[f.x + p]);
+            spec[r] = hypot(sum.x, sum.y);
+        }
+        lds_barrier();
+        {
+            const int rows = chroma_res > 0 ? chroma_res : n_bins;
+            const long long stride = layout == ZAFX_LAYOUT_FT ? TP : 1;
+            const long long base = layout == ZAFX_LAYOUT_FT ? (long long)clip * rows * TP + t : ((long long)clip * T + t) * rows;
+            for (int r = tid; r < rows; r += NT) {
+                double v;
+                if (chroma_res > 0) {   // zaf.py:693-698: rows i, i + r, i + 2r, ... summed in ascending order
+                    v = 0.0;
+                    for (int q = r; q < n_bins; q += chroma_res) v += spec[q];
+                } else {
+                    v = spec[r];
+                }
+                out[base + r * stride] = v;
+            }
+        }
+        lds_barrier();   // the compact spectrum lies in the transform buffers the next frame fills
+        PROF_MARK(7);
+    }
+}
 }  // namespace
 
 // Host side of k_mel_ft8_f64: the filterbank's bands as rows of 64 segments (zafx_mel64.hpp; see the kernel's header).
@@ -1384,6 +1611,37 @@ hipError_t build_mel64_dct(zafx_plan& pl) {   // DCT-II rows transposed and padd
     if (hipError_t e = hipMemcpy(pl.d_mel64_dctT, t.data(), t.size() * sizeof(double), hipMemcpyHostToDevice); e != hipSuccess) return e;
     pl.mel64_cpitch = cp;
     pl.mel64_dct_half = half;
+    return hipSuccess;
+}
+
+// Host side of k_cqt_ft_f64 (zafx_cqt64.hpp): rebuilt by launch_cqt_f64 whenever the kernel matrix changed
+constexpr int kCq64MaxKc2 = 4;
+static hipError_t build_cqt64(zafx_plan& pl) {
+    pl.cqt64_ok = false;
+    pl.cqt64_dirty = false;
+    const int rows = (int)pl.h_indptr.size() - 1;
+    if (!ZAFX_F64_TILED || pl.W != 32768 || rows < 1 || (int)pl.h_values64.size() != pl.nnz || pl.h_indptr.back() != pl.nnz) return hipSuccess;
+    const Cqt64Tables t = cqt64_tables(pl.h_indptr.data(), pl.h_indices.data(), reinterpret_cast<const double*>(pl.h_values64.data()), rows, pl.W, kCq64MaxKc2);
+    if (!t.ok || (size_t)t.n_cols * 16 + (size_t)t.slots * 16 + (size_t)rows * 8 > (size_t)kCq64Threads / 64 * kF64Pitch * sizeof(double2)) return hipSuccess;
+    std::vector<double2> vals(t.stream.size());
+    std::vector<int2> meta(t.stream.size());
+    for (size_t i = 0; i < t.stream.size(); ++i) vals[i] = make_double2(t.stream[i].re, t.stream[i].im), meta[i] = make_int2(t.stream[i].index, t.stream[i].slot);
+    auto up = [](auto** d, const void* h, size_t bytes) -> hipError_t {
+        if (*d) (void)hipFree(*d);
+        *d = nullptr;
+        if (hipError_t e = hipMalloc((void**)d, bytes); e != hipSuccess) return e;
+        return hipMemcpy(*d, h, bytes, hipMemcpyHostToDevice);
+    };
+    if (hipError_t e = up(&pl.d_cqt64_split, t.split.data(), t.split.size() * sizeof(int)); e != hipSuccess) return e;
+    if (hipError_t e = up(&pl.d_cqt64_vals, vals.data(), vals.size() * sizeof(double2)); e != hipSuccess) return e;
+    if (hipError_t e = up(&pl.d_cqt64_meta, meta.data(), meta.size() * sizeof(int2)); e != hipSuccess) return e;
+    if (hipError_t e = up(&pl.d_cqt64_fin, t.fin.data(), t.fin.size() * sizeof(int)); e != hipSuccess) return e;
+    pl.cqt64_kc2 = t.kc2;
+    pl.cqt64_cols = t.n_cols;
+    pl.cqt64_steps = t.steps;
+    pl.cqt64_slots = t.slots;
+    pl.cqt64_max_parts = t.max_parts;
+    pl.cqt64_ok = true;
     return hipSuccess;
 }
 
@@ -1531,6 +1789,25 @@ hipError_t launch_istft_f64(zafx_plan& pl, const double2* spec_all, double* y_al
 hipError_t launch_cqt_f64(zafx_plan& pl, const double* x, double* out, int64_t n_clips, int64_t n_samples, int T) {
     const long long total = (long long)n_clips * T;
     if (total <= 0) return hipSuccess;
+    if (pl.cqt64_dirty)
+        if (hipError_t e = build_cqt64(pl); e != hipSuccess) return e;
+    if (pl.cqt64_ok && reinterpret_cast<uintptr_t>(x) % 16 == 0 && total < (1LL << 31)) {
+        const int n_groups = (int)std::min<int64_t>(8, n_clips);
+        const long long per_group = ((n_clips + n_groups - 1) / n_groups) * (long long)T;   // frames of the longest list
+        const int grid = (int)std::min<long long>(std::max(pl.n_cus / n_groups, 1) * (long long)n_groups, per_group * n_groups);
+        const size_t smem = (size_t)(kCq64Threads / 64) * kF64Pitch * sizeof(double2) + 256 * sizeof(double2);
+        const int diff = pl.W - pl.H;
+        const int left = diff >= 0 ? (diff + 1) / 2 : -((-diff) / 2);   // ceil((fft_length - step) / 2), zaf.py:615
+        auto kern = pl.cqt64_kc2 <= 1 ? k_cqt_ft_f64<1> : pl.cqt64_kc2 == 2 ? k_cqt_ft_f64<2> : pl.cqt64_kc2 == 3 ? k_cqt_ft_f64<3> : k_cqt_ft_f64<4>;
+        const int kc2 = pl.cqt64_kc2 <= 3 ? std::max(pl.cqt64_kc2, 1) : 4;
+        if (kc2 != pl.cqt64_kc2) return hipErrorInvalidValue;   // (the split table is laid out for the plan's own count)
+        if (hipError_t e = ensure_dynamic_lds(reinterpret_cast<const void*>(kern), pl.device, smem); e != hipSuccess) return e;
+        pl.ran = "k_cqt_ft_f64";
+        hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(kCq64Threads), smem, pl.stream, x, pl.d_tws64, pl.d_cqt64_split, pl.d_cqt64_vals, pl.d_cqt64_meta,
+                           pl.d_cqt64_fin, out, (long long)n_samples, pl.H, left, T, (int)row_pitch(pl, T), (int)n_clips, n_groups, pl.prm.n_bins,
+                           pl.kind == ZAFX_CHROMA ? pl.prm.octave_resolution : 0, pl.layout, pl.cqt64_cols, pl.cqt64_steps, pl.cqt64_slots, pl.cqt64_max_parts);
+        return hipGetLastError();
+    }
     const int log2w = pl.log2nf + 1;
     const int n2 = std::min(pl.W, kCqt64Sub);
     const long long grid = std::min<long long>(total, (long long)pl.n_cus * 2);
@@ -1667,3 +1944,4 @@ hipError_t launch_imdct_f64(zafx_plan& pl, const double* coefs_all, double* y_al
 
 }  // namespace zafx
 ZAFX_PROF_EXPORT(zafx_debug_prof_mel64, g_prof_mel64)
+ZAFX_PROF_EXPORT(zafx_debug_prof_cqt64, g_prof_cqt64)

@@ -160,6 +160,13 @@ struct zafx_plan {
     int mel64_steps = 0, mel64_slots = 0, mel64_max_parts = 0, mel64_cpitch = 0, mel64_dct_half = 0;
     bool mel64_ok = false;
     double2* d_values64 = nullptr; // CQT kernel values of a float64 plan (complex128)
+    // k_cqt_ft_f64 (fft_length 32768; build_cqt64 in zafx_f64.hip, zafx_cqt64.hpp)
+    int* d_cqt64_split = nullptr;       // [2 rounds][kc2][512]: the one-sided bins a thread splits (bin | compact index << 14, -1: none)
+    double2* d_cqt64_vals = nullptr;    // [steps][512]: the matrix's non-zeros as one stream per thread ...
+    int2* d_cqt64_meta = nullptr;       // ... {compact index | conjugate << 31, slot of the partial sum or -1}
+    int2* d_cqt64_fin = nullptr;        // [rows]: {first slot, slots}
+    int cqt64_kc2 = 0, cqt64_cols = 0, cqt64_steps = 0, cqt64_slots = 0, cqt64_max_parts = 0;
+    bool cqt64_ok = false, cqt64_dirty = true;
     int bs_log2m = 0;              // > 0: window that is not a power of two -- Bluestein convolution length 2^bs_log2m (zafx_f64.hip, zafx_bs32.hip)
     mutable int call_pcm = 0;      // set by zafx_execute_pcm around a launch whose kernel reads int16 itself (1 mono, 2 stereo; pcm_direct_ok)
     void* d_pcm_float = nullptr;   // zafx_execute_pcm's float32 staging for the kinds that do not (grow-only)

@@ -1129,6 +1129,42 @@ def test_f64_mel_mfcc(zafx, wl, hop, n, nmel):
             assert relerr(cep[c], ref_cep) <= 1e-10, (layout, c)
 
 
+@pytest.mark.parametrize("n,clips,tr", [(100000, 3, 25), (33001, 9, 50), (40000, 2, 10)])
+def test_f64_cqt_on_the_tiled_kernel(zafx, n, clips, tr):
+    """fft_length 32768 in float64: k_cqt_ft_f64 (16 x 1024 decimation in frequency in two rounds of eight wavefronts, the split of the bins the
+    kernel reads only, the matrix's non-zeros as one stream per thread) -- frames that reach in front of and behind the clip (the buffer loads'
+    out-of-range zeros), odd clip lengths (samples off the 16-byte grid), both layouts, the chromagram, a genuinely complex matrix (the 24-byte
+    entries) and a matrix with columns above W/2 (conjugate bins); kernels the tiled form does not take (bins above 8191) stay on k_cqt_f64."""
+    ck = zafx.cqtkernel(44100, 24, 55, 3520)
+    assert ck.shape == (144, 32768)
+    x = np.stack([synth_clip(53, c % 7, n).astype(np.float64) + 1e-9 * (c % 7) for c in range(clips)])
+    for layout in ("FT", "TF"):
+        spec = zafx.cqtspectrogram_batch(x, 44100, tr, ck, layout=layout, f64=True)
+        assert zafx.cqt_plan(44100, tr, ck, layout=layout, f64=True).last_kernel == "k_cqt_ft_f64"
+        chroma = zafx.cqtchromagram_batch(x, 44100, tr, 24, ck, layout=layout, f64=True)
+        assert zafx.cqt_plan(44100, tr, ck, 24, layout=layout, f64=True).last_kernel == "k_cqt_ft_f64"
+        if layout == "TF":
+            spec, chroma = spec.transpose(0, 2, 1), chroma.transpose(0, 2, 1)
+        for c in range(clips):
+            ref, ref_c = orc.cqtspectrogram(x[c], 44100, tr, ck), orc.cqtchromagram(x[c], 44100, tr, 24, ck)
+            assert spec[c].shape == ref.shape and chroma[c].shape == ref_c.shape
+            assert relerr(spec[c], ref) <= TOL_F64 and relerr(chroma[c], ref_c) <= TOL_F64, (layout, c)
+    # a complex matrix with mirrored columns: rows of the reference's kernel rotated by a phase, every third entry moved to W - c
+    rng = np.random.default_rng(7)
+    coo = ck.tocoo()
+    data = coo.data * np.exp(2j * np.pi * rng.random(coo.nnz))
+    cols = np.where(np.arange(coo.nnz) % 3 == 0, 32768 - coo.col, coo.col)
+    ck2 = scipy.sparse.csr_matrix((data, (coo.row, cols)), shape=ck.shape)
+    got = zafx.cqtspectrogram_batch(x[:2], 44100, tr, ck2, f64=True)
+    assert zafx.cqt_plan(44100, tr, ck2, f64=True).last_kernel == "k_cqt_ft_f64"
+    for c in range(2):
+        assert relerr(got[c], orc.cqtspectrogram(x[c], 44100, tr, ck2)) <= TOL_F64, c
+    wide = zafx.cqtkernel(44100, 24, 55, 22050)   # the reference's docstring kernel: columns up to bin 16 613
+    got = zafx.cqtspectrogram_batch(x[:1, :40000], 44100, tr, wide, f64=True)
+    assert zafx.cqt_plan(44100, tr, wide, f64=True).last_kernel == "k_cqt_f64"
+    assert relerr(got[0], orc.cqtspectrogram(x[0, :40000], 44100, tr, wide)) <= TOL_F64
+
+
 @pytest.mark.parametrize("hop,n,clips,nmel,ncoef", [(1024, 441000, 3, 128, 20), (1024, 40000, 9, 40, 13), (512, 30001, 2, 128, 40), (777, 20000, 2, 64, 33),
                                                      (1024, 1, 2, 128, 20), (2048, 100000, 2, 13, 12)])
 def test_f64_mel_mfcc_on_the_tiled_kernel(zafx, hop, n, clips, nmel, ncoef):

@@ -68,6 +68,15 @@ elif kind in ("mel64", "mfcc64"):
     F, T = plan.out_dims(N)
     d_in, n_in, tiles = d_x, N, 27
     d_out = zafx.DeviceBuffer((B, F, T), np.float64)
+elif kind == "cqt64":
+    B, N = 64, 1323000
+    x = np.random.default_rng(0).standard_normal((8, N))
+    d_x.free()
+    d_in = zafx.DeviceBuffer.from_host(np.tile(x, (B // 8, 1)))
+    plan = zafx.cqt_plan(44100, 25, zafx.cqtkernel(44100, 24, 55, 3520), f64=True)
+    F, T = plan.out_dims(N)
+    n_in, tiles = N, T * 1.0
+    d_out = zafx.DeviceBuffer((B, F, T), np.float64)
 elif kind == "cqt":
     B, N = 128, 1323000
     x = np.random.default_rng(0).standard_normal((8, N)).astype(np.float32)
@@ -94,6 +103,6 @@ for wv in waves:
         plan.execute(d_in, d_out, B, n_in)
     plan.sync()
     fn(out)
-    per_tile = reps * (16 if kind == 'cqt' else tiles * B / 256)   # cqt: workgroup 7 = 16 frames per launch, counts are per frame
+    per_tile = reps * (tiles * B / 256 if kind == 'cqt64' else 16 if kind == 'cqt' else tiles * B / 256)   # cqt: workgroup 7 = 16 frames per launch, counts are per frame
     print(kind, f"wave {wv}: cycles per tile between marks:", " | ".join(f"{i}:{out[i] / per_tile:.0f}" for i in range(12)),
           "| total", round(sum(out) / per_tile))

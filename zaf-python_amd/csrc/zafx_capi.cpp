@@ -1102,6 +1102,7 @@ int zafx_plan_destroy(zafx_plan* pl) {
     if (pl->d_fb64) (void)hipFree(pl->d_fb64);
     if (pl->d_fb64_meta) (void)hipFree(pl->d_fb64_meta);
     if (pl->d_dct64) (void)hipFree(pl->d_dct64);
+    if (pl->d_cqt64_tw1) (void)hipFree(pl->d_cqt64_tw1);
     if (pl->d_cqt64_split) (void)hipFree(pl->d_cqt64_split);
     if (pl->d_cqt64_vals) (void)hipFree(pl->d_cqt64_vals);
     if (pl->d_cqt64_meta) (void)hipFree(pl->d_cqt64_meta);

@@ -60,7 +60,7 @@ inline Cqt64Tables cqt64_tables(const int32_t* indptr, const int32_t* indices, c
             t.split[((size_t)r * t.kc2 + i / kCq64Threads) * kCq64Threads + i % kCq64Threads] = lists[r][i] | (compact[(size_t)lists[r][i]] << 14);
     // contraction: the non-zeros in CSR order in equal consecutive shares
     const int share = (nnz + kCq64Threads - 1) / kCq64Threads;
-    t.steps = (share + 3) / 4 * 4;
+    t.steps = (share + 7) / 8 * 8;   // (the kernel requests eight entries at a time)
     if (t.steps > max_steps) return t;
     t.stream.assign((size_t)t.steps * kCq64Threads, Cqt64Entry{0.0, 0.0, 0, -1});
     t.fin.assign((size_t)rows * 2, 0);

@@ -1361,13 +1361,15 @@ __global__ __launch_bounds__(kThreadsBig) void k_cqt_f64(
 // the chromagram, the sums over octaves (zaf.py:693-698).  Workgroups share clips per XCD as k_cqt's do, so that the 94.6 % overlap of
 // neighbouring frames is served by one L2.
 // Twiddles: w_N^(m q) as products of the table values w^m, w^2m, w^4m, w^8m (at most three factors: 3e-16); the sub-transforms' first
-// exchange takes exp(-2 pi i r k / 256) from a 4-KB table in LDS, the last pass its roots from the plan's table of the roots of W.
+// exchange takes exp(-2 pi i r k / 256) from a 4-KB table in LDS, the last pass its roots from a 12-KB one (from L2 they cost three round
+// trips per sub-transform; in registers, 48 of them, they spilled).
 // ---------------------------------------------------------------------------------
 __device__ __forceinline__ double2 root1024s(const double2* __restrict__ tws, int m) {   // exp(-2 pi i m / 1024), m < 1024, from the plan's exp(-2 pi i j / 32768)
     return tws[m << 5];
 }
 // 1024-point forward transform of one wavefront, input and output in `buf` (natural order)
-__device__ __forceinline__ void fft1024_cq(double2* buf, int lane, const double2* w2tab, const double2* __restrict__ tws) {
+template <int RS>   // stride of the root table: 1 (the LDS copy) or 32 (the plan's roots of 32768)
+__device__ __forceinline__ void fft1024_cq(double2* buf, int lane, const double2* w2tab, const double2* rtab) {   // rtab[m] = exp(-2 pi i m / 1024), m < 768 (LDS)
     double2 v[16];
 #pragma unroll
     for (int i = 0; i < 16; ++i) v[i] = buf[physd(lane + 64 * i)];
@@ -1395,7 +1397,7 @@ __device__ __forceinline__ void fft1024_cq(double2* buf, int lane, const double2
 #pragma unroll
     for (int b = 0; b < 4; ++b) {
         const int k = lane + 64 * b;
-        double2 a0 = v[b], a1 = dmul(v[b + 4], root1024s(tws, k)), a2 = dmul(v[b + 8], root1024s(tws, 2 * k)), a3 = dmul(v[b + 12], root1024s(tws, 3 * k));
+        double2 a0 = v[b], a1 = dmul(v[b + 4], rtab[k * RS]), a2 = dmul(v[b + 8], rtab[2 * k * RS]), a3 = dmul(v[b + 12], rtab[3 * k * RS]);
         dft4d(a0, a1, a2, a3);
         buf[physd(k)] = a0;
         buf[physd(k + 256)] = a1;
@@ -1405,10 +1407,19 @@ __device__ __forceinline__ void fft1024_cq(double2* buf, int lane, const double2
     frame_sync<64>();
 }
 
+#ifndef ZAFX_CQ64_PREFETCH
+#define ZAFX_CQ64_PREFETCH 0   // 1, 2: half / all of the next first pass's samples requested behind the transforms of the phase before -- measured 6.8 / 8.9 ms against 4.85 (64 clips x 30 s): the 64 / 128 registers they hold spill
+#endif
+#ifndef ZAFX_CQ64_BATCH
+#define ZAFX_CQ64_BATCH 4   // entries of the contraction's stream in flight per thread (8: 5.15 ms against 4.74 for 64 clips x 30 s with 24-byte entries)
+#endif
+#ifndef ZAFX_CQ64_RTAB_LDS
+#define ZAFX_CQ64_RTAB_LDS 1   // the last pass's roots from LDS (0: from the plan's table in global memory)
+#endif
 ZAFX_PROF_ARRAY(g_prof_cqt64)
-template <int KC2>
-__global__ __launch_bounds__(kCq64Threads) void k_cqt_ft_f64(const double* __restrict__ x, const double2* __restrict__ tws,
-                                                              const int* __restrict__ split_tab, const double2* __restrict__ cvals, const int2* __restrict__ cmeta,
+template <int KC2, bool REALK>
+__global__ __launch_bounds__(kCq64Threads) void k_cqt_ft_f64(const double* __restrict__ x, const double2* __restrict__ tws, const double2* __restrict__ tw1,
+                                                              const int* __restrict__ split_tab, const void* __restrict__ cvals, const int* __restrict__ cmeta,
                                                               const int2* __restrict__ fin, double* __restrict__ out, long long n_samples, int step, int left, int T,
                                                               int TP, int n_clips, int n_groups, int n_bins, int chroma_res, int layout, int n_cols, int n_steps,
                                                               int n_slots, int max_parts) {
@@ -1416,6 +1427,7 @@ __global__ __launch_bounds__(kCq64Threads) void k_cqt_ft_f64(const double* __res
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     double2* frames = reinterpret_cast<double2*>(smem_raw);   // NW sub-transform buffers; behind the second round: compact spectrum, partial sums, levels
     double2* w2tab = frames + NW * PITCH;                     // [16][16] exp(-2 pi i r k / 256)
+    double2* rtab = w2tab + 256;                              // [768] exp(-2 pi i m / 1024): the last pass's roots of the wave-local transforms
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     double2* buf = frames + wave * PITCH;
     if (tid < 256) w2tab[tid] = root1024s(tws, 4 * (tid >> 4) * (tid & 15));
@@ -1424,6 +1436,7 @@ __global__ __launch_bounds__(kCq64Threads) void k_cqt_ft_f64(const double* __res
     for (int r = 0; r < 2; ++r)
 #pragma unroll
         for (int j = 0; j < KC2; ++j) col[r][j] = split_tab[(r * KC2 + j) * NT + tid];
+    for (int i = tid; i < 768; i += NT) rtab[i] = root1024s(tws, i);
     lds_barrier();
     // work list (as k_cqt): group = blockIdx % n_groups (the XCD when n_groups = 8) owns clips group, group + n_groups, ...; its frames, clip
     // after clip, are dealt round-robin to the group's workgroups
@@ -1431,69 +1444,113 @@ __global__ __launch_bounds__(kCq64Threads) void k_cqt_ft_f64(const double* __res
     const int n_slots_g = (gridDim.x - group + n_groups - 1) / n_groups;
     const long long n_work = (long long)((n_clips - group + n_groups - 1) / n_groups) * T;
     PROF_INIT(g_prof_cqt64);
+    // samples z[m + 1024 r] of frame `g` for m = tid + 512 j: buffer loads with the clip as descriptor, so that the zeros around the clip
+    // (zaf.py:612-620) are its out-of-range reads -- one path for every frame, one 32-bit offset per lane
+    auto load_z = [&](double2 (&z)[16], long long g, int j, int tid_l) {   // (tid_l: the thread index, opaque per frame -- see tid_o)
+        if (g >= n_work) return;
+        const int clip = group + (int)(g / T) * n_groups, t = (int)(g % T);
+        const auto rx = make_rsrc(x + (long long)clip * n_samples, (unsigned)(n_samples * 8));
+        const long long s0 = (long long)t * step - left;
+        const int voff = (int)(s0 * 8) + (tid_l + NT * j) * 16;   // (negative in front of the clip: out of range as unsigned)
+        if (s0 >= 0 && s0 + W <= n_samples) {   // (uniform) the frame lies inside the clip: 16-byte loads
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const auto raw = __builtin_amdgcn_raw_buffer_load_b128(rx, voff + r * 16384, 0, 0);   // (the whole offset per lane: the range check does not see a scalar offset)
+                __builtin_memcpy(&z[r], &raw, 16);
+            }
+        } else {   // a frame over an end of the clip: a 16-byte load that straddles the end comes back as zeros whole, so the two samples are loaded apart
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const auto re = __builtin_amdgcn_raw_buffer_load_b64(rx, voff + r * 16384, 0, 0), im = __builtin_amdgcn_raw_buffer_load_b64(rx, voff + r * 16384 + 8, 0, 0);
+                __builtin_memcpy(&z[r].x, &re, 8);
+                __builtin_memcpy(&z[r].y, &im, 8);
+            }
+        }
+    };
+    // requested ahead -- behind the transforms of the phase before, whose registers they would not fit beside: in flight under the split (and, for
+    // the next frame, under the contraction): both halves (m = tid, tid + 512) of the next first pass's samples
+    double2 zq[2][16];
+    if (ZAFX_CQ64_PREFETCH) load_z(zq[0], slot, 0, tid);
+    if (ZAFX_CQ64_PREFETCH == 2) load_z(zq[1], slot, 1, tid);
     for (long long g = slot; g < n_work; g += n_slots_g) {
         const int clip = group + (int)(g / T) * n_groups, t = (int)(g % T);
-        const double* xc = x + (long long)clip * n_samples;
-        const long long s0 = (long long)t * step - left;   // zaf.py:612-620: `left` zeros in front of the clip
-        const bool interior = s0 >= 0 && s0 + W <= n_samples && (((long long)clip * n_samples + s0) & 1) == 0;   // (uniform) 16-byte loads
-        double2 hold[2][8];   // y_q[m] of the odd q for the thread's two m
-#pragma unroll
-        for (int j = 0; j < 2; ++j) {
-            const int m = tid + NT * j;
-            double2 z[16];
-            if (interior) {
-                const double2* xp = reinterpret_cast<const double2*>(xc + s0) + m;
-#pragma unroll
-                for (int r = 0; r < 16; ++r) z[r] = xp[1024 * r];
-            } else {
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const long long s = s0 + 2 * (m + 1024 * r);
-                    z[r].x = (s >= 0 && s < n_samples) ? xc[s] : 0.0;
-                    z[r].y = (s + 1 >= 0 && s + 1 < n_samples) ? xc[s + 1] : 0.0;
-                }
-            }
-            const double2 w1 = tws[2 * m], w2 = tws[4 * m], w4 = tws[8 * m], w8 = tws[16 * m];   // exp(-2 pi i m 2^i / N) from the table of W = 2 N
-            dft16d(z);   // z[q] = sum_r z[m + 1024 r] w_16^(r q)
-            const double2 w3 = dmul(w1, w2), w5 = dmul(w1, w4), w6 = dmul(w2, w4), w7 = dmul(w3, w4), w12 = dmul(w4, w8);
-            double2* fm = frames + physd(m);
-            fm[0 * PITCH] = z[0];
-            fm[1 * PITCH] = dmul(z[2], w2);
-            fm[2 * PITCH] = dmul(z[4], w4);
-            fm[3 * PITCH] = dmul(z[6], w6);
-            fm[4 * PITCH] = dmul(z[8], w8);
-            fm[5 * PITCH] = dmul(z[10], dmul(w2, w8));
-            fm[6 * PITCH] = dmul(z[12], w12);
-            fm[7 * PITCH] = dmul(z[14], dmul(w6, w8));
-            hold[j][0] = dmul(z[1], w1);
-            hold[j][1] = dmul(z[3], w3);
-            hold[j][2] = dmul(z[5], w5);
-            hold[j][3] = dmul(z[7], w7);
-            hold[j][4] = dmul(z[9], dmul(w1, w8));
-            hold[j][5] = dmul(z[11], dmul(w3, w8));
-            hold[j][6] = dmul(z[13], dmul(w5, w8));
-            hold[j][7] = dmul(z[15], dmul(w7, w8));
-        }
-        PROF_MARK(0);
-        lds_barrier();
+        int tid_o = tid;
+        asm volatile("" : "+v"(tid_o));   // (opaque per frame: LDS addresses and table pointers are recomputed, not hoisted out of the loop and spilled)
         double2 xs[2][KC2];   // the thread's bins X[c] (real split of the packed transform, as k_stft_f64)
 #pragma unroll
         for (int round = 0; round < 2; ++round) {
-            if (round == 1) {
+            // first pass for this round's eight q (even: the 8-point transform of z[r] + z[r + 8]; odd: of (z[r] - z[r + 8]) w_16^r): the samples
+            // are read once per round (the second time from L2) -- sixteen outputs at once held 64 registers through the first round and spilled
+            if (!ZAFX_CQ64_PREFETCH) load_z(zq[0], g, 0, tid_o);
+            if (ZAFX_CQ64_PREFETCH != 2) load_z(zq[1], g, 1, tid_o);   // (1: only the first half rides ahead; both kept 128 registers through the split and spilled)
+            // both halves folded first (16 -> 8 values each: the 128 registers of samples are down to 64 before the transforms need theirs)
+            double2 af[2][8];
 #pragma unroll
-                for (int j = 0; j < 2; ++j)
+            for (int j = 0; j < 2; ++j)
 #pragma unroll
-                    for (int p = 0; p < 8; ++p) frames[p * PITCH + physd(tid + NT * j)] = hold[j][p];
-                lds_barrier();
+                for (int r = 0; r < 8; ++r) af[j][r] = round == 0 ? dadd(zq[j][r], zq[j][r + 8]) : dsub(zq[j][r], zq[j][r + 8]);
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const int m = tid_o + NT * j;
+                double2 (&a)[8] = af[j];
+                const double2 w2 = tw1[1024 + m], w4 = tw1[2048 + m], w8 = tw1[3072 + m];   // tw1[i][m] = exp(-2 pi i m 2^i / N): coalesced (the same values out of the
+                                                                                             // plan's table of the roots of W lie a cache line apart: 350 KB through the L1 per round)
+                double2* fm = frames + physd(m);
+                if (round == 0) {
+                    dft8d(a);   // a[p] = sum_r z[m + 1024 r] w_16^(2 p r)
+                    const double2 w6 = dmul(w2, w4);
+                    fm[0 * PITCH] = a[0];
+                    fm[1 * PITCH] = dmul(a[1], w2);
+                    fm[2 * PITCH] = dmul(a[2], w4);
+                    fm[3 * PITCH] = dmul(a[3], w6);
+                    fm[4 * PITCH] = dmul(a[4], w8);
+                    fm[5 * PITCH] = dmul(a[5], dmul(w2, w8));
+                    fm[6 * PITCH] = dmul(a[6], dmul(w4, w8));
+                    fm[7 * PITCH] = dmul(a[7], dmul(w6, w8));
+                } else {
+                    const double h = 0.70710678118654752440, c1 = 0.92387953251128675613, s1 = 0.38268343236508977173;
+                    a[1] = dmul(a[1], make_double2(c1, -s1));
+                    a[2] = dmul(a[2], make_double2(h, -h));
+                    a[3] = dmul(a[3], make_double2(s1, -c1));
+                    a[4] = dmul_mi(a[4]);
+                    a[5] = dmul(a[5], make_double2(-s1, -c1));
+                    a[6] = dmul(a[6], make_double2(-h, -h));
+                    a[7] = dmul(a[7], make_double2(-c1, -s1));
+                    dft8d(a);   // a[p] = sum_r z[m + 1024 r] w_16^((2 p + 1) r)
+                    const double2 w1 = tw1[m];
+                    const double2 w3 = dmul(w1, w2), w5 = dmul(w1, w4), w9 = dmul(w1, w8);
+                    fm[0 * PITCH] = dmul(a[0], w1);
+                    fm[1 * PITCH] = dmul(a[1], w3);
+                    fm[2 * PITCH] = dmul(a[2], w5);
+                    fm[3 * PITCH] = dmul(a[3], dmul(w3, w4));
+                    fm[4 * PITCH] = dmul(a[4], w9);
+                    fm[5 * PITCH] = dmul(a[5], dmul(w3, w8));
+                    fm[6 * PITCH] = dmul(a[6], dmul(w5, w8));
+                    fm[7 * PITCH] = dmul(a[7], dmul(dmul(w3, w4), w8));
+                }
             }
+            PROF_MARK(0);
+            lds_barrier();
             PROF_MARK(1);
-            fft1024_cq(buf, lane, w2tab, tws);   // wave p: sub-transform q = 2 p + round
+            {
+                int tid_f = tid;
+                asm volatile("" : "+v"(tid_f));   // (opaque per sub-transform: its forty LDS addresses are recomputed, not kept -- spilled -- across the loop)
+                double2* buf_f = frames + (tid_f >> 6) * PITCH;
+                if (ZAFX_CQ64_RTAB_LDS) fft1024_cq<1>(buf_f, tid_f & 63, w2tab, rtab);   // wave p: sub-transform q = 2 p + round
+                else fft1024_cq<32>(buf_f, tid_f & 63, w2tab, tws);
+            }
             PROF_MARK(2);
+            if (ZAFX_CQ64_PREFETCH) {
+                const long long gn = round == 0 ? g : g + n_slots_g;
+                load_z(zq[0], gn, 0, tid_o);
+                if (ZAFX_CQ64_PREFETCH == 2) load_z(zq[1], gn, 1, tid_o);
+            }
             lds_barrier();
             PROF_MARK(3);
 #pragma unroll
             for (int j = 0; j < KC2; ++j) {
-                const int cb = col[round][j];
+                int cb = col[round][j];
+                asm volatile("" : "+v"(cb));
                 const int bin = cb < 0 ? 16 + round : cb & 0x3fff;   // (idle slot: any bin of this round, result unused)
                 const int q = bin & 15, k = bin >> 4;
                 const int qn = (16 - q) & 15, kn = 1024 - k - (q != 0);   // N - bin = 16 kn + qn
@@ -1505,43 +1562,58 @@ __global__ __launch_bounds__(kCq64Threads) void k_cqt_ft_f64(const double* __res
             lds_barrier();
             PROF_MARK(4);
         }
+        constexpr int CB = ZAFX_CQ64_BATCH;
+        using KV = std::conditional_t<REALK, double, double2>;
+        const KV* vp = reinterpret_cast<const KV*>(cvals) + tid_o;
+        const int* mp = cmeta + tid_o;
+        KV kv0[CB], kv1[CB];   // the first two batches of the thread's share of the kernel matrix: requested here, used behind two barriers
+        int km0[CB], km1[CB];
+#pragma unroll
+        for (int q = 0; q < CB; ++q) kv0[q] = vp[q * NT], km0[q] = mp[q * NT];
+        if (CB < n_steps) {
+#pragma unroll
+            for (int q = 0; q < CB; ++q) kv1[q] = vp[(CB + q) * NT], km1[q] = mp[(CB + q) * NT];
+        }
         double2* Xc = frames;
         double2* parts = Xc + n_cols;
         double* spec = reinterpret_cast<double*>(parts + n_slots);
 #pragma unroll
         for (int r = 0; r < 2; ++r)
 #pragma unroll
-            for (int j = 0; j < KC2; ++j)
-                if (col[r][j] >= 0) Xc[col[r][j] >> 14] = xs[r][j];
+            for (int j = 0; j < KC2; ++j) {
+                int cb = col[r][j];
+                asm volatile("" : "+v"(cb));
+                if (cb >= 0) Xc[cb >> 14] = xs[r][j];
+            }
         lds_barrier();
         PROF_MARK(5);
-        {   // cqt_kernel * fft(frame) (zaf.py:631) over the non-zeros: the thread's share, four entries requested while the four before are used
-            const double2* vp = cvals + tid;
-            const int2* mp = cmeta + tid;
+        {   // cqt_kernel * fft(frame) (zaf.py:631) over the non-zeros: the thread's share, CB entries at a time, two batches in flight (an L2 round
+            // trip per batch otherwise: six per frame); the first two were requested in front of the compact spectrum's barrier (kv0 / kv1 above).
+            // REALK: the matrix is real up to round-off (the reference's kernel: |imag| / |real| = 1.2e-16): 12 bytes per entry instead of 24
             double2 acc = make_double2(0.0, 0.0);
-            double2 kv[4];
-            int2 km[4];
+            for (int b = 0; b < n_steps; b += CB) {
+                KV kv2[CB];
+                int km2[CB];
+                if (b + 2 * CB < n_steps) {
 #pragma unroll
-            for (int q = 0; q < 4; ++q) kv[q] = vp[q * NT], km[q] = mp[q * NT];
-            for (int b = 0; b < n_steps; b += 4) {
-                double2 nv[4];
-                int2 nm[4];
-                if (b + 4 < n_steps) {
-#pragma unroll
-                    for (int q = 0; q < 4; ++q) nv[q] = vp[(b + 4 + q) * NT], nm[q] = mp[(b + 4 + q) * NT];
+                    for (int q = 0; q < CB; ++q) kv2[q] = vp[(b + 2 * CB + q) * NT], km2[q] = mp[(b + 2 * CB + q) * NT];
                 }
+                double2 xb[CB];   // (all of the batch's bins first: behind the conditional stores below every read would wait on its own)
 #pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    double2 xv = Xc[km[q].x & 0x7fffffff];
-                    if (km[q].x < 0) xv.y = -xv.y;   // a column above W/2: X[c] = conj X[W - c]
-                    acc = dadd(acc, dmul(kv[q], xv));
-                    if (km[q].y >= 0) {
-                        parts[km[q].y] = acc;
+                for (int q = 0; q < CB; ++q) xb[q] = Xc[km0[q] & 0x1fff];
+#pragma unroll
+                for (int q = 0; q < CB; ++q) {
+                    double2 xv = xb[q];
+                    if (km0[q] & 0x2000) xv.y = -xv.y;   // a column above W/2: X[c] = conj X[W - c]
+                    if constexpr (REALK) acc = make_double2(fma(kv0[q], xv.x, acc.x), fma(kv0[q], xv.y, acc.y));
+                    else acc = dadd(acc, dmul(kv0[q], xv));
+                    if (km0[q] >> 14) {   // slot + 1 of the partial sum this entry ends
+                        parts[(km0[q] >> 14) - 1] = acc;
                         acc = make_double2(0.0, 0.0);
                     }
                 }
 #pragma unroll
-                for (int q = 0; q < 4; ++q) kv[q] = nv[q], km[q] = nm[q];
+                for (int q = 0; q < CB; ++q) kv0[q] = kv1[q], km0[q] = km1[q], kv1[q] = kv2[q], km1[q] = km2[q];
             }
         }
         lds_barrier();
@@ -1623,18 +1695,37 @@ static hipError_t build_cqt64(zafx_plan& pl) {
     if (!ZAFX_F64_TILED || pl.W != 32768 || rows < 1 || (int)pl.h_values64.size() != pl.nnz || pl.h_indptr.back() != pl.nnz) return hipSuccess;
     const Cqt64Tables t = cqt64_tables(pl.h_indptr.data(), pl.h_indices.data(), reinterpret_cast<const double*>(pl.h_values64.data()), rows, pl.W, kCq64MaxKc2);
     if (!t.ok || (size_t)t.n_cols * 16 + (size_t)t.slots * 16 + (size_t)rows * 8 > (size_t)kCq64Threads / 64 * kF64Pitch * sizeof(double2)) return hipSuccess;
-    std::vector<double2> vals(t.stream.size());
-    std::vector<int2> meta(t.stream.size());
-    for (size_t i = 0; i < t.stream.size(); ++i) vals[i] = make_double2(t.stream[i].re, t.stream[i].im), meta[i] = make_int2(t.stream[i].index, t.stream[i].slot);
+    // real up to round-off?  (then the imaginary parts move the result by less than 1e-13 of it: dropped, 12 bytes per entry instead of 24)
+    double vmax = 0.0, imax = 0.0;
+    for (const Cqt64Entry& en : t.stream) vmax = std::max(vmax, std::fabs(en.re)), imax = std::max(imax, std::fabs(en.im));
+    pl.cqt64_real = imax <= vmax * 0x1p-44;
+    std::vector<double> vals;
+    std::vector<int> meta(t.stream.size());
+    if (t.slots + 1 >= (1 << 17) || t.n_cols > 0x1fff) return hipSuccess;
+    for (size_t i = 0; i < t.stream.size(); ++i) {
+        const Cqt64Entry& en = t.stream[i];
+        vals.push_back(en.re);
+        if (!pl.cqt64_real) vals.push_back(en.im);
+        meta[i] = (en.index & 0x1fff) | (en.index < 0 ? 0x2000 : 0) | ((en.slot + 1) << 14);   // compact index | conjugate << 13 | (slot + 1) << 14
+    }
     auto up = [](auto** d, const void* h, size_t bytes) -> hipError_t {
         if (*d) (void)hipFree(*d);
         *d = nullptr;
         if (hipError_t e = hipMalloc((void**)d, bytes); e != hipSuccess) return e;
         return hipMemcpy(*d, h, bytes, hipMemcpyHostToDevice);
     };
+    std::vector<double2> tw1((size_t)4 * 1024);   // tw1[i][m] = exp(-2 pi i m 2^i / 16384), in long double
+    for (int i = 0; i < 4; ++i)
+        for (int m = 0; m < 1024; ++m) {
+            const long long num = ((long long)m << i) % 16384;
+            const long double a = -2.0L * 3.14159265358979323846264338327950288L * (long double)num / 16384.0L;
+            tw1[(size_t)i * 1024 + m] = num == 0 ? make_double2(1.0, 0.0) : num == 4096 ? make_double2(0.0, -1.0) : num == 8192 ? make_double2(-1.0, 0.0)
+                                        : num == 12288 ? make_double2(0.0, 1.0) : make_double2((double)cosl(a), (double)sinl(a));
+        }
+    if (hipError_t e = up(&pl.d_cqt64_tw1, tw1.data(), tw1.size() * sizeof(double2)); e != hipSuccess) return e;
     if (hipError_t e = up(&pl.d_cqt64_split, t.split.data(), t.split.size() * sizeof(int)); e != hipSuccess) return e;
-    if (hipError_t e = up(&pl.d_cqt64_vals, vals.data(), vals.size() * sizeof(double2)); e != hipSuccess) return e;
-    if (hipError_t e = up(&pl.d_cqt64_meta, meta.data(), meta.size() * sizeof(int2)); e != hipSuccess) return e;
+    if (hipError_t e = up(&pl.d_cqt64_vals, vals.data(), vals.size() * sizeof(double)); e != hipSuccess) return e;
+    if (hipError_t e = up(&pl.d_cqt64_meta, meta.data(), meta.size() * sizeof(int)); e != hipSuccess) return e;
     if (hipError_t e = up(&pl.d_cqt64_fin, t.fin.data(), t.fin.size() * sizeof(int)); e != hipSuccess) return e;
     pl.cqt64_kc2 = t.kc2;
     pl.cqt64_cols = t.n_cols;
@@ -1795,15 +1886,16 @@ hipError_t launch_cqt_f64(zafx_plan& pl, const double* x, double* out, int64_t n
         const int n_groups = (int)std::min<int64_t>(8, n_clips);
         const long long per_group = ((n_clips + n_groups - 1) / n_groups) * (long long)T;   // frames of the longest list
         const int grid = (int)std::min<long long>(std::max(pl.n_cus / n_groups, 1) * (long long)n_groups, per_group * n_groups);
-        const size_t smem = (size_t)(kCq64Threads / 64) * kF64Pitch * sizeof(double2) + 256 * sizeof(double2);
+        const size_t smem = (size_t)(kCq64Threads / 64) * kF64Pitch * sizeof(double2) + (256 + 768) * sizeof(double2);
         const int diff = pl.W - pl.H;
         const int left = diff >= 0 ? (diff + 1) / 2 : -((-diff) / 2);   // ceil((fft_length - step) / 2), zaf.py:615
-        auto kern = pl.cqt64_kc2 <= 1 ? k_cqt_ft_f64<1> : pl.cqt64_kc2 == 2 ? k_cqt_ft_f64<2> : pl.cqt64_kc2 == 3 ? k_cqt_ft_f64<3> : k_cqt_ft_f64<4>;
+        auto kern = pl.cqt64_real ? (pl.cqt64_kc2 <= 1 ? k_cqt_ft_f64<1, true> : pl.cqt64_kc2 == 2 ? k_cqt_ft_f64<2, true> : pl.cqt64_kc2 == 3 ? k_cqt_ft_f64<3, true> : k_cqt_ft_f64<4, true>)
+                                  : (pl.cqt64_kc2 <= 1 ? k_cqt_ft_f64<1, false> : pl.cqt64_kc2 == 2 ? k_cqt_ft_f64<2, false> : pl.cqt64_kc2 == 3 ? k_cqt_ft_f64<3, false> : k_cqt_ft_f64<4, false>);
         const int kc2 = pl.cqt64_kc2 <= 3 ? std::max(pl.cqt64_kc2, 1) : 4;
         if (kc2 != pl.cqt64_kc2) return hipErrorInvalidValue;   // (the split table is laid out for the plan's own count)
         if (hipError_t e = ensure_dynamic_lds(reinterpret_cast<const void*>(kern), pl.device, smem); e != hipSuccess) return e;
         pl.ran = "k_cqt_ft_f64";
-        hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(kCq64Threads), smem, pl.stream, x, pl.d_tws64, pl.d_cqt64_split, pl.d_cqt64_vals, pl.d_cqt64_meta,
+        hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(kCq64Threads), smem, pl.stream, x, pl.d_tws64, pl.d_cqt64_tw1, pl.d_cqt64_split, pl.d_cqt64_vals, pl.d_cqt64_meta,
                            pl.d_cqt64_fin, out, (long long)n_samples, pl.H, left, T, (int)row_pitch(pl, T), (int)n_clips, n_groups, pl.prm.n_bins,
                            pl.kind == ZAFX_CHROMA ? pl.prm.octave_resolution : 0, pl.layout, pl.cqt64_cols, pl.cqt64_steps, pl.cqt64_slots, pl.cqt64_max_parts);
         return hipGetLastError();

@@ -161,12 +161,13 @@ struct zafx_plan {
     bool mel64_ok = false;
     double2* d_values64 = nullptr; // CQT kernel values of a float64 plan (complex128)
     // k_cqt_ft_f64 (fft_length 32768; build_cqt64 in zafx_f64.hip, zafx_cqt64.hpp)
+    double2* d_cqt64_tw1 = nullptr;     // [4][1024]: exp(-2 pi i m 2^i / 16384), the first pass's twiddles (products of these)
     int* d_cqt64_split = nullptr;       // [2 rounds][kc2][512]: the one-sided bins a thread splits (bin | compact index << 14, -1: none)
-    double2* d_cqt64_vals = nullptr;    // [steps][512]: the matrix's non-zeros as one stream per thread ...
-    int2* d_cqt64_meta = nullptr;       // ... {compact index | conjugate << 31, slot of the partial sum or -1}
+    double* d_cqt64_vals = nullptr;     // [steps][512] float64 (cqt64_real) or complex128: the matrix's non-zeros as one stream per thread ...
+    int* d_cqt64_meta = nullptr;        // ... compact index | conjugate << 13 | (slot of the partial sum + 1) << 14
     int2* d_cqt64_fin = nullptr;        // [rows]: {first slot, slots}
     int cqt64_kc2 = 0, cqt64_cols = 0, cqt64_steps = 0, cqt64_slots = 0, cqt64_max_parts = 0;
-    bool cqt64_ok = false, cqt64_dirty = true;
+    bool cqt64_ok = false, cqt64_dirty = true, cqt64_real = false;
     int bs_log2m = 0;              // > 0: window that is not a power of two -- Bluestein convolution length 2^bs_log2m (zafx_f64.hip, zafx_bs32.hip)
     mutable int call_pcm = 0;      // set by zafx_execute_pcm around a launch whose kernel reads int16 itself (1 mono, 2 stereo; pcm_direct_ok)
     void* d_pcm_float = nullptr;   // zafx_execute_pcm's float32 staging for the kinds that do not (grow-only)

@@ -248,3 +248,38 @@ def test_signal_in_float64(zafx, consts, name):
     assert np.all(np.abs(got - s).max(axis=1)[live] <= 1e-9 * rows[live])
     assert relerr(zafx.istft_batch(s[None], ham, sig.HOP, f64=True)[0], orc.istft(s, ham, sig.HOP)) <= 1e-12
     assert relerr(zafx.imdct_batch(m[None], kbd, f64=True)[0], orc.imdct(m, kbd)) <= 1e-12
+
+
+@pytest.mark.parametrize("name", sig.NAMES)
+def test_signal_in_float64_mel_mfcc_cqt(zafx, consts, name):
+    """melspectrogram / mfcc / cqtspectrogram / cqtchromagram in float64 (k_mel_ft8_f64, k_cqt_ft_f64) on the same signals: 1e-12 normwise for the
+    linear outputs, and the MFCCs -- the outputs float32 cannot hold on tonal material (module docstring; the chirp: 1.9e-4) -- to 1e-10 with NO
+    floor (measured: chirp 2.8e-13, DC 1.5e-14, every other signal below 1.1e-14) wherever the reference's own coefficients are reproducible at
+    all.  They are not for a full-scale tone exactly on a bin: its far bands, at 1e-26 of the peak, hold nothing but the round-off of the
+    reference's own transform -- any second float64 program (NumPy's FFT called on the whole batch instead of frame by frame is one) moves those
+    coefficients by some 1e-9 (measured here: 7.1e-9) --, so that one signal is held to the same interval arithmetic as in float32 with
+    float64's epsilon, asserted."""
+    ham, kbd, fb, ck = consts
+    x64 = sig.signal(name, N_LONG).astype(np.float64)
+    xq64 = sig.signal(name, sig.N_CQT * 3).astype(np.float64)
+    mel = zafx.melspectrogram_batch(x64[None], ham, sig.HOP, fb, f64=True)[0]
+    assert zafx.mel_plan(ham, sig.HOP, fb, f64=True).last_kernel == "k_mel_ft8_f64"
+    cep = zafx.mfcc_batch(x64[None], ham, sig.HOP, fb, 20, f64=True)[0]
+    cq = zafx.cqtspectrogram_batch(xq64[None], sig.FS, 25, ck, f64=True)[0]
+    assert zafx.cqt_plan(sig.FS, 25, ck, f64=True).last_kernel == "k_cqt_ft_f64"
+    ch = zafx.cqtchromagram_batch(xq64[None], sig.FS, 25, 24, ck, f64=True)[0]
+    if name == "silence":
+        assert not np.any(mel) and not np.any(cq) and not np.any(ch)
+        assert np.abs(cep).max() <= 64 * np.finfo(float).eps * 36.05 * np.sqrt(128.0)   # DCT rows 1..20 of 128 equal levels log(eps)
+        return
+    ref_mel, ref_cep = orc.melspectrogram(x64, ham, sig.HOP, fb), orc.mfcc(x64, ham, sig.HOP, fb, 20)
+    ref_cq, ref_ch = orc.cqtspectrogram(xq64, sig.FS, 25, ck), orc.cqtchromagram(xq64, sig.FS, 25, 24, ck)
+    assert relerr(mel, ref_mel) <= 1e-12 and relerr(cq, ref_cq) <= 1e-12 and relerr(ch, ref_ch) <= 1e-12
+    g = relerr(cep, ref_cep)
+    _report[f"{name}_f64.mfcc"] = {"normwise": g}
+    if name == "sine_bin":
+        half = orc.stft(x64, ham, sig.HOP)[: sig.W // 2 + 1]
+        fl = mfcc_floor(half, fb.toarray(), 20, C_FLOOR, float(np.finfo(float).eps))
+        assert excess(cep, ref_cep, fl) <= 1.0, (name, g)
+    else:
+        assert g <= 1e-10, (name, g)

@@ -47,9 +47,10 @@ FS, W, H = 44100, 2048, 1024
 HBM_PEAK_GBS = 8000.0      # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 HBM_ACHIEVABLE_GBS = 6290.0   # same guide: measured-achievable copy rate
 F32_PEAK_TFLOPS = 157.3    # dense f32 vector / f32-input MFMA peak
+F64_PEAK_TFLOPS = 78.6     # float64 vector: half the f32 vector rate (v_fma_f64 issues every 4 cycles per wave: 256 CUs x 4 SIMDs x 32 FLOP/clk x 2.4 GHz; the guide lists no f64 row)
 PLACEMENT_SURVEY = 6       # further allocations of the headline's row-strided output probed AFTER every timed region (reported, never timed)
 CONFIG_KINDS = ("istft", "mel", "mfcc", "mdct", "imdct", "cqt")   # SURVEY 8(a) a2 + BASELINE configs 3, 4, 5 (config 2 = the headline)
-EXTRA_KINDS = ("stft1", "stftmag", "istft1", "stft_offgrid", "mdct_offgrid", "stft4096", "stft4096_h1024", "istft4096", "mdct4096", "mel4096", "dct", "stft64", "mdct64", "istft_offgrid", "imdct_offgrid", "stftmag_offgrid", "stft8192", "mdct8192", "istft64", "imdct64")   # one-sided pair (8f rank 4) and geometries off the benchmark's grid
+EXTRA_KINDS = ("stft1", "stftmag", "istft1", "stft_offgrid", "mdct_offgrid", "stft4096", "stft4096_h1024", "istft4096", "mdct4096", "mel4096", "dct", "stft64", "mdct64", "istft_offgrid", "imdct_offgrid", "stftmag_offgrid", "stft8192", "mdct8192", "istft64", "imdct64", "mel64", "mfcc64", "cqt64")   # one-sided pair (8f rank 4) and geometries off the benchmark's grid
 
 
 def synth(seed, c, n):
@@ -90,7 +91,9 @@ def make_workload(kind, device, layout="FT"):
         B, N, T = 1024, 1323000, 750   # BASELINE config 5: 8192 clips x 30 s over 8 GPUs = 1024 per GPU
     if kind == "dct":
         B, N, T = 16384, 1024, 1
-    if kind in ("stft64", "mdct64", "istft64", "imdct64"):
+    if kind == "cqt64":
+        B, N, T = 256, 1323000, 750   # float64 clips of 30 s are 10.6 MB: a quarter of a GPU's share of config 5 (2.7 GB), same frames per clip
+    if kind in ("stft64", "mdct64", "istft64", "imdct64", "mel64", "mfcc64"):
         B = 1024                  # the reference's own dtype (zaf.py:128, :139: float64 in, complex128 out): 40.1 / 16 B per sample
     if kind in ("stft_offgrid", "istft_offgrid", "stftmag_offgrid"):
         N, T = 442024, 433        # one more frame than config 2: rows of 433 complex64 = 3464 B, off the 128-byte grid
@@ -182,6 +185,21 @@ def make_workload(kind, device, layout="FT"):
             plan = zafx.mdct_plan(kbd, device=device, inverse=True, f64=True)
             wl.update(plan=plan, d_in=d_s, n_in=T, bytes_per_launch=B * (8 * (W // 2) * T + 8 * ((W // 2) * (T - 1) - 1)),
                       desc="Batched IMDCT in float64 of the device MDCT of the same batch: 1024 clips x 432 frames, KBD win=2048")
+    elif kind in ("mel64", "mfcc64"):   # melspectrogram / mfcc in the reference's dtype on the tiled structure (k_mel_ft8_f64)
+        d_x.free()
+        d_x = replicate64(base, B, device)
+        fb = zafx.melfilterbank(FS, W, 128)
+        rows = 128 if kind == "mel64" else 20
+        plan = zafx.mel_plan(ham, H, fb, None if kind == "mel64" else 20, device=device, f64=True)
+        wl.update(plan=plan, d_in=d_x, n_in=N, bytes_per_launch=B * (8 * N + 8 * rows * T),
+                  desc=f"Fused {kind[:-2]} in float64: 1024 clips x 10 s, win=2048 hop=1024, 128 mel filters" + (", 20 coefficients" if kind == "mfcc64" else ""))
+    elif kind == "cqt64":   # k_cqt_ft_f64
+        d_x.free()
+        d_x = replicate64(base, B, device)
+        plan = zafx.cqt_plan(FS, 25, zafx.cqtkernel(FS, 24, 55, 3520), device=device, f64=True)
+        wl.update(plan=plan, d_in=d_x, n_in=N, bytes_per_launch=B * (8 * N + 8 * 144 * T),
+                  valu_flops=B * T * 5.0 * 32768 * 15, valu_flops_real_input=B * T * 5.0 * 16384 * 14,
+                  desc="cqtspectrogram in float64: 256 clips x 30 s @ 44.1 kHz, 24 bins/octave 55-3520 Hz, 25 frames/s")
     elif kind == "stft1":   # one-sided output (rows 0..W/2), not the headline
         plan = zafx.stft_plan(ham, H, layout=layout, device=device, onesided=True)
         wl.update(plan=plan, d_in=d_x, n_in=N, bytes_per_launch=B * (4 * N + 8 * (W // 2 + 1) * T),
@@ -460,10 +478,10 @@ def parity_probe(wl):
         ref = orc.mdct(x64, kbd)
     elif kind in ("imdct", "imdct_offgrid"):
         ref = None
-    elif kind in ("mel", "mfcc"):
+    elif kind in ("mel", "mfcc", "mel64", "mfcc64"):
         fb = orc.melfilterbank(FS, W, 128)
-        ref = orc.melspectrogram(x64, ham, H, fb) if kind == "mel" else orc.mfcc(x64, ham, H, fb, 20)
-    elif kind == "cqt":
+        ref = orc.melspectrogram(x64, ham, H, fb) if kind.startswith("mel") else orc.mfcc(x64, ham, H, fb, 20)
+    elif kind in ("cqt", "cqt64"):
         ref = orc.cqtspectrogram(x64, FS, 25, orc.cqtkernel(FS, 24, 55, 3520))
     else:
         return {}
@@ -481,7 +499,7 @@ def parity_probe(wl):
         return out
     got = first if first.shape == ref.shape else first.T
     d = float(np.max(np.abs(got - ref)))
-    tol = 1e-4 if kind in ("mel", "mfcc", "cqt", "mel4096") else 1e-12 if kind.endswith("64") else 1e-5
+    tol = 1e-4 if kind in ("mel", "mfcc", "cqt", "mel4096") else 1e-10 if kind == "mfcc64" else 1e-12 if kind.endswith("64") else 1e-5
     rel = d / float(np.max(np.abs(ref)))
     out.update({"max_abs_err_vs_numpy": d, "max_rel_err_vs_numpy": rel, "tolerance": tol, "within_tolerance": bool(rel <= tol)})
     return out
@@ -642,6 +660,11 @@ def roofline_of(wl, tm, kind):
                      "valu_frac_real_input": round(wl["valu_flops_real_input"] / sec / 1e12 / F32_PEAK_TFLOPS, 4),
                      "algorithmic_flops_per_launch": wl["valu_flops"], "real_input_flops_per_launch": wl["valu_flops_real_input"],
                      "flops": wl["flops_note"], "hbm": {"achieved": round(gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(gbs / HBM_PEAK_GBS, 4)}})
+    elif kind == "cqt64":   # the float64 vector pipe (78.6 TF: MI355X_MICROARCH.md), flops as for cqt
+        tf = wl["valu_flops"] / sec / 1e12
+        roof.update({"bound": "valu", "achieved": round(tf, 2), "peak": F64_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(tf / F64_PEAK_TFLOPS, 4),
+                     "valu_frac_real_input": round(wl["valu_flops_real_input"] / sec / 1e12 / F64_PEAK_TFLOPS, 4),
+                     "hbm": {"achieved": round(gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(gbs / HBM_PEAK_GBS, 4)}})
     elif wl["mfma_flops"]:
         # with the filterbank's zero K-tiles skipped the binding roof is HBM (`frac`); how busy the two
         # arithmetic pipes are is reported beside it, each against its own 157.3 TF peak

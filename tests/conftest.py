@@ -89,17 +89,25 @@ def dct2_rows(m, lo, hi):
     return d
 
 
-def mfcc_floor(spec_ref, fb_dense, ncoef, c, eps):
-    """What an error of `bin_noise` per spectrum bin can do to zaf.mfcc (zaf.py:436-452), by interval arithmetic: the band
-    powers move by FB (2|X| nu + nu^2), the logs by the width of that interval (unbounded relative to a band the
-    reference itself only holds as round-off), the coefficients by sum |D| width, plus the rounding of the DCT's own dot
-    products over the log levels.  (ncoef, T)."""
+def mfcc_floor(spec_ref, fb_dense, ncoef, c, eps, c_bin=3.0):
+    """What float arithmetic of epsilon `eps` can do to zaf.mfcc (zaf.py:436-452) on this very signal.  (ncoef, T).
+
+    Two parts.  (i) The transform's rounding errors land on every bin of a frame at about the same absolute level, c_bin eps sqrt(log2 W)
+    times the RMS of the frame's (two-sided) spectrum -- for a tone that is its peak / sqrt(W / 2), for noise about its level --, independent
+    from bin to bin: the band powers move by the root-sum-square of FB (2 |X| nu + nu^2), the logs by the width of that interval (unbounded
+    relative to a band the reference itself only holds as round-off), the coefficients by the root-sum-square of D width.  (ii) The
+    pipeline's own roundings behind the transform -- band sums, logarithms, the DCT's dot products over the log levels --, c eps each,
+    summed linearly.  Round 6: (i) used to be c eps of the frame's PEAK on every bin, summed linearly through filterbank and DCT -- a bound
+    1e3 times above the measured errors on tones off the bin grid; now the worst measured coefficient of a signal sits at 0.13 (tones off
+    the grid) ... 0.65 (tone on a bin) of it: `error_over_floor` in the report of tests/test_gpu_signals.py."""
+    w = 2 * (spec_ref.shape[0] - 1)
     mag = np.abs(spec_ref[1:fb_dense.shape[1] + 1])
-    nu = bin_noise(spec_ref, c, eps)
+    two_sided = np.concatenate([np.abs(spec_ref) ** 2, np.abs(spec_ref[-2:0:-1]) ** 2], axis=0)
+    nu = c_bin * eps * np.sqrt(np.log2(w)) * np.sqrt(two_sided.mean(axis=0, keepdims=True))
     band = fb_dense @ (mag ** 2)
-    dband = fb_dense @ (2.0 * mag * nu + nu ** 2) + c * eps * band
+    dband = np.sqrt((fb_dense ** 2) @ ((2.0 * mag * nu + nu ** 2) ** 2)) + c * eps * band
     e = np.finfo(float).eps
     logref = np.log(band + e)
     width = np.maximum(np.log(band + dband + e) - logref, logref - np.log(np.maximum(band - dband, 0.0) + e))
     d = np.abs(dct2_rows(fb_dense.shape[0], 1, ncoef + 1))
-    return d @ width + c * eps * (d @ np.abs(logref))
+    return 1.5 * np.sqrt((d ** 2) @ (width ** 2)) + c * eps * (d @ np.abs(logref))   # (1.5: the widths of neighbouring floor-level bands are not independent)

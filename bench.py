@@ -49,7 +49,7 @@ HBM_ACHIEVABLE_GBS = 6290.0   # same guide: measured-achievable copy rate
 F32_PEAK_TFLOPS = 157.3    # dense f32 vector / f32-input MFMA peak
 F64_PEAK_TFLOPS = 78.6     # float64 vector: half the f32 vector rate (v_fma_f64 issues every 4 cycles per wave: 256 CUs x 4 SIMDs x 32 FLOP/clk x 2.4 GHz; the guide lists no f64 row)
 PLACEMENT_SURVEY = 6       # further allocations of the headline's row-strided output probed AFTER every timed region (reported, never timed)
-CONFIG_KINDS = ("istft", "mel", "mfcc", "mdct", "imdct", "cqt")   # SURVEY 8(a) a2 + BASELINE configs 3, 4, 5 (config 2 = the headline)
+CONFIG_KINDS = ("istft", "mel", "mfcc", "mel_mfcc", "mdct", "imdct", "cqt")   # SURVEY 8(a) a2 + BASELINE configs 3 (mel_mfcc: in one pass), 4, 5 (config 2 = the headline)
 EXTRA_KINDS = ("stft1", "stftmag", "istft1", "stft_offgrid", "mdct_offgrid", "stft4096", "stft4096_h1024", "istft4096", "mdct4096", "mel4096", "dct", "stft64", "mdct64", "istft_offgrid", "imdct_offgrid", "stftmag_offgrid", "stft8192", "mdct8192", "istft64", "imdct64", "mel64", "mfcc64", "cqt64")   # one-sided pair (8f rank 4) and geometries off the benchmark's grid
 
 
@@ -246,24 +246,26 @@ def make_workload(kind, device, layout="FT"):
         plan = zafx.mdct_plan(kbd, device=device, inverse=True)
         wl.update(plan=plan, d_in=d_m, n_in=T, bytes_per_launch=B * (4 * (W // 2) * T + 4 * ((W // 2) * (T - 1) - 1)),
                   desc=f"Batched IMDCT of the device MDCT of the same batch: 1024 clips x {T} frames, KBD win=2048" + (" (rows off the 128-byte grid)" if T % 32 else ""))
-    elif kind in ("mel", "mfcc"):
+    elif kind in ("mel", "mfcc", "mel_mfcc"):   # mel_mfcc: BASELINE config 3 as written ("melspectrogram + mfcc: same batch") from ONE set of transforms
         fb = zafx.melfilterbank(FS, W, 128)
-        rows = 128 if kind == "mel" else 20
-        plan = zafx.mel_plan(ham, H, fb, None if kind == "mel" else 20, device=device)
+        rows = 128 if kind == "mel" else 20 if kind == "mfcc" else 148
+        plan = zafx.mel_plan(ham, H, fb, None if kind == "mel" else 20, device=device, also_mel=kind == "mel_mfcc")
         tiles = B * ((T + 15) // 16)
         # the arithmetic the kernel's real-input form executes per frame on the vector pipe: one W/2-point complex transform
         # (5 (W/2) log2(W/2)), the window (W), the split of the packed spectrum (8 per bin) and the levels (3 per bin)
         valu = B * T * (5.0 * (W // 2) * 10 + W + 11.0 * (W // 2))
         steps, per_tile = issued_mfma_flops_per_tile(fb.toarray())
-        mfma = per_tile * tiles
-        if kind == "mfcc":
+        mfma = per_tile * tiles * (2 if kind == "mel_mfcc" else 1)   # (one pass: every K-step issues two matrix instructions, |X|^2 and |X|)
+        steps *= 2 if kind == "mel_mfcc" else 1
+        if kind != "mel":
             dsteps, dper = issued_mfma_flops_per_tile(zafx.dct2_rows(128, 20))
             steps, mfma = steps + dsteps, mfma + dper * tiles
         wl.update(plan=plan, d_in=d_x, n_in=N, bytes_per_launch=B * (4 * N + 4 * rows * T), valu_flops=valu, mfma_flops=mfma,
                   flops_note=f"vector pipe: W/2-point complex FFT + window + split + levels per frame = {valu / 1e9:.1f} GFLOP (the complex form the "
                              f"reference runs, 5 W log2 W: {B * T * 5.0 * W * 11 / 1e9:.1f}); matrix cores: {steps} issued 16x16x4 f32 K-steps per 16-frame "
                              f"tile = {mfma / 1e9:.1f} GFLOP (a dense filterbank GEMM would be {2.0 * 128 * 1024 * T * B / 1e9:.0f})",
-                  desc=f"Fused {kind}: 1024 clips x 10 s, win=2048 hop=1024, 128 mel filters" + (", 20 coefficients" if kind == "mfcc" else ""))
+                  desc=(f"Fused {kind}: 1024 clips x 10 s, win=2048 hop=1024, 128 mel filters" + (", 20 coefficients" if kind == "mfcc" else "")) if kind != "mel_mfcc" else
+                       "melspectrogram + mfcc of the same batch in ONE pass (one set of transforms, rows 0..127 mel, 128..147 mfcc): 1024 clips x 10 s, win=2048 hop=1024, 128 mel filters, 20 coefficients")
     elif kind == "cqt":
         ck = zafx.cqtkernel(FS, 24, 55, 3520)
         plan = zafx.cqt_plan(FS, 25, ck, device=device)
@@ -355,8 +357,10 @@ def _oracle_call(kind):
     if kind == "istft":
         spec = [orc.stft(c, ham, H) for c in clips]
         return (lambda i: orc.istft(spec[i], ham, H)), n, "zaf.py:214-241"
-    if kind in ("mel", "mfcc"):
+    if kind in ("mel", "mfcc", "mel_mfcc"):
         fb = orc.melfilterbank(FS, W, 128)
+        if kind == "mel_mfcc":   # what a zaf.py user runs for both: the two functions, one after the other (each with its own stft)
+            return (lambda i: (orc.melspectrogram(clips[i], ham, H, fb), orc.mfcc(clips[i], ham, H, fb, 20))), n, "zaf.py:369-373 + :436-452"
         if kind == "mel":
             return (lambda i: orc.melspectrogram(clips[i], ham, H, fb)), n, "zaf.py:369-373"
         return (lambda i: orc.mfcc(clips[i], ham, H, fb, 20)), n, "zaf.py:436-452"
@@ -478,6 +482,13 @@ def parity_probe(wl):
         ref = orc.mdct(x64, kbd)
     elif kind in ("imdct", "imdct_offgrid"):
         ref = None
+    elif kind == "mel_mfcc":   # both outputs, each against its own reference (the worse of the two is reported)
+        fb = orc.melfilterbank(FS, W, 128)
+        refs = (orc.melspectrogram(x64, ham, H, fb), orc.mfcc(x64, ham, H, fb, 20))
+        first, last = wl["d_out"].download(0, 1)[0], wl["d_out"].download(B - 8, 1)[0]
+        rels = [float(np.max(np.abs(g - r)) / np.max(np.abs(r))) for g, r in ((first[:128], refs[0]), (first[128:], refs[1]))]
+        return {"replicas_bit_identical": bool(np.array_equal(first, last)), "max_rel_err_vs_numpy": max(rels), "max_rel_err_mel": rels[0], "max_rel_err_mfcc": rels[1],
+                "tolerance": 1e-4, "within_tolerance": bool(max(rels) <= 1e-4)}
     elif kind in ("mel", "mfcc", "mel64", "mfcc64"):
         fb = orc.melfilterbank(FS, W, 128)
         ref = orc.melspectrogram(x64, ham, H, fb) if kind.startswith("mel") else orc.mfcc(x64, ham, H, fb, 20)

@@ -58,7 +58,7 @@ enum zafx_kind {
     ZAFX_MDCT = 3,   /* in (B, N) f32            -> out (B, W/2, T) f32 [FT] or (B, T, W/2) [TF]   */
     ZAFX_IMDCT = 4,  /* in (B, W/2, T)/(B,T,W/2) -> out (B, (W/2)*(T-1) - 1) f32                   */
     ZAFX_MEL = 5,    /* in (B, N) f32            -> out (B, n_filters, T) or (B, T, n_filters)     */
-    ZAFX_MFCC = 6,   /* in (B, N) f32            -> out (B, n_coefs, T)   or (B, T, n_coefs)       */
+    ZAFX_MFCC = 6,   /* in (B, N) f32            -> out (B, n_coefs, T)   or (B, T, n_coefs)  (with_mel: n_filters + n_coefs rows) */
     ZAFX_CQT = 7,    /* in (B, N) f32            -> out (B, n_bins, T)    or (B, T, n_bins)        */
     ZAFX_CHROMA = 8, /* in (B, N) f32            -> out (B, octave_resolution, T) or transposed    */
     ZAFX_LINEAR = 9, /* in (B, window_length) f32 -> out (B, n_filters) f32: y = M x per clip (a caller's own dense
@@ -127,7 +127,11 @@ typedef struct zafx_params {
                                   <= 1024.  The padding elements are never written (forward) nor used (inverse).     */
     int32_t transform_type;    /* ZAFX_DCT: 1, 2, 3 or 4 (dct_type / dst_type of zaf.py:703, :842)                    */
     int32_t transform_sine;    /* ZAFX_DCT: 0 = zaf.dct, 1 = zaf.dst                                                */
-    int32_t reserved[2];
+    int32_t with_mel;          /* ZAFX_MFCC, float32, window_length 2048, <= 128 filters, <= 32 coefficients: 1 = the melspectrogram of the SAME
+                                  transforms rides along (zaf.melspectrogram and zaf.mfcc both start with zaf.stft, zaf.py:369 / :436; BASELINE
+                                  config 3 in one pass: k_mel2 MODE 4).  Output = n_filters + n_coefs rows per clip: rows 0 .. n_filters - 1 the
+                                  melspectrogram, the rest the MFCCs -- both bit-identical to the single-output plans' results           */
+    int32_t reserved[1];
 } zafx_params;
 
 /* ---- library / device ------------------------------------------------------------ */

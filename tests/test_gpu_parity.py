@@ -480,6 +480,81 @@ def test_full_batch_mel_mfcc_device_resident(zafx):
     d_x.free()
 
 
+def test_full_batch_mel_mfcc_one_pass_device_resident(zafx):
+    """BASELINE config 3 as ONE pass (zaf.melspectrogram and zaf.mfcc start with the same zaf.stft, zaf.py:369 / :436): the with_mel form of the
+    mfcc plan (k_mel2 MODE 4) on the 1024-clip batch -- rows 0..127 the melspectrogram, rows 128..147 the MFCCs, both BIT-EQUAL to the
+    single-output plans' results over the whole batch."""
+    B, N, W, H, distinct = 1024, 441000, 2048, 1024, 8
+    base = np.stack([synth_clip(0, c, N) for c in range(distinct)])
+    d_x = _replicated_on_device(zafx, base, B)
+    ham, fb = zafx.hamming(W), zafx.melfilterbank(44100, W, 128)
+    singles = []
+    for ncoef in (None, 20):
+        plan = zafx.mel_plan(ham, H, fb, ncoef)
+        d_out = zafx.DeviceBuffer(plan.out_shape(B, N), np.float32)
+        plan.execute(d_x, d_out, B, N)
+        plan.sync()
+        singles.append(d_out.download())
+        d_out.free()
+    both = zafx.mel_plan(ham, H, fb, 20, also_mel=True)
+    assert both.out_shape(B, N) == (B, 148, 432)
+    d_out = zafx.DeviceBuffer(both.out_shape(B, N), np.float32)
+    both.execute(d_x, d_out, B, N)
+    both.sync()
+    assert both.last_kernel == "k_mel2"
+    got = d_out.download()
+    assert np.array_equal(got[:, :128], singles[0]) and np.array_equal(got[:, 128:], singles[1])
+    d_out.free()
+    d_x.free()
+
+
+@pytest.mark.parametrize("hop,n,clips,nmel,ncoef", [(1024, 100000, 3, 128, 20), (512, 30001, 2, 128, 13), (777, 20000, 2, 40, 32), (1024, 1, 2, 64, 20),
+                                                     (2048, 50000, 5, 13, 12)])
+def test_mel_mfcc_one_pass(zafx, hop, n, clips, nmel, ncoef):
+    """mel_mfcc_batch: both outputs bit-equal to melspectrogram_batch / mfcc_batch (and so within 1e-4 of the reference), whole tiles, edge
+    tiles, odd hops and lengths (the unaligned form), filterbanks whose blocks are cut in several parts, both layouts, padded rows, int16 PCM
+    in the kernel's loads (mono and stereo); geometries outside the one-pass kernel run the two plans."""
+    x = np.stack([synth_clip(59, c % 7, n) for c in range(clips)])
+    w = zafx.hamming(2048)
+    fb = zafx.melfilterbank(44100, 2048, nmel)
+    assert zafx.mel_mfcc_supported(2048, nmel, ncoef)
+    for layout in ("FT", "TF"):
+        mel, cep = zafx.mel_mfcc_batch(x, w, hop, fb, ncoef, layout=layout)
+        assert zafx.mel_plan(w, hop, fb, ncoef, layout=layout, also_mel=True).last_kernel == "k_mel2"
+        assert np.array_equal(mel, zafx.melspectrogram_batch(x, w, hop, fb, layout=layout))
+        assert np.array_equal(cep, zafx.mfcc_batch(x, w, hop, fb, ncoef, layout=layout))
+    for c in range(clips):
+        x64 = x[c].astype(np.float64)
+        assert relerr(mel[c].T, orc.melspectrogram(x64, w, hop, fb)) <= TOL_FB and relerr(cep[c].T, orc.mfcc(x64, w, hop, fb, ncoef)) <= TOL_FB
+    # padded rows through the plan interface
+    pl = zafx.mel_plan(w, hop, fb, ncoef, row_align=32, also_mel=True)
+    got = pl.run_host(x, n)
+    mel_ft, cep_ft = zafx.mel_mfcc_batch(x, w, hop, fb, ncoef)
+    assert np.array_equal(got[:, :nmel], mel_ft) and np.array_equal(got[:, nmel:], cep_ft)
+    # int16 PCM, one and two channels
+    pcm = np.clip(np.rint(x * 3000.0), -32768, 32767).astype(np.int16)
+    for p in (pcm[:, :, None], np.stack([pcm, pcm[::-1]], axis=-1)):
+        p = np.ascontiguousarray(p)
+        mel_p, cep_p = zafx.mel_mfcc_pcm_batch(p, w, hop, fb, ncoef)
+        assert np.array_equal(mel_p, zafx.melspectrogram_pcm_batch(p, w, hop, fb)) and np.array_equal(cep_p, zafx.mfcc_pcm_batch(p, w, hop, fb, ncoef))
+
+
+def test_mel_mfcc_outside_the_one_pass_kernel(zafx):
+    """Other windows, more coefficients, float64: mel_mfcc_batch runs the two plans (same results); the plan factory and the C-ABI refuse."""
+    x = np.stack([synth_clip(61, c, 20000) for c in range(2)])
+    for wl, nmel, ncoef, f64 in ((1024, 64, 13, False), (2048, 128, 40, False), (4096, 128, 20, False), (2048, 128, 20, True)):
+        w, fb = zafx.hamming(wl), zafx.melfilterbank(44100, wl, nmel)
+        assert not zafx.mel_mfcc_supported(wl, nmel, ncoef, f64)
+        mel, cep = zafx.mel_mfcc_batch(x, w, wl // 2, fb, ncoef, f64=f64)
+        assert np.array_equal(mel, zafx.melspectrogram_batch(x, w, wl // 2, fb, f64=f64)) and np.array_equal(cep, zafx.mfcc_batch(x, w, wl // 2, fb, ncoef, f64=f64))
+        with pytest.raises(ValueError):
+            zafx.mel_plan(w, wl // 2, fb, ncoef, also_mel=True, f64=f64)
+    with pytest.raises(zafx.ZafxError):
+        zafx.Plan(zafx.MFCC, window_length=1024, step_length=512, n_filters=64, n_coefs=13, with_mel=True)
+    with pytest.raises(zafx.ZafxError):
+        zafx.Plan(zafx.MEL, window_length=2048, step_length=1024, n_filters=64, with_mel=True)
+
+
 def test_full_share_cqt_device_resident(zafx, golden):
     """BASELINE config 5, one GPU's share as bench.py runs it: 1024 clips x 30 s (5.4 GB of input: clips from index 812
     on start beyond 4 GiB).  Clip 0 is the clip of the Q0 golden probes; 8 distinct clips; first, middle and last

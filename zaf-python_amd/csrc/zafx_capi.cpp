@@ -829,6 +829,9 @@ int zafx_plan_create(zafx_plan** out, int device, int kind, const zafx_params* p
             // [n_filters][64] log-mel tile in LDS: 576 rows)
             if (params->n_filters < 1 || (params->precision != ZAFX_PRECISION_F64 && params->n_filters > 576))
                 return bail("n_filters must be in [1, 576] (up to window_length / 2 with ZAFX_PRECISION_F64)");
+            if (params->with_mel != 0 && (params->with_mel != 1 || kind != ZAFX_MFCC || params->precision != ZAFX_PRECISION_F32 || params->window_length != 2048 ||
+                                          params->n_filters > 128 || params->n_coefs > 32))
+                return bail("with_mel (melspectrogram + mfcc in one pass) takes a float32 ZAFX_MFCC plan of window_length 2048, up to 128 filters and up to 32 coefficients");
             if (kind == ZAFX_MFCC && (params->n_coefs < 1 || params->n_coefs > params->n_filters))
                 return bail("n_coefs must be in [1, n_filters]");
             if (params->precision == ZAFX_PRECISION_F64) {
@@ -1235,7 +1238,7 @@ int zafx_plan_out_dims(const zafx_plan* pl, int64_t n_in, int64_t dims[2]) {
             dims[1] = stft_frames(n_in, pl->W, pl->H);
             return 0;
         case ZAFX_MEL: dims[0] = pl->prm.n_filters; dims[1] = stft_frames(n_in, pl->W, pl->H); return 0;
-        case ZAFX_MFCC: dims[0] = pl->prm.n_coefs; dims[1] = stft_frames(n_in, pl->W, pl->H); return 0;
+        case ZAFX_MFCC: dims[0] = pl->prm.n_coefs + (pl->prm.with_mel ? pl->prm.n_filters : 0); dims[1] = stft_frames(n_in, pl->W, pl->H); return 0;
         case ZAFX_ISTFT: dims[0] = std::max<int64_t>(0, n_in * h - (w - h)); dims[1] = 1; return 0;   // zaf.py:217, :236-238
         case ZAFX_MDCT: dims[0] = w / 2; dims[1] = (n_in + h - 1) / h + 1; return 0;                  // zaf.py:1033
         case ZAFX_IMDCT: dims[0] = std::max<int64_t>(0, h * (n_in - 1) - 1); dims[1] = 1; return 0;    // zaf.py:1132, :1182

@@ -574,10 +574,16 @@ __global__ __launch_bounds__(mel_threads(LOG2N, LOG2E), kMelFpb == 8 ? 2 * mel_t
 #ifndef ZAFX_MEL2
 #define ZAFX_MEL2 1
 #endif
+constexpr int kMel2DualPitch = 1057;   // float2 slots per frame buffer of the one-pass mel + mfcc form (MODE 4)
 // MFCC: the levels are |X|^2 (zaf.py:437-439); between the two barriers the owners take log(mel + eps) of their tiles, turn them into B
 // fragments (a 4 x 4 transpose of register index against 16-lane row: two v_permlane swaps) and multiply them with their block's
 // columns of the DCT-II rows (zaf.py:443-452; A fragments resident: 8 registers per owned block); the partial coefficient tiles go through
 // the exchange areas -- free between the barriers -- and 16 x n_coefs threads add them in block order.  Two more barriers per tile.
+// MODE 4 (round 6, BASELINE config 3 in ONE pass: zaf.melspectrogram and zaf.mfcc start with the same stft call, zaf.py:369 and :436): mfcc WITH the
+// melspectrogram of the same transforms.  The levels in LDS are the powers; a K-step of the product issues two matrix instructions on the same
+// A fragment (the filterbank scaled for the powers) -- B = 4 |X|^2 and B = 2 sqrt(4 |X|^2) = 2 (2 |X|): the very v_sqrt_f32 MODE 0 takes, and the
+// factor 2 against MODE 0's fragments is a power of two, so both tiles come out bit for bit as the single-output kernels' -- and an owner stores
+// its mel tile (rows 0 .. n_filters - 1 of the clip's output) before it goes on with log and DCT (rows n_filters ...).
 // MODE 0 mel, 1 mfcc; 2 / 3: the one-sided |X| / |X|^2 spectrogram of the STFT (zaf.py:83; ZAFX_SPECTRUM_MAGNITUDE / _POWER at W = 2048 in
 // the reference layout): the same transforms and levels, and in the product's place the tile's rows 0 .. N leave from the levels in LDS
 // (thread = frame tid & 15 x rows (tid >> 4) + 64 j: 64-byte runs) -- on k_stft_ft16's 8 fat waves these kinds ran at 3.2 TB/s (1.12 ms
@@ -592,17 +598,19 @@ __global__ __launch_bounds__(1024, 1) void k_mel2(const float* __restrict__ x, c
                                                    const float* __restrict__ dct2, const int* __restrict__ owner2, float* __restrict__ out, long long n_samples, int hop,
                                                    int T, int TP, int tiles, int total_tiles, int n_filters, int n_coefs, int layout) {
     using C = FftCfg<10, 4>;
-    constexpr bool MFCC = MODE == 1, SPECM = MODE >= 2, SQUARES = MODE == 1 || MODE == 3;
-    constexpr int N = C::N, P = 64, E = 16, W = 2 * N, NT = 1024, FPB = 16, PITCH = C::PITCH, EXOFF = N / 2;
+    constexpr bool DUAL = MODE == 4, MFCC = MODE == 1 || DUAL, SPECM = MODE == 2 || MODE == 3, SQUARES = MODE == 1 || MODE == 3 || DUAL;
+    // (DUAL: frame buffers 32 slots shorter -- still 2 mod 64 floats apart, the exchange area still holds what the asserts below ask for -- : the 4 KB
+    // make room for the second set of partial tiles; the other modes keep the pitch they were tuned on, and bin 0's slot behind it)
+    constexpr int N = C::N, P = 64, E = 16, W = 2 * N, NT = 1024, FPB = 16, PITCH = DUAL ? kMel2DualPitch : C::PITCH, EXOFF = N / 2;
     constexpr int DCSLOT = 2 * (EXOFF + N / 2 + N / 32) + 8;   // (SPECM) float slot of bin 0's level in a frame buffer: behind the exchange area
-    static_assert(DCSLOT < 2 * PITCH, "bin 0's level fits the frame buffer");   // exchange area: float2 slots EXOFF .. PITCH - 1 of a frame buffer
+    static_assert(!SPECM || DCSLOT < 2 * PITCH, "bin 0's level fits the frame buffer");   // exchange area: float2 slots EXOFF .. PITCH - 1 of a frame buffer
     static_assert(PITCH - EXOFF >= 8 * 63 + 31 + 8 && PITCH - EXOFF >= N / 2 + N / 32, "exchange area holds a round of the first exchange and the staged half spectrum");
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     float2* frames = reinterpret_cast<float2*>(smem_raw);
     float2* tw_l = frames + FPB * PITCH;
     float2* win_s = tw_l + C::TW;
     float2* tws_s = win_s + N;
-    float* xpart = reinterpret_cast<float*>(tws_s + N / 2 + 1);   // kMel2Slots partial tiles of cut blocks
+    float* xpart = reinterpret_cast<float*>(tws_s + N / 2 + 1);   // kMel2Slots partial tiles of cut blocks (DUAL: kMel2Slots more behind them, the mel tiles)
     float* fall = reinterpret_cast<float*>(frames);
     const int tid = threadIdx.x;
     for (int i = tid; i < C::TW; i += NT) tw_l[i] = twp[i];
@@ -868,6 +876,7 @@ __global__ __launch_bounds__(1024, 1) void k_mel2(const float* __restrict__ x, c
     };
     typedef float f32x4v __attribute__((ext_vector_type(4)));
     f32x4v acc[2][2];
+    f32x4v accm[DUAL ? 2 : 1];   // (DUAL) the mel tiles of the wave's items, their two chains already added
     // ---- the wave's items of FB . S for the tile whose levels are in LDS: A fragments from L2, eight steps' operands requested together.
     // (Measured and dropped, profiles/r04_notes.md: fragments requested a chunk or a whole tile ahead, items of <= 24 steps on every
     // wave with the partial tiles through L2, items on eight waves only -- each lost more to registers or to sixteen matrix-instruction
@@ -878,6 +887,8 @@ __global__ __launch_bounds__(1024, 1) void k_mel2(const float* __restrict__ x, c
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
             acc[j][0] = acc[j][1] = f32x4v{0.f, 0.f, 0.f, 0.f};
+            f32x4v am[2] = {f32x4v{0.f, 0.f, 0.f, 0.f}, f32x4v{0.f, 0.f, 0.f, 0.f}};
+            if constexpr (DUAL) accm[j] = am[0];
             const int steps = it_steps[j];
             if (steps <= 0) continue;
             // A fragments: buffer loads, the step in the scalar offset (no 64-bit address per lane and load); B: the levels of LDS at immediate
@@ -896,8 +907,15 @@ __global__ __launch_bounds__(1024, 1) void k_mel2(const float* __restrict__ x, c
                 }
 #pragma unroll
                 for (int u = 0; u < 8; ++u)
-                    if (s0 + u < steps) acc[j][u & 1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[u], b[u], acc[j][u & 1], 0, 0, 0);
+                    if (s0 + u < steps) {
+                        acc[j][u & 1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[u], b[u], acc[j][u & 1], 0, 0, 0);
+                        if constexpr (DUAL) {
+                            const float m2 = __builtin_amdgcn_sqrtf(b[u]);   // 2 |X| (MODE 0's level); twice that against fragments scaled for the powers
+                            am[u & 1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[u], m2 + m2, am[u & 1], 0, 0, 0);
+                        }
+                    }
             }
+            if constexpr (DUAL) accm[j] = am[0] + am[1];   // (MODE 0 adds its two chains in the epilogue: the same sum)
         }
     };
 
@@ -926,6 +944,10 @@ __global__ __launch_bounds__(1024, 1) void k_mel2(const float* __restrict__ x, c
                 float* dst = xpart + ((it_code[j] >> 10) & 3) * 256 + (4 * (lane >> 4)) * 16 + (lane & 15);
 #pragma unroll
                 for (int r = 0; r < 4; ++r) dst[r * 16] = acc[j][0][r] + acc[j][1][r];
+                if constexpr (DUAL) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) dst[kMel2Slots * 256 + r * 16] = accm[j][r];
+                }
             }
         }
     };
@@ -990,6 +1012,22 @@ __global__ __launch_bounds__(1024, 1) void k_mel2(const float* __restrict__ x, c
                 for (int h = 0; h < kMel2Slots; ++h)
                     if (mask & (1 << h)) val[r] += xpart[h * 256 + e];
             }
+            if constexpr (DUAL) {   // the melspectrogram's tile: rows 0 .. n_filters - 1 of the clip's n_filters + n_coefs rows
+                const int t = t0 + (lane & 15), rows = n_filters + n_coefs;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    float vm = accm[j][r];
+                    const int e = (4 * (lane >> 4) + r) * 16 + (lane & 15);
+#pragma unroll
+                    for (int h = 0; h < kMel2Slots; ++h)
+                        if (mask & (1 << h)) vm += xpart[(kMel2Slots + h) * 256 + e];
+                    const int m = 16 * blk + 4 * (lane >> 4) + r;
+                    if (m < n_filters && t < T) {
+                        if (layout == ZAFX_LAYOUT_FT) out[((long long)clip * rows + m) * TP + t] = vm;
+                        else out[((long long)clip * T + t) * rows + m] = vm;
+                    }
+                }
+            }
             if constexpr (MFCC) {
                 const float eps = 2.220446049250313e-16f;   // np.finfo(float).eps (zaf.py:445)
 #pragma unroll
@@ -1033,8 +1071,9 @@ __global__ __launch_bounds__(1024, 1) void k_mel2(const float* __restrict__ x, c
 #pragma unroll
                 for (int bb = 0; bb < 8; ++bb) sum += part[bb];   // (block order: deterministic)
                 if (t < T) {
-                    if (layout == ZAFX_LAYOUT_FT) out[((long long)clip * n_coefs + q) * TP + t] = sum;
-                    else out[((long long)clip * T + t) * n_coefs + q] = sum;
+                    const int rows = DUAL ? n_filters + n_coefs : n_coefs, row = DUAL ? n_filters + q : q;
+                    if (layout == ZAFX_LAYOUT_FT) out[((long long)clip * rows + row) * TP + t] = sum;
+                    else out[((long long)clip * T + t) * rows + row] = sum;
                 }
             }
             lds_barrier();   // the exchange areas are free for the next transforms
@@ -1052,11 +1091,14 @@ static hipError_t run_mel(const zafx_plan& pl, const float* x, float* out, int64
     if constexpr (ZAFX_MEL2 && LOG2N == 10 && LOG2E == 4 && kMelFpb == 16 && kMelThreads == 1024) {
         if (pl.fb.whole_ok && pl.fb.n_waves == 16 && (!mfcc || pl.dct.dct2_ok)) {   // k_mel2: the product of a tile under the transforms of the next
             using C = FftCfg<10, 4>;
-            const size_t smem = (size_t)(16 * C::PITCH + C::TW + C::N + C::N / 2 + 1) * 8 + kMel2Slots * 1024;
+            const bool dual = mfcc && pl.prm.with_mel;
+            const size_t smem = (size_t)(16 * (dual ? kMel2DualPitch : C::PITCH) + C::TW + C::N + C::N / 2 + 1) * 8 + (dual ? 2 : 1) * kMel2Slots * 1024;
             static_assert((size_t)(16 * C::PITCH + C::TW + C::N + C::N / 2 + 1) * 8 + kMel2Slots * 1024 <= (size_t)kMaxLdsBytes, "k_mel2: LDS");
+            static_assert((size_t)(16 * kMel2DualPitch + C::TW + C::N + C::N / 2 + 1) * 8 + 2 * kMel2Slots * 1024 <= (size_t)kMaxLdsBytes, "k_mel2, one-pass mel + mfcc: LDS");
             const int pcm = pl.call_pcm;   // (zafx_execute_pcm: the input is int16, mono or stereo; pcm_direct_ok vouches for the alignment ALIGNED stands for)
             auto k2 = pcm == 1 ? (mfcc ? k_mel2<ALIGNED, 1, 1> : k_mel2<ALIGNED, 0, 1>) : pcm == 2 ? (mfcc ? k_mel2<ALIGNED, 1, 2> : k_mel2<ALIGNED, 0, 2>)
                                                                                                    : (mfcc ? k_mel2<ALIGNED, 1> : k_mel2<ALIGNED, 0>);
+            if (dual) k2 = pcm == 1 ? k_mel2<ALIGNED, 4, 1> : pcm == 2 ? k_mel2<ALIGNED, 4, 2> : k_mel2<ALIGNED, 4>;
             if (hipError_t e = ensure_dynamic_lds(reinterpret_cast<const void*>(k2), pl.device, smem); e != hipSuccess) return e;
             const int tiles2 = (T + 15) / 16;
             const long long total2 = (long long)tiles2 * n_clips;
@@ -1067,6 +1109,10 @@ static hipError_t run_mel(const zafx_plan& pl, const float* x, float* out, int64
                                pl.dct.d_owner2, out, (long long)n_samples, pl.H, T, (int)row_pitch(pl, T), tiles2, (int)total2, pl.prm.n_filters, mfcc ? pl.prm.n_coefs : 0, pl.layout);
             return hipGetLastError();
         }
+    }
+    if (mfcc && pl.prm.with_mel) {
+        set_error("ZAFX_MFCC with_mel: the one-pass mel + mfcc kernel takes window_length 2048, up to 128 filters and up to 32 coefficients (run the two plans instead)");
+        return hipErrorInvalidValue;
     }
     // filterbank and DCT fragments resident in registers when the busiest wave's K-steps fit (128 filters at W = 2048: 17 + 4)
     // (a block without non-zeros has no K-step to carry its zero tile: streamed form)

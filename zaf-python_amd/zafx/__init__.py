@@ -8,7 +8,8 @@ Drop-in functions (zaf.py signatures, float64 / complex128 results):
     cqtchromagram, mdct, imdct, dct, dst
 Batched extension ((clips, samples) in, float32 / complex64 out):
     stft_batch, istft_batch, mdct_batch, imdct_batch, melspectrogram_batch, mfcc_batch,
-    cqtspectrogram_batch, cqtchromagram_batch, dct_batch, dst_batch; the same from interleaved int16 / int32 PCM:
+    cqtspectrogram_batch, cqtchromagram_batch, dct_batch, dst_batch, mel_mfcc_batch (melspectrogram + mfcc from one set of transforms);
+    the same from interleaved int16 / int32 PCM:
     stft_pcm_batch, mdct_pcm_batch, melspectrogram_pcm_batch, mfcc_pcm_batch, cqtspectrogram_pcm_batch, cqtchromagram_pcm_batch
 Device-resident API: Plan, DeviceBuffer, Comm, *_plan factories, shard helpers; one process per GPU: launch.Rendezvous,
 spawn_ranks (file rendezvous + self-launcher, no torch.distributed).
@@ -21,7 +22,7 @@ from .core import (Comm, DeviceBuffer, Plan, clear_plan_cache, cqt_plan, cqtchro
                    cqtspectrogram, cqtspectrogram_batch, imdct, imdct_batch, istft, istft_batch, istft_plan, mdct,
                    mdct_batch, mdct_plan, mel_plan, melspectrogram, melspectrogram_batch, mfcc, mfcc_batch, pcm_to_mono, pinned_empty,
                    get_precision, set_precision, stft, stft_batch, stft_pcm_batch, stft_plan, mdct_pcm_batch, melspectrogram_pcm_batch, mfcc_pcm_batch,
-                   cqtspectrogram_pcm_batch, cqtchromagram_pcm_batch)
+                   cqtspectrogram_pcm_batch, cqtchromagram_pcm_batch, mel_mfcc_batch, mel_mfcc_pcm_batch, mel_mfcc_supported)
 from .launch import Rendezvous, rank_env, spawn_ranks
 from .shard import clip_range, run_sharded, shard_sizes
 

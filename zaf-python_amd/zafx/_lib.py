@@ -40,7 +40,8 @@ class ZafxParams(ctypes.Structure):
         ("row_align", ctypes.c_int32),
         ("transform_type", ctypes.c_int32),
         ("transform_sine", ctypes.c_int32),
-        ("reserved", ctypes.c_int32 * 2),
+        ("with_mel", ctypes.c_int32),
+        ("reserved", ctypes.c_int32 * 1),
     ]
 
 

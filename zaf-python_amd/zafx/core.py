@@ -246,7 +246,8 @@ class Plan:
     _FORWARD = (_lib.STFT, _lib.MDCT, _lib.MEL, _lib.MFCC, _lib.CQT, _lib.CHROMA)   # 2-D (frequency x time) outputs
 
     def __init__(self, kind, device=0, window_length=0, step_length=0, layout="FT", n_filters=0, n_coefs=0,
-                 fft_length=0, n_bins=0, octave_resolution=0, onesided=False, f64=False, row_align=0, transform_type=0, transform_sine=False):
+                 fft_length=0, n_bins=0, octave_resolution=0, onesided=False, f64=False, row_align=0, transform_type=0, transform_sine=False,
+                 with_mel=False):
         self.kind = kind
         self.device = int(device)
         self.layout = _LAYOUTS[layout]
@@ -262,6 +263,7 @@ class Plan:
         prm.octave_resolution = int(octave_resolution)
         prm.transform_type = int(transform_type)
         prm.transform_sine = int(bool(transform_sine))
+        prm.with_mel = int(bool(with_mel))
         self.spectrum = _spectrum_of(onesided)
         prm.spectrum = self.spectrum
         prm.precision = _lib.PRECISION_F64 if f64 else _lib.PRECISION_F32
@@ -689,7 +691,9 @@ def _dense_filterbank(mel_filterbank, window_length):
     return fb
 
 
-def mel_plan(window_function, step_length, mel_filterbank, number_coefficients=None, layout="FT", device=0, row_align=0, f64=False):
+def mel_plan(window_function, step_length, mel_filterbank, number_coefficients=None, layout="FT", device=0, row_align=0, f64=False, also_mel=False):
+    """also_mel (with number_coefficients): the one-pass melspectrogram + mfcc plan (zafx_params.with_mel) -- its output holds the melspectrogram's
+    rows, then the MFCCs' (mel_mfcc_batch splits them).  float32, window 2048, up to 128 filters and 32 coefficients: mel_mfcc_supported()."""
     w, h = _as_window(window_function, any_length=True), _as_step(step_length)
     if not hasattr(mel_filterbank, "toarray"):
         raise ValueError("mel_filterbank must be a scipy.sparse matrix (as returned by melfilterbank)")
@@ -710,19 +714,27 @@ def mel_plan(window_function, step_length, mel_filterbank, number_coefficients=N
         raise ValueError(f"melspectrogram / mfcc in float64 (f64=True, or more than 576 filters) take windows of up to 2048 samples or the powers of two 4096 and 8192, got {len(w)}")
     # the cache key hashes the sparse triplet (a few KB), not the dense matrix (1 MB: 1.8 ms per call)
     csr = mel_filterbank.tocsr()
-    key = ("mfcc" if mfcc else "mel", device, len(w), h, _LAYOUTS[layout], ncoef, n_filters, _as_row_align(row_align, layout), bool(f64),
+    also_mel = bool(also_mel)
+    if also_mel and not mel_mfcc_supported(len(w), n_filters, ncoef if mfcc else 0, f64):
+        raise ValueError("also_mel needs number_coefficients <= 32, a float32 plan of window 2048 and up to 128 filters (mel_mfcc_batch runs two plans otherwise)")
+    key = ("mfcc" if mfcc else "mel", device, len(w), h, _LAYOUTS[layout], ncoef, n_filters, _as_row_align(row_align, layout), bool(f64), also_mel,
            _digest(w, csr.data, csr.indices, csr.indptr))
 
     def make():
         fb = _dense_filterbank(mel_filterbank, len(w))
         p = Plan(_lib.MFCC if mfcc else _lib.MEL, device, window_length=len(w), step_length=h, layout=layout,
-                 n_filters=fb.shape[0], n_coefs=ncoef, row_align=row_align, f64=f64)
+                 n_filters=fb.shape[0], n_coefs=ncoef, row_align=row_align, f64=f64, with_mel=also_mel)
         p.set_window(w)
         p.set_mel_filterbank(fb)
         if mfcc:
             p.set_dct(constants.dct2_rows(n_filters, ncoef))
         return p
     return _cached(key, make)
+
+
+def mel_mfcc_supported(window_length, number_filters, number_coefficients, f64=False):
+    """Geometries of the one-pass melspectrogram + mfcc kernel (k_mel2 MODE 4)."""
+    return (not f64) and window_length == 2048 and 1 <= number_filters <= 128 and 1 <= number_coefficients <= min(32, number_filters - 1)
 
 
 def _cqt_f32_max_bins(fft_length):
@@ -893,6 +905,43 @@ def mfcc_batch(clips, window_function, step_length, mel_filterbank, number_coeff
     x = x.astype(plan.in_dtype, copy=False)
     out = _run_host_into(plan, x, x.shape[1], out)
     return out if f64 else out.astype(np.float32, copy=False)
+
+
+def _split_mel_mfcc(both, n_filters, layout):
+    """(mel, mfcc) views of the one-pass plan's output: rows 0 .. n_filters - 1 and the rest (the last axis in the frame-major layout)."""
+    if _LAYOUTS[layout] == _lib.LAYOUT_FT:
+        return both[:, :n_filters], both[:, n_filters:]
+    return both[:, :, :n_filters], both[:, :, n_filters:]
+
+
+def mel_mfcc_batch(clips, window_function, step_length, mel_filterbank, number_coefficients, layout="FT", device=0, f64=False, out=None):
+    """zaf.melspectrogram AND zaf.mfcc of the same clips from ONE set of transforms (both start with the same zaf.stft, zaf.py:369 and :436;
+    BASELINE config 3): (B, N) -> ((B, n_filters, T), (B, number_coefficients, T)), views of one (B, n_filters + number_coefficients, T)
+    array (`out`, when given, is that array); both bit-identical to melspectrogram_batch / mfcc_batch.  Geometries outside the one-pass
+    kernel (mel_mfcc_supported: float32, window 2048, <= 128 filters, <= 32 coefficients) run the two plans."""
+    x = _as_clips(clips, dtype=np.float64 if f64 else np.float32)
+    w = _as_window(window_function, any_length=True)
+    n_filters = mel_filterbank.shape[0] if hasattr(mel_filterbank, "shape") else 0
+    if not mel_mfcc_supported(len(w), n_filters, int(number_coefficients), f64):
+        mel = melspectrogram_batch(x, w, step_length, mel_filterbank, layout, device, f64)
+        cep = mfcc_batch(x, w, step_length, mel_filterbank, number_coefficients, layout, device, f64)
+        if out is None:
+            return mel, cep
+        np.copyto(out, np.concatenate([mel, cep], axis=1 if _LAYOUTS[layout] == _lib.LAYOUT_FT else 2), casting="same_kind")
+        return _split_mel_mfcc(out, n_filters, layout)
+    plan = mel_plan(w, step_length, mel_filterbank, number_coefficients, layout, device, also_mel=True)
+    both = _run_host_into(plan, x, x.shape[1], out)
+    return _split_mel_mfcc(both, n_filters, layout)
+
+
+def mel_mfcc_pcm_batch(pcm, window_function, step_length, mel_filterbank, number_coefficients, layout="FT", device=0, out=None):
+    """mel_mfcc_batch of integer PCM clips (see stft_pcm_batch): int16 read inside the kernel's own loads."""
+    w = _as_window(window_function, any_length=True)
+    n_filters = mel_filterbank.shape[0]
+    if not mel_mfcc_supported(len(w), n_filters, int(number_coefficients)):
+        return mel_mfcc_batch(pcm_to_mono(pcm, device), w, step_length, mel_filterbank, number_coefficients, layout, device, out=out)
+    plan = mel_plan(w, step_length, mel_filterbank, number_coefficients, layout, device, also_mel=True)
+    return _split_mel_mfcc(plan.run_host_pcm(pcm, out=out), n_filters, layout)
 
 
 def cqtspectrogram_batch(clips, sampling_frequency, time_resolution, cqt_kernel, layout="FT", device=0, f64=False, out=None):

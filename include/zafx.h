@@ -144,6 +144,17 @@ int zafx_device_name(int device, char* buf, size_t buflen);
 #define ZAFX_ERROR_OUT_OF_MEMORY 2 /* zafx_alloc: the device has no room (= hipErrorOutOfMemory); other codes are other faults */
 int zafx_alloc(int device, void** dptr, size_t bytes);
 int zafx_free(int device, void* dptr);
+/* The fastest of `n_candidates` allocations of `bytes` for the OUTPUT of `plan` (no reference counterpart).  Where a
+ * multi-GB array lands in physical memory changes the rate of the kernels that write it with a row stride -- the reference layout's
+ * (W, T) spectra of zaf.py:139: the same STFT runs in 1.51 ms into one 7.25 GB allocation and in 1.70 ms into another of the same
+ * process -- and the address is not the caller's to choose, so a long-lived output buffer is picked by trial: all candidates are
+ * allocated (held at once: a freed one would come straight back), zafx_execute(plan, d_in, candidate, n_clips, n_in) is timed on each
+ * (one untimed launch, then `reps`; HIP events on the plan's stream), the best stays in *dptr, the others are freed.
+ * probe_ms: NULL or n_candidates floats (the time per launch of each candidate).  bytes must hold the plan's output for (n_clips,
+ * n_in).  Fewer candidates than asked are tried when the device runs out of memory (at least one).  The C twin of the Python
+ * layer's DeviceBuffer.placed. */
+int zafx_alloc_placed(zafx_plan* plan, void** dptr, size_t bytes, const void* d_in, int64_t n_clips, int64_t n_in, int n_candidates, int reps,
+                      float* probe_ms);
 int zafx_memset(int device, void* dptr, int value, size_t bytes);
 int zafx_h2d(int device, void* dst, const void* src, size_t bytes);
 int zafx_d2h(int device, void* dst, const void* src, size_t bytes);

@@ -555,6 +555,29 @@ def test_mel_mfcc_outside_the_one_pass_kernel(zafx):
         zafx.Plan(zafx.MEL, window_length=2048, step_length=1024, n_filters=64, with_mel=True)
 
 
+def test_alloc_placed_through_the_c_abi(zafx):
+    """zafx_alloc_placed (the C twin of DeviceBuffer.placed): the output buffer of a plan as the fastest of n allocations, every candidate
+    timed by the library with the plan's own kernel; the buffer it returns holds the plan's result; bad arguments fail."""
+    import ctypes
+    from zafx import _lib
+    B, N = 16, 100000
+    x = np.stack([synth_clip(67, c, N) for c in range(B)])
+    w = zafx.hamming(2048)
+    plan = zafx.stft_plan(w, 1024)
+    d_x = zafx.DeviceBuffer.from_host(x)
+    buf, times = zafx.DeviceBuffer.placed_for(plan, d_x, B, N, candidates=3, reps=4)
+    assert len(times) == 3 and all(t > 0 for t in times) and buf.shape == plan.out_shape(B, N)
+    got = buf.download()   # (the probes left the transform of d_x in it)
+    assert np.array_equal(got, zafx.stft_batch(x, w, 1024))
+    buf.free()
+    p = ctypes.c_void_p()
+    lib = _lib.load()
+    assert lib.zafx_alloc_placed(plan.handle, ctypes.byref(p), 16, d_x.ptr, B, N, 2, 1, None) != 0          # too small for the output
+    assert lib.zafx_alloc_placed(plan.handle, ctypes.byref(p), 1 << 20, d_x.ptr, 1, N, 0, 1, None) != 0     # no candidates
+    assert lib.zafx_alloc_placed(None, ctypes.byref(p), 1 << 20, d_x.ptr, 1, N, 1, 1, None) != 0
+    d_x.free()
+
+
 def test_full_share_cqt_device_resident(zafx, golden):
     """BASELINE config 5, one GPU's share as bench.py runs it: 1024 clips x 30 s (5.4 GB of input: clips from index 812
     on start beyond 4 GiB).  Clip 0 is the clip of the Q0 golden probes; 8 distinct clips; first, middle and last

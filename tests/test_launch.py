@@ -147,10 +147,21 @@ def test_rendezvous_directory_is_private_and_stale_files_are_ignored(tmp_path, m
     # ranks with different parent processes (started by hand) meet through an explicit namespace
     monkeypatch.setenv("ZAFX_RDZV_NS", "job42")
     rv = launch.Rendezvous.from_env(timeout=5.0)
-    assert rv.base_ns == "job42." and rv.ns.startswith("job42.") and len(rv.ns) > len("job42.") + 8   # (+ this launch's epoch)
+    # (the key prefix is a fixed-length digest of the name -- ADVICE r5: the name itself made "job42." a prefix of job "job42.5"'s keys, and
+    # close() deletes by prefix)
+    import hashlib
+    tag = lambda name: hashlib.blake2b(name.encode(), digest_size=8).hexdigest() + "."
+    assert rv.base_ns == tag("job42") and rv.ns.startswith(rv.base_ns) and len(rv.ns) > len(rv.base_ns) + 8   # (+ this launch's epoch)
+    monkeypatch.setenv("ZAFX_RDZV_NS", "job42.5")
+    other = launch.Rendezvous.from_env(timeout=5.0)
+    other.put("alive", b"a running job's key")
+    assert not other.base_ns.startswith(rv.base_ns) and not rv.base_ns.startswith(other.base_ns)
+    rv.close()                                    # job42 leaves ...
+    assert other.get("alive") == b"a running job's key"   # ... and job42.5's keys are still there
+    rv = other
     monkeypatch.delenv("ZAFX_RDZV_NS")
     monkeypatch.setenv("TORCHELASTIC_RUN_ID", "run7")
-    assert launch.Rendezvous.from_env(timeout=5.0).base_ns == "run7."
+    assert launch.Rendezvous.from_env(timeout=5.0).base_ns == tag("run7")
     rv.put("secret", b"unique id")
     assert os.stat(d / (rv.ns + "secret")).st_mode & 0o077 == 0   # key files are private whatever the directory allows
 

@@ -464,7 +464,7 @@ ZAFX_HD void regs_read(float2* v, const float2* buf, int p) {
 
 }  // namespace zafx
 
-#if !defined(ZAFX_HOST_EMU)
+#if !defined(ZAFX_HOST_EMU) && defined(__HIPCC__)   // (device code: not for the host-only g++ build of the C-ABI layer, `make asan`)
 namespace zafx {
 
 // Buffer (SRSRC) loads: a wave-uniform 128-bit descriptor in SGPRs + one 32-bit byte offset per lane,

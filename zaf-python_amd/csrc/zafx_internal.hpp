@@ -169,7 +169,6 @@ struct zafx_plan {
     int cqt64_kc2 = 0, cqt64_cols = 0, cqt64_steps = 0, cqt64_slots = 0, cqt64_max_parts = 0;
     bool cqt64_ok = false, cqt64_dirty = true, cqt64_real = false;
     int bs_log2m = 0;              // > 0: window that is not a power of two -- Bluestein convolution length 2^bs_log2m (zafx_f64.hip, zafx_bs32.hip)
-    mutable int call_pcm = 0;      // set by zafx_execute_pcm around a launch whose kernel reads int16 itself (1 mono, 2 stereo; pcm_direct_ok)
     void* d_pcm_float = nullptr;   // zafx_execute_pcm's float32 staging for the kinds that do not (grow-only)
     size_t pcm_float_bytes = 0;
     long long dct_den2 = 0;        // ZAFX_DCT on the chirp-z form: 2 D, the denominator of its chirp exp(-i pi j^2 / (2 D)) (k_dct_bs32)
@@ -265,6 +264,14 @@ int stft_frames_per_block(int log2n, int layout);
 int mdct_frames_per_block(int log2nf, int layout);
 
 void set_error(const std::string& msg);
+
+// zafx_execute_pcm -> launcher hand-off of "the input is int16, this many channels" (1 mono, 2 stereo; 0: float samples).  Per THREAD, not per
+// plan (plans are cached and shared between threads: a field of the plan let a concurrent float execute pick the int16 kernel), set
+// around the one zafx_execute the caller makes.  A launcher that reads int16 itself TAKES the mode (take_pcm_mode); execute_pcm fails hard when
+// nobody took it -- a route that forgot it would feed int16 to a float kernel.
+int take_pcm_mode();           // the calling thread's mode; marks it taken when non-zero
+void set_pcm_mode(int mode);   // (execute_pcm only) also clears the taken mark
+bool pcm_mode_taken();
 
 // Carry kernels (k_istft_ft16, k_imdct): number of segments to cut every clip's tile sequence into so that
 // `grid` persistent workgroups are evenly loaded (1 = whole clips; each extra segment pays one carry-only tile).

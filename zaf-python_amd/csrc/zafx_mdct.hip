@@ -1466,7 +1466,7 @@ static hipError_t run_mdct_p(const zafx_plan& pl, const float* x, float* out, in
     using G = MdctPCfg<LOG2NF, LOG2E>;
     const bool aligned = n_samples % 4 == 0 && reinterpret_cast<uintptr_t>(x) % 16 == 0 && n_samples < (1LL << 28);   // (32-bit byte offsets inside a clip)
     auto kern = aligned ? k_mdct_ft32<LOG2NF, LOG2E, true, G::NSLOT, TFOUT> : k_mdct_ft32<LOG2NF, LOG2E, false, G::NSLOT, TFOUT>;
-    const int pcm = pl.call_pcm;   // (zafx_execute_pcm: int16 in the loads; mdct_pcm_direct_ok vouches for `aligned`, W = 2048 and the reference layout)
+    const int pcm = take_pcm_mode();   // (zafx_execute_pcm: int16 in the loads; mdct_pcm_direct_ok vouches for `aligned`, W = 2048 and the reference layout)
     if constexpr (LOG2NF == 9 && !TFOUT) {
         if (pcm == 1) kern = k_mdct_ft32<LOG2NF, LOG2E, true, G::NSLOT, false, false, 1>;
         if (pcm == 2) kern = k_mdct_ft32<LOG2NF, LOG2E, true, G::NSLOT, false, false, 2>;

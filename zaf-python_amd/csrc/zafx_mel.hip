@@ -1095,7 +1095,7 @@ static hipError_t run_mel(const zafx_plan& pl, const float* x, float* out, int64
             const size_t smem = (size_t)(16 * (dual ? kMel2DualPitch : C::PITCH) + C::TW + C::N + C::N / 2 + 1) * 8 + (dual ? 2 : 1) * kMel2Slots * 1024;
             static_assert((size_t)(16 * C::PITCH + C::TW + C::N + C::N / 2 + 1) * 8 + kMel2Slots * 1024 <= (size_t)kMaxLdsBytes, "k_mel2: LDS");
             static_assert((size_t)(16 * kMel2DualPitch + C::TW + C::N + C::N / 2 + 1) * 8 + 2 * kMel2Slots * 1024 <= (size_t)kMaxLdsBytes, "k_mel2, one-pass mel + mfcc: LDS");
-            const int pcm = pl.call_pcm;   // (zafx_execute_pcm: the input is int16, mono or stereo; pcm_direct_ok vouches for the alignment ALIGNED stands for)
+            const int pcm = take_pcm_mode();   // (zafx_execute_pcm: the input is int16, mono or stereo; pcm_direct_ok vouches for the alignment ALIGNED stands for)
             auto k2 = pcm == 1 ? (mfcc ? k_mel2<ALIGNED, 1, 1> : k_mel2<ALIGNED, 0, 1>) : pcm == 2 ? (mfcc ? k_mel2<ALIGNED, 1, 2> : k_mel2<ALIGNED, 0, 2>)
                                                                                                    : (mfcc ? k_mel2<ALIGNED, 1> : k_mel2<ALIGNED, 0>);
             if (dual) k2 = pcm == 1 ? k_mel2<ALIGNED, 4, 1> : pcm == 2 ? k_mel2<ALIGNED, 4, 2> : k_mel2<ALIGNED, 4>;
@@ -1156,7 +1156,7 @@ bool launch_spec2(const zafx_plan& pl, const float* x, float* out, int64_t n_cli
     if (!ZAFX_SPEC2 || pl.log2nf != 10 || pl.log2e != 4 || pl.layout != ZAFX_LAYOUT_FT || kMelFpb != 16 || kMelThreads != 1024 || !pl.d_tw_pass || !pl.d_tw_aux) return false;
     if (pl.prm.spectrum != ZAFX_SPECTRUM_MAGNITUDE && pl.prm.spectrum != ZAFX_SPECTRUM_POWER) return false;
     if (n_samples >= (1LL << 29)) return false;
-    const int pcm = pl.call_pcm;
+    const int pcm = take_pcm_mode();
     const bool aligned = (n_samples % 2 == 0) && (pl.H % 2 == 0) && (reinterpret_cast<uintptr_t>(x) % 8 == 0);
     const bool power = pl.prm.spectrum == ZAFX_SPECTRUM_POWER;
     auto k2 = aligned ? (power ? k_mel2<true, 3> : k_mel2<true, 2>) : (power ? k_mel2<false, 3> : k_mel2<false, 2>);

@@ -2383,8 +2383,9 @@ static hipError_t run_stft_fat(const zafx_plan& pl, const float* x, float2* out,
     static_assert(F::SMEM <= (size_t)kMaxLdsBytes, "tile + tables exceed LDS");
     auto kern = k_stft_ft16<LOG2N, LOG2E, ALIGNED, SPEC, FPB>;
     if constexpr (LOG2N == 10 && SPEC < 2 && FPB == kFatFrames) {   // (zafx_execute_pcm: int16 in the loads; stft_pcm_direct_ok vouches for the geometry)
-        if (pl.call_pcm == 1) kern = k_stft_ft16<LOG2N, LOG2E, ALIGNED, SPEC, FPB, 1>;
-        if (pl.call_pcm == 2) kern = k_stft_ft16<LOG2N, LOG2E, ALIGNED, SPEC, FPB, 2>;
+        const int pcm = take_pcm_mode();
+        if (pcm == 1) kern = k_stft_ft16<LOG2N, LOG2E, ALIGNED, SPEC, FPB, 1>;
+        if (pcm == 2) kern = k_stft_ft16<LOG2N, LOG2E, ALIGNED, SPEC, FPB, 2>;
     }
     if (hipError_t e = ensure_dynamic_lds(reinterpret_cast<const void*>(kern), pl.device, F::SMEM); e != hipSuccess) return e;
     const int tiles = (T + FPB - 1) / FPB;
@@ -2406,8 +2407,9 @@ static hipError_t run_stft_fat_carry(const zafx_plan& pl, const float* x, float2
         using F = FatCfg<LOG2N, LOG2E>;
         auto kern = k_stft_ft16c<LOG2N, LOG2E, ALIGNED, SPEC>;
         if constexpr (LOG2N == 10 && ALIGNED) {
-            if (pl.call_pcm == 1) kern = k_stft_ft16c<LOG2N, LOG2E, true, SPEC, 1>;
-            if (pl.call_pcm == 2) kern = k_stft_ft16c<LOG2N, LOG2E, true, SPEC, 2>;
+            const int pcm = take_pcm_mode();
+            if (pcm == 1) kern = k_stft_ft16c<LOG2N, LOG2E, true, SPEC, 1>;
+            if (pcm == 2) kern = k_stft_ft16c<LOG2N, LOG2E, true, SPEC, 2>;
         }
         if (hipError_t e = ensure_dynamic_lds(reinterpret_cast<const void*>(kern), pl.device, F::SMEM); e != hipSuccess) return e;
         const int tiles = (T + kFatFrames - 1) / kFatFrames;

@@ -58,6 +58,7 @@ SYMBOLS = {
     "zafx_device_name": (_i, [_i, ctypes.c_char_p, _sz]),
     "zafx_alloc": (_i, [_i, ctypes.POINTER(_vp), _sz]),
     "zafx_free": (_i, [_i, _vp]),
+    "zafx_alloc_placed": (_i, [_vp, ctypes.POINTER(_vp), _sz, _vp, _i64, _i64, _i, _i, ctypes.POINTER(ctypes.c_float)]),
     "zafx_memset": (_i, [_i, _vp, _i, _sz]),
     "zafx_h2d": (_i, [_i, _vp, _vp, _sz]),
     "zafx_d2h": (_i, [_i, _vp, _vp, _sz]),

@@ -203,6 +203,19 @@ class DeviceBuffer:
                 b.free()
         return bufs[best], times
 
+    @classmethod
+    def placed_for(cls, plan, d_in, n_clips, n_in, candidates=4, reps=8):
+        """The output buffer of `plan` for (n_clips, n_in) as the fastest of `candidates` allocations, picked by the library itself
+        (zafx_alloc_placed: every candidate timed with the plan's own kernel on `d_in`): -> (buffer, [ms per launch of each candidate]).
+        The C-ABI twin of `placed` -- what a caller without this Python layer uses."""
+        shape, dtype = plan.out_shape(n_clips, n_in), plan.out_dtype
+        nbytes = int(np.prod(shape, dtype=np.int64)) * dtype.itemsize
+        p = ctypes.c_void_p()
+        times = (ctypes.c_float * int(candidates))()
+        _lib.check(_lib.load().zafx_alloc_placed(plan.handle, ctypes.byref(p), nbytes, d_in.ptr, int(n_clips), int(n_in), int(candidates), int(reps), times),
+                   "zafx_alloc_placed")
+        return cls(shape, dtype, plan.device, _ptr_from_pool=p), [float(t) for t in times]
+
     def free(self):
         if getattr(self, "ptr", None) is not None and self.ptr.value:
             _lib.load().zafx_free(self.device, self.ptr)
@@ -346,12 +359,20 @@ class Plan:
                                                 int(n_channels), d_pcm.dtype.itemsize), "zafx_pcm_to_float")
 
     def execute_pcm(self, d_pcm, d_out, n_clips, n_frames, n_channels=1):
-        """execute() on integer PCM that is already on the device: d_pcm = (clips, frames[, channels]) int16 / int32 interleaved.  mel, mfcc
-        and the |X| / |X|^2 spectrogram kinds at window 2048 read int16 (one or two channels) in their own loads -- 2 bytes per sample and
-        channel of HBM traffic instead of the pre-pass's 6 + 4 --, every other plan converts into a staging array it owns first
-        (zafx_execute_pcm; zaf.py:1202 and :65 either way)."""
-        _lib.check(_lib.load().zafx_execute_pcm(self.handle, d_pcm.ptr, d_out.ptr, int(n_clips), int(n_frames), int(n_channels),
-                                               d_pcm.dtype.itemsize), "zafx_execute_pcm")
+        """execute() on integer PCM that is already on the device: d_pcm = (clips, frames[, channels]) int16 / int32 interleaved.  At window 2048
+        mel, mfcc (and their one-pass form), the complex and the |X| / |X|^2 kinds of the STFT and the MDCT read int16 (one or two channels)
+        in their own loads -- 2 bytes per sample and channel of HBM traffic instead of the pre-pass's 6 + 4 --, every other plan converts,
+        in chunks of clips, into a bounded staging array it owns first (zafx_execute_pcm, include/zafx.h; zaf.py:1202 and :65 either way)."""
+        if d_pcm.dtype not in (np.dtype(np.int16), np.dtype(np.int32)):
+            raise ValueError("execute_pcm takes an int16 or int32 DeviceBuffer (wavread's other dtypes: convert on the host)")
+        n_clips, n_frames, n_channels = int(n_clips), int(n_frames), int(n_channels)
+        if int(np.prod(d_pcm.shape, dtype=np.int64)) < n_clips * n_frames * n_channels:
+            raise ValueError("d_pcm holds fewer than clips x frames x channels samples")
+        if d_out.nbytes < n_clips * self.clip_bytes(n_frames)[1]:
+            raise ValueError("d_out is smaller than the plan's output for these clips")
+        with self.lock:   # (the plan's staging array of the two-step route is shared state)
+            _lib.check(_lib.load().zafx_execute_pcm(self.handle, d_pcm.ptr, d_out.ptr, n_clips, n_frames, n_channels,
+                                                   d_pcm.dtype.itemsize), "zafx_execute_pcm")
 
     def timer_start(self):
         _lib.check(_lib.load().zafx_timer_start(self.handle), "zafx_timer_start")

@@ -13,6 +13,7 @@ Two ways in:
   * plain `python script.py --gpus N` with WORLD_SIZE unset: `spawn_ranks()` starts the N ranks itself
     (environment as above plus ZAFX_RDZV_DIR) and relays rank 0's stdout.
 """
+import hashlib
 import os
 import struct
 import subprocess
@@ -89,7 +90,9 @@ class Rendezvous:
         named = bool(ns) and ns != "none"
         if not named:
             ns = f"{os.getppid()}.{_start_time(os.getppid())}"
-        rv = cls(d, rank, world, timeout, namespace=ns + ".")
+        # the prefix of every key is a fixed-length digest of the name, not the name: "job42." is a prefix of "job42.5.<epoch>.bcast", and
+        # close() deletes by prefix -- one job's close would take a running job's keys with it
+        rv = cls(d, rank, world, timeout, namespace=hashlib.blake2b(ns.encode(), digest_size=8).hexdigest() + ".")
         if named:
             # a NAME comes back with every relaunch (an elastic restart keeps its run id): the keys of a job that died before
             # close() are still there under it, so the ranks first agree on an epoch that only this launch knows

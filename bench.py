@@ -50,7 +50,7 @@ F32_PEAK_TFLOPS = 157.3    # dense f32 vector / f32-input MFMA peak
 F64_PEAK_TFLOPS = 78.6     # float64 vector: half the f32 vector rate (v_fma_f64 issues every 4 cycles per wave: 256 CUs x 4 SIMDs x 32 FLOP/clk x 2.4 GHz; the guide lists no f64 row)
 PLACEMENT_SURVEY = 6       # further allocations of the headline's row-strided output probed AFTER every timed region (reported, never timed)
 CONFIG_KINDS = ("istft", "mel", "mfcc", "mel_mfcc", "mdct", "imdct", "cqt")   # SURVEY 8(a) a2 + BASELINE configs 3 (mel_mfcc: in one pass), 4, 5 (config 2 = the headline)
-EXTRA_KINDS = ("stft1", "stftmag", "istft1", "stft_offgrid", "mdct_offgrid", "stft4096", "stft4096_h1024", "istft4096", "mdct4096", "mel4096", "dct", "stft64", "mdct64", "istft_offgrid", "imdct_offgrid", "stftmag_offgrid", "stft8192", "mdct8192", "istft64", "imdct64", "mel64", "mfcc64", "cqt64")   # one-sided pair (8f rank 4) and geometries off the benchmark's grid
+EXTRA_KINDS = ("stft1", "stftmag", "istft1", "stft_offgrid", "mdct_offgrid", "stft4096", "stft4096_h1024", "istft4096", "mdct4096", "mel4096", "dct", "stft64", "mdct64", "istft_offgrid", "imdct_offgrid", "stftmag_offgrid", "stft8192", "mdct8192", "istft64", "imdct64", "mel64", "mfcc64", "cqt64", "istft_offgrid_compact", "stftmag_offgrid_compact")   # one-sided pair (8f rank 4) and geometries off the benchmark's grid
 
 
 def synth(seed, c, n):
@@ -95,6 +95,8 @@ def make_workload(kind, device, layout="FT"):
         B, N, T = 256, 1323000, 750   # float64 clips of 30 s are 10.6 MB: a quarter of a GPU's share of config 5 (2.7 GB), same frames per clip
     if kind in ("stft64", "mdct64", "istft64", "imdct64", "mel64", "mfcc64"):
         B = 1024                  # the reference's own dtype (zaf.py:128, :139: float64 in, complex128 out): 40.1 / 16 B per sample
+    compact_rows = kind.endswith("_compact")   # istft / stftmag off the grid: the *_batch functions' default (rows padded to 128-byte lines, round 6) and, `_compact`, the reference's own memory order
+    kind = kind[:-len("_compact")] if compact_rows else kind
     if kind in ("stft_offgrid", "istft_offgrid", "stftmag_offgrid"):
         N, T = 442024, 433        # one more frame than config 2: rows of 433 complex64 = 3464 B, off the 128-byte grid
     if kind == "stft4096":
@@ -113,7 +115,9 @@ def make_workload(kind, device, layout="FT"):
     for r in range(B // distinct):
         d_x.copy_from(d_base, dst_offset=r * distinct * N * 4)
     d_base.free()
-    wl = dict(kind=kind, n_clips=B, samples_per_clip=N, base=base, valu_flops=0.0, valu_flops_real_input=0.0, mfma_flops=0.0, flops_note=None, frames=T)
+    wl = dict(kind=kind + ("_compact" if compact_rows else ""), n_clips=B, samples_per_clip=N, base=base, valu_flops=0.0, valu_flops_real_input=0.0, mfma_flops=0.0, flops_note=None, frames=T)
+    pad_c64 = 16 if kind == "istft_offgrid" and not compact_rows else 0      # rows of 433 complex64 -> pitch 448
+    pad_f32 = 32 if kind == "stftmag_offgrid" and not compact_rows else 0    # rows of 433 float32 -> pitch 448
     if kind == "stft":
         plan = zafx.stft_plan(ham, H, layout=layout, device=device)
         wl.update(plan=plan, d_in=d_x, n_in=N, bytes_per_launch=B * (4 * N + 8 * W * T),
@@ -205,9 +209,11 @@ def make_workload(kind, device, layout="FT"):
         wl.update(plan=plan, d_in=d_x, n_in=N, bytes_per_launch=B * (4 * N + 8 * (W // 2 + 1) * T),
                   desc="Batched STFT, one-sided output (W/2+1, T): 1024 clips x 10 s, Hamming win=2048 hop=1024")
     elif kind in ("stftmag", "stftmag_offgrid"):   # the spectrogram the reference's examples compute (zaf.py:83), |X| of rows 0..W/2 as float32 (k_mel2, MODE 2)
-        plan = zafx.stft_plan(ham, H, layout=layout, device=device, onesided="magnitude")
+        plan = zafx.stft_plan(ham, H, layout=layout, device=device, onesided="magnitude", row_align=pad_f32)
         wl.update(plan=plan, d_in=d_x, n_in=N, bytes_per_launch=B * (4 * N + 4 * (W // 2 + 1) * T),
-                  desc=f"Batched magnitude spectrogram |X| (W/2+1, T) float32: 1024 clips x {T} frames, Hamming win=2048 hop=1024")
+                  desc=f"Batched magnitude spectrogram |X| (W/2+1, T) float32: 1024 clips x {T} frames, Hamming win=2048 hop=1024"
+                       + (", device rows padded to 128-byte lines (the *_batch functions' default off the grid; algorithmic bytes of the compact array)" if pad_f32 else
+                          ", compact rows off the 128-byte grid" if T % 32 else ""))
     elif kind == "istft1":
         fwd = zafx.stft_plan(ham, H, device=device, onesided=True)
         d_s = zafx.DeviceBuffer(fwd.out_shape(B, N), np.complex64, device)
@@ -219,15 +225,16 @@ def make_workload(kind, device, layout="FT"):
         wl.update(plan=plan, d_in=d_s, n_in=T, bytes_per_launch=B * (8 * (W // 2 + 1) * T + 4 * (T * H - (W - H))),
                   desc="Batched ISTFT from one-sided spectra: 1024 clips x 432 frames, win=2048 hop=1024")
     elif kind in ("istft", "istft_offgrid"):   # (off the grid: T = 433, rows of 3464 bytes)
-        fwd = zafx.stft_plan(ham, H, device=device)
+        fwd = zafx.stft_plan(ham, H, device=device, row_align=pad_c64)
         d_s = zafx.DeviceBuffer(fwd.out_shape(B, N), np.complex64, device)
         fwd.execute(d_x, d_s, B, N)
         INNER_LOG.append({"kind": None, "kernel": fwd.last_kernel, "launches": 1})
         fwd.sync()
         d_x.free()
-        plan = zafx.istft_plan(ham, H, device=device)
+        plan = zafx.istft_plan(ham, H, device=device, row_align=pad_c64)
         wl.update(plan=plan, d_in=d_s, n_in=T, bytes_per_launch=B * (8 * W * T + 4 * (T * H - (W - H))),
-                  desc=f"Batched ISTFT: 1024 clips x {T} frames, win=2048 hop=1024" + (" (rows off the 128-byte grid)" if T % 16 else ""))
+                  desc=f"Batched ISTFT: 1024 clips x {T} frames, win=2048 hop=1024" + (" (device rows padded to 128-byte lines: the *_batch functions' default off the grid; "
+                       "algorithmic bytes of the compact array)" if pad_c64 else " (compact rows off the 128-byte grid)" if T % 16 else ""))
     elif kind == "mdct":
         plan = zafx.mdct_plan(kbd, device=device)
         wl.update(plan=plan, d_in=d_x, n_in=N, bytes_per_launch=B * (4 * N + 4 * (W // 2) * T),
@@ -458,6 +465,7 @@ def parity_probe(wl):
     NumPy'; SURVEY 8(d) tolerance: 1e-5 stft/istft/mdct/imdct, 1e-4 mel/mfcc/cqt)."""
     from oracle import zaf_oracle as orc
     kind, base, B = wl["kind"], wl["base"], wl["n_clips"]
+    kind = kind[:-len("_compact")] if kind.endswith("_compact") else kind
     ham, kbd = orc.hamming_periodic(W), orc.kbd_window(W)
     x64 = base[0].astype(np.float64)
     if kind in ("stft", "stft1", "stft_offgrid", "stftmag", "stftmag_offgrid", "stft64"):
@@ -508,6 +516,8 @@ def parity_probe(wl):
             e = float(np.max(np.abs(first - refy)) / np.max(np.abs(refy)))
             out.update({"max_rel_err_vs_numpy": e, "within_tolerance": bool(d < tol and e <= (1e-12 if kind.endswith("64") else 1e-5))})
         return out
+    if first.ndim == 2 and first.shape[0] == ref.shape[0] and first.shape[1] > ref.shape[1]:
+        first = first[:, :ref.shape[1]]   # (rows padded to 128-byte lines on the device)
     got = first if first.shape == ref.shape else first.T
     d = float(np.max(np.abs(got - ref)))
     tol = 1e-4 if kind in ("mel", "mfcc", "cqt", "mel4096") else 1e-10 if kind == "mfcc64" else 1e-12 if kind.endswith("64") else 1e-5

@@ -21,9 +21,14 @@ TOL_FB = 1e-4
 
 @pytest.fixture(scope="module")
 def zafx():
+    """The tests of this module name the kernel a geometry must reach (last_kernel): they run the *_batch functions on COMPACT device arrays,
+    the reference's own memory order (set_row_padding("compact")) -- the default since round 6 pads rows off the 128-byte grid, which is
+    test_batch_functions_pad_rows_off_the_line_grid's subject."""
     import zafx as z
     assert z.device_count() >= 1
-    return z
+    z.set_row_padding("compact")
+    yield z
+    z.set_row_padding("auto")
 
 
 def csr(g, tag):
@@ -553,6 +558,47 @@ def test_mel_mfcc_outside_the_one_pass_kernel(zafx):
         zafx.Plan(zafx.MFCC, window_length=1024, step_length=512, n_filters=64, n_coefs=13, with_mel=True)
     with pytest.raises(zafx.ZafxError):
         zafx.Plan(zafx.MEL, window_length=2048, step_length=1024, n_filters=64, with_mel=True)
+
+
+def test_batch_functions_pad_rows_off_the_line_grid(zafx):
+    """The default of the STFT / MDCT *_batch functions (round 6, zafx.set_row_padding("auto")): a frame count off the 128-byte line grid of the
+    (F, T) rows runs on a row-padded device array -- the kernels' on-grid forms -- and the NumPy array handed back is a view of the padded
+    result with the reference's shape, dtype and indexing (a different kernel form than the compact path's: equal within rounding, both
+    within tolerance of the reference); the inverse functions take that view as it lies (no
+    copy) and any other array through a padded copy; `out=`, row_align=0, the frame-major layout and "compact" keep the compact array."""
+    n, hop = 1024 * 36 + 5, 1024           # T = 38: off the grid of 16 complex64 / 32 float32
+    x = np.stack([synth_clip(71, c, n) for c in range(3)])
+    ham, kbd = zafx.hamming(2048), zafx.kaiser_bessel_derived(2048)
+    compact = {"stft": zafx.stft_batch(x, ham, hop), "mag": zafx.stft_batch(x, ham, hop, onesided="magnitude"), "mdct": zafx.mdct_batch(x, kbd)}
+    assert all(v.flags.c_contiguous for v in compact.values())
+    zafx.set_row_padding("auto")
+    try:
+        s = zafx.stft_batch(x, ham, hop)
+        assert zafx.stft_plan(ham, hop, row_align=16).last_kernel == "k_stft_ft16"                 # the on-grid kernel, not the carry form
+        assert s.shape == (3, 2048, 38) and s.strides == (2048 * 48 * 8, 48 * 8, 8) and relerr(s, compact["stft"]) <= 2e-6 and relerr(s[0], orc.stft(x[0].astype(np.float64), ham, hop)) <= TOL_FFT
+        m = zafx.stft_batch(x, ham, hop, onesided="magnitude")
+        assert m.shape == (3, 1025, 38) and m.strides[1] == 64 * 4 and relerr(m, compact["mag"]) <= 2e-6
+        d = zafx.mdct_batch(x, kbd)
+        assert d.shape == compact["mdct"].shape and d.strides[1] == 64 * 4 and relerr(d, compact["mdct"]) <= 2e-6 and relerr(d[0], orc.mdct(x[0].astype(np.float64), kbd)) <= TOL_FFT
+        # inverse kinds: the padded view goes as it lies, a compact array through a copy -- the same samples
+        y_view, y_copy = zafx.istft_batch(s, ham, hop), zafx.istft_batch(compact["stft"], ham, hop)
+        assert zafx.istft_plan(ham, hop, row_align=16).last_kernel == "k_istft_ft16"
+        zafx.set_row_padding("compact")
+        y_compact = zafx.istft_batch(compact["stft"], ham, hop)
+        zafx.set_row_padding("auto")
+        assert relerr(y_view, y_copy) <= 2e-6 and relerr(y_view, y_compact) <= 2e-6 and np.max(np.abs(y_view[:, :n] - x)) < 1e-5
+        r_view, r_copy = zafx.imdct_batch(d, kbd), zafx.imdct_batch(compact["mdct"], kbd)
+        assert relerr(r_view, r_copy) <= 2e-6 and np.max(np.abs(r_view[:, :n - 1] - x[:, :n - 1])) < 1e-5
+        assert zafx.stft_batch(x, ham, hop, row_align=0).flags.c_contiguous and zafx.stft_batch(x, ham, hop, layout="TF").flags.c_contiguous
+        out = np.empty((3, 2048, 38), np.complex64)
+        assert zafx.stft_batch(x, ham, hop, out=out) is out and np.array_equal(out, compact["stft"])
+        assert zafx.stft_batch(x[:, :1024 * 31], ham, hop).flags.c_contiguous                       # T = 32: on the grid, nothing to pad
+        f64 = zafx.stft_batch(x.astype(np.float64), ham, hop, f64=True)                              # complex128 rows: lines of 8
+        assert f64.strides[1] == 40 * 16 and relerr(f64[0], orc.stft(x[0].astype(np.float64), ham, hop)) <= TOL_F64
+        one = zafx.stft(x[0], ham, hop)                                                              # the drop-ins hand back fresh contiguous arrays
+        assert one.flags.c_contiguous and one.dtype == np.complex128
+    finally:
+        zafx.set_row_padding("compact")
 
 
 def test_alloc_placed_through_the_c_abi(zafx):

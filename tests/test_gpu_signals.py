@@ -49,7 +49,9 @@ _report = {}
 def zafx():
     import zafx as z
     assert z.device_count() >= 1
+    z.set_row_padding("compact")   # (the kernels' compact forms are what test_signal_on_the_other_kernels names; the padded default: test_gpu_parity.py)
     yield z
+    z.set_row_padding("auto")
     path = os.environ.get("ZAFX_SIGNALS_REPORT")
     if path:
         with open(path, "w") as f:

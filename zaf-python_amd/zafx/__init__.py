@@ -22,7 +22,7 @@ from .core import (Comm, DeviceBuffer, Plan, clear_plan_cache, cqt_plan, cqtchro
                    cqtspectrogram, cqtspectrogram_batch, imdct, imdct_batch, istft, istft_batch, istft_plan, mdct,
                    mdct_batch, mdct_plan, mel_plan, melspectrogram, melspectrogram_batch, mfcc, mfcc_batch, pcm_to_mono, pinned_empty,
                    get_precision, set_precision, stft, stft_batch, stft_pcm_batch, stft_plan, mdct_pcm_batch, melspectrogram_pcm_batch, mfcc_pcm_batch,
-                   cqtspectrogram_pcm_batch, cqtchromagram_pcm_batch, mel_mfcc_batch, mel_mfcc_pcm_batch, mel_mfcc_supported)
+                   cqtspectrogram_pcm_batch, cqtchromagram_pcm_batch, mel_mfcc_batch, mel_mfcc_pcm_batch, mel_mfcc_supported, set_row_padding, get_row_padding)
 from .launch import Rendezvous, rank_env, spawn_ranks
 from .shard import clip_range, run_sharded, shard_sizes
 

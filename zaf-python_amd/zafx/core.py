@@ -253,6 +253,33 @@ def _spectrum_of(onesided):
         raise ValueError('onesided must be False, True, "magnitude" or "power"') from None
 
 
+def _rows_with_pitch(a, pitch):
+    """a: (B, F, T).  When `a` is a view of rows that lie `pitch` elements apart inside one buffer -- clip after clip, as the (B, F, pitch)
+    array of a row_align plan does -- return that (B, F, pitch) array over the same memory, else None.  (The padding behind the last
+    row must belong to the buffer too: checked against the bounds of the array that owns the memory.)"""
+    isz = a.dtype.itemsize
+    b, f, t = a.shape
+    if t > pitch or a.strides != (f * pitch * isz, pitch * isz, isz) or not a.size:
+        return None
+    owner = a
+    while isinstance(owner.base, np.ndarray):
+        owner = owner.base
+    try:
+        from numpy.lib.array_utils import byte_bounds
+    except ImportError:   # NumPy < 2
+        byte_bounds = np.byte_bounds
+    lo, hi = byte_bounds(owner)
+    start = a.__array_interface__["data"][0]
+    if start < lo or start + b * f * pitch * isz > hi:
+        return None
+    return np.lib.stride_tricks.as_strided(a, shape=(b, f, pitch), strides=(f * pitch * isz, pitch * isz, isz), writeable=False)
+
+
+def _line_elements(dtype):
+    """Elements of one 128-byte line."""
+    return 128 // np.dtype(dtype).itemsize
+
+
 class Plan:
     """One transform kind bound to one device and one HIP stream (zafx_plan)."""
 
@@ -413,16 +440,20 @@ class Plan:
         array = np.asarray(array)
         if np.iscomplexobj(array) and self.in_dtype.kind != "c":
             raise ValueError("this plan takes real input")
+        frames = None
+        if self.row_align > 1 and self.kind not in self._FORWARD and array.ndim == 3:
+            # padded rows on the device, compact (F, T) indexing on the host side.  An array that already IS rows of this pitch -- the view a
+            # forward *_batch call handed back -- goes as it lies; anything else is copied into a padded array first
+            pitch = self.row_pitch(n_in)
+            whole = _rows_with_pitch(array, pitch) if array.dtype == self.in_dtype else None
+            if whole is None:
+                whole = np.zeros(array.shape[:2] + (pitch,), dtype=self.in_dtype)
+                whole[:, :, :array.shape[2]] = array
+            array = whole
         array = np.ascontiguousarray(array, dtype=self.in_dtype)   # (an array of another dtype would be reinterpreted byte-wise)
         n_clips = array.shape[0]
-        frames = None
-        if self.row_align > 1:   # padded rows on the device, compact arrays on the host side
-            if self.kind in self._FORWARD:
-                frames = self.out_dims(n_in)[1]
-            elif array.ndim == 3:
-                padded = np.zeros(array.shape[:2] + (self.row_pitch(n_in),), dtype=array.dtype)
-                padded[:, :, :array.shape[2]] = array
-                array = padded
+        if self.row_align > 1 and self.kind in self._FORWARD:
+            frames = self.out_dims(n_in)[1]
         shape = self.out_shape(n_clips, n_in)
         if out is None:
             out = np.empty(shape, dtype=self.out_dtype)
@@ -853,7 +884,41 @@ def _run_host_into(plan, x, n_in, out):
     return out
 
 
-def stft_batch(clips, window_function, step_length, layout="FT", device=0, onesided=False, f64=False, out=None):
+_ROW_PADDING = {"value": "auto"}
+
+
+def set_row_padding(mode):
+    """How the *_batch functions of the STFT / MDCT families lay out the device (F, T) array when the caller passes neither `out` nor
+    `row_align`: "auto" (default) pads the rows to whole 128-byte lines whenever T is off that grid and hands back a view of the padded result
+    (_line_grid); "compact" always keeps the reference's own memory order (C-contiguous results, the kernels' off-grid forms)."""
+    if mode not in ("auto", "compact"):
+        raise ValueError('row padding must be "auto" or "compact"')
+    _ROW_PADDING["value"] = mode
+
+
+def get_row_padding():
+    return _ROW_PADDING["value"]
+
+
+def _line_grid(plan, n_in, out, padded_plan, frames=None, row_align=None):
+    """The plan a *_batch call of the STFT / MDCT families runs: when the frame count T is off the 128-byte line grid of the (F, T) rows in the
+    reference layout (the usual case: T % 16 != 0 for complex64 rows), the device array gets padded rows (row_align = one line) -- the kernels then
+    run at the rate they have on the grid (T = 433 against 432: ISTFT 0.47 -> 0.63 of HBM, |X| rows 0.34 -> 0.49, MDCT 0.46 -> 0.58)
+    -- and the NumPy array handed back is a VIEW of the padded result: the reference's shape, dtype and indexing, rows `pitch` elements apart
+    instead of T (C-contiguity of the result is not part of the reference's contract; np.ascontiguousarray(result) gives the compact
+    array).  A caller's own `out` array, the frame-major layout and frame counts on the grid keep the compact plan.  row_align (of the *_batch
+    functions): None = this rule, 0 = always the compact device array (the reference's own memory order), n = rows padded to n elements."""
+    if row_align is not None:
+        return padded_plan(int(row_align)) if int(row_align) > 1 and plan.layout == _lib.LAYOUT_FT else plan
+    if out is not None or plan.layout != _lib.LAYOUT_FT or plan.row_align > 1 or _ROW_PADDING["value"] != "auto":
+        return plan
+    t = plan.out_dims(n_in)[1] if frames is None else int(frames)
+    elem = plan.out_dtype if frames is None else plan.in_dtype   # the dtype of the 2-D side
+    a = _line_elements(elem)
+    return padded_plan(a) if t % a else plan
+
+
+def stft_batch(clips, window_function, step_length, layout="FT", device=0, onesided=False, f64=False, out=None, row_align=None):
     """(B, N) -> (B, W, T) complex64 [layout "FT"] or (B, T, W) ["TF"].
 
     out (every *_batch function): destination array of the result's shape and dtype, e.g. a reused zafx.pinned_empty
@@ -864,14 +929,15 @@ def stft_batch(clips, window_function, step_length, layout="FT", device=0, onesi
     result (zaf.py:83) -- and halves the bytes written; onesided="magnitude" / "power" returns |X| / |X|^2
     of those rows as a real array."""
     x = _as_clips(clips, dtype=np.float64 if f64 else np.float32)
-    plan = stft_plan(window_function, step_length, layout, device, onesided, f64)
+    plan = _line_grid(stft_plan(window_function, step_length, layout, device, onesided, f64), x.shape[1], out,
+                      lambda a: stft_plan(window_function, step_length, layout, device, onesided, f64, row_align=a), row_align=row_align)
     out = _run_host_into(plan, x.astype(plan.in_dtype, copy=False), x.shape[1], out)
     if f64 or not plan.f64:
         return out
     return out.astype(np.complex64 if np.iscomplexobj(out) else np.float32, copy=False)   # (computed in float64: window not a power of two)
 
 
-def istft_batch(spectra, window_function, step_length, layout="FT", device=0, onesided=False, f64=False, out=None):
+def istft_batch(spectra, window_function, step_length, layout="FT", device=0, onesided=False, f64=False, out=None, row_align=None):
     """(B, W, T) ["FT"] or (B, T, W) ["TF"] complex -> (B, T*H - (W-H)) float32.
 
     onesided=True takes rows 0..W/2 and completes X[W-k] = conj X[k]: the result equals the two-sided
@@ -883,30 +949,35 @@ def istft_batch(spectra, window_function, step_length, layout="FT", device=0, on
     wl, nt = (s.shape[1], s.shape[2]) if _LAYOUTS[layout] == _lib.LAYOUT_FT else (s.shape[2], s.shape[1])
     if wl != (len(w) // 2 + 1 if onesided else len(w)):
         raise ValueError("spectrum rows must equal window_length (window_length/2 + 1 when onesided)")
-    plan = istft_plan(w, step_length, layout, device, onesided, f64)
-    out = _run_host_into(plan, np.ascontiguousarray(s, dtype=plan.in_dtype), nt, out)
+    plan = _line_grid(istft_plan(w, step_length, layout, device, onesided, f64), nt, None,
+                      lambda a: istft_plan(w, step_length, layout, device, onesided, f64, row_align=a), frames=nt, row_align=row_align)
+    out = _run_host_into(plan, s if plan.row_align > 1 else np.ascontiguousarray(s, dtype=plan.in_dtype), nt, out)
     return out if f64 else out.astype(np.float32, copy=False)   # (a very small hop is computed in float64 whatever f64 says)
 
 
-def mdct_batch(clips, window_function, layout="FT", device=0, f64=False, out=None):
+def mdct_batch(clips, window_function, layout="FT", device=0, f64=False, out=None, row_align=None):
     """(B, N) -> (B, W/2, T) float32 ["FT"] or (B, T, W/2) ["TF"]; f64: float64 arrays and arithmetic."""
     x = _as_clips(clips, dtype=np.float64 if f64 else np.float32)
-    plan = mdct_plan(window_function, layout, device, f64=f64)
+    plan = _line_grid(mdct_plan(window_function, layout, device, f64=f64), x.shape[1], out,
+                      lambda a: mdct_plan(window_function, layout, device, row_align=a, f64=f64), row_align=row_align)
     out = _run_host_into(plan, x.astype(plan.in_dtype, copy=False), x.shape[1], out)
     return out if f64 else out.astype(np.float32, copy=False)
 
 
-def imdct_batch(coefficients, window_function, layout="FT", device=0, f64=False, out=None):
+def imdct_batch(coefficients, window_function, layout="FT", device=0, f64=False, out=None, row_align=None):
     """(B, W/2, T) ["FT"] or (B, T, W/2) ["TF"] -> (B, (W/2)(T-1) - 1) float32 (float64 with f64)."""
-    c = np.ascontiguousarray(coefficients, dtype=np.float64 if f64 else np.float32)
+    c = np.asarray(coefficients)
+    if c.dtype != (np.float64 if f64 else np.float32):
+        c = c.astype(np.float64 if f64 else np.float32)
     w = _as_window(window_function, any_length=True)
     if c.ndim != 3:
         raise ValueError("coefficients must be 3-D")
     nf, nt = (c.shape[1], c.shape[2]) if _LAYOUTS[layout] == _lib.LAYOUT_FT else (c.shape[2], c.shape[1])
     if 2 * nf != len(w):
         raise ValueError("coefficient rows must equal window_length/2")
-    plan = mdct_plan(w, layout, device, inverse=True, f64=f64)
-    out = _run_host_into(plan, c.astype(plan.in_dtype, copy=False), nt, out)
+    plan = _line_grid(mdct_plan(w, layout, device, inverse=True, f64=f64), nt, None,
+                      lambda a: mdct_plan(w, layout, device, inverse=True, row_align=a, f64=f64), frames=nt, row_align=row_align)
+    out = _run_host_into(plan, c if plan.row_align > 1 else c.astype(plan.in_dtype, copy=False), nt, out)
     return out if f64 else out.astype(np.float32, copy=False)
 
 

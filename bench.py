@@ -50,7 +50,7 @@ F32_PEAK_TFLOPS = 157.3    # dense f32 vector / f32-input MFMA peak
 F64_PEAK_TFLOPS = 78.6     # float64 vector: half the f32 vector rate (v_fma_f64 issues every 4 cycles per wave: 256 CUs x 4 SIMDs x 32 FLOP/clk x 2.4 GHz; the guide lists no f64 row)
 PLACEMENT_SURVEY = 6       # further allocations of the headline's row-strided output probed AFTER every timed region (reported, never timed)
 CONFIG_KINDS = ("istft", "mel", "mfcc", "mel_mfcc", "mdct", "imdct", "cqt")   # SURVEY 8(a) a2 + BASELINE configs 3 (mel_mfcc: in one pass), 4, 5 (config 2 = the headline)
-EXTRA_KINDS = ("stft1", "stftmag", "istft1", "stft_offgrid", "mdct_offgrid", "stft4096", "stft4096_h1024", "istft4096", "mdct4096", "mel4096", "dct", "stft64", "mdct64", "istft_offgrid", "imdct_offgrid", "stftmag_offgrid", "stft8192", "mdct8192", "istft64", "imdct64", "mel64", "mfcc64", "cqt64", "istft_offgrid_compact", "stftmag_offgrid_compact")   # one-sided pair (8f rank 4) and geometries off the benchmark's grid
+EXTRA_KINDS = ("stft1", "stftmag", "istft1", "stft_offgrid", "mdct_offgrid", "stft4096", "stft4096_h1024", "istft4096", "mdct4096", "mel4096", "dct", "stft64", "mdct64", "istft_offgrid", "imdct_offgrid", "stftmag_offgrid", "stft8192", "mdct8192", "istft64", "imdct64", "mel64", "mfcc64", "cqt64", "istft_offgrid_compact", "stftmag_offgrid_compact", "mel_pcm16", "mdct_pcm16", "dct1000")   # one-sided pair (8f rank 4) and geometries off the benchmark's grid
 
 
 def synth(seed, c, n):
@@ -79,6 +79,20 @@ def replicate64(base, n_clips, device):
     return d_x
 
 
+class PcmPlan:
+    """A plan fed with int16 PCM that is already on the device (zafx_execute_pcm: wavread's x / 2^15, zaf.py:1202, inside the kernel's own loads):
+    execute() of the timing loops = Plan.execute_pcm; everything else is the plan's."""
+
+    def __init__(self, plan, channels=1):
+        self._plan, self._channels = plan, channels
+
+    def execute(self, d_in, d_out, n_clips, n_in):
+        self._plan.execute_pcm(d_in, d_out, n_clips, n_in, self._channels)
+
+    def __getattr__(self, name):
+        return getattr(self._plan, name)
+
+
 def make_workload(kind, device, layout="FT"):
     """dict(plan, n_clips, n_in, d_in, d_out, samples_per_clip, bytes_per_launch, valu_flops, mfma_flops, desc, ...)."""
     import zafx
@@ -91,6 +105,8 @@ def make_workload(kind, device, layout="FT"):
         B, N, T = 1024, 1323000, 750   # BASELINE config 5: 8192 clips x 30 s over 8 GPUs = 1024 per GPU
     if kind == "dct":
         B, N, T = 16384, 1024, 1
+    if kind == "dct1000":
+        B, N, T = 16384, 1000, 1   # a length off the power-of-two grid: the chirp-z form (k_dct_bs32)
     if kind == "cqt64":
         B, N, T = 256, 1323000, 750   # float64 clips of 30 s are 10.6 MB: a quarter of a GPU's share of config 5 (2.7 GB), same frames per clip
     if kind in ("stft64", "mdct64", "istft64", "imdct64", "mel64", "mfcc64"):
@@ -281,6 +297,27 @@ def make_workload(kind, device, layout="FT"):
                   flops_note="SURVEY 8(d): 750 x 5*32768*15 per clip, the 32768-point complex FFT the reference runs; the real-input form the kernel "
                              "runs (one 16384-point complex transform per frame) needs 5*16384*14, under half",
                   desc="cqtspectrogram: 1024 clips x 30 s @ 44.1 kHz per GPU (config 5: 8192 clips over 8 GPUs), 24 bins/octave 55-3520 Hz, 25 frames/s")
+    elif kind in ("mel_pcm16", "mdct_pcm16"):   # int16 mono in the kernel's own loads, device resident: 2 bytes per sample read
+        pcm = np.clip(np.rint(base * 8192.0), -32768, 32767).astype(np.int16)   # (the same clips at -12 dBFS, as a 16-bit recorder holds them)
+        d_base = zafx.DeviceBuffer.from_host(pcm, device)
+        d_x.free()
+        d_x = zafx.DeviceBuffer((B, N), np.int16, device)
+        for r in range(B // distinct):
+            d_x.copy_from(d_base, dst_offset=r * distinct * N * 2)
+        d_base.free()
+        wl["base"] = pcm.astype(np.float32) / 32768.0   # what the parity probe's reference starts from (zaf.py:1202)
+        if kind == "mel_pcm16":
+            plan = PcmPlan(zafx.mel_plan(ham, H, zafx.melfilterbank(FS, W, 128), None, device=device))
+            wl.update(plan=plan, d_in=d_x, n_in=N, bytes_per_launch=B * (2 * N + 4 * 128 * T),
+                      desc="Fused melspectrogram from int16 mono PCM on the device (wavread's scaling in the loads): 1024 clips x 10 s, win=2048 hop=1024, 128 mel filters")
+        else:
+            plan = PcmPlan(zafx.mdct_plan(kbd, device=device))
+            wl.update(plan=plan, d_in=d_x, n_in=N, bytes_per_launch=B * (2 * N + 4 * (W // 2) * T),
+                      desc="Batched MDCT from int16 mono PCM on the device: 1024 clips x 10 s, KBD win=2048")
+    elif kind == "dct1000":   # every length the reference takes: N = 1000 as a chirp-z sum (two 2048-point transforms per vector)
+        plan = zafx.dct_plan(N, 2, device=device)
+        wl.update(plan=plan, d_in=d_x, n_in=N, bytes_per_launch=B * 8 * N,
+                  desc="zaf.dct type 2 of 16384 vectors x 1000 samples (a length off the power-of-two grid: chirp-z form)")
     elif kind == "dct":   # zaf.dct type 2 on the FFT core (k_dct): 8 bytes per sample, HBM-bound
         plan = zafx.dct_plan(N, 2, device=device)
         wl.update(plan=plan, d_in=d_x, n_in=N, bytes_per_launch=B * 8 * N,
@@ -486,8 +523,12 @@ def parity_probe(wl):
         ref = orc.melspectrogram(x64, orc.hamming_periodic(4096), 2048, orc.melfilterbank(FS, 4096, 128))
     elif kind in ("istft", "istft1", "istft4096", "istft_offgrid", "istft64", "imdct64"):
         ref = None   # (checked as a round trip below: the device spectrum is the input)
-    elif kind in ("mdct", "mdct_offgrid", "mdct64"):
+    elif kind in ("mdct", "mdct_offgrid", "mdct64", "mdct_pcm16"):
         ref = orc.mdct(x64, kbd)
+    elif kind == "mel_pcm16":
+        ref = orc.melspectrogram(x64, ham, H, orc.melfilterbank(FS, W, 128))
+    elif kind in ("dct", "dct1000"):
+        ref = orc.dct(x64, 2)
     elif kind in ("imdct", "imdct_offgrid"):
         ref = None
     elif kind == "mel_mfcc":   # both outputs, each against its own reference (the worse of the two is reported)
@@ -520,7 +561,7 @@ def parity_probe(wl):
         first = first[:, :ref.shape[1]]   # (rows padded to 128-byte lines on the device)
     got = first if first.shape == ref.shape else first.T
     d = float(np.max(np.abs(got - ref)))
-    tol = 1e-4 if kind in ("mel", "mfcc", "cqt", "mel4096") else 1e-10 if kind == "mfcc64" else 1e-12 if kind.endswith("64") else 1e-5
+    tol = 1e-4 if kind in ("mel", "mfcc", "cqt", "mel4096", "mel_pcm16") else 1e-10 if kind == "mfcc64" else 1e-12 if kind.endswith("64") else 1e-5
     rel = d / float(np.max(np.abs(ref)))
     out.update({"max_abs_err_vs_numpy": d, "max_rel_err_vs_numpy": rel, "tolerance": tol, "within_tolerance": bool(rel <= tol)})
     return out

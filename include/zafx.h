@@ -88,7 +88,10 @@ enum zafx_precision {     /* device arithmetic and array types (SURVEY 8f rank 4
     ZAFX_PRECISION_F64 = 1  /* every kind but ZAFX_LINEAR: float64 / complex128 arrays AND constants (window float64[W],
                                mel filterbank / DCT rows float64, CQT values complex128); the reference's own dtype
                                (zaf.py:128, :139), results within 1e-12 of it (mfcc 1e-10); any power-of-two window.
-                               Exactness mode: one workgroup per frame, not tuned                              */
+                               window_length 2048 in the reference layout (CQT: fft_length 32768, kernel columns in the one-sided
+                               bins 1..8191) runs on tiled kernels of its own -- k_stft_ft8_f64, k_istft_ft8_f64,
+                               k_mdct_ft16_f64, k_imdct_ft16_f64 (round 5), k_mel_ft8_f64, k_cqt_ft_f64 (round 6): 2-3 x
+                               behind the float32 kernels --, every other geometry one workgroup per frame (5-10 x)   */
 };
 
 enum zafx_constant {

@@ -3,11 +3,14 @@
 // The reference computes in float64 / complex128 (zaf.py:128, :139, :223).  The tuned kernels of
 // zafx_stft.hip are float32; a plan created with zafx_params.precision = ZAFX_PRECISION_F64 runs the
 // kernels below instead: same framing, padding, spectrum kinds and layouts, double arithmetic
-// throughout, results within 1e-12 of the reference (tests/test_gpu_parity.py).  They are written
-// for exactness, not speed: one workgroup per frame, a radix-2 Stockham FFT of the packed
-// half-length transform in LDS (twiddles from a float64 table the host builds in long double), the
-// ISTFT through a per-call scratch of time-domain frames and a gather overlap-add in the reference's
-// ascending frame order (zaf.py:226-233).
+// throughout, results within 1e-12 of the reference (tests/test_gpu_parity.py).  Two families:
+//   * tiled kernels for the benchmark geometries (W = 2048 in the reference layout; CQT: fft_length 32768) -- k_stft_ft8_f64,
+//     k_mdct_ft16_f64, k_imdct_ft16_f64, k_istft_ft8_f64 (round 5), k_mel_ft8_f64, k_cqt_ft_f64 (round 6): a frame per wavefront,
+//     1024-point transforms in registers + the wave's own LDS, tiles that make every row piece a whole 128-byte line;
+//   * for every other geometry one workgroup per frame, a radix-2 Stockham FFT of the packed half-length transform in LDS
+//     (twiddles from a float64 table the host builds in long double), the ISTFT through a per-call scratch of time-domain
+//     frames and a gather overlap-add in the reference's ascending frame order (zaf.py:226-233); windows that are not a
+//     power of two as Bluestein convolutions.
 #include <algorithm>
 #include <cstdlib>
 

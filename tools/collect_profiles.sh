@@ -10,7 +10,7 @@ REPO=$PWD
 OUT=$REPO/gpurun_out
 mkdir -p "$OUT"
 export TMPDIR=/tmp
-SQ_KINDS=${SQ_KINDS:-"mel mfcc cqt stft"}
+SQ_KINDS=${SQ_KINDS:-"mel mfcc mel_mfcc cqt stft mel64 cqt64"}
 cd /tmp || exit 1
 rm -rf "$OUT/prof_all"
 ZAFX_BENCH_INNER_LOG="$OUT/prof_all_launches.json" timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/prof_all" -o all -- \

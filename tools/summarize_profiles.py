@@ -89,14 +89,14 @@ def all_counters(kind, leg):
     acc = {}
     with open(f) as fh:
         for r in csv.DictReader(fh):
-            name = r["Kernel_Name"].split("(")[0]
+            name = r["Kernel_Name"].replace("(anonymous namespace)::", "").split("(")[0]
             s = acc.setdefault(name, {}).setdefault(r["Counter_Name"], [0, 0.0])
             s[0] += 1
             s[1] += float(r["Counter_Value"])
     return {k: {c: v / n for c, (n, v) in d.items()} for k, d in acc.items()}
 
 
-KERNEL_OF = {"mel": "k_mel", "mfcc": "k_mel", "cqt": "k_cqt", "stft": "k_stft_ft16", "dct": "k_dct"}
+KERNEL_OF = {"mel": "k_mel", "mfcc": "k_mel", "mel_mfcc": "k_mel", "cqt": "k_cqt", "stft": "k_stft_ft16", "dct": "k_dct", "mel64": "k_mel_ft8_f64", "cqt64": "k_cqt_ft_f64"}
 sq_rows = []
 for kind, kname in KERNEL_OF.items():
     merged, label = {}, kname

@@ -29,6 +29,23 @@ __device__ __forceinline__ double2 dmul(double2 a, double2 b) { return make_doub
 __device__ __forceinline__ double2 dmulc(double2 a, double2 b) { return make_double2(a.x * b.x + a.y * b.y, a.y * b.x - a.x * b.y); }
 __device__ __forceinline__ double2 dconj(double2 a) { return make_double2(a.x, -a.y); }
 
+// A 16-byte value to LDS.  ZAFX_F64_ST64 = 1 writes it as TWO 8-byte stores (volatile: never merged).  tools/exp_lds128.hip (round 6) times a
+// ds_write_b128 at four times a ds_write_b64 where ds_read_b128 costs the same as ds_read_b64 -- but in the kernels the pairs are SLOWER
+// (128 clips x 10 s: mdct 0.300 against 0.283 ms, mel 0.386 / 0.370, cqt 64 x 30 s 4.63 / 4.39): twice the DS instructions to issue.  Kept off.
+#ifndef ZAFX_F64_ST64
+#define ZAFX_F64_ST64 0
+#endif
+__device__ __forceinline__ void lds_st(double2* p, double2 v) {
+#if ZAFX_F64_ST64
+    typedef __attribute__((address_space(3))) volatile double lds_f64;
+    lds_f64* q = (lds_f64*)p;
+    q[0] = v.x;
+    q[1] = v.y;
+#else
+    *p = v;
+#endif
+}
+
 #ifndef ZAFX_F64_TILED
 #define ZAFX_F64_TILED 1   // W = 2048, reference layout: k_stft_ft8_f64 / k_mdct_ft16_f64 instead of the frame-per-workgroup kernels
 #endif
@@ -168,7 +185,7 @@ __device__ __forceinline__ void fft1024_f64(double2* v, double2* buf, int lane, 
                                             const double2* __restrict__ tws = nullptr) {
     dft16d(v);
 #pragma unroll
-    for (int r = 0; r < 16; ++r) buf[physd(16 * lane + r)] = v[r];
+    for (int r = 0; r < 16; ++r) lds_st(&buf[physd(16 * lane + r)], v[r]);
     frame_sync<64>();
 #pragma unroll
     for (int i = 0; i < 16; ++i) v[i] = buf[physd(lane + 64 * i)];
@@ -180,7 +197,7 @@ __device__ __forceinline__ void fft1024_f64(double2* v, double2* buf, int lane, 
         dft16d(v);
         const int base = ((lane >> 4) << 8) + k;
 #pragma unroll
-        for (int r = 0; r < 16; ++r) buf[physd(base + 16 * r)] = v[r];
+        for (int r = 0; r < 16; ++r) lds_st(&buf[physd(base + 16 * r)], v[r]);
     }
     frame_sync<64>();
 #pragma unroll
@@ -195,10 +212,10 @@ __device__ __forceinline__ void fft1024_f64(double2* v, double2* buf, int lane, 
         const int k = lane + 64 * b;
         double2 a0 = v[b], a1 = dmul(v[b + 4], root1024(tw, k)), a2 = dmul(v[b + 8], root1024(tw, 2 * k)), a3 = dmul(v[b + 12], root1024(tw, 3 * k));
         dft4d(a0, a1, a2, a3);
-        buf[physd(k)] = a0;
-        buf[physd(k + 256)] = a1;
-        buf[physd(k + 512)] = a2;
-        buf[physd(k + 768)] = a3;
+        lds_st(&buf[physd(k)], a0);
+        lds_st(&buf[physd(k + 256)], a1);
+        lds_st(&buf[physd(k + 512)], a2);
+        lds_st(&buf[physd(k + 768)], a3);
     }
     frame_sync<64>();
 }
@@ -262,14 +279,14 @@ __global__ __launch_bounds__(kF64Frames * 64) void k_stft_ft8_f64(const double* 
                 const double2 z0 = buf[0], zc = buf[physd(N / 2)];
                 buf[0] = make_double2(z0.x + z0.y, 0.0);
                 nyq[wave] = z0.x - z0.y;
-                buf[physd(N / 2)] = dconj(zc);
+                lds_st(&buf[physd(N / 2)], dconj(zc));
             } else {
                 const double2 zk = buf[physd(k)], zn = buf[physd(N - k)];
                 const double2 e = make_double2(0.5 * (zk.x + zn.x), 0.5 * (zk.y - zn.y));
                 const double2 d = make_double2(0.5 * (zk.x - zn.x), 0.5 * (zk.y + zn.y));
                 const double2 to = dmul(tws[k], make_double2(d.y, -d.x));
-                buf[physd(k)] = dadd(e, to);
-                buf[physd(N - k)] = dconj(dsub(e, to));
+                lds_st(&buf[physd(k)], dadd(e, to));
+                lds_st(&buf[physd(N - k)], dconj(dsub(e, to)));
             }
         }
         lds_barrier();
@@ -392,7 +409,7 @@ __global__ __launch_bounds__(kMd64Frames * 64) void k_mdct_ft16_f64(const double
         // 512 points: radix 8 three times
         dft8d(v);
 #pragma unroll
-        for (int r = 0; r < 8; ++r) buf[phys8(8 * lane + r)] = v[r];
+        for (int r = 0; r < 8; ++r) lds_st(&buf[phys8(8 * lane + r)], v[r]);
         frame_sync<64>();
 #pragma unroll
         for (int i = 0; i < 8; ++i) v[i] = buf[phys8(lane + 64 * i)];
@@ -404,7 +421,7 @@ __global__ __launch_bounds__(kMd64Frames * 64) void k_mdct_ft16_f64(const double
             dft8d(v);
             const int base = ((lane >> 3) << 6) + k;
 #pragma unroll
-            for (int r = 0; r < 8; ++r) buf[phys8(base + 8 * r)] = v[r];
+            for (int r = 0; r < 8; ++r) lds_st(&buf[phys8(base + 8 * r)], v[r]);
         }
         frame_sync<64>();
 #pragma unroll
@@ -416,14 +433,14 @@ __global__ __launch_bounds__(kMd64Frames * 64) void k_mdct_ft16_f64(const double
         // Z[lane + 64 r] = v[r]; post-twiddle y_k = Z[k] g_k and the pair's trade, in place: lane (k < 256: r < 4) needs Z[511 - k], held by lane 63 - lane
         // in register 7 - r: through LDS
 #pragma unroll
-        for (int r = 0; r < 8; ++r) buf[phys8(lane + 64 * r)] = dmul(v[r], g[lane + 64 * r]);   // y_k
+        for (int r = 0; r < 8; ++r) lds_st(&buf[phys8(lane + 64 * r)], dmul(v[r], g[lane + 64 * r]));   // y_k
         frame_sync<64>();
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             const int k = lane + 64 * r, kp = NF - 1 - k;
             const double2 yk = buf[phys8(k)], yp = buf[phys8(kp)];
-            buf[phys8(k)] = make_double2(yk.x, -yp.y);    // out[2k], out[2k+1] = out[M-1-2k']
-            buf[phys8(kp)] = make_double2(yp.x, -yk.y);   // out[2k'], out[2k'+1] = out[M-1-2k]
+            lds_st(&buf[phys8(k)], make_double2(yk.x, -yp.y));    // out[2k], out[2k+1] = out[M-1-2k']
+            lds_st(&buf[phys8(kp)], make_double2(yp.x, -yk.y));   // out[2k'], out[2k'+1] = out[M-1-2k]
         }
         lds_barrier();
         {
@@ -464,7 +481,7 @@ __global__ __launch_bounds__(kMd64Frames * 64) void k_imdct_ft16_f64(const doubl
         frame_sync<64>();
         dft8d(v);
 #pragma unroll
-        for (int r = 0; r < 8; ++r) buf[phys8(8 * lane + r)] = v[r];
+        for (int r = 0; r < 8; ++r) lds_st(&buf[phys8(8 * lane + r)], v[r]);
         frame_sync<64>();
 #pragma unroll
         for (int i = 0; i < 8; ++i) v[i] = buf[phys8(lane + 64 * i)];
@@ -476,7 +493,7 @@ __global__ __launch_bounds__(kMd64Frames * 64) void k_imdct_ft16_f64(const doubl
             dft8d(v);
             const int base = ((lane >> 3) << 6) + k;
 #pragma unroll
-            for (int r = 0; r < 8; ++r) buf[phys8(base + 8 * r)] = v[r];
+            for (int r = 0; r < 8; ++r) lds_st(&buf[phys8(base + 8 * r)], v[r]);
         }
         frame_sync<64>();
 #pragma unroll
@@ -486,14 +503,14 @@ __global__ __launch_bounds__(kMd64Frames * 64) void k_imdct_ft16_f64(const doubl
         for (int r = 1; r < 8; ++r) v[r] = dmul(v[r], root512(tw, r * lane));
         dft8d(v);
 #pragma unroll
-        for (int r = 0; r < 8; ++r) buf[phys8(lane + 64 * r)] = dmul(v[r], g[lane + 64 * r]);   // y_k = Z[k] g_k
+        for (int r = 0; r < 8; ++r) lds_st(&buf[phys8(lane + 64 * r)], dmul(v[r], g[lane + 64 * r]));   // y_k = Z[k] g_k
         frame_sync<64>();
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             const int k = lane + 64 * r, kp = NF - 1 - k;
             const double2 yk = buf[phys8(k)], yp = buf[phys8(kp)];
-            buf[phys8(k)] = make_double2(yk.x, -yp.y);
-            buf[phys8(kp)] = make_double2(yp.x, -yk.y);
+            lds_st(&buf[phys8(k)], make_double2(yk.x, -yp.y));
+            lds_st(&buf[phys8(kp)], make_double2(yp.x, -yk.y));
         }
     };
     for (int unit = blockIdx.x; unit < units; unit += gridDim.x) {
@@ -511,7 +528,7 @@ __global__ __launch_bounds__(kMd64Frames * 64) void k_imdct_ft16_f64(const doubl
 #pragma unroll
                 for (int i = 0; i < 8; ++i) {
                     const int m = lane + 64 * i;
-                    buf[phys8(m)] = dmul(make_double2(cp[(long long)(2 * m) * TP + t], cp[(long long)(M - 1 - 2 * m) * TP + t]), g[m]);
+                    lds_st(&buf[phys8(m)], dmul(make_double2(cp[(long long)(2 * m) * TP + t], cp[(long long)(M - 1 - 2 * m) * TP + t]), g[m]));
                 }
                 frame_sync<64>();
                 dct4_wave(buf, lane);
@@ -529,7 +546,7 @@ __global__ __launch_bounds__(kMd64Frames * 64) void k_imdct_ft16_f64(const doubl
 #pragma unroll
                     for (int i = 0; i < 8; ++i) {
                         const int m = mq + 64 * i;
-                        buf[phys8(m)] = dmul(make_double2(cp[(long long)(2 * m) * TP + t], cp[(long long)(M - 1 - 2 * m) * TP + t]), g[m]);
+                        lds_st(&buf[phys8(m)], dmul(make_double2(cp[(long long)(2 * m) * TP + t], cp[(long long)(M - 1 - 2 * m) * TP + t]), g[m]));
                     }
                 }
             }
@@ -588,7 +605,7 @@ __global__ __launch_bounds__(kF64Frames * 64) void k_istft_ft8_f64(const double2
             const double2 xc = row(N / 2);
             const double2 xd = ONE ? dconj(xc) : row(N + N / 2);
             const double2 h = make_double2(xc.x + xd.x, xc.y - xd.y);
-            buf[physd(N / 2)] = make_double2(-2.0 * h.y, 2.0 * h.x);
+            lds_st(&buf[physd(N / 2)], make_double2(-2.0 * h.y, 2.0 * h.x));
         } else {
             const double2 xk = row(k), xnk = row(N - k);
             const double2 xwk = ONE ? dconj(xk) : row(W - k);
@@ -599,8 +616,8 @@ __global__ __launch_bounds__(kF64Frames * 64) void k_istft_ft8_f64(const double2
             const double2 d = make_double2(ak.x - an.x, ak.y + an.y);
             const double2 o = dmulc(d, tws[k]);
             const double2 zk = make_double2(e.x - o.y, e.y + o.x), zn = make_double2(e.x + o.y, -e.y + o.x);
-            buf[physd(k)] = make_double2(zk.y, zk.x);
-            buf[physd(N - k)] = make_double2(zn.y, zn.x);
+            lds_st(&buf[physd(k)], make_double2(zk.y, zk.x));
+            lds_st(&buf[physd(N - k)], make_double2(zn.y, zn.x));
         }
     };
     auto transform = [&](double2* buf, int lane) {
@@ -1379,7 +1396,7 @@ __device__ __forceinline__ void fft1024_cq(double2* buf, int lane, const double2
     frame_sync<64>();
     dft16d(v);
 #pragma unroll
-    for (int r = 0; r < 16; ++r) buf[physd(16 * lane + r)] = v[r];
+    for (int r = 0; r < 16; ++r) lds_st(&buf[physd(16 * lane + r)], v[r]);
     frame_sync<64>();
 #pragma unroll
     for (int i = 0; i < 16; ++i) v[i] = buf[physd(lane + 64 * i)];
@@ -1391,7 +1408,7 @@ __device__ __forceinline__ void fft1024_cq(double2* buf, int lane, const double2
         dft16d(v);
         const int base = ((lane >> 4) << 8) + k;
 #pragma unroll
-        for (int r = 0; r < 16; ++r) buf[physd(base + 16 * r)] = v[r];
+        for (int r = 0; r < 16; ++r) lds_st(&buf[physd(base + 16 * r)], v[r]);
     }
     frame_sync<64>();
 #pragma unroll
@@ -1402,10 +1419,10 @@ __device__ __forceinline__ void fft1024_cq(double2* buf, int lane, const double2
         const int k = lane + 64 * b;
         double2 a0 = v[b], a1 = dmul(v[b + 4], rtab[k * RS]), a2 = dmul(v[b + 8], rtab[2 * k * RS]), a3 = dmul(v[b + 12], rtab[3 * k * RS]);
         dft4d(a0, a1, a2, a3);
-        buf[physd(k)] = a0;
-        buf[physd(k + 256)] = a1;
-        buf[physd(k + 512)] = a2;
-        buf[physd(k + 768)] = a3;
+        lds_st(&buf[physd(k)], a0);
+        lds_st(&buf[physd(k + 256)], a1);
+        lds_st(&buf[physd(k + 512)], a2);
+        lds_st(&buf[physd(k + 768)], a3);
     }
     frame_sync<64>();
 }
@@ -1502,14 +1519,14 @@ __global__ __launch_bounds__(kCq64Threads) void k_cqt_ft_f64(const double* __res
                 if (round == 0) {
                     dft8d(a);   // a[p] = sum_r z[m + 1024 r] w_16^(2 p r)
                     const double2 w6 = dmul(w2, w4);
-                    fm[0 * PITCH] = a[0];
-                    fm[1 * PITCH] = dmul(a[1], w2);
-                    fm[2 * PITCH] = dmul(a[2], w4);
-                    fm[3 * PITCH] = dmul(a[3], w6);
-                    fm[4 * PITCH] = dmul(a[4], w8);
-                    fm[5 * PITCH] = dmul(a[5], dmul(w2, w8));
-                    fm[6 * PITCH] = dmul(a[6], dmul(w4, w8));
-                    fm[7 * PITCH] = dmul(a[7], dmul(w6, w8));
+                    lds_st(&fm[0 * PITCH], a[0]);
+                    lds_st(&fm[1 * PITCH], dmul(a[1], w2));
+                    lds_st(&fm[2 * PITCH], dmul(a[2], w4));
+                    lds_st(&fm[3 * PITCH], dmul(a[3], w6));
+                    lds_st(&fm[4 * PITCH], dmul(a[4], w8));
+                    lds_st(&fm[5 * PITCH], dmul(a[5], dmul(w2, w8)));
+                    lds_st(&fm[6 * PITCH], dmul(a[6], dmul(w4, w8)));
+                    lds_st(&fm[7 * PITCH], dmul(a[7], dmul(w6, w8)));
                 } else {
                     const double h = 0.70710678118654752440, c1 = 0.92387953251128675613, s1 = 0.38268343236508977173;
                     a[1] = dmul(a[1], make_double2(c1, -s1));
@@ -1522,14 +1539,14 @@ __global__ __launch_bounds__(kCq64Threads) void k_cqt_ft_f64(const double* __res
                     dft8d(a);   // a[p] = sum_r z[m + 1024 r] w_16^((2 p + 1) r)
                     const double2 w1 = tw1[m];
                     const double2 w3 = dmul(w1, w2), w5 = dmul(w1, w4), w9 = dmul(w1, w8);
-                    fm[0 * PITCH] = dmul(a[0], w1);
-                    fm[1 * PITCH] = dmul(a[1], w3);
-                    fm[2 * PITCH] = dmul(a[2], w5);
-                    fm[3 * PITCH] = dmul(a[3], dmul(w3, w4));
-                    fm[4 * PITCH] = dmul(a[4], w9);
-                    fm[5 * PITCH] = dmul(a[5], dmul(w3, w8));
-                    fm[6 * PITCH] = dmul(a[6], dmul(w5, w8));
-                    fm[7 * PITCH] = dmul(a[7], dmul(dmul(w3, w4), w8));
+                    lds_st(&fm[0 * PITCH], dmul(a[0], w1));
+                    lds_st(&fm[1 * PITCH], dmul(a[1], w3));
+                    lds_st(&fm[2 * PITCH], dmul(a[2], w5));
+                    lds_st(&fm[3 * PITCH], dmul(a[3], dmul(w3, w4)));
+                    lds_st(&fm[4 * PITCH], dmul(a[4], w9));
+                    lds_st(&fm[5 * PITCH], dmul(a[5], dmul(w3, w8)));
+                    lds_st(&fm[6 * PITCH], dmul(a[6], dmul(w5, w8)));
+                    lds_st(&fm[7 * PITCH], dmul(a[7], dmul(dmul(w3, w4), w8)));
                 }
             }
             PROF_MARK(0);

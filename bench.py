@@ -50,7 +50,7 @@ F32_PEAK_TFLOPS = 157.3    # dense f32 vector / f32-input MFMA peak
 F64_PEAK_TFLOPS = 78.6     # float64 vector: half the f32 vector rate (v_fma_f64 issues every 4 cycles per wave: 256 CUs x 4 SIMDs x 32 FLOP/clk x 2.4 GHz; the guide lists no f64 row)
 PLACEMENT_SURVEY = 6       # further allocations of the headline's row-strided output probed AFTER every timed region (reported, never timed)
 CONFIG_KINDS = ("istft", "mel", "mfcc", "mel_mfcc", "mdct", "imdct", "cqt")   # SURVEY 8(a) a2 + BASELINE configs 3 (mel_mfcc: in one pass), 4, 5 (config 2 = the headline)
-EXTRA_KINDS = ("stft1", "stftmag", "istft1", "stft_offgrid", "mdct_offgrid", "stft4096", "stft4096_h1024", "istft4096", "mdct4096", "mel4096", "dct", "stft64", "mdct64", "istft_offgrid", "imdct_offgrid", "stftmag_offgrid", "stft8192", "mdct8192", "istft64", "imdct64", "mel64", "mfcc64", "cqt64", "istft_offgrid_compact", "stftmag_offgrid_compact", "mel_pcm16", "mdct_pcm16", "dct1000")   # one-sided pair (8f rank 4) and geometries off the benchmark's grid
+EXTRA_KINDS = ("stft1", "stftmag", "istft1", "stft_offgrid", "mdct_offgrid", "stft4096", "stft4096_h1024", "istft4096", "mdct4096", "mel4096", "dct", "stft64", "mdct64", "istft_offgrid", "imdct_offgrid", "stftmag_offgrid", "stft8192", "mdct8192", "istft64", "imdct64", "mel64", "mfcc64", "cqt64", "istft_offgrid_compact", "stftmag_offgrid_compact", "mel_pcm16", "mdct_pcm16", "dct1000", "istft8192", "imdct8192")   # one-sided pair (8f rank 4) and geometries off the benchmark's grid
 
 
 def synth(seed, c, n):
@@ -119,9 +119,9 @@ def make_workload(kind, device, layout="FT"):
         T = 217
     if kind in ("mdct_offgrid", "imdct_offgrid"):
         N, T = 442024, 433       # ceil(N / 1024) + 1 (zaf.py:1033): float32 rows of 1732 B
-    if kind == "stft8192":
+    if kind in ("stft8192", "istft8192"):
         N, T = 4096 * 111, 112    # W = 8192, hop 4096, on the line grid: ceil(N / 4096) + 1 frames
-    if kind == "mdct8192":
+    if kind in ("mdct8192", "imdct8192"):
         N, T = 4096 * 127, 128    # W = 8192 MDCT on the line grid: ceil(N / 4096) + 1 frames (zaf.py:1033)
     if kind in ("mdct4096", "mel4096", "istft4096"):
         T = 217                   # mdct: ceil(N / 2048) + 1 (odd: rows off the line grid); mel: hop 2048
@@ -164,6 +164,22 @@ def make_workload(kind, device, layout="FT"):
         plan = zafx.stft_plan(zafx.hamming(8192), 4096, layout=layout, device=device)
         wl.update(plan=plan, d_in=d_x, n_in=N, bytes_per_launch=B * (4 * N + 8 * 8192 * T),
                   desc="Batched STFT, win=8192 hop=4096: 1024 clips x 10.3 s, T = 112, two-sided c64 (W,T) layout")
+    elif kind in ("istft8192", "imdct8192"):   # the inverse kinds at W = 8192 (round 6: k_istft_ft8q), input = the device's own forward result
+        w8 = zafx.hamming(8192) if kind == "istft8192" else zafx.kaiser_bessel_derived(8192)
+        fwd = zafx.stft_plan(w8, 4096, device=device) if kind == "istft8192" else zafx.mdct_plan(w8, device=device)
+        d_s = zafx.DeviceBuffer(fwd.out_shape(B, N), fwd.out_dtype, device)
+        fwd.execute(d_x, d_s, B, N)
+        INNER_LOG.append({"kind": None, "kernel": fwd.last_kernel, "launches": 1})
+        fwd.sync()
+        d_x.free()
+        if kind == "istft8192":
+            plan = zafx.istft_plan(w8, 4096, device=device)
+            wl.update(plan=plan, d_in=d_s, n_in=T, bytes_per_launch=B * (8 * 8192 * T + 4 * (T - 1) * 4096),
+                      desc="Batched ISTFT, win=8192 hop=4096: 1024 clips x 112 frames, two-sided c64 (W,T) layout")
+        else:
+            plan = zafx.mdct_plan(w8, device=device, inverse=True)
+            wl.update(plan=plan, d_in=d_s, n_in=T, bytes_per_launch=B * (4 * 4096 * T + 4 * (4096 * (T - 1) - 1)),
+                      desc="Batched IMDCT, KBD win=8192: 1024 clips x 128 frames")
     elif kind == "mdct8192":         # k_mdct_ft32q: four bands of bins per 32-frame tile
         plan = zafx.mdct_plan(zafx.kaiser_bessel_derived(8192), device=device)
         wl.update(plan=plan, d_in=d_x, n_in=N, bytes_per_launch=B * (4 * N + 4 * 4096 * T),
@@ -521,7 +537,7 @@ def parity_probe(wl):
         ref = orc.mdct(x64, orc.kbd_window(8192))
     elif kind == "mel4096":
         ref = orc.melspectrogram(x64, orc.hamming_periodic(4096), 2048, orc.melfilterbank(FS, 4096, 128))
-    elif kind in ("istft", "istft1", "istft4096", "istft_offgrid", "istft64", "imdct64"):
+    elif kind in ("istft", "istft1", "istft4096", "istft_offgrid", "istft64", "imdct64", "istft8192", "imdct8192"):
         ref = None   # (checked as a round trip below: the device spectrum is the input)
     elif kind in ("mdct", "mdct_offgrid", "mdct64", "mdct_pcm16"):
         ref = orc.mdct(x64, kbd)
@@ -553,7 +569,8 @@ def parity_probe(wl):
         tol = 1e-11 if kind.endswith("64") else 1e-5
         out.update({"roundtrip_max_abs_residual": d, "tolerance": tol, "within_tolerance": bool(d < tol)})
         if kind.startswith("imdct"):
-            refy = orc.imdct(orc.mdct(x64, kbd), kbd)
+            kw = orc.kbd_window(8192) if kind == "imdct8192" else kbd
+            refy = orc.imdct(orc.mdct(x64, kw), kw)
             e = float(np.max(np.abs(first - refy)) / np.max(np.abs(refy)))
             out.update({"max_rel_err_vs_numpy": e, "within_tolerance": bool(d < tol and e <= (1e-12 if kind.endswith("64") else 1e-5))})
         return out

@@ -560,6 +560,36 @@ def test_mel_mfcc_outside_the_one_pass_kernel(zafx):
         zafx.Plan(zafx.MEL, window_length=2048, step_length=1024, n_filters=64, with_mel=True)
 
 
+@pytest.mark.parametrize("n,clips", [(4096 * 11 + 100, 2), (4096 * 30, 3), (5000, 1), (4096 * 70 + 1, 5), (4096 * 15, 300)])
+def test_istft_w8192_four_classes(zafx, n, clips):
+    """W = 8192, hop 4096 in the reference layout: k_istft_ft8q (round 6: the rows class by class -- 4q, 8p + 2, 8p + 1, 8p + 5 and their mirrors --,
+    one 1024-point inverse per class and frame, the quarter frames out of butterflies in registers; zaf.py:223 and :226-241 are what it
+    replaces) -- odd and even frame counts (8-byte and 16-byte row pieces), one and many tiles per clip, clips cut into segments, one-sided
+    input, an input that is not Hermitian, padded rows; other hops stay on the generic kernel."""
+    x = np.stack([synth_clip(73, c % 5, n) for c in range(clips)])
+    w = zafx.hamming(8192)
+    spec = np.stack([orc.stft(x[c].astype(np.float64), w, 4096) for c in range(min(clips, 5))])
+    spec = spec[np.arange(clips) % spec.shape[0]].astype(np.complex64)
+    ref = [orc.istft(spec[c].astype(np.complex128), w, 4096) for c in range(min(clips, 5))]
+    for one in (False, True):
+        y = zafx.istft_batch(np.ascontiguousarray(spec[:, :4097] if one else spec), w, 4096, onesided=one)
+        assert zafx.istft_plan(w, 4096, onesided=one).last_kernel == "k_istft_ft8q"
+        assert y.shape == (clips, len(ref[0]))
+        for c in range(clips):
+            assert relerr(y[c], ref[c % 5]) <= TOL_FFT, (one, c)
+        k = min(n, y.shape[1])
+        assert np.max(np.abs(y[:, :k] - x[:, :k])) < 1e-5   # COLA resynthesis (zaf.py:165-194)
+    rng = np.random.default_rng(n)
+    noisy = (spec[:2] + 0.05 * (rng.standard_normal(spec[:2].shape) + 1j * rng.standard_normal(spec[:2].shape))).astype(np.complex64)
+    y = zafx.istft_batch(noisy, w, 4096)
+    for c in range(len(noisy)):
+        assert relerr(y[c], orc.istft(noisy[c].astype(np.complex128), w, 4096)) <= TOL_FFT   # real(ifft(.)) of anything (zaf.py:223)
+    pl = zafx.istft_plan(w, 4096, row_align=16)
+    assert relerr(pl.run_host(spec[:1], spec.shape[2]), np.stack(ref[:1])) <= TOL_FFT and pl.last_kernel == "k_istft_ft8q"
+    zafx.istft_batch(np.stack([orc.stft(x[0].astype(np.float64), w, 2048)]).astype(np.complex64), w, 2048)
+    assert zafx.istft_plan(w, 2048).last_kernel != "k_istft_ft8q"
+
+
 def test_batch_functions_pad_rows_off_the_line_grid(zafx):
     """The default of the STFT / MDCT *_batch functions (round 6, zafx.set_row_padding("auto")): a frame count off the 128-byte line grid of the
     (F, T) rows runs on a row-padded device array -- the kernels' on-grid forms -- and the NumPy array handed back is a view of the padded

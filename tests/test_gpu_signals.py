@@ -233,6 +233,8 @@ def test_signal_on_the_other_kernels(zafx, name, wl, hop):
     y = zafx.istft_batch(s[None], ham, hop)[0]
     yref = orc.istft(s, ham, hop)
     assert len(y) == len(yref) and relerr(y, yref) <= TOL_FFT
+    if wl == 8192:
+        assert zafx.istft_plan(ham, hop).last_kernel == "k_istft_ft8q"
     nu = bin_noise(half, C_FLOOR, EPS32)
     gotm = zafx.stft_batch(x[None], ham, hop, onesided="magnitude")[0]
     assert check(f"{tag}.magnitude", gotm, np.abs(half), TOL_FFT, nu) <= TOL_FFT

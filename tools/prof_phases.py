@@ -27,6 +27,19 @@ if kind == "istft":
     fwd.sync()
     n_in, tiles = T, 27
     d_out = zafx.DeviceBuffer((B, plan.out_dims(T)[0]), np.float32)
+elif kind == "istft8192":
+    w = zafx.hamming(8192)
+    N = 4096 * 111
+    x = np.random.default_rng(0).standard_normal((8, N)).astype(np.float32)
+    d_x.free()
+    d_x = zafx.DeviceBuffer.from_host(np.tile(x, (B // 8, 1)))
+    fwd, plan = zafx.stft_plan(w, 4096), zafx.istft_plan(w, 4096)
+    F, T = fwd.out_dims(N)
+    d_in = zafx.DeviceBuffer((B, F, T), np.complex64)
+    fwd.execute(d_x, d_in, B, N)
+    fwd.sync()
+    n_in, tiles = T, 14
+    d_out = zafx.DeviceBuffer((B, plan.out_dims(T)[0]), np.float32)
 elif kind in ("stft", "stft1"):
     plan = zafx.stft_plan(zafx.hamming(W), H, onesided=kind == "stft1")
     F, T = plan.out_dims(N)
@@ -87,7 +100,7 @@ elif kind == "cqt":
     d_out = zafx.DeviceBuffer((B, F, T), np.float32)
 else:
     raise SystemExit("kind must be istft, mdct, imdct or cqt")
-name = "zafx_debug_prof_" + {"mfcc": "mel", "stft1": "stft", "spec": "mel", "mfcc64": "mel64"}.get(kind, kind)
+name = "zafx_debug_prof_" + {"mfcc": "mel", "stft1": "stft", "spec": "mel", "mfcc64": "mel64", "istft8192": "istft"}.get(kind, kind)
 fn = getattr(lib, name)
 out = (ctypes.c_ulonglong * 16)()
 # optional second argument: the waves to time, e.g. "0,5,15" or "all" (default: wave 1)

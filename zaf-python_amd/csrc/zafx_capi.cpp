@@ -979,7 +979,7 @@ int zafx_plan_create(zafx_plan** out, int device, int kind, const zafx_params* p
         const auto sub = build_pass_twiddles(10, 4);   // the two 1024-point band transforms of k_stft_ft16b
         e = upload(&pl->d_tw_sub, sub.data(), sub.size() * sizeof(cf32));
     }
-    if (e == hipSuccess && (kind == ZAFX_STFT || kind == ZAFX_MEL || kind == ZAFX_MFCC) && pl->log2nf == 12 && pl->prm.precision == ZAFX_PRECISION_F32 && pl->bs_log2m == 0) {
+    if (e == hipSuccess && (kind == ZAFX_STFT || kind == ZAFX_ISTFT || kind == ZAFX_MEL || kind == ZAFX_MFCC) && pl->log2nf == 12 && pl->prm.precision == ZAFX_PRECISION_F32 && pl->bs_log2m == 0) {
         const auto sub = build_pass_twiddles(10, 4);   // the four 1024-point class transforms of k_stft_ft16q, and the roots that form their inputs
         e = upload(&pl->d_tw_sub, sub.data(), sub.size() * sizeof(cf32));
         std::vector<cf32> q(4096);

@@ -2688,6 +2688,304 @@ static hipError_t run_istft_band(const zafx_plan& pl, const float2* spec, float*
     return hipGetLastError();
 }
 
+// ---------------------------------------------------------------------------------
+// inverse, reference layout, W = 8192, hop = W / 2: four CLASSES of rows per 8-frame tile (k_istft_ft8q; round 6)
+// ---------------------------------------------------------------------------------
+// The transpose of k_stft_ft16q.  The spectrum is the large side (16 bytes of it per output sample), so every row is read ONCE, and the
+// rows are taken class by class -- with x_m[n] = v[n + 2048 m] the quarter frames of the real frame v = real(ifft(X)) (zaf.py:223) and Xh the
+// Hermitian part (X[k] + conj X[W-k]) / 2 of an arbitrary input:
+//   rows 4q            = DFT_2048(s)[q],  s = x0 + x1 + x2 + x3 (real): the W = 2048 inverse (unsplit_pair + one 1024-point transform)
+//   rows 8p + 2 (+ 6)  = DFT_1024(g)[p],  g[n] = (r[n] - i r[n + 1024]) w_4096^n,  r = x0 - x1 + x2 - x3
+//   rows 8p + 1 (+ 7)  = DFT_1024(u)[p],  u[n] = h[n] + h[n + 1024],  h[n] = ((x0 - x2) - i (x1 - x3))[n] w_8192^n
+//   rows 8p + 5 (+ 3)  = DFT_1024(d)[p],  d[n] = (h[n] - h[n + 1024]) w_2048^n
+// (the rows in parentheses are the mirrors that complete the Hermitian part).  Each class is ONE 1024-point inverse transform per frame: a
+// round is gather + fold by the whole workgroup, then a wavefront transforms its frame in its own buffer and reads ITS share of the result
+// into registers -- lane l keeps the indices n = 4 l + 256 i + c (+ 1024) of s, r, u: 96 registers through the four rounds -- and the quarter
+// frames come out of four-point butterflies in registers: x0, x2 = s/4 + r/4 +- e/2, x1, x3 = s/4 - r/4 +- o/2.  Neither the four rounds of partial
+// results nor the tile's output fit LDS, and at 1024 threads not the registers either: hence 8-frame tiles (64-byte row pieces), 8 waves, 256
+// registers.  Overlap-add in the reference's ascending frame order (zaf.py:226-233): a frame's second half goes through LDS to the wave of
+// the next frame (the tile's last one to the next tile), which adds its first half and stores 16-byte pieces; the trim of zaf.py:236-238
+// drops frame 0's first half and the last frame's second.
+#ifndef ZAFX_ISTFT_QUAD
+#define ZAFX_ISTFT_QUAD 1
+#endif
+#ifndef ZAFX_ISTFT_QUAD_FV
+#define ZAFX_ISTFT_QUAD_FV 2   // frames per lane and load where the row pitch is even
+#endif
+#ifndef ZAFX_ISTFT_QUAD_DEPTH
+#define ZAFX_ISTFT_QUAD_DEPTH 2   // sweeps of a class's gather in flight per thread (two loads each; class A: four loads, half as many sweeps): 1 / 2 / 3 / 4 / 8 / 16 measured 3.32 / 3.00 / 3.14 / 3.35 / 3.15 / 5.01 ms -- shallow queues, as k_istft_ft16 found
+#endif
+#ifndef ZAFX_ISTFT_QUAD_PF
+#define ZAFX_ISTFT_QUAD_PF 0   // sweeps (of 16) of a class requested ahead of the transform before it: 2 / 4 / 8 measured 3.59 / 3.50 / 3.79 ms against 3.35 (they spill)
+#endif
+struct IstftQCfg {
+    using C = FftCfg<10, 4>;
+    static constexpr int N = C::N, FPB = 8, NT = 512, PITCH = C::PITCH, HALF = 4096;
+    static constexpr size_t REGION = (size_t)(FPB - 1) * HALF * 4 > (size_t)FPB * PITCH * 8 ? (size_t)(FPB - 1) * HALF * 4 : (size_t)FPB * PITCH * 8;
+    static constexpr size_t SMEM = REGION + 2 * HALF * 4 + (size_t)(C::TW + N / 2 + 1) * 8;
+};
+static_assert(IstftQCfg::SMEM <= (size_t)kMaxLdsBytes, "k_istft_ft8q: tile + carries + tables exceed LDS");
+
+// FV: frames per lane and load (2: 16-byte loads of two adjacent frames; needs an even row pitch)
+template <bool ONE, int FV>
+__global__ __launch_bounds__(IstftQCfg::NT) void k_istft_ft8q(const float2* __restrict__ spec, const float2* __restrict__ twp, const float2* __restrict__ twq,
+                                                               float* __restrict__ y, int T, int TP, long long out_len, float scale, int tiles, int segs,
+                                                               int seg_tiles, int total_units) {
+    using Q = IstftQCfg;
+    using C = Q::C;
+    constexpr int N = C::N, P = 64, E = C::E, W = 8192, FPB = Q::FPB, NT = Q::NT, PITCH = Q::PITCH, HALF = Q::HALF, ROWS = ONE ? W / 2 + 1 : W;
+    static_assert(C::P == 64, "a frame's 1024-point transform is one wavefront's");
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    float2* frames = reinterpret_cast<float2*>(smem_raw);        // FPB transform buffers ...
+    float* xch = reinterpret_cast<float*>(smem_raw);              // ... and, behind the fourth round, FPB - 1 second halves of frames
+    float* carry = reinterpret_cast<float*>(smem_raw + Q::REGION);   // the tile's last second half, by tile parity
+    float2* tw_l = reinterpret_cast<float2*>(carry + 2 * HALF);
+    float2* tws_l = tw_l + C::TW;                                 // exp(-2 pi i k / 2048), k <= 512: the split roots of class A
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    constexpr int LPR = FPB / FV, KS = NT / LPR;                  // lanes per row piece, rows per sweep (64 or 128)
+    const int fr = (tid % LPR) * FV, kq = tid / LPR;              // gather: my first frame of the tile, my row within a sweep
+    for (int i = tid; i < C::TW; i += NT) tw_l[i] = twp[i];
+    for (int i = tid; i <= N / 2; i += NT) tws_l[i] = twq[4 * i];
+    for (int i = tid; i < 2 * HALF; i += NT) carry[i] = 0.f;
+    lds_barrier();
+    const int row_bytes = TP * 8;
+    float2* const fb = frames + fr * PITCH;      // the buffer my gathers fold into
+    float2* const buf = frames + wave * PITCH;   // the buffer my wave transforms
+
+    PROF_INIT(g_prof);
+    for (int unit = blockIdx.x; unit < total_units; unit += gridDim.x) {
+        const int seg = unit % segs;
+        const long long clip = unit / segs;
+        const int tile_a = seg * seg_tiles, tile_b = min(tile_a + seg_tiles, tiles);
+        const auto rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float2*>(spec) + clip * ROWS * TP, 0, ROWS * row_bytes, 0x00020000);
+        float* const yc = y + clip * out_len;
+        for (int tile = tile_a > 0 ? tile_a - 1 : 0; tile < tile_b; ++tile) {
+            const bool write_out = tile >= tile_a;   // (the tile in front of a segment only leaves its last second half behind)
+            const int t0 = tile * FPB, par = tile & 1;
+            int lo = lane;
+            asm volatile("" : "+v"(lo));   // (opaque per tile: addresses are recomputed, not carried -- spilled -- across the rounds)
+            const int tb = (t0 + fr) * 8;  // byte offset of my frame within a row
+            using RV = std::conditional_t<FV == 2, float4, float2>;   // X[row] of my FV frames
+            auto raw = [&](int row) {
+                RV f;
+                if constexpr (FV == 2) {
+                    const auto v = __builtin_amdgcn_raw_buffer_load_b128(rsrc, row * row_bytes + tb, 0, 0);
+                    __builtin_memcpy(&f, &v, 16);
+                } else {
+                    const auto v = __builtin_amdgcn_raw_buffer_load_b64(rsrc, row * row_bytes + tb, 0, 0);
+                    __builtin_memcpy(&f, &v, 8);
+                }
+                return f;
+            };
+            auto conj_rv = [](RV v) {
+                if constexpr (FV == 2) return make_float4(v.x, -v.y, v.z, -v.w);
+                else return cconj(v);
+            };
+            auto part = [](RV v, int f) {   // frame f of a piece
+                if constexpr (FV == 2) return f ? make_float2(v.z, v.w) : make_float2(v.x, v.y);
+                else return v;
+            };
+            auto xat = [&](int k) {        // X[k], k < W: a one-sided input completes X[W - k] = conj X[k]
+                if (ONE && k > W / 2) return conj_rv(raw(W - k));
+                return raw(k);
+            };
+            // lane l of a wave keeps the indices j = 4 l + 256 i + c (c < 4, i < 4) and j + 1024 of its frame's sequences
+            float sA[4][2][4], rB[4][2][4];
+            float2 uC[4][4];
+            float own[4][2][2][4];   // [i][m = 0, 1][h][c]: first half of the frame (x0, x1)
+            // ---- classes B, C, D: rows 8p + c0 and their mirrors W - (8p + c0): 2 Xh[8p + c0], swapped.  The first PF sweeps of a class are
+            //      requested in front of the transform of the class before it and ride in registers across it (issue_class / fold_class).
+            constexpr int PF = ZAFX_ISTFT_QUAD_PF;
+            RV pa[PF > 0 ? PF : 1], pb[PF > 0 ? PF : 1];
+            auto issue_class = [&](int c0) {
+#pragma unroll
+                for (int sw = 0; sw < PF; ++sw) {
+                    const int a = 8 * (kq + KS * sw) + c0;
+                    if (ONE) pa[sw] = xat(a);
+                    else pa[sw] = raw(a), pb[sw] = raw(W - a);
+                }
+            };
+            auto fold_row = [&](int p, RV va, RV vb) {
+#pragma unroll
+                for (int f = 0; f < FV; ++f) {
+                    const float2 qa = part(va, f), qb = part(vb, f);
+                    const float2 g = ONE ? make_float2(2.f * qa.x, 2.f * qa.y) : make_float2(qa.x + qb.x, qa.y - qb.y);
+                    fb[f * PITCH + phys(p)] = make_float2(g.y, g.x);
+                }
+            };
+            auto fold_class = [&](int c0) {
+                lds_barrier();   // every wave has read the class before
+#pragma unroll
+                for (int sw = 0; sw < PF; ++sw) fold_row(kq + KS * sw, pa[sw], pb[sw]);
+#pragma unroll ZAFX_ISTFT_QUAD_DEPTH
+                for (int sw = PF; sw < 1024 / KS; ++sw) {
+                    const int p = kq + KS * sw, a = 8 * p + c0;
+                    if (ONE) fold_row(p, xat(a), RV{});
+                    else fold_row(p, raw(a), raw(W - a));
+                }
+            };
+            PROF_MARK(0);
+            // ---- class A: rows 4q, the W = 2048 inverse
+#pragma unroll (ZAFX_ISTFT_QUAD_DEPTH / 2 > 0 ? ZAFX_ISTFT_QUAD_DEPTH / 2 : 1)
+            for (int sw = 0; sw < 512 / KS; ++sw) {
+                const int k = kq + KS * sw;
+                if (k == 0) {
+                    const RV r0 = xat(0), r1 = xat(2048), r2 = xat(4096), r3 = ONE ? conj_rv(r1) : xat(6144);
+#pragma unroll
+                    for (int f = 0; f < FV; ++f) {
+                        const float2 q0 = part(r0, f), q1 = part(r1, f), q2 = part(r2, f), q3 = part(r3, f);
+                        const float a0 = 2.f * q0.x, an = 2.f * q2.x;
+                        fb[f * PITCH] = make_float2(a0 - an, a0 + an);
+                        const float2 a = make_float2(q1.x + q3.x, q1.y - q3.y);
+                        fb[f * PITCH + phys(N / 2)] = make_float2(-2.f * a.y, 2.f * a.x);
+                    }
+                } else {
+                    const RV r0 = xat(4 * k), r2 = xat(4096 - 4 * k);
+                    const RV r1 = ONE ? conj_rv(r0) : xat(W - 4 * k), r3 = ONE ? conj_rv(r2) : xat(4096 + 4 * k);
+#pragma unroll
+                    for (int f = 0; f < FV; ++f) {
+                        float2 zk, zn;
+                        unsplit_pair(part(r0, f), part(r1, f), part(r2, f), part(r3, f), tws_l[k], zk, zn);
+                        fb[f * PITCH + phys(k)] = zk;
+                        fb[f * PITCH + phys(N - k)] = zn;
+                    }
+                }
+            }
+            auto transform = [&]() {   // my wave's frame: forward transform of the swapped spectrum = swapped inverse transform
+                lds_barrier();
+                float2 v[E];
+                regs_read<10, 4>(v, buf, lo);
+                frame_sync<P>();
+                fft_frame<10, 4>(v, buf, lo, tw_l);
+                frame_sync<P>();
+            };
+            PROF_MARK(1);
+            issue_class(2);
+            transform();
+            PROF_MARK(2);
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int h = 0; h < 2; ++h) {
+                    const float2 q0 = buf[phys(2 * lo + 128 * i + 512 * h)], q1 = buf[phys(2 * lo + 1 + 128 * i + 512 * h)];   // (s[2n + 1], s[2n])
+                    sA[i][h][0] = q0.y, sA[i][h][1] = q0.x, sA[i][h][2] = q1.y, sA[i][h][3] = q1.x;
+                }
+            float2 w8[4][4];   // exp(-2 pi i j / 8192) of my indices
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int c = 0; c < 4; ++c) w8[i][c] = twq[4 * lo + 256 * i + c];
+            PROF_MARK(3);
+            fold_class(2);
+            PROF_MARK(4);
+            issue_class(1);
+            transform();
+            PROF_MARK(5);
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                    const float2 q = buf[phys(4 * lo + 256 * i + c)];
+                    const float2 w4 = cmul(w8[i][c], w8[i][c]);                  // w_4096^j
+                    const float2 cb = cmulc(make_float2(q.y, q.x), w4);          // g conj(w_4096^j) = 2 (r[j] - i r[j + 1024])
+                    rB[i][0][c] = cb.x, rB[i][1][c] = -cb.y;
+                }
+            fold_class(1);
+            PROF_MARK(6);
+            issue_class(5);
+            transform();
+            PROF_MARK(7);
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                    const float2 q = buf[phys(4 * lo + 256 * i + c)];
+                    uC[i][c] = make_float2(q.y, q.x);
+                }
+            fold_class(5);
+            PROF_MARK(8);
+            transform();
+            PROF_MARK(9);
+            float sec[4][2][2][4];   // [i][m - 2][h][c]: second half of the frame (x2, x3)
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                    const float2 q = buf[phys(4 * lo + 256 * i + c)];
+                    const float2 w1 = w8[i][c], w4 = cmul(w1, w1), w2 = cmul(w4, w4);          // w_8192^j, w_4096^j, w_2048^j
+                    const float2 dd = cmulc(make_float2(q.y, q.x), w2);                        // d conj(w_2048^j)
+                    const float2 h0 = make_float2(uC[i][c].x + dd.x, uC[i][c].y + dd.y), h1 = make_float2(uC[i][c].x - dd.x, uC[i][c].y - dd.y);   // 2 h[j], 2 h[j + 1024]
+                    const float2 w1b = cmul(w1, make_float2(0.70710678118654752440f, -0.70710678118654752440f));   // w_8192^(j + 1024)
+                    const float2 c0 = cmulc(h0, w1), c1 = cmulc(h1, w1b);                      // ((x0 - x2) - i (x1 - x3)) x 4, at j and j + 1024
+                    const float e[2] = {c0.x, c1.x}, o[2] = {-c0.y, -c1.y};
+#pragma unroll
+                    for (int h = 0; h < 2; ++h) {
+                        const float b = 0.5f * sA[i][h][c], r = rB[i][h][c];
+                        own[i][0][h][c] = (b + r) + e[h];   // x0
+                        sec[i][0][h][c] = (b + r) - e[h];   // x2
+                        own[i][1][h][c] = (b - r) + o[h];   // x1
+                        sec[i][1][h][c] = (b - r) - o[h];   // x3
+                    }
+                }
+            PROF_MARK(10);
+            lds_barrier();   // every wave has read its class D: the buffers become the exchange area
+            {
+                float* dst = wave == FPB - 1 ? carry + par * HALF : xch + wave * HALF;
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+#pragma unroll
+                    for (int m = 0; m < 2; ++m)
+#pragma unroll
+                        for (int h = 0; h < 2; ++h)
+                            *reinterpret_cast<float4*>(dst + 2048 * m + 1024 * h + 256 * i + 4 * lo) =
+                                make_float4(sec[i][m][h][0], sec[i][m][h][1], sec[i][m][h][2], sec[i][m][h][3]);
+            }
+            lds_barrier();
+            {
+                const int t = t0 + wave;
+                const float* src = wave == 0 ? carry + (par ^ 1) * HALF : xch + (wave - 1) * HALF;
+                const bool store = write_out && t >= 1 && t < T;   // frame t's first half + frame t - 1's second = samples (t - 1) hop ... t hop of the trimmed clip
+                float* o = yc + (long long)(t - 1) * HALF + 4 * lo;
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+#pragma unroll
+                    for (int m = 0; m < 2; ++m)
+#pragma unroll
+                        for (int h = 0; h < 2; ++h) {
+                            const float4 pv = *reinterpret_cast<const float4*>(src + 2048 * m + 1024 * h + 256 * i + 4 * lo);
+                            const float4 v = make_float4((pv.x + own[i][m][h][0]) * scale, (pv.y + own[i][m][h][1]) * scale, (pv.z + own[i][m][h][2]) * scale,
+                                                         (pv.w + own[i][m][h][3]) * scale);
+                            if (store) *reinterpret_cast<float4*>(o + 2048 * m + 1024 * h + 256 * i) = v;
+                        }
+            }
+            lds_barrier();   // the exchange area is read: the next tile folds into it
+            PROF_MARK(11);
+        }
+        // (a unit's first tile reads the carry of the tile before it: a clip starts with zeros there)
+        lds_barrier();
+        for (int i = tid; i < 2 * HALF; i += NT) carry[i] = 0.f;
+        lds_barrier();
+    }
+}
+
+template <bool ONE>
+static hipError_t run_istft_quad(const zafx_plan& pl, const float2* spec, float* y, int64_t n_clips, int T, int64_t out_len) {
+    using Q = IstftQCfg;
+    const int tiles = (T + Q::FPB - 1) / Q::FPB;
+    if ((long long)tiles * n_clips <= 0 || out_len <= 0) return hipSuccess;
+    const bool wide = ZAFX_ISTFT_QUAD_FV == 2 && row_pitch(pl, T) % 2 == 0 && reinterpret_cast<uintptr_t>(spec) % 16 == 0;   // 16-byte pieces of two frames
+    auto kern = wide ? k_istft_ft8q<ONE, 2> : k_istft_ft8q<ONE, 1>;
+    if (hipError_t e = ensure_dynamic_lds(reinterpret_cast<const void*>(kern), pl.device, Q::SMEM); e != hipSuccess) return e;
+    const int segs = carry_segments(n_clips, tiles, pl.n_cus);
+    const int seg_tiles = (tiles + segs - 1) / segs;
+    const long long units = n_clips * segs;
+    const float scale = 1.f / (8192.f * pl.cola_gain);   // 1 / W of the inverse transform (the classes carry 2 Xh); zaf.py:241
+    pl.ran = "k_istft_ft8q";
+    hipLaunchKernelGGL(kern, dim3((unsigned)std::min<long long>(units, pl.n_cus)), dim3(Q::NT), Q::SMEM, pl.stream, spec, pl.d_tw_sub, pl.d_tw_quad, y, T,
+                       (int)row_pitch(pl, T), (long long)out_len, scale, tiles, segs, seg_tiles, (int)units);
+    return hipGetLastError();
+}
+
 template <int LOG2N, int LAYOUT, bool ONE>
 static hipError_t run_istft(const zafx_plan& pl, const float2* spec, float* y, int64_t n_clips, int T, int64_t out_len) {
     if constexpr (ZAFX_ISTFT_BAND && LOG2N == 11 && LAYOUT == ZAFX_LAYOUT_FT) {
@@ -2697,6 +2995,13 @@ static hipError_t run_istft(const zafx_plan& pl, const float2* spec, float* y, i
         if (pl.d_tw_sub && pl.H % 4 == 0 && pl.H >= 512 && pl.H <= 4096 && reinterpret_cast<uintptr_t>(spec) % 8 == 0 &&
             (long long)4096 * TP * 8 < (1LL << 31) && 2LL * n_clips * ((T + 15) / 16) < (1LL << 30))
             return run_istft_band<ONE>(pl, spec, y, n_clips, T, out_len);
+    }
+    if constexpr (ZAFX_ISTFT_QUAD && LOG2N == 12 && LAYOUT == ZAFX_LAYOUT_FT) {
+        // W = 8192, hop = W / 2: the four-class kernel (32-bit byte offsets inside a clip's spectrum, 16-byte stores into the clip's samples)
+        const int64_t TP = row_pitch(pl, T);
+        if (pl.d_tw_sub && pl.d_tw_quad && pl.H == 4096 && reinterpret_cast<uintptr_t>(spec) % 8 == 0 && reinterpret_cast<uintptr_t>(y) % 16 == 0 &&
+            (long long)8192 * TP * 8 < (1LL << 31) && n_clips * (((long long)T + 7) / 8 + 1) < (1LL << 30))
+            return run_istft_quad<ONE>(pl, spec, y, n_clips, T, out_len);
     }
     if constexpr (stft_use_fat(LOG2N, LAYOUT)) {
         // the carry kernel addresses a clip through one buffer descriptor (32-bit byte offsets)

@@ -590,6 +590,39 @@ def test_istft_w8192_four_classes(zafx, n, clips):
     assert zafx.istft_plan(w, 2048).last_kernel != "k_istft_ft8q"
 
 
+@pytest.mark.parametrize("n,clips", [(4096 * 11 + 100, 2), (4096 * 30, 3), (5000, 1), (4096 * 70 + 1, 5), (4096 * 15, 300)])
+def test_imdct_w8192_two_classes(zafx, n, clips):
+    """W = 8192 in the reference layout: k_imdct_q (round 6: the coefficient rows as two classes by the parity of m -- 4m', M-1-4m' and 4m'+2,
+    M-3-4m' --, one 1024-point transform per class and frame, joined in registers; zaf.py:1138-1182 is what it replaces) -- frame counts on and
+    off the 16-byte grid of the rows (off it the batch function pads; the compact array stays on the generic kernel), one and many tiles per
+    clip, clips cut into segments, coefficients that are no MDCT of anything, TDAC reconstruction."""
+    x = np.stack([synth_clip(79, c % 5, n) for c in range(clips)])
+    w = zafx.kaiser_bessel_derived(8192)
+    co = np.stack([orc.mdct(x[c].astype(np.float64), w) for c in range(min(clips, 5))])
+    ref = [orc.imdct(co[c], w) for c in range(len(co))]
+    co = co[np.arange(clips) % co.shape[0]].astype(np.float32)
+    zafx.set_row_padding("auto")
+    try:
+        y = zafx.imdct_batch(co, w)
+        T = co.shape[2]
+        assert zafx.mdct_plan(w, inverse=True, row_align=0 if T % 32 == 0 else 32).last_kernel == "k_imdct_q"
+        assert y.shape == (clips, len(ref[0]))
+        for c in range(clips):
+            assert relerr(y[c], ref[c % 5]) <= TOL_FFT, c
+        k = min(n, y.shape[1])
+        assert np.max(np.abs(y[:, :k] - x[:, :k])) < 1e-5   # TDAC (zaf.py:1060-1096 then :1099-1185)
+        rng = np.random.default_rng(n)
+        noisy = (co[:2] + 0.05 * rng.standard_normal(co[:2].shape)).astype(np.float32)
+        y = zafx.imdct_batch(noisy, w)
+        for c in range(len(noisy)):
+            assert relerr(y[c], orc.imdct(noisy[c].astype(np.float64), w)) <= TOL_FFT
+    finally:
+        zafx.set_row_padding("compact")
+    if T % 4:
+        zafx.imdct_batch(co[:1], w)
+        assert zafx.mdct_plan(w, inverse=True).last_kernel != "k_imdct_q"   # compact rows off the 16-byte grid: the generic kernel
+
+
 def test_batch_functions_pad_rows_off_the_line_grid(zafx):
     """The default of the STFT / MDCT *_batch functions (round 6, zafx.set_row_padding("auto")): a frame count off the 128-byte line grid of the
     (F, T) rows runs on a row-padded device array -- the kernels' on-grid forms -- and the NumPy array handed back is a view of the padded

@@ -40,6 +40,19 @@ elif kind == "istft8192":
     fwd.sync()
     n_in, tiles = T, 14
     d_out = zafx.DeviceBuffer((B, plan.out_dims(T)[0]), np.float32)
+elif kind == "imdct8192":
+    w = zafx.kaiser_bessel_derived(8192)
+    N = 4096 * 111
+    x = np.random.default_rng(0).standard_normal((8, N)).astype(np.float32)
+    d_x.free()
+    d_x = zafx.DeviceBuffer.from_host(np.tile(x, (B // 8, 1)))
+    fwd, plan = zafx.mdct_plan(w), zafx.mdct_plan(w, inverse=True)
+    F, T = fwd.out_dims(N)
+    d_in = zafx.DeviceBuffer((B, F, T), np.float32)
+    fwd.execute(d_x, d_in, B, N)
+    fwd.sync()
+    n_in, tiles = T, (T + 15) // 16
+    d_out = zafx.DeviceBuffer((B, plan.out_dims(T)[0]), np.float32)
 elif kind in ("stft", "stft1"):
     plan = zafx.stft_plan(zafx.hamming(W), H, onesided=kind == "stft1")
     F, T = plan.out_dims(N)
@@ -100,7 +113,7 @@ elif kind == "cqt":
     d_out = zafx.DeviceBuffer((B, F, T), np.float32)
 else:
     raise SystemExit("kind must be istft, mdct, imdct or cqt")
-name = "zafx_debug_prof_" + {"mfcc": "mel", "stft1": "stft", "spec": "mel", "mfcc64": "mel64", "istft8192": "istft"}.get(kind, kind)
+name = "zafx_debug_prof_" + {"mfcc": "mel", "stft1": "stft", "spec": "mel", "mfcc64": "mel64", "istft8192": "istft", "imdct8192": "imdct"}.get(kind, kind)
 fn = getattr(lib, name)
 out = (ctypes.c_ulonglong * 16)()
 # optional second argument: the waves to time, e.g. "0,5,15" or "all" (default: wave 1)

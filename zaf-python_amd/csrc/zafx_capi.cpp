@@ -993,6 +993,13 @@ int zafx_plan_create(zafx_plan** out, int device, int kind, const zafx_params* p
         for (int n = 0; n < 2048; ++n) q[(size_t)n] = unit_root(n, 2048);
         if (e == hipSuccess) e = upload(&pl->d_tw_quad, q.data(), q.size() * sizeof(cf32));
     }
+    if (e == hipSuccess && kind == ZAFX_IMDCT && pl->log2nf == 11 && pl->prm.precision == ZAFX_PRECISION_F32 && pl->bs_log2m == 0) {
+        const auto sub = build_pass_twiddles(10, 4);   // k_imdct_q: the two 1024-point class transforms, and exp(-2 pi i n / 2048) that joins them
+        e = upload(&pl->d_tw_sub, sub.data(), sub.size() * sizeof(cf32));
+        std::vector<cf32> q(2048);
+        for (int n = 0; n < 2048; ++n) q[(size_t)n] = unit_root(n, 2048);
+        if (e == hipSuccess) e = upload(&pl->d_tw_quad, q.data(), q.size() * sizeof(cf32));
+    }
     if (e == hipSuccess && kind == ZAFX_MDCT && pl->log2nf == 10 && pl->prm.precision == ZAFX_PRECISION_F32 && pl->bs_log2m == 0) {
         // k_mdct_ft32b: pass tables of the two 512-point band transforms; g in band-major order, and g[n] exp(-2 pi i n / 1024)
         const auto sub = build_pass_twiddles(9, 3);

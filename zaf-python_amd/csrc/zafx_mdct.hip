@@ -1632,8 +1632,222 @@ constexpr int imdct_nslot(int log2nf, int fpb) {
     return s;
 }
 
+// ---------------------------------------------------------------------------------
+// inverse, reference layout, W = 8192: two CLASSES of rows per 16-frame tile (k_imdct_q; round 6)
+// ---------------------------------------------------------------------------------
+// The frame's NF = 2048-point transform y = FFT(c), c[m] = (X[2m] + i X[M-1-2m]) g_m (zaf.py:1138-1163 as the W/4-point algorithm of k_imdct),
+// does not fit LDS sixteen frames at a time, and the coefficient rows are the large side: they are read ONCE, as two classes by the parity of
+// m -- rows 4m', M-1-4m' (c[2m']) and rows 4m'+2, M-3-4m' (c[2m'+1]) --, each ONE 1024-point transform per frame (a wavefront per frame,
+// in its own buffer): y[k], y[k + 1024] = Ye[k] +- w_2048^k Yo[k].  A lane keeps Ye of its sixteen k across the second round (32
+// registers), forms z = y g and with it four of the frame's reals u (zaf.py:1166-1169 before the window): u[2k] = Re z_k,
+// u[2k + 2048] = Re z_(k+1024), u[4095 - 2k] = -Im z_k, u[2047 - 2k] = -Im z_(k+1024).  The unfold + window + TDAC overlap-add
+// (zaf.py:1166-1182: older frame first) then runs on u in LDS, eight frames at a time (16 frames x 16 KB do not fit): a wave stores the
+// samples between its frame and the one before (the tile's first frame: the carry of the tile before) as 16-byte pieces.
+#ifndef ZAFX_IMDCT_QUAD
+#define ZAFX_IMDCT_QUAD 1
+#endif
+#ifndef ZAFX_IMDCT_QUAD_DEPTH
+#define ZAFX_IMDCT_QUAD_DEPTH 1   // sweeps of a class's gather in flight per thread (two 16-byte loads each; measured 1 / 2 / 4: 1.46 / 1.51 / 1.67 ms;
+                                  // sweeps requested ahead -- the next tile's first class through the exchange, the second class through the first
+                                  // transform, 1 to 4 sweeps -- 1.62 to 1.81 ms: profiles/r06_notes.md section 7)
+#endif
+#ifndef ZAFX_IMDCT_QUAD_OUT
+#define ZAFX_IMDCT_QUAD_OUT 4     // output pieces (two 16-byte stores each) in flight per lane
+#endif
+struct ImdctQCfg {
+    using C = FftCfg<10, 4>;
+    static constexpr int N = C::N, FPB = 16, NT = 1024, PITCH = C::PITCH, NF = 2048, M = 4096;
+    static constexpr size_t REGION = (size_t)FPB * PITCH * 8;   // one transform buffer per frame; behind the second round u of eight frames (128 KB) + a carry
+    static constexpr size_t SMEM = REGION + (size_t)NF * 4 + (size_t)C::TW * 8 + (size_t)N * 8;   // buffers | carry (the lower half of a frame's u) | pass twiddles | g[0 .. 1024)
+};
+static_assert(ImdctQCfg::SMEM <= (size_t)kMaxLdsBytes, "k_imdct_q: tile + carry + tables exceed LDS");
+static_assert(ImdctQCfg::REGION >= (size_t)(ImdctQCfg::FPB / 2) * ImdctQCfg::M * 4 + (size_t)ImdctQCfg::NF * 4, "k_imdct_q: no room for u of eight frames and the second carry in the transform buffers");
+typedef float zafx_f4u __attribute__((ext_vector_type(4), aligned(4)));   // a 16-byte piece at any 4-byte alignment (the reference's output length (T-1) M - 1 is odd)
+
+__global__ __launch_bounds__(ImdctQCfg::NT) void k_imdct_q(const float* __restrict__ coefs, const float* __restrict__ win, const float2* __restrict__ twp,
+                                                           const float2* __restrict__ g, const float2* __restrict__ w2048, float* __restrict__ y, int T, int TP,
+                                                           long long out_len, int tiles, int segs, int seg_tiles, int total_units) {
+    using Q = ImdctQCfg;
+    using C = Q::C;
+    constexpr int P = 64, E = C::E, FPB = Q::FPB, NT = Q::NT, PITCH = Q::PITCH, NF = Q::NF, M = Q::M;
+    static_assert(C::P == 64, "a frame's 1024-point transform is one wavefront's");
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    float2* frames = reinterpret_cast<float2*>(smem_raw);   // FPB transform buffers ...
+    float* us = reinterpret_cast<float*>(smem_raw);          // ... and, behind the second round, u of eight frames at a time
+    float* carry = reinterpret_cast<float*>(smem_raw + Q::REGION);   // u[0 .. NF) of the frame before the tile
+    float* carry_b = us + (FPB / 2) * M;   // ... of the tile's eighth frame: behind u of eight frames, in the transform buffers' last 8 KB
+    float2* tw_l = reinterpret_cast<float2*>(carry + NF);
+    float2* gl = tw_l + C::TW;   // g_m, m < 1024 (g_(m + 1024) = g_m e^(-i pi / 4): unit_root(8 m + 1, 8 W))
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int f4 = (tid & 3) * 4, rq = tid >> 2;             // gather: my four frames of the tile, my row within a sweep of 256
+    for (int i = tid; i < C::TW; i += NT) tw_l[i] = twp[i];
+    for (int i = tid; i < NF; i += NT) carry[i] = 0.f;
+    for (int i = tid; i < C::N; i += NT) gl[i] = g[i];
+    lds_barrier();
+    const float2 wl = w2048[lane];   // w_2048^k of my k = lane + 64 i: this times exp(-2 pi i i / 32) (uniform: scalar registers)
+    float2 wi[16];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) wi[i] = w2048[64 * i];
+    constexpr float kR8 = 0.70710678118654752440f;
+    float2* const buf = frames + wave * PITCH;
+    PROF_INIT(g_prof_imdct);
+    const float gain = 2.f / (float)M;
+
+    for (int unit = blockIdx.x; unit < total_units; unit += gridDim.x) {
+        const int seg = unit % segs;
+        const long long clip = unit / segs;
+        const int tile_a = seg * seg_tiles, tile_b = min(tile_a + seg_tiles, tiles);
+        const __amdgpu_buffer_rsrc_t rs = make_rsrc(coefs + clip * M * TP, (unsigned)((long long)M * TP * 4));
+        float* const yc = y + clip * out_len;
+        const int tile_0 = tile_a > 0 ? tile_a - 1 : 0;
+        for (int tile = tile_0; tile < tile_b; ++tile) {
+            const bool write_out = tile >= tile_a;   // (the tile in front of a segment only leaves its last frame's lower half behind)
+            const int t0 = tile * FPB;
+            int lo = lane;
+            asm volatile("" : "+v"(lo));   // (opaque per tile: addresses are recomputed, not carried across the rounds)
+            auto fold_class = [&](int par) {   // c[2m' + par] of my four frames -> their buffers, slot m'
+#pragma unroll ZAFX_IMDCT_QUAD_DEPTH
+                for (int sw = 0; sw < 4; ++sw) {
+                    const int mp = rq + 256 * sw, m = 2 * mp + par;   // rows 2m and M-1-2m, four frames each
+                    const float4 re = buf_load_f32x4(rs, (int)(((unsigned)(2 * m) * (unsigned)TP + (unsigned)(t0 + f4)) * 4u));
+                    const float4 im = buf_load_f32x4(rs, (int)(((unsigned)(M - 1 - 2 * m) * (unsigned)TP + (unsigned)(t0 + f4)) * 4u));
+                    float2 gm = gl[2 * (rq + 256 * (sw & 1)) + par];
+                    if (sw >= 2) gm = make_float2(kR8 * (gm.x + gm.y), kR8 * (gm.y - gm.x));
+                    float2* fb = frames + f4 * PITCH + phys(mp);
+                    fb[0] = cmul(make_float2(re.x, im.x), gm);
+                    fb[PITCH] = cmul(make_float2(re.y, im.y), gm);
+                    fb[2 * PITCH] = cmul(make_float2(re.z, im.z), gm);
+                    fb[3 * PITCH] = cmul(make_float2(re.w, im.w), gm);
+                }
+            };
+            auto transform = [&]() {
+                lds_barrier();
+                float2 v[E];
+                regs_read<10, 4>(v, buf, lo);
+                frame_sync<P>();
+                fft_frame<10, 4>(v, buf, lo, tw_l);
+                frame_sync<P>();
+            };
+            PROF_MARK(0);
+            fold_class(0);
+            PROF_MARK(1);
+            transform();
+            PROF_MARK(2);
+            float2 ye[16];
+#pragma unroll
+            for (int i = 0; i < 16; ++i) ye[i] = buf[phys(lo + 64 * i)];
+            lds_barrier();   // every wave has read its first class
+            PROF_MARK(3);
+            fold_class(1);
+            PROF_MARK(4);
+            transform();
+            PROF_MARK(5);
+            float ua[16], ub[16], uc[16], ud[16];   // u[2k], u[2k + 2048], u[4095 - 2k], u[2047 - 2k] of my k = lane + 64 i
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                const int k = lo + 64 * i;
+                const float2 t = cmul(cmul(wl, wi[i]), buf[phys(k)]);
+                const float2 y0 = make_float2(ye[i].x + t.x, ye[i].y + t.y), y1 = make_float2(ye[i].x - t.x, ye[i].y - t.y);
+                const float2 gk = gl[k];
+                const float2 z0 = cmul(y0, gk), z1 = cmul(y1, gk);   // (z1 still lacks e^(-i pi / 4))
+                ua[i] = z0.x, ub[i] = kR8 * (z1.x + z1.y), uc[i] = -z0.y, ud[i] = kR8 * (z1.x - z1.y);
+            }
+            PROF_MARK(6);
+            lds_barrier();   // every wave has read its second class: the buffers become u of eight frames
+            PROF_MARK(7);
+#pragma unroll 1
+            for (int half = 0; half < 2; ++half) {   // (16 frames x 16 KB of u do not fit: frames 0-7, then 8-15; the other eight waves wait)
+                const bool mine = (wave >> 3) == half;
+                float* um = us + (wave & 7) * M;
+                if (mine) {
+#pragma unroll
+                    for (int i = 0; i < 16; ++i) {
+                        const int k = lo + 64 * i;
+                        um[2 * k] = ua[i];
+                        um[2 * k + 2048] = ub[i];
+                        um[4095 - 2 * k] = uc[i];
+                        um[2047 - 2 * k] = ud[i];
+                    }
+                    if ((wave & 7) == 7) {   // the group's last frame: its lower half is the next group's (the next tile's) older frame
+                        float* cw = half == 0 ? carry_b : carry;
+#pragma unroll
+                        for (int i = 0; i < 16; ++i) {
+                            const int k = lo + 64 * i;
+                            cw[2 * k] = ua[i];
+                            cw[2047 - 2 * k] = ud[i];
+                        }
+                    }
+                }
+                PROF_MARK(8);
+                lds_barrier();
+                PROF_MARK(9);
+                if (mine) {
+                    // the M samples between my frame t and frame t - 1 (zaf.py:1172-1182): out[n1] = gain (old(n1) w[n1 + M] + cur(n1) w[n1]),
+                    //   cur = u_t[NF + n1] (n1 < NF), -u_t[3 NF - 1 - n1];   old = -u_(t-1)[NF - 1 - n1] (n1 < NF), -u_(t-1)[n1 - NF]
+                    const int t = t0 + wave;
+                    const float* up = (wave & 7) != 0 ? um - M : half == 0 ? carry : carry_b;   // u[0 .. NF) of the frame before
+                    const bool store = write_out && t >= 1 && t < T;
+                    const long long o0 = (long long)(t - 1) * M;
+#pragma unroll ZAFX_IMDCT_QUAD_OUT
+                    for (int q = 0; q < 8; ++q) {
+                        const int n1 = 4 * lo + 256 * q;   // and n1 + NF
+                        const float4 c0 = *reinterpret_cast<const float4*>(um + NF + n1);             // u[NF + n1 ..]
+                        const float4 c1 = *reinterpret_cast<const float4*>(um + 2 * NF - 4 - n1);      // u[3 NF - 1 - (n1 + NF) - 3 ..] reversed
+                        const float4 p0 = *reinterpret_cast<const float4*>(up + NF - 4 - n1);          // u'[NF - 1 - n1 - 3 ..] reversed
+                        const float4 p1 = *reinterpret_cast<const float4*>(up + n1);                   // u'[(n1 + NF) - NF ..]
+                        const float4 wc0 = *reinterpret_cast<const float4*>(win + n1), wo0 = *reinterpret_cast<const float4*>(win + M + n1);
+                        const float4 wc1 = *reinterpret_cast<const float4*>(win + NF + n1), wo1 = *reinterpret_cast<const float4*>(win + M + NF + n1);
+                        zafx_f4u r0, r1;
+                        r0.x = (-p0.w * wo0.x + c0.x * wc0.x) * gain, r0.y = (-p0.z * wo0.y + c0.y * wc0.y) * gain;
+                        r0.z = (-p0.y * wo0.z + c0.z * wc0.z) * gain, r0.w = (-p0.x * wo0.w + c0.w * wc0.w) * gain;
+                        r1.x = (-p1.x * wo1.x + -c1.w * wc1.x) * gain, r1.y = (-p1.y * wo1.y + -c1.z * wc1.y) * gain;
+                        r1.z = (-p1.z * wo1.z + -c1.y * wc1.z) * gain, r1.w = (-p1.w * wo1.w + -c1.x * wc1.w) * gain;
+                        if (store) {
+                            *reinterpret_cast<zafx_f4u*>(yc + o0 + n1) = r0;
+                            float* d = yc + o0 + NF + n1;
+                            if (o0 + NF + n1 + 3 < out_len) {
+                                *reinterpret_cast<zafx_f4u*>(d) = r1;
+                            } else {   // the clip's last piece: the trim [H : -H - 1] drops one more sample (zaf.py:1182)
+                                if (o0 + NF + n1 < out_len) d[0] = r1.x;
+                                if (o0 + NF + n1 + 1 < out_len) d[1] = r1.y;
+                                if (o0 + NF + n1 + 2 < out_len) d[2] = r1.z;
+                            }
+                        }
+                    }
+                }
+                PROF_MARK(10);
+                lds_barrier();   // the frames' u are read
+                PROF_MARK(11);
+            }
+        }
+        for (int i = tid; i < NF; i += NT) carry[i] = 0.f;   // (a clip starts with no frame before it; read behind the next tile's barriers)
+    }
+}
+
+static hipError_t run_imdct_quad(const zafx_plan& pl, const float* coefs, float* y, int64_t n_clips, int T, int64_t out_len) {
+    using Q = ImdctQCfg;
+    const int tiles = (T + Q::FPB - 1) / Q::FPB;
+    if ((long long)tiles * n_clips <= 0 || out_len <= 0) return hipSuccess;
+    auto kern = k_imdct_q;
+    if (hipError_t e = ensure_dynamic_lds(reinterpret_cast<const void*>(kern), pl.device, Q::SMEM); e != hipSuccess) return e;
+    const int segs = carry_segments(n_clips, tiles, pl.n_cus);
+    const int seg_tiles = (tiles + segs - 1) / segs;
+    const long long units = n_clips * segs;
+    pl.ran = "k_imdct_q";
+    hipLaunchKernelGGL(kern, dim3((unsigned)std::min<long long>(units, pl.n_cus)), dim3(Q::NT), Q::SMEM, pl.stream, coefs, pl.d_window, pl.d_tw_sub, pl.d_tw_aux,
+                       pl.d_tw_quad, y, T, (int)row_pitch(pl, T), (long long)out_len, tiles, segs, seg_tiles, (int)units);
+    return hipGetLastError();
+}
+
 template <int LOG2NF, int LAYOUT>
 static hipError_t run_imdct(const zafx_plan& pl, const float* coefs, float* y, int64_t n_clips, int T, int64_t out_len) {
+    if constexpr (ZAFX_IMDCT_QUAD && LOG2NF == 11 && LAYOUT == ZAFX_LAYOUT_FT) {
+        // W = 8192: the two-class kernel (four frames per 16-byte piece: a row pitch that is a multiple of 4; 32-bit byte offsets inside a clip)
+        const int64_t TP = row_pitch(pl, T);
+        if (pl.d_tw_sub && pl.d_tw_quad && TP % 4 == 0 && reinterpret_cast<uintptr_t>(coefs) % 16 == 0 && reinterpret_cast<uintptr_t>(pl.d_window) % 16 == 0 &&
+            (long long)4096 * TP * 4 < (1LL << 31) && n_clips * (((long long)T + 15) / 16 + 1) < (1LL << 30))
+            return run_imdct_quad(pl, coefs, y, n_clips, T, out_len);
+    }
     constexpr int LOG2E = default_log2e(LOG2NF);
     constexpr int FPB = imdct_fpb(LOG2NF, LAYOUT);
     constexpr int NSLOT = imdct_nslot(LOG2NF, FPB);

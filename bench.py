@@ -330,10 +330,10 @@ def make_workload(kind, device, layout="FT"):
             plan = PcmPlan(zafx.mdct_plan(kbd, device=device))
             wl.update(plan=plan, d_in=d_x, n_in=N, bytes_per_launch=B * (2 * N + 4 * (W // 2) * T),
                       desc="Batched MDCT from int16 mono PCM on the device: 1024 clips x 10 s, KBD win=2048")
-    elif kind == "dct1000":   # every length the reference takes: N = 1000 as a chirp-z sum (two 2048-point transforms per vector)
+    elif kind == "dct1000":   # every length the reference takes: N = 1000 = k_dct's maps around a 500-point Bluestein convolution (two 1024-point transforms per vector)
         plan = zafx.dct_plan(N, 2, device=device)
         wl.update(plan=plan, d_in=d_x, n_in=N, bytes_per_launch=B * 8 * N,
-                  desc="zaf.dct type 2 of 16384 vectors x 1000 samples (a length off the power-of-two grid: chirp-z form)")
+                  desc="zaf.dct type 2 of 16384 vectors x 1000 samples (a length off the power-of-two grid: N/2-point Bluestein convolution inside k_dct's maps)")
     elif kind == "dct":   # zaf.dct type 2 on the FFT core (k_dct): 8 bytes per sample, HBM-bound
         plan = zafx.dct_plan(N, 2, device=device)
         wl.update(plan=plan, d_in=d_x, n_in=N, bytes_per_launch=B * 8 * N,

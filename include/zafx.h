@@ -66,7 +66,8 @@ enum zafx_kind {
     ZAFX_DCT = 10    /* in (B, N) f32 -> out (B, N) f32: the orthonormal dct / dst of zaf.py:703-839 / :842-981, type
                         params.transform_type = 1..4, params.transform_sine = 0 (dct) / 1 (dst), N = window_length;
                         one M-point complex FFT per vector where M = N/2 (N-1 / N+1 for type I) is a power of two 32..8192,
-                        every other N from 2 to 8192 as a chirp-z sum (two transforms of 2^ceil(log2(2N-1)) points) */
+                        every other N from 2 to 8192 on Bluestein convolutions: types 2-4 of N = 4 j two transforms of
+                        2^ceil(log2(N-1)) points around the N/2-point transform, the rest two of 2^ceil(log2(2N-1)) (chirp-z sum) */
 };
 
 enum zafx_layout {

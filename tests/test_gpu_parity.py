@@ -846,6 +846,12 @@ def test_dct_dst(zafx, golden, n):
     assert np.max(np.abs(zafx.dst(zafx.dst(x, 2), 3) - x)) < 1e-5
 
 
+def off_grid_dct_kernel(n, t):
+    """The kernel of a dct / dst length off k_dct's power-of-two grid: types 2-4 of a length 4 j keep k_dct's maps around an N/2-point Bluestein
+    convolution (k_dct_bsh, round 6: half the transform length), everything else is the chirp-z sum of all N points (k_dct_bs32)."""
+    return "k_dct_bsh" if t >= 2 and n % 4 == 0 else "k_dct_bs32"
+
+
 @pytest.mark.parametrize("n", [63, 64, 65, 1023, 1024, 1025])
 def test_dct_dst_on_the_fft_core(zafx, golden, n):
     """Lengths whose N/2 (types 2-4), N-1 (dct 1) or N+1 (dst 1) is a power of two from 32 up run on k_dct: one M-point complex
@@ -860,7 +866,7 @@ def test_dct_dst_on_the_fft_core(zafx, golden, n):
             got = fn(x, t)
             assert got.dtype == np.float64 and got.shape == x.shape and relerr(got, g[f"{name}{t}_{n}"]) <= TOL_FFT, (name, t)
             plan = zafx.dct_plan(n, t, sine)
-            assert plan.kernel_name == plan.last_kernel == ("k_dct" if on_core else "k_dct_bs32")
+            assert plan.kernel_name == plan.last_kernel == ("k_dct" if on_core else off_grid_dct_kernel(n, t))
 
 
 @pytest.mark.parametrize("n", [8, 9, 100])
@@ -871,14 +877,15 @@ def test_dct_dst_short_lengths_on_the_fft_core_too(zafx, golden, n):
     for sine, fn, name in ((False, zafx.dct, "dct"), (True, zafx.dst, "dst")):
         for t in (1, 2, 3, 4):
             assert relerr(fn(x, t), g[f"{name}{t}_{n}"]) <= TOL_FFT, (name, t)
-            assert zafx.dct_plan(n, t, sine).last_kernel == "k_dct_bs32"
+            assert zafx.dct_plan(n, t, sine).last_kernel == off_grid_dct_kernel(n, t)
 
 
-@pytest.mark.parametrize("n,rows", [(2, 5), (3, 70), (17, 300), (33, 9), (127, 64), (129, 3), (441, 100), (1000, 1500), (1764, 33), (2047, 7), (3000, 40), (4097, 5),
-                                    (5000, 3), (8191, 2), (8192 - 2, 2)])
+@pytest.mark.parametrize("n,rows", [(2, 5), (3, 70), (4, 9), (12, 1000), (17, 300), (33, 9), (127, 64), (129, 3), (132, 64), (260, 700), (441, 100), (1000, 1500), (1028, 5),
+                                    (1764, 33), (2047, 7), (2052, 300), (3000, 40), (4097, 5), (5000, 3), (8188, 40), (8191, 2), (8192 - 2, 2)])
 def test_dct_dst_of_any_length(zafx, n, rows):
     """zaf.dct / zaf.dst take any length (zaf.py:760-839, :900-981: one np.fft.fft of a symmetric extension): every length up to 8192
-    that is off the power-of-two grid of k_dct runs as a chirp-z sum (k_dct_bs32, convolution lengths 128 ... 16384), all eight
+    that is off the power-of-two grid of k_dct runs as a chirp-z sum (k_dct_bs32, convolution lengths 128 ... 16384) or, types 2-4 of a
+    length 4 j, as k_dct's maps around an N/2-point Bluestein convolution (k_dct_bsh, lengths 128 ... 8192: every one of them here), all eight
     transforms, more rows than workgroups, against the oracle; the inverse pairs II / III and IV / IV close the loop."""
     x = np.stack([synth_clip(71, c % 11, n) for c in range(rows)])
     for sine, batch, one in ((False, zafx.dct_batch, orc.dct), (True, zafx.dst_batch, orc.dst)):
@@ -886,7 +893,7 @@ def test_dct_dst_of_any_length(zafx, n, rows):
             if zafx.dct_fft_length(n, t, sine) is not None:
                 continue   # (k_dct's lengths: test_dct_dst_batches_every_size)
             got = batch(x, t)
-            assert zafx.dct_plan(n, t, sine).last_kernel == "k_dct_bs32" and got.shape == x.shape and got.dtype == np.float32
+            assert zafx.dct_plan(n, t, sine).last_kernel == off_grid_dct_kernel(n, t) and got.shape == x.shape and got.dtype == np.float32
             for c in range(min(rows, 11)):
                 assert relerr(got[c], one(x[c].astype(np.float64), t)) <= TOL_FFT, (sine, t, c)
             if rows > 11:

@@ -912,6 +912,21 @@ int zafx_plan_create(zafx_plan** out, int device, int kind, const zafx_params* p
                 aux[(size_t)(M + 1 + k)] = type == 4 ? unit_root(k, 2LL * N) : unit_root(k, 4LL * N);
             }
             pl->kernel_name = dct_kernel_name();
+        } else if (type >= 2 && N % 4 == 0 && N <= 8192) {
+            // N / 2 points, not a power of two (round 6): k_dct's maps around a Bluestein convolution of 2^bs_log2m >= 2 (N / 2) - 1 points --
+            // half the transform length of the chirp-z sum below (zafx_dct.hip, BS = true); tables A | B as above, chirp and its transform below
+            const int Mh = N / 2;
+            pl->dct_half = Mh;
+            pl->dct_den2 = Mh;   // (the chirp of an Mh-point DFT: exp(-i pi m^2 / Mh))
+            pl->log2nf = 4;
+            pl->bs_log2m = 7;
+            while ((1 << pl->bs_log2m) < 2 * Mh - 1) ++pl->bs_log2m;
+            aux.resize(2 * (size_t)(Mh + 1));
+            for (int k = 0; k <= Mh; ++k) {
+                aux[(size_t)k] = type == 4 ? unit_root(4LL * k + 1, 8LL * N) : unit_root(k, 2LL * Mh);
+                aux[(size_t)(Mh + 1 + k)] = type == 4 ? unit_root(k, 2LL * N) : unit_root(k, 4LL * N);
+            }
+            pl->kernel_name = "k_dct_bsh";
         } else if (N <= 8192) {
             // Every other length (the reference's np.fft.fft takes any, zaf.py:760-839, :900-981): all eight transforms are
             //     y[k] = s_out[k] sum_n s_in[n] x[n] cos | sin(pi (n + a)(k + b) / D),   a, b in {0, 1/2, 1},  D = N - 1 | N | N + 1,
@@ -1013,7 +1028,7 @@ int zafx_plan_create(zafx_plan** out, int device, int kind, const zafx_params* p
     }
     if (e == hipSuccess) e = upload(&pl->d_tw_aux, aux.data(), aux.size() * sizeof(cf32));
     if (e == hipSuccess && pl->prm.precision == ZAFX_PRECISION_F32 && pl->bs_log2m > 0) {   // float32 Bluestein plan (zafx_bs32.hip)
-        const int M = 1 << pl->bs_log2m, W = pl->W, F = W / 2;
+        const int M = 1 << pl->bs_log2m, W = pl->dct_half > 0 ? pl->dct_half : pl->W, F = W / 2;   // (W: the points of the transform that is convolved)
         auto twm = build_pass_twiddles(pl->bs_log2m, default_log2e(pl->bs_log2m));
         if (twm.empty()) twm.push_back(cf32{1.f, 0.f});
         e = upload(&pl->d_tw_pass, twm.data(), twm.size() * sizeof(cf32));
@@ -1035,7 +1050,7 @@ int zafx_plan_create(zafx_plan** out, int device, int kind, const zafx_params* p
             }
             if (e == hipSuccess) e = upload(&pl->d_tw_aux, pp.data(), pp.size() * sizeof(cf32));
         }
-        pl->kernel_name = kind == ZAFX_DCT ? "k_dct_bs32" : kind == ZAFX_STFT ? "k_stft_bs32" : kind == ZAFX_ISTFT ? "k_ifft_frames_bs32" : kind == ZAFX_MDCT ? "k_mdct_bs32"
+        pl->kernel_name = kind == ZAFX_DCT ? (pl->dct_half > 0 ? "k_dct_bsh" : "k_dct_bs32") : kind == ZAFX_STFT ? "k_stft_bs32" : kind == ZAFX_ISTFT ? "k_ifft_frames_bs32" : kind == ZAFX_MDCT ? "k_mdct_bs32"
                           : (kind == ZAFX_MEL || kind == ZAFX_MFCC) ? mel_wide_kernel_name() : "k_imdct_frames_bs32";
     }
     if (e == hipSuccess && pl->prm.precision == ZAFX_PRECISION_F64) {   // float64 tables, evaluated in long double
@@ -1341,7 +1356,7 @@ int zafx_execute(zafx_plan* pl, const void* d_in, void* d_out, int64_t n_clips, 
             e = launch_linear(*pl, (const float*)d_in, (float*)d_out, n_clips);
             break;
         case ZAFX_DCT:
-            e = pl->bs_log2m > 0 ? launch_dct_bs32(*pl, (const float*)d_in, (float*)d_out, n_clips) : launch_dct(*pl, (const float*)d_in, (float*)d_out, n_clips);
+            e = pl->bs_log2m > 0 && pl->dct_half == 0 ? launch_dct_bs32(*pl, (const float*)d_in, (float*)d_out, n_clips) : launch_dct(*pl, (const float*)d_in, (float*)d_out, n_clips);
             break;
         case ZAFX_CQT:
         case ZAFX_CHROMA:

@@ -171,6 +171,7 @@ struct zafx_plan {
     int bs_log2m = 0;              // > 0: window that is not a power of two -- Bluestein convolution length 2^bs_log2m (zafx_f64.hip, zafx_bs32.hip)
     void* d_pcm_float = nullptr;   // zafx_execute_pcm's float32 staging for the kinds that do not (grow-only)
     size_t pcm_float_bytes = 0;
+    int dct_half = 0;              // ZAFX_DCT, types II-IV, N = 4 j with N / 2 not a power of two: N / 2, the points of the transform inside k_dct<.., BS> (zafx_dct.hip)
     long long dct_den2 = 0;        // ZAFX_DCT on the chirp-z form: 2 D, the denominator of its chirp exp(-i pi j^2 / (2 D)) (k_dct_bs32)
     float2* d_bs_chirp = nullptr;  // float32 Bluestein plans: c[n] = exp(-i pi n^2 / W), n < W
     float2* d_bs_bhat = nullptr;   // ... and FFT_M of the wrapped conjugate chirp

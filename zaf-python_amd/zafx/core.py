@@ -1142,8 +1142,9 @@ DCT_CHIRP_MAX = 8192   # longest vector of the chirp-z form (its convolution of 
 def dct_plan(length, kind, sine=False, device=0):
     """Plan of the orthonormal dct (sine=False) / dst of type `kind` of vectors of `length` samples (zaf.py:703-839, :842-981).
     Lengths with N/2 (type 1: N -/+ 1) a power of two in [32, 8192] run ONE M-point complex transform per vector (k_dct, instead of the
-    reference's 2N-2 ... 8N-point one); every other length from 2 to 8192 runs as a chirp-z sum on the Bluestein machinery (k_dct_bs32:
-    two transforms of 2^ceil(log2(2N - 1)) points) -- O(N log N) for every length the reference takes."""
+    reference's 2N-2 ... 8N-point one); every other length from 2 to 8192 runs on the Bluestein machinery -- types 2-4 of a length 4 j as the
+    same maps around an N/2-point convolution (k_dct_bsh: two transforms of 2^ceil(log2(N - 1)) points), the rest as a chirp-z sum over all N
+    points (k_dct_bs32: two of 2^ceil(log2(2N - 1))) -- O(N log N) for every length the reference takes."""
     n = int(length)
     if dct_fft_length(n, kind, sine) is None and not 2 <= n <= DCT_CHIRP_MAX:
         raise ValueError("dct / dst plans take lengths 2 ... 8192, and longer ones whose N/2 (type 1: N-1 / N+1) is a power of two up to 8192")

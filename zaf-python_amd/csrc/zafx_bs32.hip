@@ -312,7 +312,10 @@ hipError_t launch_dct_bs32(const zafx_plan& pl, const float* x, float* y, int64_
         constexpr int L = decltype(tag)::value;
         auto kern = k_dct_bs32<L>;
         if (hipError_t e = ensure_dynamic_lds(reinterpret_cast<const void*>(kern), pl.device, BsCfg<L>::SMEM); e != hipSuccess) return e;
-        const size_t per_cu = std::max<size_t>(1, std::min<size_t>(std::min<size_t>(2048 / BsCfg<L>::P, 16), (size_t)kMaxLdsBytes / BsCfg<L>::SMEM));
+        size_t per_cu = std::max<size_t>(1, std::min<size_t>(std::min<size_t>(2048 / BsCfg<L>::P, 16), (size_t)kMaxLdsBytes / BsCfg<L>::SMEM));
+        int resident = 0;   // (registers may admit fewer workgroups than LDS: a persistent grid beyond what is resident runs a second, part-empty round)
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&resident, kern, BsCfg<L>::P, BsCfg<L>::SMEM) == hipSuccess && resident > 0)
+            per_cu = std::min<size_t>(per_cu, (size_t)resident);
         const long long grid = std::min<long long>(n_rows, (long long)pl.n_cus * (long long)per_cu);
         pl.ran = "k_dct_bs32";
         hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(BsCfg<L>::P), BsCfg<L>::SMEM, pl.stream, x, y, pl.d_tw_pass, pl.d_tw_aux, pl.d_bs_bhat, pl.W,

@@ -218,7 +218,8 @@ def test_clipped_pcm_through_the_pcm_entry_points(zafx, consts, golden, channels
 def test_signal_on_the_other_kernels(zafx, name, wl, hop):
     """The same signals through the kernels the W = 2048 / hop 1024 cases do not reach -- the two-band forms of W = 4096 (k_stft_ft16b / bc,
     k_istft_ft16b, k_mdct_ft32b / bc, k_mel_ft16b), 75 % overlap, a window that is not a power of two (the Bluestein forms), the four-class
-    forms of W = 8192 (k_stft_ft16q, k_mdct_ft32q; 48 frames: rows on the line grid) -- against the oracle with the same two bounds."""
+    forms of W = 8192 (k_stft_ft16q, k_mdct_ft32q and, round 6, their inverses k_istft_ft8q, k_imdct_q; 48 frames: rows on the line grid) -- against the
+    oracle with the same two bounds."""
     n = 40 * hop + 300 if wl != 8192 else 47 * hop - 100
     x = sig.signal(name, n)
     x64 = x.astype(np.float64)
@@ -244,6 +245,8 @@ def test_signal_on_the_other_kernels(zafx, name, wl, hop):
         assert check(f"{tag}.mdct", zafx.mdct_batch(x[None], kbd)[0], m, TOL_FFT) <= TOL_FFT
         yi, yiref = zafx.imdct_batch(m[None], kbd)[0], orc.imdct(m, kbd)
         assert len(yi) == len(yiref) and relerr(yi, yiref) <= TOL_FFT
+        if wl == 8192:
+            assert zafx.mdct_plan(kbd).last_kernel == "k_mdct_ft32q" and zafx.mdct_plan(kbd, inverse=True).last_kernel == "k_imdct_q"
     fb = zafx.melfilterbank(sig.FS, wl, 64)
     fbd = fb.toarray()
     mel_floor = fbd @ np.broadcast_to(nu, (fbd.shape[1], nu.shape[1])) + C_FLOOR * EPS32 * np.abs(orc.melspectrogram(x64, ham, hop, fb))

@@ -61,13 +61,14 @@ if trace and os.path.exists(log):
             rows.append((int(r["Dispatch_Id"]), r["Kernel_Name"].replace("(anonymous namespace)::", "").split("(")[0], int(r["End_Timestamp"]) - int(r["Start_Timestamp"])))
     rows.sort()
     pos, table = 0, []
+    TRACE_NAME = {"k_dct_bsh": "k_dct"}   # reported name -> the symbol in the trace (k_dct<LOG2M, FAM, true>)
     for ent in json.load(open(log)):
         picked = []   # (segment, duration)
         segs = ent.get("segments") or [["setup", ent["launches"]]]
         for seg, n in segs:
             got = 0
             while got < n and pos < len(rows):
-                if ent["kernel"] in rows[pos][1]:
+                if TRACE_NAME.get(ent["kernel"], ent["kernel"]) in rows[pos][1]:
                     picked.append((seg, rows[pos][2]))
                     got += 1
                 pos += 1

@@ -1427,6 +1427,10 @@ __device__ __forceinline__ void fft1024_cq(double2* buf, int lane, const double2
     frame_sync<64>();
 }
 
+#ifndef ZAFX_CQ64_SHALLOW
+#define ZAFX_CQ64_SHALLOW 1   // the first pass's loads: 1 = the second half requested when the first has arrived (sixteen 16-byte loads in flight per thread instead of
+                              // thirty-two: 256 clips x 30 s 16.84 -> 16.69 ms), 2 / 3 = eight / four in flight (16.82 / 16.83), 0 = all thirty-two at once
+#endif
 #ifndef ZAFX_CQ64_PREFETCH
 #define ZAFX_CQ64_PREFETCH 0   // 1, 2: half / all of the next first pass's samples requested behind the transforms of the phase before -- measured 6.8 / 8.9 ms against 4.85 (64 clips x 30 s): the 64 / 128 registers they hold spill
 #endif
@@ -1475,6 +1479,9 @@ __global__ __launch_bounds__(kCq64Threads) void k_cqt_ft_f64(const double* __res
         if (s0 >= 0 && s0 + W <= n_samples) {   // (uniform) the frame lies inside the clip: 16-byte loads
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
+#if ZAFX_CQ64_SHALLOW >= 2
+                if (r % (ZAFX_CQ64_SHALLOW == 2 ? 8 : 4) == 0 && r) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#endif
                 const auto raw = __builtin_amdgcn_raw_buffer_load_b128(rx, voff + r * 16384, 0, 0);   // (the whole offset per lane: the range check does not see a scalar offset)
                 __builtin_memcpy(&z[r], &raw, 16);
             }
@@ -1502,6 +1509,9 @@ __global__ __launch_bounds__(kCq64Threads) void k_cqt_ft_f64(const double* __res
             // first pass for this round's eight q (even: the 8-point transform of z[r] + z[r + 8]; odd: of (z[r] - z[r + 8]) w_16^r): the samples
             // are read once per round (the second time from L2) -- sixteen outputs at once held 64 registers through the first round and spilled
             if (!ZAFX_CQ64_PREFETCH) load_z(zq[0], g, 0, tid_o);
+#if ZAFX_CQ64_SHALLOW
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#endif
             if (ZAFX_CQ64_PREFETCH != 2) load_z(zq[1], g, 1, tid_o);   // (1: only the first half rides ahead; both kept 128 registers through the split and spilled)
             // both halves folded first (16 -> 8 values each: the 128 registers of samples are down to 64 before the transforms need theirs)
             double2 af[2][8];

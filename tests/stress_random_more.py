@@ -118,8 +118,8 @@ for it in range(max(4, iters // 6)):
 
 # DCT / DST types 1-4, random lengths
 for it in range(max(8, iters // 3)):
-    n = int(rng.integers(2, 3000))
-    nb = int(rng.integers(1, 40))
+    n = int(rng.choice([int(rng.integers(2, 3000)), 4 * int(rng.integers(1, 2049)), int(rng.integers(2, 8193))]))   # (lengths 4 j: k_dct_bsh for types 2-4)
+    nb = int(rng.integers(1, 40)) if n < 3000 else int(rng.integers(1, 600))   # (more rows than resident workgroups now and then)
     kind = int(rng.integers(1, 5))
     x = rng.standard_normal((nb, n)).astype(np.float32)
     c = int(rng.integers(0, nb))

@@ -50,7 +50,7 @@ F32_PEAK_TFLOPS = 157.3    # dense f32 vector / f32-input MFMA peak
 F64_PEAK_TFLOPS = 78.6     # float64 vector: half the f32 vector rate (v_fma_f64 issues every 4 cycles per wave: 256 CUs x 4 SIMDs x 32 FLOP/clk x 2.4 GHz; the guide lists no f64 row)
 PLACEMENT_SURVEY = 6       # further allocations of the headline's row-strided output probed AFTER every timed region (reported, never timed)
 CONFIG_KINDS = ("istft", "mel", "mfcc", "mel_mfcc", "mdct", "imdct", "cqt")   # SURVEY 8(a) a2 + BASELINE configs 3 (mel_mfcc: in one pass), 4, 5 (config 2 = the headline)
-EXTRA_KINDS = ("stft1", "stftmag", "istft1", "stft_offgrid", "mdct_offgrid", "stft4096", "stft4096_h1024", "istft4096", "mdct4096", "mel4096", "dct", "stft64", "mdct64", "istft_offgrid", "imdct_offgrid", "stftmag_offgrid", "stft8192", "mdct8192", "istft64", "imdct64", "mel64", "mfcc64", "cqt64", "istft_offgrid_compact", "stftmag_offgrid_compact", "mel_pcm16", "mdct_pcm16", "dct1000", "istft8192", "imdct8192")   # one-sided pair (8f rank 4) and geometries off the benchmark's grid
+EXTRA_KINDS = ("stft1", "stftmag", "istft1", "stft_offgrid", "mdct_offgrid", "stft4096", "stft4096_h1024", "istft4096", "mdct4096", "mel4096", "dct", "stft64", "mdct64", "istft_offgrid", "imdct_offgrid", "stftmag_offgrid", "stft8192", "mdct8192", "istft64", "imdct64", "mel64", "mfcc64", "cqt64", "istft_offgrid_compact", "stftmag_offgrid_compact", "mel_pcm16", "mdct_pcm16", "dct1000", "istft8192", "imdct8192", "stft_offgrid_padded", "mdct_offgrid_padded")   # one-sided pair (8f rank 4) and geometries off the benchmark's grid
 
 
 def synth(seed, c, n):
@@ -111,6 +111,8 @@ def make_workload(kind, device, layout="FT"):
         B, N, T = 256, 1323000, 750   # float64 clips of 30 s are 10.6 MB: a quarter of a GPU's share of config 5 (2.7 GB), same frames per clip
     if kind in ("stft64", "mdct64", "istft64", "imdct64", "mel64", "mfcc64"):
         B = 1024                  # the reference's own dtype (zaf.py:128, :139: float64 in, complex128 out): 40.1 / 16 B per sample
+    padded_rows = kind.endswith("_padded")    # stft / mdct off the grid on row-padded device arrays (what stft_batch / mdct_batch do by default since round 6)
+    kind = kind[:-len("_padded")] if padded_rows else kind
     compact_rows = kind.endswith("_compact")   # istft / stftmag off the grid: the *_batch functions' default (rows padded to 128-byte lines, round 6) and, `_compact`, the reference's own memory order
     kind = kind[:-len("_compact")] if compact_rows else kind
     if kind in ("stft_offgrid", "istft_offgrid", "stftmag_offgrid"):
@@ -131,7 +133,7 @@ def make_workload(kind, device, layout="FT"):
     for r in range(B // distinct):
         d_x.copy_from(d_base, dst_offset=r * distinct * N * 4)
     d_base.free()
-    wl = dict(kind=kind + ("_compact" if compact_rows else ""), n_clips=B, samples_per_clip=N, base=base, valu_flops=0.0, valu_flops_real_input=0.0, mfma_flops=0.0, flops_note=None, frames=T)
+    wl = dict(kind=kind + ("_compact" if compact_rows else "_padded" if padded_rows else ""), n_clips=B, samples_per_clip=N, base=base, valu_flops=0.0, valu_flops_real_input=0.0, mfma_flops=0.0, flops_note=None, frames=T)
     pad_c64 = 16 if kind == "istft_offgrid" and not compact_rows else 0      # rows of 433 complex64 -> pitch 448
     pad_f32 = 32 if kind == "stftmag_offgrid" and not compact_rows else 0    # rows of 433 float32 -> pitch 448
     if kind == "stft":
@@ -139,9 +141,10 @@ def make_workload(kind, device, layout="FT"):
         wl.update(plan=plan, d_in=d_x, n_in=N, bytes_per_launch=B * (4 * N + 8 * W * T),
                   desc="Batched STFT: 1024 clips x 10 s @ 44.1 kHz, Hamming win=2048 hop=1024, two-sided c64 (W,T) layout")
     elif kind == "stft_offgrid":   # the compact reference layout when T is not a multiple of 16
-        plan = zafx.stft_plan(ham, H, layout=layout, device=device)
+        plan = zafx.stft_plan(ham, H, layout=layout, device=device, row_align=16 if padded_rows else 0)
         wl.update(plan=plan, d_in=d_x, n_in=N, bytes_per_launch=B * (4 * N + 8 * W * T),
-                  desc="Batched STFT off the line grid: 1024 clips x 442024 samples, win=2048 hop=1024, T = 433 (rows straddle 128-byte lines), compact (W,T) layout")
+                  desc="Batched STFT off the line grid: 1024 clips x 442024 samples, win=2048 hop=1024, T = 433" + (", device rows padded to 128-byte lines (pitch 448: stft_batch's "
+                       "default off the grid; algorithmic bytes of the compact array)" if padded_rows else " (rows straddle 128-byte lines), compact (W,T) layout"))
     elif kind == "stft4096":
         plan = zafx.stft_plan(zafx.hamming(4096), 2048, layout=layout, device=device)
         wl.update(plan=plan, d_in=d_x, n_in=N, bytes_per_launch=B * (4 * N + 8 * 4096 * T),
@@ -272,9 +275,10 @@ def make_workload(kind, device, layout="FT"):
         wl.update(plan=plan, d_in=d_x, n_in=N, bytes_per_launch=B * (4 * N + 4 * (W // 2) * T),
                   desc="Batched MDCT: 1024 clips x 10 s, KBD win=2048")
     elif kind == "mdct_offgrid":   # the compact (W/2, T) layout when T is not a multiple of 16 (k_mdct_ft32's carry form)
-        plan = zafx.mdct_plan(kbd, device=device)
+        plan = zafx.mdct_plan(kbd, device=device, row_align=32 if padded_rows else 0)
         wl.update(plan=plan, d_in=d_x, n_in=N, bytes_per_launch=B * (4 * N + 4 * (W // 2) * T),
-                  desc="Batched MDCT off the line grid: 1024 clips x 442024 samples, KBD win=2048, T = 433, compact (W/2,T) layout")
+                  desc="Batched MDCT off the line grid: 1024 clips x 442024 samples, KBD win=2048, T = 433" + (", device rows padded to 128-byte lines (pitch 448: mdct_batch's "
+                       "default off the grid; algorithmic bytes of the compact array)" if padded_rows else ", compact (W/2,T) layout"))
     elif kind in ("imdct", "imdct_offgrid"):
         fwd = zafx.mdct_plan(kbd, device=device)
         d_m = zafx.DeviceBuffer(fwd.out_shape(B, N), np.float32, device)
@@ -518,7 +522,7 @@ def parity_probe(wl):
     NumPy'; SURVEY 8(d) tolerance: 1e-5 stft/istft/mdct/imdct, 1e-4 mel/mfcc/cqt)."""
     from oracle import zaf_oracle as orc
     kind, base, B = wl["kind"], wl["base"], wl["n_clips"]
-    kind = kind[:-len("_compact")] if kind.endswith("_compact") else kind
+    kind = kind[:-len("_compact")] if kind.endswith("_compact") else kind[:-len("_padded")] if kind.endswith("_padded") else kind
     ham, kbd = orc.hamming_periodic(W), orc.kbd_window(W)
     x64 = base[0].astype(np.float64)
     if kind in ("stft", "stft1", "stft_offgrid", "stftmag", "stftmag_offgrid", "stft64"):

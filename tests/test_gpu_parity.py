@@ -1348,7 +1348,8 @@ def test_f64_cqt_on_the_tiled_kernel(zafx, n, clips, tr):
     """fft_length 32768 in float64: k_cqt_ft_f64 (16 x 1024 decimation in frequency in two rounds of eight wavefronts, the split of the bins the
     kernel reads only, the matrix's non-zeros as one stream per thread) -- frames that reach in front of and behind the clip (the buffer loads'
     out-of-range zeros), odd clip lengths (samples off the 16-byte grid), both layouts, the chromagram, a genuinely complex matrix (the 24-byte
-    entries) and a matrix with columns above W/2 (conjugate bins); kernels the tiled form does not take (bins above 8191) stay on k_cqt_f64."""
+    entries), a matrix with columns above W/2 (conjugate bins) and kernels of other frequency ranges (what the sub-transforms' last pass may skip follows
+    the highest column); kernels the tiled form does not take (bins above 8191) stay on k_cqt_f64."""
     ck = zafx.cqtkernel(44100, 24, 55, 3520)
     assert ck.shape == (144, 32768)
     x = np.stack([synth_clip(53, c % 7, n).astype(np.float64) + 1e-9 * (c % 7) for c in range(clips)])
@@ -1373,6 +1374,15 @@ def test_f64_cqt_on_the_tiled_kernel(zafx, n, clips, tr):
     assert zafx.cqt_plan(44100, tr, ck2, f64=True).last_kernel == "k_cqt_ft_f64"
     for c in range(2):
         assert relerr(got[c], orc.cqtspectrogram(x[c], 44100, tr, ck2)) <= TOL_F64, c
+    # the sub-transforms' last pass writes only the quarters of their output the split reads: kernels whose highest column lies in every band of
+    # that decision -- klo = (highest column) >> 4 = 20 (one quarter of the wave's outputs at either end), 70, 164 (above), 249 and 448 (>= 256: everything)
+    shifted = scipy.sparse.csr_matrix((coo.data, (coo.row, np.where(coo.row >= 100, coo.col + 4500, coo.col))), shape=ck.shape)   # columns up to 7172
+    for ckb, klo in ((zafx.cqtkernel(44100, 24, 55, 440), 20), (zafx.cqtkernel(44100, 24, 55, 1500), 70), (zafx.cqtkernel(44100, 24, 55, 5300), 249), (shifted, 448)):
+        assert ckb.shape[1] == 32768 and ckb.indices.max() >> 4 == klo
+        got = zafx.cqtspectrogram_batch(x[:2], 44100, tr, ckb, f64=True)
+        assert zafx.cqt_plan(44100, tr, ckb, f64=True).last_kernel == "k_cqt_ft_f64", klo
+        for c in range(2):
+            assert relerr(got[c], orc.cqtspectrogram(x[c], 44100, tr, ckb)) <= TOL_F64, (klo, c)
     wide = zafx.cqtkernel(44100, 24, 55, 22050)   # the reference's docstring kernel: columns up to bin 16 613
     got = zafx.cqtspectrogram_batch(x[:1, :40000], 44100, tr, wide, f64=True)
     assert zafx.cqt_plan(44100, tr, wide, f64=True).last_kernel == "k_cqt_f64"

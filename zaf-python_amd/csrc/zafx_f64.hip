@@ -1388,7 +1388,11 @@ __device__ __forceinline__ double2 root1024s(const double2* __restrict__ tws, in
     return tws[m << 5];
 }
 // 1024-point forward transform of one wavefront, input and output in `buf` (natural order)
-template <int RS>   // stride of the root table: 1 (the LDS copy) or 32 (the plan's roots of 32768)
+// FULL = false: no index k = bin >> 4 the split reads lies in 256 .. 767 (bins c and N - c of every kernel column c: k <= klo and k >= 1023 - klo with
+// klo = (highest column) >> 4 < 256 -- the reference's kernel: columns up to bin 2634, klo = 164), and the last pass neither forms nor writes the two
+// middle quarters of its output: 8 of 16 stores (256 clips x 30 s: 16.61 -> 15.94 ms).  Skipping, wave by wave, also the quarter-waves of the outer
+// quarters that klo leaves out (6 stores) is SLOWER (16.2: a scalar branch per store).
+template <int RS, bool FULL>   // RS: stride of the root table: 1 (the LDS copy) or 32 (the plan's roots of 32768); FULL: klo >= 256
 __device__ __forceinline__ void fft1024_cq(double2* buf, int lane, const double2* w2tab, const double2* rtab) {   // rtab[m] = exp(-2 pi i m / 1024), m < 768 (LDS)
     double2 v[16];
 #pragma unroll
@@ -1418,11 +1422,17 @@ __device__ __forceinline__ void fft1024_cq(double2* buf, int lane, const double2
     for (int b = 0; b < 4; ++b) {
         const int k = lane + 64 * b;
         double2 a0 = v[b], a1 = dmul(v[b + 4], rtab[k * RS]), a2 = dmul(v[b + 8], rtab[2 * k * RS]), a3 = dmul(v[b + 12], rtab[3 * k * RS]);
-        dft4d(a0, a1, a2, a3);
-        lds_st(&buf[physd(k)], a0);
-        lds_st(&buf[physd(k + 256)], a1);
-        lds_st(&buf[physd(k + 512)], a2);
-        lds_st(&buf[physd(k + 768)], a3);
+        if constexpr (FULL) {
+            dft4d(a0, a1, a2, a3);
+            lds_st(&buf[physd(k)], a0);
+            lds_st(&buf[physd(k + 256)], a1);
+            lds_st(&buf[physd(k + 512)], a2);
+            lds_st(&buf[physd(k + 768)], a3);
+        } else {   // outputs k and k + 768 only
+            const double2 t0 = dadd(a0, a2), t1 = dsub(a0, a2), t2 = dadd(a1, a3), t3 = dmul_mi(dsub(a1, a3));
+            lds_st(&buf[physd(k)], dadd(t0, t2));
+            lds_st(&buf[physd(k + 768)], dsub(t1, t3));
+        }
     }
     frame_sync<64>();
 }
@@ -1441,7 +1451,7 @@ __device__ __forceinline__ void fft1024_cq(double2* buf, int lane, const double2
 #define ZAFX_CQ64_RTAB_LDS 1   // the last pass's roots from LDS (0: from the plan's table in global memory)
 #endif
 ZAFX_PROF_ARRAY(g_prof_cqt64)
-template <int KC2, bool REALK>
+template <int KC2, bool REALK, bool FULL>
 __global__ __launch_bounds__(kCq64Threads) void k_cqt_ft_f64(const double* __restrict__ x, const double2* __restrict__ tws, const double2* __restrict__ tw1,
                                                               const int* __restrict__ split_tab, const void* __restrict__ cvals, const int* __restrict__ cmeta,
                                                               const int2* __restrict__ fin, double* __restrict__ out, long long n_samples, int step, int left, int T,
@@ -1566,8 +1576,8 @@ __global__ __launch_bounds__(kCq64Threads) void k_cqt_ft_f64(const double* __res
                 int tid_f = tid;
                 asm volatile("" : "+v"(tid_f));   // (opaque per sub-transform: its forty LDS addresses are recomputed, not kept -- spilled -- across the loop)
                 double2* buf_f = frames + (tid_f >> 6) * PITCH;
-                if (ZAFX_CQ64_RTAB_LDS) fft1024_cq<1>(buf_f, tid_f & 63, w2tab, rtab);   // wave p: sub-transform q = 2 p + round
-                else fft1024_cq<32>(buf_f, tid_f & 63, w2tab, tws);
+                if (ZAFX_CQ64_RTAB_LDS) fft1024_cq<1, FULL>(buf_f, tid_f & 63, w2tab, rtab);   // wave p: sub-transform q = 2 p + round
+                else fft1024_cq<32, FULL>(buf_f, tid_f & 63, w2tab, tws);
             }
             PROF_MARK(2);
             if (ZAFX_CQ64_PREFETCH) {
@@ -1762,6 +1772,9 @@ static hipError_t build_cqt64(zafx_plan& pl) {
     pl.cqt64_steps = t.steps;
     pl.cqt64_slots = t.slots;
     pl.cqt64_max_parts = t.max_parts;
+    int max_col = 0;
+    for (int i = 0; i < pl.nnz; ++i) max_col = std::max(max_col, pl.h_indices[(size_t)i]);
+    pl.cqt64_klo = max_col >> 4;   // (columns 1 .. 8191: klo <= 511; the mirrors N - c lie at k >= 1023 - klo)
     pl.cqt64_ok = true;
     return hipSuccess;
 }
@@ -1919,8 +1932,12 @@ hipError_t launch_cqt_f64(zafx_plan& pl, const double* x, double* out, int64_t n
         const size_t smem = (size_t)(kCq64Threads / 64) * kF64Pitch * sizeof(double2) + (256 + 768) * sizeof(double2);
         const int diff = pl.W - pl.H;
         const int left = diff >= 0 ? (diff + 1) / 2 : -((-diff) / 2);   // ceil((fft_length - step) / 2), zaf.py:615
-        auto kern = pl.cqt64_real ? (pl.cqt64_kc2 <= 1 ? k_cqt_ft_f64<1, true> : pl.cqt64_kc2 == 2 ? k_cqt_ft_f64<2, true> : pl.cqt64_kc2 == 3 ? k_cqt_ft_f64<3, true> : k_cqt_ft_f64<4, true>)
-                                  : (pl.cqt64_kc2 <= 1 ? k_cqt_ft_f64<1, false> : pl.cqt64_kc2 == 2 ? k_cqt_ft_f64<2, false> : pl.cqt64_kc2 == 3 ? k_cqt_ft_f64<3, false> : k_cqt_ft_f64<4, false>);
+        auto pick = [&](auto full) {
+            constexpr bool F = decltype(full)::value;
+            return pl.cqt64_real ? (pl.cqt64_kc2 <= 1 ? k_cqt_ft_f64<1, true, F> : pl.cqt64_kc2 == 2 ? k_cqt_ft_f64<2, true, F> : pl.cqt64_kc2 == 3 ? k_cqt_ft_f64<3, true, F> : k_cqt_ft_f64<4, true, F>)
+                                 : (pl.cqt64_kc2 <= 1 ? k_cqt_ft_f64<1, false, F> : pl.cqt64_kc2 == 2 ? k_cqt_ft_f64<2, false, F> : pl.cqt64_kc2 == 3 ? k_cqt_ft_f64<3, false, F> : k_cqt_ft_f64<4, false, F>);
+        };
+        auto kern = pl.cqt64_klo >= 256 ? pick(std::true_type{}) : pick(std::false_type{});   // (FULL: the last pass of the sub-transforms writes every quarter)
         const int kc2 = pl.cqt64_kc2 <= 3 ? std::max(pl.cqt64_kc2, 1) : 4;
         if (kc2 != pl.cqt64_kc2) return hipErrorInvalidValue;   // (the split table is laid out for the plan's own count)
         if (hipError_t e = ensure_dynamic_lds(reinterpret_cast<const void*>(kern), pl.device, smem); e != hipSuccess) return e;

@@ -166,7 +166,7 @@ struct zafx_plan {
     double* d_cqt64_vals = nullptr;     // [steps][512] float64 (cqt64_real) or complex128: the matrix's non-zeros as one stream per thread ...
     int* d_cqt64_meta = nullptr;        // ... compact index | conjugate << 13 | (slot of the partial sum + 1) << 14
     int2* d_cqt64_fin = nullptr;        // [rows]: {first slot, slots}
-    int cqt64_kc2 = 0, cqt64_cols = 0, cqt64_steps = 0, cqt64_slots = 0, cqt64_max_parts = 0;
+    int cqt64_kc2 = 0, cqt64_cols = 0, cqt64_steps = 0, cqt64_slots = 0, cqt64_max_parts = 0, cqt64_klo = 511;   // klo: (highest kernel column) >> 4, what the sub-transforms' last pass may skip (fft1024_cq)
     bool cqt64_ok = false, cqt64_dirty = true, cqt64_real = false;
     int bs_log2m = 0;              // > 0: window that is not a power of two -- Bluestein convolution length 2^bs_log2m (zafx_f64.hip, zafx_bs32.hip)
     void* d_pcm_float = nullptr;   // zafx_execute_pcm's float32 staging for the kinds that do not (grow-only)

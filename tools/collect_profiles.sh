@@ -10,7 +10,8 @@ REPO=$PWD
 OUT=$REPO/gpurun_out
 mkdir -p "$OUT"
 export TMPDIR=/tmp
-SQ_KINDS=${SQ_KINDS:-"mel mfcc mel_mfcc cqt stft mel64 cqt64"}
+SQ_KINDS=${SQ_KINDS:-"mel mfcc mel_mfcc cqt stft mel64 cqt64 istft8192 imdct8192"}
+if [ -z "$SQ_ONLY" ]; then
 cd /tmp || exit 1
 rm -rf "$OUT/prof_all"
 ZAFX_BENCH_INNER_LOG="$OUT/prof_all_launches.json" timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/prof_all" -o all -- \
@@ -19,6 +20,7 @@ cp "$OUT/bench_detail.json" "$OUT/bench_detail_profiled.json" 2>/dev/null
 cd "$REPO" || exit 1
 timeout 900 python bench.py --gpus 1 --steps 20 --warmup 5 > "$OUT/bench_all.json" 2> "$OUT/bench_all.log"   # the driver's own command
 cp "$OUT/bench_detail.json" "$OUT/bench_detail_plain.json" 2>/dev/null   # (the counter passes below write their own)
+fi   # (SQ_ONLY=1: only the counter passes below, for the kinds in SQ_KINDS)
 cd /tmp || exit 1
 for k in $SQ_KINDS; do
   rm -rf "$OUT/pmc_${k}_SQ" "$OUT/pmc_${k}_LDS"

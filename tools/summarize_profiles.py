@@ -97,7 +97,7 @@ def all_counters(kind, leg):
     return {k: {c: v / n for c, (n, v) in d.items()} for k, d in acc.items()}
 
 
-KERNEL_OF = {"mel": "k_mel", "mfcc": "k_mel", "mel_mfcc": "k_mel", "cqt": "k_cqt", "stft": "k_stft_ft16", "dct": "k_dct", "mel64": "k_mel_ft8_f64", "cqt64": "k_cqt_ft_f64"}
+KERNEL_OF = {"mel": "k_mel", "mfcc": "k_mel", "mel_mfcc": "k_mel", "cqt": "k_cqt", "stft": "k_stft_ft16", "dct": "k_dct", "mel64": "k_mel_ft8_f64", "cqt64": "k_cqt_ft_f64", "istft8192": "k_istft_ft8q", "imdct8192": "k_imdct_q"}
 sq_rows = []
 for kind, kname in KERNEL_OF.items():
     merged, label = {}, kname

@@ -50,7 +50,7 @@ F32_PEAK_TFLOPS = 157.3    # dense f32 vector / f32-input MFMA peak
 F64_PEAK_TFLOPS = 78.6     # float64 vector: half the f32 vector rate (v_fma_f64 issues every 4 cycles per wave: 256 CUs x 4 SIMDs x 32 FLOP/clk x 2.4 GHz; the guide lists no f64 row)
 PLACEMENT_SURVEY = 6       # further allocations of the headline's row-strided output probed AFTER every timed region (reported, never timed)
 CONFIG_KINDS = ("istft", "mel", "mfcc", "mel_mfcc", "mdct", "imdct", "cqt")   # SURVEY 8(a) a2 + BASELINE configs 3 (mel_mfcc: in one pass), 4, 5 (config 2 = the headline)
-EXTRA_KINDS = ("stft1", "stftmag", "istft1", "stft_offgrid", "mdct_offgrid", "stft4096", "stft4096_h1024", "istft4096", "mdct4096", "mel4096", "dct", "stft64", "mdct64", "istft_offgrid", "imdct_offgrid", "stftmag_offgrid", "stft8192", "mdct8192", "istft64", "imdct64", "mel64", "mfcc64", "cqt64", "istft_offgrid_compact", "stftmag_offgrid_compact", "mel_pcm16", "mdct_pcm16", "dct1000", "istft8192", "imdct8192", "stft_offgrid_padded", "mdct_offgrid_padded")   # one-sided pair (8f rank 4) and geometries off the benchmark's grid
+EXTRA_KINDS = ("stft1", "stftmag", "istft1", "stft_offgrid", "mdct_offgrid", "stft4096", "stft4096_h1024", "istft4096", "mdct4096", "mel4096", "dct", "stft64", "mdct64", "istft_offgrid", "imdct_offgrid", "stftmag_offgrid", "stft8192", "mdct8192", "istft64", "imdct64", "mel64", "mfcc64", "cqt64", "istft_offgrid_compact", "stftmag_offgrid_compact", "mel_pcm16", "mdct_pcm16", "dct1000", "istft8192", "imdct8192", "stft_offgrid_padded", "mdct_offgrid_padded", "stft4096_padded", "istft4096_padded", "mdct4096_padded")   # one-sided pair (8f rank 4) and geometries off the benchmark's grid
 
 
 def synth(seed, c, n):
@@ -146,23 +146,24 @@ def make_workload(kind, device, layout="FT"):
                   desc="Batched STFT off the line grid: 1024 clips x 442024 samples, win=2048 hop=1024, T = 433" + (", device rows padded to 128-byte lines (pitch 448: stft_batch's "
                        "default off the grid; algorithmic bytes of the compact array)" if padded_rows else " (rows straddle 128-byte lines), compact (W,T) layout"))
     elif kind == "stft4096":
-        plan = zafx.stft_plan(zafx.hamming(4096), 2048, layout=layout, device=device)
+        plan = zafx.stft_plan(zafx.hamming(4096), 2048, layout=layout, device=device, row_align=16 if padded_rows else 0)
         wl.update(plan=plan, d_in=d_x, n_in=N, bytes_per_launch=B * (4 * N + 8 * 4096 * T),
-                  desc="Batched STFT, win=4096 hop=2048: 1024 clips x 10 s, T = 217, two-sided c64 (W,T) layout")
+                  desc="Batched STFT, win=4096 hop=2048: 1024 clips x 10 s, T = 217, two-sided c64 (W,T) layout" + (", device rows padded to 128-byte lines (pitch 224: stft_batch's default off the grid; "
+                       "algorithmic bytes of the compact array)" if padded_rows else ""))
     elif kind == "stft4096_h1024":   # W = 4096 on the line grid (T = 432): k_stft_ft16b, two bands of bins per 16-frame tile
         plan = zafx.stft_plan(zafx.hamming(4096), 1024, layout=layout, device=device)
         wl.update(plan=plan, d_in=d_x, n_in=N, bytes_per_launch=B * (4 * N + 8 * 4096 * T),
                   desc="Batched STFT, win=4096 hop=1024: 1024 clips x 10 s, T = 432, two-sided c64 (W,T) layout")
     elif kind == "istft4096":        # k_istft_ft16b: one band of samples (even / odd packed samples) per workgroup; T = 217 is odd: 8-byte row pieces
-        fwd = zafx.stft_plan(zafx.hamming(4096), 2048, device=device)
+        fwd = zafx.stft_plan(zafx.hamming(4096), 2048, device=device, row_align=16 if padded_rows else 0)
         d_s = zafx.DeviceBuffer(fwd.out_shape(B, N), np.complex64, device)
         fwd.execute(d_x, d_s, B, N)
         INNER_LOG.append({"kind": None, "kernel": fwd.last_kernel, "launches": 1})
         fwd.sync()
         d_x.free()
-        plan = zafx.istft_plan(zafx.hamming(4096), 2048, device=device)
+        plan = zafx.istft_plan(zafx.hamming(4096), 2048, device=device, row_align=16 if padded_rows else 0)
         wl.update(plan=plan, d_in=d_s, n_in=T, bytes_per_launch=B * (8 * 4096 * T + 4 * (T * 2048 - 2048)),
-                  desc="Batched ISTFT, win=4096 hop=2048: 1024 clips x 217 frames")
+                  desc="Batched ISTFT, win=4096 hop=2048: 1024 clips x 217 frames" + (" (device rows padded to 128-byte lines: istft_batch's default off the grid)" if padded_rows else ""))
     elif kind == "stft8192":         # k_stft_ft16q: four classes of bins per 16-frame tile
         plan = zafx.stft_plan(zafx.hamming(8192), 4096, layout=layout, device=device)
         wl.update(plan=plan, d_in=d_x, n_in=N, bytes_per_launch=B * (4 * N + 8 * 8192 * T),
@@ -188,9 +189,10 @@ def make_workload(kind, device, layout="FT"):
         wl.update(plan=plan, d_in=d_x, n_in=N, bytes_per_launch=B * (4 * N + 4 * 4096 * T),
                   desc="Batched MDCT, KBD win=8192: 1024 clips x 11.8 s, T = 128, compact (W/2,T) layout")
     elif kind == "mdct4096":         # k_mdct_ft32b (32-frame tiles, two bands of bins); T = 217 is odd: rows off the line grid
-        plan = zafx.mdct_plan(zafx.kaiser_bessel_derived(4096), device=device)
+        plan = zafx.mdct_plan(zafx.kaiser_bessel_derived(4096), device=device, row_align=32 if padded_rows else 0)
         wl.update(plan=plan, d_in=d_x, n_in=N, bytes_per_launch=B * (4 * N + 4 * 2048 * T),
-                  desc="Batched MDCT, KBD win=4096: 1024 clips x 10 s, T = 217, compact (W/2,T) layout")
+                  desc="Batched MDCT, KBD win=4096: 1024 clips x 10 s, T = 217, " + ("device rows padded to 128-byte lines (pitch 224: mdct_batch's default off the grid; algorithmic bytes of the "
+                       "compact array)" if padded_rows else "compact (W/2,T) layout"))
     elif kind == "mel4096":          # k_mel_ft16b: the two-band STFT kernel with the filterbank product in place of the stores
         plan = zafx.mel_plan(zafx.hamming(4096), 2048, zafx.melfilterbank(FS, 4096, 128), device=device)
         wl.update(plan=plan, d_in=d_x, n_in=N, bytes_per_launch=B * (4 * N + 4 * 128 * T),

@@ -590,6 +590,36 @@ def test_istft_w8192_four_classes(zafx, n, clips):
     assert zafx.istft_plan(w, 2048).last_kernel != "k_istft_ft8q"
 
 
+@pytest.mark.parametrize("n,clips", [(2048 * 11 + 100, 2), (2048 * 31, 3), (3000, 1), (2048 * 70 + 1, 5), (2048 * 40, 300), (441000, 9)])
+def test_istft_w4096_two_classes(zafx, n, clips):
+    """W = 4096, hop 2048 in the reference layout: k_istft_ft16d (round 6: the even rows as the W = 2048 inverse of x0 + x1, the rows 4p + 1 and their
+    mirrors as one 1024-point inverse that gives x0 - x1; every row read once where k_istft_ft16b read every row per band; zaf.py:223 and :226-241
+    are what it replaces) -- odd and even frame counts (8-byte and 16-byte row pieces), one and many tiles per clip, clips cut into segments,
+    one-sided input, an input that is not Hermitian, padded rows; other hops stay on the band kernel."""
+    x = np.stack([synth_clip(83, c % 5, n) for c in range(clips)])
+    w = zafx.hamming(4096)
+    spec = np.stack([orc.stft(x[c].astype(np.float64), w, 2048) for c in range(min(clips, 5))])
+    spec = spec[np.arange(clips) % spec.shape[0]].astype(np.complex64)
+    ref = [orc.istft(spec[c].astype(np.complex128), w, 2048) for c in range(min(clips, 5))]
+    for one in (False, True):
+        y = zafx.istft_batch(np.ascontiguousarray(spec[:, :2049] if one else spec), w, 2048, onesided=one)
+        assert zafx.istft_plan(w, 2048, onesided=one).last_kernel == "k_istft_ft16d"
+        assert y.shape == (clips, len(ref[0]))
+        for c in range(clips):
+            assert relerr(y[c], ref[c % 5]) <= TOL_FFT, (one, c)
+        k = min(n, y.shape[1])
+        assert np.max(np.abs(y[:, :k] - x[:, :k])) < 1e-5   # COLA resynthesis (zaf.py:165-194)
+    rng = np.random.default_rng(n)
+    noisy = (spec[:2] + 0.05 * (rng.standard_normal(spec[:2].shape) + 1j * rng.standard_normal(spec[:2].shape))).astype(np.complex64)
+    y = zafx.istft_batch(noisy, w, 2048)
+    for c in range(len(noisy)):
+        assert relerr(y[c], orc.istft(noisy[c].astype(np.complex128), w, 2048)) <= TOL_FFT   # real(ifft(.)) of anything (zaf.py:223)
+    pl = zafx.istft_plan(w, 2048, row_align=16)
+    assert relerr(pl.run_host(spec[:1], spec.shape[2]), np.stack(ref[:1])) <= TOL_FFT and pl.last_kernel == "k_istft_ft16d"
+    zafx.istft_batch(np.stack([orc.stft(x[0].astype(np.float64), w, 1024)]).astype(np.complex64), w, 1024)
+    assert zafx.istft_plan(w, 1024).last_kernel == "k_istft_ft16b"
+
+
 @pytest.mark.parametrize("n,clips", [(4096 * 11 + 100, 2), (4096 * 30, 3), (5000, 1), (4096 * 70 + 1, 5), (4096 * 15, 300)])
 def test_imdct_w8192_two_classes(zafx, n, clips):
     """W = 8192 in the reference layout: k_imdct_q (round 6: the coefficient rows as two classes by the parity of m -- 4m', M-1-4m' and 4m'+2,
@@ -1053,7 +1083,7 @@ def test_istft_w4096_two_bands(zafx, hop, n, clips):
     got = zafx.istft_batch(full, w, hop)
     # the band form for hops that are multiples of 4 from 512 up (odd row pitches: its 8-byte row pieces), the generic kernel otherwise
     assert zafx.istft_plan(w, hop).kernel_name == "k_istft_ft16b"
-    assert zafx.istft_plan(w, hop).last_kernel == ("k_istft_ft16b" if hop % 4 == 0 and hop >= 512 else "k_istft"), hop
+    assert zafx.istft_plan(w, hop).last_kernel == ("k_istft_ft16d" if hop == 2048 else "k_istft_ft16b" if hop % 4 == 0 and hop >= 512 else "k_istft"), hop   # (hop W / 2: round 6's two-class kernel)
     for c in range(min(clips, 7)):
         ref = orc.istft(full[c], w, hop)
         assert got[c].shape == ref.shape and relerr(got[c], ref) <= TOL_FFT, c

@@ -2986,8 +2986,235 @@ static hipError_t run_istft_quad(const zafx_plan& pl, const float2* spec, float*
     return hipGetLastError();
 }
 
+// ---------------------------------------------------------------------------------
+// inverse, reference layout, W = 4096, hop = W / 2: two CLASSES of rows per 16-frame tile (k_istft_ft16d; round 6)
+// ---------------------------------------------------------------------------------
+// k_istft_ft8q's first two classes are the whole of W = 4096: with x0, x1 the halves of the real frame v = real(ifft(X)) (zaf.py:223) and Xh the
+// Hermitian part of an arbitrary input,
+//   rows 2q           = DFT_2048(s)[q],  s = x0 + x1 (real): the W = 2048 inverse (unsplit_pair + one 1024-point transform)
+//   rows 4p + 1 (+ 3) = DFT_1024(u)[p],  u[n] = (d[n] - i d[n + 1024]) w_4096^n,  d = x0 - x1
+// and x0 = (s + d) / 2, x1 = (s - d) / 2 in registers (a lane keeps its 32 values of s across the second round).  Every row is read ONCE --
+// k_istft_ft16b runs one band of SAMPLES per workgroup and each band needs every row: 1.79 x the algorithmic bytes -- as 128-byte pieces (16
+// frames), a wavefront transforms its frame in its own buffer, and the overlap-add (zaf.py:226-233, hop = W / 2: a frame's second half + the next
+// frame's first) goes through LDS to the wave of the next frame (the tile's last one: to the next tile) with 16-byte stores.
+#ifndef ZAFX_ISTFT_DUO
+#define ZAFX_ISTFT_DUO 1
+#endif
+#ifndef ZAFX_ISTFT_DUO_DEPTH
+#define ZAFX_ISTFT_DUO_DEPTH 1   // sweeps of a class's gather in flight per thread (1 / 2 / 4: 1.87 / 1.92 / 1.98 ms on padded rows, 2.95 / 3.06 / 3.53 compact at T = 217)
+#endif
+struct IstftDCfg {
+    using C = FftCfg<10, 4>;
+    static constexpr int N = C::N, FPB = 16, NT = 1024, PITCH = C::PITCH, HALF = 2048;
+    static constexpr size_t REGION = (size_t)FPB * PITCH * 8;   // FPB transform buffers; behind the second round FPB - 1 second halves (8 KB each)
+    static constexpr size_t SMEM = REGION + (size_t)HALF * 4 + (size_t)(C::TW + N) * 8;   // buffers | carry | pass twiddles | exp(-2 pi i k / 4096), k < 1024
+};
+static_assert(IstftDCfg::SMEM <= (size_t)kMaxLdsBytes && IstftDCfg::REGION >= (size_t)(IstftDCfg::FPB - 1) * IstftDCfg::HALF * 4, "k_istft_ft16d: tile + carry + tables exceed LDS");
+
+// FV: frames per lane and load (2: 16-byte loads of two adjacent frames; needs an even row pitch)
+template <bool ONE, int FV>
+__global__ __launch_bounds__(IstftDCfg::NT) void k_istft_ft16d(const float2* __restrict__ spec, const float2* __restrict__ twp, const float2* __restrict__ tww,
+                                                                float* __restrict__ y, int T, int TP, long long out_len, float scale, int tiles, int segs,
+                                                                int seg_tiles, int total_units) {
+    using Q = IstftDCfg;
+    using C = Q::C;
+    constexpr int N = C::N, P = 64, E = C::E, W = 4096, FPB = Q::FPB, NT = Q::NT, PITCH = Q::PITCH, HALF = Q::HALF, ROWS = ONE ? W / 2 + 1 : W;
+    static_assert(C::P == 64, "a frame's 1024-point transform is one wavefront's");
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    float2* frames = reinterpret_cast<float2*>(smem_raw);        // FPB transform buffers ...
+    float* xch = reinterpret_cast<float*>(smem_raw);              // ... and, behind the second round, FPB - 1 second halves of frames
+    float* carry = reinterpret_cast<float*>(smem_raw + Q::REGION);   // the second half of the frame before the tile
+    float2* tw_l = reinterpret_cast<float2*>(carry + HALF);
+    float2* tww_l = tw_l + C::TW;                                 // exp(-2 pi i k / 4096), k < 1024: the second class's roots; [2k] = the first class's split roots
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    constexpr int LPR = FPB / FV, KS = NT / LPR;                  // lanes per row piece, rows per sweep (128 or 64)
+    const int fr = (tid % LPR) * FV, kq = tid / LPR;              // gather: my first frame of the tile, my row within a sweep
+    for (int i = tid; i < C::TW; i += NT) tw_l[i] = twp[i];
+    for (int i = tid; i < N; i += NT) tww_l[i] = tww[i];   // (the plan's real-split roots)
+    for (int i = tid; i < HALF; i += NT) carry[i] = 0.f;
+    lds_barrier();
+    const int row_bytes = TP * 8;
+    float2* const fb = frames + fr * PITCH;      // the buffer my gathers fold into
+    float2* const buf = frames + wave * PITCH;   // the buffer my wave transforms
+
+    for (int unit = blockIdx.x; unit < total_units; unit += gridDim.x) {
+        const int seg = unit % segs;
+        const long long clip = unit / segs;
+        const int tile_a = seg * seg_tiles, tile_b = min(tile_a + seg_tiles, tiles);
+        const auto rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float2*>(spec) + clip * ROWS * TP, 0, ROWS * row_bytes, 0x00020000);
+        float* const yc = y + clip * out_len;
+        for (int tile = tile_a > 0 ? tile_a - 1 : 0; tile < tile_b; ++tile) {
+            const bool write_out = tile >= tile_a;   // (the tile in front of a segment only leaves its last second half behind)
+            const int t0 = tile * FPB;
+            int lo = lane;
+            asm volatile("" : "+v"(lo));   // (opaque per tile: addresses are recomputed, not carried -- spilled -- across the rounds)
+            const int tb = (t0 + fr) * 8;  // byte offset of my frame within a row
+            using RV = std::conditional_t<FV == 2, float4, float2>;   // X[row] of my FV frames
+            auto raw = [&](int row) {
+                RV f;
+                if constexpr (FV == 2) {
+                    const auto v = __builtin_amdgcn_raw_buffer_load_b128(rsrc, row * row_bytes + tb, 0, 0);
+                    __builtin_memcpy(&f, &v, 16);
+                } else {
+                    const auto v = __builtin_amdgcn_raw_buffer_load_b64(rsrc, row * row_bytes + tb, 0, 0);
+                    __builtin_memcpy(&f, &v, 8);
+                }
+                return f;
+            };
+            auto conj_rv = [](RV v) {
+                if constexpr (FV == 2) return make_float4(v.x, -v.y, v.z, -v.w);
+                else return cconj(v);
+            };
+            auto part = [](RV v, int f) {   // frame f of a piece
+                if constexpr (FV == 2) return f ? make_float2(v.z, v.w) : make_float2(v.x, v.y);
+                else return v;
+            };
+            auto xat = [&](int k) {        // X[k], k < W: a one-sided input completes X[W - k] = conj X[k]
+                if (ONE && k > W / 2) return conj_rv(raw(W - k));
+                return raw(k);
+            };
+            // ---- first class: rows 2q, the W = 2048 inverse
+#pragma unroll ZAFX_ISTFT_DUO_DEPTH
+            for (int sw = 0; sw < 512 / KS; ++sw) {
+                const int k = kq + KS * sw;
+                if (k == 0) {
+                    const RV r0 = xat(0), r1 = xat(1024), r2 = xat(2048), r3 = ONE ? conj_rv(r1) : xat(3072);
+#pragma unroll
+                    for (int f = 0; f < FV; ++f) {
+                        const float2 q0 = part(r0, f), q1 = part(r1, f), q2 = part(r2, f), q3 = part(r3, f);
+                        const float a0 = 2.f * q0.x, an = 2.f * q2.x;
+                        fb[f * PITCH] = make_float2(a0 - an, a0 + an);
+                        const float2 a = make_float2(q1.x + q3.x, q1.y - q3.y);
+                        fb[f * PITCH + phys(N / 2)] = make_float2(-2.f * a.y, 2.f * a.x);
+                    }
+                } else {
+                    const RV r0 = xat(2 * k), r2 = xat(2048 - 2 * k);
+                    const RV r1 = ONE ? conj_rv(r0) : xat(W - 2 * k), r3 = ONE ? conj_rv(r2) : xat(2048 + 2 * k);
+#pragma unroll
+                    for (int f = 0; f < FV; ++f) {
+                        float2 zk, zn;
+                        unsplit_pair(part(r0, f), part(r1, f), part(r2, f), part(r3, f), tww_l[2 * k], zk, zn);
+                        fb[f * PITCH + phys(k)] = zk;
+                        fb[f * PITCH + phys(N - k)] = zn;
+                    }
+                }
+            }
+            auto transform = [&]() {   // my wave's frame: forward transform of the swapped spectrum = swapped inverse transform
+                lds_barrier();
+                float2 v[E];
+                regs_read<10, 4>(v, buf, lo);
+                frame_sync<P>();
+                fft_frame<10, 4>(v, buf, lo, tw_l);
+                frame_sync<P>();
+            };
+            transform();
+            // lane l of a wave keeps the indices j = 4 l + 256 i + c (c < 4, i < 4) and j + 1024 of its frame's sequences
+            float sA[4][2][4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int h = 0; h < 2; ++h) {
+                    const float2 q0 = buf[phys(2 * lo + 128 * i + 512 * h)], q1 = buf[phys(2 * lo + 1 + 128 * i + 512 * h)];   // (s[2n + 1], s[2n])
+                    sA[i][h][0] = q0.y, sA[i][h][1] = q0.x, sA[i][h][2] = q1.y, sA[i][h][3] = q1.x;
+                }
+            // ---- second class: rows 4p + 1 and their mirrors W - (4p + 1): 2 Xh[4p + 1], swapped
+            lds_barrier();   // every wave has read the first class
+#pragma unroll ZAFX_ISTFT_DUO_DEPTH
+            for (int sw = 0; sw < 1024 / KS; ++sw) {
+                const int p = kq + KS * sw, a = 4 * p + 1;
+                const RV va = ONE ? xat(a) : raw(a), vb = ONE ? RV{} : raw(W - a);
+#pragma unroll
+                for (int f = 0; f < FV; ++f) {
+                    const float2 qa = part(va, f), qb = part(vb, f);
+                    const float2 g = ONE ? make_float2(2.f * qa.x, 2.f * qa.y) : make_float2(qa.x + qb.x, qa.y - qb.y);
+                    fb[f * PITCH + phys(p)] = make_float2(g.y, g.x);
+                }
+            }
+            transform();
+            float own[4][2][4], sec[4][2][4];   // [i][h][c]: the frame's first half x0 and second half x1 at j + 1024 h
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                    const int j = 4 * lo + 256 * i + c;
+                    const float2 q = buf[phys(j)];
+                    const float2 cb = cmulc(make_float2(q.y, q.x), tww_l[j]);   // u conj(w_4096^j) = 2 (d[j] - i d[j + 1024])
+                    const float r[2] = {cb.x, -cb.y};
+#pragma unroll
+                    for (int h = 0; h < 2; ++h) {
+                        const float b = 0.5f * sA[i][h][c];
+                        own[i][h][c] = b + r[h];
+                        sec[i][h][c] = b - r[h];
+                    }
+                }
+            lds_barrier();   // every wave has read its second class: the buffers become the exchange area
+            if (wave < FPB - 1) {
+                float* dst = xch + wave * HALF;
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+#pragma unroll
+                    for (int h = 0; h < 2; ++h)
+                        *reinterpret_cast<float4*>(dst + 1024 * h + 256 * i + 4 * lo) = make_float4(sec[i][h][0], sec[i][h][1], sec[i][h][2], sec[i][h][3]);
+            }
+            lds_barrier();
+            {
+                const int t = t0 + wave;
+                const float* src = wave == 0 ? carry : xch + (wave - 1) * HALF;
+                const bool store = write_out && t >= 1 && t < T;   // frame t's first half + frame t - 1's second = samples (t - 1) hop ... t hop of the trimmed clip
+                float* o = yc + (long long)(t - 1) * HALF + 4 * lo;
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+#pragma unroll
+                    for (int h = 0; h < 2; ++h) {
+                        const float4 pv = *reinterpret_cast<const float4*>(src + 1024 * h + 256 * i + 4 * lo);
+                        const float4 v = make_float4((pv.x + own[i][h][0]) * scale, (pv.y + own[i][h][1]) * scale, (pv.z + own[i][h][2]) * scale,
+                                                     (pv.w + own[i][h][3]) * scale);
+                        if (store) *reinterpret_cast<float4*>(o + 1024 * h + 256 * i) = v;
+                    }
+            }
+            lds_barrier();   // the exchange area and the carry are read: the next tile folds into the one, the tile's last frame leaves its second half in the other
+            if (wave == FPB - 1) {
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+#pragma unroll
+                    for (int h = 0; h < 2; ++h)
+                        *reinterpret_cast<float4*>(carry + 1024 * h + 256 * i + 4 * lo) = make_float4(sec[i][h][0], sec[i][h][1], sec[i][h][2], sec[i][h][3]);
+            }
+        }
+        // (a unit's first tile reads the carry of the tile before it: a clip starts with zeros there)
+        lds_barrier();
+        for (int i = tid; i < HALF; i += NT) carry[i] = 0.f;
+        lds_barrier();
+    }
+}
+
+template <bool ONE>
+static hipError_t run_istft_duo(const zafx_plan& pl, const float2* spec, float* y, int64_t n_clips, int T, int64_t out_len) {
+    using Q = IstftDCfg;
+    const int tiles = (T + Q::FPB - 1) / Q::FPB;
+    if ((long long)tiles * n_clips <= 0 || out_len <= 0) return hipSuccess;
+    const bool wide = row_pitch(pl, T) % 2 == 0 && reinterpret_cast<uintptr_t>(spec) % 16 == 0;   // 16-byte pieces of two frames
+    auto kern = wide ? k_istft_ft16d<ONE, 2> : k_istft_ft16d<ONE, 1>;
+    if (hipError_t e = ensure_dynamic_lds(reinterpret_cast<const void*>(kern), pl.device, Q::SMEM); e != hipSuccess) return e;
+    const int segs = carry_segments(n_clips, tiles, pl.n_cus);
+    const int seg_tiles = (tiles + segs - 1) / segs;
+    const long long units = n_clips * segs;
+    const float scale = 1.f / (4096.f * pl.cola_gain);   // 1 / W of the inverse transform (the classes carry 2 Xh); zaf.py:241
+    pl.ran = "k_istft_ft16d";
+    hipLaunchKernelGGL(kern, dim3((unsigned)std::min<long long>(units, pl.n_cus)), dim3(Q::NT), Q::SMEM, pl.stream, spec, pl.d_tw_sub, pl.d_tw_aux, y, T,
+                       (int)row_pitch(pl, T), (long long)out_len, scale, tiles, segs, seg_tiles, (int)units);
+    return hipGetLastError();
+}
+
 template <int LOG2N, int LAYOUT, bool ONE>
 static hipError_t run_istft(const zafx_plan& pl, const float2* spec, float* y, int64_t n_clips, int T, int64_t out_len) {
+    if constexpr (ZAFX_ISTFT_DUO && LOG2N == 11 && LAYOUT == ZAFX_LAYOUT_FT) {
+        // W = 4096, hop = W / 2: the two-class kernel (32-bit byte offsets inside a clip's spectrum, 16-byte stores into the clip's samples)
+        const int64_t TP = row_pitch(pl, T);
+        if (pl.d_tw_sub && pl.d_tw_aux && pl.H == 2048 && reinterpret_cast<uintptr_t>(spec) % 8 == 0 && reinterpret_cast<uintptr_t>(y) % 16 == 0 &&
+            (long long)4096 * TP * 8 < (1LL << 31) && n_clips * (((long long)T + 15) / 16 + 1) < (1LL << 30))
+            return run_istft_duo<ONE>(pl, spec, y, n_clips, T, out_len);
+    }
     if constexpr (ZAFX_ISTFT_BAND && LOG2N == 11 && LAYOUT == ZAFX_LAYOUT_FT) {
         // W = 4096: the band form wants a hop that is a multiple of 4 (a sample keeps its residue mod 4 from frame to frame), at least 512
         // (ceil(W / H) - 1 <= 7 halo frames; the carry fits LDS), 32-bit byte offsets inside a clip's spectrum

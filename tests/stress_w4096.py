@@ -1,4 +1,4 @@
-"""Random geometries at W = 4096 (the band kernels of round 3: k_stft_ft16b / bc, k_istft_ft16b, k_mdct_ft32b, the 16-frame k_imdct, k_melfb) and at
+"""Random geometries at W = 4096 (the band kernels of round 3: k_stft_ft16b / bc, k_istft_ft16b and -- hop W / 2, round 6 -- k_istft_ft16d, k_mdct_ft32b, the 16-frame k_imdct, k_melfb) and at
 W = 8192 (two draws in five; round 5: k_stft_ft16q, k_mdct_ft32q, mel / mfcc through k_stft_ft16q + k_melfb; round 6: k_istft_ft8q at hop W / 2, k_imdct_q) against the oracle -- run by tests/test_gpu_stress.py with fixed seeds, or by hand:
     python tests/stress_w4096.py [seed [iterations]]"""
 import sys, os

@@ -217,7 +217,7 @@ def test_clipped_pcm_through_the_pcm_entry_points(zafx, consts, golden, channels
 @pytest.mark.parametrize("wl,hop", [(4096, 2048), (2048, 512), (1000, 250), (8192, 4096)])
 def test_signal_on_the_other_kernels(zafx, name, wl, hop):
     """The same signals through the kernels the W = 2048 / hop 1024 cases do not reach -- the two-band forms of W = 4096 (k_stft_ft16b / bc,
-    k_istft_ft16b, k_mdct_ft32b / bc, k_mel_ft16b), 75 % overlap, a window that is not a power of two (the Bluestein forms), the four-class
+    k_istft_ft16d, k_mdct_ft32b / bc, k_mel_ft16b), 75 % overlap, a window that is not a power of two (the Bluestein forms), the four-class
     forms of W = 8192 (k_stft_ft16q, k_mdct_ft32q and, round 6, their inverses k_istft_ft8q, k_imdct_q; 48 frames: rows on the line grid) -- against the
     oracle with the same two bounds."""
     n = 40 * hop + 300 if wl != 8192 else 47 * hop - 100
@@ -236,6 +236,8 @@ def test_signal_on_the_other_kernels(zafx, name, wl, hop):
     assert len(y) == len(yref) and relerr(y, yref) <= TOL_FFT
     if wl == 8192:
         assert zafx.istft_plan(ham, hop).last_kernel == "k_istft_ft8q"
+    if wl == 4096:
+        assert zafx.istft_plan(ham, hop).last_kernel == "k_istft_ft16d"   # (hop W / 2: the two-class kernel of round 6)
     nu = bin_noise(half, C_FLOOR, EPS32)
     gotm = zafx.stft_batch(x[None], ham, hop, onesided="magnitude")[0]
     assert check(f"{tag}.magnitude", gotm, np.abs(half), TOL_FFT, nu) <= TOL_FFT

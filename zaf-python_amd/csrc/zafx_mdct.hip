@@ -163,7 +163,7 @@ __global__ __launch_bounds__(NSLOT * 64) void k_mdct_ft32(
     int segs = 1, int seg_tiles = 0, int units = 0) {
     static_assert(!(CARRY && TFOUT), "the carry form is for the reference layout");
     using C = FftCfg<LOG2NF, LOG2E>;
-    constexpr int NF = C::N, M = 2 * NF, W = 4 * NF, P = C::P, E = C::E, FPB = kMdctTile, NT = NSLOT * P;
+    constexpr int NF = C::N, M = 2 * NF, P = C::P, E = C::E, FPB = kMdctTile, NT = NSLOT * P;
     constexpr int FPW = FPB / NSLOT;                    // frames per wave and tile
     constexpr int NU = NF / 4;                          // 16-sample groups per frame (see fold below)
     constexpr int UPL = NU >= P ? NU / P : 1;           // groups per lane
@@ -516,7 +516,7 @@ __global__ __launch_bounds__(MdctBandCfg::NT) void k_mdct_ft32b(
     using G = MdctBandCfg;
     using C = G::C;
     constexpr int NF = G::NF, HB = G::HB, M = G::M, P = 64, E = 8, FPB = G::FPB, NSLOT = G::NSLOT, NT = G::NT, FPW = FPB / NSLOT;
-    constexpr int NU = NF / 4;   // 16-sample groups per frame
+    [[maybe_unused]] constexpr int NU = NF / 4;   // 16-sample groups per frame
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     float2* frames = reinterpret_cast<float2*>(smem_raw);
     float2* tw_l = frames + FPB * C::PITCH;

@@ -2826,7 +2826,8 @@ __global__ __launch_bounds__(IstftQCfg::NT) void k_istft_ft8q(const float2* __re
             };
             PROF_MARK(0);
             // ---- class A: rows 4q, the W = 2048 inverse
-#pragma unroll (ZAFX_ISTFT_QUAD_DEPTH / 2 > 0 ? ZAFX_ISTFT_QUAD_DEPTH / 2 : 1)
+            constexpr int kDepthA = ZAFX_ISTFT_QUAD_DEPTH / 2 > 0 ? ZAFX_ISTFT_QUAD_DEPTH / 2 : 1;   // (class A issues four loads per sweep: half as many sweeps in flight)
+#pragma unroll kDepthA
             for (int sw = 0; sw < 512 / KS; ++sw) {
                 const int k = kq + KS * sw;
                 if (k == 0) {

@@ -2579,9 +2579,12 @@ static hipError_t run_stft(const zafx_plan& pl, const float* x, float2* out, int
 #ifndef ZAFX_STFT_CARRY
 #define ZAFX_STFT_CARRY 1
 #endif
+#ifndef ZAFX_STFT_CARRY_ALWAYS
+#define ZAFX_STFT_CARRY_ALWAYS(log2n) ((log2n) == 9)   // W = 1024, two-sided: the carry form also on the line grid (863 / 864 frames: 1.90 ms against k_stft_ft16's 2.22; one-sided 1.31 against 1.21: not; W = 512, 256: 2.15 / 2.54 against 2.05 / 2.12: not)
+#endif
         if constexpr (SPEC < 2 && ZAFX_STFT_CARRY) {
             // rows off the 128-byte grid (the array itself only needs its 8-byte alignment): the carry form writes whole lines anyway
-            if ((row_pitch(pl, T) % 16 != 0 || reinterpret_cast<uintptr_t>(out) % 128 != 0) && reinterpret_cast<uintptr_t>(out) % 8 == 0 && n_clips * (long long)T < (1LL << 31))
+            if (((SPEC == 0 && ZAFX_STFT_CARRY_ALWAYS(LOG2N)) || row_pitch(pl, T) % 16 != 0 || reinterpret_cast<uintptr_t>(out) % 128 != 0) && reinterpret_cast<uintptr_t>(out) % 8 == 0 && n_clips * (long long)T < (1LL << 31))
                 return aligned && n_samples < (1LL << 29) && (long long)T * pl.H < (1LL << 29) ? run_stft_fat_carry<LOG2N, true, SPEC>(pl, x, out, n_clips, n_samples, T)
                                : run_stft_fat_carry<LOG2N, false, SPEC>(pl, x, out, n_clips, n_samples, T);
         }

@@ -217,6 +217,12 @@ struct PcmPoint {
     static constexpr float scale() { return PCM == 1 ? 1.f / 32768.f : PCM == 2 ? 1.f / 65536.f : 1.f; }
 };
 
+// Opaque per-tile lane indices also below 32 points per thread: without them the compiler carries the thread's window and twiddle values across the tiles
+// (W = 1024: 224 registers, one workgroup per CU where LDS admits two; with them 71-81).  Measured, 1024 clips x 10 s at hop W / 2 on padded rows: W = 512
+// 2.01 -> 1.87 ms, W = 1024 one-sided 1.21 -> 1.16, |X| 1.08 -> 1.07 (compact rows: 1.15 -> 1.28), W = 256 2.13 -> 2.16: on for W = 512 and the complex kinds of W = 1024.
+#ifndef ZAFX_STFT_FAT_OPAQUE
+#define ZAFX_STFT_FAT_OPAQUE(log2n, spec) ((log2n) == 8 || ((log2n) == 9 && (spec) <= 1))
+#endif
 template <int LOG2N, int LOG2E, bool ALIGNED, int SPEC, int FPB_ = kFatFrames, int PCM = 0>
 __global__ __launch_bounds__(kFatWaves * 64) void k_stft_ft16(
     const float* __restrict__ x, const float* __restrict__ win, const float2* __restrict__ twp,
@@ -259,7 +265,7 @@ __global__ __launch_bounds__(kFatWaves * 64) void k_stft_ft16(
         if (tlv >= total_tiles) return;
         const int tl = xcd ? xcd_order(tlv, total_tiles) : tlv;
         int p = p_lane;   // (opaque at 32 points per thread: the 64-bit sample offsets of the edge path are recomputed, not hoisted)
-        if constexpr (E >= 32) asm volatile("" : "+v"(p));
+        if constexpr (E >= 32 || ZAFX_STFT_FAT_OPAQUE(LOG2N, SPEC)) asm volatile("" : "+v"(p));
         const int clip = tl / tiles, tile = tl % tiles;
         const float* xc = x + (long long)clip * n_samples;   // (PCM 2: a "sample" is one 4-byte frame of two int16)
         const long long first = (long long)tile * FPB * hop - N;               // first sample of the tile
@@ -317,7 +323,7 @@ __global__ __launch_bounds__(kFatWaves * 64) void k_stft_ft16(
         const int t0 = tile * FPB;
         PROF_MARK(0);
         int po = p;   // opaque copy: window and twiddle reads are not hoisted out of the tile loop (at 32 points per
-        if constexpr (E >= 32) asm volatile("" : "+v"(po));   // thread the hoisted values no longer fit beside the prefetch)
+        if constexpr (E >= 32 || ZAFX_STFT_FAT_OPAQUE(LOG2N, SPEC)) asm volatile("" : "+v"(po));   // thread the hoisted values no longer fit beside the prefetch)
 #pragma unroll
         for (int f = 0; f < FPW; ++f) {
             float2 v[E];
@@ -346,7 +352,7 @@ __global__ __launch_bounds__(kFatWaves * 64) void k_stft_ft16(
         if (t0 + tt < T) {
             float2* o = spec_base<SPEC>(out, (long long)clip * ROWS * TP + (t0 + tt));
             int kqo = kq;   // (opaque at 32 points per thread: the split roots of the 16 iterations are not carried across tiles)
-            if constexpr (E >= 32) asm volatile("" : "+v"(kqo));
+            if constexpr (E >= 32 || ZAFX_STFT_FAT_OPAQUE(LOG2N, SPEC)) asm volatile("" : "+v"(kqo));
             auto store_tile = [&](auto stream) {
                 constexpr bool ST = decltype(stream)::value;
                 // Every workgroup starts its sweep over the rows somewhere else (its XCD and its place in the XCD decide): the

@@ -146,6 +146,9 @@ int zafx_device_name(int device, char* buf, size_t buflen);
 
 /* ---- device memory (synchronous helpers; caller owns the allocations) -------------- */
 #define ZAFX_ERROR_OUT_OF_MEMORY 2 /* zafx_alloc: the device has no room (= hipErrorOutOfMemory); other codes are other faults */
+/* Arrays of 1 GiB and more are assembled from separate physical allocations of ZAFX_ALLOC_CHUNK_MB (default 64) MiB mapped back to back into one range
+ * (HIP's virtual-memory API; 0 = plain hipMalloc): where a multi-GB array lies in physical memory moves the kernels that write it by up to 12 %, and on most
+ * boxes the chunked form lands where hipMalloc's first allocation does not.  Pointers from zafx_alloc go back to zafx_free, not to hipFree. */
 int zafx_alloc(int device, void** dptr, size_t bytes);
 int zafx_free(int device, void* dptr);
 /* The fastest of `n_candidates` allocations of `bytes` for the OUTPUT of `plan` (no reference counterpart).  Where a

@@ -1,0 +1,42 @@
+// Does the placement effect follow the physical fragment size?  Device memory through HIP's virtual-memory API: physical chunks of a chosen
+// size mapped back to back into one reserved range.   hipcc -O2 -shared -fPIC --offload-arch=gfx950 -o tools/bin/libvmm.so tools/exp_vmm.hip
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <vector>
+
+extern "C" size_t vmm_granularity(int recommended) {
+    hipMemAllocationProp prop = {};
+    prop.type = hipMemAllocationTypePinned;
+    prop.location.type = hipMemLocationTypeDevice;
+    prop.location.id = 0;
+    size_t g = 0;
+    if (hipMemGetAllocationGranularity(&g, &prop, recommended ? hipMemAllocationGranularityRecommended : hipMemAllocationGranularityMinimum) != hipSuccess) return 0;
+    return g;
+}
+
+// bytes rounded up to whole chunks; chunk = 0: one physical allocation
+extern "C" void* vmm_alloc(size_t bytes, size_t chunk) {
+    hipMemAllocationProp prop = {};
+    prop.type = hipMemAllocationTypePinned;
+    prop.location.type = hipMemLocationTypeDevice;
+    prop.location.id = 0;
+    size_t g = 0;
+    if (hipMemGetAllocationGranularity(&g, &prop, hipMemAllocationGranularityRecommended) != hipSuccess || g == 0) return nullptr;
+    if (chunk == 0) chunk = (bytes + g - 1) / g * g;
+    chunk = (chunk + g - 1) / g * g;
+    const size_t n = (bytes + chunk - 1) / chunk, total = n * chunk;
+    void* base = nullptr;
+    if (hipMemAddressReserve(&base, total, 0, nullptr, 0) != hipSuccess) return nullptr;
+    for (size_t i = 0; i < n; ++i) {
+        hipMemGenericAllocationHandle_t h;
+        if (hipMemCreate(&h, chunk, &prop, 0) != hipSuccess) { fprintf(stderr, "hipMemCreate failed at chunk %zu\n", i); return nullptr; }
+        if (hipMemMap((char*)base + i * chunk, chunk, 0, h, 0) != hipSuccess) { fprintf(stderr, "hipMemMap failed\n"); return nullptr; }
+        (void)hipMemRelease(h);   // (stays alive through the mapping)
+    }
+    hipMemAccessDesc d = {};
+    d.location.type = hipMemLocationTypeDevice;
+    d.location.id = 0;
+    d.flags = hipMemAccessFlagsProtReadWrite;
+    if (hipMemSetAccess(base, total, &d, 1) != hipSuccess) { fprintf(stderr, "hipMemSetAccess failed\n"); return nullptr; }
+    return base;
+}

@@ -6,6 +6,7 @@
 #include <algorithm>
 #include <cmath>
 #include <complex>
+#include <cstdlib>
 #include <cstring>
 #include <map>
 #include <mutex>
@@ -730,15 +731,112 @@ int zafx_device_name(int device, char* buf, size_t buflen) {
     return 0;
 }
 
+// ---------------------------------------------------------------------------------
+// Large device arrays: physical memory in CHUNKS, mapped back to back into one reserved range (HIP's virtual-memory API).
+// ---------------------------------------------------------------------------------
+// Where hipMalloc puts the 7.25 GB spectrum of BASELINE config 2 moves k_stft_ft16 between 1.50 and 1.70 ms (six rounds of "placement").
+// Round 6 (tools/placement_vmm.py; bench.py --kind stft in fresh processes on a dozen boxes): the same array built from separate physical allocations of
+// 32 ... 512 MiB lands at 1.49-1.55 ms on most boxes where hipMalloc's lands at 1.69-1.70 (four boxes, chunks of 64 MiB | 512 MiB | hipMalloc:
+// 1.52 | 1.55 | 1.70, 1.49 | 1.53 | 1.69, 1.52 | 1.52 | 1.52, 1.69 | 1.69 | 1.69; ONE 8-GiB physical allocation: as hipMalloc) -- never worse, not always
+// better: what decides is where in physical memory the array lies, and separate allocations are drawn from elsewhere.  zafx_alloc therefore
+// assembles every array of kVmmMin bytes or more from pieces of ZAFX_ALLOC_CHUNK_MB (64) MiB; smaller ones, and everything when ZAFX_ALLOC_CHUNK_MB=0 or the API is not there,
+// come from hipMalloc.  zafx_free unmaps and releases; copies, memsets and kernels see one contiguous range either way.
+namespace {
+constexpr size_t kVmmMin = 1ull << 30;
+std::mutex g_vmm_mu;
+std::map<void*, size_t> g_vmm;   // base -> bytes mapped
+
+size_t vmm_chunk_bytes() {
+    static const size_t chunk = [] {
+        const char* s = std::getenv("ZAFX_ALLOC_CHUNK_MB");
+        const long mb = s && *s ? std::atol(s) : 64;
+        return mb > 0 ? (size_t)mb << 20 : (size_t)0;
+    }();
+    return chunk;
+}
+
+void vmm_release(void* base, size_t mapped, size_t reserved) {
+    if (mapped) (void)hipMemUnmap(base, mapped);
+    (void)hipMemAddressFree(base, reserved);
+}
+
+hipError_t vmm_alloc(int device, void** out, size_t bytes) {
+    hipMemAllocationProp prop = {};
+    prop.type = hipMemAllocationTypePinned;
+    prop.location.type = hipMemLocationTypeDevice;
+    prop.location.id = device;
+    size_t g = 0;
+    if (hipError_t e = hipMemGetAllocationGranularity(&g, &prop, hipMemAllocationGranularityRecommended); e != hipSuccess || g == 0) return e != hipSuccess ? e : hipErrorNotSupported;
+    const size_t chunk = (vmm_chunk_bytes() + g - 1) / g * g, total = (bytes + g - 1) / g * g;
+    void* base = nullptr;
+    if (hipError_t e = hipMemAddressReserve(&base, total, 0, nullptr, 0); e != hipSuccess) return e;
+    size_t off = 0;
+    while (off < total) {
+        const size_t n = std::min(chunk, total - off);
+        hipMemGenericAllocationHandle_t h;
+        hipError_t e = hipMemCreate(&h, n, &prop, 0);
+        if (e == hipSuccess) {
+            e = hipMemMap(static_cast<char*>(base) + off, n, 0, h, 0);
+            (void)hipMemRelease(h);   // (the mapping keeps the memory; it goes with the unmap)
+        }
+        if (e != hipSuccess) {
+            vmm_release(base, off, total);
+            return e;
+        }
+        off += n;
+    }
+    hipMemAccessDesc access = {};
+    access.location.type = hipMemLocationTypeDevice;
+    access.location.id = device;
+    access.flags = hipMemAccessFlagsProtReadWrite;
+    if (hipError_t e = hipMemSetAccess(base, total, &access, 1); e != hipSuccess) {
+        vmm_release(base, total, total);
+        return e;
+    }
+    {
+        std::lock_guard<std::mutex> lock(g_vmm_mu);
+        g_vmm[base] = total;
+    }
+    *out = base;
+    return hipSuccess;
+}
+
+// the library's device allocator (zafx_alloc, zafx_alloc_placed)
+hipError_t device_alloc(int device, void** out, size_t bytes) {
+    if (bytes >= kVmmMin && vmm_chunk_bytes() > 0) {
+        const hipError_t e = vmm_alloc(device, out, bytes);
+        if (e == hipSuccess || e == hipErrorOutOfMemory) return e;
+        (void)hipGetLastError();   // (no virtual-memory API on this stack: the plain allocator)
+    }
+    return hipMalloc(out, bytes ? bytes : 1);
+}
+
+hipError_t device_free(void* p) {
+    size_t mapped = 0;
+    {
+        std::lock_guard<std::mutex> lock(g_vmm_mu);
+        const auto it = g_vmm.find(p);
+        if (it != g_vmm.end()) {
+            mapped = it->second;
+            g_vmm.erase(it);
+        }
+    }
+    if (!mapped) return hipFree(p);
+    if (hipError_t e = hipDeviceSynchronize(); e != hipSuccess) return e;   // (as hipFree does: no kernel may still use the range)
+    if (hipError_t e = hipMemUnmap(p, mapped); e != hipSuccess) return e;
+    return hipMemAddressFree(p, mapped);
+}
+}  // namespace
+
 int zafx_alloc(int device, void** dptr, size_t bytes) {
     if (!dptr) return fail_msg("null argument");
     ZAFX_HIP(hipSetDevice(device));
-    ZAFX_HIP(hipMalloc(dptr, bytes ? bytes : 1));
+    ZAFX_HIP(device_alloc(device, dptr, bytes));
     return 0;
 }
 int zafx_free(int device, void* dptr) {
     ZAFX_HIP(hipSetDevice(device));
-    ZAFX_HIP(hipFree(dptr));
+    ZAFX_HIP(device_free(dptr));
     return 0;
 }
 int zafx_memset(int device, void* dptr, int value, size_t bytes) {
@@ -1628,7 +1726,7 @@ int zafx_alloc_placed(zafx_plan* pl, void** dptr, size_t bytes, const void* d_in
     std::vector<void*> cand;
     for (int i = 0; i < n_candidates; ++i) {
         void* p = nullptr;
-        const hipError_t e = hipMalloc(&p, bytes ? bytes : 1);
+        const hipError_t e = device_alloc(pl->device, &p, bytes);   // (the library's allocator: arrays of 1 GiB and more in chunks, see zafx_alloc)
         if (e != hipSuccess) {
             (void)hipGetLastError();
             if (cand.empty()) return fail("zafx_alloc_placed", e);
@@ -1651,7 +1749,7 @@ int zafx_alloc_placed(zafx_plan* pl, void** dptr, size_t bytes, const void* d_in
     if (probe_ms)
         for (int i = (int)cand.size(); i < n_candidates; ++i) probe_ms[i] = -1.f;   // (not tried)
     for (size_t i = 0; i < cand.size(); ++i)
-        if (ret || (int)i != best) (void)hipFree(cand[i]);
+        if (ret || (int)i != best) (void)device_free(cand[i]);
     if (ret) return ret;
     *dptr = cand[(size_t)best];
     return 0;

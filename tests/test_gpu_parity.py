@@ -694,6 +694,26 @@ def test_batch_functions_pad_rows_off_the_line_grid(zafx):
         zafx.set_row_padding("compact")
 
 
+def test_large_arrays_come_in_chunks(zafx):
+    """zafx_alloc assembles arrays of 1 GiB and more from 64-MiB physical allocations mapped back to back (round 6, DESIGN 3: where a multi-GB array
+    lies decides the rate of the kernels that write it): one contiguous range to copies and kernels -- a pattern written and read back across the chunk
+    borders --, released by zafx_free (200 x 2 GiB allocated and freed would not fit the device if anything stayed behind)."""
+    n = (1 << 30) + (64 << 20) + 12345 * 8
+    host = (np.arange(n // 8, dtype=np.uint64) * np.uint64(0x9E3779B97F4A7C15)) >> np.uint64(7)
+    d = zafx.DeviceBuffer.from_host(host)
+    back = d.download()
+    assert back.shape == host.shape and np.array_equal(back, host)
+    for border in (64 << 20, 1 << 30):   # (a few words either side of two borders, through the partial-download path)
+        k = border // 8
+        assert np.array_equal(d.download(k - 4, 8), host[k - 4:k + 4])
+    d.free()
+    for _ in range(200):
+        zafx.DeviceBuffer((1 << 31,), np.uint8).free()
+    small = zafx.DeviceBuffer((1000,), np.float32)   # (below the threshold: the plain allocator)
+    small.free()
+
+
+
 def test_alloc_placed_through_the_c_abi(zafx):
     """zafx_alloc_placed (the C twin of DeviceBuffer.placed): the output buffer of a plan as the fastest of n allocations, every candidate
     timed by the library with the plan's own kernel; the buffer it returns holds the plan's result; bad arguments fail."""

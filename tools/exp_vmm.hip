@@ -40,3 +40,40 @@ extern "C" void* vmm_alloc(size_t bytes, size_t chunk) {
     if (hipMemSetAccess(base, total, &d, 1) != hipSuccess) { fprintf(stderr, "hipMemSetAccess failed\n"); return nullptr; }
     return base;
 }
+
+// Per-chunk write rate: n chunks of `chunk` bytes (separate physical allocations), each filled `reps` times; out[i] = microseconds per fill of chunk i
+extern "C" int vmm_probe(size_t chunk, int n, int reps, float* out) {
+    hipMemAllocationProp prop = {};
+    prop.type = hipMemAllocationTypePinned;
+    prop.location.type = hipMemLocationTypeDevice;
+    prop.location.id = 0;
+    void* base = nullptr;
+    if (hipMemAddressReserve(&base, chunk * n, 0, nullptr, 0) != hipSuccess) return 1;
+    for (int i = 0; i < n; ++i) {
+        hipMemGenericAllocationHandle_t h;
+        if (hipMemCreate(&h, chunk, &prop, 0) != hipSuccess) return 2;
+        if (hipMemMap((char*)base + (size_t)i * chunk, chunk, 0, h, 0) != hipSuccess) return 3;
+        (void)hipMemRelease(h);
+    }
+    hipMemAccessDesc d = {};
+    d.location.type = hipMemLocationTypeDevice;
+    d.location.id = 0;
+    d.flags = hipMemAccessFlagsProtReadWrite;
+    if (hipMemSetAccess(base, chunk * n, &d, 1) != hipSuccess) return 4;
+    hipEvent_t e0, e1;
+    hipEventCreate(&e0);
+    hipEventCreate(&e1);
+    for (int w = 0; w < 200; ++w) hipMemsetAsync(base, 0, chunk, 0);   // clock ramp
+    for (int i = 0; i < n; ++i) {
+        char* p = (char*)base + (size_t)i * chunk;
+        hipMemsetAsync(p, 1, chunk, 0);
+        hipEventRecord(e0, 0);
+        for (int r = 0; r < reps; ++r) hipMemsetAsync(p, r, chunk, 0);
+        hipEventRecord(e1, 0);
+        hipEventSynchronize(e1);
+        float ms = 0.f;
+        hipEventElapsedTime(&ms, e0, e1);
+        out[i] = ms * 1e3f / reps;
+    }
+    return 0;
+}

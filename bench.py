@@ -920,7 +920,7 @@ def compact_line(full):
                                 "vs_baseline", "dtype") if k in full}
     out["data"] = "synthetic white noise f32 (default_rng([0,c]).standard_normal); 8 distinct clips replicated on device to 1024 per GPU"
     cfg = full["config"]
-    out["config"] = {k: cfg[k] for k in ("workload", "clips_per_gpu", "samples_per_clip", "parallelism", "layout") if k in cfg}
+    out["config"] = {k: cfg[k] for k in ("workload", "clips_per_gpu", "samples_per_clip", "parallelism", "layout", "allocator") if k in cfg}
     pl = cfg.get("placement")
     if isinstance(pl, dict) and "survey_probe_ms" in pl:
         out["config"]["placement_survey_ms"] = pl["survey_probe_ms"]
@@ -1127,7 +1127,9 @@ def main():
                        "parallelism": f"clip-sharded x{world}", "constants_broadcast": head["constants_broadcast"],
                        "launcher": "file rendezvous (zafx/launch.py), no torch.distributed" if rdzv is not None else "single process",
                        "layout": "FT (reference memory order)" if args.layout == "FT" else "TF (frame-major)",
-                       "placement": head.get("placement", "first allocation")},
+                       "placement": head.get("placement", "first allocation"),
+                       "allocator": ("hipMalloc (ZAFX_ALLOC_CHUNK_MB=0)" if os.environ.get("ZAFX_ALLOC_CHUNK_MB", "64").strip() in ("0", "") else
+                                     f"zafx_alloc: arrays of 1 GiB and more in {os.environ.get('ZAFX_ALLOC_CHUNK_MB', '64')}-MiB physical chunks (HIP virtual-memory API)")},
             "roofline": head["roofline"],
         }
         if rccl is not None:

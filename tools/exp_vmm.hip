@@ -15,6 +15,8 @@ extern "C" size_t vmm_granularity(int recommended) {
 }
 
 // bytes rounded up to whole chunks; chunk = 0: one physical allocation
+static size_t g_align = 0;
+extern "C" void vmm_set_align(size_t a) { g_align = a; }
 extern "C" void* vmm_alloc(size_t bytes, size_t chunk) {
     hipMemAllocationProp prop = {};
     prop.type = hipMemAllocationTypePinned;
@@ -26,7 +28,7 @@ extern "C" void* vmm_alloc(size_t bytes, size_t chunk) {
     chunk = (chunk + g - 1) / g * g;
     const size_t n = (bytes + chunk - 1) / chunk, total = n * chunk;
     void* base = nullptr;
-    if (hipMemAddressReserve(&base, total, 0, nullptr, 0) != hipSuccess) return nullptr;
+    if (hipMemAddressReserve(&base, total, g_align, nullptr, 0) != hipSuccess) return nullptr;
     for (size_t i = 0; i < n; ++i) {
         hipMemGenericAllocationHandle_t h;
         if (hipMemCreate(&h, chunk, &prop, 0) != hipSuccess) { fprintf(stderr, "hipMemCreate failed at chunk %zu\n", i); return nullptr; }

@@ -27,6 +27,8 @@ class Raw:
         self.ptr = ctypes.c_void_p(ptr)
 
 
+vmm.vmm_set_align.argtypes = [ctypes.c_size_t]
+vmm.vmm_set_align(int(os.environ.get("VMM_ALIGN_MB", "0")) << 20)
 for mib in [int(a) for a in sys.argv[1:]] or [0, 2, 64, 1024, 0]:
     if mib == 0:
         d = zafx.DeviceBuffer(shape, pl.out_dtype)

@@ -714,6 +714,33 @@ def test_large_arrays_come_in_chunks(zafx):
 
 
 
+def test_plain_allocator_switch():
+    """ZAFX_ALLOC_CHUNK_MB=0: every array from hipMalloc (the switch a caller has when the virtual-memory API is unwanted): a 1.1 GiB round trip and an STFT in a
+    fresh process with the variable set."""
+    import os
+    import subprocess
+    import sys
+    ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = (
+        "import sys, numpy as np\n"
+        f"sys.path.insert(0, {os.path.join(ROOT, 'zaf-python_amd')!r}); sys.path.insert(0, {ROOT!r})\n"
+        "import zafx\n"
+        "from oracle import zaf_oracle as orc\n"
+        "h = np.arange((1 << 30) // 8 + 12345 * 1024, dtype=np.uint64)\n"
+        "d = zafx.DeviceBuffer.from_host(h)\n"
+        "assert np.array_equal(d.download(), h)\n"
+        "d.free()\n"
+        "x = np.random.default_rng(3).standard_normal((2, 30000)).astype(np.float32)\n"
+        "w = zafx.hamming(2048)\n"
+        "s = zafx.stft_batch(x, w, 1024)\n"
+        "r = orc.stft(x[1].astype(np.float64), w, 1024)\n"
+        "assert np.max(np.abs(s[1] - r)) / np.max(np.abs(r)) < 1e-5\n"
+        "print('plain allocator ok')\n")
+    res = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, ZAFX_ALLOC_CHUNK_MB="0"), capture_output=True, text=True, timeout=600)
+    assert res.returncode == 0 and "plain allocator ok" in res.stdout, (res.stdout + res.stderr)[-2000:]
+
+
+
 def test_alloc_placed_through_the_c_abi(zafx):
     """zafx_alloc_placed (the C twin of DeviceBuffer.placed): the output buffer of a plan as the fastest of n allocations, every candidate
     timed by the library with the plan's own kernel; the buffer it returns holds the plan's result; bad arguments fail."""
